@@ -1,0 +1,61 @@
+/*
+ *  stringzillas_rocm.h - ADDITIVE entry points of the ROCm build.  Nothing here changes a reference signature;
+ *  a caller that only knows <stringzillas/stringzillas.h> never needs this header.
+ *
+ *  - szs_rocm_last_call_profile : device-event kernel time and work counters of the last engine call - the
+ *    counterpart of the reference's `cuda_status_t::elapsed_milliseconds` / "Kernel GCUPS"
+ *    (/root/reference/include/stringzillas/types.cuh:280-298,482-534; bench/similarities.cuh:303-308).
+ *  - szs_rocm_shard_rows        : longest-processing-time assignment of query rows to N GPUs;
+ *    the reference has no multi-GPU path at all (one engine call = one device, stringzillas.h:137).
+ *  - szs_rocm_plan_probe        : exposes the host planner so it can be unit-tested without a GPU.
+ */
+#ifndef STRINGZILLAS_ROCM_H_
+#define STRINGZILLAS_ROCM_H_
+
+#include "stringzillas.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct szs_rocm_call_profile_t {
+    double kernel_milliseconds;   /* hipEvent pair around the scoring launches, on the scope's stream */
+    double host_milliseconds;     /* wall time of the whole C-ABI call, planning and copies included */
+    sz_u64_t cells;               /* sum over scored pairs of len(query) * len(candidate): the GCUPS numerator */
+    sz_u64_t pairs;               /* scored pairs (lower triangle only in symmetric mode) */
+    sz_u64_t algorithmic_bytes;   /* sum over pairs of len(q) + len(c) + 2 * 4 + 8   */
+    sz_u64_t unique_bytes;        /* bytes of both tapes + offsets + the results matrix, each counted once */
+    sz_u32_t launches;            /* kernel launches issued */
+    sz_u32_t longest_query;
+    sz_u32_t longest_candidate;
+    sz_u32_t reserved;
+} szs_rocm_call_profile_t;
+
+/** Copies the profile of the most recent call made through `engine` (any of the four engine handle types). */
+SZ_API_RUNTIME sz_status_t szs_rocm_last_call_profile(void *engine, szs_rocm_call_profile_t *profile);
+
+/**
+ *  Deals `rows` query rows to `shards` devices so that the summed `row_weights` per shard are as equal as the
+ *  longest-processing-time heuristic makes them (sort descending, always give to the lightest shard).
+ *  `shard_of_row[i]` receives the shard of row i; `shard_loads` (optional) the resulting per-shard weight sums.
+ */
+SZ_API_RUNTIME sz_status_t szs_rocm_shard_rows(sz_size_t const *row_weights, sz_size_t rows, sz_size_t shards,
+                                               sz_u32_t *shard_of_row, sz_u64_t *shard_loads);
+
+/**
+ *  Runs the host planner on bare length arrays.  Outputs (all optional):
+ *    candidate_order[c]  - candidate indices by ascending length (stable);
+ *    query_order[q]      - query indices grouped by kernel variant;
+ *    query_variant[q]    - the variant (Myers: 32-bit words rounded to an instantiated kernel; 0 = weighted kernel)
+ *                          of the query at planned position q;
+ *    cells               - sum of len(q) * len(c) over live pairs.
+ */
+SZ_API_RUNTIME sz_status_t szs_rocm_plan_probe(int unit_cost, int symmetric, sz_u32_t const *query_lengths,
+                                               sz_size_t queries_count, sz_u32_t const *candidate_lengths,
+                                               sz_size_t candidates_count, sz_u32_t *candidate_order,
+                                               sz_u32_t *query_order, sz_u32_t *query_variant, sz_u64_t *cells);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STRINGZILLAS_ROCM_H_ */

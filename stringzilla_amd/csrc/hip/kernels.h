@@ -1,0 +1,76 @@
+/*
+ *  kernels.h - the thin C layer between the C host (csrc/host) and the hand-written gfx950 kernels (csrc/hip).
+ *
+ *  Everything here is `extern "C"`, takes plain pointers and sizes, enqueues work on the given HIP stream and
+ *  returns the `hipError_t` of the launch as an int (0 = success).  No call blocks; no call allocates.
+ *
+ *  Data model shared by all kernels:
+ *    - a string is a `szs_string_ref_t` {absolute device address, byte length, index in the caller's collection};
+ *    - candidates arrive LENGTH-SORTED so that the 64 lanes of a wavefront, one candidate each, walk texts of
+ *      near-equal length (lock-step waste is bounded by the length spread inside one 64-candidate block);
+ *    - queries arrive grouped by kernel variant; a workgroup scores ONE query against 256 candidates;
+ *    - results go straight to `results[query.index * stride + candidate.index]` as 64-bit values (plus the
+ *      mirror cell in symmetric mode) - there is no per-cell task array, no sort of tasks, no scatter pass
+ *      (the reference's cuda.cuh:1652-1711,2082,2146 machinery has no counterpart here).
+ */
+#ifndef SZS_ROCM_KERNELS_H_
+#define SZS_ROCM_KERNELS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct szs_string_ref_t {
+    uint64_t address; /* absolute, device-accessible */
+    uint32_t length;  /* bytes */
+    uint32_t index;   /* row (queries) or column (candidates) of the results matrix */
+} szs_string_ref_t;
+
+#define SZS_CANDIDATES_PER_WORKGROUP 256u
+#define SZS_MYERS_MAX_WORDS 64u /* 32-bit words: queries up to 2048 bytes take the bit-parallel kernel */
+
+/**
+ *  Unit-cost Levenshtein, bit-parallel Myers/Hyyro on 32-bit words with a full-width carry chain.
+ *  `words` = ceil(query length / 32) for EVERY query in `queries[0..queries_count)` (0-length queries use 1).
+ *  Launches ceil(candidates_count / 256) * queries_count workgroups of 256 threads.
+ *  symmetric != 0: only cells with candidate.index <= query.index are scored, and mirrored.
+ */
+unsigned szs_hip_levenshtein_myers_round_words(unsigned words);
+int szs_hip_levenshtein_myers(unsigned words, szs_string_ref_t const *queries, uint32_t queries_count,
+                              szs_string_ref_t const *candidates, uint32_t candidates_count, uint64_t *results,
+                              uint64_t results_row_stride, int symmetric, void *stream);
+
+/** Scoring model handed to the weighted kernels; lives in device memory, one per engine. */
+typedef struct szs_cost_model_t {
+    int16_t substitution[32 * 32]; /* [query class][candidate class]; Levenshtein engines: negated costs */
+    uint8_t byte_to_class[256];
+    int32_t gap_open;   /* signed, ADDED (negated for Levenshtein) */
+    int32_t gap_extend; /* == gap_open for linear gaps */
+    int32_t uniform_match, uniform_mismatch; /* Levenshtein engines: negated uniform costs; unused otherwise */
+} szs_cost_model_t;
+
+enum {
+    szs_objective_global_k = 0,      /* Needleman-Wunsch: bottom-right cell */
+    szs_objective_local_k = 1,       /* Smith-Waterman: best cell, substitution branch clamped at 0 */
+    szs_objective_distance_k = 2     /* weighted Levenshtein: global on negated uniform costs, result negated */
+};
+
+/**
+ *  Weighted scorer: one (query, candidate) pair per lane, the query shared by the wavefront, DP walked in strips
+ *  of query rows held in registers, the strip boundary row parked in `boundary` (global memory, [column][lane]).
+ *  `boundary` needs szs_hip_weighted_boundary_bytes(...) bytes.
+ */
+int szs_hip_weighted_scores(int objective, int affine, szs_cost_model_t const *model, szs_string_ref_t const *queries,
+                            uint32_t queries_count, szs_string_ref_t const *candidates, uint32_t candidates_count,
+                            uint32_t longest_candidate, int64_t *results, uint64_t results_row_stride, int symmetric,
+                            void *boundary, void *stream);
+size_t szs_hip_weighted_boundary_bytes(int affine, uint32_t queries_count, uint32_t candidates_count,
+                                       uint32_t longest_candidate);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SZS_ROCM_KERNELS_H_ */

@@ -1,0 +1,331 @@
+/*
+ *  dispatch.c - one engine call, start to finish: normalise inputs -> plan -> upload refs -> launch -> synchronise.
+ *
+ *  ROCm counterpart of the reference's `cross_()` / `run_trampoline_()` (cuda.cuh:4247-4417,4435-4741) and
+ *  `cuda_weighted_cross_()` (cuda.cuh:5913).  Same observable behaviour - synchronous call, results in the caller's
+ *  matrix, device-accessibility checks on the strings, staged copy when `results` is not device-visible - with a
+ *  different mechanism (see plan.c).  Nothing here computes a score on the CPU.
+ */
+#include "szs_internal.h"
+
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+static double now_milliseconds(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+typedef struct {
+    int host_readable;
+    int device_accessible;
+} pointer_traits_t;
+
+static pointer_traits_t classify_pointer(void const *pointer) {
+    pointer_traits_t traits = {1, 0};
+    if (!pointer) return traits;
+    hipPointerAttribute_t attributes;
+    memset(&attributes, 0, sizeof(attributes));
+    hipError_t const error = hipPointerGetAttributes(&attributes, pointer);
+    if (error != hipSuccess) { /* older runtimes report plain host memory as an error */
+        (void)hipGetLastError();
+        return traits;
+    }
+    switch (attributes.type) {
+    case hipMemoryTypeDevice: traits.host_readable = 0, traits.device_accessible = 1; break;
+    case hipMemoryTypeHost: traits.host_readable = 1, traits.device_accessible = 1; break;
+    case hipMemoryTypeManaged: traits.host_readable = 1, traits.device_accessible = 1; break;
+    default: traits.host_readable = 1, traits.device_accessible = 0; break; /* unregistered host memory */
+    }
+    return traits;
+}
+
+/**
+ *  Produces absolute addresses and 32-bit lengths for every string of one side.
+ *  Tapes whose offsets live in device-only memory are downloaded through the pinned staging area first.
+ */
+static sz_status_t gather_strings(szs_engine_s *engine, int device, hipStream_t stream, szs_input_t const *input,
+                                  size_t staging_offset, uint64_t *addresses, uint32_t *lengths,
+                                  uint64_t *total_bytes, char const **error_message) {
+    size_t const count = input->count;
+    *total_bytes = 0;
+    if (input->kind == szs_input_sequence_k) {
+        sz_sequence_t const *sequence = input->sequence;
+        int checked = 0;
+        for (size_t i = 0; i < count; ++i) {
+            char const *start = sequence->get_start(sequence->handle, i);
+            size_t const length = sequence->get_length(sequence->handle, i);
+            if (length > 0xFFFFFFFFull) return szs_report(sz_overflow_risk_k, error_message, NULL);
+            if (length && !checked) { /* like the reference, vet one representative string (cuda.cuh:4268-4272) */
+                if (!classify_pointer(start).device_accessible)
+                    return szs_report(sz_device_memory_mismatch_k, error_message, NULL);
+                checked = 1;
+            }
+            addresses[i] = (uint64_t)(uintptr_t)start, lengths[i] = (uint32_t)length;
+            *total_bytes += length;
+        }
+        return sz_success_k;
+    }
+
+    size_t const offset_size = input->kind == szs_input_u32tape_k ? 4 : 8;
+    void const *offsets = input->offsets;
+    if (!offsets) return szs_report(sz_status_unknown_k, error_message, "Tape offsets must not be null");
+    if (!classify_pointer(offsets).host_readable) {
+        size_t const bytes = (count + 1) * offset_size;
+        void *landing = (char *)engine->pinned_staging.pointer + staging_offset;
+        hipError_t error = hipMemcpyAsync(landing, offsets, bytes, hipMemcpyDeviceToHost, stream);
+        if (error == hipSuccess) error = hipStreamSynchronize(stream);
+        if (error != hipSuccess) return szs_report_hip(error, error_message);
+        offsets = landing;
+    }
+    (void)device;
+    uint64_t const base = (uint64_t)(uintptr_t)input->data;
+    if (offset_size == 4) {
+        uint32_t const *o = (uint32_t const *)offsets;
+        for (size_t i = 0; i < count; ++i) {
+            if (o[i + 1] < o[i]) return szs_report(sz_unexpected_dimensions_k, error_message, "Tape offsets must ascend");
+            addresses[i] = base + o[i], lengths[i] = o[i + 1] - o[i];
+        }
+        *total_bytes = (uint64_t)o[count] - o[0];
+    }
+    else {
+        uint64_t const *o = (uint64_t const *)offsets;
+        for (size_t i = 0; i < count; ++i) {
+            if (o[i + 1] < o[i]) return szs_report(sz_unexpected_dimensions_k, error_message, "Tape offsets must ascend");
+            uint64_t const length = o[i + 1] - o[i];
+            if (length > 0xFFFFFFFFull) return szs_report(sz_overflow_risk_k, error_message, NULL);
+            addresses[i] = base + o[i], lengths[i] = (uint32_t)length;
+        }
+        *total_bytes = o[count] - o[0];
+    }
+    if (*total_bytes && !classify_pointer(input->data).device_accessible)
+        return szs_report(sz_device_memory_mismatch_k, error_message, NULL);
+    return sz_success_k;
+}
+
+static void fill_cost_model(szs_engine_s const *engine, szs_cost_model_t *model) {
+    memset(model, 0, sizeof(*model));
+    if (engine->family == szs_family_levenshtein_k || engine->family == szs_family_levenshtein_utf8_k) {
+        /* Minimising non-negative costs == maximising their negation; the kernel negates the result back. */
+        model->uniform_match = -(int32_t)engine->match, model->uniform_mismatch = -(int32_t)engine->mismatch;
+        model->gap_open = -(int32_t)engine->open, model->gap_extend = -(int32_t)engine->extend;
+    }
+    else {
+        for (int i = 0; i < 32 * 32; ++i) model->substitution[i] = engine->class_costs[i];
+        memcpy(model->byte_to_class, engine->byte_to_class, 256);
+        model->gap_open = engine->open, model->gap_extend = engine->extend;
+    }
+}
+
+static void release_device_state(szs_engine_s *engine) {
+    szs_buffer_release(&engine->pinned_staging);
+    szs_buffer_release(&engine->device_refs);
+    szs_buffer_release(&engine->device_results);
+    szs_buffer_release(&engine->device_boundary);
+    szs_buffer_release(&engine->device_model);
+    szs_buffer_release(&engine->device_tape);
+    if (engine->events_device >= 0) {
+        (void)hipEventDestroy(engine->event_start);
+        (void)hipEventDestroy(engine->event_stop);
+        engine->events_device = -1;
+    }
+    engine->model_uploaded_device = -1;
+}
+
+void szs_engine_release(szs_engine_s *engine) {
+    if (engine->device >= 0) {
+        int previous = 0;
+        (void)hipGetDevice(&previous);
+        (void)hipSetDevice(engine->device);
+        release_device_state(engine);
+        (void)hipSetDevice(previous);
+    }
+    szs_buffer_release(&engine->host_lengths);
+}
+
+sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input_t const *queries,
+                             szs_input_t const *candidates, void *results, size_t results_row_stride,
+                             char const **error_message) {
+    double const call_started = now_milliseconds();
+    if (!engine || engine->magic != SZS_ENGINE_MAGIC)
+        return szs_report(sz_status_unknown_k, error_message, "Engine must be initialized");
+    if (!queries) return szs_report(sz_status_unknown_k, error_message, "Queries must not be null");
+    if (engine->family == szs_family_levenshtein_utf8_k) /* a "next" row, not built yet */
+        return szs_report(sz_status_unknown_k, error_message, "UTF-8 codepoint distances are not implemented in the ROCm build yet");
+
+    int device = 0;
+    hipStream_t stream = NULL;
+    sz_status_t status = szs_scope_bind_gpu(scope, &device, &stream, error_message);
+    if (status != sz_success_k) return status;
+
+    int const symmetric = candidates == NULL;
+    size_t const queries_count = queries->count;
+    size_t const candidates_count = symmetric ? queries_count : candidates->count;
+    memset(&engine->last_profile, 0, sizeof(engine->last_profile));
+    if (!queries_count || !candidates_count) return szs_report(sz_success_k, error_message, NULL); /* cuda.cuh:4257 */
+    if (queries_count > 0xFFFFFFFFull || candidates_count > 0xFFFFFFFFull)
+        return szs_report(sz_overflow_risk_k, error_message, NULL);
+    if (!results) return szs_report(sz_status_unknown_k, error_message, "Results must not be null");
+    if (results_row_stride < candidates_count) return szs_report(sz_unexpected_dimensions_k, error_message, NULL);
+
+    if (engine->device != device) { /* scratch follows the device of the call */
+        if (engine->device >= 0) {
+            (void)hipSetDevice(engine->device);
+            release_device_state(engine);
+            (void)hipSetDevice(device);
+        }
+        engine->device = device;
+    }
+    if (engine->events_device != device) {
+        hipError_t error = hipEventCreate(&engine->event_start);
+        if (error == hipSuccess) error = hipEventCreate(&engine->event_stop);
+        if (error != hipSuccess) return szs_report_hip(error, error_message);
+        engine->events_device = device;
+    }
+
+    uint32_t const q_count = (uint32_t)queries_count, c_count = (uint32_t)candidates_count;
+    size_t const most = q_count > c_count ? q_count : c_count;
+
+    /* Host scratch: [q addresses][c addresses][q lengths][c lengths][sort keys] */
+    size_t const host_bytes = ((size_t)q_count + c_count) * (sizeof(uint64_t) + sizeof(uint32_t)) + most * sizeof(uint32_t);
+    status = szs_buffer_reserve(&engine->host_lengths, szs_memory_host_k, 0, host_bytes, error_message);
+    if (status != sz_success_k) return status;
+    uint64_t *q_addresses = (uint64_t *)engine->host_lengths.pointer;
+    uint64_t *c_addresses = q_addresses + q_count;
+    uint32_t *q_lengths = (uint32_t *)(c_addresses + c_count);
+    uint32_t *c_lengths = q_lengths + q_count;
+    uint32_t *keys = c_lengths + c_count;
+
+    /* Pinned staging: [refs of queries][refs of candidates][offset downloads of both sides] */
+    size_t const refs_bytes = ((size_t)q_count + c_count) * sizeof(szs_string_ref_t);
+    size_t const offsets_bytes = ((size_t)q_count + c_count + 2) * sizeof(uint64_t);
+    status = szs_buffer_reserve(&engine->pinned_staging, szs_memory_pinned_k, device, refs_bytes + offsets_bytes,
+                                error_message);
+    if (status != sz_success_k) return status;
+    status = szs_buffer_reserve(&engine->device_refs, szs_memory_device_k, device, refs_bytes, error_message);
+    if (status != sz_success_k) return status;
+
+    uint64_t query_bytes = 0, candidate_bytes = 0;
+    status = gather_strings(engine, device, stream, queries, refs_bytes, q_addresses, q_lengths, &query_bytes, error_message);
+    if (status != sz_success_k) return status;
+    if (symmetric) {
+        memcpy(c_addresses, q_addresses, (size_t)q_count * sizeof(uint64_t));
+        memcpy(c_lengths, q_lengths, (size_t)q_count * sizeof(uint32_t));
+        candidate_bytes = query_bytes;
+    }
+    else {
+        status = gather_strings(engine, device, stream, candidates, refs_bytes + ((size_t)q_count + 1) * sizeof(uint64_t),
+                                c_addresses, c_lengths, &candidate_bytes, error_message);
+        if (status != sz_success_k) return status;
+    }
+
+    /* Plan straight into the pinned staging area, then ship both ref arrays in one copy. */
+    szs_string_ref_t *host_query_refs = (szs_string_ref_t *)engine->pinned_staging.pointer;
+    szs_string_ref_t *host_candidate_refs = host_query_refs + q_count;
+    szs_plan_t plan;
+    int const use_myers = engine->family == szs_family_levenshtein_k && engine->is_unit_cost;
+    szs_plan_build(use_myers, symmetric, q_addresses, q_lengths, q_count, c_addresses, c_lengths, c_count,
+                   host_query_refs, host_candidate_refs, keys, &plan);
+
+    /* Cell width: this build scores weighted cells in 32 bits, so refuse what the reference would widen to 64 bits
+     * (reach rule, serial.hpp:135-162,370-386). */
+    int const maximise = engine->family == szs_family_needleman_wunsch_k || engine->family == szs_family_smith_waterman_k;
+    uint64_t const span = maximise ? (uint64_t)plan.longest_query + plan.longest_candidate
+                                   : (plan.longest_query > plan.longest_candidate ? plan.longest_query : plan.longest_candidate);
+    uint64_t const reach = (span + (engine->is_linear ? 1 : 3)) * (engine->magnitude ? engine->magnitude : 1);
+    if (reach >= 0x7FFFFFF0ull) return szs_report(sz_overflow_risk_k, error_message, NULL);
+
+    szs_string_ref_t *device_query_refs = (szs_string_ref_t *)engine->device_refs.pointer;
+    szs_string_ref_t *device_candidate_refs = device_query_refs + q_count;
+    hipError_t error = hipMemcpyAsync(device_query_refs, host_query_refs, refs_bytes, hipMemcpyHostToDevice, stream);
+    if (error != hipSuccess) return szs_report_hip(error, error_message);
+
+    /* Where do results go?  Device-visible matrices are written in place; anything else is staged densely. */
+    int const direct = classify_pointer(results).device_accessible;
+    void *device_results = results;
+    size_t device_stride = results_row_stride;
+    if (!direct) {
+        status = szs_buffer_reserve(&engine->device_results, szs_memory_device_k, device,
+                                    (size_t)q_count * c_count * sizeof(uint64_t), error_message);
+        if (status != sz_success_k) return status;
+        device_results = engine->device_results.pointer, device_stride = c_count;
+    }
+
+    /* Weighted kernels need the cost model and a strip-boundary workspace on the device. */
+    int needs_weighted = !use_myers;
+    for (unsigned g = 0; g < plan.groups_count; ++g) needs_weighted |= plan.groups[g].variant == 0;
+    if (needs_weighted) {
+        if (engine->model_uploaded_device != device) {
+            status = szs_buffer_reserve(&engine->device_model, szs_memory_device_k, device, sizeof(szs_cost_model_t),
+                                        error_message);
+            if (status != sz_success_k) return status;
+            szs_cost_model_t model;
+            fill_cost_model(engine, &model);
+            error = hipMemcpy(engine->device_model.pointer, &model, sizeof(model), hipMemcpyHostToDevice);
+            if (error != hipSuccess) return szs_report_hip(error, error_message);
+            engine->model_uploaded_device = device;
+        }
+        size_t const boundary_bytes =
+            szs_hip_weighted_boundary_bytes(!engine->is_linear, q_count, c_count, plan.longest_candidate);
+        status = szs_buffer_reserve(&engine->device_boundary, szs_memory_device_k, device, boundary_bytes, error_message);
+        if (status != sz_success_k) return status;
+    }
+
+    /* ---- launches, bracketed by the engine's event pair on the scope's stream ---- */
+    error = hipEventRecord(engine->event_start, stream);
+    if (error != hipSuccess) return szs_report_hip(error, error_message);
+    uint32_t launches = 0;
+    int const objective = engine->family == szs_family_needleman_wunsch_k   ? szs_objective_global_k
+                          : engine->family == szs_family_smith_waterman_k ? szs_objective_local_k
+                                                                          : szs_objective_distance_k;
+    for (unsigned g = 0; g < plan.groups_count; ++g) {
+        szs_plan_group_t const *group = &plan.groups[g];
+        int launch_error;
+        if (group->variant)
+            launch_error = szs_hip_levenshtein_myers(group->variant, device_query_refs + group->first, group->count,
+                                                     device_candidate_refs, c_count, (uint64_t *)device_results,
+                                                     device_stride, symmetric, stream);
+        else
+            launch_error = szs_hip_weighted_scores(objective, !engine->is_linear,
+                                                   (szs_cost_model_t const *)engine->device_model.pointer,
+                                                   device_query_refs + group->first, group->count,
+                                                   device_candidate_refs, c_count, plan.longest_candidate,
+                                                   (int64_t *)device_results, device_stride, symmetric,
+                                                   engine->device_boundary.pointer, stream);
+        if (launch_error) return szs_report_hip((hipError_t)launch_error, error_message);
+        ++launches;
+    }
+    error = hipEventRecord(engine->event_stop, stream);
+    if (error != hipSuccess) return szs_report_hip(error, error_message);
+
+    if (!direct) /* one strided copy back into the caller's host matrix (reference: cuMemcpy2DAsync, cuda.cuh:2205-2215) */
+        error = hipMemcpy2DAsync(results, results_row_stride * sizeof(uint64_t), device_results,
+                                 device_stride * sizeof(uint64_t), (size_t)c_count * sizeof(uint64_t), q_count,
+                                 hipMemcpyDeviceToHost, stream);
+    if (error == hipSuccess) error = hipStreamSynchronize(stream); /* the call is synchronous, like the reference's */
+    if (error != hipSuccess) return szs_report_hip(error, error_message);
+
+    float kernel_ms = 0;
+    (void)hipEventElapsedTime(&kernel_ms, engine->event_start, engine->event_stop);
+    szs_rocm_call_profile_t *profile = &engine->last_profile;
+    uint64_t const pairs = symmetric ? (uint64_t)q_count * (q_count + 1) / 2 : (uint64_t)q_count * c_count;
+    profile->kernel_milliseconds = kernel_ms;
+    profile->cells = plan.cells;
+    profile->pairs = pairs;
+    /* Canonical pair-streaming bytes: len(q) + len(c) + two 4-byte offsets + one 8-byte result per pair. */
+    profile->algorithmic_bytes = symmetric ? 0 : (uint64_t)c_count * query_bytes + (uint64_t)q_count * candidate_bytes;
+    if (symmetric) {
+        uint64_t prefix = 0, bytes = 0;
+        for (uint32_t i = 0; i < q_count; ++i) prefix += q_lengths[i], bytes += (uint64_t)q_lengths[i] * (i + 1) + prefix;
+        profile->algorithmic_bytes = bytes;
+    }
+    profile->algorithmic_bytes += pairs * 16;
+    profile->unique_bytes = query_bytes + (symmetric ? 0 : candidate_bytes) +
+                            ((uint64_t)q_count + 1 + (symmetric ? 0 : c_count + 1)) * 4 + (uint64_t)q_count * c_count * 8;
+    profile->launches = launches;
+    profile->longest_query = plan.longest_query, profile->longest_candidate = plan.longest_candidate;
+    profile->host_milliseconds = now_milliseconds() - call_started;
+    return szs_report(sz_success_k, error_message, NULL);
+}

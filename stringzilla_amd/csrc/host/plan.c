@@ -1,0 +1,186 @@
+/*
+ *  plan.c - the host planner: pure C, no HIP, unit-tested on CPU through szs_rocm_plan_probe / szs_rocm_shard_rows.
+ *
+ *  The reference routes work per *cell*: it materialises a 112-byte task per (query, candidate) pair on the device,
+ *  counting-sorts the tasks by size tier and scatters results afterwards (cuda.cuh:1652-1711,1887-1957,2082,2146) -
+ *  112 MB of bookkeeping traffic per million pairs.  A cross-product does not need that: tiering the ROWS and the
+ *  COLUMNS tiers every cell.  So the plan is O(Q + C):
+ *    - candidates are sorted by length, so each 64-lane wavefront (one candidate per lane) walks near-equal texts;
+ *    - queries are grouped by kernel variant (for the bit-parallel kernel: the 32-bit word count of their bit-vector,
+ *      rounded up to an instantiated kernel), one launch per group;
+ *    - nothing per cell is ever stored: kernels write results[query.index * stride + candidate.index] directly.
+ */
+#include "szs_internal.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+static int compare_u64(void const *a, void const *b) {
+    uint64_t const x = *(uint64_t const *)a, y = *(uint64_t const *)b;
+    return x < y ? -1 : x > y;
+}
+
+/** Stable ascending sort of indices [0, count) by `lengths`; `order` receives the permutation. */
+static void sort_by_length(uint32_t const *lengths, uint32_t count, uint32_t longest, uint32_t *order) {
+    if (count == 0) return;
+    if (longest < (1u << 16)) { /* counting sort: O(count + longest), the common case */
+        uint32_t *bins = (uint32_t *)calloc((size_t)longest + 2, sizeof(uint32_t));
+        if (bins) {
+            for (uint32_t i = 0; i < count; ++i) bins[lengths[i] + 1]++;
+            for (uint32_t l = 0; l <= longest; ++l) bins[l + 1] += bins[l];
+            for (uint32_t i = 0; i < count; ++i) order[bins[lengths[i]]++] = i;
+            free(bins);
+            return;
+        }
+    }
+    uint64_t *keys = (uint64_t *)malloc((size_t)count * sizeof(uint64_t));
+    if (!keys) { /* degrade to the identity order: still correct, only less balanced */
+        for (uint32_t i = 0; i < count; ++i) order[i] = i;
+        return;
+    }
+    for (uint32_t i = 0; i < count; ++i) keys[i] = ((uint64_t)lengths[i] << 32) | i; /* index breaks ties: stable */
+    qsort(keys, count, sizeof(uint64_t), compare_u64);
+    for (uint32_t i = 0; i < count; ++i) order[i] = (uint32_t)keys[i];
+    free(keys);
+}
+
+static unsigned myers_variant(uint32_t length) {
+    unsigned const words = length ? (length + 31) / 32 : 1;
+    return words <= SZS_MYERS_MAX_WORDS ? szs_hip_levenshtein_myers_round_words(words) : 0;
+}
+
+void szs_plan_build(int myers, int symmetric, uint64_t const *query_addresses, uint32_t const *query_lengths,
+                    uint32_t queries_count, uint64_t const *candidate_addresses, uint32_t const *candidate_lengths,
+                    uint32_t candidates_count, szs_string_ref_t *query_refs, szs_string_ref_t *candidate_refs,
+                    uint32_t *keys, szs_plan_t *plan) {
+    memset(plan, 0, sizeof(*plan));
+    uint64_t query_bytes = 0, candidate_bytes = 0;
+    for (uint32_t i = 0; i < queries_count; ++i) {
+        if (query_lengths[i] > plan->longest_query) plan->longest_query = query_lengths[i];
+        query_bytes += query_lengths[i];
+    }
+    for (uint32_t i = 0; i < candidates_count; ++i) {
+        if (candidate_lengths[i] > plan->longest_candidate) plan->longest_candidate = candidate_lengths[i];
+        candidate_bytes += candidate_lengths[i];
+    }
+    if (symmetric) { /* lower triangle incl. diagonal: sum_i len_i * sum_{j <= i} len_j */
+        uint64_t prefix = 0, cells = 0;
+        for (uint32_t i = 0; i < queries_count; ++i) prefix += query_lengths[i], cells += (uint64_t)query_lengths[i] * prefix;
+        plan->cells = cells;
+    }
+    else { plan->cells = query_bytes * candidate_bytes; }
+
+    /* Candidates: ascending length. */
+    sort_by_length(candidate_lengths, candidates_count, plan->longest_candidate, keys);
+    for (uint32_t slot = 0; slot < candidates_count; ++slot) {
+        uint32_t const c = keys[slot];
+        candidate_refs[slot].address = candidate_addresses[c];
+        candidate_refs[slot].length = candidate_lengths[c];
+        candidate_refs[slot].index = c;
+    }
+
+    /* Queries: grouped by variant, ascending; variant 0 (weighted kernel) goes last for Myers plans. */
+    if (!myers) {
+        for (uint32_t q = 0; q < queries_count; ++q) {
+            query_refs[q].address = query_addresses[q];
+            query_refs[q].length = query_lengths[q];
+            query_refs[q].index = q;
+        }
+        if (queries_count) {
+            plan->groups_count = 1;
+            plan->groups[0].variant = 0, plan->groups[0].first = 0, plan->groups[0].count = queries_count;
+        }
+        return;
+    }
+    uint32_t histogram[SZS_MYERS_MAX_WORDS + 2];
+    memset(histogram, 0, sizeof(histogram));
+    for (uint32_t q = 0; q < queries_count; ++q) {
+        unsigned const variant = myers_variant(query_lengths[q]);
+        histogram[variant ? variant : SZS_MYERS_MAX_WORDS + 1]++;
+    }
+    uint32_t starts[SZS_MYERS_MAX_WORDS + 2];
+    uint32_t running = 0;
+    for (unsigned v = 1; v <= SZS_MYERS_MAX_WORDS + 1; ++v) {
+        starts[v] = running;
+        if (histogram[v]) {
+            szs_plan_group_t *group = &plan->groups[plan->groups_count++];
+            group->variant = v <= SZS_MYERS_MAX_WORDS ? v : 0;
+            group->first = running, group->count = histogram[v];
+        }
+        running += histogram[v];
+    }
+    for (uint32_t q = 0; q < queries_count; ++q) {
+        unsigned const variant = myers_variant(query_lengths[q]);
+        uint32_t const slot = starts[variant ? variant : SZS_MYERS_MAX_WORDS + 1]++;
+        query_refs[slot].address = query_addresses[q];
+        query_refs[slot].length = query_lengths[q];
+        query_refs[slot].index = q;
+    }
+}
+
+/* ---- exported probes ------------------------------------------------------------------------------------------------ */
+
+sz_status_t szs_rocm_plan_probe(int unit_cost, int symmetric, sz_u32_t const *query_lengths, sz_size_t queries_count,
+                                sz_u32_t const *candidate_lengths, sz_size_t candidates_count,
+                                sz_u32_t *candidate_order, sz_u32_t *query_order, sz_u32_t *query_variant,
+                                sz_u64_t *cells) {
+    if (queries_count > 0xFFFFFFFFu || candidates_count > 0xFFFFFFFFu) return sz_overflow_risk_k;
+    uint32_t const q = (uint32_t)queries_count, c = (uint32_t)candidates_count;
+    size_t const most = q > c ? q : c;
+    uint64_t *addresses = (uint64_t *)calloc(most + 1, sizeof(uint64_t));
+    szs_string_ref_t *query_refs = (szs_string_ref_t *)calloc((size_t)q + 1, sizeof(szs_string_ref_t));
+    szs_string_ref_t *candidate_refs = (szs_string_ref_t *)calloc((size_t)c + 1, sizeof(szs_string_ref_t));
+    uint32_t *keys = (uint32_t *)calloc(most + 1, sizeof(uint32_t));
+    if (!addresses || !query_refs || !candidate_refs || !keys) {
+        free(addresses), free(query_refs), free(candidate_refs), free(keys);
+        return sz_bad_alloc_k;
+    }
+    szs_plan_t plan;
+    szs_plan_build(unit_cost, symmetric, addresses, query_lengths, q, addresses, candidate_lengths, c, query_refs,
+                   candidate_refs, keys, &plan);
+    if (candidate_order)
+        for (uint32_t i = 0; i < c; ++i) candidate_order[i] = candidate_refs[i].index;
+    if (query_order)
+        for (uint32_t i = 0; i < q; ++i) query_order[i] = query_refs[i].index;
+    if (query_variant)
+        for (unsigned g = 0; g < plan.groups_count; ++g)
+            for (uint32_t i = 0; i < plan.groups[g].count; ++i)
+                query_variant[plan.groups[g].first + i] = plan.groups[g].variant;
+    if (cells) *cells = plan.cells;
+    free(addresses), free(query_refs), free(candidate_refs), free(keys);
+    return sz_success_k;
+}
+
+typedef struct {
+    uint64_t weight;
+    uint32_t row;
+} weighted_row_t;
+
+static int compare_rows_descending(void const *a, void const *b) {
+    weighted_row_t const *x = (weighted_row_t const *)a, *y = (weighted_row_t const *)b;
+    if (x->weight != y->weight) return x->weight > y->weight ? -1 : 1;
+    return x->row < y->row ? -1 : x->row > y->row;
+}
+
+sz_status_t szs_rocm_shard_rows(sz_size_t const *row_weights, sz_size_t rows, sz_size_t shards, sz_u32_t *shard_of_row,
+                                sz_u64_t *shard_loads) {
+    if (!shards || !shard_of_row || (rows && !row_weights) || rows > 0xFFFFFFFFu) return sz_unexpected_dimensions_k;
+    weighted_row_t *sorted = (weighted_row_t *)malloc((rows + 1) * sizeof(weighted_row_t));
+    uint64_t *loads = (uint64_t *)calloc(shards, sizeof(uint64_t));
+    if (!sorted || !loads) {
+        free(sorted), free(loads);
+        return sz_bad_alloc_k;
+    }
+    for (size_t i = 0; i < rows; ++i) sorted[i].weight = row_weights[i], sorted[i].row = (uint32_t)i;
+    qsort(sorted, rows, sizeof(weighted_row_t), compare_rows_descending);
+    for (size_t i = 0; i < rows; ++i) { /* heaviest first, always onto the lightest shard */
+        size_t lightest = 0;
+        for (size_t s = 1; s < shards; ++s)
+            if (loads[s] < loads[lightest]) lightest = s;
+        loads[lightest] += sorted[i].weight;
+        shard_of_row[sorted[i].row] = (uint32_t)lightest;
+    }
+    if (shard_loads) memcpy(shard_loads, loads, shards * sizeof(uint64_t));
+    free(sorted), free(loads);
+    return sz_success_k;
+}

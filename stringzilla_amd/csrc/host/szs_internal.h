@@ -1,0 +1,146 @@
+/*
+ *  szs_internal.h - private declarations of the C host side of libstringzillas_rocm_shared.so.
+ *
+ *  The host is plain C11.  It owns: status/message plumbing, device scopes, engine objects, input
+ *  normalisation (tapes / callback sequences -> string refs), the planner (length-sorting candidates, grouping
+ *  queries per kernel variant) and the launch sequence.  It reaches the GPU only through the HIP runtime C API
+ *  and through the `extern "C"` launchers of csrc/hip/kernels.h.  There is no CPU scoring path in this library.
+ */
+#ifndef SZS_INTERNAL_H_
+#define SZS_INTERNAL_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+
+#include "../../../include/stringzillas/stringzillas.h"
+#include "../../../include/stringzillas/stringzillas_rocm.h"
+#include "../hip/kernels.h"
+
+#define SZS_VERSION_MAJOR 5 /* tracks the reference ABI: /root/reference/include/stringzilla/stringzilla.h:79-81 */
+#define SZS_VERSION_MINOR 1
+#define SZS_VERSION_PATCH 2
+
+/* ---- status plumbing (reference: c/stringzillas/stringzillas.cuh:207-257) ---------------------------------------- */
+
+/** Stores the static message for `status` (or `override_message` verbatim) and returns `status`. */
+sz_status_t szs_report(sz_status_t status, char const **error_message, char const *override_message);
+/** Maps a HIP failure to `sz_status_unknown_k` (or `sz_bad_alloc_k` for OOM) with the HIP error *name* as message. */
+sz_status_t szs_report_hip(hipError_t error, char const **error_message);
+
+/* ---- device scopes ----------------------------------------------------------------------------------------------- */
+
+typedef enum { szs_scope_default_k = 0, szs_scope_cpu_k = 1, szs_scope_gpu_k = 2 } szs_scope_kind_t;
+
+typedef struct szs_scope_s {
+    szs_scope_kind_t kind;
+    size_t cpu_cores;
+    int gpu_device;
+    hipStream_t stream; /* created lazily on first use; non-blocking */
+} szs_scope_s;
+
+/** Resolves a scope handle to (device ordinal, stream) for a GPU engine; CPU scopes are a mismatch. */
+sz_status_t szs_scope_bind_gpu(szs_scope_s *scope, int *device, hipStream_t *stream, char const **error_message);
+
+/* ---- grow-only buffers ------------------------------------------------------------------------------------------- */
+
+typedef enum { szs_memory_host_k = 0, szs_memory_pinned_k = 1, szs_memory_device_k = 2 } szs_memory_kind_t;
+
+typedef struct szs_buffer_t {
+    void *pointer;
+    size_t capacity;
+    szs_memory_kind_t kind;
+    int device; /* for pinned / device memory */
+} szs_buffer_t;
+
+/** Ensures `buffer` holds at least `bytes`; contents are NOT preserved. */
+sz_status_t szs_buffer_reserve(szs_buffer_t *buffer, szs_memory_kind_t kind, int device, size_t bytes,
+                               char const **error_message);
+void szs_buffer_release(szs_buffer_t *buffer);
+
+/* ---- engines ----------------------------------------------------------------------------------------------------- */
+
+typedef enum {
+    szs_family_levenshtein_k = 0,
+    szs_family_levenshtein_utf8_k = 1,
+    szs_family_needleman_wunsch_k = 2,
+    szs_family_smith_waterman_k = 3
+} szs_family_t;
+
+typedef struct szs_engine_s {
+    uint32_t magic;
+    szs_family_t family;
+    /* cost model as given at init */
+    int8_t match, mismatch, open, extend;
+    uint8_t byte_to_class[256];
+    int8_t class_costs[32 * 32];
+    int is_linear;    /* open == extend (levenshtein.cuh:117) */
+    int is_unit_cost; /* match 0, mismatch 1, gap 1: bit-parallel kernel (serial.hpp:118-120) */
+    unsigned magnitude; /* max |cost| over substitutions and gaps, for the reach rule (serial.hpp:135-162) */
+
+    /* grow-only scratch, bound to the device of the last call */
+    int device;
+    szs_buffer_t host_lengths;   /* host: addresses + lengths of both sides, sort keys */
+    szs_buffer_t pinned_staging; /* pinned: offsets downloads, string-ref uploads */
+    szs_buffer_t device_refs;    /* device: string refs of both sides */
+    szs_buffer_t device_results; /* device: dense results when the caller's matrix is not device-accessible */
+    szs_buffer_t device_boundary;/* device: strip boundaries of the weighted kernels */
+    szs_buffer_t device_model;   /* device: szs_cost_model_t */
+    szs_buffer_t device_tape;    /* device: flattened copy of callback-sequence strings living in host memory */
+    int model_uploaded_device;
+    hipEvent_t event_start, event_stop;
+    int events_device;
+
+    szs_rocm_call_profile_t last_profile;
+} szs_engine_s;
+
+#define SZS_ENGINE_MAGIC 0x535A5345u
+
+/* ---- inputs ------------------------------------------------------------------------------------------------------ */
+
+typedef enum { szs_input_u32tape_k = 0, szs_input_u64tape_k = 1, szs_input_sequence_k = 2 } szs_input_kind_t;
+
+typedef struct szs_input_t {
+    szs_input_kind_t kind;
+    size_t count;
+    char const *data;          /* tapes */
+    void const *offsets;       /* tapes: count + 1 entries of 4 or 8 bytes */
+    sz_sequence_t const *sequence;
+} szs_input_t;
+
+/* ---- planner (plan.c) - pure host logic, unit-tested without a GPU through the szs_rocm_plan_* exports ------------ */
+
+typedef struct szs_plan_group_t {
+    unsigned variant;     /* Myers: rounded word count; weighted: 0 */
+    uint32_t first, count;/* slice of the planned query array */
+} szs_plan_group_t;
+
+#define SZS_PLAN_MAX_GROUPS 24
+
+typedef struct szs_plan_t {
+    uint32_t longest_query, longest_candidate;
+    uint64_t cells; /* sum over live pairs of len(q) * len(c): the GCUPS numerator (bench/similarities.cuh:344-366) */
+    unsigned groups_count;
+    szs_plan_group_t groups[SZS_PLAN_MAX_GROUPS];
+} szs_plan_t;
+
+/**
+ *  Fills `candidate_refs` with the candidates sorted by ascending length (stable), and `query_refs` grouped by kernel
+ *  variant (ascending), each group keeping the original order.  `myers` selects word-count grouping; queries too long
+ *  for the bit-parallel kernel land in a final group with variant 0 (scored by the weighted kernel).
+ *  Lengths and addresses are parallel arrays.  Scratch `keys` must hold max(q, c) uint32_t.
+ */
+void szs_plan_build(int myers, int symmetric, uint64_t const *query_addresses, uint32_t const *query_lengths,
+                    uint32_t queries_count, uint64_t const *candidate_addresses, uint32_t const *candidate_lengths,
+                    uint32_t candidates_count, szs_string_ref_t *query_refs, szs_string_ref_t *candidate_refs,
+                    uint32_t *keys, szs_plan_t *plan);
+
+/* ---- the call (dispatch.c) --------------------------------------------------------------------------------------- */
+
+sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input_t const *queries,
+                             szs_input_t const *candidates /* NULL: symmetric */, void *results,
+                             size_t results_row_stride, char const **error_message);
+
+#endif /* SZS_INTERNAL_H_ */

@@ -1,0 +1,100 @@
+"""Synthetic inputs for the configurations named in BASELINE.json / SURVEY.md section 8(d).
+
+Pure numpy, seeded, no oracle and no device code in here: used by bench.py, by the GPU parity tests and by the CPU
+baseline leg so that all three see byte-identical batches.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import Strs
+
+ASCII_PRINTABLE = np.arange(0x20, 0x7F, dtype=np.uint8)
+AMINO_ACIDS = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)
+NUCLEOTIDES = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def random_tape(rng: np.random.Generator, count: int, low: int, high: int, alphabet: np.ndarray) -> Strs:
+    """`count` strings with lengths ~ U[low, high] over `alphabet`, packed as a u32 tape."""
+    lengths = rng.integers(low, high + 1, size=count, dtype=np.int64)
+    offsets = np.zeros(count + 1, dtype=np.uint32)
+    np.cumsum(lengths, out=offsets[1:])
+    data = alphabet[rng.integers(0, len(alphabet), size=int(offsets[-1]))]
+    return Strs.from_tape(data, offsets)
+
+
+def zipf_utf8_tape(rng: np.random.Generator, count: int, low: int = 8, high: int = 2048, exponent: float = 1.1) -> Strs:
+    """Config 5: mixed 1-4-byte UTF-8 text whose BYTE length follows Zipf(s) clipped to [low, high]."""
+    ranks = np.arange(low, high + 1, dtype=np.float64)
+    weights = ranks ** (-exponent)
+    lengths = rng.choice(np.arange(low, high + 1), size=count, p=weights / weights.sum())
+    pools = {
+        1: [bytes([c]) for c in range(0x20, 0x7F)],
+        2: [chr(c).encode() for c in list(range(0xC0, 0x17F)) + list(range(0x410, 0x450))],
+        3: [chr(c).encode() for c in range(0x4E00, 0x4E00 + 512)],
+        4: [chr(c).encode() for c in range(0x1F600, 0x1F640)],
+    }
+    widths = rng.choice([1, 2, 3, 4], size=int(lengths.sum()), p=[0.70, 0.20, 0.08, 0.02])
+    strings, cursor = [], 0
+    for target in lengths:
+        parts, size = [], 0
+        while size < target:
+            width = int(widths[cursor % len(widths)])
+            cursor += 1
+            if size + width > target:
+                width = 1  # finish with ASCII so the byte length is exact
+            pool = pools[width]
+            parts.append(pool[int(rng.integers(0, len(pool)))])
+            size += width
+        strings.append(b"".join(parts))
+    return Strs(strings)
+
+
+@dataclass
+class Workload:
+    name: str
+    kind: str  # "levenshtein" | "needleman_wunsch" | "smith_waterman"
+    queries: Strs
+    candidates: Strs
+    costs: dict  # engine constructor keywords besides the substitution table
+    table: Optional[str] = None  # "blosum62" | "nuc44"
+
+    @property
+    def pairs(self) -> int:
+        return len(self.queries) * len(self.candidates)
+
+    @property
+    def cells(self) -> int:
+        return int(self.queries.lengths().sum()) * int(self.candidates.lengths().sum())
+
+
+def config(index: int, scale: float = 1.0) -> Workload:
+    """The five BASELINE.json configs as concrete, seeded batches.  `scale` < 1 shrinks
+    the matrix side for parity tests that must finish in seconds on the CPU oracle."""
+    rng = np.random.default_rng(index)
+    side = lambda n: max(1, int(round(n * scale)))
+    if index == 1:
+        return Workload("cfg1: 100x100 ASCII len U[48,80], Levenshtein unit", "levenshtein",
+                        random_tape(rng, side(100), 48, 80, ASCII_PRINTABLE),
+                        random_tape(rng, side(100), 48, 80, ASCII_PRINTABLE), dict(match=0, mismatch=1, open=1, extend=1))
+    if index == 2:
+        return Workload("cfg2: 1024x1024 ASCII len U[96,160], Levenshtein unit", "levenshtein",
+                        random_tape(rng, side(1024), 96, 160, ASCII_PRINTABLE),
+                        random_tape(rng, side(1024), 96, 160, ASCII_PRINTABLE), dict(match=0, mismatch=1, open=1, extend=1))
+    if index == 3:
+        return Workload("cfg3: 1024x1024 protein len U[384,640], NW BLOSUM62 linear -4", "needleman_wunsch",
+                        random_tape(rng, side(1024), 384, 640, AMINO_ACIDS),
+                        random_tape(rng, side(1024), 384, 640, AMINO_ACIDS), dict(open=-4, extend=-4), "blosum62")
+    if index == 4:
+        return Workload("cfg4: 512x512 DNA len U[3072,5120], SW NUC.4.4 affine -4/-1", "smith_waterman",
+                        random_tape(rng, side(512), 3072, 5120, NUCLEOTIDES),
+                        random_tape(rng, side(512), 3072, 5120, NUCLEOTIDES), dict(open=-4, extend=-1), "nuc44")
+    if index == 5:
+        return Workload("cfg5: 3163x3163 UTF-8 Zipf(1.1) bytes [8,2048], byte-level Levenshtein unit", "levenshtein",
+                        zipf_utf8_tape(rng, side(3163)), zipf_utf8_tape(rng, side(3163)),
+                        dict(match=0, mismatch=1, open=1, extend=1))
+    raise ValueError(f"unknown config {index}")

@@ -1,0 +1,326 @@
+"""`-m gpu`: the HIP path, called through the C-ABI, against the CPU oracle, the committed golden matrices and the
+reference's known answers.  Bit-exact everywhere: this path is integer arithmetic.
+
+Mirrors the reference's own test plan for the path: KATs (test/similarities.cuh:609-625),
+fuzz equivalence over cost schemes (:654-763), cross-product shapes incl. empties (:1283-1326), kernel-tier edges
+(:1961-2108), closed forms (:1006-1153) and the input-format / error behaviour of the C shim.
+"""
+import ctypes
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import stringzilla_amd as szs  # noqa: E402
+from stringzilla_amd import _abi, matrices, workloads  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+
+    assert torch.cuda.is_available(), "the gpu-marked tests need a GPU"
+    return szs.DeviceScope(gpu_device=0)
+
+
+def _unhex(items):
+    return [bytes.fromhex(x) for x in items]
+
+
+def _rand(rng, count, lo, hi, alphabet):
+    return [bytes(rng.choice(alphabet) for _ in range(rng.randint(lo, hi))) for _ in range(count)]
+
+
+# ---- known answers and golden matrices --------------------------------------------------------------------------------
+
+
+def test_known_answers(gpu, golden):
+    _, kats = golden
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+    for group in ("levenshtein_unit", "levenshtein_unit_python"):
+        firsts = [v[0].encode() for v in kats[group]["vectors"]]
+        seconds = [v[1].encode() for v in kats[group]["vectors"]]
+        matrix = engine(firsts, seconds, device=gpu)
+        assert matrix.dtype == np.uint64
+        assert np.diagonal(matrix).tolist() == [v[2] for v in kats[group]["vectors"]]
+        for first, second, expected in kats[group]["vectors"]:  # and as 1x1 calls, like the reference emulates pairs
+            assert int(engine([first.encode()], [second.encode()], device=gpu)[0, 0]) == expected
+    match, mismatch, open_, extend = kats["levenshtein_custom_gaps"]["costs"]
+    custom = szs.LevenshteinDistances(match=match, mismatch=mismatch, open=open_, extend=extend, capabilities=gpu)
+    for first, second, expected in kats["levenshtein_custom_gaps"]["vectors"]:
+        assert int(custom([first.encode()], [second.encode()], device=gpu)[0, 0]) == expected, (first, second)
+
+
+def test_golden_reference_matrices(gpu, golden):
+    """Every matrix the real reference engines produced (tests/golden/make_golden.py) must be reproduced exactly."""
+    cases, _ = golden
+    tables = {k: (np.array(v["byte_to_class"], np.uint8), np.array(v["class_costs"], np.int8).reshape(32, 32))
+              for k, v in cases["tables"].items()}
+    engines = {}
+    for case in cases["cases"]:
+        queries, candidates = _unhex(case["queries"]), _unhex(case["candidates"])
+        if case["kind"] == "levenshtein":
+            key = ("levenshtein", tuple(case["costs"]))
+            if key not in engines:
+                m, x, o, e = case["costs"]
+                engines[key] = szs.LevenshteinDistances(match=m, mismatch=x, open=o, extend=e, capabilities=gpu)
+            dtype = np.uint64
+        else:
+            key = (case["kind"], case["table"], tuple(case["gaps"]))
+            if key not in engines:
+                cls = szs.NeedlemanWunschScores if case["kind"] == "needleman_wunsch" else szs.SmithWatermanScores
+                engines[key] = cls(*tables[case["table"]], open=case["gaps"][0], extend=case["gaps"][1], capabilities=gpu)
+            dtype = np.int64
+        engine = engines[key]
+        got = engine(queries, candidates, device=gpu)
+        expected = np.array(case["matrix"], dtype=dtype).reshape(len(queries), len(candidates))
+        assert np.array_equal(got, expected), (case["kind"], case["name"], key)
+        sym = engine(queries, device=gpu)
+        expected_sym = np.array(case["symmetric"], dtype=dtype).reshape(len(queries), len(queries))
+        assert np.array_equal(sym, expected_sym), (case["kind"], case["name"], key, "symmetric")
+
+
+# ---- fuzz equivalence against the oracle -------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("costs", [(0, 1, 1, 1), (1, 3, 3, 3), (0, 1, 4, 2), (0, 4, 3, 2), (2, 5, 4, 1)])
+def test_levenshtein_fuzz(gpu, oracle, costs):
+    rng = random.Random(hash(costs) & 0xFFFF)
+    engine = szs.LevenshteinDistances(*costs, capabilities=gpu)
+    for alphabet, lo, hi, q_count, c_count in [
+        (b"ABC", 1, 200, 16, 16),                # the reference's default fuzz config (test/stringzilla.hpp:395-400)
+        (b"ACGT", 0, 40, 9, 300),                # more than one 256-candidate workgroup, empties included
+        (bytes(range(256)), 25, 40, 5, 70),      # bytes >= 0x80 (parity trap 6)
+        (b"AB", 120, 136, 7, 65),                # straddles the 4-word / 5-word kernels
+    ]:
+        queries, candidates = _rand(rng, q_count, lo, hi, alphabet), _rand(rng, c_count, lo, hi, alphabet)
+        assert np.array_equal(engine(queries, candidates, device=gpu), oracle.levenshtein(queries, candidates, *costs))
+        assert np.array_equal(engine(queries, device=gpu), oracle.levenshtein(queries, None, *costs))
+
+
+def test_levenshtein_every_kernel_width(gpu, oracle):
+    """One query per instantiated bit-parallel kernel (1..64 words), plus queries beyond 2048 bytes that fall through to
+    the weighted kernel - all in ONE call, so the planner's grouping is exercised too."""
+    rng = random.Random(77)
+    edges = [0, 1, 31, 32, 33, 64, 65, 96, 97, 128, 129, 160, 161, 192, 224, 225, 256, 257, 320, 321, 384, 385, 512, 513,
+             640, 768, 769, 1024, 1025, 1536, 1537, 2048, 2049, 2500]
+    queries = [bytes(rng.choice(b"ACGT") for _ in range(n)) for n in edges]
+    candidates = _rand(rng, 70, 0, 300, b"ACGT") + [queries[9], queries[-1][:2100]]
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+    got = engine(queries, candidates, device=gpu)
+    assert np.array_equal(got, oracle.levenshtein(queries, candidates))
+    profile = engine.last_call_profile()
+    assert profile.launches >= 16 and profile.cells == sum(map(len, queries)) * sum(map(len, candidates))
+
+
+@pytest.mark.parametrize("kind", ["needleman_wunsch", "smith_waterman"])
+@pytest.mark.parametrize("gaps", [(-4, -4), (-4, -1), (-1, -1), (-11, -2), (-2, -5)])
+def test_alignment_fuzz(gpu, oracle, kind, gaps):
+    rng = random.Random(hash((kind, gaps)) & 0xFFFF)
+    asym_map = np.array([rng.randint(0, 31) for _ in range(256)], dtype=np.uint8)
+    asym_tab = np.array([[rng.randint(-9, 9) for _ in range(32)] for _ in range(32)], dtype=np.int8)
+    cls = szs.NeedlemanWunschScores if kind == "needleman_wunsch" else szs.SmithWatermanScores
+    for (byte_to_class, class_costs), alphabet in [
+        (matrices.blosum62(), b"ARNDCQEGHILKMFPSTWYVBZX"),
+        (matrices.nuc44(), b"ACGTN"),
+        ((asym_map, asym_tab), bytes(range(256))),  # asymmetric table: the query must pick the ROW (parity trap 5)
+    ]:
+        engine = cls(byte_to_class, class_costs, open=gaps[0], extend=gaps[1], capabilities=gpu)
+        for lo, hi, q_count, c_count in [(1, 200, 12, 12), (0, 50, 5, 280), (15, 17, 6, 20), (30, 70, 3, 40)]:
+            queries, candidates = _rand(rng, q_count, lo, hi, alphabet), _rand(rng, c_count, lo, hi, alphabet)
+            expected = getattr(oracle, kind)(queries, candidates, byte_to_class, class_costs, *gaps)
+            got = engine(queries, candidates, device=gpu)
+            assert got.dtype == np.int64 and np.array_equal(got, expected), (kind, gaps, lo, hi)
+            expected_sym = getattr(oracle, kind)(queries, None, byte_to_class, class_costs, *gaps)
+            assert np.array_equal(engine(queries, device=gpu), expected_sym), (kind, gaps, lo, hi, "symmetric")
+
+
+def test_cross_product_shapes(gpu, oracle):
+    """1xN, Nx1, 1x1, ragged with empties, rectangular, empty sides (test/similarities.cuh:1283-1326)."""
+    rng = random.Random(5)
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+    nw = szs.NeedlemanWunschScores(*matrices.blosum62(), open=-4, extend=-1, capabilities=gpu)
+    for q_count, c_count in [(1, 9), (9, 1), (1, 1), (6, 6), (3, 11), (0, 4), (4, 0), (0, 0)]:
+        queries, candidates = _rand(rng, q_count, 0, 30, b"ARND"), _rand(rng, c_count, 0, 30, b"ARND")
+        if q_count == 6:
+            queries[2] = b""
+            candidates[4] = b""
+        got = engine(queries, candidates, device=gpu)
+        assert got.shape == (q_count, c_count)
+        assert np.array_equal(got, oracle.levenshtein(queries, candidates))
+        got = nw(queries, candidates, device=gpu)
+        assert np.array_equal(got, oracle.needleman_wunsch(queries, candidates, *matrices.blosum62(), -4, -1))
+
+
+def test_symmetric_universals(gpu):
+    rng = random.Random(9)
+    strings = _rand(rng, 300, 0, 90, b"ACGT")
+    matrix = szs.LevenshteinDistances(capabilities=gpu)(strings, device=gpu)
+    assert np.array_equal(matrix, matrix.T) and not np.diagonal(matrix).any()  # test/similarities.cuh:1259-1264
+
+
+def test_closed_forms(gpu):
+    rng = random.Random(10)
+    strings = _rand(rng, 40, 0, 400, b"ACGT")
+    lengths = np.array([len(s) for s in strings], dtype=np.int64)
+    unit = szs.LevenshteinDistances(capabilities=gpu)
+    assert np.array_equal(unit(strings, [b""], device=gpu)[:, 0], lengths.astype(np.uint64))        # d(x, "") = |x|
+    assert not np.diagonal(unit(strings, strings, device=gpu)).any()                                 # d(x, x) = 0
+    weird = szs.LevenshteinDistances(match=0, mismatch=2, open=5, extend=2, capabilities=gpu)
+    expected = np.where(lengths > 0, 5 + 2 * (lengths - 1), 0).astype(np.uint64)                    # serial.hpp:165-175
+    assert np.array_equal(weird([b""], strings, device=gpu)[0], expected)
+    table = matrices.nuc44()
+    sw = szs.SmithWatermanScores(*table, open=-4, extend=-1, capabilities=gpu)
+    assert not sw(strings, [b""], device=gpu).any()                                                 # serial.hpp:3077-3080
+    assert np.array_equal(np.diagonal(sw(strings, strings, device=gpu)), 5 * lengths)               # all matches
+    nw = szs.NeedlemanWunschScores(*table, open=-4, extend=-4, capabilities=gpu)
+    assert np.array_equal(nw(strings, [b""], device=gpu)[:, 0], -4 * lengths)
+
+
+# ---- the C shim's formats and error behaviour -------------------------------------------------------------------------
+
+
+def test_input_formats_and_result_placement(gpu, oracle):
+    import torch
+
+    rng = random.Random(21)
+    queries, candidates = _rand(rng, 7, 0, 150, b"ACGT"), _rand(rng, 300, 0, 150, b"ACGT")
+    expected = oracle.levenshtein(queries, candidates)
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+
+    wide_q, wide_c = szs.Strs(queries, wide_offsets=True), szs.Strs(candidates, wide_offsets=True)
+    assert np.array_equal(engine(wide_q, wide_c, device=gpu), expected)                   # *_u64tape
+
+    out = np.full((7, 300), 0xDEADBEEF, dtype=np.uint64)                                  # plain host results: staged copy
+    assert engine(queries, candidates, device=gpu, out=out) is out and np.array_equal(out, expected)
+
+    padded = torch.full((7, 320), -7, dtype=torch.int64, device="cuda")                   # stride > columns
+    view = padded[:, :300]
+    engine(queries, candidates, device=gpu, out=view)
+    assert np.array_equal(view.cpu().numpy().view(np.uint64), expected)
+    assert (padded[:, 300:] == -7).all()                                                  # padding never written (cuda.cuh:2201-2203)
+
+    # Unified memory from the library's own allocator, host-written, device-read, host-read back.
+    q_tape, c_tape = szs.Strs(queries), szs.Strs(candidates)
+    blocks = []
+
+    def unified_copy(array):
+        pointer = _abi.lib.szs_unified_alloc(max(array.nbytes, 1))
+        assert pointer
+        ctypes.memmove(pointer, array.ctypes.data, array.nbytes)
+        blocks.append((pointer, array.nbytes))
+        return pointer
+
+    results_pointer = _abi.lib.szs_unified_alloc(7 * 300 * 8)
+    q_struct = _abi.U32Tape(unified_copy(q_tape.data), unified_copy(q_tape.offsets), 7)
+    c_struct = _abi.U32Tape(unified_copy(c_tape.data), unified_copy(c_tape.offsets), 300)
+    error = ctypes.c_char_p()
+    status = _abi.lib.szs_levenshtein_distances_u32tape(engine.handle, gpu.handle, ctypes.byref(q_struct), ctypes.byref(c_struct),
+                                                        results_pointer, 300, ctypes.byref(error))
+    assert status == 0, error.value
+    unified = np.ctypeslib.as_array(ctypes.cast(results_pointer, ctypes.POINTER(ctypes.c_uint64)), shape=(7, 300))
+    assert np.array_equal(unified, expected)
+    for pointer, size in blocks:
+        _abi.lib.szs_unified_free(pointer, size)
+    _abi.lib.szs_unified_free(results_pointer, 7 * 300 * 8)
+
+
+def test_callback_sequences(gpu, oracle):
+    """`sz_sequence_t`: strings reached through host callbacks, each at its own device address."""
+    import torch
+
+    rng = random.Random(22)
+    queries, candidates = _rand(rng, 5, 1, 60, b"ACGT"), _rand(rng, 9, 1, 60, b"ACGT")
+    keep = []
+
+    def sequence_of(strings):
+        tensors = [torch.tensor(list(s), dtype=torch.uint8, device="cuda") for s in strings]
+        starts = [t.data_ptr() for t in tensors]
+        lengths = [len(s) for s in strings]
+        get_start = _abi.MEMBER_START(lambda handle, i: starts[i])
+        get_length = _abi.MEMBER_LENGTH(lambda handle, i: lengths[i])
+        keep.extend([tensors, get_start, get_length])
+        return _abi.Sequence(None, len(strings), get_start, get_length)
+
+    q_seq, c_seq = sequence_of(queries), sequence_of(candidates)
+    results = torch.zeros((5, 9), dtype=torch.int64, device="cuda")
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+    error = ctypes.c_char_p()
+    status = _abi.lib.szs_levenshtein_distances(engine.handle, gpu.handle, ctypes.byref(q_seq), ctypes.byref(c_seq),
+                                                results.data_ptr(), 9, ctypes.byref(error))
+    assert status == 0, error.value
+    assert np.array_equal(results.cpu().numpy().view(np.uint64), oracle.levenshtein(queries, candidates))
+
+
+def test_error_behaviour(gpu):
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+    strs = szs.Strs([b"abc", b"abd"]).to_device(0)
+    with pytest.raises(szs.StringZillasError) as failure:  # GPU engine + CPU scope (levenshtein.cuh:86)
+        engine(strs, strs, device=szs.DeviceScope(cpu_cores=2))
+    assert failure.value.status_name == "device_code_mismatch"
+
+    host_data = np.frombuffer(b"abcabd", dtype=np.uint8).copy()  # plain host memory (cuda.cuh:4268-4272)
+    host_offsets = np.array([0, 3, 6], dtype=np.uint32)
+    tape = _abi.U32Tape(host_data.ctypes.data, host_offsets.ctypes.data, 2)
+    out = np.zeros((2, 2), dtype=np.uint64)
+    error = ctypes.c_char_p()
+    status = _abi.lib.szs_levenshtein_distances_u32tape(engine.handle, gpu.handle, ctypes.byref(tape), ctypes.byref(tape),
+                                                        out.ctypes.data, 2, ctypes.byref(error))
+    assert status == -18 and error.value == b"Use device-reachable or unified memory"
+
+    untouched = np.full((2, 2), 7, dtype=np.uint64)  # empty side: success, nothing written (cuda.cuh:4257)
+    assert engine(strs, szs.Strs([]), device=gpu).shape == (2, 0)
+    empty = _abi.U32Tape(host_data.ctypes.data, host_offsets.ctypes.data, 0)
+    status = _abi.lib.szs_levenshtein_distances_u32tape(engine.handle, gpu.handle, ctypes.byref(empty), ctypes.byref(tape),
+                                                        untouched.ctypes.data, 2, ctypes.byref(error))
+    assert status == 0 and (untouched == 7).all()
+
+    assert engine(strs, strs)[0, 1] == 1  # default scope lazily binds GPU 0 (stringzillas.cuh:303-320)
+    assert "cuda" in szs.DeviceScope(gpu_device=0).capabilities and "cuda" in szs.__capabilities__
+
+    with pytest.raises(szs.StringZillasError):
+        szs.DeviceScope(gpu_device=64)
+
+
+# ---- BASELINE.json configs: scaled against the oracle, full size through size-independent properties -------------------
+
+
+@pytest.mark.parametrize("index,scale", [(1, 1.0), (2, 1 / 8), (3, 1 / 32), (4, 1 / 128), (5, 1 / 24)])
+def test_baseline_configs_scaled(gpu, oracle, index, scale):
+    load = workloads.config(index, scale=scale)
+    queries = [load.queries[i] for i in range(len(load.queries))]
+    candidates = [load.candidates[i] for i in range(len(load.candidates))]
+    if load.kind == "levenshtein":
+        engine = szs.LevenshteinDistances(**load.costs, capabilities=gpu)
+        expected = oracle.levenshtein(queries, candidates, **load.costs)
+    else:
+        table = matrices.by_name(load.table)
+        cls = szs.NeedlemanWunschScores if load.kind == "needleman_wunsch" else szs.SmithWatermanScores
+        engine = cls(*table, **load.costs, capabilities=gpu)
+        expected = getattr(oracle, load.kind)(queries, candidates, *table, load.costs["open"], load.costs["extend"])
+    got = engine(load.queries, load.candidates, device=gpu)
+    assert np.array_equal(got, expected), load.name
+    assert engine.last_call_profile().cells == load.cells
+
+
+def test_config2_full_size_properties(gpu, oracle):
+    """1,048,576 pairs: too many for the CPU oracle in seconds, so check (a) a random sample of rows exactly,
+    (b) the transposed call gives the transposed matrix, (c) the triangle inequality bounds |len(q) - len(c)| <= d <=
+    max(len), (d) the self-similarity call is symmetric with a zero diagonal."""
+    load = workloads.config(2)
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+    matrix = engine(load.queries, load.candidates, device=gpu)
+    assert matrix.shape == (1024, 1024)
+    rng = np.random.default_rng(0)
+    rows = rng.choice(1024, size=6, replace=False)
+    candidates = [load.candidates[i] for i in range(1024)]
+    expected = oracle.levenshtein([load.queries[int(r)] for r in rows], candidates)
+    assert np.array_equal(matrix[rows], expected)
+    assert np.array_equal(engine(load.candidates, load.queries, device=gpu), matrix.T)
+    q_len, c_len = load.queries.lengths()[:, None], load.candidates.lengths()[None, :]
+    assert (matrix.astype(np.int64) >= np.abs(q_len - c_len)).all() and (matrix.astype(np.int64) <= np.maximum(q_len, c_len)).all()
+    self_matrix = engine(load.queries, device=gpu)
+    assert np.array_equal(self_matrix, self_matrix.T) and not np.diagonal(self_matrix).any()
+    assert engine.last_call_profile().pairs == 1024 * 1025 // 2

@@ -1,0 +1,164 @@
+"""CPU-side checks (`-m "not gpu"`): the C-ABI library loads and exports every declared symbol, the host planner and
+the row sharder behave, stock matrices agree with the golden tables, and everything fails LOUDLY without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import stringzilla_amd as szs
+from stringzilla_amd import _abi, matrices, workloads
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols(header):
+    text = open(os.path.join(ROOT, "include", "stringzillas", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return re.findall(r"SZ_API_RUNTIME\s+[\w\s\*]+?\b(szs?_\w+)\s*\(", text)
+
+
+def test_library_exports_every_declared_symbol():
+    declared = _declared_symbols("stringzillas.h")
+    assert len(declared) == 41, declared  # the reference's 41 (stringzillas.h:36-613)
+    assert sorted(declared) == sorted(_abi.REFERENCE_SYMBOLS)
+    extra = _declared_symbols("stringzillas_rocm.h")
+    assert sorted(extra) == ["szs_rocm_last_call_profile", "szs_rocm_plan_probe", "szs_rocm_shard_rows"]
+    for name in declared + extra:
+        assert hasattr(_abi.lib, name), name
+
+
+def test_version_and_capabilities_without_gpu():
+    assert (szs.__version__) == "5.1.2"
+    comptime = _abi.lib.szs_capabilities_comptime()
+    assert comptime == (_abi.CAP_SERIAL | _abi.CAP_CUDA)
+    runtime = _abi.lib.szs_capabilities_runtime()
+    assert runtime & _abi.CAP_SERIAL
+    assert _abi.lib.szs_capabilities() == (comptime & runtime)
+
+
+def test_struct_layouts_match_the_header():
+    assert ctypes.sizeof(_abi.U32Tape) == 24 and ctypes.sizeof(_abi.U64Tape) == 24 and ctypes.sizeof(_abi.Sequence) == 32
+    assert ctypes.sizeof(_abi.CallProfile) == 64
+
+
+def test_engines_refuse_cpu_capabilities_loudly():
+    """No CPU fallback: a capability mask without the GPU bit is an error, not a silent serial engine."""
+    with pytest.raises(szs.StringZillasError) as failure:
+        szs.LevenshteinDistances(capabilities=("serial",))
+    assert failure.value.status_name == "missing_gpu"
+    table = matrices.blosum62()
+    with pytest.raises(szs.StringZillasError):
+        szs.NeedlemanWunschScores(*table, capabilities=("serial", "parallel"))
+    engine, error = ctypes.c_void_p(), ctypes.c_char_p()
+    status = _abi.lib.szs_fingerprints_init(64, 256, None, 0, 0, None, _abi.CAP_CUDA, ctypes.byref(engine), ctypes.byref(error))
+    assert status == -16 and b"not part of the ROCm build" in error.value
+
+
+def test_scopes():
+    default, cpu = szs.DeviceScope(), szs.DeviceScope(cpu_cores=4)
+    cores, error = ctypes.c_size_t(), ctypes.c_char_p()
+    assert _abi.lib.szs_device_scope_get_cpu_cores(cpu.handle, ctypes.byref(cores), ctypes.byref(error)) == 0
+    assert cores.value == 4
+    assert _abi.lib.szs_device_scope_get_gpu_device(cpu.handle, ctypes.byref(cores), ctypes.byref(error)) != 0
+    assert "serial" in default.capabilities
+    assert (cpu.capabilities_mask & _abi.CAP_CUDA) == 0  # CPU scopes never advertise the GPU engines
+
+
+def test_unified_allocator_entry_points_exist():
+    class Allocator(ctypes.Structure):
+        _fields_ = [("allocate", ctypes.c_void_p), ("free", ctypes.c_void_p), ("handle", ctypes.c_void_p)]
+
+    allocator, error = Allocator(), ctypes.c_char_p()
+    assert _abi.lib.sz_memory_allocator_init_unified(ctypes.byref(allocator), ctypes.byref(error)) == 0
+    assert allocator.allocate and allocator.free
+
+
+def _probe(unit, symmetric, q_lengths, c_lengths):
+    q = np.asarray(q_lengths, dtype=np.uint32)
+    c = np.asarray(c_lengths, dtype=np.uint32)
+    c_order, q_order, q_variant = np.zeros(len(c), np.uint32), np.zeros(len(q), np.uint32), np.zeros(len(q), np.uint32)
+    cells = ctypes.c_uint64()
+    status = _abi.lib.szs_rocm_plan_probe(unit, symmetric, q.ctypes.data, len(q), c.ctypes.data, len(c), c_order.ctypes.data,
+                                          q_order.ctypes.data, q_variant.ctypes.data, ctypes.addressof(cells))
+    assert status == 0
+    return c_order, q_order, q_variant, cells.value
+
+
+def test_planner_sorts_candidates_and_groups_queries():
+    rng = np.random.default_rng(0)
+    q_lengths = rng.integers(0, 3000, size=500)
+    c_lengths = rng.integers(0, 70000, size=700)  # beyond 65535: exercises the comparison-sort path
+    c_order, q_order, q_variant, cells = _probe(1, 0, q_lengths, c_lengths)
+    assert sorted(c_order.tolist()) == list(range(700))
+    sorted_lengths = c_lengths[c_order]
+    assert (np.diff(sorted_lengths) >= 0).all()
+    # stable: equal lengths keep their original order
+    for a, b in zip(c_order[:-1], c_order[1:]):
+        if c_lengths[a] == c_lengths[b]:
+            assert a < b
+    assert sorted(q_order.tolist()) == list(range(500))
+    for position, q in enumerate(q_order):
+        words = max(1, -(-int(q_lengths[q]) // 32))
+        variant = int(q_variant[position])
+        if words > 64:
+            assert variant == 0  # too long for the bit-parallel kernel: weighted kernel
+        else:
+            assert variant >= words and variant in (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 20, 24, 32, 48, 64)
+    variants = q_variant.tolist()
+    nonzero = [v for v in variants if v]
+    assert nonzero == sorted(nonzero) and variants[len(nonzero):] == [0] * (500 - len(nonzero))
+    assert cells == int(q_lengths.sum()) * int(c_lengths.sum())
+
+
+def test_planner_counts_symmetric_cells():
+    lengths = [3, 0, 7, 5]
+    _, _, _, cells = _probe(1, 1, lengths, lengths)
+    assert cells == sum(lengths[i] * lengths[j] for i in range(4) for j in range(i + 1))
+    _, q_order, q_variant, _ = _probe(0, 0, lengths, lengths)  # weighted engines: one group, original order
+    assert q_order.tolist() == [0, 1, 2, 3] and q_variant.tolist() == [0, 0, 0, 0]
+
+
+def test_shard_rows_balances_like_lpt():
+    rng = np.random.default_rng(5)
+    weights = rng.zipf(1.3, size=3163).clip(8, 2048).astype(np.uint64)
+    for shards in (1, 2, 4, 8):
+        assignment, loads = np.zeros(len(weights), np.uint32), np.zeros(shards, np.uint64)
+        status = _abi.lib.szs_rocm_shard_rows(weights.ctypes.data, len(weights), shards, assignment.ctypes.data, loads.ctypes.data)
+        assert status == 0 and assignment.max() < shards
+        recomputed = np.bincount(assignment, weights=weights.astype(np.float64), minlength=shards)
+        assert np.array_equal(recomputed.astype(np.uint64), loads)
+        assert loads.max() - loads.min() <= weights.max()  # LPT: within one (largest) row of perfectly even
+    assert _abi.lib.szs_rocm_shard_rows(weights.ctypes.data, 4, 0, assignment.ctypes.data, None) != 0
+
+
+def test_stock_matrices_match_golden(golden):
+    tables, _ = golden
+    for name in ("blosum62", "nuc44"):
+        byte_to_class, class_costs = matrices.by_name(name)
+        assert byte_to_class.tolist() == tables["tables"][name]["byte_to_class"]
+        assert class_costs.reshape(-1).tolist() == tables["tables"][name]["class_costs"]
+
+
+def test_workloads_are_seeded_and_shaped():
+    a, b = workloads.config(2, scale=1 / 16), workloads.config(2, scale=1 / 16)
+    assert np.array_equal(a.queries.data, b.queries.data) and np.array_equal(a.candidates.offsets, b.candidates.offsets)
+    lengths = a.queries.lengths()
+    assert len(a.queries) == 64 and lengths.min() >= 96 and lengths.max() <= 160
+    assert a.cells == int(lengths.sum()) * int(a.candidates.lengths().sum())
+    zipf = workloads.config(5, scale=1 / 32)
+    z = zipf.queries.lengths()
+    assert z.min() >= 8 and z.max() <= 2048
+    for i in range(len(zipf.queries)):
+        zipf.queries[i].decode("utf-8")  # valid UTF-8 by construction
+
+
+def test_strs_tapes_and_no_cpu_fallback():
+    strs = szs.Strs(["hello", b"\xff\x00", ""])
+    assert len(strs) == 3 and strs[1] == b"\xff\x00" and strs.offsets.tolist() == [0, 5, 7, 7]
+    import torch
+
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            strs.to_device()
