@@ -107,6 +107,15 @@ if not os.path.exists(LIBRARY_PATH):
         "__graft_entry__ as g; g.build()'`). stringzilla_amd has no CPU fallback."
     )
 
+# ONE HIP runtime per process.  PyTorch wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7, the SONAME this
+# library NEEDs).  If torch is imported first, the dynamic linker binds this library to the runtime torch already loaded,
+# so pointers, streams and device state are shared; if this library were loaded first, /opt/rocm's runtime would come in
+# and torch would later load a SECOND one beside it, and then sees no GPU.  Hence: torch first, whenever it is installed.
+try:
+    import torch as _torch  # noqa: F401
+except ImportError:  # C-only deployments: the RUNPATH'd /opt/rocm runtime is used
+    _torch = None
+
 lib = ctypes.CDLL(LIBRARY_PATH)
 for _name, (_restype, _argtypes) in SIGNATURES.items():
     _fn = getattr(lib, _name)  # AttributeError here = the library does not export what the header declares
