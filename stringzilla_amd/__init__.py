@@ -92,7 +92,7 @@ class DeviceScope:
 
     def __del__(self):
         handle = getattr(self, "handle", None)
-        if handle:
+        if handle and lib is not None:  # `lib` is gone when the interpreter is tearing the module down
             lib.szs_device_scope_free(handle)
             self.handle = None
 

@@ -1,0 +1,127 @@
+"""Node-level sharding of one cross-product over N GPUs: one process per GPU, `torch.distributed` (RCCL over xGMI).
+
+The path shards embarrassingly: cells are independent, so query ROWS are dealt to ranks and every
+rank scores `its rows x all candidates` through its own single-GPU engine - the C-ABI stays one device per scope, like
+the reference's (stringzillas.h:137; the reference has no multi-GPU path at all).  The only exchange steps are
+
+  1. replicate the inputs:  broadcast of the candidates tape and of the (small) query tape from the source rank;
+  2. optionally, `gather=True`: all-gather the result row blocks so that every rank holds the full matrix.
+
+Rows are dealt by longest-processing-time on `len(query)` (`szs_rocm_shard_rows`), so ragged batches (config 5: Zipf
+lengths) stay balanced; `last_balance` reports max/mean of the per-rank loads.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from typing import Callable, Optional
+
+import numpy as np
+
+from . import Strs, _abi
+
+
+def shard_rows(lengths: np.ndarray, shards: int):
+    """LPT assignment: returns (shard_of_row[uint32], loads[uint64]); weight of a row = len(query) + 1."""
+    weights = np.ascontiguousarray(lengths, dtype=np.uint64) + np.uint64(1)
+    shard_of_row = np.zeros(len(weights), dtype=np.uint32)
+    loads = np.zeros(shards, dtype=np.uint64)
+    status = _abi.lib.szs_rocm_shard_rows(weights.ctypes.data, len(weights), shards, shard_of_row.ctypes.data, loads.ctypes.data)
+    if status != 0:
+        raise _abi.StringZillasError(status, "szs_rocm_shard_rows failed")
+    return shard_of_row, loads
+
+
+def _select(strs: Strs, rows: np.ndarray) -> Strs:
+    """Sub-tape holding `rows` of `strs`, in that order."""
+    offsets = strs.offsets.astype(np.int64)
+    lengths = offsets[rows + 1] - offsets[rows]
+    new_offsets = np.zeros(len(rows) + 1, dtype=strs.offsets.dtype)
+    np.cumsum(lengths, out=new_offsets[1:])
+    data = np.concatenate([strs.data[offsets[r]:offsets[r + 1]] for r in rows]) if len(rows) and lengths.sum() else np.zeros(1, np.uint8)
+    return Strs.from_tape(data, new_offsets)
+
+
+class ShardedEngine:
+    """Wraps a single-GPU engine (`LevenshteinDistances`, `NeedlemanWunschScores`, ...) for a process group.
+
+    `score(queries, candidates) -> ndarray[rows, columns]` defaults to the engine call on this rank's GPU; tests on a
+    GPU-less box inject a stand-in so that the partition / exchange / reassembly logic runs under `gloo`.
+    """
+
+    def __init__(self, engine=None, scope=None, group=None, score: Optional[Callable] = None):
+        import torch.distributed as dist
+
+        self._dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.engine = engine
+        self.scope = scope
+        if score is None:
+            if engine is None:
+                raise ValueError("ShardedEngine needs an engine (there is no CPU fallback)")
+            score = lambda queries, candidates: engine(queries, candidates, device=scope)
+        self._score = score
+        self.last_balance = 1.0
+        self.last_rows: Optional[np.ndarray] = None
+
+    def _device(self):
+        import torch
+
+        backend = self._dist.get_backend(self.group)
+        if backend == "nccl":  # RCCL: collectives run on device buffers
+            return torch.device("cuda", self.scope.gpu_device if self.scope is not None and self.scope.gpu_device is not None else torch.cuda.current_device())
+        return torch.device("cpu")
+
+    def _broadcast_tape(self, strs: Optional[Strs], source: int) -> Strs:
+        import torch
+
+        device = self._device()
+        header = torch.zeros(3, dtype=torch.int64, device=device)
+        if self.rank == source:
+            header = torch.tensor([strs.data.size, strs.count, int(strs.wide_offsets)], dtype=torch.int64, device=device)
+        self._dist.broadcast(header, source, group=self.group)
+        size, count, wide = (int(x) for x in header.tolist())
+        offset_dtype, torch_offset = (np.uint64, torch.int64) if wide else (np.uint32, torch.int32)
+        if self.rank == source:
+            data = torch.from_numpy(strs.data).to(device)
+            offsets = torch.from_numpy(strs.offsets.view(np.int64 if wide else np.int32)).to(device)
+        else:
+            data = torch.empty(size, dtype=torch.uint8, device=device)
+            offsets = torch.empty(count + 1, dtype=torch_offset, device=device)
+        self._dist.broadcast(data, source, group=self.group)
+        self._dist.broadcast(offsets, source, group=self.group)
+        if self.rank == source:
+            return strs
+        return Strs.from_tape(data.cpu().numpy(), offsets.cpu().numpy().view(offset_dtype))
+
+    def __call__(self, queries: Optional[Strs], candidates: Optional[Strs], source: int = 0, gather: bool = False):
+        """Every rank calls this; only `source` needs to pass the inputs.  Returns (row_indices, local_matrix) - this
+        rank's result rows and which global rows they are - or, with `gather=True`, the full matrix on every rank."""
+        import torch
+
+        queries = self._broadcast_tape(queries, source)
+        candidates = self._broadcast_tape(candidates, source)
+        shard_of_row, loads = shard_rows(queries.lengths(), self.world)
+        self.last_balance = float(loads.max() / max(loads.mean(), 1.0))
+        rows = np.nonzero(shard_of_row == self.rank)[0]
+        self.last_rows = rows
+        local = self._score(_select(queries, rows), candidates) if len(rows) else np.zeros((0, len(candidates)), dtype=np.int64)
+        if not gather:
+            return rows, local
+
+        device = self._device()
+        columns = len(candidates)
+        counts = np.bincount(shard_of_row, minlength=self.world)
+        longest = int(counts.max()) if len(counts) else 0
+        padded = torch.zeros((longest, columns), dtype=torch.int64, device=device)
+        if len(rows):
+            padded[:len(rows)] = torch.from_numpy(np.ascontiguousarray(local).view(np.int64)).to(device)
+        blocks = [torch.empty_like(padded) for _ in range(self.world)]
+        self._dist.all_gather(blocks, padded, group=self.group)
+        full = np.zeros((len(queries), columns), dtype=np.asarray(local).dtype)
+        for rank, block in enumerate(blocks):
+            owned = np.nonzero(shard_of_row == rank)[0]
+            full[owned] = block[:len(owned)].cpu().numpy().view(full.dtype)
+        return full
