@@ -1,0 +1,37 @@
+#!/bin/bash
+# profile_gpu.sh TAG [bench args...] - the measurement recipe behind profiles/rNN/ (run on the GPU box through gpurun).
+#
+#   1. bench.py (the judged line)                                     -> gpurun_out/TAG/bench.json
+#   2. rocprofv3 --kernel-trace --stats of the SAME command            -> gpurun_out/TAG/stats/*kernel_stats.csv
+#   3. PMC passes, each in its own run (the TCC block has 4 slots: FETCH_SIZE takes 3, WRITE_SIZE 2), never mixed with
+#      trace domains other than --kernel-trace                         -> gpurun_out/TAG/pmc_*/
+#   4. scripts/pmc_summary.py folds the PMC csvs into per-kernel averages -> gpurun_out/TAG/pmc_summary.json
+#
+# HBM traffic unit corrections (MI355X_MICROARCH.md, HBM section) are applied by pmc_summary.py, not here.
+set -u
+TAG=${1:-run}; shift || true
+ARGS=("$@")
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+SHORT=(--steps 20 --warmup 5 --no-cpu-baseline)
+
+python "$ROOT/bench.py" "${ARGS[@]}" > "$OUT/bench.json" 2> "$OUT/bench.err" || echo "bench failed" >> "$OUT/bench.err"
+tail -c 3000 "$OUT/bench.json"
+
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- python "$ROOT/bench.py" "${ARGS[@]}" "${SHORT[@]}" > "$OUT/stats.log" 2>&1
+for pass in "FETCH_SIZE" "WRITE_SIZE" \
+            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU" \
+            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE" \
+            "TCC_HIT_sum TCC_MISS_sum"; do
+    name=$(echo "$pass" | awk '{print $1}')
+    rocprofv3 --kernel-trace --output-format csv --pmc $pass -d "$OUT/pmc_$name" -o pmc -- python "$ROOT/bench.py" "${ARGS[@]}" "${SHORT[@]}" > "$OUT/pmc_$name.log" 2>&1 \
+        || echo "pmc pass $name failed (see $OUT/pmc_$name.log)"
+done
+python "$ROOT/scripts/pmc_summary.py" "$OUT" > "$OUT/pmc_summary.json" 2> "$OUT/pmc_summary.err"
+cat "$OUT/pmc_summary.json" | head -c 6000
+# keep the merged-back payload small: the raw per-dispatch traces are large
+find "$OUT" -name "*_kernel_trace.csv" -size +4M -delete
+find "$OUT" -name "*.db" -delete
+du -sh "$OUT"

@@ -31,10 +31,13 @@ typedef struct szs_string_ref_t {
 
 #define SZS_CANDIDATES_PER_WORKGROUP 256u
 #define SZS_MYERS_MAX_WORDS 64u /* 32-bit words: queries up to 2048 bytes take the bit-parallel kernel */
+#define SZS_MYERS_SHORT_WORDS 8u /* queries up to 256 bytes share ONE launch that picks the width per workgroup */
 
 /**
  *  Unit-cost Levenshtein, bit-parallel Myers/Hyyro on 32-bit words with a full-width carry chain.
- *  `words` = ceil(query length / 32) for EVERY query in `queries[0..queries_count)` (0-length queries use 1).
+ *  `words` is a launch variant from szs_hip_levenshtein_myers_round_words(): SZS_MYERS_SHORT_WORDS scores any mix of
+ *  queries of up to 256 bytes (each at its own exact width); a larger value requires ceil(length / 32) <= words for
+ *  EVERY query in `queries[0..queries_count)`.  Queries should arrive longest first (heaviest workgroups first).
  *  Launches ceil(candidates_count / 256) * queries_count workgroups of 256 threads.
  *  symmetric != 0: only cells with candidate.index <= query.index are scored, and mirrored.
  */

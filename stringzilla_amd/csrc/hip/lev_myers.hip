@@ -24,12 +24,21 @@
  *    the step loop runs to the wave's longest text and shorter lanes only stop accumulating their score.
  *  - Results are written straight to results[query.index * stride + candidate.index] (+ mirror when symmetric).
  *
- *  Cost per text byte per lane: 13 VALU per word + ~7 -> ~0.45 VALU/cell at W = 4; LDS: one ds_read_b128 per
- *  four words.  HBM: tapes once + 8 B per result; see DESIGN.md section 5 for the roofline arithmetic.
+ *  - Queries of up to 256 bytes - whatever mix of lengths - are ONE launch: the word count is a per-workgroup scalar
+ *    decision inside `levenshtein_myers_short_kernel`, so a batch straddling several widths pays neither a launch per
+ *    width nor padding to the widest.  Longer queries use one instantiated width per launch.
+ *
+ *  Cost per text byte per lane (ISA count, W = 4): 48 VALU = 10.5 per word + 2 history pushes + LDS addressing, i.e.
+ *  0.38 VALU per DP cell; LDS: one ds_read_b128 per four words.  HBM: tapes once + 8 B per result; see DESIGN.md
+ *  section 5 for the roofline arithmetic and scripts/valu_peak.hip for the measured VALU ceiling of this mix.
  */
 #include "device_common.hpp"
 
 namespace szs_hip {
+
+#ifndef SZS_MYERS_SHORT_TEXT_DWORDS
+#define SZS_MYERS_SHORT_TEXT_DWORDS 4 // text dwords per main-loop iteration of the short-query bodies
+#endif
 
 /** LDS image of Peq for a W-word pattern: 16-byte rows for W >= 3 (ds_read_b128), 8 for W = 2, 4 for W = 1. */
 template <int words_>
@@ -91,23 +100,57 @@ __device__ __forceinline__ void myers_column(u32 (&vp)[words_], u32 (&vn)[words_
     hp_top = hp_below, hn_top = hn_below;
 }
 
+/** Per-lane running state of one (query, candidate) pair between column batches. */
+template <int words_>
+struct myers_state_t {
+    u32 vp[words_], vn[words_];
+    // The score changes by (bit 31 of HP) - (bit 31 of HN) of the top word per column.  Instead of extracting, masking
+    // and adding both bits every column (7 VALU), each column pushes them into two history registers (one
+    // `v_alignbit_b32` each); once per batch the columns that lie inside this lane's text are selected with a mask
+    // and counted with `v_bcnt_u32_b32`, which also accumulates.
+    u32 hp_history, hn_history;
+    u32 increments, decrements; // distance = increments - decrements
+};
+
+/** Advances one lane by `4 * dwords_` text columns whose bytes are packed in `symbols`, first column = `column`. */
+template <int words_, int dwords_>
+__device__ __forceinline__ void myers_advance(u32 const *peq, myers_state_t<words_> &state, u32 const (&symbols)[dwords_],
+                                              u32 column, u32 text_length) {
+    constexpr u32 columns = 4 * dwords_;
+#pragma unroll
+    for (int step = 0; step < (int)columns; ++step) {
+        u32 const symbol = (symbols[step / 4] >> (8 * (step % 4))) & 0xFFu;
+        u32 eq[words_];
+        load_match_masks<words_>(peq, symbol, eq);
+        u32 hp_top, hn_top;
+        myers_column<words_>(state.vp, state.vn, eq, hp_top, hn_top);
+        state.hp_history = __builtin_amdgcn_alignbit(state.hp_history, hp_top, 31); // (history << 1) | (top >> 31)
+        state.hn_history = __builtin_amdgcn_alignbit(state.hn_history, hn_top, 31);
+    }
+    // The first column of this batch sits at bit (columns - 1) of the histories, the last at bit 0; `inside` of them
+    // belong to this lane's text.
+    u32 const remaining = text_length > column ? text_length - column : 0u;
+    u32 const inside = remaining < columns ? remaining : columns;
+    constexpr u32 window = (1u << columns) - 1u;
+    u32 const mask = ((window << columns) >> inside) & window;
+    state.increments += (u32)__builtin_popcount(state.hp_history & mask);
+    state.decrements += (u32)__builtin_popcount(state.hn_history & mask);
+}
+
 /**
- *  @tparam words_        32-bit words of the pattern bit-vector; every query of the launch fits in 32 * words_ bytes.
- *  @tparam text_dwords_  text dwords consumed per loop iteration (4 bytes each): 4 for short patterns, 1 for long ones
- *                        to keep the unrolled body inside the instruction cache.
+ *  One workgroup: one query against 256 candidates, one candidate per lane.
+ *
+ *  @tparam words_        32-bit words of the pattern bit-vector; the query fits in 32 * words_ bytes.
+ *  @tparam text_dwords_  text dwords consumed per main-loop iteration (4 bytes each): 4 for short patterns, 1 for long
+ *                        ones to keep the unrolled body inside the instruction cache.  A 1-dword tail loop finishes the
+ *                        wavefront's longest text, so lock-step waste is under 4 columns.
  */
 template <int words_, int text_dwords_>
-__global__ __launch_bounds__(256) void levenshtein_myers_kernel(szs_string_ref_t const *__restrict__ queries,
-                                                                 szs_string_ref_t const *__restrict__ candidates,
-                                                                 u32 candidates_count, u32 candidate_blocks,
-                                                                 u64 *__restrict__ results, u64 results_row_stride,
-                                                                 int symmetric) {
+__device__ __forceinline__ void myers_workgroup(u32 *peq, szs_string_ref_t const query,
+                                                szs_string_ref_t const *__restrict__ candidates, u32 candidates_count,
+                                                u32 candidate_block, u64 *__restrict__ results, u64 results_row_stride,
+                                                int symmetric) {
     using layout = peq_layout<words_>;
-    __shared__ __attribute__((aligned(16))) u32 peq[layout::total_dwords];
-
-    u32 const query_slot = blockIdx.x / candidate_blocks;
-    u32 const candidate_block = blockIdx.x % candidate_blocks;
-    szs_string_ref_t const query = queries[query_slot];
     u32 const query_length = query.length;
     u32 const pad = 32u * words_ - query_length; // phantom low rows
 
@@ -132,62 +175,123 @@ __global__ __launch_bounds__(256) void levenshtein_myers_kernel(szs_string_ref_t
     u32 const text_length = live ? candidate.length : 0;
     u32 const longest_in_wave = wave_max_u32(text_length);
 
-    u32 vp[words_], vn[words_];
+    myers_state_t<words_> state;
 #pragma unroll
     for (int w = 0; w < words_; ++w) {
         u32 const first_bit = 32u * w;
-        vp[w] = first_bit >= pad ? ~0u : (first_bit + 32u <= pad ? 0u : (~0u << (pad - first_bit)));
-        vn[w] = 0;
+        state.vp[w] = first_bit >= pad ? ~0u : (first_bit + 32u <= pad ? 0u : (~0u << (pad - first_bit)));
+        state.vn[w] = 0;
     }
-    u32 distance = query_length;
+    state.hp_history = state.hn_history = 0;
+    state.increments = query_length, state.decrements = 0;
 
+    // `raw_low` is text dword `dword`; `ahead[d]` is text dword `dword + 1 + d`, loaded one iteration early.
     text_stream_t const text(candidate.address, text_length);
     u32 raw_low = text.raw(0);
-    u32 raw_next[text_dwords_];
+    u32 ahead[text_dwords_];
 #pragma unroll
-    for (int d = 0; d < text_dwords_; ++d) raw_next[d] = text.raw(1 + d);
+    for (int d = 0; d < text_dwords_; ++d) ahead[d] = text.raw(1 + d);
 
-    for (u32 column = 0, dword = 0; column < longest_in_wave; column += 4 * text_dwords_, dword += text_dwords_) {
+    constexpr u32 columns_per_iteration = 4 * text_dwords_;
+    u32 column = 0, dword = 0;
+    for (; column + columns_per_iteration <= longest_in_wave; column += columns_per_iteration, dword += text_dwords_) {
         u32 symbols[text_dwords_];
-        symbols[0] = text.splice(raw_low, raw_next[0]);
+        symbols[0] = text.splice(raw_low, ahead[0]);
 #pragma unroll
-        for (int d = 1; d < text_dwords_; ++d) symbols[d] = text.splice(raw_next[d - 1], raw_next[d]);
-        raw_low = raw_next[text_dwords_ - 1];
+        for (int d = 1; d < text_dwords_; ++d) symbols[d] = text.splice(ahead[d - 1], ahead[d]);
+        raw_low = ahead[text_dwords_ - 1];
         // Issue the next iteration's loads now; they retire under the VALU work below.
 #pragma unroll
-        for (int d = 0; d < text_dwords_; ++d) raw_next[d] = text.raw(dword + text_dwords_ + 1 + d);
-
+        for (int d = 0; d < text_dwords_; ++d) ahead[d] = text.raw(dword + text_dwords_ + 1 + d);
+        myers_advance<words_, text_dwords_>(peq, state, symbols, column, text_length);
+    }
+    // Tail: fewer than `columns_per_iteration` columns are left, all of their dwords are already in `ahead`.
+#pragma unroll 1
+    for (int d = 0; column < longest_in_wave; column += 4, ++d) {
+        u32 next = 0;
 #pragma unroll
-        for (int step = 0; step < 4 * text_dwords_; ++step) {
-            u32 const symbol = (symbols[step / 4] >> (8 * (step % 4))) & 0xFFu;
-            u32 eq[words_];
-            load_match_masks<words_>(peq, symbol, eq);
-            u32 hp_top, hn_top;
-            myers_column<words_>(vp, vn, eq, hp_top, hn_top);
-            u32 const delta = (hp_top >> 31) - (hn_top >> 31);
-            distance += column + step < text_length ? delta : 0u;
-        }
+        for (int k = 0; k < text_dwords_; ++k) next = d == k ? ahead[k] : next;
+        u32 const symbols[1] = {text.splice(raw_low, next)};
+        raw_low = next;
+        myers_advance<words_, 1>(peq, state, symbols, column, text_length);
     }
 
     if (live) {
+        u32 const distance = state.increments - state.decrements;
         results[(u64)query.index * results_row_stride + candidate.index] = distance;
         if (symmetric && candidate.index != query.index)
             results[(u64)candidate.index * results_row_stride + query.index] = distance;
     }
 }
 
+/** Workgroup -> (query, candidate block).  Queries arrive longest first and candidates ascending, so walking the
+ *  candidate blocks backwards hands out the heaviest work first and the launch ends on its lightest workgroups. */
+__device__ __forceinline__ void myers_work_item(u32 candidate_blocks, u32 &query_slot, u32 &candidate_block) {
+    query_slot = blockIdx.x / candidate_blocks;
+    candidate_block = candidate_blocks - 1 - blockIdx.x % candidate_blocks;
+}
+
+/** Long queries (more than 8 words): every query of the launch uses the same instantiated width. */
 template <int words_>
-static int launch_myers(szs_string_ref_t const *queries, u32 queries_count, szs_string_ref_t const *candidates,
-                        u32 candidates_count, u64 *results, u64 stride, int symmetric, hipStream_t stream) {
-    constexpr int text_dwords = words_ <= 8 ? 4 : 1;
+__global__ __launch_bounds__(256) void levenshtein_myers_long_kernel(szs_string_ref_t const *__restrict__ queries,
+                                                                      szs_string_ref_t const *__restrict__ candidates,
+                                                                      u32 candidates_count, u32 candidate_blocks,
+                                                                      u64 *__restrict__ results, u64 results_row_stride,
+                                                                      int symmetric) {
+    __shared__ __attribute__((aligned(16))) u32 peq[peq_layout<words_>::total_dwords];
+    u32 query_slot, candidate_block;
+    myers_work_item(candidate_blocks, query_slot, candidate_block);
+    myers_workgroup<words_, 1>(peq, queries[query_slot], candidates, candidates_count, candidate_block, results,
+                               results_row_stride, symmetric);
+}
+
+/**
+ *  Short queries (up to 256 bytes = 8 words), ANY mix of lengths in ONE launch: the width is a per-workgroup (scalar)
+ *  decision, so every query runs at exactly ceil(length / 32) words, and a batch whose queries straddle several widths
+ *  needs neither one launch per width nor padding to a common width.  All eight bodies fit the 64-VGPR budget.
+ */
+__global__ __launch_bounds__(256) void levenshtein_myers_short_kernel(szs_string_ref_t const *__restrict__ queries,
+                                                                       szs_string_ref_t const *__restrict__ candidates,
+                                                                       u32 candidates_count, u32 candidate_blocks,
+                                                                       u64 *__restrict__ results, u64 results_row_stride,
+                                                                       int symmetric) {
+    __shared__ __attribute__((aligned(16))) u32 peq[peq_layout<8>::total_dwords];
+    u32 query_slot, candidate_block;
+    myers_work_item(candidate_blocks, query_slot, candidate_block);
+    szs_string_ref_t const query = queries[query_slot];
+    u32 const words = __builtin_amdgcn_readfirstlane(query.length ? (query.length + 31u) / 32u : 1u);
+#define SZS_MYERS_BODY(W)                                                                                              \
+    case W:                                                                                                            \
+        myers_workgroup<W, SZS_MYERS_SHORT_TEXT_DWORDS>(peq, query, candidates, candidates_count, candidate_block,    \
+                                                        results, results_row_stride, symmetric);                      \
+        break;
+    switch (words) {
+        SZS_MYERS_BODY(1)
+        SZS_MYERS_BODY(2)
+        SZS_MYERS_BODY(3)
+        SZS_MYERS_BODY(4)
+        SZS_MYERS_BODY(5)
+        SZS_MYERS_BODY(6)
+        SZS_MYERS_BODY(7)
+    default: // 8; the host never sends longer queries here
+        myers_workgroup<8, SZS_MYERS_SHORT_TEXT_DWORDS>(peq, query, candidates, candidates_count, candidate_block, results,
+                                                        results_row_stride, symmetric);
+        break;
+    }
+#undef SZS_MYERS_BODY
+}
+
+template <typename kernel_t>
+static int launch_myers(kernel_t kernel, szs_string_ref_t const *queries, u32 queries_count,
+                        szs_string_ref_t const *candidates, u32 candidates_count, u64 *results, u64 stride, int symmetric,
+                        hipStream_t stream) {
     u32 const candidate_blocks = (candidates_count + SZS_CANDIDATES_PER_WORKGROUP - 1) / SZS_CANDIDATES_PER_WORKGROUP;
     // Keep each grid under 2^30 workgroups; enormous cross-products are cut along the query axis.
     u32 const queries_per_launch = candidate_blocks ? (1u << 30) / candidate_blocks : queries_count;
     for (u32 first = 0; first < queries_count; first += queries_per_launch) {
         u32 const batch = queries_count - first < queries_per_launch ? queries_count - first : queries_per_launch;
-        hipLaunchKernelGGL((levenshtein_myers_kernel<words_, text_dwords>), dim3(batch * candidate_blocks), dim3(256), 0,
-                           stream, queries + first, candidates, candidates_count, candidate_blocks, results, stride,
-                           symmetric);
+        hipLaunchKernelGGL(kernel, dim3(batch * candidate_blocks), dim3(256), 0, stream, queries + first, candidates,
+                           candidates_count, candidate_blocks, results, stride, symmetric);
         hipError_t const error = hipGetLastError();
         if (error != hipSuccess) return (int)error;
     }
@@ -203,16 +307,13 @@ extern "C" int szs_hip_levenshtein_myers(unsigned words, szs_string_ref_t const 
     if (!queries_count || !candidates_count) return 0;
     hipStream_t const s = static_cast<hipStream_t>(stream);
 #define SZS_MYERS_CASE(W)                                                                                              \
-    case W: return launch_myers<W>(queries, queries_count, candidates, candidates_count, results, results_row_stride, symmetric, s);
+    case W:                                                                                                            \
+        return launch_myers(levenshtein_myers_long_kernel<W>, queries, queries_count, candidates, candidates_count,   \
+                            results, results_row_stride, symmetric, s);
     switch (words) {
-        SZS_MYERS_CASE(1)
-        SZS_MYERS_CASE(2)
-        SZS_MYERS_CASE(3)
-        SZS_MYERS_CASE(4)
-        SZS_MYERS_CASE(5)
-        SZS_MYERS_CASE(6)
-        SZS_MYERS_CASE(7)
-        SZS_MYERS_CASE(8)
+    case SZS_MYERS_SHORT_WORDS:
+        return launch_myers(levenshtein_myers_short_kernel, queries, queries_count, candidates, candidates_count, results,
+                            results_row_stride, symmetric, s);
         SZS_MYERS_CASE(10)
         SZS_MYERS_CASE(12)
         SZS_MYERS_CASE(16)
@@ -226,10 +327,11 @@ extern "C" int szs_hip_levenshtein_myers(unsigned words, szs_string_ref_t const 
 #undef SZS_MYERS_CASE
 }
 
-/** The word counts the launcher has instances for, ascending; the host rounds each query up to the next one. */
+/** The launch variant for a query of `words` 32-bit words: SZS_MYERS_SHORT_WORDS for everything the mixed-width kernel
+ *  takes, else the next instantiated long width; 0 = too long for the bit-parallel kernels. */
 extern "C" unsigned szs_hip_levenshtein_myers_round_words(unsigned words) {
-    static unsigned const steps[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 20, 24, 32, 48, 64};
+    static unsigned const steps[] = {SZS_MYERS_SHORT_WORDS, 10, 12, 16, 20, 24, 32, 48, 64};
     for (unsigned i = 0; i < sizeof(steps) / sizeof(steps[0]); ++i)
         if (words <= steps[i]) return steps[i];
-    return 0; /* too long for the bit-parallel kernel */
+    return 0;
 }

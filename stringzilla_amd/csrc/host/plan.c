@@ -79,7 +79,10 @@ void szs_plan_build(int myers, int symmetric, uint64_t const *query_addresses, u
         candidate_refs[slot].index = c;
     }
 
-    /* Queries: grouped by variant, ascending; variant 0 (weighted kernel) goes last for Myers plans. */
+    /* Queries: LONGEST FIRST.  The launch variant is monotone in the length, so descending order makes every variant a
+     * contiguous slice - first the queries too long for the bit-parallel kernels (variant 0, weighted kernel), then the
+     * long widths from the widest down, last the one mixed-width launch of all short queries - and within a launch the
+     * heaviest workgroups are handed out first, so a launch drains on its lightest work. */
     if (!myers) {
         for (uint32_t q = 0; q < queries_count; ++q) {
             query_refs[q].address = query_addresses[q];
@@ -92,29 +95,19 @@ void szs_plan_build(int myers, int symmetric, uint64_t const *query_addresses, u
         }
         return;
     }
-    uint32_t histogram[SZS_MYERS_MAX_WORDS + 2];
-    memset(histogram, 0, sizeof(histogram));
-    for (uint32_t q = 0; q < queries_count; ++q) {
-        unsigned const variant = myers_variant(query_lengths[q]);
-        histogram[variant ? variant : SZS_MYERS_MAX_WORDS + 1]++;
-    }
-    uint32_t starts[SZS_MYERS_MAX_WORDS + 2];
-    uint32_t running = 0;
-    for (unsigned v = 1; v <= SZS_MYERS_MAX_WORDS + 1; ++v) {
-        starts[v] = running;
-        if (histogram[v]) {
-            szs_plan_group_t *group = &plan->groups[plan->groups_count++];
-            group->variant = v <= SZS_MYERS_MAX_WORDS ? v : 0;
-            group->first = running, group->count = histogram[v];
-        }
-        running += histogram[v];
-    }
-    for (uint32_t q = 0; q < queries_count; ++q) {
-        unsigned const variant = myers_variant(query_lengths[q]);
-        uint32_t const slot = starts[variant ? variant : SZS_MYERS_MAX_WORDS + 1]++;
+    sort_by_length(query_lengths, queries_count, plan->longest_query, keys);
+    for (uint32_t slot = 0; slot < queries_count; ++slot) {
+        uint32_t const q = keys[queries_count - 1 - slot]; /* ascending order read backwards */
         query_refs[slot].address = query_addresses[q];
         query_refs[slot].length = query_lengths[q];
         query_refs[slot].index = q;
+        unsigned const variant = myers_variant(query_lengths[q]);
+        szs_plan_group_t *group = plan->groups_count ? &plan->groups[plan->groups_count - 1] : NULL;
+        if (!group || group->variant != variant) {
+            group = &plan->groups[plan->groups_count++];
+            group->variant = variant, group->first = slot, group->count = 0;
+        }
+        group->count++;
     }
 }
 

@@ -101,8 +101,9 @@ def test_levenshtein_fuzz(gpu, oracle, costs):
 
 
 def test_levenshtein_every_kernel_width(gpu, oracle):
-    """One query per instantiated bit-parallel kernel (1..64 words), plus queries beyond 2048 bytes that fall through to
-    the weighted kernel - all in ONE call, so the planner's grouping is exercised too."""
+    """Queries at both edges of every bit-parallel width (1..8 words inside the mixed-width short kernel, then each
+    instantiated long width up to 64 words), plus queries beyond 2048 bytes that fall through to the weighted kernel -
+    all in ONE call, so the planner's grouping is exercised too: 1 short + 8 long + 1 weighted launch."""
     rng = random.Random(77)
     edges = [0, 1, 31, 32, 33, 64, 65, 96, 97, 128, 129, 160, 161, 192, 224, 225, 256, 257, 320, 321, 384, 385, 512, 513,
              640, 768, 769, 1024, 1025, 1536, 1537, 2048, 2049, 2500]
@@ -112,7 +113,8 @@ def test_levenshtein_every_kernel_width(gpu, oracle):
     got = engine(queries, candidates, device=gpu)
     assert np.array_equal(got, oracle.levenshtein(queries, candidates))
     profile = engine.last_call_profile()
-    assert profile.launches >= 16 and profile.cells == sum(map(len, queries)) * sum(map(len, candidates))
+    assert profile.launches == 10, profile.launches
+    assert profile.cells == sum(map(len, queries)) * sum(map(len, candidates))
 
 
 @pytest.mark.parametrize("kind", ["needleman_wunsch", "smith_waterman"])
