@@ -16,12 +16,13 @@
  *    The reference's CPU form is block-based with explicit HP/HN carries between 64-bit blocks (serial.hpp:2182-2204);
  *    the full-width form computes the same column of the DP matrix, hence the same distance (tests pin this).
  *  - The pattern is RIGHT-aligned in its W words: position i sits at bit (32 W - len + i).  The `pad` low bits are
- *    phantom rows initialised VP = VN = Eq = 0; they stay inert (HP = 1, HN = 0 forever) and hand the `+1 per column`
- *    top-row boundary into the first real bit through the ordinary shift.  The score bit is then ALWAYS bit 31 of
- *    the top word - no per-query variable shift in the inner loop - and one kernel instance serves every query
- *    whose length fits in W words (a zero-length query degenerates to `distance = candidate length` by itself).
- *  - Candidates are length-sorted by the host, so the 64 lanes of a wave finish within a few steps of each other;
- *    the step loop runs to the wave's longest text and shorter lanes only stop accumulating their score.
+ *    phantom rows initialised VP = VN = Eq = 0; they stay inert (HP = 1, HN = 0, VP = VN = 0 forever) and hand the
+ *    `+1 per column` top-row boundary into the first real bit through the ordinary shift.  One kernel body serves every
+ *    query whose length fits in W words (a zero-length query degenerates to `distance = candidate length` by itself).
+ *  - No per-column score tracking: when a lane has consumed its text, distance = len(text) + popcount(VP) - popcount(VN)
+ *    (row deltas telescope; phantom rows contribute nothing).  Lanes that finish before their wavefront's longest text
+ *    are frozen by the EXEC mask.  Candidates are length-sorted by the host, so the 64 lanes of a wave finish within
+ *    a few columns of each other and the predicated part of the loop is short.
  *  - Results are written straight to results[query.index * stride + candidate.index] (+ mirror when symmetric).
  *
  *  - Queries of up to 256 bytes - whatever mix of lengths - are ONE launch: the word count is a per-workgroup scalar
@@ -73,13 +74,9 @@ __device__ __forceinline__ void load_match_masks(u32 const *peq, u32 symbol, u32
     else { eq[0] = peq[symbol]; }
 }
 
-/**
- *  One column of the DP matrix: consumes the match masks of one text byte, updates the vertical delta vectors and
- *  returns the pre-shift horizontal deltas of the TOP word (bit 31 = the last pattern row).
- */
+/** One column of the DP matrix: consumes the match masks of one text byte and updates the vertical delta vectors. */
 template <int words_>
-__device__ __forceinline__ void myers_column(u32 (&vp)[words_], u32 (&vn)[words_], u32 const (&eq)[words_], u32 &hp_top,
-                                             u32 &hn_top) {
+__device__ __forceinline__ void myers_column(u32 (&vp)[words_], u32 (&vn)[words_], u32 const (&eq)[words_]) {
     u32 carry = 0, hp_below = 0, hn_below = 0;
 #pragma unroll
     for (int w = 0; w < words_; ++w) {
@@ -97,53 +94,36 @@ __device__ __forceinline__ void myers_column(u32 (&vp)[words_], u32 (&vn)[words_
         vp[w] = hn_shifted | ~(xv | hp_shifted);
         vn[w] = hp_shifted & xv;
     }
-    hp_top = hp_below, hn_top = hn_below;
 }
 
-/** Per-lane running state of one (query, candidate) pair between column batches. */
-template <int words_>
-struct myers_state_t {
-    u32 vp[words_], vn[words_];
-    // The score changes by (bit 31 of HP) - (bit 31 of HN) of the top word per column.  Instead of extracting, masking
-    // and adding both bits every column (7 VALU), each column pushes them into two history registers (one
-    // `v_alignbit_b32` each); once per batch the columns that lie inside this lane's text are selected with a mask
-    // and counted with `v_bcnt_u32_b32`, which also accumulates.
-    u32 hp_history, hn_history;
-    u32 increments, decrements; // distance = increments - decrements
-};
-
-/** Advances one lane by `4 * dwords_` text columns whose bytes are packed in `symbols`, first column = `column`. */
+/** Advances one lane by `4 * dwords_` text columns whose bytes are packed in `symbols`; every lane takes every column. */
 template <int words_, int dwords_>
-__device__ __forceinline__ void myers_advance(u32 const *peq, myers_state_t<words_> &state, u32 const (&symbols)[dwords_],
-                                              u32 column, u32 text_length) {
-    constexpr u32 columns = 4 * dwords_;
+__device__ __forceinline__ void myers_advance(u32 const *peq, u32 (&vp)[words_], u32 (&vn)[words_],
+                                              u32 const (&symbols)[dwords_]) {
 #pragma unroll
-    for (int step = 0; step < (int)columns; ++step) {
+    for (int step = 0; step < 4 * dwords_; ++step) {
         u32 const symbol = (symbols[step / 4] >> (8 * (step % 4))) & 0xFFu;
         u32 eq[words_];
         load_match_masks<words_>(peq, symbol, eq);
-        u32 hp_top, hn_top;
-        myers_column<words_>(state.vp, state.vn, eq, hp_top, hn_top);
-        state.hp_history = __builtin_amdgcn_alignbit(state.hp_history, hp_top, 31); // (history << 1) | (top >> 31)
-        state.hn_history = __builtin_amdgcn_alignbit(state.hn_history, hn_top, 31);
+        myers_column<words_>(vp, vn, eq);
     }
-    // The first column of this batch sits at bit (columns - 1) of the histories, the last at bit 0; `inside` of them
-    // belong to this lane's text.
-    u32 const remaining = text_length > column ? text_length - column : 0u;
-    u32 const inside = remaining < columns ? remaining : columns;
-    constexpr u32 window = (1u << columns) - 1u;
-    u32 const mask = ((window << columns) >> inside) & window;
-    state.increments += (u32)__builtin_popcount(state.hp_history & mask);
-    state.decrements += (u32)__builtin_popcount(state.hn_history & mask);
 }
 
 /**
  *  One workgroup: one query against 256 candidates, one candidate per lane.
  *
+ *  The distance is never accumulated column by column.  Row deltas telescope: D[m][j] = D[0][j] + sum_i (VP_i - VN_i),
+ *  so once a lane has consumed its whole text, distance = text length + popcount(VP) - popcount(VN) (phantom rows hold
+ *  VP = VN = 0 and drop out).  A lane whose text has ended must therefore FREEZE its state while longer texts of the
+ *  same wavefront go on - which is what the EXEC mask does for free:
+ *    - main loop: all 64 lanes still have a full batch of columns left -> no predication, no per-column bookkeeping;
+ *    - ragged tail (from the wavefront's shortest text to its longest): every column is predicated on
+ *      `column < text length`, finished lanes are simply masked off.
+ *  Candidates arrive length-sorted, so the ragged tail is a handful of columns unless the batch itself is ragged.
+ *
  *  @tparam words_        32-bit words of the pattern bit-vector; the query fits in 32 * words_ bytes.
  *  @tparam text_dwords_  text dwords consumed per main-loop iteration (4 bytes each): 4 for short patterns, 1 for long
- *                        ones to keep the unrolled body inside the instruction cache.  A 1-dword tail loop finishes the
- *                        wavefront's longest text, so lock-step waste is under 4 columns.
+ *                        ones to keep the unrolled body inside the instruction cache.
  */
 template <int words_, int text_dwords_>
 __device__ __forceinline__ void myers_workgroup(u32 *peq, szs_string_ref_t const query,
@@ -174,50 +154,60 @@ __device__ __forceinline__ void myers_workgroup(u32 *peq, szs_string_ref_t const
     if (symmetric && candidate.index > query.index) live = false; // upper triangle: mirrored from below
     u32 const text_length = live ? candidate.length : 0;
     u32 const longest_in_wave = wave_max_u32(text_length);
+    u32 const shortest_in_wave = ~wave_max_u32(live ? ~text_length : 0u); // over live lanes; no live lane: ~0, unused
 
-    myers_state_t<words_> state;
+    u32 vp[words_], vn[words_];
 #pragma unroll
     for (int w = 0; w < words_; ++w) {
         u32 const first_bit = 32u * w;
-        state.vp[w] = first_bit >= pad ? ~0u : (first_bit + 32u <= pad ? 0u : (~0u << (pad - first_bit)));
-        state.vn[w] = 0;
+        vp[w] = first_bit >= pad ? ~0u : (first_bit + 32u <= pad ? 0u : (~0u << (pad - first_bit)));
+        vn[w] = 0;
     }
-    state.hp_history = state.hn_history = 0;
-    state.increments = query_length, state.decrements = 0;
 
     // `raw_low` is text dword `dword`; `ahead[d]` is text dword `dword + 1 + d`, loaded one iteration early.
     text_stream_t const text(candidate.address, text_length);
     u32 raw_low = text.raw(0);
-    u32 ahead[text_dwords_];
-#pragma unroll
-    for (int d = 0; d < text_dwords_; ++d) ahead[d] = text.raw(1 + d);
-
-    constexpr u32 columns_per_iteration = 4 * text_dwords_;
     u32 column = 0, dword = 0;
-    for (; column + columns_per_iteration <= longest_in_wave; column += columns_per_iteration, dword += text_dwords_) {
-        u32 symbols[text_dwords_];
-        symbols[0] = text.splice(raw_low, ahead[0]);
+    constexpr u32 columns_per_iteration = 4 * text_dwords_;
+    if (columns_per_iteration <= shortest_in_wave && longest_in_wave) {
+        u32 ahead[text_dwords_];
 #pragma unroll
-        for (int d = 1; d < text_dwords_; ++d) symbols[d] = text.splice(ahead[d - 1], ahead[d]);
-        raw_low = ahead[text_dwords_ - 1];
-        // Issue the next iteration's loads now; they retire under the VALU work below.
+        for (int d = 0; d < text_dwords_; ++d) ahead[d] = text.raw(1 + d);
+        for (; column + columns_per_iteration <= shortest_in_wave; column += columns_per_iteration, dword += text_dwords_) {
+            u32 symbols[text_dwords_];
+            symbols[0] = text.splice(raw_low, ahead[0]);
 #pragma unroll
-        for (int d = 0; d < text_dwords_; ++d) ahead[d] = text.raw(dword + text_dwords_ + 1 + d);
-        myers_advance<words_, text_dwords_>(peq, state, symbols, column, text_length);
+            for (int d = 1; d < text_dwords_; ++d) symbols[d] = text.splice(ahead[d - 1], ahead[d]);
+            raw_low = ahead[text_dwords_ - 1];
+            // Issue the next iteration's loads now; they retire under the VALU work below.
+#pragma unroll
+            for (int d = 0; d < text_dwords_; ++d) ahead[d] = text.raw(dword + text_dwords_ + 1 + d);
+            myers_advance<words_, text_dwords_>(peq, vp, vn, symbols);
+        }
     }
-    // Tail: fewer than `columns_per_iteration` columns are left, all of their dwords are already in `ahead`.
+    // ---- ragged tail: one dword (4 columns) per iteration, each column predicated on this lane's own length.
+    if (column < longest_in_wave) {
+        u32 next = text.raw(dword + 1);
 #pragma unroll 1
-    for (int d = 0; column < longest_in_wave; column += 4, ++d) {
-        u32 next = 0;
+        for (; column < longest_in_wave; column += 4, ++dword) {
+            u32 const after = text.raw(dword + 2);
+            u32 const symbols = text.splice(raw_low, next);
+            raw_low = next, next = after;
 #pragma unroll
-        for (int k = 0; k < text_dwords_; ++k) next = d == k ? ahead[k] : next;
-        u32 const symbols[1] = {text.splice(raw_low, next)};
-        raw_low = next;
-        myers_advance<words_, 1>(peq, state, symbols, column, text_length);
+            for (int step = 0; step < 4; ++step) {
+                if (column + step < text_length) {
+                    u32 eq[words_];
+                    load_match_masks<words_>(peq, (symbols >> (8 * step)) & 0xFFu, eq);
+                    myers_column<words_>(vp, vn, eq);
+                }
+            }
+        }
     }
 
     if (live) {
-        u32 const distance = state.increments - state.decrements;
+        u32 distance = text_length;
+#pragma unroll
+        for (int w = 0; w < words_; ++w) distance += (u32)__builtin_popcount(vp[w]) - (u32)__builtin_popcount(vn[w]);
         results[(u64)query.index * results_row_stride + candidate.index] = distance;
         if (symmetric && candidate.index != query.index)
             results[(u64)candidate.index * results_row_stride + query.index] = distance;
@@ -250,7 +240,10 @@ __global__ __launch_bounds__(256) void levenshtein_myers_long_kernel(szs_string_
  *  decision, so every query runs at exactly ceil(length / 32) words, and a batch whose queries straddle several widths
  *  needs neither one launch per width nor padding to a common width.  All eight bodies fit the 64-VGPR budget.
  */
-__global__ __launch_bounds__(256) void levenshtein_myers_short_kernel(szs_string_ref_t const *__restrict__ queries,
+#ifndef SZS_MYERS_SHORT_WAVES
+#define SZS_MYERS_SHORT_WAVES 1
+#endif
+__global__ __launch_bounds__(256, SZS_MYERS_SHORT_WAVES) void levenshtein_myers_short_kernel(szs_string_ref_t const *__restrict__ queries,
                                                                        szs_string_ref_t const *__restrict__ candidates,
                                                                        u32 candidates_count, u32 candidate_blocks,
                                                                        u64 *__restrict__ results, u64 results_row_stride,
