@@ -43,11 +43,31 @@ static pointer_traits_t classify_pointer(void const *pointer) {
 }
 
 /**
- *  Produces absolute addresses and 32-bit lengths for every string of one side.
- *  Tapes whose offsets live in device-only memory are downloaded through the pinned staging area first.
+ *  Tapes whose offsets live in device-only memory must be read by the host planner: this ENQUEUES their download into
+ *  the pinned staging area (no synchronisation - the caller waits once for both sides) and returns where the host will
+ *  find the offsets; host-readable offsets are returned as they are.  `*pending` is set when a copy was enqueued.
  */
-static sz_status_t gather_strings(szs_engine_s *engine, int device, hipStream_t stream, szs_input_t const *input,
-                                  size_t staging_offset, uint64_t *addresses, uint32_t *lengths,
+static sz_status_t prefetch_offsets(szs_engine_s *engine, hipStream_t stream, szs_input_t const *input,
+                                    size_t staging_offset, void const **host_offsets, int *pending,
+                                    char const **error_message) {
+    *host_offsets = input->offsets;
+    if (input->kind == szs_input_sequence_k) return sz_success_k;
+    if (!input->offsets) return szs_report(sz_status_unknown_k, error_message, "Tape offsets must not be null");
+    if (classify_pointer(input->offsets).host_readable) return sz_success_k;
+    size_t const offset_size = input->kind == szs_input_u32tape_k ? 4 : 8;
+    void *landing = (char *)engine->pinned_staging.pointer + staging_offset;
+    hipError_t const error = hipMemcpyAsync(landing, input->offsets, (input->count + 1) * offset_size,
+                                            hipMemcpyDeviceToHost, stream);
+    if (error != hipSuccess) return szs_report_hip(error, error_message);
+    *host_offsets = landing, *pending = 1;
+    return sz_success_k;
+}
+
+/**
+ *  Produces absolute addresses and 32-bit lengths for every string of one side, from a callback sequence or from a
+ *  tape whose offsets are readable at `offsets` (see prefetch_offsets).
+ */
+static sz_status_t gather_strings(szs_input_t const *input, void const *offsets, uint64_t *addresses, uint32_t *lengths,
                                   uint64_t *total_bytes, char const **error_message) {
     size_t const count = input->count;
     *total_bytes = 0;
@@ -70,17 +90,6 @@ static sz_status_t gather_strings(szs_engine_s *engine, int device, hipStream_t 
     }
 
     size_t const offset_size = input->kind == szs_input_u32tape_k ? 4 : 8;
-    void const *offsets = input->offsets;
-    if (!offsets) return szs_report(sz_status_unknown_k, error_message, "Tape offsets must not be null");
-    if (!classify_pointer(offsets).host_readable) {
-        size_t const bytes = (count + 1) * offset_size;
-        void *landing = (char *)engine->pinned_staging.pointer + staging_offset;
-        hipError_t error = hipMemcpyAsync(landing, offsets, bytes, hipMemcpyDeviceToHost, stream);
-        if (error == hipSuccess) error = hipStreamSynchronize(stream);
-        if (error != hipSuccess) return szs_report_hip(error, error_message);
-        offsets = landing;
-    }
-    (void)device;
     uint64_t const base = (uint64_t)(uintptr_t)input->data;
     if (offset_size == 4) {
         uint32_t const *o = (uint32_t const *)offsets;
@@ -207,8 +216,23 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
     status = szs_buffer_reserve(&engine->device_refs, szs_memory_device_k, device, refs_bytes, error_message);
     if (status != sz_success_k) return status;
 
+    /* Offsets in device-only memory: both downloads are enqueued back to back and waited for ONCE. */
+    void const *q_offsets = NULL, *c_offsets = NULL;
+    int downloads_pending = 0;
+    status = prefetch_offsets(engine, stream, queries, refs_bytes, &q_offsets, &downloads_pending, error_message);
+    if (status != sz_success_k) return status;
+    if (!symmetric) {
+        status = prefetch_offsets(engine, stream, candidates, refs_bytes + ((size_t)q_count + 1) * sizeof(uint64_t),
+                                  &c_offsets, &downloads_pending, error_message);
+        if (status != sz_success_k) return status;
+    }
+    if (downloads_pending) {
+        hipError_t const error = hipStreamSynchronize(stream);
+        if (error != hipSuccess) return szs_report_hip(error, error_message);
+    }
+
     uint64_t query_bytes = 0, candidate_bytes = 0;
-    status = gather_strings(engine, device, stream, queries, refs_bytes, q_addresses, q_lengths, &query_bytes, error_message);
+    status = gather_strings(queries, q_offsets, q_addresses, q_lengths, &query_bytes, error_message);
     if (status != sz_success_k) return status;
     if (symmetric) {
         memcpy(c_addresses, q_addresses, (size_t)q_count * sizeof(uint64_t));
@@ -216,8 +240,7 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
         candidate_bytes = query_bytes;
     }
     else {
-        status = gather_strings(engine, device, stream, candidates, refs_bytes + ((size_t)q_count + 1) * sizeof(uint64_t),
-                                c_addresses, c_lengths, &candidate_bytes, error_message);
+        status = gather_strings(candidates, c_offsets, c_addresses, c_lengths, &candidate_bytes, error_message);
         if (status != sz_success_k) return status;
     }
 
