@@ -14,14 +14,27 @@
  *  - One workgroup = one QUERY x 256 CANDIDATES, one (query, candidate) pair per lane.  Lanes never talk to each
  *    other: there is no anti-diagonal, no shuffle, no shared DP row.  Utilisation comes from the batch (the C-ABI is
  *    a cross-product), and candidates are length-sorted so a wavefront's 64 texts end together.
- *  - The DP matrix of a pair is walked in horizontal STRIPS of `rows_` query rows.  Inside a strip the lane sweeps
- *    the candidate left to right; the strip's column of `rows_` cells (and its horizontal-gap track for affine gaps)
- *    lives in VGPRs.  Only the strip's bottom row must survive until the next strip: it is parked in a per-lane
- *    BOUNDARY array in global memory laid out [column][lane], so a wavefront reads/writes one coalesced 256-byte
- *    line per column.  Traffic: 2 x 4 B per `rows_` cells (x2 for affine).
- *  - Substitution costs come from a per-strip QUERY PROFILE in LDS: profile[candidate class][row] = cost(query[row],
- *    class) as packed int8, so ONE ds_read_b128 hands a lane the costs of 16 cells.  The query is shared by the whole
- *    workgroup, so the profile is built once per strip by 32 (class table) or 256 (uniform costs) threads.
+ *  - The DP matrix of a pair is walked in horizontal STRIPS of 32 query rows.  Inside a strip the lane sweeps the
+ *    candidate left to right; the strip's column of 32 cells (plus the gap tracks) lives in VGPRs.  Only the strip's
+ *    bottom row must survive until the next strip: it is parked in a per-lane BOUNDARY array in global memory laid out
+ *    [column][lane], so a wavefront reads/writes one coalesced 256-byte line per column: 8 B (linear) or 16 B (affine)
+ *    of traffic per 32 cells, prefetched one text dword (4 columns) ahead.
+ *  - Substitution costs come from a per-strip QUERY PROFILE in LDS indexed by the raw candidate BYTE:
+ *    profile[byte][row] = cost(query[row], byte) as packed int8, 32 bytes per symbol, so two ds_read_b128 hand a lane
+ *    the costs of 32 cells and the byte -> class map never appears in the inner loop.  The query is shared by the whole
+ *    workgroup, so the profile is built once per strip by 256 threads (one symbol each) from an LDS copy of the table.
+ *  - Arithmetic is shaped for the measured gfx950 integer rates (scripts/valu_peak.hip: v_add_u32 ~2.6 cycles per
+ *    wave-instruction, v_max_i32 / v_max3_i32 / SDWA adds ~4.2):
+ *        linear:  sub = diag + cost (one SDWA add, sign-extending the cost byte in place),
+ *                 h   = max3(above + gap, left + gap, sub)   where `x + gap` is computed once per produced cell
+ *                 -> 3 VALU per cell;
+ *        affine:  across = max(left_h + open, across + extend), down = max(above_h + open, down + extend),
+ *                 h = max3(down, across, sub) with `h + open`, `across + extend`, `down + extend` each formed once
+ *                 -> 7 VALU per cell;
+ *        local:   +1 (the substitution branch is clamped at 0) and a max3 tree per column for the running best.
+ *  - No per-column length checks in the main loop: it runs while ALL 64 lanes of the wavefront still have a whole text
+ *    dword left; the ragged rest (from the wavefront's shortest text to its longest) predicates every column on the
+ *    lane's own length, i.e. finished lanes are frozen by the EXEC mask and keep their final column in registers.
  *  - Cells are 32-bit.  The host refuses inputs whose worst-case reach (serial.hpp:135-162) leaves int32.
  *  - Persistent grid: workgroups stride over (query, candidate-block) work items, so the boundary workspace is sized
  *    by the number of RESIDENT workgroups, not by the size of the results matrix.
@@ -32,15 +45,89 @@
 
 namespace szs_hip {
 
-constexpr int weighted_rows_k = 16;          // strip height: 16 int8 costs = one ds_read_b128
+constexpr int weighted_rows_k = 32;                      // strip height: 32 int8 costs = two ds_read_b128
 constexpr u32 weighted_block_threads_k = 256;
-constexpr u32 weighted_max_resident_blocks_k = 256 * 4; // persistent grid ceiling: 256 CUs x 4 workgroups
+constexpr u32 weighted_max_resident_blocks_k = 256 * 4;  // persistent grid ceiling: 256 CUs x 4 workgroups
+constexpr u32 weighted_boundary_slack_k = 8;             // columns the boundary prefetch may run past the longest text
 
 __device__ __forceinline__ i32 max2(i32 a, i32 b) { return a > b ? a : b; }
 __device__ __forceinline__ i32 max3(i32 a, i32 b, i32 c) { return max2(max2(a, b), c); }
-__device__ __forceinline__ i32 cost_byte(uint4 const &packed, int row) {
-    u32 const word = row < 4 ? packed.x : row < 8 ? packed.y : row < 12 ? packed.z : packed.w;
-    return (i32)(int8_t)(word >> (8 * (row & 3)));
+
+/** The 32 substitution costs of one text byte against the 32 query rows of the strip, as fetched from LDS. */
+struct cost_column_t {
+    u32 packed[weighted_rows_k / 4];
+    __device__ __forceinline__ i32 operator[](int row) const { return (i32)(int8_t)(packed[row / 4] >> (8 * (row % 4))); }
+};
+
+__device__ __forceinline__ cost_column_t load_costs(int8_t const *profile, u32 symbol) {
+    uint4 const *rows = reinterpret_cast<uint4 const *>(profile) + symbol * (weighted_rows_k / 16);
+    uint4 const low = rows[0], high = rows[1];
+    cost_column_t costs;
+    costs.packed[0] = low.x, costs.packed[1] = low.y, costs.packed[2] = low.z, costs.packed[3] = low.w;
+    costs.packed[4] = high.x, costs.packed[5] = high.y, costs.packed[6] = high.z, costs.packed[7] = high.w;
+    return costs;
+}
+
+/**
+ *  The cells of one strip column, per lane, in the form the recurrences consume them.
+ *  Linear gaps keep `h` and `h + gap`; affine gaps keep `h`, `h + open` and the horizontal-gap track pre-extended.
+ */
+template <bool affine_>
+struct strip_column_t {
+    i32 h[weighted_rows_k];            // H(row, column): becomes the diagonal of the next column
+    i32 h_gapped[weighted_rows_k];     // H + gap (linear) or H + open (affine): the "left" input of the next column
+    i32 across_extended[affine_ ? weighted_rows_k : 1]; // affine: horizontal-gap track + extend
+};
+
+/**
+ *  Advances one lane by one column of the strip.
+ *
+ *  @param above_h      H(first_row - 1, j): the row above the strip at this column (border or parked boundary).
+ *  @param above_down   affine: the vertical-gap track of that row; ignored for linear gaps.
+ *  @param diagonal     H(first_row - 1, j - 1); replaced by `above_h` for the next column.
+ *  @param down_out     affine: the vertical-gap track of the strip's bottom row at this column.
+ *  @param best         local: running maximum over the rows `[0, counted_rows)` of this column.
+ */
+template <bool local_, bool affine_>
+__device__ __forceinline__ void advance_column(strip_column_t<affine_> &column, cost_column_t const &costs, i32 above_h,
+                                               i32 above_down, i32 &diagonal, i32 gap_open, i32 gap_extend,
+                                               i32 &down_out, i32 &best, u32 counted_rows) {
+    constexpr int rows = weighted_rows_k;
+    i32 diag = diagonal;
+    diagonal = above_h;
+    i32 above_gapped = above_h + gap_open;                       // linear: above + gap;  affine: above + open
+    i32 down_extended = affine_ ? above_down + gap_extend : 0;   // affine: vertical-gap track + extend
+    i32 down = 0;
+#pragma unroll
+    for (int r = 0; r < rows; ++r) {
+        i32 substituted = diag + costs[r];
+        if constexpr (local_) substituted = max2(substituted, 0); // only this branch is clamped (serial.hpp:957-965)
+        diag = column.h[r];
+        i32 cell;
+        if constexpr (affine_) {
+            i32 const across = max2(column.h_gapped[r], column.across_extended[r]); // serial.hpp:1091-1102
+            down = max2(above_gapped, down_extended);
+            cell = max3(down, across, substituted);
+            column.across_extended[r] = across + gap_extend;
+            down_extended = down + gap_extend;
+        }
+        else { cell = max3(above_gapped, column.h_gapped[r], substituted); } // serial.hpp:846-848
+        column.h[r] = cell;
+        above_gapped = cell + gap_open;
+        column.h_gapped[r] = above_gapped;
+    }
+    down_out = down;
+    if constexpr (local_) {
+        if (counted_rows >= (u32)rows) { // every row is real: a max3 tree, half an instruction per cell
+#pragma unroll
+            for (int r = 0; r < rows; r += 2) best = max3(best, column.h[r], column.h[r + 1]);
+        }
+        else { // last strip of a query whose length is not a multiple of the strip height: padded rows never count
+#pragma unroll
+            for (int r = 0; r < rows; ++r)
+                if ((u32)r < counted_rows) best = max2(best, column.h[r]);
+        }
+    }
 }
 
 /**
@@ -56,17 +143,23 @@ __global__ __launch_bounds__(256) void weighted_scores_kernel(
     i64 *__restrict__ results, u64 results_row_stride, int symmetric, i32 *__restrict__ boundary, u32 boundary_columns) {
 
     constexpr int rows = weighted_rows_k;
-    constexpr int classes = uniform_ ? 256 : 32;
-    __shared__ __attribute__((aligned(16))) int8_t profile[classes * rows];
+    __shared__ __attribute__((aligned(16))) int8_t profile[256 * rows]; // [candidate byte][row]
+    __shared__ int8_t table[32 * 32];                                   // [query class][candidate class]
     __shared__ u8 class_of_byte[256];
+    __shared__ u8 strip_classes[rows];                                  // classes (uniform_: bytes) of the strip's rows
 
     i32 const gap_open = model->gap_open, gap_extend = model->gap_extend;
-    if constexpr (!uniform_) class_of_byte[threadIdx.x] = model->byte_to_class[threadIdx.x];
+    if constexpr (!uniform_) {
+        class_of_byte[threadIdx.x] = model->byte_to_class[threadIdx.x];
+        for (u32 i = threadIdx.x; i < 32 * 32; i += weighted_block_threads_k) table[i] = (int8_t)model->substitution[i];
+    }
+    i32 const uniform_match = model->uniform_match, uniform_mismatch = model->uniform_mismatch;
 
     // This workgroup's private boundary rows: [column][lane], one plane for H and one for the vertical-gap track.
     u64 const plane = (u64)boundary_columns * weighted_block_threads_k;
-    i32 *const boundary_scores = boundary + (u64)blockIdx.x * plane * (affine_ ? 2 : 1) + threadIdx.x;
-    i32 *const boundary_gaps = boundary_scores + plane;
+    i32 *const boundary_h = boundary + (u64)blockIdx.x * plane * (affine_ ? 2 : 1) + threadIdx.x;
+    i32 *const boundary_down = boundary_h + plane;
+    auto parked = [](i32 *base, u32 j) -> i32 & { return base[(u64)j * weighted_block_threads_k]; };
 
     u64 const work_items = (u64)queries_count * candidate_blocks;
     for (u64 work = blockIdx.x; work < work_items; work += gridDim.x) {
@@ -78,6 +171,7 @@ __global__ __launch_bounds__(256) void weighted_scores_kernel(
         if (symmetric && candidate.index > query.index) live = false;
         u32 const text_length = live ? candidate.length : 0;
         u32 const longest_in_wave = wave_max_u32(text_length);
+        u32 const shortest_in_wave = ~wave_max_u32(live ? ~text_length : 0u); // over live lanes
         text_stream_t const text(candidate.address, text_length);
         u8 const *const pattern = reinterpret_cast<u8 const *>(query.address);
         u32 const query_length = query.length;
@@ -100,95 +194,119 @@ __global__ __launch_bounds__(256) void weighted_scores_kernel(
             bool const is_first_strip = first_row == 0;
             bool const is_last_strip = first_row + rows >= query_length;
 
-            // ---- query profile of this strip
-            __syncthreads(); // everyone is done with the previous strip's profile (and class_of_byte is written)
-            if (threadIdx.x < (u32)classes) {
-                u32 packed[rows / 4] = {0, 0, 0, 0};
+            // ---- query profile of this strip: thread t owns candidate byte t
+            __syncthreads(); // everyone is done with the previous strip's profile (and the table copies are written)
+            if (threadIdx.x < (u32)rows) {
+                u8 symbol = 0;
+                if (threadIdx.x < rows_here) symbol = pattern[first_row + threadIdx.x];
+                strip_classes[threadIdx.x] = uniform_ ? symbol : class_of_byte[symbol];
+            }
+            __syncthreads();
+            {
+                u32 const mine = uniform_ ? threadIdx.x : (u32)class_of_byte[threadIdx.x];
+                u32 packed[rows / 4];
 #pragma unroll
                 for (int r = 0; r < rows; ++r) {
-                    i32 cost = 0;
+                    i32 cost = 0; // padded rows: never read back (global) / never counted (local)
                     if ((u32)r < rows_here) {
-                        u8 const symbol = pattern[first_row + r];
-                        if constexpr (uniform_)
-                            cost = symbol == threadIdx.x ? model->uniform_match : model->uniform_mismatch;
+                        if constexpr (uniform_) cost = strip_classes[r] == mine ? uniform_match : uniform_mismatch;
                         else // cost(query, candidate) = table[class(query)][class(candidate)]: the QUERY picks the row
-                            cost = model->substitution[(u32)class_of_byte[symbol] * 32 + threadIdx.x];
+                            cost = table[(u32)strip_classes[r] * 32 + mine];
                     }
+                    if (r % 4 == 0) packed[r / 4] = 0;
                     packed[r / 4] |= ((u32)cost & 0xFFu) << (8 * (r % 4));
                 }
-                reinterpret_cast<uint4 *>(profile)[threadIdx.x] = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+                uint4 *mine_rows = reinterpret_cast<uint4 *>(profile) + threadIdx.x * (rows / 16);
+                mine_rows[0] = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+                mine_rows[1] = make_uint4(packed[4], packed[5], packed[6], packed[7]);
             }
             __syncthreads();
 
             // ---- column 0 of the strip.  Track seeds are the FINITE "discard" values of the reference:
             //      global: border + open + extend (serial.hpp:1049-1056); local: open + extend (serial.hpp:1195-1201).
-            i32 cells[rows], gaps_across[affine_ ? rows : 1];
+            strip_column_t<affine_> column;
 #pragma unroll
             for (int r = 0; r < rows; ++r) {
-                cells[r] = border(first_row + r + 1);
-                if constexpr (affine_) gaps_across[r] = cells[r] + gap_open + gap_extend;
+                column.h[r] = border(first_row + r + 1);
+                column.h_gapped[r] = column.h[r] + gap_open;
+                if constexpr (affine_) column.across_extended[r] = column.h[r] + gap_open + gap_extend + gap_extend;
             }
-            i32 above_left = border(first_row); // DP cell (first_row, column - 1)
+            i32 diagonal = border(first_row); // DP cell (first_row - 1, column - 1)
+            i32 best = 0, down_out = 0;
 
-            u32 raw_low = text.raw(0), raw_high = text.raw(1);
-            for (u32 column = 0; column < longest_in_wave; column += 4) {
-                u32 const symbols = text.splice(raw_low, raw_high);
-                raw_low = raw_high;
-                raw_high = text.raw(column / 4 + 2);
-#pragma unroll
-                for (int step = 0; step < 4; ++step) {
-                    u32 const j = column + step + 1; // 1-based DP column
-                    if (j > text_length) continue;   // this lane's text has ended; others in the wave go on
-                    u32 const symbol = (symbols >> (8 * step)) & 0xFFu;
-                    u32 const klass = uniform_ ? symbol : (u32)class_of_byte[symbol];
-                    uint4 const costs = reinterpret_cast<uint4 const *>(profile)[klass];
+            // The row above the strip at column j (1-based): the border for the first strip, else the parked boundary.
+            auto above_of = [&](u32 j, i32 &above_h, i32 &above_down) {
+                if (is_first_strip) {
+                    above_h = border(j);
+                    above_down = above_h + gap_open + gap_extend;
+                }
+                else {
+                    above_h = parked(boundary_h, j);
+                    above_down = affine_ ? parked(boundary_down, j) : 0;
+                }
+            };
 
-                    // The row above the strip at this column: the border for the first strip, else the parked boundary.
-                    i32 above, above_gap = 0;
-                    if (is_first_strip) {
-                        above = border(j);
-                        if constexpr (affine_) above_gap = above + gap_open + gap_extend;
-                    }
-                    else {
-                        above = boundary_scores[(u64)j * weighted_block_threads_k];
-                        if constexpr (affine_) above_gap = boundary_gaps[(u64)j * weighted_block_threads_k];
-                    }
-
-                    i32 diagonal = above_left;
-                    above_left = above;
+            u32 column_index = 0, dword = 0; // columns [0, column_index) are done
+            u32 raw_low = text.raw(0);
+            // ---- main loop: whole text dwords that EVERY live lane of the wavefront still has
+            if (shortest_in_wave >= 4 && longest_in_wave) {
+                u32 raw_high = text.raw(1);
+                i32 above_h[4], above_down[4];
 #pragma unroll
-                    for (int r = 0; r < rows; ++r) {
-                        i32 const left = cells[r];
-                        i32 substituted = diagonal + cost_byte(costs, r);
-                        if constexpr (local_) substituted = max2(substituted, 0); // only this branch is clamped
-                        i32 cell;
-                        if constexpr (affine_) {
-                            i32 const gap_across = max2(left + gap_open, gaps_across[r] + gap_extend);
-                            i32 const gap_down = max2(above + gap_open, above_gap + gap_extend);
-                            cell = max3(gap_down, gap_across, substituted);
-                            gaps_across[r] = gap_across;
-                            above_gap = gap_down;
-                        }
-                        else { cell = max2(max2(above, left) + gap_open, substituted); }
-                        if constexpr (local_) {
-                            if ((u32)r < rows_here) score = max2(score, cell); // padded rows never count
-                        }
-                        diagonal = left;
-                        above = cell;
-                        cells[r] = cell;
-                    }
-                    if (!is_last_strip) {
-                        boundary_scores[(u64)j * weighted_block_threads_k] = cells[rows - 1];
-                        if constexpr (affine_) boundary_gaps[(u64)j * weighted_block_threads_k] = above_gap;
-                    }
-                    else if constexpr (!local_) {
-                        if (j == text_length) { // bottom-right cell: last real row of the last strip
+                for (int step = 0; step < 4; ++step) above_of(1 + step, above_h[step], above_down[step]);
+                for (; column_index + 4 <= shortest_in_wave; column_index += 4, ++dword) {
+                    u32 const symbols = text.splice(raw_low, raw_high);
+                    raw_low = raw_high;
+                    raw_high = text.raw(dword + 2);
+                    i32 now_h[4], now_down[4];
 #pragma unroll
-                            for (int r = 0; r < rows; ++r)
-                                if ((u32)r + 1 == rows_here) score = cells[r];
+                    for (int step = 0; step < 4; ++step) now_h[step] = above_h[step], now_down[step] = above_down[step];
+                    // Prefetch the next dword's boundary cells; the slack columns make the overrun harmless.
+#pragma unroll
+                    for (int step = 0; step < 4; ++step) above_of(column_index + 5 + step, above_h[step], above_down[step]);
+#pragma unroll
+                    for (int step = 0; step < 4; ++step) {
+                        cost_column_t const costs = load_costs(profile, (symbols >> (8 * step)) & 0xFFu);
+                        advance_column<local_, affine_>(column, costs, now_h[step], now_down[step], diagonal, gap_open,
+                                                        gap_extend, down_out, best, rows_here);
+                        if (!is_last_strip) {
+                            parked(boundary_h, column_index + step + 1) = column.h[rows - 1];
+                            if constexpr (affine_) parked(boundary_down, column_index + step + 1) = down_out;
                         }
                     }
                 }
+            }
+            // ---- ragged rest: every column predicated on this lane's own length
+            if (column_index < longest_in_wave) {
+                u32 raw_high = text.raw(dword + 1);
+#pragma unroll 1
+                for (; column_index < longest_in_wave; column_index += 4, ++dword) {
+                    u32 const symbols = text.splice(raw_low, raw_high);
+                    raw_low = raw_high;
+                    raw_high = text.raw(dword + 2);
+#pragma unroll
+                    for (int step = 0; step < 4; ++step) {
+                        u32 const j = column_index + step + 1; // 1-based DP column
+                        if (j <= text_length) {
+                            i32 above_h, above_down;
+                            above_of(j, above_h, above_down);
+                            cost_column_t const costs = load_costs(profile, (symbols >> (8 * step)) & 0xFFu);
+                            advance_column<local_, affine_>(column, costs, above_h, above_down, diagonal, gap_open,
+                                                            gap_extend, down_out, best, rows_here);
+                            if (!is_last_strip) {
+                                parked(boundary_h, j) = column.h[rows - 1];
+                                if constexpr (affine_) parked(boundary_down, j) = down_out;
+                            }
+                        }
+                    }
+                }
+            }
+
+            if constexpr (local_) score = max2(score, best);
+            else if (is_last_strip) { // bottom-right cell: last real row of the last strip, frozen at the lane's last column
+#pragma unroll
+                for (int r = 0; r < rows; ++r)
+                    if ((u32)r + 1 == rows_here) score = column.h[r];
             }
         }
 
@@ -215,7 +333,7 @@ static int launch_weighted(szs_cost_model_t const *model, szs_string_ref_t const
     u32 const grid = weighted_grid(queries_count, candidates_count);
     hipLaunchKernelGGL((weighted_scores_kernel<local_, affine_, uniform_>), dim3(grid), dim3(weighted_block_threads_k), 0,
                        stream, model, queries, queries_count, candidates, candidates_count, candidate_blocks, results,
-                       stride, symmetric, static_cast<i32 *>(boundary), longest_candidate + 1);
+                       stride, symmetric, static_cast<i32 *>(boundary), longest_candidate + 1 + weighted_boundary_slack_k);
     return (int)hipGetLastError();
 }
 
@@ -224,8 +342,8 @@ static int launch_weighted(szs_cost_model_t const *model, szs_string_ref_t const
 extern "C" size_t szs_hip_weighted_boundary_bytes(int affine, uint32_t queries_count, uint32_t candidates_count,
                                                   uint32_t longest_candidate) {
     using namespace szs_hip;
-    return (size_t)weighted_grid(queries_count, candidates_count) * (longest_candidate + 1) * weighted_block_threads_k *
-           sizeof(i32) * (affine ? 2 : 1);
+    return (size_t)weighted_grid(queries_count, candidates_count) * (longest_candidate + 1 + weighted_boundary_slack_k) *
+           weighted_block_threads_k * sizeof(i32) * (affine ? 2 : 1);
 }
 
 extern "C" int szs_hip_weighted_scores(int objective, int affine, szs_cost_model_t const *model,
