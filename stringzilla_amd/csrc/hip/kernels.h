@@ -64,13 +64,14 @@ enum {
 /**
  *  Weighted scorer: one (query, candidate) pair per lane, the query shared by the wavefront, DP walked in strips
  *  of query rows held in registers, the strip boundary row parked in `boundary` (global memory, [column][lane]).
- *  `boundary` needs szs_hip_weighted_boundary_bytes(...) bytes.
+ *  `boundary` needs szs_hip_weighted_boundary_bytes(...) bytes (work counter + one boundary per RESIDENT workgroup)
+ *  and must be called with the target device current.  Queries should arrive longest first.
  */
 int szs_hip_weighted_scores(int objective, int affine, szs_cost_model_t const *model, szs_string_ref_t const *queries,
                             uint32_t queries_count, szs_string_ref_t const *candidates, uint32_t candidates_count,
                             uint32_t longest_candidate, int64_t *results, uint64_t results_row_stride, int symmetric,
                             void *boundary, void *stream);
-size_t szs_hip_weighted_boundary_bytes(int affine, uint32_t queries_count, uint32_t candidates_count,
+size_t szs_hip_weighted_boundary_bytes(int objective, int affine, uint32_t queries_count, uint32_t candidates_count,
                                        uint32_t longest_candidate);
 
 #ifdef __cplusplus

@@ -36,8 +36,9 @@
  *    dword left; the ragged rest (from the wavefront's shortest text to its longest) predicates every column on the
  *    lane's own length, i.e. finished lanes are frozen by the EXEC mask and keep their final column in registers.
  *  - Cells are 32-bit.  The host refuses inputs whose worst-case reach (serial.hpp:135-162) leaves int32.
- *  - Persistent grid: workgroups stride over (query, candidate-block) work items, so the boundary workspace is sized
- *    by the number of RESIDENT workgroups, not by the size of the results matrix.
+ *  - Persistent grid sized to what the device can keep RESIDENT (occupancy query x CUs); workgroups pull
+ *    (query, candidate-block) items, heaviest first, from one atomic counter, so the boundary workspace is sized by
+ *    resident workgroups - not by the results matrix - and ragged batches balance themselves.
  *
  *  Exact boundary values (parity traps of SURVEY.md section 8a) are spelled out next to the code that uses them.
  */
@@ -47,7 +48,6 @@ namespace szs_hip {
 
 constexpr int weighted_rows_k = 32;                      // strip height: 32 int8 costs = two ds_read_b128
 constexpr u32 weighted_block_threads_k = 256;
-constexpr u32 weighted_max_resident_blocks_k = 256 * 4;  // persistent grid ceiling: 256 CUs x 4 workgroups
 constexpr u32 weighted_boundary_slack_k = 8;             // columns the boundary prefetch may run past the longest text
 
 __device__ __forceinline__ i32 max2(i32 a, i32 b) { return a > b ? a : b; }
@@ -140,13 +140,15 @@ template <bool local_, bool affine_, bool uniform_>
 __global__ __launch_bounds__(256) void weighted_scores_kernel(
     szs_cost_model_t const *__restrict__ model, szs_string_ref_t const *__restrict__ queries, u32 queries_count,
     szs_string_ref_t const *__restrict__ candidates, u32 candidates_count, u32 candidate_blocks,
-    i64 *__restrict__ results, u64 results_row_stride, int symmetric, i32 *__restrict__ boundary, u32 boundary_columns) {
+    i64 *__restrict__ results, u64 results_row_stride, int symmetric, i32 *__restrict__ boundary, u32 boundary_columns,
+    u32 *__restrict__ work_counter) {
 
     constexpr int rows = weighted_rows_k;
     __shared__ __attribute__((aligned(16))) int8_t profile[256 * rows]; // [candidate byte][row]
     __shared__ int8_t table[32 * 32];                                   // [query class][candidate class]
     __shared__ u8 class_of_byte[256];
     __shared__ u8 strip_classes[rows];                                  // classes (uniform_: bytes) of the strip's rows
+    __shared__ u32 claimed_work;
 
     i32 const gap_open = model->gap_open, gap_extend = model->gap_extend;
     if constexpr (!uniform_) {
@@ -161,10 +163,19 @@ __global__ __launch_bounds__(256) void weighted_scores_kernel(
     i32 *const boundary_down = boundary_h + plane;
     auto parked = [](i32 *base, u32 j) -> i32 & { return base[(u64)j * weighted_block_threads_k]; };
 
-    u64 const work_items = (u64)queries_count * candidate_blocks;
-    for (u64 work = blockIdx.x; work < work_items; work += gridDim.x) {
+    // Work items are (query, candidate block) pairs, handed out through one device-wide counter: queries arrive longest
+    // first and candidate blocks are walked from the longest texts down, so the heaviest items start first and the
+    // launch drains on its lightest ones, whatever the grid size and however uneven the lengths are.
+    u32 const work_items = queries_count * candidate_blocks;
+    for (;;) {
+        __syncthreads(); // the previous item's LDS (profile, claimed_work) is no longer in use
+        if (threadIdx.x == 0) claimed_work = atomicAdd(work_counter, 1u);
+        __syncthreads();
+        u32 const work = claimed_work;
+        if (work >= work_items) break;
         szs_string_ref_t const query = queries[work / candidate_blocks];
-        u32 const candidate_slot = (u32)(work % candidate_blocks) * weighted_block_threads_k + threadIdx.x;
+        u32 const candidate_slot =
+            (candidate_blocks - 1 - work % candidate_blocks) * weighted_block_threads_k + threadIdx.x;
         bool live = candidate_slot < candidates_count;
         szs_string_ref_t candidate = {0, 0, 0};
         if (live) candidate = candidates[candidate_slot];
@@ -319,31 +330,80 @@ __global__ __launch_bounds__(256) void weighted_scores_kernel(
     }
 }
 
-static u32 weighted_grid(u32 queries_count, u32 candidates_count) {
-    u64 const blocks = (candidates_count + weighted_block_threads_k - 1) / weighted_block_threads_k;
-    u64 const work = (u64)queries_count * blocks;
-    return (u32)(work < weighted_max_resident_blocks_k ? work : weighted_max_resident_blocks_k);
+constexpr size_t weighted_header_bytes_k = 256; // the work counter lives at the head of the boundary workspace
+
+/** Workgroups that can be RESIDENT at once for this kernel instance on the current device (never more than the work). */
+template <bool local_, bool affine_, bool uniform_>
+static u32 weighted_grid(u64 work_items) {
+    static int resident = 0; // per instance; one device architecture per process
+    if (!resident) {
+        int device = 0, units = 0, per_unit = 0;
+        if (hipGetDevice(&device) != hipSuccess ||
+            hipDeviceGetAttribute(&units, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_unit, weighted_scores_kernel<local_, affine_, uniform_>,
+                                                         (int)weighted_block_threads_k, 0) != hipSuccess ||
+            units <= 0 || per_unit <= 0) {
+            (void)hipGetLastError();
+            units = 256, per_unit = 2;
+        }
+        resident = units * per_unit;
+    }
+    return (u32)(work_items < (u64)resident ? work_items : (u64)resident);
+}
+
+static u64 weighted_work_items(u32 queries_count, u32 candidates_count) {
+    return (u64)queries_count * ((candidates_count + weighted_block_threads_k - 1) / weighted_block_threads_k);
+}
+
+template <bool local_, bool affine_, bool uniform_>
+static size_t weighted_workspace_bytes(u32 queries_count, u32 candidates_count, u32 longest_candidate) {
+    u32 const grid = weighted_grid<local_, affine_, uniform_>(weighted_work_items(queries_count, candidates_count));
+    return weighted_header_bytes_k + (size_t)grid * (longest_candidate + 1 + weighted_boundary_slack_k) *
+                                         weighted_block_threads_k * sizeof(i32) * (affine_ ? 2 : 1);
 }
 
 template <bool local_, bool affine_, bool uniform_>
 static int launch_weighted(szs_cost_model_t const *model, szs_string_ref_t const *queries, u32 queries_count,
                            szs_string_ref_t const *candidates, u32 candidates_count, u32 longest_candidate, i64 *results,
-                           u64 stride, int symmetric, void *boundary, hipStream_t stream) {
+                           u64 stride, int symmetric, void *workspace, hipStream_t stream) {
     u32 const candidate_blocks = (candidates_count + weighted_block_threads_k - 1) / weighted_block_threads_k;
-    u32 const grid = weighted_grid(queries_count, candidates_count);
+    u64 const work_items = weighted_work_items(queries_count, candidates_count);
+    if (work_items > 0xFFFFFFF0ull) return (int)hipErrorInvalidValue; // the host cuts larger cross-products
+    u32 const grid = weighted_grid<local_, affine_, uniform_>(work_items);
+    u32 *const counter = static_cast<u32 *>(workspace);
+    i32 *const boundary = reinterpret_cast<i32 *>(static_cast<char *>(workspace) + weighted_header_bytes_k);
+    hipError_t error = hipMemsetAsync(counter, 0, sizeof(u32), stream);
+    if (error != hipSuccess) return (int)error;
     hipLaunchKernelGGL((weighted_scores_kernel<local_, affine_, uniform_>), dim3(grid), dim3(weighted_block_threads_k), 0,
                        stream, model, queries, queries_count, candidates, candidates_count, candidate_blocks, results,
-                       stride, symmetric, static_cast<i32 *>(boundary), longest_candidate + 1 + weighted_boundary_slack_k);
+                       stride, symmetric, boundary, longest_candidate + 1 + weighted_boundary_slack_k, counter);
     return (int)hipGetLastError();
 }
 
 } // namespace szs_hip
 
-extern "C" size_t szs_hip_weighted_boundary_bytes(int affine, uint32_t queries_count, uint32_t candidates_count,
-                                                  uint32_t longest_candidate) {
+#define SZS_WEIGHTED_DISPATCH(CALL)                                                                                   \
+    switch (objective) {                                                                                               \
+    case szs_objective_global_k:                                                                                       \
+        if (affine) CALL(false, true, false);                                                                          \
+        CALL(false, false, false);                                                                                     \
+    case szs_objective_local_k:                                                                                        \
+        if (affine) CALL(true, true, false);                                                                           \
+        CALL(true, false, false);                                                                                      \
+    case szs_objective_distance_k:                                                                                     \
+        if (affine) CALL(false, true, true);                                                                           \
+        CALL(false, false, true);                                                                                      \
+    default: break;                                                                                                    \
+    }
+
+extern "C" size_t szs_hip_weighted_boundary_bytes(int objective, int affine, uint32_t queries_count,
+                                                  uint32_t candidates_count, uint32_t longest_candidate) {
     using namespace szs_hip;
-    return (size_t)weighted_grid(queries_count, candidates_count) * (longest_candidate + 1 + weighted_boundary_slack_k) *
-           weighted_block_threads_k * sizeof(i32) * (affine ? 2 : 1);
+#define SZS_WEIGHTED_BYTES(LOCAL, AFFINE, UNIFORM)                                                                     \
+    return weighted_workspace_bytes<LOCAL, AFFINE, UNIFORM>(queries_count, candidates_count, longest_candidate)
+    SZS_WEIGHTED_DISPATCH(SZS_WEIGHTED_BYTES)
+#undef SZS_WEIGHTED_BYTES
+    return 0;
 }
 
 extern "C" int szs_hip_weighted_scores(int objective, int affine, szs_cost_model_t const *model,
@@ -354,20 +414,10 @@ extern "C" int szs_hip_weighted_scores(int objective, int affine, szs_cost_model
     using namespace szs_hip;
     if (!queries_count || !candidates_count) return 0;
     hipStream_t const s = static_cast<hipStream_t>(stream);
-#define SZS_WEIGHTED(LOCAL, AFFINE, UNIFORM)                                                                           \
+#define SZS_WEIGHTED_LAUNCH(LOCAL, AFFINE, UNIFORM)                                                                    \
     return launch_weighted<LOCAL, AFFINE, UNIFORM>(model, queries, queries_count, candidates, candidates_count,       \
                                                    longest_candidate, results, results_row_stride, symmetric, boundary, s)
-    switch (objective) {
-    case szs_objective_global_k:
-        if (affine) SZS_WEIGHTED(false, true, false);
-        SZS_WEIGHTED(false, false, false);
-    case szs_objective_local_k:
-        if (affine) SZS_WEIGHTED(true, true, false);
-        SZS_WEIGHTED(true, false, false);
-    case szs_objective_distance_k:
-        if (affine) SZS_WEIGHTED(false, true, true);
-        SZS_WEIGHTED(false, false, true);
-    default: return (int)hipErrorInvalidValue;
-    }
-#undef SZS_WEIGHTED
+    SZS_WEIGHTED_DISPATCH(SZS_WEIGHTED_LAUNCH)
+#undef SZS_WEIGHTED_LAUNCH
+    return (int)hipErrorInvalidValue;
 }

@@ -276,6 +276,9 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
         device_results = engine->device_results.pointer, device_stride = c_count;
     }
 
+    int const objective = engine->family == szs_family_needleman_wunsch_k   ? szs_objective_global_k
+                          : engine->family == szs_family_smith_waterman_k ? szs_objective_local_k
+                                                                          : szs_objective_distance_k;
     /* Weighted kernels need the cost model and a strip-boundary workspace on the device. */
     int needs_weighted = !use_myers;
     for (unsigned g = 0; g < plan.groups_count; ++g) needs_weighted |= plan.groups[g].variant == 0;
@@ -291,7 +294,7 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
             engine->model_uploaded_device = device;
         }
         size_t const boundary_bytes =
-            szs_hip_weighted_boundary_bytes(!engine->is_linear, q_count, c_count, plan.longest_candidate);
+            szs_hip_weighted_boundary_bytes(objective, !engine->is_linear, q_count, c_count, plan.longest_candidate);
         status = szs_buffer_reserve(&engine->device_boundary, szs_memory_device_k, device, boundary_bytes, error_message);
         if (status != sz_success_k) return status;
     }
@@ -300,9 +303,6 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
     error = hipEventRecord(engine->event_start, stream);
     if (error != hipSuccess) return szs_report_hip(error, error_message);
     uint32_t launches = 0;
-    int const objective = engine->family == szs_family_needleman_wunsch_k   ? szs_objective_global_k
-                          : engine->family == szs_family_smith_waterman_k ? szs_objective_local_k
-                                                                          : szs_objective_distance_k;
     for (unsigned g = 0; g < plan.groups_count; ++g) {
         szs_plan_group_t const *group = &plan.groups[g];
         int launch_error;

@@ -82,26 +82,15 @@ void szs_plan_build(int myers, int symmetric, uint64_t const *query_addresses, u
     /* Queries: LONGEST FIRST.  The launch variant is monotone in the length, so descending order makes every variant a
      * contiguous slice - first the queries too long for the bit-parallel kernels (variant 0, weighted kernel), then the
      * long widths from the widest down, last the one mixed-width launch of all short queries - and within a launch the
-     * heaviest workgroups are handed out first, so a launch drains on its lightest work. */
-    if (!myers) {
-        for (uint32_t q = 0; q < queries_count; ++q) {
-            query_refs[q].address = query_addresses[q];
-            query_refs[q].length = query_lengths[q];
-            query_refs[q].index = q;
-        }
-        if (queries_count) {
-            plan->groups_count = 1;
-            plan->groups[0].variant = 0, plan->groups[0].first = 0, plan->groups[0].count = queries_count;
-        }
-        return;
-    }
+     * heaviest workgroups are handed out first, so a launch drains on its lightest work.  The weighted engines use
+     * the same order for their single group (variant 0): their kernels pull work items heaviest first. */
     sort_by_length(query_lengths, queries_count, plan->longest_query, keys);
     for (uint32_t slot = 0; slot < queries_count; ++slot) {
         uint32_t const q = keys[queries_count - 1 - slot]; /* ascending order read backwards */
         query_refs[slot].address = query_addresses[q];
         query_refs[slot].length = query_lengths[q];
         query_refs[slot].index = q;
-        unsigned const variant = myers_variant(query_lengths[q]);
+        unsigned const variant = myers ? myers_variant(query_lengths[q]) : 0; /* weighted engines: one group */
         szs_plan_group_t *group = plan->groups_count ? &plan->groups[plan->groups_count - 1] : NULL;
         if (!group || group->variant != variant) {
             group = &plan->groups[plan->groups_count++];

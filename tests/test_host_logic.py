@@ -119,8 +119,8 @@ def test_planner_counts_symmetric_cells():
     lengths = [3, 0, 7, 5]
     _, _, _, cells = _probe(1, 1, lengths, lengths)
     assert cells == sum(lengths[i] * lengths[j] for i in range(4) for j in range(i + 1))
-    _, q_order, q_variant, _ = _probe(0, 0, lengths, lengths)  # weighted engines: one group, original order
-    assert q_order.tolist() == [0, 1, 2, 3] and q_variant.tolist() == [0, 0, 0, 0]
+    _, q_order, q_variant, _ = _probe(0, 0, lengths, lengths)  # weighted engines: one group, longest first
+    assert q_order.tolist() == [2, 3, 0, 1] and q_variant.tolist() == [0, 0, 0, 0]
 
 
 def test_shard_rows_balances_like_lpt():
