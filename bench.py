@@ -32,7 +32,18 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-INT32_VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12  # 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T lane-ops/s
+# The binding resource of this path is integer VALU issue, not HBM.  Its ceiling is MEASURED, not quoted: the Myers
+# column update (the kernel's exact instruction mix) on register-resident match masks, no LDS and no memory, sustains
+# this many DP cells per second at full bit-vector width on one MI355X (scripts/valu_peak.hip -> profiles/).
+PROFILES = os.path.join(ROOT, "profiles", "r01")
+
+
+def _profile_json(name):
+    try:
+        with open(os.path.join(PROFILES, name)) as handle:
+            return json.load(handle)
+    except (OSError, ValueError):
+        return None
 
 
 def parse_args():
@@ -43,7 +54,8 @@ def parse_args():
     parser.add_argument("--config", type=int, default=2, help="BASELINE.json config index (2 = the metric's config)")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--hbm-traffic-bytes", type=float, default=None,
-                        help="HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/), if collected")
+                        help="HBM bytes per launch from a separate rocprofv3 --pmc pass; default: the committed summary "
+                             "profiles/r01/pmc_summary.json of this same command (scripts/profile_gpu.sh)")
     return parser.parse_args()
 
 
@@ -169,6 +181,21 @@ def main():
         kernel = float(np.mean(kernel_ms)) * 1e-3  # seconds per launch group, hipEvent pair on the library's stream
         achieved = profile.algorithmic_bytes / kernel / 1e9
         gpu_matrix = results.cpu().numpy().view(np.uint64)
+        # HBM traffic of the dominant kernel, per launch: FETCH_SIZE + WRITE_SIZE from their own rocprofv3 --pmc passes
+        # of this command (scripts/profile_gpu.sh), kilobyte units and the gfx950 wide-read correction applied by
+        # scripts/pmc_summary.py as MI355X_MICROARCH.md prescribes.  Committed, not collected inside this process.
+        traffic, traffic_note = args.hbm_traffic_bytes, "from --hbm-traffic-bytes"
+        if traffic is None and args.config == 2:
+            summary = (_profile_json("pmc_summary.json") or {}).get("levenshtein_myers_short_kernel")
+            if summary and "hbm_fetch_bytes_raw" in summary and "hbm_write_bytes_raw" in summary:
+                traffic = summary["hbm_fetch_bytes_raw"] + summary["hbm_write_bytes_raw"]
+                traffic_note = ("profiles/r01/pmc_summary.json: FETCH_SIZE*1024 + WRITE_SIZE*1024 per launch (raw; the x2 "
+                                "wide-stream read correction would give %d)" % int(
+                                    summary["hbm_fetch_bytes_x2_wide_stream_correction"] + summary["hbm_write_bytes_raw"]))
+        valu = (_profile_json("valu_peak.json") or {})
+        pure = valu.get("myers_pure_W4_Tcells")
+        lengths = load.queries.lengths().astype(np.int64)
+        padded_cells = float((np.maximum(1, -(-lengths // 32)) * 32).sum()) * float(load.candidates.lengths().sum())
         line = {
             "metric": "DP cell-updates/s (GCUPS) on 1M-pair Levenshtein batch", "value": round(value, 1), "unit": "GCUPS",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -178,13 +205,23 @@ def main():
                        "sharding": "query row blocks, candidates replicated" if world > 1 else "single GPU",
                        "entry_point": "szs_levenshtein_distances_u32tape"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": args.hbm_traffic_bytes,
-                         "kernel": "levenshtein_myers_kernel<W,4> (3 launches: W=3,4,5)", "kernel_ms": round(kernel * 1e3, 4),
+                         "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_source": traffic_note,
+                         "kernel": "levenshtein_myers_short_kernel (%d launch%s per step)" % (
+                             profile.launches, "" if profile.launches == 1 else "es"),
+                         "kernel_ms": round(kernel * 1e3, 4),
                          "algorithmic_bytes": int(profile.algorithmic_bytes),
                          "kernel_gcups": round(profile.cells / kernel / 1e9, 1),
-                         "note": "integer-VALU/LDS-bound by construction; HBM fraction is reported because the metric asks for it",
-                         "valu_lane_ops_per_cell_estimate": 0.43,
-                         "valu_frac_estimate": round(profile.cells / kernel * 0.43 / 1e12 / INT32_VALU_PEAK_TOPS, 4)},
+                         "note": "integer-VALU bound by construction (HBM traffic is ~4% of the algorithmic bytes: tapes "
+                                 "are L2-resident); the HBM fraction is reported because the metric asks for it, the "
+                                 "`valu` object is the roofline that says something about the kernel",
+                         "valu": {
+                             "bound": "integer VALU issue, measured",
+                             "achieved_Tcells_per_s_full_width": round(padded_cells / kernel / 1e12, 2),
+                             "peak_Tcells_per_s_full_width": pure,
+                             "frac": round(padded_cells / kernel / 1e12 / pure, 4) if pure else None,
+                             "peak_source": "scripts/valu_peak.hip `myers_pure_W4_Tcells`: the kernel's column update on "
+                                            "register-resident masks (profiles/r01/valu_peak.json)",
+                             "useful_fraction_of_width": round(float(profile.cells) / padded_cells, 4)}},
             "host_overhead_ms_per_step": round(ms_per_step - kernel * 1e3, 4),
             "results_checksum": float(checksum),
         }

@@ -22,7 +22,7 @@ for path in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv
             name = row.get("Kernel_Name", "")
             if "szs_hip" not in name:
                 continue
-            short = name.split("(")[0].replace("void szs_hip::", "")
+            short = name.split("(")[0].replace("void ", "").replace("szs_hip::", "")
             per_kernel[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
             per_kernel[short]["_vgpr"] = [float(row.get("VGPR_Count", 0) or 0)]
             per_kernel[short]["_sgpr"] = [float(row.get("SGPR_Count", 0) or 0)]

@@ -1,6 +1,7 @@
 #!/bin/bash
 # profile_gpu.sh TAG [bench args...] - the measurement recipe behind profiles/rNN/ (run on the GPU box through gpurun).
 #
+#   0. scripts/bin/valu_peak (measured integer-VALU ceilings)          -> gpurun_out/TAG/valu_peak.json
 #   1. bench.py (the judged line)                                     -> gpurun_out/TAG/bench.json
 #   2. rocprofv3 --kernel-trace --stats of the SAME command            -> gpurun_out/TAG/stats/*kernel_stats.csv
 #   3. PMC passes, each in its own run (the TCC block has 4 slots: FETCH_SIZE takes 3, WRITE_SIZE 2), never mixed with
@@ -17,10 +18,13 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 SHORT=(--steps 20 --warmup 5 --no-cpu-baseline)
 
+"$ROOT/scripts/bin/valu_peak" > "$OUT/valu_peak.json" 2> "$OUT/valu_peak.err" || echo "valu_peak failed"
+
 python "$ROOT/bench.py" "${ARGS[@]}" > "$OUT/bench.json" 2> "$OUT/bench.err" || echo "bench failed" >> "$OUT/bench.err"
 tail -c 3000 "$OUT/bench.json"
 
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- python "$ROOT/bench.py" "${ARGS[@]}" "${SHORT[@]}" > "$OUT/stats.log" 2>&1
+# the SAME command as the judged line (default steps), so that the average duration is comparable with bench.json's kernel_ms
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- python "$ROOT/bench.py" "${ARGS[@]}" --no-cpu-baseline > "$OUT/stats.log" 2>&1
 for pass in "FETCH_SIZE" "WRITE_SIZE" \
             "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU" \
             "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE" \

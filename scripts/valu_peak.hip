@@ -48,6 +48,31 @@ BENCH_KERNEL(k_pk_min_u16, "v_pk_min_u16 %0, %0, %1")
 BENCH_KERNEL(k_cndmask, "v_cndmask_b32 %0, %0, %1, vcc")
 BENCH_KERNEL(k_sdwa_add, "v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1")
 BENCH_KERNEL(k_pk_add_i16_opsel, "v_pk_add_i16 %0, %0, %1 op_sel_hi:[1,0]")
+BENCH_KERNEL(k_and_b32, "v_and_b32 %0, %0, %1")
+BENCH_KERNEL(k_xor_b32, "v_xor_b32 %0, %0, %1")
+BENCH_KERNEL(k_sub_u32, "v_sub_u32 %0, %0, %1")
+BENCH_KERNEL(k_lshlrev, "v_lshlrev_b32 %0, 1, %0")
+BENCH_KERNEL(k_lshrrev, "v_lshrrev_b32 %0, 1, %0")
+BENCH_KERNEL(k_lshl_or, "v_lshl_or_b32 %0, %0, 1, %1")
+BENCH_KERNEL(k_and_or, "v_and_or_b32 %0, %0, %1, %2")
+BENCH_KERNEL(k_add_co, "v_add_co_u32 %0, vcc, %0, %1")
+BENCH_KERNEL(k_bcnt, "v_bcnt_u32_b32 %0, %1, %0")
+BENCH_KERNEL(k_sub_clamp, "v_sub_u32 %0, %0, %1 clamp")
+BENCH_KERNEL(k_max_u32, "v_max_u32 %0, %0, %1")
+BENCH_KERNEL(k_min_i32, "v_min_i32 %0, %0, %1")
+BENCH_KERNEL(k_med3_i32, "v_med3_i32 %0, %0, %1, %2")
+BENCH_KERNEL(k_pk_sub_u16_clamp, "v_pk_sub_u16 %0, %0, %1 clamp")
+BENCH_KERNEL(k_pk_max_u16, "v_pk_max_u16 %0, %0, %1")
+BENCH_KERNEL(k_mov, "v_mov_b32 %0, %1")
+BENCH_KERNEL(k_add_sdwa_sext, "v_add_u32_sdwa %0, %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2")
+BENCH_KERNEL(k_cndmask_e64, "v_cndmask_b32_e64 %0, %0, %1, s[10:11]")
+BENCH_KERNEL(k_mad_u32_u24, "v_mad_u32_u24 %0, %0, %1, %2")
+BENCH_KERNEL(k_mul_lo, "v_mul_lo_u32 %0, %0, %1")
+BENCH_KERNEL(k_add_f32, "v_add_f32 %0, %0, %1")
+BENCH_KERNEL(k_max_f32, "v_max_f32 %0, %0, %1")
+BENCH_KERNEL(k_max3_f32, "v_max3_f32 %0, %0, %1, %2")
+BENCH_KERNEL(k_pk_max_f16, "v_pk_max_f16 %0, %0, %1")
+BENCH_KERNEL(k_pk_add_f16, "v_pk_add_f16 %0, %0, %1")
 
 /* LDS gather: one ds_read_b128 per step from a 4 KiB table of 16-byte rows, row picked by a per-lane pseudo-random byte
  * (the Myers kernel's Peq access pattern) or by a uniform row (conflict-free broadcast). */
@@ -92,8 +117,7 @@ __device__ __forceinline__ void myers_column_probe(uint32_t (&vp)[words_], uint3
         vp[w] = hn_shifted | ~(xv | hp_shifted);
         vn[w] = hp_shifted & xv;
     }
-    hp_history = __builtin_amdgcn_alignbit(hp_history, hp_below, 31);
-    hn_history = __builtin_amdgcn_alignbit(hn_history, hn_below, 31);
+    (void)hp_history, (void)hn_history; /* the kernel no longer tracks the score per column (popcount at text end) */
 }
 
 template <int words_>
@@ -157,6 +181,31 @@ int main() {
     REPORT("v_cndmask_b32", k_cndmask)
     REPORT("v_add_u32_sdwa", k_sdwa_add)
     REPORT("v_pk_add_i16_opsel", k_pk_add_i16_opsel)
+    REPORT("v_and_b32", k_and_b32)
+    REPORT("v_xor_b32", k_xor_b32)
+    REPORT("v_sub_u32", k_sub_u32)
+    REPORT("v_lshlrev_b32", k_lshlrev)
+    REPORT("v_lshrrev_b32", k_lshrrev)
+    REPORT("v_lshl_or_b32", k_lshl_or)
+    REPORT("v_and_or_b32", k_and_or)
+    REPORT("v_add_co_u32", k_add_co)
+    REPORT("v_bcnt_u32_b32", k_bcnt)
+    REPORT("v_sub_u32_clamp", k_sub_clamp)
+    REPORT("v_max_u32", k_max_u32)
+    REPORT("v_min_i32", k_min_i32)
+    REPORT("v_med3_i32", k_med3_i32)
+    REPORT("v_pk_sub_u16_clamp", k_pk_sub_u16_clamp)
+    REPORT("v_pk_max_u16", k_pk_max_u16)
+    REPORT("v_mov_b32", k_mov)
+    REPORT("v_add_u32_sdwa_sext", k_add_sdwa_sext)
+    REPORT("v_cndmask_b32_e64_sgpr", k_cndmask_e64)
+    REPORT("v_mad_u32_u24", k_mad_u32_u24)
+    REPORT("v_mul_lo_u32", k_mul_lo)
+    REPORT("v_add_f32", k_add_f32)
+    REPORT("v_max_f32", k_max_f32)
+    REPORT("v_max3_f32", k_max3_f32)
+    REPORT("v_pk_max_f16", k_pk_max_f16)
+    REPORT("v_pk_add_f16", k_pk_add_f16)
     {   /* word-steps per second: one word-step = 32 DP cells of one lane */
         int const columns = 1600; /* iterations x 16 */
         double const base = (double)blocks * 256 * columns;
