@@ -82,6 +82,10 @@ class _Checker:
         name = "levenshtein" if self._prefix.startswith("szs_ref") else "levenshtein_cross"
         return self._run(name, [_i8(match), _i8(mismatch), _i8(open), _i8(extend)], queries, candidates, np.uint64)
 
+    def levenshtein_utf8(self, queries, candidates=None, match=0, mismatch=1, open=1, extend=1):
+        name = "levenshtein_utf8" if self._prefix.startswith("szs_ref") else "levenshtein_utf8_cross"
+        return self._run(name, [_i8(match), _i8(mismatch), _i8(open), _i8(extend)], queries, candidates, np.uint64)
+
     def _scores(self, kind, queries, candidates, byte_to_class, class_costs, open, extend):
         byte_to_class = np.ascontiguousarray(byte_to_class, dtype=np.uint8)
         class_costs = np.ascontiguousarray(class_costs, dtype=np.int8).reshape(-1)
@@ -109,7 +113,8 @@ def oracle() -> _Checker:
         if not os.path.exists(_ORACLE_SO):
             build(with_reference=False)
         _oracle_lib = ctypes.CDLL(_ORACLE_SO)
-        for name in ("szo_levenshtein", "szo_levenshtein_linear", "szo_levenshtein_affine", "szo_levenshtein_myers"):
+        for name in ("szo_levenshtein", "szo_levenshtein_linear", "szo_levenshtein_affine", "szo_levenshtein_myers",
+                     "szo_levenshtein_utf8"):
             getattr(_oracle_lib, name).restype = ctypes.c_uint64
         for name in ("szo_needleman_wunsch", "szo_smith_waterman"):
             getattr(_oracle_lib, name).restype = ctypes.c_int64

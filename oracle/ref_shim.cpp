@@ -142,6 +142,27 @@ int szs_ref_levenshtein(int tier, int threads, int8_t match, int8_t mismatch, in
                                                             szs::affine_gap_costs_t {open, extend});
 }
 
+/**
+ *  Codepoint-level Levenshtein through the reference's UTF-8 engines (serial.hpp:678,685; SIMD siblings exist for
+ *  linear gaps only, mirroring the ladder of c/stringzillas/levenshtein.cuh:266-312).
+ */
+int szs_ref_levenshtein_utf8(int tier, int threads, int8_t match, int8_t mismatch, int8_t open, int8_t extend,
+                             char const *q_data, uint64_t const *q_offsets, size_t q_count, //
+                             char const *c_data, uint64_t const *c_offsets, size_t c_count, //
+                             size_t *results, size_t stride) {
+    views_t queries = views_from_tape(q_data, q_offsets, q_count);
+    views_t candidates_storage;
+    views_t const *candidates = nullptr;
+    if (c_data || c_offsets) candidates_storage = views_from_tape(c_data, c_offsets, c_count), candidates = &candidates_storage;
+    szs::uniform_substitution_costs_t subs {match, mismatch};
+    if (open == extend)
+        return dispatch_tier<size_t, szs::levenshtein_utf8_serial_t, szs::levenshtein_utf8_haswell_t,
+                             szs::levenshtein_utf8_icelake_t>(tier, queries, candidates, results, stride, threads, subs,
+                                                              szs::linear_gap_costs_t {open});
+    return run_cross<size_t>([&] { return szs::affine_levenshtein_utf8_serial_t {subs, szs::affine_gap_costs_t {open, extend}}; },
+                             queries, candidates, results, stride, threads);
+}
+
 int szs_ref_needleman_wunsch(int tier, int threads, uint8_t const *byte_to_class, int8_t const *class_costs,
                              int8_t open, int8_t extend,                                      //
                              char const *q_data, uint64_t const *q_offsets, size_t q_count, //

@@ -44,6 +44,15 @@ uint64_t szo_levenshtein_myers(char const *q, size_t q_len, char const *c, size_
 uint64_t szo_levenshtein(char const *q, size_t q_len, char const *c, size_t c_len, int8_t match, int8_t mismatch,
                          int8_t open, int8_t extend);
 
+/** `sz_rune_decode_unchecked` over a whole string (include/stringzilla/utf8_runes/serial.h:111-124): returns the rune
+ *  count; `runes` needs room for `length` entries.  Bytes missing from a truncated final sequence read as zero. */
+size_t szo_utf8_decode(char const *utf8, size_t length, uint32_t *runes);
+
+/** Codepoint-level Levenshtein distance, linear or affine gaps: restates `levenshtein_distance_utf8`,
+ *  serial.hpp:2704-2900 (transcode both sides, then the same recurrences over 32-bit symbols). */
+uint64_t szo_levenshtein_utf8(char const *q, size_t q_len, char const *c, size_t c_len, int8_t match, int8_t mismatch,
+                              int8_t open, int8_t extend);
+
 /** Needleman-Wunsch global score; `open == extend` selects the linear recurrence (needleman_wunsch.cuh:99-118).
  *  Restates test/similarities.cuh:72-98 (linear), :185-229 (Gotoh) and serial.hpp:2910-3007.
  *  cost(a, b) = class_costs[byte_to_class[(u8)a] * 32 + byte_to_class[(u8)b]]   (serial.hpp:199-204). */
@@ -62,6 +71,10 @@ int64_t szo_smith_waterman(char const *q, size_t q_len, char const *c, size_t c_
 void szo_levenshtein_cross(char const *q_data, uint64_t const *q_offsets, size_t q_count, char const *c_data,
                            uint64_t const *c_offsets, size_t c_count, int8_t match, int8_t mismatch, int8_t open,
                            int8_t extend, uint64_t *results, size_t stride);
+
+void szo_levenshtein_utf8_cross(char const *q_data, uint64_t const *q_offsets, size_t q_count, char const *c_data,
+                                uint64_t const *c_offsets, size_t c_count, int8_t match, int8_t mismatch, int8_t open,
+                                int8_t extend, uint64_t *results, size_t stride);
 
 void szo_needleman_wunsch_cross(char const *q_data, uint64_t const *q_offsets, size_t q_count, char const *c_data,
                                 uint64_t const *c_offsets, size_t c_count, uint8_t const *byte_to_class,

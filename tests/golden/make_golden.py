@@ -115,5 +115,50 @@ def main():
     print(f"wrote {path}: {len(cases)} cases, {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def main_utf8():
+    """Codepoint-level goldens from the reference's UTF-8 engines (serial.hpp:678,685) -> reference_utf8_matrices.json.
+    Alphabets mix 1/2/3/4-byte runes like the reference's own fuzz ("AÉ中😀", test/similarities.cuh:1504); the degenerate
+    corpus is test/similarities.py:678-687; lengths are in RUNES."""
+    ref = ob.reference(tier=0)
+    rng = random.Random(20260922)
+    pools = {"mixed": "AÉ中😀", "latin_cyrillic": "abc абв", "cjk": "日本語中文字漢", "ascii": "ABC", "wide": "aé中😀bñ語🚀 "}
+    shapes = [("one_by_many", 1, 9, 1, 48), ("many_by_one", 9, 1, 1, 48), ("ragged_square", 6, 6, 0, 40),
+              ("rectangular", 4, 40, 1, 48), ("straddles_words", 5, 5, 60, 70), ("beyond_short_kernel", 3, 4, 250, 300)]
+    costs_list = [(0, 1, 1, 1), (1, 3, 3, 3), (0, 1, 4, 2), (0, 4, 3, 3)]
+    cases = []
+
+    def text(pool, lo, hi):
+        return "".join(rng.choice(pool) for _ in range(rng.randint(lo, hi))).encode("utf-8")
+
+    for name, q_count, c_count, lo, hi in shapes:
+        for pool_name, pool in pools.items():
+            queries = [text(pool, lo, hi) for _ in range(q_count)]
+            candidates = [text(pool, lo, hi) for _ in range(c_count)]
+            if name == "ragged_square":
+                queries[2] = b""
+                candidates[4] = b""
+            for costs in costs_list:
+                cases.append(dict(name=f"{name}/{pool_name}", costs=list(costs), queries=hexes(queries),
+                                  candidates=hexes(candidates),
+                                  matrix=ref.levenshtein_utf8(queries, candidates, *costs).tolist(),
+                                  symmetric=ref.levenshtein_utf8(queries, None, *costs).tolist()))
+    degenerate = ["", "x", "é", "🚀", "あ" * 10, "abcXYZ123", "こんにちは世界" * 5, "あ" * 600 + "い" * 20]
+    degenerate = [s.encode("utf-8") for s in degenerate]
+    for costs in costs_list:
+        cases.append(dict(name="degenerate_corpus", costs=list(costs), queries=hexes(degenerate),
+                          candidates=hexes(degenerate),
+                          matrix=ref.levenshtein_utf8(degenerate, degenerate, *costs).tolist(),
+                          symmetric=ref.levenshtein_utf8(degenerate, None, *costs).tolist()))
+    out = dict(generator="tests/golden/make_golden.py (main_utf8)",
+               source="oracle/_ref/libszs_ref.so = reference v5.1.2 levenshtein_utf8_serial_t / "
+                      "affine_levenshtein_utf8_serial_t (serial.hpp:678,685)", cases=cases)
+    path = os.path.join(HERE, "reference_utf8_matrices.json")
+    with open(path, "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+    print(f"wrote {path}: {len(cases)} cases, {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 if __name__ == "__main__":
-    main()
+    if "--utf8-only" not in sys.argv:
+        main()
+    main_utf8()
