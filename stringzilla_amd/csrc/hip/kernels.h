@@ -46,6 +46,22 @@ int szs_hip_levenshtein_myers(unsigned words, szs_string_ref_t const *queries, u
                               szs_string_ref_t const *candidates, uint32_t candidates_count, uint64_t *results,
                               uint64_t results_row_stride, int symmetric, void *stream);
 
+/**
+ *  Codepoint-level twin of the short-query bit-parallel kernel: strings are UTF-32 arrays (`address` points at `u32`
+ *  runes, `length` counts runes) produced by szs_hip_utf8_transcode; every query has at most 256 runes.
+ */
+int szs_hip_levenshtein_myers_runes(szs_string_ref_t const *queries, uint32_t queries_count,
+                                    szs_string_ref_t const *candidates, uint32_t candidates_count, uint64_t *results,
+                                    uint64_t results_row_stride, int symmetric, void *stream);
+
+/**
+ *  Transcodes `count` UTF-8 strings (byte refs) into UTF-32 with the value contract of `sz_rune_decode_unchecked`:
+ *  string i's runes land at `runes + rune_starts[i]`, its rune count in `rune_counts[i]`; `*any_multibyte` is OR-ed
+ *  with 1 when any string holds a byte >= 0x80 (the caller zeroes it).  One thread per string.
+ */
+int szs_hip_utf8_transcode(szs_string_ref_t const *strings, uint32_t count, uint64_t const *rune_starts, uint32_t *runes,
+                           uint32_t *rune_counts, uint32_t *any_multibyte, void *stream);
+
 /** Scoring model handed to the weighted kernels; lives in device memory, one per engine. */
 typedef struct szs_cost_model_t {
     int16_t substitution[32 * 32]; /* [query class][candidate class]; Levenshtein engines: negated costs */
@@ -58,7 +74,8 @@ typedef struct szs_cost_model_t {
 enum {
     szs_objective_global_k = 0,      /* Needleman-Wunsch: bottom-right cell */
     szs_objective_local_k = 1,       /* Smith-Waterman: best cell, substitution branch clamped at 0 */
-    szs_objective_distance_k = 2     /* weighted Levenshtein: global on negated uniform costs, result negated */
+    szs_objective_distance_k = 2,    /* weighted Levenshtein: global on negated uniform costs, result negated */
+    szs_objective_distance_runes_k = 3 /* the same over UTF-32 strings (addresses point at u32 runes, lengths in runes) */
 };
 
 /**

@@ -41,26 +41,43 @@ namespace szs_hip {
 #define SZS_MYERS_SHORT_TEXT_DWORDS 4 // text dwords per main-loop iteration of the short-query bodies
 #endif
 
-/** LDS image of Peq for a W-word pattern: 16-byte rows for W >= 3 (ds_read_b128), 8 for W = 2, 4 for W = 1. */
-template <int words_>
+constexpr int byte_rows_k = 256;        // Peq rows of the byte kernels: one per byte value
+constexpr int rune_slots_k = 512;       // Peq rows of the rune kernels: one per slot of the open-addressing rune table
+constexpr u32 rune_slot_empty_k = ~0u;  // no decoded rune has this value (4-byte sequences top out below 2^21)
+
+/** LDS image of Peq for a W-word pattern: 16-byte rows for W >= 3 (ds_read_b128), 8 for W = 2, 4 for W = 1.
+ *  A row belongs to a byte value (byte kernels) or to a slot of the rune hash table (codepoint kernels). */
+template <int words_, int rows_ = byte_rows_k>
 struct peq_layout {
     static constexpr int chunk_words = words_ >= 3 ? 4 : words_;             // words fetched by one LDS read
-    static constexpr int chunks = (words_ + chunk_words - 1) / chunk_words;  // LDS reads per text byte
-    static constexpr int total_dwords = chunks * 256 * chunk_words;
-    /** dword index of word `w` of the mask of byte `symbol`: [chunk][symbol][word in chunk] */
-    __device__ static constexpr int dword_index(int symbol, int w) {
-        return ((w / chunk_words) * 256 + symbol) * chunk_words + (w % chunk_words);
+    static constexpr int chunks = (words_ + chunk_words - 1) / chunk_words;  // LDS reads per text symbol
+    static constexpr int total_dwords = chunks * rows_ * chunk_words;
+    /** dword index of word `w` of the mask in row `row`: [chunk][row][word in chunk] */
+    __device__ static constexpr int dword_index(int row, int w) {
+        return ((w / chunk_words) * rows_ + row) * chunk_words + (w % chunk_words);
     }
 };
 
-template <int words_>
+/** Slot of `rune` in the workgroup's open-addressing table, or the empty slot its probe sequence ends on - whose Peq
+ *  row is all zeros, exactly the match mask of a symbol the pattern does not contain. */
+__device__ __forceinline__ u32 rune_slot_hash(u32 rune) { return (rune * 2654435761u) >> 23; }
+__device__ __forceinline__ u32 find_rune_slot(u32 const *keys, u32 rune) {
+    u32 slot = rune_slot_hash(rune);
+    for (;;) {
+        u32 const key = keys[slot];
+        if (key == rune || key == rune_slot_empty_k) return slot;
+        slot = (slot + 1) & (rune_slots_k - 1);
+    }
+}
+
+template <int words_, int rows_>
 __device__ __forceinline__ void load_match_masks(u32 const *peq, u32 symbol, u32 (&eq)[words_]) {
-    using layout = peq_layout<words_>;
+    using layout = peq_layout<words_, rows_>;
     if constexpr (layout::chunk_words == 4) {
         uint4 const *rows = reinterpret_cast<uint4 const *>(peq);
 #pragma unroll
         for (int chunk = 0; chunk < layout::chunks; ++chunk) {
-            uint4 const row = rows[chunk * 256 + symbol];
+            uint4 const row = rows[chunk * rows_ + symbol];
             if (chunk * 4 + 0 < words_) eq[chunk * 4 + 0] = row.x;
             if (chunk * 4 + 1 < words_) eq[chunk * 4 + 1] = row.y;
             if (chunk * 4 + 2 < words_) eq[chunk * 4 + 2] = row.z;
@@ -96,19 +113,6 @@ __device__ __forceinline__ void myers_column(u32 (&vp)[words_], u32 (&vn)[words_
     }
 }
 
-/** Advances one lane by `4 * dwords_` text columns whose bytes are packed in `symbols`; every lane takes every column. */
-template <int words_, int dwords_>
-__device__ __forceinline__ void myers_advance(u32 const *peq, u32 (&vp)[words_], u32 (&vn)[words_],
-                                              u32 const (&symbols)[dwords_]) {
-#pragma unroll
-    for (int step = 0; step < 4 * dwords_; ++step) {
-        u32 const symbol = (symbols[step / 4] >> (8 * (step % 4))) & 0xFFu;
-        u32 eq[words_];
-        load_match_masks<words_>(peq, symbol, eq);
-        myers_column<words_>(vp, vn, eq);
-    }
-}
-
 /**
  *  One workgroup: one query against 256 candidates, one candidate per lane.
  *
@@ -121,23 +125,42 @@ __device__ __forceinline__ void myers_advance(u32 const *peq, u32 (&vp)[words_],
  *      `column < text length`, finished lanes are simply masked off.
  *  Candidates arrive length-sorted, so the ragged tail is a handful of columns unless the batch itself is ragged.
  *
- *  @tparam words_        32-bit words of the pattern bit-vector; the query fits in 32 * words_ bytes.
- *  @tparam text_dwords_  text dwords consumed per main-loop iteration (4 bytes each): 4 for short patterns, 1 for long
- *                        ones to keep the unrolled body inside the instruction cache.
+ *  @tparam words_        32-bit words of the pattern bit-vector; the query fits in 32 * words_ symbols.
+ *  @tparam text_dwords_  text dwords consumed per main-loop iteration: 4 for short patterns, 1 for long ones to keep
+ *                        the unrolled body inside the instruction cache.  Bytes: 4 columns per dword; runes: 1.
+ *  @tparam runes_        symbols are UTF-32 codepoints (strings are `u32` arrays, lengths count runes) and Peq is keyed
+ *                        through the workgroup's rune table `keys` instead of directly by byte value.
  */
-template <int words_, int text_dwords_>
-__device__ __forceinline__ void myers_workgroup(u32 *peq, szs_string_ref_t const query,
+template <int words_, int text_dwords_, bool runes_>
+__device__ __forceinline__ void myers_workgroup(u32 *peq, u32 *keys, szs_string_ref_t const query,
                                                 szs_string_ref_t const *__restrict__ candidates, u32 candidates_count,
                                                 u32 candidate_block, u64 *__restrict__ results, u64 results_row_stride,
                                                 int symmetric) {
-    using layout = peq_layout<words_>;
+    constexpr int rows = runes_ ? rune_slots_k : byte_rows_k;
+    using layout = peq_layout<words_, rows>;
     u32 const query_length = query.length;
     u32 const pad = 32u * words_ - query_length; // phantom low rows
 
-    // ---- Peq: zero, then scatter the pattern's bits (LDS atomics; a 128-byte query is 128 ORs per workgroup).
+    // ---- Peq: zero, then scatter the pattern's bits (LDS atomics; a 128-symbol query is 128 ORs per workgroup).
     for (int i = threadIdx.x; i < layout::total_dwords; i += 256) peq[i] = 0;
+    if constexpr (runes_)
+        for (int i = threadIdx.x; i < rune_slots_k; i += 256) keys[i] = rune_slot_empty_k;
     __syncthreads();
-    {
+    if constexpr (runes_) {
+        u32 const *pattern = reinterpret_cast<u32 const *>(query.address);
+        for (u32 i = threadIdx.x; i < query_length; i += 256) {
+            u32 const rune = pattern[i];
+            u32 slot = rune_slot_hash(rune); // claim the rune's slot: at most 256 distinct runes in 512 slots
+            for (;;) {
+                u32 const previous = atomicCAS(&keys[slot], rune_slot_empty_k, rune);
+                if (previous == rune_slot_empty_k || previous == rune) break;
+                slot = (slot + 1) & (rune_slots_k - 1);
+            }
+            u32 const position = pad + i;
+            atomicOr(&peq[layout::dword_index((int)slot, (int)(position >> 5))], 1u << (position & 31));
+        }
+    }
+    else {
         u8 const *pattern = reinterpret_cast<u8 const *>(query.address);
         for (u32 i = threadIdx.x; i < query_length; i += 256) {
             u32 const position = pad + i;
@@ -164,42 +187,72 @@ __device__ __forceinline__ void myers_workgroup(u32 *peq, szs_string_ref_t const
         vn[w] = 0;
     }
 
-    // `raw_low` is text dword `dword`; `ahead[d]` is text dword `dword + 1 + d`, loaded one iteration early.
-    text_stream_t const text(candidate.address, text_length);
-    u32 raw_low = text.raw(0);
-    u32 column = 0, dword = 0;
-    constexpr u32 columns_per_iteration = 4 * text_dwords_;
-    if (columns_per_iteration <= shortest_in_wave && longest_in_wave) {
-        u32 ahead[text_dwords_];
+    // One DP column: the match masks of `symbol` (a byte, or a rune looked up through the rune table) update VP / VN.
+    auto take = [&](u32 symbol) {
+        u32 eq[words_];
+        load_match_masks<words_, rows>(peq, runes_ ? find_rune_slot(keys, symbol) : symbol, eq);
+        myers_column<words_>(vp, vn, eq);
+    };
+
+    u32 column = 0;
+    if constexpr (runes_) {
+        // ---- codepoints: one aligned dword per column
+        u32 const *const runes = reinterpret_cast<u32 const *>(candidate.address);
+        auto rune_at = [&](u32 index) -> u32 { return index < text_length ? runes[index] : 0u; };
+        constexpr u32 columns_per_iteration = 2 * text_dwords_ > 4 ? 4 : 2 * text_dwords_; // keep the prefetch window small
+        if (columns_per_iteration <= shortest_in_wave && longest_in_wave) {
+            u32 ahead[columns_per_iteration];
 #pragma unroll
-        for (int d = 0; d < text_dwords_; ++d) ahead[d] = text.raw(1 + d);
-        for (; column + columns_per_iteration <= shortest_in_wave; column += columns_per_iteration, dword += text_dwords_) {
-            u32 symbols[text_dwords_];
-            symbols[0] = text.splice(raw_low, ahead[0]);
+            for (u32 d = 0; d < columns_per_iteration; ++d) ahead[d] = rune_at(d);
+            for (; column + columns_per_iteration <= shortest_in_wave; column += columns_per_iteration) {
+                u32 symbols[columns_per_iteration];
 #pragma unroll
-            for (int d = 1; d < text_dwords_; ++d) symbols[d] = text.splice(ahead[d - 1], ahead[d]);
-            raw_low = ahead[text_dwords_ - 1];
-            // Issue the next iteration's loads now; they retire under the VALU work below.
+                for (u32 d = 0; d < columns_per_iteration; ++d) symbols[d] = ahead[d];
 #pragma unroll
-            for (int d = 0; d < text_dwords_; ++d) ahead[d] = text.raw(dword + text_dwords_ + 1 + d);
-            myers_advance<words_, text_dwords_>(peq, vp, vn, symbols);
+                for (u32 d = 0; d < columns_per_iteration; ++d) ahead[d] = rune_at(column + columns_per_iteration + d);
+#pragma unroll
+                for (u32 d = 0; d < columns_per_iteration; ++d) take(symbols[d]);
+            }
         }
-    }
-    // ---- ragged tail: one dword (4 columns) per iteration, each column predicated on this lane's own length.
-    if (column < longest_in_wave) {
-        u32 next = text.raw(dword + 1);
 #pragma unroll 1
-        for (; column < longest_in_wave; column += 4, ++dword) {
-            u32 const after = text.raw(dword + 2);
-            u32 const symbols = text.splice(raw_low, next);
-            raw_low = next, next = after;
+        for (; column < longest_in_wave; ++column)
+            if (column < text_length) take(runes[column]);
+    }
+    else {
+        // ---- bytes: `raw_low` is text dword `dword`; `ahead[d]` is text dword `dword + 1 + d`, loaded one iteration early
+        text_stream_t const text(candidate.address, text_length);
+        u32 raw_low = text.raw(0);
+        u32 dword = 0;
+        constexpr u32 columns_per_iteration = 4 * text_dwords_;
+        if (columns_per_iteration <= shortest_in_wave && longest_in_wave) {
+            u32 ahead[text_dwords_];
 #pragma unroll
-            for (int step = 0; step < 4; ++step) {
-                if (column + step < text_length) {
-                    u32 eq[words_];
-                    load_match_masks<words_>(peq, (symbols >> (8 * step)) & 0xFFu, eq);
-                    myers_column<words_>(vp, vn, eq);
-                }
+            for (int d = 0; d < text_dwords_; ++d) ahead[d] = text.raw(1 + d);
+            for (; column + columns_per_iteration <= shortest_in_wave;
+                 column += columns_per_iteration, dword += text_dwords_) {
+                u32 symbols[text_dwords_];
+                symbols[0] = text.splice(raw_low, ahead[0]);
+#pragma unroll
+                for (int d = 1; d < text_dwords_; ++d) symbols[d] = text.splice(ahead[d - 1], ahead[d]);
+                raw_low = ahead[text_dwords_ - 1];
+                // Issue the next iteration's loads now; they retire under the VALU work below.
+#pragma unroll
+                for (int d = 0; d < text_dwords_; ++d) ahead[d] = text.raw(dword + text_dwords_ + 1 + d);
+#pragma unroll
+                for (int step = 0; step < 4 * text_dwords_; ++step) take((symbols[step / 4] >> (8 * (step % 4))) & 0xFFu);
+            }
+        }
+        // ---- ragged tail: one dword (4 columns) per iteration, each column predicated on this lane's own length.
+        if (column < longest_in_wave) {
+            u32 next = text.raw(dword + 1);
+#pragma unroll 1
+            for (; column < longest_in_wave; column += 4, ++dword) {
+                u32 const after = text.raw(dword + 2);
+                u32 const symbols = text.splice(raw_low, next);
+                raw_low = next, next = after;
+#pragma unroll
+                for (int step = 0; step < 4; ++step)
+                    if (column + step < text_length) take((symbols >> (8 * step)) & 0xFFu);
             }
         }
     }
@@ -231,32 +284,34 @@ __global__ __launch_bounds__(256) void levenshtein_myers_long_kernel(szs_string_
     __shared__ __attribute__((aligned(16))) u32 peq[peq_layout<words_>::total_dwords];
     u32 query_slot, candidate_block;
     myers_work_item(candidate_blocks, query_slot, candidate_block);
-    myers_workgroup<words_, 1>(peq, queries[query_slot], candidates, candidates_count, candidate_block, results,
-                               results_row_stride, symmetric);
+    myers_workgroup<words_, 1, false>(peq, nullptr, queries[query_slot], candidates, candidates_count, candidate_block,
+                                      results, results_row_stride, symmetric);
 }
 
-/**
- *  Short queries (up to 256 bytes = 8 words), ANY mix of lengths in ONE launch: the width is a per-workgroup (scalar)
- *  decision, so every query runs at exactly ceil(length / 32) words, and a batch whose queries straddle several widths
- *  needs neither one launch per width nor padding to a common width.  All eight bodies fit the 64-VGPR budget.
- */
 #ifndef SZS_MYERS_SHORT_WAVES
 #define SZS_MYERS_SHORT_WAVES 1
 #endif
-__global__ __launch_bounds__(256, SZS_MYERS_SHORT_WAVES) void levenshtein_myers_short_kernel(szs_string_ref_t const *__restrict__ queries,
-                                                                       szs_string_ref_t const *__restrict__ candidates,
-                                                                       u32 candidates_count, u32 candidate_blocks,
-                                                                       u64 *__restrict__ results, u64 results_row_stride,
-                                                                       int symmetric) {
-    __shared__ __attribute__((aligned(16))) u32 peq[peq_layout<8>::total_dwords];
+/**
+ *  Short queries (up to 256 symbols = 8 words), ANY mix of lengths in ONE launch: the width is a per-workgroup (scalar)
+ *  decision, so every query runs at exactly ceil(length / 32) words, and a batch whose queries straddle several widths
+ *  needs neither one launch per width nor padding to a common width.  All eight byte bodies fit the 64-VGPR budget.
+ *  `runes_`: the codepoint-level twin - strings are UTF-32 arrays produced by utf8.hip, Peq is keyed by a rune table.
+ */
+template <bool runes_>
+__global__ __launch_bounds__(256, SZS_MYERS_SHORT_WAVES) void levenshtein_myers_short_kernel(
+    szs_string_ref_t const *__restrict__ queries, szs_string_ref_t const *__restrict__ candidates, u32 candidates_count,
+    u32 candidate_blocks, u64 *__restrict__ results, u64 results_row_stride, int symmetric) {
+    __shared__ __attribute__((aligned(16))) u32 peq[peq_layout<8, runes_ ? rune_slots_k : byte_rows_k>::total_dwords];
+    __shared__ u32 keys[runes_ ? rune_slots_k : 1];
     u32 query_slot, candidate_block;
     myers_work_item(candidate_blocks, query_slot, candidate_block);
     szs_string_ref_t const query = queries[query_slot];
     u32 const words = __builtin_amdgcn_readfirstlane(query.length ? (query.length + 31u) / 32u : 1u);
 #define SZS_MYERS_BODY(W)                                                                                              \
     case W:                                                                                                            \
-        myers_workgroup<W, SZS_MYERS_SHORT_TEXT_DWORDS>(peq, query, candidates, candidates_count, candidate_block,    \
-                                                        results, results_row_stride, symmetric);                      \
+        myers_workgroup<W, SZS_MYERS_SHORT_TEXT_DWORDS, runes_>(peq, keys, query, candidates, candidates_count,       \
+                                                                candidate_block, results, results_row_stride,         \
+                                                                symmetric);                                           \
         break;
     switch (words) {
         SZS_MYERS_BODY(1)
@@ -267,8 +322,8 @@ __global__ __launch_bounds__(256, SZS_MYERS_SHORT_WAVES) void levenshtein_myers_
         SZS_MYERS_BODY(6)
         SZS_MYERS_BODY(7)
     default: // 8; the host never sends longer queries here
-        myers_workgroup<8, SZS_MYERS_SHORT_TEXT_DWORDS>(peq, query, candidates, candidates_count, candidate_block, results,
-                                                        results_row_stride, symmetric);
+        myers_workgroup<8, SZS_MYERS_SHORT_TEXT_DWORDS, runes_>(peq, keys, query, candidates, candidates_count,
+                                                                candidate_block, results, results_row_stride, symmetric);
         break;
     }
 #undef SZS_MYERS_BODY
@@ -305,7 +360,7 @@ extern "C" int szs_hip_levenshtein_myers(unsigned words, szs_string_ref_t const 
                             results, results_row_stride, symmetric, s);
     switch (words) {
     case SZS_MYERS_SHORT_WORDS:
-        return launch_myers(levenshtein_myers_short_kernel, queries, queries_count, candidates, candidates_count, results,
+        return launch_myers(levenshtein_myers_short_kernel<false>, queries, queries_count, candidates, candidates_count, results,
                             results_row_stride, symmetric, s);
         SZS_MYERS_CASE(10)
         SZS_MYERS_CASE(12)
@@ -318,6 +373,16 @@ extern "C" int szs_hip_levenshtein_myers(unsigned words, szs_string_ref_t const 
     default: return (int)hipErrorInvalidValue;
     }
 #undef SZS_MYERS_CASE
+}
+
+extern "C" int szs_hip_levenshtein_myers_runes(szs_string_ref_t const *queries, uint32_t queries_count,
+                                               szs_string_ref_t const *candidates, uint32_t candidates_count,
+                                               uint64_t *results, uint64_t results_row_stride, int symmetric,
+                                               void *stream) {
+    using namespace szs_hip;
+    if (!queries_count || !candidates_count) return 0;
+    return launch_myers(levenshtein_myers_short_kernel<true>, queries, queries_count, candidates, candidates_count, results,
+                        results_row_stride, symmetric, static_cast<hipStream_t>(stream));
 }
 
 /** The launch variant for a query of `words` 32-bit words: SZS_MYERS_SHORT_WORDS for everything the mixed-width kernel

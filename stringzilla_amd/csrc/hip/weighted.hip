@@ -135,8 +135,12 @@ __device__ __forceinline__ void advance_column(strip_column_t<affine_> &column, 
  *  @tparam affine_   Gotoh's three-track recurrence instead of the single-track linear one.
  *  @tparam uniform_  costs are (match, mismatch) on raw bytes - weighted Levenshtein, computed as a maximisation of
  *                    negated costs and negated back on output - instead of the 32x32 class table.
+ *  @tparam runes_    (with uniform_) symbols are UTF-32 codepoints: strings are `u32` arrays produced by utf8.hip, lengths
+ *                    count runes, and the strip profile is keyed by the slots of a 64-entry rune table of the strip's own
+ *                    (at most 32 distinct) runes instead of by byte value; a rune the strip does not contain probes to
+ *                    an empty slot, whose profile row is "mismatch against every row".
  */
-template <bool local_, bool affine_, bool uniform_>
+template <bool local_, bool affine_, bool uniform_, bool runes_ = false>
 __global__ __launch_bounds__(256) void weighted_scores_kernel(
     szs_cost_model_t const *__restrict__ model, szs_string_ref_t const *__restrict__ queries, u32 queries_count,
     szs_string_ref_t const *__restrict__ candidates, u32 candidates_count, u32 candidate_blocks,
@@ -149,6 +153,18 @@ __global__ __launch_bounds__(256) void weighted_scores_kernel(
     __shared__ u8 class_of_byte[256];
     __shared__ u8 strip_classes[rows];                                  // classes (uniform_: bytes) of the strip's rows
     __shared__ u32 claimed_work;
+    constexpr u32 strip_slots = 64, strip_slot_empty = ~0u; // rune table of one strip: load factor <= 1/2
+    __shared__ u32 strip_keys[runes_ ? strip_slots : 1];
+    __shared__ u32 strip_runes[runes_ ? rows : 1];
+    static_assert(!runes_ || uniform_, "codepoint scoring exists for uniform costs only");
+    auto strip_slot_of = [&](u32 rune) -> u32 { // the rune's slot, or the empty slot its probe sequence ends on
+        u32 slot = (rune * 2654435761u) >> 26;
+        for (;;) {
+            u32 const key = strip_keys[slot];
+            if (key == rune || key == strip_slot_empty) return slot;
+            slot = (slot + 1) & (strip_slots - 1);
+        }
+    };
 
     i32 const gap_open = model->gap_open, gap_extend = model->gap_extend;
     if constexpr (!uniform_) {
@@ -205,22 +221,38 @@ __global__ __launch_bounds__(256) void weighted_scores_kernel(
             bool const is_first_strip = first_row == 0;
             bool const is_last_strip = first_row + rows >= query_length;
 
-            // ---- query profile of this strip: thread t owns candidate byte t
+            // ---- query profile of this strip: thread t owns candidate byte t (runes: rune-table slot t)
             __syncthreads(); // everyone is done with the previous strip's profile (and the table copies are written)
-            if (threadIdx.x < (u32)rows) {
+            if constexpr (runes_) {
+                if (threadIdx.x < strip_slots) strip_keys[threadIdx.x] = strip_slot_empty;
+                __syncthreads();
+                if (threadIdx.x < rows_here) {
+                    u32 const rune = reinterpret_cast<u32 const *>(query.address)[first_row + threadIdx.x];
+                    strip_runes[threadIdx.x] = rune;
+                    u32 slot = (rune * 2654435761u) >> 26;
+                    for (;;) {
+                        u32 const previous = atomicCAS(&strip_keys[slot], strip_slot_empty, rune);
+                        if (previous == strip_slot_empty || previous == rune) break;
+                        slot = (slot + 1) & (strip_slots - 1);
+                    }
+                }
+            }
+            else if (threadIdx.x < (u32)rows) {
                 u8 symbol = 0;
                 if (threadIdx.x < rows_here) symbol = pattern[first_row + threadIdx.x];
                 strip_classes[threadIdx.x] = uniform_ ? symbol : class_of_byte[symbol];
             }
             __syncthreads();
-            {
-                u32 const mine = uniform_ ? threadIdx.x : (u32)class_of_byte[threadIdx.x];
+            if (!runes_ || threadIdx.x < strip_slots) {
+                u32 const mine = runes_ ? strip_keys[runes_ ? threadIdx.x % strip_slots : 0]
+                                        : (uniform_ ? threadIdx.x : (u32)class_of_byte[threadIdx.x]);
                 u32 packed[rows / 4];
 #pragma unroll
                 for (int r = 0; r < rows; ++r) {
                     i32 cost = 0; // padded rows: never read back (global) / never counted (local)
                     if ((u32)r < rows_here) {
-                        if constexpr (uniform_) cost = strip_classes[r] == mine ? uniform_match : uniform_mismatch;
+                        if constexpr (runes_) cost = strip_runes[r] == mine ? uniform_match : uniform_mismatch;
+                        else if constexpr (uniform_) cost = strip_classes[r] == mine ? uniform_match : uniform_mismatch;
                         else // cost(query, candidate) = table[class(query)][class(candidate)]: the QUERY picks the row
                             cost = table[(u32)strip_classes[r] * 32 + mine];
                     }
@@ -258,26 +290,45 @@ __global__ __launch_bounds__(256) void weighted_scores_kernel(
             };
 
             u32 column_index = 0, dword = 0; // columns [0, column_index) are done
-            u32 raw_low = text.raw(0);
-            // ---- main loop: whole text dwords that EVERY live lane of the wavefront still has
+            u32 const *const runes = reinterpret_cast<u32 const *>(candidate.address);
+            auto rune_at = [&](u32 index) -> u32 { return index < text_length ? runes[index] : 0u; };
+            u32 raw_low = runes_ ? 0u : text.raw(0);
+            // The profile row of the symbol in column `column_index + step`, given this batch of four columns.
+            auto profile_row = [&](u32 const (&batch)[4], int step) -> u32 {
+                if constexpr (runes_) return strip_slot_of(batch[step]);
+                else return (batch[0] >> (8 * step)) & 0xFFu;
+            };
+            // ---- main loop: whole batches of four columns that EVERY live lane of the wavefront still has
             if (shortest_in_wave >= 4 && longest_in_wave) {
-                u32 raw_high = text.raw(1);
+                u32 raw_high = runes_ ? 0u : text.raw(1);
+                u32 ahead[4] = {0, 0, 0, 0}; // runes: the next batch, loaded one iteration early
+                if constexpr (runes_)
+                    for (int step = 0; step < 4; ++step) ahead[step] = rune_at(step);
                 i32 above_h[4], above_down[4];
 #pragma unroll
                 for (int step = 0; step < 4; ++step) above_of(1 + step, above_h[step], above_down[step]);
                 for (; column_index + 4 <= shortest_in_wave; column_index += 4, ++dword) {
-                    u32 const symbols = text.splice(raw_low, raw_high);
-                    raw_low = raw_high;
-                    raw_high = text.raw(dword + 2);
+                    u32 batch[4];
+                    if constexpr (runes_) {
+#pragma unroll
+                        for (int step = 0; step < 4; ++step) batch[step] = ahead[step];
+#pragma unroll
+                        for (int step = 0; step < 4; ++step) ahead[step] = rune_at(column_index + 4 + step);
+                    }
+                    else {
+                        batch[0] = text.splice(raw_low, raw_high);
+                        raw_low = raw_high;
+                        raw_high = text.raw(dword + 2);
+                    }
                     i32 now_h[4], now_down[4];
 #pragma unroll
                     for (int step = 0; step < 4; ++step) now_h[step] = above_h[step], now_down[step] = above_down[step];
-                    // Prefetch the next dword's boundary cells; the slack columns make the overrun harmless.
+                    // Prefetch the next batch's boundary cells; the slack columns make the overrun harmless.
 #pragma unroll
                     for (int step = 0; step < 4; ++step) above_of(column_index + 5 + step, above_h[step], above_down[step]);
 #pragma unroll
                     for (int step = 0; step < 4; ++step) {
-                        cost_column_t const costs = load_costs(profile, (symbols >> (8 * step)) & 0xFFu);
+                        cost_column_t const costs = load_costs(profile, profile_row(batch, step));
                         advance_column<local_, affine_>(column, costs, now_h[step], now_down[step], diagonal, gap_open,
                                                         gap_extend, down_out, best, rows_here);
                         if (!is_last_strip) {
@@ -289,19 +340,26 @@ __global__ __launch_bounds__(256) void weighted_scores_kernel(
             }
             // ---- ragged rest: every column predicated on this lane's own length
             if (column_index < longest_in_wave) {
-                u32 raw_high = text.raw(dword + 1);
+                u32 raw_high = runes_ ? 0u : text.raw(dword + 1);
 #pragma unroll 1
                 for (; column_index < longest_in_wave; column_index += 4, ++dword) {
-                    u32 const symbols = text.splice(raw_low, raw_high);
-                    raw_low = raw_high;
-                    raw_high = text.raw(dword + 2);
+                    u32 batch[4] = {0, 0, 0, 0};
+                    if constexpr (runes_) {
+#pragma unroll
+                        for (int step = 0; step < 4; ++step) batch[step] = rune_at(column_index + step);
+                    }
+                    else {
+                        batch[0] = text.splice(raw_low, raw_high);
+                        raw_low = raw_high;
+                        raw_high = text.raw(dword + 2);
+                    }
 #pragma unroll
                     for (int step = 0; step < 4; ++step) {
                         u32 const j = column_index + step + 1; // 1-based DP column
                         if (j <= text_length) {
                             i32 above_h, above_down;
                             above_of(j, above_h, above_down);
-                            cost_column_t const costs = load_costs(profile, (symbols >> (8 * step)) & 0xFFu);
+                            cost_column_t const costs = load_costs(profile, profile_row(batch, step));
                             advance_column<local_, affine_>(column, costs, above_h, above_down, diagonal, gap_open,
                                                             gap_extend, down_out, best, rows_here);
                             if (!is_last_strip) {
@@ -333,14 +391,14 @@ __global__ __launch_bounds__(256) void weighted_scores_kernel(
 constexpr size_t weighted_header_bytes_k = 256; // the work counter lives at the head of the boundary workspace
 
 /** Workgroups that can be RESIDENT at once for this kernel instance on the current device (never more than the work). */
-template <bool local_, bool affine_, bool uniform_>
+template <bool local_, bool affine_, bool uniform_, bool runes_ = false>
 static u32 weighted_grid(u64 work_items) {
     static int resident = 0; // per instance; one device architecture per process
     if (!resident) {
         int device = 0, units = 0, per_unit = 0;
         if (hipGetDevice(&device) != hipSuccess ||
             hipDeviceGetAttribute(&units, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_unit, weighted_scores_kernel<local_, affine_, uniform_>,
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_unit, weighted_scores_kernel<local_, affine_, uniform_, runes_>,
                                                          (int)weighted_block_threads_k, 0) != hipSuccess ||
             units <= 0 || per_unit <= 0) {
             (void)hipGetLastError();
@@ -355,26 +413,26 @@ static u64 weighted_work_items(u32 queries_count, u32 candidates_count) {
     return (u64)queries_count * ((candidates_count + weighted_block_threads_k - 1) / weighted_block_threads_k);
 }
 
-template <bool local_, bool affine_, bool uniform_>
+template <bool local_, bool affine_, bool uniform_, bool runes_ = false>
 static size_t weighted_workspace_bytes(u32 queries_count, u32 candidates_count, u32 longest_candidate) {
-    u32 const grid = weighted_grid<local_, affine_, uniform_>(weighted_work_items(queries_count, candidates_count));
+    u32 const grid = weighted_grid<local_, affine_, uniform_, runes_>(weighted_work_items(queries_count, candidates_count));
     return weighted_header_bytes_k + (size_t)grid * (longest_candidate + 1 + weighted_boundary_slack_k) *
                                          weighted_block_threads_k * sizeof(i32) * (affine_ ? 2 : 1);
 }
 
-template <bool local_, bool affine_, bool uniform_>
+template <bool local_, bool affine_, bool uniform_, bool runes_ = false>
 static int launch_weighted(szs_cost_model_t const *model, szs_string_ref_t const *queries, u32 queries_count,
                            szs_string_ref_t const *candidates, u32 candidates_count, u32 longest_candidate, i64 *results,
                            u64 stride, int symmetric, void *workspace, hipStream_t stream) {
     u32 const candidate_blocks = (candidates_count + weighted_block_threads_k - 1) / weighted_block_threads_k;
     u64 const work_items = weighted_work_items(queries_count, candidates_count);
     if (work_items > 0xFFFFFFF0ull) return (int)hipErrorInvalidValue; // the host cuts larger cross-products
-    u32 const grid = weighted_grid<local_, affine_, uniform_>(work_items);
+    u32 const grid = weighted_grid<local_, affine_, uniform_, runes_>(work_items);
     u32 *const counter = static_cast<u32 *>(workspace);
     i32 *const boundary = reinterpret_cast<i32 *>(static_cast<char *>(workspace) + weighted_header_bytes_k);
     hipError_t error = hipMemsetAsync(counter, 0, sizeof(u32), stream);
     if (error != hipSuccess) return (int)error;
-    hipLaunchKernelGGL((weighted_scores_kernel<local_, affine_, uniform_>), dim3(grid), dim3(weighted_block_threads_k), 0,
+    hipLaunchKernelGGL((weighted_scores_kernel<local_, affine_, uniform_, runes_>), dim3(grid), dim3(weighted_block_threads_k), 0,
                        stream, model, queries, queries_count, candidates, candidates_count, candidate_blocks, results,
                        stride, symmetric, boundary, longest_candidate + 1 + weighted_boundary_slack_k, counter);
     return (int)hipGetLastError();
@@ -393,14 +451,17 @@ static int launch_weighted(szs_cost_model_t const *model, szs_string_ref_t const
     case szs_objective_distance_k:                                                                                     \
         if (affine) CALL(false, true, true);                                                                           \
         CALL(false, false, true);                                                                                      \
+    case szs_objective_distance_runes_k:                                                                               \
+        if (affine) CALL(false, true, true, true);                                                                     \
+        CALL(false, false, true, true);                                                                                \
     default: break;                                                                                                    \
     }
 
 extern "C" size_t szs_hip_weighted_boundary_bytes(int objective, int affine, uint32_t queries_count,
                                                   uint32_t candidates_count, uint32_t longest_candidate) {
     using namespace szs_hip;
-#define SZS_WEIGHTED_BYTES(LOCAL, AFFINE, UNIFORM)                                                                     \
-    return weighted_workspace_bytes<LOCAL, AFFINE, UNIFORM>(queries_count, candidates_count, longest_candidate)
+#define SZS_WEIGHTED_BYTES(...)                                                                                       \
+    return weighted_workspace_bytes<__VA_ARGS__>(queries_count, candidates_count, longest_candidate)
     SZS_WEIGHTED_DISPATCH(SZS_WEIGHTED_BYTES)
 #undef SZS_WEIGHTED_BYTES
     return 0;
@@ -414,9 +475,9 @@ extern "C" int szs_hip_weighted_scores(int objective, int affine, szs_cost_model
     using namespace szs_hip;
     if (!queries_count || !candidates_count) return 0;
     hipStream_t const s = static_cast<hipStream_t>(stream);
-#define SZS_WEIGHTED_LAUNCH(LOCAL, AFFINE, UNIFORM)                                                                    \
-    return launch_weighted<LOCAL, AFFINE, UNIFORM>(model, queries, queries_count, candidates, candidates_count,       \
-                                                   longest_candidate, results, results_row_stride, symmetric, boundary, s)
+#define SZS_WEIGHTED_LAUNCH(...)                                                                                      \
+    return launch_weighted<__VA_ARGS__>(model, queries, queries_count, candidates, candidates_count, longest_candidate, \
+                                        results, results_row_stride, symmetric, boundary, s)
     SZS_WEIGHTED_DISPATCH(SZS_WEIGHTED_LAUNCH)
 #undef SZS_WEIGHTED_LAUNCH
     return (int)hipErrorInvalidValue;

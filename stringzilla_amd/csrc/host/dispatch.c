@@ -114,6 +114,68 @@ static sz_status_t gather_strings(szs_input_t const *input, void const *offsets,
     return sz_success_k;
 }
 
+/**
+ *  Transcodes both sides (one side when symmetric) to UTF-32 on the device and, if the corpus is not pure ASCII,
+ *  rewrites `addresses` / `lengths` in place to point at the runes and to count runes.  One extra synchronisation:
+ *  the planner needs the rune counts.  String i's runes start at the prefix sum of BYTE lengths (runes <= bytes).
+ */
+static sz_status_t transcode_to_runes(szs_engine_s *engine, int device, hipStream_t stream, int symmetric,
+                                      uint64_t *q_addresses, uint32_t *q_lengths, uint32_t q_count,
+                                      uint64_t *c_addresses, uint32_t *c_lengths, uint32_t c_count, int *runes,
+                                      char const **error_message) {
+    size_t const strings = (size_t)q_count + (symmetric ? 0 : c_count);
+    /* staging layout, host and device alike: [refs][rune starts][rune counts][flag] */
+    size_t const refs_at = 0, starts_at = refs_at + strings * sizeof(szs_string_ref_t);
+    size_t const counts_at = starts_at + strings * sizeof(uint64_t), flag_at = counts_at + strings * sizeof(uint32_t);
+    size_t const staging_bytes = flag_at + sizeof(uint32_t);
+    sz_status_t status = szs_buffer_reserve(&engine->pinned_transcode, szs_memory_pinned_k, device, staging_bytes, error_message);
+    if (status != sz_success_k) return status;
+    status = szs_buffer_reserve(&engine->device_transcode, szs_memory_device_k, device, staging_bytes, error_message);
+    if (status != sz_success_k) return status;
+
+    char *const host = (char *)engine->pinned_transcode.pointer, *const remote = (char *)engine->device_transcode.pointer;
+    szs_string_ref_t *refs = (szs_string_ref_t *)(host + refs_at);
+    uint64_t *starts = (uint64_t *)(host + starts_at);
+    uint64_t total = 0;
+    for (size_t i = 0; i < strings; ++i) {
+        int const is_query = i < q_count;
+        size_t const k = is_query ? i : i - q_count;
+        refs[i].address = is_query ? q_addresses[k] : c_addresses[k];
+        refs[i].length = is_query ? q_lengths[k] : c_lengths[k];
+        refs[i].index = (uint32_t)i;
+        starts[i] = total, total += refs[i].length;
+    }
+    *(uint32_t *)(host + flag_at) = 0;
+    status = szs_buffer_reserve(&engine->device_runes, szs_memory_device_k, device, (total + 1) * sizeof(uint32_t), error_message);
+    if (status != sz_success_k) return status;
+
+    hipError_t error = hipMemcpyAsync(remote, host, counts_at, hipMemcpyHostToDevice, stream);
+    if (error == hipSuccess) error = hipMemsetAsync(remote + flag_at, 0, sizeof(uint32_t), stream);
+    if (error != hipSuccess) return szs_report_hip(error, error_message);
+    int const launch_error = szs_hip_utf8_transcode(
+        (szs_string_ref_t const *)(remote + refs_at), (uint32_t)strings, (uint64_t const *)(remote + starts_at),
+        (uint32_t *)engine->device_runes.pointer, (uint32_t *)(remote + counts_at), (uint32_t *)(remote + flag_at), stream);
+    if (launch_error) return szs_report_hip((hipError_t)launch_error, error_message);
+    error = hipMemcpyAsync(host + counts_at, remote + counts_at, staging_bytes - counts_at, hipMemcpyDeviceToHost, stream);
+    if (error == hipSuccess) error = hipStreamSynchronize(stream);
+    if (error != hipSuccess) return szs_report_hip(error, error_message);
+
+    *runes = *(uint32_t const *)(host + flag_at) != 0;
+    if (!*runes) return sz_success_k;
+    uint32_t const *counts = (uint32_t const *)(host + counts_at);
+    uint64_t const base = (uint64_t)(uintptr_t)engine->device_runes.pointer;
+    for (size_t i = 0; i < strings; ++i) {
+        uint64_t const address = base + starts[i] * sizeof(uint32_t);
+        if (i < q_count) q_addresses[i] = address, q_lengths[i] = counts[i];
+        else c_addresses[i - q_count] = address, c_lengths[i - q_count] = counts[i];
+    }
+    if (symmetric) {
+        memcpy(c_addresses, q_addresses, (size_t)q_count * sizeof(uint64_t));
+        memcpy(c_lengths, q_lengths, (size_t)q_count * sizeof(uint32_t));
+    }
+    return sz_success_k;
+}
+
 static void fill_cost_model(szs_engine_s const *engine, szs_cost_model_t *model) {
     memset(model, 0, sizeof(*model));
     if (engine->family == szs_family_levenshtein_k || engine->family == szs_family_levenshtein_utf8_k) {
@@ -135,6 +197,9 @@ static void release_device_state(szs_engine_s *engine) {
     szs_buffer_release(&engine->device_boundary);
     szs_buffer_release(&engine->device_model);
     szs_buffer_release(&engine->device_tape);
+    szs_buffer_release(&engine->device_runes);
+    szs_buffer_release(&engine->device_transcode);
+    szs_buffer_release(&engine->pinned_transcode);
     if (engine->events_device >= 0) {
         (void)hipEventDestroy(engine->event_start);
         (void)hipEventDestroy(engine->event_stop);
@@ -161,8 +226,6 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
     if (!engine || engine->magic != SZS_ENGINE_MAGIC)
         return szs_report(sz_status_unknown_k, error_message, "Engine must be initialized");
     if (!queries) return szs_report(sz_status_unknown_k, error_message, "Queries must not be null");
-    if (engine->family == szs_family_levenshtein_utf8_k) /* a "next" row, not built yet */
-        return szs_report(sz_status_unknown_k, error_message, "UTF-8 codepoint distances are not implemented in the ROCm build yet");
 
     int device = 0;
     hipStream_t stream = NULL;
@@ -244,12 +307,23 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
         if (status != sz_success_k) return status;
     }
 
+    /* Codepoint-level engine: transcode every string to UTF-32 ONCE (hip/utf8.hip), then plan and score on runes.  When
+     * no string holds a byte >= 0x80 the corpus is ASCII and the byte kernels compute the same distances - the
+     * reference takes the same shortcut pair by pair (serial.hpp:2809-2813). */
+    int runes = 0;
+    if (engine->family == szs_family_levenshtein_utf8_k) {
+        status = transcode_to_runes(engine, device, stream, symmetric, q_addresses, q_lengths, q_count, c_addresses,
+                                    c_lengths, c_count, &runes, error_message);
+        if (status != sz_success_k) return status;
+    }
+
     /* Plan straight into the pinned staging area, then ship both ref arrays in one copy. */
     szs_string_ref_t *host_query_refs = (szs_string_ref_t *)engine->pinned_staging.pointer;
     szs_string_ref_t *host_candidate_refs = host_query_refs + q_count;
     szs_plan_t plan;
-    int const use_myers = engine->family == szs_family_levenshtein_k && engine->is_unit_cost;
-    szs_plan_build(use_myers, symmetric, q_addresses, q_lengths, q_count, c_addresses, c_lengths, c_count,
+    int const use_myers = engine->is_unit_cost && (engine->family == szs_family_levenshtein_k ||
+                                                   engine->family == szs_family_levenshtein_utf8_k);
+    szs_plan_build(!use_myers ? 0 : runes ? SZS_MYERS_SHORT_WORDS : SZS_MYERS_MAX_WORDS, symmetric, q_addresses, q_lengths, q_count, c_addresses, c_lengths, c_count,
                    host_query_refs, host_candidate_refs, keys, &plan);
 
     /* Cell width: this build scores weighted cells in 32 bits, so refuse what the reference would widen to 64 bits
@@ -278,6 +352,7 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
 
     int const objective = engine->family == szs_family_needleman_wunsch_k   ? szs_objective_global_k
                           : engine->family == szs_family_smith_waterman_k ? szs_objective_local_k
+                          : runes                                         ? szs_objective_distance_runes_k
                                                                           : szs_objective_distance_k;
     /* Weighted kernels need the cost model and a strip-boundary workspace on the device. */
     int needs_weighted = !use_myers;
@@ -306,7 +381,11 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
     for (unsigned g = 0; g < plan.groups_count; ++g) {
         szs_plan_group_t const *group = &plan.groups[g];
         int launch_error;
-        if (group->variant)
+        if (group->variant && runes)
+            launch_error = szs_hip_levenshtein_myers_runes(device_query_refs + group->first, group->count,
+                                                           device_candidate_refs, c_count, (uint64_t *)device_results,
+                                                           device_stride, symmetric, stream);
+        else if (group->variant)
             launch_error = szs_hip_levenshtein_myers(group->variant, device_query_refs + group->first, group->count,
                                                      device_candidate_refs, c_count, (uint64_t *)device_results,
                                                      device_stride, symmetric, stream);

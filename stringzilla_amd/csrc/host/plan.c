@@ -44,12 +44,12 @@ static void sort_by_length(uint32_t const *lengths, uint32_t count, uint32_t lon
     free(keys);
 }
 
-static unsigned myers_variant(uint32_t length) {
+static unsigned myers_variant(uint32_t length, unsigned widest) {
     unsigned const words = length ? (length + 31) / 32 : 1;
-    return words <= SZS_MYERS_MAX_WORDS ? szs_hip_levenshtein_myers_round_words(words) : 0;
+    return words <= widest ? szs_hip_levenshtein_myers_round_words(words) : 0;
 }
 
-void szs_plan_build(int myers, int symmetric, uint64_t const *query_addresses, uint32_t const *query_lengths,
+void szs_plan_build(unsigned myers, int symmetric, uint64_t const *query_addresses, uint32_t const *query_lengths,
                     uint32_t queries_count, uint64_t const *candidate_addresses, uint32_t const *candidate_lengths,
                     uint32_t candidates_count, szs_string_ref_t *query_refs, szs_string_ref_t *candidate_refs,
                     uint32_t *keys, szs_plan_t *plan) {
@@ -90,7 +90,7 @@ void szs_plan_build(int myers, int symmetric, uint64_t const *query_addresses, u
         query_refs[slot].address = query_addresses[q];
         query_refs[slot].length = query_lengths[q];
         query_refs[slot].index = q;
-        unsigned const variant = myers ? myers_variant(query_lengths[q]) : 0; /* weighted engines: one group */
+        unsigned const variant = myers ? myers_variant(query_lengths[q], myers) : 0; /* weighted engines: one group */
         szs_plan_group_t *group = plan->groups_count ? &plan->groups[plan->groups_count - 1] : NULL;
         if (!group || group->variant != variant) {
             group = &plan->groups[plan->groups_count++];
@@ -118,7 +118,7 @@ sz_status_t szs_rocm_plan_probe(int unit_cost, int symmetric, sz_u32_t const *qu
         return sz_bad_alloc_k;
     }
     szs_plan_t plan;
-    szs_plan_build(unit_cost, symmetric, addresses, query_lengths, q, addresses, candidate_lengths, c, query_refs,
+    szs_plan_build(unit_cost ? SZS_MYERS_MAX_WORDS : 0, symmetric, addresses, query_lengths, q, addresses, candidate_lengths, c, query_refs,
                    candidate_refs, keys, &plan);
     if (candidate_order)
         for (uint32_t i = 0; i < c; ++i) candidate_order[i] = candidate_refs[i].index;

@@ -89,6 +89,9 @@ typedef struct szs_engine_s {
     szs_buffer_t device_boundary;/* device: strip boundaries of the weighted kernels */
     szs_buffer_t device_model;   /* device: szs_cost_model_t */
     szs_buffer_t device_tape;    /* device: flattened copy of callback-sequence strings living in host memory */
+    szs_buffer_t device_runes;   /* device: UTF-32 transcription of both sides (codepoint-level engine) */
+    szs_buffer_t device_transcode; /* device: raw refs, rune starts, rune counts and the multibyte flag of that pass */
+    szs_buffer_t pinned_transcode; /* pinned: the host's side of the same */
     int model_uploaded_device;
     hipEvent_t event_start, event_stop;
     int events_device;
@@ -128,11 +131,12 @@ typedef struct szs_plan_t {
 
 /**
  *  Fills `candidate_refs` with the candidates sorted by ascending length (stable), and `query_refs` grouped by kernel
- *  variant (ascending), each group keeping the original order.  `myers` selects word-count grouping; queries too long
- *  for the bit-parallel kernel land in a final group with variant 0 (scored by the weighted kernel).
+ *  variant, longest first.  `myers` = widest bit-vector (in 32-bit words) a bit-parallel kernel exists for - 0 for the
+ *  weighted engines, SZS_MYERS_MAX_WORDS for bytes, SZS_MYERS_SHORT_WORDS for codepoints; longer queries get variant 0
+ *  (scored by the weighted kernel).
  *  Lengths and addresses are parallel arrays.  Scratch `keys` must hold max(q, c) uint32_t.
  */
-void szs_plan_build(int myers, int symmetric, uint64_t const *query_addresses, uint32_t const *query_lengths,
+void szs_plan_build(unsigned myers, int symmetric, uint64_t const *query_addresses, uint32_t const *query_lengths,
                     uint32_t queries_count, uint64_t const *candidate_addresses, uint32_t const *candidate_lengths,
                     uint32_t candidates_count, szs_string_ref_t *query_refs, szs_string_ref_t *candidate_refs,
                     uint32_t *keys, szs_plan_t *plan);

@@ -326,3 +326,68 @@ def test_config2_full_size_properties(gpu, oracle):
     self_matrix = engine(load.queries, device=gpu)
     assert np.array_equal(self_matrix, self_matrix.T) and not np.diagonal(self_matrix).any()
     assert engine.last_call_profile().pairs == 1024 * 1025 // 2
+
+
+# ---- codepoint-level Levenshtein (szs_levenshtein_distances_utf8*) ----------------------------------------------------
+
+
+@pytest.fixture(scope="module")
+def golden_utf8():
+    import json
+    import os
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "reference_utf8_matrices.json")) as f:
+        return json.load(f)
+
+
+def test_utf8_known_answers(gpu, golden):
+    _, kats = golden
+    unit = szs.LevenshteinDistancesUTF8(capabilities=gpu)
+    for first, second, expected in kats["levenshtein_utf8_runes"]["vectors"]:
+        assert int(unit([first.encode()], [second.encode()], device=gpu)[0, 0]) == expected, (first, second)
+    match, mismatch, open_, extend = kats["levenshtein_utf8_custom_gaps"]["costs"]
+    custom = szs.LevenshteinDistancesUTF8(match=match, mismatch=mismatch, open=open_, extend=extend, capabilities=gpu)
+    for first, second, expected in kats["levenshtein_utf8_custom_gaps"]["vectors"]:
+        assert int(custom([first.encode()], [second.encode()], device=gpu)[0, 0]) == expected, (first, second)
+
+
+def test_utf8_golden_reference_matrices(gpu, golden_utf8):
+    """Matrices produced by the reference's own UTF-8 engines (linear and affine, unit and non-unit costs, 1-4 byte
+    runes, queries on both sides of the 256-rune bit-parallel limit, the degenerate corpus of test/similarities.py)."""
+    engines = {}
+    for case in golden_utf8["cases"]:
+        costs = tuple(case["costs"])
+        if costs not in engines:
+            m, x, o, e = costs
+            engines[costs] = szs.LevenshteinDistancesUTF8(match=m, mismatch=x, open=o, extend=e, capabilities=gpu)
+        queries, candidates = _unhex(case["queries"]), _unhex(case["candidates"])
+        got = engines[costs](queries, candidates, device=gpu)
+        expected = np.array(case["matrix"], dtype=np.uint64).reshape(len(queries), len(candidates))
+        assert got.dtype == np.uint64 and np.array_equal(got, expected), (case["name"], costs)
+        sym = engines[costs](queries, device=gpu)
+        expected_sym = np.array(case["symmetric"], dtype=np.uint64).reshape(len(queries), len(queries))
+        assert np.array_equal(sym, expected_sym), (case["name"], costs, "symmetric")
+
+
+@pytest.mark.parametrize("costs", [(0, 1, 1, 1), (1, 3, 3, 3), (0, 1, 4, 2)])
+def test_utf8_fuzz(gpu, oracle, costs):
+    rng = random.Random(hash(costs) & 0xFFF)
+    engine = szs.LevenshteinDistancesUTF8(*costs, capabilities=gpu)
+    pools = ["AÉ中😀", "abc абв", "日本語中文字漢", "aé中😀bñ語🚀 ", "".join(chr(0x4E00 + i) for i in range(400))]
+    for pool in pools:
+        for lo, hi, q_count, c_count in [(0, 48, 7, 300), (200, 300, 3, 70), (1, 20, 64, 5)]:
+            text = lambda: "".join(rng.choice(pool) for _ in range(rng.randint(lo, hi))).encode()
+            queries, candidates = [text() for _ in range(q_count)], [text() for _ in range(c_count)]
+            expected = oracle.levenshtein_utf8(queries, candidates, *costs)
+            assert np.array_equal(engine(queries, candidates, device=gpu), expected), (pool[:4], lo, hi)
+    # ASCII corpus: the byte kernels take over and must agree with both oracles
+    strings = [bytes(rng.choice(b"ACGT ") for _ in range(rng.randint(0, 90))) for _ in range(40)]
+    assert np.array_equal(engine(strings, device=gpu), oracle.levenshtein_utf8(strings, None, *costs))
+    assert np.array_equal(engine(strings, device=gpu), oracle.levenshtein(strings, None, *costs))
+
+
+def test_utf8_malformed_bytes_follow_the_unchecked_contract(gpu, oracle):
+    """`sz_rune_decode_unchecked`: stray continuation bytes, unvalidated tails, over-long leads - never an error."""
+    engine = szs.LevenshteinDistancesUTF8(capabilities=gpu)
+    strings = [b"\x80\xbfabc", b"\xc3\x41\xc3", b"ab\xe4\xb8", b"\xf8\x80\x80\x80A", "é中".encode(), b"", b"\xff\xfe\xfd\xfc\xfb"]
+    assert np.array_equal(engine(strings, strings, device=gpu), oracle.levenshtein_utf8(strings, strings))
