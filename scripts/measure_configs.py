@@ -25,6 +25,8 @@ for index in [int(x) for x in args.configs.split(",")]:
     load = workloads.config(index, scale=args.scale)
     if load.kind == "levenshtein":
         engine = szs.LevenshteinDistances(**load.costs, capabilities=gpu)
+    elif load.kind == "levenshtein_utf8":
+        engine = szs.LevenshteinDistancesUTF8(**load.costs, capabilities=gpu)
     else:
         cls = szs.NeedlemanWunschScores if load.kind == "needleman_wunsch" else szs.SmithWatermanScores
         engine = cls(*matrices.by_name(load.table), **load.costs, capabilities=gpu)

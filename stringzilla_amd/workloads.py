@@ -57,7 +57,7 @@ def zipf_utf8_tape(rng: np.random.Generator, count: int, low: int = 8, high: int
 @dataclass
 class Workload:
     name: str
-    kind: str  # "levenshtein" | "needleman_wunsch" | "smith_waterman"
+    kind: str  # "levenshtein" | "levenshtein_utf8" | "needleman_wunsch" | "smith_waterman"
     queries: Strs
     candidates: Strs
     costs: dict  # engine constructor keywords besides the substitution table
@@ -96,5 +96,10 @@ def config(index: int, scale: float = 1.0) -> Workload:
     if index == 5:
         return Workload("cfg5: 3163x3163 UTF-8 Zipf(1.1) bytes [8,2048], byte-level Levenshtein unit", "levenshtein",
                         zipf_utf8_tape(rng, side(3163)), zipf_utf8_tape(rng, side(3163)),
+                        dict(match=0, mismatch=1, open=1, extend=1))
+    if index == 6:  # config 5's batch scored at the CODEPOINT level: not a BASELINE.json line
+        rng = np.random.default_rng(5)
+        return Workload("cfg5u: 3163x3163 UTF-8 Zipf(1.1) bytes [8,2048], codepoint-level Levenshtein unit",
+                        "levenshtein_utf8", zipf_utf8_tape(rng, side(3163)), zipf_utf8_tape(rng, side(3163)),
                         dict(match=0, mismatch=1, open=1, extend=1))
     raise ValueError(f"unknown config {index}")
