@@ -328,6 +328,34 @@ def test_config2_full_size_properties(gpu, oracle):
     assert engine.last_call_profile().pairs == 1024 * 1025 // 2
 
 
+@pytest.mark.parametrize("index,sampled_pairs", [(3, 400), (4, 24), (5, 300), (6, 300)])
+def test_full_size_configs_sampled(gpu, oracle, index, sampled_pairs):
+    """Configs 3, 4, 5 (and 5 at the codepoint level) at BASELINE.json's FULL size: the whole matrix is computed on the
+    GPU, a random sample of its cells is recomputed by the CPU oracle as 1 x 1 problems, and size-independent properties
+    are checked on all of it (symmetric tables => the transposed call is the transposed matrix; bounds)."""
+    load = workloads.config(index)
+    if load.kind in ("levenshtein", "levenshtein_utf8"):
+        cls = szs.LevenshteinDistances if load.kind == "levenshtein" else szs.LevenshteinDistancesUTF8
+        engine = cls(**load.costs, capabilities=gpu)
+        scorer = oracle.levenshtein if load.kind == "levenshtein" else oracle.levenshtein_utf8
+        one = lambda q, c: int(scorer([q], [c], **load.costs)[0, 0])
+    else:
+        table = matrices.by_name(load.table)
+        cls = szs.NeedlemanWunschScores if load.kind == "needleman_wunsch" else szs.SmithWatermanScores
+        engine = cls(*table, **load.costs, capabilities=gpu)
+        one = lambda q, c: int(getattr(oracle, load.kind)([q], [c], *table, load.costs["open"], load.costs["extend"])[0, 0])
+    matrix = engine(load.queries, load.candidates, device=gpu)
+    assert matrix.shape == (len(load.queries), len(load.candidates))
+    rng = np.random.default_rng(index)
+    for q, c in zip(rng.integers(0, len(load.queries), sampled_pairs), rng.integers(0, len(load.candidates), sampled_pairs)):
+        assert int(matrix[q, c]) == one(load.queries[int(q)], load.candidates[int(c)]), (load.name, int(q), int(c))
+    if index != 4:  # config 4's transposed call is another 1.3 s of GPU time for no new code path
+        assert np.array_equal(engine(load.candidates, load.queries, device=gpu), matrix.T)
+    if load.kind == "smith_waterman":
+        shortest = np.minimum(load.queries.lengths()[:, None], load.candidates.lengths()[None, :])
+        assert (matrix >= 0).all() and (matrix <= 5 * shortest).all()  # NUC.4.4: a match scores 5
+
+
 # ---- codepoint-level Levenshtein (szs_levenshtein_distances_utf8*) ----------------------------------------------------
 
 
