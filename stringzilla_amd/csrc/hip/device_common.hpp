@@ -55,6 +55,12 @@ struct text_stream_t {
         return dword_index < valid_dwords ? aligned_base[dword_index] : 0u;
     }
 
+    /** Branch-free variant for hot loops: reads past the last valid dword re-read that dword (the bytes are never
+     *  consumed).  Requires `valid_dwords >= 1`, i.e. a non-empty string. */
+    __device__ __forceinline__ u32 raw_clamped(u32 dword_index) const {
+        return aligned_base[dword_index < valid_dwords ? dword_index : valid_dwords - 1];
+    }
+
     /** Text bytes [4k, 4k+4) given raw dwords k and k+1. */
     __device__ __forceinline__ u32 splice(u32 raw_low, u32 raw_high) const {
         return __builtin_amdgcn_alignbyte(raw_high, raw_low, byte_shift);

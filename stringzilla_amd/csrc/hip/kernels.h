@@ -75,7 +75,8 @@ enum {
     szs_objective_global_k = 0,      /* Needleman-Wunsch: bottom-right cell */
     szs_objective_local_k = 1,       /* Smith-Waterman: best cell, substitution branch clamped at 0 */
     szs_objective_distance_k = 2,    /* weighted Levenshtein: global on negated uniform costs, result negated */
-    szs_objective_distance_runes_k = 3 /* the same over UTF-32 strings (addresses point at u32 runes, lengths in runes) */
+    szs_objective_distance_runes_k = 3, /* the same over UTF-32 strings (addresses point at u32 runes, lengths in runes) */
+    szs_objective_local_saturating_k = 4 /* Smith-Waterman with gap costs <= 0: unsigned-saturating gap arithmetic */
 };
 
 /**
@@ -83,12 +84,14 @@ enum {
  *  of query rows held in registers, the strip boundary row parked in `boundary` (global memory, [column][lane]).
  *  `boundary` needs szs_hip_weighted_boundary_bytes(...) bytes (work counter + one boundary per RESIDENT workgroup)
  *  and must be called with the target device current.  Queries should arrive longest first.
+ *  `narrow` != 0 promises that every value parked on a strip boundary fits int16 (global objectives: the reach of
+ *  serial.hpp:135-162; saturating local: shortest side x largest cost); boundaries are then stored in 16 bits.
  */
-int szs_hip_weighted_scores(int objective, int affine, szs_cost_model_t const *model, szs_string_ref_t const *queries,
+int szs_hip_weighted_scores(int objective, int affine, int narrow, szs_cost_model_t const *model, szs_string_ref_t const *queries,
                             uint32_t queries_count, szs_string_ref_t const *candidates, uint32_t candidates_count,
                             uint32_t longest_candidate, int64_t *results, uint64_t results_row_stride, int symmetric,
                             void *boundary, void *stream);
-size_t szs_hip_weighted_boundary_bytes(int objective, int affine, uint32_t queries_count, uint32_t candidates_count,
+size_t szs_hip_weighted_boundary_bytes(int objective, int affine, int narrow, uint32_t queries_count, uint32_t candidates_count,
                                        uint32_t longest_candidate);
 
 #ifdef __cplusplus

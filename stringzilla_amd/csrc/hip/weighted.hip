@@ -44,9 +44,14 @@
  */
 #include "device_common.hpp"
 
+#include <type_traits>
+
 namespace szs_hip {
 
-constexpr int weighted_rows_k = 32;                      // strip height: 32 int8 costs = two ds_read_b128
+#ifndef SZS_WEIGHTED_ROWS
+#define SZS_WEIGHTED_ROWS 32
+#endif
+constexpr int weighted_rows_k = SZS_WEIGHTED_ROWS;        // strip height: 32 int8 costs = two ds_read_b128
 constexpr u32 weighted_block_threads_k = 256;
 constexpr u32 weighted_boundary_slack_k = 8;             // columns the boundary prefetch may run past the longest text
 
@@ -61,10 +66,13 @@ struct cost_column_t {
 
 __device__ __forceinline__ cost_column_t load_costs(int8_t const *profile, u32 symbol) {
     uint4 const *rows = reinterpret_cast<uint4 const *>(profile) + symbol * (weighted_rows_k / 16);
-    uint4 const low = rows[0], high = rows[1];
     cost_column_t costs;
-    costs.packed[0] = low.x, costs.packed[1] = low.y, costs.packed[2] = low.z, costs.packed[3] = low.w;
-    costs.packed[4] = high.x, costs.packed[5] = high.y, costs.packed[6] = high.z, costs.packed[7] = high.w;
+#pragma unroll
+    for (int chunk = 0; chunk < weighted_rows_k / 16; ++chunk) {
+        uint4 const part = rows[chunk];
+        costs.packed[4 * chunk + 0] = part.x, costs.packed[4 * chunk + 1] = part.y;
+        costs.packed[4 * chunk + 2] = part.z, costs.packed[4 * chunk + 3] = part.w;
+    }
     return costs;
 }
 
@@ -80,6 +88,21 @@ struct strip_column_t {
 };
 
 /**
+ *  `value + gap` in the arithmetic of the kernel instance.
+ *  Plain: a signed add.  Saturating (local alignment with non-positive gap costs): every quantity a gap is applied to is
+ *  >= 0 - H because the substitution branch is clamped at 0, the two gap tracks because clamping THEM at 0 as well can
+ *  never change an H (a negative track value only ever loses against the clamped substitution branch, and what it
+ *  propagates stays negative) - so `max(value + gap, 0)` is ONE unsigned saturating subtract of the penalty, a
+ *  fast-class VALU op (`v_sub_u32 ... clamp`), and the explicit clamp of the substitution branch disappears:
+ *  max3 over two non-negative operands and `diag + cost` is already >= 0.
+ */
+template <bool saturating_>
+__device__ __forceinline__ i32 gapped(i32 value, i32 gap) {
+    if constexpr (saturating_) return (i32)__builtin_elementwise_sub_sat((u32)value, (u32)(-gap));
+    else return value + gap;
+}
+
+/**
  *  Advances one lane by one column of the strip.
  *
  *  @param above_h      H(first_row - 1, j): the row above the strip at this column (border or parked boundary).
@@ -88,32 +111,32 @@ struct strip_column_t {
  *  @param down_out     affine: the vertical-gap track of the strip's bottom row at this column.
  *  @param best         local: running maximum over the rows `[0, counted_rows)` of this column.
  */
-template <bool local_, bool affine_>
+template <bool local_, bool affine_, bool saturating_>
 __device__ __forceinline__ void advance_column(strip_column_t<affine_> &column, cost_column_t const &costs, i32 above_h,
                                                i32 above_down, i32 &diagonal, i32 gap_open, i32 gap_extend,
                                                i32 &down_out, i32 &best, u32 counted_rows) {
     constexpr int rows = weighted_rows_k;
     i32 diag = diagonal;
     diagonal = above_h;
-    i32 above_gapped = above_h + gap_open;                       // linear: above + gap;  affine: above + open
-    i32 down_extended = affine_ ? above_down + gap_extend : 0;   // affine: vertical-gap track + extend
+    i32 above_gapped = gapped<saturating_>(above_h, gap_open);                        // above + gap (linear) / + open
+    i32 down_extended = affine_ ? gapped<saturating_>(above_down, gap_extend) : 0;    // vertical-gap track + extend
     i32 down = 0;
 #pragma unroll
     for (int r = 0; r < rows; ++r) {
         i32 substituted = diag + costs[r];
-        if constexpr (local_) substituted = max2(substituted, 0); // only this branch is clamped (serial.hpp:957-965)
+        if constexpr (local_ && !saturating_) substituted = max2(substituted, 0); // only this branch is clamped (serial.hpp:957-965)
         diag = column.h[r];
         i32 cell;
         if constexpr (affine_) {
             i32 const across = max2(column.h_gapped[r], column.across_extended[r]); // serial.hpp:1091-1102
             down = max2(above_gapped, down_extended);
             cell = max3(down, across, substituted);
-            column.across_extended[r] = across + gap_extend;
-            down_extended = down + gap_extend;
+            column.across_extended[r] = gapped<saturating_>(across, gap_extend);
+            down_extended = gapped<saturating_>(down, gap_extend);
         }
         else { cell = max3(above_gapped, column.h_gapped[r], substituted); } // serial.hpp:846-848
         column.h[r] = cell;
-        above_gapped = cell + gap_open;
+        above_gapped = gapped<saturating_>(cell, gap_open);
         column.h_gapped[r] = above_gapped;
     }
     down_out = down;
@@ -135,16 +158,20 @@ __device__ __forceinline__ void advance_column(strip_column_t<affine_> &column, 
  *  @tparam affine_   Gotoh's three-track recurrence instead of the single-track linear one.
  *  @tparam uniform_  costs are (match, mismatch) on raw bytes - weighted Levenshtein, computed as a maximisation of
  *                    negated costs and negated back on output - instead of the 32x32 class table.
+ *  @tparam saturating_ (with local_) both gap costs are <= 0: gap arithmetic is unsigned-saturating, see `gapped`.
+ *  @tparam narrow_   the host has proven every parked value fits int16 (reach rule for global scores, shortest side x
+ *                    largest cost for saturating local ones): the boundary rows are stored as 16-bit values, halving
+ *                    the only HBM traffic of the kernel that scales with the DP matrix.
  *  @tparam runes_    (with uniform_) symbols are UTF-32 codepoints: strings are `u32` arrays produced by utf8.hip, lengths
  *                    count runes, and the strip profile is keyed by the slots of a 64-entry rune table of the strip's own
  *                    (at most 32 distinct) runes instead of by byte value; a rune the strip does not contain probes to
  *                    an empty slot, whose profile row is "mismatch against every row".
  */
-template <bool local_, bool affine_, bool uniform_, bool runes_ = false>
+template <bool local_, bool affine_, bool uniform_, bool runes_ = false, bool saturating_ = false, bool narrow_ = false>
 __global__ __launch_bounds__(256) void weighted_scores_kernel(
     szs_cost_model_t const *__restrict__ model, szs_string_ref_t const *__restrict__ queries, u32 queries_count,
     szs_string_ref_t const *__restrict__ candidates, u32 candidates_count, u32 candidate_blocks,
-    i64 *__restrict__ results, u64 results_row_stride, int symmetric, i32 *__restrict__ boundary, u32 boundary_columns,
+    i64 *__restrict__ results, u64 results_row_stride, int symmetric, void *__restrict__ boundary, u32 boundary_columns,
     u32 *__restrict__ work_counter) {
 
     constexpr int rows = weighted_rows_k;
@@ -157,6 +184,7 @@ __global__ __launch_bounds__(256) void weighted_scores_kernel(
     __shared__ u32 strip_keys[runes_ ? strip_slots : 1];
     __shared__ u32 strip_runes[runes_ ? rows : 1];
     static_assert(!runes_ || uniform_, "codepoint scoring exists for uniform costs only");
+    static_assert(!saturating_ || local_, "saturating gap arithmetic is a local-alignment form");
     auto strip_slot_of = [&](u32 rune) -> u32 { // the rune's slot, or the empty slot its probe sequence ends on
         u32 slot = (rune * 2654435761u) >> 26;
         for (;;) {
@@ -175,9 +203,11 @@ __global__ __launch_bounds__(256) void weighted_scores_kernel(
 
     // This workgroup's private boundary rows: [column][lane], one plane for H and one for the vertical-gap track.
     u64 const plane = (u64)boundary_columns * weighted_block_threads_k;
-    i32 *const boundary_h = boundary + (u64)blockIdx.x * plane * (affine_ ? 2 : 1) + threadIdx.x;
-    i32 *const boundary_down = boundary_h + plane;
-    auto parked = [](i32 *base, u32 j) -> i32 & { return base[(u64)j * weighted_block_threads_k]; };
+    using parked_t = typename std::conditional<narrow_, int16_t, i32>::type;
+    parked_t *const boundary_h =
+        static_cast<parked_t *>(boundary) + (u64)blockIdx.x * plane * (affine_ ? 2 : 1) + threadIdx.x;
+    parked_t *const boundary_down = boundary_h + plane;
+    auto parked = [](parked_t *base, u32 j) -> parked_t & { return base[(u64)j * weighted_block_threads_k]; };
 
     // Work items are (query, candidate block) pairs, handed out through one device-wide counter: queries arrive longest
     // first and candidate blocks are walked from the longest texts down, so the heaviest items start first and the
@@ -199,7 +229,11 @@ __global__ __launch_bounds__(256) void weighted_scores_kernel(
         u32 const text_length = live ? candidate.length : 0;
         u32 const longest_in_wave = wave_max_u32(text_length);
         u32 const shortest_in_wave = ~wave_max_u32(live ? ~text_length : 0u); // over live lanes
-        text_stream_t const text(candidate.address, text_length);
+        // Lanes without a text (dead, or an empty candidate) stream from the workspace instead: always-valid memory, so
+        // the branch-free reads of the main loop need no predicate.  Their symbols are never consumed.
+        u64 const safe_address = text_length ? candidate.address : (u64)(uintptr_t)boundary_h;
+        text_stream_t text(safe_address, text_length);
+        if (!text_length) text.valid_dwords = 1;
         u8 const *const pattern = reinterpret_cast<u8 const *>(query.address);
         u32 const query_length = query.length;
 
@@ -260,8 +294,9 @@ __global__ __launch_bounds__(256) void weighted_scores_kernel(
                     packed[r / 4] |= ((u32)cost & 0xFFu) << (8 * (r % 4));
                 }
                 uint4 *mine_rows = reinterpret_cast<uint4 *>(profile) + threadIdx.x * (rows / 16);
-                mine_rows[0] = make_uint4(packed[0], packed[1], packed[2], packed[3]);
-                mine_rows[1] = make_uint4(packed[4], packed[5], packed[6], packed[7]);
+#pragma unroll
+                for (int chunk = 0; chunk < rows / 16; ++chunk)
+                    mine_rows[chunk] = make_uint4(packed[4 * chunk], packed[4 * chunk + 1], packed[4 * chunk + 2], packed[4 * chunk + 3]);
             }
             __syncthreads();
 
@@ -271,8 +306,9 @@ __global__ __launch_bounds__(256) void weighted_scores_kernel(
 #pragma unroll
             for (int r = 0; r < rows; ++r) {
                 column.h[r] = border(first_row + r + 1);
-                column.h_gapped[r] = column.h[r] + gap_open;
-                if constexpr (affine_) column.across_extended[r] = column.h[r] + gap_open + gap_extend + gap_extend;
+                column.h_gapped[r] = gapped<saturating_>(column.h[r], gap_open);
+                if constexpr (affine_) // saturating: the (negative) seed is clamped like every other track value
+                    column.across_extended[r] = saturating_ ? 0 : column.h[r] + gap_open + gap_extend + gap_extend;
             }
             i32 diagonal = border(first_row); // DP cell (first_row - 1, column - 1)
             i32 best = 0, down_out = 0;
@@ -281,7 +317,7 @@ __global__ __launch_bounds__(256) void weighted_scores_kernel(
             auto above_of = [&](u32 j, i32 &above_h, i32 &above_down) {
                 if (is_first_strip) {
                     above_h = border(j);
-                    above_down = above_h + gap_open + gap_extend;
+                    above_down = saturating_ ? 0 : above_h + gap_open + gap_extend;
                 }
                 else {
                     above_h = parked(boundary_h, j);
@@ -290,7 +326,7 @@ __global__ __launch_bounds__(256) void weighted_scores_kernel(
             };
 
             u32 column_index = 0, dword = 0; // columns [0, column_index) are done
-            u32 const *const runes = reinterpret_cast<u32 const *>(candidate.address);
+            u32 const *const runes = reinterpret_cast<u32 const *>(safe_address);
             auto rune_at = [&](u32 index) -> u32 { return index < text_length ? runes[index] : 0u; };
             u32 raw_low = runes_ ? 0u : text.raw(0);
             // The profile row of the symbol in column `column_index + step`, given this batch of four columns.
@@ -298,43 +334,64 @@ __global__ __launch_bounds__(256) void weighted_scores_kernel(
                 if constexpr (runes_) return strip_slot_of(batch[step]);
                 else return (batch[0] >> (8 * step)) & 0xFFu;
             };
-            // ---- main loop: whole batches of four columns that EVERY live lane of the wavefront still has
+            // ---- main loop: whole batches of four columns that EVERY live lane of the wavefront still has.
+            // Straight-line on purpose: the boundary cells of the next batch are loaded UNCONDITIONALLY (for the first
+            // strip they are garbage and the border is selected when they are consumed), the strip's bottom row is
+            // stored unconditionally (the last strip's copy is never read), text reads are index-clamped instead of
+            // predicated.  No branch splits the batch, so hipcc can count outstanding loads and stores exactly
+            // (`s_waitcnt vmcnt(n)` instead of draining the stores of the previous batch before every batch) and can
+            // hoist the LDS cost reads of a column above the arithmetic of the previous one.
             if (shortest_in_wave >= 4 && longest_in_wave) {
-                u32 raw_high = runes_ ? 0u : text.raw(1);
+                u32 raw_high = runes_ ? 0u : text.raw_clamped(1);
                 u32 ahead[4] = {0, 0, 0, 0}; // runes: the next batch, loaded one iteration early
                 if constexpr (runes_)
-                    for (int step = 0; step < 4; ++step) ahead[step] = rune_at(step);
-                i32 above_h[4], above_down[4];
+                    for (int step = 0; step < 4; ++step) ahead[step] = runes[step];
+                parked_t ahead_h[4], ahead_down[affine_ ? 4 : 1];
 #pragma unroll
-                for (int step = 0; step < 4; ++step) above_of(1 + step, above_h[step], above_down[step]);
+                for (int step = 0; step < 4; ++step) {
+                    ahead_h[step] = parked(boundary_h, 1 + step);
+                    if constexpr (affine_) ahead_down[step] = parked(boundary_down, 1 + step);
+                }
                 for (; column_index + 4 <= shortest_in_wave; column_index += 4, ++dword) {
                     u32 batch[4];
                     if constexpr (runes_) {
+                        u32 const last = text_length ? text_length - 1 : 0;
 #pragma unroll
                         for (int step = 0; step < 4; ++step) batch[step] = ahead[step];
 #pragma unroll
-                        for (int step = 0; step < 4; ++step) ahead[step] = rune_at(column_index + 4 + step);
+                        for (int step = 0; step < 4; ++step) {
+                            u32 const index = column_index + 4 + step;
+                            ahead[step] = runes[index < last ? index : last];
+                        }
                     }
                     else {
                         batch[0] = text.splice(raw_low, raw_high);
                         raw_low = raw_high;
-                        raw_high = text.raw(dword + 2);
+                        raw_high = text.raw_clamped(dword + 2);
                     }
                     i32 now_h[4], now_down[4];
 #pragma unroll
-                    for (int step = 0; step < 4; ++step) now_h[step] = above_h[step], now_down[step] = above_down[step];
+                    for (int step = 0; step < 4; ++step) {
+                        i32 const edge = border(column_index + 1 + step);
+                        now_h[step] = is_first_strip ? edge : (i32)ahead_h[step];
+                        now_down[step] = !affine_          ? 0
+                                         : !is_first_strip ? (i32)ahead_down[affine_ ? step : 0]
+                                         : saturating_     ? 0
+                                                           : edge + gap_open + gap_extend;
+                    }
                     // Prefetch the next batch's boundary cells; the slack columns make the overrun harmless.
 #pragma unroll
-                    for (int step = 0; step < 4; ++step) above_of(column_index + 5 + step, above_h[step], above_down[step]);
+                    for (int step = 0; step < 4; ++step) {
+                        ahead_h[step] = parked(boundary_h, column_index + 5 + step);
+                        if constexpr (affine_) ahead_down[step] = parked(boundary_down, column_index + 5 + step);
+                    }
 #pragma unroll
                     for (int step = 0; step < 4; ++step) {
                         cost_column_t const costs = load_costs(profile, profile_row(batch, step));
-                        advance_column<local_, affine_>(column, costs, now_h[step], now_down[step], diagonal, gap_open,
-                                                        gap_extend, down_out, best, rows_here);
-                        if (!is_last_strip) {
-                            parked(boundary_h, column_index + step + 1) = column.h[rows - 1];
-                            if constexpr (affine_) parked(boundary_down, column_index + step + 1) = down_out;
-                        }
+                        advance_column<local_, affine_, saturating_>(column, costs, now_h[step], now_down[step], diagonal,
+                                                                     gap_open, gap_extend, down_out, best, rows_here);
+                        parked(boundary_h, column_index + step + 1) = (parked_t)column.h[rows - 1];
+                        if constexpr (affine_) parked(boundary_down, column_index + step + 1) = (parked_t)down_out;
                     }
                 }
             }
@@ -360,11 +417,11 @@ __global__ __launch_bounds__(256) void weighted_scores_kernel(
                             i32 above_h, above_down;
                             above_of(j, above_h, above_down);
                             cost_column_t const costs = load_costs(profile, profile_row(batch, step));
-                            advance_column<local_, affine_>(column, costs, above_h, above_down, diagonal, gap_open,
+                            advance_column<local_, affine_, saturating_>(column, costs, above_h, above_down, diagonal, gap_open,
                                                             gap_extend, down_out, best, rows_here);
                             if (!is_last_strip) {
-                                parked(boundary_h, j) = column.h[rows - 1];
-                                if constexpr (affine_) parked(boundary_down, j) = down_out;
+                                parked(boundary_h, j) = (parked_t)column.h[rows - 1];
+                                if constexpr (affine_) parked(boundary_down, j) = (parked_t)down_out;
                             }
                         }
                     }
@@ -391,14 +448,14 @@ __global__ __launch_bounds__(256) void weighted_scores_kernel(
 constexpr size_t weighted_header_bytes_k = 256; // the work counter lives at the head of the boundary workspace
 
 /** Workgroups that can be RESIDENT at once for this kernel instance on the current device (never more than the work). */
-template <bool local_, bool affine_, bool uniform_, bool runes_ = false>
+template <bool local_, bool affine_, bool uniform_, bool runes_ = false, bool saturating_ = false, bool narrow_ = false>
 static u32 weighted_grid(u64 work_items) {
     static int resident = 0; // per instance; one device architecture per process
     if (!resident) {
         int device = 0, units = 0, per_unit = 0;
         if (hipGetDevice(&device) != hipSuccess ||
             hipDeviceGetAttribute(&units, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_unit, weighted_scores_kernel<local_, affine_, uniform_, runes_>,
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_unit, weighted_scores_kernel<local_, affine_, uniform_, runes_, saturating_, narrow_>,
                                                          (int)weighted_block_threads_k, 0) != hipSuccess ||
             units <= 0 || per_unit <= 0) {
             (void)hipGetLastError();
@@ -413,26 +470,26 @@ static u64 weighted_work_items(u32 queries_count, u32 candidates_count) {
     return (u64)queries_count * ((candidates_count + weighted_block_threads_k - 1) / weighted_block_threads_k);
 }
 
-template <bool local_, bool affine_, bool uniform_, bool runes_ = false>
+template <bool local_, bool affine_, bool uniform_, bool runes_ = false, bool saturating_ = false, bool narrow_ = false>
 static size_t weighted_workspace_bytes(u32 queries_count, u32 candidates_count, u32 longest_candidate) {
-    u32 const grid = weighted_grid<local_, affine_, uniform_, runes_>(weighted_work_items(queries_count, candidates_count));
+    u32 const grid = weighted_grid<local_, affine_, uniform_, runes_, saturating_, narrow_>(weighted_work_items(queries_count, candidates_count));
     return weighted_header_bytes_k + (size_t)grid * (longest_candidate + 1 + weighted_boundary_slack_k) *
-                                         weighted_block_threads_k * sizeof(i32) * (affine_ ? 2 : 1);
+                                         weighted_block_threads_k * (narrow_ ? sizeof(int16_t) : sizeof(i32)) * (affine_ ? 2 : 1);
 }
 
-template <bool local_, bool affine_, bool uniform_, bool runes_ = false>
+template <bool local_, bool affine_, bool uniform_, bool runes_ = false, bool saturating_ = false, bool narrow_ = false>
 static int launch_weighted(szs_cost_model_t const *model, szs_string_ref_t const *queries, u32 queries_count,
                            szs_string_ref_t const *candidates, u32 candidates_count, u32 longest_candidate, i64 *results,
                            u64 stride, int symmetric, void *workspace, hipStream_t stream) {
     u32 const candidate_blocks = (candidates_count + weighted_block_threads_k - 1) / weighted_block_threads_k;
     u64 const work_items = weighted_work_items(queries_count, candidates_count);
     if (work_items > 0xFFFFFFF0ull) return (int)hipErrorInvalidValue; // the host cuts larger cross-products
-    u32 const grid = weighted_grid<local_, affine_, uniform_, runes_>(work_items);
+    u32 const grid = weighted_grid<local_, affine_, uniform_, runes_, saturating_, narrow_>(work_items);
     u32 *const counter = static_cast<u32 *>(workspace);
-    i32 *const boundary = reinterpret_cast<i32 *>(static_cast<char *>(workspace) + weighted_header_bytes_k);
+    void *const boundary = static_cast<char *>(workspace) + weighted_header_bytes_k;
     hipError_t error = hipMemsetAsync(counter, 0, sizeof(u32), stream);
     if (error != hipSuccess) return (int)error;
-    hipLaunchKernelGGL((weighted_scores_kernel<local_, affine_, uniform_, runes_>), dim3(grid), dim3(weighted_block_threads_k), 0,
+    hipLaunchKernelGGL((weighted_scores_kernel<local_, affine_, uniform_, runes_, saturating_, narrow_>), dim3(grid), dim3(weighted_block_threads_k), 0,
                        stream, model, queries, queries_count, candidates, candidates_count, candidate_blocks, results,
                        stride, symmetric, boundary, longest_candidate + 1 + weighted_boundary_slack_k, counter);
     return (int)hipGetLastError();
@@ -443,11 +500,18 @@ static int launch_weighted(szs_cost_model_t const *model, szs_string_ref_t const
 #define SZS_WEIGHTED_DISPATCH(CALL)                                                                                   \
     switch (objective) {                                                                                               \
     case szs_objective_global_k:                                                                                       \
+        if (narrow && affine) CALL(false, true, false, false, false, true);                                            \
+        if (narrow) CALL(false, false, false, false, false, true);                                                     \
         if (affine) CALL(false, true, false);                                                                          \
         CALL(false, false, false);                                                                                     \
     case szs_objective_local_k:                                                                                        \
         if (affine) CALL(true, true, false);                                                                           \
         CALL(true, false, false);                                                                                      \
+    case szs_objective_local_saturating_k:                                                                             \
+        if (narrow && affine) CALL(true, true, false, false, true, true);                                              \
+        if (narrow) CALL(true, false, false, false, true, true);                                                       \
+        if (affine) CALL(true, true, false, false, true);                                                              \
+        CALL(true, false, false, false, true);                                                                         \
     case szs_objective_distance_k:                                                                                     \
         if (affine) CALL(false, true, true);                                                                           \
         CALL(false, false, true);                                                                                      \
@@ -457,7 +521,7 @@ static int launch_weighted(szs_cost_model_t const *model, szs_string_ref_t const
     default: break;                                                                                                    \
     }
 
-extern "C" size_t szs_hip_weighted_boundary_bytes(int objective, int affine, uint32_t queries_count,
+extern "C" size_t szs_hip_weighted_boundary_bytes(int objective, int affine, int narrow, uint32_t queries_count,
                                                   uint32_t candidates_count, uint32_t longest_candidate) {
     using namespace szs_hip;
 #define SZS_WEIGHTED_BYTES(...)                                                                                       \
@@ -467,7 +531,7 @@ extern "C" size_t szs_hip_weighted_boundary_bytes(int objective, int affine, uin
     return 0;
 }
 
-extern "C" int szs_hip_weighted_scores(int objective, int affine, szs_cost_model_t const *model,
+extern "C" int szs_hip_weighted_scores(int objective, int affine, int narrow, szs_cost_model_t const *model,
                                        szs_string_ref_t const *queries, uint32_t queries_count,
                                        szs_string_ref_t const *candidates, uint32_t candidates_count,
                                        uint32_t longest_candidate, int64_t *results, uint64_t results_row_stride,

@@ -351,9 +351,18 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
     }
 
     int const objective = engine->family == szs_family_needleman_wunsch_k   ? szs_objective_global_k
-                          : engine->family == szs_family_smith_waterman_k ? szs_objective_local_k
+                          : engine->family == szs_family_smith_waterman_k
+                              ? (engine->open <= 0 && engine->extend <= 0 ? szs_objective_local_saturating_k : szs_objective_local_k)
                           : runes                                         ? szs_objective_distance_runes_k
                                                                           : szs_objective_distance_k;
+    /* 16-bit strip boundaries when every parked value provably fits: global scores are bounded by the reach, saturating
+     * local ones by (shorter side) x (largest cost) - the reference narrows its cells by the same kind of bound. */
+    uint64_t const shorter_side = plan.longest_query < plan.longest_candidate ? plan.longest_query : plan.longest_candidate;
+    int const narrow = objective == szs_objective_global_k ? reach < 32000
+                       : objective == szs_objective_local_saturating_k
+                           ? (shorter_side + 3) * (engine->magnitude ? engine->magnitude : 1) < 32000
+                           : 0;
+
     /* Weighted kernels need the cost model and a strip-boundary workspace on the device. */
     int needs_weighted = !use_myers;
     for (unsigned g = 0; g < plan.groups_count; ++g) needs_weighted |= plan.groups[g].variant == 0;
@@ -369,7 +378,7 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
             engine->model_uploaded_device = device;
         }
         size_t const boundary_bytes =
-            szs_hip_weighted_boundary_bytes(objective, !engine->is_linear, q_count, c_count, plan.longest_candidate);
+            szs_hip_weighted_boundary_bytes(objective, !engine->is_linear, narrow, q_count, c_count, plan.longest_candidate);
         status = szs_buffer_reserve(&engine->device_boundary, szs_memory_device_k, device, boundary_bytes, error_message);
         if (status != sz_success_k) return status;
     }
@@ -390,7 +399,7 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
                                                      device_candidate_refs, c_count, (uint64_t *)device_results,
                                                      device_stride, symmetric, stream);
         else
-            launch_error = szs_hip_weighted_scores(objective, !engine->is_linear,
+            launch_error = szs_hip_weighted_scores(objective, !engine->is_linear, narrow,
                                                    (szs_cost_model_t const *)engine->device_model.pointer,
                                                    device_query_refs + group->first, group->count,
                                                    device_candidate_refs, c_count, plan.longest_candidate,

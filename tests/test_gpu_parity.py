@@ -139,6 +139,28 @@ def test_alignment_fuzz(gpu, oracle, kind, gaps):
             assert np.array_equal(engine(queries, device=gpu), expected_sym), (kind, gaps, lo, hi, "symmetric")
 
 
+def test_alignment_wide_and_narrow_boundaries(gpu, oracle):
+    """The strip boundary is parked in 16 bits when the host can bound every parked value (reach < 32000 for global,
+    shortest side x largest cost for saturating local scores) and in 32 bits otherwise: score both regimes, plus local
+    alignment with a POSITIVE gap cost, which takes the generic signed kernel instead of the saturating one."""
+    rng = random.Random(91)
+    table = matrices.blosum62()
+    for lo, hi, q_count, c_count, gaps in [(1450, 1600, 2, 70, (-4, -4)), (1450, 1600, 2, 70, (-11, -2)),   # reach > 32000
+                                           (100, 180, 4, 300, (-4, -1)), (3000, 3300, 1, 65, (-4, -1))]:
+        queries = _rand(rng, q_count, lo, hi, b"ARNDCQEGHILKMFPSTWYV")
+        candidates = _rand(rng, c_count, lo, hi, b"ARNDCQEGHILKMFPSTWYV")
+        for kind in ("needleman_wunsch", "smith_waterman"):
+            cls = szs.NeedlemanWunschScores if kind == "needleman_wunsch" else szs.SmithWatermanScores
+            engine = cls(*table, open=gaps[0], extend=gaps[1], capabilities=gpu)
+            expected = getattr(oracle, kind)(queries, candidates, *table, *gaps)
+            assert np.array_equal(engine(queries, candidates, device=gpu), expected), (kind, lo, hi, gaps)
+    queries, candidates = _rand(rng, 5, 20, 90, b"ACGT"), _rand(rng, 70, 20, 90, b"ACGT")
+    for gaps in [(1, 1), (2, -1), (-3, 1)]:
+        engine = szs.SmithWatermanScores(*matrices.nuc44(), open=gaps[0], extend=gaps[1], capabilities=gpu)
+        expected = oracle.smith_waterman(queries, candidates, *matrices.nuc44(), *gaps)
+        assert np.array_equal(engine(queries, candidates, device=gpu), expected), gaps
+
+
 def test_cross_product_shapes(gpu, oracle):
     """1xN, Nx1, 1x1, ragged with empties, rectangular, empty sides (test/similarities.cuh:1283-1326)."""
     rng = random.Random(5)
