@@ -219,15 +219,25 @@ __device__ __forceinline__ void myers_workgroup(u32 *peq, u32 *keys, szs_string_
             if (column < text_length) take(runes[column]);
     }
     else {
-        // ---- bytes: `raw_low` is text dword `dword`; `ahead[d]` is text dword `dword + 1 + d`, loaded one iteration early
-        text_stream_t const text(candidate.address, text_length);
+        // ---- bytes: `raw_low` is text dword `dword`; `ahead[d]` is text dword `dword + 1 + d`, loaded one iteration early.
+        // Lanes without a text stream from the query instead (always-valid memory; their symbols are never consumed), so
+        // the main loop's reads are index-clamped, not predicated: no branch splits the unrolled batch.
+        u64 const safe_address = text_length ? candidate.address : query.address;
+        text_stream_t text(safe_address, text_length);
+        if (!text_length) text.valid_dwords = query_length ? 1 : 0;
         u32 raw_low = text.raw(0);
         u32 dword = 0;
         constexpr u32 columns_per_iteration = 4 * text_dwords_;
-        if (columns_per_iteration <= shortest_in_wave && longest_in_wave) {
+#ifndef SZS_MYERS_CLAMPED_READS
+#define SZS_MYERS_CLAMPED_READS(TEXT_DWORDS) ((TEXT_DWORDS) == 1)
+#endif
+        // Measured on MI355X: index-clamped (branch-free) reads help the one-dword loops of the long kernels; the
+        // 16-column batches of the short kernels schedule better with the predicated reads.
+        constexpr bool clamped_reads = SZS_MYERS_CLAMPED_READS(text_dwords_);
+        if (columns_per_iteration <= shortest_in_wave && longest_in_wave && query_length) {
             u32 ahead[text_dwords_];
 #pragma unroll
-            for (int d = 0; d < text_dwords_; ++d) ahead[d] = text.raw(1 + d);
+            for (int d = 0; d < text_dwords_; ++d) ahead[d] = clamped_reads ? text.raw_clamped(1 + d) : text.raw(1 + d);
             for (; column + columns_per_iteration <= shortest_in_wave;
                  column += columns_per_iteration, dword += text_dwords_) {
                 u32 symbols[text_dwords_];
@@ -237,7 +247,9 @@ __device__ __forceinline__ void myers_workgroup(u32 *peq, u32 *keys, szs_string_
                 raw_low = ahead[text_dwords_ - 1];
                 // Issue the next iteration's loads now; they retire under the VALU work below.
 #pragma unroll
-                for (int d = 0; d < text_dwords_; ++d) ahead[d] = text.raw(dword + text_dwords_ + 1 + d);
+                for (int d = 0; d < text_dwords_; ++d)
+                    ahead[d] = clamped_reads ? text.raw_clamped(dword + text_dwords_ + 1 + d)
+                                             : text.raw(dword + text_dwords_ + 1 + d);
 #pragma unroll
                 for (int step = 0; step < 4 * text_dwords_; ++step) take((symbols[step / 4] >> (8 * (step % 4))) & 0xFFu);
             }

@@ -167,8 +167,11 @@ __device__ __forceinline__ void advance_column(strip_column_t<affine_> &column, 
  *                    (at most 32 distinct) runes instead of by byte value; a rune the strip does not contain probes to
  *                    an empty slot, whose profile row is "mismatch against every row".
  */
+#ifndef SZS_WEIGHTED_WAVES
+#define SZS_WEIGHTED_WAVES 1
+#endif
 template <bool local_, bool affine_, bool uniform_, bool runes_ = false, bool saturating_ = false, bool narrow_ = false>
-__global__ __launch_bounds__(256) void weighted_scores_kernel(
+__global__ __launch_bounds__(256, SZS_WEIGHTED_WAVES) void weighted_scores_kernel(
     szs_cost_model_t const *__restrict__ model, szs_string_ref_t const *__restrict__ queries, u32 queries_count,
     szs_string_ref_t const *__restrict__ candidates, u32 candidates_count, u32 candidate_blocks,
     i64 *__restrict__ results, u64 results_row_stride, int symmetric, void *__restrict__ boundary, u32 boundary_columns,
