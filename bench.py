@@ -53,6 +53,10 @@ def parse_args():
     parser.add_argument("--warmup", type=int, default=20)
     parser.add_argument("--config", type=int, default=2, help="BASELINE.json config index (2 = the metric's config)")
     parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI)")
+    parser.add_argument("--same-device", action="store_true",
+                        help="testing aid: every rank uses cuda:0 (with --backend gloo), to exercise the N > 1 code "
+                             "path on a one-GPU box; the numbers of such a run mean nothing")
     parser.add_argument("--hbm-traffic-bytes", type=float, default=None,
                         help="HBM bytes per launch from a separate rocprofv3 --pmc pass; default: the committed summary "
                              "profiles/r01/pmc_summary.json of this same command (scripts/profile_gpu.sh)")
@@ -105,9 +109,12 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     where = torch.device("cuda", local_rank)
