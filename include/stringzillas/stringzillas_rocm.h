@@ -7,7 +7,7 @@
  *    (/root/reference/include/stringzillas/types.cuh:280-298,482-534; bench/similarities.cuh:303-308).
  *  - szs_rocm_shard_rows        : longest-processing-time assignment of query rows to N GPUs;
  *    the reference has no multi-GPU path at all (one engine call = one device, stringzillas.h:137).
- *  - szs_rocm_plan_probe        : exposes the host planner so it can be unit-tested without a GPU.
+ *  - szs_rocm_plan_probe, szs_rocm_orientation_probe : expose the host planner so it can be unit-tested without a GPU.
  */
 #ifndef STRINGZILLAS_ROCM_H_
 #define STRINGZILLAS_ROCM_H_
@@ -28,6 +28,8 @@ typedef struct szs_rocm_call_profile_t {
     sz_u32_t launches;            /* kernel launches issued */
     sz_u32_t longest_query;
     sz_u32_t longest_candidate;
+    sz_u32_t tier;                /* 0: one pair per lane (lev_myers.hip, weighted.hip); 1: systolic (systolic.hip) */
+    sz_u32_t transposed;          /* 1: the planner swapped the sides (candidates on workgroups, queries on lanes) */
     sz_u32_t reserved;
 } szs_rocm_call_profile_t;
 
@@ -54,6 +56,17 @@ SZ_API_RUNTIME sz_status_t szs_rocm_plan_probe(int unit_cost, int symmetric, sz_
                                                sz_size_t queries_count, sz_u32_t const *candidate_lengths,
                                                sz_size_t candidates_count, sz_u32_t *candidate_order,
                                                sz_u32_t *query_order, sz_u32_t *query_variant, sz_u64_t *cells);
+
+/**
+ *  Runs the planner's tier / orientation decision on bare length arrays (no GPU needed): `*tier` receives 0 (one pair per
+ *  lane) or 1 (systolic: one pair per chain of wavefronts), `*transposed` whether the sides are swapped so that the
+ *  candidates take the workgroup / band role.  `unit_cost`: the engine is unit-cost Levenshtein (bit-parallel kernels
+ *  exist); `uniform`: any Levenshtein engine; `candidate_lengths` is ignored for symmetric calls.
+ */
+SZ_API_RUNTIME sz_status_t szs_rocm_orientation_probe(int unit_cost, int affine, int uniform, int symmetric,
+                                                      sz_u32_t const *query_lengths, sz_size_t queries_count,
+                                                      sz_u32_t const *candidate_lengths, sz_size_t candidates_count,
+                                                      int *tier, int *transposed);
 
 #ifdef __cplusplus
 }

@@ -53,7 +53,7 @@ class CallProfile(ctypes.Structure):
         ("kernel_milliseconds", ctypes.c_double), ("host_milliseconds", ctypes.c_double),
         ("cells", ctypes.c_uint64), ("pairs", ctypes.c_uint64), ("algorithmic_bytes", ctypes.c_uint64),
         ("unique_bytes", ctypes.c_uint64), ("launches", ctypes.c_uint32), ("longest_query", ctypes.c_uint32),
-        ("longest_candidate", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+        ("longest_candidate", ctypes.c_uint32), ("tier", ctypes.c_uint32), ("transposed", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
     ]
 
 
@@ -97,6 +97,7 @@ SIGNATURES = {
     "szs_rocm_last_call_profile": (c_int, [c_void_p, ctypes.POINTER(CallProfile)]),
     "szs_rocm_shard_rows": (c_int, [c_void_p, c_size_t, c_size_t, c_void_p, c_void_p]),
     "szs_rocm_plan_probe": (c_int, [c_int, c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "szs_rocm_orientation_probe": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p]),
 }
 
 REFERENCE_SYMBOLS = [name for name in SIGNATURES if not name.startswith("szs_rocm_")]  # the reference's 41

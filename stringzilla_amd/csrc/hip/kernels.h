@@ -29,6 +29,10 @@ typedef struct szs_string_ref_t {
     uint32_t index;   /* row (queries) or column (candidates) of the results matrix */
 } szs_string_ref_t;
 
+/* The `symmetric` argument of every scoring launcher is a set of layout flags: */
+#define SZS_LAYOUT_SYMMETRIC 1  /* score candidate.index <= query.index only and mirror each result */
+#define SZS_LAYOUT_TRANSPOSED 2 /* the host swapped the sides: results[candidate.index * stride + query.index] */
+
 #define SZS_CANDIDATES_PER_WORKGROUP 256u
 #define SZS_MYERS_MAX_WORDS 64u /* 32-bit words: queries up to 2048 bytes take the bit-parallel kernel */
 #define SZS_MYERS_SHORT_WORDS 8u /* queries up to 256 bytes share ONE launch that picks the width per workgroup */
@@ -93,6 +97,22 @@ int szs_hip_weighted_scores(int objective, int affine, int narrow, szs_cost_mode
                             void *boundary, void *stream);
 size_t szs_hip_weighted_boundary_bytes(int objective, int affine, int narrow, uint32_t queries_count, uint32_t candidates_count,
                                        uint32_t longest_candidate);
+
+/**
+ *  The few-pairs tier of the weighted scorers (hip/systolic.hip): a pair is spread over wavefronts - 64 lanes x R rows
+ *  per band, lanes skewed by one column and chained by DPP, bands chained through `workspace` - instead of owning one
+ *  lane.  Same objectives, cost model, string refs and result addressing as szs_hip_weighted_scores; queries need no
+ *  particular order.  `workspace` needs szs_hip_systolic_workspace_bytes(...) bytes (0 = the job is too large for
+ *  this tier); both must be called with the target device current.
+ */
+#define SZS_SYSTOLIC_BAND_ROWS 512u /* 64 lanes x 8 rows; szs_hip_systolic_band_rows() returns the same */
+unsigned szs_hip_systolic_band_rows(void);
+size_t szs_hip_systolic_workspace_bytes(int affine, uint32_t queries_count, uint32_t candidates_count,
+                                        uint32_t longest_query, uint32_t longest_candidate);
+int szs_hip_systolic_scores(int objective, int affine, szs_cost_model_t const *model, szs_string_ref_t const *queries,
+                            uint32_t queries_count, szs_string_ref_t const *candidates, uint32_t candidates_count,
+                            uint32_t longest_query, uint32_t longest_candidate, int64_t *results,
+                            uint64_t results_row_stride, int symmetric, void *workspace, void *stream);
 
 #ifdef __cplusplus
 }

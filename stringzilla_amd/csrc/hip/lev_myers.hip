@@ -174,7 +174,7 @@ __device__ __forceinline__ void myers_workgroup(u32 *peq, u32 *keys, szs_string_
     bool live = candidate_slot < candidates_count;
     szs_string_ref_t candidate = {0, 0, 0};
     if (live) candidate = candidates[candidate_slot];
-    if (symmetric && candidate.index > query.index) live = false; // upper triangle: mirrored from below
+    if ((symmetric & SZS_LAYOUT_SYMMETRIC) && candidate.index > query.index) live = false; // upper triangle: mirrored from below
     u32 const text_length = live ? candidate.length : 0;
     u32 const longest_in_wave = wave_max_u32(text_length);
     u32 const shortest_in_wave = ~wave_max_u32(live ? ~text_length : 0u); // over live lanes; no live lane: ~0, unused
@@ -273,9 +273,11 @@ __device__ __forceinline__ void myers_workgroup(u32 *peq, u32 *keys, szs_string_
         u32 distance = text_length;
 #pragma unroll
         for (int w = 0; w < words_; ++w) distance += (u32)__builtin_popcount(vp[w]) - (u32)__builtin_popcount(vn[w]);
-        results[(u64)query.index * results_row_stride + candidate.index] = distance;
-        if (symmetric && candidate.index != query.index)
-            results[(u64)candidate.index * results_row_stride + query.index] = distance;
+        bool const transposed = (symmetric & SZS_LAYOUT_TRANSPOSED) != 0; // kernel roles swapped by the host
+        u64 const row = transposed ? candidate.index : query.index, column = transposed ? query.index : candidate.index;
+        results[row * results_row_stride + column] = distance;
+        if ((symmetric & SZS_LAYOUT_SYMMETRIC) && candidate.index != query.index)
+            results[column * results_row_stride + row] = distance;
     }
 }
 

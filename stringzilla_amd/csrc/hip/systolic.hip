@@ -1,0 +1,507 @@
+/*
+ *  systolic.hip - the FEW-PAIRS tier of the weighted scorers on gfx950: Needleman-Wunsch, Smith-Waterman and weighted /
+ *  codepoint-level Levenshtein for cross-products too small to give every lane of the device a pair of its own.
+ *
+ *  Fills the slot of the reference's intra-pair tiers
+ *      (affine_)score_per_cuda_warp_        /root/reference/include/stringzillas/similarities/cuda.cuh:1246-1500
+ *      (affine_)score_across_cuda_device_   .../similarities/cuda.cuh:729-1170   (128x128 tiles, `progress[]` counters)
+ *  and must return exactly what the serial scorers return (serial.hpp:2527-2693,2910-3124; recurrences :778-1278).
+ *
+ *  weighted.hip gives every (query, candidate) pair ONE lane.  That is the right shape for a million pairs and the wrong
+ *  one for a 1 x 1 call of two 100 KB strings, or for 16 x 16 reads of 4 KB: a handful of lanes would walk the whole
+ *  matrix alone.  Here a pair is spread over wavefronts instead, as a two-level systolic array:
+ *
+ *  - A BAND is 64 x R consecutive query rows (R = 8: 512 rows) and belongs to one wavefront; lane l owns rows
+ *    [R l, R l + R) of the band, its column of R cells (plus gap tracks) lives in VGPRs, exactly like a strip of
+ *    weighted.hip.
+ *  - The lanes of a wavefront are skewed by one column: at step t lane l scores column t - l.  What lane l needs from
+ *    above - H (and the vertical-gap track) of lane l-1's bottom row at the same column - was produced by lane l-1 one
+ *    step earlier and arrives through ONE `v_mov_b32_dpp wave_shr:1`; the candidate symbol travels down the lanes the
+ *    same way.  No LDS, no barrier, no shuffle through memory: per step a lane exchanges 2 (linear) or 3 (affine)
+ *    registers and scores R cells.
+ *  - Lane 0's inputs (the candidate symbol, the row above the band) are wave-uniform per step: each lane preloads one
+ *    column of the next 64 (coalesced), and `v_readlane_b32` picks the step's value into an SGPR.
+ *  - Bands of one pair are chained THROUGH MEMORY: lane 63 parks the band's bottom row [column] in the workspace and
+ *    publishes a progress counter (release) every 64 columns; the wavefront of the next band spins on that counter
+ *    (acquire) before it preloads a chunk.  Bands are handed out through one atomic ticket counter in (pair, band)
+ *    order, so the band a wavefront waits for always holds an EARLIER ticket, i.e. is already running or finished:
+ *    forward progress without a co-residency requirement, whatever the grid size.  All bands of a long pair are thus
+ *    in flight at once, each trailing its predecessor by ~128 columns.
+ *  - Substitution costs: class-table engines build a per-band profile in LDS, profile[class][lane] = the R int8 costs
+ *    of the lane's rows against that class (one conflict-free ds_read_b64 per step; the candidate is mapped to classes
+ *    when the chunk is preloaded).  Uniform-cost engines (weighted / codepoint Levenshtein) compare the symbol with the
+ *    lane's R query symbols held in registers - bytes and UTF-32 runes alike.
+ *
+ *  Borders, the finite affine "discard" seeds and the clamp of local alignment follow weighted.hip (and through it
+ *  serial.hpp:821-823,1045-1056,1195-1201,957-965) to the letter; tests pin both tiers against the same oracle.
+ */
+#include "device_common.hpp"
+
+namespace szs_hip {
+
+#ifndef SZS_SYSTOLIC_ROWS
+#define SZS_SYSTOLIC_ROWS 8
+#endif
+constexpr int systolic_rows_k = SZS_SYSTOLIC_ROWS;              // R: query rows per lane
+constexpr u32 systolic_band_rows_k = 64u * systolic_rows_k;     // query rows per band = per wavefront
+constexpr u32 systolic_waves_k = 4;                             // wavefronts per workgroup; each pulls its own tickets
+constexpr u32 systolic_chunk_k = 64;                            // columns per hand-over between bands
+constexpr u32 systolic_slack_k = 64;                            // parked columns past the longest candidate
+constexpr size_t systolic_header_bytes_k = 256;                 // ticket counter at the head of the workspace
+static_assert(systolic_rows_k % 4 == 0 && systolic_rows_k <= 16, "R int8 costs are fetched as one LDS read");
+static_assert(systolic_band_rows_k == SZS_SYSTOLIC_BAND_ROWS, "the host planner models bands of this height");
+
+__device__ __forceinline__ i32 smax2(i32 a, i32 b) { return a > b ? a : b; }
+__device__ __forceinline__ i32 smax3(i32 a, i32 b, i32 c) { return smax2(smax2(a, b), c); }
+
+/** `value` of lane l-1 for every lane l >= 1; lane 0 receives `first` (wave-uniform).  One v_mov_b32_dpp wave_shr:1. */
+__device__ __forceinline__ u32 from_lane_above(u32 first, u32 value) {
+    return (u32)__builtin_amdgcn_update_dpp((int)first, (int)value, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+}
+__device__ __forceinline__ i32 from_lane_above(i32 first, i32 value) {
+    return __builtin_amdgcn_update_dpp(first, value, 0x138, 0xF, 0xF, false);
+}
+
+/** See weighted.hip `gapped`: plain signed add, or - local alignment with non-positive gap costs, where every value a
+ *  gap applies to is >= 0 - one unsigned saturating subtract of the penalty. */
+template <bool saturating_>
+__device__ __forceinline__ i32 systolic_gapped(i32 value, i32 gap) {
+    if constexpr (saturating_) return (i32)__builtin_elementwise_sub_sat((u32)value, (u32)(-gap));
+    else return value + gap;
+}
+
+/** The lane's column of R cells in the form the recurrences consume them (weighted.hip `strip_column_t`). */
+template <bool affine_>
+struct systolic_column_t {
+    i32 h[systolic_rows_k];
+    i32 h_gapped[systolic_rows_k];
+    i32 across_extended[affine_ ? systolic_rows_k : 1];
+};
+
+/**
+ *  One lane, one column: the recurrences of serial.hpp:846-848 (linear) and :1091-1102 (Gotoh), local alignment clamping
+ *  only the substitution branch (:957-965, :1238-1239).  `cost_of(r)` yields the substitution cost of row r.
+ */
+template <bool local_, bool affine_, bool saturating_, typename cost_of_t>
+__device__ __forceinline__ void systolic_advance(systolic_column_t<affine_> &column, cost_of_t cost_of, i32 above_h,
+                                                 i32 above_down, i32 &diagonal, i32 gap_open, i32 gap_extend,
+                                                 i32 &down_out, i32 &best, u32 counted_rows) {
+    constexpr int rows = systolic_rows_k;
+    i32 diag = diagonal;
+    diagonal = above_h;
+    i32 above_gapped = systolic_gapped<saturating_>(above_h, gap_open);
+    i32 down_extended = affine_ ? systolic_gapped<saturating_>(above_down, gap_extend) : 0;
+    i32 down = 0;
+#pragma unroll
+    for (int r = 0; r < rows; ++r) {
+        i32 substituted = diag + cost_of(r);
+        if constexpr (local_ && !saturating_) substituted = smax2(substituted, 0);
+        diag = column.h[r];
+        i32 cell;
+        if constexpr (affine_) {
+            i32 const across = smax2(column.h_gapped[r], column.across_extended[r]);
+            down = smax2(above_gapped, down_extended);
+            cell = smax3(down, across, substituted);
+            column.across_extended[r] = systolic_gapped<saturating_>(across, gap_extend);
+            down_extended = systolic_gapped<saturating_>(down, gap_extend);
+        }
+        else { cell = smax3(above_gapped, column.h_gapped[r], substituted); }
+        column.h[r] = cell;
+        above_gapped = systolic_gapped<saturating_>(cell, gap_open);
+        column.h_gapped[r] = above_gapped;
+    }
+    down_out = down;
+    if constexpr (local_) {
+        if (counted_rows >= (u32)rows) {
+#pragma unroll
+            for (int r = 0; r < rows; r += 2) best = smax3(best, column.h[r], column.h[r + 1]);
+        }
+        else { // lanes of the last band that hold padded rows: those never count
+#pragma unroll
+            for (int r = 0; r < rows; ++r)
+                if ((u32)r < counted_rows) best = smax2(best, column.h[r]);
+        }
+    }
+}
+
+/**
+ *  @tparam local_       Smith-Waterman instead of a global alignment.
+ *  @tparam affine_      Gotoh's three tracks instead of one.
+ *  @tparam uniform_     (match, mismatch) costs on raw symbols - Levenshtein engines, maximising negated costs - instead
+ *                       of the 32x32 class table.
+ *  @tparam runes_       (with uniform_) strings are UTF-32 arrays, lengths count runes.
+ *  @tparam saturating_  (with local_) both gap costs <= 0: unsigned-saturating gap arithmetic.
+ *
+ *  Workspace (all zeroed by the launcher except the parked rows):
+ *    progress[pair * max_bands + band]  columns of that band's bottom row that are parked and visible
+ *    pair_best[pair], pair_done[pair]   local alignment: running maximum and finished bands of the pair
+ *    parked[pair][plane][column]        bottom rows in flight (plane 0: H, plane 1: vertical-gap track), reused IN PLACE
+ *                                       by successive bands: a band overwrites column j 63 steps after it consumed it.
+ */
+template <bool local_, bool affine_, bool uniform_, bool runes_, bool saturating_>
+__global__ __launch_bounds__(64 * systolic_waves_k) void systolic_scores_kernel(
+    szs_cost_model_t const *__restrict__ model, szs_string_ref_t const *__restrict__ queries, u32 queries_count,
+    szs_string_ref_t const *__restrict__ candidates, u32 candidates_count, u32 max_bands, i64 *__restrict__ results,
+    u64 results_row_stride, int symmetric, u32 *__restrict__ work_counter, u32 *progress, i32 *pair_best, u32 *pair_done,
+    i32 *parked, u32 parked_columns) {
+
+    constexpr int rows = systolic_rows_k;
+    constexpr int cost_dwords = rows / 4;
+    static_assert(!runes_ || uniform_, "codepoint scoring exists for uniform costs only");
+    static_assert(!saturating_ || local_, "saturating gap arithmetic is a local-alignment form");
+
+    // Class-table engines: [wave][class][lane] packed int8 costs of the lane's rows; shared: the table and the byte map.
+    __shared__ __attribute__((aligned(16))) u32 profiles[uniform_ ? 1 : systolic_waves_k * 32 * 64 * cost_dwords];
+    __shared__ int8_t table[uniform_ ? 1 : 32 * 32];
+    __shared__ u8 class_of_byte[uniform_ ? 1 : 256];
+
+    u32 const lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    i32 const gap_open = model->gap_open, gap_extend = model->gap_extend;
+    i32 const uniform_match = model->uniform_match, uniform_mismatch = model->uniform_mismatch;
+    if constexpr (!uniform_) {
+        class_of_byte[threadIdx.x] = model->byte_to_class[threadIdx.x];
+        for (u32 i = threadIdx.x; i < 32 * 32; i += 64 * systolic_waves_k) table[i] = (int8_t)model->substitution[i];
+        __syncthreads(); // the only barrier: from here on every wavefront runs on its own
+    }
+    u32 *const profile = profiles + (uniform_ ? 0 : wave * 32 * 64 * cost_dwords) + (uniform_ ? 0 : lane * cost_dwords);
+
+    u64 const total_tickets = (u64)queries_count * candidates_count * max_bands;
+    u32 const planes = affine_ ? 2 : 1;
+
+    for (;;) {
+        u32 ticket = 0;
+        if (lane == 0) ticket = atomicAdd(work_counter, 1u);
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
+        if (ticket >= total_tickets) break;
+        u32 const pair = ticket / max_bands, band = ticket % max_bands;
+        szs_string_ref_t const query = queries[pair / candidates_count];
+        szs_string_ref_t const candidate = candidates[pair % candidates_count];
+        if ((symmetric & SZS_LAYOUT_SYMMETRIC) && candidate.index > query.index) continue; // upper triangle: mirrored from below
+        u32 const m = query.length, n = candidate.length;
+        u32 const bands = m ? (m + systolic_band_rows_k - 1) / systolic_band_rows_k : 1;
+        if (band >= bands) continue;
+
+        // All-gap borders (weighted.hip; serial.hpp:821-823,1045-1047): DP cell (k, 0) and (0, k).
+        auto border = [&](u32 k) -> i32 {
+            if constexpr (local_) return 0;
+            if constexpr (affine_) return k ? gap_open + gap_extend * (i32)(k - 1) : 0;
+            return gap_open * (i32)k;
+        };
+        auto write_result = [&](i32 score) {
+            i64 const value = uniform_ ? -(i64)score : (i64)score;
+            bool const transposed = (symmetric & SZS_LAYOUT_TRANSPOSED) != 0; // kernel roles swapped by the host
+            u64 const row = transposed ? candidate.index : query.index, column = transposed ? query.index : candidate.index;
+            results[row * results_row_stride + column] = value;
+            if ((symmetric & SZS_LAYOUT_SYMMETRIC) && candidate.index != query.index)
+                results[column * results_row_stride + row] = value;
+        };
+        if (m == 0 || n == 0) { // an empty side never enters the column loop: the score is the border itself
+            if (lane == 0) write_result(local_ ? 0 : border(m ? m : n));
+            continue;
+        }
+
+        bool const first_band = band == 0, last_band = band + 1 == bands;
+        u32 const band_first = band * systolic_band_rows_k;
+        u32 const first_row = band_first + lane * rows;                                // 0-based string row
+        u32 const my_rows = first_row >= m ? 0u : (m - first_row < (u32)rows ? m - first_row : (u32)rows);
+
+        // ---- the lane's query rows: classes folded into the LDS profile, or raw symbols kept in registers
+        u32 query_symbols[uniform_ ? rows : 1];
+        if constexpr (uniform_) {
+#pragma unroll
+            for (int r = 0; r < rows; ++r) {
+                u32 symbol = ~0u; // padded rows: equal to no byte and to no decoded rune
+                if ((u32)r < my_rows)
+                    symbol = runes_ ? reinterpret_cast<u32 const *>(query.address)[first_row + r]
+                                    : (u32) reinterpret_cast<u8 const *>(query.address)[first_row + r];
+                query_symbols[r] = symbol;
+            }
+        }
+        else {
+            u32 classes[rows];
+#pragma unroll
+            for (int r = 0; r < rows; ++r)
+                classes[r] = (u32)r < my_rows ? (u32)class_of_byte[reinterpret_cast<u8 const *>(query.address)[first_row + r]] : 0u;
+            for (u32 candidate_class = 0; candidate_class < 32; ++candidate_class) {
+                u32 packed[cost_dwords];
+#pragma unroll
+                for (int r = 0; r < rows; ++r) {
+                    // cost(query, candidate) = table[class(query)][class(candidate)]: the QUERY picks the row
+                    i32 const cost = (u32)r < my_rows ? (i32)table[classes[r] * 32 + candidate_class] : 0;
+                    if (r % 4 == 0) packed[r / 4] = 0;
+                    packed[r / 4] |= ((u32)cost & 0xFFu) << (8 * (r % 4));
+                }
+#pragma unroll
+                for (int d = 0; d < cost_dwords; ++d) profile[candidate_class * 64 * cost_dwords + d] = packed[d];
+            }
+        }
+
+        // ---- column 0 of the lane's rows; finite "discard" seeds of the gap tracks (serial.hpp:1049-1056,1195-1201)
+        systolic_column_t<affine_> column;
+#pragma unroll
+        for (int r = 0; r < rows; ++r) {
+            column.h[r] = border(first_row + r + 1);
+            column.h_gapped[r] = systolic_gapped<saturating_>(column.h[r], gap_open);
+            if constexpr (affine_)
+                column.across_extended[r] = saturating_ ? 0 : column.h[r] + gap_open + gap_extend + gap_extend;
+        }
+        i32 diagonal = border(first_row); // DP cell (row above the lane's first, column - 1)
+        i32 best = 0, down_out = 0;
+        i32 bottom_h = 0, bottom_down = 0; // this lane's bottom row at its latest column: what the lane below consumes
+
+        i32 *const parked_h = parked + (u64)pair * planes * parked_columns; // [1-based DP column]
+        i32 *const parked_down = parked_h + parked_columns;
+        u32 *const progress_out = progress + (u64)pair * max_bands + band;
+        u32 const *const progress_in = progress_out - 1;
+
+        auto symbol_at = [&](u32 index) -> u32 { // what lane 0 feeds into the array for column `index` < n
+            if constexpr (runes_) return reinterpret_cast<u32 const *>(candidate.address)[index];
+            else if constexpr (uniform_) return (u32) reinterpret_cast<u8 const *>(candidate.address)[index];
+            else return (u32)class_of_byte[reinterpret_cast<u8 const *>(candidate.address)[index]];
+        };
+
+        // Lane 0's inputs are preloaded a chunk (64 columns, one per lane) at a time and picked per step by readlane:
+        //   `chunk_*` feed the steps of the current chunk, `next_*` were loaded one chunk EARLIER for the chunk after it,
+        //   so neither the text nor the parked row is ever waited for inside a chunk.  The price is that a band only
+        //   starts a chunk when its predecessor has parked the NEXT chunk as well (it trails by ~192 columns, not ~128).
+        u32 chunk_symbols = 0, next_symbols = lane < n ? symbol_at(lane) : 0u;
+        i32 chunk_above = 0, chunk_down = 0, next_above = 0, next_down = 0;
+        u32 parked_seen = 0; // the predecessor's progress counter as last read
+        auto preload_above = [&](u32 chunk_first) { // columns [chunk_first, chunk_first + 64) of the predecessor's bottom row
+            u32 const needed = chunk_first + 64 < n ? chunk_first + 64 : n;
+            while (parked_seen < needed) {
+                parked_seen = __hip_atomic_load(progress_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (parked_seen < needed) __builtin_amdgcn_s_sleep(2);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            u32 const mine = chunk_first + lane;
+            if (mine < n) {
+                next_above = parked_h[mine + 1];
+                if constexpr (affine_) next_down = parked_down[mine + 1];
+            }
+        };
+        if (!first_band) preload_above(0);
+        u32 const steps = n + 63; // lane l is busy during steps [l, l + n)
+
+        // The symbol pipeline runs ONE STEP AHEAD of the score pipeline: `symbol_ahead` of lane l is the symbol of the
+        // column the lane scores next step, so its profile row is fetched from LDS a whole step before it is consumed.
+        u32 symbol_ahead = 0;
+        u32 costs_ahead[uniform_ ? 1 : cost_dwords];
+        auto advance_symbols = [&](u32 fed_symbol) {
+            symbol_ahead = from_lane_above(fed_symbol, symbol_ahead);
+            if constexpr (!uniform_) { // always a valid class: everything ever fed is a class id or 0
+                u32 const *const row = profile + symbol_ahead * (64 * cost_dwords);
+                if constexpr (cost_dwords == 2) {
+                    uint2 const both = *reinterpret_cast<uint2 const *>(row);
+                    costs_ahead[0] = both.x, costs_ahead[1] = both.y;
+                }
+                else if constexpr (cost_dwords == 4) {
+                    uint4 const all = *reinterpret_cast<uint4 const *>(row);
+                    costs_ahead[0] = all.x, costs_ahead[1] = all.y, costs_ahead[2] = all.z, costs_ahead[3] = all.w;
+                }
+                else { costs_ahead[0] = row[0]; }
+            }
+        };
+
+        // One step of the whole wavefront.  `slot` = step % 64 selects lane 0's inputs out of the preloaded chunk.
+        auto step = [&](u32 t, u32 slot, auto predicated) {
+            u32 const symbol = symbol_ahead; // of column t - lane
+            u32 packed[uniform_ ? 1 : cost_dwords];
+            if constexpr (!uniform_)
+                for (int d = 0; d < cost_dwords; ++d) packed[d] = costs_ahead[d];
+            // feed column t + 1 into the symbol pipeline: the last slot of a chunk takes it from the next chunk's preload
+            u32 const fed_symbol = slot == 63 ? (u32)__builtin_amdgcn_readlane((int)next_symbols, 0)
+                                              : (u32)__builtin_amdgcn_readlane((int)chunk_symbols, (int)(slot + 1));
+            advance_symbols(fed_symbol);
+
+            i32 fed_above, fed_down = 0;
+            if (first_band) {
+                fed_above = border(t + 1);
+                if constexpr (affine_) fed_down = saturating_ ? 0 : fed_above + gap_open + gap_extend;
+            }
+            else {
+                fed_above = __builtin_amdgcn_readlane(chunk_above, (int)slot);
+                if constexpr (affine_) fed_down = __builtin_amdgcn_readlane(chunk_down, (int)slot);
+            }
+            i32 const above_h = from_lane_above(fed_above, bottom_h);
+            i32 above_down = 0;
+            if constexpr (affine_) above_down = from_lane_above(fed_down, bottom_down);
+            bool const busy = decltype(predicated)::value ? (t - lane) < n : true;
+            if (busy) {
+                if constexpr (uniform_) {
+                    auto cost_of = [&](int r) -> i32 { return query_symbols[r] == symbol ? uniform_match : uniform_mismatch; };
+                    systolic_advance<local_, affine_, saturating_>(column, cost_of, above_h, above_down, diagonal, gap_open,
+                                                                   gap_extend, down_out, best, my_rows);
+                }
+                else {
+                    auto cost_of = [&](int r) -> i32 { return (i32)(int8_t)(packed[r / 4] >> (8 * (r % 4))); };
+                    systolic_advance<local_, affine_, saturating_>(column, cost_of, above_h, above_down, diagonal, gap_open,
+                                                                   gap_extend, down_out, best, my_rows);
+                }
+                bottom_h = column.h[rows - 1];
+                if constexpr (affine_) bottom_down = down_out;
+                if (!last_band && lane == 63) { // the band's bottom row, 1-based DP column t - 62
+                    parked_h[t - 62] = bottom_h;
+                    if constexpr (affine_) parked_down[t - 62] = bottom_down;
+                }
+            }
+            // Publish the parked columns every `systolic_chunk_k` of them and at the end of the text.
+            if (!last_band && t >= 63) {
+                u32 const parked_count = t - 62;
+                if ((parked_count % systolic_chunk_k == 0 || parked_count == n) && lane == 63)
+                    __hip_atomic_store(progress_out, parked_count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        };
+
+        for (u32 chunk_first = 0; chunk_first < steps; chunk_first += 64) {
+            // ---- lane 0 is about to consume columns [chunk_first, chunk_first + 64)
+            if (chunk_first < n) {
+                chunk_symbols = next_symbols, chunk_above = next_above, chunk_down = next_down;
+                u32 const mine = chunk_first + 64 + lane; // the column this lane preloads for the chunk after this one
+                next_symbols = mine < n ? symbol_at(mine) : 0u;
+                if (!first_band && chunk_first + 64 < n) preload_above(chunk_first + 64);
+                if (chunk_first == 0) advance_symbols((u32)__builtin_amdgcn_readlane((int)chunk_symbols, 0)); // column 0
+            }
+            bool const steady = chunk_first >= 64 && chunk_first + 64 <= n; // every lane busy during all 64 steps
+            if (steady) {
+#pragma unroll 2
+                for (u32 slot = 0; slot < 64; ++slot) step(chunk_first + slot, slot, std::false_type {});
+            }
+            else {
+                u32 const stop = steps - chunk_first < 64 ? steps - chunk_first : 64;
+#pragma unroll 1
+                for (u32 slot = 0; slot < stop; ++slot) step(chunk_first + slot, slot, std::true_type {});
+            }
+        }
+
+        // ---- the pair's score
+        if constexpr (local_) {
+            u32 const wave_best = wave_max_u32((u32)best); // local scores are >= 0
+            if (bands == 1) {
+                if (lane == 0) write_result((i32)wave_best);
+            }
+            else if (lane == 0) { // the band that finishes last reports the maximum over all of them
+                __hip_atomic_fetch_max(pair_best + pair, (i32)wave_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                u32 const finished =
+                    __hip_atomic_fetch_add(pair_done + pair, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                if (finished + 1 == bands)
+                    write_result(__hip_atomic_load(pair_best + pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            }
+        }
+        else if (last_band) { // bottom-right cell: the last real row, frozen at the owning lane's last column
+            u32 const last_row = m - 1 - band_first;
+            i32 mine = 0;
+#pragma unroll
+            for (int r = 0; r < rows; ++r)
+                if ((u32)r == last_row % rows) mine = column.h[r];
+            i32 const score = __builtin_amdgcn_readlane(mine, (int)(last_row / rows));
+            if (lane == 0) write_result(score);
+        }
+    }
+}
+
+/** Workgroups of this instance the device keeps resident at once (the grid never needs to be larger). */
+template <bool local_, bool affine_, bool uniform_, bool runes_, bool saturating_>
+static u32 systolic_grid(u64 tickets) {
+    static int resident = 0;
+    if (!resident) {
+        int device = 0, units = 0, per_unit = 0;
+        if (hipGetDevice(&device) != hipSuccess ||
+            hipDeviceGetAttribute(&units, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_unit, systolic_scores_kernel<local_, affine_, uniform_, runes_, saturating_>,
+                                                         (int)(64 * systolic_waves_k), 0) != hipSuccess ||
+            units <= 0 || per_unit <= 0) {
+            (void)hipGetLastError();
+            units = 256, per_unit = 2;
+        }
+        resident = units * per_unit;
+    }
+    u64 const wanted = (tickets + systolic_waves_k - 1) / systolic_waves_k;
+    return (u32)(wanted < (u64)resident ? wanted : (u64)resident);
+}
+
+struct systolic_layout_t {
+    u64 pairs, tickets;
+    u32 max_bands, parked_columns;
+    size_t progress_at, best_at, done_at, parked_at, zeroed_bytes, total_bytes;
+};
+
+static systolic_layout_t systolic_layout(int affine, u32 queries_count, u32 candidates_count, u32 longest_query,
+                                         u32 longest_candidate) {
+    systolic_layout_t layout;
+    layout.pairs = (u64)queries_count * candidates_count;
+    layout.max_bands = longest_query ? (longest_query + systolic_band_rows_k - 1) / systolic_band_rows_k : 1;
+    layout.tickets = layout.pairs * layout.max_bands;
+    layout.parked_columns = longest_candidate + 1 + systolic_slack_k;
+    layout.progress_at = systolic_header_bytes_k;
+    layout.best_at = layout.progress_at + layout.tickets * sizeof(u32);
+    layout.done_at = layout.best_at + layout.pairs * sizeof(i32);
+    layout.zeroed_bytes = layout.done_at + layout.pairs * sizeof(u32);
+    layout.parked_at = (layout.zeroed_bytes + 255) & ~(size_t)255;
+    layout.total_bytes = layout.parked_at + layout.pairs * (affine ? 2 : 1) * layout.parked_columns * sizeof(i32);
+    return layout;
+}
+
+template <bool local_, bool affine_, bool uniform_, bool runes_ = false, bool saturating_ = false>
+static int launch_systolic(szs_cost_model_t const *model, szs_string_ref_t const *queries, u32 queries_count,
+                           szs_string_ref_t const *candidates, u32 candidates_count, u32 longest_query,
+                           u32 longest_candidate, i64 *results, u64 stride, int symmetric, void *workspace,
+                           hipStream_t stream) {
+    systolic_layout_t const layout = systolic_layout(affine_, queries_count, candidates_count, longest_query, longest_candidate);
+    if (layout.tickets > 0xFFFFFFF0ull) return (int)hipErrorInvalidValue; // the host keeps larger jobs on weighted.hip
+    char *const base = static_cast<char *>(workspace);
+    hipError_t const error = hipMemsetAsync(base, 0, layout.zeroed_bytes, stream);
+    if (error != hipSuccess) return (int)error;
+    u32 const grid = systolic_grid<local_, affine_, uniform_, runes_, saturating_>(layout.tickets);
+    hipLaunchKernelGGL((systolic_scores_kernel<local_, affine_, uniform_, runes_, saturating_>), dim3(grid),
+                       dim3(64 * systolic_waves_k), 0, stream, model, queries, queries_count, candidates, candidates_count,
+                       layout.max_bands, results, stride, symmetric, reinterpret_cast<u32 *>(base),
+                       reinterpret_cast<u32 *>(base + layout.progress_at), reinterpret_cast<i32 *>(base + layout.best_at),
+                       reinterpret_cast<u32 *>(base + layout.done_at), reinterpret_cast<i32 *>(base + layout.parked_at),
+                       layout.parked_columns);
+    return (int)hipGetLastError();
+}
+
+} // namespace szs_hip
+
+extern "C" unsigned szs_hip_systolic_band_rows(void) { return szs_hip::systolic_band_rows_k; }
+
+extern "C" size_t szs_hip_systolic_workspace_bytes(int affine, uint32_t queries_count, uint32_t candidates_count,
+                                                   uint32_t longest_query, uint32_t longest_candidate) {
+    szs_hip::systolic_layout_t const layout =
+        szs_hip::systolic_layout(affine, queries_count, candidates_count, longest_query, longest_candidate);
+    return layout.tickets > 0xFFFFFFF0ull ? 0 : layout.total_bytes;
+}
+
+extern "C" int szs_hip_systolic_scores(int objective, int affine, szs_cost_model_t const *model,
+                                       szs_string_ref_t const *queries, uint32_t queries_count,
+                                       szs_string_ref_t const *candidates, uint32_t candidates_count,
+                                       uint32_t longest_query, uint32_t longest_candidate, int64_t *results,
+                                       uint64_t results_row_stride, int symmetric, void *workspace, void *stream) {
+    using namespace szs_hip;
+    if (!queries_count || !candidates_count) return 0;
+    hipStream_t const s = static_cast<hipStream_t>(stream);
+#define SZS_SYSTOLIC_LAUNCH(...)                                                                                       \
+    return launch_systolic<__VA_ARGS__>(model, queries, queries_count, candidates, candidates_count, longest_query,    \
+                                        longest_candidate, results, results_row_stride, symmetric, workspace, s)
+    switch (objective) {
+    case szs_objective_global_k:
+        if (affine) SZS_SYSTOLIC_LAUNCH(false, true, false);
+        SZS_SYSTOLIC_LAUNCH(false, false, false);
+    case szs_objective_local_k:
+        if (affine) SZS_SYSTOLIC_LAUNCH(true, true, false);
+        SZS_SYSTOLIC_LAUNCH(true, false, false);
+    case szs_objective_local_saturating_k:
+        if (affine) SZS_SYSTOLIC_LAUNCH(true, true, false, false, true);
+        SZS_SYSTOLIC_LAUNCH(true, false, false, false, true);
+    case szs_objective_distance_k:
+        if (affine) SZS_SYSTOLIC_LAUNCH(false, true, true);
+        SZS_SYSTOLIC_LAUNCH(false, false, true);
+    case szs_objective_distance_runes_k:
+        if (affine) SZS_SYSTOLIC_LAUNCH(false, true, true, true);
+        SZS_SYSTOLIC_LAUNCH(false, false, true, true);
+    default: break;
+    }
+#undef SZS_SYSTOLIC_LAUNCH
+    return (int)hipErrorInvalidValue;
+}

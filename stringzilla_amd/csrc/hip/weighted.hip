@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256, SZS_WEIGHTED_WAVES) void weighted_scores_kerne
         bool live = candidate_slot < candidates_count;
         szs_string_ref_t candidate = {0, 0, 0};
         if (live) candidate = candidates[candidate_slot];
-        if (symmetric && candidate.index > query.index) live = false;
+        if ((symmetric & SZS_LAYOUT_SYMMETRIC) && candidate.index > query.index) live = false;
         u32 const text_length = live ? candidate.length : 0;
         u32 const longest_in_wave = wave_max_u32(text_length);
         u32 const shortest_in_wave = ~wave_max_u32(live ? ~text_length : 0u); // over live lanes
@@ -441,9 +441,11 @@ __global__ __launch_bounds__(256, SZS_WEIGHTED_WAVES) void weighted_scores_kerne
 
         if (live) {
             i64 const value = uniform_ ? -(i64)score : (i64)score;
-            results[(u64)query.index * results_row_stride + candidate.index] = value;
-            if (symmetric && candidate.index != query.index)
-                results[(u64)candidate.index * results_row_stride + query.index] = value;
+            bool const transposed = (symmetric & SZS_LAYOUT_TRANSPOSED) != 0; // kernel roles swapped by the host
+            u64 const row = transposed ? candidate.index : query.index, column = transposed ? query.index : candidate.index;
+            results[row * results_row_stride + column] = value;
+            if ((symmetric & SZS_LAYOUT_SYMMETRIC) && candidate.index != query.index)
+                results[column * results_row_stride + row] = value;
         }
     }
 }

@@ -176,7 +176,7 @@ static sz_status_t transcode_to_runes(szs_engine_s *engine, int device, hipStrea
     return sz_success_k;
 }
 
-static void fill_cost_model(szs_engine_s const *engine, szs_cost_model_t *model) {
+static void fill_cost_model(szs_engine_s const *engine, int transposed, szs_cost_model_t *model) {
     memset(model, 0, sizeof(*model));
     if (engine->family == szs_family_levenshtein_k || engine->family == szs_family_levenshtein_utf8_k) {
         /* Minimising non-negative costs == maximising their negation; the kernel negates the result back. */
@@ -184,7 +184,11 @@ static void fill_cost_model(szs_engine_s const *engine, szs_cost_model_t *model)
         model->gap_open = -(int32_t)engine->open, model->gap_extend = -(int32_t)engine->extend;
     }
     else {
-        for (int i = 0; i < 32 * 32; ++i) model->substitution[i] = engine->class_costs[i];
+        /* cost(query, candidate) = table[class(query)][class(candidate)] (serial.hpp:199-204): when the planner swapped
+         * the sides, the kernel's "query" is the caller's candidate, so it must see the transposed table. */
+        for (int i = 0; i < 32; ++i)
+            for (int j = 0; j < 32; ++j)
+                model->substitution[i * 32 + j] = transposed ? engine->class_costs[j * 32 + i] : engine->class_costs[i * 32 + j];
         memcpy(model->byte_to_class, engine->byte_to_class, 256);
         model->gap_open = engine->open, model->gap_extend = engine->extend;
     }
@@ -317,25 +321,44 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
         if (status != sz_success_k) return status;
     }
 
-    /* Plan straight into the pinned staging area, then ship both ref arrays in one copy. */
-    szs_string_ref_t *host_query_refs = (szs_string_ref_t *)engine->pinned_staging.pointer;
-    szs_string_ref_t *host_candidate_refs = host_query_refs + q_count;
-    szs_plan_t plan;
     int const use_myers = engine->is_unit_cost && (engine->family == szs_family_levenshtein_k ||
                                                    engine->family == szs_family_levenshtein_utf8_k);
-    szs_plan_build(!use_myers ? 0 : runes ? SZS_MYERS_SHORT_WORDS : SZS_MYERS_MAX_WORDS, symmetric, q_addresses, q_lengths, q_count, c_addresses, c_lengths, c_count,
+    int const maximise = engine->family == szs_family_needleman_wunsch_k || engine->family == szs_family_smith_waterman_k;
+    unsigned const myers_words = !use_myers ? 0 : runes ? SZS_MYERS_SHORT_WORDS : SZS_MYERS_MAX_WORDS;
+
+    /* ---- orientation and tier.  Every kernel puts ONE side on workgroups / band chains (its "queries") and the other
+     * on lanes / columns (its "candidates"); which real side plays which role is free - gap costs apply to both strings
+     * alike and a swapped class table is its transpose - so a cycle model of both tiers (plan.c) is evaluated for both
+     * orientations and the cheaper one runs.  1024 queries x 1 candidate thus become 1 workgroup row of 1024 lanes
+     * instead of 1024 workgroups with one live lane each.  Symmetric calls have nothing to swap. */
+    uint32_t q_longest = 0, c_longest = 0;
+    for (uint32_t i = 0; i < q_count; ++i) q_longest = q_lengths[i] > q_longest ? q_lengths[i] : q_longest;
+    for (uint32_t i = 0; i < c_count; ++i) c_longest = c_lengths[i] > c_longest ? c_lengths[i] : c_longest;
+    int tier = SZS_TIER_LANES, transposed = 0;
+    szs_plan_orient(myers_words * 32, !engine->is_linear, !maximise, symmetric, q_lengths, q_count, c_lengths, c_count,
+                    szs_hip_systolic_band_rows(), &tier, &transposed);
+    /* kernel roles */
+    uint64_t *const kq_addresses = transposed ? c_addresses : q_addresses, *const kc_addresses = transposed ? q_addresses : c_addresses;
+    uint32_t *const kq_lengths = transposed ? c_lengths : q_lengths, *const kc_lengths = transposed ? q_lengths : c_lengths;
+    uint32_t const kq_count = transposed ? c_count : q_count, kc_count = transposed ? q_count : c_count;
+    int const layout = (symmetric ? SZS_LAYOUT_SYMMETRIC : 0) | (transposed ? SZS_LAYOUT_TRANSPOSED : 0);
+
+    /* Plan straight into the pinned staging area, then ship both ref arrays in one copy. */
+    szs_string_ref_t *host_query_refs = (szs_string_ref_t *)engine->pinned_staging.pointer;
+    szs_string_ref_t *host_candidate_refs = host_query_refs + kq_count;
+    szs_plan_t plan;
+    szs_plan_build(myers_words, symmetric, kq_addresses, kq_lengths, kq_count, kc_addresses, kc_lengths, kc_count,
                    host_query_refs, host_candidate_refs, keys, &plan);
 
     /* Cell width: this build scores weighted cells in 32 bits, so refuse what the reference would widen to 64 bits
      * (reach rule, serial.hpp:135-162,370-386). */
-    int const maximise = engine->family == szs_family_needleman_wunsch_k || engine->family == szs_family_smith_waterman_k;
     uint64_t const span = maximise ? (uint64_t)plan.longest_query + plan.longest_candidate
                                    : (plan.longest_query > plan.longest_candidate ? plan.longest_query : plan.longest_candidate);
     uint64_t const reach = (span + (engine->is_linear ? 1 : 3)) * (engine->magnitude ? engine->magnitude : 1);
     if (reach >= 0x7FFFFFF0ull) return szs_report(sz_overflow_risk_k, error_message, NULL);
 
     szs_string_ref_t *device_query_refs = (szs_string_ref_t *)engine->device_refs.pointer;
-    szs_string_ref_t *device_candidate_refs = device_query_refs + q_count;
+    szs_string_ref_t *device_candidate_refs = device_query_refs + kq_count;
     hipError_t error = hipMemcpyAsync(device_query_refs, host_query_refs, refs_bytes, hipMemcpyHostToDevice, stream);
     if (error != hipSuccess) return szs_report_hip(error, error_message);
 
@@ -363,22 +386,34 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
                            ? (shorter_side + 3) * (engine->magnitude ? engine->magnitude : 1) < 32000
                            : 0;
 
+    /* The systolic tier scores every engine family with its weighted recurrences, so it needs the cost model and its
+     * own workspace; a job with too many pairs in flight for that workspace stays on the lanes tier. */
+    size_t systolic_bytes = 0;
+    if (tier == SZS_TIER_SYSTOLIC) {
+        systolic_bytes = szs_hip_systolic_workspace_bytes(!engine->is_linear, kq_count, kc_count, plan.longest_query,
+                                                          plan.longest_candidate);
+        if (!systolic_bytes || systolic_bytes > ((size_t)32 << 30)) tier = SZS_TIER_LANES;
+    }
+
     /* Weighted kernels need the cost model and a strip-boundary workspace on the device. */
-    int needs_weighted = !use_myers;
+    int needs_weighted = !use_myers || tier == SZS_TIER_SYSTOLIC;
     for (unsigned g = 0; g < plan.groups_count; ++g) needs_weighted |= plan.groups[g].variant == 0;
     if (needs_weighted) {
-        if (engine->model_uploaded_device != device) {
+        if (engine->model_uploaded_device != device || engine->model_uploaded_transposed != transposed) {
             status = szs_buffer_reserve(&engine->device_model, szs_memory_device_k, device, sizeof(szs_cost_model_t),
                                         error_message);
             if (status != sz_success_k) return status;
             szs_cost_model_t model;
-            fill_cost_model(engine, &model);
-            error = hipMemcpy(engine->device_model.pointer, &model, sizeof(model), hipMemcpyHostToDevice);
+            fill_cost_model(engine, transposed, &model);
+            error = hipMemcpyAsync(engine->device_model.pointer, &model, sizeof(model), hipMemcpyHostToDevice, stream);
+            if (error == hipSuccess) error = hipStreamSynchronize(stream); /* `model` lives on this stack frame */
             if (error != hipSuccess) return szs_report_hip(error, error_message);
-            engine->model_uploaded_device = device;
+            engine->model_uploaded_device = device, engine->model_uploaded_transposed = transposed;
         }
         size_t const boundary_bytes =
-            szs_hip_weighted_boundary_bytes(objective, !engine->is_linear, narrow, q_count, c_count, plan.longest_candidate);
+            tier == SZS_TIER_SYSTOLIC
+                ? systolic_bytes
+                : szs_hip_weighted_boundary_bytes(objective, !engine->is_linear, narrow, kq_count, kc_count, plan.longest_candidate);
         status = szs_buffer_reserve(&engine->device_boundary, szs_memory_device_k, device, boundary_bytes, error_message);
         if (status != sz_success_k) return status;
     }
@@ -387,23 +422,31 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
     error = hipEventRecord(engine->event_start, stream);
     if (error != hipSuccess) return szs_report_hip(error, error_message);
     uint32_t launches = 0;
-    for (unsigned g = 0; g < plan.groups_count; ++g) {
+    if (tier == SZS_TIER_SYSTOLIC) { /* one launch for the whole cross-product, whatever the planner's groups */
+        int const launch_error = szs_hip_systolic_scores(
+            objective, !engine->is_linear, (szs_cost_model_t const *)engine->device_model.pointer,
+            device_query_refs, kq_count, device_candidate_refs, kc_count, plan.longest_query, plan.longest_candidate,
+            (int64_t *)device_results, device_stride, layout, engine->device_boundary.pointer, stream);
+        if (launch_error) return szs_report_hip((hipError_t)launch_error, error_message);
+        ++launches;
+    }
+    for (unsigned g = 0; tier == SZS_TIER_LANES && g < plan.groups_count; ++g) {
         szs_plan_group_t const *group = &plan.groups[g];
         int launch_error;
         if (group->variant && runes)
             launch_error = szs_hip_levenshtein_myers_runes(device_query_refs + group->first, group->count,
-                                                           device_candidate_refs, c_count, (uint64_t *)device_results,
-                                                           device_stride, symmetric, stream);
+                                                           device_candidate_refs, kc_count, (uint64_t *)device_results,
+                                                           device_stride, layout, stream);
         else if (group->variant)
             launch_error = szs_hip_levenshtein_myers(group->variant, device_query_refs + group->first, group->count,
-                                                     device_candidate_refs, c_count, (uint64_t *)device_results,
-                                                     device_stride, symmetric, stream);
+                                                     device_candidate_refs, kc_count, (uint64_t *)device_results,
+                                                     device_stride, layout, stream);
         else
             launch_error = szs_hip_weighted_scores(objective, !engine->is_linear, narrow,
                                                    (szs_cost_model_t const *)engine->device_model.pointer,
                                                    device_query_refs + group->first, group->count,
-                                                   device_candidate_refs, c_count, plan.longest_candidate,
-                                                   (int64_t *)device_results, device_stride, symmetric,
+                                                   device_candidate_refs, kc_count, plan.longest_candidate,
+                                                   (int64_t *)device_results, device_stride, layout,
                                                    engine->device_boundary.pointer, stream);
         if (launch_error) return szs_report_hip((hipError_t)launch_error, error_message);
         ++launches;
@@ -436,7 +479,9 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
     profile->unique_bytes = query_bytes + (symmetric ? 0 : candidate_bytes) +
                             ((uint64_t)q_count + 1 + (symmetric ? 0 : c_count + 1)) * 4 + (uint64_t)q_count * c_count * 8;
     profile->launches = launches;
-    profile->longest_query = plan.longest_query, profile->longest_candidate = plan.longest_candidate;
+    profile->tier = (uint32_t)tier;
+    profile->transposed = (uint32_t)transposed;
+    profile->longest_query = q_longest, profile->longest_candidate = c_longest;
     profile->host_milliseconds = now_milliseconds() - call_started;
     return szs_report(sz_success_k, error_message, NULL);
 }

@@ -100,6 +100,85 @@ void szs_plan_build(unsigned myers, int symmetric, uint64_t const *query_address
     }
 }
 
+/* ---- tier and orientation choice ------------------------------------------------------------------------------------ */
+
+/**
+ *  Estimated SIMD cycles of a call and the tier that achieves them: lanes tier (lev_myers.hip / weighted.hip: one pair
+ *  per lane, one query per workgroup) or systolic tier (systolic.hip: one pair per chain of wavefronts).  A throughput
+ *  model good to a factor of two - which is all the decisions need, the alternatives are an order of magnitude apart
+ *  wherever they matter:
+ *    lanes    : a wavefront scores one query against up to 64 candidates, its lanes in lock step, `lane_rate` cells per
+ *               lane-cycle; at most 1024 wavefronts advance at once; the call lasts at least as long as its largest pair;
+ *    systolic : a wavefront-step scores 64 x R cells in `step_cycles`; a (pair, band) ticket takes len(candidate) + 63
+ *               steps; at most 1024 wavefronts advance at once; the call lasts at least as long as the band chain of its
+ *               largest pair (each band trails its predecessor by ~192 steps).
+ *  Constants from the measured gfx950 rates (profiles/r01/valu_peak.json): fast VALU ~2.5 cycles, slow ~4.2.
+ */
+double szs_plan_estimate(unsigned bit_parallel_limit, int affine, int uniform, int symmetric,
+                         uint32_t const *query_lengths, uint32_t queries_count, uint32_t candidates_count,
+                         uint64_t candidate_symbols, uint32_t longest_query, uint32_t longest_candidate,
+                         unsigned band_rows, int *tier) {
+    *tier = SZS_TIER_LANES;
+    if (!queries_count || !candidates_count) return 0;
+    double const simds = 1024.0;
+    double const mean_candidate = (double)candidate_symbols / candidates_count;
+    double const scale = symmetric ? 0.5 : 1.0; /* half the matrix is scored */
+
+    double query_symbols = 0, bands_total = 0;
+    for (uint32_t i = 0; i < queries_count; ++i) {
+        query_symbols += query_lengths[i];
+        bands_total += query_lengths[i] ? (query_lengths[i] + band_rows - 1) / band_rows : 1;
+    }
+
+    /* lanes: cells per lane-cycle; the bit-parallel kernels only exist up to `bit_parallel_limit` symbols per query */
+    int const bit_parallel = bit_parallel_limit && longest_query <= bit_parallel_limit;
+    double const lane_rate = bit_parallel ? 0.85 : 1.0 / ((affine ? 7.0 : 3.0) * 4.2);
+    double const waves_per_query = (candidates_count + 63) / 64;
+    double const lane_waves = queries_count * waves_per_query * scale;
+    double lanes_cycles = query_symbols * mean_candidate * waves_per_query * scale / lane_rate / (lane_waves < simds ? (lane_waves < 1 ? 1 : lane_waves) : simds);
+    double const largest_pair = (double)longest_query * longest_candidate / lane_rate;
+    if (largest_pair > lanes_cycles) lanes_cycles = largest_pair;
+
+    double const rows_per_lane = band_rows / 64.0;
+    double const ops_per_cell = (affine ? 7.0 : 3.0) + (uniform ? 2.0 : 0.0);
+    double const step_cycles = ops_per_cell * rows_per_lane * 4.2 + 40.0;
+    double tickets = bands_total * candidates_count * scale;
+    if (tickets < 1) tickets = 1;
+    double systolic_cycles = tickets * (mean_candidate + 63.0) * step_cycles / (tickets < simds ? tickets : simds);
+    double const longest_chain = (double)((longest_query + band_rows - 1) / band_rows);
+    double const chain_cycles = (longest_candidate + 63.0 + 192.0 * (longest_chain > 1 ? longest_chain - 1 : 0)) * step_cycles;
+    if (chain_cycles > systolic_cycles) systolic_cycles = chain_cycles;
+
+    char const *forced = getenv("SZS_ROCM_TIER"); /* testing aid: lanes | systolic */
+    if (forced && forced[0] == 'l') return lanes_cycles;
+    if (forced && forced[0] == 's') return *tier = SZS_TIER_SYSTOLIC, systolic_cycles;
+    if (!band_rows || systolic_cycles >= 0.7 * lanes_cycles) return lanes_cycles; /* ties go to the simpler tier */
+    *tier = SZS_TIER_SYSTOLIC;
+    return systolic_cycles;
+}
+
+void szs_plan_orient(unsigned bit_parallel_limit, int affine, int uniform, int symmetric, uint32_t const *query_lengths,
+                     uint32_t queries_count, uint32_t const *candidate_lengths, uint32_t candidates_count,
+                     unsigned band_rows, int *tier, int *transposed) {
+    uint64_t q_symbols = 0, c_symbols = 0;
+    uint32_t q_longest = 0, c_longest = 0;
+    for (uint32_t i = 0; i < queries_count; ++i)
+        q_symbols += query_lengths[i], q_longest = query_lengths[i] > q_longest ? query_lengths[i] : q_longest;
+    for (uint32_t i = 0; i < candidates_count; ++i)
+        c_symbols += candidate_lengths[i], c_longest = candidate_lengths[i] > c_longest ? candidate_lengths[i] : c_longest;
+    int swapped_tier = SZS_TIER_LANES;
+    double const cycles = szs_plan_estimate(bit_parallel_limit, affine, uniform, symmetric, query_lengths, queries_count,
+                                            candidates_count, c_symbols, q_longest, c_longest, band_rows, tier);
+    *transposed = 0;
+    if (symmetric) return; /* nothing to swap */
+    double const swapped_cycles = szs_plan_estimate(bit_parallel_limit, affine, uniform, 0, candidate_lengths,
+                                                    candidates_count, queries_count, q_symbols, c_longest, q_longest,
+                                                    band_rows, &swapped_tier);
+    char const *forced = getenv("SZS_ROCM_SWAP"); /* testing aid: 0 | 1 */
+    *transposed = forced ? forced[0] == '1' : swapped_cycles < 0.6 * cycles;
+    if (*transposed) *tier = swapped_tier;
+}
+
 /* ---- exported probes ------------------------------------------------------------------------------------------------ */
 
 sz_status_t szs_rocm_plan_probe(int unit_cost, int symmetric, sz_u32_t const *query_lengths, sz_size_t queries_count,
@@ -130,6 +209,17 @@ sz_status_t szs_rocm_plan_probe(int unit_cost, int symmetric, sz_u32_t const *qu
                 query_variant[plan.groups[g].first + i] = plan.groups[g].variant;
     if (cells) *cells = plan.cells;
     free(addresses), free(query_refs), free(candidate_refs), free(keys);
+    return sz_success_k;
+}
+
+sz_status_t szs_rocm_orientation_probe(int unit_cost, int affine, int uniform, int symmetric,
+                                       sz_u32_t const *query_lengths, sz_size_t queries_count,
+                                       sz_u32_t const *candidate_lengths, sz_size_t candidates_count, int *tier,
+                                       int *transposed) {
+    if (queries_count > 0xFFFFFFFFu || candidates_count > 0xFFFFFFFFu || !tier || !transposed) return sz_overflow_risk_k;
+    szs_plan_orient(unit_cost ? SZS_MYERS_MAX_WORDS * 32 : 0, affine, uniform, symmetric, query_lengths,
+                    (uint32_t)queries_count, symmetric ? query_lengths : candidate_lengths,
+                    (uint32_t)(symmetric ? queries_count : candidates_count), SZS_SYSTOLIC_BAND_ROWS, tier, transposed);
     return sz_success_k;
 }
 

@@ -93,6 +93,7 @@ typedef struct szs_engine_s {
     szs_buffer_t device_transcode; /* device: raw refs, rune starts, rune counts and the multibyte flag of that pass */
     szs_buffer_t pinned_transcode; /* pinned: the host's side of the same */
     int model_uploaded_device;
+    int model_uploaded_transposed; /* the uploaded class table is the transpose (sides swapped by the planner) */
     hipEvent_t event_start, event_stop;
     int events_device;
 
@@ -140,6 +141,29 @@ void szs_plan_build(unsigned myers, int symmetric, uint64_t const *query_address
                     uint32_t queries_count, uint64_t const *candidate_addresses, uint32_t const *candidate_lengths,
                     uint32_t candidates_count, szs_string_ref_t *query_refs, szs_string_ref_t *candidate_refs,
                     uint32_t *keys, szs_plan_t *plan);
+
+#define SZS_TIER_LANES 0    /* one pair per lane: lev_myers.hip, weighted.hip */
+#define SZS_TIER_SYSTOLIC 1 /* one pair per chain of wavefronts: systolic.hip */
+
+/**
+ *  Estimated SIMD cycles of a call in its better tier (plan.c), for one orientation of the cross-product: the caller
+ *  evaluates both (queries as the workgroup / band side, or candidates) and may swap the sides, which every scorer
+ *  here permits - gap costs apply to both strings alike, and a swapped class table is its transpose.
+ *  `bit_parallel_limit`: longest query (symbols) the Myers kernels take, 0 for weighted engines; `uniform`:
+ *  Levenshtein-family costs.  `SZS_ROCM_TIER=lanes|systolic` forces the tier (testing aid).
+ */
+double szs_plan_estimate(unsigned bit_parallel_limit, int affine, int uniform, int symmetric,
+                         uint32_t const *query_lengths, uint32_t queries_count, uint32_t candidates_count,
+                         uint64_t candidate_symbols, uint32_t longest_query, uint32_t longest_candidate,
+                         unsigned band_rows, int *tier);
+
+/**
+ *  The decision itself: evaluates szs_plan_estimate for both orientations and reports the tier to run and whether the
+ *  sides are swapped (never for symmetric calls).  `SZS_ROCM_SWAP=0|1` forces the orientation (testing aid).
+ */
+void szs_plan_orient(unsigned bit_parallel_limit, int affine, int uniform, int symmetric, uint32_t const *query_lengths,
+                     uint32_t queries_count, uint32_t const *candidate_lengths, uint32_t candidates_count,
+                     unsigned band_rows, int *tier, int *transposed);
 
 /* ---- the call (dispatch.c) --------------------------------------------------------------------------------------- */
 

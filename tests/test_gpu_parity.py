@@ -441,3 +441,208 @@ def test_utf8_malformed_bytes_follow_the_unchecked_contract(gpu, oracle):
     engine = szs.LevenshteinDistancesUTF8(capabilities=gpu)
     strings = [b"\x80\xbfabc", b"\xc3\x41\xc3", b"ab\xe4\xb8", b"\xf8\x80\x80\x80A", "é中".encode(), b"", b"\xff\xfe\xfd\xfc\xfb"]
     assert np.array_equal(engine(strings, strings, device=gpu), oracle.levenshtein_utf8(strings, strings))
+
+
+# ---- the systolic (few-pairs) tier: hip/systolic.hip -----------------------------------------------------------------
+
+
+import contextlib  # noqa: E402
+import os  # noqa: E402
+
+
+@contextlib.contextmanager
+def forced_tier(name):
+    """`SZS_ROCM_TIER` overrides the planner's cycle model for one call (csrc/host/plan.c)."""
+    previous = os.environ.get("SZS_ROCM_TIER")
+    os.environ["SZS_ROCM_TIER"] = name
+    try:
+        yield
+    finally:
+        if previous is None:
+            del os.environ["SZS_ROCM_TIER"]
+        else:
+            os.environ["SZS_ROCM_TIER"] = previous
+
+
+def test_systolic_known_answers_and_golden_matrices(gpu, golden):
+    """Everything the real reference engines produced must come out of the systolic tier as well."""
+    cases, kats = golden
+    with forced_tier("systolic"):
+        engine = szs.LevenshteinDistances(capabilities=gpu)
+        for group in ("levenshtein_unit", "levenshtein_unit_python"):
+            firsts = [v[0].encode() for v in kats[group]["vectors"]]
+            seconds = [v[1].encode() for v in kats[group]["vectors"]]
+            assert np.diagonal(engine(firsts, seconds, device=gpu)).tolist() == [v[2] for v in kats[group]["vectors"]]
+            assert engine.last_call_profile().tier == 1
+        tables = {k: (np.array(v["byte_to_class"], np.uint8), np.array(v["class_costs"], np.int8).reshape(32, 32))
+                  for k, v in cases["tables"].items()}
+        engines = {}
+        for case in cases["cases"]:
+            queries, candidates = _unhex(case["queries"]), _unhex(case["candidates"])
+            if case["kind"] == "levenshtein":
+                key = ("levenshtein", tuple(case["costs"]))
+                if key not in engines:
+                    m, x, o, e = case["costs"]
+                    engines[key] = szs.LevenshteinDistances(match=m, mismatch=x, open=o, extend=e, capabilities=gpu)
+                dtype = np.uint64
+            else:
+                key = (case["kind"], case["table"], tuple(case["gaps"]))
+                if key not in engines:
+                    cls = szs.NeedlemanWunschScores if case["kind"] == "needleman_wunsch" else szs.SmithWatermanScores
+                    engines[key] = cls(*tables[case["table"]], open=case["gaps"][0], extend=case["gaps"][1], capabilities=gpu)
+                dtype = np.int64
+            got = engines[key](queries, candidates, device=gpu)
+            expected = np.array(case["matrix"], dtype=dtype).reshape(len(queries), len(candidates))
+            assert np.array_equal(got, expected), (case["kind"], case["name"], key)
+            sym = engines[key](queries, device=gpu)
+            expected_sym = np.array(case["symmetric"], dtype=dtype).reshape(len(queries), len(queries))
+            assert np.array_equal(sym, expected_sym), (case["kind"], case["name"], key, "symmetric")
+
+
+@pytest.mark.parametrize("kind", ["needleman_wunsch", "smith_waterman"])
+@pytest.mark.parametrize("gaps", [(-4, -4), (-4, -1), (-11, -2), (2, -1)])
+def test_systolic_alignment_fuzz(gpu, oracle, kind, gaps):
+    """Band edges (512 rows per wavefront), lane edges (8 rows per lane), the 64-column hand-over chunks, empties, more
+    candidates than lanes, asymmetric tables; local alignment with a positive gap cost takes the non-saturating form."""
+    rng = random.Random(hash((kind, gaps)) & 0xFFFF)
+    asym_map = np.array([rng.randint(0, 31) for _ in range(256)], dtype=np.uint8)
+    asym_tab = np.array([[rng.randint(-9, 9) for _ in range(32)] for _ in range(32)], dtype=np.int8)
+    cls = szs.NeedlemanWunschScores if kind == "needleman_wunsch" else szs.SmithWatermanScores
+    if kind == "needleman_wunsch" and gaps[0] > 0:
+        pytest.skip("positive gap costs are exercised on the local form only")
+    with forced_tier("systolic"):
+        for (byte_to_class, class_costs), alphabet in [
+            (matrices.blosum62(), b"ARNDCQEGHILKMFPSTWYVBZX"),
+            (matrices.nuc44(), b"ACGTN"),
+            ((asym_map, asym_tab), bytes(range(256))),
+        ]:
+            engine = cls(byte_to_class, class_costs, open=gaps[0], extend=gaps[1], capabilities=gpu)
+            for lo, hi, q_count, c_count in [(0, 20, 9, 9), (1, 200, 6, 12), (500, 530, 4, 5), (1000, 1100, 2, 3),
+                                             (60, 70, 3, 70), (1530, 1540, 1, 2)]:
+                queries, candidates = _rand(rng, q_count, lo, hi, alphabet), _rand(rng, c_count, lo, hi, alphabet)
+                expected = getattr(oracle, kind)(queries, candidates, byte_to_class, class_costs, *gaps)
+                got = engine(queries, candidates, device=gpu)
+                assert engine.last_call_profile().tier == 1
+                assert np.array_equal(got, expected), (kind, gaps, lo, hi)
+                expected_sym = getattr(oracle, kind)(queries, None, byte_to_class, class_costs, *gaps)
+                assert np.array_equal(engine(queries, device=gpu), expected_sym), (kind, gaps, lo, hi, "symmetric")
+
+
+@pytest.mark.parametrize("costs", [(0, 1, 1, 1), (1, 3, 3, 3), (0, 1, 4, 2), (2, 5, 4, 1)])
+def test_systolic_levenshtein_fuzz(gpu, oracle, costs):
+    rng = random.Random(hash(costs) & 0xFFFF)
+    with forced_tier("systolic"):
+        engine = szs.LevenshteinDistances(*costs, capabilities=gpu)
+        for alphabet, lo, hi, q_count, c_count in [(b"ABC", 0, 200, 8, 8), (bytes(range(256)), 25, 40, 5, 70),
+                                                   (b"ACGT", 505, 520, 3, 4), (b"AB", 1020, 1030, 2, 3)]:
+            queries, candidates = _rand(rng, q_count, lo, hi, alphabet), _rand(rng, c_count, lo, hi, alphabet)
+            assert np.array_equal(engine(queries, candidates, device=gpu), oracle.levenshtein(queries, candidates, *costs))
+            assert engine.last_call_profile().tier == 1
+            assert np.array_equal(engine(queries, device=gpu), oracle.levenshtein(queries, None, *costs))
+        runes = szs.LevenshteinDistancesUTF8(*costs, capabilities=gpu)
+        for pool in ["AÉ中😀", "aé中😀bñ語🚀 ", "".join(chr(0x4E00 + i) for i in range(400))]:
+            for lo, hi, q_count, c_count in [(0, 48, 5, 9), (500, 530, 2, 3)]:
+                text = lambda: "".join(rng.choice(pool) for _ in range(rng.randint(lo, hi))).encode()
+                queries, candidates = [text() for _ in range(q_count)], [text() for _ in range(c_count)]
+                expected = oracle.levenshtein_utf8(queries, candidates, *costs)
+                assert np.array_equal(runes(queries, candidates, device=gpu), expected), (pool[:4], lo, hi)
+                assert runes.last_call_profile().tier == 1
+
+
+def test_systolic_long_pairs_pick_the_tier_themselves(gpu, oracle):
+    """A handful of long pairs: the planner's cycle model must route them to the systolic tier on its own (a band chain of
+    ten wavefronts per pair here), and a million short pairs must stay on the lanes tier."""
+    rng = random.Random(123)
+    queries, candidates = _rand(rng, 2, 4800, 5200, b"ACGT"), _rand(rng, 3, 4800, 5200, b"ACGT")
+    table = matrices.nuc44()
+    for cls, kind, gaps in [(szs.NeedlemanWunschScores, "needleman_wunsch", (-4, -4)),
+                            (szs.SmithWatermanScores, "smith_waterman", (-4, -1)),
+                            (szs.NeedlemanWunschScores, "needleman_wunsch", (-5, -2))]:
+        engine = cls(*table, open=gaps[0], extend=gaps[1], capabilities=gpu)
+        got = engine(queries, candidates, device=gpu)
+        assert engine.last_call_profile().tier == 1, kind
+        assert np.array_equal(got, getattr(oracle, kind)(queries, candidates, *table, *gaps)), (kind, gaps)
+    unit = szs.LevenshteinDistances(capabilities=gpu)
+    assert np.array_equal(unit(queries, candidates, device=gpu), oracle.levenshtein(queries, candidates))
+    assert unit.last_call_profile().tier == 1
+    load = workloads.config(2, scale=1 / 4)
+    unit(load.queries, load.candidates, device=gpu)
+    assert unit.last_call_profile().tier == 0
+
+
+def test_systolic_single_very_long_pair(gpu, oracle):
+    """1 x 1 call of two 40 KB strings (the reference's `score_across_cuda_device_` regime, cuda.cuh:715-716):
+    79 bands in flight, checked exactly; then both orders of an uneven pair."""
+    rng = random.Random(321)
+    first, second = _rand(rng, 1, 40000, 40000, b"ACGT"), _rand(rng, 1, 40500, 40500, b"ACGT")
+    nw = szs.NeedlemanWunschScores(*matrices.nuc44(), open=-4, extend=-1, capabilities=gpu)
+    expected = oracle.needleman_wunsch(first, second, *matrices.nuc44(), -4, -1)
+    assert np.array_equal(nw(first, second, device=gpu), expected)
+    assert nw.last_call_profile().tier == 1
+    assert np.array_equal(nw(second, first, device=gpu), expected.T)  # NUC.4.4 is symmetric
+    unit = szs.LevenshteinDistances(capabilities=gpu)
+    short = [first[0][:700]]
+    assert np.array_equal(unit(first, short, device=gpu), oracle.levenshtein(first, short))
+    assert np.array_equal(unit(short, first, device=gpu), oracle.levenshtein(short, first))
+
+
+# ---- orientation: the planner may put the candidates on workgroups and the queries on lanes -----------------------------
+
+
+@contextlib.contextmanager
+def forced_swap(value):
+    previous = os.environ.get("SZS_ROCM_SWAP")
+    os.environ["SZS_ROCM_SWAP"] = value
+    try:
+        yield
+    finally:
+        if previous is None:
+            del os.environ["SZS_ROCM_SWAP"]
+        else:
+            os.environ["SZS_ROCM_SWAP"] = previous
+
+
+@pytest.mark.parametrize("tier", ["lanes", "systolic"])
+def test_swapped_sides_give_the_same_matrix(gpu, oracle, tier):
+    """Forced swap on every engine family, with an ASYMMETRIC class table (the kernel must then see its transpose),
+    ragged rectangular shapes, a padded device matrix and a staged host matrix."""
+    import torch
+
+    rng = random.Random(404)
+    asym_map = np.array([rng.randint(0, 31) for _ in range(256)], dtype=np.uint8)
+    asym_tab = np.array([[rng.randint(-9, 9) for _ in range(32)] for _ in range(32)], dtype=np.int8)
+    queries, candidates = _rand(rng, 7, 0, 120, bytes(range(256))), _rand(rng, 70, 0, 90, bytes(range(256)))
+    with forced_tier(tier), forced_swap("1"):
+        for costs in [(0, 1, 1, 1), (1, 3, 3, 3), (0, 2, 4, 1)]:
+            engine = szs.LevenshteinDistances(*costs, capabilities=gpu)
+            assert np.array_equal(engine(queries, candidates, device=gpu), oracle.levenshtein(queries, candidates, *costs))
+            assert engine.last_call_profile().transposed == 1
+        for kind, cls in [("needleman_wunsch", szs.NeedlemanWunschScores), ("smith_waterman", szs.SmithWatermanScores)]:
+            for gaps in [(-3, -3), (-5, -1)]:
+                engine = cls(asym_map, asym_tab, open=gaps[0], extend=gaps[1], capabilities=gpu)
+                expected = getattr(oracle, kind)(queries, candidates, asym_map, asym_tab, *gaps)
+                assert np.array_equal(engine(queries, candidates, device=gpu), expected), (kind, gaps)
+                assert engine.last_call_profile().transposed == 1
+                padded = torch.full((7, 80), -7, dtype=torch.int64, device="cuda")  # stride > columns
+                engine(queries, candidates, device=gpu, out=padded[:, :70])
+                assert np.array_equal(padded[:, :70].cpu().numpy(), expected) and (padded[:, 70:] == -7).all()
+                host = np.zeros((7, 70), dtype=np.int64)                             # staged through a dense device copy
+                engine(queries, candidates, device=gpu, out=host)
+                assert np.array_equal(host, expected)
+                with forced_swap("0"):  # the same engine, back in the caller's orientation: the table is re-uploaded
+                    assert np.array_equal(engine(queries, candidates, device=gpu), expected)
+                    assert engine.last_call_profile().transposed == 0
+        utf8 = szs.LevenshteinDistancesUTF8(capabilities=gpu)
+        texts = lambda count, lo, hi: ["".join(rng.choice("aé中😀bñ") for _ in range(rng.randint(lo, hi))).encode() for _ in range(count)]
+        q, c = texts(5, 0, 60), texts(9, 0, 40)
+        assert np.array_equal(utf8(q, c, device=gpu), oracle.levenshtein_utf8(q, c))
+
+
+def test_tall_cross_products_are_turned_on_their_side(gpu, oracle):
+    rng = random.Random(405)
+    queries, candidates = _rand(rng, 6000, 90, 140, b"ACGT"), _rand(rng, 2, 90, 140, b"ACGT")  # 6000 one-lane wavefronts, or 188 full ones
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+    assert np.array_equal(engine(queries, candidates, device=gpu), oracle.levenshtein(queries, candidates))
+    assert engine.last_call_profile().transposed == 1 and engine.last_call_profile().tier == 0
+    assert np.array_equal(engine(candidates, queries, device=gpu), oracle.levenshtein(candidates, queries))
+    assert engine.last_call_profile().transposed == 0

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     assert len(declared) == 41, declared  # the reference's 41 (stringzillas.h:36-613)
     assert sorted(declared) == sorted(_abi.REFERENCE_SYMBOLS)
     extra = _declared_symbols("stringzillas_rocm.h")
-    assert sorted(extra) == ["szs_rocm_last_call_profile", "szs_rocm_plan_probe", "szs_rocm_shard_rows"]
+    assert sorted(extra) == ["szs_rocm_last_call_profile", "szs_rocm_orientation_probe", "szs_rocm_plan_probe", "szs_rocm_shard_rows"]
     for name in declared + extra:
         assert hasattr(_abi.lib, name), name
 
@@ -40,7 +40,7 @@ def test_version_and_capabilities_without_gpu():
 
 def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(_abi.U32Tape) == 24 and ctypes.sizeof(_abi.U64Tape) == 24 and ctypes.sizeof(_abi.Sequence) == 32
-    assert ctypes.sizeof(_abi.CallProfile) == 64
+    assert ctypes.sizeof(_abi.CallProfile) == 72
 
 
 def test_engines_refuse_cpu_capabilities_loudly():
@@ -121,6 +121,34 @@ def test_planner_counts_symmetric_cells():
     assert cells == sum(lengths[i] * lengths[j] for i in range(4) for j in range(i + 1))
     _, q_order, q_variant, _ = _probe(0, 0, lengths, lengths)  # weighted engines: one group, longest first
     assert q_order.tolist() == [2, 3, 0, 1] and q_variant.tolist() == [0, 0, 0, 0]
+
+
+def _orientation(unit, affine, uniform, symmetric, q, c):
+    q, c = np.asarray(q, dtype=np.uint32), np.asarray(c, dtype=np.uint32)
+    tier, transposed = ctypes.c_int(-1), ctypes.c_int(-1)
+    status = _abi.lib.szs_rocm_orientation_probe(unit, affine, uniform, symmetric, q.ctypes.data, len(q), c.ctypes.data, len(c),
+                                                 ctypes.addressof(tier), ctypes.addressof(transposed))
+    assert status == 0
+    return tier.value, transposed.value
+
+
+def test_planner_picks_tier_and_orientation():
+    """The cycle model of csrc/host/plan.c: BASELINE.json's big cross-products stay one-pair-per-lane, a handful of long
+    pairs go to the systolic tier, and a tall-and-thin cross-product is turned on its side."""
+    lanes, systolic = 0, 1
+    assert _orientation(1, 0, 1, 0, [128] * 1024, [128] * 1024) == (lanes, 0)        # config 2
+    assert _orientation(0, 0, 0, 0, [512] * 1024, [512] * 1024) == (lanes, 0)        # config 3
+    assert _orientation(0, 1, 0, 0, [4096] * 512, [4096] * 512) == (lanes, 0)        # config 4
+    assert _orientation(0, 0, 0, 0, [100000], [100000]) == (systolic, 0)             # one very long pair
+    assert _orientation(1, 0, 1, 0, [100000], [100000]) == (systolic, 0)             # ... also for unit costs
+    assert _orientation(0, 1, 0, 0, [4096] * 16, [4096] * 16) == (systolic, 0)       # 256 reads: 16 lanes would be busy
+    assert _orientation(1, 0, 1, 0, [2000] * 4, [2000] * 4)[0] == systolic
+    assert _orientation(0, 0, 0, 0, [64] * 64, [64] * 64)[0] == lanes                # tiny strings: nothing to spread
+    assert _orientation(1, 0, 1, 0, [128] * 4096, [128]) == (lanes, 1)               # 4096 x 1: candidates on workgroups
+    assert _orientation(1, 0, 1, 0, [128], [128] * 4096) == (lanes, 0)               # 1 x 4096 already is the good way
+    assert _orientation(0, 0, 0, 1, [512] * 2000, [])[1] == 0                        # symmetric: nothing to swap
+    # short queries against a few very long candidates: the long side should own the band chains
+    assert _orientation(0, 0, 0, 0, [100] * 8, [50000] * 2) == (systolic, 1)
 
 
 def test_shard_rows_balances_like_lpt():
