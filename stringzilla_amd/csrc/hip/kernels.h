@@ -103,7 +103,9 @@ size_t szs_hip_weighted_boundary_bytes(int objective, int affine, int narrow, ui
  *  per band, lanes skewed by one column and chained by DPP, bands chained through `workspace` - instead of owning one
  *  lane.  Same objectives, cost model, string refs and result addressing as szs_hip_weighted_scores; queries need no
  *  particular order.  `workspace` needs szs_hip_systolic_workspace_bytes(...) bytes (0 = the job is too large for
- *  this tier); both must be called with the target device current.
+ *  this tier); both must be called with the target device current.  After the launch has completed, the 32-bit word at
+ *  `workspace + 4` is non-zero if a band gave up waiting for its predecessor (a broken invariant, never expected): the
+ *  results are then invalid and the host reports the failure instead of hanging the device.
  */
 #define SZS_SYSTOLIC_BAND_ROWS 512u /* 64 lanes x 8 rows; szs_hip_systolic_band_rows() returns the same */
 unsigned szs_hip_systolic_band_rows(void);

@@ -47,7 +47,8 @@ constexpr u32 systolic_band_rows_k = 64u * systolic_rows_k;     // query rows pe
 constexpr u32 systolic_waves_k = 4;                             // wavefronts per workgroup; each pulls its own tickets
 constexpr u32 systolic_chunk_k = 64;                            // columns per hand-over between bands
 constexpr u32 systolic_slack_k = 64;                            // parked columns past the longest candidate
-constexpr size_t systolic_header_bytes_k = 256;                 // ticket counter at the head of the workspace
+constexpr size_t systolic_header_bytes_k = 256;                 // ticket counter [0] and stall flag [1] at the head of the workspace
+constexpr u32 systolic_spin_limit_k = 1u << 20;                 // polls of a predecessor's counter before giving up
 static_assert(systolic_rows_k % 4 == 0 && systolic_rows_k <= 16, "R int8 costs are fetched as one LDS read");
 static_assert(systolic_band_rows_k == SZS_SYSTOLIC_BAND_ROWS, "the host planner models bands of this height");
 
@@ -269,9 +270,16 @@ __global__ __launch_bounds__(64 * systolic_waves_k) void systolic_scores_kernel(
         u32 parked_seen = 0; // the predecessor's progress counter as last read
         auto preload_above = [&](u32 chunk_first) { // columns [chunk_first, chunk_first + 64) of the predecessor's bottom row
             u32 const needed = chunk_first + 64 < n ? chunk_first + 64 : n;
-            while (parked_seen < needed) {
+            for (u32 spins = 0; parked_seen < needed; ++spins) {
                 parked_seen = __hip_atomic_load(progress_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (parked_seen < needed) __builtin_amdgcn_s_sleep(2);
+                if (parked_seen >= needed) break;
+                __builtin_amdgcn_s_sleep(2);
+                // A predecessor only ever needs to score ~128 columns to satisfy this wait (microseconds).  Never hang the
+                // device on a broken invariant: give up after ~a second, flag the call, let the host report the failure.
+                if (spins > systolic_spin_limit_k) {
+                    if (lane == 0) __hip_atomic_fetch_or(work_counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             u32 const mine = chunk_first + lane;

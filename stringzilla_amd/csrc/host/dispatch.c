@@ -453,6 +453,12 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
     }
     error = hipEventRecord(engine->event_stop, stream);
     if (error != hipSuccess) return szs_report_hip(error, error_message);
+    uint32_t *const stall_flag = (uint32_t *)((char *)engine->pinned_staging.pointer + refs_bytes); /* offsets area: done with */
+    *stall_flag = 0;
+    if (tier == SZS_TIER_SYSTOLIC) {
+        error = hipMemcpyAsync(stall_flag, (char *)engine->device_boundary.pointer + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+        if (error != hipSuccess) return szs_report_hip(error, error_message);
+    }
 
     if (!direct) /* one strided copy back into the caller's host matrix (reference: cuMemcpy2DAsync, cuda.cuh:2205-2215) */
         error = hipMemcpy2DAsync(results, results_row_stride * sizeof(uint64_t), device_results,
@@ -460,6 +466,7 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
                                  hipMemcpyDeviceToHost, stream);
     if (error == hipSuccess) error = hipStreamSynchronize(stream); /* the call is synchronous, like the reference's */
     if (error != hipSuccess) return szs_report_hip(error, error_message);
+    if (*stall_flag) return szs_report(sz_status_unknown_k, error_message, "Systolic pipeline stalled");
 
     float kernel_ms = 0;
     (void)hipEventElapsedTime(&kernel_ms, engine->event_start, engine->event_stop);
