@@ -100,21 +100,27 @@ size_t szs_hip_weighted_boundary_bytes(int objective, int affine, int narrow, ui
 
 /**
  *  The few-pairs tier of the weighted scorers (hip/systolic.hip): a pair is spread over wavefronts - 64 lanes x R rows
- *  per band, lanes skewed by one column and chained by DPP, bands chained through `workspace` - instead of owning one
- *  lane.  Same objectives, cost model, string refs and result addressing as szs_hip_weighted_scores; queries need no
- *  particular order.  `workspace` needs szs_hip_systolic_workspace_bytes(...) bytes (0 = the job is too large for
- *  this tier); both must be called with the target device current.  After the launch has completed, the 32-bit word at
- *  `workspace + 4` is non-zero if a band gave up waiting for its predecessor (a broken invariant, never expected): the
- *  results are then invalid and the host reports the failure instead of hanging the device.
+ *  per band, lanes skewed by one column and chained by DPP, bands chained through memory - instead of owning one lane.
+ *  Same objectives, cost model, string refs and result addressing as szs_hip_weighted_scores; queries need no
+ *  particular order.  Two device blocks, sized by szs_hip_systolic_workspace_bytes (returns 0 when the job is too
+ *  large for this tier):
+ *    `control` - epoch-tagged 64-bit words (ticket counter, stall flag, per-band progress, per-pair best / done).  The
+ *                caller zeroes the block ONCE when it allocates it and passes a strictly increasing `epoch` >= 1 with
+ *                every launch that uses it; nothing is ever cleared between launches.
+ *    `parked`  - the band bottom rows in flight; contents never matter.
+ *  Both must be called with the target device current.  After the launch has completed, the 64-bit word at
+ *  `control + 8` equals ((uint64_t)epoch << 32 | 1) if a band gave up waiting for its predecessor (a broken invariant,
+ *  never expected): the results are then invalid and the host reports the failure instead of hanging the device.
  */
 #define SZS_SYSTOLIC_BAND_ROWS 512u /* 64 lanes x 8 rows; szs_hip_systolic_band_rows() returns the same */
 unsigned szs_hip_systolic_band_rows(void);
-size_t szs_hip_systolic_workspace_bytes(int affine, uint32_t queries_count, uint32_t candidates_count,
-                                        uint32_t longest_query, uint32_t longest_candidate);
+int szs_hip_systolic_workspace_bytes(int affine, uint32_t queries_count, uint32_t candidates_count, uint32_t longest_query,
+                                     uint32_t longest_candidate, size_t *control_bytes, size_t *parked_bytes);
 int szs_hip_systolic_scores(int objective, int affine, szs_cost_model_t const *model, szs_string_ref_t const *queries,
                             uint32_t queries_count, szs_string_ref_t const *candidates, uint32_t candidates_count,
                             uint32_t longest_query, uint32_t longest_candidate, int64_t *results,
-                            uint64_t results_row_stride, int symmetric, void *workspace, void *stream);
+                            uint64_t results_row_stride, int symmetric, void *control, void *parked, uint32_t epoch,
+                            void *stream);
 
 #ifdef __cplusplus
 }

@@ -47,8 +47,8 @@ constexpr u32 systolic_band_rows_k = 64u * systolic_rows_k;     // query rows pe
 constexpr u32 systolic_waves_k = 4;                             // wavefronts per workgroup; each pulls its own tickets
 constexpr u32 systolic_chunk_k = 64;                            // columns per hand-over between bands
 constexpr u32 systolic_slack_k = 64;                            // parked columns past the longest candidate
-constexpr size_t systolic_header_bytes_k = 256;                 // ticket counter [0] and stall flag [1] at the head of the workspace
-constexpr u32 systolic_spin_limit_k = 1u << 20;                 // polls of a predecessor's counter before giving up
+constexpr size_t systolic_header_bytes_k = 256;                 // ticket counter [0] and stall flag [1] at the head of the control block
+constexpr u32 systolic_spin_limit_k = 1u << 18;                 // polls of a predecessor's counter before giving up
 static_assert(systolic_rows_k % 4 == 0 && systolic_rows_k <= 16, "R int8 costs are fetched as one LDS read");
 static_assert(systolic_band_rows_k == SZS_SYSTOLIC_BAND_ROWS, "the host planner models bands of this height");
 
@@ -143,8 +143,8 @@ template <bool local_, bool affine_, bool uniform_, bool runes_, bool saturating
 __global__ __launch_bounds__(64 * systolic_waves_k) void systolic_scores_kernel(
     szs_cost_model_t const *__restrict__ model, szs_string_ref_t const *__restrict__ queries, u32 queries_count,
     szs_string_ref_t const *__restrict__ candidates, u32 candidates_count, u32 max_bands, i64 *__restrict__ results,
-    u64 results_row_stride, int symmetric, u32 *__restrict__ work_counter, u32 *progress, i32 *pair_best, u32 *pair_done,
-    i32 *parked, u32 parked_columns) {
+    u64 results_row_stride, int symmetric, u64 *__restrict__ work_counter, u64 *progress, u64 *pair_best, u64 *pair_done,
+    i32 *parked, u32 parked_columns, u32 epoch) {
 
     constexpr int rows = systolic_rows_k;
     constexpr int cost_dwords = rows / 4;
@@ -167,11 +167,18 @@ __global__ __launch_bounds__(64 * systolic_waves_k) void systolic_scores_kernel(
     u32 *const profile = profiles + (uniform_ ? 0 : wave * 32 * 64 * cost_dwords) + (uniform_ ? 0 : lane * cost_dwords);
 
     u64 const total_tickets = (u64)queries_count * candidates_count * max_bands;
+    u64 const tag = (u64)epoch << 32;
     u32 const planes = affine_ ? 2 : 1;
 
     for (;;) {
+        // Every word of the control block is tagged with the launch's epoch in its high half, so NOTHING in it has to be
+        // zeroed between launches (and no launch depends on a preceding fill having landed): the first fetch-max lifts a
+        // word left by an older launch to (epoch, 0), values of older epochs compare below everything of this one.
         u32 ticket = 0;
-        if (lane == 0) ticket = atomicAdd(work_counter, 1u);
+        if (lane == 0) {
+            __hip_atomic_fetch_max(work_counter, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ticket = (u32)__hip_atomic_fetch_add(work_counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         ticket = __builtin_amdgcn_readfirstlane(ticket);
         if (ticket >= total_tickets) break;
         u32 const pair = ticket / max_bands, band = ticket % max_bands;
@@ -252,8 +259,8 @@ __global__ __launch_bounds__(64 * systolic_waves_k) void systolic_scores_kernel(
 
         i32 *const parked_h = parked + (u64)pair * planes * parked_columns; // [1-based DP column]
         i32 *const parked_down = parked_h + parked_columns;
-        u32 *const progress_out = progress + (u64)pair * max_bands + band;
-        u32 const *const progress_in = progress_out - 1;
+        u64 *const progress_out = progress + (u64)pair * max_bands + band;
+        u64 const *const progress_in = progress_out - 1;
 
         auto symbol_at = [&](u32 index) -> u32 { // what lane 0 feeds into the array for column `index` < n
             if constexpr (runes_) return reinterpret_cast<u32 const *>(candidate.address)[index];
@@ -267,18 +274,23 @@ __global__ __launch_bounds__(64 * systolic_waves_k) void systolic_scores_kernel(
         //   starts a chunk when its predecessor has parked the NEXT chunk as well (it trails by ~192 columns, not ~128).
         u32 chunk_symbols = 0, next_symbols = lane < n ? symbol_at(lane) : 0u;
         i32 chunk_above = 0, chunk_down = 0, next_above = 0, next_down = 0;
-        u32 parked_seen = 0; // the predecessor's progress counter as last read
+        u64 parked_seen = 0; // the predecessor's progress word (epoch, columns) as last read
+        bool abandoned = false; // a wait of this band has timed out: its results are void, never wait again
         auto preload_above = [&](u32 chunk_first) { // columns [chunk_first, chunk_first + 64) of the predecessor's bottom row
-            u32 const needed = chunk_first + 64 < n ? chunk_first + 64 : n;
-            for (u32 spins = 0; parked_seen < needed; ++spins) {
+            u64 const needed = tag | (chunk_first + 64 < n ? chunk_first + 64 : n);
+            for (u32 spins = 0; parked_seen < needed && !abandoned; ++spins) {
                 parked_seen = __hip_atomic_load(progress_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (parked_seen >= needed) break;
                 __builtin_amdgcn_s_sleep(2);
                 // A predecessor only ever needs to score ~128 columns to satisfy this wait (microseconds).  Never hang the
-                // device on a broken invariant: give up after ~a second, flag the call, let the host report the failure.
-                if (spins > systolic_spin_limit_k) {
-                    if (lane == 0) __hip_atomic_fetch_or(work_counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
+                // device on a broken invariant: give up after a fraction of a second - at once if another band already
+                // has - flag the call, and let the host report the failure.
+                bool const hopeless = spins > systolic_spin_limit_k ||
+                                      (spins % 1024 == 1023 && __hip_atomic_load(work_counter + 1, __ATOMIC_RELAXED,
+                                                                                 __HIP_MEMORY_SCOPE_AGENT) == (tag | 1));
+                if (hopeless) {
+                    if (lane == 0) __hip_atomic_fetch_max(work_counter + 1, tag | 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    abandoned = true;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -357,7 +369,7 @@ __global__ __launch_bounds__(64 * systolic_waves_k) void systolic_scores_kernel(
             if (!last_band && t >= 63) {
                 u32 const parked_count = t - 62;
                 if ((parked_count % systolic_chunk_k == 0 || parked_count == n) && lane == 63)
-                    __hip_atomic_store(progress_out, parked_count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(progress_out, tag | parked_count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             }
         };
 
@@ -389,11 +401,12 @@ __global__ __launch_bounds__(64 * systolic_waves_k) void systolic_scores_kernel(
                 if (lane == 0) write_result((i32)wave_best);
             }
             else if (lane == 0) { // the band that finishes last reports the maximum over all of them
-                __hip_atomic_fetch_max(pair_best + pair, (i32)wave_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_max(pair_best + pair, tag | wave_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_max(pair_done + pair, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 u32 const finished =
-                    __hip_atomic_fetch_add(pair_done + pair, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                    (u32)__hip_atomic_fetch_add(pair_done + pair, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
                 if (finished + 1 == bands)
-                    write_result(__hip_atomic_load(pair_best + pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    write_result((i32)(u32)__hip_atomic_load(pair_best + pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             }
         }
         else if (last_band) { // bottom-right cell: the last real row, frozen at the owning lane's last column
@@ -428,10 +441,12 @@ static u32 systolic_grid(u64 tickets) {
     return (u32)(wanted < (u64)resident ? wanted : (u64)resident);
 }
 
+/** Two blocks: `control` (epoch-tagged 64-bit words: ticket counter, stall flag, progress, best, done - zeroed ONCE when
+ *  the block is allocated, never between launches) and `parked` (the bottom rows in flight; plain data). */
 struct systolic_layout_t {
     u64 pairs, tickets;
     u32 max_bands, parked_columns;
-    size_t progress_at, best_at, done_at, parked_at, zeroed_bytes, total_bytes;
+    size_t progress_at, best_at, done_at, control_bytes, parked_bytes;
 };
 
 static systolic_layout_t systolic_layout(int affine, u32 queries_count, u32 candidates_count, u32 longest_query,
@@ -442,31 +457,30 @@ static systolic_layout_t systolic_layout(int affine, u32 queries_count, u32 cand
     layout.tickets = layout.pairs * layout.max_bands;
     layout.parked_columns = longest_candidate + 1 + systolic_slack_k;
     layout.progress_at = systolic_header_bytes_k;
-    layout.best_at = layout.progress_at + layout.tickets * sizeof(u32);
-    layout.done_at = layout.best_at + layout.pairs * sizeof(i32);
-    layout.zeroed_bytes = layout.done_at + layout.pairs * sizeof(u32);
-    layout.parked_at = (layout.zeroed_bytes + 255) & ~(size_t)255;
-    layout.total_bytes = layout.parked_at + layout.pairs * (affine ? 2 : 1) * layout.parked_columns * sizeof(i32);
+    layout.best_at = layout.progress_at + layout.tickets * sizeof(u64);
+    layout.done_at = layout.best_at + layout.pairs * sizeof(u64);
+    layout.control_bytes = layout.done_at + layout.pairs * sizeof(u64);
+    layout.parked_bytes = layout.pairs * (affine ? 2 : 1) * layout.parked_columns * sizeof(i32);
     return layout;
 }
+
+constexpr u64 systolic_ticket_limit_k = 0x7FFFFFF0ull; // tickets, plus one failing fetch per wavefront, stay below 2^32
 
 template <bool local_, bool affine_, bool uniform_, bool runes_ = false, bool saturating_ = false>
 static int launch_systolic(szs_cost_model_t const *model, szs_string_ref_t const *queries, u32 queries_count,
                            szs_string_ref_t const *candidates, u32 candidates_count, u32 longest_query,
-                           u32 longest_candidate, i64 *results, u64 stride, int symmetric, void *workspace,
-                           hipStream_t stream) {
+                           u32 longest_candidate, i64 *results, u64 stride, int symmetric, void *control, void *parked,
+                           u32 epoch, hipStream_t stream) {
     systolic_layout_t const layout = systolic_layout(affine_, queries_count, candidates_count, longest_query, longest_candidate);
-    if (layout.tickets > 0xFFFFFFF0ull) return (int)hipErrorInvalidValue; // the host keeps larger jobs on weighted.hip
-    char *const base = static_cast<char *>(workspace);
-    hipError_t const error = hipMemsetAsync(base, 0, layout.zeroed_bytes, stream);
-    if (error != hipSuccess) return (int)error;
+    if (layout.tickets > systolic_ticket_limit_k) return (int)hipErrorInvalidValue; // the host keeps larger jobs on weighted.hip
+    char *const base = static_cast<char *>(control);
     u32 const grid = systolic_grid<local_, affine_, uniform_, runes_, saturating_>(layout.tickets);
     hipLaunchKernelGGL((systolic_scores_kernel<local_, affine_, uniform_, runes_, saturating_>), dim3(grid),
                        dim3(64 * systolic_waves_k), 0, stream, model, queries, queries_count, candidates, candidates_count,
-                       layout.max_bands, results, stride, symmetric, reinterpret_cast<u32 *>(base),
-                       reinterpret_cast<u32 *>(base + layout.progress_at), reinterpret_cast<i32 *>(base + layout.best_at),
-                       reinterpret_cast<u32 *>(base + layout.done_at), reinterpret_cast<i32 *>(base + layout.parked_at),
-                       layout.parked_columns);
+                       layout.max_bands, results, stride, symmetric, reinterpret_cast<u64 *>(base),
+                       reinterpret_cast<u64 *>(base + layout.progress_at), reinterpret_cast<u64 *>(base + layout.best_at),
+                       reinterpret_cast<u64 *>(base + layout.done_at), static_cast<i32 *>(parked), layout.parked_columns,
+                       epoch);
     return (int)hipGetLastError();
 }
 
@@ -474,24 +488,28 @@ static int launch_systolic(szs_cost_model_t const *model, szs_string_ref_t const
 
 extern "C" unsigned szs_hip_systolic_band_rows(void) { return szs_hip::systolic_band_rows_k; }
 
-extern "C" size_t szs_hip_systolic_workspace_bytes(int affine, uint32_t queries_count, uint32_t candidates_count,
-                                                   uint32_t longest_query, uint32_t longest_candidate) {
+extern "C" int szs_hip_systolic_workspace_bytes(int affine, uint32_t queries_count, uint32_t candidates_count,
+                                                uint32_t longest_query, uint32_t longest_candidate, size_t *control_bytes,
+                                                size_t *parked_bytes) {
     szs_hip::systolic_layout_t const layout =
         szs_hip::systolic_layout(affine, queries_count, candidates_count, longest_query, longest_candidate);
-    return layout.tickets > 0xFFFFFFF0ull ? 0 : layout.total_bytes;
+    if (layout.tickets > szs_hip::systolic_ticket_limit_k) return 0;
+    *control_bytes = layout.control_bytes, *parked_bytes = layout.parked_bytes + 256;
+    return 1;
 }
 
 extern "C" int szs_hip_systolic_scores(int objective, int affine, szs_cost_model_t const *model,
                                        szs_string_ref_t const *queries, uint32_t queries_count,
                                        szs_string_ref_t const *candidates, uint32_t candidates_count,
                                        uint32_t longest_query, uint32_t longest_candidate, int64_t *results,
-                                       uint64_t results_row_stride, int symmetric, void *workspace, void *stream) {
+                                       uint64_t results_row_stride, int symmetric, void *control, void *parked,
+                                       uint32_t epoch, void *stream) {
     using namespace szs_hip;
     if (!queries_count || !candidates_count) return 0;
     hipStream_t const s = static_cast<hipStream_t>(stream);
 #define SZS_SYSTOLIC_LAUNCH(...)                                                                                       \
     return launch_systolic<__VA_ARGS__>(model, queries, queries_count, candidates, candidates_count, longest_query,    \
-                                        longest_candidate, results, results_row_stride, symmetric, workspace, s)
+                                        longest_candidate, results, results_row_stride, symmetric, control, parked, epoch, s)
     switch (objective) {
     case szs_objective_global_k:
         if (affine) SZS_SYSTOLIC_LAUNCH(false, true, false);

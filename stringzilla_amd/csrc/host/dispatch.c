@@ -200,6 +200,7 @@ static void release_device_state(szs_engine_s *engine) {
     szs_buffer_release(&engine->device_results);
     szs_buffer_release(&engine->device_boundary);
     szs_buffer_release(&engine->device_model);
+    szs_buffer_release(&engine->device_systolic);
     szs_buffer_release(&engine->device_tape);
     szs_buffer_release(&engine->device_runes);
     szs_buffer_release(&engine->device_transcode);
@@ -388,11 +389,26 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
 
     /* The systolic tier scores every engine family with its weighted recurrences, so it needs the cost model and its
      * own workspace; a job with too many pairs in flight for that workspace stays on the lanes tier. */
-    size_t systolic_bytes = 0;
+    size_t systolic_control_bytes = 0, systolic_parked_bytes = 0;
+    if (tier == SZS_TIER_SYSTOLIC &&
+        (!szs_hip_systolic_workspace_bytes(!engine->is_linear, kq_count, kc_count, plan.longest_query, plan.longest_candidate,
+                                           &systolic_control_bytes, &systolic_parked_bytes) ||
+         systolic_control_bytes + systolic_parked_bytes > ((size_t)32 << 30)))
+        tier = SZS_TIER_LANES;
     if (tier == SZS_TIER_SYSTOLIC) {
-        systolic_bytes = szs_hip_systolic_workspace_bytes(!engine->is_linear, kq_count, kc_count, plan.longest_query,
-                                                          plan.longest_candidate);
-        if (!systolic_bytes || systolic_bytes > ((size_t)32 << 30)) tier = SZS_TIER_LANES;
+        /* The control block is zeroed when it is (re)allocated and never again: its words carry the epoch of the launch
+         * that wrote them, so a launch neither needs nor waits for a fill (hip/kernels.h). */
+        int const fresh = !engine->device_systolic.pointer || engine->device_systolic.capacity < systolic_control_bytes ||
+                          engine->device_systolic.device != device; /* the reserve below will (re)allocate */
+        status = szs_buffer_reserve(&engine->device_systolic, szs_memory_device_k, device, systolic_control_bytes, error_message);
+        if (status != sz_success_k) return status;
+        if (fresh || engine->systolic_epoch >= 0xFFFFFFF0u) {
+            error = hipMemsetAsync(engine->device_systolic.pointer, 0, engine->device_systolic.capacity, stream);
+            if (error == hipSuccess) error = hipStreamSynchronize(stream);
+            if (error != hipSuccess) return szs_report_hip(error, error_message);
+            engine->systolic_epoch = 0;
+        }
+        engine->systolic_epoch++;
     }
 
     /* Weighted kernels need the cost model and a strip-boundary workspace on the device. */
@@ -412,7 +428,7 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
         }
         size_t const boundary_bytes =
             tier == SZS_TIER_SYSTOLIC
-                ? systolic_bytes
+                ? systolic_parked_bytes
                 : szs_hip_weighted_boundary_bytes(objective, !engine->is_linear, narrow, kq_count, kc_count, plan.longest_candidate);
         status = szs_buffer_reserve(&engine->device_boundary, szs_memory_device_k, device, boundary_bytes, error_message);
         if (status != sz_success_k) return status;
@@ -426,7 +442,8 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
         int const launch_error = szs_hip_systolic_scores(
             objective, !engine->is_linear, (szs_cost_model_t const *)engine->device_model.pointer,
             device_query_refs, kq_count, device_candidate_refs, kc_count, plan.longest_query, plan.longest_candidate,
-            (int64_t *)device_results, device_stride, layout, engine->device_boundary.pointer, stream);
+            (int64_t *)device_results, device_stride, layout, engine->device_systolic.pointer,
+            engine->device_boundary.pointer, engine->systolic_epoch, stream);
         if (launch_error) return szs_report_hip((hipError_t)launch_error, error_message);
         ++launches;
     }
@@ -453,10 +470,10 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
     }
     error = hipEventRecord(engine->event_stop, stream);
     if (error != hipSuccess) return szs_report_hip(error, error_message);
-    uint32_t *const stall_flag = (uint32_t *)((char *)engine->pinned_staging.pointer + refs_bytes); /* offsets area: done with */
+    uint64_t *const stall_flag = (uint64_t *)((char *)engine->pinned_staging.pointer + refs_bytes); /* offsets area: done with */
     *stall_flag = 0;
     if (tier == SZS_TIER_SYSTOLIC) {
-        error = hipMemcpyAsync(stall_flag, (char *)engine->device_boundary.pointer + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+        error = hipMemcpyAsync(stall_flag, (char *)engine->device_systolic.pointer + 8, sizeof(uint64_t), hipMemcpyDeviceToHost, stream);
         if (error != hipSuccess) return szs_report_hip(error, error_message);
     }
 
@@ -466,7 +483,8 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
                                  hipMemcpyDeviceToHost, stream);
     if (error == hipSuccess) error = hipStreamSynchronize(stream); /* the call is synchronous, like the reference's */
     if (error != hipSuccess) return szs_report_hip(error, error_message);
-    if (*stall_flag) return szs_report(sz_status_unknown_k, error_message, "Systolic pipeline stalled");
+    if (tier == SZS_TIER_SYSTOLIC && *stall_flag == (((uint64_t)engine->systolic_epoch << 32) | 1))
+        return szs_report(sz_status_unknown_k, error_message, "Systolic pipeline stalled");
 
     float kernel_ms = 0;
     (void)hipEventElapsedTime(&kernel_ms, engine->event_start, engine->event_stop);

@@ -88,6 +88,8 @@ typedef struct szs_engine_s {
     szs_buffer_t device_results; /* device: dense results when the caller's matrix is not device-accessible */
     szs_buffer_t device_boundary;/* device: strip boundaries of the weighted kernels */
     szs_buffer_t device_model;   /* device: szs_cost_model_t */
+    szs_buffer_t device_systolic;/* device: control block of the systolic tier (epoch-tagged words, zeroed once) */
+    uint32_t systolic_epoch;     /* launches that have used `device_systolic` since it was zeroed */
     szs_buffer_t device_tape;    /* device: flattened copy of callback-sequence strings living in host memory */
     szs_buffer_t device_runes;   /* device: UTF-32 transcription of both sides (codepoint-level engine) */
     szs_buffer_t device_transcode; /* device: raw refs, rune starts, rune counts and the multibyte flag of that pass */
