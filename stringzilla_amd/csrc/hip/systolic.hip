@@ -44,7 +44,30 @@ namespace szs_hip {
 #endif
 constexpr int systolic_rows_k = SZS_SYSTOLIC_ROWS;              // R: query rows per lane
 constexpr u32 systolic_band_rows_k = 64u * systolic_rows_k;     // query rows per band = per wavefront
-constexpr u32 systolic_waves_k = 4;                             // wavefronts per workgroup; each pulls its own tickets
+#ifndef SZS_SYSTOLIC_WAVES
+#define SZS_SYSTOLIC_WAVES 4
+#endif
+constexpr u32 systolic_waves_k = SZS_SYSTOLIC_WAVES;            // wavefronts per workgroup; each pulls its own tickets
+#ifdef SZS_SYSTOLIC_PARKED_PARITY // debugging aid: odd and even bands park in separate copies instead of in place
+constexpr u32 systolic_parked_copies_k = 2;
+#else
+constexpr u32 systolic_parked_copies_k = 1;
+#endif
+/** A parked cell is written by one wavefront and read by another one, possibly on another XCD. */
+__device__ __forceinline__ i32 parked_load(i32 const *cell) {
+#ifdef SZS_SYSTOLIC_ATOMIC_PARKED
+    return __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    return *cell;
+#endif
+}
+__device__ __forceinline__ void parked_store(i32 *cell, i32 value) {
+#ifdef SZS_SYSTOLIC_ATOMIC_PARKED
+    __hip_atomic_store(cell, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    *cell = value;
+#endif
+}
 constexpr u32 systolic_chunk_k = 64;                            // columns per hand-over between bands
 constexpr u32 systolic_slack_k = 64;                            // parked columns past the longest candidate
 constexpr size_t systolic_header_bytes_k = 256;                 // ticket counter [0] and stall flag [1] at the head of the control block
@@ -257,8 +280,12 @@ __global__ __launch_bounds__(64 * systolic_waves_k) void systolic_scores_kernel(
         i32 best = 0, down_out = 0;
         i32 bottom_h = 0, bottom_down = 0; // this lane's bottom row at its latest column: what the lane below consumes
 
-        i32 *const parked_h = parked + (u64)pair * planes * parked_columns; // [1-based DP column]
+        // [1-based DP column]; what this band parks, and what its predecessor parked (the same row unless debugging)
+        i32 *const parked_h = parked + ((u64)pair * systolic_parked_copies_k + band % systolic_parked_copies_k) * planes * parked_columns;
         i32 *const parked_down = parked_h + parked_columns;
+        i32 const *const above_parked_h =
+            parked + ((u64)pair * systolic_parked_copies_k + (band + 1) % systolic_parked_copies_k) * planes * parked_columns;
+        i32 const *const above_parked_down = above_parked_h + parked_columns;
         u64 *const progress_out = progress + (u64)pair * max_bands + band;
         u64 const *const progress_in = progress_out - 1;
 
@@ -296,8 +323,8 @@ __global__ __launch_bounds__(64 * systolic_waves_k) void systolic_scores_kernel(
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             u32 const mine = chunk_first + lane;
             if (mine < n) {
-                next_above = parked_h[mine + 1];
-                if constexpr (affine_) next_down = parked_down[mine + 1];
+                next_above = parked_load(above_parked_h + mine + 1);
+                if constexpr (affine_) next_down = parked_load(above_parked_down + mine + 1);
             }
         };
         if (!first_band) preload_above(0);
@@ -361,8 +388,8 @@ __global__ __launch_bounds__(64 * systolic_waves_k) void systolic_scores_kernel(
                 bottom_h = column.h[rows - 1];
                 if constexpr (affine_) bottom_down = down_out;
                 if (!last_band && lane == 63) { // the band's bottom row, 1-based DP column t - 62
-                    parked_h[t - 62] = bottom_h;
-                    if constexpr (affine_) parked_down[t - 62] = bottom_down;
+                    parked_store(parked_h + (t - 62), bottom_h);
+                    if constexpr (affine_) parked_store(parked_down + (t - 62), bottom_down);
                 }
             }
             // Publish the parked columns every `systolic_chunk_k` of them and at the end of the text.
@@ -460,7 +487,7 @@ static systolic_layout_t systolic_layout(int affine, u32 queries_count, u32 cand
     layout.best_at = layout.progress_at + layout.tickets * sizeof(u64);
     layout.done_at = layout.best_at + layout.pairs * sizeof(u64);
     layout.control_bytes = layout.done_at + layout.pairs * sizeof(u64);
-    layout.parked_bytes = layout.pairs * (affine ? 2 : 1) * layout.parked_columns * sizeof(i32);
+    layout.parked_bytes = layout.pairs * systolic_parked_copies_k * (affine ? 2 : 1) * layout.parked_columns * sizeof(i32);
     return layout;
 }
 
