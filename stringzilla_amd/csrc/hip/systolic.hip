@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64 * systolic_waves_k) void systolic_scores_kernel(
     u64 const tag = (u64)epoch << 32;
     u32 const planes = affine_ ? 2 : 1;
 
-    for (;;) {
+    { // one ticket per wavefront: the grid holds exactly as many wavefronts as there are tickets
         // Every word of the control block is tagged with the launch's epoch in its high half, so NOTHING in it has to be
         // zeroed between launches (and no launch depends on a preceding fill having landed): the first fetch-max lifts a
         // word left by an older launch to (epoch, 0), values of older epochs compare below everything of this one.
@@ -203,14 +203,14 @@ __global__ __launch_bounds__(64 * systolic_waves_k) void systolic_scores_kernel(
             ticket = (u32)__hip_atomic_fetch_add(work_counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         ticket = __builtin_amdgcn_readfirstlane(ticket);
-        if (ticket >= total_tickets) break;
+        if (ticket >= total_tickets) return;
         u32 const pair = ticket / max_bands, band = ticket % max_bands;
         szs_string_ref_t const query = queries[pair / candidates_count];
         szs_string_ref_t const candidate = candidates[pair % candidates_count];
-        if ((symmetric & SZS_LAYOUT_SYMMETRIC) && candidate.index > query.index) continue; // upper triangle: mirrored from below
+        if ((symmetric & SZS_LAYOUT_SYMMETRIC) && candidate.index > query.index) return; // upper triangle: mirrored from below
         u32 const m = query.length, n = candidate.length;
         u32 const bands = m ? (m + systolic_band_rows_k - 1) / systolic_band_rows_k : 1;
-        if (band >= bands) continue;
+        if (band >= bands) return;
 
         // All-gap borders (weighted.hip; serial.hpp:821-823,1045-1047): DP cell (k, 0) and (0, k).
         auto border = [&](u32 k) -> i32 {
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(64 * systolic_waves_k) void systolic_scores_kernel(
         };
         if (m == 0 || n == 0) { // an empty side never enters the column loop: the score is the border itself
             if (lane == 0) write_result(local_ ? 0 : border(m ? m : n));
-            continue;
+            return;
         }
 
         bool const first_band = band == 0, last_band = band + 1 == bands;
@@ -329,6 +329,12 @@ __global__ __launch_bounds__(64 * systolic_waves_k) void systolic_scores_kernel(
         };
         if (!first_band) preload_above(0);
         u32 const steps = n + 63; // lane l is busy during steps [l, l + n)
+#ifdef SZS_SYSTOLIC_TRACE
+        u32 trace_in = 0, trace_out = 0; // sums of the row consumed from above (lane 0) and of the row parked (lane 63)
+        if (lane == 0 && (pair == 0 || total_tickets <= 64))
+            printf("enter ticket %u pair %u band %u/%u m %u n %u q.index %u c.index %u epoch %u\n", ticket, pair, band, bands, m, n,
+                   query.index, candidate.index, epoch);
+#endif
 
         // The symbol pipeline runs ONE STEP AHEAD of the score pipeline: `symbol_ahead` of lane l is the symbol of the
         // column the lane scores next step, so its profile row is fetched from LDS a whole step before it is consumed.
@@ -370,6 +376,9 @@ __global__ __launch_bounds__(64 * systolic_waves_k) void systolic_scores_kernel(
                 fed_above = __builtin_amdgcn_readlane(chunk_above, (int)slot);
                 if constexpr (affine_) fed_down = __builtin_amdgcn_readlane(chunk_down, (int)slot);
             }
+#ifdef SZS_SYSTOLIC_TRACE
+            if (t < n) trace_in += (u32)fed_above * (t + 1);
+#endif
             i32 const above_h = from_lane_above(fed_above, bottom_h);
             i32 above_down = 0;
             if constexpr (affine_) above_down = from_lane_above(fed_down, bottom_down);
@@ -388,6 +397,9 @@ __global__ __launch_bounds__(64 * systolic_waves_k) void systolic_scores_kernel(
                 bottom_h = column.h[rows - 1];
                 if constexpr (affine_) bottom_down = down_out;
                 if (!last_band && lane == 63) { // the band's bottom row, 1-based DP column t - 62
+#ifdef SZS_SYSTOLIC_TRACE
+                    trace_out += (u32)bottom_h * (t - 62);
+#endif
                     parked_store(parked_h + (t - 62), bottom_h);
                     if constexpr (affine_) parked_store(parked_down + (t - 62), bottom_down);
                 }
@@ -421,6 +433,14 @@ __global__ __launch_bounds__(64 * systolic_waves_k) void systolic_scores_kernel(
             }
         }
 
+#ifdef SZS_SYSTOLIC_TRACE
+        {
+            u32 const out = (u32)__builtin_amdgcn_readlane((int)trace_out, 63);
+            if (lane == 0 && (pair == 0 || total_tickets <= 64))
+                printf("leave ticket %u pair %u band %u/%u above-sum %08x parked-sum %08x abandoned %d\n", ticket, pair, band, bands,
+                       trace_in, out, (int)abandoned);
+        }
+#endif
         // ---- the pair's score
         if constexpr (local_) {
             u32 const wave_best = wave_max_u32((u32)best); // local scores are >= 0
@@ -448,25 +468,10 @@ __global__ __launch_bounds__(64 * systolic_waves_k) void systolic_scores_kernel(
     }
 }
 
-/** Workgroups of this instance the device keeps resident at once (the grid never needs to be larger). */
-template <bool local_, bool affine_, bool uniform_, bool runes_, bool saturating_>
-static u32 systolic_grid(u64 tickets) {
-    static int resident = 0;
-    if (!resident) {
-        int device = 0, units = 0, per_unit = 0;
-        if (hipGetDevice(&device) != hipSuccess ||
-            hipDeviceGetAttribute(&units, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_unit, systolic_scores_kernel<local_, affine_, uniform_, runes_, saturating_>,
-                                                         (int)(64 * systolic_waves_k), 0) != hipSuccess ||
-            units <= 0 || per_unit <= 0) {
-            (void)hipGetLastError();
-            units = 256, per_unit = 2;
-        }
-        resident = units * per_unit;
-    }
-    u64 const wanted = (tickets + systolic_waves_k - 1) / systolic_waves_k;
-    return (u32)(wanted < (u64)resident ? wanted : (u64)resident);
-}
+/** One wavefront per ticket.  Wavefronts the device cannot hold yet simply start later; a wavefront draws its ticket
+ *  when it starts RUNNING, so the holder of every earlier ticket is running or done - the forward-progress argument of
+ *  the band chain does not care how many workgroups are resident. */
+static u32 systolic_grid(u64 tickets) { return (u32)((tickets + systolic_waves_k - 1) / systolic_waves_k); }
 
 /** Two blocks: `control` (epoch-tagged 64-bit words: ticket counter, stall flag, progress, best, done - zeroed ONCE when
  *  the block is allocated, never between launches) and `parked` (the bottom rows in flight; plain data). */
@@ -501,7 +506,7 @@ static int launch_systolic(szs_cost_model_t const *model, szs_string_ref_t const
     systolic_layout_t const layout = systolic_layout(affine_, queries_count, candidates_count, longest_query, longest_candidate);
     if (layout.tickets > systolic_ticket_limit_k) return (int)hipErrorInvalidValue; // the host keeps larger jobs on weighted.hip
     char *const base = static_cast<char *>(control);
-    u32 const grid = systolic_grid<local_, affine_, uniform_, runes_, saturating_>(layout.tickets);
+    u32 const grid = systolic_grid(layout.tickets);
     hipLaunchKernelGGL((systolic_scores_kernel<local_, affine_, uniform_, runes_, saturating_>), dim3(grid),
                        dim3(64 * systolic_waves_k), 0, stream, model, queries, queries_count, candidates, candidates_count,
                        layout.max_bands, results, stride, symmetric, reinterpret_cast<u64 *>(base),

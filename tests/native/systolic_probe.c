@@ -74,7 +74,8 @@ int main(int argc, char **argv) {
     int8_t extend = argc > 8 ? (int8_t)atoi(argv[8]) : (is_lev ? (family[3] ? 3 : 1) : (family[0] == 's' ? -1 : -4));
     int8_t const match = is_lev && family[3] ? 1 : 0, mismatch = is_lev && family[3] ? 3 : 1;
     signal(SIGALRM, on_alarm);
-    alarm(40);
+    unsigned const patience = getenv("PROBE_ALARM") ? (unsigned)atoi(getenv("PROBE_ALARM")) : 40;
+    alarm(patience);
 
     uint8_t byte_to_class[256];
     int8_t class_costs[32 * 32];
@@ -108,7 +109,7 @@ int main(int argc, char **argv) {
     int failures = 0;
     for (int run = 0; run < repeats; ++run) {
         stage = "engine call";
-        alarm(40);
+        alarm(patience);
         hipMemset(device_results, 0xEE, cells_count * 8);
         double const started = now_ms();
         if (is_lev) status = szs_levenshtein_distances_u32tape(engine, scope, &q_tape, &c_tape, (sz_size_t *)device_results, c_count, &error);
