@@ -48,25 +48,15 @@ constexpr u32 systolic_band_rows_k = 64u * systolic_rows_k;     // query rows pe
 #define SZS_SYSTOLIC_WAVES 4
 #endif
 constexpr u32 systolic_waves_k = SZS_SYSTOLIC_WAVES;            // wavefronts per workgroup; each pulls its own tickets
-#ifdef SZS_SYSTOLIC_PARKED_PARITY // debugging aid: odd and even bands park in separate copies instead of in place
-constexpr u32 systolic_parked_copies_k = 2;
-#else
-constexpr u32 systolic_parked_copies_k = 1;
-#endif
-/** A parked cell is written by one wavefront and read by another one, possibly on another XCD. */
+/** A parked cell is written by one wavefront and read by another one, usually on another XCD.  Both sides use
+ *  agent-scope accesses (`sc1`: the cell lives at the device's coherence point, not in an XCD's write-back L2), so the
+ *  release / acquire around a chunk has nothing left to write back or to re-fetch - measured 1.5x faster on a 16 x 16
+ *  batch of 4 KB strings than plain stores flushed by `buffer_wbl2`, and one assumption fewer about the caches. */
 __device__ __forceinline__ i32 parked_load(i32 const *cell) {
-#ifdef SZS_SYSTOLIC_ATOMIC_PARKED
     return __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-    return *cell;
-#endif
 }
 __device__ __forceinline__ void parked_store(i32 *cell, i32 value) {
-#ifdef SZS_SYSTOLIC_ATOMIC_PARKED
     __hip_atomic_store(cell, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-    *cell = value;
-#endif
 }
 constexpr u32 systolic_chunk_k = 64;                            // columns per hand-over between bands
 constexpr u32 systolic_slack_k = 64;                            // parked columns past the longest candidate
@@ -280,12 +270,11 @@ __global__ __launch_bounds__(64 * systolic_waves_k) void systolic_scores_kernel(
         i32 best = 0, down_out = 0;
         i32 bottom_h = 0, bottom_down = 0; // this lane's bottom row at its latest column: what the lane below consumes
 
-        // [1-based DP column]; what this band parks, and what its predecessor parked (the same row unless debugging)
-        i32 *const parked_h = parked + ((u64)pair * systolic_parked_copies_k + band % systolic_parked_copies_k) * planes * parked_columns;
+        // [1-based DP column]: the row this band parks IS the row its predecessor parked - a band overwrites column j 63
+        // steps after it consumed it, and nobody but its successor reads it afterwards.
+        i32 *const parked_h = parked + (u64)pair * planes * parked_columns;
         i32 *const parked_down = parked_h + parked_columns;
-        i32 const *const above_parked_h =
-            parked + ((u64)pair * systolic_parked_copies_k + (band + 1) % systolic_parked_copies_k) * planes * parked_columns;
-        i32 const *const above_parked_down = above_parked_h + parked_columns;
+        i32 const *const above_parked_h = parked_h, *const above_parked_down = parked_down;
         u64 *const progress_out = progress + (u64)pair * max_bands + band;
         u64 const *const progress_in = progress_out - 1;
 
@@ -492,7 +481,7 @@ static systolic_layout_t systolic_layout(int affine, u32 queries_count, u32 cand
     layout.best_at = layout.progress_at + layout.tickets * sizeof(u64);
     layout.done_at = layout.best_at + layout.pairs * sizeof(u64);
     layout.control_bytes = layout.done_at + layout.pairs * sizeof(u64);
-    layout.parked_bytes = layout.pairs * systolic_parked_copies_k * (affine ? 2 : 1) * layout.parked_columns * sizeof(i32);
+    layout.parked_bytes = layout.pairs * (affine ? 2 : 1) * layout.parked_columns * sizeof(i32);
     return layout;
 }
 
