@@ -25,6 +25,24 @@ def gpu():
     return szs.DeviceScope(gpu_device=0)
 
 
+import contextlib  # noqa: E402
+import os  # noqa: E402
+
+
+@contextlib.contextmanager
+def forced_tier(name):
+    """`SZS_ROCM_TIER` overrides the planner's cycle model for one call (csrc/host/plan.c)."""
+    previous = os.environ.get("SZS_ROCM_TIER")
+    os.environ["SZS_ROCM_TIER"] = name
+    try:
+        yield
+    finally:
+        if previous is None:
+            del os.environ["SZS_ROCM_TIER"]
+        else:
+            os.environ["SZS_ROCM_TIER"] = previous
+
+
 def _unhex(items):
     return [bytes.fromhex(x) for x in items]
 
@@ -110,7 +128,8 @@ def test_levenshtein_every_kernel_width(gpu, oracle):
     queries = [bytes(rng.choice(b"ACGT") for _ in range(n)) for n in edges]
     candidates = _rand(rng, 70, 0, 300, b"ACGT") + [queries[9], queries[-1][:2100]]
     engine = szs.LevenshteinDistances(capabilities=gpu)
-    got = engine(queries, candidates, device=gpu)
+    with forced_tier("lanes"):  # 34 x 72 pairs: left alone, the planner would hand this batch to the systolic tier
+        got = engine(queries, candidates, device=gpu)
     assert np.array_equal(got, oracle.levenshtein(queries, candidates))
     profile = engine.last_call_profile()
     assert profile.launches == 10, profile.launches
@@ -444,24 +463,6 @@ def test_utf8_malformed_bytes_follow_the_unchecked_contract(gpu, oracle):
 
 
 # ---- the systolic (few-pairs) tier: hip/systolic.hip -----------------------------------------------------------------
-
-
-import contextlib  # noqa: E402
-import os  # noqa: E402
-
-
-@contextlib.contextmanager
-def forced_tier(name):
-    """`SZS_ROCM_TIER` overrides the planner's cycle model for one call (csrc/host/plan.c)."""
-    previous = os.environ.get("SZS_ROCM_TIER")
-    os.environ["SZS_ROCM_TIER"] = name
-    try:
-        yield
-    finally:
-        if previous is None:
-            del os.environ["SZS_ROCM_TIER"]
-        else:
-            os.environ["SZS_ROCM_TIER"] = previous
 
 
 def test_systolic_known_answers_and_golden_matrices(gpu, golden):
