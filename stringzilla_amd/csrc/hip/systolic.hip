@@ -58,7 +58,8 @@ __device__ __forceinline__ i32 parked_load(i32 const *cell) {
 __device__ __forceinline__ void parked_store(i32 *cell, i32 value) {
     __hip_atomic_store(cell, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-constexpr u32 systolic_chunk_k = 64;                            // columns per hand-over between bands
+constexpr u32 systolic_columns_k = 4;                           // K: consecutive columns a lane scores per step
+constexpr u32 systolic_chunk_steps_k = 16;                      // steps (of K columns) per hand-over between bands
 constexpr u32 systolic_slack_k = 64;                            // parked columns past the longest candidate
 constexpr size_t systolic_header_bytes_k = 256;                 // ticket counter [0] and stall flag [1] at the head of the control block
 constexpr u32 systolic_spin_limit_k = 1u << 18;                 // polls of a predecessor's counter before giving up
@@ -146,11 +147,12 @@ __device__ __forceinline__ void systolic_advance(systolic_column_t<affine_> &col
  *  @tparam runes_       (with uniform_) strings are UTF-32 arrays, lengths count runes.
  *  @tparam saturating_  (with local_) both gap costs <= 0: unsigned-saturating gap arithmetic.
  *
- *  Workspace (all zeroed by the launcher except the parked rows):
+ *  Control block (epoch-tagged 64-bit words, see hip/kernels.h) and parked rows:
+ *    work_counter[0], [1]               ticket counter, stall flag
  *    progress[pair * max_bands + band]  columns of that band's bottom row that are parked and visible
  *    pair_best[pair], pair_done[pair]   local alignment: running maximum and finished bands of the pair
  *    parked[pair][plane][column]        bottom rows in flight (plane 0: H, plane 1: vertical-gap track), reused IN PLACE
- *                                       by successive bands: a band overwrites column j 63 steps after it consumed it.
+ *                                       by successive bands: a band overwrites a column 63 steps after it consumed it.
  */
 template <bool local_, bool affine_, bool uniform_, bool runes_, bool saturating_>
 __global__ __launch_bounds__(64 * systolic_waves_k) void systolic_scores_kernel(
@@ -161,8 +163,11 @@ __global__ __launch_bounds__(64 * systolic_waves_k) void systolic_scores_kernel(
 
     constexpr int rows = systolic_rows_k;
     constexpr int cost_dwords = rows / 4;
+    constexpr u32 K = systolic_columns_k;
+    constexpr u32 chunk_steps = systolic_chunk_steps_k;
     static_assert(!runes_ || uniform_, "codepoint scoring exists for uniform costs only");
     static_assert(!saturating_ || local_, "saturating gap arithmetic is a local-alignment form");
+    static_assert(K == 4, "byte / class symbols of one step travel packed in one dword");
 
     // Class-table engines: [wave][class][lane] packed int8 costs of the lane's rows; shared: the table and the byte map.
     __shared__ __attribute__((aligned(16))) u32 profiles[uniform_ ? 1 : systolic_waves_k * 32 * 64 * cost_dwords];
@@ -183,277 +188,319 @@ __global__ __launch_bounds__(64 * systolic_waves_k) void systolic_scores_kernel(
     u64 const tag = (u64)epoch << 32;
     u32 const planes = affine_ ? 2 : 1;
 
-    { // one ticket per wavefront: the grid holds exactly as many wavefronts as there are tickets
-        // Every word of the control block is tagged with the launch's epoch in its high half, so NOTHING in it has to be
-        // zeroed between launches (and no launch depends on a preceding fill having landed): the first fetch-max lifts a
-        // word left by an older launch to (epoch, 0), values of older epochs compare below everything of this one.
-        u32 ticket = 0;
-        if (lane == 0) {
-            __hip_atomic_fetch_max(work_counter, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ticket = (u32)__hip_atomic_fetch_add(work_counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        ticket = __builtin_amdgcn_readfirstlane(ticket);
-        if (ticket >= total_tickets) return;
-        u32 const pair = ticket / max_bands, band = ticket % max_bands;
-        szs_string_ref_t const query = queries[pair / candidates_count];
-        szs_string_ref_t const candidate = candidates[pair % candidates_count];
-        if ((symmetric & SZS_LAYOUT_SYMMETRIC) && candidate.index > query.index) return; // upper triangle: mirrored from below
-        u32 const m = query.length, n = candidate.length;
-        u32 const bands = m ? (m + systolic_band_rows_k - 1) / systolic_band_rows_k : 1;
-        if (band >= bands) return;
+    // ---- one ticket per wavefront: the grid holds exactly as many wavefronts as there are tickets.
+    // Every word of the control block is tagged with the launch's epoch in its high half, so NOTHING in it has to be zeroed
+    // between launches (and no launch depends on a preceding fill having landed): the first fetch-max lifts a word left by
+    // an older launch to (epoch, 0), values of older epochs compare below everything of this one.
+    u32 ticket = 0;
+    if (lane == 0) {
+        __hip_atomic_fetch_max(work_counter, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = (u32)__hip_atomic_fetch_add(work_counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    if (ticket >= total_tickets) return;
+    u32 const pair = ticket / max_bands, band = ticket % max_bands;
+    szs_string_ref_t const query = queries[pair / candidates_count];
+    szs_string_ref_t const candidate = candidates[pair % candidates_count];
+    if ((symmetric & SZS_LAYOUT_SYMMETRIC) && candidate.index > query.index) return; // upper triangle: mirrored from below
+    u32 const m = query.length, n = candidate.length;
+    u32 const bands = m ? (m + systolic_band_rows_k - 1) / systolic_band_rows_k : 1;
+    if (band >= bands) return;
 
-        // All-gap borders (weighted.hip; serial.hpp:821-823,1045-1047): DP cell (k, 0) and (0, k).
-        auto border = [&](u32 k) -> i32 {
-            if constexpr (local_) return 0;
-            if constexpr (affine_) return k ? gap_open + gap_extend * (i32)(k - 1) : 0;
-            return gap_open * (i32)k;
-        };
-        auto write_result = [&](i32 score) {
-            i64 const value = uniform_ ? -(i64)score : (i64)score;
-            bool const transposed = (symmetric & SZS_LAYOUT_TRANSPOSED) != 0; // kernel roles swapped by the host
-            u64 const row = transposed ? candidate.index : query.index, column = transposed ? query.index : candidate.index;
-            results[row * results_row_stride + column] = value;
-            if ((symmetric & SZS_LAYOUT_SYMMETRIC) && candidate.index != query.index)
-                results[column * results_row_stride + row] = value;
-        };
-        if (m == 0 || n == 0) { // an empty side never enters the column loop: the score is the border itself
-            if (lane == 0) write_result(local_ ? 0 : border(m ? m : n));
-            return;
-        }
+    // All-gap borders (weighted.hip; serial.hpp:821-823,1045-1047): DP cell (k, 0) and (0, k).
+    auto border = [&](u32 k) -> i32 {
+        if constexpr (local_) return 0;
+        if constexpr (affine_) return k ? gap_open + gap_extend * (i32)(k - 1) : 0;
+        return gap_open * (i32)k;
+    };
+    auto write_result = [&](i32 score) {
+        i64 const value = uniform_ ? -(i64)score : (i64)score;
+        bool const transposed = (symmetric & SZS_LAYOUT_TRANSPOSED) != 0; // kernel roles swapped by the host
+        u64 const row = transposed ? candidate.index : query.index, column = transposed ? query.index : candidate.index;
+        results[row * results_row_stride + column] = value;
+        if ((symmetric & SZS_LAYOUT_SYMMETRIC) && candidate.index != query.index)
+            results[column * results_row_stride + row] = value;
+    };
+    if (m == 0 || n == 0) { // an empty side never enters the column loop: the score is the border itself
+        if (lane == 0) write_result(local_ ? 0 : border(m ? m : n));
+        return;
+    }
 
-        bool const first_band = band == 0, last_band = band + 1 == bands;
-        u32 const band_first = band * systolic_band_rows_k;
-        u32 const first_row = band_first + lane * rows;                                // 0-based string row
-        u32 const my_rows = first_row >= m ? 0u : (m - first_row < (u32)rows ? m - first_row : (u32)rows);
+    bool const first_band = band == 0, last_band = band + 1 == bands;
+    u32 const band_first = band * systolic_band_rows_k;
+    u32 const first_row = band_first + lane * rows;                                // 0-based string row
+    u32 const my_rows = first_row >= m ? 0u : (m - first_row < (u32)rows ? m - first_row : (u32)rows);
 
-        // ---- the lane's query rows: classes folded into the LDS profile, or raw symbols kept in registers
-        u32 query_symbols[uniform_ ? rows : 1];
-        if constexpr (uniform_) {
-#pragma unroll
-            for (int r = 0; r < rows; ++r) {
-                u32 symbol = ~0u; // padded rows: equal to no byte and to no decoded rune
-                if ((u32)r < my_rows)
-                    symbol = runes_ ? reinterpret_cast<u32 const *>(query.address)[first_row + r]
-                                    : (u32) reinterpret_cast<u8 const *>(query.address)[first_row + r];
-                query_symbols[r] = symbol;
-            }
-        }
-        else {
-            u32 classes[rows];
-#pragma unroll
-            for (int r = 0; r < rows; ++r)
-                classes[r] = (u32)r < my_rows ? (u32)class_of_byte[reinterpret_cast<u8 const *>(query.address)[first_row + r]] : 0u;
-            for (u32 candidate_class = 0; candidate_class < 32; ++candidate_class) {
-                u32 packed[cost_dwords];
-#pragma unroll
-                for (int r = 0; r < rows; ++r) {
-                    // cost(query, candidate) = table[class(query)][class(candidate)]: the QUERY picks the row
-                    i32 const cost = (u32)r < my_rows ? (i32)table[classes[r] * 32 + candidate_class] : 0;
-                    if (r % 4 == 0) packed[r / 4] = 0;
-                    packed[r / 4] |= ((u32)cost & 0xFFu) << (8 * (r % 4));
-                }
-#pragma unroll
-                for (int d = 0; d < cost_dwords; ++d) profile[candidate_class * 64 * cost_dwords + d] = packed[d];
-            }
-        }
-
-        // ---- column 0 of the lane's rows; finite "discard" seeds of the gap tracks (serial.hpp:1049-1056,1195-1201)
-        systolic_column_t<affine_> column;
+    // ---- the lane's query rows: classes folded into the LDS profile, or raw symbols kept in registers
+    u32 query_symbols[uniform_ ? rows : 1];
+    if constexpr (uniform_) {
 #pragma unroll
         for (int r = 0; r < rows; ++r) {
-            column.h[r] = border(first_row + r + 1);
-            column.h_gapped[r] = systolic_gapped<saturating_>(column.h[r], gap_open);
-            if constexpr (affine_)
-                column.across_extended[r] = saturating_ ? 0 : column.h[r] + gap_open + gap_extend + gap_extend;
+            u32 symbol = ~0u; // padded rows: equal to no byte and to no decoded rune
+            if ((u32)r < my_rows)
+                symbol = runes_ ? reinterpret_cast<u32 const *>(query.address)[first_row + r]
+                                : (u32) reinterpret_cast<u8 const *>(query.address)[first_row + r];
+            query_symbols[r] = symbol;
         }
-        i32 diagonal = border(first_row); // DP cell (row above the lane's first, column - 1)
-        i32 best = 0, down_out = 0;
-        i32 bottom_h = 0, bottom_down = 0; // this lane's bottom row at its latest column: what the lane below consumes
+    }
+    else {
+        u32 classes[rows];
+#pragma unroll
+        for (int r = 0; r < rows; ++r)
+            classes[r] = (u32)r < my_rows ? (u32)class_of_byte[reinterpret_cast<u8 const *>(query.address)[first_row + r]] : 0u;
+        for (u32 candidate_class = 0; candidate_class < 32; ++candidate_class) {
+            u32 packed[cost_dwords];
+#pragma unroll
+            for (int r = 0; r < rows; ++r) {
+                // cost(query, candidate) = table[class(query)][class(candidate)]: the QUERY picks the row
+                i32 const cost = (u32)r < my_rows ? (i32)table[classes[r] * 32 + candidate_class] : 0;
+                if (r % 4 == 0) packed[r / 4] = 0;
+                packed[r / 4] |= ((u32)cost & 0xFFu) << (8 * (r % 4));
+            }
+#pragma unroll
+            for (int d = 0; d < cost_dwords; ++d) profile[candidate_class * 64 * cost_dwords + d] = packed[d];
+        }
+    }
 
-        // [1-based DP column]: the row this band parks IS the row its predecessor parked - a band overwrites column j 63
-        // steps after it consumed it, and nobody but its successor reads it afterwards.
-        i32 *const parked_h = parked + (u64)pair * planes * parked_columns;
-        i32 *const parked_down = parked_h + parked_columns;
-        i32 const *const above_parked_h = parked_h, *const above_parked_down = parked_down;
-        u64 *const progress_out = progress + (u64)pair * max_bands + band;
-        u64 const *const progress_in = progress_out - 1;
+    // ---- column 0 of the lane's rows; finite "discard" seeds of the gap tracks (serial.hpp:1049-1056,1195-1201)
+    systolic_column_t<affine_> column;
+#pragma unroll
+    for (int r = 0; r < rows; ++r) {
+        column.h[r] = border(first_row + r + 1);
+        column.h_gapped[r] = systolic_gapped<saturating_>(column.h[r], gap_open);
+        if constexpr (affine_)
+            column.across_extended[r] = saturating_ ? 0 : column.h[r] + gap_open + gap_extend + gap_extend;
+    }
+    i32 diagonal = border(first_row); // DP cell (row above the lane's first, column - 1)
+    i32 best = 0, down_out = 0;
+    // this lane's bottom row at the K columns of its latest step: what the lane below consumes one step later
+    i32 bottom_h[K] = {0, 0, 0, 0}, bottom_down[affine_ ? K : 1] = {0};
 
-        auto symbol_at = [&](u32 index) -> u32 { // what lane 0 feeds into the array for column `index` < n
-            if constexpr (runes_) return reinterpret_cast<u32 const *>(candidate.address)[index];
-            else if constexpr (uniform_) return (u32) reinterpret_cast<u8 const *>(candidate.address)[index];
-            else return (u32)class_of_byte[reinterpret_cast<u8 const *>(candidate.address)[index]];
-        };
+    // [1-based DP column]: the row this band parks IS the row its predecessor parked - a band overwrites a column 63
+    // steps after it consumed it, and nobody but its successor reads it afterwards.
+    i32 *const parked_h = parked + (u64)pair * planes * parked_columns;
+    i32 *const parked_down = parked_h + parked_columns;
+    u64 *const progress_out = progress + (u64)pair * max_bands + band;
+    u64 const *const progress_in = progress_out - 1;
 
-        // Lane 0's inputs are preloaded a chunk (64 columns, one per lane) at a time and picked per step by readlane:
-        //   `chunk_*` feed the steps of the current chunk, `next_*` were loaded one chunk EARLIER for the chunk after it,
-        //   so neither the text nor the parked row is ever waited for inside a chunk.  The price is that a band only
-        //   starts a chunk when its predecessor has parked the NEXT chunk as well (it trails by ~192 columns, not ~128).
-        u32 chunk_symbols = 0, next_symbols = lane < n ? symbol_at(lane) : 0u;
-        i32 chunk_above = 0, chunk_down = 0, next_above = 0, next_down = 0;
-        u64 parked_seen = 0; // the predecessor's progress word (epoch, columns) as last read
-        bool abandoned = false; // a wait of this band has timed out: its results are void, never wait again
-        auto preload_above = [&](u32 chunk_first) { // columns [chunk_first, chunk_first + 64) of the predecessor's bottom row
-            u64 const needed = tag | (chunk_first + 64 < n ? chunk_first + 64 : n);
-            for (u32 spins = 0; parked_seen < needed && !abandoned; ++spins) {
-                parked_seen = __hip_atomic_load(progress_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (parked_seen >= needed) break;
-                __builtin_amdgcn_s_sleep(2);
-                // A predecessor only ever needs to score ~128 columns to satisfy this wait (microseconds).  Never hang the
-                // device on a broken invariant: give up after a fraction of a second - at once if another band already
-                // has - flag the call, and let the host report the failure.
-                bool const hopeless = spins > systolic_spin_limit_k ||
-                                      (spins % 1024 == 1023 && __hip_atomic_load(work_counter + 1, __ATOMIC_RELAXED,
-                                                                                 __HIP_MEMORY_SCOPE_AGENT) == (tag | 1));
-                if (hopeless) {
-                    if (lane == 0) __hip_atomic_fetch_max(work_counter + 1, tag | 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    abandoned = true;
+    // The symbols of one step: K class ids / bytes packed in one dword, or K runes.
+    constexpr int symbol_words = runes_ ? (int)K : 1;
+    struct step_symbols_t {
+        u32 word[symbol_words];
+    };
+    auto load_step_symbols = [&](u32 step_index) -> step_symbols_t { // columns K step_index .. K step_index + K - 1; 0 past the text
+        step_symbols_t symbols;
+#pragma unroll
+        for (int w = 0; w < symbol_words; ++w) symbols.word[w] = 0;
+#pragma unroll
+        for (u32 j = 0; j < K; ++j) {
+            u32 const index = K * step_index + j;
+            if (index < n) {
+                if constexpr (runes_) symbols.word[j] = reinterpret_cast<u32 const *>(candidate.address)[index];
+                else {
+                    u32 symbol = reinterpret_cast<u8 const *>(candidate.address)[index];
+                    if constexpr (!uniform_) symbol = class_of_byte[symbol];
+                    symbols.word[0] |= symbol << (8 * j);
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            u32 const mine = chunk_first + lane;
-            if (mine < n) {
-                next_above = parked_load(above_parked_h + mine + 1);
-                if constexpr (affine_) next_down = parked_load(above_parked_down + mine + 1);
-            }
-        };
-        if (!first_band) preload_above(0);
-        u32 const steps = n + 63; // lane l is busy during steps [l, l + n)
-#ifdef SZS_SYSTOLIC_TRACE
-        u32 trace_in = 0, trace_out = 0; // sums of the row consumed from above (lane 0) and of the row parked (lane 63)
-        if (lane == 0 && (pair == 0 || total_tickets <= 64))
-            printf("enter ticket %u pair %u band %u/%u m %u n %u q.index %u c.index %u epoch %u\n", ticket, pair, band, bands, m, n,
-                   query.index, candidate.index, epoch);
-#endif
+        }
+        return symbols;
+    };
+    auto symbol_of = [&](step_symbols_t const &symbols, u32 j) -> u32 {
+        if constexpr (runes_) return symbols.word[j];
+        else return (symbols.word[0] >> (8 * j)) & 0xFFu;
+    };
 
-        // The symbol pipeline runs ONE STEP AHEAD of the score pipeline: `symbol_ahead` of lane l is the symbol of the
-        // column the lane scores next step, so its profile row is fetched from LDS a whole step before it is consumed.
-        u32 symbol_ahead = 0;
-        u32 costs_ahead[uniform_ ? 1 : cost_dwords];
-        auto advance_symbols = [&](u32 fed_symbol) {
-            symbol_ahead = from_lane_above(fed_symbol, symbol_ahead);
-            if constexpr (!uniform_) { // always a valid class: everything ever fed is a class id or 0
-                u32 const *const row = profile + symbol_ahead * (64 * cost_dwords);
+    // Lane 0's inputs are preloaded a chunk (16 steps = 64 columns; lane k < 16 holds step k's K columns) at a time and
+    // picked per step by readlane: `chunk_*` feed the steps of the current chunk, `next_*` were loaded one chunk EARLIER
+    // for the chunk after it, so neither the text nor the parked row is ever waited for inside a chunk.  The price is
+    // that a band only starts a chunk when its predecessor has parked the NEXT chunk as well.
+    step_symbols_t chunk_symbols = load_step_symbols(0), next_symbols = load_step_symbols(lane < chunk_steps ? lane : 0);
+    i32 chunk_above[K] = {0, 0, 0, 0}, next_above[K] = {0, 0, 0, 0};
+    i32 chunk_down[affine_ ? K : 1] = {0}, next_down[affine_ ? K : 1] = {0};
+    u64 parked_seen = 0;    // the predecessor's progress word (epoch, columns) as last read
+    bool abandoned = false; // a wait of this band has timed out: its results are void, never wait again
+    auto preload_above = [&](u32 first_step) { // the predecessor's bottom row under the steps [first_step, first_step + 16)
+        u32 const last_column = K * (first_step + chunk_steps);
+        u64 const needed = tag | (last_column < n ? last_column : n);
+        for (u32 spins = 0; parked_seen < needed && !abandoned; ++spins) {
+            parked_seen = __hip_atomic_load(progress_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (parked_seen >= needed) break;
+            __builtin_amdgcn_s_sleep(2);
+            // A predecessor only ever needs to score a few hundred columns to satisfy this wait (microseconds).  Never
+            // hang the device on a broken invariant: give up after a fraction of a second - at once if another band
+            // already has - flag the call, and let the host report the failure.
+            bool const hopeless = spins > systolic_spin_limit_k ||
+                                  (spins % 1024 == 1023 && __hip_atomic_load(work_counter + 1, __ATOMIC_RELAXED,
+                                                                             __HIP_MEMORY_SCOPE_AGENT) == (tag | 1));
+            if (hopeless) {
+                if (lane == 0) __hip_atomic_fetch_max(work_counter + 1, tag | 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                abandoned = true;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (lane < chunk_steps) {
+#pragma unroll
+            for (u32 j = 0; j < K; ++j) {
+                u32 const index = K * (first_step + lane) + j;
+                if (index < n) {
+                    next_above[j] = parked_load(parked_h + index + 1);
+                    if constexpr (affine_) next_down[j] = parked_load(parked_down + index + 1);
+                }
+            }
+        }
+    };
+    if (!first_band) preload_above(0);
+    u32 const column_steps = (n + K - 1) / K; // steps a lane needs for the whole text
+    u32 const steps = column_steps + 63;      // lane l is busy during steps [l, l + column_steps)
+
+    // The symbol pipeline runs ONE STEP AHEAD of the score pipeline: `symbols_ahead` of lane l holds the symbols of the
+    // columns the lane scores next step, so their profile rows are fetched from LDS a whole step before they are consumed.
+    step_symbols_t symbols_ahead;
+#pragma unroll
+    for (int w = 0; w < symbol_words; ++w) symbols_ahead.word[w] = 0;
+    u32 costs_ahead[uniform_ ? 1 : K][uniform_ ? 1 : cost_dwords];
+    auto advance_symbols = [&](step_symbols_t const &fed) {
+#pragma unroll
+        for (int w = 0; w < symbol_words; ++w) symbols_ahead.word[w] = from_lane_above(fed.word[w], symbols_ahead.word[w]);
+        if constexpr (!uniform_) { // always valid classes: everything ever fed is a class id or 0
+#pragma unroll
+            for (u32 j = 0; j < K; ++j) {
+                u32 const *const row = profile + symbol_of(symbols_ahead, j) * (64 * cost_dwords);
                 if constexpr (cost_dwords == 2) {
                     uint2 const both = *reinterpret_cast<uint2 const *>(row);
-                    costs_ahead[0] = both.x, costs_ahead[1] = both.y;
+                    costs_ahead[j][0] = both.x, costs_ahead[j][1] = both.y;
                 }
                 else if constexpr (cost_dwords == 4) {
                     uint4 const all = *reinterpret_cast<uint4 const *>(row);
-                    costs_ahead[0] = all.x, costs_ahead[1] = all.y, costs_ahead[2] = all.z, costs_ahead[3] = all.w;
+                    costs_ahead[j][0] = all.x, costs_ahead[j][1] = all.y, costs_ahead[j][2] = all.z, costs_ahead[j][3] = all.w;
                 }
-                else { costs_ahead[0] = row[0]; }
+                else { costs_ahead[j][0] = row[0]; }
             }
-        };
+        }
+    };
+    auto pick = [&](step_symbols_t const &from, u32 slot) -> step_symbols_t { // lane `slot`'s copy, wave-uniform
+        step_symbols_t picked;
+#pragma unroll
+        for (int w = 0; w < symbol_words; ++w) picked.word[w] = (u32)__builtin_amdgcn_readlane((int)from.word[w], (int)slot);
+        return picked;
+    };
 
-        // One step of the whole wavefront.  `slot` = step % 64 selects lane 0's inputs out of the preloaded chunk.
-        auto step = [&](u32 t, u32 slot, auto predicated) {
-            u32 const symbol = symbol_ahead; // of column t - lane
-            u32 packed[uniform_ ? 1 : cost_dwords];
-            if constexpr (!uniform_)
-                for (int d = 0; d < cost_dwords; ++d) packed[d] = costs_ahead[d];
-            // feed column t + 1 into the symbol pipeline: the last slot of a chunk takes it from the next chunk's preload
-            u32 const fed_symbol = slot == 63 ? (u32)__builtin_amdgcn_readlane((int)next_symbols, 0)
-                                              : (u32)__builtin_amdgcn_readlane((int)chunk_symbols, (int)(slot + 1));
-            advance_symbols(fed_symbol);
+    // One step of the whole wavefront: every busy lane scores K columns.  `slot` = step % 16 selects lane 0's inputs.
+    auto step = [&](u32 t, u32 slot, auto predicated) {
+        step_symbols_t const symbols = symbols_ahead; // of columns K (t - lane) ...
+        u32 packed[uniform_ ? 1 : K][uniform_ ? 1 : cost_dwords];
+        if constexpr (!uniform_) {
+#pragma unroll
+            for (u32 j = 0; j < K; ++j)
+#pragma unroll
+                for (int d = 0; d < cost_dwords; ++d) packed[j][d] = costs_ahead[j][d];
+        }
+        // feed step t + 1 into the symbol pipeline: the last slot of a chunk takes it from the next chunk's preload
+        advance_symbols(slot + 1 == chunk_steps ? pick(next_symbols, 0) : pick(chunk_symbols, slot + 1));
 
+        i32 above_h[K], above_down[K];
+#pragma unroll
+        for (u32 j = 0; j < K; ++j) {
             i32 fed_above, fed_down = 0;
             if (first_band) {
-                fed_above = border(t + 1);
+                fed_above = border(K * t + j + 1);
                 if constexpr (affine_) fed_down = saturating_ ? 0 : fed_above + gap_open + gap_extend;
             }
             else {
-                fed_above = __builtin_amdgcn_readlane(chunk_above, (int)slot);
-                if constexpr (affine_) fed_down = __builtin_amdgcn_readlane(chunk_down, (int)slot);
+                fed_above = __builtin_amdgcn_readlane(chunk_above[j], (int)slot);
+                if constexpr (affine_) fed_down = __builtin_amdgcn_readlane(chunk_down[affine_ ? j : 0], (int)slot);
             }
-#ifdef SZS_SYSTOLIC_TRACE
-            if (t < n) trace_in += (u32)fed_above * (t + 1);
-#endif
-            i32 const above_h = from_lane_above(fed_above, bottom_h);
-            i32 above_down = 0;
-            if constexpr (affine_) above_down = from_lane_above(fed_down, bottom_down);
-            bool const busy = decltype(predicated)::value ? (t - lane) < n : true;
-            if (busy) {
-                if constexpr (uniform_) {
-                    auto cost_of = [&](int r) -> i32 { return query_symbols[r] == symbol ? uniform_match : uniform_mismatch; };
-                    systolic_advance<local_, affine_, saturating_>(column, cost_of, above_h, above_down, diagonal, gap_open,
-                                                                   gap_extend, down_out, best, my_rows);
-                }
-                else {
-                    auto cost_of = [&](int r) -> i32 { return (i32)(int8_t)(packed[r / 4] >> (8 * (r % 4))); };
-                    systolic_advance<local_, affine_, saturating_>(column, cost_of, above_h, above_down, diagonal, gap_open,
-                                                                   gap_extend, down_out, best, my_rows);
-                }
-                bottom_h = column.h[rows - 1];
-                if constexpr (affine_) bottom_down = down_out;
-                if (!last_band && lane == 63) { // the band's bottom row, 1-based DP column t - 62
-#ifdef SZS_SYSTOLIC_TRACE
-                    trace_out += (u32)bottom_h * (t - 62);
-#endif
-                    parked_store(parked_h + (t - 62), bottom_h);
-                    if constexpr (affine_) parked_store(parked_down + (t - 62), bottom_down);
-                }
-            }
-            // Publish the parked columns every `systolic_chunk_k` of them and at the end of the text.
-            if (!last_band && t >= 63) {
-                u32 const parked_count = t - 62;
-                if ((parked_count % systolic_chunk_k == 0 || parked_count == n) && lane == 63)
-                    __hip_atomic_store(progress_out, tag | parked_count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        };
-
-        for (u32 chunk_first = 0; chunk_first < steps; chunk_first += 64) {
-            // ---- lane 0 is about to consume columns [chunk_first, chunk_first + 64)
-            if (chunk_first < n) {
-                chunk_symbols = next_symbols, chunk_above = next_above, chunk_down = next_down;
-                u32 const mine = chunk_first + 64 + lane; // the column this lane preloads for the chunk after this one
-                next_symbols = mine < n ? symbol_at(mine) : 0u;
-                if (!first_band && chunk_first + 64 < n) preload_above(chunk_first + 64);
-                if (chunk_first == 0) advance_symbols((u32)__builtin_amdgcn_readlane((int)chunk_symbols, 0)); // column 0
-            }
-            bool const steady = chunk_first >= 64 && chunk_first + 64 <= n; // every lane busy during all 64 steps
-            if (steady) {
-#pragma unroll 2
-                for (u32 slot = 0; slot < 64; ++slot) step(chunk_first + slot, slot, std::false_type {});
-            }
-            else {
-                u32 const stop = steps - chunk_first < 64 ? steps - chunk_first : 64;
-#pragma unroll 1
-                for (u32 slot = 0; slot < stop; ++slot) step(chunk_first + slot, slot, std::true_type {});
-            }
+            above_h[j] = from_lane_above(fed_above, bottom_h[j]);
+            above_down[j] = 0;
+            if constexpr (affine_) above_down[j] = from_lane_above(fed_down, bottom_down[affine_ ? j : 0]);
         }
-
-#ifdef SZS_SYSTOLIC_TRACE
-        {
-            u32 const out = (u32)__builtin_amdgcn_readlane((int)trace_out, 63);
-            if (lane == 0 && (pair == 0 || total_tickets <= 64))
-                printf("leave ticket %u pair %u band %u/%u above-sum %08x parked-sum %08x abandoned %d\n", ticket, pair, band, bands,
-                       trace_in, out, (int)abandoned);
-        }
-#endif
-        // ---- the pair's score
-        if constexpr (local_) {
-            u32 const wave_best = wave_max_u32((u32)best); // local scores are >= 0
-            if (bands == 1) {
-                if (lane == 0) write_result((i32)wave_best);
-            }
-            else if (lane == 0) { // the band that finishes last reports the maximum over all of them
-                __hip_atomic_fetch_max(pair_best + pair, tag | wave_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_max(pair_done + pair, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                u32 const finished =
-                    (u32)__hip_atomic_fetch_add(pair_done + pair, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-                if (finished + 1 == bands)
-                    write_result((i32)(u32)__hip_atomic_load(pair_best + pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            }
-        }
-        else if (last_band) { // bottom-right cell: the last real row, frozen at the owning lane's last column
-            u32 const last_row = m - 1 - band_first;
-            i32 mine = 0;
+        u32 const my_step = t - lane; // wraps for lanes that have not started yet
+        bool const busy = decltype(predicated)::value ? my_step < column_steps : true;
+        if (busy) {
 #pragma unroll
-            for (int r = 0; r < rows; ++r)
-                if ((u32)r == last_row % rows) mine = column.h[r];
-            i32 const score = __builtin_amdgcn_readlane(mine, (int)(last_row / rows));
-            if (lane == 0) write_result(score);
+            for (u32 j = 0; j < K; ++j) {
+                bool const inside = decltype(predicated)::value ? K * my_step + j < n : true; // the last step may be ragged
+                if (inside) {
+                    if constexpr (uniform_) {
+                        u32 const symbol = symbol_of(symbols, j);
+                        auto cost_of = [&](int r) -> i32 { return query_symbols[r] == symbol ? uniform_match : uniform_mismatch; };
+                        systolic_advance<local_, affine_, saturating_>(column, cost_of, above_h[j], above_down[j], diagonal,
+                                                                       gap_open, gap_extend, down_out, best, my_rows);
+                    }
+                    else {
+                        auto cost_of = [&](int r) -> i32 { return (i32)(int8_t)(packed[j][r / 4] >> (8 * (r % 4))); };
+                        systolic_advance<local_, affine_, saturating_>(column, cost_of, above_h[j], above_down[j], diagonal,
+                                                                       gap_open, gap_extend, down_out, best, my_rows);
+                    }
+                    bottom_h[j] = column.h[rows - 1];
+                    if constexpr (affine_) bottom_down[j] = down_out;
+                    if (!last_band && lane == 63) { // the band's bottom row, 1-based DP column
+                        parked_store(parked_h + K * my_step + j + 1, bottom_h[j]);
+                        if constexpr (affine_) parked_store(parked_down + K * my_step + j + 1, bottom_down[affine_ ? j : 0]);
+                    }
+                }
+            }
         }
+        // Publish the parked columns every 16 steps of lane 63 and at the end of the text.
+        if (!last_band && t >= 63) {
+            u32 const parked_steps = t - 62;
+            if ((parked_steps % chunk_steps == 0 || t + 1 == steps) && lane == 63) {
+                u32 const parked_count = K * parked_steps < n ? K * parked_steps : n;
+                __hip_atomic_store(progress_out, tag | parked_count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
+
+    for (u32 chunk_first = 0; chunk_first < steps; chunk_first += chunk_steps) {
+        // ---- lane 0 is about to consume the steps [chunk_first, chunk_first + 16)
+        if (K * chunk_first < n) {
+            chunk_symbols = next_symbols;
+#pragma unroll
+            for (u32 j = 0; j < K; ++j) {
+                chunk_above[j] = next_above[j];
+                if constexpr (affine_) chunk_down[j] = next_down[j];
+            }
+            next_symbols = load_step_symbols(chunk_first + chunk_steps + (lane < chunk_steps ? lane : 0)); // retires under the steps below
+            if (!first_band && K * (chunk_first + chunk_steps) < n) preload_above(chunk_first + chunk_steps);
+            if (chunk_first == 0) advance_symbols(pick(chunk_symbols, 0)); // the columns of step 0
+        }
+        // every lane busy, with K whole columns, during all 16 steps?
+        bool const steady = chunk_first >= 64 && K * (chunk_first + chunk_steps) <= n;
+        if (steady) {
+#pragma unroll 1
+            for (u32 slot = 0; slot < chunk_steps; ++slot) step(chunk_first + slot, slot, std::false_type {});
+        }
+        else {
+            u32 const stop = steps - chunk_first < chunk_steps ? steps - chunk_first : chunk_steps;
+#pragma unroll 1
+            for (u32 slot = 0; slot < stop; ++slot) step(chunk_first + slot, slot, std::true_type {});
+        }
+    }
+
+    // ---- the pair's score
+    if constexpr (local_) {
+        u32 const wave_best = wave_max_u32((u32)best); // local scores are >= 0
+        if (bands == 1) {
+            if (lane == 0) write_result((i32)wave_best);
+        }
+        else if (lane == 0) { // the band that finishes last reports the maximum over all of them
+            __hip_atomic_fetch_max(pair_best + pair, tag | wave_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_max(pair_done + pair, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            u32 const finished =
+                (u32)__hip_atomic_fetch_add(pair_done + pair, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (finished + 1 == bands)
+                write_result((i32)(u32)__hip_atomic_load(pair_best + pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+    }
+    else if (last_band) { // bottom-right cell: the last real row, frozen at the owning lane's last column
+        u32 const last_row = m - 1 - band_first;
+        i32 mine = 0;
+#pragma unroll
+        for (int r = 0; r < rows; ++r)
+            if ((u32)r == last_row % rows) mine = column.h[r];
+        i32 const score = __builtin_amdgcn_readlane(mine, (int)(last_row / rows));
+        if (lane == 0) write_result(score);
     }
 }
 

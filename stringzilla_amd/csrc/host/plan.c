@@ -109,9 +109,9 @@ void szs_plan_build(unsigned myers, int symmetric, uint64_t const *query_address
  *  wherever they matter:
  *    lanes    : a wavefront scores one query against up to 64 candidates, its lanes in lock step, `lane_rate` cells per
  *               lane-cycle; at most 1024 wavefronts advance at once; the call lasts at least as long as its largest pair;
- *    systolic : a wavefront-step scores 64 x R cells in `step_cycles`; a (pair, band) ticket takes len(candidate) + 63
- *               steps; at most 1024 wavefronts advance at once; the call lasts at least as long as the band chain of its
- *               largest pair (each band trails its predecessor by ~192 steps).
+ *    systolic : a wavefront-step scores 64 x R x K cells in `step_cycles`; a (pair, band) ticket takes len(candidate) / K
+ *               + 63 steps; at most 1024 wavefronts advance at once; the call lasts at least as long as the band chain of
+ *               its largest pair (each band trails its predecessor by ~95 steps).
  *  Constants from the measured gfx950 rates (profiles/r01/valu_peak.json): fast VALU ~2.5 cycles, slow ~4.2.
  */
 double szs_plan_estimate(unsigned bit_parallel_limit, int affine, int uniform, int symmetric,
@@ -139,14 +139,15 @@ double szs_plan_estimate(unsigned bit_parallel_limit, int affine, int uniform, i
     double const largest_pair = (double)longest_query * longest_candidate / lane_rate;
     if (largest_pair > lanes_cycles) lanes_cycles = largest_pair;
 
-    double const rows_per_lane = band_rows / 64.0;
+    double const rows_per_lane = band_rows / 64.0, columns_per_step = 4.0; /* hip/systolic.hip: R x K cells per lane-step */
     double const ops_per_cell = (affine ? 7.0 : 3.0) + (uniform ? 2.0 : 0.0);
-    double const step_cycles = ops_per_cell * rows_per_lane * 4.2 + 40.0;
+    double const step_cycles = ops_per_cell * rows_per_lane * columns_per_step * 4.2 + 80.0;
     double tickets = bands_total * candidates_count * scale;
     if (tickets < 1) tickets = 1;
-    double systolic_cycles = tickets * (mean_candidate + 63.0) * step_cycles / (tickets < simds ? tickets : simds);
+    double systolic_cycles = tickets * (mean_candidate / columns_per_step + 63.0) * step_cycles / (tickets < simds ? tickets : simds);
     double const longest_chain = (double)((longest_query + band_rows - 1) / band_rows);
-    double const chain_cycles = (longest_candidate + 63.0 + 192.0 * (longest_chain > 1 ? longest_chain - 1 : 0)) * step_cycles;
+    double const chain_cycles =
+        (longest_candidate / columns_per_step + 63.0 + 95.0 * (longest_chain > 1 ? longest_chain - 1 : 0)) * step_cycles;
     if (chain_cycles > systolic_cycles) systolic_cycles = chain_cycles;
 
     char const *forced = getenv("SZS_ROCM_TIER"); /* testing aid: lanes | systolic */
