@@ -387,7 +387,13 @@ __global__ __launch_bounds__(64 * systolic_waves_k) void systolic_scores_kernel(
     };
 
     // One step of the whole wavefront: every busy lane scores K columns.  `slot` = step % 16 selects lane 0's inputs.
-    auto step = [&](u32 t, u32 slot, auto predicated) {
+    // `predicated`: some lane is idle or past the end of the text during this chunk; `topmost`: the band's row above is
+    // the DP border, not a parked row.  Both are compile-time variants so that the common body - every lane busy, K whole
+    // columns - is straight-line code: four independent column recurrences the scheduler can interleave, which is worth
+    // a factor of 1.7 to a wavefront that has its SIMD to itself (scripts/wave_latency.hip: 8.1 cycles per dependent
+    // instruction, 4.6 with independent work in between).
+    auto step = [&](u32 t, u32 slot, auto predicated, auto topmost) {
+        constexpr bool is_predicated = decltype(predicated)::value, is_topmost = decltype(topmost)::value;
         step_symbols_t const symbols = symbols_ahead; // of columns K (t - lane) ...
         u32 packed[uniform_ ? 1 : K][uniform_ ? 1 : cost_dwords];
         if constexpr (!uniform_) {
@@ -403,7 +409,7 @@ __global__ __launch_bounds__(64 * systolic_waves_k) void systolic_scores_kernel(
 #pragma unroll
         for (u32 j = 0; j < K; ++j) {
             i32 fed_above, fed_down = 0;
-            if (first_band) {
+            if constexpr (is_topmost) {
                 fed_above = border(K * t + j + 1);
                 if constexpr (affine_) fed_down = saturating_ ? 0 : fed_above + gap_open + gap_extend;
             }
@@ -416,11 +422,11 @@ __global__ __launch_bounds__(64 * systolic_waves_k) void systolic_scores_kernel(
             if constexpr (affine_) above_down[j] = from_lane_above(fed_down, bottom_down[affine_ ? j : 0]);
         }
         u32 const my_step = t - lane; // wraps for lanes that have not started yet
-        bool const busy = decltype(predicated)::value ? my_step < column_steps : true;
+        bool const busy = is_predicated ? my_step < column_steps : true;
         if (busy) {
 #pragma unroll
             for (u32 j = 0; j < K; ++j) {
-                bool const inside = decltype(predicated)::value ? K * my_step + j < n : true; // the last step may be ragged
+                bool const inside = is_predicated ? K * my_step + j < n : true; // the last step may be ragged
                 if (inside) {
                     if constexpr (uniform_) {
                         u32 const symbol = symbol_of(symbols, j);
@@ -435,10 +441,14 @@ __global__ __launch_bounds__(64 * systolic_waves_k) void systolic_scores_kernel(
                     }
                     bottom_h[j] = column.h[rows - 1];
                     if constexpr (affine_) bottom_down[j] = down_out;
-                    if (!last_band && lane == 63) { // the band's bottom row, 1-based DP column
-                        parked_store(parked_h + K * my_step + j + 1, bottom_h[j]);
-                        if constexpr (affine_) parked_store(parked_down + K * my_step + j + 1, bottom_down[affine_ ? j : 0]);
-                    }
+                }
+            }
+            if (!last_band && lane == 63) { // the band's bottom row under this step's columns, 1-based DP column
+#pragma unroll
+                for (u32 j = 0; j < K; ++j) {
+                    if (is_predicated && K * my_step + j >= n) continue;
+                    parked_store(parked_h + K * my_step + j + 1, bottom_h[j]);
+                    if constexpr (affine_) parked_store(parked_down + K * my_step + j + 1, bottom_down[affine_ ? j : 0]);
                 }
             }
         }
@@ -449,6 +459,19 @@ __global__ __launch_bounds__(64 * systolic_waves_k) void systolic_scores_kernel(
                 u32 const parked_count = K * parked_steps < n ? K * parked_steps : n;
                 __hip_atomic_store(progress_out, tag | parked_count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             }
+        }
+    };
+    auto run_chunk = [&](u32 chunk_first, auto topmost) {
+        // every lane busy, with K whole columns, during all 16 steps?
+        bool const steady = chunk_first >= 64 && K * (chunk_first + chunk_steps) <= n;
+        if (steady) {
+#pragma unroll 1
+            for (u32 slot = 0; slot < chunk_steps; ++slot) step(chunk_first + slot, slot, std::false_type {}, topmost);
+        }
+        else {
+            u32 const stop = steps - chunk_first < chunk_steps ? steps - chunk_first : chunk_steps;
+#pragma unroll 1
+            for (u32 slot = 0; slot < stop; ++slot) step(chunk_first + slot, slot, std::true_type {}, topmost);
         }
     };
 
@@ -465,17 +488,8 @@ __global__ __launch_bounds__(64 * systolic_waves_k) void systolic_scores_kernel(
             if (!first_band && K * (chunk_first + chunk_steps) < n) preload_above(chunk_first + chunk_steps);
             if (chunk_first == 0) advance_symbols(pick(chunk_symbols, 0)); // the columns of step 0
         }
-        // every lane busy, with K whole columns, during all 16 steps?
-        bool const steady = chunk_first >= 64 && K * (chunk_first + chunk_steps) <= n;
-        if (steady) {
-#pragma unroll 1
-            for (u32 slot = 0; slot < chunk_steps; ++slot) step(chunk_first + slot, slot, std::false_type {});
-        }
-        else {
-            u32 const stop = steps - chunk_first < chunk_steps ? steps - chunk_first : chunk_steps;
-#pragma unroll 1
-            for (u32 slot = 0; slot < stop; ++slot) step(chunk_first + slot, slot, std::true_type {});
-        }
+        if (first_band) run_chunk(chunk_first, std::true_type {});
+        else run_chunk(chunk_first, std::false_type {});
     }
 
     // ---- the pair's score
