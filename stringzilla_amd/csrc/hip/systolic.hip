@@ -338,7 +338,10 @@ __global__ __launch_bounds__(64 * systolic_waves_k) void systolic_scores_kernel(
                 abandoned = true;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // Parked cells and progress words are all agent-scope (sc1) accesses, coherent by themselves: nothing has to be
+        // invalidated here (an agent-scope acquire would `buffer_inv sc1` the XCD's L2 under everybody's feet every 16
+        // steps).  The loads below are issued after the counter has been SEEN, which is all the ordering they need.
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (lane < chunk_steps) {
 #pragma unroll
             for (u32 j = 0; j < K; ++j) {
@@ -457,7 +460,10 @@ __global__ __launch_bounds__(64 * systolic_waves_k) void systolic_scores_kernel(
             u32 const parked_steps = t - 62;
             if ((parked_steps % chunk_steps == 0 || t + 1 == steps) && lane == 63) {
                 u32 const parked_count = K * parked_steps < n ? K * parked_steps : n;
-                __hip_atomic_store(progress_out, tag | parked_count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                // wait for the parked cells (sc1 stores: acknowledged at the device's coherence point) - no L2 write-back
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // compiler ordering
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every parked store of this lane has been acknowledged
+                __hip_atomic_store(progress_out, tag | parked_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     };
