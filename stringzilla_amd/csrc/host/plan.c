@@ -130,18 +130,25 @@ double szs_plan_estimate(unsigned bit_parallel_limit, int affine, int uniform, i
         bands_total += query_lengths[i] ? (query_lengths[i] + band_rows - 1) / band_rows : 1;
     }
 
-    /* lanes: cells per lane-cycle; the bit-parallel kernels only exist up to `bit_parallel_limit` symbols per query */
+    /* lanes: cells per lane-cycle; the bit-parallel kernels only exist up to `bit_parallel_limit` symbols per query.
+     * A wavefront that has its SIMD to itself issues a dependent instruction every ~8 cycles instead of every ~4
+     * (scripts/wave_latency.hip), so an underfilled device runs each lane at about half its saturated rate. */
     int const bit_parallel = bit_parallel_limit && longest_query <= bit_parallel_limit;
-    double const lane_rate = bit_parallel ? 0.85 : 1.0 / ((affine ? 7.0 : 3.0) * 4.2);
     double const waves_per_query = (candidates_count + 63) / 64;
-    double const lane_waves = queries_count * waves_per_query * scale;
-    double lanes_cycles = query_symbols * mean_candidate * waves_per_query * scale / lane_rate / (lane_waves < simds ? (lane_waves < 1 ? 1 : lane_waves) : simds);
+    double lane_waves = queries_count * waves_per_query * scale;
+    if (lane_waves < 1) lane_waves = 1;
+    double const fill = lane_waves >= 2 * simds ? 1.0 : lane_waves <= simds ? 0.5 : lane_waves / (2 * simds);
+    double const lane_rate = (bit_parallel ? 0.85 : 1.0 / ((affine ? 7.0 : 3.0) * 4.2)) * fill;
+    double lanes_cycles = query_symbols * mean_candidate * waves_per_query * scale / lane_rate / (lane_waves < simds ? lane_waves : simds);
     double const largest_pair = (double)longest_query * longest_candidate / lane_rate;
     if (largest_pair > lanes_cycles) lanes_cycles = largest_pair;
 
-    double const rows_per_lane = band_rows / 64.0, columns_per_step = 4.0; /* hip/systolic.hip: R x K cells per lane-step */
-    double const ops_per_cell = (affine ? 7.0 : 3.0) + (uniform ? 2.0 : 0.0);
-    double const step_cycles = ops_per_cell * rows_per_lane * columns_per_step * 4.2 + 80.0;
+    /* systolic: measured on MI355X (profiles/r01/shapes_v6.jsonl): a wavefront-step of 64 lanes x 8 rows x 4 columns
+     * takes ~1400 cycles with linear gaps and ~2700 with affine gaps, class-table and uniform costs alike, whether the
+     * wavefront is alone on its SIMD or shares it (LDS holds two profiles per SIMD). */
+    double const columns_per_step = 4.0;
+    double const step_cycles = affine ? 2700.0 : 1400.0;
+    (void)uniform;
     double tickets = bands_total * candidates_count * scale;
     if (tickets < 1) tickets = 1;
     double systolic_cycles = tickets * (mean_candidate / columns_per_step + 63.0) * step_cycles / (tickets < simds ? tickets : simds);
@@ -153,7 +160,7 @@ double szs_plan_estimate(unsigned bit_parallel_limit, int affine, int uniform, i
     char const *forced = getenv("SZS_ROCM_TIER"); /* testing aid: lanes | systolic */
     if (forced && forced[0] == 'l') return lanes_cycles;
     if (forced && forced[0] == 's') return *tier = SZS_TIER_SYSTOLIC, systolic_cycles;
-    if (!band_rows || systolic_cycles >= 0.7 * lanes_cycles) return lanes_cycles; /* ties go to the simpler tier */
+    if (!band_rows || systolic_cycles >= 0.8 * lanes_cycles) return lanes_cycles; /* ties go to the simpler tier */
     *tier = SZS_TIER_SYSTOLIC;
     return systolic_cycles;
 }
