@@ -140,6 +140,68 @@ __device__ __forceinline__ void systolic_advance(systolic_column_t<affine_> &col
 }
 
 /**
+ *  One lane, K = 4 consecutive columns, interleaved: iteration i scores row i of the first column, row i - 1 of the second,
+ *  ... - four cells on one anti-diagonal, none depending on another - so a wavefront alone on its SIMD overlaps the latency
+ *  of one column's chain with the work of the other three (scripts/wave_latency.hip: 8.1 cycles per dependent instruction
+ *  against 4.6 with four chains in flight).  Same recurrences, same in-place column state as `systolic_advance` called
+ *  K times: column j + 1 reads row r only after column j has written it, and keeps its own diagonal like the sequential form.
+ *  Every row counts for `best` (the caller takes the sequential form for the one band with padded rows).
+ *  `cost_of(j, r)`: substitution cost of row r against the symbol of column j.
+ */
+template <bool local_, bool affine_, bool saturating_, typename cost_of_t>
+__device__ __forceinline__ void systolic_advance_interleaved(systolic_column_t<affine_> &column, cost_of_t cost_of,
+                                                             i32 const (&above_h)[systolic_columns_k],
+                                                             i32 const (&above_down)[systolic_columns_k], i32 &diagonal,
+                                                             i32 gap_open, i32 gap_extend,
+                                                             i32 (&bottom_h)[systolic_columns_k],
+                                                             i32 (&bottom_down)[affine_ ? systolic_columns_k : 1], i32 &best) {
+    constexpr int rows = systolic_rows_k, columns = (int)systolic_columns_k;
+    i32 diag[columns], above_gapped[columns], down_extended[columns], down[columns];
+#pragma unroll
+    for (int j = 0; j < columns; ++j) {
+        diag[j] = j == 0 ? diagonal : above_h[j ? j - 1 : 0];
+        above_gapped[j] = systolic_gapped<saturating_>(above_h[j], gap_open);
+        down_extended[j] = affine_ ? systolic_gapped<saturating_>(above_down[j], gap_extend) : 0;
+        down[j] = 0;
+    }
+    diagonal = above_h[columns - 1];
+#pragma unroll
+    for (int i = 0; i < rows + columns - 1; ++i) {
+        i32 fresh[columns];
+#pragma unroll
+        for (int j = 0; j < columns; ++j) {
+            fresh[j] = 0; // local scores are >= 0: a neutral element for the running maximum
+            int const r = i - j;
+            if (r < 0 || r >= rows) continue;
+            i32 substituted = diag[j] + cost_of(j, r);
+            if constexpr (local_ && !saturating_) substituted = smax2(substituted, 0);
+            diag[j] = column.h[r];
+            i32 cell;
+            if constexpr (affine_) {
+                i32 const across = smax2(column.h_gapped[r], column.across_extended[r]);
+                down[j] = smax2(above_gapped[j], down_extended[j]);
+                cell = smax3(down[j], across, substituted);
+                column.across_extended[r] = systolic_gapped<saturating_>(across, gap_extend);
+                down_extended[j] = systolic_gapped<saturating_>(down[j], gap_extend);
+            }
+            else { cell = smax3(above_gapped[j], column.h_gapped[r], substituted); }
+            column.h[r] = cell;
+            above_gapped[j] = systolic_gapped<saturating_>(cell, gap_open);
+            column.h_gapped[r] = above_gapped[j];
+            fresh[j] = cell;
+            if (r == rows - 1) {
+                bottom_h[j] = cell;
+                if constexpr (affine_) bottom_down[affine_ ? j : 0] = down[j];
+            }
+        }
+        if constexpr (local_) {
+            best = smax3(best, fresh[0], fresh[1]);
+            best = smax3(best, fresh[2], fresh[3]);
+        }
+    }
+}
+
+/**
  *  @tparam local_       Smith-Waterman instead of a global alignment.
  *  @tparam affine_      Gotoh's three tracks instead of one.
  *  @tparam uniform_     (match, mismatch) costs on raw symbols - Levenshtein engines, maximising negated costs - instead
@@ -355,6 +417,7 @@ __global__ __launch_bounds__(64 * systolic_waves_k) void systolic_scores_kernel(
     };
     if (!first_band) preload_above(0);
     u32 const column_steps = (n + K - 1) / K; // steps a lane needs for the whole text
+    bool const every_row_counts = !last_band || m - band_first >= systolic_band_rows_k; // no lane of this band holds padded rows
     u32 const steps = column_steps + 63;      // lane l is busy during steps [l, l + column_steps)
 
     // The symbol pipeline runs ONE STEP AHEAD of the score pipeline: `symbols_ahead` of lane l holds the symbols of the
@@ -427,23 +490,46 @@ __global__ __launch_bounds__(64 * systolic_waves_k) void systolic_scores_kernel(
         u32 const my_step = t - lane; // wraps for lanes that have not started yet
         bool const busy = is_predicated ? my_step < column_steps : true;
         if (busy) {
-#pragma unroll
-            for (u32 j = 0; j < K; ++j) {
-                bool const inside = is_predicated ? K * my_step + j < n : true; // the last step may be ragged
-                if (inside) {
+            bool interleaved = false;
+            if constexpr (!is_predicated) {
+                if (!local_ || every_row_counts) { // K whole columns: the interleaved form
+                    interleaved = true;
                     if constexpr (uniform_) {
-                        u32 const symbol = symbol_of(symbols, j);
-                        auto cost_of = [&](int r) -> i32 { return query_symbols[r] == symbol ? uniform_match : uniform_mismatch; };
-                        systolic_advance<local_, affine_, saturating_>(column, cost_of, above_h[j], above_down[j], diagonal,
-                                                                       gap_open, gap_extend, down_out, best, my_rows);
+                        u32 step_symbol[K];
+#pragma unroll
+                        for (u32 j = 0; j < K; ++j) step_symbol[j] = symbol_of(symbols, j);
+                        auto cost_of = [&](int j, int r) -> i32 {
+                            return query_symbols[r] == step_symbol[j] ? uniform_match : uniform_mismatch;
+                        };
+                        systolic_advance_interleaved<local_, affine_, saturating_>(column, cost_of, above_h, above_down, diagonal,
+                                                                                   gap_open, gap_extend, bottom_h, bottom_down, best);
                     }
                     else {
-                        auto cost_of = [&](int r) -> i32 { return (i32)(int8_t)(packed[j][r / 4] >> (8 * (r % 4))); };
-                        systolic_advance<local_, affine_, saturating_>(column, cost_of, above_h[j], above_down[j], diagonal,
-                                                                       gap_open, gap_extend, down_out, best, my_rows);
+                        auto cost_of = [&](int j, int r) -> i32 { return (i32)(int8_t)(packed[j][r / 4] >> (8 * (r % 4))); };
+                        systolic_advance_interleaved<local_, affine_, saturating_>(column, cost_of, above_h, above_down, diagonal,
+                                                                                   gap_open, gap_extend, bottom_h, bottom_down, best);
                     }
-                    bottom_h[j] = column.h[rows - 1];
-                    if constexpr (affine_) bottom_down[j] = down_out;
+                }
+            }
+            if (!interleaved) {
+#pragma unroll
+                for (u32 j = 0; j < K; ++j) {
+                    bool const inside = is_predicated ? K * my_step + j < n : true; // the last step may be ragged
+                    if (inside) {
+                        if constexpr (uniform_) {
+                            u32 const symbol = symbol_of(symbols, j);
+                            auto cost_of = [&](int r) -> i32 { return query_symbols[r] == symbol ? uniform_match : uniform_mismatch; };
+                            systolic_advance<local_, affine_, saturating_>(column, cost_of, above_h[j], above_down[j], diagonal,
+                                                                           gap_open, gap_extend, down_out, best, my_rows);
+                        }
+                        else {
+                            auto cost_of = [&](int r) -> i32 { return (i32)(int8_t)(packed[j][r / 4] >> (8 * (r % 4))); };
+                            systolic_advance<local_, affine_, saturating_>(column, cost_of, above_h[j], above_down[j], diagonal,
+                                                                           gap_open, gap_extend, down_out, best, my_rows);
+                        }
+                        bottom_h[j] = column.h[rows - 1];
+                        if constexpr (affine_) bottom_down[j] = down_out;
+                    }
                 }
             }
             if (!last_band && lane == 63) { // the band's bottom row under this step's columns, 1-based DP column
