@@ -9,28 +9,40 @@
  *
  *  weighted.hip gives every (query, candidate) pair ONE lane.  That is the right shape for a million pairs and the wrong
  *  one for a 1 x 1 call of two 100 KB strings, or for 16 x 16 reads of 4 KB: a handful of lanes would walk the whole
- *  matrix alone.  Here a pair is spread over wavefronts instead, as a two-level systolic array:
+ *  matrix alone (measured: 19 GCUPS on 16 x 16 x 4 KB; this file: 1.9 TCUPS).  Here a pair is spread over wavefronts
+ *  instead, as a two-level systolic array:
  *
  *  - A BAND is 64 x R consecutive query rows (R = 8: 512 rows) and belongs to one wavefront; lane l owns rows
  *    [R l, R l + R) of the band, its column of R cells (plus gap tracks) lives in VGPRs, exactly like a strip of
- *    weighted.hip.
- *  - The lanes of a wavefront are skewed by one column: at step t lane l scores column t - l.  What lane l needs from
- *    above - H (and the vertical-gap track) of lane l-1's bottom row at the same column - was produced by lane l-1 one
- *    step earlier and arrives through ONE `v_mov_b32_dpp wave_shr:1`; the candidate symbol travels down the lanes the
- *    same way.  No LDS, no barrier, no shuffle through memory: per step a lane exchanges 2 (linear) or 3 (affine)
- *    registers and scores R cells.
- *  - Lane 0's inputs (the candidate symbol, the row above the band) are wave-uniform per step: each lane preloads one
- *    column of the next 64 (coalesced), and `v_readlane_b32` picks the step's value into an SGPR.
- *  - Bands of one pair are chained THROUGH MEMORY: lane 63 parks the band's bottom row [column] in the workspace and
- *    publishes a progress counter (release) every 64 columns; the wavefront of the next band spins on that counter
- *    (acquire) before it preloads a chunk.  Bands are handed out through one atomic ticket counter in (pair, band)
- *    order, so the band a wavefront waits for always holds an EARLIER ticket, i.e. is already running or finished:
- *    forward progress without a co-residency requirement, whatever the grid size.  All bands of a long pair are thus
- *    in flight at once, each trailing its predecessor by ~128 columns.
+ *    weighted.hip.  A lane scores K = 4 consecutive columns per step (R x K = 32 cells between two exchanges; in the
+ *    steady state the four column recurrences are interleaved along the anti-diagonal, so they overlap).
+ *  - The lanes of a wavefront are skewed by one step: at step t lane l scores columns K (t - l) ... + K - 1.  What lane l
+ *    needs from above - H (and the vertical-gap track) of lane l-1's bottom row under the same columns - was produced by
+ *    lane l-1 one step earlier and arrives through `v_mov_b32_dpp wave_shr:1`; the candidate symbols (K class ids or
+ *    bytes packed in one dword) travel down the lanes the same way, one step AHEAD of the scores, so that their cost rows
+ *    are fetched from LDS a whole step before they are needed.  No barrier, no shuffle through memory.
+ *  - Lane 0's inputs (the symbols, the row above the band) are wave-uniform per step: lanes 0..15 preload a chunk of 16
+ *    steps (64 columns) one chunk in advance, and `v_readlane_b32` picks the step's values into SGPRs.
+ *  - Bands of one pair are chained THROUGH MEMORY: lane 63 parks the band's bottom row [column] and publishes a progress
+ *    word every 16 steps; the wavefront of the next band polls that word before it preloads a chunk.  Parked cells and
+ *    progress words are agent-scope (`sc1`) accesses - coherent at the device level by themselves - so the hand-over
+ *    needs no L2 write-back and no invalidate, only "stores acknowledged before the word is published".
+ *  - ONE TICKET PER WAVEFRONT, drawn from an atomic counter in (pair, band) order when the wavefront starts running: the
+ *    band a wavefront waits for always holds an EARLIER ticket, i.e. is running or finished - forward progress without
+ *    any co-residency requirement.  All bands of a long pair are thus in flight at once, each trailing its predecessor
+ *    by ~95 steps (63 of lane skew + 2 chunks of hand-over).
+ *  - The control words (ticket counter, progress, local-alignment best / done) are tagged with the launch's EPOCH in
+ *    their high half: a word of an older launch compares below everything of this one, so nothing is ever cleared
+ *    between launches and no launch depends on a fill having landed.  A wait that cannot be satisfied (a broken
+ *    invariant, never observed) gives up after a fraction of a second and flags the call instead of hanging the device.
  *  - Substitution costs: class-table engines build a per-band profile in LDS, profile[class][lane] = the R int8 costs
- *    of the lane's rows against that class (one conflict-free ds_read_b64 per step; the candidate is mapped to classes
- *    when the chunk is preloaded).  Uniform-cost engines (weighted / codepoint Levenshtein) compare the symbol with the
- *    lane's R query symbols held in registers - bytes and UTF-32 runes alike.
+ *    of the lane's rows against that class (conflict-free ds_read_b64; the candidate is mapped to classes when the chunk
+ *    is preloaded).  Uniform-cost engines (weighted / codepoint Levenshtein) compare the symbol with the lane's R query
+ *    symbols held in registers - bytes and UTF-32 runes alike.
+ *
+ *  What bounds it (profiles/r01/wave_latency.json, shapes_v6.jsonl): a wavefront that has its SIMD to itself issues a
+ *  dependent instruction every ~8 cycles, a step is ~170 instructions = ~1400 cycles (2700 with affine gaps), and a pair
+ *  needs len(candidate) / K + 63 + 95 (bands - 1) steps end to end.  R = 8, K = 4 sits at the minimum of that product.
  *
  *  Borders, the finite affine "discard" seeds and the clamp of local alignment follow weighted.hip (and through it
  *  serial.hpp:821-823,1045-1056,1195-1201,957-965) to the letter; tests pin both tiers against the same oracle.
