@@ -58,7 +58,7 @@ static sz_status_t prefetch_offsets(szs_engine_s *engine, hipStream_t stream, sz
     size_t const offset_size = input->kind == szs_input_u32tape_k ? 4 : 8;
     void *landing = (char *)engine->pinned_staging.pointer + staging_offset;
     hipError_t const error = hipMemcpyAsync(landing, input->offsets, (input->count + 1) * offset_size,
-                                            hipMemcpyDefault, stream);
+                                            hipMemcpyDeviceToHost, stream);
     if (error != hipSuccess) return szs_report_hip(error, error_message);
     *host_offsets = landing, *pending = 1;
     return sz_success_k;
