@@ -8,6 +8,7 @@
  */
 #include "szs_internal.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -229,6 +230,16 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
                              szs_input_t const *candidates, void *results, size_t results_row_stride,
                              char const **error_message) {
     double const call_started = now_milliseconds();
+    static int trace = -1; /* SZS_ROCM_TRACE=1: per-phase host times of every call on stderr (a measuring aid) */
+    if (trace < 0) trace = getenv("SZS_ROCM_TRACE") != NULL;
+    double phase_started = call_started, phases[6] = {0, 0, 0, 0, 0, 0};
+#define SZS_PHASE(INDEX)                                                                                               \
+    do {                                                                                                               \
+        if (trace) {                                                                                                   \
+            double const now = now_milliseconds();                                                                     \
+            phases[INDEX] += now - phase_started, phase_started = now;                                                 \
+        }                                                                                                              \
+    } while (0)
     if (!engine || engine->magic != SZS_ENGINE_MAGIC)
         return szs_report(sz_status_unknown_k, error_message, "Engine must be initialized");
     if (!queries) return szs_report(sz_status_unknown_k, error_message, "Queries must not be null");
@@ -300,6 +311,7 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
         if (error != hipSuccess) return szs_report_hip(error, error_message);
     }
 
+    SZS_PHASE(0); /* checks, buffers, offsets download + its synchronisation */
     uint64_t query_bytes = 0, candidate_bytes = 0;
     status = gather_strings(queries, q_offsets, q_addresses, q_lengths, &query_bytes, error_message);
     if (status != sz_success_k) return status;
@@ -359,6 +371,7 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
     uint64_t const reach = (span + (engine->is_linear ? 1 : 3)) * (engine->magnitude ? engine->magnitude : 1);
     if (reach >= 0x7FFFFFF0ull) return szs_report(sz_overflow_risk_k, error_message, NULL);
 
+    SZS_PHASE(1); /* gathering strings, transcoding, orientation, planning */
     szs_string_ref_t *device_query_refs = (szs_string_ref_t *)engine->device_refs.pointer;
     szs_string_ref_t *device_candidate_refs = device_query_refs + kq_count;
     hipError_t error = hipMemcpyAsync(device_query_refs, host_query_refs, refs_bytes, hipMemcpyHostToDevice, stream);
@@ -440,6 +453,7 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
         if (status != sz_success_k) return status;
     }
 
+    SZS_PHASE(2); /* ref upload enqueued, result placement, workspaces */
     /* ---- launches, bracketed by the engine's event pair on the scope's stream ---- */
     error = hipEventRecord(engine->event_start, stream);
     if (error != hipSuccess) return szs_report_hip(error, error_message);
@@ -487,7 +501,9 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
         error = hipMemcpy2DAsync(results, results_row_stride * sizeof(uint64_t), device_results,
                                  device_stride * sizeof(uint64_t), (size_t)c_count * sizeof(uint64_t), q_count,
                                  hipMemcpyDefault, stream);
+    SZS_PHASE(3); /* launches enqueued */
     if (error == hipSuccess) error = hipStreamSynchronize(stream); /* the call is synchronous, like the reference's */
+    SZS_PHASE(4); /* waiting for the device */
     if (error != hipSuccess) return szs_report_hip(error, error_message);
     if (tier == SZS_TIER_SYSTOLIC && *stall_flag == (((uint64_t)engine->systolic_epoch << 32) | 1))
         return szs_report(sz_status_unknown_k, error_message, "Systolic pipeline stalled");
@@ -514,5 +530,11 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
     profile->transposed = (uint32_t)transposed;
     profile->longest_query = q_longest, profile->longest_candidate = c_longest;
     profile->host_milliseconds = now_milliseconds() - call_started;
+    SZS_PHASE(5);
+    if (trace)
+        fprintf(stderr, "szs call: %.1f us = offsets %.1f + plan %.1f + upload %.1f + launch %.1f + wait %.1f + wrap %.1f | kernel %.1f us\n",
+                profile->host_milliseconds * 1e3, phases[0] * 1e3, phases[1] * 1e3, phases[2] * 1e3, phases[3] * 1e3, phases[4] * 1e3,
+                phases[5] * 1e3, kernel_ms * 1e3);
+#undef SZS_PHASE
     return szs_report(sz_success_k, error_message, NULL);
 }
