@@ -21,3 +21,11 @@ run sw 8 8 3072 5120 2
 run nw 128 128 800 1200 2
 run lev 1 1 90000 110000 2
 run nw 1 1 90000 110000 2
+export SZS_ROCM_TIER=chain
+run lev 1 1 300 500 2
+run lev 5 7 0 40 2
+run lev 64 64 300 500 2
+run lev 3 4 2040 2056 2
+run lev 16 16 3072 5120 3
+run lev 128 128 800 1200 2
+run lev 1 1 90000 110000 2

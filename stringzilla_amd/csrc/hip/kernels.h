@@ -122,6 +122,20 @@ int szs_hip_systolic_scores(int objective, int affine, szs_cost_model_t const *m
                             uint64_t results_row_stride, int symmetric, void *control, void *parked, uint32_t epoch,
                             void *stream);
 
+/**
+ *  Unit-cost byte-level Levenshtein for few, long pairs (hip/myers_chain.hip): the bit-parallel recurrence on the band
+ *  chain of the systolic tier - 64 lanes x 32 rows per band, 8 columns per step, one dword of horizontal deltas handed
+ *  from lane to lane and from band to band.  Any query length.  Control block and epoch exactly as for
+ *  szs_hip_systolic_scores (the two kernels may share one control block); `parked` holds one dword per step and pair.
+ */
+#define SZS_MYERS_CHAIN_BAND_ROWS 2048u
+int szs_hip_myers_chain_workspace_bytes(uint32_t queries_count, uint32_t candidates_count, uint32_t longest_query,
+                                        uint32_t longest_candidate, size_t *control_bytes, size_t *parked_bytes);
+int szs_hip_myers_chain(szs_string_ref_t const *queries, uint32_t queries_count, szs_string_ref_t const *candidates,
+                        uint32_t candidates_count, uint32_t longest_query, uint32_t longest_candidate, uint64_t *results,
+                        uint64_t results_row_stride, int layout_flags, void *control, void *parked, uint32_t epoch,
+                        void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -349,8 +349,10 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
     for (uint32_t i = 0; i < q_count; ++i) q_longest = q_lengths[i] > q_longest ? q_lengths[i] : q_longest;
     for (uint32_t i = 0; i < c_count; ++i) c_longest = c_lengths[i] > c_longest ? c_lengths[i] : c_longest;
     int tier = SZS_TIER_LANES, transposed = 0;
-    szs_plan_orient(myers_words * 32, !engine->is_linear, !maximise, symmetric, q_lengths, q_count, c_lengths, c_count,
-                    szs_hip_systolic_band_rows(), &tier, &transposed);
+    szs_plan_orient(myers_words * 32, use_myers && !runes, !engine->is_linear, !maximise, symmetric, q_lengths, q_count,
+                    c_lengths, c_count, szs_hip_systolic_band_rows(), &tier, &transposed);
+    char const *const forced_tier = getenv("SZS_ROCM_TIER"); /* `systolic` on a unit-cost engine means the DP recurrences */
+    if (tier == SZS_TIER_MYERS_CHAIN && forced_tier && forced_tier[0] == 's') tier = SZS_TIER_SYSTOLIC;
     /* kernel roles */
     uint64_t *const kq_addresses = transposed ? c_addresses : q_addresses, *const kc_addresses = transposed ? q_addresses : c_addresses;
     uint32_t *const kq_lengths = transposed ? c_lengths : q_lengths, *const kc_lengths = transposed ? q_lengths : c_lengths;
@@ -414,7 +416,13 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
                                            &systolic_control_bytes, &systolic_parked_bytes) ||
          systolic_control_bytes + systolic_parked_bytes > ((size_t)32 << 30)))
         tier = SZS_TIER_LANES;
-    if (tier == SZS_TIER_SYSTOLIC) {
+    if (tier == SZS_TIER_MYERS_CHAIN &&
+        (!szs_hip_myers_chain_workspace_bytes(kq_count, kc_count, plan.longest_query, plan.longest_candidate,
+                                              &systolic_control_bytes, &systolic_parked_bytes) ||
+         systolic_control_bytes + systolic_parked_bytes > ((size_t)32 << 30)))
+        tier = SZS_TIER_LANES;
+    int const chained = tier == SZS_TIER_SYSTOLIC || tier == SZS_TIER_MYERS_CHAIN;
+    if (chained) {
         /* The control block is zeroed when it is (re)allocated and never again: its words carry the epoch of the launch
          * that wrote them, so a launch neither needs nor waits for a fill (hip/kernels.h). */
         int const fresh = !engine->device_systolic.pointer || engine->device_systolic.capacity < systolic_control_bytes ||
@@ -432,7 +440,11 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
 
     /* Weighted kernels need the cost model and a strip-boundary workspace on the device. */
     int needs_weighted = !use_myers || tier == SZS_TIER_SYSTOLIC;
-    for (unsigned g = 0; g < plan.groups_count; ++g) needs_weighted |= plan.groups[g].variant == 0;
+    if (tier == SZS_TIER_MYERS_CHAIN) { /* no cost model; its parked deltas live in the boundary buffer like the systolic rows */
+        status = szs_buffer_reserve(&engine->device_boundary, szs_memory_device_k, device, systolic_parked_bytes, error_message);
+        if (status != sz_success_k) return status;
+    }
+    for (unsigned g = 0; tier != SZS_TIER_MYERS_CHAIN && g < plan.groups_count; ++g) needs_weighted |= plan.groups[g].variant == 0;
     if (needs_weighted) {
         if (engine->model_uploaded_device != device || engine->model_uploaded_transposed != transposed) {
             status = szs_buffer_reserve(&engine->device_model, szs_memory_device_k, device, sizeof(szs_cost_model_t),
@@ -467,6 +479,14 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
         if (launch_error) return szs_report_hip((hipError_t)launch_error, error_message);
         ++launches;
     }
+    if (tier == SZS_TIER_MYERS_CHAIN) {
+        int const launch_error = szs_hip_myers_chain(device_query_refs, kq_count, device_candidate_refs, kc_count,
+                                                     plan.longest_query, plan.longest_candidate, (uint64_t *)device_results,
+                                                     device_stride, layout, engine->device_systolic.pointer,
+                                                     engine->device_boundary.pointer, engine->systolic_epoch, stream);
+        if (launch_error) return szs_report_hip((hipError_t)launch_error, error_message);
+        ++launches;
+    }
     for (unsigned g = 0; tier == SZS_TIER_LANES && g < plan.groups_count; ++g) {
         szs_plan_group_t const *group = &plan.groups[g];
         int launch_error;
@@ -492,7 +512,7 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
     if (error != hipSuccess) return szs_report_hip(error, error_message);
     uint64_t *const stall_flag = (uint64_t *)((char *)engine->pinned_staging.pointer + refs_bytes); /* offsets area: done with */
     *stall_flag = 0;
-    if (tier == SZS_TIER_SYSTOLIC) {
+    if (chained) {
         error = hipMemcpyAsync(stall_flag, (char *)engine->device_systolic.pointer + 8, sizeof(uint64_t), hipMemcpyDeviceToHost, stream);
         if (error != hipSuccess) return szs_report_hip(error, error_message);
     }
@@ -505,7 +525,7 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
     if (error == hipSuccess) error = hipStreamSynchronize(stream); /* the call is synchronous, like the reference's */
     SZS_PHASE(4); /* waiting for the device */
     if (error != hipSuccess) return szs_report_hip(error, error_message);
-    if (tier == SZS_TIER_SYSTOLIC && *stall_flag == (((uint64_t)engine->systolic_epoch << 32) | 1))
+    if (chained && *stall_flag == (((uint64_t)engine->systolic_epoch << 32) | 1))
         return szs_report(sz_status_unknown_k, error_message, "Systolic pipeline stalled");
 
     float kernel_ms = 0;

@@ -114,10 +114,11 @@ void szs_plan_build(unsigned myers, int symmetric, uint64_t const *query_address
  *               its largest pair (each band trails its predecessor by ~95 steps).
  *  Constants from the measured gfx950 rates (profiles/r01/valu_peak.json): fast VALU ~2.5 cycles, slow ~4.2.
  */
-double szs_plan_estimate(unsigned bit_parallel_limit, int affine, int uniform, int symmetric,
+double szs_plan_estimate(unsigned bit_parallel_limit, int bit_parallel_chain, int affine, int uniform, int symmetric,
                          uint32_t const *query_lengths, uint32_t queries_count, uint32_t candidates_count,
                          uint64_t candidate_symbols, uint32_t longest_query, uint32_t longest_candidate,
                          unsigned band_rows, int *tier) {
+    if (bit_parallel_chain) band_rows = SZS_MYERS_CHAIN_BAND_ROWS; /* hip/myers_chain.hip: 64 lanes x 32 rows x 8 columns */
     *tier = SZS_TIER_LANES;
     if (!queries_count || !candidates_count) return 0;
     double const simds = 1024.0;
@@ -146,8 +147,8 @@ double szs_plan_estimate(unsigned bit_parallel_limit, int affine, int uniform, i
     /* systolic: measured on MI355X (profiles/r01/shapes_v6.jsonl): a wavefront-step of 64 lanes x 8 rows x 4 columns
      * takes ~1400 cycles with linear gaps and ~2700 with affine gaps, class-table and uniform costs alike, whether the
      * wavefront is alone on its SIMD or shares it (LDS holds two profiles per SIMD). */
-    double const columns_per_step = 4.0;
-    double const step_cycles = affine ? 2700.0 : 1400.0;
+    double const columns_per_step = bit_parallel_chain ? 8.0 : 4.0;
+    double const step_cycles = bit_parallel_chain ? 1800.0 : affine ? 2700.0 : 1400.0;
     (void)uniform;
     double tickets = bands_total * candidates_count * scale;
     if (tickets < 1) tickets = 1;
@@ -159,13 +160,14 @@ double szs_plan_estimate(unsigned bit_parallel_limit, int affine, int uniform, i
 
     char const *forced = getenv("SZS_ROCM_TIER"); /* testing aid: lanes | systolic */
     if (forced && forced[0] == 'l') return lanes_cycles;
-    if (forced && forced[0] == 's') return *tier = SZS_TIER_SYSTOLIC, systolic_cycles;
+    int const chained = bit_parallel_chain ? SZS_TIER_MYERS_CHAIN : SZS_TIER_SYSTOLIC;
+    if (forced && (forced[0] == 's' || forced[0] == 'c')) return *tier = chained, systolic_cycles;
     if (!band_rows || systolic_cycles >= 0.8 * lanes_cycles) return lanes_cycles; /* ties go to the simpler tier */
-    *tier = SZS_TIER_SYSTOLIC;
+    *tier = chained;
     return systolic_cycles;
 }
 
-void szs_plan_orient(unsigned bit_parallel_limit, int affine, int uniform, int symmetric, uint32_t const *query_lengths,
+void szs_plan_orient(unsigned bit_parallel_limit, int bit_parallel_chain, int affine, int uniform, int symmetric, uint32_t const *query_lengths,
                      uint32_t queries_count, uint32_t const *candidate_lengths, uint32_t candidates_count,
                      unsigned band_rows, int *tier, int *transposed) {
     uint64_t q_symbols = 0, c_symbols = 0;
@@ -175,11 +177,11 @@ void szs_plan_orient(unsigned bit_parallel_limit, int affine, int uniform, int s
     for (uint32_t i = 0; i < candidates_count; ++i)
         c_symbols += candidate_lengths[i], c_longest = candidate_lengths[i] > c_longest ? candidate_lengths[i] : c_longest;
     int swapped_tier = SZS_TIER_LANES;
-    double const cycles = szs_plan_estimate(bit_parallel_limit, affine, uniform, symmetric, query_lengths, queries_count,
+    double const cycles = szs_plan_estimate(bit_parallel_limit, bit_parallel_chain, affine, uniform, symmetric, query_lengths, queries_count,
                                             candidates_count, c_symbols, q_longest, c_longest, band_rows, tier);
     *transposed = 0;
     if (symmetric) return; /* nothing to swap */
-    double const swapped_cycles = szs_plan_estimate(bit_parallel_limit, affine, uniform, 0, candidate_lengths,
+    double const swapped_cycles = szs_plan_estimate(bit_parallel_limit, bit_parallel_chain, affine, uniform, 0, candidate_lengths,
                                                     candidates_count, queries_count, q_symbols, c_longest, q_longest,
                                                     band_rows, &swapped_tier);
     char const *forced = getenv("SZS_ROCM_SWAP"); /* testing aid: 0 | 1 */
@@ -225,7 +227,7 @@ sz_status_t szs_rocm_orientation_probe(int unit_cost, int affine, int uniform, i
                                        sz_u32_t const *candidate_lengths, sz_size_t candidates_count, int *tier,
                                        int *transposed) {
     if (queries_count > 0xFFFFFFFFu || candidates_count > 0xFFFFFFFFu || !tier || !transposed) return sz_overflow_risk_k;
-    szs_plan_orient(unit_cost ? SZS_MYERS_MAX_WORDS * 32 : 0, affine, uniform, symmetric, query_lengths,
+    szs_plan_orient(unit_cost ? SZS_MYERS_MAX_WORDS * 32 : 0, unit_cost, affine, uniform, symmetric, query_lengths,
                     (uint32_t)queries_count, symmetric ? query_lengths : candidate_lengths,
                     (uint32_t)(symmetric ? queries_count : candidates_count), SZS_SYSTOLIC_BAND_ROWS, tier, transposed);
     return sz_success_k;

@@ -146,6 +146,7 @@ void szs_plan_build(unsigned myers, int symmetric, uint64_t const *query_address
 
 #define SZS_TIER_LANES 0    /* one pair per lane: lev_myers.hip, weighted.hip */
 #define SZS_TIER_SYSTOLIC 1 /* one pair per chain of wavefronts: systolic.hip */
+#define SZS_TIER_MYERS_CHAIN 2 /* the same chain with the bit-parallel recurrence: myers_chain.hip (unit-cost bytes) */
 
 /**
  *  Estimated SIMD cycles of a call in its better tier (plan.c), for one orientation of the cross-product: the caller
@@ -154,7 +155,7 @@ void szs_plan_build(unsigned myers, int symmetric, uint64_t const *query_address
  *  `bit_parallel_limit`: longest query (symbols) the Myers kernels take, 0 for weighted engines; `uniform`:
  *  Levenshtein-family costs.  `SZS_ROCM_TIER=lanes|systolic` forces the tier (testing aid).
  */
-double szs_plan_estimate(unsigned bit_parallel_limit, int affine, int uniform, int symmetric,
+double szs_plan_estimate(unsigned bit_parallel_limit, int bit_parallel_chain, int affine, int uniform, int symmetric,
                          uint32_t const *query_lengths, uint32_t queries_count, uint32_t candidates_count,
                          uint64_t candidate_symbols, uint32_t longest_query, uint32_t longest_candidate,
                          unsigned band_rows, int *tier);
@@ -163,7 +164,7 @@ double szs_plan_estimate(unsigned bit_parallel_limit, int affine, int uniform, i
  *  The decision itself: evaluates szs_plan_estimate for both orientations and reports the tier to run and whether the
  *  sides are swapped (never for symmetric calls).  `SZS_ROCM_SWAP=0|1` forces the orientation (testing aid).
  */
-void szs_plan_orient(unsigned bit_parallel_limit, int affine, int uniform, int symmetric, uint32_t const *query_lengths,
+void szs_plan_orient(unsigned bit_parallel_limit, int bit_parallel_chain, int affine, int uniform, int symmetric, uint32_t const *query_lengths,
                      uint32_t queries_count, uint32_t const *candidate_lengths, uint32_t candidates_count,
                      unsigned band_rows, int *tier, int *transposed);
 

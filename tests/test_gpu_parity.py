@@ -565,10 +565,29 @@ def test_systolic_long_pairs_pick_the_tier_themselves(gpu, oracle):
         assert np.array_equal(got, getattr(oracle, kind)(queries, candidates, *table, *gaps)), (kind, gaps)
     unit = szs.LevenshteinDistances(capabilities=gpu)
     assert np.array_equal(unit(queries, candidates, device=gpu), oracle.levenshtein(queries, candidates))
-    assert unit.last_call_profile().tier == 1
+    assert unit.last_call_profile().tier == 2  # unit costs: the bit-parallel band chain (hip/myers_chain.hip)
     load = workloads.config(2, scale=1 / 4)
     unit(load.queries, load.candidates, device=gpu)
     assert unit.last_call_profile().tier == 0
+
+
+def test_myers_chain_fuzz(gpu, oracle):
+    """hip/myers_chain.hip: band edges (2048 rows per wavefront), word edges (32 rows per lane), the 8-column steps and
+    128-column hand-over chunks, empties, bytes >= 0x80, ragged batches, symmetric calls, swapped sides."""
+    rng = random.Random(2048)
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+    with forced_tier("chain"):
+        for alphabet, lo, hi, q_count, c_count in [(b"ABC", 0, 70, 9, 9), (bytes(range(256)), 25, 40, 5, 70), (b"ACGT", 120, 136, 7, 5),
+                                                   (b"AB", 2040, 2056, 3, 4), (b"ACGT", 4090, 4100, 2, 3), (b"ACGT", 1, 6200, 6, 6),
+                                                   (b"ACGT", 500, 530, 64, 3)]:
+            queries, candidates = _rand(rng, q_count, lo, hi, alphabet), _rand(rng, c_count, lo, hi, alphabet)
+            assert np.array_equal(engine(queries, candidates, device=gpu), oracle.levenshtein(queries, candidates)), (lo, hi)
+            assert engine.last_call_profile().tier == 2
+            assert np.array_equal(engine(queries, device=gpu), oracle.levenshtein(queries, None)), (lo, hi, "symmetric")
+        with forced_swap("1"):
+            queries, candidates = _rand(rng, 3, 100, 2500, b"ACGT"), _rand(rng, 5, 100, 5000, b"ACGT")
+            assert np.array_equal(engine(queries, candidates, device=gpu), oracle.levenshtein(queries, candidates))
+            assert engine.last_call_profile().transposed == 1
 
 
 def test_systolic_single_very_long_pair(gpu, oracle):

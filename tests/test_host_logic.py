@@ -135,14 +135,14 @@ def _orientation(unit, affine, uniform, symmetric, q, c):
 def test_planner_picks_tier_and_orientation():
     """The cycle model of csrc/host/plan.c: BASELINE.json's big cross-products stay one-pair-per-lane, a handful of long
     pairs go to the systolic tier, and a tall-and-thin cross-product is turned on its side."""
-    lanes, systolic = 0, 1
+    lanes, systolic, chain = 0, 1, 2  # chain: the bit-parallel band chain, the chained tier of unit-cost byte engines
     assert _orientation(1, 0, 1, 0, [128] * 1024, [128] * 1024) == (lanes, 0)        # config 2
     assert _orientation(0, 0, 0, 0, [512] * 1024, [512] * 1024) == (lanes, 0)        # config 3
     assert _orientation(0, 1, 0, 0, [4096] * 512, [4096] * 512) == (lanes, 0)        # config 4
     assert _orientation(0, 0, 0, 0, [100000], [100000]) == (systolic, 0)             # one very long pair
-    assert _orientation(1, 0, 1, 0, [100000], [100000]) == (systolic, 0)             # ... also for unit costs
+    assert _orientation(1, 0, 1, 0, [100000], [100000]) == (chain, 0)                # ... unit costs: bit-parallel chain
     assert _orientation(0, 1, 0, 0, [4096] * 16, [4096] * 16) == (systolic, 0)       # 256 reads: 16 lanes would be busy
-    assert _orientation(1, 0, 1, 0, [2000] * 4, [2000] * 4)[0] == systolic
+    assert _orientation(1, 0, 1, 0, [2000] * 4, [2000] * 4)[0] == chain
     assert _orientation(0, 0, 0, 0, [64] * 64, [64] * 64)[0] == lanes                # tiny strings: nothing to spread
     assert _orientation(1, 0, 1, 0, [128] * 4096, [128]) == (lanes, 1)               # 4096 x 1: candidates on workgroups
     assert _orientation(1, 0, 1, 0, [128], [128] * 4096) == (lanes, 0)               # 1 x 4096 already is the good way
