@@ -12,6 +12,10 @@
  *    - the *_icelake_t and *_haswell_t siblings                      serial.hpp:696-725 (bodies in icelake.hpp / haswell.hpp)
  *    - error_costs_32x32_t::blosum62() / nuc44()                     serial.hpp:221-287
  *
+ *    - floating_rolling_hashers<sz_cap_serial_k, 64> and basic_rolling_hashers<floating_rolling_hasher<f64_t>, u32_t>
+ *                                                                    include/stringzillas/fingerprints/serial.hpp:1119,646
+ *      composed exactly as the reference's C shim composes them    c/stringzillas/fingerprints.cuh:49-176
+ *
  *  ForkUnion (the reference's thread pool) is an absent submodule, so rows are sharded over std::thread here,
  *  one engine instance per thread (the reference's engines are not re-entrant: serial.hpp:3694-3745).
  */
@@ -21,6 +25,7 @@
 #include <thread>
 #include <vector>
 
+#include <stringzillas/fingerprints.hpp>
 #include <stringzillas/similarities.hpp>
 
 namespace szs = ashvardanian::stringzillas;
@@ -206,6 +211,49 @@ void szs_ref_substitution_table(int which, uint8_t *byte_to_class, int8_t *class
     szs::error_costs_32x32_t costs = which == 0 ? szs::error_costs_32x32_t::blosum62() : szs::error_costs_32x32_t::nuc44();
     std::memcpy(byte_to_class, costs.byte_to_class, 256);
     std::memcpy(class_costs, costs.class_substitution_costs, 32 * 32);
+}
+
+/**
+ *  MinHash fingerprints + Count-Min counts of `count` texts (u64 tape), through the reference's own serial engines, with
+ *  the same choice of engine the reference's `szs_fingerprints_init` makes (c/stringzillas/fingerprints.cuh:49-176):
+ *  slices of 64 dimensions sharing one window width when `dimensions` is a whole multiple of 64 x widths, else one
+ *  per-dimension hasher with interleaved widths.  Rows are `dimensions` consecutive u32.
+ */
+int szs_ref_fingerprints(size_t dimensions, size_t alphabet_size, size_t const *window_widths, size_t window_widths_count,
+                         uint64_t seed, char const *data, uint64_t const *offsets, size_t count, uint32_t *min_hashes,
+                         uint32_t *min_counts) {
+    constexpr size_t slice = 64;
+    size_t const default_widths[] = {3, 4, 5, 7, 9, 11, 15, 31};
+    if (!window_widths || !window_widths_count) window_widths = default_widths, window_widths_count = 8;
+    if (!alphabet_size) alphabet_size = 256;
+    views_t const texts = views_from_tape(data, offsets, count);
+    size_t const per_width_min = dimensions / window_widths_count;
+    size_t const per_width_max = (dimensions + window_widths_count - 1) / window_widths_count;
+    bool const sliced = per_width_min == per_width_max && per_width_min % slice == 0;
+    using byte_span_t = ashvardanian::stringzilla::span<ashvardanian::stringzilla::byte_t const>;
+    if (sliced) {
+        using hashers_t = szs::floating_rolling_hashers<sz_cap_serial_k, slice>;
+        for (size_t i = 0; i != dimensions / slice; ++i) {
+            hashers_t hashers;
+            if ((int)hashers.try_seed(window_widths[i % window_widths_count], alphabet_size, i * slice, seed) != 0) return -1;
+            for (size_t t = 0; t != count; ++t) {
+                byte_span_t text {reinterpret_cast<ashvardanian::stringzilla::byte_t const *>(texts[t].data()), texts[t].size()};
+                hashers.fingerprint(text, typename hashers_t::min_hashes_span_t {min_hashes + t * dimensions + i * slice},
+                                    typename hashers_t::min_counts_span_t {min_counts + t * dimensions + i * slice});
+            }
+        }
+        return 1;
+    }
+    szs::basic_rolling_hashers<szs::floating_rolling_hasher<double>, uint32_t> hashers;
+    for (size_t d = 0; d != dimensions; ++d)
+        if ((int)hashers.try_extend(window_widths[d % window_widths_count], 1, alphabet_size, seed) != 0) return -1;
+    for (size_t t = 0; t != count; ++t) {
+        byte_span_t text {reinterpret_cast<ashvardanian::stringzilla::byte_t const *>(texts[t].data()), texts[t].size()};
+        ashvardanian::stringzilla::span<uint32_t> hashes {min_hashes + t * dimensions, dimensions};
+        ashvardanian::stringzilla::span<uint32_t> counts {min_counts + t * dimensions, dimensions};
+        if ((int)hashers.try_fingerprint(text, hashes, counts) != 0) return -1;
+    }
+    return 2;
 }
 
 } // extern "C"

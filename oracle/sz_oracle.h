@@ -96,6 +96,18 @@ void szo_nuc44(uint8_t *byte_to_class, int8_t *class_costs);
 /** Worst-case reach of serial.hpp:135-162: ((maximise ? q+c : max(q,c)) + (linear ? 1 : 3)) * max(magnitude, 1). */
 uint64_t szo_worst_case_reach(size_t q_len, size_t c_len, int maximise, int affine, unsigned magnitude);
 
+/* ---- rolling MinHash / Count-Min fingerprints (sz_oracle_fingerprints.c; reference: fingerprints/serial.hpp) ---- */
+
+/** Per-dimension parameters exactly as the reference seeds them; `window_widths` NULL / 0 = its defaults. */
+void szo_fingerprint_parameters(size_t dimensions, size_t const *window_widths, size_t window_widths_count, uint64_t seed,
+                                size_t *widths, double *multipliers, double *modulos, double *inverse_modulos,
+                                double *negative_discarding_multipliers);
+
+/** `min_hashes` / `min_counts`: `count` rows of `dimensions` consecutive u32. */
+void szo_fingerprints_cross(char const *data, uint64_t const *offsets, size_t count, size_t dimensions, size_t alphabet_size,
+                            size_t const *window_widths, size_t window_widths_count, uint64_t seed, uint32_t *min_hashes,
+                            uint32_t *min_counts);
+
 #ifdef __cplusplus
 }
 #endif

@@ -136,6 +136,24 @@ int szs_hip_myers_chain(szs_string_ref_t const *queries, uint32_t queries_count,
                         uint64_t results_row_stride, int layout_flags, void *control, void *parked, uint32_t epoch,
                         void *stream);
 
+/**
+ *  Rolling MinHash / Count-Min fingerprints (hip/fingerprints.hip).  One lane per dimension, one workgroup per 256
+ *  dimensions x one SEGMENT (4096 window positions) of one text; texts of several segments are merged by a second kernel.
+ *  Host-prepared tables, all in device memory: `segment_text[segment]` (NULL when every text has exactly one segment),
+ *  `segment_prefix[text]` / `partial_prefix[text]` (first segment / first partial slot of each text; count + 1 entries),
+ *  `merge_list[merge_count]` (slots of the texts with more than one segment), the per-dimension parameters, and
+ *  `partial_*` with one (double, u32) per (segment of a multi-segment text, dimension).  Output strides in BYTES.
+ */
+#define SZS_FINGERPRINT_SEGMENT 4096u
+#define SZS_FINGERPRINT_MAX_WIDTH 1024u
+int szs_hip_fingerprints(szs_string_ref_t const *texts, uint32_t texts_count, uint32_t const *segment_text,
+                         uint32_t const *segment_prefix, uint32_t const *partial_prefix, uint32_t total_segments,
+                         uint32_t const *merge_list, uint32_t merge_count, uint32_t dimensions, uint32_t const *widths,
+                         double const *multipliers, double const *modulos, double const *reciprocals,
+                         double const *complements, double *partial_minimums, uint32_t *partial_counts,
+                         uint32_t *min_hashes, uint64_t min_hashes_stride, uint32_t *min_counts,
+                         uint64_t min_counts_stride, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

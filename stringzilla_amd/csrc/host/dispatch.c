@@ -19,14 +19,8 @@ static double now_milliseconds(void) {
     return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
 
-typedef struct {
-    int host_readable;
-    int device_accessible;
-    int device_resident; /* hipMalloc'ed: writes from a kernel stay in HBM instead of crossing the host link */
-} pointer_traits_t;
-
-static pointer_traits_t classify_pointer(void const *pointer) {
-    pointer_traits_t traits = {1, 0, 0};
+szs_pointer_traits_t szs_classify_pointer(void const *pointer) {
+    szs_pointer_traits_t traits = {1, 0, 0};
     if (!pointer) return traits;
     hipPointerAttribute_t attributes;
     memset(&attributes, 0, sizeof(attributes));
@@ -49,15 +43,14 @@ static pointer_traits_t classify_pointer(void const *pointer) {
  *  the pinned staging area (no synchronisation - the caller waits once for both sides) and returns where the host will
  *  find the offsets; host-readable offsets are returned as they are.  `*pending` is set when a copy was enqueued.
  */
-static sz_status_t prefetch_offsets(szs_engine_s *engine, hipStream_t stream, szs_input_t const *input,
-                                    size_t staging_offset, void const **host_offsets, int *pending,
-                                    char const **error_message) {
+sz_status_t szs_prefetch_offsets(void *pinned_staging, hipStream_t stream, szs_input_t const *input, size_t staging_offset,
+                                 void const **host_offsets, int *pending, char const **error_message) {
     *host_offsets = input->offsets;
     if (input->kind == szs_input_sequence_k) return sz_success_k;
     if (!input->offsets) return szs_report(sz_status_unknown_k, error_message, "Tape offsets must not be null");
-    if (classify_pointer(input->offsets).host_readable) return sz_success_k;
+    if (szs_classify_pointer(input->offsets).host_readable) return sz_success_k;
     size_t const offset_size = input->kind == szs_input_u32tape_k ? 4 : 8;
-    void *landing = (char *)engine->pinned_staging.pointer + staging_offset;
+    void *landing = (char *)pinned_staging + staging_offset;
     hipError_t const error = hipMemcpyAsync(landing, input->offsets, (input->count + 1) * offset_size,
                                             hipMemcpyDeviceToHost, stream);
     if (error != hipSuccess) return szs_report_hip(error, error_message);
@@ -69,8 +62,8 @@ static sz_status_t prefetch_offsets(szs_engine_s *engine, hipStream_t stream, sz
  *  Produces absolute addresses and 32-bit lengths for every string of one side, from a callback sequence or from a
  *  tape whose offsets are readable at `offsets` (see prefetch_offsets).
  */
-static sz_status_t gather_strings(szs_input_t const *input, void const *offsets, uint64_t *addresses, uint32_t *lengths,
-                                  uint64_t *total_bytes, char const **error_message) {
+sz_status_t szs_gather_strings(szs_input_t const *input, void const *offsets, uint64_t *addresses, uint32_t *lengths,
+                               uint64_t *total_bytes, char const **error_message) {
     size_t const count = input->count;
     *total_bytes = 0;
     if (input->kind == szs_input_sequence_k) {
@@ -81,7 +74,7 @@ static sz_status_t gather_strings(szs_input_t const *input, void const *offsets,
             size_t const length = sequence->get_length(sequence->handle, i);
             if (length > 0xFFFFFFFFull) return szs_report(sz_overflow_risk_k, error_message, NULL);
             if (length && !checked) { /* like the reference, vet one representative string (cuda.cuh:4268-4272) */
-                if (!classify_pointer(start).device_accessible)
+                if (!szs_classify_pointer(start).device_accessible)
                     return szs_report(sz_device_memory_mismatch_k, error_message, NULL);
                 checked = 1;
             }
@@ -111,7 +104,7 @@ static sz_status_t gather_strings(szs_input_t const *input, void const *offsets,
         }
         *total_bytes = o[count] - o[0];
     }
-    if (*total_bytes && !classify_pointer(input->data).device_accessible)
+    if (*total_bytes && !szs_classify_pointer(input->data).device_accessible)
         return szs_report(sz_device_memory_mismatch_k, error_message, NULL);
     return sz_success_k;
 }
@@ -299,10 +292,12 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
     /* Offsets in device-only memory: both downloads are enqueued back to back and waited for ONCE. */
     void const *q_offsets = NULL, *c_offsets = NULL;
     int downloads_pending = 0;
-    status = prefetch_offsets(engine, stream, queries, refs_bytes, &q_offsets, &downloads_pending, error_message);
+    status = szs_prefetch_offsets(engine->pinned_staging.pointer, stream, queries, refs_bytes, &q_offsets, &downloads_pending,
+                                  error_message);
     if (status != sz_success_k) return status;
     if (!symmetric) {
-        status = prefetch_offsets(engine, stream, candidates, refs_bytes + ((size_t)q_count + 1) * sizeof(uint64_t),
+        status = szs_prefetch_offsets(engine->pinned_staging.pointer, stream, candidates,
+                                      refs_bytes + ((size_t)q_count + 1) * sizeof(uint64_t),
                                   &c_offsets, &downloads_pending, error_message);
         if (status != sz_success_k) return status;
     }
@@ -313,7 +308,7 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
 
     SZS_PHASE(0); /* checks, buffers, offsets download + its synchronisation */
     uint64_t query_bytes = 0, candidate_bytes = 0;
-    status = gather_strings(queries, q_offsets, q_addresses, q_lengths, &query_bytes, error_message);
+    status = szs_gather_strings(queries, q_offsets, q_addresses, q_lengths, &query_bytes, error_message);
     if (status != sz_success_k) return status;
     if (symmetric) {
         memcpy(c_addresses, q_addresses, (size_t)q_count * sizeof(uint64_t));
@@ -321,7 +316,7 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
         candidate_bytes = query_bytes;
     }
     else {
-        status = gather_strings(candidates, c_offsets, c_addresses, c_lengths, &candidate_bytes, error_message);
+        status = szs_gather_strings(candidates, c_offsets, c_addresses, c_lengths, &candidate_bytes, error_message);
         if (status != sz_success_k) return status;
     }
 
@@ -383,7 +378,7 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
      * kernel at all, and unified / pinned memory only across the host link, 8 scattered bytes at a time (measured on
      * config 2: 0.90 ms instead of 0.22 ms of kernel time) - those are staged densely in HBM and copied out in one
      * piece, unless the matrix is so small that the extra copy costs more than it saves. */
-    pointer_traits_t const results_traits = classify_pointer(results);
+    szs_pointer_traits_t const results_traits = szs_classify_pointer(results);
     int const direct = results_traits.device_accessible &&
                        (results_traits.device_resident || (size_t)q_count * c_count * sizeof(uint64_t) < ((size_t)256 << 10));
     void *device_results = results;

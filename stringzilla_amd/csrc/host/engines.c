@@ -1,6 +1,6 @@
 /*
  *  engines.c - the `extern "C"` engine entry points: init / call (sequence, u32tape, u64tape) / free for the four
- *  similarity families, the fingerprint placeholders, and the ROCm profile accessor.
+ *  similarity families and for the fingerprint engines, and the ROCm profile accessor.
  *
  *  ROCm counterpart of c/stringzillas/{levenshtein,needleman_wunsch,smith_waterman,fingerprints}.cuh.
  *  The capability ladder of the reference (levenshtein.cuh:107-200) collapses to one rung here: this build ships
@@ -215,41 +215,42 @@ sz_status_t szs_smith_waterman_scores_u64tape(szs_smith_waterman_scores_t engine
 }
 void szs_smith_waterman_scores_free(szs_smith_waterman_scores_t engine) { engine_free(engine); }
 
-/* ---- fingerprints (stringzillas.h:532-596): out of scope, exported so that bindings still resolve all 41 symbols ---- */
-
-static char const fingerprints_message[] = "Fingerprint engines are not part of the ROCm build";
+/* ---- fingerprints (stringzillas.h:532-596): host/fingerprints.c + hip/fingerprints.hip -------------------------------- */
 
 sz_status_t szs_fingerprints_init(sz_size_t dimensions, sz_size_t alphabet_size, sz_size_t const *window_widths,
                                   sz_size_t window_widths_count, sz_u64_t seed, sz_memory_allocator_t const *alloc,
                                   sz_capability_t capabilities, szs_fingerprints_t *engine, char const **error_message) {
-    (void)dimensions, (void)alphabet_size, (void)window_widths, (void)window_widths_count, (void)seed, (void)alloc;
-    (void)capabilities, (void)engine;
-    return szs_report(sz_missing_gpu_k, error_message, fingerprints_message);
+    (void)alloc; /* accepted and ignored, as in the reference (fingerprints.cuh:38) */
+    return szs_fingerprints_create(dimensions, alphabet_size, window_widths, window_widths_count, seed, capabilities, engine,
+                                   error_message);
 }
 sz_status_t szs_fingerprints_sequence(szs_fingerprints_t engine, szs_device_scope_t device, sz_sequence_t const *texts,
                                       sz_u32_t *min_hashes, sz_size_t min_hashes_stride, sz_u32_t *min_counts,
                                       sz_size_t min_counts_stride, char const **error_message) {
-    (void)engine, (void)device, (void)texts, (void)min_hashes, (void)min_hashes_stride, (void)min_counts;
-    (void)min_counts_stride;
-    return szs_report(sz_missing_gpu_k, error_message, fingerprints_message);
+    if (!texts) return szs_report(sz_status_unknown_k, error_message, "Input texts cannot be null");
+    szs_input_t const input = input_from_sequence(texts);
+    return szs_fingerprints_call((szs_fingerprints_s *)engine, (szs_scope_s *)device, &input, min_hashes, min_hashes_stride,
+                                 min_counts, min_counts_stride, error_message);
 }
 sz_status_t szs_fingerprints_u64tape(szs_fingerprints_t engine, szs_device_scope_t device,
                                      sz_sequence_u64tape_t const *texts, sz_u32_t *min_hashes,
                                      sz_size_t min_hashes_stride, sz_u32_t *min_counts, sz_size_t min_counts_stride,
                                      char const **error_message) {
-    (void)engine, (void)device, (void)texts, (void)min_hashes, (void)min_hashes_stride, (void)min_counts;
-    (void)min_counts_stride;
-    return szs_report(sz_missing_gpu_k, error_message, fingerprints_message);
+    if (!texts) return szs_report(sz_status_unknown_k, error_message, "Input texts cannot be null");
+    szs_input_t const input = input_from_u64tape(texts);
+    return szs_fingerprints_call((szs_fingerprints_s *)engine, (szs_scope_s *)device, &input, min_hashes, min_hashes_stride,
+                                 min_counts, min_counts_stride, error_message);
 }
 sz_status_t szs_fingerprints_u32tape(szs_fingerprints_t engine, szs_device_scope_t device,
                                      sz_sequence_u32tape_t const *texts, sz_u32_t *min_hashes,
                                      sz_size_t min_hashes_stride, sz_u32_t *min_counts, sz_size_t min_counts_stride,
                                      char const **error_message) {
-    (void)engine, (void)device, (void)texts, (void)min_hashes, (void)min_hashes_stride, (void)min_counts;
-    (void)min_counts_stride;
-    return szs_report(sz_missing_gpu_k, error_message, fingerprints_message);
+    if (!texts) return szs_report(sz_status_unknown_k, error_message, "Input texts cannot be null");
+    szs_input_t const input = input_from_u32tape(texts);
+    return szs_fingerprints_call((szs_fingerprints_s *)engine, (szs_scope_s *)device, &input, min_hashes, min_hashes_stride,
+                                 min_counts, min_counts_stride, error_message);
 }
-void szs_fingerprints_free(szs_fingerprints_t engine) { (void)engine; }
+void szs_fingerprints_free(szs_fingerprints_t engine) { szs_fingerprints_destroy((szs_fingerprints_s *)engine); }
 
 /* ---- ROCm extension --------------------------------------------------------------------------------------------------- */
 

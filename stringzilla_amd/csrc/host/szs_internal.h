@@ -116,6 +116,33 @@ typedef struct szs_input_t {
     sz_sequence_t const *sequence;
 } szs_input_t;
 
+/* ---- input normalisation shared by the similarity and fingerprint calls (dispatch.c) ----------------------------- */
+
+typedef struct {
+    int host_readable;
+    int device_accessible;
+    int device_resident; /* hipMalloc'ed: writes from a kernel stay in HBM instead of crossing the host link */
+} szs_pointer_traits_t;
+
+szs_pointer_traits_t szs_classify_pointer(void const *pointer);
+/** Enqueues the download of device-only tape offsets into `pinned_staging + staging_offset`; see dispatch.c. */
+sz_status_t szs_prefetch_offsets(void *pinned_staging, hipStream_t stream, szs_input_t const *input, size_t staging_offset,
+                                 void const **host_offsets, int *pending, char const **error_message);
+/** Absolute addresses and 32-bit lengths of every string of one side; vets device accessibility like the reference. */
+sz_status_t szs_gather_strings(szs_input_t const *input, void const *offsets, uint64_t *addresses, uint32_t *lengths,
+                               uint64_t *total_bytes, char const **error_message);
+
+/* ---- fingerprint engines (fingerprints.c) --------------------------------------------------------------------------- */
+
+typedef struct szs_fingerprints_s szs_fingerprints_s;
+sz_status_t szs_fingerprints_create(sz_size_t dimensions, sz_size_t alphabet_size, sz_size_t const *window_widths,
+                                    sz_size_t window_widths_count, sz_u64_t seed, sz_capability_t capabilities,
+                                    szs_fingerprints_t *engine, char const **error_message);
+sz_status_t szs_fingerprints_call(szs_fingerprints_s *engine, szs_scope_s *scope, szs_input_t const *texts,
+                                  sz_u32_t *min_hashes, sz_size_t min_hashes_stride, sz_u32_t *min_counts,
+                                  sz_size_t min_counts_stride, char const **error_message);
+void szs_fingerprints_destroy(szs_fingerprints_s *engine);
+
 /* ---- planner (plan.c) - pure host logic, unit-tested without a GPU through the szs_rocm_plan_* exports ------------ */
 
 typedef struct szs_plan_group_t {
