@@ -58,7 +58,7 @@ __device__ __forceinline__ void fingerprint_export(fingerprint_state_t const &st
  *  @param segment_prefix   [texts + 1] global index of each text's first segment
  *  @param partial_prefix   [texts + 1] index of each text's first PARTIAL slot; texts of one segment have none and write
  *                          their fingerprint straight to the outputs (the common case: many short documents)
- *  @param widths, multipliers, modulos, reciprocals, complements   [dimensions] per-dimension parameters (host/fingerprints.c)
+ *  @param widths, multipliers, modulos, reciprocals, complements   [dimensions] per-dimension parameters (host/fingerprint_engines.c)
  */
 __global__ __launch_bounds__(fingerprint_threads_k) void fingerprint_segments_kernel(
     szs_string_ref_t const *__restrict__ texts, u32 first_segment, u32 const *__restrict__ segment_text,

@@ -215,7 +215,7 @@ sz_status_t szs_smith_waterman_scores_u64tape(szs_smith_waterman_scores_t engine
 }
 void szs_smith_waterman_scores_free(szs_smith_waterman_scores_t engine) { engine_free(engine); }
 
-/* ---- fingerprints (stringzillas.h:532-596): host/fingerprints.c + hip/fingerprints.hip -------------------------------- */
+/* ---- fingerprints (stringzillas.h:532-596): host/fingerprint_engines.c + hip/fingerprints.hip -------------------------------- */
 
 sz_status_t szs_fingerprints_init(sz_size_t dimensions, sz_size_t alphabet_size, sz_size_t const *window_widths,
                                   sz_size_t window_widths_count, sz_u64_t seed, sz_memory_allocator_t const *alloc,

@@ -1,5 +1,5 @@
 /*
- *  fingerprints.c - rolling MinHash / Count-Min fingerprint engines: parameter seeding, input normalisation, the segment
+ *  fingerprint_engines.c - rolling MinHash / Count-Min fingerprint engines: parameter seeding, input normalisation, the segment
  *  plan and the launch.  ROCm counterpart of c/stringzillas/fingerprints.cuh (init, the three call flavours, free) and of
  *  the seeding in include/stringzillas/fingerprints/serial.hpp:495-534.  Nothing here hashes a byte on the CPU.
  *

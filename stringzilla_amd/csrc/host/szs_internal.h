@@ -132,7 +132,7 @@ sz_status_t szs_prefetch_offsets(void *pinned_staging, hipStream_t stream, szs_i
 sz_status_t szs_gather_strings(szs_input_t const *input, void const *offsets, uint64_t *addresses, uint32_t *lengths,
                                uint64_t *total_bytes, char const **error_message);
 
-/* ---- fingerprint engines (fingerprints.c) --------------------------------------------------------------------------- */
+/* ---- fingerprint engines (fingerprint_engines.c) --------------------------------------------------------------------------- */
 
 typedef struct szs_fingerprints_s szs_fingerprints_s;
 sz_status_t szs_fingerprints_create(sz_size_t dimensions, sz_size_t alphabet_size, sz_size_t const *window_widths,
