@@ -165,3 +165,35 @@ def reference_table(which: int):
     byte_to_class, class_costs = np.zeros(256, np.uint8), np.zeros(1024, np.int8)
     _ref_lib.szs_ref_substitution_table(ctypes.c_int(which), _ptr(byte_to_class), _ptr(class_costs))
     return byte_to_class, class_costs.reshape(32, 32)
+
+
+# ---- rolling MinHash / Count-Min fingerprints ----------------------------------------------------------------------------
+
+
+def _fingerprint_arguments(texts, dimensions, window_widths, seed):
+    data, offsets = make_tape(list(texts))
+    widths = None if window_widths is None else np.ascontiguousarray(window_widths, dtype=np.uint64)
+    hashes = np.zeros((len(texts), dimensions), dtype=np.uint32)
+    counts = np.zeros((len(texts), dimensions), dtype=np.uint32)
+    return data, offsets, widths, hashes, counts
+
+
+def oracle_fingerprints(texts: Sequence[bytes], dimensions: int, window_widths=None, seed: int = 0, alphabet_size: int = 256):
+    """(min_hashes, min_counts) of the plain-C restatement (oracle/sz_oracle_fingerprints.c)."""
+    lib = oracle_lib()
+    data, offsets, widths, hashes, counts = _fingerprint_arguments(texts, dimensions, window_widths, seed)
+    lib.szo_fingerprints_cross(_ptr(data), _ptr(offsets), _sz(len(texts)), _sz(dimensions), _sz(alphabet_size), _ptr(widths),
+                               _sz(0 if widths is None else len(widths)), ctypes.c_uint64(seed), _ptr(hashes), _ptr(counts))
+    return hashes, counts
+
+
+def reference_fingerprints(texts: Sequence[bytes], dimensions: int, window_widths=None, seed: int = 0, alphabet_size: int = 256):
+    """The same through the REFERENCE's own serial engines (oracle/_ref/libszs_ref.so), composed like its C shim does;
+    also returns which engine that was: 1 = 64-dimension slices, 2 = per-dimension fallback."""
+    lib = ctypes.CDLL(_REF_SO)
+    data, offsets, widths, hashes, counts = _fingerprint_arguments(texts, dimensions, window_widths, seed)
+    kind = lib.szs_ref_fingerprints(_sz(dimensions), _sz(alphabet_size), _ptr(widths), _sz(0 if widths is None else len(widths)),
+                                    ctypes.c_uint64(seed), _ptr(data), _ptr(offsets), _sz(len(texts)), _ptr(hashes), _ptr(counts))
+    if kind <= 0:
+        raise RuntimeError("reference fingerprint engine failed")
+    return hashes, counts, kind

@@ -25,7 +25,7 @@ from ._abi import CallProfile, StringZillasError, lib
 
 __all__ = [
     "DeviceScope", "Strs", "LevenshteinDistances", "LevenshteinDistancesUTF8", "NeedlemanWunschScores",
-    "SmithWatermanScores", "StringZillasError", "to_device", "__capabilities__", "__version__",
+    "SmithWatermanScores", "Fingerprints", "StringZillasError", "to_device", "__capabilities__", "__version__",
 ]
 
 __version__ = f"{lib.szs_version_major()}.{lib.szs_version_minor()}.{lib.szs_version_patch()}"
@@ -306,3 +306,60 @@ class SmithWatermanScores(NeedlemanWunschScores):
     _call_u32 = staticmethod(lib.szs_smith_waterman_scores_u32tape)
     _call_u64 = staticmethod(lib.szs_smith_waterman_scores_u64tape)
     _init = staticmethod(lib.szs_smith_waterman_scores_init)
+
+
+class Fingerprints:
+    """`Fingerprints(ndim, window_widths=None, alphabet_size=256, seed=0, capabilities=None)` - rolling MinHash /
+    Count-Min sketches (`szs_fingerprints_*`; /root/reference/python/README.md:549-590).  Called as
+    `engine(texts, device=None, out=None)`, returns `(hashes, counts)`: two `uint32` matrices of shape `(len(texts), ndim)`."""
+
+    def __init__(self, ndim: int, window_widths=None, alphabet_size: int = 256, seed: int = 0, capabilities=None):
+        self.handle = ctypes.c_void_p()
+        self.ndim = int(ndim)
+        self._scope = capabilities if isinstance(capabilities, DeviceScope) else None
+        self._mask = _capability_mask(capabilities)
+        widths = None if window_widths is None else np.ascontiguousarray(window_widths, dtype=np.uint64)
+        error = ctypes.c_char_p()
+        status = lib.szs_fingerprints_init(self.ndim, alphabet_size, None if widths is None else widths.ctypes.data,
+                                           0 if widths is None else len(widths), seed, None, self._mask,
+                                           ctypes.byref(self.handle), ctypes.byref(error))
+        _abi.check(status, error)
+
+    @property
+    def capabilities(self) -> tuple:  # the reference spells this one without underscores (README.md:571)
+        return _capability_names(self._mask & lib.szs_capabilities())
+
+    def __call__(self, texts, device: Optional[DeviceScope] = None, out=None):
+        import torch
+
+        scope = device or self._scope or _get_default_scope()
+        gpu_device = scope.gpu_device if scope.gpu_device is not None else 0
+        texts = _as_strs(texts)
+        rows = len(texts)
+        if out is not None:
+            hashes, counts = out
+            for matrix in (hashes, counts):
+                if not isinstance(matrix, np.ndarray) or matrix.shape != (rows, self.ndim) or matrix.dtype != np.uint32 or (
+                        rows and matrix.strides[1] != 4):
+                    raise ValueError("`out` must be a pair of (len(texts), ndim) uint32 NumPy matrices with contiguous rows")
+            pointers = (hashes.ctypes.data, hashes.strides[0] if rows else self.ndim * 4,
+                        counts.ctypes.data, counts.strides[0] if rows else self.ndim * 4)
+            device_out = None
+        else:
+            device_out = torch.empty((2, max(rows, 1), self.ndim), dtype=torch.int32, device=torch.device("cuda", gpu_device))
+            pointers = (device_out[0].data_ptr(), self.ndim * 4, device_out[1].data_ptr(), self.ndim * 4)
+        tape = texts._tape(gpu_device)
+        call = lib.szs_fingerprints_u64tape if texts.wide_offsets else lib.szs_fingerprints_u32tape
+        error = ctypes.c_char_p()
+        _abi.check(call(self.handle, scope.handle, ctypes.byref(tape), pointers[0], pointers[1], pointers[2], pointers[3],
+                        ctypes.byref(error)), error)
+        if out is not None:
+            return out
+        both = device_out[:, :rows].cpu().numpy().view(np.uint32)
+        return both[0], both[1]
+
+    def __del__(self):
+        handle = getattr(self, "handle", None)
+        if handle and lib is not None:
+            lib.szs_fingerprints_free(handle)
+            self.handle = None

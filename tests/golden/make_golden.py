@@ -115,6 +115,31 @@ def main():
     print(f"wrote {path}: {len(cases)} cases, {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def main_fingerprints():
+    """tests/golden/reference_fingerprints.json: (min_hashes, min_counts) the reference's serial fingerprint engines
+    produce - the 64-dimension slices (`floating_rolling_hashers`, fingerprints/serial.hpp:1119) and the per-dimension
+    fallback (`basic_rolling_hashers`, :646), chosen like its C shim chooses them (c/stringzillas/fingerprints.cuh:49-62)."""
+    rng = random.Random(20260923)
+    cases = []
+    for name, dimensions, widths, seed, shapes in [
+        ("defaults_512", 512, None, 0, [(0, 40, b"ACGT"), (90, 130, b"ACGT")]),
+        ("one_width_64", 64, [7], 42, [(0, 12, b"AB"), (300, 400, bytes(range(256)))]),
+        ("two_widths_128", 128, [4, 9], 7, [(3, 5, b"ACGT"), (4090, 4110, b"ACGT")]),
+        ("fallback_100", 100, None, 1, [(0, 70, b"abcdefgh ")]),
+        ("fallback_7", 7, [3, 5], 3, [(0, 9, b"xy"), (8190, 8200, b"ACGT")]),
+        ("wide_192", 192, [2, 5, 33], 99, [(30, 36, bytes(range(256))), (0, 3, b"z")]),
+    ]:
+        texts = []
+        for lo, hi, alphabet in shapes:
+            texts += rand_strings(rng, 4, lo, hi, alphabet)
+        hashes, counts, kind = ob.reference_fingerprints(texts, dimensions, widths, seed)
+        cases.append({"name": name, "dimensions": dimensions, "window_widths": widths, "seed": seed, "reference_engine": kind,
+                      "texts": hexes(texts), "min_hashes": hashes.tolist(), "min_counts": counts.tolist()})
+    with open(os.path.join(HERE, "reference_fingerprints.json"), "w") as handle:
+        json.dump({"generator": "tests/golden/make_golden.py main_fingerprints()", "cases": cases}, handle)
+    print("wrote reference_fingerprints.json:", len(cases), "cases")
+
+
 def main_utf8():
     """Codepoint-level goldens from the reference's UTF-8 engines (serial.hpp:678,685) -> reference_utf8_matrices.json.
     Alphabets mix 1/2/3/4-byte runes like the reference's own fuzz ("AÉ中😀", test/similarities.cuh:1504); the degenerate
@@ -158,7 +183,12 @@ def main_utf8():
     print(f"wrote {path}: {len(cases)} cases, {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+if __name__ == "__main__" and "--fingerprints-only" in sys.argv:
+    main_fingerprints()
+    sys.exit(0)
+
 if __name__ == "__main__":
     if "--utf8-only" not in sys.argv:
         main()
+        main_fingerprints()
     main_utf8()

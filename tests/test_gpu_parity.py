@@ -666,3 +666,45 @@ def test_tall_cross_products_are_turned_on_their_side(gpu, oracle):
     assert engine.last_call_profile().transposed == 1 and engine.last_call_profile().tier == 0
     assert np.array_equal(engine(candidates, queries, device=gpu), oracle.levenshtein(candidates, queries))
     assert engine.last_call_profile().transposed == 0
+
+
+# ---- rolling MinHash / Count-Min fingerprints (szs_fingerprints_*; hip/fingerprints.hip) ------------------------------
+
+
+def test_fingerprints_golden_reference(gpu):
+    """What the reference's serial engines produced (64-dimension slices and per-dimension fallback alike)."""
+    import json
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "reference_fingerprints.json")) as f:
+        cases = json.load(f)["cases"]
+    for case in cases:
+        engine = szs.Fingerprints(case["dimensions"], window_widths=case["window_widths"], seed=case["seed"], capabilities=gpu)
+        hashes, counts = engine(_unhex(case["texts"]), device=gpu)
+        assert hashes.dtype == np.uint32 and hashes.shape == (len(case["texts"]), case["dimensions"])
+        assert np.array_equal(hashes, np.array(case["min_hashes"], dtype=np.uint32)), case["name"]
+        assert np.array_equal(counts, np.array(case["min_counts"], dtype=np.uint32)), case["name"]
+
+
+def test_fingerprints_fuzz(gpu):
+    """Empty texts, texts shorter than / equal to a window, several 4096-position segments per text (merged on the
+    device), every byte value, odd dimension counts (idle lanes), wide tapes, NumPy `out=` buffers (staged copy)."""
+    from oracle import binding
+
+    rng = random.Random(64)
+    for dimensions, widths, seed in [(64, [7], 0), (512, None, 1), (1024, None, 2), (100, None, 3), (13, [2, 4, 31], 4), (320, [3, 1024], 5)]:
+        texts = [bytes(rng.randrange(256) for _ in range(n))
+                 for n in [0, 1, 2, 3, 6, 7, 8, 30, 31, 32, 100, 1023, 1024, 1025, 4095, 4096, 4097, 9000, rng.randint(0, 20000)]]
+        engine = szs.Fingerprints(dimensions, window_widths=widths, seed=seed, capabilities=gpu)
+        expected = binding.oracle_fingerprints(texts, dimensions, widths, seed)
+        got = engine(texts, device=gpu)
+        assert np.array_equal(got[0], expected[0]) and np.array_equal(got[1], expected[1]), (dimensions, widths)
+        wide = engine(szs.Strs(texts, wide_offsets=True), device=gpu)
+        assert np.array_equal(wide[0], expected[0]) and np.array_equal(wide[1], expected[1]), (dimensions, "u64tape")
+        out = (np.zeros((len(texts), dimensions), np.uint32), np.zeros((len(texts), dimensions), np.uint32))
+        engine(texts, device=gpu, out=out)
+        assert np.array_equal(out[0], expected[0]) and np.array_equal(out[1], expected[1]), (dimensions, "out=")
+    assert szs.Fingerprints(64, capabilities=gpu)([], device=gpu)[0].shape == (0, 64)
+    with pytest.raises(szs.StringZillasError):
+        szs.Fingerprints(64, window_widths=[1], capabilities=gpu)  # the reference asserts width > 1
+    with pytest.raises(szs.StringZillasError):
+        szs.Fingerprints(64, capabilities=("serial",))

@@ -107,6 +107,17 @@ def test_reference_binding_scores_on_the_gpu(modules, oracle):
         got = scorer(sz.Strs(proteins), sz.Strs(others), device=gpu)
         assert got.dtype == np.int64
         assert np.array_equal(got, getattr(oracle, kind)(p_bytes, o_bytes, byte_to_class, class_costs, *gaps)), (kind, gaps)
+    # fingerprints through the reference's `szs.Fingerprints` (python/stringzillas/fingerprints.c)
+    from oracle import binding
+
+    documents = _rand(rng, 25, 0, 6000, b"ACGT") + ["", "ab"]
+    for ndim, widths in [(128, None), (256, np.array([4, 8, 16], dtype=np.uint64)), (70, None)]:
+        sketcher = szs.Fingerprints(ndim=ndim, window_widths=widths, seed=7, capabilities=gpu)
+        hashes, counts = sketcher(sz.Strs(documents), device=gpu)
+        expected = binding.oracle_fingerprints([d.encode("latin-1") for d in documents], ndim,
+                                               None if widths is None else widths.tolist(), seed=7)
+        assert hashes.shape == (len(documents), ndim) and hashes.dtype == np.uint32
+        assert np.array_equal(hashes, expected[0]) and np.array_equal(counts, expected[1]), ndim
     # a handful of long reads: the planner routes them to the systolic tier behind the same Python call
     reads, genome = _rand(rng, 3, 3000, 3300, b"ACGT"), _rand(rng, 2, 3000, 3300, b"ACGT")
     nuc = matrices.nuc44()
