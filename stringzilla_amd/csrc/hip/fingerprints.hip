@@ -99,24 +99,30 @@ __global__ __launch_bounds__(fingerprint_threads_k) void fingerprint_segments_ke
     // This dimension's windows end at positions >= width - 1.
     u32 const my_first_end = first_end > width - 1 ? first_end : width - 1;
     if (owns_dimension && my_first_end < last_end) {
-        u32 const warm_from = my_first_end - (width - 1); // first byte of the first window
-        double hash = 0.0;
-        for (u32 i = warm_from; i < last_end; ++i) {
-            double const incoming = (double)((u32)staged[i - staged_from] + 1u);
-            // the byte leaving the window; nothing leaves while the first window is still filling up
-            double const outgoing = i >= warm_from + width ? (double)((u32)staged[i - width - staged_from] + 1u) : 0.0;
-            double x = __builtin_fma(hash, multiplier, incoming);
-            x = __builtin_fma(complement, outgoing, x);
-            // Barrett with a reciprocal rounded down: quotient in {floor(x / modulo) - 1, floor(x / modulo)}
+        u8 const *const window_bytes = staged - staged_from; // window_bytes[i] = byte i of the text
+        auto term = [&](u32 i) -> double { return (double)((u32)window_bytes[i] + 1u); };
+        // x < 2^52 -> x mod modulo: Barrett with a reciprocal rounded DOWN, so the quotient is floor(x / modulo) or one
+        // less and a single conditional subtraction finishes the job
+        auto reduce = [&](double x) -> double {
             double const quotient = __builtin_floor(x * reciprocal);
-            double residue = __builtin_fma(-quotient, modulo, x);
-            residue = residue >= modulo ? residue - modulo : residue;
-            hash = residue;
-            if (i >= my_first_end) { // a whole window ends here
-                bool const smaller = hash < state.minimum;
-                state.count = smaller ? 1u : state.count + (hash == state.minimum ? 1u : 0u);
-                state.minimum = smaller ? hash : state.minimum;
-            }
+            double const residue = __builtin_fma(-quotient, modulo, x);
+            return residue >= modulo ? residue - modulo : residue;
+        };
+        // ---- the first window of this stretch: `width` bytes enter, none leaves
+        u32 i = my_first_end - (width - 1);
+        double hash = 0.0;
+        for (; i <= my_first_end; ++i) hash = reduce(__builtin_fma(hash, multiplier, term(i)));
+        state.minimum = hash, state.count = 1;
+        // ---- every further position: one byte enters, one leaves, one window ends - straight-line, unrolled so that the
+        // LDS byte reads of the next positions are in flight under the arithmetic of the current one
+#pragma unroll 4
+        for (; i < last_end; ++i) {
+            double x = __builtin_fma(hash, multiplier, term(i));
+            x = __builtin_fma(complement, term(i - width), x);
+            hash = reduce(x);
+            bool const smaller = hash < state.minimum;
+            state.count = smaller ? 1u : state.count + (hash == state.minimum ? 1u : 0u);
+            state.minimum = smaller ? hash : state.minimum;
         }
     }
     if (!owns_dimension) return;
