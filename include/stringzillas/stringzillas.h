@@ -282,9 +282,17 @@ SZ_API_RUNTIME sz_status_t szs_smith_waterman_scores_u64tape(szs_smith_waterman_
                                                              char const **error_message);
 SZ_API_RUNTIME void szs_smith_waterman_scores_free(szs_smith_waterman_scores_t engine);
 
-/* ---- fingerprints (stringzillas.h:532-596) - OUT OF SCOPE for this hot path ---------------- */
-/*  Exported so that bindings resolving all 41 symbols at load time keep working; every call reports
- *  `sz_missing_gpu_k` with the message "Fingerprint engines are not part of the ROCm build". */
+/* ---- fingerprints (stringzillas.h:532-596) - the "next" row of SURVEY.md section 8f-3 --------------------------------- */
+/*  Rolling MinHash + Count-Min sketches: per dimension, the minimum over all windows of a text of a polynomial rolling
+ *  hash, its low 32 bits and the number of windows that attain it - bit-exact with the reference's serial engines
+ *  (include/stringzillas/fingerprints/serial.hpp:1119,646), per-dimension parameters and window widths assigned exactly as
+ *  its C shim assigns them (c/stringzillas/fingerprints.cuh:31-176).
+ *    dimensions        > 0; ideally a multiple of 64 x the number of window widths (one width per wavefront)
+ *    alphabet_size     accepted, unused by the reference's f64 hasher (0 = 256)
+ *    window_widths     NULL / 0 = {3, 4, 5, 7, 9, 11, 15, 31}; every width within [2, 1024], else sz_unexpected_dimensions_k
+ *    min_hashes        `count` rows of `dimensions` u32, rows `min_hashes_stride` BYTES apart (>= 4 * dimensions, multiple of 4);
+ *    min_counts        likewise.  A text shorter than a dimension's window yields hash 0xFFFFFFFF and count 0.
+ *  Outputs may live in device, unified or plain host memory (the latter two are staged); text bytes must be device-accessible. */
 
 SZ_API_RUNTIME sz_status_t szs_fingerprints_init(sz_size_t dimensions, sz_size_t alphabet_size,
                                                  sz_size_t const *window_widths, sz_size_t window_widths_count,
