@@ -296,7 +296,7 @@ static chain_layout_t chain_layout(u32 queries_count, u32 candidates_count, u32 
 extern "C" int szs_hip_myers_chain_workspace_bytes(uint32_t queries_count, uint32_t candidates_count, uint32_t longest_query,
                                                    uint32_t longest_candidate, size_t *control_bytes, size_t *parked_bytes) {
     szs_hip::chain_layout_t const layout = szs_hip::chain_layout(queries_count, candidates_count, longest_query, longest_candidate);
-    if (layout.tickets > 0x7FFFFFF0ull) return 0; // tickets, plus one failing fetch per surplus wavefront, stay below 2^32
+    if (layout.tickets > (1ull << 26) - 16) return 0; // one wavefront per ticket: 64 x tickets threads must stay below 2^32
     *control_bytes = layout.control_bytes, *parked_bytes = layout.parked_bytes + 256;
     return 1;
 }
@@ -308,7 +308,7 @@ extern "C" int szs_hip_myers_chain(szs_string_ref_t const *queries, uint32_t que
     using namespace szs_hip;
     if (!queries_count || !candidates_count) return 0;
     chain_layout_t const layout = chain_layout(queries_count, candidates_count, longest_query, longest_candidate);
-    if (layout.tickets > 0x7FFFFFF0ull) return (int)hipErrorInvalidValue;
+    if (layout.tickets > (1ull << 26) - 16) return (int)hipErrorInvalidValue;
     char *const base = static_cast<char *>(control);
     hipLaunchKernelGGL(myers_chain_kernel, dim3((u32)layout.tickets), dim3(64), 0, static_cast<hipStream_t>(stream), queries,
                        queries_count, candidates, candidates_count, layout.max_bands, results, results_row_stride, layout_flags,

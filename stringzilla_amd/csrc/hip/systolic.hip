@@ -650,7 +650,7 @@ static systolic_layout_t systolic_layout(int affine, u32 queries_count, u32 cand
     return layout;
 }
 
-constexpr u64 systolic_ticket_limit_k = 0x7FFFFFF0ull; // tickets, plus one failing fetch per wavefront, stay below 2^32
+constexpr u64 systolic_ticket_limit_k = (1ull << 26) - 16; // one wavefront per ticket: 64 x tickets threads must stay below 2^32
 
 template <bool local_, bool affine_, bool uniform_, bool runes_ = false, bool saturating_ = false>
 static int launch_systolic(szs_cost_model_t const *model, szs_string_ref_t const *queries, u32 queries_count,
