@@ -708,3 +708,34 @@ def test_fingerprints_fuzz(gpu):
         szs.Fingerprints(64, window_widths=[1], capabilities=gpu)  # the reference asserts width > 1
     with pytest.raises(szs.StringZillasError):
         szs.Fingerprints(64, capabilities=("serial",))
+
+
+def test_fingerprints_callback_sequences_and_unified_outputs(gpu):
+    """`szs_fingerprints_sequence` (strings reached through host callbacks, each at its own device address) and outputs in
+    unified memory with a padded row stride."""
+    import torch
+
+    from oracle import binding
+
+    rng = random.Random(65)
+    texts = [bytes(rng.choice(b"ACGT") for _ in range(n)) for n in (0, 5, 64, 300, 5000)]
+    tensors = [torch.tensor(list(t) or [0], dtype=torch.uint8, device="cuda") for t in texts]
+    starts, lengths = [t.data_ptr() for t in tensors], [len(t) for t in texts]
+    get_start = _abi.MEMBER_START(lambda handle, i: starts[i])
+    get_length = _abi.MEMBER_LENGTH(lambda handle, i: lengths[i])
+    sequence = _abi.Sequence(None, len(texts), get_start, get_length)
+    engine = szs.Fingerprints(128, window_widths=[4, 9], seed=11, capabilities=gpu)
+    stride = 128 * 4 + 32
+    hashes_pointer = _abi.lib.szs_unified_alloc(len(texts) * stride)
+    counts_pointer = _abi.lib.szs_unified_alloc(len(texts) * stride)
+    ctypes.memset(hashes_pointer, 0xEE, len(texts) * stride), ctypes.memset(counts_pointer, 0xEE, len(texts) * stride)
+    error = ctypes.c_char_p()
+    status = _abi.lib.szs_fingerprints_sequence(engine.handle, gpu.handle, ctypes.byref(sequence), hashes_pointer, stride,
+                                                counts_pointer, stride, ctypes.byref(error))
+    assert status == 0, error.value
+    expected = binding.oracle_fingerprints(texts, 128, [4, 9], seed=11)
+    for pointer, want in ((hashes_pointer, expected[0]), (counts_pointer, expected[1])):
+        raw = np.ctypeslib.as_array(ctypes.cast(pointer, ctypes.POINTER(ctypes.c_uint32)), shape=(len(texts), stride // 4))
+        assert np.array_equal(raw[:, :128], want)
+        assert (raw[:, 128:] == 0xEEEEEEEE).all()  # padding never written
+    _abi.lib.szs_unified_free(hashes_pointer, len(texts) * stride), _abi.lib.szs_unified_free(counts_pointer, len(texts) * stride)
