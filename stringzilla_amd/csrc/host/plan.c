@@ -152,7 +152,10 @@ double szs_plan_estimate(unsigned bit_parallel_limit, int bit_parallel_chain, in
     (void)uniform;
     double tickets = bands_total * candidates_count * scale;
     if (tickets < 1) tickets = 1;
-    double systolic_cycles = tickets * (mean_candidate / columns_per_step + 63.0) * step_cycles / (tickets < simds ? tickets : simds);
+    /* wavefronts that advance at once: one per SIMD, but the bit-parallel chain keeps 64 KB of match masks per wavefront
+     * in LDS, two wavefronts per CU */
+    double const slots = bit_parallel_chain ? 512.0 : simds;
+    double systolic_cycles = tickets * (mean_candidate / columns_per_step + 63.0) * step_cycles / (tickets < slots ? tickets : slots);
     double const longest_chain = (double)((longest_query + band_rows - 1) / band_rows);
     double const chain_cycles =
         (longest_candidate / columns_per_step + 63.0 + 95.0 * (longest_chain > 1 ? longest_chain - 1 : 0)) * step_cycles;
