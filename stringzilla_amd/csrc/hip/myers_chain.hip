@@ -13,8 +13,10 @@
  *  both: 32 cells per ~19 instructions AND one pair per chain of wavefronts.
  *
  *  - A BAND is 64 lanes x 32 pattern rows = 2048 rows = one wavefront; lane l owns word l of the band's bit-vector:
- *    VP / VN of rows [32 l, 32 l + 32).  Its match masks Peq[symbol][lane] live in LDS (64 KB per wavefront, conflict-free
- *    ds_read_b32: the lanes of a wavefront read consecutive dwords), built once per band by the lane itself.
+ *    VP / VN of rows [32 l, 32 l + 32).  The match masks Peq[symbol][lane] of the band live in LDS (64 KB, conflict-free
+ *    ds_read_b32: the lanes of a wavefront read consecutive dwords).  They depend on the QUERY only, so the four
+ *    wavefronts of a workgroup score four different candidates against the same query band and share one table -
+ *    which is what lets 8 wavefronts live on a CU instead of 2 when a batch is large.
  *  - A lane advances K = 8 text columns per step.  Between words only the horizontal deltas of a word's LAST row travel:
  *    2 bits per column, so ONE dword per step (`v_mov_b32_dpp wave_shr:1`) carries everything lane l + 1 needs from
  *    lane l; the K text bytes travel the same way one step ahead, so their masks are fetched from LDS a step early.
@@ -34,6 +36,7 @@ constexpr u32 chain_chunk_steps_k = 16;         // steps per hand-over between b
 constexpr u32 chain_slack_words_k = 64;         // parked words past the longest candidate
 constexpr size_t chain_header_bytes_k = 256;    // ticket counter [0] and stall flag [1]: the layout systolic.hip uses
 constexpr u32 chain_spin_limit_k = 1u << 18;
+constexpr u32 chain_max_waves_k = 16;           // wavefronts per workgroup: up to 16 CANDIDATES against the same query band
 static_assert(chain_band_rows_k == SZS_MYERS_CHAIN_BAND_ROWS, "the host planner models bands of this height");
 static_assert(chain_columns_k == 8, "the text bytes of one step travel in two dwords, the deltas in one");
 
@@ -79,7 +82,8 @@ __device__ __forceinline__ u32 chain_word_step(u32 &vp, u32 &vn, u32 eq, u32 hp_
  *    done[pair]                          bands of the pair that have published their partial sum
  *  parked[pair][step]: one dword per step, bit 2j / 2j+1 = the +1 / -1 delta under the band's last row at column K step + j.
  */
-__global__ __launch_bounds__(64) void myers_chain_kernel(szs_string_ref_t const *__restrict__ queries, u32 queries_count,
+template <u32 chain_waves_k>
+__global__ __launch_bounds__(64 * chain_waves_k) void myers_chain_kernel(szs_string_ref_t const *__restrict__ queries, u32 queries_count,
                                                         szs_string_ref_t const *__restrict__ candidates,
                                                         u32 candidates_count, u32 max_bands, u64 *__restrict__ results,
                                                         u64 results_row_stride, int layout_flags,
@@ -88,24 +92,45 @@ __global__ __launch_bounds__(64) void myers_chain_kernel(szs_string_ref_t const 
     constexpr u32 K = chain_columns_k, chunk_steps = chain_chunk_steps_k;
     __shared__ u32 peq[256 * 64]; // [symbol][lane]: the whole 64 KB a workgroup may declare statically
 
-    u32 const lane = threadIdx.x;
-    u64 const total_tickets = (u64)queries_count * candidates_count * max_bands;
+    u32 const lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    u32 const candidate_groups = (candidates_count + chain_waves_k - 1) / chain_waves_k;
+    u64 const total_tickets = (u64)queries_count * candidate_groups * max_bands;
     u64 const tag = (u64)epoch << 32;
 
-    u32 ticket = 0;
-    if (lane == 0) {
+    // One ticket per WORKGROUP, in (query, candidate group, band) order; the table doubles as the mailbox that hands the
+    // ticket to the other wavefronts before it is built.
+    if (threadIdx.x == 0) {
         __hip_atomic_fetch_max(work_counter, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ticket = (u32)__hip_atomic_fetch_add(work_counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        peq[0] = (u32)__hip_atomic_fetch_add(work_counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    __syncthreads();
+    u32 const ticket = __builtin_amdgcn_readfirstlane(peq[0]);
+    __syncthreads();
     if (ticket >= total_tickets) return;
-    u32 const pair = ticket / max_bands, band = ticket % max_bands;
-    szs_string_ref_t const query = queries[pair / candidates_count];
-    szs_string_ref_t const candidate = candidates[pair % candidates_count];
-    if ((layout_flags & SZS_LAYOUT_SYMMETRIC) && candidate.index > query.index) return;
-    u32 const m = query.length, n = candidate.length;
+    u32 const band = ticket % max_bands, group = (ticket / max_bands) % candidate_groups;
+    szs_string_ref_t const query = queries[ticket / max_bands / candidate_groups];
+    u32 const m = query.length;
     u32 const bands = m ? (m + chain_band_rows_k - 1) / chain_band_rows_k : 1;
-    if (band >= bands) return;
+    if (band >= bands) return; // the whole workgroup: nothing below depends on the candidate yet
+
+    // ---- Peq of this query band, built by all 256 threads: thread t owns the rows t, t + 256, ... of the band
+    for (u32 i = threadIdx.x; i < 256 * 64; i += 64 * chain_waves_k) peq[i] = 0;
+    __syncthreads();
+    {
+        u32 const band_first_row = band * chain_band_rows_k;
+        u32 const band_rows = m - band_first_row < chain_band_rows_k ? m - band_first_row : chain_band_rows_k;
+        u8 const *const pattern = reinterpret_cast<u8 const *>(query.address) + band_first_row;
+        for (u32 r = threadIdx.x; r < band_rows; r += 64 * chain_waves_k) atomicOr(&peq[(u32)pattern[r] * 64 + r / 32], 1u << (r % 32));
+    }
+    __syncthreads(); // the only barriers: from here on every wavefront runs on its own
+
+    // ---- this wavefront's candidate
+    u32 const candidate_slot = group * chain_waves_k + wave;
+    if (candidate_slot >= candidates_count) return;
+    szs_string_ref_t const candidate = candidates[candidate_slot];
+    if ((layout_flags & SZS_LAYOUT_SYMMETRIC) && candidate.index > query.index) return;
+    u32 const n = candidate.length;
+    u32 const pair = (ticket / max_bands / candidate_groups) * candidates_count + candidate_slot;
 
     auto write_result = [&](u64 distance) {
         bool const transposed = (layout_flags & SZS_LAYOUT_TRANSPOSED) != 0;
@@ -115,20 +140,13 @@ __global__ __launch_bounds__(64) void myers_chain_kernel(szs_string_ref_t const 
             results[column * results_row_stride + row] = distance;
     };
     if (m == 0 || n == 0) { // the distance to an empty string is the other one's length
-        if (lane == 0) write_result(m ? m : n);
+        if (lane == 0 && band == 0) write_result(m ? m : n);
         return;
     }
 
     bool const first_band = band == 0, last_band = band + 1 == bands;
     u32 const first_row = band * chain_band_rows_k + lane * 32u;
     u32 const my_rows = first_row >= m ? 0u : (m - first_row < 32u ? m - first_row : 32u);
-
-    // ---- Peq of this lane's word: column `lane` of the LDS table is private to the lane, so no barrier and no atomics
-    for (u32 symbol = 0; symbol < 256; ++symbol) peq[symbol * 64 + lane] = 0;
-    {
-        u8 const *const pattern = reinterpret_cast<u8 const *>(query.address) + first_row;
-        for (u32 r = 0; r < my_rows; ++r) peq[(u32)pattern[r] * 64 + lane] |= 1u << r;
-    }
 
     // D[i][0] = i: every vertical delta starts at +1.  Rows past the end of the pattern (last word of the last band)
     // sit BELOW the real ones and cannot influence them; they are masked out of the final count.
@@ -273,7 +291,7 @@ __global__ __launch_bounds__(64) void myers_chain_kernel(szs_string_ref_t const 
 
 struct chain_layout_t {
     u64 pairs, tickets;
-    u32 max_bands, parked_words;
+    u32 max_bands, parked_words, waves;
     size_t progress_at, partial_at, done_at, control_bytes, parked_bytes;
 };
 
@@ -281,11 +299,23 @@ static chain_layout_t chain_layout(u32 queries_count, u32 candidates_count, u32 
     chain_layout_t layout;
     layout.pairs = (u64)queries_count * candidates_count;
     layout.max_bands = longest_query ? (longest_query + chain_band_rows_k - 1) / chain_band_rows_k : 1;
-    layout.tickets = layout.pairs * layout.max_bands;
+    // Wavefronts per workgroup.  A CU holds two 64 KB tables.  A step is one long dependency chain, so a wavefront that
+    // shares its SIMD with few others advances fastest: a small batch gets 4 wavefronts per table (all of them build it,
+    // whatever the candidate count) and spreads over the chip; a large one is bound by how many wavefronts advance at
+    // once, and every doubling raises that - up to 8 per SIMD, 8192 on the chip (profiles/r01/chain_waves_v1.txt).
+    u64 const wavefronts = layout.pairs * layout.max_bands;
+    u32 waves = wavefronts <= 2048 ? 4 : wavefronts <= 4096 ? 8 : chain_max_waves_k;
+    while (waves > 4 && waves / 2 >= candidates_count) waves /= 2;
+    if (char const *forced = std::getenv("SZS_ROCM_CHAIN_WAVES")) { // a testing aid, like SZS_ROCM_TIER
+        int const asked = std::atoi(forced);
+        if (asked == 4 || asked == 8 || asked == 16) waves = (u32)asked;
+    }
+    layout.waves = waves;
+    layout.tickets = (u64)queries_count * ((candidates_count + waves - 1) / waves) * layout.max_bands; // workgroups
     layout.parked_words = (longest_candidate + chain_columns_k - 1) / chain_columns_k + chain_slack_words_k;
-    layout.progress_at = chain_header_bytes_k;
-    layout.partial_at = layout.progress_at + layout.tickets * sizeof(u64);
-    layout.done_at = layout.partial_at + layout.tickets * sizeof(u64);
+    layout.progress_at = chain_header_bytes_k; // progress and partial sums: one word per (pair, band)
+    layout.partial_at = layout.progress_at + layout.pairs * layout.max_bands * sizeof(u64);
+    layout.done_at = layout.partial_at + layout.pairs * layout.max_bands * sizeof(u64);
     layout.control_bytes = layout.done_at + layout.pairs * sizeof(u64);
     layout.parked_bytes = layout.pairs * layout.parked_words * sizeof(u32);
     return layout;
@@ -296,7 +326,8 @@ static chain_layout_t chain_layout(u32 queries_count, u32 candidates_count, u32 
 extern "C" int szs_hip_myers_chain_workspace_bytes(uint32_t queries_count, uint32_t candidates_count, uint32_t longest_query,
                                                    uint32_t longest_candidate, size_t *control_bytes, size_t *parked_bytes) {
     szs_hip::chain_layout_t const layout = szs_hip::chain_layout(queries_count, candidates_count, longest_query, longest_candidate);
-    if (layout.tickets > (1ull << 26) - 16) return 0; // one wavefront per ticket: 64 x tickets threads must stay below 2^32
+    if (layout.tickets * layout.waves > (1ull << 26) - 1024 || layout.pairs * layout.max_bands > (1ull << 28)) // threads < 2^32
+        return 0;
     *control_bytes = layout.control_bytes, *parked_bytes = layout.parked_bytes + 256;
     return 1;
 }
@@ -308,12 +339,19 @@ extern "C" int szs_hip_myers_chain(szs_string_ref_t const *queries, uint32_t que
     using namespace szs_hip;
     if (!queries_count || !candidates_count) return 0;
     chain_layout_t const layout = chain_layout(queries_count, candidates_count, longest_query, longest_candidate);
-    if (layout.tickets > (1ull << 26) - 16) return (int)hipErrorInvalidValue;
+    if (layout.tickets * layout.waves > (1ull << 26) - 1024) return (int)hipErrorInvalidValue;
     char *const base = static_cast<char *>(control);
-    hipLaunchKernelGGL(myers_chain_kernel, dim3((u32)layout.tickets), dim3(64), 0, static_cast<hipStream_t>(stream), queries,
-                       queries_count, candidates, candidates_count, layout.max_bands, results, results_row_stride, layout_flags,
-                       reinterpret_cast<u64 *>(base), reinterpret_cast<u64 *>(base + layout.progress_at),
-                       reinterpret_cast<u64 *>(base + layout.partial_at), reinterpret_cast<u64 *>(base + layout.done_at),
-                       static_cast<u32 *>(parked), layout.parked_words, epoch);
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3((u32)layout.tickets), dim3(64 * layout.waves), 0, static_cast<hipStream_t>(stream), queries,
+                           queries_count, candidates, candidates_count, layout.max_bands, results, results_row_stride, layout_flags,
+                           reinterpret_cast<u64 *>(base), reinterpret_cast<u64 *>(base + layout.progress_at),
+                           reinterpret_cast<u64 *>(base + layout.partial_at), reinterpret_cast<u64 *>(base + layout.done_at),
+                           static_cast<u32 *>(parked), layout.parked_words, epoch);
+    };
+    switch (layout.waves) {
+    case 4: launch(myers_chain_kernel<4>); break;
+    case 8: launch(myers_chain_kernel<8>); break;
+    default: launch(myers_chain_kernel<16>); break;
+    }
     return (int)hipGetLastError();
 }

@@ -152,9 +152,19 @@ double szs_plan_estimate(unsigned bit_parallel_limit, int bit_parallel_chain, in
     (void)uniform;
     double tickets = bands_total * candidates_count * scale;
     if (tickets < 1) tickets = 1;
-    /* wavefronts that advance at once: one per SIMD, but the bit-parallel chain keeps 64 KB of match masks per wavefront
-     * in LDS, two wavefronts per CU */
-    double const slots = bit_parallel_chain ? 512.0 : simds;
+    /* Wavefronts that advance at once: one per SIMD.  The bit-parallel chain keeps 64 KB of match masks per workgroup in
+     * LDS - two workgroups per CU, each scoring up to 16 candidates against one query band - and its step is a single
+     * dependency chain, so wavefronts sharing a SIMD slow each other down far less than proportionally.  Measured
+     * (profiles/r01/chain_waves_v1.txt), w resident wavefronts advance like 2300 w / (w + 3200) lone ones: 2560 like
+     * ~1000, 8192 like ~1650, 32768 like ~2050, half a million like ~2300. */
+    double slots = simds;
+    if (bit_parallel_chain) {
+        double const resident = 512.0 * (candidates_count < 16 ? candidates_count : 16);
+        double const advancing = tickets < resident ? tickets : resident, lone = advancing < 512.0 ? advancing : 512.0;
+        slots = 2300.0 * tickets / (tickets + 3200.0);
+        if (slots > advancing) slots = advancing;
+        if (slots < lone) slots = lone;
+    }
     double systolic_cycles = tickets * (mean_candidate / columns_per_step + 63.0) * step_cycles / (tickets < slots ? tickets : slots);
     double const longest_chain = (double)((longest_query + band_rows - 1) / band_rows);
     double const chain_cycles =
