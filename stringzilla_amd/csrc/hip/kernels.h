@@ -99,6 +99,19 @@ size_t szs_hip_weighted_boundary_bytes(int objective, int affine, int narrow, ui
                                        uint32_t longest_candidate);
 
 /**
+ *  Two cells per VALU operation (hip/weighted_packed.hip): the same lanes-tier scorer for class-table engines whose DP
+ *  values provably fit int16 - `local` = 0: Needleman-Wunsch with reach (serial.hpp:135-162) < 32000; `local` = 1:
+ *  Smith-Waterman with both gap costs <= 0 and (shortest side + 3) x largest cost < 32000.  `classes` = 1 + the largest
+ *  value of `byte_to_class` (<= 32).  Workspace and calling rules as for szs_hip_weighted_scores.
+ */
+int szs_hip_weighted_packed_scores(int local, int affine, uint32_t classes, szs_cost_model_t const *model,
+                                   szs_string_ref_t const *queries, uint32_t queries_count, szs_string_ref_t const *candidates,
+                                   uint32_t candidates_count, uint32_t longest_candidate, int64_t *results,
+                                   uint64_t results_row_stride, int symmetric, void *boundary, void *stream);
+size_t szs_hip_weighted_packed_boundary_bytes(int local, int affine, uint32_t classes, uint32_t queries_count,
+                                              uint32_t candidates_count, uint32_t longest_candidate);
+
+/**
  *  The few-pairs tier of the weighted scorers (hip/systolic.hip): a pair is spread over wavefronts - 64 lanes x R rows
  *  per band, lanes skewed by one column and chained by DPP, bands chained through memory - instead of owning one lane.
  *  Same objectives, cost model, string refs and result addressing as szs_hip_weighted_scores; queries need no

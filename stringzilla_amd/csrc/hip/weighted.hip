@@ -80,10 +80,14 @@ __device__ __forceinline__ cost_column_t load_costs(int8_t const *profile, u32 s
  *  The cells of one strip column, per lane, in the form the recurrences consume them.
  *  Linear gaps keep `h` and `h + gap`; affine gaps keep `h`, `h + open` and the horizontal-gap track pre-extended.
  */
+#ifndef SZS_WEIGHTED_RECOMPUTE
+#define SZS_WEIGHTED_RECOMPUTE 0
+#endif
 template <bool affine_>
 struct strip_column_t {
+    static constexpr bool keeps_gapped = !(affine_ && SZS_WEIGHTED_RECOMPUTE);
     i32 h[weighted_rows_k];            // H(row, column): becomes the diagonal of the next column
-    i32 h_gapped[weighted_rows_k];     // H + gap (linear) or H + open (affine): the "left" input of the next column
+    i32 h_gapped[keeps_gapped ? weighted_rows_k : 1]; // H + gap (linear) or H + open (affine): the "left" input of the next column
     i32 across_extended[affine_ ? weighted_rows_k : 1]; // affine: horizontal-gap track + extend
 };
 
@@ -128,7 +132,9 @@ __device__ __forceinline__ void advance_column(strip_column_t<affine_> &column, 
         diag = column.h[r];
         i32 cell;
         if constexpr (affine_) {
-            i32 const across = max2(column.h_gapped[r], column.across_extended[r]); // serial.hpp:1091-1102
+            i32 const left_gapped = strip_column_t<affine_>::keeps_gapped ? column.h_gapped[strip_column_t<affine_>::keeps_gapped ? r : 0]
+                                                                          : gapped<saturating_>(diag, gap_open);
+            i32 const across = max2(left_gapped, column.across_extended[r]); // serial.hpp:1091-1102
             down = max2(above_gapped, down_extended);
             cell = max3(down, across, substituted);
             column.across_extended[r] = gapped<saturating_>(across, gap_extend);
@@ -137,11 +143,14 @@ __device__ __forceinline__ void advance_column(strip_column_t<affine_> &column, 
         else { cell = max3(above_gapped, column.h_gapped[r], substituted); } // serial.hpp:846-848
         column.h[r] = cell;
         above_gapped = gapped<saturating_>(cell, gap_open);
-        column.h_gapped[r] = above_gapped;
+        if constexpr (strip_column_t<affine_>::keeps_gapped) column.h_gapped[r] = above_gapped;
     }
     down_out = down;
     if constexpr (local_) {
-        if (counted_rows >= (u32)rows) { // every row is real: a max3 tree, half an instruction per cell
+        // Saturating form (gaps <= 0, everything clamped at 0): a padded row - cost 0 against every symbol - can only
+        // hold what it inherited, minus penalties, from real cells above it or to its left, all of them counted already.
+        // So padded rows may be counted too, and the column needs no branch.
+        if (saturating_ || counted_rows >= (u32)rows) { // every row counts: a max3 tree, half an instruction per cell
 #pragma unroll
             for (int r = 0; r < rows; r += 2) best = max3(best, column.h[r], column.h[r + 1]);
         }
@@ -309,7 +318,7 @@ __global__ __launch_bounds__(256, SZS_WEIGHTED_WAVES) void weighted_scores_kerne
 #pragma unroll
             for (int r = 0; r < rows; ++r) {
                 column.h[r] = border(first_row + r + 1);
-                column.h_gapped[r] = gapped<saturating_>(column.h[r], gap_open);
+                if constexpr (strip_column_t<affine_>::keeps_gapped) column.h_gapped[r] = gapped<saturating_>(column.h[r], gap_open);
                 if constexpr (affine_) // saturating: the (negative) seed is clamped like every other track value
                     column.across_extended[r] = saturating_ ? 0 : column.h[r] + gap_open + gap_extend + gap_extend;
             }

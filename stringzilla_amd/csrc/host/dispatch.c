@@ -403,6 +403,15 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
                            ? (shorter_side + 3) * (engine->magnitude ? engine->magnitude : 1) < 32000
                            : 0;
 
+    /* Two cells per VALU operation (hip/weighted_packed.hip) when EVERY DP value fits 16 bits, not just the parked ones:
+     * the same two bounds cover all cells and tracks - the reach is a bound on any sum of (rows + columns + 3) costs. */
+    uint32_t classes = 0;
+    if (maximise)
+        for (int i = 0; i < 256; ++i) classes = engine->byte_to_class[i] >= classes ? (uint32_t)engine->byte_to_class[i] + 1 : classes;
+    char const *const forced_packed = getenv("SZS_ROCM_PACKED"); /* testing aid: 0 pins the 32-bit kernel */
+    int const packed = maximise && narrow && classes <= 32 && !(forced_packed && forced_packed[0] == '0');
+    int const packed_local = objective == szs_objective_local_saturating_k;
+
     /* The systolic tier scores every engine family with its weighted recurrences, so it needs the cost model and its
      * own workspace; a job with too many pairs in flight for that workspace stays on the lanes tier. */
     size_t systolic_control_bytes = 0, systolic_parked_bytes = 0;
@@ -455,7 +464,9 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
         size_t const boundary_bytes =
             tier == SZS_TIER_SYSTOLIC
                 ? systolic_parked_bytes
-                : szs_hip_weighted_boundary_bytes(objective, !engine->is_linear, narrow, kq_count, kc_count, plan.longest_candidate);
+                : packed ? szs_hip_weighted_packed_boundary_bytes(packed_local, !engine->is_linear, classes, kq_count, kc_count,
+                                                                  plan.longest_candidate)
+                         : szs_hip_weighted_boundary_bytes(objective, !engine->is_linear, narrow, kq_count, kc_count, plan.longest_candidate);
         status = szs_buffer_reserve(&engine->device_boundary, szs_memory_device_k, device, boundary_bytes, error_message);
         if (status != sz_success_k) return status;
     }
@@ -493,6 +504,13 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
             launch_error = szs_hip_levenshtein_myers(group->variant, device_query_refs + group->first, group->count,
                                                      device_candidate_refs, kc_count, (uint64_t *)device_results,
                                                      device_stride, layout, stream);
+        else if (packed)
+            launch_error = szs_hip_weighted_packed_scores(packed_local, !engine->is_linear, classes,
+                                                          (szs_cost_model_t const *)engine->device_model.pointer,
+                                                          device_query_refs + group->first, group->count,
+                                                          device_candidate_refs, kc_count, plan.longest_candidate,
+                                                          (int64_t *)device_results, device_stride, layout,
+                                                          engine->device_boundary.pointer, stream);
         else
             launch_error = szs_hip_weighted_scores(objective, !engine->is_linear, narrow,
                                                    (szs_cost_model_t const *)engine->device_model.pointer,
