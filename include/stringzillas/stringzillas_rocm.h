@@ -28,9 +28,9 @@ typedef struct szs_rocm_call_profile_t {
     sz_u32_t launches;            /* kernel launches issued */
     sz_u32_t longest_query;
     sz_u32_t longest_candidate;
-    sz_u32_t tier;                /* 0: one pair per lane (lev_myers.hip, weighted.hip); 1: systolic (systolic.hip) */
+    sz_u32_t tier;                /* 0: one pair per lane (lev_myers.hip, weighted*.hip); 1: systolic.hip; 2: myers_chain.hip */
     sz_u32_t transposed;          /* 1: the planner swapped the sides (candidates on workgroups, queries on lanes) */
-    sz_u32_t reserved;
+    sz_u32_t cell_bits;           /* width of the DP cells of the last launch: 16 (weighted_packed.hip), 32, or 0 (bit-parallel) */
 } szs_rocm_call_profile_t;
 
 /** Copies the profile of the most recent call made through `engine` (any of the four engine handle types). */

@@ -53,7 +53,7 @@ class CallProfile(ctypes.Structure):
         ("kernel_milliseconds", ctypes.c_double), ("host_milliseconds", ctypes.c_double),
         ("cells", ctypes.c_uint64), ("pairs", ctypes.c_uint64), ("algorithmic_bytes", ctypes.c_uint64),
         ("unique_bytes", ctypes.c_uint64), ("launches", ctypes.c_uint32), ("longest_query", ctypes.c_uint32),
-        ("longest_candidate", ctypes.c_uint32), ("tier", ctypes.c_uint32), ("transposed", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+        ("longest_candidate", ctypes.c_uint32), ("tier", ctypes.c_uint32), ("transposed", ctypes.c_uint32), ("cell_bits", ctypes.c_uint32),
     ]
 
 

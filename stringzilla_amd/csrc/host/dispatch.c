@@ -475,7 +475,7 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
     /* ---- launches, bracketed by the engine's event pair on the scope's stream ---- */
     error = hipEventRecord(engine->event_start, stream);
     if (error != hipSuccess) return szs_report_hip(error, error_message);
-    uint32_t launches = 0;
+    uint32_t launches = 0, cell_bits = 0;
     if (tier == SZS_TIER_SYSTOLIC) { /* one launch for the whole cross-product, whatever the planner's groups */
         int const launch_error = szs_hip_systolic_scores(
             objective, !engine->is_linear, (szs_cost_model_t const *)engine->device_model.pointer,
@@ -483,7 +483,7 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
             (int64_t *)device_results, device_stride, layout, engine->device_systolic.pointer,
             engine->device_boundary.pointer, engine->systolic_epoch, stream);
         if (launch_error) return szs_report_hip((hipError_t)launch_error, error_message);
-        ++launches;
+        ++launches, cell_bits = 32;
     }
     if (tier == SZS_TIER_MYERS_CHAIN) {
         int const launch_error = szs_hip_myers_chain(device_query_refs, kq_count, device_candidate_refs, kc_count,
@@ -504,20 +504,24 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
             launch_error = szs_hip_levenshtein_myers(group->variant, device_query_refs + group->first, group->count,
                                                      device_candidate_refs, kc_count, (uint64_t *)device_results,
                                                      device_stride, layout, stream);
-        else if (packed)
+        else if (packed) {
+            cell_bits = 16;
             launch_error = szs_hip_weighted_packed_scores(packed_local, !engine->is_linear, classes,
                                                           (szs_cost_model_t const *)engine->device_model.pointer,
                                                           device_query_refs + group->first, group->count,
                                                           device_candidate_refs, kc_count, plan.longest_candidate,
                                                           (int64_t *)device_results, device_stride, layout,
                                                           engine->device_boundary.pointer, stream);
-        else
+        }
+        else {
+            cell_bits = 32;
             launch_error = szs_hip_weighted_scores(objective, !engine->is_linear, narrow,
                                                    (szs_cost_model_t const *)engine->device_model.pointer,
                                                    device_query_refs + group->first, group->count,
                                                    device_candidate_refs, kc_count, plan.longest_candidate,
                                                    (int64_t *)device_results, device_stride, layout,
                                                    engine->device_boundary.pointer, stream);
+        }
         if (launch_error) return szs_report_hip((hipError_t)launch_error, error_message);
         ++launches;
     }
@@ -561,6 +565,7 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
     profile->launches = launches;
     profile->tier = (uint32_t)tier;
     profile->transposed = (uint32_t)transposed;
+    profile->cell_bits = cell_bits;
     profile->longest_query = q_longest, profile->longest_candidate = c_longest;
     profile->host_milliseconds = now_milliseconds() - call_started;
     SZS_PHASE(5);

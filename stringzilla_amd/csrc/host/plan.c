@@ -141,6 +141,10 @@ double szs_plan_estimate(unsigned bit_parallel_limit, int bit_parallel_chain, in
     double const fill = lane_waves >= 2 * simds ? 1.0 : lane_waves <= simds ? 0.5 : lane_waves / (2 * simds);
     double const lane_rate = (bit_parallel ? 0.85 : 1.0 / ((affine ? 7.0 : 3.0) * 4.2)) * fill;
     double lanes_cycles = query_symbols * mean_candidate * waves_per_query * scale / lane_rate / (lane_waves < simds ? lane_waves : simds);
+    /* A workgroup is four wavefronts; with fewer than 193 candidates some of them have no pair at all, and the live ones
+     * of neighbouring workgroups do not spread evenly over the SIMDs (4096 x 1 x 128 B measured 2x the model). */
+    double const live_waves = waves_per_query < 4 ? waves_per_query : 4;
+    lanes_cycles *= 1.0 + 0.5 * (1.0 - live_waves / 4.0);
     double const largest_pair = (double)longest_query * longest_candidate / lane_rate;
     if (largest_pair > lanes_cycles) lanes_cycles = largest_pair;
 

@@ -180,6 +180,55 @@ def test_alignment_wide_and_narrow_boundaries(gpu, oracle):
         assert np.array_equal(engine(queries, candidates, device=gpu), expected), gaps
 
 
+@contextlib.contextmanager
+def forced_env(name, value):
+    previous = os.environ.get(name)
+    os.environ[name] = value
+    try:
+        yield
+    finally:
+        if previous is None:
+            del os.environ[name]
+        else:
+            os.environ[name] = previous
+
+
+@pytest.mark.parametrize("kind", ["needleman_wunsch", "smith_waterman"])
+def test_packed_and_wide_cells_agree(gpu, oracle, kind):
+    """Class-table engines whose values provably fit 16 bits run hip/weighted_packed.hip (two cells per operation, the
+    lower half of a strip one column behind the upper one); `SZS_ROCM_PACKED=0` pins the 32-bit kernel.  Both must give
+    the oracle's matrix: every strip shape (1..70 query rows: empty lower half, ragged last strip), candidates shorter
+    than one batch, empties, a 32-class asymmetric table (largest pair profile), symmetric mode, swapped sides."""
+    rng = random.Random(77 if kind == "needleman_wunsch" else 78)
+    asym_map = np.array([rng.randint(0, 31) for _ in range(256)], dtype=np.uint8)
+    asym_map[:32] = np.arange(32, dtype=np.uint8)  # every class in use
+    asym_tab = np.array([[rng.randint(-9, 9) for _ in range(32)] for _ in range(32)], dtype=np.int8)
+    cls = szs.NeedlemanWunschScores if kind == "needleman_wunsch" else szs.SmithWatermanScores
+    for (byte_to_class, class_costs), alphabet in [(matrices.blosum62(), b"ARNDCQEGHILKMFPSTWYVBZX*"), (matrices.nuc44(), b"ACGTN"),
+                                                   ((asym_map, asym_tab), bytes(range(256)))]:
+        for gaps in [(-4, -4), (-5, -1), (-1, -3)]:
+            engine = cls(byte_to_class, class_costs, open=gaps[0], extend=gaps[1], capabilities=gpu)
+            queries = [bytes(rng.choice(alphabet) for _ in range(length)) for length in list(range(0, 36)) + [47, 48, 49, 63, 64, 65, 70]]
+            candidates = _rand(rng, 300, 0, 90, alphabet) + _rand(rng, 40, 0, 3, alphabet)
+            expected = getattr(oracle, kind)(queries, candidates, byte_to_class, class_costs, *gaps)
+            expected_sym = getattr(oracle, kind)(queries, None, byte_to_class, class_costs, *gaps)
+            for pinned, bits in [("1", 16), ("0", 32)]:
+                with forced_env("SZS_ROCM_PACKED", pinned), forced_tier("lanes"):
+                    assert np.array_equal(engine(queries, candidates, device=gpu), expected), (kind, gaps, pinned)
+                    assert engine.last_call_profile().cell_bits == bits
+                    assert np.array_equal(engine(queries, device=gpu), expected_sym), (kind, gaps, pinned, "symmetric")
+                    with forced_env("SZS_ROCM_SWAP", "1"):
+                        assert np.array_equal(engine(queries, candidates, device=gpu), expected), (kind, gaps, pinned, "swapped")
+                        assert engine.last_call_profile().transposed == 1 and engine.last_call_profile().cell_bits == bits
+    # beyond 16 bits the packed kernel is not an option: reach (1600 + 1600 + 3) x 11 > 32000
+    engine = cls(*matrices.blosum62(), open=-11, extend=-2, capabilities=gpu)
+    queries, candidates = _rand(rng, 2, 1500, 1600, b"ARNDCQEGHILKMFPSTWYV"), _rand(rng, 65, 1500, 1600, b"ARNDCQEGHILKMFPSTWYV")
+    expected = getattr(oracle, kind)(queries, candidates, *matrices.blosum62(), -11, -2)
+    with forced_tier("lanes"):
+        assert np.array_equal(engine(queries, candidates, device=gpu), expected)
+        assert engine.last_call_profile().cell_bits == (32 if kind == "needleman_wunsch" else 16)
+
+
 def test_cross_product_shapes(gpu, oracle):
     """1xN, Nx1, 1x1, ragged with empties, rectangular, empty sides (test/similarities.cuh:1283-1326)."""
     rng = random.Random(5)
