@@ -193,7 +193,8 @@ def main():
         # scripts/pmc_summary.py as MI355X_MICROARCH.md prescribes.  Committed, not collected inside this process.
         traffic, traffic_note = args.hbm_traffic_bytes, "from --hbm-traffic-bytes"
         if traffic is None and args.config == 2:
-            summary = (_profile_json("pmc_summary.json") or {}).get("levenshtein_myers_short_kernel")
+            summary = next((counters for name, counters in (_profile_json("pmc_summary.json") or {}).items()
+                            if name.startswith("levenshtein_myers_short_kernel")), None)  # the name carries template arguments
             if summary and "hbm_fetch_bytes_raw" in summary and "hbm_write_bytes_raw" in summary:
                 traffic = summary["hbm_fetch_bytes_raw"] + summary["hbm_write_bytes_raw"]
                 traffic_note = ("profiles/r01/pmc_summary.json: FETCH_SIZE*1024 + WRITE_SIZE*1024 per launch (raw; the x2 "

@@ -43,6 +43,19 @@ def forced_tier(name):
             os.environ["SZS_ROCM_TIER"] = previous
 
 
+@contextlib.contextmanager
+def forced_env(name, value):
+    previous = os.environ.get(name)
+    os.environ[name] = value
+    try:
+        yield
+    finally:
+        if previous is None:
+            del os.environ[name]
+        else:
+            os.environ[name] = previous
+
+
 def _unhex(items):
     return [bytes.fromhex(x) for x in items]
 
@@ -178,19 +191,6 @@ def test_alignment_wide_and_narrow_boundaries(gpu, oracle):
         engine = szs.SmithWatermanScores(*matrices.nuc44(), open=gaps[0], extend=gaps[1], capabilities=gpu)
         expected = oracle.smith_waterman(queries, candidates, *matrices.nuc44(), *gaps)
         assert np.array_equal(engine(queries, candidates, device=gpu), expected), gaps
-
-
-@contextlib.contextmanager
-def forced_env(name, value):
-    previous = os.environ.get(name)
-    os.environ[name] = value
-    try:
-        yield
-    finally:
-        if previous is None:
-            del os.environ[name]
-        else:
-            os.environ[name] = previous
 
 
 @pytest.mark.parametrize("kind", ["needleman_wunsch", "smith_waterman"])
@@ -637,6 +637,27 @@ def test_myers_chain_fuzz(gpu, oracle):
             queries, candidates = _rand(rng, 3, 100, 2500, b"ACGT"), _rand(rng, 5, 100, 5000, b"ACGT")
             assert np.array_equal(engine(queries, candidates, device=gpu), oracle.levenshtein(queries, candidates))
             assert engine.last_call_profile().transposed == 1
+
+
+@pytest.mark.parametrize("waves", ["4", "8", "16"])
+def test_myers_chain_shares_one_mask_table_between_candidates(gpu, oracle, waves):
+    """A workgroup of hip/myers_chain.hip scores 4 / 8 / 16 candidates against ONE query band (one 64 KB match-mask table):
+    candidate counts that do not fill the last workgroup, queries of one and of several bands in one batch, symmetric
+    calls (wavefronts above the diagonal leave after the table is built), and the launcher's own choice at a size where
+    it picks 16."""
+    rng = random.Random(int(waves))
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+    with forced_tier("chain"), forced_env("SZS_ROCM_CHAIN_WAVES", waves), forced_swap("0"):
+        for q_count, c_count, lo, hi in [(3, 1, 10, 300), (5, 13, 0, 2300), (9, 37, 1900, 2200), (2, 70, 4000, 4300)]:
+            queries, candidates = _rand(rng, q_count, lo, hi, b"ACGT"), _rand(rng, c_count, lo, hi, b"ACGTN")
+            assert np.array_equal(engine(queries, candidates, device=gpu), oracle.levenshtein(queries, candidates)), (q_count, c_count)
+            assert engine.last_call_profile().tier == 2
+        queries = _rand(rng, 21, 1500, 2600, b"ACGT")
+        assert np.array_equal(engine(queries, device=gpu), oracle.levenshtein(queries, None))
+    if waves == "16":  # 70 x 70 x 2 bands = 9800 wavefronts: the launcher goes to 16 per workgroup by itself
+        queries, candidates = _rand(rng, 70, 2100, 2300, b"ACGT"), _rand(rng, 70, 2100, 2300, b"ACGT")
+        with forced_tier("chain"), forced_swap("0"):
+            assert np.array_equal(engine(queries, candidates, device=gpu), oracle.levenshtein(queries, candidates))
 
 
 def test_systolic_single_very_long_pair(gpu, oracle):
