@@ -59,6 +59,17 @@ int szs_hip_levenshtein_myers_runes(szs_string_ref_t const *queries, uint32_t qu
                                     uint64_t results_row_stride, int symmetric, void *stream);
 
 /**
+ *  Codepoint queries of 257 to 2048 runes: `words` is a long launch variant of szs_hip_levenshtein_myers_round_words()
+ *  (10 ... 64) and every query of the launch fits it.  Peq rows are keyed by dense rune ids in dynamic LDS (up to 160 KB
+ *  per workgroup); runes beyond the table's capacity are matched against the pattern directly, so the result is exact
+ *  whatever the alphabet.  Returns hipErrorNotSupported when the device refuses that much LDS - the caller then scores
+ *  the group with the rune-keyed DP kernel (szs_hip_weighted_scores, szs_objective_distance_runes_k).
+ */
+int szs_hip_levenshtein_myers_runes_long(unsigned words, szs_string_ref_t const *queries, uint32_t queries_count,
+                                         szs_string_ref_t const *candidates, uint32_t candidates_count, uint64_t *results,
+                                         uint64_t results_row_stride, int symmetric, void *stream);
+
+/**
  *  Transcodes `count` UTF-8 strings (byte refs) into UTF-32 with the value contract of `sz_rune_decode_unchecked`:
  *  string i's runes land at `runes + rune_starts[i]`, its rune count in `rune_counts[i]`; `*any_multibyte` is OR-ed
  *  with 1 when any string holds a byte >= 0x80 (the caller zeroes it).  One thread per string.

@@ -35,6 +35,8 @@
  */
 #include "device_common.hpp"
 
+#include <cstdlib>
+
 namespace szs_hip {
 
 #ifndef SZS_MYERS_SHORT_TEXT_DWORDS
@@ -343,6 +345,213 @@ __global__ __launch_bounds__(256, SZS_MYERS_SHORT_WAVES) void levenshtein_myers_
 #undef SZS_MYERS_BODY
 }
 
+/* ---- codepoint queries of more than 256 runes ----------------------------------------------------------------------
+ *
+ *  The short rune kernel keys Peq by the SLOT of a 512-slot rune table - fine for at most 256 distinct runes and 8 words.
+ *  A query of 2048 runes may hold 2048 distinct ones, and 4096 slots x 64 words would be a megabyte.  So here the runes
+ *  of the pattern get DENSE ids (1, 2, ... in the order the slots happen to be claimed) and Peq has one row per id, up to
+ *  `id_capacity` rows - whatever fits the LDS the launch was given (text in any alphabet repeats its runes: config 5's
+ *  1560-rune strings hold ~400 distinct ones).  Id 0 is "not in the pattern" (an all-zero row).  Runes beyond the
+ *  capacity get the OVERFLOW id: their match mask is rebuilt from the pattern itself, column by column, only by the
+ *  lanes that meet one - slow (a pass over the pattern per column) but exact, rare, and nobody else's business: no
+ *  failure flag, no second launch.
+ *
+ *  Dynamic LDS: peq[(id_capacity + 1) rows, laid out like peq_layout] | keys[slots] | ids[slots] (u16).
+ */
+constexpr u32 rune_overflow_id_k = 0xFFFFu;
+
+template <int words_>
+__device__ __forceinline__ void myers_long_runes_workgroup(u32 *lds, u32 rune_slots, u32 id_capacity, szs_string_ref_t const query,
+                                                           szs_string_ref_t const *__restrict__ candidates,
+                                                           u32 candidates_count, u32 candidate_block,
+                                                           u64 *__restrict__ results, u64 results_row_stride, int symmetric) {
+    constexpr int chunks = (words_ + 3) / 4;
+    u32 const rows = id_capacity + 1; // row 0: runes the pattern does not contain
+    u32 *const peq = lds;
+    u32 *const keys = peq + (size_t)chunks * rows * 4;
+    uint16_t *const ids = reinterpret_cast<uint16_t *>(keys + rune_slots);
+    __shared__ u32 claimed_ids;
+    u32 const slot_mask = rune_slots - 1, hash_shift = 32u - (u32)__builtin_ctz(rune_slots);
+    auto dword_index = [&](u32 row, u32 w) -> u32 { return ((w / 4) * rows + row) * 4 + (w % 4); };
+
+    u32 const query_length = query.length;
+    u32 const pad = 32u * words_ - query_length; // phantom low rows
+    u32 const *const pattern = reinterpret_cast<u32 const *>(query.address);
+
+    // ---- rune table and Peq: claim slots, number them, scatter the pattern's bits
+    for (u32 i = threadIdx.x; i < (u32)chunks * rows * 4; i += 256) peq[i] = 0;
+    for (u32 i = threadIdx.x; i < rune_slots; i += 256) keys[i] = rune_slot_empty_k, ids[i] = 0;
+    if (threadIdx.x == 0) claimed_ids = 0;
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < query_length; i += 256) {
+        u32 const rune = pattern[i];
+        u32 slot = (rune * 2654435761u) >> hash_shift; // at most 32 * words_ distinct runes in twice as many slots
+        for (;;) {
+            u32 const previous = atomicCAS(&keys[slot], rune_slot_empty_k, rune);
+            if (previous == rune_slot_empty_k || previous == rune) break;
+            slot = (slot + 1) & slot_mask;
+        }
+    }
+    __syncthreads();
+    for (u32 slot = threadIdx.x; slot < rune_slots; slot += 256)
+        if (keys[slot] != rune_slot_empty_k) {
+            u32 const id = atomicAdd(&claimed_ids, 1u) + 1;
+            ids[slot] = (uint16_t)(id <= id_capacity ? id : rune_overflow_id_k);
+        }
+    __syncthreads();
+    auto id_of = [&](u32 rune) -> u32 { // 0: not in the pattern
+        u32 slot = (rune * 2654435761u) >> hash_shift;
+        for (;;) {
+            u32 const key = keys[slot];
+            if (key == rune) return ids[slot];
+            if (key == rune_slot_empty_k) return 0;
+            slot = (slot + 1) & slot_mask;
+        }
+    };
+    for (u32 i = threadIdx.x; i < query_length; i += 256) {
+        u32 const id = id_of(pattern[i]), position = pad + i;
+        if (id != rune_overflow_id_k) atomicOr(&peq[dword_index(id, position >> 5)], 1u << (position & 31));
+    }
+    __syncthreads();
+
+    // ---- this lane's candidate
+    u32 const candidate_slot = candidate_block * SZS_CANDIDATES_PER_WORKGROUP + threadIdx.x;
+    bool live = candidate_slot < candidates_count;
+    szs_string_ref_t candidate = {0, 0, 0};
+    if (live) candidate = candidates[candidate_slot];
+    if ((symmetric & SZS_LAYOUT_SYMMETRIC) && candidate.index > query.index) live = false;
+    u32 const text_length = live ? candidate.length : 0;
+    u32 const longest_in_wave = wave_max_u32(text_length);
+    u32 const shortest_in_wave = ~wave_max_u32(live ? ~text_length : 0u);
+
+    u32 vp[words_], vn[words_];
+#pragma unroll
+    for (int w = 0; w < words_; ++w) {
+        u32 const first_bit = 32u * w;
+        vp[w] = first_bit >= pad ? ~0u : (first_bit + 32u <= pad ? 0u : (~0u << (pad - first_bit)));
+        vn[w] = 0;
+    }
+
+    auto take = [&](u32 rune) {
+        u32 eq[words_];
+        u32 const id = id_of(rune);
+        if (id != rune_overflow_id_k) {
+            uint4 const *table = reinterpret_cast<uint4 const *>(peq);
+#pragma unroll
+            for (int chunk = 0; chunk < chunks; ++chunk) {
+                uint4 const row = table[chunk * rows + id];
+                if (chunk * 4 + 0 < words_) eq[chunk * 4 + 0] = row.x;
+                if (chunk * 4 + 1 < words_) eq[chunk * 4 + 1] = row.y;
+                if (chunk * 4 + 2 < words_) eq[chunk * 4 + 2] = row.z;
+                if (chunk * 4 + 3 < words_) eq[chunk * 4 + 3] = row.w;
+            }
+        }
+        else { // a rune past the table's capacity: its mask, straight from the pattern
+#pragma unroll
+            for (int w = 0; w < words_; ++w) {
+                u32 bits = 0;
+#pragma unroll 1
+                for (u32 bit = 0; bit < 32; ++bit) {
+                    u32 const position = 32u * w + bit;
+                    if (position >= pad && pattern[position - pad] == rune) bits |= 1u << bit;
+                }
+                eq[w] = bits;
+            }
+        }
+        myers_column<words_>(vp, vn, eq);
+    };
+
+    // ---- codepoints: one aligned dword per column, two columns per iteration, loaded one iteration early
+    u32 const *const runes = reinterpret_cast<u32 const *>(candidate.address);
+    auto rune_at = [&](u32 index) -> u32 { return index < text_length ? runes[index] : 0u; };
+    u32 column = 0;
+    if (2 <= shortest_in_wave && longest_in_wave) {
+        u32 ahead[2] = {rune_at(0), rune_at(1)};
+        for (; column + 2 <= shortest_in_wave; column += 2) {
+            u32 const first = ahead[0], second = ahead[1];
+            ahead[0] = rune_at(column + 2), ahead[1] = rune_at(column + 3);
+            take(first), take(second);
+        }
+    }
+#pragma unroll 1
+    for (; column < longest_in_wave; ++column)
+        if (column < text_length) take(runes[column]);
+
+    if (live) {
+        u32 distance = text_length;
+#pragma unroll
+        for (int w = 0; w < words_; ++w) distance += (u32)__builtin_popcount(vp[w]) - (u32)__builtin_popcount(vn[w]);
+        bool const transposed = (symmetric & SZS_LAYOUT_TRANSPOSED) != 0;
+        u64 const row = transposed ? candidate.index : query.index, column_of = transposed ? query.index : candidate.index;
+        results[row * results_row_stride + column_of] = distance;
+        if ((symmetric & SZS_LAYOUT_SYMMETRIC) && candidate.index != query.index)
+            results[column_of * results_row_stride + row] = distance;
+    }
+}
+
+template <int words_>
+__global__ __launch_bounds__(256) void levenshtein_myers_long_runes_kernel(szs_string_ref_t const *__restrict__ queries,
+                                                                            szs_string_ref_t const *__restrict__ candidates,
+                                                                            u32 candidates_count, u32 candidate_blocks,
+                                                                            u64 *__restrict__ results, u64 results_row_stride,
+                                                                            int symmetric, u32 rune_slots, u32 id_capacity) {
+    extern __shared__ __attribute__((aligned(16))) u32 rune_lds[];
+    u32 query_slot, candidate_block;
+    myers_work_item(candidate_blocks, query_slot, candidate_block);
+    myers_long_runes_workgroup<words_>(rune_lds, rune_slots, id_capacity, queries[query_slot], candidates, candidates_count,
+                                       candidate_block, results, results_row_stride, symmetric);
+}
+
+/** LDS plan of one long rune launch: slots = twice the runes a query of `words` words can hold; as many Peq rows as the
+ *  budget leaves - two workgroups per CU (80 KB each) when that still numbers 512 runes, else one (all 160 KB). */
+static bool rune_lds_plan(unsigned words, u32 &rune_slots, u32 &id_capacity, size_t &bytes) {
+    rune_slots = 1;
+    while (rune_slots < 64u * words) rune_slots *= 2;
+    size_t const table_bytes = (size_t)rune_slots * (sizeof(u32) + sizeof(uint16_t)), row_bytes = (size_t)((words + 3) / 4) * 16;
+    size_t const most_runes = 32u * words;
+    char const *const forced_text = std::getenv("SZS_ROCM_RUNE_IDS"); // a testing aid: shrinks the table so that runes overflow it
+    long const forced = forced_text ? std::atol(forced_text) : 0;
+    size_t const shared = ((size_t)80 << 10) - 1024, whole = ((size_t)160 << 10) - 1024; // a little static LDS on top
+    size_t capacity = shared > table_bytes + row_bytes ? (shared - table_bytes) / row_bytes - 1 : 0;
+    if (capacity < 512 && capacity < most_runes) capacity = whole > table_bytes + row_bytes ? (whole - table_bytes) / row_bytes - 1 : 0;
+    if (capacity > most_runes) capacity = most_runes;
+    if (capacity > 0xFFF0) capacity = 0xFFF0;
+    if (forced > 0 && (size_t)forced < capacity) capacity = (size_t)forced;
+    if (capacity < 1) return false;
+    id_capacity = (u32)capacity;
+    bytes = (capacity + 1) * row_bytes + table_bytes;
+    return true;
+}
+
+template <int words_>
+static int launch_long_runes(szs_string_ref_t const *queries, u32 queries_count, szs_string_ref_t const *candidates,
+                             u32 candidates_count, u64 *results, u64 stride, int symmetric, hipStream_t stream) {
+    u32 rune_slots = 0, id_capacity = 0;
+    size_t bytes = 0;
+    if (!rune_lds_plan(words_, rune_slots, id_capacity, bytes)) return (int)hipErrorNotSupported;
+    static int granted = 0; // per width: has this much dynamic LDS been granted to the kernel?
+    if (!granted) {
+        hipError_t const error = hipFuncSetAttribute(reinterpret_cast<void const *>(levenshtein_myers_long_runes_kernel<words_>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)160 << 10) - 1024));
+        if (error != hipSuccess) {
+            (void)hipGetLastError();
+            return (int)hipErrorNotSupported; // the host falls back to the rune-keyed DP kernel
+        }
+        granted = 1;
+    }
+    u32 const candidate_blocks = (candidates_count + SZS_CANDIDATES_PER_WORKGROUP - 1) / SZS_CANDIDATES_PER_WORKGROUP;
+    u32 const queries_per_launch = candidate_blocks ? (1u << 30) / candidate_blocks : queries_count;
+    for (u32 first = 0; first < queries_count; first += queries_per_launch) {
+        u32 const batch = queries_count - first < queries_per_launch ? queries_count - first : queries_per_launch;
+        hipLaunchKernelGGL(levenshtein_myers_long_runes_kernel<words_>, dim3(batch * candidate_blocks), dim3(256), bytes, stream,
+                           queries + first, candidates, candidates_count, candidate_blocks, results, stride, symmetric,
+                           rune_slots, id_capacity);
+        hipError_t const error = hipGetLastError();
+        if (error != hipSuccess) return (int)error;
+    }
+    return 0;
+}
+
 template <typename kernel_t>
 static int launch_myers(kernel_t kernel, szs_string_ref_t const *queries, u32 queries_count,
                         szs_string_ref_t const *candidates, u32 candidates_count, u64 *results, u64 stride, int symmetric,
@@ -397,6 +606,29 @@ extern "C" int szs_hip_levenshtein_myers_runes(szs_string_ref_t const *queries, 
     if (!queries_count || !candidates_count) return 0;
     return launch_myers(levenshtein_myers_short_kernel<true>, queries, queries_count, candidates, candidates_count, results,
                         results_row_stride, symmetric, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int szs_hip_levenshtein_myers_runes_long(unsigned words, szs_string_ref_t const *queries, uint32_t queries_count,
+                                                    szs_string_ref_t const *candidates, uint32_t candidates_count,
+                                                    uint64_t *results, uint64_t results_row_stride, int symmetric,
+                                                    void *stream) {
+    using namespace szs_hip;
+    if (!queries_count || !candidates_count) return 0;
+    hipStream_t const s = static_cast<hipStream_t>(stream);
+#define SZS_MYERS_RUNES_CASE(W)                                                                                        \
+    case W: return launch_long_runes<W>(queries, queries_count, candidates, candidates_count, results, results_row_stride, symmetric, s);
+    switch (words) {
+        SZS_MYERS_RUNES_CASE(10)
+        SZS_MYERS_RUNES_CASE(12)
+        SZS_MYERS_RUNES_CASE(16)
+        SZS_MYERS_RUNES_CASE(20)
+        SZS_MYERS_RUNES_CASE(24)
+        SZS_MYERS_RUNES_CASE(32)
+        SZS_MYERS_RUNES_CASE(48)
+        SZS_MYERS_RUNES_CASE(64)
+    default: return (int)hipErrorInvalidValue;
+    }
+#undef SZS_MYERS_RUNES_CASE
 }
 
 /** The launch variant for a query of `words` 32-bit words: SZS_MYERS_SHORT_WORDS for everything the mixed-width kernel

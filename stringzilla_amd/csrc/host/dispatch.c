@@ -333,7 +333,7 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
     int const use_myers = engine->is_unit_cost && (engine->family == szs_family_levenshtein_k ||
                                                    engine->family == szs_family_levenshtein_utf8_k);
     int const maximise = engine->family == szs_family_needleman_wunsch_k || engine->family == szs_family_smith_waterman_k;
-    unsigned const myers_words = !use_myers ? 0 : runes ? SZS_MYERS_SHORT_WORDS : SZS_MYERS_MAX_WORDS;
+    unsigned const myers_words = !use_myers ? 0 : SZS_MYERS_MAX_WORDS; /* bytes and codepoints alike: up to 2048 symbols */
 
     /* ---- orientation and tier.  Every kernel puts ONE side on workgroups / band chains (its "queries") and the other
      * on lanes / columns (its "candidates"); which real side plays which role is free - gap costs apply to both strings
@@ -443,7 +443,7 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
     }
 
     /* Weighted kernels need the cost model and a strip-boundary workspace on the device. */
-    int needs_weighted = !use_myers || tier == SZS_TIER_SYSTOLIC;
+    int needs_weighted = !use_myers || tier == SZS_TIER_SYSTOLIC || runes; /* runes: the fallback of the long rune kernels */
     if (tier == SZS_TIER_MYERS_CHAIN) { /* no cost model; its parked deltas live in the boundary buffer like the systolic rows */
         status = szs_buffer_reserve(&engine->device_boundary, szs_memory_device_k, device, systolic_parked_bytes, error_message);
         if (status != sz_success_k) return status;
@@ -496,10 +496,24 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
     for (unsigned g = 0; tier == SZS_TIER_LANES && g < plan.groups_count; ++g) {
         szs_plan_group_t const *group = &plan.groups[g];
         int launch_error;
-        if (group->variant && runes)
-            launch_error = szs_hip_levenshtein_myers_runes(device_query_refs + group->first, group->count,
-                                                           device_candidate_refs, kc_count, (uint64_t *)device_results,
-                                                           device_stride, layout, stream);
+        if (group->variant && runes) {
+            launch_error = group->variant == SZS_MYERS_SHORT_WORDS
+                               ? szs_hip_levenshtein_myers_runes(device_query_refs + group->first, group->count,
+                                                                 device_candidate_refs, kc_count, (uint64_t *)device_results,
+                                                                 device_stride, layout, stream)
+                               : szs_hip_levenshtein_myers_runes_long(group->variant, device_query_refs + group->first,
+                                                                      group->count, device_candidate_refs, kc_count,
+                                                                      (uint64_t *)device_results, device_stride, layout, stream);
+            if (launch_error == (int)hipErrorNotSupported) { /* no LDS for the rune table: the rune-keyed DP kernel */
+                cell_bits = 32;
+                launch_error = szs_hip_weighted_scores(objective, !engine->is_linear, 0,
+                                                       (szs_cost_model_t const *)engine->device_model.pointer,
+                                                       device_query_refs + group->first, group->count,
+                                                       device_candidate_refs, kc_count, plan.longest_candidate,
+                                                       (int64_t *)device_results, device_stride, layout,
+                                                       engine->device_boundary.pointer, stream);
+            }
+        }
         else if (group->variant)
             launch_error = szs_hip_levenshtein_myers(group->variant, device_query_refs + group->first, group->count,
                                                      device_candidate_refs, kc_count, (uint64_t *)device_results,

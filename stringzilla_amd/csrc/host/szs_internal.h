@@ -162,7 +162,7 @@ typedef struct szs_plan_t {
 /**
  *  Fills `candidate_refs` with the candidates sorted by ascending length (stable), and `query_refs` grouped by kernel
  *  variant, longest first.  `myers` = widest bit-vector (in 32-bit words) a bit-parallel kernel exists for - 0 for the
- *  weighted engines, SZS_MYERS_MAX_WORDS for bytes, SZS_MYERS_SHORT_WORDS for codepoints; longer queries get variant 0
+ *  weighted engines, SZS_MYERS_MAX_WORDS for bytes and codepoints; longer queries get variant 0
  *  (scored by the weighted kernel).
  *  Lengths and addresses are parallel arrays.  Scratch `keys` must hold max(q, c) uint32_t.
  */

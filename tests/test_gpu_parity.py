@@ -504,6 +504,35 @@ def test_utf8_fuzz(gpu, oracle, costs):
     assert np.array_equal(engine(strings, device=gpu), oracle.levenshtein(strings, None, *costs))
 
 
+def test_utf8_long_queries_stay_bit_parallel(gpu, oracle):
+    """Queries of 257..2048 runes take the long rune kernels (dense rune ids in dynamic LDS): every instantiated width,
+    texts whose distinct runes exceed the id table (the overflow runes are matched against the pattern directly) both
+    naturally - 1500 distinct CJK runes in one query - and with the table shrunk to 5 ids, symmetric calls, empties."""
+    rng = random.Random(2049)
+    small = "abcdefghij klmno\u00e9\u00f1\u0436\u0444\u4e2d\u6587\U0001F600"
+    wide = [chr(c) for c in range(0x4E00, 0x4E00 + 3000)]
+    def text(alphabet, runes):
+        return "".join(rng.choice(alphabet) for _ in range(runes)).encode("utf-8")
+    engine = szs.LevenshteinDistancesUTF8(capabilities=gpu)
+    queries = [text(small, n) for n in (257, 300, 320, 321, 384, 385, 500, 512, 513, 640, 700, 768, 769, 1000, 1024, 1025, 1500, 1536, 1537, 2000, 2048)]
+    candidates = [text(small, rng.randint(0, 2100)) for _ in range(30)] + [b"", text(small, 1), text(wide, 900)]
+    expected = oracle.levenshtein_utf8(queries, candidates)
+    with forced_tier("lanes"), forced_swap("0"):
+        assert np.array_equal(engine(queries, candidates, device=gpu), expected)
+        assert engine.last_call_profile().cell_bits == 0  # no DP kernel ran: bit-parallel all the way
+        with forced_env("SZS_ROCM_RUNE_IDS", "5"):
+            assert np.array_equal(engine(queries, candidates, device=gpu), expected)
+        rich = [text(wide, n) for n in (300, 900, 1500, 2048)] + [text(small, 1200)]
+        others = [text(wide, rng.randint(200, 2048)) for _ in range(10)] + rich[:2]
+        assert np.array_equal(engine(rich, others, device=gpu), oracle.levenshtein_utf8(rich, others))
+        assert np.array_equal(engine(rich, device=gpu), oracle.levenshtein_utf8(rich, None))
+    # beyond 2048 runes the rune-keyed DP recurrences take over
+    longer = [text(small, 2049), text(small, 2500)]
+    with forced_tier("lanes"), forced_swap("0"):  # (left alone, the planner would put the shorter side on the bit-vectors)
+        assert np.array_equal(engine(longer, candidates[:9], device=gpu), oracle.levenshtein_utf8(longer, candidates[:9]))
+        assert engine.last_call_profile().cell_bits == 32
+
+
 def test_utf8_malformed_bytes_follow_the_unchecked_contract(gpu, oracle):
     """`sz_rune_decode_unchecked`: stray continuation bytes, unvalidated tails, over-long leads - never an error."""
     engine = szs.LevenshteinDistancesUTF8(capabilities=gpu)
