@@ -59,6 +59,16 @@ int szs_hip_levenshtein_myers_runes(szs_string_ref_t const *queries, uint32_t qu
                                     uint64_t results_row_stride, int symmetric, void *stream);
 
 /**
+ *  Byte queries of more than 2048 bytes, unit costs: the same recurrence in horizontal strips of 2048 rows; the deltas
+ *  under a strip's last row (one bit pair per text column) are parked in `workspace` - szs_hip_levenshtein_myers_banded_bytes()
+ *  bytes, sized by the RESIDENT workgroups - for the strip below.  Queries should arrive longest first.
+ */
+int szs_hip_levenshtein_myers_banded(szs_string_ref_t const *queries, uint32_t queries_count, szs_string_ref_t const *candidates,
+                                     uint32_t candidates_count, uint32_t longest_candidate, uint64_t *results,
+                                     uint64_t results_row_stride, int symmetric, void *workspace, void *stream);
+size_t szs_hip_levenshtein_myers_banded_bytes(uint32_t queries_count, uint32_t candidates_count, uint32_t longest_candidate);
+
+/**
  *  Codepoint queries of 257 to 2048 runes: `words` is a long launch variant of szs_hip_levenshtein_myers_round_words()
  *  (10 ... 64) and every query of the launch fits it.  Peq rows are keyed by dense rune ids in dynamic LDS (up to 160 KB
  *  per workgroup); runes beyond the table's capacity are matched against the pattern directly, so the result is exact

@@ -345,6 +345,211 @@ __global__ __launch_bounds__(256, SZS_MYERS_SHORT_WAVES) void levenshtein_myers_
 #undef SZS_MYERS_BODY
 }
 
+/* ---- byte queries of more than 2048 bytes: horizontal strips of 2048 rows --------------------------------------------
+ *
+ *  The reference's serial Myers is block-based and takes any length (serial.hpp:2223-2300); the 64-word register file of
+ *  a lane does not.  So a long pattern is cut into STRIPS of up to 64 words.  Inside a strip the add's carry ripples through
+ *  all 64 words as in every kernel above; BETWEEN strips only the horizontal deltas of the strip's last row cross - one
+ *  (+1, -1) bit pair per text column, Hyyro's block boundary (`Eq |= hn_in`, the shifted-in bits of HP / HN) - and they
+ *  are parked, 16 columns to a dword, in a per-workgroup array [dword][lane] in global memory, overwritten in place by
+ *  the next strip.  Phantom rows pad the FIRST strip (low bits), so every later strip is full and the pattern's last
+ *  row is bit 31 of the last word of the last strip.  distance = len(text) + sum over strips popcount(VP) - popcount(VN).
+ *  Persistent grid (the parked arrays are per resident workgroup); work items (query, candidate block), heaviest first.
+ */
+constexpr int banded_widest_k = 64;            // words of the widest strip: the register file of a lane
+constexpr size_t banded_header_bytes_k = 256;
+
+/** One column of one strip; `hp_in` / `hn_in` are the deltas entering the strip's first row as 0 / 1 values; the bit pair
+ *  leaving its last row comes back as hp | hn << 1. */
+template <int words_>
+__device__ __forceinline__ u32 myers_strip_column(u32 (&vp)[words_], u32 (&vn)[words_], u32 const (&eq)[words_], u32 hp_in,
+                                                  u32 hn_in) {
+    u32 carry = 0, hp_below = 0, hn_below = 0;
+#pragma unroll
+    for (int w = 0; w < words_; ++w) {
+        u32 const xv = eq[w] | vn[w];
+        u32 const eq_in = w == 0 ? (eq[w] | hn_in) : eq[w]; // a -1 entering from above acts like a match in the first row
+        u32 carry_out;
+        u32 const sum = __builtin_addc(eq_in & vp[w], vp[w], carry, &carry_out);
+        carry = carry_out;
+        u32 const d0 = (sum ^ vp[w]) | eq_in;
+        u32 const hp = vn[w] | ~(d0 | vp[w]);
+        u32 const hn = vp[w] & d0;
+        u32 const hp_shifted = w == 0 ? ((hp << 1) | hp_in) : __builtin_amdgcn_alignbit(hp, hp_below, 31);
+        u32 const hn_shifted = w == 0 ? ((hn << 1) | hn_in) : __builtin_amdgcn_alignbit(hn, hn_below, 31);
+        hp_below = hp, hn_below = hn;
+        vp[w] = hn_shifted | ~(xv | hp_shifted);
+        vn[w] = hp_shifted & xv;
+    }
+    return (hp_below >> 31) | ((hn_below >> 31) << 1);
+}
+
+/**
+ *  All strips of one (query, candidate block) item at a fixed strip width; returns this lane's sum over the strips of
+ *  popcount(VP) - popcount(VN).  Called by the whole workgroup (it synchronises around every Peq build).
+ */
+template <int words_>
+__device__ __forceinline__ i32 myers_strips(u32 *peq, szs_string_ref_t const query, u32 strips, text_stream_t const &text,
+                                            u32 text_length, u32 shortest_in_wave, u32 longest_in_wave, u32 *parked_mine) {
+    using layout = peq_layout<words_>;
+    constexpr u32 strip_rows = 32u * words_;
+    u32 const query_length = query.length;
+    u32 const pad = strips * strip_rows - query_length; // phantom low rows of the FIRST strip
+    u8 const *const pattern = reinterpret_cast<u8 const *>(query.address);
+    i32 delta_sum = 0;
+    for (u32 strip = 0; strip < strips; ++strip) {
+        bool const first_strip = strip == 0, last_strip = strip + 1 == strips;
+        // ---- Peq of this strip: bit b of the strip is pattern[strip * strip_rows + b - pad]
+        __syncthreads();
+        for (int i = threadIdx.x; i < layout::total_dwords; i += 256) peq[i] = 0;
+        __syncthreads();
+        for (u32 bit = threadIdx.x; bit < strip_rows; bit += 256) {
+            u32 const position = strip * strip_rows + bit;
+            if (position >= pad) atomicOr(&peq[layout::dword_index(pattern[position - pad], (int)(bit >> 5))], 1u << (bit & 31));
+        }
+        __syncthreads();
+
+        u32 vp[words_], vn[words_];
+#pragma unroll
+        for (int w = 0; w < words_; ++w) {
+            u32 const first_bit = 32u * w; // phantom rows (first strip only) hold VP = VN = 0
+            vp[w] = !first_strip || first_bit >= pad ? ~0u : (first_bit + 32u <= pad ? 0u : (~0u << (pad - first_bit)));
+            vn[w] = 0;
+        }
+
+        // Deltas of 16 columns per dword: `entering` was parked by the strip above, `leaving` collects this strip's.
+        u32 entering = 0, leaving = 0;
+        auto take = [&](u32 symbol, u32 column) {
+            u32 eq[words_];
+            load_match_masks<words_, byte_rows_k>(peq, symbol, eq);
+            u32 const slot = 2 * (column & 15u);
+            u32 const hp_in = first_strip ? 1u : (entering >> slot) & 1u; // DP row 0 grows by one per column
+            u32 const hn_in = first_strip ? 0u : (entering >> (slot + 1)) & 1u;
+            leaving |= myers_strip_column<words_>(vp, vn, eq, hp_in, hn_in) << slot;
+        };
+
+        u32 column = 0, dword = 0;
+        u32 raw_low = text.raw(0);
+        // ---- main loop: one text dword (4 columns) per iteration while EVERY live lane still has 4 columns
+        if (4 <= shortest_in_wave && longest_in_wave) {
+            u32 ahead = text.raw_clamped(1);
+            for (; column + 4 <= shortest_in_wave; column += 4, ++dword) {
+                u32 const symbols = text.splice(raw_low, ahead);
+                raw_low = ahead;
+                ahead = text.raw_clamped(dword + 2);
+                if ((dword & 3u) == 0) { // a new group of 16 columns
+                    if (!first_strip) entering = parked_mine[(u64)(dword / 4) * 256];
+                    leaving = 0;
+                }
+#pragma unroll
+                for (int step = 0; step < 4; ++step) take((symbols >> (8 * step)) & 0xFFu, column + step);
+                if ((dword & 3u) == 3 && !last_strip) parked_mine[(u64)(dword / 4) * 256] = leaving;
+            }
+        }
+        // A main loop that stops inside a group of 16 columns parks what it has: a lane whose text ends right there
+        // never gets to the tail, and a lane that does overwrites the dword with a superset of these bits.
+        if ((dword & 3u) != 0 && !last_strip) parked_mine[(u64)(dword / 4) * 256] = leaving;
+        // ---- ragged tail: every column predicated on this lane's own length
+        if (column < longest_in_wave) {
+            u32 next = text.raw(dword + 1);
+#pragma unroll 1
+            for (; column < longest_in_wave; column += 4, ++dword) {
+                u32 const after = text.raw(dword + 2);
+                u32 const symbols = text.splice(raw_low, next);
+                raw_low = next, next = after;
+                if ((dword & 3u) == 0) {
+                    if (!first_strip && column < text_length) entering = parked_mine[(u64)(dword / 4) * 256];
+                    leaving = 0;
+                }
+#pragma unroll
+                for (int step = 0; step < 4; ++step)
+                    if (column + step < text_length) take((symbols >> (8 * step)) & 0xFFu, column + step);
+                // a group is parked when it is complete or when the text ends inside it
+                if (!last_strip && column < text_length && ((dword & 3u) == 3 || column + 4 >= text_length))
+                    parked_mine[(u64)(dword / 4) * 256] = leaving;
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < words_; ++w) delta_sum += (i32)__builtin_popcount(vp[w]) - (i32)__builtin_popcount(vn[w]);
+    }
+    return delta_sum;
+}
+
+__global__ __launch_bounds__(256) void levenshtein_myers_banded_kernel(szs_string_ref_t const *__restrict__ queries,
+                                                                        u32 queries_count,
+                                                                        szs_string_ref_t const *__restrict__ candidates,
+                                                                        u32 candidates_count, u32 candidate_blocks,
+                                                                        u64 *__restrict__ results, u64 results_row_stride,
+                                                                        int symmetric, u32 *__restrict__ parked,
+                                                                        u32 parked_dwords, u32 *__restrict__ work_counter) {
+    __shared__ __attribute__((aligned(16))) u32 peq[peq_layout<banded_widest_k>::total_dwords];
+    __shared__ u32 claimed_work;
+    // parked deltas of this workgroup: [dword = 16 columns][lane]
+    u32 *const parked_mine = parked + (u64)blockIdx.x * parked_dwords * 256 + threadIdx.x;
+
+    u32 const work_items = queries_count * candidate_blocks;
+    for (;;) {
+        __syncthreads(); // the previous item's Peq and ticket are no longer in use
+        if (threadIdx.x == 0) claimed_work = atomicAdd(work_counter, 1u);
+        __syncthreads();
+        u32 const work = claimed_work;
+        if (work >= work_items) break;
+        szs_string_ref_t const query = queries[work / candidate_blocks];
+        u32 const candidate_slot = (candidate_blocks - 1 - work % candidate_blocks) * SZS_CANDIDATES_PER_WORKGROUP + threadIdx.x;
+        bool live = candidate_slot < candidates_count;
+        szs_string_ref_t candidate = {0, 0, 0};
+        if (live) candidate = candidates[candidate_slot];
+        if ((symmetric & SZS_LAYOUT_SYMMETRIC) && candidate.index > query.index) live = false;
+        u32 const text_length = live ? candidate.length : 0;
+        u32 const longest_in_wave = wave_max_u32(text_length);
+        u32 const shortest_in_wave = ~wave_max_u32(live ? ~text_length : 0u);
+        u64 const safe_address = text_length ? candidate.address : query.address; // lanes without a text: see myers_workgroup
+        text_stream_t text(safe_address, text_length);
+        if (!text_length) text.valid_dwords = query.length ? 1 : 0;
+
+        // As few strips as the widest width allows, all of the same width, that width rounded up to 8 words: a query of
+        // 2150 bytes is two strips of 40 words, not one of 64 and one nearly empty.
+        u32 const total_words = __builtin_amdgcn_readfirstlane(query.length ? (query.length + 31u) / 32u : 1u);
+        u32 const strips = (total_words + banded_widest_k - 1) / banded_widest_k;
+        u32 const strip_words = ((total_words + strips - 1) / strips + 7u) / 8u * 8u;
+        i32 delta_sum;
+        switch (strip_words) {
+        case 8: case 16: case 24: case 32: // (the host sends queries of more than 64 words, i.e. 33 or more words per strip)
+            delta_sum = myers_strips<32>(peq, query, strips, text, text_length, shortest_in_wave, longest_in_wave, parked_mine);
+            break;
+        case 40: delta_sum = myers_strips<40>(peq, query, strips, text, text_length, shortest_in_wave, longest_in_wave, parked_mine); break;
+        case 48: delta_sum = myers_strips<48>(peq, query, strips, text, text_length, shortest_in_wave, longest_in_wave, parked_mine); break;
+        case 56: delta_sum = myers_strips<56>(peq, query, strips, text, text_length, shortest_in_wave, longest_in_wave, parked_mine); break;
+        default: delta_sum = myers_strips<64>(peq, query, strips, text, text_length, shortest_in_wave, longest_in_wave, parked_mine); break;
+        }
+
+        if (live) {
+            u64 const distance = (u64)((i64)text_length + delta_sum);
+            bool const transposed = (symmetric & SZS_LAYOUT_TRANSPOSED) != 0;
+            u64 const row = transposed ? candidate.index : query.index, column_of = transposed ? query.index : candidate.index;
+            results[row * results_row_stride + column_of] = distance;
+            if ((symmetric & SZS_LAYOUT_SYMMETRIC) && candidate.index != query.index)
+                results[column_of * results_row_stride + row] = distance;
+        }
+    }
+}
+
+static u32 banded_grid(u64 work_items) {
+    static int resident = 0;
+    if (!resident) {
+        int device = 0, units = 0, per_unit = 0;
+        if (hipGetDevice(&device) != hipSuccess ||
+            hipDeviceGetAttribute(&units, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_unit, levenshtein_myers_banded_kernel, 256, 0) != hipSuccess ||
+            units <= 0 || per_unit <= 0) {
+            (void)hipGetLastError();
+            units = 256, per_unit = 1;
+        }
+        resident = units * per_unit;
+    }
+    return (u32)(work_items < (u64)resident ? work_items : (u64)resident);
+}
+
 /* ---- codepoint queries of more than 256 runes ----------------------------------------------------------------------
  *
  *  The short rune kernel keys Peq by the SLOT of a 512-slot rune table - fine for at most 256 distinct runes and 8 words.
@@ -606,6 +811,32 @@ extern "C" int szs_hip_levenshtein_myers_runes(szs_string_ref_t const *queries, 
     if (!queries_count || !candidates_count) return 0;
     return launch_myers(levenshtein_myers_short_kernel<true>, queries, queries_count, candidates, candidates_count, results,
                         results_row_stride, symmetric, static_cast<hipStream_t>(stream));
+}
+
+extern "C" size_t szs_hip_levenshtein_myers_banded_bytes(uint32_t queries_count, uint32_t candidates_count, uint32_t longest_candidate) {
+    using namespace szs_hip;
+    u64 const work_items = (u64)queries_count * ((candidates_count + SZS_CANDIDATES_PER_WORKGROUP - 1) / SZS_CANDIDATES_PER_WORKGROUP);
+    return banded_header_bytes_k + (size_t)banded_grid(work_items) * (longest_candidate / 16 + 2) * 256 * sizeof(u32);
+}
+
+extern "C" int szs_hip_levenshtein_myers_banded(szs_string_ref_t const *queries, uint32_t queries_count,
+                                                szs_string_ref_t const *candidates, uint32_t candidates_count,
+                                                uint32_t longest_candidate, uint64_t *results, uint64_t results_row_stride,
+                                                int symmetric, void *workspace, void *stream) {
+    using namespace szs_hip;
+    if (!queries_count || !candidates_count) return 0;
+    u32 const candidate_blocks = (candidates_count + SZS_CANDIDATES_PER_WORKGROUP - 1) / SZS_CANDIDATES_PER_WORKGROUP;
+    u64 const work_items = (u64)queries_count * candidate_blocks;
+    if (work_items > 0xFFFFFFF0ull) return (int)hipErrorInvalidValue;
+    hipStream_t const s = static_cast<hipStream_t>(stream);
+    u32 *const counter = static_cast<u32 *>(workspace);
+    hipError_t const error = hipMemsetAsync(counter, 0, sizeof(u32), s);
+    if (error != hipSuccess) return (int)error;
+    hipLaunchKernelGGL(levenshtein_myers_banded_kernel, dim3(banded_grid(work_items)), dim3(256), 0, s, queries, queries_count,
+                       candidates, candidates_count, candidate_blocks, results, results_row_stride, symmetric,
+                       reinterpret_cast<u32 *>(static_cast<char *>(workspace) + banded_header_bytes_k), longest_candidate / 16 + 2,
+                       counter);
+    return (int)hipGetLastError();
 }
 
 extern "C" int szs_hip_levenshtein_myers_runes_long(unsigned words, szs_string_ref_t const *queries, uint32_t queries_count,

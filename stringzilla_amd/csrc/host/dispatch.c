@@ -344,7 +344,9 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
     for (uint32_t i = 0; i < q_count; ++i) q_longest = q_lengths[i] > q_longest ? q_lengths[i] : q_longest;
     for (uint32_t i = 0; i < c_count; ++i) c_longest = c_lengths[i] > c_longest ? c_lengths[i] : c_longest;
     int tier = SZS_TIER_LANES, transposed = 0;
-    szs_plan_orient(myers_words * 32, use_myers && !runes, !engine->is_linear, !maximise, symmetric, q_lengths, q_count,
+    /* bit-parallel at any length for bytes (2048-row strips beyond 64 words), up to 2048 symbols for codepoints */
+    int const banded = use_myers && !runes;
+    szs_plan_orient(banded ? 0xFFFFFFFFu : myers_words * 32, use_myers && !runes, !engine->is_linear, !maximise, symmetric, q_lengths, q_count,
                     c_lengths, c_count, szs_hip_systolic_band_rows(), &tier, &transposed);
     char const *const forced_tier = getenv("SZS_ROCM_TIER"); /* `systolic` on a unit-cost engine means the DP recurrences */
     if (tier == SZS_TIER_MYERS_CHAIN && forced_tier && forced_tier[0] == 's') tier = SZS_TIER_SYSTOLIC;
@@ -461,12 +463,16 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
             if (error != hipSuccess) return szs_report_hip(error, error_message);
             engine->model_uploaded_device = device, engine->model_uploaded_transposed = transposed;
         }
-        size_t const boundary_bytes =
+        size_t boundary_bytes =
             tier == SZS_TIER_SYSTOLIC
                 ? systolic_parked_bytes
                 : packed ? szs_hip_weighted_packed_boundary_bytes(packed_local, !engine->is_linear, classes, kq_count, kc_count,
                                                                   plan.longest_candidate)
                          : szs_hip_weighted_boundary_bytes(objective, !engine->is_linear, narrow, kq_count, kc_count, plan.longest_candidate);
+        if (banded && tier == SZS_TIER_LANES) { /* queries beyond 64 words: the strip kernel's parked deltas instead */
+            size_t const banded_bytes = szs_hip_levenshtein_myers_banded_bytes(kq_count, kc_count, plan.longest_candidate);
+            boundary_bytes = banded_bytes > boundary_bytes ? banded_bytes : boundary_bytes;
+        }
         status = szs_buffer_reserve(&engine->device_boundary, szs_memory_device_k, device, boundary_bytes, error_message);
         if (status != sz_success_k) return status;
     }
@@ -518,6 +524,10 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
             launch_error = szs_hip_levenshtein_myers(group->variant, device_query_refs + group->first, group->count,
                                                      device_candidate_refs, kc_count, (uint64_t *)device_results,
                                                      device_stride, layout, stream);
+        else if (banded)
+            launch_error = szs_hip_levenshtein_myers_banded(device_query_refs + group->first, group->count, device_candidate_refs,
+                                                            kc_count, plan.longest_candidate, (uint64_t *)device_results,
+                                                            device_stride, layout, engine->device_boundary.pointer, stream);
         else if (packed) {
             cell_bits = 16;
             launch_error = szs_hip_weighted_packed_scores(packed_local, !engine->is_linear, classes,

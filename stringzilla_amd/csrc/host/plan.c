@@ -244,7 +244,7 @@ sz_status_t szs_rocm_orientation_probe(int unit_cost, int affine, int uniform, i
                                        sz_u32_t const *candidate_lengths, sz_size_t candidates_count, int *tier,
                                        int *transposed) {
     if (queries_count > 0xFFFFFFFFu || candidates_count > 0xFFFFFFFFu || !tier || !transposed) return sz_overflow_risk_k;
-    szs_plan_orient(unit_cost ? SZS_MYERS_MAX_WORDS * 32 : 0, unit_cost, affine, uniform, symmetric, query_lengths,
+    szs_plan_orient(unit_cost ? 0xFFFFFFFFu : 0, unit_cost, affine, uniform, symmetric, query_lengths, /* as dispatch.c does for bytes */
                     (uint32_t)queries_count, symmetric ? query_lengths : candidate_lengths,
                     (uint32_t)(symmetric ? queries_count : candidates_count), SZS_SYSTOLIC_BAND_ROWS, tier, transposed);
     return sz_success_k;

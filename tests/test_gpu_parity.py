@@ -133,8 +133,8 @@ def test_levenshtein_fuzz(gpu, oracle, costs):
 
 def test_levenshtein_every_kernel_width(gpu, oracle):
     """Queries at both edges of every bit-parallel width (1..8 words inside the mixed-width short kernel, then each
-    instantiated long width up to 64 words), plus queries beyond 2048 bytes that fall through to the weighted kernel -
-    all in ONE call, so the planner's grouping is exercised too: 1 short + 8 long + 1 weighted launch."""
+    instantiated long width up to 64 words), plus queries beyond 2048 bytes that take the strip kernel - all in ONE call,
+    so the planner's grouping is exercised too: 1 short + 8 long + 1 strip launch."""
     rng = random.Random(77)
     edges = [0, 1, 31, 32, 33, 64, 65, 96, 97, 128, 129, 160, 161, 192, 224, 225, 256, 257, 320, 321, 384, 385, 512, 513,
              640, 768, 769, 1024, 1025, 1536, 1537, 2048, 2049, 2500]
@@ -147,6 +147,26 @@ def test_levenshtein_every_kernel_width(gpu, oracle):
     profile = engine.last_call_profile()
     assert profile.launches == 10, profile.launches
     assert profile.cells == sum(map(len, queries)) * sum(map(len, candidates))
+
+
+def test_levenshtein_beyond_2048_bytes_in_strips(gpu, oracle):
+    """Unit-cost byte queries of more than 2048 bytes stay bit-parallel on the lanes tier: strips of 2048 rows whose
+    last-row deltas are parked 16 columns to a dword (lev_myers.hip, `levenshtein_myers_banded_kernel`).  Strip edges
+    (2048 k and k +- 1 rows), texts that end on and around the 4-column and 16-column boundaries, a wavefront whose
+    shortest text ends inside a group, empties, bytes >= 0x80, symmetric calls, and a batch mixing every kernel width."""
+    rng = random.Random(4096)
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+    with forced_tier("lanes"), forced_swap("0"):
+        queries = [bytes(rng.choice(b"ACGT") for _ in range(n)) for n in (2049, 2050, 3000, 4095, 4096, 4097, 6143, 6144, 6145, 7000)]
+        candidates = [bytes(rng.choice(b"ACGT") for _ in range(n)) for n in list(range(0, 70)) + [127, 128, 129, 1000, 2047, 2048, 2049, 5000, 6500]]
+        assert np.array_equal(engine(queries, candidates, device=gpu), oracle.levenshtein(queries, candidates))
+        assert engine.last_call_profile().cell_bits == 0 and engine.last_call_profile().tier == 0
+        ragged = _rand(rng, 300, 20, 28, bytes(range(256))) + _rand(rng, 40, 3000, 3100, bytes(range(256)))  # 24: mid-group
+        wide = _rand(rng, 3, 2100, 5000, bytes(range(256)))
+        assert np.array_equal(engine(wide, ragged, device=gpu), oracle.levenshtein(wide, ragged))
+        mixed = _rand(rng, 12, 1, 5000, b"AB") + [b""]
+        assert np.array_equal(engine(mixed, device=gpu), oracle.levenshtein(mixed, None))
+        assert np.array_equal(engine(mixed, mixed[:5], device=gpu), oracle.levenshtein(mixed, mixed[:5]))
 
 
 @pytest.mark.parametrize("kind", ["needleman_wunsch", "smith_waterman"])
