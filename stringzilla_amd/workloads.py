@@ -103,3 +103,41 @@ def config(index: int, scale: float = 1.0) -> Workload:
                         "levenshtein_utf8", zipf_utf8_tape(rng, side(3163)), zipf_utf8_tape(rng, side(3163)),
                         dict(match=0, mismatch=1, open=1, extend=1))
     raise ValueError(f"unknown config {index}")
+
+
+def tokenize_dataset(data: bytes, tokens: str = "words", max_tokens: int = 0, unique: bool = False) -> Strs:
+    """The reference's benchmark tokeniser (`bench/shared.hpp:240-262,440-480`), for runs on real text (`xlsum.csv`,
+    `acgt_*.txt`: `CONTRIBUTING.md:320-324`) instead of the synthetic configurations:
+
+      - the dataset is cut to the largest power of two that fits (`bit_floor`, `:451`);
+      - `tokens`: "file" (one token), "lines" (split at `\\n`), "words" (split at C `isspace` bytes: space, \\t \\n \\v \\f \\r)
+        or a positive integer N as a string (words of exactly N bytes) - `STRINGWARS_TOKENS`; empty tokens are dropped;
+      - `unique` sorts and deduplicates (`STRINGWARS_UNIQUE`), `max_tokens` keeps the first so many (`STRINGWARS_MAX_TOKENS`).
+
+    Returns the tokens as a u32 tape over ONE copy of the dataset bytes (tokens are views, as in the reference).
+    """
+    size = 1 << (len(data).bit_length() - 1) if data else 0
+    buffer = np.frombuffer(data, dtype=np.uint8, count=size)
+    if tokens == "file":
+        spans = [(0, size)] if size else []
+    else:
+        if tokens == "lines":
+            separators = buffer == 0x0A
+        else:
+            separators = np.isin(buffer, np.frombuffer(b" \t\n\v\f\r", dtype=np.uint8))
+        edges = np.flatnonzero(separators)
+        starts = np.concatenate(([0], edges + 1))
+        ends = np.concatenate((edges, [size]))
+        keep = ends > starts
+        if tokens not in ("lines", "words"):
+            width = int(tokens)
+            if width <= 0:
+                raise ValueError("The tokenization mode must be 'file', 'lines', 'words', or a positive integer.")
+            keep &= (ends - starts) == width
+        spans = list(zip(starts[keep].tolist(), ends[keep].tolist()))
+    pieces = [bytes(buffer[start:end]) for start, end in spans]
+    if unique:
+        pieces = sorted(set(pieces))
+    if max_tokens:
+        pieces = pieces[:max_tokens]
+    return Strs(pieces)

@@ -192,3 +192,21 @@ def test_strs_tapes_and_no_cpu_fallback():
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError, match="no CPU fallback"):
             strs.to_device()
+
+
+def test_dataset_tokeniser_follows_the_reference_benchmark():
+    """bench/shared.hpp:240-262,440-480: power-of-two cut, separators, dropped empties, N-byte words, unique, cap."""
+    data = b"alpha beta\tgamma\n\ndelta  epsilon\rzeta\x0bwxyz end"  # 46 bytes -> cut to 32
+    assert len(data) == 46
+    words = workloads.tokenize_dataset(data, "words")
+    assert [words[i] for i in range(len(words))] == [b"alpha", b"beta", b"gamma", b"delta", b"epsilon"]
+    lines = workloads.tokenize_dataset(data, "lines")
+    assert [lines[i] for i in range(len(lines))] == [b"alpha beta\tgamma", b"delta  epsilon"]
+    assert [workloads.tokenize_dataset(data, "file")[0]] == [data[:32]]
+    fives = workloads.tokenize_dataset(data, "5")
+    assert [fives[i] for i in range(len(fives))] == [b"alpha", b"gamma", b"delta"]
+    repeated = workloads.tokenize_dataset(b"b a b a c c c d " * 4, "words", unique=True, max_tokens=3)
+    assert [repeated[i] for i in range(len(repeated))] == [b"a", b"b", b"c"]
+    assert len(workloads.tokenize_dataset(b"", "words")) == 0
+    with pytest.raises(ValueError):
+        workloads.tokenize_dataset(b"abcd", "0")
