@@ -291,8 +291,11 @@ __device__ __forceinline__ void myers_work_item(u32 candidate_blocks, u32 &query
 }
 
 /** Long queries (more than 8 words): every query of the launch uses the same instantiated width. */
+#ifndef SZS_MYERS_LONG_WAVES
+#define SZS_MYERS_LONG_WAVES 2 // two wavefronts per SIMD at every width: 64 words then cost 11 spilled registers and still
+#endif                         // run 1.3x faster than one wavefront with none (profiles/r01/myers_long_occupancy_v1.txt)
 template <int words_>
-__global__ __launch_bounds__(256) void levenshtein_myers_long_kernel(szs_string_ref_t const *__restrict__ queries,
+__global__ __launch_bounds__(256, SZS_MYERS_LONG_WAVES) void levenshtein_myers_long_kernel(szs_string_ref_t const *__restrict__ queries,
                                                                       szs_string_ref_t const *__restrict__ candidates,
                                                                       u32 candidates_count, u32 candidate_blocks,
                                                                       u64 *__restrict__ results, u64 results_row_stride,
