@@ -444,7 +444,7 @@ __device__ __forceinline__ i32 myers_strips(u32 *peq, szs_string_ref_t const que
                     if (!first_strip) entering = parked_mine[(u64)(dword / 4) * 256];
                     leaving = 0;
                 }
-#pragma unroll
+#pragma unroll 1 // one column body per width instead of four: that is what lets all five widths fit 256 registers
                 for (int step = 0; step < 4; ++step) take((symbols >> (8 * step)) & 0xFFu, column + step);
                 if ((dword & 3u) == 3 && !last_strip) parked_mine[(u64)(dword / 4) * 256] = leaving;
             }
@@ -464,7 +464,7 @@ __device__ __forceinline__ i32 myers_strips(u32 *peq, szs_string_ref_t const que
                     if (!first_strip && column < text_length) entering = parked_mine[(u64)(dword / 4) * 256];
                     leaving = 0;
                 }
-#pragma unroll
+#pragma unroll 1
                 for (int step = 0; step < 4; ++step)
                     if (column + step < text_length) take((symbols >> (8 * step)) & 0xFFu, column + step);
                 // a group is parked when it is complete or when the text ends inside it
@@ -478,7 +478,7 @@ __device__ __forceinline__ i32 myers_strips(u32 *peq, szs_string_ref_t const que
     return delta_sum;
 }
 
-__global__ __launch_bounds__(256) void levenshtein_myers_banded_kernel(szs_string_ref_t const *__restrict__ queries,
+__global__ __launch_bounds__(256, 2) /* two wavefronts per SIMD, like the long kernels */ void levenshtein_myers_banded_kernel(szs_string_ref_t const *__restrict__ queries,
                                                                         u32 queries_count,
                                                                         szs_string_ref_t const *__restrict__ candidates,
                                                                         u32 candidates_count, u32 candidate_blocks,
