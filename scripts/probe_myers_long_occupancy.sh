@@ -1,3 +1,7 @@
+#!/bin/bash
+# probe_myers_long_occupancy.sh - the long Myers kernels at one vs two wavefronts per SIMD (results: profiles/r01/
+# myers_long_occupancy_v1.txt; two is the default since).  `base` is the in-tree library; build the other side with
+#   make -C stringzilla_amd/csrc OUT=../lib_variants/long2 EXTRA="-DSZS_MYERS_LONG_WAVES=2"      (or =1, to compare back)
 P=tests/native/bin/systolic_probe
 export PROBE_ALARM=60 PROBE_NO_ORACLE=1 SZS_ROCM_SWAP=0 SZS_ROCM_TIER=lanes
 for v in base long2; do

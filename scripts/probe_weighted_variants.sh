@@ -1,3 +1,10 @@
+#!/bin/bash
+# probe_weighted_variants.sh - A/B of build variants of hip/weighted.hip through the C probe (results: profiles/r01/
+# weighted_occupancy_variants_v1.txt).  Build the variants first, in-tree, next to the real library:
+#   make -C stringzilla_amd/csrc OUT=../lib_variants/w3  EXTRA="-DSZS_WEIGHTED_WAVES=3"
+#   make -C stringzilla_amd/csrc OUT=../lib_variants/w3r EXTRA="-DSZS_WEIGHTED_WAVES=3 -DSZS_WEIGHTED_RECOMPUTE=1"
+#   make -C stringzilla_amd/csrc OUT=../lib_variants/w2r EXTRA="-DSZS_WEIGHTED_RECOMPUTE=1"
+# (stringzilla_amd/lib_variants/ is git-ignored; the probe picks a variant up through LD_LIBRARY_PATH.)
 P=tests/native/bin/systolic_probe
 export SZS_ROCM_SWAP=0 PROBE_ALARM=60 SZS_ROCM_TIER=lanes
 for v in w3 w3r w2r; do
