@@ -150,6 +150,32 @@ def test_planner_picks_tier_and_orientation():
     assert _orientation(0, 0, 0, 0, [100] * 8, [50000] * 2)[0] == systolic           # few pairs, however lopsided
 
 
+def test_planner_keeps_long_byte_queries_bit_parallel():
+    """Unit-cost bytes are bit-parallel at any length (2048-row strips on the lanes tier, the band chain for few pairs):
+    the measured cross-over of profiles/r01/lanes_vs_chain_v2.txt - full devices on lanes, thin batches on the chain."""
+    lanes, chain = 0, 2
+    assert _orientation(1, 0, 1, 0, [2550] * 512, [2550] * 512) == (lanes, 0)
+    assert _orientation(1, 0, 1, 0, [4100] * 256, [4100] * 256) == (lanes, 0)
+    assert _orientation(1, 0, 1, 0, [4100] * 128, [4100] * 128) == (chain, 0)
+    assert _orientation(1, 0, 1, 0, [16200] * 64, [16200] * 64) == (chain, 0)
+    assert _orientation(1, 0, 1, 0, [128] * 4096, [100]) == (lanes, 1)  # one live wavefront per workgroup: swap
+
+
+def test_every_declared_kernel_entry_point_is_defined():
+    """hip/kernels.h is the contract between the C host and the HIP kernels: each `szs_hip_*` it declares must be a
+    function of the library (the symbols are hidden, so look at the static symbol table)."""
+    import subprocess
+
+    header = open(os.path.join(ROOT, "stringzilla_amd", "csrc", "hip", "kernels.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(szs_hip_\w+)\s*\(", header))
+    assert len(declared) >= 17, declared
+    library = os.path.join(ROOT, "stringzilla_amd", "lib", "libstringzillas_rocm_shared.so")
+    table = subprocess.run(["nm", library], capture_output=True, text=True, check=True).stdout
+    defined = {line.split()[-1] for line in table.splitlines() if len(line.split()) == 3 and line.split()[1] in "tT"}
+    assert declared <= defined, sorted(declared - defined)
+
+
 def test_shard_rows_balances_like_lpt():
     rng = np.random.default_rng(5)
     weights = rng.zipf(1.3, size=3163).clip(8, 2048).astype(np.uint64)
