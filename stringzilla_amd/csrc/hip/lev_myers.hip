@@ -1,5 +1,5 @@
 /*
- *  lev_myers.hip - unit-cost byte-level Levenshtein distances on gfx950, bit-parallel (Myers 1999 / Hyyro 2003).
+ *  lev_myers.hip - unit-cost Levenshtein distances (bytes and codepoints) on gfx950, bit-parallel (Myers 1999 / Hyyro 2003).
  *
  *  Replaces, for the ROCm build, the reference's family of unit-cost kernels
  *      unit_myers_*_per_cuda_thread_/warp_   /root/reference/include/stringzillas/similarities/cuda.cuh:2389-2860
@@ -27,7 +27,10 @@
  *
  *  - Queries of up to 256 bytes - whatever mix of lengths - are ONE launch: the word count is a per-workgroup scalar
  *    decision inside `levenshtein_myers_short_kernel`, so a batch straddling several widths pays neither a launch per
- *    width nor padding to the widest.  Longer queries use one instantiated width per launch.
+ *    width nor padding to the widest.  Longer queries use one instantiated width per launch (up to 64 words), and
+ *    beyond 2048 bytes horizontal strips of equal width whose last-row deltas are parked per text column (further down).
+ *  - Codepoint twins of all of it up to 2048 runes: UTF-32 texts, Peq keyed through a rune table in LDS (slots for the
+ *    short kernel, dense ids for the long ones) - the reference's open-addressing Peq (serial.hpp:2328-2512) on a GPU.
  *
  *  Cost per text byte per lane (ISA count, W = 4): 48 VALU = 10.5 per word + 2 history pushes + LDS addressing, i.e.
  *  0.38 VALU per DP cell; LDS: one ds_read_b128 per four words.  HBM: tapes once + 8 B per result; see DESIGN.md
