@@ -191,7 +191,8 @@ def main():
         # HBM traffic of the dominant kernel, per launch: FETCH_SIZE + WRITE_SIZE from their own rocprofv3 --pmc passes
         # of this command (scripts/profile_gpu.sh), kilobyte units and the gfx950 wide-read correction applied by
         # scripts/pmc_summary.py as MI355X_MICROARCH.md prescribes.  Committed, not collected inside this process.
-        traffic, traffic_note = args.hbm_traffic_bytes, "from --hbm-traffic-bytes"
+        traffic = args.hbm_traffic_bytes
+        traffic_note = "from --hbm-traffic-bytes" if traffic is not None else "no committed PMC pass for this config"
         if traffic is None and args.config == 2:
             summary = next((counters for name, counters in (_profile_json("pmc_summary.json") or {}).items()
                             if name.startswith("levenshtein_myers_short_kernel")), None)  # the name carries template arguments
@@ -214,8 +215,8 @@ def main():
                        "entry_point": "szs_levenshtein_distances_u32tape"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_source": traffic_note,
-                         "kernel": "levenshtein_myers_short_kernel (%d launch%s per step)" % (
-                             profile.launches, "" if profile.launches == 1 else "es"),
+                         "kernel": ("levenshtein_myers_short_kernel (1 launch per step)" if profile.launches == 1 else
+                                    "levenshtein_myers_short_kernel + long-width kernels (%d launches per step)" % profile.launches),
                          "kernel_ms": round(kernel * 1e3, 4),
                          "algorithmic_bytes": int(profile.algorithmic_bytes),
                          "kernel_gcups": round(profile.cells / kernel / 1e9, 1),
