@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""bench.py - BASELINE.json's metric on BASELINE.json's config, through the C-ABI.
+"""bench.py - BASELINE.json's metric on BASELINE.json's configs, through the C-ABI.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2] [--extra-configs 3,4,5,6] [--no-cpu-baseline]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Metric : DP cell-updates/s (GCUPS) = sum over scored pairs of len(query) * len(candidate) / seconds / 1e9
@@ -9,13 +9,21 @@ Metric : DP cell-updates/s (GCUPS) = sum over scored pairs of len(query) * len(c
 Step   : one `szs_levenshtein_distances_u32tape` call - the whole synchronous C-ABI call, host planning included - over
          config 2: a 1024 x 1024 cross-product (1,048,576 pairs) of printable-ASCII strings, length U[96,160], unit costs.
          Tapes and the results matrix are resident in HBM before the timed region starts.
-N > 1  : one process per GPU.  The batch shards by QUERY ROW BLOCKS: every rank scores its own
+N > 1  : one process per GPU.  The HEADLINE shards by QUERY ROW BLOCKS: every rank scores its own
          1024 query rows against the same 1024 candidates (broadcast once over RCCL/xGMI before timing), so per-GPU work
          is fixed: "weak" scaling, and the timed path has no collective (rows are independent; results stay sharded).
-Lines  : rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel against HBM with ALGORITHMIC bytes
+Line   : rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel against HBM with ALGORITHMIC bytes
          (272 B per pair at len 128: len(q) + len(c) + 2 offsets + one 8-byte result) over the
          hipEvent-measured kernel time the library records on its own stream.  `cpu_baseline` times the reference's own
          SIMD engines (oracle/_ref, built from /root/reference) on this box's host cores - a reported baseline only.
+configs: the same line carries a `configs` array - one record per other BASELINE.json config (3: NW BLOSUM62, 4: SW
+         affine NUC.4.4, 5: byte-level Levenshtein on Zipf UTF-8, 5u: the same at the codepoint level), each timed
+         through its own C-ABI entry point with its kernel and wall GCUPS, checksum, HBM roofline, the VALU counters of
+         its dominant kernel (profiles/r02, committed PMC passes) and the reference's Ice Lake engine as `cpu_baseline`
+         on a stated sample whose cells are also compared with the GPU's.  With N > 1 configs 4 and 5 are STRONG-scaled
+         the way BASELINE.json specifies them: ONE batch, rows dealt over the ranks by LPT (`stringzilla_amd/sharded.py`),
+         per-GPU busy time, imbalance = max / mean, aggregate GCUPS - plus the same batch through the single-process C
+         entry `szs_rocm_node_*` (one host thread per GPU) when the library exports it.
 """
 
 import argparse
@@ -35,15 +43,18 @@ HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 # The binding resource of this path is integer VALU issue, not HBM.  Its ceiling is MEASURED, not quoted: the Myers
 # column update (the kernel's exact instruction mix) on register-resident match masks, no LDS and no memory, sustains
 # this many DP cells per second at full bit-vector width on one MI355X (scripts/valu_peak.hip -> profiles/).
-PROFILES = os.path.join(ROOT, "profiles", "r01")
+PROFILE_DIRS = [os.path.join(ROOT, "profiles", "r02"), os.path.join(ROOT, "profiles", "r01")]
+VALU_LANE_OPS_PEAK = 39.3e12  # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz: one full-rate VALU lane-op per lane per cycle
 
 
 def _profile_json(name):
-    try:
-        with open(os.path.join(PROFILES, name)) as handle:
-            return json.load(handle)
-    except (OSError, ValueError):
-        return None
+    for directory in PROFILE_DIRS:
+        try:
+            with open(os.path.join(directory, name)) as handle:
+                return json.load(handle), os.path.relpath(os.path.join(directory, name), ROOT)
+        except (OSError, ValueError):
+            continue
+    return None, None
 
 
 def parse_args():
@@ -51,7 +62,12 @@ def parse_args():
     parser.add_argument("--gpus", type=int, default=1)
     parser.add_argument("--steps", type=int, default=200)
     parser.add_argument("--warmup", type=int, default=20)
-    parser.add_argument("--config", type=int, default=2, help="BASELINE.json config index (2 = the metric's config)")
+    parser.add_argument("--config", type=int, default=2, help="BASELINE.json config index of the headline (2 = the metric's config)")
+    parser.add_argument("--extra-configs", default=None,
+                        help="comma-separated configs reported in the `configs` array (default: 3,4,5,6 on one GPU, "
+                             "4,5 strong-scaled on several; 'none' to skip)")
+    parser.add_argument("--extra-seconds", type=float, default=4.0, help="GPU time budget per extra config")
+    parser.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU time budget per cpu_baseline sample")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI)")
     parser.add_argument("--same-device", action="store_true",
@@ -59,18 +75,61 @@ def parse_args():
                              "path on a one-GPU box; the numbers of such a run mean nothing")
     parser.add_argument("--hbm-traffic-bytes", type=float, default=None,
                         help="HBM bytes per launch from a separate rocprofv3 --pmc pass; default: the committed summary "
-                             "profiles/r01/pmc_summary.json of this same command (scripts/profile_gpu.sh)")
+                             "profiles/rNN/pmc_summary.json of this same command (scripts/profile_gpu.sh)")
     return parser.parse_args()
 
 
-def cpu_baseline(load, gpu_matrix):
-    """Times the reference's own CPU engines (best SIMD tier, all host threads) on the same batch and checks that they
-    produce the very matrix the GPU produced.  Test-infrastructure code path: the only place bench.py touches oracle/."""
-    from oracle import binding
+# ---- engines and entry points per workload kind -------------------------------------------------------------------------
 
-    strings = lambda tape: [tape[i] for i in range(len(tape))]
-    queries, candidates = strings(load.queries), strings(load.candidates)
+ENTRY_POINTS = {
+    "levenshtein": "szs_levenshtein_distances_u32tape", "levenshtein_utf8": "szs_levenshtein_distances_utf8_u32tape",
+    "needleman_wunsch": "szs_needleman_wunsch_scores_u32tape", "smith_waterman": "szs_smith_waterman_scores_u32tape",
+}
+
+
+def make_engine(load, scope):
+    import stringzilla_amd as szs
+    from stringzilla_amd import matrices
+
+    if load.kind == "levenshtein":
+        return szs.LevenshteinDistances(**load.costs, capabilities=scope)
+    if load.kind == "levenshtein_utf8":
+        return szs.LevenshteinDistancesUTF8(**load.costs, capabilities=scope)
+    cls = szs.NeedlemanWunschScores if load.kind == "needleman_wunsch" else szs.SmithWatermanScores
+    return cls(*matrices.by_name(load.table), **load.costs, capabilities=scope)
+
+
+def make_step(engine, scope, load, queries, candidates, results, device_index):
+    """The raw C-ABI call of this workload as a closure (ctypes only inside the timed loop)."""
+    from stringzilla_amd import _abi
+
+    call = getattr(_abi.lib, ENTRY_POINTS[load.kind])
+    q_tape, c_tape = queries._tape(device_index), candidates._tape(device_index)
+    error = ctypes.c_char_p()
+    columns = len(candidates)
+
+    def step():
+        status = call(engine.handle, scope.handle, ctypes.byref(q_tape), ctypes.byref(c_tape), results.data_ptr(), columns,
+                      ctypes.byref(error))
+        if status:
+            raise RuntimeError(f"{ENTRY_POINTS[load.kind]} failed: {status} {error.value}")
+
+    step.keepalive = (q_tape, c_tape, queries, candidates)
+    return step
+
+
+# ---- the reference's CPU engines beside it ---------------------------------------------------------------------------------
+
+def cpu_baseline(load, gpu_matrix, seconds):
+    """Times the reference's own CPU engines (best SIMD tier, all host threads) on a BOUNDED sample of the same batch -
+    evenly spaced query rows x evenly spaced candidates, sized by a calibration pass to about `seconds` of CPU work, the
+    whole batch when that fits - and checks that they produce the very cells the GPU produced.  Test-infrastructure
+    code path: the only place bench.py touches oracle/."""
+    from oracle import binding
+    from stringzilla_amd import matrices
+
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    checker, kind, label = None, None, None
     if binding.reference_available():
         try:
             tier = binding.reference_best_tier()
@@ -78,25 +137,225 @@ def cpu_baseline(load, gpu_matrix):
             kind, label = "reference", {0: "serial", 1: "haswell (AVX2)", 2: "icelake (AVX-512)"}[tier]
         except OSError:
             checker = None
-    else:
-        checker = None
     if checker is None:
         checker, kind, label, cores = binding.oracle(), "port", "plain-C oracle", 1
-    run = lambda: checker.levenshtein(queries, candidates, **load.costs)
+
+    def run(rows, columns):
+        queries = [load.queries[int(i)] for i in rows]
+        candidates = [load.candidates[int(j)] for j in columns]
+        if load.kind == "levenshtein":
+            return checker.levenshtein(queries, candidates, **load.costs)
+        if load.kind == "levenshtein_utf8":
+            return checker.levenshtein_utf8(queries, candidates, **load.costs)
+        scorer = checker.needleman_wunsch if load.kind == "needleman_wunsch" else checker.smith_waterman
+        return scorer(queries, candidates, *matrices.by_name(load.table), **load.costs)
+
+    q_lengths, c_lengths = load.queries.lengths(), load.candidates.lengths()
+    spaced = lambda count, take: np.unique(np.linspace(0, count - 1, num=max(1, min(count, take))).round().astype(np.int64))
+    cells_of = lambda rows, columns: float(q_lengths[rows].sum()) * float(c_lengths[columns].sum())
+
+    # calibration: one row per thread (the shim deals contiguous row blocks to threads) x a few candidates
+    rows = spaced(len(q_lengths), max(cores, 1))
+    columns = spaced(len(c_lengths), 8)
     started = time.perf_counter()
-    matrix = run()
+    run(rows, columns)
+    rate = cells_of(rows, columns) / max(time.perf_counter() - started, 1e-4)
+    budget_cells = rate * seconds
+    # grow the sample towards the budget: first more candidates, then more rows
+    take_columns = int(min(len(c_lengths), max(8, budget_cells / max(cells_of(rows, np.arange(len(c_lengths))) / len(c_lengths), 1.0))))
+    columns = spaced(len(c_lengths), take_columns)
+    if take_columns == len(c_lengths):
+        per_row = cells_of(np.arange(len(q_lengths)), columns) / len(q_lengths)
+        rows = spaced(len(q_lengths), int(min(len(q_lengths), max(len(rows), budget_cells / max(per_row, 1.0)))))
+    whole = len(rows) == len(q_lengths) and len(columns) == len(c_lengths)
+
+    started = time.perf_counter()
+    matrix = run(rows, columns)
     first = time.perf_counter() - started
-    assert np.array_equal(matrix, gpu_matrix), "CPU baseline and GPU disagree"
-    repeats = int(max(1, min(50, 10.0 / max(first, 1e-3))))  # about 10 s of CPU work in total
+    expected = gpu_matrix[np.ix_(rows, columns)]
+    assert np.array_equal(matrix.view(np.int64), expected.view(np.int64)), "CPU baseline and GPU disagree"
+    repeats = int(max(1, min(50, (seconds - first) / max(first, 1e-3))))
     started = time.perf_counter()
     for _ in range(repeats):
-        run()
+        run(rows, columns)
     elapsed = (time.perf_counter() - started) / repeats
+    what = (f"the full {len(q_lengths)}x{len(c_lengths)} batch of the timed config" if whole else
+            f"{len(rows)} evenly spaced query rows x {len(columns)} evenly spaced candidates of the timed config")
     return {
-        "value": round(load.cells / elapsed / 1e9, 2), "unit": "GCUPS", "cores": cores, "kind": kind,
-        "sample": f"the full {len(queries)}x{len(candidates)} batch of the timed config, {repeats} repeats, "
-                  f"{label} tier, {cores} threads, tape packing included; matrix verified equal to the GPU's",
+        "value": round(cells_of(rows, columns) / elapsed / 1e9, 2), "unit": "GCUPS", "cores": cores, "kind": kind,
+        "sample": f"{what}, {repeats} repeats, {label} tier, {cores} threads, tape packing included; "
+                  f"the sampled cells verified equal to the GPU's",
     }
+
+
+# ---- rooflines -------------------------------------------------------------------------------------------------------------
+
+DOMINANT_KERNEL = {  # the kernel that owns (nearly) all of a config's time, by name prefix in the PMC summaries
+    2: "levenshtein_myers_short_kernel", 3: "weighted_packed_kernel<false, false>", 4: "weighted_packed_kernel<true, true>",
+    5: "levenshtein_myers_long_kernel", 6: "levenshtein_myers_long_runes_kernel",
+}
+
+
+def roofline(config, profile, kernel_seconds, traffic_override=None):
+    """HBM roofline from the ALGORITHMIC bytes of one call over the measured kernel time, the PMC traffic of the
+    dominant kernel from the committed passes of this command, and - what actually binds - its VALU issue rate."""
+    achieved = profile.algorithmic_bytes / kernel_seconds / 1e9
+    record = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+              "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic_override, "kernel_ms": round(kernel_seconds * 1e3, 4),
+              "algorithmic_bytes": int(profile.algorithmic_bytes), "launches_per_step": int(profile.launches),
+              "kernel_gcups": round(profile.cells / kernel_seconds / 1e9, 1)}
+    summary, where = _profile_json("pmc_summary.json" if config == 2 else "pmc_configs.json")
+    wanted = DOMINANT_KERNEL.get(config, "")
+    counters = None
+    for name, entry in (summary or {}).items():
+        if wanted and name.startswith(wanted) and (counters is None or entry.get("_share", 0) > counters.get("_share", 0)):
+            counters, record["kernel"] = entry, name
+    if counters is None:
+        record["traffic_source"] = "no committed PMC pass for this config" if traffic_override is None else "from --hbm-traffic-bytes"
+        return record
+    if traffic_override is None and "hbm_fetch_bytes_raw" in counters and "hbm_write_bytes_raw" in counters:
+        scale = counters.get("_launches_per_call", 1.0)
+        record["traffic"] = (counters["hbm_fetch_bytes_raw"] + counters["hbm_write_bytes_raw"]) * scale
+        record["traffic_source"] = (f"{where}: (FETCH_SIZE + WRITE_SIZE) x 1024 per launch of the dominant kernel, committed "
+                                    f"rocprofv3 --pmc passes of this command (raw; wide-stream reads may count double)")
+    if "SQ_INSTS_VALU" in counters:
+        # wave-instructions x 64 lanes over the kernel's own profiled duration, against one lane-op per lane per cycle
+        duration = counters.get("_duration_seconds") or kernel_seconds
+        lane_ops = counters["SQ_INSTS_VALU"] * 64.0
+        record["valu"] = {
+            "bound": "integer VALU issue (PMC)", "source": where,
+            "wave_instructions_per_launch": counters["SQ_INSTS_VALU"],
+            "lane_ops_per_cell": round(lane_ops * counters.get("_launches_per_call", 1.0) / max(float(profile.cells), 1.0), 4)
+            if counters.get("_cells_match", True) else None,
+            "achieved_Tlane_ops_per_s": round(lane_ops / duration / 1e12, 2),
+            "peak_Tlane_ops_per_s": VALU_LANE_OPS_PEAK / 1e12,
+            "frac": round(lane_ops / duration / VALU_LANE_OPS_PEAK, 4),
+            "lds_conflict_fraction": round(counters["lds_conflict_fraction"], 4) if "lds_conflict_fraction" in counters else None,
+        }
+    return record
+
+
+def time_config(step, engine, budget_seconds, fence, floor=2, ceiling=50):
+    """Warm-up call, then as many timed calls as `budget_seconds` allows; returns (wall s per call, kernel s per call)."""
+    step()
+    fence()
+    started = time.perf_counter()
+    step()
+    once = time.perf_counter() - started
+    repeats = int(max(floor, min(ceiling, budget_seconds / max(once, 1e-4))))
+    kernel = []
+    fence()
+    started = time.perf_counter()
+    for _ in range(repeats):
+        step()
+        kernel.append(engine.last_call_profile().kernel_milliseconds * 1e-3)
+    fence()
+    return (time.perf_counter() - started) / repeats, float(np.mean(kernel)), repeats
+
+
+def measure_extra(config, scope, device_index, args, fence, with_cpu):
+    """One record of the `configs` array on ONE GPU: the whole batch through the config's own entry point."""
+    import torch
+
+    from stringzilla_amd import workloads
+
+    load = workloads.config(config)
+    engine = make_engine(load, scope)
+    queries, candidates = load.queries.to_device(device_index), load.candidates.to_device(device_index)
+    results = torch.empty((len(queries), len(candidates)), dtype=torch.int64, device=torch.device("cuda", device_index))
+    step = make_step(engine, scope, load, queries, candidates, results, device_index)
+    wall, kernel, repeats = time_config(step, engine, args.extra_seconds, fence)
+    profile = engine.last_call_profile()
+    record = {
+        "config": config, "workload": load.name, "entry_point": ENTRY_POINTS[load.kind], "n_gpus": 1,
+        "pairs": int(profile.pairs), "cells": int(profile.cells), "steps": repeats,
+        "value": round(profile.cells / wall / 1e9, 1), "unit": "GCUPS", "ms_per_step": round(wall * 1e3, 3),
+        "kernel_gcups": round(profile.cells / kernel / 1e9, 1), "tier": int(profile.tier), "cell_bits": int(profile.cell_bits),
+        "dtype": {0: "u32 bit-vectors", 16: "i16 cells, two per VALU op", 32: "i32 cells", 64: "i64 cells"}.get(int(profile.cell_bits), "?"),
+        "results_checksum": int(results.sum().item()),
+        "roofline": roofline(config, profile, kernel),
+    }
+    if with_cpu:
+        try:
+            record["cpu_baseline"] = cpu_baseline(load, results.cpu().numpy(), args.cpu_seconds)
+        except AssertionError:
+            raise
+        except Exception as problem:  # the checker is optional equipment; the GPU numbers stand without it
+            record["cpu_baseline"] = {"error": repr(problem)}
+    return record
+
+
+def measure_strong(config, scope, device_index, args, fence, dist, world, rank, where):
+    """Configs 4 and 5 as BASELINE.json states them: ONE batch whose query rows are dealt over the GPUs of the node.
+    Rank 0 owns the batch; tapes are replicated by an RCCL broadcast (device to device); every rank scores its rows; no
+    collective on the data path.  Reports per-GPU busy time, imbalance and the aggregate rate."""
+    import torch
+
+    from stringzilla_amd import sharded, workloads
+
+    load = workloads.config(config)  # seeded: every rank can name the engine; only rank 0's copy of the strings is used
+    engine = make_engine(load, scope)
+    busy, state = [], {}
+
+    def score(queries, candidates):
+        queries.to_device(device_index), candidates.to_device(device_index)
+        out = torch.empty((len(queries), len(candidates)), dtype=torch.int64, device=where)
+        step = make_step(engine, scope, load, queries, candidates, out, device_index)
+        wall, kernel, repeats = time_config(step, engine, args.extra_seconds, lambda: torch.cuda.synchronize(), floor=2, ceiling=20)
+        busy.append(wall), state.update(kernel=kernel, repeats=repeats)
+        return out
+
+    node = sharded.ShardedEngine(engine=engine, scope=scope, score=score)
+    fence()
+    rows, local = node(load.queries if rank == 0 else None, load.candidates if rank == 0 else None, source=0)
+    profile = engine.last_call_profile()
+    mine = torch.tensor([busy[0] if busy else 0.0, float(profile.cells) if busy else 0.0, float(len(rows)),
+                         float(local.sum()) if len(rows) else 0.0, state.get("kernel", 0.0)], dtype=torch.float64,
+                        device=where if dist.get_backend() == "nccl" else "cpu")
+    gathered = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    if rank:
+        return None
+    seconds = np.array([float(g[0]) for g in gathered])
+    cells = sum(float(g[1]) for g in gathered)
+    return {
+        "config": config, "workload": load.name, "entry_point": ENTRY_POINTS[load.kind], "n_gpus": world, "scaling": "strong",
+        "sharding": "query rows dealt by LPT on len(query), both tapes replicated by RCCL broadcast, results stay sharded",
+        "cells": int(cells), "rows_per_gpu": [int(g[2]) for g in gathered],
+        "busy_ms_per_gpu": [round(s * 1e3, 3) for s in seconds.tolist()],
+        "kernel_ms_per_gpu": [round(float(g[4]) * 1e3, 3) for g in gathered],
+        "imbalance_max_over_mean": round(float(seconds.max() / max(seconds.mean(), 1e-12)), 4),
+        "row_weight_imbalance": round(node.last_balance, 4),
+        "value": round(cells / seconds.max() / 1e9, 1), "unit": "GCUPS",
+        "results_checksum": int(sum(float(g[3]) for g in gathered)), "same_device": bool(args.same_device),
+    }
+
+
+def measure_c_node(config, devices, args):
+    """The same strong-scaled batch through the single-process C entry (`szs_rocm_node_*`): one host thread per GPU inside
+    the library, tapes replicated by `hipMemcpyPeerAsync`.  Runs on rank 0 while the other ranks wait at a barrier."""
+    import torch
+
+    import stringzilla_amd as szs
+    from stringzilla_amd import workloads
+
+    if not hasattr(szs, "Node"):
+        return None
+    load = workloads.config(config)
+    node = szs.Node(devices)
+    engine = node.engine_for(load)
+    out = torch.empty((len(load.queries), len(load.candidates)), dtype=torch.int64, device=torch.device("cuda", devices[0]))
+    load.queries.to_device(devices[0]), load.candidates.to_device(devices[0])
+    engine(load.queries, load.candidates, out=out)
+    started = time.perf_counter()
+    repeats = 2
+    for _ in range(repeats):
+        stats = engine(load.queries, load.candidates, out=out)
+    wall = (time.perf_counter() - started) / repeats
+    return {"config": config, "entry_point": "szs_rocm_node_scores_u32tape", "n_gpus": len(devices), "scaling": "strong",
+            "value": round(load.cells / wall / 1e9, 1), "unit": "GCUPS", "ms_per_step": round(wall * 1e3, 3),
+            "busy_ms_per_gpu": [round(x, 3) for x in stats["busy_ms"]], "rows_per_gpu": stats["rows"],
+            "results_checksum": int(out.sum().item())}
 
 
 def main():
@@ -105,7 +364,7 @@ def main():
     import torch.distributed as dist
 
     import stringzilla_amd as szs
-    from stringzilla_amd import _abi, workloads
+    from stringzilla_amd import workloads
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -121,37 +380,28 @@ def main():
 
     # ---- the batch: rank r owns query rows [1024 r, 1024 (r + 1)); candidates are shared by all ranks
     load = workloads.config(args.config)
-    if load.kind != "levenshtein":
-        raise SystemExit("bench.py times the Levenshtein path; other configs are parity-test cases")
     if rank:
         rng = np.random.default_rng(args.config + 1000 * rank)
         low, high = int(load.queries.lengths().min()), int(load.queries.lengths().max())
         load.queries = workloads.random_tape(rng, len(load.queries), 96 if args.config == 2 else low,
                                              160 if args.config == 2 else high, workloads.ASCII_PRINTABLE)
     queries = load.queries.to_device(local_rank)
-    if world > 1:  # the one exchange step of the path: replicate the candidates tape over RCCL / xGMI, before timing
+    if world > 1:  # the one exchange step of the path: replicate the candidates tape over RCCL / xGMI, before timing;
+        # the received tape stays in HBM (only its offsets are mirrored on the host)
         size = torch.tensor([load.candidates.data.size], device=where)
         dist.broadcast(size, 0)
         data = torch.from_numpy(load.candidates.data).to(where) if rank == 0 else torch.empty(int(size), dtype=torch.uint8, device=where)
         offsets = torch.from_numpy(load.candidates.offsets.view(np.int32)).to(where) if rank == 0 else torch.empty(len(load.candidates) + 1, dtype=torch.int32, device=where)
         dist.broadcast(data, 0)
         dist.broadcast(offsets, 0)
-        load.candidates = szs.Strs.from_tape(data.cpu().numpy(), offsets.cpu().numpy().view(np.uint32))
-        load.candidates._device = (local_rank, data, offsets)
+        load.candidates = szs.Strs.from_device(data, offsets)
     candidates = load.candidates.to_device(local_rank)
 
     scope = szs.DeviceScope(gpu_device=local_rank)
-    engine = szs.LevenshteinDistances(**load.costs, capabilities=scope)
+    engine = make_engine(load, scope)
     rows, columns = len(queries), len(candidates)
     results = torch.empty((rows, columns), dtype=torch.int64, device=where)
-    q_tape, c_tape = queries._tape(local_rank), candidates._tape(local_rank)
-    error = ctypes.c_char_p()
-
-    def step():
-        status = _abi.lib.szs_levenshtein_distances_u32tape(engine.handle, scope.handle, ctypes.byref(q_tape), ctypes.byref(c_tape),
-                                                            results.data_ptr(), columns, ctypes.byref(error))
-        if status:
-            raise RuntimeError(f"szs_levenshtein_distances_u32tape failed: {status} {error.value}")
+    step = make_step(engine, scope, load, queries, candidates, results, local_rank)
 
     def fence():
         torch.cuda.synchronize()
@@ -182,29 +432,56 @@ def main():
         dist.all_reduce(checksum)
     total_cells = float(cells_per_rank)
 
+    # ---- the other configs (after the headline's timed region; every rank takes part when N > 1)
+    if args.extra_configs is None:
+        extras = [3, 4, 5, 6] if world == 1 else [4, 5]
+    else:
+        extras = [] if args.extra_configs.strip().lower() in ("", "none") else [int(x) for x in args.extra_configs.split(",")]
+    records = []
+    for config in extras:
+        try:
+            if world == 1:
+                records.append(measure_extra(config, scope, local_rank, args, fence, not args.no_cpu_baseline))
+            else:
+                record = measure_strong(config, scope, local_rank, args, fence, dist, world, rank, where)
+                if record is not None:
+                    records.append(record)
+        except AssertionError:
+            raise
+        except Exception as problem:  # an extra record must never cost the headline line
+            records.append({"config": config, "error": repr(problem)})
+    if world > 1 and not args.same_device and extras:
+        fence()
+        if rank == 0:  # single-process C driver over the same GPUs, while the other ranks wait
+            for config in extras:
+                try:
+                    record = measure_c_node(config, list(range(world)), args)
+                    if record is not None:
+                        records.append(record)
+                except Exception as problem:
+                    records.append({"config": config, "entry_point": "szs_rocm_node_scores_u32tape", "error": repr(problem)})
+        fence()
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total_cells * args.steps / elapsed / 1e9
         kernel = float(np.mean(kernel_ms)) * 1e-3  # seconds per launch group, hipEvent pair on the library's stream
-        achieved = profile.algorithmic_bytes / kernel / 1e9
-        gpu_matrix = results.cpu().numpy().view(np.uint64)
-        # HBM traffic of the dominant kernel, per launch: FETCH_SIZE + WRITE_SIZE from their own rocprofv3 --pmc passes
-        # of this command (scripts/profile_gpu.sh), kilobyte units and the gfx950 wide-read correction applied by
-        # scripts/pmc_summary.py as MI355X_MICROARCH.md prescribes.  Committed, not collected inside this process.
-        traffic = args.hbm_traffic_bytes
-        traffic_note = "from --hbm-traffic-bytes" if traffic is not None else "no committed PMC pass for this config"
-        if traffic is None and args.config == 2:
-            summary = next((counters for name, counters in (_profile_json("pmc_summary.json") or {}).items()
-                            if name.startswith("levenshtein_myers_short_kernel")), None)  # the name carries template arguments
-            if summary and "hbm_fetch_bytes_raw" in summary and "hbm_write_bytes_raw" in summary:
-                traffic = summary["hbm_fetch_bytes_raw"] + summary["hbm_write_bytes_raw"]
-                traffic_note = ("profiles/r01/pmc_summary.json: FETCH_SIZE*1024 + WRITE_SIZE*1024 per launch (raw; the x2 "
-                                "wide-stream read correction would give %d)" % int(
-                                    summary["hbm_fetch_bytes_x2_wide_stream_correction"] + summary["hbm_write_bytes_raw"]))
-        valu = (_profile_json("valu_peak.json") or {})
-        pure = valu.get("myers_pure_W4_Tcells")
+        gpu_matrix = results.cpu().numpy()
+        valu_table, valu_where = _profile_json("valu_peak.json")
+        pure = (valu_table or {}).get("myers_pure_W4_Tcells")
         lengths = load.queries.lengths().astype(np.int64)
         padded_cells = float((np.maximum(1, -(-lengths // 32)) * 32).sum()) * float(load.candidates.lengths().sum())
+        line_roofline = roofline(args.config, profile, kernel, args.hbm_traffic_bytes)
+        line_roofline["note"] = ("integer-VALU bound by construction (HBM traffic is a few % of the algorithmic bytes: tapes are "
+                                 "L2-resident); the HBM fraction is reported because the metric asks for it, the `valu` and "
+                                 "`myers_ceiling` objects are the rooflines that say something about the kernel")
+        if load.kind == "levenshtein" and pure:
+            line_roofline["myers_ceiling"] = {
+                "bound": "integer VALU issue, measured", "achieved_Tcells_per_s_full_width": round(padded_cells / kernel / 1e12, 2),
+                "peak_Tcells_per_s_full_width": pure, "frac": round(padded_cells / kernel / 1e12 / pure, 4),
+                "peak_source": f"scripts/valu_peak.hip `myers_pure_W4_Tcells`: the kernel's column update on "
+                               f"register-resident masks ({valu_where})",
+                "useful_fraction_of_width": round(float(profile.cells) / padded_cells, 4)}
         line = {
             "metric": "DP cell-updates/s (GCUPS) on 1M-pair Levenshtein batch", "value": round(value, 1), "unit": "GCUPS",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -212,30 +489,15 @@ def main():
             "data": "synthetic",
             "config": {"workload": load.name, "pairs_per_gpu": rows * columns, "cells_per_gpu": int(profile.cells),
                        "sharding": "query row blocks, candidates replicated" if world > 1 else "single GPU",
-                       "entry_point": "szs_levenshtein_distances_u32tape"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_source": traffic_note,
-                         "kernel": ("levenshtein_myers_short_kernel (1 launch per step)" if profile.launches == 1 else
-                                    "levenshtein_myers_short_kernel + long-width kernels (%d launches per step)" % profile.launches),
-                         "kernel_ms": round(kernel * 1e3, 4),
-                         "algorithmic_bytes": int(profile.algorithmic_bytes),
-                         "kernel_gcups": round(profile.cells / kernel / 1e9, 1),
-                         "note": "integer-VALU bound by construction (HBM traffic is ~4% of the algorithmic bytes: tapes "
-                                 "are L2-resident); the HBM fraction is reported because the metric asks for it, the "
-                                 "`valu` object is the roofline that says something about the kernel",
-                         "valu": {
-                             "bound": "integer VALU issue, measured",
-                             "achieved_Tcells_per_s_full_width": round(padded_cells / kernel / 1e12, 2),
-                             "peak_Tcells_per_s_full_width": pure,
-                             "frac": round(padded_cells / kernel / 1e12 / pure, 4) if pure else None,
-                             "peak_source": "scripts/valu_peak.hip `myers_pure_W4_Tcells`: the kernel's column update on "
-                                            "register-resident masks (profiles/r01/valu_peak.json)",
-                             "useful_fraction_of_width": round(float(profile.cells) / padded_cells, 4)}},
+                       "entry_point": ENTRY_POINTS[load.kind]},
+            "roofline": line_roofline,
             "host_overhead_ms_per_step": round(ms_per_step - kernel * 1e3, 4),
             "results_checksum": float(checksum),
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(load, gpu_matrix)
+            line["cpu_baseline"] = cpu_baseline(load, gpu_matrix, args.cpu_seconds)
+        if records:
+            line["configs"] = records
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -30,7 +30,8 @@ typedef struct szs_rocm_call_profile_t {
     sz_u32_t longest_candidate;
     sz_u32_t tier;                /* 0: one pair per lane (lev_myers.hip, weighted*.hip); 1: systolic.hip; 2: myers_chain.hip */
     sz_u32_t transposed;          /* 1: the planner swapped the sides (candidates on workgroups, queries on lanes) */
-    sz_u32_t cell_bits;           /* width of the DP cells of the last launch: 16 (weighted_packed.hip), 32, or 0 (bit-parallel) */
+    sz_u32_t cell_bits;           /* width of the DP cells of the last launch: 16 (weighted_packed.hip), 32, 64 (wide.hip), or 0 (bit-parallel) */
+    sz_u32_t planner;             /* 0: planned on the host; 1: on the device (hip/planner.hip); 2: on the device, launches speculated */
 } szs_rocm_call_profile_t;
 
 /** Copies the profile of the most recent call made through `engine` (any of the four engine handle types). */
@@ -67,6 +68,15 @@ SZ_API_RUNTIME sz_status_t szs_rocm_orientation_probe(int unit_cost, int affine,
                                                       sz_u32_t const *query_lengths, sz_size_t queries_count,
                                                       sz_u32_t const *candidate_lengths, sz_size_t candidates_count,
                                                       int *tier, int *transposed);
+
+/**
+ *  Tuning / testing knobs (csrc/host/tuning.c).  The library reads the `SZS_ROCM_*` environment variables ONCE, when it
+ *  is loaded; afterwards a knob changes only through this call.  `knob` is one of "tier" (lanes | systolic | chain),
+ *  "swap" (0 | 1), "packed" (0), "rune_ids" (n), "chain_waves" (4 | 8 | 16), "trace" (0 | 1), "cells" (64),
+ *  "planner" (host | device), "speculate" (0) - or its environment spelling ("SZS_ROCM_TIER" ...); `value` NULL, "" or
+ *  "auto" restores the automatic choice.  No knob changes a result: they pick among kernels that compute the same scores.
+ */
+SZ_API_RUNTIME sz_status_t szs_rocm_tuning_set(char const *knob, char const *value);
 
 #ifdef __cplusplus
 }

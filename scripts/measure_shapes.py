@@ -71,9 +71,9 @@ for label, q_count, c_count, length in SHAPES:
             if mode == "pinned" and longest_pair * (1 if name == "lev_unit" and length <= 2048 else 12) > args.lanes_budget:
                 continue  # one lane would walk this pair for seconds to minutes
             if mode == "pinned":
-                os.environ["SZS_ROCM_TIER"], os.environ["SZS_ROCM_SWAP"] = "lanes", "0"
+                _abi.tuning_set("tier", "lanes"), _abi.tuning_set("swap", "0")
             else:
-                os.environ.pop("SZS_ROCM_TIER", None), os.environ.pop("SZS_ROCM_SWAP", None)
+                _abi.tuning_set("tier", None), _abi.tuning_set("swap", None)
             engine = make()
             kernel, wall, profile = timed(engine, queries, candidates, out, args.repeats)
             sums[mode] = int(out.sum().item())
@@ -85,4 +85,4 @@ for label, q_count, c_count, length in SHAPES:
             }), flush=True)
         if len(sums) == 2:
             assert sums["auto"] == sums["pinned"], (label, name, sums)
-os.environ.pop("SZS_ROCM_TIER", None), os.environ.pop("SZS_ROCM_SWAP", None)
+_abi.tuning_set("tier", None), _abi.tuning_set("swap", None)

@@ -112,7 +112,9 @@ class Strs:
     binding hands to `szs_*_u32tape` / `_u64tape`: python/stringzillas/similarities.c:275-318).
 
     The tape is assembled on the host and moved to device memory on first use (the reference's binding swaps the
-    collection to its unified allocator at the same point: similarities.c:268-272)."""
+    collection to its unified allocator at the same point: similarities.c:268-272).  A tape that was BORN on a device
+    (`from_device`: the receiving side of an RCCL broadcast) keeps its bytes there; only the offsets - which the host
+    planner and the row dealer read - are mirrored on the host, the bytes are downloaded if somebody asks for them."""
 
     def __init__(self, strings: Iterable[Union[str, bytes, bytearray, memoryview]] = (), wide_offsets: bool = False):
         encoded = [s.encode("utf-8") if isinstance(s, str) else bytes(s) for s in strings]
@@ -123,19 +125,38 @@ class Strs:
         if self.count:
             np.cumsum(np.fromiter((len(s) for s in encoded), dtype=np.uint64, count=self.count), out=offsets[1:])
         self.offsets = offsets
-        self.data = np.frombuffer(b"".join(encoded), dtype=np.uint8).copy() if total else np.zeros(1, np.uint8)
-        self._device = None  # (device index, data tensor, offsets tensor)
+        self._data = np.frombuffer(b"".join(encoded), dtype=np.uint8).copy() if total else np.zeros(1, np.uint8)
+        self._device = None  # (device index or "cpu", data tensor, offsets tensor)
 
     @classmethod
     def from_tape(cls, data: np.ndarray, offsets: np.ndarray) -> "Strs":
         self = cls.__new__(cls)
-        self.data = np.ascontiguousarray(data, dtype=np.uint8) if data.size else np.zeros(1, np.uint8)
+        self._data = np.ascontiguousarray(data, dtype=np.uint8) if data.size else np.zeros(1, np.uint8)
         self.offsets = np.ascontiguousarray(offsets)
         assert self.offsets.dtype in (np.uint32, np.uint64)
         self.wide_offsets = self.offsets.dtype == np.uint64
         self.count = len(offsets) - 1
         self._device = None
         return self
+
+    @classmethod
+    def from_device(cls, data, offsets) -> "Strs":
+        """A tape whose bytes (`uint8` tensor) and offsets (`int32` / `int64` tensor holding the unsigned values) already
+        live in torch memory - device memory after an RCCL broadcast, host memory under `gloo`."""
+        self = cls.__new__(cls)
+        self._data = None
+        self.wide_offsets = offsets.element_size() == 8
+        self.offsets = offsets.cpu().numpy().view(np.uint64 if self.wide_offsets else np.uint32)
+        self.count = len(self.offsets) - 1
+        self._device = (data.device.index if data.device.type == "cuda" else "cpu", data, offsets)
+        return self
+
+    @property
+    def data(self) -> np.ndarray:
+        if self._data is None:  # born on a device: download on demand
+            host = self._device[1].cpu().numpy()
+            self._data = host if host.size else np.zeros(1, np.uint8)
+        return self._data
 
     def __len__(self) -> int:
         return self.count
@@ -146,6 +167,31 @@ class Strs:
     def lengths(self) -> np.ndarray:
         return np.diff(self.offsets.astype(np.int64))
 
+    def select(self, rows: np.ndarray) -> "Strs":
+        """Sub-tape holding `rows` of this tape, in that order; gathered where the bytes live (on the device for a
+        device-born tape: one index computation and one gather, nothing crosses the host link)."""
+        rows = np.asarray(rows, dtype=np.int64)
+        offsets = self.offsets.astype(np.int64)
+        starts, lengths = offsets[rows], offsets[rows + 1] - offsets[rows]
+        new_offsets = np.zeros(len(rows) + 1, dtype=self.offsets.dtype)
+        np.cumsum(lengths, out=new_offsets[1:])
+        total = int(new_offsets[-1])
+        if self._data is None and self._device is not None:
+            import torch
+
+            _, data, _ = self._device
+            if total:
+                shift = torch.from_numpy(np.repeat(starts - new_offsets[:-1].astype(np.int64), lengths)).to(data.device)
+                gathered = data[torch.arange(total, device=data.device) + shift]
+            else:
+                gathered = torch.zeros(1, dtype=torch.uint8, device=data.device)
+            signed = torch.from_numpy(new_offsets.view(np.int64 if self.wide_offsets else np.int32)).to(data.device)
+            return Strs.from_device(gathered, signed)
+        if total:
+            index = np.arange(total, dtype=np.int64) + np.repeat(starts - new_offsets[:-1].astype(np.int64), lengths)
+            return Strs.from_tape(self.data[index], new_offsets)
+        return Strs.from_tape(np.zeros(1, np.uint8), new_offsets)
+
     def to_device(self, gpu_device: int = 0) -> "Strs":
         if self._device is None or self._device[0] != gpu_device:
             import torch
@@ -153,6 +199,9 @@ class Strs:
             if not torch.cuda.is_available():
                 raise RuntimeError("stringzilla_amd needs a GPU: torch.cuda.is_available() is False (no CPU fallback)")
             where = torch.device("cuda", gpu_device)
+            if self._device is not None and self._data is None:  # born elsewhere: move the tensors
+                self._device = (gpu_device, self._device[1].to(where), self._device[2].to(where))
+                return self
             data = torch.from_numpy(self.data).to(where)
             # torch has no uint32/uint64 arithmetic, but plain storage is all we need: view as signed of equal width.
             signed = self.offsets.view(np.int64 if self.wide_offsets else np.int32)

@@ -54,6 +54,7 @@ class CallProfile(ctypes.Structure):
         ("cells", ctypes.c_uint64), ("pairs", ctypes.c_uint64), ("algorithmic_bytes", ctypes.c_uint64),
         ("unique_bytes", ctypes.c_uint64), ("launches", ctypes.c_uint32), ("longest_query", ctypes.c_uint32),
         ("longest_candidate", ctypes.c_uint32), ("tier", ctypes.c_uint32), ("transposed", ctypes.c_uint32), ("cell_bits", ctypes.c_uint32),
+        ("planner", ctypes.c_uint32),
     ]
 
 
@@ -98,6 +99,7 @@ SIGNATURES = {
     "szs_rocm_shard_rows": (c_int, [c_void_p, c_size_t, c_size_t, c_void_p, c_void_p]),
     "szs_rocm_plan_probe": (c_int, [c_int, c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "szs_rocm_orientation_probe": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "szs_rocm_tuning_set": (c_int, [c_char_p, c_char_p]),
 }
 
 REFERENCE_SYMBOLS = [name for name in SIGNATURES if not name.startswith("szs_rocm_")]  # the reference's 41
@@ -129,6 +131,15 @@ class StringZillasError(RuntimeError):
         self.status = status
         self.status_name = STATUS_NAMES.get(status, str(status))
         super().__init__(f"sz_status_t {self.status_name} ({status}): {message or 'no message'}")
+
+
+def tuning_set(knob: str, value=None) -> None:
+    """`szs_rocm_tuning_set`: pins one of the library's tuning / testing knobs ("tier", "swap", "packed", "rune_ids",
+    "chain_waves", "trace", "cells", "planner", "speculate" or the `SZS_ROCM_*` spelling); None restores the automatic
+    choice.  The environment is only read once, when the library is loaded."""
+    status = lib.szs_rocm_tuning_set(knob.encode(), None if value is None else str(value).encode())
+    if status != 0:
+        raise ValueError(f"unknown tuning knob {knob!r}")
 
 
 def check(status: int, error: c_char_p) -> None:

@@ -18,6 +18,18 @@ using i64 = int64_t;
 
 constexpr u32 wave_size_k = 64;
 
+/* ---- host side: occupancy / attribute caches are kept PER DEVICE ORDINAL (the C-ABI allows one scope per GPU inside one
+ *      process, each driven by its own host thread).  A slot holds an idempotent value, written and read with relaxed
+ *      atomics: two threads that race on the first use compute the same number. */
+constexpr int device_slots_k = 64;
+inline int device_slot() {
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) (void)hipGetLastError(), device = 0;
+    return device < 0 || device >= device_slots_k ? 0 : device;
+}
+inline int cached(int const *slot) { return __atomic_load_n(slot, __ATOMIC_RELAXED); }
+inline void remember(int *slot, int value) { __atomic_store_n(slot, value, __ATOMIC_RELAXED); }
+
 /** Maximum of `value` over the 64 lanes of the wavefront (butterfly over ds_swizzle / DPP via __shfl_xor). */
 __device__ __forceinline__ u32 wave_max_u32(u32 value) {
 #pragma unroll

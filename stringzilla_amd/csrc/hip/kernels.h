@@ -79,6 +79,72 @@ int szs_hip_levenshtein_myers_runes_long(unsigned words, szs_string_ref_t const 
                                          szs_string_ref_t const *candidates, uint32_t candidates_count, uint64_t *results,
                                          uint64_t results_row_stride, int symmetric, void *stream);
 
+/* ---- tuning knobs (host/tuning.c): read from the environment ONCE at load, changed only by szs_rocm_tuning_set -------- */
+
+enum {
+    szs_knob_tier_k = 0,    /* -1 automatic | 0 lanes | 1 systolic | 2 chain */
+    szs_knob_swap_k,        /* -1 automatic | 0 | 1: the planner's orientation */
+    szs_knob_packed_k,      /* -1 automatic | 0: pin the 32-bit weighted kernel */
+    szs_knob_rune_ids_k,    /* -1 automatic | n: shrink the rune table of the long codepoint kernels to n ids */
+    szs_knob_chain_waves_k, /* -1 automatic | 4 / 8 / 16: wavefronts per workgroup of the bit-parallel chain */
+    szs_knob_trace_k,       /* 0 | 1: per-phase host times of every call on stderr */
+    szs_knob_cells_k,       /* -1 automatic | 64: force the 64-bit cell tier */
+    szs_knob_planner_k,     /* -1 automatic | 0 host | 1 device */
+    szs_knob_speculate_k,   /* -1 automatic | 0: never enqueue scoring launches before the plan is known */
+    szs_knob_count_k
+};
+int szs_tuning_get(int knob);
+
+/* ---- the planner on the device (hip/planner.hip) ------------------------------------------------------------------------- */
+
+#define SZS_PLAN_VARIANTS 10u /* slot 0: no bit-parallel width (weighted / strip kernels); 1..9: SZS_MYERS_SHORT_WORDS, 10 ... 64 */
+#define SZS_PLAN_DEVICE_LONGEST 12287u /* longest string the device planner sorts (LDS histogram); beyond: host planner */
+#define SZS_PLAN_STATUS_DESCENDING 1u /* tape offsets do not ascend */
+#define SZS_PLAN_STATUS_OVERFLOW 2u   /* a string of 4 GiB or more */
+#define SZS_PLAN_STATUS_UNSORTED 4u   /* a side was not sorted (status above, or strings beyond SZS_PLAN_DEVICE_LONGEST) */
+
+/** What the tier / orientation model (host/plan.c) needs to know about one side of a cross-product. */
+typedef struct szs_side_stats_t {
+    uint32_t count, longest;
+    uint64_t symbols;        /* sum of the lengths */
+    uint64_t bands_systolic; /* sum of ceil(length / SZS_SYSTOLIC_BAND_ROWS), at least 1 per string */
+    uint64_t bands_chain;    /* the same for SZS_MYERS_CHAIN_BAND_ROWS */
+} szs_side_stats_t;
+
+/** One side of the planner's input and output: a tape (32- or 64-bit offsets, device-accessible) and two ref arrays. */
+typedef struct szs_plan_side_t {
+    void const *offsets;
+    uint64_t base; /* address of the tape's bytes */
+    uint32_t count, wide;
+    szs_string_ref_t *ascending, *descending;
+} szs_plan_side_t;
+
+/** The launch shape the host has ALREADY enqueued scoring kernels for (speculation on the previous call's shape). */
+typedef struct szs_plan_expectation_t {
+    uint32_t enabled;
+    uint32_t query_side;  /* which side takes the kernels' query role: 0 = the caller's queries, 1 = its candidates */
+    uint32_t longest[2];  /* upper bounds the workspaces and cell widths were chosen for: queries, candidates */
+    uint32_t variant_counts[SZS_PLAN_VARIANTS]; /* strings per launch variant on the query side: must match exactly */
+    uint32_t sequence;    /* echoed into the summary, so that a stale summary is never mistaken for this call's */
+} szs_plan_expectation_t;
+
+typedef struct szs_plan_summary_t {
+    uint32_t status;           /* SZS_PLAN_STATUS_* bits; 0 = both sides planned */
+    uint32_t speculation_held; /* the batch fits the expectation: the speculated launches scored it */
+    szs_side_stats_t side[2];  /* queries, candidates (symmetric: twice the same) */
+    uint32_t variant_counts[2][SZS_PLAN_VARIANTS];
+    uint64_t symmetric_cells;  /* symmetric calls: cells of the lower triangle */
+    uint32_t sequence;
+} szs_plan_summary_t;
+
+/**
+ *  Plans one call on the device: reads the offsets of both tapes (`candidates` NULL: symmetric), writes for each side the
+ *  refs sorted by ascending and by descending length, and the summary (pinned host memory is fine).  With `expected`
+ *  enabled and violated, every ref is written with length 0.  One workgroup; see hip/planner.hip.
+ */
+int szs_hip_plan(szs_plan_side_t const *queries, szs_plan_side_t const *candidates, unsigned myers_words,
+                 szs_plan_expectation_t const *expected, szs_plan_summary_t *summary, void *stream);
+
 /**
  *  Transcodes `count` UTF-8 strings (byte refs) into UTF-32 with the value contract of `sz_rune_decode_unchecked`:
  *  string i's runes land at `runes + rune_starts[i]`, its rune count in `rune_counts[i]`; `*any_multibyte` is OR-ed
@@ -131,6 +197,19 @@ int szs_hip_weighted_packed_scores(int local, int affine, uint32_t classes, szs_
                                    uint64_t results_row_stride, int symmetric, void *boundary, void *stream);
 size_t szs_hip_weighted_packed_boundary_bytes(int local, int affine, uint32_t classes, uint32_t queries_count,
                                               uint32_t candidates_count, uint32_t longest_candidate);
+
+/**
+ *  The 64-bit cell tier (hip/wide.hip): every objective above on an anti-diagonal walker with int64 cells, one pair per
+ *  workgroup - for inputs whose reach (serial.hpp:135-162) leaves 32 bits, where the reference widens its cells too
+ *  (serial.hpp:370-386, cuda.cuh:5863-5874).  Same refs, cost model and result addressing as szs_hip_weighted_scores;
+ *  `workspace` holds szs_hip_wide_workspace_bytes(...) bytes (a work counter + 3 or 7 diagonals per resident pair).
+ */
+int szs_hip_wide_scores(int objective, int affine, szs_cost_model_t const *model, szs_string_ref_t const *queries,
+                        uint32_t queries_count, szs_string_ref_t const *candidates, uint32_t candidates_count,
+                        uint32_t longest_query, uint32_t longest_candidate, int64_t *results, uint64_t results_row_stride,
+                        int layout, void *workspace, void *stream);
+size_t szs_hip_wide_workspace_bytes(int affine, uint32_t queries_count, uint32_t candidates_count, uint32_t longest_query,
+                                    uint32_t longest_candidate);
 
 /**
  *  The few-pairs tier of the weighted scorers (hip/systolic.hip): a pair is spread over wavefronts - 64 lanes x R rows

@@ -541,7 +541,9 @@ __global__ __launch_bounds__(256, 2) /* two wavefronts per SIMD, like the long k
 }
 
 static u32 banded_grid(u64 work_items) {
-    static int resident = 0;
+    static int resident_of[device_slots_k]; // per device ordinal
+    int *const slot = &resident_of[device_slot()];
+    int resident = cached(slot);
     if (!resident) {
         int device = 0, units = 0, per_unit = 0;
         if (hipGetDevice(&device) != hipSuccess ||
@@ -552,6 +554,7 @@ static u32 banded_grid(u64 work_items) {
             units = 256, per_unit = 1;
         }
         resident = units * per_unit;
+        remember(slot, resident);
     }
     return (u32)(work_items < (u64)resident ? work_items : (u64)resident);
 }
@@ -720,8 +723,7 @@ static bool rune_lds_plan(unsigned words, u32 &rune_slots, u32 &id_capacity, siz
     while (rune_slots < 64u * words) rune_slots *= 2;
     size_t const table_bytes = (size_t)rune_slots * (sizeof(u32) + sizeof(uint16_t)), row_bytes = (size_t)((words + 3) / 4) * 16;
     size_t const most_runes = 32u * words;
-    char const *const forced_text = std::getenv("SZS_ROCM_RUNE_IDS"); // a testing aid: shrinks the table so that runes overflow it
-    long const forced = forced_text ? std::atol(forced_text) : 0;
+    long const forced = szs_tuning_get(szs_knob_rune_ids_k); // a testing aid: shrinks the table so that runes overflow it
     size_t const shared = ((size_t)80 << 10) - 1024, whole = ((size_t)160 << 10) - 1024; // a little static LDS on top
     size_t capacity = shared > table_bytes + row_bytes ? (shared - table_bytes) / row_bytes - 1 : 0;
     if (capacity < 512 && capacity < most_runes) capacity = whole > table_bytes + row_bytes ? (whole - table_bytes) / row_bytes - 1 : 0;
@@ -740,15 +742,16 @@ static int launch_long_runes(szs_string_ref_t const *queries, u32 queries_count,
     u32 rune_slots = 0, id_capacity = 0;
     size_t bytes = 0;
     if (!rune_lds_plan(words_, rune_slots, id_capacity, bytes)) return (int)hipErrorNotSupported;
-    static int granted = 0; // per width: has this much dynamic LDS been granted to the kernel?
-    if (!granted) {
+    static int granted_on[device_slots_k]; // per width and device: has this much dynamic LDS been granted to the kernel?
+    int *const granted = &granted_on[device_slot()];
+    if (!cached(granted)) {
         hipError_t const error = hipFuncSetAttribute(reinterpret_cast<void const *>(levenshtein_myers_long_runes_kernel<words_>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)160 << 10) - 1024));
         if (error != hipSuccess) {
             (void)hipGetLastError();
             return (int)hipErrorNotSupported; // the host falls back to the rune-keyed DP kernel
         }
-        granted = 1;
+        remember(granted, 1);
     }
     u32 const candidate_blocks = (candidates_count + SZS_CANDIDATES_PER_WORKGROUP - 1) / SZS_CANDIDATES_PER_WORKGROUP;
     u32 const queries_per_launch = candidate_blocks ? (1u << 30) / candidate_blocks : queries_count;

@@ -306,10 +306,8 @@ static chain_layout_t chain_layout(u32 queries_count, u32 candidates_count, u32 
     u64 const wavefronts = layout.pairs * layout.max_bands;
     u32 waves = wavefronts <= 2048 ? 4 : wavefronts <= 4096 ? 8 : chain_max_waves_k;
     while (waves > 4 && waves / 2 >= candidates_count) waves /= 2;
-    if (char const *forced = std::getenv("SZS_ROCM_CHAIN_WAVES")) { // a testing aid, like SZS_ROCM_TIER
-        int const asked = std::atoi(forced);
-        if (asked == 4 || asked == 8 || asked == 16) waves = (u32)asked;
-    }
+    int const asked = szs_tuning_get(szs_knob_chain_waves_k); // a testing aid, like the `tier` knob (host/tuning.c)
+    if (asked == 4 || asked == 8 || asked == 16) waves = (u32)asked;
     layout.waves = waves;
     layout.tickets = (u64)queries_count * ((candidates_count + waves - 1) / waves) * layout.max_bands; // workgroups
     layout.parked_words = (longest_candidate + chain_columns_k - 1) / chain_columns_k + chain_slack_words_k;

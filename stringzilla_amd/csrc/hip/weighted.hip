@@ -464,7 +464,9 @@ constexpr size_t weighted_header_bytes_k = 256; // the work counter lives at the
 /** Workgroups that can be RESIDENT at once for this kernel instance on the current device (never more than the work). */
 template <bool local_, bool affine_, bool uniform_, bool runes_ = false, bool saturating_ = false, bool narrow_ = false>
 static u32 weighted_grid(u64 work_items) {
-    static int resident = 0; // per instance; one device architecture per process
+    static int resident_of[device_slots_k]; // per instance and device ordinal
+    int *const slot = &resident_of[device_slot()];
+    int resident = cached(slot);
     if (!resident) {
         int device = 0, units = 0, per_unit = 0;
         if (hipGetDevice(&device) != hipSuccess ||
@@ -476,6 +478,7 @@ static u32 weighted_grid(u64 work_items) {
             units = 256, per_unit = 2;
         }
         resident = units * per_unit;
+        remember(slot, resident);
     }
     return (u32)(work_items < (u64)resident ? work_items : (u64)resident);
 }

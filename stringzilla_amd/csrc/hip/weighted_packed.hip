@@ -391,8 +391,10 @@ static size_t packed_profile_bytes(u32 classes) { return (size_t)(classes + 1) *
 /** Workgroups that can be RESIDENT at once for this kernel instance with this profile size (never more than the work). */
 template <bool local_, bool affine_>
 static u32 packed_grid(u64 work_items, u32 classes) {
-    static int resident[34] = {0}; // per instance and class count; one device architecture per process
-    if (!resident[classes]) {
+    static int resident_of[device_slots_k][34]; // per instance, device ordinal and class count
+    int *const slot = &resident_of[device_slot()][classes];
+    int resident = cached(slot);
+    if (!resident) {
         int device = 0, units = 0, per_unit = 0;
         size_t const profile_bytes = packed_profile_bytes(classes);
         if (hipFuncSetAttribute(reinterpret_cast<void const *>(weighted_packed_kernel<local_, affine_>),
@@ -405,9 +407,10 @@ static u32 packed_grid(u64 work_items, u32 classes) {
             (void)hipGetLastError();
             units = 256, per_unit = 1;
         }
-        resident[classes] = units * per_unit;
+        resident = units * per_unit;
+        remember(slot, resident);
     }
-    return (u32)(work_items < (u64)resident[classes] ? work_items : (u64)resident[classes]);
+    return (u32)(work_items < (u64)resident ? work_items : (u64)resident);
 }
 
 static u64 packed_work_items(u32 queries_count, u32 candidates_count) {

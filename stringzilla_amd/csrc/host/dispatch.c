@@ -1,10 +1,23 @@
 /*
- *  dispatch.c - one engine call, start to finish: normalise inputs -> plan -> upload refs -> launch -> synchronise.
+ *  dispatch.c - one engine call, start to finish: normalise inputs -> plan -> decide -> launch -> synchronise.
  *
  *  ROCm counterpart of the reference's `cross_()` / `run_trampoline_()` (cuda.cuh:4247-4417,4435-4741) and
  *  `cuda_weighted_cross_()` (cuda.cuh:5913).  Same observable behaviour - synchronous call, results in the caller's
  *  matrix, device-accessibility checks on the strings, staged copy when `results` is not device-visible - with a
- *  different mechanism (see plan.c).  Nothing here computes a score on the CPU.
+ *  different mechanism (see plan.c, hip/planner.hip).  Nothing here computes a score on the CPU.
+ *
+ *  Two ways to the same launches:
+ *    device-planned  both inputs are tapes whose offsets the GPU can read: hip/planner.hip turns the offsets into sorted refs
+ *                    and a summary; the host never reads an offset.  When the previous call of this engine had the same
+ *                    counts, the scoring launches are enqueued BEHIND the planner right away, shaped like that call; the
+ *                    planner blanks the refs if the batch does not fit that shape and the host, after the call's one
+ *                    synchronisation, re-plans from the summary.  A batch stream of stable shape thus costs one planner
+ *                    launch + the scoring launches + one wait - no download, no host sort, no upload.
+ *    host-planned    callback sequences, the codepoint engine (needs the transcoding pass first), offsets only the host
+ *                    can read, strings too long for the device planner's histogram: as in round 1, minus the per-call
+ *                    allocations.
+ *  Every failure after the first enqueue leaves through one exit that drains the stream first: the call is synchronous
+ *  also when it fails, so the caller may free its buffers the moment it returns.
  */
 #include "szs_internal.h"
 
@@ -146,13 +159,16 @@ static sz_status_t transcode_to_runes(szs_engine_s *engine, int device, hipStrea
 
     hipError_t error = hipMemcpyAsync(remote, host, counts_at, hipMemcpyHostToDevice, stream);
     if (error == hipSuccess) error = hipMemsetAsync(remote + flag_at, 0, sizeof(uint32_t), stream);
-    if (error != hipSuccess) return szs_report_hip(error, error_message);
-    int const launch_error = szs_hip_utf8_transcode(
-        (szs_string_ref_t const *)(remote + refs_at), (uint32_t)strings, (uint64_t const *)(remote + starts_at),
-        (uint32_t *)engine->device_runes.pointer, (uint32_t *)(remote + counts_at), (uint32_t *)(remote + flag_at), stream);
-    if (launch_error) return szs_report_hip((hipError_t)launch_error, error_message);
-    error = hipMemcpyAsync(host + counts_at, remote + counts_at, staging_bytes - counts_at, hipMemcpyDeviceToHost, stream);
-    if (error == hipSuccess) error = hipStreamSynchronize(stream);
+    if (error == hipSuccess) {
+        int const launch_error = szs_hip_utf8_transcode(
+            (szs_string_ref_t const *)(remote + refs_at), (uint32_t)strings, (uint64_t const *)(remote + starts_at),
+            (uint32_t *)engine->device_runes.pointer, (uint32_t *)(remote + counts_at), (uint32_t *)(remote + flag_at), stream);
+        error = (hipError_t)launch_error;
+    }
+    if (error == hipSuccess)
+        error = hipMemcpyAsync(host + counts_at, remote + counts_at, staging_bytes - counts_at, hipMemcpyDeviceToHost, stream);
+    hipError_t const drained = hipStreamSynchronize(stream); /* also on failure: nothing stays in flight */
+    if (error == hipSuccess) error = drained;
     if (error != hipSuccess) return szs_report_hip(error, error_message);
 
     *runes = *(uint32_t const *)(host + flag_at) != 0;
@@ -200,12 +216,15 @@ static void release_device_state(szs_engine_s *engine) {
     szs_buffer_release(&engine->device_runes);
     szs_buffer_release(&engine->device_transcode);
     szs_buffer_release(&engine->pinned_transcode);
+    szs_buffer_release(&engine->device_plan_refs);
+    szs_buffer_release(&engine->pinned_summary);
     if (engine->events_device >= 0) {
         (void)hipEventDestroy(engine->event_start);
         (void)hipEventDestroy(engine->event_stop);
         engine->events_device = -1;
     }
     engine->model_uploaded_device = -1;
+    if (engine->remembered) engine->remembered->valid = 0;
 }
 
 void szs_engine_release(szs_engine_s *engine) {
@@ -217,22 +236,627 @@ void szs_engine_release(szs_engine_s *engine) {
         (void)hipSetDevice(previous);
     }
     szs_buffer_release(&engine->host_lengths);
+    szs_buffer_release(&engine->host_scratch);
+    free(engine->remembered);
+    engine->remembered = NULL;
+}
+
+/* ---- the decision: everything that follows from the statistics of the two sides ---------------------------------------- */
+
+static sz_status_t decide(szs_engine_s const *engine, int symmetric, int runes, int force_lanes, szs_side_stats_t const *q_stats,
+                          szs_side_stats_t const *c_stats, uint32_t const *q_variants, uint32_t const *c_variants,
+                          uint64_t cells, szs_decision_t *d, char const **error_message) {
+    memset(d, 0, sizeof(*d));
+    d->symmetric = symmetric, d->runes = runes;
+    d->q_count = q_stats->count, d->c_count = c_stats->count;
+    d->longest[0] = q_stats->longest, d->longest[1] = c_stats->longest;
+    d->use_myers = engine->is_unit_cost && (engine->family == szs_family_levenshtein_k || engine->family == szs_family_levenshtein_utf8_k);
+    d->maximise = engine->family == szs_family_needleman_wunsch_k || engine->family == szs_family_smith_waterman_k;
+    /* bit-parallel at any length for bytes (2048-row strips beyond 64 words), up to 2048 symbols for codepoints */
+    d->banded = d->use_myers && !runes;
+
+    /* ---- orientation and tier.  Every kernel puts ONE side on workgroups / band chains (its "queries") and the other
+     * on lanes / columns (its "candidates"); which real side plays which role is free - gap costs apply to both strings
+     * alike and a swapped class table is its transpose - so a cycle model of both tiers (plan.c) is evaluated for both
+     * orientations and the cheaper one runs.  1024 queries x 1 candidate thus become 1 workgroup row of 1024 lanes
+     * instead of 1024 workgroups with one live lane each.  Symmetric calls have nothing to swap. */
+    szs_plan_orient(d->banded ? 0xFFFFFFFFu : (d->use_myers ? SZS_MYERS_MAX_WORDS * 32 : 0), d->use_myers && !runes, !engine->is_linear,
+                    !d->maximise, symmetric, q_stats, c_stats, szs_hip_systolic_band_rows(), &d->tier, &d->transposed);
+    /* the `tier` knob: `systolic` on a unit-cost engine means the DP recurrences, `chain` the bit-parallel chain */
+    if (d->tier == SZS_TIER_MYERS_CHAIN && szs_tuning_get(szs_knob_tier_k) == SZS_TIER_SYSTOLIC) d->tier = SZS_TIER_SYSTOLIC;
+    if (force_lanes) d->tier = SZS_TIER_LANES;
+
+    szs_side_stats_t const *kq = d->transposed ? c_stats : q_stats, *kc = d->transposed ? q_stats : c_stats;
+    uint32_t const *kq_variants = d->transposed ? c_variants : q_variants;
+    d->kq_count = kq->count, d->kc_count = kc->count;
+    d->layout = (symmetric ? SZS_LAYOUT_SYMMETRIC : 0) | (d->transposed ? SZS_LAYOUT_TRANSPOSED : 0);
+    d->plan.longest_query = kq->longest, d->plan.longest_candidate = kc->longest, d->plan.cells = cells;
+    memcpy(d->variant_counts, kq_variants, sizeof(d->variant_counts));
+    szs_plan_groups(kq_variants, &d->plan);
+
+    /* Cell width (reach rule, serial.hpp:135-162,370-386): 16-bit pairs, 32 bits, or the 64-bit tier (hip/wide.hip). */
+    uint64_t const span = d->maximise ? (uint64_t)d->plan.longest_query + d->plan.longest_candidate
+                                      : (d->plan.longest_query > d->plan.longest_candidate ? d->plan.longest_query : d->plan.longest_candidate);
+    uint64_t const magnitude = engine->magnitude ? engine->magnitude : 1;
+    uint64_t const reach = (span + (engine->is_linear ? 1 : 3)) * magnitude;
+    /* Unit-cost engines never need wide cells: their distances are bounded by the longer string, below 2^32 by construction. */
+    d->wide_cells = szs_tuning_get(szs_knob_cells_k) == 64 || (!d->use_myers && reach >= 0x7FFFFFF0ull);
+
+    d->objective = engine->family == szs_family_needleman_wunsch_k   ? szs_objective_global_k
+                   : engine->family == szs_family_smith_waterman_k
+                       ? (engine->open <= 0 && engine->extend <= 0 ? szs_objective_local_saturating_k : szs_objective_local_k)
+                   : runes                                         ? szs_objective_distance_runes_k
+                                                                   : szs_objective_distance_k;
+    /* 16-bit strip boundaries when every parked value provably fits: global scores are bounded by the reach, saturating
+     * local ones by (shorter side) x (largest cost) - the reference narrows its cells by the same kind of bound. */
+    uint64_t const shorter_side = d->plan.longest_query < d->plan.longest_candidate ? d->plan.longest_query : d->plan.longest_candidate;
+    d->narrow = d->objective == szs_objective_global_k              ? reach < 32000
+                : d->objective == szs_objective_local_saturating_k ? (shorter_side + 3) * magnitude < 32000
+                                                                    : 0;
+    /* Two cells per VALU operation (hip/weighted_packed.hip) when EVERY DP value fits 16 bits, not just the parked ones:
+     * the same two bounds cover all cells and tracks - the reach is a bound on any sum of (rows + columns + 3) costs. */
+    if (d->maximise)
+        for (int i = 0; i < 256; ++i) d->classes = engine->byte_to_class[i] >= d->classes ? (uint32_t)engine->byte_to_class[i] + 1 : d->classes;
+    d->packed = d->maximise && d->narrow && d->classes <= 32 && szs_tuning_get(szs_knob_packed_k) != 0;
+    d->packed_local = d->objective == szs_objective_local_saturating_k;
+
+    if (d->wide_cells) /* one tier only: the anti-diagonal walker with 64-bit cells, whatever the shape of the batch */
+        d->tier = SZS_TIER_LANES, d->packed = 0, d->narrow = 0;
+
+    /* The systolic tier scores every engine family with its weighted recurrences, so it needs the cost model and its
+     * own workspace; a job with too many pairs in flight for that workspace stays on the lanes tier. */
+    if (d->tier == SZS_TIER_SYSTOLIC &&
+        (!szs_hip_systolic_workspace_bytes(!engine->is_linear, d->kq_count, d->kc_count, d->plan.longest_query, d->plan.longest_candidate,
+                                           &d->systolic_control_bytes, &d->systolic_parked_bytes) ||
+         d->systolic_control_bytes + d->systolic_parked_bytes > ((size_t)32 << 30)))
+        d->tier = SZS_TIER_LANES;
+    if (d->tier == SZS_TIER_MYERS_CHAIN &&
+        (!szs_hip_myers_chain_workspace_bytes(d->kq_count, d->kc_count, d->plan.longest_query, d->plan.longest_candidate,
+                                              &d->systolic_control_bytes, &d->systolic_parked_bytes) ||
+         d->systolic_control_bytes + d->systolic_parked_bytes > ((size_t)32 << 30)))
+        d->tier = SZS_TIER_LANES;
+    (void)error_message;
+    d->valid = 1;
+    return sz_success_k;
+}
+
+/** Does the lanes tier of this decision run a kernel that reads the cost model / the weighted strip workspace? */
+static int has_group_of_variant_zero(szs_decision_t const *d) {
+    for (unsigned g = 0; g < d->plan.groups_count; ++g)
+        if (d->plan.groups[g].variant == 0) return 1;
+    return 0;
+}
+
+static sz_status_t upload_model(szs_engine_s *engine, szs_decision_t const *d, int device, hipStream_t stream,
+                                char const **error_message) {
+    if (engine->model_uploaded_device == device && engine->model_uploaded_transposed == d->transposed) return sz_success_k;
+    sz_status_t const status = szs_buffer_reserve(&engine->device_model, szs_memory_device_k, device, sizeof(szs_cost_model_t), error_message);
+    if (status != sz_success_k) return status;
+    fill_cost_model(engine, d->transposed, &engine->host_model); /* lives in the engine: the copy may complete later */
+    hipError_t const error = hipMemcpyAsync(engine->device_model.pointer, &engine->host_model, sizeof(szs_cost_model_t), hipMemcpyHostToDevice, stream);
+    if (error != hipSuccess) return szs_report_hip(error, error_message);
+    engine->model_uploaded_device = device, engine->model_uploaded_transposed = d->transposed;
+    return sz_success_k;
+}
+
+/** Size of the weighted lanes kernels' strip workspace for this decision. */
+static size_t weighted_boundary_bytes(szs_engine_s const *engine, szs_decision_t const *d) {
+    return d->packed ? szs_hip_weighted_packed_boundary_bytes(d->packed_local, !engine->is_linear, d->classes, d->kq_count, d->kc_count,
+                                                              d->plan.longest_candidate)
+                     : szs_hip_weighted_boundary_bytes(d->objective, !engine->is_linear, d->narrow, d->kq_count, d->kc_count,
+                                                       d->plan.longest_candidate);
+}
+
+/**
+ *  Workspaces and the cost model, sized for the kernels that CAN launch - and only those: the strip kernel of long byte
+ *  queries parks 0.25 B per column and lane where the weighted kernels park 4, so a unit-cost call over 100 KB strings
+ *  reserves ~5 GB, not ~77.
+ */
+static sz_status_t prepare(szs_engine_s *engine, szs_decision_t const *d, int device, hipStream_t stream, char const **error_message) {
+    sz_status_t status = sz_success_k;
+    hipError_t error = hipSuccess;
+    int const chained = d->tier == SZS_TIER_SYSTOLIC || d->tier == SZS_TIER_MYERS_CHAIN;
+    if (chained) {
+        /* The control block is zeroed when it is (re)allocated and never again: its words carry the epoch of the launch
+         * that wrote them, so a launch neither needs nor waits for a fill (hip/kernels.h). */
+        int const fresh = !engine->device_systolic.pointer || engine->device_systolic.capacity < d->systolic_control_bytes ||
+                          engine->device_systolic.device != device; /* the reserve below will (re)allocate */
+        status = szs_buffer_reserve(&engine->device_systolic, szs_memory_device_k, device, d->systolic_control_bytes, error_message);
+        if (status != sz_success_k) return status;
+        if (fresh || engine->systolic_epoch >= 0xFFFFFFF0u) {
+            error = hipMemsetAsync(engine->device_systolic.pointer, 0, engine->device_systolic.capacity, stream);
+            if (error != hipSuccess) return szs_report_hip(error, error_message);
+            engine->systolic_epoch = 0;
+        }
+        engine->systolic_epoch++;
+        status = szs_buffer_reserve(&engine->device_boundary, szs_memory_device_k, device, d->systolic_parked_bytes, error_message);
+        if (status != sz_success_k) return status;
+        if (d->tier == SZS_TIER_SYSTOLIC) return upload_model(engine, d, device, stream, error_message);
+        return sz_success_k;
+    }
+    if (d->wide_cells) {
+        size_t const bytes = szs_hip_wide_workspace_bytes(!engine->is_linear, d->kq_count, d->kc_count, d->plan.longest_query,
+                                                          d->plan.longest_candidate);
+        status = szs_buffer_reserve(&engine->device_boundary, szs_memory_device_k, device, bytes, error_message);
+        if (status != sz_success_k) return status;
+        return upload_model(engine, d, device, stream, error_message);
+    }
+    int const variant_zero = has_group_of_variant_zero(d);
+    size_t boundary_bytes = 0;
+    if (!d->use_myers || (d->runes && variant_zero)) { /* the weighted kernels: every non-unit engine; rune queries beyond 2048 */
+        status = upload_model(engine, d, device, stream, error_message);
+        if (status != sz_success_k) return status;
+        boundary_bytes = weighted_boundary_bytes(engine, d);
+    }
+    else if (d->banded && variant_zero) /* byte queries beyond 64 words: the strip kernel's parked deltas, nothing else */
+        boundary_bytes = szs_hip_levenshtein_myers_banded_bytes(d->kq_count, d->kc_count, d->plan.longest_candidate);
+    if (boundary_bytes) status = szs_buffer_reserve(&engine->device_boundary, szs_memory_device_k, device, boundary_bytes, error_message);
+    return status;
+}
+
+/** Launches of one decision over device refs in kernel roles.  Returns the first launch error; counts launches. */
+static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int device, szs_string_ref_t const *query_refs,
+                          szs_string_ref_t const *candidate_refs, void *device_results, size_t device_stride, hipStream_t stream,
+                          uint32_t *launches, uint32_t *cell_bits, sz_status_t *status, char const **error_message) {
+    int launch_error = 0;
+    szs_cost_model_t const *const model = (szs_cost_model_t const *)engine->device_model.pointer;
+    *status = sz_success_k;
+    if (d->tier == SZS_TIER_SYSTOLIC) { /* one launch for the whole cross-product, whatever the planner's groups */
+        launch_error = szs_hip_systolic_scores(d->objective, !engine->is_linear, model, query_refs, d->kq_count, candidate_refs,
+                                               d->kc_count, d->plan.longest_query, d->plan.longest_candidate, (int64_t *)device_results,
+                                               device_stride, d->layout, engine->device_systolic.pointer,
+                                               engine->device_boundary.pointer, engine->systolic_epoch, stream);
+        ++*launches, *cell_bits = 32;
+        return (hipError_t)launch_error;
+    }
+    if (d->tier == SZS_TIER_MYERS_CHAIN) {
+        launch_error = szs_hip_myers_chain(query_refs, d->kq_count, candidate_refs, d->kc_count, d->plan.longest_query,
+                                           d->plan.longest_candidate, (uint64_t *)device_results, device_stride, d->layout,
+                                           engine->device_systolic.pointer, engine->device_boundary.pointer, engine->systolic_epoch, stream);
+        ++*launches;
+        return (hipError_t)launch_error;
+    }
+    if (d->wide_cells) {
+        launch_error = szs_hip_wide_scores(d->objective, !engine->is_linear, model, query_refs, d->kq_count, candidate_refs, d->kc_count,
+                                           d->plan.longest_query, d->plan.longest_candidate, (int64_t *)device_results, device_stride,
+                                           d->layout, engine->device_boundary.pointer, stream);
+        ++*launches, *cell_bits = 64;
+        return (hipError_t)launch_error;
+    }
+    /* Persistent kernels address their work items with 32 bits: cross-products beyond that are cut along the query axis. */
+    uint64_t const candidate_blocks = ((uint64_t)d->kc_count + SZS_CANDIDATES_PER_WORKGROUP - 1) / SZS_CANDIDATES_PER_WORKGROUP;
+    uint32_t const queries_per_launch = (uint32_t)(0xFFFFFFF0ull / (candidate_blocks ? candidate_blocks : 1));
+    for (unsigned g = 0; g < d->plan.groups_count; ++g) {
+        szs_plan_group_t const *group = &d->plan.groups[g];
+        for (uint32_t done = 0; done < group->count; done += queries_per_launch) {
+            szs_string_ref_t const *const queries = query_refs + group->first + done;
+            uint32_t const count = group->count - done < queries_per_launch ? group->count - done : queries_per_launch;
+            if (group->variant && d->runes) {
+                launch_error = group->variant == SZS_MYERS_SHORT_WORDS
+                                   ? szs_hip_levenshtein_myers_runes(queries, count, candidate_refs, d->kc_count, (uint64_t *)device_results,
+                                                                     device_stride, d->layout, stream)
+                                   : szs_hip_levenshtein_myers_runes_long(group->variant, queries, count, candidate_refs, d->kc_count,
+                                                                          (uint64_t *)device_results, device_stride, d->layout, stream);
+                if (launch_error == (int)hipErrorNotSupported) { /* no LDS for the rune table: the rune-keyed DP kernel, whose
+                                                                    workspace is reserved here, on the one path that needs it */
+                    *status = upload_model(engine, d, device, stream, error_message);
+                    if (*status == sz_success_k)
+                        *status = szs_buffer_reserve(&engine->device_boundary, szs_memory_device_k, device,
+                                                     szs_hip_weighted_boundary_bytes(d->objective, !engine->is_linear, 0, d->kq_count, d->kc_count,
+                                                                                     d->plan.longest_candidate), error_message);
+                    if (*status != sz_success_k) return hipSuccess;
+                    *cell_bits = 32;
+                    launch_error = szs_hip_weighted_scores(d->objective, !engine->is_linear, 0, (szs_cost_model_t const *)engine->device_model.pointer,
+                                                           queries, count, candidate_refs, d->kc_count, d->plan.longest_candidate,
+                                                           (int64_t *)device_results, device_stride, d->layout, engine->device_boundary.pointer, stream);
+                }
+            }
+            else if (group->variant)
+                launch_error = szs_hip_levenshtein_myers(group->variant, queries, count, candidate_refs, d->kc_count, (uint64_t *)device_results,
+                                                         device_stride, d->layout, stream);
+            else if (d->banded)
+                launch_error = szs_hip_levenshtein_myers_banded(queries, count, candidate_refs, d->kc_count, d->plan.longest_candidate,
+                                                                (uint64_t *)device_results, device_stride, d->layout,
+                                                                engine->device_boundary.pointer, stream);
+            else if (d->packed) {
+                *cell_bits = 16;
+                launch_error = szs_hip_weighted_packed_scores(d->packed_local, !engine->is_linear, d->classes, model, queries, count, candidate_refs,
+                                                              d->kc_count, d->plan.longest_candidate, (int64_t *)device_results, device_stride,
+                                                              d->layout, engine->device_boundary.pointer, stream);
+            }
+            else {
+                *cell_bits = 32;
+                launch_error = szs_hip_weighted_scores(d->objective, !engine->is_linear, d->narrow, model, queries, count, candidate_refs,
+                                                       d->kc_count, d->plan.longest_candidate, (int64_t *)device_results, device_stride,
+                                                       d->layout, engine->device_boundary.pointer, stream);
+            }
+            if (launch_error) return (hipError_t)launch_error;
+            ++*launches;
+        }
+    }
+    return hipSuccess;
+}
+
+/* ---- one call ---------------------------------------------------------------------------------------------------------- */
+
+typedef struct szs_call_t {
+    szs_engine_s *engine;
+    int device;
+    hipStream_t stream;
+    szs_input_t const *queries, *candidates;
+    int symmetric;
+    uint32_t q_count, c_count;
+    void *results;
+    size_t results_row_stride;
+    int direct; /* kernels write the caller's matrix in place */
+    void *device_results;
+    size_t device_stride;
+    double started, phase_started, phases[6];
+    int trace;
+    char const **error_message;
+} szs_call_t;
+
+static void phase(szs_call_t *call, int index) {
+    if (!call->trace) return;
+    double const now = now_milliseconds();
+    call->phases[index] += now - call->phase_started, call->phase_started = now;
+}
+
+/** Everything after the last launch: stop event, stall flag, copy-out, THE wait, profile.  `enqueued` failures and every
+ *  failure in here drain the stream before the status leaves the library. */
+static sz_status_t finish(szs_call_t *call, szs_decision_t const *d, hipError_t error, sz_status_t status, uint32_t launches,
+                          uint32_t cell_bits, uint64_t query_symbols, uint64_t candidate_symbols, int *stalled) {
+    szs_engine_s *engine = call->engine;
+    hipStream_t const stream = call->stream;
+    int const chained = d->tier == SZS_TIER_SYSTOLIC || d->tier == SZS_TIER_MYERS_CHAIN;
+    uint64_t *const stall_flag = (uint64_t *)engine->pinned_summary.pointer + 64; /* behind the planner's summary */
+    *stall_flag = 0;
+    if (error == hipSuccess && status == sz_success_k) error = hipEventRecord(engine->event_stop, stream);
+    if (error == hipSuccess && status == sz_success_k && chained)
+        error = hipMemcpyAsync(stall_flag, (char *)engine->device_systolic.pointer + 8, sizeof(uint64_t), hipMemcpyDeviceToHost, stream);
+    if (error == hipSuccess && status == sz_success_k && !call->direct) /* one strided copy back into the caller's host matrix
+                                                                           (reference: cuMemcpy2DAsync, cuda.cuh:2205-2215) */
+        error = hipMemcpy2DAsync(call->results, call->results_row_stride * sizeof(uint64_t), call->device_results,
+                                 call->device_stride * sizeof(uint64_t), (size_t)call->c_count * sizeof(uint64_t), call->q_count,
+                                 hipMemcpyDefault, stream);
+    phase(call, 3); /* launches enqueued */
+    hipError_t const drained = hipStreamSynchronize(stream); /* the call is synchronous, like the reference's - also when it fails */
+    phase(call, 4); /* waiting for the device */
+    if (status != sz_success_k) return status;
+    if (error == hipSuccess) error = drained;
+    if (error != hipSuccess) return szs_report_hip(error, call->error_message);
+    *stalled = chained && *stall_flag == (((uint64_t)engine->systolic_epoch << 32) | 1);
+    if (*stalled) return sz_success_k; /* the caller re-runs the batch on the lanes tier */
+
+    float kernel_ms = 0;
+    (void)hipEventElapsedTime(&kernel_ms, engine->event_start, engine->event_stop);
+    szs_rocm_call_profile_t *profile = &engine->last_profile;
+    uint64_t const q_count = call->q_count, c_count = call->c_count;
+    uint64_t const pairs = call->symmetric ? q_count * (q_count + 1) / 2 : q_count * c_count;
+    profile->kernel_milliseconds = kernel_ms;
+    profile->cells = d->plan.cells;
+    profile->pairs = pairs;
+    /* Canonical pair-streaming bytes: len(q) + len(c) + two 4-byte offsets + one 8-byte result per pair; over the lower
+     * triangle string i meets i + 1 partners as a query and n - i as a candidate: n + 1 times in all. */
+    profile->algorithmic_bytes = call->symmetric ? (q_count + 1) * query_symbols : c_count * query_symbols + q_count * candidate_symbols;
+    profile->algorithmic_bytes += pairs * 16;
+    profile->unique_bytes = query_symbols + (call->symmetric ? 0 : candidate_symbols) +
+                            (q_count + 1 + (call->symmetric ? 0 : c_count + 1)) * 4 + q_count * c_count * 8;
+    profile->launches = launches;
+    profile->tier = (uint32_t)d->tier;
+    profile->transposed = (uint32_t)d->transposed;
+    profile->cell_bits = cell_bits;
+    profile->longest_query = d->longest[0], profile->longest_candidate = d->longest[1];
+    profile->host_milliseconds = now_milliseconds() - call->started;
+    phase(call, 5);
+    if (call->trace)
+        fprintf(stderr, "szs call: %.1f us = setup %.1f + plan %.1f + prepare %.1f + launch %.1f + wait %.1f + wrap %.1f | kernel %.1f us | %s\n",
+                profile->host_milliseconds * 1e3, call->phases[0] * 1e3, call->phases[1] * 1e3, call->phases[2] * 1e3,
+                call->phases[3] * 1e3, call->phases[4] * 1e3, call->phases[5] * 1e3, kernel_ms * 1e3,
+                profile->planner == 2 ? "device-planned, speculated" : profile->planner == 1 ? "device-planned" : "host-planned");
+    return szs_report(sz_success_k, call->error_message, NULL);
+}
+
+/** Where do results go?  Matrices in device memory are written in place.  Plain host memory cannot be written by a
+ *  kernel at all, and unified / pinned memory only across the host link, 8 scattered bytes at a time (measured on
+ *  config 2: 0.90 ms instead of 0.22 ms of kernel time) - those are staged densely in HBM and copied out in one
+ *  piece, unless the matrix is so small that the extra copy costs more than it saves. */
+static sz_status_t place_results(szs_call_t *call) {
+    szs_engine_s *engine = call->engine;
+    szs_pointer_traits_t const traits = szs_classify_pointer(call->results);
+    size_t const matrix_bytes = (size_t)call->q_count * call->c_count * sizeof(uint64_t);
+    call->direct = traits.device_accessible && (traits.device_resident || matrix_bytes < ((size_t)256 << 10));
+    call->device_results = call->results, call->device_stride = call->results_row_stride;
+    if (call->direct) return sz_success_k;
+    sz_status_t const status = szs_buffer_reserve(&engine->device_results, szs_memory_device_k, call->device, matrix_bytes, call->error_message);
+    if (status != sz_success_k) return status;
+    call->device_results = engine->device_results.pointer, call->device_stride = call->c_count;
+    return sz_success_k;
+}
+
+/* ---- device-planned calls ---------------------------------------------------------------------------------------------- */
+
+#define SZS_PLAN_DEVICE_MOST_STRINGS (1u << 18) /* per side; one workgroup plans, so larger batches go to the host planner */
+#define SZS_NOT_DEVICE_PLANNABLE ((sz_status_t)1) /* internal: take the host-planned path instead */
+
+static int device_plannable(szs_engine_s const *engine, szs_input_t const *input) {
+    if (input->kind == szs_input_sequence_k || !input->offsets || !input->data) return 0;
+    if (input->count > SZS_PLAN_DEVICE_MOST_STRINGS) return 0;
+    (void)engine;
+    return szs_classify_pointer(input->offsets).device_accessible && szs_classify_pointer(input->data).device_accessible;
+}
+
+static sz_status_t cross_device_planned(szs_call_t *call) {
+    szs_engine_s *engine = call->engine;
+    hipStream_t const stream = call->stream;
+    int const device = call->device, symmetric = call->symmetric;
+    uint32_t const q_count = call->q_count, c_count = call->c_count;
+    char const **error_message = call->error_message;
+
+    size_t const refs_bytes = 2 * ((size_t)q_count + (symmetric ? 0 : c_count)) * sizeof(szs_string_ref_t);
+    sz_status_t status = szs_buffer_reserve(&engine->device_plan_refs, szs_memory_device_k, device, refs_bytes, error_message);
+    if (status != sz_success_k) return status;
+    szs_string_ref_t *const base = (szs_string_ref_t *)engine->device_plan_refs.pointer;
+    szs_plan_side_t q_side = {call->queries->offsets, (uint64_t)(uintptr_t)call->queries->data, q_count,
+                              call->queries->kind == szs_input_u64tape_k, base, base + q_count};
+    szs_plan_side_t c_side = q_side;
+    if (!symmetric) {
+        szs_plan_side_t const other = {call->candidates->offsets, (uint64_t)(uintptr_t)call->candidates->data, c_count,
+                                       call->candidates->kind == szs_input_u64tape_k, base + 2 * (size_t)q_count,
+                                       base + 2 * (size_t)q_count + c_count};
+        c_side = other;
+    }
+    szs_plan_summary_t volatile *const summary = (szs_plan_summary_t volatile *)engine->pinned_summary.pointer;
+    int const use_myers = engine->is_unit_cost && engine->family == szs_family_levenshtein_k;
+    unsigned const myers_words = use_myers ? SZS_MYERS_MAX_WORDS : 0;
+    if (!engine->remembered) {
+        engine->remembered = (szs_decision_t *)calloc(1, sizeof(szs_decision_t));
+        if (!engine->remembered) return szs_report(sz_bad_alloc_k, error_message, NULL);
+    }
+    szs_decision_t *const remembered = engine->remembered;
+    status = place_results(call);
+    if (status != sz_success_k) return status;
+    phase(call, 0);
+
+    /* ---- speculate: launches shaped like the previous call go in right behind the planner */
+    hipError_t error = hipSuccess;
+    int const speculate = remembered->valid && remembered->tier == SZS_TIER_LANES && remembered->q_count == q_count &&
+                          remembered->c_count == c_count && remembered->symmetric == symmetric &&
+                          szs_tuning_get(szs_knob_speculate_k) != 0 && szs_tuning_get(szs_knob_tier_k) < 0 &&
+                          szs_tuning_get(szs_knob_swap_k) < 0 && szs_tuning_get(szs_knob_cells_k) < 0 && szs_tuning_get(szs_knob_packed_k) < 0;
+    szs_plan_summary_t seen;
+    int have_summary = 0;
+    if (speculate) {
+        szs_decision_t const *d = remembered;
+        szs_plan_expectation_t expected;
+        memset(&expected, 0, sizeof(expected));
+        expected.enabled = 1, expected.query_side = (uint32_t)d->transposed;
+        expected.longest[0] = d->longest[0], expected.longest[1] = d->longest[1];
+        memcpy(expected.variant_counts, d->variant_counts, sizeof(expected.variant_counts));
+        expected.sequence = ++engine->plan_sequence;
+        status = prepare(engine, d, device, stream, error_message); /* buffers of the previous call: nothing to allocate */
+        if (status != sz_success_k) return status;
+        phase(call, 2);
+        uint32_t launches = 0, cell_bits = 0;
+        error = (hipError_t)szs_hip_plan(&q_side, symmetric ? NULL : &c_side, myers_words, &expected, (szs_plan_summary_t *)summary, stream);
+        if (error != hipSuccess) return szs_report_hip(error, error_message); /* nothing enqueued yet */
+        error = hipEventRecord(engine->event_start, stream);
+        szs_string_ref_t const *const query_refs = d->transposed ? c_side.descending : q_side.descending;
+        szs_string_ref_t const *const candidate_refs = d->transposed ? q_side.ascending : c_side.ascending;
+        sz_status_t enqueue_status = sz_success_k;
+        if (error == hipSuccess)
+            error = enqueue(engine, d, device, query_refs, candidate_refs, call->device_results, call->device_stride, stream, &launches,
+                            &cell_bits, &enqueue_status, error_message);
+        /* the summary is read after the wait inside finish(); profile numbers come from it, so finish() runs on a copy of
+         * the decision whose statistics are filled in afterwards - do the wait here instead */
+        int stalled = 0;
+        szs_decision_t scored = *d;
+        engine->last_profile.planner = 2;
+        status = finish(call, &scored, error, enqueue_status, launches, cell_bits, 0, 0, &stalled);
+        if (status != sz_success_k) return status;
+        memcpy(&seen, (void const *)summary, sizeof(seen));
+        have_summary = seen.sequence == expected.sequence;
+        if (have_summary && !seen.status && seen.speculation_held) {
+            /* the batch had the remembered shape and has been scored; complete the profile from the summary */
+            szs_rocm_call_profile_t *profile = &engine->last_profile;
+            uint64_t const pairs = profile->pairs;
+            profile->cells = symmetric ? seen.symmetric_cells : seen.side[0].symbols * seen.side[1].symbols;
+            profile->algorithmic_bytes = (symmetric ? ((uint64_t)q_count + 1) * seen.side[0].symbols
+                                                    : (uint64_t)c_count * seen.side[0].symbols + (uint64_t)q_count * seen.side[1].symbols) + pairs * 16;
+            profile->unique_bytes += seen.side[0].symbols + (symmetric ? 0 : seen.side[1].symbols);
+            profile->longest_query = seen.side[0].longest, profile->longest_candidate = seen.side[1].longest;
+            return szs_report(sz_success_k, error_message, NULL);
+        }
+        /* the shape changed (or the offsets are malformed): the refs were blanked, nothing real was scored */
+    }
+
+    /* ---- plan, wait, decide, launch */
+    if (!have_summary) {
+        szs_plan_expectation_t none;
+        memset(&none, 0, sizeof(none));
+        none.sequence = ++engine->plan_sequence;
+        error = (hipError_t)szs_hip_plan(&q_side, symmetric ? NULL : &c_side, myers_words, &none, (szs_plan_summary_t *)summary, stream);
+        hipError_t const drained = hipStreamSynchronize(stream);
+        if (error == hipSuccess) error = drained;
+        if (error != hipSuccess) return szs_report_hip(error, error_message);
+        memcpy(&seen, (void const *)summary, sizeof(seen));
+        if (seen.sequence != none.sequence) return szs_report(sz_status_unknown_k, error_message, "The device planner did not report");
+    }
+    if (seen.status & SZS_PLAN_STATUS_DESCENDING) return szs_report(sz_unexpected_dimensions_k, error_message, "Tape offsets must ascend");
+    if (seen.status & SZS_PLAN_STATUS_OVERFLOW) return szs_report(sz_overflow_risk_k, error_message, NULL);
+    if (seen.status & SZS_PLAN_STATUS_UNSORTED) return SZS_NOT_DEVICE_PLANNABLE; /* strings beyond the planner's histogram */
+    phase(call, 1);
+
+    for (int attempt = 0; attempt < 2; ++attempt) { /* second round: a stalled band chain is re-run on the lanes tier */
+        szs_decision_t d;
+        uint64_t const cells = symmetric ? seen.symmetric_cells : seen.side[0].symbols * seen.side[1].symbols;
+        status = decide(engine, symmetric, 0, attempt > 0, &seen.side[0], &seen.side[1], seen.variant_counts[0], seen.variant_counts[1], cells,
+                        &d, error_message);
+        if (status != sz_success_k) return status;
+        status = prepare(engine, &d, device, stream, error_message);
+        if (status != sz_success_k) return status;
+        phase(call, 2);
+        if (have_summary) { /* the refs on the device are blank (failed speculation): write the real ones */
+            szs_plan_expectation_t none;
+            memset(&none, 0, sizeof(none));
+            none.sequence = ++engine->plan_sequence;
+            error = (hipError_t)szs_hip_plan(&q_side, symmetric ? NULL : &c_side, myers_words, &none, (szs_plan_summary_t *)summary, stream);
+            if (error != hipSuccess) return szs_report_hip(error, error_message);
+            have_summary = 0;
+        }
+        uint32_t launches = 0, cell_bits = 0;
+        error = hipEventRecord(engine->event_start, stream);
+        szs_string_ref_t const *const query_refs = d.transposed ? c_side.descending : q_side.descending;
+        szs_string_ref_t const *const candidate_refs = d.transposed ? q_side.ascending : c_side.ascending;
+        sz_status_t enqueue_status = sz_success_k;
+        if (error == hipSuccess)
+            error = enqueue(engine, &d, device, query_refs, candidate_refs, call->device_results, call->device_stride, stream, &launches,
+                            &cell_bits, &enqueue_status, error_message);
+        int stalled = 0;
+        engine->last_profile.planner = 1;
+        status = finish(call, &d, error, enqueue_status, launches, cell_bits, seen.side[0].symbols, seen.side[1].symbols, &stalled);
+        if (status != sz_success_k) return status;
+        if (!stalled) {
+            *remembered = d; /* the next call of this shape goes in speculatively */
+            return sz_success_k;
+        }
+    }
+    return szs_report(sz_status_unknown_k, error_message, "Systolic pipeline stalled");
+}
+
+/* ---- host-planned calls ------------------------------------------------------------------------------------------------ */
+
+static sz_status_t cross_host_planned(szs_call_t *call) {
+    szs_engine_s *engine = call->engine;
+    hipStream_t const stream = call->stream;
+    int const device = call->device, symmetric = call->symmetric;
+    uint32_t const q_count = call->q_count, c_count = call->c_count;
+    szs_input_t const *const queries = call->queries, *const candidates = call->candidates;
+    char const **error_message = call->error_message;
+    size_t const most = q_count > c_count ? q_count : c_count;
+
+    /* Pinned staging: [refs of queries][refs of candidates][offset downloads of both sides] */
+    size_t const refs_bytes = ((size_t)q_count + c_count) * sizeof(szs_string_ref_t);
+    size_t const offsets_bytes = ((size_t)q_count + c_count + 2) * sizeof(uint64_t);
+    sz_status_t status = szs_buffer_reserve(&engine->pinned_staging, szs_memory_pinned_k, device, refs_bytes + offsets_bytes, error_message);
+    if (status != sz_success_k) return status;
+    status = szs_buffer_reserve(&engine->device_refs, szs_memory_device_k, device, refs_bytes, error_message);
+    if (status != sz_success_k) return status;
+
+    /* Offsets in device-only memory: both downloads are enqueued back to back and waited for ONCE. */
+    void const *q_offsets = NULL, *c_offsets = NULL;
+    int downloads_pending = 0;
+    status = szs_prefetch_offsets(engine->pinned_staging.pointer, stream, queries, refs_bytes, &q_offsets, &downloads_pending, error_message);
+    if (status == sz_success_k && !symmetric)
+        status = szs_prefetch_offsets(engine->pinned_staging.pointer, stream, candidates,
+                                      refs_bytes + ((size_t)q_count + 1) * sizeof(uint64_t), &c_offsets, &downloads_pending, error_message);
+    if (downloads_pending) {
+        hipError_t const error = hipStreamSynchronize(stream); /* also when the second enqueue failed */
+        if (status == sz_success_k && error != hipSuccess) return szs_report_hip(error, error_message);
+    }
+    if (status != sz_success_k) return status;
+    phase(call, 0); /* checks, buffers, offsets download + its synchronisation */
+
+    /* Host scratch: [q addresses][c addresses][q lengths][c lengths] */
+    size_t const fixed_bytes = ((size_t)q_count + c_count) * (sizeof(uint64_t) + sizeof(uint32_t));
+    status = szs_buffer_reserve(&engine->host_lengths, szs_memory_host_k, 0, fixed_bytes, error_message);
+    if (status != sz_success_k) return status;
+    uint64_t *q_addresses = (uint64_t *)engine->host_lengths.pointer;
+    uint64_t *c_addresses = q_addresses + q_count;
+    uint32_t *q_lengths = (uint32_t *)(c_addresses + c_count);
+    uint32_t *c_lengths = q_lengths + q_count;
+
+    uint64_t query_bytes = 0, candidate_bytes = 0;
+    status = szs_gather_strings(queries, q_offsets, q_addresses, q_lengths, &query_bytes, error_message);
+    if (status != sz_success_k) return status;
+    if (symmetric) {
+        memcpy(c_addresses, q_addresses, (size_t)q_count * sizeof(uint64_t));
+        memcpy(c_lengths, q_lengths, (size_t)q_count * sizeof(uint32_t));
+        candidate_bytes = query_bytes;
+    }
+    else {
+        status = szs_gather_strings(candidates, c_offsets, c_addresses, c_lengths, &candidate_bytes, error_message);
+        if (status != sz_success_k) return status;
+    }
+
+    /* Codepoint-level engine: transcode every string to UTF-32 ONCE (hip/utf8.hip), then plan and score on runes.  When
+     * no string holds a byte >= 0x80 the corpus is ASCII and the byte kernels compute the same distances - the
+     * reference takes the same shortcut pair by pair (serial.hpp:2809-2813). */
+    int runes = 0;
+    if (engine->family == szs_family_levenshtein_utf8_k) {
+        status = transcode_to_runes(engine, device, stream, symmetric, q_addresses, q_lengths, q_count, c_addresses, c_lengths, c_count,
+                                    &runes, error_message);
+        if (status != sz_success_k) return status;
+    }
+
+    int const use_myers = engine->is_unit_cost && (engine->family == szs_family_levenshtein_k || engine->family == szs_family_levenshtein_utf8_k);
+    unsigned const myers_words = !use_myers ? 0 : SZS_MYERS_MAX_WORDS; /* bytes and codepoints alike: up to 2048 symbols */
+    szs_side_stats_t q_stats, c_stats;
+    uint32_t q_variants[SZS_PLAN_VARIANTS], c_variants[SZS_PLAN_VARIANTS];
+    szs_side_stats(q_lengths, q_count, myers_words, &q_stats, q_variants);
+    szs_side_stats(c_lengths, c_count, myers_words, &c_stats, c_variants);
+    uint64_t cells = q_stats.symbols * c_stats.symbols;
+    if (symmetric) { /* lower triangle incl. diagonal: sum_i len_i * sum_{j <= i} len_j */
+        uint64_t prefix = 0;
+        cells = 0;
+        for (uint32_t i = 0; i < q_count; ++i) prefix += q_lengths[i], cells += (uint64_t)q_lengths[i] * prefix;
+    }
+    /* The planner's own scratch (sort keys + counting bins), grow-only like everything else: no allocation per call. */
+    uint32_t const longest = q_stats.longest > c_stats.longest ? q_stats.longest : c_stats.longest;
+    size_t const keys_bytes = (most * sizeof(uint32_t) + 15) & ~(size_t)15;
+    status = szs_buffer_reserve(&engine->host_scratch, szs_memory_host_k, 0, keys_bytes + szs_plan_scratch_bytes((uint32_t)most, longest), error_message);
+    if (status != sz_success_k) return status;
+    uint32_t *const keys = (uint32_t *)engine->host_scratch.pointer;
+    void *const scratch = (char *)engine->host_scratch.pointer + keys_bytes;
+
+    status = place_results(call);
+    if (status != sz_success_k) return status;
+
+    for (int attempt = 0; attempt < 2; ++attempt) { /* second round: a stalled band chain is re-run on the lanes tier */
+        szs_decision_t d;
+        status = decide(engine, symmetric, runes, attempt > 0, &q_stats, &c_stats, q_variants, c_variants, cells, &d, error_message);
+        if (status != sz_success_k) return status;
+        /* kernel roles */
+        uint64_t *const kq_addresses = d.transposed ? c_addresses : q_addresses, *const kc_addresses = d.transposed ? q_addresses : c_addresses;
+        uint32_t *const kq_lengths = d.transposed ? c_lengths : q_lengths, *const kc_lengths = d.transposed ? q_lengths : c_lengths;
+
+        /* Plan straight into the pinned staging area, then ship both ref arrays in one copy. */
+        szs_string_ref_t *host_query_refs = (szs_string_ref_t *)engine->pinned_staging.pointer;
+        szs_string_ref_t *host_candidate_refs = host_query_refs + d.kq_count;
+        szs_plan_t sorted;
+        szs_plan_build(myers_words, symmetric, kq_addresses, kq_lengths, d.kq_count, kc_addresses, kc_lengths, d.kc_count, host_query_refs,
+                       host_candidate_refs, keys, scratch, &sorted);
+        phase(call, 1); /* gathering strings, transcoding, orientation, planning */
+
+        status = prepare(engine, &d, device, stream, error_message);
+        if (status != sz_success_k) return status;
+        szs_string_ref_t *device_query_refs = (szs_string_ref_t *)engine->device_refs.pointer;
+        szs_string_ref_t *device_candidate_refs = device_query_refs + d.kq_count;
+        hipError_t error = hipMemcpyAsync(device_query_refs, host_query_refs, refs_bytes, hipMemcpyHostToDevice, stream);
+        phase(call, 2); /* ref upload enqueued, result placement, workspaces */
+
+        /* ---- launches, bracketed by the engine's event pair on the scope's stream ---- */
+        uint32_t launches = 0, cell_bits = 0;
+        sz_status_t enqueue_status = sz_success_k;
+        if (error == hipSuccess) error = hipEventRecord(engine->event_start, stream);
+        if (error == hipSuccess)
+            error = enqueue(engine, &d, device, device_query_refs, device_candidate_refs, call->device_results, call->device_stride, stream,
+                            &launches, &cell_bits, &enqueue_status, error_message);
+        int stalled = 0;
+        engine->last_profile.planner = 0;
+        status = finish(call, &d, error, enqueue_status, launches, cell_bits, query_bytes, candidate_bytes, &stalled);
+        if (status != sz_success_k || !stalled) return status;
+    }
+    return szs_report(sz_status_unknown_k, error_message, "Systolic pipeline stalled");
 }
 
 sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input_t const *queries,
                              szs_input_t const *candidates, void *results, size_t results_row_stride,
                              char const **error_message) {
-    double const call_started = now_milliseconds();
-    static int trace = -1; /* SZS_ROCM_TRACE=1: per-phase host times of every call on stderr (a measuring aid) */
-    if (trace < 0) trace = getenv("SZS_ROCM_TRACE") != NULL;
-    double phase_started = call_started, phases[6] = {0, 0, 0, 0, 0, 0};
-#define SZS_PHASE(INDEX)                                                                                               \
-    do {                                                                                                               \
-        if (trace) {                                                                                                   \
-            double const now = now_milliseconds();                                                                     \
-            phases[INDEX] += now - phase_started, phase_started = now;                                                 \
-        }                                                                                                              \
-    } while (0)
+    szs_call_t call;
+    memset(&call, 0, sizeof(call));
+    call.started = call.phase_started = now_milliseconds();
+    call.trace = szs_tuning_get(szs_knob_trace_k) > 0; /* per-phase host times of every call on stderr (a measuring aid) */
     if (!engine || engine->magic != SZS_ENGINE_MAGIC)
         return szs_report(sz_status_unknown_k, error_message, "Engine must be initialized");
     if (!queries) return szs_report(sz_status_unknown_k, error_message, "Queries must not be null");
@@ -266,337 +890,20 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
         if (error != hipSuccess) return szs_report_hip(error, error_message);
         engine->events_device = device;
     }
-
-    uint32_t const q_count = (uint32_t)queries_count, c_count = (uint32_t)candidates_count;
-    size_t const most = q_count > c_count ? q_count : c_count;
-
-    /* Host scratch: [q addresses][c addresses][q lengths][c lengths][sort keys] */
-    size_t const host_bytes = ((size_t)q_count + c_count) * (sizeof(uint64_t) + sizeof(uint32_t)) + most * sizeof(uint32_t);
-    status = szs_buffer_reserve(&engine->host_lengths, szs_memory_host_k, 0, host_bytes, error_message);
-    if (status != sz_success_k) return status;
-    uint64_t *q_addresses = (uint64_t *)engine->host_lengths.pointer;
-    uint64_t *c_addresses = q_addresses + q_count;
-    uint32_t *q_lengths = (uint32_t *)(c_addresses + c_count);
-    uint32_t *c_lengths = q_lengths + q_count;
-    uint32_t *keys = c_lengths + c_count;
-
-    /* Pinned staging: [refs of queries][refs of candidates][offset downloads of both sides] */
-    size_t const refs_bytes = ((size_t)q_count + c_count) * sizeof(szs_string_ref_t);
-    size_t const offsets_bytes = ((size_t)q_count + c_count + 2) * sizeof(uint64_t);
-    status = szs_buffer_reserve(&engine->pinned_staging, szs_memory_pinned_k, device, refs_bytes + offsets_bytes,
-                                error_message);
-    if (status != sz_success_k) return status;
-    status = szs_buffer_reserve(&engine->device_refs, szs_memory_device_k, device, refs_bytes, error_message);
+    /* pinned: the device planner's summary, and behind it the stall flag of the chained tiers */
+    status = szs_buffer_reserve(&engine->pinned_summary, szs_memory_pinned_k, device, 1024, error_message);
     if (status != sz_success_k) return status;
 
-    /* Offsets in device-only memory: both downloads are enqueued back to back and waited for ONCE. */
-    void const *q_offsets = NULL, *c_offsets = NULL;
-    int downloads_pending = 0;
-    status = szs_prefetch_offsets(engine->pinned_staging.pointer, stream, queries, refs_bytes, &q_offsets, &downloads_pending,
-                                  error_message);
-    if (status != sz_success_k) return status;
-    if (!symmetric) {
-        status = szs_prefetch_offsets(engine->pinned_staging.pointer, stream, candidates,
-                                      refs_bytes + ((size_t)q_count + 1) * sizeof(uint64_t),
-                                  &c_offsets, &downloads_pending, error_message);
-        if (status != sz_success_k) return status;
+    call.engine = engine, call.device = device, call.stream = stream;
+    call.queries = queries, call.candidates = candidates, call.symmetric = symmetric;
+    call.q_count = (uint32_t)queries_count, call.c_count = (uint32_t)candidates_count;
+    call.results = results, call.results_row_stride = results_row_stride, call.error_message = error_message;
+
+    int const planner = szs_tuning_get(szs_knob_planner_k);
+    if (planner != 0 && engine->family != szs_family_levenshtein_utf8_k && device_plannable(engine, queries) &&
+        (symmetric || device_plannable(engine, candidates))) {
+        status = cross_device_planned(&call);
+        if (status != SZS_NOT_DEVICE_PLANNABLE) return status;
     }
-    if (downloads_pending) {
-        hipError_t const error = hipStreamSynchronize(stream);
-        if (error != hipSuccess) return szs_report_hip(error, error_message);
-    }
-
-    SZS_PHASE(0); /* checks, buffers, offsets download + its synchronisation */
-    uint64_t query_bytes = 0, candidate_bytes = 0;
-    status = szs_gather_strings(queries, q_offsets, q_addresses, q_lengths, &query_bytes, error_message);
-    if (status != sz_success_k) return status;
-    if (symmetric) {
-        memcpy(c_addresses, q_addresses, (size_t)q_count * sizeof(uint64_t));
-        memcpy(c_lengths, q_lengths, (size_t)q_count * sizeof(uint32_t));
-        candidate_bytes = query_bytes;
-    }
-    else {
-        status = szs_gather_strings(candidates, c_offsets, c_addresses, c_lengths, &candidate_bytes, error_message);
-        if (status != sz_success_k) return status;
-    }
-
-    /* Codepoint-level engine: transcode every string to UTF-32 ONCE (hip/utf8.hip), then plan and score on runes.  When
-     * no string holds a byte >= 0x80 the corpus is ASCII and the byte kernels compute the same distances - the
-     * reference takes the same shortcut pair by pair (serial.hpp:2809-2813). */
-    int runes = 0;
-    if (engine->family == szs_family_levenshtein_utf8_k) {
-        status = transcode_to_runes(engine, device, stream, symmetric, q_addresses, q_lengths, q_count, c_addresses,
-                                    c_lengths, c_count, &runes, error_message);
-        if (status != sz_success_k) return status;
-    }
-
-    int const use_myers = engine->is_unit_cost && (engine->family == szs_family_levenshtein_k ||
-                                                   engine->family == szs_family_levenshtein_utf8_k);
-    int const maximise = engine->family == szs_family_needleman_wunsch_k || engine->family == szs_family_smith_waterman_k;
-    unsigned const myers_words = !use_myers ? 0 : SZS_MYERS_MAX_WORDS; /* bytes and codepoints alike: up to 2048 symbols */
-
-    /* ---- orientation and tier.  Every kernel puts ONE side on workgroups / band chains (its "queries") and the other
-     * on lanes / columns (its "candidates"); which real side plays which role is free - gap costs apply to both strings
-     * alike and a swapped class table is its transpose - so a cycle model of both tiers (plan.c) is evaluated for both
-     * orientations and the cheaper one runs.  1024 queries x 1 candidate thus become 1 workgroup row of 1024 lanes
-     * instead of 1024 workgroups with one live lane each.  Symmetric calls have nothing to swap. */
-    uint32_t q_longest = 0, c_longest = 0;
-    for (uint32_t i = 0; i < q_count; ++i) q_longest = q_lengths[i] > q_longest ? q_lengths[i] : q_longest;
-    for (uint32_t i = 0; i < c_count; ++i) c_longest = c_lengths[i] > c_longest ? c_lengths[i] : c_longest;
-    int tier = SZS_TIER_LANES, transposed = 0;
-    /* bit-parallel at any length for bytes (2048-row strips beyond 64 words), up to 2048 symbols for codepoints */
-    int const banded = use_myers && !runes;
-    szs_plan_orient(banded ? 0xFFFFFFFFu : myers_words * 32, use_myers && !runes, !engine->is_linear, !maximise, symmetric, q_lengths, q_count,
-                    c_lengths, c_count, szs_hip_systolic_band_rows(), &tier, &transposed);
-    char const *const forced_tier = getenv("SZS_ROCM_TIER"); /* `systolic` on a unit-cost engine means the DP recurrences */
-    if (tier == SZS_TIER_MYERS_CHAIN && forced_tier && forced_tier[0] == 's') tier = SZS_TIER_SYSTOLIC;
-    /* kernel roles */
-    uint64_t *const kq_addresses = transposed ? c_addresses : q_addresses, *const kc_addresses = transposed ? q_addresses : c_addresses;
-    uint32_t *const kq_lengths = transposed ? c_lengths : q_lengths, *const kc_lengths = transposed ? q_lengths : c_lengths;
-    uint32_t const kq_count = transposed ? c_count : q_count, kc_count = transposed ? q_count : c_count;
-    int const layout = (symmetric ? SZS_LAYOUT_SYMMETRIC : 0) | (transposed ? SZS_LAYOUT_TRANSPOSED : 0);
-
-    /* Plan straight into the pinned staging area, then ship both ref arrays in one copy. */
-    szs_string_ref_t *host_query_refs = (szs_string_ref_t *)engine->pinned_staging.pointer;
-    szs_string_ref_t *host_candidate_refs = host_query_refs + kq_count;
-    szs_plan_t plan;
-    szs_plan_build(myers_words, symmetric, kq_addresses, kq_lengths, kq_count, kc_addresses, kc_lengths, kc_count,
-                   host_query_refs, host_candidate_refs, keys, &plan);
-
-    /* Cell width: this build scores weighted cells in 32 bits, so refuse what the reference would widen to 64 bits
-     * (reach rule, serial.hpp:135-162,370-386). */
-    uint64_t const span = maximise ? (uint64_t)plan.longest_query + plan.longest_candidate
-                                   : (plan.longest_query > plan.longest_candidate ? plan.longest_query : plan.longest_candidate);
-    uint64_t const reach = (span + (engine->is_linear ? 1 : 3)) * (engine->magnitude ? engine->magnitude : 1);
-    if (reach >= 0x7FFFFFF0ull) return szs_report(sz_overflow_risk_k, error_message, NULL);
-
-    SZS_PHASE(1); /* gathering strings, transcoding, orientation, planning */
-    szs_string_ref_t *device_query_refs = (szs_string_ref_t *)engine->device_refs.pointer;
-    szs_string_ref_t *device_candidate_refs = device_query_refs + kq_count;
-    hipError_t error = hipMemcpyAsync(device_query_refs, host_query_refs, refs_bytes, hipMemcpyHostToDevice, stream);
-    if (error != hipSuccess) return szs_report_hip(error, error_message);
-
-    /* Where do results go?  Matrices in device memory are written in place.  Plain host memory cannot be written by a
-     * kernel at all, and unified / pinned memory only across the host link, 8 scattered bytes at a time (measured on
-     * config 2: 0.90 ms instead of 0.22 ms of kernel time) - those are staged densely in HBM and copied out in one
-     * piece, unless the matrix is so small that the extra copy costs more than it saves. */
-    szs_pointer_traits_t const results_traits = szs_classify_pointer(results);
-    int const direct = results_traits.device_accessible &&
-                       (results_traits.device_resident || (size_t)q_count * c_count * sizeof(uint64_t) < ((size_t)256 << 10));
-    void *device_results = results;
-    size_t device_stride = results_row_stride;
-    if (!direct) {
-        status = szs_buffer_reserve(&engine->device_results, szs_memory_device_k, device,
-                                    (size_t)q_count * c_count * sizeof(uint64_t), error_message);
-        if (status != sz_success_k) return status;
-        device_results = engine->device_results.pointer, device_stride = c_count;
-    }
-
-    int const objective = engine->family == szs_family_needleman_wunsch_k   ? szs_objective_global_k
-                          : engine->family == szs_family_smith_waterman_k
-                              ? (engine->open <= 0 && engine->extend <= 0 ? szs_objective_local_saturating_k : szs_objective_local_k)
-                          : runes                                         ? szs_objective_distance_runes_k
-                                                                          : szs_objective_distance_k;
-    /* 16-bit strip boundaries when every parked value provably fits: global scores are bounded by the reach, saturating
-     * local ones by (shorter side) x (largest cost) - the reference narrows its cells by the same kind of bound. */
-    uint64_t const shorter_side = plan.longest_query < plan.longest_candidate ? plan.longest_query : plan.longest_candidate;
-    int const narrow = objective == szs_objective_global_k ? reach < 32000
-                       : objective == szs_objective_local_saturating_k
-                           ? (shorter_side + 3) * (engine->magnitude ? engine->magnitude : 1) < 32000
-                           : 0;
-
-    /* Two cells per VALU operation (hip/weighted_packed.hip) when EVERY DP value fits 16 bits, not just the parked ones:
-     * the same two bounds cover all cells and tracks - the reach is a bound on any sum of (rows + columns + 3) costs. */
-    uint32_t classes = 0;
-    if (maximise)
-        for (int i = 0; i < 256; ++i) classes = engine->byte_to_class[i] >= classes ? (uint32_t)engine->byte_to_class[i] + 1 : classes;
-    char const *const forced_packed = getenv("SZS_ROCM_PACKED"); /* testing aid: 0 pins the 32-bit kernel */
-    int const packed = maximise && narrow && classes <= 32 && !(forced_packed && forced_packed[0] == '0');
-    int const packed_local = objective == szs_objective_local_saturating_k;
-
-    /* The systolic tier scores every engine family with its weighted recurrences, so it needs the cost model and its
-     * own workspace; a job with too many pairs in flight for that workspace stays on the lanes tier. */
-    size_t systolic_control_bytes = 0, systolic_parked_bytes = 0;
-    if (tier == SZS_TIER_SYSTOLIC &&
-        (!szs_hip_systolic_workspace_bytes(!engine->is_linear, kq_count, kc_count, plan.longest_query, plan.longest_candidate,
-                                           &systolic_control_bytes, &systolic_parked_bytes) ||
-         systolic_control_bytes + systolic_parked_bytes > ((size_t)32 << 30)))
-        tier = SZS_TIER_LANES;
-    if (tier == SZS_TIER_MYERS_CHAIN &&
-        (!szs_hip_myers_chain_workspace_bytes(kq_count, kc_count, plan.longest_query, plan.longest_candidate,
-                                              &systolic_control_bytes, &systolic_parked_bytes) ||
-         systolic_control_bytes + systolic_parked_bytes > ((size_t)32 << 30)))
-        tier = SZS_TIER_LANES;
-    int const chained = tier == SZS_TIER_SYSTOLIC || tier == SZS_TIER_MYERS_CHAIN;
-    if (chained) {
-        /* The control block is zeroed when it is (re)allocated and never again: its words carry the epoch of the launch
-         * that wrote them, so a launch neither needs nor waits for a fill (hip/kernels.h). */
-        int const fresh = !engine->device_systolic.pointer || engine->device_systolic.capacity < systolic_control_bytes ||
-                          engine->device_systolic.device != device; /* the reserve below will (re)allocate */
-        status = szs_buffer_reserve(&engine->device_systolic, szs_memory_device_k, device, systolic_control_bytes, error_message);
-        if (status != sz_success_k) return status;
-        if (fresh || engine->systolic_epoch >= 0xFFFFFFF0u) {
-            error = hipMemsetAsync(engine->device_systolic.pointer, 0, engine->device_systolic.capacity, stream);
-            if (error == hipSuccess) error = hipStreamSynchronize(stream);
-            if (error != hipSuccess) return szs_report_hip(error, error_message);
-            engine->systolic_epoch = 0;
-        }
-        engine->systolic_epoch++;
-    }
-
-    /* Weighted kernels need the cost model and a strip-boundary workspace on the device. */
-    int needs_weighted = !use_myers || tier == SZS_TIER_SYSTOLIC || runes; /* runes: the fallback of the long rune kernels */
-    if (tier == SZS_TIER_MYERS_CHAIN) { /* no cost model; its parked deltas live in the boundary buffer like the systolic rows */
-        status = szs_buffer_reserve(&engine->device_boundary, szs_memory_device_k, device, systolic_parked_bytes, error_message);
-        if (status != sz_success_k) return status;
-    }
-    for (unsigned g = 0; tier != SZS_TIER_MYERS_CHAIN && g < plan.groups_count; ++g) needs_weighted |= plan.groups[g].variant == 0;
-    if (needs_weighted) {
-        if (engine->model_uploaded_device != device || engine->model_uploaded_transposed != transposed) {
-            status = szs_buffer_reserve(&engine->device_model, szs_memory_device_k, device, sizeof(szs_cost_model_t),
-                                        error_message);
-            if (status != sz_success_k) return status;
-            szs_cost_model_t model;
-            fill_cost_model(engine, transposed, &model);
-            error = hipMemcpyAsync(engine->device_model.pointer, &model, sizeof(model), hipMemcpyHostToDevice, stream);
-            if (error == hipSuccess) error = hipStreamSynchronize(stream); /* `model` lives on this stack frame */
-            if (error != hipSuccess) return szs_report_hip(error, error_message);
-            engine->model_uploaded_device = device, engine->model_uploaded_transposed = transposed;
-        }
-        size_t boundary_bytes =
-            tier == SZS_TIER_SYSTOLIC
-                ? systolic_parked_bytes
-                : packed ? szs_hip_weighted_packed_boundary_bytes(packed_local, !engine->is_linear, classes, kq_count, kc_count,
-                                                                  plan.longest_candidate)
-                         : szs_hip_weighted_boundary_bytes(objective, !engine->is_linear, narrow, kq_count, kc_count, plan.longest_candidate);
-        if (banded && tier == SZS_TIER_LANES) { /* queries beyond 64 words: the strip kernel's parked deltas instead */
-            size_t const banded_bytes = szs_hip_levenshtein_myers_banded_bytes(kq_count, kc_count, plan.longest_candidate);
-            boundary_bytes = banded_bytes > boundary_bytes ? banded_bytes : boundary_bytes;
-        }
-        status = szs_buffer_reserve(&engine->device_boundary, szs_memory_device_k, device, boundary_bytes, error_message);
-        if (status != sz_success_k) return status;
-    }
-
-    SZS_PHASE(2); /* ref upload enqueued, result placement, workspaces */
-    /* ---- launches, bracketed by the engine's event pair on the scope's stream ---- */
-    error = hipEventRecord(engine->event_start, stream);
-    if (error != hipSuccess) return szs_report_hip(error, error_message);
-    uint32_t launches = 0, cell_bits = 0;
-    if (tier == SZS_TIER_SYSTOLIC) { /* one launch for the whole cross-product, whatever the planner's groups */
-        int const launch_error = szs_hip_systolic_scores(
-            objective, !engine->is_linear, (szs_cost_model_t const *)engine->device_model.pointer,
-            device_query_refs, kq_count, device_candidate_refs, kc_count, plan.longest_query, plan.longest_candidate,
-            (int64_t *)device_results, device_stride, layout, engine->device_systolic.pointer,
-            engine->device_boundary.pointer, engine->systolic_epoch, stream);
-        if (launch_error) return szs_report_hip((hipError_t)launch_error, error_message);
-        ++launches, cell_bits = 32;
-    }
-    if (tier == SZS_TIER_MYERS_CHAIN) {
-        int const launch_error = szs_hip_myers_chain(device_query_refs, kq_count, device_candidate_refs, kc_count,
-                                                     plan.longest_query, plan.longest_candidate, (uint64_t *)device_results,
-                                                     device_stride, layout, engine->device_systolic.pointer,
-                                                     engine->device_boundary.pointer, engine->systolic_epoch, stream);
-        if (launch_error) return szs_report_hip((hipError_t)launch_error, error_message);
-        ++launches;
-    }
-    for (unsigned g = 0; tier == SZS_TIER_LANES && g < plan.groups_count; ++g) {
-        szs_plan_group_t const *group = &plan.groups[g];
-        int launch_error;
-        if (group->variant && runes) {
-            launch_error = group->variant == SZS_MYERS_SHORT_WORDS
-                               ? szs_hip_levenshtein_myers_runes(device_query_refs + group->first, group->count,
-                                                                 device_candidate_refs, kc_count, (uint64_t *)device_results,
-                                                                 device_stride, layout, stream)
-                               : szs_hip_levenshtein_myers_runes_long(group->variant, device_query_refs + group->first,
-                                                                      group->count, device_candidate_refs, kc_count,
-                                                                      (uint64_t *)device_results, device_stride, layout, stream);
-            if (launch_error == (int)hipErrorNotSupported) { /* no LDS for the rune table: the rune-keyed DP kernel */
-                cell_bits = 32;
-                launch_error = szs_hip_weighted_scores(objective, !engine->is_linear, 0,
-                                                       (szs_cost_model_t const *)engine->device_model.pointer,
-                                                       device_query_refs + group->first, group->count,
-                                                       device_candidate_refs, kc_count, plan.longest_candidate,
-                                                       (int64_t *)device_results, device_stride, layout,
-                                                       engine->device_boundary.pointer, stream);
-            }
-        }
-        else if (group->variant)
-            launch_error = szs_hip_levenshtein_myers(group->variant, device_query_refs + group->first, group->count,
-                                                     device_candidate_refs, kc_count, (uint64_t *)device_results,
-                                                     device_stride, layout, stream);
-        else if (banded)
-            launch_error = szs_hip_levenshtein_myers_banded(device_query_refs + group->first, group->count, device_candidate_refs,
-                                                            kc_count, plan.longest_candidate, (uint64_t *)device_results,
-                                                            device_stride, layout, engine->device_boundary.pointer, stream);
-        else if (packed) {
-            cell_bits = 16;
-            launch_error = szs_hip_weighted_packed_scores(packed_local, !engine->is_linear, classes,
-                                                          (szs_cost_model_t const *)engine->device_model.pointer,
-                                                          device_query_refs + group->first, group->count,
-                                                          device_candidate_refs, kc_count, plan.longest_candidate,
-                                                          (int64_t *)device_results, device_stride, layout,
-                                                          engine->device_boundary.pointer, stream);
-        }
-        else {
-            cell_bits = 32;
-            launch_error = szs_hip_weighted_scores(objective, !engine->is_linear, narrow,
-                                                   (szs_cost_model_t const *)engine->device_model.pointer,
-                                                   device_query_refs + group->first, group->count,
-                                                   device_candidate_refs, kc_count, plan.longest_candidate,
-                                                   (int64_t *)device_results, device_stride, layout,
-                                                   engine->device_boundary.pointer, stream);
-        }
-        if (launch_error) return szs_report_hip((hipError_t)launch_error, error_message);
-        ++launches;
-    }
-    error = hipEventRecord(engine->event_stop, stream);
-    if (error != hipSuccess) return szs_report_hip(error, error_message);
-    uint64_t *const stall_flag = (uint64_t *)((char *)engine->pinned_staging.pointer + refs_bytes); /* offsets area: done with */
-    *stall_flag = 0;
-    if (chained) {
-        error = hipMemcpyAsync(stall_flag, (char *)engine->device_systolic.pointer + 8, sizeof(uint64_t), hipMemcpyDeviceToHost, stream);
-        if (error != hipSuccess) return szs_report_hip(error, error_message);
-    }
-
-    if (!direct) /* one strided copy back into the caller's host matrix (reference: cuMemcpy2DAsync, cuda.cuh:2205-2215) */
-        error = hipMemcpy2DAsync(results, results_row_stride * sizeof(uint64_t), device_results,
-                                 device_stride * sizeof(uint64_t), (size_t)c_count * sizeof(uint64_t), q_count,
-                                 hipMemcpyDefault, stream);
-    SZS_PHASE(3); /* launches enqueued */
-    if (error == hipSuccess) error = hipStreamSynchronize(stream); /* the call is synchronous, like the reference's */
-    SZS_PHASE(4); /* waiting for the device */
-    if (error != hipSuccess) return szs_report_hip(error, error_message);
-    if (chained && *stall_flag == (((uint64_t)engine->systolic_epoch << 32) | 1))
-        return szs_report(sz_status_unknown_k, error_message, "Systolic pipeline stalled");
-
-    float kernel_ms = 0;
-    (void)hipEventElapsedTime(&kernel_ms, engine->event_start, engine->event_stop);
-    szs_rocm_call_profile_t *profile = &engine->last_profile;
-    uint64_t const pairs = symmetric ? (uint64_t)q_count * (q_count + 1) / 2 : (uint64_t)q_count * c_count;
-    profile->kernel_milliseconds = kernel_ms;
-    profile->cells = plan.cells;
-    profile->pairs = pairs;
-    /* Canonical pair-streaming bytes: len(q) + len(c) + two 4-byte offsets + one 8-byte result per pair. */
-    profile->algorithmic_bytes = symmetric ? 0 : (uint64_t)c_count * query_bytes + (uint64_t)q_count * candidate_bytes;
-    if (symmetric) {
-        uint64_t prefix = 0, bytes = 0;
-        for (uint32_t i = 0; i < q_count; ++i) prefix += q_lengths[i], bytes += (uint64_t)q_lengths[i] * (i + 1) + prefix;
-        profile->algorithmic_bytes = bytes;
-    }
-    profile->algorithmic_bytes += pairs * 16;
-    profile->unique_bytes = query_bytes + (symmetric ? 0 : candidate_bytes) +
-                            ((uint64_t)q_count + 1 + (symmetric ? 0 : c_count + 1)) * 4 + (uint64_t)q_count * c_count * 8;
-    profile->launches = launches;
-    profile->tier = (uint32_t)tier;
-    profile->transposed = (uint32_t)transposed;
-    profile->cell_bits = cell_bits;
-    profile->longest_query = q_longest, profile->longest_candidate = c_longest;
-    profile->host_milliseconds = now_milliseconds() - call_started;
-    SZS_PHASE(5);
-    if (trace)
-        fprintf(stderr, "szs call: %.1f us = offsets %.1f + plan %.1f + upload %.1f + launch %.1f + wait %.1f + wrap %.1f | kernel %.1f us\n",
-                profile->host_milliseconds * 1e3, phases[0] * 1e3, phases[1] * 1e3, phases[2] * 1e3, phases[3] * 1e3, phases[4] * 1e3,
-                phases[5] * 1e3, kernel_ms * 1e3);
-#undef SZS_PHASE
-    return szs_report(sz_success_k, error_message, NULL);
+    return cross_host_planned(&call);
 }

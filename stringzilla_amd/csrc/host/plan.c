@@ -20,58 +20,91 @@ static int compare_u64(void const *a, void const *b) {
     return x < y ? -1 : x > y;
 }
 
-/** Stable ascending sort of indices [0, count) by `lengths`; `order` receives the permutation. */
-static void sort_by_length(uint32_t const *lengths, uint32_t count, uint32_t longest, uint32_t *order) {
+size_t szs_plan_scratch_bytes(uint32_t count, uint32_t longest) {
+    /* valid for BOTH sides of a call, whichever holds the longest string: a side whose own longest is shorter may still
+     * take the counting sort */
+    size_t const counting = ((size_t)(longest < (1u << 16) ? longest : (1u << 16) - 1) + 2) * sizeof(uint32_t);
+    size_t const keyed = (size_t)count * sizeof(uint64_t);
+    return (counting > keyed ? counting : keyed) + 16;
+}
+
+/** Stable ascending sort of indices [0, count) by `lengths`; `order` receives the permutation.  No allocation: `scratch`
+ *  holds szs_plan_scratch_bytes(count, longest) bytes (the engine's grow-only host buffer). */
+static void sort_by_length(uint32_t const *lengths, uint32_t count, uint32_t longest, uint32_t *order, void *scratch) {
     if (count == 0) return;
     if (longest < (1u << 16)) { /* counting sort: O(count + longest), the common case */
-        uint32_t *bins = (uint32_t *)calloc((size_t)longest + 2, sizeof(uint32_t));
-        if (bins) {
-            for (uint32_t i = 0; i < count; ++i) bins[lengths[i] + 1]++;
-            for (uint32_t l = 0; l <= longest; ++l) bins[l + 1] += bins[l];
-            for (uint32_t i = 0; i < count; ++i) order[bins[lengths[i]]++] = i;
-            free(bins);
-            return;
-        }
-    }
-    uint64_t *keys = (uint64_t *)malloc((size_t)count * sizeof(uint64_t));
-    if (!keys) { /* degrade to the identity order: still correct, only less balanced */
-        for (uint32_t i = 0; i < count; ++i) order[i] = i;
+        uint32_t *bins = (uint32_t *)scratch;
+        memset(bins, 0, ((size_t)longest + 2) * sizeof(uint32_t));
+        for (uint32_t i = 0; i < count; ++i) bins[lengths[i] + 1]++;
+        for (uint32_t l = 0; l <= longest; ++l) bins[l + 1] += bins[l];
+        for (uint32_t i = 0; i < count; ++i) order[bins[lengths[i]]++] = i;
         return;
     }
+    uint64_t *keys = (uint64_t *)scratch;
     for (uint32_t i = 0; i < count; ++i) keys[i] = ((uint64_t)lengths[i] << 32) | i; /* index breaks ties: stable */
     qsort(keys, count, sizeof(uint64_t), compare_u64);
     for (uint32_t i = 0; i < count; ++i) order[i] = (uint32_t)keys[i];
-    free(keys);
 }
 
-static unsigned myers_variant(uint32_t length, unsigned widest) {
+static unsigned const variant_steps[SZS_PLAN_VARIANTS] = {0, SZS_MYERS_SHORT_WORDS, 10, 12, 16, 20, 24, 32, 48, 64};
+
+/** Slot of a string in `variant_counts` (hip/kernels.h): 0 = no bit-parallel width, 1 = the mixed short launch, 2..9 = the
+ *  long widths in ascending order. */
+static unsigned variant_slot(uint32_t length, unsigned widest) {
     unsigned const words = length ? (length + 31) / 32 : 1;
-    return words <= widest ? szs_hip_levenshtein_myers_round_words(words) : 0;
+    if (!widest || words > widest) return 0;
+    for (unsigned slot = 1; slot < SZS_PLAN_VARIANTS; ++slot)
+        if (words <= variant_steps[slot]) return slot;
+    return 0;
+}
+
+void szs_side_stats(uint32_t const *lengths, uint32_t count, unsigned myers, szs_side_stats_t *stats, uint32_t *variant_counts) {
+    memset(stats, 0, sizeof(*stats));
+    if (variant_counts) memset(variant_counts, 0, SZS_PLAN_VARIANTS * sizeof(uint32_t));
+    stats->count = count;
+    for (uint32_t i = 0; i < count; ++i) {
+        uint32_t const length = lengths[i];
+        if (length > stats->longest) stats->longest = length;
+        stats->symbols += length;
+        stats->bands_systolic += length ? (length + SZS_SYSTOLIC_BAND_ROWS - 1) / SZS_SYSTOLIC_BAND_ROWS : 1;
+        stats->bands_chain += length ? (length + SZS_MYERS_CHAIN_BAND_ROWS - 1) / SZS_MYERS_CHAIN_BAND_ROWS : 1;
+        if (variant_counts) variant_counts[variant_slot(length, myers)]++;
+    }
+}
+
+void szs_plan_groups(uint32_t const *variant_counts, szs_plan_t *plan) {
+    /* Queries arrive LONGEST FIRST: the strings no bit-parallel width takes (slot 0), then the long widths from the
+     * widest down, last the one mixed-width launch of all short queries. */
+    plan->groups_count = 0;
+    uint32_t first = 0;
+    for (unsigned step = 0; step < SZS_PLAN_VARIANTS; ++step) {
+        unsigned const slot = step == 0 ? 0 : SZS_PLAN_VARIANTS - step;
+        if (!variant_counts[slot]) continue;
+        szs_plan_group_t *group = &plan->groups[plan->groups_count++];
+        group->variant = variant_steps[slot], group->first = first, group->count = variant_counts[slot];
+        first += variant_counts[slot];
+    }
 }
 
 void szs_plan_build(unsigned myers, int symmetric, uint64_t const *query_addresses, uint32_t const *query_lengths,
                     uint32_t queries_count, uint64_t const *candidate_addresses, uint32_t const *candidate_lengths,
                     uint32_t candidates_count, szs_string_ref_t *query_refs, szs_string_ref_t *candidate_refs,
-                    uint32_t *keys, szs_plan_t *plan) {
+                    uint32_t *keys, void *scratch, szs_plan_t *plan) {
     memset(plan, 0, sizeof(*plan));
-    uint64_t query_bytes = 0, candidate_bytes = 0;
-    for (uint32_t i = 0; i < queries_count; ++i) {
-        if (query_lengths[i] > plan->longest_query) plan->longest_query = query_lengths[i];
-        query_bytes += query_lengths[i];
-    }
-    for (uint32_t i = 0; i < candidates_count; ++i) {
-        if (candidate_lengths[i] > plan->longest_candidate) plan->longest_candidate = candidate_lengths[i];
-        candidate_bytes += candidate_lengths[i];
-    }
+    szs_side_stats_t query_stats, candidate_stats;
+    uint32_t variant_counts[SZS_PLAN_VARIANTS];
+    szs_side_stats(query_lengths, queries_count, myers, &query_stats, variant_counts);
+    szs_side_stats(candidate_lengths, candidates_count, 0, &candidate_stats, NULL);
+    plan->longest_query = query_stats.longest, plan->longest_candidate = candidate_stats.longest;
     if (symmetric) { /* lower triangle incl. diagonal: sum_i len_i * sum_{j <= i} len_j */
         uint64_t prefix = 0, cells = 0;
         for (uint32_t i = 0; i < queries_count; ++i) prefix += query_lengths[i], cells += (uint64_t)query_lengths[i] * prefix;
         plan->cells = cells;
     }
-    else { plan->cells = query_bytes * candidate_bytes; }
+    else { plan->cells = query_stats.symbols * candidate_stats.symbols; }
 
     /* Candidates: ascending length. */
-    sort_by_length(candidate_lengths, candidates_count, plan->longest_candidate, keys);
+    sort_by_length(candidate_lengths, candidates_count, plan->longest_candidate, keys, scratch);
     for (uint32_t slot = 0; slot < candidates_count; ++slot) {
         uint32_t const c = keys[slot];
         candidate_refs[slot].address = candidate_addresses[c];
@@ -84,20 +117,14 @@ void szs_plan_build(unsigned myers, int symmetric, uint64_t const *query_address
      * long widths from the widest down, last the one mixed-width launch of all short queries - and within a launch the
      * heaviest workgroups are handed out first, so a launch drains on its lightest work.  The weighted engines use
      * the same order for their single group (variant 0): their kernels pull work items heaviest first. */
-    sort_by_length(query_lengths, queries_count, plan->longest_query, keys);
+    sort_by_length(query_lengths, queries_count, plan->longest_query, keys, scratch);
     for (uint32_t slot = 0; slot < queries_count; ++slot) {
         uint32_t const q = keys[queries_count - 1 - slot]; /* ascending order read backwards */
         query_refs[slot].address = query_addresses[q];
         query_refs[slot].length = query_lengths[q];
         query_refs[slot].index = q;
-        unsigned const variant = myers ? myers_variant(query_lengths[q], myers) : 0; /* weighted engines: one group */
-        szs_plan_group_t *group = plan->groups_count ? &plan->groups[plan->groups_count - 1] : NULL;
-        if (!group || group->variant != variant) {
-            group = &plan->groups[plan->groups_count++];
-            group->variant = variant, group->first = slot, group->count = 0;
-        }
-        group->count++;
     }
+    szs_plan_groups(variant_counts, plan);
 }
 
 /* ---- tier and orientation choice ------------------------------------------------------------------------------------ */
@@ -113,23 +140,22 @@ void szs_plan_build(unsigned myers, int symmetric, uint64_t const *query_address
  *               + 63 steps; at most 1024 wavefronts advance at once; the call lasts at least as long as the band chain of
  *               its largest pair (each band trails its predecessor by ~95 steps).
  *  Constants from the measured gfx950 rates (profiles/r01/valu_peak.json): fast VALU ~2.5 cycles, slow ~4.2.
+ *  Inputs are the per-side statistics only (hip/kernels.h: szs_side_stats_t), so that the device planner's summary feeds
+ *  the same model as the host planner's length arrays.
  */
 double szs_plan_estimate(unsigned bit_parallel_limit, int bit_parallel_chain, int affine, int uniform, int symmetric,
-                         uint32_t const *query_lengths, uint32_t queries_count, uint32_t candidates_count,
-                         uint64_t candidate_symbols, uint32_t longest_query, uint32_t longest_candidate,
-                         unsigned band_rows, int *tier) {
+                         szs_side_stats_t const *queries, szs_side_stats_t const *candidates, unsigned band_rows, int *tier) {
     if (bit_parallel_chain) band_rows = SZS_MYERS_CHAIN_BAND_ROWS; /* hip/myers_chain.hip: 64 lanes x 32 rows x 8 columns */
     *tier = SZS_TIER_LANES;
+    uint32_t const queries_count = queries->count, candidates_count = candidates->count;
+    uint32_t const longest_query = queries->longest, longest_candidate = candidates->longest;
     if (!queries_count || !candidates_count) return 0;
     double const simds = 1024.0;
-    double const mean_candidate = (double)candidate_symbols / candidates_count;
+    double const mean_candidate = (double)candidates->symbols / candidates_count;
     double const scale = symmetric ? 0.5 : 1.0; /* half the matrix is scored */
 
-    double query_symbols = 0, bands_total = 0;
-    for (uint32_t i = 0; i < queries_count; ++i) {
-        query_symbols += query_lengths[i];
-        bands_total += query_lengths[i] ? (query_lengths[i] + band_rows - 1) / band_rows : 1;
-    }
+    double const query_symbols = (double)queries->symbols;
+    double const bands_total = (double)(bit_parallel_chain ? queries->bands_chain : queries->bands_systolic);
 
     /* lanes: cells per lane-cycle; the bit-parallel kernels only exist up to `bit_parallel_limit` symbols per query.
      * A wavefront that has its SIMD to itself issues a dependent instruction every ~8 cycles instead of every ~4
@@ -175,34 +201,27 @@ double szs_plan_estimate(unsigned bit_parallel_limit, int bit_parallel_chain, in
         (longest_candidate / columns_per_step + 63.0 + 95.0 * (longest_chain > 1 ? longest_chain - 1 : 0)) * step_cycles;
     if (chain_cycles > systolic_cycles) systolic_cycles = chain_cycles;
 
-    char const *forced = getenv("SZS_ROCM_TIER"); /* testing aid: lanes | systolic */
-    if (forced && forced[0] == 'l') return lanes_cycles;
+    int const forced = szs_tuning_get(szs_knob_tier_k); /* testing aid (host/tuning.c): lanes | systolic | chain */
+    if (forced == SZS_TIER_LANES) return lanes_cycles;
     int const chained = bit_parallel_chain ? SZS_TIER_MYERS_CHAIN : SZS_TIER_SYSTOLIC;
-    if (forced && (forced[0] == 's' || forced[0] == 'c')) return *tier = chained, systolic_cycles;
+    if (forced == SZS_TIER_SYSTOLIC || forced == SZS_TIER_MYERS_CHAIN) return *tier = chained, systolic_cycles;
     if (!band_rows || systolic_cycles >= 0.8 * lanes_cycles) return lanes_cycles; /* ties go to the simpler tier */
     *tier = chained;
     return systolic_cycles;
 }
 
-void szs_plan_orient(unsigned bit_parallel_limit, int bit_parallel_chain, int affine, int uniform, int symmetric, uint32_t const *query_lengths,
-                     uint32_t queries_count, uint32_t const *candidate_lengths, uint32_t candidates_count,
-                     unsigned band_rows, int *tier, int *transposed) {
-    uint64_t q_symbols = 0, c_symbols = 0;
-    uint32_t q_longest = 0, c_longest = 0;
-    for (uint32_t i = 0; i < queries_count; ++i)
-        q_symbols += query_lengths[i], q_longest = query_lengths[i] > q_longest ? query_lengths[i] : q_longest;
-    for (uint32_t i = 0; i < candidates_count; ++i)
-        c_symbols += candidate_lengths[i], c_longest = candidate_lengths[i] > c_longest ? candidate_lengths[i] : c_longest;
+void szs_plan_orient(unsigned bit_parallel_limit, int bit_parallel_chain, int affine, int uniform, int symmetric,
+                     szs_side_stats_t const *queries, szs_side_stats_t const *candidates, unsigned band_rows, int *tier,
+                     int *transposed) {
     int swapped_tier = SZS_TIER_LANES;
-    double const cycles = szs_plan_estimate(bit_parallel_limit, bit_parallel_chain, affine, uniform, symmetric, query_lengths, queries_count,
-                                            candidates_count, c_symbols, q_longest, c_longest, band_rows, tier);
+    double const cycles = szs_plan_estimate(bit_parallel_limit, bit_parallel_chain, affine, uniform, symmetric, queries,
+                                            candidates, band_rows, tier);
     *transposed = 0;
     if (symmetric) return; /* nothing to swap */
-    double const swapped_cycles = szs_plan_estimate(bit_parallel_limit, bit_parallel_chain, affine, uniform, 0, candidate_lengths,
-                                                    candidates_count, queries_count, q_symbols, c_longest, q_longest,
-                                                    band_rows, &swapped_tier);
-    char const *forced = getenv("SZS_ROCM_SWAP"); /* testing aid: 0 | 1 */
-    *transposed = forced ? forced[0] == '1' : swapped_cycles < 0.6 * cycles;
+    double const swapped_cycles = szs_plan_estimate(bit_parallel_limit, bit_parallel_chain, affine, uniform, 0, candidates,
+                                                    queries, band_rows, &swapped_tier);
+    int const forced = szs_tuning_get(szs_knob_swap_k); /* testing aid: 0 | 1 */
+    *transposed = forced >= 0 ? forced == 1 : swapped_cycles < 0.6 * cycles;
     if (*transposed) *tier = swapped_tier;
 }
 
@@ -219,13 +238,17 @@ sz_status_t szs_rocm_plan_probe(int unit_cost, int symmetric, sz_u32_t const *qu
     szs_string_ref_t *query_refs = (szs_string_ref_t *)calloc((size_t)q + 1, sizeof(szs_string_ref_t));
     szs_string_ref_t *candidate_refs = (szs_string_ref_t *)calloc((size_t)c + 1, sizeof(szs_string_ref_t));
     uint32_t *keys = (uint32_t *)calloc(most + 1, sizeof(uint32_t));
-    if (!addresses || !query_refs || !candidate_refs || !keys) {
-        free(addresses), free(query_refs), free(candidate_refs), free(keys);
+    uint32_t longest = 0;
+    for (uint32_t i = 0; i < q; ++i) longest = query_lengths[i] > longest ? query_lengths[i] : longest;
+    for (uint32_t i = 0; i < c; ++i) longest = candidate_lengths[i] > longest ? candidate_lengths[i] : longest;
+    void *scratch = malloc(szs_plan_scratch_bytes((uint32_t)most, longest));
+    if (!addresses || !query_refs || !candidate_refs || !keys || !scratch) {
+        free(addresses), free(query_refs), free(candidate_refs), free(keys), free(scratch);
         return sz_bad_alloc_k;
     }
     szs_plan_t plan;
     szs_plan_build(unit_cost ? SZS_MYERS_MAX_WORDS : 0, symmetric, addresses, query_lengths, q, addresses, candidate_lengths, c, query_refs,
-                   candidate_refs, keys, &plan);
+                   candidate_refs, keys, scratch, &plan);
     if (candidate_order)
         for (uint32_t i = 0; i < c; ++i) candidate_order[i] = candidate_refs[i].index;
     if (query_order)
@@ -235,7 +258,7 @@ sz_status_t szs_rocm_plan_probe(int unit_cost, int symmetric, sz_u32_t const *qu
             for (uint32_t i = 0; i < plan.groups[g].count; ++i)
                 query_variant[plan.groups[g].first + i] = plan.groups[g].variant;
     if (cells) *cells = plan.cells;
-    free(addresses), free(query_refs), free(candidate_refs), free(keys);
+    free(addresses), free(query_refs), free(candidate_refs), free(keys), free(scratch);
     return sz_success_k;
 }
 
@@ -244,9 +267,12 @@ sz_status_t szs_rocm_orientation_probe(int unit_cost, int affine, int uniform, i
                                        sz_u32_t const *candidate_lengths, sz_size_t candidates_count, int *tier,
                                        int *transposed) {
     if (queries_count > 0xFFFFFFFFu || candidates_count > 0xFFFFFFFFu || !tier || !transposed) return sz_overflow_risk_k;
-    szs_plan_orient(unit_cost ? 0xFFFFFFFFu : 0, unit_cost, affine, uniform, symmetric, query_lengths, /* as dispatch.c does for bytes */
-                    (uint32_t)queries_count, symmetric ? query_lengths : candidate_lengths,
-                    (uint32_t)(symmetric ? queries_count : candidates_count), SZS_SYSTOLIC_BAND_ROWS, tier, transposed);
+    szs_side_stats_t query_stats, candidate_stats;
+    szs_side_stats(query_lengths, (uint32_t)queries_count, 0, &query_stats, NULL);
+    szs_side_stats(symmetric ? query_lengths : candidate_lengths, (uint32_t)(symmetric ? queries_count : candidates_count), 0,
+                   &candidate_stats, NULL);
+    szs_plan_orient(unit_cost ? 0xFFFFFFFFu : 0, unit_cost, affine, uniform, symmetric, &query_stats, &candidate_stats, /* as dispatch.c does for bytes */
+                    SZS_SYSTOLIC_BAND_ROWS, tier, transposed);
     return sz_success_k;
 }
 

@@ -82,7 +82,8 @@ typedef struct szs_engine_s {
 
     /* grow-only scratch, bound to the device of the last call */
     int device;
-    szs_buffer_t host_lengths;   /* host: addresses + lengths of both sides, sort keys */
+    szs_buffer_t host_lengths;   /* host: addresses + lengths of both sides */
+    szs_buffer_t host_scratch;   /* host: the planner's sort keys and counting bins */
     szs_buffer_t pinned_staging; /* pinned: offsets downloads, string-ref uploads */
     szs_buffer_t device_refs;    /* device: string refs of both sides */
     szs_buffer_t device_results; /* device: dense results when the caller's matrix is not device-accessible */
@@ -96,8 +97,15 @@ typedef struct szs_engine_s {
     szs_buffer_t pinned_transcode; /* pinned: the host's side of the same */
     int model_uploaded_device;
     int model_uploaded_transposed; /* the uploaded class table is the transpose (sides swapped by the planner) */
+    szs_cost_model_t host_model;   /* what was uploaded: lives as long as the engine, so the upload needs no wait */
     hipEvent_t event_start, event_stop;
     int events_device;
+
+    /* device-side planning (hip/planner.hip) */
+    szs_buffer_t device_plan_refs; /* device: ascending + descending refs of both sides */
+    szs_buffer_t pinned_summary;   /* pinned: the planner's szs_plan_summary_t */
+    uint32_t plan_sequence;        /* echoed by the planner: tells this call's summary from a stale one */
+    struct szs_decision_t *remembered; /* the launch shape of the previous device-planned call (speculation), or NULL */
 
     szs_rocm_call_profile_t last_profile;
 } szs_engine_s;
@@ -160,16 +168,44 @@ typedef struct szs_plan_t {
 } szs_plan_t;
 
 /**
+ *  What to launch for one call.  A pure function of the engine's cost model and of the statistics of the two sides (their
+ *  counts, longest strings, sums, band counts and strings per launch variant) - the host planner computes those from its
+ *  length arrays, the device planner delivers them in its summary.  Every field stays VALID for any batch with the same
+ *  counts, the same strings per launch variant on the kernels' query side and no longer longest strings, which is exactly
+ *  what hip/planner.hip verifies before it lets speculated launches score anything.
+ */
+typedef struct szs_decision_t {
+    int valid;
+    int symmetric, runes;
+    uint32_t q_count, c_count; /* the caller's sides */
+    int tier, transposed, layout;
+    int use_myers, banded, maximise;
+    int objective, narrow, packed, packed_local, wide_cells;
+    uint32_t classes;
+    uint32_t kq_count, kc_count; /* kernel roles */
+    uint32_t longest[2];         /* the caller's sides: queries, candidates */
+    szs_plan_t plan;             /* kernel roles: groups of the query side, longest strings, cells */
+    size_t systolic_control_bytes, systolic_parked_bytes;
+    uint32_t variant_counts[SZS_PLAN_VARIANTS]; /* of the kernels' query side */
+} szs_decision_t;
+
+/**
  *  Fills `candidate_refs` with the candidates sorted by ascending length (stable), and `query_refs` grouped by kernel
  *  variant, longest first.  `myers` = widest bit-vector (in 32-bit words) a bit-parallel kernel exists for - 0 for the
  *  weighted engines, SZS_MYERS_MAX_WORDS for bytes and codepoints; longer queries get variant 0
  *  (scored by the weighted kernel).
- *  Lengths and addresses are parallel arrays.  Scratch `keys` must hold max(q, c) uint32_t.
+ *  Lengths and addresses are parallel arrays.  Scratch: `keys` holds max(q, c) uint32_t, `scratch`
+ *  szs_plan_scratch_bytes(max(q, c), longest string) bytes - the planner itself never allocates.
  */
+size_t szs_plan_scratch_bytes(uint32_t count, uint32_t longest);
 void szs_plan_build(unsigned myers, int symmetric, uint64_t const *query_addresses, uint32_t const *query_lengths,
                     uint32_t queries_count, uint64_t const *candidate_addresses, uint32_t const *candidate_lengths,
                     uint32_t candidates_count, szs_string_ref_t *query_refs, szs_string_ref_t *candidate_refs,
-                    uint32_t *keys, szs_plan_t *plan);
+                    uint32_t *keys, void *scratch, szs_plan_t *plan);
+/** Statistics of one side (what the tier model reads) and, optionally, its strings per launch variant. */
+void szs_side_stats(uint32_t const *lengths, uint32_t count, unsigned myers, szs_side_stats_t *stats, uint32_t *variant_counts);
+/** Launch groups of queries sorted longest first, from their per-variant counts (hip/kernels.h: SZS_PLAN_VARIANTS). */
+void szs_plan_groups(uint32_t const *variant_counts, szs_plan_t *plan);
 
 #define SZS_TIER_LANES 0    /* one pair per lane: lev_myers.hip, weighted.hip */
 #define SZS_TIER_SYSTOLIC 1 /* one pair per chain of wavefronts: systolic.hip */
@@ -180,20 +216,18 @@ void szs_plan_build(unsigned myers, int symmetric, uint64_t const *query_address
  *  evaluates both (queries as the workgroup / band side, or candidates) and may swap the sides, which every scorer
  *  here permits - gap costs apply to both strings alike, and a swapped class table is its transpose.
  *  `bit_parallel_limit`: longest query (symbols) the Myers kernels take, 0 for weighted engines; `uniform`:
- *  Levenshtein-family costs.  `SZS_ROCM_TIER=lanes|systolic` forces the tier (testing aid).
+ *  Levenshtein-family costs.  The `tier` knob (host/tuning.c) forces the tier (testing aid).
  */
 double szs_plan_estimate(unsigned bit_parallel_limit, int bit_parallel_chain, int affine, int uniform, int symmetric,
-                         uint32_t const *query_lengths, uint32_t queries_count, uint32_t candidates_count,
-                         uint64_t candidate_symbols, uint32_t longest_query, uint32_t longest_candidate,
-                         unsigned band_rows, int *tier);
+                         szs_side_stats_t const *queries, szs_side_stats_t const *candidates, unsigned band_rows, int *tier);
 
 /**
  *  The decision itself: evaluates szs_plan_estimate for both orientations and reports the tier to run and whether the
- *  sides are swapped (never for symmetric calls).  `SZS_ROCM_SWAP=0|1` forces the orientation (testing aid).
+ *  sides are swapped (never for symmetric calls).  The `swap` knob forces the orientation (testing aid).
  */
-void szs_plan_orient(unsigned bit_parallel_limit, int bit_parallel_chain, int affine, int uniform, int symmetric, uint32_t const *query_lengths,
-                     uint32_t queries_count, uint32_t const *candidate_lengths, uint32_t candidates_count,
-                     unsigned band_rows, int *tier, int *transposed);
+void szs_plan_orient(unsigned bit_parallel_limit, int bit_parallel_chain, int affine, int uniform, int symmetric,
+                     szs_side_stats_t const *queries, szs_side_stats_t const *candidates, unsigned band_rows, int *tier,
+                     int *transposed);
 
 /* ---- the call (dispatch.c) --------------------------------------------------------------------------------------- */
 

@@ -32,16 +32,6 @@ def shard_rows(lengths: np.ndarray, shards: int):
     return shard_of_row, loads
 
 
-def _select(strs: Strs, rows: np.ndarray) -> Strs:
-    """Sub-tape holding `rows` of `strs`, in that order."""
-    offsets = strs.offsets.astype(np.int64)
-    lengths = offsets[rows + 1] - offsets[rows]
-    new_offsets = np.zeros(len(rows) + 1, dtype=strs.offsets.dtype)
-    np.cumsum(lengths, out=new_offsets[1:])
-    data = np.concatenate([strs.data[offsets[r]:offsets[r + 1]] for r in rows]) if len(rows) and lengths.sum() else np.zeros(1, np.uint8)
-    return Strs.from_tape(data, new_offsets)
-
-
 class ShardedEngine:
     """Wraps a single-GPU engine (`LevenshteinDistances`, `NeedlemanWunschScores`, ...) for a process group.
 
@@ -61,7 +51,14 @@ class ShardedEngine:
         if score is None:
             if engine is None:
                 raise ValueError("ShardedEngine needs an engine (there is no CPU fallback)")
-            score = lambda queries, candidates: engine(queries, candidates, device=scope)
+
+            def score(queries, candidates):  # this rank's rows x all candidates, results left in HBM
+                import torch
+
+                gpu = scope.gpu_device if scope is not None and scope.gpu_device is not None else torch.cuda.current_device()
+                out = torch.empty((len(queries), len(candidates)), dtype=torch.int64, device=torch.device("cuda", gpu))
+                return engine(queries, candidates, device=scope, out=out)
+
         self._score = score
         self.last_balance = 1.0
         self.last_rows: Optional[np.ndarray] = None
@@ -75,6 +72,8 @@ class ShardedEngine:
         return torch.device("cpu")
 
     def _broadcast_tape(self, strs: Optional[Strs], source: int) -> Strs:
+        """Replicates one tape from `source`.  The receiving side keeps bytes and offsets where the collective delivered
+        them - in HBM under RCCL - and mirrors only the offsets on the host (the row dealer and the planner read them)."""
         import torch
 
         device = self._device()
@@ -83,10 +82,14 @@ class ShardedEngine:
             header = torch.tensor([strs.data.size, strs.count, int(strs.wide_offsets)], dtype=torch.int64, device=device)
         self._dist.broadcast(header, source, group=self.group)
         size, count, wide = (int(x) for x in header.tolist())
-        offset_dtype, torch_offset = (np.uint64, torch.int64) if wide else (np.uint32, torch.int32)
+        torch_offset = torch.int64 if wide else torch.int32
         if self.rank == source:
-            data = torch.from_numpy(strs.data).to(device)
-            offsets = torch.from_numpy(strs.offsets.view(np.int64 if wide else np.int32)).to(device)
+            if device.type == "cuda":
+                strs.to_device(device.index)
+                _, data, offsets = strs._device
+            else:
+                data = torch.from_numpy(strs.data)
+                offsets = torch.from_numpy(strs.offsets.view(np.int64 if wide else np.int32))
         else:
             data = torch.empty(size, dtype=torch.uint8, device=device)
             offsets = torch.empty(count + 1, dtype=torch_offset, device=device)
@@ -94,11 +97,12 @@ class ShardedEngine:
         self._dist.broadcast(offsets, source, group=self.group)
         if self.rank == source:
             return strs
-        return Strs.from_tape(data.cpu().numpy(), offsets.cpu().numpy().view(offset_dtype))
+        return Strs.from_device(data, offsets)
 
     def __call__(self, queries: Optional[Strs], candidates: Optional[Strs], source: int = 0, gather: bool = False):
         """Every rank calls this; only `source` needs to pass the inputs.  Returns (row_indices, local_matrix) - this
-        rank's result rows and which global rows they are - or, with `gather=True`, the full matrix on every rank."""
+        rank's result rows and which global rows they are - or, with `gather=True`, the full matrix on every rank
+        (a tensor on the collective's device when the scorer returned tensors, else a NumPy matrix)."""
         import torch
 
         queries = self._broadcast_tape(queries, source)
@@ -107,21 +111,27 @@ class ShardedEngine:
         self.last_balance = float(loads.max() / max(loads.mean(), 1.0))
         rows = np.nonzero(shard_of_row == self.rank)[0]
         self.last_rows = rows
-        local = self._score(_select(queries, rows), candidates) if len(rows) else np.zeros((0, len(candidates)), dtype=np.int64)
+        local = self._score(queries.select(rows), candidates) if len(rows) else np.zeros((0, len(candidates)), dtype=np.int64)
         if not gather:
             return rows, local
 
+        # The one collective on the result side: equal-sized (padded) row blocks, all-gathered and dealt back to their
+        # global rows on the collective's device - nothing is staged through host memory under RCCL.
         device = self._device()
         columns = len(candidates)
         counts = np.bincount(shard_of_row, minlength=self.world)
         longest = int(counts.max()) if len(counts) else 0
+        as_tensor = isinstance(local, torch.Tensor)
+        dtype = np.int64 if as_tensor else np.asarray(local).dtype
         padded = torch.zeros((longest, columns), dtype=torch.int64, device=device)
         if len(rows):
-            padded[:len(rows)] = torch.from_numpy(np.ascontiguousarray(local).view(np.int64)).to(device)
+            block = local if as_tensor else torch.from_numpy(np.ascontiguousarray(local).view(np.int64))
+            padded[:len(rows)] = block.to(device)
         blocks = [torch.empty_like(padded) for _ in range(self.world)]
         self._dist.all_gather(blocks, padded, group=self.group)
-        full = np.zeros((len(queries), columns), dtype=np.asarray(local).dtype)
+        full = torch.zeros((len(queries), columns), dtype=torch.int64, device=device)
         for rank, block in enumerate(blocks):
             owned = np.nonzero(shard_of_row == rank)[0]
-            full[owned] = block[:len(owned)].cpu().numpy().view(full.dtype)
-        return full
+            if len(owned):
+                full[torch.from_numpy(owned).to(device)] = block[:len(owned)]
+        return full if as_tensor else full.cpu().numpy().view(dtype)

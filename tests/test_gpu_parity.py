@@ -30,30 +30,21 @@ import os  # noqa: E402
 
 
 @contextlib.contextmanager
-def forced_tier(name):
-    """`SZS_ROCM_TIER` overrides the planner's cycle model for one call (csrc/host/plan.c)."""
-    previous = os.environ.get("SZS_ROCM_TIER")
-    os.environ["SZS_ROCM_TIER"] = name
-    try:
-        yield
-    finally:
-        if previous is None:
-            del os.environ["SZS_ROCM_TIER"]
-        else:
-            os.environ["SZS_ROCM_TIER"] = previous
-
-
-@contextlib.contextmanager
 def forced_env(name, value):
-    previous = os.environ.get(name)
-    os.environ[name] = value
+    """Pins one tuning knob of the library for the calls inside the block (`szs_rocm_tuning_set`, csrc/host/tuning.c: the
+    environment itself is only read when the library is loaded), then restores the automatic choice."""
+    from stringzilla_amd import _abi
+
+    _abi.tuning_set(name, value)
     try:
         yield
     finally:
-        if previous is None:
-            del os.environ[name]
-        else:
-            os.environ[name] = previous
+        _abi.tuning_set(name, None)
+
+
+def forced_tier(name):
+    """The `tier` knob overrides the planner's cycle model (csrc/host/plan.c)."""
+    return forced_env("SZS_ROCM_TIER", name)
 
 
 def _unhex(items):
@@ -728,17 +719,8 @@ def test_systolic_single_very_long_pair(gpu, oracle):
 # ---- orientation: the planner may put the candidates on workgroups and the queries on lanes -----------------------------
 
 
-@contextlib.contextmanager
 def forced_swap(value):
-    previous = os.environ.get("SZS_ROCM_SWAP")
-    os.environ["SZS_ROCM_SWAP"] = value
-    try:
-        yield
-    finally:
-        if previous is None:
-            del os.environ["SZS_ROCM_SWAP"]
-        else:
-            os.environ["SZS_ROCM_SWAP"] = previous
+    return forced_env("SZS_ROCM_SWAP", value)
 
 
 @pytest.mark.parametrize("tier", ["lanes", "systolic"])

@@ -1,0 +1,235 @@
+"""`-m gpu`: the pieces added in round 2, each against the CPU oracle through the C-ABI, bit-exact.
+
+  - the planner on the device (csrc/hip/planner.hip) and the speculated launches behind it: every family, ragged and
+    degenerate shapes, 32- and 64-bit tapes, symmetric calls, batches whose shape changes between calls;
+  - the 64-bit cell tier (csrc/hip/wide.hip), forced onto inputs small enough to check (the reference widens its cells
+    by the reach rule, serial.hpp:135-162, cuda.cuh:5863-5874);
+  - failure paths stay synchronous: a failing call returns with the stream drained and the engine usable.
+"""
+import contextlib
+import ctypes
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import stringzilla_amd as szs  # noqa: E402
+from stringzilla_amd import _abi, matrices, workloads  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+
+    assert torch.cuda.is_available(), "the gpu-marked tests need a GPU"
+    return szs.DeviceScope(gpu_device=0)
+
+
+@contextlib.contextmanager
+def knob(name, value):
+    _abi.tuning_set(name, value)
+    try:
+        yield
+    finally:
+        _abi.tuning_set(name, None)
+
+
+def _strings(rng, count, low, high, alphabet=b"ACGT"):
+    return [bytes(rng.choice(alphabet) for _ in range(rng.randint(low, high))) for _ in range(count)]
+
+
+def _engines(gpu):
+    blosum, nuc = matrices.blosum62(), matrices.nuc44()
+    return [
+        ("lev_unit", szs.LevenshteinDistances(capabilities=gpu), lambda o, q, c: o.levenshtein(q, c)),
+        ("lev_weighted", szs.LevenshteinDistances(1, 3, 3, 3, capabilities=gpu), lambda o, q, c: o.levenshtein(q, c, 1, 3, 3, 3)),
+        ("lev_affine", szs.LevenshteinDistances(0, 1, 4, 2, capabilities=gpu), lambda o, q, c: o.levenshtein(q, c, 0, 1, 4, 2)),
+        ("nw_linear", szs.NeedlemanWunschScores(*blosum, open=-4, extend=-4, capabilities=gpu),
+         lambda o, q, c: o.needleman_wunsch(q, c, *blosum, -4, -4)),
+        ("nw_affine", szs.NeedlemanWunschScores(*blosum, open=-5, extend=-1, capabilities=gpu),
+         lambda o, q, c: o.needleman_wunsch(q, c, *blosum, -5, -1)),
+        ("sw_linear", szs.SmithWatermanScores(*nuc, open=-3, extend=-3, capabilities=gpu),
+         lambda o, q, c: o.smith_waterman(q, c, *nuc, -3, -3)),
+        ("sw_affine", szs.SmithWatermanScores(*nuc, open=-4, extend=-1, capabilities=gpu),
+         lambda o, q, c: o.smith_waterman(q, c, *nuc, -4, -1)),
+    ]
+
+
+def test_device_and_host_planners_score_the_same_matrices(gpu, oracle):
+    """Every family, a ragged batch: the device-planned call, the same call speculated on the previous shape, and the
+    host-planned call all equal the oracle; the profile says which planner ran."""
+    rng = random.Random(11)
+    queries = _strings(rng, 37, 0, 300, b"ARNDCQEGHILKMFPSTWYV") + [b""]
+    candidates = _strings(rng, 301, 0, 200, b"ARNDCQEGHILKMFPSTWYV") + [b"", b"A"]
+    for name, engine, expected_of in _engines(gpu):
+        expected = expected_of(oracle, queries, candidates).view(np.int64)
+        q, c = szs.Strs(queries), szs.Strs(candidates)
+        first = engine(q, c, device=gpu).view(np.int64)
+        assert engine.last_call_profile().planner == 1, name  # planned on the device, nothing to speculate on yet
+        assert np.array_equal(first, expected), name
+        second = engine(q, c, device=gpu).view(np.int64)
+        assert engine.last_call_profile().planner == 2, name  # launches went in behind the planner
+        assert np.array_equal(second, expected), name
+        with knob("planner", "host"):
+            third = engine(q, c, device=gpu).view(np.int64)
+            assert engine.last_call_profile().planner == 0, name
+        assert np.array_equal(third, expected), name
+        with knob("speculate", "0"):
+            fourth = engine(q, c, device=gpu).view(np.int64)
+            assert engine.last_call_profile().planner == 1, name
+        assert np.array_equal(fourth, expected), name
+
+
+def test_speculation_survives_a_change_of_shape(gpu, oracle):
+    """Same counts, different lengths: launch variants, longest strings and with them the remembered shape change from
+    call to call (short -> long queries -> short again -> longer candidates).  Whatever the speculated launches did to the
+    results matrix, the call must return the right one."""
+    rng = random.Random(5)
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+    nw = szs.NeedlemanWunschScores(*matrices.blosum62(), open=-4, extend=-4, capabilities=gpu)
+    table = matrices.blosum62()
+    shapes = [((10, 100), (50, 150)), ((200, 700), (50, 150)), ((10, 100), (50, 150)), ((10, 100), (400, 900)),
+              ((0, 40), (0, 30)), ((2100, 2300), (100, 300)), ((10, 100), (50, 150))]
+    planners = []
+    for (q_low, q_high), (c_low, c_high) in shapes:
+        queries = _strings(rng, 24, q_low, q_high, b"ARNDCQEGHILKMFPSTWYV")
+        candidates = _strings(rng, 260, c_low, c_high, b"ARNDCQEGHILKMFPSTWYV")
+        got = engine(queries, candidates, device=gpu)
+        assert np.array_equal(got, oracle.levenshtein(queries, candidates))
+        planners.append(engine.last_call_profile().planner)
+        got = nw(queries, candidates, device=gpu)
+        assert np.array_equal(got, oracle.needleman_wunsch(queries, candidates, *table, -4, -4))
+    assert planners[0] == 1 and 1 in planners[1:]  # at least one speculation was refused and re-planned
+    # the same batch twice in a row is speculated
+    again = engine(queries, candidates, device=gpu)
+    assert engine.last_call_profile().planner == 2 and np.array_equal(again, oracle.levenshtein(queries, candidates))
+
+
+def test_device_planner_formats(gpu, oracle):
+    """64-bit tapes, symmetric calls, strided result rows, one-string sides and offsets that do not start at zero."""
+    import torch
+
+    rng = random.Random(3)
+    strings = _strings(rng, 70, 0, 180)
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+    expected = oracle.levenshtein(strings, strings)
+    for wide in (False, True):
+        tape = szs.Strs(strings, wide_offsets=wide)
+        for _ in range(2):  # plain, then speculated
+            assert np.array_equal(engine(tape, device=gpu), expected)  # symmetric
+            assert np.array_equal(engine(tape, tape, device=gpu), expected)
+    sw = szs.SmithWatermanScores(*matrices.nuc44(), open=-4, extend=-1, capabilities=gpu)
+    expected_sw = oracle.smith_waterman(strings, strings, *matrices.nuc44(), -4, -1)
+    for _ in range(2):
+        assert np.array_equal(sw(szs.Strs(strings), device=gpu), expected_sw)
+
+    # strided results in device memory, padding untouched
+    out = torch.full((70, 96), -7, dtype=torch.int64, device="cuda")
+    view = out[:, :70]
+    engine(szs.Strs(strings), szs.Strs(strings), device=gpu, out=view)
+    assert np.array_equal(view.cpu().numpy().view(np.uint64), expected) and bool((out[:, 70:] == -7).all())
+
+    # a tape whose offsets start inside the buffer: sub-tape of a larger one
+    whole = szs.Strs(strings)
+    whole.to_device(0)
+    _, data, offsets = whole._device
+    sub = _abi.U32Tape(data.data_ptr(), offsets.data_ptr() + 4 * 10, 50)  # strings 10 .. 59
+    results = torch.empty((50, 50), dtype=torch.int64, device="cuda")
+    error = ctypes.c_char_p()
+    for _ in range(2):
+        status = _abi.lib.szs_levenshtein_distances_u32tape(engine.handle, gpu.handle, ctypes.byref(sub), ctypes.byref(sub),
+                                                            results.data_ptr(), 50, ctypes.byref(error))
+        assert status == 0, error.value
+        assert np.array_equal(results.cpu().numpy().view(np.uint64), expected[10:60, 10:60])
+
+    # 1 x N and N x 1
+    one = [strings[5]]
+    assert np.array_equal(engine(one, strings, device=gpu), expected[5:6])
+    assert np.array_equal(engine(strings, one, device=gpu), expected[:, 5:6])
+
+
+def test_device_planner_reports_malformed_tapes(gpu):
+    import torch
+
+    data = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    offsets = torch.tensor([0, 10, 5, 20], dtype=torch.int32, device="cuda")  # descends
+    tape = _abi.U32Tape(data.data_ptr(), offsets.data_ptr(), 3)
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+    results = torch.zeros((3, 3), dtype=torch.int64, device="cuda")
+    error = ctypes.c_char_p()
+    for _ in range(2):
+        status = _abi.lib.szs_levenshtein_distances_u32tape(engine.handle, gpu.handle, ctypes.byref(tape), ctypes.byref(tape),
+                                                            results.data_ptr(), 3, ctypes.byref(error))
+        assert status == -15 and b"ascend" in error.value
+    good = torch.tensor([0, 10, 15, 20], dtype=torch.int32, device="cuda")
+    tape = _abi.U32Tape(data.data_ptr(), good.data_ptr(), 3)
+    status = _abi.lib.szs_levenshtein_distances_u32tape(engine.handle, gpu.handle, ctypes.byref(tape), ctypes.byref(tape),
+                                                        results.data_ptr(), 3, ctypes.byref(error))
+    assert status == 0  # the engine is still usable
+    assert results.cpu().numpy().tolist() == [[0, 5, 5], [5, 0, 0], [5, 0, 0]]
+
+
+def test_strings_beyond_the_device_planner_fall_back_to_the_host_planner(gpu, oracle):
+    rng = random.Random(9)
+    queries = _strings(rng, 3, 13000, 14000)  # longer than the planner's histogram
+    candidates = _strings(rng, 5, 100, 2000)
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+    for _ in range(2):
+        assert np.array_equal(engine(queries, candidates, device=gpu), oracle.levenshtein(queries, candidates))
+        assert engine.last_call_profile().planner == 0
+
+
+@pytest.mark.parametrize("planner", ["host", "device"])
+def test_wide_cells_agree_with_the_oracle(gpu, oracle, planner):
+    """The 64-bit tier forced onto small inputs: every family, empties, symmetric, both planners."""
+    rng = random.Random(21)
+    queries = _strings(rng, 9, 0, 90, b"ARNDCQEGHILKMFPSTWYV") + [b""]
+    candidates = _strings(rng, 13, 0, 120, b"ARNDCQEGHILKMFPSTWYV") + [b""]
+    with knob("cells", "64"), knob("planner", planner):
+        for name, engine, expected_of in _engines(gpu):
+            got = engine(queries, candidates, device=gpu).view(np.int64)
+            assert engine.last_call_profile().cell_bits == 64, name
+            assert np.array_equal(got, expected_of(oracle, queries, candidates).view(np.int64)), name
+            symmetric = engine(queries, device=gpu).view(np.int64)
+            assert np.array_equal(symmetric, expected_of(oracle, queries, queries).view(np.int64)), name
+        utf8 = szs.LevenshteinDistancesUTF8(1, 2, 3, 3, capabilities=gpu)
+        words = ["naïve", "façade", "日本語のテキスト", "😀 smile", "", "plain ascii"]
+        got = utf8(words, device=gpu)
+        assert utf8.last_call_profile().cell_bits == 64
+        assert np.array_equal(got, oracle.levenshtein_utf8([w.encode() for w in words], [w.encode() for w in words], 1, 2, 3, 3))
+
+
+def test_wide_cells_with_the_largest_costs(gpu):
+    """Costs of magnitude 127 through the 64-bit tier, checked against closed forms: a string against itself scores
+    127 n, against the empty string gap x n.  (A pair that really overflows 32 bits needs ~17 M symbols per side - 10^14
+    cells - so the tier is exercised through the `cells` knob; the host selects it by the reach rule, serial.hpp:135-162.)"""
+    byte_to_class = np.zeros(256, np.uint8)
+    costs = np.full((32, 32), -127, np.int8)
+    np.fill_diagonal(costs, 127)
+    engine = szs.NeedlemanWunschScores(byte_to_class, costs, open=-127, extend=-127, capabilities=gpu)
+    text = np.zeros(4096, np.uint8).tobytes()
+    with knob("cells", "64"):
+        got = engine([text, b""], [text, b""], device=gpu)
+    assert engine.last_call_profile().cell_bits == 64
+    assert got.tolist() == [[127 * 4096, -127 * 4096], [-127 * 4096, 0]]
+
+
+def test_failing_calls_leave_the_engine_usable(gpu, oracle):
+    """A call that fails after work was enqueued returns with the stream drained (no kernel still writing `results`), and
+    the next call on the same engine succeeds."""
+    import torch
+
+    strings = [b"kitten", b"sitting", b"saturday", b"sunday"]
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+    tape = szs.Strs(strings)
+    tape.to_device(0)
+    q_tape = tape._tape(0)
+    results = torch.zeros((4, 4), dtype=torch.int64, device="cuda")
+    error = ctypes.c_char_p()
+    # stride smaller than the candidate count: refused before anything is enqueued
+    status = _abi.lib.szs_levenshtein_distances_u32tape(engine.handle, gpu.handle, ctypes.byref(q_tape), ctypes.byref(q_tape),
+                                                        results.data_ptr(), 2, ctypes.byref(error))
+    assert status == -15
+    assert np.array_equal(engine(strings, strings, device=gpu), oracle.levenshtein(strings, strings))

@@ -24,7 +24,9 @@ def test_library_exports_every_declared_symbol():
     assert len(declared) == 41, declared  # the reference's 41 (stringzillas.h:36-613)
     assert sorted(declared) == sorted(_abi.REFERENCE_SYMBOLS)
     extra = _declared_symbols("stringzillas_rocm.h")
-    assert sorted(extra) == ["szs_rocm_last_call_profile", "szs_rocm_orientation_probe", "szs_rocm_plan_probe", "szs_rocm_shard_rows"]
+    assert sorted(extra) == sorted(name for name in _abi.SIGNATURES if name.startswith("szs_rocm_"))  # additive, all bound
+    assert {"szs_rocm_last_call_profile", "szs_rocm_orientation_probe", "szs_rocm_plan_probe", "szs_rocm_shard_rows",
+            "szs_rocm_tuning_set"} <= set(extra)
     for name in declared + extra:
         assert hasattr(_abi.lib, name), name
 
@@ -40,7 +42,7 @@ def test_version_and_capabilities_without_gpu():
 
 def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(_abi.U32Tape) == 24 and ctypes.sizeof(_abi.U64Tape) == 24 and ctypes.sizeof(_abi.Sequence) == 32
-    assert ctypes.sizeof(_abi.CallProfile) == 72
+    assert ctypes.sizeof(_abi.CallProfile) == 80
 
 
 def test_engines_refuse_cpu_capabilities_loudly():
