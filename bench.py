@@ -204,18 +204,23 @@ def roofline(config, profile, kernel_seconds, traffic_override=None):
               "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic_override, "kernel_ms": round(kernel_seconds * 1e3, 4),
               "algorithmic_bytes": int(profile.algorithmic_bytes), "launches_per_step": int(profile.launches),
               "kernel_gcups": round(profile.cells / kernel_seconds / 1e9, 1)}
-    summary, where = _profile_json("pmc_summary.json" if config == 2 else "pmc_configs.json")
+    summary, where = _profile_json("pmc_configs.json")  # "cfgN:kernel" -> counters (scripts/pmc_configs.py)
     wanted = DOMINANT_KERNEL.get(config, "")
     counters = None
     for name, entry in (summary or {}).items():
-        if wanted and name.startswith(wanted) and (counters is None or entry.get("_share", 0) > counters.get("_share", 0)):
-            counters, record["kernel"] = entry, name
+        kernel = name.split(":", 1)[-1]
+        if entry.get("_config") == config and wanted and kernel.startswith(wanted) and (counters is None or entry.get("_share", 0) > counters.get("_share", 0)):
+            counters, record["kernel"] = entry, kernel
+    if counters is None and config == 2:  # round 1's summary of the headline kernel, until round 2's passes are committed
+        summary, where = _profile_json("pmc_summary.json")
+        for name, entry in (summary or {}).items():
+            if name.startswith(wanted):
+                counters, record["kernel"] = entry, name
     if counters is None:
         record["traffic_source"] = "no committed PMC pass for this config" if traffic_override is None else "from --hbm-traffic-bytes"
         return record
     if traffic_override is None and "hbm_fetch_bytes_raw" in counters and "hbm_write_bytes_raw" in counters:
-        scale = counters.get("_launches_per_call", 1.0)
-        record["traffic"] = (counters["hbm_fetch_bytes_raw"] + counters["hbm_write_bytes_raw"]) * scale
+        record["traffic"] = counters["hbm_fetch_bytes_raw"] + counters["hbm_write_bytes_raw"]
         record["traffic_source"] = (f"{where}: (FETCH_SIZE + WRITE_SIZE) x 1024 per launch of the dominant kernel, committed "
                                     f"rocprofv3 --pmc passes of this command (raw; wide-stream reads may count double)")
     if "SQ_INSTS_VALU" in counters:
@@ -225,8 +230,8 @@ def roofline(config, profile, kernel_seconds, traffic_override=None):
         record["valu"] = {
             "bound": "integer VALU issue (PMC)", "source": where,
             "wave_instructions_per_launch": counters["SQ_INSTS_VALU"],
-            "lane_ops_per_cell": round(lane_ops * counters.get("_launches_per_call", 1.0) / max(float(profile.cells), 1.0), 4)
-            if counters.get("_cells_match", True) else None,
+            "share_of_the_configs_kernel_time": round(counters["_share"], 4) if "_share" in counters else None,
+            "lane_ops_per_cell": round(lane_ops / max(float(profile.cells), 1.0), 4) if int(profile.launches) == 1 else None,
             "achieved_Tlane_ops_per_s": round(lane_ops / duration / 1e12, 2),
             "peak_Tlane_ops_per_s": VALU_LANE_OPS_PEAK / 1e12,
             "frac": round(lane_ops / duration / VALU_LANE_OPS_PEAK, 4),

@@ -69,6 +69,68 @@ SZ_API_RUNTIME sz_status_t szs_rocm_orientation_probe(int unit_cost, int affine,
                                                       sz_u32_t const *candidate_lengths, sz_size_t candidates_count,
                                                       int *tier, int *transposed);
 
+/* ---- one cross-product over the N GPUs of a host (csrc/host/node.c) ------------------------------
+ *
+ *  The reference's C-ABI is one device per call (stringzillas.h:137) and has no multi-GPU path; what its threading rules
+ *  allow - N scopes and N engines on N host threads - is packaged here: query ROWS are dealt to the GPUs by LPT on their
+ *  lengths, both tapes are replicated to every GPU once per call (peer-to-peer over xGMI when they live on a GPU), one host
+ *  thread per GPU runs the ordinary single-GPU engine on `its rows x all candidates`, and every result row is copied to its
+ *  place in the caller's matrix.  Scores are bit-identical to the single-GPU engines': they ARE the single-GPU engines.
+ */
+#define SZS_ROCM_NODE_MOST_GPUS 16
+
+typedef void *szs_rocm_node_t;        /* a set of GPUs of this host */
+typedef void *szs_rocm_node_engine_t; /* one cost model, instantiated on every GPU of a node */
+
+typedef struct szs_rocm_node_stats_t {
+    sz_size_t gpus;
+    double wall_milliseconds;                             /* the whole call */
+    double busy_milliseconds[SZS_ROCM_NODE_MOST_GPUS];    /* per GPU: replication + scoring + placing its rows */
+    double kernel_milliseconds[SZS_ROCM_NODE_MOST_GPUS];  /* per GPU: the scoring kernels alone (hipEvent pair) */
+    sz_u64_t cells[SZS_ROCM_NODE_MOST_GPUS];              /* per GPU: DP cells scored */
+    sz_u64_t row_weights[SZS_ROCM_NODE_MOST_GPUS];        /* per GPU: sum of (len(query) + 1) over its rows - what LPT balances */
+    sz_u32_t rows[SZS_ROCM_NODE_MOST_GPUS];               /* per GPU: query rows dealt to it */
+} szs_rocm_node_stats_t;
+
+/** `gpu_devices` NULL or `count` 0: every visible GPU.  `*node` receives the handle. */
+SZ_API_RUNTIME sz_status_t szs_rocm_node_init(sz_size_t const *gpu_devices, sz_size_t count, szs_rocm_node_t *node,
+                                              char const **error_message);
+SZ_API_RUNTIME sz_size_t szs_rocm_node_size(szs_rocm_node_t node);
+SZ_API_RUNTIME void szs_rocm_node_free(szs_rocm_node_t node);
+
+/** Engines of a node: same arguments and meaning as `szs_*_init` (stringzillas.h), `*engine` must be NULL on entry. */
+SZ_API_RUNTIME sz_status_t szs_rocm_node_levenshtein_distances_init(szs_rocm_node_t node, sz_error_cost_t match,
+                                                                    sz_error_cost_t mismatch, sz_error_cost_t open,
+                                                                    sz_error_cost_t extend, szs_rocm_node_engine_t *engine,
+                                                                    char const **error_message);
+SZ_API_RUNTIME sz_status_t szs_rocm_node_levenshtein_distances_utf8_init(szs_rocm_node_t node, sz_error_cost_t match,
+                                                                         sz_error_cost_t mismatch, sz_error_cost_t open,
+                                                                         sz_error_cost_t extend, szs_rocm_node_engine_t *engine,
+                                                                         char const **error_message);
+SZ_API_RUNTIME sz_status_t szs_rocm_node_needleman_wunsch_scores_init(szs_rocm_node_t node, sz_u8_t const *byte_to_class,
+                                                                      sz_error_cost_t const *class_substitution_costs,
+                                                                      sz_error_cost_t open, sz_error_cost_t extend,
+                                                                      szs_rocm_node_engine_t *engine, char const **error_message);
+SZ_API_RUNTIME sz_status_t szs_rocm_node_smith_waterman_scores_init(szs_rocm_node_t node, sz_u8_t const *byte_to_class,
+                                                                    sz_error_cost_t const *class_substitution_costs,
+                                                                    sz_error_cost_t open, sz_error_cost_t extend,
+                                                                    szs_rocm_node_engine_t *engine, char const **error_message);
+SZ_API_RUNTIME void szs_rocm_node_engine_free(szs_rocm_node_engine_t engine);
+
+/**
+ *  Scores all `queries x candidates` (`candidates` NULL: queries against themselves) into `results[q * stride + c]`, 8-byte
+ *  cells (`sz_size_t` distances / `sz_ssize_t` scores).  Tapes may live in host, pinned, unified or any GPU's memory;
+ *  so may `results`.  Synchronous.  `stats` (optional) receives the per-GPU timing the multi-GPU configs ask to report.
+ */
+SZ_API_RUNTIME sz_status_t szs_rocm_node_scores_u32tape(szs_rocm_node_engine_t engine, sz_sequence_u32tape_t const *queries,
+                                                        sz_sequence_u32tape_t const *candidates, void *results,
+                                                        sz_size_t results_row_stride, szs_rocm_node_stats_t *stats,
+                                                        char const **error_message);
+SZ_API_RUNTIME sz_status_t szs_rocm_node_scores_u64tape(szs_rocm_node_engine_t engine, sz_sequence_u64tape_t const *queries,
+                                                        sz_sequence_u64tape_t const *candidates, void *results,
+                                                        sz_size_t results_row_stride, szs_rocm_node_stats_t *stats,
+                                                        char const **error_message);
+
 /**
  *  Tuning / testing knobs (csrc/host/tuning.c).  The library reads the `SZS_ROCM_*` environment variables ONCE, when it
  *  is loaded; afterwards a knob changes only through this call.  `knob` is one of "tier" (lanes | systolic | chain),

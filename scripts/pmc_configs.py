@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""pmc_configs.py DIR - folds the per-config rocprofv3 runs of scripts/profile_configs.sh (DIR/cfgN/{stats,pmc_*}) into one
+JSON keyed "cfgN:kernel": per-dispatch averages of every counter, the kernel's average duration and share of its config's
+kernel time (from the --stats run, NOT from the slower counter runs), and the derived figures bench.py reports:
+
+    hbm_fetch_bytes_raw / hbm_write_bytes_raw   FETCH_SIZE / WRITE_SIZE are in KILOBYTES (MI355X_MICROARCH.md, HBM section);
+                                                gfx950 counts wide coalesced streaming reads at half their size - raw values
+                                                are kept and labelled as such
+    valu_lane_ops_per_second                    SQ_INSTS_VALU x 64 / duration
+    valu_busy_fraction                          SQ_ACTIVE_INST_VALU x 4 / (SQ_BUSY_CYCLES x SIMDs) when both were collected
+    lds_conflict_fraction                       SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+root = sys.argv[1]
+summary = {}
+
+
+def short_name(name):
+    return name.split("(")[0].replace("void ", "").replace("szs_hip::", "").strip()
+
+
+for directory in sorted(glob.glob(os.path.join(root, "cfg*"))):
+    config = int(re.sub(r"\D", "", os.path.basename(directory)))
+    durations, total = {}, 0.0
+    for path in glob.glob(os.path.join(directory, "stats", "**", "*kernel_stats.csv"), recursive=True):
+        with open(path, newline="") as handle:
+            for row in csv.DictReader(handle):
+                if "szs_hip" not in row["Name"]:
+                    continue
+                name = short_name(row["Name"])
+                durations[name] = {"_duration_seconds": float(row["AverageNs"]) * 1e-9, "_calls": int(row["Calls"]),
+                                   "_total_seconds": float(row["TotalDurationNs"]) * 1e-9}
+                total += float(row["TotalDurationNs"]) * 1e-9
+    per_kernel = defaultdict(lambda: defaultdict(list))
+    for path in glob.glob(os.path.join(directory, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+        with open(path, newline="") as handle:
+            for row in csv.DictReader(handle):
+                name = row.get("Kernel_Name", "")
+                if "szs_hip" not in name:
+                    continue
+                short = short_name(name)
+                per_kernel[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
+                per_kernel[short]["_vgpr"] = [float(row.get("VGPR_Count", 0) or 0)]
+                per_kernel[short]["_lds"] = [float(row.get("LDS_Block_Size", 0) or 0)]
+                per_kernel[short]["_grid"].append(float(row.get("Grid_Size", 0) or 0))
+    for kernel in sorted(set(durations) | set(per_kernel)):
+        counters = per_kernel.get(kernel, {})
+        entry = {name: sum(values) / len(values) for name, values in counters.items()}
+        entry["_config"] = config
+        entry.update(durations.get(kernel, {}))
+        entry["_share"] = entry.get("_total_seconds", 0.0) / total if total else 0.0
+        if counters:
+            entry["dispatches_sampled"] = max(len(v) for v in counters.values())
+        if "FETCH_SIZE" in entry:
+            entry["hbm_fetch_bytes_raw"] = entry["FETCH_SIZE"] * 1024
+        if "WRITE_SIZE" in entry:
+            entry["hbm_write_bytes_raw"] = entry["WRITE_SIZE"] * 1024
+        if "SQ_INSTS_VALU" in entry and entry.get("_duration_seconds"):
+            entry["valu_lane_ops_per_second"] = entry["SQ_INSTS_VALU"] * 64 / entry["_duration_seconds"]
+        if entry.get("SQ_LDS_IDX_ACTIVE"):
+            entry["lds_conflict_fraction"] = entry.get("SQ_LDS_BANK_CONFLICT", 0.0) / entry["SQ_LDS_IDX_ACTIVE"]
+        if entry.get("SQ_BUSY_CYCLES") and "SQ_ACTIVE_INST_VALU" in entry:
+            # SQ_ACTIVE_INST_VALU counts quad-cycles summed over SIMDs; SQ_BUSY_CYCLES is summed over shader engines
+            entry["valu_active_over_busy"] = entry["SQ_ACTIVE_INST_VALU"] / entry["SQ_BUSY_CYCLES"]
+        summary[f"cfg{config}:{kernel}"] = entry
+print(json.dumps(summary, indent=1))

@@ -25,7 +25,8 @@ from ._abi import CallProfile, StringZillasError, lib
 
 __all__ = [
     "DeviceScope", "Strs", "LevenshteinDistances", "LevenshteinDistancesUTF8", "NeedlemanWunschScores",
-    "SmithWatermanScores", "Fingerprints", "StringZillasError", "to_device", "__capabilities__", "__version__",
+    "SmithWatermanScores", "Fingerprints", "StringZillasError", "to_device", "Node", "NodeEngine", "__capabilities__",
+    "__version__",
 ]
 
 __version__ = f"{lib.szs_version_major()}.{lib.szs_version_minor()}.{lib.szs_version_patch()}"
@@ -411,4 +412,123 @@ class Fingerprints:
         handle = getattr(self, "handle", None)
         if handle and lib is not None:
             lib.szs_fingerprints_free(handle)
+            self.handle = None
+
+
+class NodeEngine:
+    """One cost model on every GPU of a `Node`; `engine(queries, candidates=None, out=None)` scores the whole cross-product
+    with its query rows dealt over the GPUs (`szs_rocm_node_scores_*`, csrc/host/node.c) and returns the per-GPU statistics
+    of the call as a dict (the matrix lands in `out`, or is returned when `out` is None)."""
+
+    def __init__(self, node: "Node", kind: str, *arguments):
+        self.node = node
+        self.handle = ctypes.c_void_p()
+        error = ctypes.c_char_p()
+        init = getattr(lib, f"szs_rocm_node_{kind}_init")
+        if kind in ("needleman_wunsch_scores", "smith_waterman_scores"):
+            byte_to_class = np.ascontiguousarray(arguments[0], dtype=np.uint8)
+            costs = np.ascontiguousarray(arguments[1], dtype=np.int8)
+            if byte_to_class.size != 256 or costs.size != 32 * 32:
+                raise ValueError("byte_to_class must hold 256 bytes and class_substitution_costs 32x32 int8 values")
+            status = init(node.handle, byte_to_class.ctypes.data, costs.ctypes.data, arguments[2], arguments[3],
+                          ctypes.byref(self.handle), ctypes.byref(error))
+        else:
+            status = init(node.handle, *arguments, ctypes.byref(self.handle), ctypes.byref(error))
+        _abi.check(status, error)
+        self._signed = kind in ("needleman_wunsch_scores", "smith_waterman_scores")
+        self.last_stats: Optional[dict] = None
+
+    def __call__(self, queries, candidates=None, out=None):
+        import torch
+
+        queries = _as_strs(queries)
+        candidates = None if candidates is None else _as_strs(candidates)
+        if candidates is not None and queries.wide_offsets != candidates.wide_offsets:
+            queries = Strs.from_tape(queries.data, queries.offsets.astype(np.uint64))
+            candidates = Strs.from_tape(candidates.data, candidates.offsets.astype(np.uint64))
+        rows, columns = len(queries), len(queries if candidates is None else candidates)
+
+        def tape_of(strs):  # where the bytes already are: a GPU if they were moved there, else host memory
+            if strs._device is not None and strs._device[0] != "cpu":
+                return strs._tape(strs._device[0])
+            tape_type = _abi.U64Tape if strs.wide_offsets else _abi.U32Tape
+            return tape_type(strs.data.ctypes.data, strs.offsets.ctypes.data, strs.count)
+
+        q_tape = tape_of(queries)
+        c_tape = None if candidates is None else tape_of(candidates)
+        if out is None:
+            results = np.zeros((rows, max(columns, 1)), dtype=np.int64)[:, :columns]
+            pointer, stride = results.ctypes.data, max(columns, 1)
+        elif isinstance(out, np.ndarray):
+            if out.shape != (rows, columns) or out.dtype.itemsize != 8 or (columns and out.strides[1] != 8):
+                raise ValueError("`out` must be a (rows, columns) matrix of 8-byte cells with contiguous rows")
+            results, pointer, stride = out, out.ctypes.data, out.strides[0] // 8
+        else:
+            if tuple(out.shape) != (rows, columns) or out.element_size() != 8 or (columns and out.stride(1) != 1):
+                raise ValueError("`out` must be a (rows, columns) matrix of 8-byte cells with contiguous rows")
+            results, pointer, stride = out, out.data_ptr(), out.stride(0) if rows > 1 else max(columns, 1)
+        stats, error = _abi.NodeStats(), ctypes.c_char_p()
+        call = lib.szs_rocm_node_scores_u64tape if queries.wide_offsets else lib.szs_rocm_node_scores_u32tape
+        status = call(self.handle, ctypes.byref(q_tape), None if c_tape is None else ctypes.byref(c_tape), pointer, stride,
+                      ctypes.byref(stats), ctypes.byref(error))
+        _abi.check(status, error)
+        gpus = int(stats.gpus)
+        self.last_stats = {
+            "gpus": gpus, "wall_ms": float(stats.wall_milliseconds), "busy_ms": [float(stats.busy_milliseconds[i]) for i in range(gpus)],
+            "kernel_ms": [float(stats.kernel_milliseconds[i]) for i in range(gpus)], "cells": [int(stats.cells[i]) for i in range(gpus)],
+            "rows": [int(stats.rows[i]) for i in range(gpus)], "row_weights": [int(stats.row_weights[i]) for i in range(gpus)],
+        }
+        if out is None:
+            return results.view(np.int64 if self._signed else np.uint64)
+        return self.last_stats
+
+    def __del__(self):
+        handle = getattr(self, "handle", None)
+        if handle and lib is not None:
+            lib.szs_rocm_node_engine_free(handle)
+            self.handle = None
+
+
+class Node:
+    """`Node(gpu_devices=None)` - a set of GPUs of this host driven from ONE process, one host thread per GPU inside the
+    library (`szs_rocm_node_*`).  The multi-process flavour over `torch.distributed` is `stringzilla_amd.sharded`."""
+
+    def __init__(self, gpu_devices: Optional[Sequence[int]] = None):
+        self.handle = ctypes.c_void_p()
+        error = ctypes.c_char_p()
+        devices = None if gpu_devices is None else np.ascontiguousarray(list(gpu_devices), dtype=np.uint64)
+        status = lib.szs_rocm_node_init(None if devices is None else devices.ctypes.data, 0 if devices is None else len(devices),
+                                        ctypes.byref(self.handle), ctypes.byref(error))
+        _abi.check(status, error)
+
+    def __len__(self) -> int:
+        return int(lib.szs_rocm_node_size(self.handle))
+
+    def levenshtein_distances(self, match=0, mismatch=1, open=1, extend=1) -> NodeEngine:
+        return NodeEngine(self, "levenshtein_distances", match, mismatch, open, extend)
+
+    def levenshtein_distances_utf8(self, match=0, mismatch=1, open=1, extend=1) -> NodeEngine:
+        return NodeEngine(self, "levenshtein_distances_utf8", match, mismatch, open, extend)
+
+    def needleman_wunsch_scores(self, byte_to_class, class_substitution_costs, open=-1, extend=-1) -> NodeEngine:
+        return NodeEngine(self, "needleman_wunsch_scores", byte_to_class, class_substitution_costs, open, extend)
+
+    def smith_waterman_scores(self, byte_to_class, class_substitution_costs, open=-1, extend=-1) -> NodeEngine:
+        return NodeEngine(self, "smith_waterman_scores", byte_to_class, class_substitution_costs, open, extend)
+
+    def engine_for(self, load) -> NodeEngine:
+        """The engine a `workloads.Workload` names."""
+        from . import matrices
+
+        if load.kind == "levenshtein":
+            return self.levenshtein_distances(**load.costs)
+        if load.kind == "levenshtein_utf8":
+            return self.levenshtein_distances_utf8(**load.costs)
+        make = self.needleman_wunsch_scores if load.kind == "needleman_wunsch" else self.smith_waterman_scores
+        return make(*matrices.by_name(load.table), **load.costs)
+
+    def __del__(self):
+        handle = getattr(self, "handle", None)
+        if handle and lib is not None:
+            lib.szs_rocm_node_free(handle)
             self.handle = None

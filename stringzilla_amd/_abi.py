@@ -58,6 +58,18 @@ class CallProfile(ctypes.Structure):
     ]
 
 
+NODE_MOST_GPUS = 16
+
+
+class NodeStats(ctypes.Structure):
+    _fields_ = [
+        ("gpus", c_size_t), ("wall_milliseconds", ctypes.c_double),
+        ("busy_milliseconds", ctypes.c_double * NODE_MOST_GPUS), ("kernel_milliseconds", ctypes.c_double * NODE_MOST_GPUS),
+        ("cells", ctypes.c_uint64 * NODE_MOST_GPUS), ("row_weights", ctypes.c_uint64 * NODE_MOST_GPUS),
+        ("rows", ctypes.c_uint32 * NODE_MOST_GPUS),
+    ]
+
+
 ERR = ctypes.POINTER(c_char_p)
 ENGINE_OUT = ctypes.POINTER(c_void_p)
 
@@ -100,6 +112,15 @@ SIGNATURES = {
     "szs_rocm_plan_probe": (c_int, [c_int, c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "szs_rocm_orientation_probe": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p]),
     "szs_rocm_tuning_set": (c_int, [c_char_p, c_char_p]),
+    "szs_rocm_node_init": (c_int, [c_void_p, c_size_t, ENGINE_OUT, ERR]),
+    "szs_rocm_node_size": (c_size_t, [c_void_p]), "szs_rocm_node_free": (None, [c_void_p]),
+    "szs_rocm_node_levenshtein_distances_init": (c_int, [c_void_p, c_int8, c_int8, c_int8, c_int8, ENGINE_OUT, ERR]),
+    "szs_rocm_node_levenshtein_distances_utf8_init": (c_int, [c_void_p, c_int8, c_int8, c_int8, c_int8, ENGINE_OUT, ERR]),
+    "szs_rocm_node_needleman_wunsch_scores_init": (c_int, [c_void_p, c_void_p, c_void_p, c_int8, c_int8, ENGINE_OUT, ERR]),
+    "szs_rocm_node_smith_waterman_scores_init": (c_int, [c_void_p, c_void_p, c_void_p, c_int8, c_int8, ENGINE_OUT, ERR]),
+    "szs_rocm_node_engine_free": (None, [c_void_p]),
+    "szs_rocm_node_scores_u32tape": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, ctypes.POINTER(NodeStats), ERR]),
+    "szs_rocm_node_scores_u64tape": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, ctypes.POINTER(NodeStats), ERR]),
 }
 
 REFERENCE_SYMBOLS = [name for name in SIGNATURES if not name.startswith("szs_rocm_")]  # the reference's 41
@@ -133,13 +154,21 @@ class StringZillasError(RuntimeError):
         super().__init__(f"sz_status_t {self.status_name} ({status}): {message or 'no message'}")
 
 
-def tuning_set(knob: str, value=None) -> None:
+_KNOBS = {"tier": "SZS_ROCM_TIER", "swap": "SZS_ROCM_SWAP", "packed": "SZS_ROCM_PACKED", "rune_ids": "SZS_ROCM_RUNE_IDS",
+          "chain_waves": "SZS_ROCM_CHAIN_WAVES", "trace": "SZS_ROCM_TRACE", "cells": "SZS_ROCM_CELLS",
+          "planner": "SZS_ROCM_PLANNER", "speculate": "SZS_ROCM_SPECULATE"}
+_knob_values = {name: os.environ.get(variable) for name, variable in _KNOBS.items()}  # what the library read when it was loaded
+
+
+def tuning_set(knob: str, value=None):
     """`szs_rocm_tuning_set`: pins one of the library's tuning / testing knobs ("tier", "swap", "packed", "rune_ids",
     "chain_waves", "trace", "cells", "planner", "speculate" or the `SZS_ROCM_*` spelling); None restores the automatic
-    choice.  The environment is only read once, when the library is loaded."""
-    status = lib.szs_rocm_tuning_set(knob.encode(), None if value is None else str(value).encode())
-    if status != 0:
+    choice.  The environment is only read once, when the library is loaded.  Returns the previous setting."""
+    name = next((short for short, variable in _KNOBS.items() if knob in (short, variable)), None)
+    if name is None or lib.szs_rocm_tuning_set(name.encode(), None if value is None else str(value).encode()) != 0:
         raise ValueError(f"unknown tuning knob {knob!r}")
+    previous, _knob_values[name] = _knob_values[name], None if value is None else str(value)
+    return previous
 
 
 def check(status: int, error: c_char_p) -> None:

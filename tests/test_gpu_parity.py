@@ -35,11 +35,11 @@ def forced_env(name, value):
     environment itself is only read when the library is loaded), then restores the automatic choice."""
     from stringzilla_amd import _abi
 
-    _abi.tuning_set(name, value)
+    previous = _abi.tuning_set(name, value)
     try:
         yield
     finally:
-        _abi.tuning_set(name, None)
+        _abi.tuning_set(name, previous)  # nested blocks restore the outer setting, not "automatic"
 
 
 def forced_tier(name):

@@ -29,11 +29,11 @@ def gpu():
 
 @contextlib.contextmanager
 def knob(name, value):
-    _abi.tuning_set(name, value)
+    previous = _abi.tuning_set(name, value)
     try:
         yield
     finally:
-        _abi.tuning_set(name, None)
+        _abi.tuning_set(name, previous)  # nested blocks restore the outer setting, not "automatic"
 
 
 def _strings(rng, count, low, high, alphabet=b"ACGT"):
@@ -233,3 +233,60 @@ def test_failing_calls_leave_the_engine_usable(gpu, oracle):
                                                         results.data_ptr(), 2, ctypes.byref(error))
     assert status == -15
     assert np.array_equal(engine(strings, strings, device=gpu), oracle.levenshtein(strings, strings))
+
+
+# ---- the multi-GPU C entry (csrc/host/node.c) on whatever GPUs this box has ---------------------------------------------
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
+def test_node_engines_match_the_oracle(oracle, devices):
+    """`szs_rocm_node_*`: rows dealt over the node's GPUs (the same GPU named several times exercises the threads, the
+    replicas and the row placement on a one-GPU box), every family, tapes in host and in device memory, results into host
+    NumPy, device tensors and padded matrices."""
+    import torch
+
+    rng = random.Random(77)
+    queries = _strings(rng, 41, 0, 260) + [b""]
+    candidates = _strings(rng, 67, 0, 300) + [b""]
+    node = szs.Node(devices)
+    assert len(node) == len(devices)
+    nuc = matrices.nuc44()
+    cases = [
+        (node.levenshtein_distances(), oracle.levenshtein(queries, candidates)),
+        (node.levenshtein_distances(1, 3, 4, 2), oracle.levenshtein(queries, candidates, 1, 3, 4, 2)),
+        (node.needleman_wunsch_scores(*nuc, open=-4, extend=-1), oracle.needleman_wunsch(queries, candidates, *nuc, -4, -1)),
+        (node.smith_waterman_scores(*nuc, open=-3, extend=-3), oracle.smith_waterman(queries, candidates, *nuc, -3, -3)),
+    ]
+    for engine, expected in cases:
+        expected = expected.view(np.int64)
+        assert np.array_equal(engine(queries, candidates).view(np.int64), expected)        # host tapes, host matrix
+        stats = engine.last_stats
+        assert stats["gpus"] == len(devices) and sum(stats["rows"]) == len(queries)
+        assert max(stats["row_weights"]) <= 1.25 * (sum(stats["row_weights"]) / len(devices)) + 300  # LPT balance
+        q, c = szs.Strs(queries).to_device(0), szs.Strs(candidates).to_device(0)
+        out = torch.full((len(queries), len(candidates) + 5), -9, dtype=torch.int64, device="cuda")
+        engine(q, c, out=out[:, :len(candidates)])                                         # device tapes, padded device matrix
+        assert np.array_equal(out[:, :len(candidates)].cpu().numpy(), expected) and bool((out[:, len(candidates):] == -9).all())
+        assert np.array_equal(engine(q, c).view(np.int64), expected)                       # again: replicas and blocks reused
+    symmetric = node.levenshtein_distances()(queries)                                      # candidates omitted: the full square
+    assert np.array_equal(symmetric, oracle.levenshtein(queries, queries))
+    utf8 = node.levenshtein_distances_utf8()
+    words = [w.encode() for w in ["naïve", "façade", "日本語", "😀 smile", "", "plain", "naive", "facade"]]
+    assert np.array_equal(utf8(words, words), oracle.levenshtein_utf8(words, words))
+
+
+def test_node_probe_from_plain_c():
+    """The same entry driven from C without Python or torch in the process (tests/native/node_probe.c)."""
+    import json
+    import os
+    import subprocess
+
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "native", "bin", "node_probe")
+    if not os.path.exists(probe):
+        pytest.skip("tests/native/bin/node_probe is not built")
+    for family, arguments in [("lev", ["90", "130", "0", "400"]), ("nw", ["40", "70", "0", "200"]), ("sw", ["33", "300", "5", "150"])]:
+        for gpus in (["0"], ["0", "0"]):
+            done = subprocess.run([probe, family, *arguments, *gpus], capture_output=True, text=True, timeout=300)
+            assert done.returncode == 0, (family, gpus, done.stdout, done.stderr)
+            report = json.loads(done.stdout.strip().splitlines()[-1])
+            assert report["mismatches"] == 0 and report["gpus"] == len(gpus)
