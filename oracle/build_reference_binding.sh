@@ -42,4 +42,11 @@ compile szs python/stringzillas/stringzillas.c python/stringzillas/device_scope.
 gcc -shared -fPIC "$OUT"/obj/szs_*.o -o "$OUT/stringzillas$SUFFIX" -L"$ROOT/stringzilla_amd/lib" -lstringzillas_rocm_shared \
     -Wl,-rpath,'$ORIGIN/../../../stringzilla_amd/lib'
 rm -rf "$OUT/obj"
+# The reference's OWN Python test suite for this path (test/similarities.py and the two helper modules it imports) is
+# carried along the same way - into oracle/_ref/, which is git-ignored: reference-derived, never in this repository's
+# history, but it travels to the GPU box with the snapshot, where /root/reference does not exist.
+# tests/test_reference_suite.py runs it, unmodified, against the binding built above.
+SUITE=$HERE/_ref/reference_tests/test
+mkdir -p "$SUITE"
+for file in __init__.py similarities.py sz_helpers.py szs_helpers.py; do cp "$REFERENCE/test/$file" "$SUITE/$file"; done
 echo "built $OUT/stringzilla$SUFFIX and $OUT/stringzillas$SUFFIX against libstringzillas_rocm_shared.so"

@@ -91,6 +91,9 @@ enum {
     szs_knob_cells_k,       /* -1 automatic | 64: force the 64-bit cell tier */
     szs_knob_planner_k,     /* -1 automatic | 0 host | 1 device */
     szs_knob_speculate_k,   /* -1 automatic | 0: never enqueue scoring launches before the plan is known */
+    szs_knob_cpu_requests_k, /* -1 / 0 strict: engines need sz_cap_cuda_k, CPU scopes are a mismatch | 1 ("gpu"): capability
+                                masks without the GPU bit and CPU scopes are served by the GPU engines on device 0 */
+    szs_knob_streams_k,     /* -1 automatic | 0: every launch of a call on the scope's one stream */
     szs_knob_count_k
 };
 int szs_tuning_get(int knob);

@@ -259,6 +259,24 @@ __device__ __forceinline__ void myers_workgroup(u32 *peq, u32 *keys, szs_string_
                 for (int step = 0; step < 4 * text_dwords_; ++step) take((symbols[step / 4] >> (8 * (step % 4))) & 0xFFu);
             }
         }
+#ifndef SZS_MYERS_MID_LOOP
+#define SZS_MYERS_MID_LOOP 0
+#endif
+        // ---- between the two (build variant): whole dwords that every live lane still has, one at a time, unpredicated -
+        // the batch above leaves up to 4 * text_dwords_ - 1 columns to the per-column predicates of the tail otherwise.
+        if constexpr (SZS_MYERS_MID_LOOP && text_dwords_ > 1) {
+            if (column + 4 <= shortest_in_wave && longest_in_wave && query_length) {
+                u32 ahead_one = text.raw(dword + 1);
+#pragma unroll 1
+                for (; column + 4 <= shortest_in_wave; column += 4, ++dword) {
+                    u32 const symbols = text.splice(raw_low, ahead_one);
+                    raw_low = ahead_one;
+                    ahead_one = text.raw(dword + 2);
+#pragma unroll
+                    for (int step = 0; step < 4; ++step) take((symbols >> (8 * step)) & 0xFFu);
+                }
+            }
+        }
         // ---- ragged tail: one dword (4 columns) per iteration, each column predicated on this lane's own length.
         if (column < longest_in_wave) {
             u32 next = text.raw(dword + 1);

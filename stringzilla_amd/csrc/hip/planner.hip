@@ -67,62 +67,84 @@ __device__ __forceinline__ u32 block_exclusive_scan(u32 value, u32 *scratch, u32
     return scratch[wave] + inclusive - value;
 }
 
+/** Statistics of one side, reduced over the workgroup WITHOUT atomics: hipcc turns an LDS atomic on a wave-uniform address
+ *  into a scalar loop over the 64 lanes (7 SALU instructions per lane and atomic - fifteen of them made the planner a 40 us
+ *  kernel); a shuffle butterfly per value and one LDS slot per wavefront is ~300 instructions. */
+constexpr int plan_values_k = 5 + SZS_PLAN_VARIANTS; // longest (max), status (or), symbols, bands x 2, strings per variant (sums)
+
+__device__ __forceinline__ u64 shuffle_xor_u64(u64 value, int offset) {
+    u32 const low = (u32)__shfl_xor((int)(u32)value, offset, 64), high = (u32)__shfl_xor((int)(u32)(value >> 32), offset, 64);
+    return ((u64)high << 32) | low;
+}
+
 __global__ __launch_bounds__(plan_threads_k) void plan_kernel(szs_plan_side_t queries, szs_plan_side_t candidates,
                                                               int symmetric, u32 myers_words,
                                                               szs_plan_expectation_t expected,
                                                               szs_plan_summary_t *__restrict__ summary) {
     __shared__ u32 histogram[plan_bins_k];
     __shared__ u32 scan_scratch[plan_threads_k / 64 + 1];
-    __shared__ u32 shared_longest[2], shared_status, shared_variants[2][SZS_PLAN_VARIANTS];
-    __shared__ unsigned long long shared_symbols[2], shared_bands_systolic[2], shared_bands_chain[2], shared_cells;
+    __shared__ unsigned long long wave_values[2][plan_threads_k / 64][plan_values_k];
+    __shared__ unsigned long long side_values[2][plan_values_k];
+    __shared__ unsigned long long chunk_sums[plan_threads_k], shared_cells;
     __shared__ u32 shared_held;
 
-    u32 const tid = threadIdx.x;
-    if (tid < 2) shared_longest[tid] = 0, shared_symbols[tid] = 0, shared_bands_systolic[tid] = 0, shared_bands_chain[tid] = 0;
-    if (tid < 2 * SZS_PLAN_VARIANTS) shared_variants[tid / SZS_PLAN_VARIANTS][tid % SZS_PLAN_VARIANTS] = 0;
-    if (tid == 0) shared_status = 0, shared_cells = 0, shared_held = 0;
-    __syncthreads();
-
+    u32 const tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     int const sides = symmetric ? 1 : 2;
     // ---- pass 1: lengths and the statistics every decision is made from
     for (int s = 0; s < sides; ++s) {
         szs_plan_side_t const &side = s ? candidates : queries;
-        u32 longest = 0, status = 0, variants[SZS_PLAN_VARIANTS] = {0};
-        u64 symbols = 0, bands_systolic = 0, bands_chain = 0;
+        u64 values[plan_values_k];
+#pragma unroll
+        for (int k = 0; k < plan_values_k; ++k) values[k] = 0;
         for (u32 i = tid; i < side.count; i += plan_threads_k) {
             u64 const from = tape_offset(side.offsets, side.wide, i), to = tape_offset(side.offsets, side.wide, (u64)i + 1);
-            if (to < from) status |= SZS_PLAN_STATUS_DESCENDING;
+            if (to < from) values[1] |= SZS_PLAN_STATUS_DESCENDING;
             u64 const wide_length = to < from ? 0 : to - from;
-            if (wide_length > 0xFFFFFFFFull) status |= SZS_PLAN_STATUS_OVERFLOW;
+            if (wide_length > 0xFFFFFFFFull) values[1] |= SZS_PLAN_STATUS_OVERFLOW;
             u32 const length = (u32)wide_length;
-            longest = length > longest ? length : longest;
-            symbols += length;
-            bands_systolic += length ? (length + SZS_SYSTOLIC_BAND_ROWS - 1) / SZS_SYSTOLIC_BAND_ROWS : 1;
-            bands_chain += length ? (length + SZS_MYERS_CHAIN_BAND_ROWS - 1) / SZS_MYERS_CHAIN_BAND_ROWS : 1;
+            values[0] = length > values[0] ? length : values[0];
+            values[2] += length;
+            values[3] += length ? (length + SZS_SYSTOLIC_BAND_ROWS - 1) / SZS_SYSTOLIC_BAND_ROWS : 1;
+            values[4] += length ? (length + SZS_MYERS_CHAIN_BAND_ROWS - 1) / SZS_MYERS_CHAIN_BAND_ROWS : 1;
             u32 const slot = variant_slot(length, myers_words);
 #pragma unroll
-            for (u32 v = 0; v < SZS_PLAN_VARIANTS; ++v) variants[v] += slot == v;
+            for (u32 v = 0; v < SZS_PLAN_VARIANTS; ++v) values[5 + v] += slot == v;
         }
-        atomicMax(&shared_longest[s], longest);
-        if (status) atomicOr(&shared_status, status);
-        atomicAdd(&shared_symbols[s], (unsigned long long)symbols);
-        atomicAdd(&shared_bands_systolic[s], (unsigned long long)bands_systolic);
-        atomicAdd(&shared_bands_chain[s], (unsigned long long)bands_chain);
 #pragma unroll
-        for (u32 v = 0; v < SZS_PLAN_VARIANTS; ++v)
-            if (variants[v]) atomicAdd(&shared_variants[s][v], variants[v]);
+        for (int k = 0; k < plan_values_k; ++k) {
+            u64 value = values[k];
+#pragma unroll
+            for (int offset = 32; offset >= 1; offset >>= 1) {
+                u64 const other = shuffle_xor_u64(value, offset);
+                value = k == 0 ? (other > value ? other : value) : k == 1 ? (value | other) : value + other;
+            }
+            if (lane == 0) wave_values[s][wave][k] = value;
+        }
     }
     __syncthreads();
+    if (tid < (u32)(sides * plan_values_k)) {
+        int const s = tid / plan_values_k, k = tid % plan_values_k;
+        u64 value = 0;
+        for (int w = 0; w < plan_threads_k / 64; ++w) {
+            u64 const other = wave_values[s][w][k];
+            value = k == 0 ? (other > value ? other : value) : k == 1 ? (value | other) : value + other;
+        }
+        side_values[s][k] = value;
+    }
+    if (tid == 0) shared_cells = 0, shared_held = 0;
+    __syncthreads();
+    u32 const shared_status = (u32)(side_values[0][1] | (symmetric ? 0 : side_values[1][1]));
+    u32 const shared_longest[2] = {(u32)side_values[0][0], (u32)side_values[symmetric ? 0 : 1][0]};
 
     // ---- symmetric calls: cells of the lower triangle = sum_i len_i * sum_{j <= i} len_j, in the caller's order
     if (symmetric) {
         u32 const chunk = (queries.count + plan_threads_k - 1) / plan_threads_k;
-        u32 const first = tid * chunk, last = first + chunk < queries.count ? first + chunk : queries.count;
+        u32 const first = tid * chunk < queries.count ? tid * chunk : queries.count;
+        u32 const last = first + chunk < queries.count ? first + chunk : queries.count;
         u64 mine = 0;
         for (u32 i = first; i < last; ++i)
             mine += tape_offset(queries.offsets, queries.wide, (u64)i + 1) - tape_offset(queries.offsets, queries.wide, i);
         // prefix of the chunk sums: 64-bit, so two 32-bit scans would not do - a serial pass by one thread is 1024 adds
-        __shared__ unsigned long long chunk_sums[plan_threads_k];
         chunk_sums[tid] = mine;
         __syncthreads();
         if (tid == 0) {
@@ -138,7 +160,16 @@ __global__ __launch_bounds__(plan_threads_k) void plan_kernel(szs_plan_side_t qu
             u64 const length = tape_offset(queries.offsets, queries.wide, (u64)i + 1) - tape_offset(queries.offsets, queries.wide, i);
             running += length, cells += length * running;
         }
-        atomicAdd(&shared_cells, (unsigned long long)cells);
+#pragma unroll
+        for (int offset = 32; offset >= 1; offset >>= 1) cells += shuffle_xor_u64(cells, offset);
+        __syncthreads();
+        if (lane == 0) chunk_sums[wave] = cells;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long total = 0;
+            for (int w = 0; w < plan_threads_k / 64; ++w) total += chunk_sums[w];
+            shared_cells = total;
+        }
         __syncthreads();
     }
 
@@ -147,7 +178,7 @@ __global__ __launch_bounds__(plan_threads_k) void plan_kernel(szs_plan_side_t qu
         u32 held = expected.enabled && !shared_status;
         if (held) {
             int const query_side = symmetric ? 0 : (int)expected.query_side;
-            for (u32 v = 0; v < SZS_PLAN_VARIANTS; ++v) held &= shared_variants[query_side][v] == expected.variant_counts[v];
+            for (u32 v = 0; v < SZS_PLAN_VARIANTS; ++v) held &= (u32)side_values[query_side][5 + v] == expected.variant_counts[v];
             held &= shared_longest[0] <= expected.longest[0];
             held &= shared_longest[symmetric ? 0 : 1] <= expected.longest[1];
         }
@@ -195,21 +226,22 @@ __global__ __launch_bounds__(plan_threads_k) void plan_kernel(szs_plan_side_t qu
     }
     __syncthreads();
 
-    if (tid == 0) {
-        summary->status = shared_status | (unsorted ? SZS_PLAN_STATUS_UNSORTED : 0u);
-        summary->speculation_held = shared_held;
+    if (tid == 0) { // one struct, written once: the host reads it after the stream has drained
+        szs_plan_summary_t report;
+        report.status = shared_status | (unsorted ? SZS_PLAN_STATUS_UNSORTED : 0u);
+        report.speculation_held = shared_held;
         for (int s = 0; s < 2; ++s) {
             int const from = symmetric ? 0 : s;
-            summary->side[s].count = from ? candidates.count : queries.count;
-            summary->side[s].longest = shared_longest[from];
-            summary->side[s].symbols = shared_symbols[from];
-            summary->side[s].bands_systolic = shared_bands_systolic[from];
-            summary->side[s].bands_chain = shared_bands_chain[from];
-            for (u32 v = 0; v < SZS_PLAN_VARIANTS; ++v) summary->variant_counts[s][v] = shared_variants[from][v];
+            report.side[s].count = from ? candidates.count : queries.count;
+            report.side[s].longest = (u32)side_values[from][0];
+            report.side[s].symbols = side_values[from][2];
+            report.side[s].bands_systolic = side_values[from][3];
+            report.side[s].bands_chain = side_values[from][4];
+            for (u32 v = 0; v < SZS_PLAN_VARIANTS; ++v) report.variant_counts[s][v] = (u32)side_values[from][5 + v];
         }
-        summary->symmetric_cells = shared_cells;
-        __threadfence_system();
-        summary->sequence = expected.sequence; // written last: the host can tell a fresh summary from a stale one
+        report.symmetric_cells = shared_cells;
+        report.sequence = expected.sequence; // the host can tell a fresh summary from a stale one
+        *summary = report;
     }
 }
 

@@ -80,12 +80,16 @@ struct packed_costs_t {
     u32 pairs[packed_registers_k];
 };
 
-__device__ __forceinline__ packed_costs_t load_packed_costs(u32 const *profile, u32 class_pair) {
-    uint4 const *rows = reinterpret_cast<uint4 const *>(profile) + class_pair * (packed_registers_k / 4);
+/** Layout [chunk of 4 registers][class pair][4 registers]: one ds_read_b128 per chunk, and within one instruction the 64
+ *  lanes' addresses differ by multiples of 16 B, i.e. spread over all bank groups.  Round 1 kept a pair's 16 registers
+ *  together (64-byte rows): every lane of an instruction then hit one of only two (four) bank groups and the LDS was busy
+ *  89 % of config 3's kernel time, 72 % of it in conflicts (profiles/r02/pmc_configs.json). */
+__device__ __forceinline__ packed_costs_t load_packed_costs(u32 const *profile, u32 class_pair, u32 class_pairs) {
+    uint4 const *rows = reinterpret_cast<uint4 const *>(profile) + class_pair;
     packed_costs_t costs;
 #pragma unroll
     for (int chunk = 0; chunk < packed_registers_k / 4; ++chunk) {
-        uint4 const part = rows[chunk];
+        uint4 const part = rows[chunk * class_pairs];
         costs.pairs[4 * chunk + 0] = part.x, costs.pairs[4 * chunk + 1] = part.y;
         costs.pairs[4 * chunk + 2] = part.z, costs.pairs[4 * chunk + 3] = part.w;
     }
@@ -134,8 +138,11 @@ __device__ __forceinline__ void packed_advance(packed_column_t<affine_> &column,
  *                   instead of Needleman-Wunsch.
  *  @tparam affine_  Gotoh's three-track recurrence instead of the single-track linear one.
  */
+#ifndef SZS_PACKED_AFFINE_WAVES
+#define SZS_PACKED_AFFINE_WAVES 3
+#endif
 template <bool local_, bool affine_>
-__global__ __launch_bounds__(256, affine_ ? 3 : 4) void weighted_packed_kernel( // three / four wavefronts per SIMD: no spills either way
+__global__ __launch_bounds__(256, affine_ ? SZS_PACKED_AFFINE_WAVES : 4) void weighted_packed_kernel( // three / four wavefronts per SIMD: no spills either way
     szs_cost_model_t const *__restrict__ model, szs_string_ref_t const *__restrict__ queries, u32 queries_count,
     szs_string_ref_t const *__restrict__ candidates, u32 candidates_count, u32 candidate_blocks,
     i64 *__restrict__ results, u64 results_row_stride, int layout_flags, int16_t *__restrict__ boundary,
@@ -143,7 +150,7 @@ __global__ __launch_bounds__(256, affine_ ? 3 : 4) void weighted_packed_kernel( 
 
     constexpr bool saturating_ = local_;
     constexpr int registers = packed_registers_k, rows = packed_strip_rows_k;
-    extern __shared__ __attribute__((aligned(16))) u32 pair_profile[]; // [class of symbol t * K + class of symbol t - 1][16]
+    extern __shared__ __attribute__((aligned(16))) u32 pair_profile[]; // [register chunk][class of symbol t * K + class of symbol t - 1][4]
     __shared__ int8_t table[32 * 32];                                  // [query class][candidate class]
     __shared__ u8 class_of_byte[256];
     __shared__ u8 strip_classes[rows];                                 // 0xFF: a padded row
@@ -213,10 +220,10 @@ __global__ __launch_bounds__(256, affine_ ? 3 : 4) void weighted_packed_kernel( 
                     i32 const lower = lower_row != 0xFF && lower_class != null_class ? table[lower_row * 32 + lower_class] : 0;
                     packed[r] = ((u32)upper & 0xFFFFu) | ((u32)lower << 16);
                 }
-                uint4 *const mine = reinterpret_cast<uint4 *>(pair_profile) + pair * (registers / 4);
+                uint4 *const mine = reinterpret_cast<uint4 *>(pair_profile) + pair;
 #pragma unroll
                 for (int chunk = 0; chunk < registers / 4; ++chunk)
-                    mine[chunk] = make_uint4(packed[4 * chunk], packed[4 * chunk + 1], packed[4 * chunk + 2], packed[4 * chunk + 3]);
+                    mine[chunk * class_slots * class_slots] = make_uint4(packed[4 * chunk], packed[4 * chunk + 1], packed[4 * chunk + 2], packed[4 * chunk + 3]);
             }
             __syncthreads();
 
@@ -245,7 +252,7 @@ __global__ __launch_bounds__(256, affine_ ? 3 : 4) void weighted_packed_kernel( 
 
             // One step for this lane: A scores DP column `j` (symbol class `upper_class`), B scores column j - 1.
             auto step = [&](u32 upper_class, i32 above_h, i32 above_down) {
-                packed_costs_t const costs = load_packed_costs(pair_profile, upper_class * class_slots + previous_class);
+                packed_costs_t const costs = load_packed_costs(pair_profile, upper_class * class_slots + previous_class, class_slots * class_slots);
                 previous_class = upper_class;
                 // hand-over: A's last row at column j - 1 (low half of register 15, before this step) becomes B's row above
                 pk_i16 const above_pk = pk_bits((pk_raw(column.h[registers - 1]) << 16) | ((u32)above_h & 0xFFFFu));

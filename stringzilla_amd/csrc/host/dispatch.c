@@ -76,9 +76,10 @@ sz_status_t szs_prefetch_offsets(void *pinned_staging, hipStream_t stream, szs_i
  *  tape whose offsets are readable at `offsets` (see prefetch_offsets).
  */
 sz_status_t szs_gather_strings(szs_input_t const *input, void const *offsets, uint64_t *addresses, uint32_t *lengths,
-                               uint64_t *total_bytes, char const **error_message) {
+                               uint64_t *total_bytes, int *needs_staging, char const **error_message) {
     size_t const count = input->count;
     *total_bytes = 0;
+    if (needs_staging) *needs_staging = 0;
     if (input->kind == szs_input_sequence_k) {
         sz_sequence_t const *sequence = input->sequence;
         int checked = 0;
@@ -87,8 +88,10 @@ sz_status_t szs_gather_strings(szs_input_t const *input, void const *offsets, ui
             size_t const length = sequence->get_length(sequence->handle, i);
             if (length > 0xFFFFFFFFull) return szs_report(sz_overflow_risk_k, error_message, NULL);
             if (length && !checked) { /* like the reference, vet one representative string (cuda.cuh:4268-4272) */
-                if (!szs_classify_pointer(start).device_accessible)
-                    return szs_report(sz_device_memory_mismatch_k, error_message, NULL);
+                if (!szs_classify_pointer(start).device_accessible) {
+                    if (!needs_staging) return szs_report(sz_device_memory_mismatch_k, error_message, NULL);
+                    *needs_staging = 1;
+                }
                 checked = 1;
             }
             addresses[i] = (uint64_t)(uintptr_t)start, lengths[i] = (uint32_t)length;
@@ -117,8 +120,31 @@ sz_status_t szs_gather_strings(szs_input_t const *input, void const *offsets, ui
         }
         *total_bytes = o[count] - o[0];
     }
-    if (*total_bytes && !szs_classify_pointer(input->data).device_accessible)
-        return szs_report(sz_device_memory_mismatch_k, error_message, NULL);
+    if (*total_bytes && !szs_classify_pointer(input->data).device_accessible) {
+        if (!needs_staging) return szs_report(sz_device_memory_mismatch_k, error_message, NULL);
+        *needs_staging = 1;
+    }
+    return sz_success_k;
+}
+
+/**
+ *  `cpu_requests = gpu` only (host/tuning.c): a caller that asked for a CPU engine hands over strings in plain host
+ *  memory, which no kernel can read.  Their bytes are packed into the engine's pinned staging tape, shipped to HBM in one
+ *  copy, and `addresses` are rewritten to point there.  (By default such inputs are refused with
+ *  sz_device_memory_mismatch_k, like the reference's GPU engines do: cuda.cuh:4268-4272.)
+ */
+static sz_status_t stage_host_strings(szs_engine_s *engine, hipStream_t stream, uint64_t *addresses, uint32_t const *lengths,
+                                      uint32_t count, uint64_t total_bytes, size_t tape_offset, char const **error_message) {
+    if (!total_bytes) return sz_success_k;
+    char *const pinned = (char *)engine->pinned_tape.pointer + tape_offset, *const remote = (char *)engine->device_tape.pointer + tape_offset;
+    uint64_t cursor = 0;
+    for (uint32_t i = 0; i < count; ++i) {
+        memcpy(pinned + cursor, (void const *)(uintptr_t)addresses[i], lengths[i]);
+        addresses[i] = (uint64_t)(uintptr_t)(remote + cursor);
+        cursor += lengths[i];
+    }
+    hipError_t const error = hipMemcpyAsync(remote, pinned, total_bytes, hipMemcpyHostToDevice, stream);
+    if (error != hipSuccess) return szs_report_hip(error, error_message);
     return sz_success_k;
 }
 
@@ -213,6 +239,7 @@ static void release_device_state(szs_engine_s *engine) {
     szs_buffer_release(&engine->device_model);
     szs_buffer_release(&engine->device_systolic);
     szs_buffer_release(&engine->device_tape);
+    szs_buffer_release(&engine->pinned_tape);
     szs_buffer_release(&engine->device_runes);
     szs_buffer_release(&engine->device_transcode);
     szs_buffer_release(&engine->pinned_transcode);
@@ -222,6 +249,11 @@ static void release_device_state(szs_engine_s *engine) {
         (void)hipEventDestroy(engine->event_start);
         (void)hipEventDestroy(engine->event_stop);
         engine->events_device = -1;
+    }
+    if (engine->aux_device >= 0) {
+        for (int i = 0; i < SZS_AUX_STREAMS; ++i) (void)hipStreamDestroy(engine->aux_streams[i]), (void)hipEventDestroy(engine->aux_done[i]);
+        (void)hipEventDestroy(engine->fork_event);
+        engine->aux_device = -1;
     }
     engine->model_uploaded_device = -1;
     if (engine->remembered) engine->remembered->valid = 0;
@@ -426,25 +458,53 @@ static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int dev
     /* Persistent kernels address their work items with 32 bits: cross-products beyond that are cut along the query axis. */
     uint64_t const candidate_blocks = ((uint64_t)d->kc_count + SZS_CANDIDATES_PER_WORKGROUP - 1) / SZS_CANDIDATES_PER_WORKGROUP;
     uint32_t const queries_per_launch = (uint32_t)(0xFFFFFFF0ull / (candidate_blocks ? candidate_blocks : 1));
-    for (unsigned g = 0; g < d->plan.groups_count; ++g) {
+
+    /* A batch of mixed lengths is several launches (one per bit-vector width), and every launch ends in a tail: its last,
+     * longest pairs hold a few wavefronts while the rest of the chip idles - on config 5 the two widest launches kept 0.7
+     * of a wavefront per SIMD resident (profiles/r02/pmc_configs.json).  The launches are independent (disjoint result
+     * cells), so they fan out over the engine's auxiliary streams and fill each other's tails; only the launches that
+     * share the strip workspace (`device_boundary`) stay on the scope's stream, in order. */
+    int const fan_out = d->plan.groups_count > 1 && szs_tuning_get(szs_knob_streams_k) != 0;
+    hipError_t error = hipSuccess;
+    if (fan_out) {
+        if (engine->aux_device != device) {
+            for (int i = 0; i < SZS_AUX_STREAMS && error == hipSuccess; ++i) {
+                error = hipStreamCreateWithFlags(&engine->aux_streams[i], hipStreamNonBlocking);
+                if (error == hipSuccess) error = hipEventCreateWithFlags(&engine->aux_done[i], hipEventDisableTiming);
+            }
+            if (error == hipSuccess) error = hipEventCreateWithFlags(&engine->fork_event, hipEventDisableTiming);
+            if (error != hipSuccess) return error;
+            engine->aux_device = device;
+        }
+        error = hipEventRecord(engine->fork_event, stream);
+        for (int i = 0; i < SZS_AUX_STREAMS && error == hipSuccess; ++i) error = hipStreamWaitEvent(engine->aux_streams[i], engine->fork_event, 0);
+        if (error != hipSuccess) return error; /* nothing has been launched on the auxiliary streams */
+    }
+    unsigned next_lane = 0; /* round-robin over {scope's stream, auxiliary streams} for launches that need no workspace */
+    for (unsigned g = 0; g < d->plan.groups_count && !launch_error && *status == sz_success_k; ++g) {
         szs_plan_group_t const *group = &d->plan.groups[g];
-        for (uint32_t done = 0; done < group->count; done += queries_per_launch) {
+        int const uses_workspace = group->variant == 0;
+        unsigned const lane = fan_out && !uses_workspace ? next_lane++ % (SZS_AUX_STREAMS + 1) : 0;
+        hipStream_t const target = lane ? engine->aux_streams[lane - 1] : stream;
+        for (uint32_t done = 0; done < group->count && !launch_error && *status == sz_success_k; done += queries_per_launch) {
             szs_string_ref_t const *const queries = query_refs + group->first + done;
             uint32_t const count = group->count - done < queries_per_launch ? group->count - done : queries_per_launch;
             if (group->variant && d->runes) {
                 launch_error = group->variant == SZS_MYERS_SHORT_WORDS
                                    ? szs_hip_levenshtein_myers_runes(queries, count, candidate_refs, d->kc_count, (uint64_t *)device_results,
-                                                                     device_stride, d->layout, stream)
+                                                                     device_stride, d->layout, target)
                                    : szs_hip_levenshtein_myers_runes_long(group->variant, queries, count, candidate_refs, d->kc_count,
-                                                                          (uint64_t *)device_results, device_stride, d->layout, stream);
+                                                                          (uint64_t *)device_results, device_stride, d->layout, target);
                 if (launch_error == (int)hipErrorNotSupported) { /* no LDS for the rune table: the rune-keyed DP kernel, whose
-                                                                    workspace is reserved here, on the one path that needs it */
+                                                                    workspace is reserved here, on the one path that needs it -
+                                                                    and on the scope's stream, like every user of that workspace */
+                    launch_error = 0;
                     *status = upload_model(engine, d, device, stream, error_message);
                     if (*status == sz_success_k)
                         *status = szs_buffer_reserve(&engine->device_boundary, szs_memory_device_k, device,
                                                      szs_hip_weighted_boundary_bytes(d->objective, !engine->is_linear, 0, d->kq_count, d->kc_count,
                                                                                      d->plan.longest_candidate), error_message);
-                    if (*status != sz_success_k) return hipSuccess;
+                    if (*status != sz_success_k) break;
                     *cell_bits = 32;
                     launch_error = szs_hip_weighted_scores(d->objective, !engine->is_linear, 0, (szs_cost_model_t const *)engine->device_model.pointer,
                                                            queries, count, candidate_refs, d->kc_count, d->plan.longest_candidate,
@@ -453,28 +513,36 @@ static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int dev
             }
             else if (group->variant)
                 launch_error = szs_hip_levenshtein_myers(group->variant, queries, count, candidate_refs, d->kc_count, (uint64_t *)device_results,
-                                                         device_stride, d->layout, stream);
+                                                         device_stride, d->layout, target);
             else if (d->banded)
                 launch_error = szs_hip_levenshtein_myers_banded(queries, count, candidate_refs, d->kc_count, d->plan.longest_candidate,
                                                                 (uint64_t *)device_results, device_stride, d->layout,
-                                                                engine->device_boundary.pointer, stream);
+                                                                engine->device_boundary.pointer, target);
             else if (d->packed) {
                 *cell_bits = 16;
                 launch_error = szs_hip_weighted_packed_scores(d->packed_local, !engine->is_linear, d->classes, model, queries, count, candidate_refs,
                                                               d->kc_count, d->plan.longest_candidate, (int64_t *)device_results, device_stride,
-                                                              d->layout, engine->device_boundary.pointer, stream);
+                                                              d->layout, engine->device_boundary.pointer, target);
             }
             else {
                 *cell_bits = 32;
                 launch_error = szs_hip_weighted_scores(d->objective, !engine->is_linear, d->narrow, model, queries, count, candidate_refs,
                                                        d->kc_count, d->plan.longest_candidate, (int64_t *)device_results, device_stride,
-                                                       d->layout, engine->device_boundary.pointer, stream);
+                                                       d->layout, engine->device_boundary.pointer, target);
             }
-            if (launch_error) return (hipError_t)launch_error;
-            ++*launches;
+            if (!launch_error) ++*launches;
         }
     }
-    return hipSuccess;
+    if (fan_out) /* join, also after a failed launch: whatever was enqueued anywhere is drained by the wait on the scope's stream */
+        for (int i = 0; i < SZS_AUX_STREAMS; ++i) {
+            hipError_t joined = hipEventRecord(engine->aux_done[i], engine->aux_streams[i]);
+            if (joined == hipSuccess) joined = hipStreamWaitEvent(stream, engine->aux_done[i], 0);
+            if (joined != hipSuccess) { /* cannot order the streams: wait here, so that nothing outlives the call */
+                (void)hipStreamSynchronize(engine->aux_streams[i]);
+                if (!launch_error) launch_error = (int)joined;
+            }
+        }
+    return (hipError_t)launch_error;
 }
 
 /* ---- one call ---------------------------------------------------------------------------------------------------------- */
@@ -767,16 +835,33 @@ static sz_status_t cross_host_planned(szs_call_t *call) {
     uint32_t *c_lengths = q_lengths + q_count;
 
     uint64_t query_bytes = 0, candidate_bytes = 0;
-    status = szs_gather_strings(queries, q_offsets, q_addresses, q_lengths, &query_bytes, error_message);
+    int const may_stage = szs_tuning_get(szs_knob_cpu_requests_k) == 1;
+    int stage_queries = 0, stage_candidates = 0;
+    status = szs_gather_strings(queries, q_offsets, q_addresses, q_lengths, &query_bytes, may_stage ? &stage_queries : NULL, error_message);
     if (status != sz_success_k) return status;
+    if (!symmetric) {
+        status = szs_gather_strings(candidates, c_offsets, c_addresses, c_lengths, &candidate_bytes, may_stage ? &stage_candidates : NULL,
+                                    error_message);
+        if (status != sz_success_k) return status;
+    }
+    if (stage_queries || stage_candidates) { /* host-only strings of a caller that asked for a CPU engine */
+        size_t const tape_bytes = (stage_queries ? query_bytes : 0) + (stage_candidates ? candidate_bytes : 0) + 16;
+        status = szs_buffer_reserve(&engine->pinned_tape, szs_memory_pinned_k, device, tape_bytes, error_message);
+        if (status == sz_success_k) status = szs_buffer_reserve(&engine->device_tape, szs_memory_device_k, device, tape_bytes, error_message);
+        if (status == sz_success_k && stage_queries)
+            status = stage_host_strings(engine, stream, q_addresses, q_lengths, q_count, query_bytes, 0, error_message);
+        if (status == sz_success_k && stage_candidates)
+            status = stage_host_strings(engine, stream, c_addresses, c_lengths, c_count, candidate_bytes,
+                                        stage_queries ? query_bytes : 0, error_message);
+        if (status != sz_success_k) {
+            (void)hipStreamSynchronize(stream);
+            return status;
+        }
+    }
     if (symmetric) {
         memcpy(c_addresses, q_addresses, (size_t)q_count * sizeof(uint64_t));
         memcpy(c_lengths, q_lengths, (size_t)q_count * sizeof(uint32_t));
         candidate_bytes = query_bytes;
-    }
-    else {
-        status = szs_gather_strings(candidates, c_offsets, c_addresses, c_lengths, &candidate_bytes, error_message);
-        if (status != sz_success_k) return status;
     }
 
     /* Codepoint-level engine: transcode every string to UTF-32 ONCE (hip/utf8.hip), then plan and score on runes.  When

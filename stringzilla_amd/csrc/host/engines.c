@@ -19,7 +19,9 @@ static sz_status_t engine_new(szs_family_t family, sz_capability_t capabilities,
                               char const **error_message) {
     if (!out) return szs_report(sz_status_unknown_k, error_message, "Engine must not be null");
     if (*out) return szs_report(sz_status_unknown_k, error_message, "Engine must be uninitialized");
-    if ((capabilities & sz_cap_cuda_k) == 0)
+    /* Strict by default; with the `cpu_requests` knob set to "gpu" a mask without the GPU bit is served by the only engines
+     * this build has (host/tuning.c) - the results are the same numbers, computed on the GPU. */
+    if ((capabilities & sz_cap_cuda_k) == 0 && szs_tuning_get(szs_knob_cpu_requests_k) != 1)
         return szs_report(sz_missing_gpu_k, error_message,
                           "The ROCm build ships GPU engines only: request sz_cap_cuda_k (e.g. from a GPU device scope)");
     if ((szs_capabilities() & sz_cap_cuda_k) == 0) return szs_report(sz_missing_gpu_k, error_message, NULL);
@@ -27,7 +29,7 @@ static sz_status_t engine_new(szs_family_t family, sz_capability_t capabilities,
     if (!engine) return szs_report(sz_bad_alloc_k, error_message, NULL);
     engine->magic = SZS_ENGINE_MAGIC;
     engine->family = family;
-    engine->device = -1, engine->events_device = -1, engine->model_uploaded_device = -1;
+    engine->device = -1, engine->events_device = -1, engine->model_uploaded_device = -1, engine->aux_device = -1;
     *created = engine;
     *out = engine;
     return szs_report(sz_success_k, error_message, NULL);

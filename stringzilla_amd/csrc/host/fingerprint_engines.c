@@ -49,7 +49,9 @@ sz_status_t szs_fingerprints_create(sz_size_t dimensions, sz_size_t alphabet_siz
     (void)alphabet_size; /* the reference's f64 hasher derives nothing from it (serial.hpp:524-533) */
     if (!out) return szs_report(sz_status_unknown_k, error_message, "Engine must not be null");
     if (*out) return szs_report(sz_status_unknown_k, error_message, "Engine must be uninitialized");
-    if ((capabilities & sz_cap_cuda_k) == 0)
+    /* Strict by default; with the `cpu_requests` knob set to "gpu" a mask without the GPU bit is served by the only engines
+     * this build has (host/tuning.c) - the results are the same numbers, computed on the GPU. */
+    if ((capabilities & sz_cap_cuda_k) == 0 && szs_tuning_get(szs_knob_cpu_requests_k) != 1)
         return szs_report(sz_missing_gpu_k, error_message,
                           "The ROCm build ships GPU engines only: request sz_cap_cuda_k (e.g. from a GPU device scope)");
     if ((szs_capabilities() & sz_cap_cuda_k) == 0) return szs_report(sz_missing_gpu_k, error_message, NULL);
@@ -178,7 +180,7 @@ sz_status_t szs_fingerprints_call(szs_fingerprints_s *engine, szs_scope_s *scope
         if (error != hipSuccess) return szs_report_hip(error, error_message);
     }
     uint64_t total_bytes = 0;
-    status = szs_gather_strings(texts, host_offsets, addresses, lengths, &total_bytes, error_message);
+    status = szs_gather_strings(texts, host_offsets, addresses, lengths, &total_bytes, NULL, error_message);
     if (status != sz_success_k) return status;
 
     /* The segment plan: a text is cut into stretches of SZS_FINGERPRINT_SEGMENT window positions hashed independently. */

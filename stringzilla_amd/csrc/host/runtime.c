@@ -181,8 +181,9 @@ void szs_device_scope_free(szs_device_scope_t handle) {
 
 sz_status_t szs_scope_bind_gpu(szs_scope_s *scope, int *device, hipStream_t *stream, char const **error_message) {
     if (!scope) return szs_report(sz_status_unknown_k, error_message, "Scope must not be null");
-    if (scope->kind == szs_scope_cpu_k) return szs_report(sz_device_code_mismatch_k, error_message, NULL);
-    if (scope->kind == szs_scope_default_k) {
+    int const cpu_requests_on_gpu = szs_tuning_get(szs_knob_cpu_requests_k) == 1; /* see engines.c: engine_new */
+    if (scope->kind == szs_scope_cpu_k && !cpu_requests_on_gpu) return szs_report(sz_device_code_mismatch_k, error_message, NULL);
+    if (scope->kind == szs_scope_default_k || scope->kind == szs_scope_cpu_k) {
         /* A default scope used with a GPU engine binds device 0 (stringzillas.cuh:303-320,355-365). */
         int devices = 0;
         if (hipGetDeviceCount(&devices) != hipSuccess || devices <= 0) {

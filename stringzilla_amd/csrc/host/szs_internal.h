@@ -91,7 +91,8 @@ typedef struct szs_engine_s {
     szs_buffer_t device_model;   /* device: szs_cost_model_t */
     szs_buffer_t device_systolic;/* device: control block of the systolic tier (epoch-tagged words, zeroed once) */
     uint32_t systolic_epoch;     /* launches that have used `device_systolic` since it was zeroed */
-    szs_buffer_t device_tape;    /* device: flattened copy of callback-sequence strings living in host memory */
+    szs_buffer_t device_tape;    /* device: packed copy of strings living in plain host memory (`cpu_requests = gpu` only) */
+    szs_buffer_t pinned_tape;    /* pinned: the host side of that copy */
     szs_buffer_t device_runes;   /* device: UTF-32 transcription of both sides (codepoint-level engine) */
     szs_buffer_t device_transcode; /* device: raw refs, rune starts, rune counts and the multibyte flag of that pass */
     szs_buffer_t pinned_transcode; /* pinned: the host's side of the same */
@@ -100,6 +101,11 @@ typedef struct szs_engine_s {
     szs_cost_model_t host_model;   /* what was uploaded: lives as long as the engine, so the upload needs no wait */
     hipEvent_t event_start, event_stop;
     int events_device;
+    /* launches of different bit-vector widths fan out over these and fill each other's tails (dispatch.c: enqueue) */
+#define SZS_AUX_STREAMS 3
+    hipStream_t aux_streams[SZS_AUX_STREAMS];
+    hipEvent_t aux_done[SZS_AUX_STREAMS], fork_event;
+    int aux_device; /* device the auxiliary streams live on, -1: none yet */
 
     /* device-side planning (hip/planner.hip) */
     szs_buffer_t device_plan_refs; /* device: ascending + descending refs of both sides */
@@ -138,7 +144,8 @@ sz_status_t szs_prefetch_offsets(void *pinned_staging, hipStream_t stream, szs_i
                                  void const **host_offsets, int *pending, char const **error_message);
 /** Absolute addresses and 32-bit lengths of every string of one side; vets device accessibility like the reference. */
 sz_status_t szs_gather_strings(szs_input_t const *input, void const *offsets, uint64_t *addresses, uint32_t *lengths,
-                               uint64_t *total_bytes, char const **error_message);
+                               uint64_t *total_bytes, int *needs_staging /* NULL: host-only strings are an error */,
+                               char const **error_message);
 
 /* ---- fingerprint engines (fingerprint_engines.c) --------------------------------------------------------------------------- */
 

@@ -29,6 +29,8 @@ static struct {
     [szs_knob_cells_k] = {"cells", "SZS_ROCM_CELLS"},
     [szs_knob_planner_k] = {"planner", "SZS_ROCM_PLANNER"},
     [szs_knob_speculate_k] = {"speculate", "SZS_ROCM_SPECULATE"},
+    [szs_knob_cpu_requests_k] = {"cpu_requests", "SZS_ROCM_CPU_REQUESTS"},
+    [szs_knob_streams_k] = {"streams", "SZS_ROCM_STREAMS"},
 };
 
 /** Text -> value.  -1 always means "automatic".  Tier names: lanes 0, systolic 1, chain 2; planner: host 0, device 1. */
@@ -42,6 +44,10 @@ static int parse_knob(int knob, char const *text) {
     if (knob == szs_knob_planner_k) {
         if (text[0] == 'h') return 0;
         if (text[0] == 'd') return 1;
+    }
+    if (knob == szs_knob_cpu_requests_k) {
+        if (text[0] == 'g') return 1; /* "gpu" */
+        if (text[0] == 's') return 0; /* "strict" */
     }
     return atoi(text);
 }
