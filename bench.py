@@ -68,6 +68,8 @@ def parse_args():
                              "4,5 strong-scaled on several; 'none' to skip)")
     parser.add_argument("--extra-seconds", type=float, default=4.0, help="GPU time budget per extra config")
     parser.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU time budget per cpu_baseline sample")
+    parser.add_argument("--extra-scale", type=float, default=1.0,
+                        help="testing aid: shrinks the matrix side of the `configs` records (1.0 = BASELINE.json's sizes)")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI)")
     parser.add_argument("--same-device", action="store_true",
@@ -264,7 +266,7 @@ def measure_extra(config, scope, device_index, args, fence, with_cpu):
 
     from stringzilla_amd import workloads
 
-    load = workloads.config(config)
+    load = workloads.config(config, scale=args.extra_scale)
     engine = make_engine(load, scope)
     queries, candidates = load.queries.to_device(device_index), load.candidates.to_device(device_index)
     results = torch.empty((len(queries), len(candidates)), dtype=torch.int64, device=torch.device("cuda", device_index))
@@ -298,7 +300,7 @@ def measure_strong(config, scope, device_index, args, fence, dist, world, rank, 
 
     from stringzilla_amd import sharded, workloads
 
-    load = workloads.config(config)  # seeded: every rank can name the engine; only rank 0's copy of the strings is used
+    load = workloads.config(config, scale=args.extra_scale)  # seeded: every rank can name the engine; only rank 0's strings are used
     engine = make_engine(load, scope)
     busy, state = [], {}
 
@@ -346,7 +348,7 @@ def measure_c_node(config, devices, args):
 
     if not hasattr(szs, "Node"):
         return None
-    load = workloads.config(config)
+    load = workloads.config(config, scale=args.extra_scale)
     node = szs.Node(devices)
     engine = node.engine_for(load)
     out = torch.empty((len(load.queries), len(load.candidates)), dtype=torch.int64, device=torch.device("cuda", devices[0]))
@@ -430,6 +432,35 @@ def main():
         elapsed = float(slowest)
 
     profile = engine.last_call_profile()
+
+    # ---- the same step on batches the engine has NOT just seen: two different batches of the config's shape, alternating, so
+    # that no call finds the plan of its own tapes on the device (csrc/host/dispatch.c re-uses that plan after validating it
+    # in the kernels; a stream of fresh batches pays for the planner kernel instead).  Reported beside the headline.
+    fresh = None
+    if world == 1 and args.config == 2:
+        other = workloads.random_tape(np.random.default_rng(4242), len(load.queries), 96, 160, workloads.ASCII_PRINTABLE).to_device(local_rank)
+        other_candidates = workloads.random_tape(np.random.default_rng(4243), len(load.candidates), 96, 160, workloads.ASCII_PRINTABLE).to_device(local_rank)
+        other_step = make_step(engine, scope, load, other, other_candidates, results, local_rank)
+        other_cells = int(other.lengths().sum()) * int(other_candidates.lengths().sum())
+        for _ in range(max(2, args.warmup // 2)):
+            other_step(), step()
+        planners = set()
+        fence()
+        fresh_started = time.perf_counter()
+        for _ in range(max(1, args.steps // 2)):
+            other_step()
+            planners.add(int(engine.last_call_profile().planner))
+            step()
+            planners.add(int(engine.last_call_profile().planner))
+        fence()
+        fresh_elapsed = time.perf_counter() - fresh_started
+        pairs_of_steps = max(1, args.steps // 2)
+        fresh = {"what": "two different batches of the same shape, alternating: every call plans its tapes afresh on the device",
+                 "ms_per_step": round(fresh_elapsed / (2 * pairs_of_steps) * 1e3, 4),
+                 "value": round((other_cells + int(profile.cells)) * pairs_of_steps / fresh_elapsed / 1e9, 1), "unit": "GCUPS",
+                 "planner_modes_seen": sorted(planners)}
+        step()  # leave the results matrix holding the headline batch's scores for the checks below
+
     cells_per_rank = torch.tensor([float(profile.cells)], dtype=torch.float64, device=where)
     checksum = results.sum().reshape(1).to(torch.float64)
     if world > 1:
@@ -455,12 +486,12 @@ def main():
             raise
         except Exception as problem:  # an extra record must never cost the headline line
             records.append({"config": config, "error": repr(problem)})
-    if world > 1 and not args.same_device and extras:
+    if world > 1 and extras:
         fence()
         if rank == 0:  # single-process C driver over the same GPUs, while the other ranks wait
             for config in extras:
                 try:
-                    record = measure_c_node(config, list(range(world)), args)
+                    record = measure_c_node(config, [0] * world if args.same_device else list(range(world)), args)
                     if record is not None:
                         records.append(record)
                 except Exception as problem:
@@ -488,17 +519,24 @@ def main():
                                f"register-resident masks ({valu_where})",
                 "useful_fraction_of_width": round(float(profile.cells) / padded_cells, 4)}
         line = {
-            "metric": "DP cell-updates/s (GCUPS) on 1M-pair Levenshtein batch", "value": round(value, 1), "unit": "GCUPS",
+            "metric": "DP cell-updates/s (GCUPS) on 1M-pair Levenshtein batch" if args.config == 2 else f"DP cell-updates/s (GCUPS), {load.name}",
+            "value": round(value, 1), "unit": "GCUPS",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 bit-vectors (u64 results)",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {0: "u32 bit-vectors (u64 results)", 16: "i16 cells, two per VALU op (i64 results)", 32: "i32 cells (i64 results)",
+                      64: "i64 cells"}.get(int(profile.cell_bits), "u32"),
             "data": "synthetic",
             "config": {"workload": load.name, "pairs_per_gpu": rows * columns, "cells_per_gpu": int(profile.cells),
                        "sharding": "query row blocks, candidates replicated" if world > 1 else "single GPU",
                        "entry_point": ENTRY_POINTS[load.kind]},
             "roofline": line_roofline,
             "host_overhead_ms_per_step": round(ms_per_step - kernel * 1e3, 4),
+            "planner": {0: "host", 1: "device", 2: "device, launches speculated on the previous call's shape",
+                        3: "plan of the previous call re-used for the same tapes, validated in the kernels"}.get(int(profile.planner)),
             "results_checksum": float(checksum),
         }
+        if fresh is not None:
+            line["fresh_batches"] = fresh
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(load, gpu_matrix, args.cpu_seconds)
         if records:

@@ -46,9 +46,29 @@ typedef struct szs_string_ref_t {
  *  symmetric != 0: only cells with candidate.index <= query.index are scored, and mirrored.
  */
 unsigned szs_hip_levenshtein_myers_round_words(unsigned words);
+
+/**
+ *  Refs that were planned for an EARLIER call may be handed to the byte kernels again when the caller passes the same tapes
+ *  (same data and offsets pointers, same counts): with a guard, every workgroup checks its query ref and every lane its
+ *  candidate ref against the offsets AS THEY ARE NOW - `offsets[index + 1] - offsets[index] == length` and
+ *  `base + offsets[index] == address` - BEFORE touching the string.  A ref that no longer describes its string is not
+ *  dereferenced, nothing is written for it, and `*stale` (pinned host memory) receives `sequence`; the host then re-plans.
+ *  `side[0]` describes the tape of the kernel's queries, `side[1]` of its candidates.
+ */
+typedef struct szs_ref_guard_t {
+    uint32_t enabled, sequence;
+    uint32_t *stale;
+    struct {
+        void const *offsets;
+        uint64_t base;
+        uint32_t wide, count;
+    } side[2];
+} szs_ref_guard_t;
+
 int szs_hip_levenshtein_myers(unsigned words, szs_string_ref_t const *queries, uint32_t queries_count,
                               szs_string_ref_t const *candidates, uint32_t candidates_count, uint64_t *results,
-                              uint64_t results_row_stride, int symmetric, void *stream);
+                              uint64_t results_row_stride, int symmetric, szs_ref_guard_t const *guard /* may be NULL */,
+                              void *stream);
 
 /**
  *  Codepoint-level twin of the short-query bit-parallel kernel: strings are UTF-32 arrays (`address` points at `u32`
@@ -94,6 +114,7 @@ enum {
     szs_knob_cpu_requests_k, /* -1 / 0 strict: engines need sz_cap_cuda_k, CPU scopes are a mismatch | 1 ("gpu"): capability
                                 masks without the GPU bit and CPU scopes are served by the GPU engines on device 0 */
     szs_knob_streams_k,     /* -1 automatic | 0: every launch of a call on the scope's one stream */
+    szs_knob_reuse_k,       /* -1 automatic | 0: never re-use the refs planned for the previous call of the same tapes */
     szs_knob_count_k
 };
 int szs_tuning_get(int knob);

@@ -96,6 +96,21 @@ __device__ __forceinline__ void load_match_masks(u32 const *peq, u32 symbol, u32
     else { eq[0] = peq[symbol]; }
 }
 
+/** Does `ref` still describe string `ref.index` of its tape?  (szs_ref_guard_t, hip/kernels.h.) */
+__device__ __forceinline__ bool ref_is_current(szs_ref_guard_t const &guard, int side, szs_string_ref_t const &ref) {
+    if (ref.index >= guard.side[side].count) return false;
+    u64 from, to;
+    if (guard.side[side].wide) {
+        u64 const *offsets = static_cast<u64 const *>(guard.side[side].offsets);
+        from = offsets[ref.index], to = offsets[(u64)ref.index + 1];
+    }
+    else {
+        u32 const *offsets = static_cast<u32 const *>(guard.side[side].offsets);
+        from = offsets[ref.index], to = offsets[(u64)ref.index + 1];
+    }
+    return to >= from && to - from == ref.length && guard.side[side].base + from == ref.address;
+}
+
 /** One column of the DP matrix: consumes the match masks of one text byte and updates the vertical delta vectors. */
 template <int words_>
 __device__ __forceinline__ void myers_column(u32 (&vp)[words_], u32 (&vn)[words_], u32 const (&eq)[words_]) {
@@ -140,9 +155,13 @@ template <int words_, int text_dwords_, bool runes_>
 __device__ __forceinline__ void myers_workgroup(u32 *peq, u32 *keys, szs_string_ref_t const query,
                                                 szs_string_ref_t const *__restrict__ candidates, u32 candidates_count,
                                                 u32 candidate_block, u64 *__restrict__ results, u64 results_row_stride,
-                                                int symmetric) {
+                                                int symmetric, szs_ref_guard_t const &guard) {
     constexpr int rows = runes_ ? rune_slots_k : byte_rows_k;
     using layout = peq_layout<words_, rows>;
+    if (guard.enabled && !ref_is_current(guard, 0, query)) { // refs of an earlier call: this query's no longer holds - uniform
+        if (threadIdx.x == 0) *guard.stale = guard.sequence;
+        return;
+    }
     u32 const query_length = query.length;
     u32 const pad = 32u * words_ - query_length; // phantom low rows
 
@@ -179,6 +198,10 @@ __device__ __forceinline__ void myers_workgroup(u32 *peq, u32 *keys, szs_string_
     bool live = candidate_slot < candidates_count;
     szs_string_ref_t candidate = {0, 0, 0};
     if (live) candidate = candidates[candidate_slot];
+    if (live && guard.enabled && !ref_is_current(guard, 1, candidate)) { // a stale candidate ref is never dereferenced
+        *guard.stale = guard.sequence;
+        live = false;
+    }
     if ((symmetric & SZS_LAYOUT_SYMMETRIC) && candidate.index > query.index) live = false; // upper triangle: mirrored from below
     u32 const text_length = live ? candidate.length : 0;
     u32 const longest_in_wave = wave_max_u32(text_length);
@@ -320,12 +343,12 @@ __global__ __launch_bounds__(256, SZS_MYERS_LONG_WAVES) void levenshtein_myers_l
                                                                       szs_string_ref_t const *__restrict__ candidates,
                                                                       u32 candidates_count, u32 candidate_blocks,
                                                                       u64 *__restrict__ results, u64 results_row_stride,
-                                                                      int symmetric) {
+                                                                      int symmetric, szs_ref_guard_t guard) {
     __shared__ __attribute__((aligned(16))) u32 peq[peq_layout<words_>::total_dwords];
     u32 query_slot, candidate_block;
     myers_work_item(candidate_blocks, query_slot, candidate_block);
     myers_workgroup<words_, 1, false>(peq, nullptr, queries[query_slot], candidates, candidates_count, candidate_block,
-                                      results, results_row_stride, symmetric);
+                                      results, results_row_stride, symmetric, guard);
 }
 
 #ifndef SZS_MYERS_SHORT_WAVES
@@ -340,7 +363,7 @@ __global__ __launch_bounds__(256, SZS_MYERS_LONG_WAVES) void levenshtein_myers_l
 template <bool runes_>
 __global__ __launch_bounds__(256, SZS_MYERS_SHORT_WAVES) void levenshtein_myers_short_kernel(
     szs_string_ref_t const *__restrict__ queries, szs_string_ref_t const *__restrict__ candidates, u32 candidates_count,
-    u32 candidate_blocks, u64 *__restrict__ results, u64 results_row_stride, int symmetric) {
+    u32 candidate_blocks, u64 *__restrict__ results, u64 results_row_stride, int symmetric, szs_ref_guard_t guard) {
     __shared__ __attribute__((aligned(16))) u32 peq[peq_layout<8, runes_ ? rune_slots_k : byte_rows_k>::total_dwords];
     __shared__ u32 keys[runes_ ? rune_slots_k : 1];
     u32 query_slot, candidate_block;
@@ -351,7 +374,7 @@ __global__ __launch_bounds__(256, SZS_MYERS_SHORT_WAVES) void levenshtein_myers_
     case W:                                                                                                            \
         myers_workgroup<W, SZS_MYERS_SHORT_TEXT_DWORDS, runes_>(peq, keys, query, candidates, candidates_count,       \
                                                                 candidate_block, results, results_row_stride,         \
-                                                                symmetric);                                           \
+                                                                symmetric, guard);                                    \
         break;
     switch (words) {
         SZS_MYERS_BODY(1)
@@ -363,7 +386,7 @@ __global__ __launch_bounds__(256, SZS_MYERS_SHORT_WAVES) void levenshtein_myers_
         SZS_MYERS_BODY(7)
     default: // 8; the host never sends longer queries here
         myers_workgroup<8, SZS_MYERS_SHORT_TEXT_DWORDS, runes_>(peq, keys, query, candidates, candidates_count,
-                                                                candidate_block, results, results_row_stride, symmetric);
+                                                                candidate_block, results, results_row_stride, symmetric, guard);
         break;
     }
 #undef SZS_MYERS_BODY
@@ -787,14 +810,16 @@ static int launch_long_runes(szs_string_ref_t const *queries, u32 queries_count,
 template <typename kernel_t>
 static int launch_myers(kernel_t kernel, szs_string_ref_t const *queries, u32 queries_count,
                         szs_string_ref_t const *candidates, u32 candidates_count, u64 *results, u64 stride, int symmetric,
-                        hipStream_t stream) {
+                        szs_ref_guard_t const *guard_or_null, hipStream_t stream) {
+    szs_ref_guard_t guard = {};
+    if (guard_or_null) guard = *guard_or_null;
     u32 const candidate_blocks = (candidates_count + SZS_CANDIDATES_PER_WORKGROUP - 1) / SZS_CANDIDATES_PER_WORKGROUP;
     // Keep each grid under 2^30 workgroups; enormous cross-products are cut along the query axis.
     u32 const queries_per_launch = candidate_blocks ? (1u << 30) / candidate_blocks : queries_count;
     for (u32 first = 0; first < queries_count; first += queries_per_launch) {
         u32 const batch = queries_count - first < queries_per_launch ? queries_count - first : queries_per_launch;
         hipLaunchKernelGGL(kernel, dim3(batch * candidate_blocks), dim3(256), 0, stream, queries + first, candidates,
-                           candidates_count, candidate_blocks, results, stride, symmetric);
+                           candidates_count, candidate_blocks, results, stride, symmetric, guard);
         hipError_t const error = hipGetLastError();
         if (error != hipSuccess) return (int)error;
     }
@@ -805,18 +830,19 @@ static int launch_myers(kernel_t kernel, szs_string_ref_t const *queries, u32 qu
 
 extern "C" int szs_hip_levenshtein_myers(unsigned words, szs_string_ref_t const *queries, uint32_t queries_count,
                                          szs_string_ref_t const *candidates, uint32_t candidates_count,
-                                         uint64_t *results, uint64_t results_row_stride, int symmetric, void *stream) {
+                                         uint64_t *results, uint64_t results_row_stride, int symmetric,
+                                         szs_ref_guard_t const *guard, void *stream) {
     using namespace szs_hip;
     if (!queries_count || !candidates_count) return 0;
     hipStream_t const s = static_cast<hipStream_t>(stream);
 #define SZS_MYERS_CASE(W)                                                                                              \
     case W:                                                                                                            \
         return launch_myers(levenshtein_myers_long_kernel<W>, queries, queries_count, candidates, candidates_count,   \
-                            results, results_row_stride, symmetric, s);
+                            results, results_row_stride, symmetric, guard, s);
     switch (words) {
     case SZS_MYERS_SHORT_WORDS:
         return launch_myers(levenshtein_myers_short_kernel<false>, queries, queries_count, candidates, candidates_count, results,
-                            results_row_stride, symmetric, s);
+                            results_row_stride, symmetric, guard, s);
         SZS_MYERS_CASE(10)
         SZS_MYERS_CASE(12)
         SZS_MYERS_CASE(16)
@@ -837,7 +863,7 @@ extern "C" int szs_hip_levenshtein_myers_runes(szs_string_ref_t const *queries, 
     using namespace szs_hip;
     if (!queries_count || !candidates_count) return 0;
     return launch_myers(levenshtein_myers_short_kernel<true>, queries, queries_count, candidates, candidates_count, results,
-                        results_row_stride, symmetric, static_cast<hipStream_t>(stream));
+                        results_row_stride, symmetric, nullptr, static_cast<hipStream_t>(stream));
 }
 
 extern "C" size_t szs_hip_levenshtein_myers_banded_bytes(uint32_t queries_count, uint32_t candidates_count, uint32_t longest_candidate) {

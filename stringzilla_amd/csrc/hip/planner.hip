@@ -90,6 +90,20 @@ __global__ __launch_bounds__(plan_threads_k) void plan_kernel(szs_plan_side_t qu
 
     u32 const tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     int const sides = symmetric ? 1 : 2;
+    // The planner is a chain of dependent memory round trips, not of instructions: a load from HBM and back is a microsecond
+    // or two.  So every thread fetches the offsets of ITS first string of both sides up front - one round trip for the whole
+    // kernel when a side has at most 1024 strings - and all three passes read them from registers.
+    u64 first_from[2] = {0, 0}, first_to[2] = {0, 0};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        szs_plan_side_t const &side = s ? candidates : queries;
+        if (s < sides && tid < side.count)
+            first_from[s] = tape_offset(side.offsets, side.wide, tid), first_to[s] = tape_offset(side.offsets, side.wide, (u64)tid + 1);
+    }
+    auto span_of = [&](int s, szs_plan_side_t const &side, u32 i, u64 &from, u64 &to) {
+        if (i == tid) from = first_from[s], to = first_to[s];
+        else from = tape_offset(side.offsets, side.wide, i), to = tape_offset(side.offsets, side.wide, (u64)i + 1);
+    };
     // ---- pass 1: lengths and the statistics every decision is made from
     for (int s = 0; s < sides; ++s) {
         szs_plan_side_t const &side = s ? candidates : queries;
@@ -97,7 +111,8 @@ __global__ __launch_bounds__(plan_threads_k) void plan_kernel(szs_plan_side_t qu
 #pragma unroll
         for (int k = 0; k < plan_values_k; ++k) values[k] = 0;
         for (u32 i = tid; i < side.count; i += plan_threads_k) {
-            u64 const from = tape_offset(side.offsets, side.wide, i), to = tape_offset(side.offsets, side.wide, (u64)i + 1);
+            u64 from, to;
+            span_of(s, side, i, from, to);
             if (to < from) values[1] |= SZS_PLAN_STATUS_DESCENDING;
             u64 const wide_length = to < from ? 0 : to - from;
             if (wide_length > 0xFFFFFFFFull) values[1] |= SZS_PLAN_STATUS_OVERFLOW;
@@ -200,8 +215,11 @@ __global__ __launch_bounds__(plan_threads_k) void plan_kernel(szs_plan_side_t qu
         __syncthreads(); // the histogram of the previous side is done with
         for (u32 b = tid; b < bins; b += plan_threads_k) histogram[b] = 0;
         __syncthreads();
-        for (u32 i = tid; i < side.count; i += plan_threads_k)
-            atomicAdd(&histogram[(u32)(tape_offset(side.offsets, side.wide, (u64)i + 1) - tape_offset(side.offsets, side.wide, i))], 1u);
+        for (u32 i = tid; i < side.count; i += plan_threads_k) {
+            u64 from, to;
+            span_of(s, side, i, from, to);
+            atomicAdd(&histogram[(u32)(to - from)], 1u);
+        }
         __syncthreads();
         u32 const chunk = (bins + plan_threads_k - 1) / plan_threads_k;
         u32 const first_bin = tid * chunk, last_bin = first_bin + chunk < bins ? first_bin + chunk : bins;
@@ -215,8 +233,9 @@ __global__ __launch_bounds__(plan_threads_k) void plan_kernel(szs_plan_side_t qu
         }
         __syncthreads();
         for (u32 i = tid; i < side.count; i += plan_threads_k) {
-            u64 const from = tape_offset(side.offsets, side.wide, i);
-            u32 const length = (u32)(tape_offset(side.offsets, side.wide, (u64)i + 1) - from);
+            u64 from, to;
+            span_of(s, side, i, from, to);
+            u32 const length = (u32)(to - from);
             u32 const position = atomicAdd(&histogram[length], 1u); // equal lengths: any order scores the same matrix
             szs_string_ref_t ref;
             ref.address = side.base + from, ref.length = blank ? 0u : length, ref.index = i;

@@ -80,16 +80,21 @@ struct packed_costs_t {
     u32 pairs[packed_registers_k];
 };
 
-/** Layout [chunk of 4 registers][class pair][4 registers]: one ds_read_b128 per chunk, and within one instruction the 64
- *  lanes' addresses differ by multiples of 16 B, i.e. spread over all bank groups.  Round 1 kept a pair's 16 registers
- *  together (64-byte rows): every lane of an instruction then hit one of only two (four) bank groups and the LDS was busy
- *  89 % of config 3's kernel time, 72 % of it in conflicts (profiles/r02/pmc_configs.json). */
+/** Two layouts of the pair profile.
+ *  chunk-major  [chunk of 4 registers][class pair][4 registers]: within one ds_read_b128 the 64 lanes' addresses differ by
+ *               multiples of 16 B and spread over all bank groups.  Round 1 kept a pair's 16 registers together (64-byte
+ *               rows): every lane of an instruction then hit one of only two (four) bank groups and the LDS was busy 89 % of
+ *               config 3's kernel time, 72 % of it in conflicts (profiles/r02/pmc_configs.json); chunk-major: 25.0 -> 23.0 ms.
+ *  pair-major   [class pair][16 registers]: one address, four immediate offsets - three VALU additions fewer per step.  The
+ *               affine kernels do twice the arithmetic per LDS byte and are bound by VALU issue (LDS busy 29 %): they keep it
+ *               (config 4: 793 ms pair-major, 809 ms chunk-major). */
+template <bool chunk_major_>
 __device__ __forceinline__ packed_costs_t load_packed_costs(u32 const *profile, u32 class_pair, u32 class_pairs) {
-    uint4 const *rows = reinterpret_cast<uint4 const *>(profile) + class_pair;
+    uint4 const *rows = reinterpret_cast<uint4 const *>(profile) + (chunk_major_ ? class_pair : class_pair * (packed_registers_k / 4));
     packed_costs_t costs;
 #pragma unroll
     for (int chunk = 0; chunk < packed_registers_k / 4; ++chunk) {
-        uint4 const part = rows[chunk * class_pairs];
+        uint4 const part = rows[chunk_major_ ? chunk * class_pairs : chunk];
         costs.pairs[4 * chunk + 0] = part.x, costs.pairs[4 * chunk + 1] = part.y;
         costs.pairs[4 * chunk + 2] = part.z, costs.pairs[4 * chunk + 3] = part.w;
     }
@@ -157,6 +162,7 @@ __global__ __launch_bounds__(256, affine_ ? SZS_PACKED_AFFINE_WAVES : 4) void we
     __shared__ u32 claimed_work;
 
     u32 const class_slots = classes + 1, null_class = classes; // the null symbol costs 0 against every row
+    constexpr bool chunk_major = !affine_;                      // layout of the pair profile: see load_packed_costs
     i32 const gap_open = model->gap_open, gap_extend = model->gap_extend;
     pk_i16 const open_pk = saturating_ ? pk_pair(-gap_open, -gap_open) : pk_pair(gap_open, gap_open);
     pk_i16 const extend_pk = saturating_ ? pk_pair(-gap_extend, -gap_extend) : pk_pair(gap_extend, gap_extend);
@@ -220,10 +226,10 @@ __global__ __launch_bounds__(256, affine_ ? SZS_PACKED_AFFINE_WAVES : 4) void we
                     i32 const lower = lower_row != 0xFF && lower_class != null_class ? table[lower_row * 32 + lower_class] : 0;
                     packed[r] = ((u32)upper & 0xFFFFu) | ((u32)lower << 16);
                 }
-                uint4 *const mine = reinterpret_cast<uint4 *>(pair_profile) + pair;
+                uint4 *const mine = reinterpret_cast<uint4 *>(pair_profile) + (chunk_major ? pair : pair * (registers / 4));
 #pragma unroll
                 for (int chunk = 0; chunk < registers / 4; ++chunk)
-                    mine[chunk * class_slots * class_slots] = make_uint4(packed[4 * chunk], packed[4 * chunk + 1], packed[4 * chunk + 2], packed[4 * chunk + 3]);
+                    mine[chunk_major ? chunk * class_slots * class_slots : chunk] = make_uint4(packed[4 * chunk], packed[4 * chunk + 1], packed[4 * chunk + 2], packed[4 * chunk + 3]);
             }
             __syncthreads();
 
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(256, affine_ ? SZS_PACKED_AFFINE_WAVES : 4) void we
 
             // One step for this lane: A scores DP column `j` (symbol class `upper_class`), B scores column j - 1.
             auto step = [&](u32 upper_class, i32 above_h, i32 above_down) {
-                packed_costs_t const costs = load_packed_costs(pair_profile, upper_class * class_slots + previous_class, class_slots * class_slots);
+                packed_costs_t const costs = load_packed_costs<chunk_major>(pair_profile, upper_class * class_slots + previous_class, class_slots * class_slots);
                 previous_class = upper_class;
                 // hand-over: A's last row at column j - 1 (low half of register 15, before this step) becomes B's row above
                 pk_i16 const above_pk = pk_bits((pk_raw(column.h[registers - 1]) << 16) | ((u32)above_h & 0xFFFFu));

@@ -429,6 +429,7 @@ static sz_status_t prepare(szs_engine_s *engine, szs_decision_t const *d, int de
 /** Launches of one decision over device refs in kernel roles.  Returns the first launch error; counts launches. */
 static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int device, szs_string_ref_t const *query_refs,
                           szs_string_ref_t const *candidate_refs, void *device_results, size_t device_stride, hipStream_t stream,
+                          szs_ref_guard_t const *guard /* refs of an earlier call: validate in the kernels; else NULL */,
                           uint32_t *launches, uint32_t *cell_bits, sz_status_t *status, char const **error_message) {
     int launch_error = 0;
     szs_cost_model_t const *const model = (szs_cost_model_t const *)engine->device_model.pointer;
@@ -513,7 +514,7 @@ static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int dev
             }
             else if (group->variant)
                 launch_error = szs_hip_levenshtein_myers(group->variant, queries, count, candidate_refs, d->kc_count, (uint64_t *)device_results,
-                                                         device_stride, d->layout, target);
+                                                         device_stride, d->layout, guard, target);
             else if (d->banded)
                 launch_error = szs_hip_levenshtein_myers_banded(queries, count, candidate_refs, d->kc_count, d->plan.longest_candidate,
                                                                 (uint64_t *)device_results, device_stride, d->layout,
@@ -621,7 +622,10 @@ static sz_status_t finish(szs_call_t *call, szs_decision_t const *d, hipError_t 
         fprintf(stderr, "szs call: %.1f us = setup %.1f + plan %.1f + prepare %.1f + launch %.1f + wait %.1f + wrap %.1f | kernel %.1f us | %s\n",
                 profile->host_milliseconds * 1e3, call->phases[0] * 1e3, call->phases[1] * 1e3, call->phases[2] * 1e3,
                 call->phases[3] * 1e3, call->phases[4] * 1e3, call->phases[5] * 1e3, kernel_ms * 1e3,
-                profile->planner == 2 ? "device-planned, speculated" : profile->planner == 1 ? "device-planned" : "host-planned");
+                profile->planner == 3   ? "previous plan of the same tapes, validated in the kernels"
+                : profile->planner == 2 ? "device-planned, speculated"
+                : profile->planner == 1 ? "device-planned"
+                                        : "host-planned");
     return szs_report(sz_success_k, call->error_message, NULL);
 }
 
@@ -643,6 +647,14 @@ static sz_status_t place_results(szs_call_t *call) {
 }
 
 /* ---- device-planned calls ---------------------------------------------------------------------------------------------- */
+
+/** The refs on the device are the complete plan of exactly these tapes: remember what they were planned from. */
+static void stamp_refs(szs_decision_t *remembered, void const *const data[2], void const *const offsets[2], int const wide[2],
+                       szs_plan_summary_t const *summary) {
+    for (int s = 0; s < 2; ++s) remembered->key_data[s] = data[s], remembered->key_offsets[s] = offsets[s], remembered->key_wide[s] = wide[s];
+    remembered->summary = *summary;
+    remembered->refs_current = 1;
+}
 
 #define SZS_PLAN_DEVICE_MOST_STRINGS (1u << 18) /* per side; one workgroup plans, so larger batches go to the host planner */
 #define SZS_NOT_DEVICE_PLANNABLE ((sz_status_t)1) /* internal: take the host-planned path instead */
@@ -686,12 +698,58 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
     if (status != sz_success_k) return status;
     phase(call, 0);
 
-    /* ---- speculate: launches shaped like the previous call go in right behind the planner */
     hipError_t error = hipSuccess;
+    int const knobs_automatic = szs_tuning_get(szs_knob_speculate_k) != 0 && szs_tuning_get(szs_knob_tier_k) < 0 &&
+                                szs_tuning_get(szs_knob_swap_k) < 0 && szs_tuning_get(szs_knob_cells_k) < 0 && szs_tuning_get(szs_knob_packed_k) < 0;
+    void const *const key_data[2] = {call->queries->data, symmetric ? call->queries->data : call->candidates->data};
+    void const *const key_offsets[2] = {call->queries->offsets, symmetric ? call->queries->offsets : call->candidates->offsets};
+    int const key_wide[2] = {(int)q_side.wide, (int)c_side.wide};
+
+    /* ---- the same tapes again?  The refs planned for them are still on the device: no planner at all.  Every workgroup
+     * and lane of the byte kernels checks its ref against the offsets as they are NOW before it touches a string
+     * (hip/kernels.h: szs_ref_guard_t), so a tape that was rewritten in place, freed or reallocated costs one re-plan, never a
+     * wrong score or a stray read.  Only launches whose kernels carry the guard take this path: unit-cost byte queries of
+     * up to 2048 bytes - the calls short enough for 25 us of planning to matter. */
+    if (remembered->valid && remembered->refs_current && knobs_automatic && szs_tuning_get(szs_knob_reuse_k) != 0 &&
+        remembered->tier == SZS_TIER_LANES && remembered->use_myers && !remembered->runes && !remembered->wide_cells &&
+        !has_group_of_variant_zero(remembered) && remembered->q_count == q_count && remembered->c_count == c_count &&
+        remembered->symmetric == symmetric && remembered->key_data[0] == key_data[0] && remembered->key_data[1] == key_data[1] &&
+        remembered->key_offsets[0] == key_offsets[0] && remembered->key_offsets[1] == key_offsets[1] &&
+        remembered->key_wide[0] == key_wide[0] && remembered->key_wide[1] == key_wide[1]) {
+        szs_decision_t const *d = remembered;
+        uint32_t volatile *const stale = (uint32_t volatile *)((char *)engine->pinned_summary.pointer + 768);
+        szs_ref_guard_t guard;
+        memset(&guard, 0, sizeof(guard));
+        guard.enabled = 1, guard.sequence = ++engine->plan_sequence, guard.stale = (uint32_t *)stale;
+        for (int role = 0; role < 2; ++role) { /* kernel roles: 0 = its queries, 1 = its candidates */
+            szs_plan_side_t const *side = (role == 0) == (d->transposed == 0) ? &q_side : &c_side;
+            if (symmetric) side = &q_side;
+            guard.side[role].offsets = side->offsets, guard.side[role].base = side->base;
+            guard.side[role].wide = side->wide, guard.side[role].count = side->count;
+        }
+        *stale = 0;
+        status = prepare(engine, d, device, stream, error_message);
+        if (status != sz_success_k) return status;
+        phase(call, 2);
+        uint32_t launches = 0, cell_bits = 0;
+        sz_status_t enqueue_status = sz_success_k;
+        error = hipEventRecord(engine->event_start, stream);
+        szs_string_ref_t const *const query_refs = d->transposed ? c_side.descending : q_side.descending;
+        szs_string_ref_t const *const candidate_refs = d->transposed ? q_side.ascending : c_side.ascending;
+        if (error == hipSuccess)
+            error = enqueue(engine, d, device, query_refs, candidate_refs, call->device_results, call->device_stride, stream, &guard, &launches,
+                            &cell_bits, &enqueue_status, error_message);
+        int stalled = 0;
+        engine->last_profile.planner = 3;
+        status = finish(call, d, error, enqueue_status, launches, cell_bits, d->summary.side[0].symbols, d->summary.side[1].symbols, &stalled);
+        if (status != sz_success_k) return status;
+        if (*stale != guard.sequence) return sz_success_k; /* every ref still described its string: scored */
+        remembered->refs_current = 0;                      /* the tapes changed under the same pointers: plan them afresh */
+    }
+
+    /* ---- speculate: launches shaped like the previous call go in right behind the planner */
     int const speculate = remembered->valid && remembered->tier == SZS_TIER_LANES && remembered->q_count == q_count &&
-                          remembered->c_count == c_count && remembered->symmetric == symmetric &&
-                          szs_tuning_get(szs_knob_speculate_k) != 0 && szs_tuning_get(szs_knob_tier_k) < 0 &&
-                          szs_tuning_get(szs_knob_swap_k) < 0 && szs_tuning_get(szs_knob_cells_k) < 0 && szs_tuning_get(szs_knob_packed_k) < 0;
+                          remembered->c_count == c_count && remembered->symmetric == symmetric && knobs_automatic;
     szs_plan_summary_t seen;
     int have_summary = 0;
     if (speculate) {
@@ -706,6 +764,7 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
         if (status != sz_success_k) return status;
         phase(call, 2);
         uint32_t launches = 0, cell_bits = 0;
+        remembered->refs_current = 0; /* the planner is about to overwrite the refs */
         error = (hipError_t)szs_hip_plan(&q_side, symmetric ? NULL : &c_side, myers_words, &expected, (szs_plan_summary_t *)summary, stream);
         if (error != hipSuccess) return szs_report_hip(error, error_message); /* nothing enqueued yet */
         error = hipEventRecord(engine->event_start, stream);
@@ -713,7 +772,7 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
         szs_string_ref_t const *const candidate_refs = d->transposed ? q_side.ascending : c_side.ascending;
         sz_status_t enqueue_status = sz_success_k;
         if (error == hipSuccess)
-            error = enqueue(engine, d, device, query_refs, candidate_refs, call->device_results, call->device_stride, stream, &launches,
+            error = enqueue(engine, d, device, query_refs, candidate_refs, call->device_results, call->device_stride, stream, NULL, &launches,
                             &cell_bits, &enqueue_status, error_message);
         /* the summary is read after the wait inside finish(); profile numbers come from it, so finish() runs on a copy of
          * the decision whose statistics are filled in afterwards - do the wait here instead */
@@ -733,12 +792,14 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
                                                     : (uint64_t)c_count * seen.side[0].symbols + (uint64_t)q_count * seen.side[1].symbols) + pairs * 16;
             profile->unique_bytes += seen.side[0].symbols + (symmetric ? 0 : seen.side[1].symbols);
             profile->longest_query = seen.side[0].longest, profile->longest_candidate = seen.side[1].longest;
+            stamp_refs(remembered, key_data, key_offsets, key_wide, &seen);
             return szs_report(sz_success_k, error_message, NULL);
         }
         /* the shape changed (or the offsets are malformed): the refs were blanked, nothing real was scored */
     }
 
     /* ---- plan, wait, decide, launch */
+    remembered->refs_current = 0;
     if (!have_summary) {
         szs_plan_expectation_t none;
         memset(&none, 0, sizeof(none));
@@ -778,14 +839,15 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
         szs_string_ref_t const *const candidate_refs = d.transposed ? q_side.ascending : c_side.ascending;
         sz_status_t enqueue_status = sz_success_k;
         if (error == hipSuccess)
-            error = enqueue(engine, &d, device, query_refs, candidate_refs, call->device_results, call->device_stride, stream, &launches,
+            error = enqueue(engine, &d, device, query_refs, candidate_refs, call->device_results, call->device_stride, stream, NULL, &launches,
                             &cell_bits, &enqueue_status, error_message);
         int stalled = 0;
         engine->last_profile.planner = 1;
         status = finish(call, &d, error, enqueue_status, launches, cell_bits, seen.side[0].symbols, seen.side[1].symbols, &stalled);
         if (status != sz_success_k) return status;
         if (!stalled) {
-            *remembered = d; /* the next call of this shape goes in speculatively */
+            *remembered = d; /* the next call of this shape goes in speculatively - or, on the same tapes, without a planner */
+            stamp_refs(remembered, key_data, key_offsets, key_wide, &seen);
             return sz_success_k;
         }
     }
@@ -926,7 +988,7 @@ static sz_status_t cross_host_planned(szs_call_t *call) {
         if (error == hipSuccess) error = hipEventRecord(engine->event_start, stream);
         if (error == hipSuccess)
             error = enqueue(engine, &d, device, device_query_refs, device_candidate_refs, call->device_results, call->device_stride, stream,
-                            &launches, &cell_bits, &enqueue_status, error_message);
+                            NULL, &launches, &cell_bits, &enqueue_status, error_message);
         int stalled = 0;
         engine->last_profile.planner = 0;
         status = finish(call, &d, error, enqueue_status, launches, cell_bits, query_bytes, candidate_bytes, &stalled);

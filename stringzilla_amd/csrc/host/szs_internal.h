@@ -194,6 +194,11 @@ typedef struct szs_decision_t {
     szs_plan_t plan;             /* kernel roles: groups of the query side, longest strings, cells */
     size_t systolic_control_bytes, systolic_parked_bytes;
     uint32_t variant_counts[SZS_PLAN_VARIANTS]; /* of the kernels' query side */
+    /* what the refs on the device were planned FROM (device-planned calls): the key of the guarded re-use, dispatch.c */
+    int refs_current;          /* engine->device_plan_refs holds the complete plan of exactly these tapes */
+    void const *key_data[2], *key_offsets[2];
+    int key_wide[2];
+    szs_plan_summary_t summary; /* of that plan: the call profile is filled from it */
 } szs_decision_t;
 
 /**

@@ -31,6 +31,7 @@ static struct {
     [szs_knob_speculate_k] = {"speculate", "SZS_ROCM_SPECULATE"},
     [szs_knob_cpu_requests_k] = {"cpu_requests", "SZS_ROCM_CPU_REQUESTS"},
     [szs_knob_streams_k] = {"streams", "SZS_ROCM_STREAMS"},
+    [szs_knob_reuse_k] = {"reuse", "SZS_ROCM_REUSE"},
 };
 
 /** Text -> value.  -1 always means "automatic".  Tier names: lanes 0, systolic 1, chain 2; planner: host 0, device 1. */

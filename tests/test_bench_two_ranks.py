@@ -1,0 +1,57 @@
+"""`-m gpu`: bench.py's N > 1 code path on a one-GPU box - two real ranks under `torch.distributed.run`, both on cuda:0
+(`--same-device --backend gloo`): the weak-scaled headline, the strong-scaled records of configs 4 and 5 (rows dealt by LPT
+over the ranks, tapes broadcast and kept where the collective delivered them) and the single-process C entry
+(`szs_rocm_node_*`) over the same "GPUs".  The numbers of such a run mean nothing; the checksums must equal a plain
+single-GPU computation of the same (scaled) batches."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_ranks_on_one_device():
+    import stringzilla_amd as szs
+    from stringzilla_amd import matrices, workloads
+
+    scale = 1 / 8
+    command = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+               "--backend", "gloo", "--same-device", "--extra-scale", str(scale), "--extra-seconds", "0.2"]
+    done = subprocess.run(command, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert done.returncode == 0, done.stdout[-3000:] + done.stderr[-3000:]
+    line = json.loads([text for text in done.stdout.splitlines() if text.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["config"]["pairs_per_gpu"] == 1024 * 1024
+
+    gpu = szs.DeviceScope(gpu_device=0)
+    expected = {}
+    for config in (4, 5):
+        load = workloads.config(config, scale=scale)
+        if load.kind == "levenshtein":
+            engine = szs.LevenshteinDistances(**load.costs, capabilities=gpu)
+        else:
+            engine = szs.SmithWatermanScores(*matrices.by_name(load.table), **load.costs, capabilities=gpu)
+        expected[config] = (int(engine(load.queries, load.candidates, device=gpu).view(np.int64).sum()), load.cells, len(load.queries))
+    records = line["configs"]
+    strong = {record["config"]: record for record in records if record.get("scaling") == "strong" and "sharding" in record}
+    node = {record["config"]: record for record in records if record.get("entry_point", "").startswith("szs_rocm_node")}
+    for config in (4, 5):
+        checksum, cells, rows = expected[config]
+        assert "error" not in strong[config] and "error" not in node[config], (strong[config], node[config])
+        assert strong[config]["results_checksum"] == checksum and strong[config]["cells"] == cells
+        assert sum(strong[config]["rows_per_gpu"]) == rows and len(strong[config]["busy_ms_per_gpu"]) == 2
+        assert strong[config]["imbalance_max_over_mean"] >= 1.0
+        assert node[config]["results_checksum"] == checksum and sum(node[config]["rows_per_gpu"]) == rows

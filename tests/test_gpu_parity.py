@@ -429,28 +429,45 @@ def test_config2_full_size_properties(gpu, oracle):
     assert engine.last_call_profile().pairs == 1024 * 1025 // 2
 
 
-@pytest.mark.parametrize("index,sampled_pairs", [(3, 400), (4, 24), (5, 300), (6, 300)])
-def test_full_size_configs_sampled(gpu, oracle, index, sampled_pairs):
-    """Configs 3, 4, 5 (and 5 at the codepoint level) at BASELINE.json's FULL size: the whole matrix is computed on the
-    GPU, a random sample of its cells is recomputed by the CPU oracle as 1 x 1 problems, and size-independent properties
-    are checked on all of it (symmetric tables => the transposed call is the transposed matrix; bounds)."""
+@pytest.mark.parametrize("index", [3, 4, 5, 6])
+def test_full_size_configs_whole_rows(gpu, oracle, index):
+    """Configs 3, 4, 5 (and 5 at the codepoint level) at BASELINE.json's FULL size: the whole matrix is computed on the GPU
+    and WHOLE ROWS of it - the longest, the shortest and the median query, and three more at random, each against EVERY
+    candidate - are recomputed on the CPU: every lane position of every candidate block and every strip phase of the
+    kernels is covered at the sizes the configs name (the reference checks every timed batch the same way,
+    bench/similarities.cuh:410-423).  The checker is the reference's own engine (oracle/_ref, all host threads) when it is
+    built, the plain-C oracle otherwise; the candidates take the row role there so that the threads have rows to share
+    (all tables and costs of these configs are symmetric).  Size-independent properties are checked on all of it."""
+    import os
+
+    from oracle import binding
+
     load = workloads.config(index)
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    checker = binding.reference(tier=binding.reference_best_tier(), threads=threads) if binding.reference_available() else oracle
     if load.kind in ("levenshtein", "levenshtein_utf8"):
         cls = szs.LevenshteinDistances if load.kind == "levenshtein" else szs.LevenshteinDistancesUTF8
         engine = cls(**load.costs, capabilities=gpu)
-        scorer = oracle.levenshtein if load.kind == "levenshtein" else oracle.levenshtein_utf8
-        one = lambda q, c: int(scorer([q], [c], **load.costs)[0, 0])
+        scorer = checker.levenshtein if load.kind == "levenshtein" else checker.levenshtein_utf8
+        score = lambda rows, columns: scorer(rows, columns, **load.costs)
     else:
         table = matrices.by_name(load.table)
         cls = szs.NeedlemanWunschScores if load.kind == "needleman_wunsch" else szs.SmithWatermanScores
         engine = cls(*table, **load.costs, capabilities=gpu)
-        one = lambda q, c: int(getattr(oracle, load.kind)([q], [c], *table, load.costs["open"], load.costs["extend"])[0, 0])
+        score = lambda rows, columns: getattr(checker, load.kind)(rows, columns, *table, load.costs["open"], load.costs["extend"])
     matrix = engine(load.queries, load.candidates, device=gpu)
     assert matrix.shape == (len(load.queries), len(load.candidates))
+
+    lengths = load.queries.lengths()
+    order = np.argsort(lengths, kind="stable")
     rng = np.random.default_rng(index)
-    for q, c in zip(rng.integers(0, len(load.queries), sampled_pairs), rng.integers(0, len(load.candidates), sampled_pairs)):
-        assert int(matrix[q, c]) == one(load.queries[int(q)], load.candidates[int(c)]), (load.name, int(q), int(c))
-    if index != 4:  # config 4's transposed call is another 1.3 s of GPU time for no new code path
+    picked = {int(order[-1]), int(order[0]), int(order[len(order) // 2])} | {int(i) for i in rng.integers(0, len(lengths), 3)}
+    picked = sorted(picked)
+    candidates = [load.candidates[i] for i in range(len(load.candidates))]
+    expected = score(candidates, [load.queries[i] for i in picked])  # (candidates x picked rows): transposed roles
+    assert np.array_equal(matrix[picked].view(np.int64), expected.T.view(np.int64)), load.name
+
+    if index != 4:  # config 4's transposed call is another second of GPU time for no new code path
         assert np.array_equal(engine(load.candidates, load.queries, device=gpu), matrix.T)
     if load.kind == "smith_waterman":
         shortest = np.minimum(load.queries.lengths()[:, None], load.candidates.lengths()[None, :])

@@ -70,8 +70,16 @@ def test_device_and_host_planners_score_the_same_matrices(gpu, oracle):
         assert engine.last_call_profile().planner == 1, name  # planned on the device, nothing to speculate on yet
         assert np.array_equal(first, expected), name
         second = engine(q, c, device=gpu).view(np.int64)
-        assert engine.last_call_profile().planner == 2, name  # launches went in behind the planner
+        profile = engine.last_call_profile()
+        # lanes tier: the same tapes again need no planner when the kernels can validate the refs themselves (unit-cost
+        # bytes); otherwise the launches go in behind the planner
+        assert profile.planner == ((3 if name == "lev_unit" else 2) if profile.tier == 0 else 1), name
         assert np.array_equal(second, expected), name
+        with knob("reuse", "0"):
+            again = engine(q, c, device=gpu).view(np.int64)
+            profile = engine.last_call_profile()
+            assert profile.planner == (2 if profile.tier == 0 else 1), name
+        assert np.array_equal(again, expected), name
         with knob("planner", "host"):
             third = engine(q, c, device=gpu).view(np.int64)
             assert engine.last_call_profile().planner == 0, name
@@ -104,7 +112,68 @@ def test_speculation_survives_a_change_of_shape(gpu, oracle):
     assert planners[0] == 1 and 1 in planners[1:]  # at least one speculation was refused and re-planned
     # the same batch twice in a row is speculated
     again = engine(queries, candidates, device=gpu)
-    assert engine.last_call_profile().planner == 2 and np.array_equal(again, oracle.levenshtein(queries, candidates))
+    assert engine.last_call_profile().planner in (2, 3) and np.array_equal(again, oracle.levenshtein(queries, candidates))
+
+
+def test_reused_plans_notice_tapes_rewritten_in_place(gpu, oracle):
+    """The same device buffers, call after call, with their CONTENTS changing underneath: bytes only (the plan still holds),
+    a boundary moved between two strings, every string shortened, the whole tape re-packed.  The kernels validate the refs
+    of the previous plan against the offsets as they are now; whatever they find, the call returns the right matrix."""
+    import torch
+
+    rng = random.Random(17)
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+
+    def pack(strings, capacity):
+        offsets = np.zeros(len(strings) + 1, dtype=np.int32)
+        np.cumsum([len(s) for s in strings], out=offsets[1:])
+        data = np.zeros(capacity, dtype=np.uint8)
+        blob = np.frombuffer(b"".join(strings), dtype=np.uint8)
+        data[:blob.size] = blob
+        return data, offsets
+
+    queries = _strings(rng, 30, 20, 200)
+    candidates = _strings(rng, 300, 20, 200)
+    capacity_q, capacity_c = 30 * 200 + 64, 300 * 200 + 64
+    q_data, q_offsets = (torch.from_numpy(a).cuda() for a in pack(queries, capacity_q))
+    c_data, c_offsets = (torch.from_numpy(a).cuda() for a in pack(candidates, capacity_c))
+    q_tape = _abi.U32Tape(q_data.data_ptr(), q_offsets.data_ptr(), len(queries))
+    c_tape = _abi.U32Tape(c_data.data_ptr(), c_offsets.data_ptr(), len(candidates))
+    results = torch.empty((len(queries), len(candidates)), dtype=torch.int64, device="cuda")
+    error = ctypes.c_char_p()
+
+    def score_and_check(q_strings, c_strings):
+        results.fill_(-1)
+        status = _abi.lib.szs_levenshtein_distances_u32tape(engine.handle, gpu.handle, ctypes.byref(q_tape), ctypes.byref(c_tape),
+                                                            results.data_ptr(), len(c_strings), ctypes.byref(error))
+        assert status == 0, error.value
+        assert np.array_equal(results.cpu().numpy().view(np.uint64), oracle.levenshtein(q_strings, c_strings))
+        return engine.last_call_profile().planner
+
+    assert score_and_check(queries, candidates) == 1
+    assert score_and_check(queries, candidates) == 3                       # same tapes: the plan is re-used
+    # new bytes, same lengths: the plan still describes the tapes
+    candidates = [bytes(rng.choice(b"ACGT") for _ in s) for s in candidates]
+    c_data.copy_(torch.from_numpy(pack(candidates, capacity_c)[0]).cuda())
+    assert score_and_check(queries, candidates) == 3
+    # one boundary moves: two candidate refs are stale
+    joined = candidates[7] + candidates[8]
+    candidates[7], candidates[8] = joined[:5], joined[5:]
+    c_offsets.copy_(torch.from_numpy(pack(candidates, capacity_c)[1]).cuda())
+    assert score_and_check(queries, candidates) != 3
+    assert score_and_check(queries, candidates) == 3
+    # every query shortened: every query ref is stale, and would over-read if it were trusted
+    queries = [s[: max(1, len(s) // 3)] for s in queries]
+    data, offsets = pack(queries, capacity_q)
+    q_data.copy_(torch.from_numpy(data).cuda()), q_offsets.copy_(torch.from_numpy(offsets).cuda())
+    assert score_and_check(queries, candidates) != 3
+    # both tapes re-packed with other strings of other lengths
+    queries, candidates = _strings(rng, 30, 0, 190), _strings(rng, 300, 0, 190)
+    for tensors, strings, capacity in ((q_data, q_offsets), queries, capacity_q), ((c_data, c_offsets), candidates, capacity_c):
+        data, offsets = pack(strings, capacity)
+        tensors[0].copy_(torch.from_numpy(data).cuda()), tensors[1].copy_(torch.from_numpy(offsets).cuda())
+    assert score_and_check(queries, candidates) != 3
+    assert score_and_check(queries, candidates) == 3
 
 
 def test_device_planner_formats(gpu, oracle):
@@ -290,3 +359,50 @@ def test_node_probe_from_plain_c():
             assert done.returncode == 0, (family, gpus, done.stdout, done.stderr)
             report = json.loads(done.stdout.strip().splitlines()[-1])
             assert report["mismatches"] == 0 and report["gpus"] == len(gpus)
+
+
+# ---- 64-bit tapes at scale: offsets beyond 2^32 (reference stringzillas.h:83-92) -------------------------------------------
+
+
+@pytest.mark.parametrize("planner", ["device", "host"])
+def test_u64_tape_with_offsets_beyond_4_gib(gpu, oracle, planner):
+    """A `sz_sequence_u64tape_t` over a 4.5 GB buffer whose strings all start beyond byte 2^32 - a corpus that does not fit
+    a 32-bit tape.  5 GB of HBM is nothing on a 288 GB part; the strings themselves are small, so the oracle checks every
+    cell.  Both planners, every engine family that reads a tape."""
+    import torch
+
+    rng = random.Random(13)
+    base = (1 << 32) + 12345
+    strings = _strings(rng, 40, 0, 300, b"ACGT")
+    lengths = np.array([len(s) for s in strings], dtype=np.uint64)
+    offsets = np.zeros(len(strings) + 1, dtype=np.uint64)
+    offsets[0] = base
+    np.cumsum(lengths, out=offsets[1:])
+    offsets[1:] += np.uint64(base)
+    data = torch.empty(base + int(lengths.sum()) + 64, dtype=torch.uint8, device="cuda")  # contents below 2^32 never read
+    payload = torch.from_numpy(np.frombuffer(b"".join(strings), dtype=np.uint8).copy()).cuda()
+    data[base:base + payload.numel()] = payload
+    device_offsets = torch.from_numpy(offsets.view(np.int64)).cuda()
+    tape = _abi.U64Tape(data.data_ptr(), device_offsets.data_ptr(), len(strings))
+    results = torch.empty((len(strings), len(strings)), dtype=torch.int64, device="cuda")
+    error = ctypes.c_char_p()
+    nuc = matrices.nuc44()
+    cases = [
+        (szs.LevenshteinDistances(capabilities=gpu), _abi.lib.szs_levenshtein_distances_u64tape, oracle.levenshtein(strings, strings)),
+        (szs.LevenshteinDistancesUTF8(capabilities=gpu), _abi.lib.szs_levenshtein_distances_utf8_u64tape,
+         oracle.levenshtein_utf8(strings, strings)),
+        (szs.NeedlemanWunschScores(*nuc, open=-4, extend=-1, capabilities=gpu), _abi.lib.szs_needleman_wunsch_scores_u64tape,
+         oracle.needleman_wunsch(strings, strings, *nuc, -4, -1)),
+        (szs.SmithWatermanScores(*nuc, open=-4, extend=-1, capabilities=gpu), _abi.lib.szs_smith_waterman_scores_u64tape,
+         oracle.smith_waterman(strings, strings, *nuc, -4, -1)),
+    ]
+    with knob("planner", planner):
+        for engine, call, expected in cases:
+            for candidates in (tape, None):  # rectangular call, then the symmetric one
+                results.fill_(-1)
+                status = call(engine.handle, gpu.handle, ctypes.byref(tape), None if candidates is None else ctypes.byref(candidates),
+                              results.data_ptr(), len(strings), ctypes.byref(error))
+                assert status == 0, error.value
+                assert np.array_equal(results.cpu().numpy(), expected.view(np.int64))
+    del data
+    torch.cuda.empty_cache()
