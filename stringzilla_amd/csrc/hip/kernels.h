@@ -99,6 +99,17 @@ int szs_hip_levenshtein_myers_runes_long(unsigned words, szs_string_ref_t const 
                                          szs_string_ref_t const *candidates, uint32_t candidates_count, uint64_t *results,
                                          uint64_t results_row_stride, int symmetric, void *stream);
 
+/**
+ *  Codepoint queries of more than 2048 runes, unit costs: the strips of szs_hip_levenshtein_myers_banded with a dense-id
+ *  rune table rebuilt per strip (dynamic LDS, like szs_hip_levenshtein_myers_runes_long).  `workspace` holds
+ *  szs_hip_levenshtein_myers_banded_runes_bytes() bytes (0: the device cannot host the table).  Returns hipErrorNotSupported
+ *  when the device refuses the LDS - the caller then scores the group with the rune-keyed DP kernel.
+ */
+int szs_hip_levenshtein_myers_banded_runes(szs_string_ref_t const *queries, uint32_t queries_count, szs_string_ref_t const *candidates,
+                                           uint32_t candidates_count, uint32_t longest_candidate, uint64_t *results,
+                                           uint64_t results_row_stride, int symmetric, void *workspace, void *stream);
+size_t szs_hip_levenshtein_myers_banded_runes_bytes(uint32_t queries_count, uint32_t candidates_count, uint32_t longest_candidate);
+
 /* ---- tuning knobs (host/tuning.c): read from the environment ONCE at load, changed only by szs_rocm_tuning_set -------- */
 
 enum {
@@ -122,7 +133,7 @@ int szs_tuning_get(int knob);
 /* ---- the planner on the device (hip/planner.hip) ------------------------------------------------------------------------- */
 
 #define SZS_PLAN_VARIANTS 10u /* slot 0: no bit-parallel width (weighted / strip kernels); 1..9: SZS_MYERS_SHORT_WORDS, 10 ... 64 */
-#define SZS_PLAN_DEVICE_LONGEST 12287u /* longest string the device planner sorts (LDS histogram); beyond: host planner */
+#define SZS_PLAN_DEVICE_LONGEST 6143u /* longest string the device planner sorts (two LDS histograms); beyond: host planner */
 #define SZS_PLAN_STATUS_DESCENDING 1u /* tape offsets do not ascend */
 #define SZS_PLAN_STATUS_OVERFLOW 2u   /* a string of 4 GiB or more */
 #define SZS_PLAN_STATUS_UNSORTED 4u   /* a side was not sorted (status above, or strings beyond SZS_PLAN_DEVICE_LONGEST) */

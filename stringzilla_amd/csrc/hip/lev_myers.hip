@@ -43,7 +43,7 @@
 namespace szs_hip {
 
 #ifndef SZS_MYERS_SHORT_TEXT_DWORDS
-#define SZS_MYERS_SHORT_TEXT_DWORDS 4 // text dwords per main-loop iteration of the short-query bodies
+#define SZS_MYERS_SHORT_TEXT_DWORDS 2 // text dwords per main-loop iteration of the short-query bodies: 8 columns (16 left ~7 columns per lane to the predicated tail; measured +1.3 % on config 2)
 #endif
 
 constexpr int byte_rows_k = 256;        // Peq rows of the byte kernels: one per byte value
@@ -807,6 +807,185 @@ static int launch_long_runes(szs_string_ref_t const *queries, u32 queries_count,
     return 0;
 }
 
+/* ---- codepoint queries of more than 2048 runes: the strips of the byte kernel with the rune table of the long rune kernels -----
+ *
+ *  The reference's rune Myers is length-agnostic (serial.hpp:2328-2512: an open-addressing Peq per 64-rune block).  Here a
+ *  long pattern is cut into strips of up to 2048 runes exactly like a long byte pattern (myers_strips above): the carry
+ *  ripples through a strip's words, the horizontal deltas under its last row are parked per text column, 16 to a dword.
+ *  What differs is the match-mask table: a strip's runes get dense ids (claim slots with atomicCAS, number the claimed slots)
+ *  and Peq has one row per id, REBUILT FOR EVERY STRIP from that strip's runes only; runes past the table's capacity get
+ *  the overflow id and their mask is rebuilt from the strip's slice of the pattern by the lanes that meet one.  Columns
+ *  are taken one at a time, each predicated on the lane's own text length: this kernel exists so that no codepoint query
+ *  falls back to the cell-by-cell recurrences, not to set records.
+ */
+template <int words_>
+__global__ __launch_bounds__(256) void levenshtein_myers_banded_runes_kernel(
+    szs_string_ref_t const *__restrict__ queries, u32 queries_count, szs_string_ref_t const *__restrict__ candidates,
+    u32 candidates_count, u32 candidate_blocks, u64 *__restrict__ results, u64 results_row_stride, int symmetric,
+    u32 *__restrict__ parked, u32 parked_dwords, u32 *__restrict__ work_counter, u32 rune_slots, u32 id_capacity) {
+    extern __shared__ __attribute__((aligned(16))) u32 strip_lds[];
+    __shared__ u32 claimed_work, claimed_ids;
+    constexpr int chunks = (words_ + 3) / 4;
+    constexpr u32 strip_rows = 32u * words_;
+    u32 const rows = id_capacity + 1; // row 0: runes the strip does not contain
+    u32 *const peq = strip_lds;
+    u32 *const keys = peq + (size_t)chunks * rows * 4;
+    uint16_t *const ids = reinterpret_cast<uint16_t *>(keys + rune_slots);
+    u32 const slot_mask = rune_slots - 1, hash_shift = 32u - (u32)__builtin_ctz(rune_slots);
+    auto dword_index = [&](u32 row, u32 w) -> u32 { return ((w / 4) * rows + row) * 4 + (w % 4); };
+    u32 *const parked_mine = parked + (u64)blockIdx.x * parked_dwords * 256 + threadIdx.x; // [dword = 16 columns][lane]
+
+    u32 const work_items = queries_count * candidate_blocks;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) claimed_work = atomicAdd(work_counter, 1u);
+        __syncthreads();
+        u32 const work = claimed_work;
+        if (work >= work_items) break;
+        szs_string_ref_t const query = queries[work / candidate_blocks];
+        u32 const candidate_slot = (candidate_blocks - 1 - work % candidate_blocks) * SZS_CANDIDATES_PER_WORKGROUP + threadIdx.x;
+        bool live = candidate_slot < candidates_count;
+        szs_string_ref_t candidate = {0, 0, 0};
+        if (live) candidate = candidates[candidate_slot];
+        if ((symmetric & SZS_LAYOUT_SYMMETRIC) && candidate.index > query.index) live = false;
+        u32 const text_length = live ? candidate.length : 0;
+        u32 const longest_in_wave = wave_max_u32(text_length);
+        u32 const *const runes = reinterpret_cast<u32 const *>(candidate.address);
+        u32 const *const pattern = reinterpret_cast<u32 const *>(query.address);
+
+        u32 const query_length = query.length;
+        u32 const total_words = query_length ? (query_length + 31u) / 32u : 1u;
+        u32 const strips = (total_words + words_ - 1) / words_;
+        u32 const pad = strips * strip_rows - query_length; // phantom low rows of the FIRST strip
+        i32 delta_sum = 0;
+        for (u32 strip = 0; strip < strips; ++strip) {
+            bool const first_strip = strip == 0, last_strip = strip + 1 == strips;
+            u32 const strip_base = strip * strip_rows; // bit b of the strip is pattern[strip_base + b - pad]
+            // ---- rune table and Peq of this strip
+            __syncthreads();
+            for (u32 i = threadIdx.x; i < (u32)chunks * rows * 4; i += 256) peq[i] = 0;
+            for (u32 i = threadIdx.x; i < rune_slots; i += 256) keys[i] = rune_slot_empty_k, ids[i] = 0;
+            if (threadIdx.x == 0) claimed_ids = 0;
+            __syncthreads();
+            for (u32 bit = threadIdx.x; bit < strip_rows; bit += 256) {
+                u32 const position = strip_base + bit;
+                if (position < pad) continue;
+                u32 const rune = pattern[position - pad];
+                u32 slot = (rune * 2654435761u) >> hash_shift;
+                for (;;) {
+                    u32 const previous = atomicCAS(&keys[slot], rune_slot_empty_k, rune);
+                    if (previous == rune_slot_empty_k || previous == rune) break;
+                    slot = (slot + 1) & slot_mask;
+                }
+            }
+            __syncthreads();
+            for (u32 slot = threadIdx.x; slot < rune_slots; slot += 256)
+                if (keys[slot] != rune_slot_empty_k) {
+                    u32 const id = atomicAdd(&claimed_ids, 1u) + 1;
+                    ids[slot] = (uint16_t)(id <= id_capacity ? id : rune_overflow_id_k);
+                }
+            __syncthreads();
+            auto id_of = [&](u32 rune) -> u32 { // 0: not in this strip
+                u32 slot = (rune * 2654435761u) >> hash_shift;
+                for (;;) {
+                    u32 const key = keys[slot];
+                    if (key == rune) return ids[slot];
+                    if (key == rune_slot_empty_k) return 0;
+                    slot = (slot + 1) & slot_mask;
+                }
+            };
+            for (u32 bit = threadIdx.x; bit < strip_rows; bit += 256) {
+                u32 const position = strip_base + bit;
+                if (position < pad) continue;
+                u32 const id = id_of(pattern[position - pad]);
+                if (id != rune_overflow_id_k) atomicOr(&peq[dword_index(id, bit >> 5)], 1u << (bit & 31));
+            }
+            __syncthreads();
+
+            u32 vp[words_], vn[words_];
+#pragma unroll
+            for (int w = 0; w < words_; ++w) {
+                u32 const first_bit = 32u * w; // phantom rows (first strip only) hold VP = VN = 0
+                vp[w] = !first_strip || first_bit >= pad ? ~0u : (first_bit + 32u <= pad ? 0u : (~0u << (pad - first_bit)));
+                vn[w] = 0;
+            }
+            u32 entering = 0, leaving = 0;
+#pragma unroll 1
+            for (u32 column = 0; column < longest_in_wave; ++column) {
+                if (column >= text_length) continue;
+                if ((column & 15u) == 0) {
+                    entering = first_strip ? 0u : parked_mine[(u64)(column / 16) * 256];
+                    leaving = 0;
+                }
+                u32 const rune = runes[column];
+                u32 eq[words_];
+                u32 const id = id_of(rune);
+                if (id != rune_overflow_id_k) {
+                    uint4 const *table = reinterpret_cast<uint4 const *>(peq);
+#pragma unroll
+                    for (int chunk = 0; chunk < chunks; ++chunk) {
+                        uint4 const row = table[chunk * rows + id];
+                        if (chunk * 4 + 0 < words_) eq[chunk * 4 + 0] = row.x;
+                        if (chunk * 4 + 1 < words_) eq[chunk * 4 + 1] = row.y;
+                        if (chunk * 4 + 2 < words_) eq[chunk * 4 + 2] = row.z;
+                        if (chunk * 4 + 3 < words_) eq[chunk * 4 + 3] = row.w;
+                    }
+                }
+                else { // a rune past the table's capacity: its mask, straight from this strip's slice of the pattern
+#pragma unroll
+                    for (int w = 0; w < words_; ++w) {
+                        u32 bits = 0;
+#pragma unroll 1
+                        for (u32 bit = 0; bit < 32; ++bit) {
+                            u32 const position = strip_base + 32u * w + bit;
+                            if (position >= pad && pattern[position - pad] == rune) bits |= 1u << bit;
+                        }
+                        eq[w] = bits;
+                    }
+                }
+                u32 const slot = 2 * (column & 15u);
+                u32 const hp_in = first_strip ? 1u : (entering >> slot) & 1u; // DP row 0 grows by one per column
+                u32 const hn_in = first_strip ? 0u : (entering >> (slot + 1)) & 1u;
+                leaving |= myers_strip_column<words_>(vp, vn, eq, hp_in, hn_in) << slot;
+                if (!last_strip && ((column & 15u) == 15 || column + 1 == text_length)) parked_mine[(u64)(column / 16) * 256] = leaving;
+            }
+#pragma unroll
+            for (int w = 0; w < words_; ++w) delta_sum += (i32)__builtin_popcount(vp[w]) - (i32)__builtin_popcount(vn[w]);
+        }
+
+        if (live) {
+            u64 const distance = (u64)((i64)text_length + delta_sum);
+            bool const transposed = (symmetric & SZS_LAYOUT_TRANSPOSED) != 0;
+            u64 const row = transposed ? candidate.index : query.index, column_of = transposed ? query.index : candidate.index;
+            results[row * results_row_stride + column_of] = distance;
+            if ((symmetric & SZS_LAYOUT_SYMMETRIC) && candidate.index != query.index) results[column_of * results_row_stride + row] = distance;
+        }
+    }
+}
+
+constexpr int banded_runes_words_k = 64; // one instantiation: strips of 2048 runes (a 2049-rune query is two strips)
+
+/** Resident workgroups of the codepoint strip kernel with `lds_bytes` of dynamic LDS, per device. */
+static u32 banded_runes_grid(u64 work_items, size_t lds_bytes) {
+    static int resident_of[device_slots_k];
+    int *const slot = &resident_of[device_slot()];
+    int resident = cached(slot);
+    if (!resident) {
+        int device = 0, units = 0, per_unit = 0;
+        if (hipGetDevice(&device) != hipSuccess ||
+            hipDeviceGetAttribute(&units, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_unit, levenshtein_myers_banded_runes_kernel<banded_runes_words_k>, 256,
+                                                         lds_bytes) != hipSuccess ||
+            units <= 0 || per_unit <= 0) {
+            (void)hipGetLastError();
+            units = 256, per_unit = 1;
+        }
+        resident = units * per_unit;
+        remember(slot, resident);
+    }
+    return (u32)(work_items < (u64)resident ? work_items : (u64)resident);
+}
+
 template <typename kernel_t>
 static int launch_myers(kernel_t kernel, szs_string_ref_t const *queries, u32 queries_count,
                         szs_string_ref_t const *candidates, u32 candidates_count, u64 *results, u64 stride, int symmetric,
@@ -889,6 +1068,50 @@ extern "C" int szs_hip_levenshtein_myers_banded(szs_string_ref_t const *queries,
                        candidates, candidates_count, candidate_blocks, results, results_row_stride, symmetric,
                        reinterpret_cast<u32 *>(static_cast<char *>(workspace) + banded_header_bytes_k), longest_candidate / 16 + 2,
                        counter);
+    return (int)hipGetLastError();
+}
+
+extern "C" size_t szs_hip_levenshtein_myers_banded_runes_bytes(uint32_t queries_count, uint32_t candidates_count,
+                                                               uint32_t longest_candidate) {
+    using namespace szs_hip;
+    u32 rune_slots = 0, id_capacity = 0;
+    size_t lds_bytes = 0;
+    if (!rune_lds_plan(banded_runes_words_k, rune_slots, id_capacity, lds_bytes)) return 0;
+    u64 const work_items = (u64)queries_count * ((candidates_count + SZS_CANDIDATES_PER_WORKGROUP - 1) / SZS_CANDIDATES_PER_WORKGROUP);
+    return banded_header_bytes_k + (size_t)banded_runes_grid(work_items, lds_bytes) * (longest_candidate / 16 + 2) * 256 * sizeof(u32);
+}
+
+extern "C" int szs_hip_levenshtein_myers_banded_runes(szs_string_ref_t const *queries, uint32_t queries_count,
+                                                      szs_string_ref_t const *candidates, uint32_t candidates_count,
+                                                      uint32_t longest_candidate, uint64_t *results, uint64_t results_row_stride,
+                                                      int symmetric, void *workspace, void *stream) {
+    using namespace szs_hip;
+    if (!queries_count || !candidates_count) return 0;
+    u32 rune_slots = 0, id_capacity = 0;
+    size_t lds_bytes = 0;
+    if (!rune_lds_plan(banded_runes_words_k, rune_slots, id_capacity, lds_bytes)) return (int)hipErrorNotSupported;
+    static int granted_on[device_slots_k];
+    int *const granted = &granted_on[device_slot()];
+    if (!cached(granted)) {
+        hipError_t const error = hipFuncSetAttribute(reinterpret_cast<void const *>(levenshtein_myers_banded_runes_kernel<banded_runes_words_k>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)160 << 10) - 1024));
+        if (error != hipSuccess) {
+            (void)hipGetLastError();
+            return (int)hipErrorNotSupported; // the host falls back to the rune-keyed DP kernel
+        }
+        remember(granted, 1);
+    }
+    u32 const candidate_blocks = (candidates_count + SZS_CANDIDATES_PER_WORKGROUP - 1) / SZS_CANDIDATES_PER_WORKGROUP;
+    u64 const work_items = (u64)queries_count * candidate_blocks;
+    if (work_items > 0xFFFFFFF0ull) return (int)hipErrorInvalidValue;
+    hipStream_t const s = static_cast<hipStream_t>(stream);
+    u32 *const counter = static_cast<u32 *>(workspace);
+    hipError_t const error = hipMemsetAsync(counter, 0, sizeof(u32), s);
+    if (error != hipSuccess) return (int)error;
+    hipLaunchKernelGGL(levenshtein_myers_banded_runes_kernel<banded_runes_words_k>, dim3(banded_runes_grid(work_items, lds_bytes)), dim3(256),
+                       lds_bytes, s, queries, queries_count, candidates, candidates_count, candidate_blocks, results, results_row_stride,
+                       symmetric, reinterpret_cast<u32 *>(static_cast<char *>(workspace) + banded_header_bytes_k),
+                       longest_candidate / 16 + 2, counter, rune_slots, id_capacity);
     return (int)hipGetLastError();
 }
 

@@ -8,15 +8,17 @@
  *  the first scoring launch could even be enqueued (18 % of config 2's wall time).  Here the same plan is produced by ONE
  *  workgroup of 1024 threads straight from the caller's offsets:
  *
- *    pass 1  per side: lengths, their maximum and sum, the band counts the tier model wants, the number of strings per
- *            bit-parallel launch variant; offsets that descend or strings of 4 GiB are flagged, not scored;
- *    check   the host may have enqueued the scoring launches ALREADY, shaped like the previous call of this engine (same
- *            launch variants, workspaces sized for the previous longest strings).  If this batch does not fit that shape,
- *            every ref is written with length 0 - the speculated launches then score empty strings, memory-safe and over
- *            in microseconds - and `speculation_held` stays 0; the host re-plans from the summary and launches again;
- *    pass 2  per side: counting sort by length in LDS (histogram, block-wide exclusive scan, scatter) into TWO ref arrays,
- *            ascending (the lane side of every kernel) and descending (the workgroup side: longest first makes every
- *            launch variant a contiguous slice and hands out the heaviest workgroups first).
+ *    histogram   both sides at once: every string's length goes into its side's LDS histogram; offsets that descend,
+ *                strings of 4 GiB and strings beyond the histogram are flagged, not scored (the host planner takes over);
+ *    statistics  everything the host decides from - strings per bit-parallel launch variant, longest string, sums, the
+ *                band counts of the tier model - is read off the histogram: 6 bins per thread, one scan, four reductions;
+ *    check       the host may have enqueued the scoring launches ALREADY, shaped like the previous call of this engine
+ *                (same launch variants, workspaces sized for the previous longest strings).  If this batch does not fit
+ *                that shape, every ref is written with length 0 - the speculated launches then score empty strings,
+ *                memory-safe and over in microseconds - and `speculation_held` stays 0; the host re-plans from the summary;
+ *    scatter     counting sort: bins become positions, every string lands in TWO ref arrays, ascending (the lane side of
+ *                every kernel) and descending (the workgroup side: longest first makes every launch variant a contiguous
+ *                slice and hands out the heaviest workgroups first).
  *
  *  The summary lands in pinned host memory; the host reads it after the call's ONE synchronisation.
  *  Strings of `plan_bins_k` bytes or more are not sorted here (`status` says so; the host planner takes over).
@@ -26,141 +28,177 @@
 namespace szs_hip {
 
 constexpr int plan_threads_k = 1024;
-constexpr u32 plan_bins_k = SZS_PLAN_DEVICE_LONGEST + 1; // lengths below this are counting-sorted in LDS
+constexpr int plan_waves_k = plan_threads_k / 64;
+constexpr u32 plan_bins_k = SZS_PLAN_DEVICE_LONGEST + 1;         // lengths below this are counting-sorted in LDS
+constexpr u32 plan_chunk_k = plan_bins_k / plan_threads_k;       // histogram bins per thread
+static_assert(plan_bins_k % plan_threads_k == 0, "the histogram is cut into equal chunks");
 
 __device__ __forceinline__ u64 tape_offset(void const *offsets, u32 wide, u64 index) {
     return wide ? static_cast<u64 const *>(offsets)[index] : (u64) static_cast<u32 const *>(offsets)[index];
 }
 
-/** Index into `variant_counts` of a string of `length` symbols: 0 = no bit-parallel width takes it. */
-__device__ __forceinline__ u32 variant_slot(u32 length, u32 myers_words) {
-    if (!myers_words) return 0;
-    u32 const words = length ? (length + 31u) / 32u : 1u;
-    if (words > myers_words) return 0;
-    // SZS_MYERS_SHORT_WORDS, 10, 12, 16, 20, 24, 32, 48, 64 - szs_hip_levenshtein_myers_round_words()
-    return words <= 8 ? 1 : words <= 10 ? 2 : words <= 12 ? 3 : words <= 16 ? 4 : words <= 20 ? 5 : words <= 24 ? 6 : words <= 32 ? 7 : words <= 48 ? 8 : 9;
+/** Longest string (symbols) of launch variant `slot` 1 ... 9 (szs_hip_levenshtein_myers_round_words(): 8, 10 ... 64 words). */
+__device__ __forceinline__ u32 variant_longest(u32 slot) {
+    constexpr u32 words[SZS_PLAN_VARIANTS] = {0, SZS_MYERS_SHORT_WORDS, 10, 12, 16, 20, 24, 32, 48, 64};
+    return 32u * words[slot];
 }
-
-/** Block-wide exclusive scan of one value per thread (1024 threads = 16 wavefronts); returns this thread's prefix and
- *  leaves the block total in `*total`.  `scratch` holds 17 words. */
-__device__ __forceinline__ u32 block_exclusive_scan(u32 value, u32 *scratch, u32 *total) {
-    u32 const lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    u32 inclusive = value;
-#pragma unroll
-    for (int offset = 1; offset < 64; offset <<= 1) {
-        u32 const other = (u32)__shfl_up((int)inclusive, offset, 64);
-        if (lane >= (u32)offset) inclusive += other;
-    }
-    __syncthreads(); // scratch may still be read by a previous call
-    if (lane == 63) scratch[wave] = inclusive;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        u32 running = 0;
-        for (int w = 0; w < plan_threads_k / 64; ++w) {
-            u32 const sum = scratch[w];
-            scratch[w] = running, running += sum;
-        }
-        scratch[plan_threads_k / 64] = running;
-    }
-    __syncthreads();
-    *total = scratch[plan_threads_k / 64];
-    return scratch[wave] + inclusive - value;
-}
-
-/** Statistics of one side, reduced over the workgroup WITHOUT atomics: hipcc turns an LDS atomic on a wave-uniform address
- *  into a scalar loop over the 64 lanes (7 SALU instructions per lane and atomic - fifteen of them made the planner a 40 us
- *  kernel); a shuffle butterfly per value and one LDS slot per wavefront is ~300 instructions. */
-constexpr int plan_values_k = 5 + SZS_PLAN_VARIANTS; // longest (max), status (or), symbols, bands x 2, strings per variant (sums)
 
 __device__ __forceinline__ u64 shuffle_xor_u64(u64 value, int offset) {
     u32 const low = (u32)__shfl_xor((int)(u32)value, offset, 64), high = (u32)__shfl_xor((int)(u32)(value >> 32), offset, 64);
     return ((u64)high << 32) | low;
 }
 
+/**
+ *  What bounds this kernel is LATENCY - dependent memory round trips, workgroup barriers, LDS crossbar shuffles - not work:
+ *  a side of 1024 strings is one string per thread.  So both sides advance through every phase TOGETHER (two histograms,
+ *  half the barriers), each thread keeps its strings' offsets in registers from the first load on, and every statistic the
+ *  host wants - counts per launch variant, longest string, sums, band counts - is read off the HISTOGRAM of the lengths
+ *  (6 bins per thread, then one scan and four reductions per side) instead of being reduced string by string (round 2's
+ *  first version reduced fifteen 64-bit values per side through LDS atomics, which hipcc expands into scalar loops over
+ *  the 64 lanes: 40 us; then through shuffles: 25 us).
+ */
 __global__ __launch_bounds__(plan_threads_k) void plan_kernel(szs_plan_side_t queries, szs_plan_side_t candidates,
                                                               int symmetric, u32 myers_words,
                                                               szs_plan_expectation_t expected,
                                                               szs_plan_summary_t *__restrict__ summary) {
-    __shared__ u32 histogram[plan_bins_k];
-    __shared__ u32 scan_scratch[plan_threads_k / 64 + 1];
-    __shared__ unsigned long long wave_values[2][plan_threads_k / 64][plan_values_k];
-    __shared__ unsigned long long side_values[2][plan_values_k];
+    __shared__ u32 histogram[2][plan_bins_k];
+    __shared__ u32 wave_counts[2][plan_waves_k], wave_symbols[2][plan_waves_k], wave_bands_systolic[2][plan_waves_k],
+        wave_bands_chain[2][plan_waves_k], wave_longest[2][plan_waves_k], wave_status[plan_waves_k];
+    __shared__ u32 side_count_before_wave[2][plan_waves_k], side_symbols[2], side_bands_systolic[2], side_bands_chain[2],
+        side_longest[2], side_strings[2], variants[2][SZS_PLAN_VARIANTS], shared_status, shared_held;
     __shared__ unsigned long long chunk_sums[plan_threads_k], shared_cells;
-    __shared__ u32 shared_held;
 
     u32 const tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     int const sides = symmetric ? 1 : 2;
-    // The planner is a chain of dependent memory round trips, not of instructions: a load from HBM and back is a microsecond
-    // or two.  So every thread fetches the offsets of ITS first string of both sides up front - one round trip for the whole
-    // kernel when a side has at most 1024 strings - and all three passes read them from registers.
+    szs_plan_side_t const *const side_of[2] = {&queries, &candidates};
+#ifdef SZS_PLAN_TIMESTAMPS // measuring aid (build variant): 100 MHz timestamps of the phases, behind the summary, for the trace
+    unsigned long long *const stamps = reinterpret_cast<unsigned long long *>(summary) + 40;
+#define SZS_PLAN_STAMP(K) do { if (tid == 0) stamps[K] = wall_clock64(); } while (0)
+#else
+#define SZS_PLAN_STAMP(K) do {} while (0)
+#endif
+    SZS_PLAN_STAMP(0);
+
+    // ---- phase 0: both histograms cleared; each thread's first string of each side fetched (one round trip for the kernel
+    //      when a side has at most 1024 strings: every later phase reads registers)
     u64 first_from[2] = {0, 0}, first_to[2] = {0, 0};
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        szs_plan_side_t const &side = s ? candidates : queries;
-        if (s < sides && tid < side.count)
-            first_from[s] = tape_offset(side.offsets, side.wide, tid), first_to[s] = tape_offset(side.offsets, side.wide, (u64)tid + 1);
-    }
-    auto span_of = [&](int s, szs_plan_side_t const &side, u32 i, u64 &from, u64 &to) {
-        if (i == tid) from = first_from[s], to = first_to[s];
-        else from = tape_offset(side.offsets, side.wide, i), to = tape_offset(side.offsets, side.wide, (u64)i + 1);
-    };
-    // ---- pass 1: lengths and the statistics every decision is made from
-    for (int s = 0; s < sides; ++s) {
-        szs_plan_side_t const &side = s ? candidates : queries;
-        u64 values[plan_values_k];
+    for (int s = 0; s < 2; ++s)
+        if (s < sides && tid < side_of[s]->count)
+            first_from[s] = tape_offset(side_of[s]->offsets, side_of[s]->wide, tid),
+            first_to[s] = tape_offset(side_of[s]->offsets, side_of[s]->wide, (u64)tid + 1);
+    for (int s = 0; s < sides; ++s)
 #pragma unroll
-        for (int k = 0; k < plan_values_k; ++k) values[k] = 0;
-        for (u32 i = tid; i < side.count; i += plan_threads_k) {
-            u64 from, to;
-            span_of(s, side, i, from, to);
-            if (to < from) values[1] |= SZS_PLAN_STATUS_DESCENDING;
-            u64 const wide_length = to < from ? 0 : to - from;
-            if (wide_length > 0xFFFFFFFFull) values[1] |= SZS_PLAN_STATUS_OVERFLOW;
-            u32 const length = (u32)wide_length;
-            values[0] = length > values[0] ? length : values[0];
-            values[2] += length;
-            values[3] += length ? (length + SZS_SYSTOLIC_BAND_ROWS - 1) / SZS_SYSTOLIC_BAND_ROWS : 1;
-            values[4] += length ? (length + SZS_MYERS_CHAIN_BAND_ROWS - 1) / SZS_MYERS_CHAIN_BAND_ROWS : 1;
-            u32 const slot = variant_slot(length, myers_words);
-#pragma unroll
-            for (u32 v = 0; v < SZS_PLAN_VARIANTS; ++v) values[5 + v] += slot == v;
-        }
-#pragma unroll
-        for (int k = 0; k < plan_values_k; ++k) {
-            u64 value = values[k];
-#pragma unroll
-            for (int offset = 32; offset >= 1; offset >>= 1) {
-                u64 const other = shuffle_xor_u64(value, offset);
-                value = k == 0 ? (other > value ? other : value) : k == 1 ? (value | other) : value + other;
-            }
-            if (lane == 0) wave_values[s][wave][k] = value;
-        }
-    }
-    __syncthreads();
-    if (tid < (u32)(sides * plan_values_k)) {
-        int const s = tid / plan_values_k, k = tid % plan_values_k;
-        u64 value = 0;
-        for (int w = 0; w < plan_threads_k / 64; ++w) {
-            u64 const other = wave_values[s][w][k];
-            value = k == 0 ? (other > value ? other : value) : k == 1 ? (value | other) : value + other;
-        }
-        side_values[s][k] = value;
-    }
+        for (u32 k = 0; k < plan_chunk_k; ++k) histogram[s][k * plan_threads_k + tid] = 0;
     if (tid == 0) shared_cells = 0, shared_held = 0;
     __syncthreads();
-    u32 const shared_status = (u32)(side_values[0][1] | (symmetric ? 0 : side_values[1][1]));
-    u32 const shared_longest[2] = {(u32)side_values[0][0], (u32)side_values[symmetric ? 0 : 1][0]};
+    SZS_PLAN_STAMP(1);
+    auto span_of = [&](int s, u32 i, u64 &from, u64 &to) {
+        if (i == tid) from = first_from[s], to = first_to[s];
+        else from = tape_offset(side_of[s]->offsets, side_of[s]->wide, i), to = tape_offset(side_of[s]->offsets, side_of[s]->wide, (u64)i + 1);
+    };
+
+    // ---- phase 1: the histogram of the lengths; malformed or over-long strings only raise a flag (the host takes over)
+    u32 status = 0;
+    for (int s = 0; s < sides; ++s)
+        for (u32 i = tid; i < side_of[s]->count; i += plan_threads_k) {
+            u64 from, to;
+            span_of(s, i, from, to);
+            if (to < from) status |= SZS_PLAN_STATUS_DESCENDING;
+            else if (to - from > 0xFFFFFFFFull) status |= SZS_PLAN_STATUS_OVERFLOW;
+            else if (to - from >= plan_bins_k) status |= SZS_PLAN_STATUS_UNSORTED;
+            else atomicAdd(&histogram[s][(u32)(to - from)], 1u); // per-lane addresses: a plain ds_add
+        }
+#pragma unroll
+    for (int offset = 32; offset >= 1; offset >>= 1) status |= (u32)__shfl_xor((int)status, offset, 64);
+    if (lane == 0) wave_status[wave] = status;
+    __syncthreads();
+    SZS_PLAN_STAMP(2);
+
+    // ---- phase 2: every statistic from the histogram.  Thread t owns bins [6 t, 6 t + 6) of both sides.
+    u32 chunk_counts[2] = {0, 0}, chunk_inclusive[2] = {0, 0};
+    for (int s = 0; s < sides; ++s) {
+        u32 symbols = 0, bands_systolic = 0, bands_chain = 0, longest = 0;
+#pragma unroll
+        for (u32 k = 0; k < plan_chunk_k; ++k) {
+            u32 const length = tid * plan_chunk_k + k, strings = histogram[s][length];
+            chunk_counts[s] += strings;
+            symbols += strings * length;
+            bands_systolic += strings * (length ? (length + SZS_SYSTOLIC_BAND_ROWS - 1) / SZS_SYSTOLIC_BAND_ROWS : 1);
+            bands_chain += strings * (length ? (length + SZS_MYERS_CHAIN_BAND_ROWS - 1) / SZS_MYERS_CHAIN_BAND_ROWS : 1);
+            longest = strings ? length : longest;
+        }
+        u32 inclusive = chunk_counts[s];
+#pragma unroll
+        for (int offset = 1; offset < 64; offset <<= 1) {
+            u32 const other = (u32)__shfl_up((int)inclusive, offset, 64);
+            if (lane >= (u32)offset) inclusive += other;
+        }
+        chunk_inclusive[s] = inclusive;
+#pragma unroll
+        for (int offset = 32; offset >= 1; offset >>= 1) {
+            symbols += (u32)__shfl_xor((int)symbols, offset, 64);
+            bands_systolic += (u32)__shfl_xor((int)bands_systolic, offset, 64);
+            bands_chain += (u32)__shfl_xor((int)bands_chain, offset, 64);
+            u32 const other = (u32)__shfl_xor((int)longest, offset, 64);
+            longest = other > longest ? other : longest;
+        }
+        if (lane == 63) wave_counts[s][wave] = inclusive;
+        if (lane == 0)
+            wave_symbols[s][wave] = symbols, wave_bands_systolic[s][wave] = bands_systolic, wave_bands_chain[s][wave] = bands_chain,
+            wave_longest[s][wave] = longest;
+    }
+    __syncthreads();
+    if (tid < (u32)sides) { // one thread per side folds the sixteen wavefronts
+        int const s = (int)tid;
+        u32 running = 0, symbols = 0, bands_systolic = 0, bands_chain = 0, longest = 0;
+        for (int w = 0; w < plan_waves_k; ++w) {
+            side_count_before_wave[s][w] = running, running += wave_counts[s][w];
+            symbols += wave_symbols[s][w], bands_systolic += wave_bands_systolic[s][w], bands_chain += wave_bands_chain[s][w];
+            longest = wave_longest[s][w] > longest ? wave_longest[s][w] : longest;
+        }
+        side_strings[s] = running, side_symbols[s] = symbols, side_bands_systolic[s] = bands_systolic, side_bands_chain[s] = bands_chain;
+        side_longest[s] = longest;
+    }
+    if (tid == 2) {
+        u32 all = 0;
+        for (int w = 0; w < plan_waves_k; ++w) all |= wave_status[w];
+        shared_status = all;
+    }
+    __syncthreads();
+
+    SZS_PLAN_STAMP(3);
+    // ---- phase 3: bins become positions (exclusive prefix); strings per launch variant are differences of positions
+    for (int s = 0; s < sides; ++s) {
+        u32 running = side_count_before_wave[s][wave] + chunk_inclusive[s] - chunk_counts[s];
+#pragma unroll
+        for (u32 k = 0; k < plan_chunk_k; ++k) {
+            u32 const length = tid * plan_chunk_k + k, strings = histogram[s][length];
+            histogram[s][length] = running, running += strings;
+        }
+    }
+    __syncthreads();
+    if (tid < (u32)(sides * SZS_PLAN_VARIANTS)) {
+        int const s = tid / SZS_PLAN_VARIANTS;
+        u32 const slot = tid % SZS_PLAN_VARIANTS, total = side_strings[s];
+        auto strings_shorter_than = [&](u32 length) -> u32 { return length < plan_bins_k ? histogram[s][length] : total; };
+        u32 strings;
+        if (!myers_words) strings = slot == 0 ? total : 0; // weighted engines: one launch group
+        else if (slot == 0) strings = total - strings_shorter_than(variant_longest(SZS_PLAN_VARIANTS - 1) + 1);
+        else strings = strings_shorter_than(variant_longest(slot) + 1) - (slot == 1 ? 0 : strings_shorter_than(variant_longest(slot - 1) + 1));
+        variants[s][slot] = strings;
+    }
+    __syncthreads();
 
     // ---- symmetric calls: cells of the lower triangle = sum_i len_i * sum_{j <= i} len_j, in the caller's order
-    if (symmetric) {
+    if (symmetric && !shared_status) {
         u32 const chunk = (queries.count + plan_threads_k - 1) / plan_threads_k;
         u32 const first = tid * chunk < queries.count ? tid * chunk : queries.count;
         u32 const last = first + chunk < queries.count ? first + chunk : queries.count;
         u64 mine = 0;
         for (u32 i = first; i < last; ++i)
             mine += tape_offset(queries.offsets, queries.wide, (u64)i + 1) - tape_offset(queries.offsets, queries.wide, i);
-        // prefix of the chunk sums: 64-bit, so two 32-bit scans would not do - a serial pass by one thread is 1024 adds
-        chunk_sums[tid] = mine;
+        chunk_sums[tid] = mine; // prefix of the chunk sums: 64-bit; a serial pass by one thread is 1024 additions
         __syncthreads();
         if (tid == 0) {
             unsigned long long running = 0;
@@ -182,86 +220,71 @@ __global__ __launch_bounds__(plan_threads_k) void plan_kernel(szs_plan_side_t qu
         __syncthreads();
         if (tid == 0) {
             unsigned long long total = 0;
-            for (int w = 0; w < plan_threads_k / 64; ++w) total += chunk_sums[w];
+            for (int w = 0; w < plan_waves_k; ++w) total += chunk_sums[w];
             shared_cells = total;
         }
         __syncthreads();
     }
 
+    SZS_PLAN_STAMP(4);
     // ---- does this batch have the shape the host already enqueued launches for?
     if (tid == 0) {
         u32 held = expected.enabled && !shared_status;
         if (held) {
             int const query_side = symmetric ? 0 : (int)expected.query_side;
-            for (u32 v = 0; v < SZS_PLAN_VARIANTS; ++v) held &= (u32)side_values[query_side][5 + v] == expected.variant_counts[v];
-            held &= shared_longest[0] <= expected.longest[0];
-            held &= shared_longest[symmetric ? 0 : 1] <= expected.longest[1];
+            for (u32 v = 0; v < SZS_PLAN_VARIANTS; ++v) held &= variants[query_side][v] == expected.variant_counts[v];
+            held &= side_longest[0] <= expected.longest[0];
+            held &= side_longest[symmetric ? 0 : 1] <= expected.longest[1];
         }
         shared_held = held;
     }
     __syncthreads();
     bool const blank = expected.enabled && !shared_held; // speculated launches must find nothing to score
-    u32 unsorted = 0;
+    SZS_PLAN_STAMP(5);
 
-    // ---- pass 2: counting sort by length, ascending and descending ref arrays
-    for (int s = 0; s < sides; ++s) {
-        szs_plan_side_t const &side = s ? candidates : queries;
-        u32 const longest = shared_longest[s];
-        if (shared_status || longest >= plan_bins_k) { // the host planner takes over
-            unsorted = 1;
-            continue;
-        }
-        u32 const bins = longest + 1;
-        __syncthreads(); // the histogram of the previous side is done with
-        for (u32 b = tid; b < bins; b += plan_threads_k) histogram[b] = 0;
-        __syncthreads();
-        for (u32 i = tid; i < side.count; i += plan_threads_k) {
-            u64 from, to;
-            span_of(s, side, i, from, to);
-            atomicAdd(&histogram[(u32)(to - from)], 1u);
-        }
-        __syncthreads();
-        u32 const chunk = (bins + plan_threads_k - 1) / plan_threads_k;
-        u32 const first_bin = tid * chunk, last_bin = first_bin + chunk < bins ? first_bin + chunk : bins;
-        u32 mine = 0;
-        for (u32 b = first_bin; b < last_bin; ++b) mine += histogram[b];
-        u32 total;
-        u32 running = block_exclusive_scan(mine, scan_scratch, &total);
-        for (u32 b = first_bin; b < last_bin; ++b) {
-            u32 const here = histogram[b];
-            histogram[b] = running, running += here;
-        }
-        __syncthreads();
-        for (u32 i = tid; i < side.count; i += plan_threads_k) {
-            u64 from, to;
-            span_of(s, side, i, from, to);
-            u32 const length = (u32)(to - from);
-            u32 const position = atomicAdd(&histogram[length], 1u); // equal lengths: any order scores the same matrix
-            szs_string_ref_t ref;
-            ref.address = side.base + from, ref.length = blank ? 0u : length, ref.index = i;
-            side.ascending[position] = ref;
-            side.descending[side.count - 1 - position] = ref;
-        }
+    // ---- phase 4: scatter into the ascending and the descending ref arrays
+    if (shared_status) { // nothing was sorted; launches that are already in flight must still find only empty strings
+        if (expected.enabled)
+            for (int s = 0; s < sides; ++s)
+                for (u32 i = tid; i < side_of[s]->count; i += plan_threads_k) {
+                    szs_string_ref_t ref;
+                    ref.address = side_of[s]->base, ref.length = 0, ref.index = i;
+                    side_of[s]->ascending[i] = ref, side_of[s]->descending[i] = ref;
+                }
     }
-    __syncthreads();
+    else
+        for (int s = 0; s < sides; ++s)
+            for (u32 i = tid; i < side_of[s]->count; i += plan_threads_k) {
+                u64 from, to;
+                span_of(s, i, from, to);
+                u32 const length = (u32)(to - from);
+                u32 const position = atomicAdd(&histogram[s][length], 1u); // equal lengths: any order scores the same matrix
+                szs_string_ref_t ref;
+                ref.address = side_of[s]->base + from, ref.length = blank ? 0u : length, ref.index = i;
+                side_of[s]->ascending[position] = ref;
+                side_of[s]->descending[side_of[s]->count - 1 - position] = ref;
+            }
 
+    SZS_PLAN_STAMP(6);
     if (tid == 0) { // one struct, written once: the host reads it after the stream has drained
         szs_plan_summary_t report;
-        report.status = shared_status | (unsorted ? SZS_PLAN_STATUS_UNSORTED : 0u);
+        report.status = shared_status;
         report.speculation_held = shared_held;
         for (int s = 0; s < 2; ++s) {
             int const from = symmetric ? 0 : s;
             report.side[s].count = from ? candidates.count : queries.count;
-            report.side[s].longest = (u32)side_values[from][0];
-            report.side[s].symbols = side_values[from][2];
-            report.side[s].bands_systolic = side_values[from][3];
-            report.side[s].bands_chain = side_values[from][4];
-            for (u32 v = 0; v < SZS_PLAN_VARIANTS; ++v) report.variant_counts[s][v] = (u32)side_values[from][5 + v];
+            report.side[s].longest = side_longest[from];
+            report.side[s].symbols = side_symbols[from];
+            report.side[s].bands_systolic = side_bands_systolic[from];
+            report.side[s].bands_chain = side_bands_chain[from];
+            for (u32 v = 0; v < SZS_PLAN_VARIANTS; ++v) report.variant_counts[s][v] = variants[from][v];
         }
         report.symmetric_cells = shared_cells;
         report.sequence = expected.sequence; // the host can tell a fresh summary from a stale one
         *summary = report;
     }
+    SZS_PLAN_STAMP(7);
+#undef SZS_PLAN_STAMP
 }
 
 } // namespace szs_hip

@@ -156,7 +156,10 @@ __global__ __launch_bounds__(256, affine_ ? SZS_PACKED_AFFINE_WAVES : 4) void we
     constexpr bool saturating_ = local_;
     constexpr int registers = packed_registers_k, rows = packed_strip_rows_k;
     extern __shared__ __attribute__((aligned(16))) u32 pair_profile[]; // [register chunk][class of symbol t * K + class of symbol t - 1][4]
-    __shared__ int8_t table[32 * 32];                                  // [query class][candidate class]
+    // The 32 x 32 table itself stays in global memory (2 KB, cache-resident, read only while a strip's profile is built):
+    // BLOSUM62's 25 x 25 pair profile is 40,000 B, and with a kilobyte less of static LDS FOUR workgroups fit a CU instead
+    // of three - config 3's 4096 work items then take 4 full rounds instead of 5.33 (profiles/r02).
+    int16_t const *const table = model->substitution;                   // [query class][candidate class]
     __shared__ u8 class_of_byte[256];
     __shared__ u8 strip_classes[rows];                                 // 0xFF: a padded row
     __shared__ u32 claimed_work;
@@ -167,7 +170,6 @@ __global__ __launch_bounds__(256, affine_ ? SZS_PACKED_AFFINE_WAVES : 4) void we
     pk_i16 const open_pk = saturating_ ? pk_pair(-gap_open, -gap_open) : pk_pair(gap_open, gap_open);
     pk_i16 const extend_pk = saturating_ ? pk_pair(-gap_extend, -gap_extend) : pk_pair(gap_extend, gap_extend);
     class_of_byte[threadIdx.x] = model->byte_to_class[threadIdx.x];
-    for (u32 i = threadIdx.x; i < 32 * 32; i += packed_block_threads_k) table[i] = (int8_t)model->substitution[i];
 
     // This workgroup's private boundary rows: [column][lane], one plane for H and one for the vertical-gap track.
     u64 const plane = (u64)boundary_columns * packed_block_threads_k;

@@ -415,7 +415,10 @@ static sz_status_t prepare(szs_engine_s *engine, szs_decision_t const *d, int de
     }
     int const variant_zero = has_group_of_variant_zero(d);
     size_t boundary_bytes = 0;
-    if (!d->use_myers || (d->runes && variant_zero)) { /* the weighted kernels: every non-unit engine; rune queries beyond 2048 */
+    if (d->use_myers && d->runes && variant_zero) /* codepoint queries beyond 2048 runes: the strip kernel's parked deltas */
+        boundary_bytes = szs_hip_levenshtein_myers_banded_runes_bytes(d->kq_count, d->kc_count, d->plan.longest_candidate);
+    if (!d->use_myers || (d->runes && variant_zero && !boundary_bytes)) { /* the weighted kernels: every non-unit engine (and
+                                                                             long rune queries on a device without the LDS) */
         status = upload_model(engine, d, device, stream, error_message);
         if (status != sz_success_k) return status;
         boundary_bytes = weighted_boundary_bytes(engine, d);
@@ -519,6 +522,24 @@ static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int dev
                 launch_error = szs_hip_levenshtein_myers_banded(queries, count, candidate_refs, d->kc_count, d->plan.longest_candidate,
                                                                 (uint64_t *)device_results, device_stride, d->layout,
                                                                 engine->device_boundary.pointer, target);
+            else if (d->use_myers && d->runes) { /* codepoints beyond 2048 runes: strips with a rune table per strip */
+                launch_error = szs_hip_levenshtein_myers_banded_runes(queries, count, candidate_refs, d->kc_count, d->plan.longest_candidate,
+                                                                      (uint64_t *)device_results, device_stride, d->layout,
+                                                                      engine->device_boundary.pointer, target);
+                if (launch_error == (int)hipErrorNotSupported) { /* as above: the rune-keyed DP kernel and its workspace */
+                    launch_error = 0;
+                    *status = upload_model(engine, d, device, stream, error_message);
+                    if (*status == sz_success_k)
+                        *status = szs_buffer_reserve(&engine->device_boundary, szs_memory_device_k, device,
+                                                     szs_hip_weighted_boundary_bytes(d->objective, !engine->is_linear, 0, d->kq_count, d->kc_count,
+                                                                                     d->plan.longest_candidate), error_message);
+                    if (*status != sz_success_k) break;
+                    *cell_bits = 32;
+                    launch_error = szs_hip_weighted_scores(d->objective, !engine->is_linear, 0, (szs_cost_model_t const *)engine->device_model.pointer,
+                                                           queries, count, candidate_refs, d->kc_count, d->plan.longest_candidate,
+                                                           (int64_t *)device_results, device_stride, d->layout, engine->device_boundary.pointer, stream);
+                }
+            }
             else if (d->packed) {
                 *cell_bits = 16;
                 launch_error = szs_hip_weighted_packed_scores(d->packed_local, !engine->is_linear, d->classes, model, queries, count, candidate_refs,
@@ -618,6 +639,14 @@ static sz_status_t finish(szs_call_t *call, szs_decision_t const *d, hipError_t 
     profile->longest_query = d->longest[0], profile->longest_candidate = d->longest[1];
     profile->host_milliseconds = now_milliseconds() - call->started;
     phase(call, 5);
+#ifdef SZS_PLAN_TIMESTAMPS
+    if (call->trace) {
+        unsigned long long const *stamps = (unsigned long long const *)engine->pinned_summary.pointer + 40;
+        fprintf(stderr, "planner phases (10 ns ticks):");
+        for (int k = 1; k < 8; ++k) fprintf(stderr, " %lld", (long long)(stamps[k] - stamps[k - 1]));
+        fprintf(stderr, "\n");
+    }
+#endif
     if (call->trace)
         fprintf(stderr, "szs call: %.1f us = setup %.1f + plan %.1f + prepare %.1f + launch %.1f + wait %.1f + wrap %.1f | kernel %.1f us | %s\n",
                 profile->host_milliseconds * 1e3, call->phases[0] * 1e3, call->phases[1] * 1e3, call->phases[2] * 1e3,

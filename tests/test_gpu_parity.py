@@ -554,11 +554,15 @@ def test_utf8_long_queries_stay_bit_parallel(gpu, oracle):
         others = [text(wide, rng.randint(200, 2048)) for _ in range(10)] + rich[:2]
         assert np.array_equal(engine(rich, others, device=gpu), oracle.levenshtein_utf8(rich, others))
         assert np.array_equal(engine(rich, device=gpu), oracle.levenshtein_utf8(rich, None))
-    # beyond 2048 runes the rune-keyed DP recurrences take over
-    longer = [text(small, 2049), text(small, 2500)]
+    # beyond 2048 runes: strips of 2048 runes, the rune table rebuilt per strip - still no DP kernel
+    longer = [text(small, 2049), text(small, 2500), text(small, 4096), text(small, 4097), text(wide, 5000), text(small, 6200)]
+    texts = candidates[:9] + [text(wide, 900), text(wide, 3000), text(small, 17), text(small, 16), text(small, 33)]
     with forced_tier("lanes"), forced_swap("0"):  # (left alone, the planner would put the shorter side on the bit-vectors)
-        assert np.array_equal(engine(longer, candidates[:9], device=gpu), oracle.levenshtein_utf8(longer, candidates[:9]))
-        assert engine.last_call_profile().cell_bits == 32
+        assert np.array_equal(engine(longer, texts, device=gpu), oracle.levenshtein_utf8(longer, texts))
+        assert engine.last_call_profile().cell_bits == 0
+        with forced_env("SZS_ROCM_RUNE_IDS", "5"):  # nearly every rune overflows the table: masks straight from the pattern
+            assert np.array_equal(engine(longer[:3], texts[:6], device=gpu), oracle.levenshtein_utf8(longer[:3], texts[:6]))
+        assert np.array_equal(engine(longer[:4], device=gpu), oracle.levenshtein_utf8(longer[:4], None))  # symmetric
 
 
 def test_utf8_malformed_bytes_follow_the_unchecked_contract(gpu, oracle):
