@@ -192,52 +192,43 @@ def cpu_baseline(load, gpu_matrix, seconds):
 
 # ---- rooflines -------------------------------------------------------------------------------------------------------------
 
-DOMINANT_KERNEL = {  # the kernel that owns (nearly) all of a config's time, by name prefix in the PMC summaries
-    2: "levenshtein_myers_short_kernel", 3: "weighted_packed_kernel<false, false>", 4: "weighted_packed_kernel<true, true>",
-    5: "levenshtein_myers_long_kernel", 6: "levenshtein_myers_long_runes_kernel",
-}
-
-
 def roofline(config, profile, kernel_seconds, traffic_override=None):
-    """HBM roofline from the ALGORITHMIC bytes of one call over the measured kernel time, the PMC traffic of the
-    dominant kernel from the committed passes of this command, and - what actually binds - its VALU issue rate."""
+    """HBM roofline from the ALGORITHMIC bytes of one call over the kernel time measured live (hipEvent pair on the library's
+    stream), beside what the committed rocprofv3 --pmc passes of this same command saw: HBM bytes actually moved per call
+    and - what actually binds this path - VALU issue and LDS occupancy (scripts/profile_configs.sh -> profiles/rNN)."""
     achieved = profile.algorithmic_bytes / kernel_seconds / 1e9
     record = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
               "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic_override, "kernel_ms": round(kernel_seconds * 1e3, 4),
               "algorithmic_bytes": int(profile.algorithmic_bytes), "launches_per_step": int(profile.launches),
               "kernel_gcups": round(profile.cells / kernel_seconds / 1e9, 1)}
-    summary, where = _profile_json("pmc_configs.json")  # "cfgN:kernel" -> counters (scripts/pmc_configs.py)
-    wanted = DOMINANT_KERNEL.get(config, "")
-    counters = None
-    for name, entry in (summary or {}).items():
-        kernel = name.split(":", 1)[-1]
-        if entry.get("_config") == config and wanted and kernel.startswith(wanted) and (counters is None or entry.get("_share", 0) > counters.get("_share", 0)):
-            counters, record["kernel"] = entry, kernel
-    if counters is None and config == 2:  # round 1's summary of the headline kernel, until round 2's passes are committed
-        summary, where = _profile_json("pmc_summary.json")
-        for name, entry in (summary or {}).items():
-            if name.startswith(wanted):
-                counters, record["kernel"] = entry, name
-    if counters is None:
+    summary, where = _profile_json("pmc_configs.json")  # "cfgN:kernel" and "cfgN:__call__" (scripts/pmc_configs.py)
+    call = (summary or {}).get(f"cfg{config}:__call__")
+    if not call:
         record["traffic_source"] = "no committed PMC pass for this config" if traffic_override is None else "from --hbm-traffic-bytes"
         return record
-    if traffic_override is None and "hbm_fetch_bytes_raw" in counters and "hbm_write_bytes_raw" in counters:
-        record["traffic"] = counters["hbm_fetch_bytes_raw"] + counters["hbm_write_bytes_raw"]
-        record["traffic_source"] = (f"{where}: (FETCH_SIZE + WRITE_SIZE) x 1024 per launch of the dominant kernel, committed "
-                                    f"rocprofv3 --pmc passes of this command (raw; wide-stream reads may count double)")
-    if "SQ_INSTS_VALU" in counters:
-        # wave-instructions x 64 lanes over the kernel's own profiled duration, against one lane-op per lane per cycle
-        duration = counters.get("_duration_seconds") or kernel_seconds
-        lane_ops = counters["SQ_INSTS_VALU"] * 64.0
+    kernels = call.get("kernels", {})
+    if kernels:
+        dominant = max(kernels, key=lambda name: kernels[name]["share_of_kernel_time"])
+        record["kernel"] = dominant if len(kernels) == 1 else f"{dominant} + {len(kernels) - 1} more (launches of different widths overlap on four streams)"
+    if traffic_override is None and "hbm_fetch_bytes_raw" in call and "hbm_write_bytes_raw" in call:
+        record["traffic"] = round(call["hbm_fetch_bytes_raw"] + call["hbm_write_bytes_raw"])
+        record["traffic_source"] = (f"{where}: (FETCH_SIZE + WRITE_SIZE) x 1024 summed over the kernels of one call, committed rocprofv3 "
+                                    f"--pmc passes of this command (raw; wide-stream reads may count double)")
+    if "SQ_INSTS_VALU" in call:
+        lane_ops = call["SQ_INSTS_VALU"] * 64.0
         record["valu"] = {
             "bound": "integer VALU issue (PMC)", "source": where,
-            "wave_instructions_per_launch": counters["SQ_INSTS_VALU"],
-            "share_of_the_configs_kernel_time": round(counters["_share"], 4) if "_share" in counters else None,
-            "lane_ops_per_cell": round(lane_ops / max(float(profile.cells), 1.0), 4) if int(profile.launches) == 1 else None,
-            "achieved_Tlane_ops_per_s": round(lane_ops / duration / 1e12, 2),
+            "wave_instructions_per_call": round(call["SQ_INSTS_VALU"]),
+            "lane_ops_per_cell": round(lane_ops / max(float(profile.cells), 1.0), 4),
+            "achieved_Tlane_ops_per_s": round(lane_ops / kernel_seconds / 1e12, 2),
             "peak_Tlane_ops_per_s": VALU_LANE_OPS_PEAK / 1e12,
-            "frac": round(lane_ops / duration / VALU_LANE_OPS_PEAK, 4),
-            "lds_conflict_fraction": round(counters["lds_conflict_fraction"], 4) if "lds_conflict_fraction" in counters else None,
+            "frac": round(lane_ops / kernel_seconds / VALU_LANE_OPS_PEAK, 4),
+            "busy_fraction_under_rocprof": round(call["valu_busy_fraction"], 4) if "valu_busy_fraction" in call else None,
+            "lds_busy_fraction": round(call["lds_busy_fraction"], 4) if "lds_busy_fraction" in call else None,
+            "lds_conflict_fraction": round(call["lds_conflict_fraction"], 4) if "lds_conflict_fraction" in call else None,
+            "note": "frac = VALU wave-instructions x 64 lanes per second over one full-rate lane-op per lane per cycle (256 CUs x 4 SIMDs "
+                    "x 16 lanes x 2.4 GHz); add / logic opcodes issue at up to 1.7x that rate on gfx950, carries, shifts and packed "
+                    "16-bit opcodes at 1x (profiles/r02/valu_peak.json)",
         }
     return record
 

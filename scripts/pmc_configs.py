@@ -70,4 +70,38 @@ for directory in sorted(glob.glob(os.path.join(root, "cfg*"))):
             # SQ_ACTIVE_INST_VALU counts quad-cycles summed over SIMDs; SQ_BUSY_CYCLES is summed over shader engines
             entry["valu_active_over_busy"] = entry["SQ_ACTIVE_INST_VALU"] / entry["SQ_BUSY_CYCLES"]
         summary[f"cfg{config}:{kernel}"] = entry
+    # ---- the whole call: what one C-ABI call of this config issues and moves, summed over its kernels (which may overlap on
+    #      several streams: per-kernel durations then add up to more than the call)
+    try:
+        with open(os.path.join(directory, "bench.json")) as handle:
+            line = json.loads(handle.read().strip().splitlines()[-1])
+        calls = line["steps"] + line["warmup"]
+        call = {"_config": config, "_calls_timed": calls, "_kernel_seconds_per_call": line["roofline"]["kernel_ms"] * 1e-3,
+                "_cells_per_call": line["config"]["cells_per_gpu"], "kernels": {}}
+        totals = defaultdict(float)
+        scoring = {name: entry for name, entry in summary.items()
+                   if entry.get("_config") == config and not name.endswith(":__call__") and "plan_kernel" not in name and "utf8_transcode" not in name}
+        launches_seen = sum(entry.get("_calls", 0) for entry in scoring.values())
+        launches_per_call = line["roofline"].get("launches_per_step", 1)
+        for name, entry in scoring.items():
+            # the run may hold more calls than steps + warm-up (bench.py's fresh-batch leg): scale by the launches one call makes
+            per_call = entry.get("_calls", 0) / max(launches_seen, 1) * launches_per_call
+            call["kernels"][name.split(":", 1)[1]] = {"launches_per_call": round(per_call, 3), "share_of_kernel_time": round(entry.get("_share", 0.0), 4)}
+            for counter in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT",
+                            "hbm_fetch_bytes_raw", "hbm_write_bytes_raw"):
+                if counter in entry:
+                    totals[counter] += entry[counter] * per_call
+        call.update(totals)
+        seconds = call["_kernel_seconds_per_call"]
+        if "SQ_INSTS_VALU" in call and seconds:
+            call["valu_lane_ops_per_second"] = call["SQ_INSTS_VALU"] * 64 / seconds
+            call["valu_lane_ops_per_cell"] = call["SQ_INSTS_VALU"] * 64 / max(call["_cells_per_call"], 1)
+        if "SQ_ACTIVE_INST_VALU" in call and seconds:  # quad-cycles summed over 1024 SIMDs against the call's kernel time at 2.4 GHz
+            call["valu_busy_fraction"] = call["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (seconds * 2.4e9)
+        if call.get("SQ_LDS_IDX_ACTIVE"):
+            call["lds_conflict_fraction"] = call.get("SQ_LDS_BANK_CONFLICT", 0.0) / call["SQ_LDS_IDX_ACTIVE"]
+            call["lds_busy_fraction"] = call["SQ_LDS_IDX_ACTIVE"] / 256 / (seconds * 2.4e9)  # cycles summed over 256 CUs
+        summary[f"cfg{config}:__call__"] = call
+    except (OSError, ValueError, KeyError, IndexError) as problem:
+        print(f"cfg{config}: no call-level record ({problem})", file=sys.stderr)
 print(json.dumps(summary, indent=1))

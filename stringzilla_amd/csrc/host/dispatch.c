@@ -284,7 +284,7 @@ static sz_status_t decide(szs_engine_s const *engine, int symmetric, int runes, 
     d->longest[0] = q_stats->longest, d->longest[1] = c_stats->longest;
     d->use_myers = engine->is_unit_cost && (engine->family == szs_family_levenshtein_k || engine->family == szs_family_levenshtein_utf8_k);
     d->maximise = engine->family == szs_family_needleman_wunsch_k || engine->family == szs_family_smith_waterman_k;
-    /* bit-parallel at any length for bytes (2048-row strips beyond 64 words), up to 2048 symbols for codepoints */
+    /* bit-parallel at any length (2048-row strips beyond 64 words); `banded` names the byte flavour of the strip kernel */
     d->banded = d->use_myers && !runes;
 
     /* ---- orientation and tier.  Every kernel puts ONE side on workgroups / band chains (its "queries") and the other
@@ -292,7 +292,7 @@ static sz_status_t decide(szs_engine_s const *engine, int symmetric, int runes, 
      * alike and a swapped class table is its transpose - so a cycle model of both tiers (plan.c) is evaluated for both
      * orientations and the cheaper one runs.  1024 queries x 1 candidate thus become 1 workgroup row of 1024 lanes
      * instead of 1024 workgroups with one live lane each.  Symmetric calls have nothing to swap. */
-    szs_plan_orient(d->banded ? 0xFFFFFFFFu : (d->use_myers ? SZS_MYERS_MAX_WORDS * 32 : 0), d->use_myers && !runes, !engine->is_linear,
+    szs_plan_orient(d->use_myers ? 0xFFFFFFFFu : 0 /* bit-parallel at any length, bytes and codepoints alike */, d->use_myers && !runes, !engine->is_linear,
                     !d->maximise, symmetric, q_stats, c_stats, szs_hip_systolic_band_rows(), &d->tier, &d->transposed);
     /* the `tier` knob: `systolic` on a unit-cost engine means the DP recurrences, `chain` the bit-parallel chain */
     if (d->tier == SZS_TIER_MYERS_CHAIN && szs_tuning_get(szs_knob_tier_k) == SZS_TIER_SYSTOLIC) d->tier = SZS_TIER_SYSTOLIC;

@@ -102,7 +102,9 @@ typedef struct szs_engine_s {
     hipEvent_t event_start, event_stop;
     int events_device;
     /* launches of different bit-vector widths fan out over these and fill each other's tails (dispatch.c: enqueue) */
+#ifndef SZS_AUX_STREAMS
 #define SZS_AUX_STREAMS 3
+#endif
     hipStream_t aux_streams[SZS_AUX_STREAMS];
     hipEvent_t aux_done[SZS_AUX_STREAMS], fork_event;
     int aux_device; /* device the auxiliary streams live on, -1: none yet */
