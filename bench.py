@@ -273,8 +273,9 @@ def measure_extra(config, scope, device_index, args, fence, with_cpu):
         "results_checksum": int(results.sum().item()),
         "roofline": roofline(config, profile, kernel),
     }
-    if with_cpu:  # timed later, after every GPU measurement of the run (the host cores are busy for ~10 s per baseline)
-        record["_cpu_baseline_inputs"] = (load, results.cpu().numpy())
+    if with_cpu:  # timed later, after every GPU measurement of the run (the host cores are busy for ~10 s per baseline); the
+        # matrix stays in HBM until then - downloading 80 MB here would idle the shader engines right before the headline
+        record["_cpu_baseline_inputs"] = (load, results)
     return record
 
 
@@ -284,7 +285,7 @@ def attach_cpu_baselines(records, seconds):
         if inputs is None:
             continue
         try:
-            record["cpu_baseline"] = cpu_baseline(inputs[0], inputs[1], seconds)
+            record["cpu_baseline"] = cpu_baseline(inputs[0], inputs[1].cpu().numpy(), seconds)
         except AssertionError:
             raise
         except Exception as problem:  # the checker is optional equipment; the GPU numbers stand without it

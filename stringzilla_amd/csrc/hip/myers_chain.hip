@@ -35,7 +35,7 @@ constexpr u32 chain_columns_k = 8;              // K: text columns a lane advanc
 constexpr u32 chain_chunk_steps_k = 16;         // steps per hand-over between bands (128 columns)
 constexpr u32 chain_slack_words_k = 64;         // parked words past the longest candidate
 constexpr size_t chain_header_bytes_k = 256;    // ticket counter [0] and stall flag [1]: the layout systolic.hip uses
-constexpr u32 chain_spin_limit_k = 1u << 18;
+constexpr unsigned long long chain_patience_ticks_k = 200000000ull; // 2 s of the 100 MHz wall clock: how long a band waits for its predecessor before it flags the call (the host then re-runs it on the lanes tier)
 constexpr u32 chain_max_waves_k = 16;           // wavefronts per workgroup: up to 16 CANDIDATES against the same query band
 static_assert(chain_band_rows_k == SZS_MYERS_CHAIN_BAND_ROWS, "the host planner models bands of this height");
 static_assert(chain_columns_k == 8, "the text bytes of one step travel in two dwords, the deltas in one");
@@ -181,11 +181,13 @@ __global__ __launch_bounds__(64 * chain_waves_k) void myers_chain_kernel(szs_str
     auto preload_bits = [&](u32 first_step) { // the predecessor's deltas under the steps [first_step, first_step + 16)
         u32 const last_column = K * (first_step + chunk_steps);
         u64 const needed = tag | (last_column < n ? last_column : n);
+        unsigned long long wait_started = 0;
         for (u32 spins = 0; parked_seen < needed && !abandoned; ++spins) {
             parked_seen = __hip_atomic_load(progress_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (parked_seen >= needed) break;
             __builtin_amdgcn_s_sleep(2);
-            bool const hopeless = spins > chain_spin_limit_k ||
+            if (spins == 0) wait_started = wall_clock64();
+            bool const hopeless = (spins % 256 == 255 && wall_clock64() - wait_started > chain_patience_ticks_k) ||
                                   (spins % 1024 == 1023 && __hip_atomic_load(work_counter + 1, __ATOMIC_RELAXED,
                                                                              __HIP_MEMORY_SCOPE_AGENT) == (tag | 1));
             if (hopeless) { // never hang the device on a broken invariant: flag the call, let the host report it

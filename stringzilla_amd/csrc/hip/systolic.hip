@@ -74,7 +74,9 @@ constexpr u32 systolic_columns_k = 4;                           // K: consecutiv
 constexpr u32 systolic_chunk_steps_k = 16;                      // steps (of K columns) per hand-over between bands
 constexpr u32 systolic_slack_k = 64;                            // parked columns past the longest candidate
 constexpr size_t systolic_header_bytes_k = 256;                 // ticket counter [0] and stall flag [1] at the head of the control block
-constexpr u32 systolic_spin_limit_k = 1u << 18;                 // polls of a predecessor's counter before giving up
+constexpr unsigned long long systolic_patience_ticks_k = 200000000ull; // 2 s of the 100 MHz wall clock: how long a band waits for its
+                                                                     // predecessor before it flags the call - ELAPSED time, not a poll count: a slow predecessor
+                                                                     // (a shared GPU, a profiler) is not a stall; the host re-runs a flagged call on the lanes tier
 static_assert(systolic_rows_k % 4 == 0 && systolic_rows_k <= 16, "R int8 costs are fetched as one LDS read");
 static_assert(systolic_band_rows_k == SZS_SYSTOLIC_BAND_ROWS, "the host planner models bands of this height");
 
@@ -397,14 +399,16 @@ __global__ __launch_bounds__(64 * systolic_waves_k) void systolic_scores_kernel(
     auto preload_above = [&](u32 first_step) { // the predecessor's bottom row under the steps [first_step, first_step + 16)
         u32 const last_column = K * (first_step + chunk_steps);
         u64 const needed = tag | (last_column < n ? last_column : n);
+        unsigned long long wait_started = 0;
         for (u32 spins = 0; parked_seen < needed && !abandoned; ++spins) {
             parked_seen = __hip_atomic_load(progress_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (parked_seen >= needed) break;
             __builtin_amdgcn_s_sleep(2);
             // A predecessor only ever needs to score a few hundred columns to satisfy this wait (microseconds).  Never
-            // hang the device on a broken invariant: give up after a fraction of a second - at once if another band
+            // hang the device on a broken invariant: give up after two seconds - at once if another band
             // already has - flag the call, and let the host report the failure.
-            bool const hopeless = spins > systolic_spin_limit_k ||
+            if (spins == 0) wait_started = wall_clock64();
+            bool const hopeless = (spins % 256 == 255 && wall_clock64() - wait_started > systolic_patience_ticks_k) ||
                                   (spins % 1024 == 1023 && __hip_atomic_load(work_counter + 1, __ATOMIC_RELAXED,
                                                                              __HIP_MEMORY_SCOPE_AGENT) == (tag | 1));
             if (hopeless) {

@@ -238,3 +238,41 @@ def test_dataset_tokeniser_follows_the_reference_benchmark():
     assert len(workloads.tokenize_dataset(b"", "words")) == 0
     with pytest.raises(ValueError):
         workloads.tokenize_dataset(b"abcd", "0")
+
+
+def test_tuning_knobs_are_set_by_call_not_by_environment():
+    """`SZS_ROCM_*` is read once, when the library is loaded; afterwards only `szs_rocm_tuning_set` changes a knob."""
+    import os
+
+    assert _abi.tuning_set("tier", "lanes") in (None, os.environ.get("SZS_ROCM_TIER"))
+    assert _abi.tuning_set("SZS_ROCM_TIER", None) == "lanes"      # the environment spelling names the same knob
+    for knob in ("swap", "packed", "rune_ids", "chain_waves", "trace", "cells", "planner", "speculate", "cpu_requests", "streams", "reuse"):
+        previous = _abi.tuning_set(knob, "1")
+        _abi.tuning_set(knob, previous)
+    with pytest.raises(ValueError):
+        _abi.tuning_set("no_such_knob", "1")
+    assert _abi.lib.szs_rocm_tuning_set(b"no_such_knob", b"1") != 0 and _abi.lib.szs_rocm_tuning_set(None, None) != 0
+    os.environ["SZS_ROCM_TIER"] = "systolic"                      # too late to matter: never read again
+    lengths = np.full(4, 100, dtype=np.uint32)
+    tier, transposed = ctypes.c_int(-1), ctypes.c_int(-1)
+    assert _abi.lib.szs_rocm_orientation_probe(1, 0, 1, 0, lengths.ctypes.data, 4, lengths.ctypes.data, 4, ctypes.byref(tier),
+                                               ctypes.byref(transposed)) == 0
+    del os.environ["SZS_ROCM_TIER"]
+    with_env_ignored = tier.value
+    _abi.tuning_set("tier", "lanes")
+    assert _abi.lib.szs_rocm_orientation_probe(1, 0, 1, 0, lengths.ctypes.data, 4, lengths.ctypes.data, 4, ctypes.byref(tier),
+                                               ctypes.byref(transposed)) == 0
+    _abi.tuning_set("tier", None)
+    assert tier.value == 0 and with_env_ignored in (0, 1, 2)
+
+
+def test_node_entry_fails_loudly_without_a_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: tests/test_gpu_round2.py covers the node entry")
+    with pytest.raises(szs.StringZillasError) as failure:
+        szs.Node([0])
+    assert failure.value.status_name == "missing_gpu"
+    assert _abi.lib.szs_rocm_node_size(None) == 0
+    _abi.lib.szs_rocm_node_free(None), _abi.lib.szs_rocm_node_engine_free(None)  # null handles are ignored, like every *_free
