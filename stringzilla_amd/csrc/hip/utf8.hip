@@ -21,57 +21,94 @@
 namespace szs_hip {
 
 /**
- *  One string per thread; strings are independent and the pass is O(bytes) next to O(Q C len^2 / 32).  What costs here is
- *  LATENCY, not work: round 1 read the string a byte at a time, every read dependent on the previous rune's length - one
- *  global-memory round trip per rune, 0.9 ms for config 5's 2 KB strings.  Now a thread walks its string in aligned 16-byte
- *  chunks held in registers, the next chunk in flight while the current one is decoded: a round trip per 16 bytes, hidden.
- *  Only chunks that overlap the string are ever loaded (same 16-byte line as a byte the caller owns).
+ *  One string per WAVEFRONT, 64 bytes per step, one byte per lane - and still the sequential contract, bit for bit.
+ *
+ *  `sz_rune_decode_unchecked` takes the length of a sequence from its lead byte alone, so which bytes ARE leads is a chain:
+ *  position p is a lead iff some lead q < p has q + length(byte q) == p.  One thread per string followed that chain byte by
+ *  byte - a dependent global-memory round trip per rune in round 1 (0.9 ms for config 5's 2 KB strings, and it would have
+ *  been half a second for a 1 MB document).  Here the chain is the ORBIT of the chunk's first lead under
+ *  `next(p) = p + length(byte p)`, and an orbit is computed by pointer doubling: after step k the marked set holds
+ *  next^i(start) for every i < 2^(k+1), and next^(2^(k+1)) = next^(2^k) o next^(2^k) - six steps for 64 positions, each one
+ *  LDS scatter / gather and one lane permute.  Chunks of plain ASCII (no byte >= 0x80, no sequence hanging in from the
+ *  chunk before) skip all of it: every byte is a lead.  A lead's rune index is a popcount of the lead mask below it, so the
+ *  runes of a chunk are written in one coalesced burst.  The next chunk's bytes are in flight while this one is decoded.
  */
-__global__ __launch_bounds__(256) void utf8_transcode_kernel(szs_string_ref_t const *__restrict__ strings, u32 count,
-                                                             u64 const *__restrict__ rune_starts,
-                                                             u32 *__restrict__ runes, u32 *__restrict__ rune_counts,
-                                                             u32 *__restrict__ any_multibyte) {
-    u32 const i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    u64 const address = strings[i].address;
-    u32 const length = strings[i].length;
-    u32 *const out = runes + rune_starts[i];
-    uint4 const *const lines = reinterpret_cast<uint4 const *>(address & ~(u64)15);
-    u32 const skew = (u32)(address & 15);                          // string byte b is stream byte skew + b
-    u32 const line_count = length ? (skew + length + 15) / 16 : 0; // lines that hold string bytes
-    uint4 const zero = make_uint4(0, 0, 0, 0);
-    uint4 current = line_count ? lines[0] : zero, next = line_count > 1 ? lines[1] : zero;
-    u32 line = 0, produced = 0, multibyte = 0;
-    // the four stream bytes starting at stream position `at`, which lies in the current line
-    auto four_bytes = [&](u32 at) -> u32 {
-        u32 const word = (at >> 2) & 3u;
-        u32 const low = word == 0 ? current.x : word == 1 ? current.y : word == 2 ? current.z : current.w;
-        u32 const high = word == 0 ? current.y : word == 1 ? current.z : word == 2 ? current.w : next.x;
-        return __builtin_amdgcn_alignbyte(high, low, at & 3u);
-    };
-    for (u32 progress = 0; progress < length;) {
-        u32 const at = skew + progress;
-        if ((at >> 4) != line) { // the lead byte lies in the next line: it becomes the current one, its successor is fetched
-            ++line;
-            current = next;
-            next = line + 1 < line_count ? lines[line + 1] : zero;
-        }
-        u32 const bytes = four_bytes(at);
-        u32 const lead = bytes & 0xFFu;
-        u32 const sequence = 1u + (lead >= 0xC0u) + (lead >= 0xE0u) + (lead >= 0xF0u);
-        u32 tail[3];
+constexpr int transcode_waves_k = 4; // wavefronts (strings in flight) per workgroup
+
+__global__ __launch_bounds__(64 * transcode_waves_k) void utf8_transcode_kernel(szs_string_ref_t const *__restrict__ strings, u32 count,
+                                                                                u64 const *__restrict__ rune_starts,
+                                                                                u32 *__restrict__ runes, u32 *__restrict__ rune_counts,
+                                                                                u32 *__restrict__ any_multibyte) {
+    __shared__ u8 reached[transcode_waves_k][64];
+    u32 const lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    u8 volatile *const mine = reached[wave];
+    u64 const below = (1ull << lane) - 1; // lanes before this one
+    for (u32 i = blockIdx.x * transcode_waves_k + wave; i < count; i += gridDim.x * transcode_waves_k) {
+        u8 const *const bytes = reinterpret_cast<u8 const *>(strings[i].address);
+        u32 const length = strings[i].length;
+        u32 *const out = runes + rune_starts[i];
+        u32 produced = 0, hanging = 0; // `hanging`: bytes at the head of the chunk that belong to the previous chunk's last rune
+        bool multibyte = false;
+        u32 ahead = lane < length ? bytes[lane] : 0u; // the chunk after the current one, loaded one step early
+        for (u32 base = 0; base < length; base += 64) {
+            u32 const byte = ahead;
+            u32 const after = base + 64 + lane;
+            ahead = after < length ? bytes[after] : 0u;
+            bool const valid = base + lane < length;
+            u64 const valid_mask = __ballot(valid);
+            u32 const sequence = 1u + (byte >= 0xC0u) + (byte >= 0xE0u) + (byte >= 0xF0u);
+            u64 const high_mask = __ballot(valid && byte >= 0x80u);
+            multibyte |= high_mask != 0;
+
+            u64 leads;
+            if (!high_mask && !hanging) leads = valid_mask; // plain ASCII: every byte is a lead
+            else {
+                u32 jump = valid ? lane + sequence : 64u; // next^(2^k) of this position, 64 = beyond the chunk
+                jump = jump > 64u ? 64u : jump;
+                u64 marked = hanging < 64u ? 1ull << hanging : 0ull;
 #pragma unroll
-        for (u32 k = 1; k < 4; ++k) tail[k - 1] = k < sequence && progress + k < length ? (bytes >> (8 * k)) & 0x3Fu : 0u;
-        u32 rune = lead;
-        if (sequence == 2) rune = (lead & 0x1Fu) << 6 | tail[0];
-        if (sequence == 3) rune = (lead & 0x0Fu) << 12 | tail[0] << 6 | tail[1];
-        if (sequence == 4) rune = (lead & 0x07u) << 18 | tail[0] << 12 | tail[1] << 6 | tail[2];
-        out[produced++] = rune;
-        progress += sequence;
-        multibyte |= lead >= 0x80u; // any byte >= 0x80 takes the pair off the reference's ASCII shortcut (serial.hpp:2809)
+                for (int k = 0; k < 6; ++k) {
+                    mine[lane] = 0;
+                    __builtin_amdgcn_wave_barrier();
+                    if (((marked >> lane) & 1ull) && jump < 64u) mine[jump] = 1;
+                    __builtin_amdgcn_wave_barrier();
+                    marked |= __ballot(mine[lane] != 0);
+                    __builtin_amdgcn_wave_barrier();
+                    u32 const onward = (u32)__shfl((int)jump, (int)(jump & 63u), 64); // next^(2^k) of where this lane lands
+                    jump = jump < 64u ? onward : 64u;
+                }
+                leads = marked & valid_mask;
+            }
+
+            // ---- decode the leads: tail bytes come from the lanes above, the last three lanes' from the chunk ahead
+            u32 tail[3];
+#pragma unroll
+            for (u32 k = 1; k < 4; ++k) {
+                u32 const here = (u32)__shfl((int)byte, (int)((lane + k) & 63u), 64);
+                u32 const there = (u32)__shfl((int)ahead, (int)((lane + k) & 63u), 64);
+                u32 const source = lane + k < 64u ? here : there;
+                tail[k - 1] = k < sequence && base + lane + k < length ? source & 0x3Fu : 0u;
+            }
+            u32 rune = byte;
+            if (sequence == 2) rune = (byte & 0x1Fu) << 6 | tail[0];
+            if (sequence == 3) rune = (byte & 0x0Fu) << 12 | tail[0] << 6 | tail[1];
+            if (sequence == 4) rune = (byte & 0x07u) << 18 | tail[0] << 12 | tail[1] << 6 | tail[2];
+            if ((leads >> lane) & 1ull) out[produced + (u32)__popcll(leads & below)] = rune;
+            produced += (u32)__popcll(leads);
+
+            // ---- what hangs over into the next chunk: the last lead's sequence may end beyond this one
+            if (leads) {
+                u32 const last = 63u - (u32)__clzll(leads);
+                u32 const end = last + (u32)__shfl((int)sequence, (int)last, 64);
+                hanging = end > 64u ? end - 64u : 0u;
+            }
+            else hanging = hanging >= 64u ? hanging - 64u : 0u; // (a chunk without leads: cannot happen, sequences are <= 4 bytes)
+        }
+        if (lane == 0) {
+            rune_counts[i] = produced;
+            if (multibyte) atomicOr(any_multibyte, 1u);
+        }
     }
-    rune_counts[i] = produced;
-    if (multibyte) atomicOr(any_multibyte, 1u);
 }
 
 } // namespace szs_hip
@@ -80,7 +117,8 @@ extern "C" int szs_hip_utf8_transcode(szs_string_ref_t const *strings, uint32_t 
                                       uint32_t *runes, uint32_t *rune_counts, uint32_t *any_multibyte, void *stream) {
     using namespace szs_hip;
     if (!count) return 0;
-    hipLaunchKernelGGL(utf8_transcode_kernel, dim3((count + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+    u32 const blocks = (count + transcode_waves_k - 1) / transcode_waves_k;
+    hipLaunchKernelGGL(utf8_transcode_kernel, dim3(blocks < 65536u ? blocks : 65536u), dim3(64 * transcode_waves_k), 0, static_cast<hipStream_t>(stream),
                        strings, count, rune_starts, runes, rune_counts, any_multibyte);
     return (int)hipGetLastError();
 }
