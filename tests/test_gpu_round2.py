@@ -406,3 +406,30 @@ def test_u64_tape_with_offsets_beyond_4_gib(gpu, oracle, planner):
                 assert np.array_equal(results.cpu().numpy(), expected.view(np.int64))
     del data
     torch.cuda.empty_cache()
+
+
+# ---- real text through the reference's benchmark tokeniser (bench/shared.hpp:240-290) ------------------------------------
+
+
+@pytest.mark.parametrize("tokens", ["words", "lines"])
+def test_real_text_tokens_match_the_oracle(gpu, oracle, tokens):
+    """The only real prose in this image is the documentation that travels with the repository (a few
+    hundred KB of English, Markdown tables and code, with multi-byte punctuation): tokenised the way the reference's bench
+    does (`workloads.tokenize_dataset`), 400 x 400 tokens drawn like `bench/similarities.cuh` draws them, scored at the byte
+    and at the codepoint level, every cell against the oracle.  Real text is ragged (words of 1 .. 40 bytes, lines of
+    0 .. 1100) and repetitive (duplicates, shared prefixes) in ways the synthetic configs are not."""
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    corpus = b"".join(open(os.path.join(root, name), "rb").read() for name in ("SURVEY.md", "DESIGN.md"))
+    found = workloads.tokenize_dataset(corpus, tokens)
+    assert len(found) > 300
+    rng = np.random.default_rng(7)
+    queries = [found[int(i)] for i in rng.integers(0, len(found), size=400)]
+    candidates = [found[int(i)] for i in rng.integers(0, len(found), size=400)]
+    assert any(max(q) >= 0x80 for q in queries + candidates if q), "the sample should hold multi-byte text"
+    for engine, expected in ((szs.LevenshteinDistances(capabilities=gpu), oracle.levenshtein(queries, candidates)),
+                             (szs.LevenshteinDistancesUTF8(capabilities=gpu), oracle.levenshtein_utf8(queries, candidates)),
+                             (szs.LevenshteinDistances(0, 2, 3, 1, capabilities=gpu), oracle.levenshtein(queries, candidates, 0, 2, 3, 1))):
+        for _ in range(2):
+            assert np.array_equal(engine(queries, candidates, device=gpu), expected)
