@@ -120,6 +120,45 @@ __device__ __forceinline__ void myers_column_probe(uint32_t (&vp)[words_], uint3
     (void)hp_history, (void)hn_history; /* the kernel no longer tracks the score per column (popcount at text end) */
 }
 
+/* The same column in BLOCK form (Myers 1999 for long patterns; the reference's serial.hpp:2182-2204): no carry between the
+ * words of the add - a -1 entering a word from below acts like a match in its first row - so the add is a plain v_add_u32
+ * and the shifts take their low bit from the word below as a 0 / 1 value.  Measured beside the full-width form to decide
+ * which one the kernels should use. */
+template <int words_, bool add_shift_>
+__device__ __forceinline__ void myers_column_block_probe(uint32_t (&vp)[words_], uint32_t (&vn)[words_], uint32_t const (&eq)[words_]) {
+    uint32_t hp_in = 1, hn_in = 0;
+#pragma unroll
+    for (int w = 0; w < words_; ++w) {
+        uint32_t const xv = eq[w] | vn[w];
+        uint32_t const eq_in = eq[w] | hn_in;
+        uint32_t const sum = (eq_in & vp[w]) + vp[w];
+        uint32_t const d0 = (sum ^ vp[w]) | eq_in;
+        uint32_t const hp = vn[w] | ~(d0 | vp[w]);
+        uint32_t const hn = vp[w] & d0;
+        uint32_t const hp_shifted = add_shift_ ? ((hp + hp) | hp_in) : ((hp << 1) | hp_in);
+        uint32_t const hn_shifted = add_shift_ ? ((hn + hn) | hn_in) : ((hn << 1) | hn_in);
+        hp_in = hp >> 31, hn_in = hn >> 31;
+        vp[w] = hn_shifted | ~(xv | hp_shifted);
+        vn[w] = hp_shifted & xv;
+    }
+}
+
+template <int words_, bool add_shift_>
+__global__ __launch_bounds__(256) void k_myers_block(uint32_t *out, uint32_t seed, int iterations) {
+    uint32_t vp[words_], vn[words_], eq[4][words_];
+    for (int w = 0; w < words_; ++w) {
+        vp[w] = ~0u, vn[w] = 0;
+        for (int k = 0; k < 4; ++k) eq[k][w] = (seed * (w + 3) + threadIdx.x * 2654435761u) >> (k * 3 + (blockIdx.x & 3));
+    }
+    for (int i = 0; i < iterations; ++i) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) myers_column_block_probe<words_, add_shift_>(vp, vn, eq[k & 3]);
+    }
+    uint32_t sum = 0;
+    for (int w = 0; w < words_; ++w) sum ^= vp[w] ^ vn[w];
+    if (sum == 0x12345678u) out[0] = sum;
+}
+
 template <int words_>
 __global__ __launch_bounds__(256) void k_myers_pure(uint32_t *out, uint32_t seed, int iterations) {
     uint32_t vp[words_], vn[words_], eq[4][words_];
@@ -213,6 +252,10 @@ int main() {
         printf(", \"myers_pure_W5_Tcells\": %.2f", base * 160 / time_kernel(k_myers_pure<5>, out, columns / 16, blocks) / 1e12);
         printf(", \"myers_pure_W8_Tcells\": %.2f", base * 256 / time_kernel(k_myers_pure<8>, out, columns / 16, blocks) / 1e12);
         printf(", \"myers_pure_W1_Tcells\": %.2f", base * 32 / time_kernel(k_myers_pure<1>, out, columns / 16, blocks) / 1e12);
+        printf(", \"myers_block_W4_Tcells\": %.2f", base * 128 / time_kernel((k_myers_block<4, false>), out, columns / 16, blocks) / 1e12);
+        printf(", \"myers_block_addshift_W4_Tcells\": %.2f", base * 128 / time_kernel((k_myers_block<4, true>), out, columns / 16, blocks) / 1e12);
+        printf(", \"myers_block_W8_Tcells\": %.2f", base * 256 / time_kernel((k_myers_block<8, false>), out, columns / 16, blocks) / 1e12);
+        printf(", \"myers_block_addshift_W8_Tcells\": %.2f", base * 256 / time_kernel((k_myers_block<8, true>), out, columns / 16, blocks) / 1e12);
     }
     double const lds_reads = (double)blocks * 256 * iterations * INNER;
     printf(", \"ds_read_b128_random95_Tlane_reads\": %.3f", lds_reads / time_kernel(k_lds_b128<1>, out, iterations, blocks) / 1e12);
