@@ -71,6 +71,16 @@ int szs_hip_levenshtein_myers(unsigned words, szs_string_ref_t const *queries, u
                               void *stream);
 
 /**
+ *  The same for the long widths (`words` = 24 (2 lanes only), 32, 48 or 64) with every pair spread over `lanes` = 2 or 4 adjacent lanes - a
+ *  strip pipeline inside the wavefront: 1 / lanes of the one-lane-per-pair kernels' floor (the longest pair), the same work.
+ *  Every query of the launch fits `words`; a workgroup scores one query against 256 / lanes candidates.
+ */
+int szs_hip_levenshtein_myers_split(unsigned words, unsigned lanes, szs_string_ref_t const *queries, uint32_t queries_count,
+                                    szs_string_ref_t const *candidates, uint32_t candidates_count, uint64_t *results,
+                                    uint64_t results_row_stride, int symmetric, szs_ref_guard_t const *guard /* may be NULL */,
+                                    void *stream);
+
+/**
  *  Codepoint-level twin of the short-query bit-parallel kernel: strings are UTF-32 arrays (`address` points at `u32`
  *  runes, `length` counts runes) produced by szs_hip_utf8_transcode; every query has at most 256 runes.
  */
@@ -126,6 +136,7 @@ enum {
                                 masks without the GPU bit and CPU scopes are served by the GPU engines on device 0 */
     szs_knob_streams_k,     /* -1 automatic | 0: every launch of a call on the scope's one stream */
     szs_knob_reuse_k,       /* -1 automatic | 0: never re-use the refs planned for the previous call of the same tapes */
+    szs_knob_split_k,       /* -1 automatic | 0 / 2 / 4: lanes per pair of the long byte kernels (24 ... 64 words) */
     szs_knob_count_k
 };
 int szs_tuning_get(int knob);

@@ -581,6 +581,138 @@ __global__ __launch_bounds__(256, 2) /* two wavefronts per SIMD, like the long k
     }
 }
 
+/* ---- long byte queries, SEVERAL LANES PER PAIR -------------------------------------------------------------------------------
+ *
+ *  One lane per pair makes the longest pair the floor of a launch: a 2048 x 2048-byte pair is 2048 columns x 64 words x 10.5
+ *  instructions in ONE lane, 2-5 ms, however idle the rest of the chip is (a wavefront that has its SIMD to itself issues a
+ *  dependent instruction every ~8 cycles).  On one GPU the floor hides behind other work; an eighth of config 5 on each of 8
+ *  GPUs is 1.7 ms of work under a 5.5 ms floor (profiles/r02/shard_preview.jsonl).
+ *
+ *  Here a pair is spread over L = 2 or 4 ADJACENT lanes: lane k holds words [k W / L, (k + 1) W / L) of the pattern's
+ *  bit-vector and runs k columns behind lane k - 1 - a systolic strip pipeline inside the wavefront.  Between the strips of
+ *  neighbouring lanes only the horizontal deltas of the strip's last row cross (Hyyro's block boundary, as between the strips
+ *  of the kernel above); they travel with the text symbol in one `v_mov_b32_dpp row_shr:1` per column.  Same instructions per
+ *  cell (+2 % for the hand-over), 1 / L of the floor, W / L words of state per lane (no spills at 64 words).
+ */
+template <int words_per_lane_, int lanes_>
+__global__ __launch_bounds__(256, 2) void levenshtein_myers_split_kernel(szs_string_ref_t const *__restrict__ queries,
+                                                                        szs_string_ref_t const *__restrict__ candidates,
+                                                                        u32 candidates_count, u32 candidate_blocks,
+                                                                        u64 *__restrict__ results, u64 results_row_stride,
+                                                                        int symmetric, szs_ref_guard_t guard) {
+    constexpr int words = words_per_lane_ * lanes_;
+    constexpr u32 pairs_per_block = 256u / lanes_;
+    constexpr int chunks_per_lane = words_per_lane_ / 4;
+    static_assert(words_per_lane_ % 4 == 0 && (lanes_ == 2 || lanes_ == 4), "whole 16-byte Peq chunks per lane");
+    using layout = peq_layout<words>;
+    __shared__ __attribute__((aligned(16))) u32 peq[layout::total_dwords];
+
+    u32 const query_slot = blockIdx.x / candidate_blocks, candidate_block = candidate_blocks - 1 - blockIdx.x % candidate_blocks;
+    szs_string_ref_t const query = queries[query_slot];
+    if (guard.enabled && !ref_is_current(guard, 0, query)) {
+        if (threadIdx.x == 0) *guard.stale = guard.sequence;
+        return;
+    }
+    u32 const query_length = query.length;
+    u32 const pad = 32u * words - query_length; // phantom low rows: all in lane 0's words (a launch variant spans < 512 rows)
+    for (int i = threadIdx.x; i < layout::total_dwords; i += 256) peq[i] = 0;
+    __syncthreads();
+    {
+        u8 const *pattern = reinterpret_cast<u8 const *>(query.address);
+        for (u32 i = threadIdx.x; i < query_length; i += 256) {
+            u32 const position = pad + i;
+            atomicOr(&peq[layout::dword_index(pattern[i], (int)(position >> 5))], 1u << (position & 31));
+        }
+    }
+    __syncthreads();
+
+    u32 const part = threadIdx.x % lanes_, pair = threadIdx.x / lanes_;
+    u32 const candidate_slot = candidate_block * pairs_per_block + pair;
+    bool live = candidate_slot < candidates_count;
+    szs_string_ref_t candidate = {0, 0, 0};
+    if (live) candidate = candidates[candidate_slot];
+    if (live && guard.enabled && !ref_is_current(guard, 1, candidate)) {
+        *guard.stale = guard.sequence;
+        live = false;
+    }
+    if ((symmetric & SZS_LAYOUT_SYMMETRIC) && candidate.index > query.index) live = false;
+    u32 const text_length = live ? candidate.length : 0;
+    u32 const longest_in_wave = wave_max_u32(text_length);
+
+    u32 vp[words_per_lane_], vn[words_per_lane_];
+#pragma unroll
+    for (int w = 0; w < words_per_lane_; ++w) {
+        u32 const first_bit = 32u * (part * words_per_lane_ + w);
+        vp[w] = first_bit >= pad ? ~0u : (first_bit + 32u <= pad ? 0u : (~0u << (pad - first_bit)));
+        vn[w] = 0;
+    }
+    // this lane's Peq chunks: rows of 16 bytes, chunk-major (peq_layout): chunk c of symbol s at uint4 index c * 256 + s
+    uint4 const *const my_rows = reinterpret_cast<uint4 const *>(peq) + part * chunks_per_lane * byte_rows_k;
+
+    u64 const safe_address = text_length ? candidate.address : query.address; // lanes without a text: see myers_workgroup
+    text_stream_t text(safe_address, text_length);
+    if (!text_length) text.valid_dwords = query_length ? 1 : 0;
+    u32 raw_low = text.raw(0), next = text.raw(1);
+    u32 incoming = 0; // from the lane below: symbol (8 bits) | hp << 8 | hn << 9 | valid << 10 of the column it has just finished
+    u32 const steps = longest_in_wave ? longest_in_wave + lanes_ - 1 : 0;
+#pragma unroll 1
+    for (u32 step = 0, dword = 0; step < steps; step += 4, ++dword) {
+        u32 const symbols = text.splice(raw_low, next);
+        raw_low = next, next = text.raw(dword + 2);
+#pragma unroll
+        for (u32 sub = 0; sub < 4; ++sub) {
+            bool const head = part == 0;
+            u32 const symbol = head ? (symbols >> (8 * sub)) & 0xFFu : incoming & 0xFFu;
+            u32 const hp_in = head ? 1u : (incoming >> 8) & 1u; // DP row 0 grows by one per column
+            u32 const hn_in = head ? 0u : (incoming >> 9) & 1u;
+            bool const active = head ? step + sub < text_length : ((incoming >> 10) & 1u) != 0;
+            u32 outgoing = 0;
+            if (active) {
+                u32 eq[words_per_lane_];
+#pragma unroll
+                for (int chunk = 0; chunk < chunks_per_lane; ++chunk) {
+                    uint4 const row = my_rows[chunk * byte_rows_k + symbol];
+                    eq[chunk * 4 + 0] = row.x, eq[chunk * 4 + 1] = row.y, eq[chunk * 4 + 2] = row.z, eq[chunk * 4 + 3] = row.w;
+                }
+                outgoing = symbol | (myers_strip_column<words_per_lane_>(vp, vn, eq, hp_in, hn_in) << 8) | (1u << 10);
+            }
+            // row_shr:1 - every lane takes its lower neighbour's word; the first lane of a row of 16 (a `head`) takes zero
+            incoming = (u32)__builtin_amdgcn_update_dpp(0, (int)outgoing, 0x111, 0xF, 0xF, true);
+        }
+    }
+
+    i32 delta = 0;
+#pragma unroll
+    for (int w = 0; w < words_per_lane_; ++w) delta += (i32)__builtin_popcount(vp[w]) - (i32)__builtin_popcount(vn[w]);
+#pragma unroll
+    for (int offset = 1; offset < lanes_; offset <<= 1) delta += __shfl_xor(delta, offset, 64);
+    if (live && part == 0) {
+        u64 const distance = (u64)((i64)text_length + delta);
+        bool const transposed = (symmetric & SZS_LAYOUT_TRANSPOSED) != 0;
+        u64 const row = transposed ? candidate.index : query.index, column_of = transposed ? query.index : candidate.index;
+        results[row * results_row_stride + column_of] = distance;
+        if ((symmetric & SZS_LAYOUT_SYMMETRIC) && candidate.index != query.index) results[column_of * results_row_stride + row] = distance;
+    }
+}
+
+template <int words_per_lane_, int lanes_>
+static int launch_myers_split(szs_string_ref_t const *queries, u32 queries_count, szs_string_ref_t const *candidates, u32 candidates_count,
+                              u64 *results, u64 stride, int symmetric, szs_ref_guard_t const *guard_or_null, hipStream_t stream) {
+    szs_ref_guard_t guard = {};
+    if (guard_or_null) guard = *guard_or_null;
+    u32 const pairs_per_block = 256u / lanes_;
+    u32 const candidate_blocks = (candidates_count + pairs_per_block - 1) / pairs_per_block;
+    u32 const queries_per_launch = candidate_blocks ? (1u << 30) / candidate_blocks : queries_count;
+    for (u32 first = 0; first < queries_count; first += queries_per_launch) {
+        u32 const batch = queries_count - first < queries_per_launch ? queries_count - first : queries_per_launch;
+        hipLaunchKernelGGL((levenshtein_myers_split_kernel<words_per_lane_, lanes_>), dim3(batch * candidate_blocks), dim3(256), 0, stream,
+                           queries + first, candidates, candidates_count, candidate_blocks, results, stride, symmetric, guard);
+        hipError_t const error = hipGetLastError();
+        if (error != hipSuccess) return (int)error;
+    }
+    return 0;
+}
+
 static u32 banded_grid(u64 work_items) {
     static int resident_of[device_slots_k]; // per device ordinal
     int *const slot = &resident_of[device_slot()];
@@ -1033,6 +1165,26 @@ extern "C" int szs_hip_levenshtein_myers(unsigned words, szs_string_ref_t const 
     default: return (int)hipErrorInvalidValue;
     }
 #undef SZS_MYERS_CASE
+}
+
+extern "C" int szs_hip_levenshtein_myers_split(unsigned words, unsigned lanes, szs_string_ref_t const *queries, uint32_t queries_count,
+                                               szs_string_ref_t const *candidates, uint32_t candidates_count, uint64_t *results,
+                                               uint64_t results_row_stride, int symmetric, szs_ref_guard_t const *guard, void *stream) {
+    using namespace szs_hip;
+    if (!queries_count || !candidates_count) return 0;
+    hipStream_t const s = static_cast<hipStream_t>(stream);
+#define SZS_SPLIT_CASE(W, L)                                                                                           \
+    if (words == W && lanes == L)                                                                                      \
+        return launch_myers_split<W / L, L>(queries, queries_count, candidates, candidates_count, results, results_row_stride, symmetric, guard, s);
+    SZS_SPLIT_CASE(24, 2)
+    SZS_SPLIT_CASE(32, 2)
+    SZS_SPLIT_CASE(48, 2)
+    SZS_SPLIT_CASE(64, 2)
+    SZS_SPLIT_CASE(32, 4)
+    SZS_SPLIT_CASE(48, 4)
+    SZS_SPLIT_CASE(64, 4)
+#undef SZS_SPLIT_CASE
+    return (int)hipErrorInvalidValue;
 }
 
 extern "C" int szs_hip_levenshtein_myers_runes(szs_string_ref_t const *queries, uint32_t queries_count,

@@ -429,6 +429,19 @@ static sz_status_t prepare(szs_engine_s *engine, szs_decision_t const *d, int de
     return status;
 }
 
+/**
+ *  Lanes per pair for a launch of the long byte widths: two when the launch fills the device anyway (measured on config 5:
+ *  13.5 -> 12.5 ms, the state of a 64-word pattern no longer spills), four when it has so few workgroups that its longest
+ *  pairs ARE its duration (an eighth of config 5: 5.4 -> 3.5 ms); 24 words split in two only (whole 16-byte Peq chunks per
+ *  lane).  The `split` knob pins 0, 2 or 4.
+ */
+static unsigned split_lanes_of(int knob, unsigned variant, uint64_t workgroups_unsplit) {
+    if (variant != 24 && variant != 32 && variant != 48 && variant != 64) return 0;
+    unsigned lanes = knob == 0 ? 0u : knob == 2 || knob == 4 ? (unsigned)knob : workgroups_unsplit < 1024 ? 4u : 2u;
+    if (variant == 24 && lanes == 4) lanes = 2;
+    return lanes;
+}
+
 /** Launches of one decision over device refs in kernel roles.  Returns the first launch error; counts launches. */
 static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int device, szs_string_ref_t const *query_refs,
                           szs_string_ref_t const *candidate_refs, void *device_results, size_t device_stride, hipStream_t stream,
@@ -484,6 +497,9 @@ static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int dev
         for (int i = 0; i < SZS_AUX_STREAMS && error == hipSuccess; ++i) error = hipStreamWaitEvent(engine->aux_streams[i], engine->fork_event, 0);
         if (error != hipSuccess) return error; /* nothing has been launched on the auxiliary streams */
     }
+    /* Lanes per pair of the long byte kernels (lev_myers.hip: levenshtein_myers_split_kernel): 1 / L of the floor that the
+     * longest pair puts under a launch, for the same work. */
+    int const split_knob = szs_tuning_get(szs_knob_split_k);
     unsigned next_lane = 0; /* round-robin over {scope's stream, auxiliary streams} for launches that need no workspace */
     for (unsigned g = 0; g < d->plan.groups_count && !launch_error && *status == sz_success_k; ++g) {
         szs_plan_group_t const *group = &d->plan.groups[g];
@@ -515,6 +531,10 @@ static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int dev
                                                            (int64_t *)device_results, device_stride, d->layout, engine->device_boundary.pointer, stream);
                 }
             }
+            else if (group->variant >= 24 && split_lanes_of(split_knob, group->variant, (uint64_t)group->count * candidate_blocks))
+                launch_error = szs_hip_levenshtein_myers_split(group->variant, split_lanes_of(split_knob, group->variant, (uint64_t)group->count * candidate_blocks),
+                                                               queries, count, candidate_refs, d->kc_count,
+                                                               (uint64_t *)device_results, device_stride, d->layout, guard, target);
             else if (group->variant)
                 launch_error = szs_hip_levenshtein_myers(group->variant, queries, count, candidate_refs, d->kc_count, (uint64_t *)device_results,
                                                          device_stride, d->layout, guard, target);

@@ -433,3 +433,24 @@ def test_real_text_tokens_match_the_oracle(gpu, oracle, tokens):
                              (szs.LevenshteinDistances(0, 2, 3, 1, capabilities=gpu), oracle.levenshtein(queries, candidates, 0, 2, 3, 1))):
         for _ in range(2):
             assert np.array_equal(engine(queries, candidates, device=gpu), expected)
+
+
+# ---- several lanes per pair for the long byte widths (lev_myers.hip: levenshtein_myers_split_kernel) ----------------------
+
+
+@pytest.mark.parametrize("lanes", ["2", "4", None])
+def test_split_lanes_agree_with_the_oracle(gpu, oracle, lanes):
+    """Queries of 641 .. 2048 bytes (launch variants 24, 32, 48, 64 words) with every pair spread over 2 or 4 lanes: every width
+    boundary, ragged candidates from empty to longer than the queries, more candidates than one workgroup takes, symmetric."""
+    rng = random.Random(64 + int(lanes or 0))
+    lengths = (641, 700, 768, 769, 800, 1023, 1024, 1025, 1100, 1500, 1536, 1537, 1600, 2000, 2047, 2048)
+    queries = [bytes(rng.choice(b"ACGTN") for _ in range(n)) for n in lengths]
+    candidates = _strings(rng, 150, 0, 2300, b"ACGTN") + [b"", b"A", queries[3], queries[-1][:-1]]
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+    expected = oracle.levenshtein(queries, candidates)
+    with knob("split", lanes), knob("tier", "lanes"), knob("swap", "0"):
+        for _ in range(2):  # planned, then the plan re-used (the split kernels carry the guard too)
+            assert np.array_equal(engine(queries, candidates, device=gpu), expected)
+        assert np.array_equal(engine(queries, device=gpu), oracle.levenshtein(queries, queries))
+    with knob("split", "0"), knob("tier", "lanes"), knob("swap", "0"):
+        assert np.array_equal(engine(queries, candidates, device=gpu), expected)
