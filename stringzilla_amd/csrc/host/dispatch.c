@@ -482,6 +482,7 @@ static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int dev
      * cells), so they fan out over the engine's auxiliary streams and fill each other's tails; only the launches that
      * share the strip workspace (`device_boundary`) stay on the scope's stream, in order. */
     int const fan_out = d->plan.groups_count > 1 && szs_tuning_get(szs_knob_streams_k) != 0;
+    unsigned const aux_used = !fan_out ? 0u : d->plan.groups_count - 1 < SZS_AUX_STREAMS ? d->plan.groups_count - 1 : (unsigned)SZS_AUX_STREAMS;
     hipError_t error = hipSuccess;
     if (fan_out) {
         if (engine->aux_device != device) {
@@ -494,17 +495,23 @@ static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int dev
             engine->aux_device = device;
         }
         error = hipEventRecord(engine->fork_event, stream);
-        for (int i = 0; i < SZS_AUX_STREAMS && error == hipSuccess; ++i) error = hipStreamWaitEvent(engine->aux_streams[i], engine->fork_event, 0);
+        for (unsigned i = 0; i < aux_used && error == hipSuccess; ++i) error = hipStreamWaitEvent(engine->aux_streams[i], engine->fork_event, 0);
         if (error != hipSuccess) return error; /* nothing has been launched on the auxiliary streams */
     }
     /* Lanes per pair of the long byte kernels (lev_myers.hip: levenshtein_myers_split_kernel): 1 / L of the floor that the
      * longest pair puts under a launch, for the same work. */
     int const split_knob = szs_tuning_get(szs_knob_split_k);
-    unsigned next_lane = 0; /* round-robin over {scope's stream, auxiliary streams} for launches that need no workspace */
+    /* Launches that need no workspace are dealt over {scope's stream, auxiliary streams} back and forth (0 .. n, n .. 0, ...):
+     * the groups come widest - slowest - first, so the second launch of a lane is the lightest one left. */
+    unsigned next_lane = 0;
     for (unsigned g = 0; g < d->plan.groups_count && !launch_error && *status == sz_success_k; ++g) {
         szs_plan_group_t const *group = &d->plan.groups[g];
         int const uses_workspace = group->variant == 0;
-        unsigned const lane = fan_out && !uses_workspace ? next_lane++ % (SZS_AUX_STREAMS + 1) : 0;
+        unsigned lane = 0;
+        if (fan_out && !uses_workspace) {
+            unsigned const turn = next_lane / (aux_used + 1), place = next_lane % (aux_used + 1);
+            lane = turn & 1 ? aux_used - place : place, ++next_lane;
+        }
         hipStream_t const target = lane ? engine->aux_streams[lane - 1] : stream;
         for (uint32_t done = 0; done < group->count && !launch_error && *status == sz_success_k; done += queries_per_launch) {
             szs_string_ref_t const *const queries = query_refs + group->first + done;
@@ -576,7 +583,7 @@ static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int dev
         }
     }
     if (fan_out) /* join, also after a failed launch: whatever was enqueued anywhere is drained by the wait on the scope's stream */
-        for (int i = 0; i < SZS_AUX_STREAMS; ++i) {
+        for (unsigned i = 0; i < aux_used; ++i) {
             hipError_t joined = hipEventRecord(engine->aux_done[i], engine->aux_streams[i]);
             if (joined == hipSuccess) joined = hipStreamWaitEvent(stream, engine->aux_done[i], 0);
             if (joined != hipSuccess) { /* cannot order the streams: wait here, so that nothing outlives the call */

@@ -103,7 +103,7 @@ typedef struct szs_engine_s {
     int events_device;
     /* launches of different bit-vector widths fan out over these and fill each other's tails (dispatch.c: enqueue) */
 #ifndef SZS_AUX_STREAMS
-#define SZS_AUX_STREAMS 3
+#define SZS_AUX_STREAMS 7
 #endif
     hipStream_t aux_streams[SZS_AUX_STREAMS];
     hipEvent_t aux_done[SZS_AUX_STREAMS], fork_event;
