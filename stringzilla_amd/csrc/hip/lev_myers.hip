@@ -594,14 +594,21 @@ __global__ __launch_bounds__(256, 2) /* two wavefronts per SIMD, like the long k
  *  of the kernel above); they travel with the text symbol in one `v_mov_b32_dpp row_shr:1` per column.  Same instructions per
  *  cell (+2 % for the hand-over), 1 / L of the floor, W / L words of state per lane (no spills at 64 words).
  */
+#ifndef SZS_SPLIT_WIDE_BLOCKS
+#define SZS_SPLIT_WIDE_BLOCKS 0 /* 1: 256 pairs (256 x L threads) per workgroup - measured slower on config 5 (11.9 vs 11.4 ms:
+                                   coarser workgroups, and the other widths' launches already fill the SIMDs); 0: 256 threads */
+#endif
+template <int lanes_>
+constexpr u32 split_threads_k = SZS_SPLIT_WIDE_BLOCKS ? 256u * lanes_ : 256u;
+
 template <int words_per_lane_, int lanes_>
-__global__ __launch_bounds__(256, 2) void levenshtein_myers_split_kernel(szs_string_ref_t const *__restrict__ queries,
+__global__ __launch_bounds__(split_threads_k<lanes_>) void levenshtein_myers_split_kernel(szs_string_ref_t const *__restrict__ queries,
                                                                         szs_string_ref_t const *__restrict__ candidates,
                                                                         u32 candidates_count, u32 candidate_blocks,
                                                                         u64 *__restrict__ results, u64 results_row_stride,
                                                                         int symmetric, szs_ref_guard_t guard) {
     constexpr int words = words_per_lane_ * lanes_;
-    constexpr u32 pairs_per_block = 256u / lanes_;
+    constexpr u32 threads = split_threads_k<lanes_>, pairs_per_block = threads / lanes_;
     constexpr int chunks_per_lane = words_per_lane_ / 4;
     static_assert(words_per_lane_ % 4 == 0 && (lanes_ == 2 || lanes_ == 4), "whole 16-byte Peq chunks per lane");
     using layout = peq_layout<words>;
@@ -615,11 +622,11 @@ __global__ __launch_bounds__(256, 2) void levenshtein_myers_split_kernel(szs_str
     }
     u32 const query_length = query.length;
     u32 const pad = 32u * words - query_length; // phantom low rows: all in lane 0's words (a launch variant spans < 512 rows)
-    for (int i = threadIdx.x; i < layout::total_dwords; i += 256) peq[i] = 0;
+    for (u32 i = threadIdx.x; i < (u32)layout::total_dwords; i += threads) peq[i] = 0;
     __syncthreads();
     {
         u8 const *pattern = reinterpret_cast<u8 const *>(query.address);
-        for (u32 i = threadIdx.x; i < query_length; i += 256) {
+        for (u32 i = threadIdx.x; i < query_length; i += threads) {
             u32 const position = pad + i;
             atomicOr(&peq[layout::dword_index(pattern[i], (int)(position >> 5))], 1u << (position & 31));
         }
@@ -700,13 +707,14 @@ static int launch_myers_split(szs_string_ref_t const *queries, u32 queries_count
                               u64 *results, u64 stride, int symmetric, szs_ref_guard_t const *guard_or_null, hipStream_t stream) {
     szs_ref_guard_t guard = {};
     if (guard_or_null) guard = *guard_or_null;
-    u32 const pairs_per_block = 256u / lanes_;
+    u32 const pairs_per_block = split_threads_k<lanes_> / lanes_;
     u32 const candidate_blocks = (candidates_count + pairs_per_block - 1) / pairs_per_block;
     u32 const queries_per_launch = candidate_blocks ? (1u << 30) / candidate_blocks : queries_count;
     for (u32 first = 0; first < queries_count; first += queries_per_launch) {
         u32 const batch = queries_count - first < queries_per_launch ? queries_count - first : queries_per_launch;
-        hipLaunchKernelGGL((levenshtein_myers_split_kernel<words_per_lane_, lanes_>), dim3(batch * candidate_blocks), dim3(256), 0, stream,
-                           queries + first, candidates, candidates_count, candidate_blocks, results, stride, symmetric, guard);
+        hipLaunchKernelGGL((levenshtein_myers_split_kernel<words_per_lane_, lanes_>), dim3(batch * candidate_blocks),
+                           dim3(split_threads_k<lanes_>), 0, stream, queries + first, candidates, candidates_count, candidate_blocks, results, stride,
+                           symmetric, guard);
         hipError_t const error = hipGetLastError();
         if (error != hipSuccess) return (int)error;
     }
@@ -735,71 +743,134 @@ static u32 banded_grid(u64 work_items) {
 /* ---- codepoint queries of more than 256 runes ----------------------------------------------------------------------
  *
  *  The short rune kernel keys Peq by the SLOT of a 512-slot rune table - fine for at most 256 distinct runes and 8 words.
- *  A query of 2048 runes may hold 2048 distinct ones, and 4096 slots x 64 words would be a megabyte.  So here the runes
- *  of the pattern get DENSE ids (1, 2, ... in the order the slots happen to be claimed) and Peq has one row per id, up to
- *  `id_capacity` rows - whatever fits the LDS the launch was given (text in any alphabet repeats its runes: config 5's
- *  1560-rune strings hold ~400 distinct ones).  Id 0 is "not in the pattern" (an all-zero row).  Runes beyond the
- *  capacity get the OVERFLOW id: their match mask is rebuilt from the pattern itself, column by column, only by the
- *  lanes that meet one - slow (a pass over the pattern per column) but exact, rare, and nobody else's business: no
- *  failure flag, no second launch.
+ *  A query of 2048 runes may hold 2048 distinct ones; a dense row of 64 words for each would be half a megabyte, and even
+ *  the 700 rows that fit a CU's 160 KB leave room for ONE workgroup per CU (config 5u spent 11 ms under its 48-word launch
+ *  that way, for 1.7 ms of instructions).  But a pattern of n runes sets n bits in the whole table, so at most n of its
+ *  16-byte CHUNKS (4 words, 128 pattern rows) are non-zero, whatever the alphabet.  rune_masks_t stores exactly those:
  *
- *  Dynamic LDS: peq[(id_capacity + 1) rows, laid out like peq_layout] | keys[slots] | ids[slots] (u16).
+ *    entries[slots]            hash table, one dword per slot: rune << 11 | id - one LDS read answers a probe;
+ *                              ids are dense, 1 .. capacity in the order slots were claimed, 0 = not in the pattern,
+ *                              2047 = OVERFLOW (more distinct runes than `capacity`)
+ *    pointers[id][chunk]       u16 byte offset of that chunk in the pool; 0 = the all-zero chunk
+ *    pool[(32 words + 1) x 16 B]  the non-zero chunks, handed out in the order they were first needed
+ *
+ *  48 words: 24 KB of pool + 16 KB of hash + 32 B per id - 1,170 ids in half a CU's LDS, where dense rows gave 290.
+ *  A column costs one more dependent LDS read (pointers, then chunks) and a `v_bfe` per chunk.  Overflowing runes have their
+ *  mask rebuilt from the pattern itself, column by column, only by the lanes that meet one - slow (a pass over the pattern
+ *  per column) but exact, rare, and nobody else's business: no failure flag, no second launch.
  */
-constexpr u32 rune_overflow_id_k = 0xFFFFu;
+constexpr u32 rune_id_bits_k = 11, rune_sparse_overflow_k = (1u << rune_id_bits_k) - 1;
+
+template <int words_, int lanes_>
+struct rune_masks_t {
+    static constexpr int chunks = (words_ + 3) / 4;
+    static_assert(chunks % lanes_ == 0, "whole chunks per lane");
+    static constexpr int part_chunks = chunks / lanes_;            // chunks one lane of a pair reads per column
+    static constexpr int part_stride = (part_chunks + 3) / 4 * 4;  // u16 entries: every part starts 8-byte aligned
+    static constexpr int row_stride = part_stride * lanes_;
+    static constexpr u32 pool_dwords = (32u * words_ + 1u) * 4u;
+
+    u32 *pool, *entries, *bitmap;
+    uint16_t *pointers;
+    u32 rune_slots, slot_mask, hash_shift, id_capacity;
+
+    __device__ __forceinline__ rune_masks_t(u32 *lds, u32 slots, u32 capacity)
+        : pool(lds), entries(lds + pool_dwords), rune_slots(slots), slot_mask(slots - 1), hash_shift(32u - (u32)__builtin_ctz(slots)),
+          id_capacity(capacity) {
+        pointers = reinterpret_cast<uint16_t *>(entries + slots);
+        bitmap = reinterpret_cast<u32 *>(pointers + (size_t)(capacity + 1) * row_stride);
+    }
+    __host__ __device__ static constexpr size_t bytes(size_t slots, size_t capacity) {
+        return ((size_t)pool_dwords + slots) * 4 + (capacity + 1) * row_stride * 2 + (((capacity + 1) * chunks + 31) / 32) * 4;
+    }
+    __device__ __forceinline__ u32 pointer_index(u32 id, u32 chunk) const {
+        return id * row_stride + (chunk / part_chunks) * part_stride + chunk % part_chunks;
+    }
+    __device__ __forceinline__ u32 id_of(u32 rune) const { // 0: not in the pattern
+        u32 slot = (rune * 2654435761u) >> hash_shift;
+        for (;;) {
+            u32 const entry = entries[slot];
+            if ((entry >> rune_id_bits_k) == rune) return entry & rune_sparse_overflow_k;
+            if (entry == rune_slot_empty_k) return 0;
+            slot = (slot + 1) & slot_mask;
+        }
+    }
+
+    /** All `threads` threads of the workgroup; `counters` are two dwords of static LDS. */
+    __device__ __forceinline__ void build(u32 const *pattern, u32 length, u32 pad, u32 threads, u32 *counters) const {
+        for (u32 i = threadIdx.x; i < (length + 1) * 4; i += threads) pool[i] = 0;
+        for (u32 i = threadIdx.x; i < rune_slots; i += threads) entries[i] = rune_slot_empty_k;
+        u32 const pointer_dwords = (id_capacity + 1) * row_stride / 2, bitmap_dwords = ((id_capacity + 1) * chunks + 31) / 32;
+        for (u32 i = threadIdx.x; i < pointer_dwords; i += threads) reinterpret_cast<u32 *>(pointers)[i] = 0;
+        for (u32 i = threadIdx.x; i < bitmap_dwords; i += threads) bitmap[i] = 0;
+        if (threadIdx.x < 2) counters[threadIdx.x] = 0;
+        __syncthreads();
+        for (u32 i = threadIdx.x; i < length; i += threads) { // claim a slot per distinct rune: at most 32 words_ runes in twice as many slots
+            u32 const rune = pattern[i], key = rune << rune_id_bits_k;
+            u32 slot = (rune * 2654435761u) >> hash_shift;
+            for (;;) {
+                u32 const previous = atomicCAS(&entries[slot], rune_slot_empty_k, key);
+                if (previous == rune_slot_empty_k || (previous >> rune_id_bits_k) == rune) break;
+                slot = (slot + 1) & slot_mask;
+            }
+        }
+        __syncthreads();
+        for (u32 slot = threadIdx.x; slot < rune_slots; slot += threads)
+            if (entries[slot] != rune_slot_empty_k) {
+                u32 const id = atomicAdd(&counters[0], 1u) + 1;
+                entries[slot] |= id <= id_capacity ? id : rune_sparse_overflow_k;
+            }
+        __syncthreads();
+        for (u32 i = threadIdx.x; i < length; i += threads) { // the first to need (id, chunk) takes the next chunk of the pool
+            u32 const id = id_of(pattern[i]), chunk = (pad + i) >> 7;
+            if (id == rune_sparse_overflow_k) continue;
+            u32 const bit = id * chunks + chunk, mask = 1u << (bit & 31);
+            if (!(atomicOr(&bitmap[bit >> 5], mask) & mask))
+                pointers[pointer_index(id, chunk)] = (uint16_t)((atomicAdd(&counters[1], 1u) + 1) * 16);
+        }
+        __syncthreads();
+        for (u32 i = threadIdx.x; i < length; i += threads) {
+            u32 const id = id_of(pattern[i]), position = pad + i;
+            if (id == rune_sparse_overflow_k) continue;
+            atomicOr(&pool[pointers[pointer_index(id, position >> 7)] / 4 + ((position >> 5) & 3)], 1u << (position & 31));
+        }
+        __syncthreads();
+    }
+
+    /** The words [part x part_chunks x 4, ...) of rune `id`'s mask (`id` is not the overflow id). */
+    template <int count_>
+    __device__ __forceinline__ void load(u32 id, u32 part, u32 (&eq)[count_]) const {
+        uint2 const *const row = reinterpret_cast<uint2 const *>(pointers + id * row_stride + part * part_stride);
+        char const *const base = reinterpret_cast<char const *>(pool);
+#pragma unroll
+        for (int group = 0; group < part_stride / 4; ++group) {
+            uint2 const four = row[group];
+            u32 const offsets[4] = {four.x & 0xFFFFu, four.x >> 16, four.y & 0xFFFFu, four.y >> 16};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int const chunk = group * 4 + k;
+                if (chunk >= part_chunks) continue;
+                uint4 const words = *reinterpret_cast<uint4 const *>(base + offsets[k]);
+                if (chunk * 4 + 0 < count_) eq[chunk * 4 + 0] = words.x;
+                if (chunk * 4 + 1 < count_) eq[chunk * 4 + 1] = words.y;
+                if (chunk * 4 + 2 < count_) eq[chunk * 4 + 2] = words.z;
+                if (chunk * 4 + 3 < count_) eq[chunk * 4 + 3] = words.w;
+            }
+        }
+    }
+};
 
 template <int words_>
 __device__ __forceinline__ void myers_long_runes_workgroup(u32 *lds, u32 rune_slots, u32 id_capacity, szs_string_ref_t const query,
                                                            szs_string_ref_t const *__restrict__ candidates,
                                                            u32 candidates_count, u32 candidate_block,
                                                            u64 *__restrict__ results, u64 results_row_stride, int symmetric) {
-    constexpr int chunks = (words_ + 3) / 4;
-    u32 const rows = id_capacity + 1; // row 0: runes the pattern does not contain
-    u32 *const peq = lds;
-    u32 *const keys = peq + (size_t)chunks * rows * 4;
-    uint16_t *const ids = reinterpret_cast<uint16_t *>(keys + rune_slots);
-    __shared__ u32 claimed_ids;
-    u32 const slot_mask = rune_slots - 1, hash_shift = 32u - (u32)__builtin_ctz(rune_slots);
-    auto dword_index = [&](u32 row, u32 w) -> u32 { return ((w / 4) * rows + row) * 4 + (w % 4); };
-
+    rune_masks_t<words_, 1> const masks(lds, rune_slots, id_capacity);
+    __shared__ u32 counters[2];
     u32 const query_length = query.length;
     u32 const pad = 32u * words_ - query_length; // phantom low rows
     u32 const *const pattern = reinterpret_cast<u32 const *>(query.address);
-
-    // ---- rune table and Peq: claim slots, number them, scatter the pattern's bits
-    for (u32 i = threadIdx.x; i < (u32)chunks * rows * 4; i += 256) peq[i] = 0;
-    for (u32 i = threadIdx.x; i < rune_slots; i += 256) keys[i] = rune_slot_empty_k, ids[i] = 0;
-    if (threadIdx.x == 0) claimed_ids = 0;
-    __syncthreads();
-    for (u32 i = threadIdx.x; i < query_length; i += 256) {
-        u32 const rune = pattern[i];
-        u32 slot = (rune * 2654435761u) >> hash_shift; // at most 32 * words_ distinct runes in twice as many slots
-        for (;;) {
-            u32 const previous = atomicCAS(&keys[slot], rune_slot_empty_k, rune);
-            if (previous == rune_slot_empty_k || previous == rune) break;
-            slot = (slot + 1) & slot_mask;
-        }
-    }
-    __syncthreads();
-    for (u32 slot = threadIdx.x; slot < rune_slots; slot += 256)
-        if (keys[slot] != rune_slot_empty_k) {
-            u32 const id = atomicAdd(&claimed_ids, 1u) + 1;
-            ids[slot] = (uint16_t)(id <= id_capacity ? id : rune_overflow_id_k);
-        }
-    __syncthreads();
-    auto id_of = [&](u32 rune) -> u32 { // 0: not in the pattern
-        u32 slot = (rune * 2654435761u) >> hash_shift;
-        for (;;) {
-            u32 const key = keys[slot];
-            if (key == rune) return ids[slot];
-            if (key == rune_slot_empty_k) return 0;
-            slot = (slot + 1) & slot_mask;
-        }
-    };
-    for (u32 i = threadIdx.x; i < query_length; i += 256) {
-        u32 const id = id_of(pattern[i]), position = pad + i;
-        if (id != rune_overflow_id_k) atomicOr(&peq[dword_index(id, position >> 5)], 1u << (position & 31));
-    }
-    __syncthreads();
+    masks.build(pattern, query_length, pad, 256, counters);
 
     // ---- this lane's candidate
     u32 const candidate_slot = candidate_block * SZS_CANDIDATES_PER_WORKGROUP + threadIdx.x;
@@ -821,18 +892,8 @@ __device__ __forceinline__ void myers_long_runes_workgroup(u32 *lds, u32 rune_sl
 
     auto take = [&](u32 rune) {
         u32 eq[words_];
-        u32 const id = id_of(rune);
-        if (id != rune_overflow_id_k) {
-            uint4 const *table = reinterpret_cast<uint4 const *>(peq);
-#pragma unroll
-            for (int chunk = 0; chunk < chunks; ++chunk) {
-                uint4 const row = table[chunk * rows + id];
-                if (chunk * 4 + 0 < words_) eq[chunk * 4 + 0] = row.x;
-                if (chunk * 4 + 1 < words_) eq[chunk * 4 + 1] = row.y;
-                if (chunk * 4 + 2 < words_) eq[chunk * 4 + 2] = row.z;
-                if (chunk * 4 + 3 < words_) eq[chunk * 4 + 3] = row.w;
-            }
-        }
+        u32 const id = masks.id_of(rune);
+        if (id != rune_sparse_overflow_k) masks.load(id, 0, eq);
         else { // a rune past the table's capacity: its mask, straight from the pattern
 #pragma unroll
             for (int w = 0; w < words_; ++w) {
@@ -889,9 +950,9 @@ __global__ __launch_bounds__(256) void levenshtein_myers_long_runes_kernel(szs_s
                                        candidate_block, results, results_row_stride, symmetric);
 }
 
-/** LDS plan of one long rune launch: slots = twice the runes a query of `words` words can hold; as many Peq rows as the
+/** LDS plan of the strip kernel (dense rows per rune id, u16 ids beside u32 keys): slots = twice the runes a query of `words` words can hold; as many Peq rows as the
  *  budget leaves - two workgroups per CU (80 KB each) when that still numbers 512 runes, else one (all 160 KB). */
-static bool rune_lds_plan(unsigned words, u32 &rune_slots, u32 &id_capacity, size_t &bytes) {
+static bool rune_lds_plan_dense(unsigned words, u32 &rune_slots, u32 &id_capacity, size_t &bytes) {
     rune_slots = 1;
     while (rune_slots < 64u * words) rune_slots *= 2;
     size_t const table_bytes = (size_t)rune_slots * (sizeof(u32) + sizeof(uint16_t)), row_bytes = (size_t)((words + 3) / 4) * 16;
@@ -909,12 +970,45 @@ static bool rune_lds_plan(unsigned words, u32 &rune_slots, u32 &id_capacity, siz
     return true;
 }
 
+/**
+ *  LDS plan of one long rune launch (rune_masks_t<words, lanes>): slots = twice the runes a query of `words` words can hold;
+ *  the SMALLEST share of a CU's 160 KB (a quarter, a third, half, all) whose id capacity covers 768 distinct runes or every
+ *  rune the query can hold - text repeats its runes (config 5u's 1560-rune strings hold ~400 distinct ones, 2048 CJK
+ *  characters of running text ~600); what overflows takes the slow path, correctly.
+ */
+template <int words_, int lanes_>
+static bool rune_lds_plan(u32 &rune_slots, u32 &id_capacity, size_t &bytes) {
+    using masks = rune_masks_t<words_, lanes_>;
+    rune_slots = 1;
+    while (rune_slots < 64u * words_) rune_slots *= 2;
+    size_t const most_runes = 32u * words_, wanted = most_runes < 768 ? most_runes : 768;
+    long const forced = szs_tuning_get(szs_knob_rune_ids_k); // a testing aid: shrinks the table so that runes overflow it
+    size_t capacity = 0;
+    for (size_t share = 4; share >= 1; --share) {
+        size_t const budget = ((size_t)160 << 10) / share - 1024; // a little static LDS on top
+        size_t low = 0, high = rune_sparse_overflow_k - 1;         // the largest capacity whose table fits the budget
+        while (low < high) {
+            size_t const middle = (low + high + 1) / 2;
+            if (masks::bytes(rune_slots, middle) <= budget) low = middle;
+            else high = middle - 1;
+        }
+        capacity = masks::bytes(rune_slots, low) <= budget ? low : 0;
+        if (capacity >= wanted) break;
+    }
+    if (capacity > most_runes) capacity = most_runes;
+    if (forced > 0 && (size_t)forced < capacity) capacity = (size_t)forced;
+    if (capacity < 1) return false;
+    id_capacity = (u32)capacity;
+    bytes = (masks::bytes(rune_slots, capacity) + 15) / 16 * 16;
+    return true;
+}
+
 template <int words_>
 static int launch_long_runes(szs_string_ref_t const *queries, u32 queries_count, szs_string_ref_t const *candidates,
                              u32 candidates_count, u64 *results, u64 stride, int symmetric, hipStream_t stream) {
     u32 rune_slots = 0, id_capacity = 0;
     size_t bytes = 0;
-    if (!rune_lds_plan(words_, rune_slots, id_capacity, bytes)) return (int)hipErrorNotSupported;
+    if (!rune_lds_plan<words_, 1>(rune_slots, id_capacity, bytes)) return (int)hipErrorNotSupported;
     static int granted_on[device_slots_k]; // per width and device: has this much dynamic LDS been granted to the kernel?
     int *const granted = &granted_on[device_slot()];
     if (!cached(granted)) {
@@ -938,6 +1032,140 @@ static int launch_long_runes(szs_string_ref_t const *queries, u32 queries_count,
     }
     return 0;
 }
+
+/* ---- long codepoint queries, several lanes per pair ----------------------------------------------------------------------
+ *
+ *  levenshtein_myers_split_kernel for UTF-32 texts.  Here the split buys more than the shorter floor: a 48- or 64-word rune
+ *  query needs most of a CU's LDS for its match-mask rows (one per DISTINCT rune, up to 700), so the one-lane-per-pair kernel
+ *  above runs ONE workgroup of four wavefronts per CU - a wavefront per SIMD, every LDS round trip exposed (config 5u: the
+ *  48-word launch took 8.9 ms for 1.7 ms of instructions, profiles/r02/pmc_configs.json).  This kernel keeps 256 pairs per
+ *  workgroup - the same table serves 256 x L threads, L wavefronts per SIMD - and each lane carries 1 / L of the state.
+ *
+ *  The head lane of a pair resolves the rune's row id (one probe per pair and column, not per lane) and hands it up with the
+ *  boundary deltas: id (16 bits) | hp << 16 | hn << 17 | valid << 18.  A rune beyond the table's capacity (id 2047) travels
+ *  in a second move, taken only by wavefronts that hold one, and every lane rebuilds its own words of the mask from the pattern.
+ */
+template <int words_per_lane_, int lanes_>
+__global__ __launch_bounds__(256 * lanes_) void levenshtein_myers_split_runes_kernel(szs_string_ref_t const *__restrict__ queries,
+                                                                                      szs_string_ref_t const *__restrict__ candidates,
+                                                                                      u32 candidates_count, u32 candidate_blocks,
+                                                                                      u64 *__restrict__ results, u64 results_row_stride,
+                                                                                      int symmetric, u32 rune_slots, u32 id_capacity) {
+    constexpr int words = words_per_lane_ * lanes_;
+    constexpr u32 threads = 256u * lanes_;
+    static_assert(words_per_lane_ % 4 == 0 && (lanes_ == 2 || lanes_ == 4), "whole 16-byte Peq chunks per lane");
+    extern __shared__ __attribute__((aligned(16))) u32 rune_lds[];
+    rune_masks_t<words, lanes_> const masks(rune_lds, rune_slots, id_capacity);
+    __shared__ u32 counters[2];
+
+    u32 const query_slot = blockIdx.x / candidate_blocks, candidate_block = candidate_blocks - 1 - blockIdx.x % candidate_blocks;
+    szs_string_ref_t const query = queries[query_slot];
+    u32 const query_length = query.length;
+    u32 const pad = 32u * words - query_length; // phantom low rows
+    u32 const *const pattern = reinterpret_cast<u32 const *>(query.address);
+    masks.build(pattern, query_length, pad, threads, counters);
+
+    u32 const part = threadIdx.x % lanes_, pair = threadIdx.x / lanes_;
+    u32 const candidate_slot = candidate_block * 256u + pair;
+    bool live = candidate_slot < candidates_count;
+    szs_string_ref_t candidate = {0, 0, 0};
+    if (live) candidate = candidates[candidate_slot];
+    if ((symmetric & SZS_LAYOUT_SYMMETRIC) && candidate.index > query.index) live = false;
+    u32 const text_length = live ? candidate.length : 0;
+    u32 const longest_in_wave = wave_max_u32(text_length);
+    bool const head = part == 0;
+
+    u32 vp[words_per_lane_], vn[words_per_lane_];
+#pragma unroll
+    for (int w = 0; w < words_per_lane_; ++w) {
+        u32 const first_bit = 32u * (part * words_per_lane_ + w);
+        vp[w] = first_bit >= pad ? ~0u : (first_bit + 32u <= pad ? 0u : (~0u << (pad - first_bit)));
+        vn[w] = 0;
+    }
+    u32 const *const runes = reinterpret_cast<u32 const *>(candidate.address);
+    auto rune_at = [&](u32 index) -> u32 { return head && index < text_length ? runes[index] : 0u; };
+    u32 ahead[2] = {rune_at(0), rune_at(1)};
+    u32 incoming = 0, incoming_rune = 0;
+    u32 const steps = longest_in_wave ? longest_in_wave + lanes_ - 1 : 0;
+#pragma unroll 1
+    for (u32 step = 0; step < steps; ++step) {
+        u32 const own = ahead[0];
+        ahead[0] = ahead[1], ahead[1] = rune_at(step + 2);
+        bool const active = head ? step < text_length : ((incoming >> 18) & 1u) != 0;
+        u32 const rune = head ? own : incoming_rune;
+        u32 id = incoming & 0xFFFFu;
+        if (head) id = active ? masks.id_of(own) : 0u;
+        u32 const hp_in = head ? 1u : (incoming >> 16) & 1u; // DP row 0 grows by one per column
+        u32 const hn_in = head ? 0u : (incoming >> 17) & 1u;
+        u32 outgoing = 0;
+        if (active) {
+            u32 eq[words_per_lane_];
+            if (id != rune_sparse_overflow_k) masks.load(id, part, eq);
+            else { // a rune past the table's capacity: this lane's words of its mask, straight from the pattern
+#pragma unroll
+                for (int w = 0; w < words_per_lane_; ++w) {
+                    u32 bits = 0;
+#pragma unroll 1
+                    for (u32 bit = 0; bit < 32; ++bit) {
+                        u32 const position = 32u * (part * words_per_lane_ + w) + bit;
+                        if (position >= pad && pattern[position - pad] == rune) bits |= 1u << bit;
+                    }
+                    eq[w] = bits;
+                }
+            }
+            outgoing = id | (myers_strip_column<words_per_lane_>(vp, vn, eq, hp_in, hn_in) << 16) | (1u << 18);
+        }
+        // row_shr:1 - every lane takes its lower neighbour's word; the first lane of a row of 16 (a `head`) takes zero
+        incoming = (u32)__builtin_amdgcn_update_dpp(0, (int)outgoing, 0x111, 0xF, 0xF, true);
+        if (__any(active && id == rune_sparse_overflow_k))
+            incoming_rune = (u32)__builtin_amdgcn_update_dpp(0, (int)rune, 0x111, 0xF, 0xF, true);
+    }
+
+    i32 delta = 0;
+#pragma unroll
+    for (int w = 0; w < words_per_lane_; ++w) delta += (i32)__builtin_popcount(vp[w]) - (i32)__builtin_popcount(vn[w]);
+#pragma unroll
+    for (int offset = 1; offset < lanes_; offset <<= 1) delta += __shfl_xor(delta, offset, 64);
+    if (live && head) {
+        u64 const distance = (u64)((i64)text_length + delta);
+        bool const transposed = (symmetric & SZS_LAYOUT_TRANSPOSED) != 0;
+        u64 const row = transposed ? candidate.index : query.index, column_of = transposed ? query.index : candidate.index;
+        results[row * results_row_stride + column_of] = distance;
+        if ((symmetric & SZS_LAYOUT_SYMMETRIC) && candidate.index != query.index) results[column_of * results_row_stride + row] = distance;
+    }
+}
+
+template <int words_per_lane_, int lanes_>
+static int launch_split_runes(szs_string_ref_t const *queries, u32 queries_count, szs_string_ref_t const *candidates, u32 candidates_count,
+                              u64 *results, u64 stride, int symmetric, hipStream_t stream) {
+    u32 rune_slots = 0, id_capacity = 0;
+    size_t bytes = 0;
+    if (!rune_lds_plan<words_per_lane_ * lanes_, lanes_>(rune_slots, id_capacity, bytes)) return (int)hipErrorNotSupported;
+    static int granted_on[device_slots_k];
+    int *const granted = &granted_on[device_slot()];
+    if (!cached(granted)) {
+        hipError_t const error = hipFuncSetAttribute(reinterpret_cast<void const *>(levenshtein_myers_split_runes_kernel<words_per_lane_, lanes_>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)160 << 10) - 1024));
+        if (error != hipSuccess) {
+            (void)hipGetLastError();
+            return (int)hipErrorNotSupported;
+        }
+        remember(granted, 1);
+    }
+    u32 const candidate_blocks = (candidates_count + 255u) / 256u;
+    u32 const queries_per_launch = candidate_blocks ? (1u << 30) / candidate_blocks : queries_count;
+    for (u32 first = 0; first < queries_count; first += queries_per_launch) {
+        u32 const batch = queries_count - first < queries_per_launch ? queries_count - first : queries_per_launch;
+        hipLaunchKernelGGL((levenshtein_myers_split_runes_kernel<words_per_lane_, lanes_>), dim3(batch * candidate_blocks), dim3(256u * lanes_),
+                           bytes, stream, queries + first, candidates, candidates_count, candidate_blocks, results, stride, symmetric, rune_slots,
+                           id_capacity);
+        hipError_t const error = hipGetLastError();
+        if (error != hipSuccess) return (int)error;
+    }
+    return 0;
+}
+
+constexpr u32 rune_overflow_id_k = 0xFFFFu; // the strip kernel below: dense rows, u16 ids beside the keys
 
 /* ---- codepoint queries of more than 2048 runes: the strips of the byte kernel with the rune table of the long rune kernels -----
  *
@@ -1228,7 +1456,7 @@ extern "C" size_t szs_hip_levenshtein_myers_banded_runes_bytes(uint32_t queries_
     using namespace szs_hip;
     u32 rune_slots = 0, id_capacity = 0;
     size_t lds_bytes = 0;
-    if (!rune_lds_plan(banded_runes_words_k, rune_slots, id_capacity, lds_bytes)) return 0;
+    if (!rune_lds_plan_dense(banded_runes_words_k, rune_slots, id_capacity, lds_bytes)) return 0;
     u64 const work_items = (u64)queries_count * ((candidates_count + SZS_CANDIDATES_PER_WORKGROUP - 1) / SZS_CANDIDATES_PER_WORKGROUP);
     return banded_header_bytes_k + (size_t)banded_runes_grid(work_items, lds_bytes) * (longest_candidate / 16 + 2) * 256 * sizeof(u32);
 }
@@ -1241,7 +1469,7 @@ extern "C" int szs_hip_levenshtein_myers_banded_runes(szs_string_ref_t const *qu
     if (!queries_count || !candidates_count) return 0;
     u32 rune_slots = 0, id_capacity = 0;
     size_t lds_bytes = 0;
-    if (!rune_lds_plan(banded_runes_words_k, rune_slots, id_capacity, lds_bytes)) return (int)hipErrorNotSupported;
+    if (!rune_lds_plan_dense(banded_runes_words_k, rune_slots, id_capacity, lds_bytes)) return (int)hipErrorNotSupported;
     static int granted_on[device_slots_k];
     int *const granted = &granted_on[device_slot()];
     if (!cached(granted)) {
@@ -1265,6 +1493,27 @@ extern "C" int szs_hip_levenshtein_myers_banded_runes(szs_string_ref_t const *qu
                        symmetric, reinterpret_cast<u32 *>(static_cast<char *>(workspace) + banded_header_bytes_k),
                        longest_candidate / 16 + 2, counter, rune_slots, id_capacity);
     return (int)hipGetLastError();
+}
+
+extern "C" int szs_hip_levenshtein_myers_runes_split(unsigned words, unsigned lanes, szs_string_ref_t const *queries,
+                                                     uint32_t queries_count, szs_string_ref_t const *candidates,
+                                                     uint32_t candidates_count, uint64_t *results, uint64_t results_row_stride,
+                                                     int symmetric, void *stream) {
+    using namespace szs_hip;
+    if (!queries_count || !candidates_count) return 0;
+    hipStream_t const s = static_cast<hipStream_t>(stream);
+#define SZS_SPLIT_RUNES_CASE(W, L)                                                                                     \
+    if (words == W && lanes == L)                                                                                      \
+        return launch_split_runes<W / L, L>(queries, queries_count, candidates, candidates_count, results, results_row_stride, symmetric, s);
+    SZS_SPLIT_RUNES_CASE(24, 2)
+    SZS_SPLIT_RUNES_CASE(32, 2)
+    SZS_SPLIT_RUNES_CASE(48, 2)
+    SZS_SPLIT_RUNES_CASE(64, 2)
+    SZS_SPLIT_RUNES_CASE(32, 4)
+    SZS_SPLIT_RUNES_CASE(48, 4)
+    SZS_SPLIT_RUNES_CASE(64, 4)
+#undef SZS_SPLIT_RUNES_CASE
+    return (int)hipErrorInvalidValue;
 }
 
 extern "C" int szs_hip_levenshtein_myers_runes_long(unsigned words, szs_string_ref_t const *queries, uint32_t queries_count,

@@ -442,6 +442,13 @@ static unsigned split_lanes_of(int knob, unsigned variant, uint64_t workgroups_u
     return lanes;
 }
 
+/** The same for codepoints: 48 and 64 words always over four lanes - their rune table leaves room for one workgroup per CU,
+ *  and only the split kernel puts more than one wavefront per SIMD behind it (lev_myers.hip). */
+static unsigned split_lanes_of_runes(int knob, unsigned variant, uint64_t workgroups_unsplit) {
+    unsigned const lanes = split_lanes_of(knob, variant, workgroups_unsplit);
+    return lanes && knob < 0 && variant >= 48 ? 4u : lanes;
+}
+
 /** Launches of one decision over device refs in kernel roles.  Returns the first launch error; counts launches. */
 static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int device, szs_string_ref_t const *query_refs,
                           szs_string_ref_t const *candidate_refs, void *device_results, size_t device_stride, hipStream_t stream,
@@ -517,11 +524,14 @@ static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int dev
             szs_string_ref_t const *const queries = query_refs + group->first + done;
             uint32_t const count = group->count - done < queries_per_launch ? group->count - done : queries_per_launch;
             if (group->variant && d->runes) {
+                unsigned const lanes = split_lanes_of_runes(split_knob, group->variant, (uint64_t)group->count * candidate_blocks);
                 launch_error = group->variant == SZS_MYERS_SHORT_WORDS
                                    ? szs_hip_levenshtein_myers_runes(queries, count, candidate_refs, d->kc_count, (uint64_t *)device_results,
                                                                      device_stride, d->layout, target)
-                                   : szs_hip_levenshtein_myers_runes_long(group->variant, queries, count, candidate_refs, d->kc_count,
-                                                                          (uint64_t *)device_results, device_stride, d->layout, target);
+                               : lanes ? szs_hip_levenshtein_myers_runes_split(group->variant, lanes, queries, count, candidate_refs, d->kc_count,
+                                                                               (uint64_t *)device_results, device_stride, d->layout, target)
+                                       : szs_hip_levenshtein_myers_runes_long(group->variant, queries, count, candidate_refs, d->kc_count,
+                                                                              (uint64_t *)device_results, device_stride, d->layout, target);
                 if (launch_error == (int)hipErrorNotSupported) { /* no LDS for the rune table: the rune-keyed DP kernel, whose
                                                                     workspace is reserved here, on the one path that needs it -
                                                                     and on the scope's stream, like every user of that workspace */

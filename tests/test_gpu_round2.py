@@ -454,3 +454,23 @@ def test_split_lanes_agree_with_the_oracle(gpu, oracle, lanes):
         assert np.array_equal(engine(queries, device=gpu), oracle.levenshtein(queries, queries))
     with knob("split", "0"), knob("tier", "lanes"), knob("swap", "0"):
         assert np.array_equal(engine(queries, candidates, device=gpu), expected)
+
+
+@pytest.mark.parametrize("lanes,rune_ids", [("2", None), ("4", None), (None, None), ("4", "40"), ("2", "3")])
+def test_split_lanes_of_codepoints_agree_with_the_oracle(gpu, oracle, lanes, rune_ids):
+    """The codepoint twin: queries of 641 .. 2048 runes from a 300-rune alphabet of 1 .. 4-byte sequences, pairs over 2 or 4
+    lanes; with `rune_ids` the match-mask table is shrunk so that most runes overflow it and travel beside the deltas."""
+    rng = random.Random(640 + int(lanes or 0) + int(rune_ids or 0))
+    alphabet = [chr(c) for c in list(range(0x41, 0x5B)) + list(range(0x3B1, 0x3C9)) + list(range(0x4E00, 0x4EF0)) + list(range(0x1F600, 0x1F60A))]
+    text = lambda n: "".join(rng.choice(alphabet) for _ in range(n)).encode()
+    lengths = (641, 768, 769, 1023, 1024, 1025, 1536, 1537, 2000, 2047, 2048)
+    queries = [text(n) for n in lengths]
+    candidates = [text(rng.randrange(0, 2300)) for _ in range(140)] + [b"", "\u03b1".encode(), queries[3], queries[-1][:-4]]
+    engine = szs.LevenshteinDistancesUTF8(capabilities=gpu)
+    expected = oracle.levenshtein_utf8(queries, candidates)
+    with knob("split", lanes), knob("rune_ids", rune_ids), knob("tier", "lanes"), knob("swap", "0"):
+        for _ in range(2):
+            assert np.array_equal(engine(queries, candidates, device=gpu), expected)
+        assert np.array_equal(engine(queries, device=gpu), oracle.levenshtein_utf8(queries, queries))
+    with knob("split", "0"), knob("tier", "lanes"), knob("swap", "0"):
+        assert np.array_equal(engine(queries, candidates, device=gpu), expected)
