@@ -1,8 +1,8 @@
 #!/bin/bash
 ROOT=$(cd "$(dirname "$0")/.." && pwd); OUT=$ROOT/gpurun_out/${1:-quick}; mkdir -p "$OUT"; cd "$ROOT"
 shift || true
-start=$(date +%s.%N)
-python bench.py "$@" > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "exit $? in $(echo "$(date +%s.%N) - $start" | bc) s"
+SECONDS=0
+python bench.py "$@" > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "exit $? in $SECONDS s"
 python - "$OUT/bench.json" <<'PY'
 import json, sys
 line = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
