@@ -553,8 +553,8 @@ __global__ __launch_bounds__(256, 2) /* two wavefronts per SIMD, like the long k
         __syncthreads();
         u32 const work = claimed_work;
         if (work >= work_items) break;
-        szs_string_ref_t const query = queries[work / candidate_blocks];
-        u32 const candidate_slot = (candidate_blocks - 1 - work % candidate_blocks) * SZS_CANDIDATES_PER_WORKGROUP + threadIdx.x;
+        szs_string_ref_t const query = queries[work % queries_count]; // candidate-block-major, heaviest block first
+        u32 const candidate_slot = (candidate_blocks - 1 - work / queries_count) * SZS_CANDIDATES_PER_WORKGROUP + threadIdx.x;
         bool live = candidate_slot < candidates_count;
         szs_string_ref_t candidate = {0, 0, 0};
         if (live) candidate = candidates[candidate_slot];
@@ -1216,8 +1216,8 @@ __global__ __launch_bounds__(256) void levenshtein_myers_banded_runes_kernel(
         __syncthreads();
         u32 const work = claimed_work;
         if (work >= work_items) break;
-        szs_string_ref_t const query = queries[work / candidate_blocks];
-        u32 const candidate_slot = (candidate_blocks - 1 - work % candidate_blocks) * SZS_CANDIDATES_PER_WORKGROUP + threadIdx.x;
+        szs_string_ref_t const query = queries[work % queries_count]; // candidate-block-major, heaviest block first
+        u32 const candidate_slot = (candidate_blocks - 1 - work / queries_count) * SZS_CANDIDATES_PER_WORKGROUP + threadIdx.x;
         bool live = candidate_slot < candidates_count;
         szs_string_ref_t candidate = {0, 0, 0};
         if (live) candidate = candidates[candidate_slot];

@@ -231,9 +231,9 @@ __global__ __launch_bounds__(256, SZS_WEIGHTED_WAVES) void weighted_scores_kerne
         __syncthreads();
         u32 const work = claimed_work;
         if (work >= work_items) break;
-        szs_string_ref_t const query = queries[work / candidate_blocks];
+        szs_string_ref_t const query = queries[work % queries_count]; // candidate-block-major, heaviest block first
         u32 const candidate_slot =
-            (candidate_blocks - 1 - work % candidate_blocks) * weighted_block_threads_k + threadIdx.x;
+            (candidate_blocks - 1 - work / queries_count) * weighted_block_threads_k + threadIdx.x;
         bool live = candidate_slot < candidates_count;
         szs_string_ref_t candidate = {0, 0, 0};
         if (live) candidate = candidates[candidate_slot];

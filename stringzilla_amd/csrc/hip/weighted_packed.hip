@@ -48,7 +48,10 @@ typedef unsigned short pk_u16 __attribute__((ext_vector_type(2)));
 
 constexpr int packed_registers_k = 16;                   // registers per strip track: 32 query rows
 constexpr int packed_strip_rows_k = 2 * packed_registers_k;
-constexpr u32 packed_block_threads_k = 256;
+#ifndef SZS_PACKED_BLOCK_THREADS
+#define SZS_PACKED_BLOCK_THREADS 256
+#endif
+constexpr u32 packed_block_threads_k = SZS_PACKED_BLOCK_THREADS;
 constexpr u32 packed_boundary_slack_k = 8;               // columns the boundary prefetch may run past the longest text
 constexpr size_t packed_header_bytes_k = 256;            // the work counter lives at the head of the boundary workspace
 
@@ -147,7 +150,7 @@ __device__ __forceinline__ void packed_advance(packed_column_t<affine_> &column,
 #define SZS_PACKED_AFFINE_WAVES 3
 #endif
 template <bool local_, bool affine_>
-__global__ __launch_bounds__(256, affine_ ? SZS_PACKED_AFFINE_WAVES : 4) void weighted_packed_kernel( // three / four wavefronts per SIMD: no spills either way
+__global__ __launch_bounds__(packed_block_threads_k, affine_ ? SZS_PACKED_AFFINE_WAVES : 4) void weighted_packed_kernel( // three / four wavefronts per SIMD: no spills either way
     szs_cost_model_t const *__restrict__ model, szs_string_ref_t const *__restrict__ queries, u32 queries_count,
     szs_string_ref_t const *__restrict__ candidates, u32 candidates_count, u32 candidate_blocks,
     i64 *__restrict__ results, u64 results_row_stride, int layout_flags, int16_t *__restrict__ boundary,
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(256, affine_ ? SZS_PACKED_AFFINE_WAVES : 4) void we
     i32 const gap_open = model->gap_open, gap_extend = model->gap_extend;
     pk_i16 const open_pk = saturating_ ? pk_pair(-gap_open, -gap_open) : pk_pair(gap_open, gap_open);
     pk_i16 const extend_pk = saturating_ ? pk_pair(-gap_extend, -gap_extend) : pk_pair(gap_extend, gap_extend);
-    class_of_byte[threadIdx.x] = model->byte_to_class[threadIdx.x];
+    for (u32 byte = threadIdx.x; byte < 256; byte += packed_block_threads_k) class_of_byte[byte] = model->byte_to_class[byte];
 
     // This workgroup's private boundary rows: [column][lane], one plane for H and one for the vertical-gap track.
     u64 const plane = (u64)boundary_columns * packed_block_threads_k;
@@ -184,8 +187,9 @@ __global__ __launch_bounds__(256, affine_ ? SZS_PACKED_AFFINE_WAVES : 4) void we
         __syncthreads();
         u32 const work = claimed_work;
         if (work >= work_items) break;
-        szs_string_ref_t const query = queries[work / candidate_blocks];
-        u32 const candidate_slot = (candidate_blocks - 1 - work % candidate_blocks) * packed_block_threads_k + threadIdx.x;
+        // candidate-block-major, heaviest block first (lev_myers.hip: myers_work_item): +7 % on config 3, +6 % on config 4
+        szs_string_ref_t const query = queries[work % queries_count];
+        u32 const candidate_slot = (candidate_blocks - 1 - work / queries_count) * packed_block_threads_k + threadIdx.x;
         bool live = candidate_slot < candidates_count;
         szs_string_ref_t candidate = {0, 0, 0};
         if (live) candidate = candidates[candidate_slot];
