@@ -21,6 +21,8 @@
  */
 #include "szs_internal.h"
 
+#include <pthread.h>
+
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -250,8 +252,8 @@ static void release_device_state(szs_engine_s *engine) {
         (void)hipEventDestroy(engine->event_stop);
         engine->events_device = -1;
     }
-    if (engine->aux_device >= 0) {
-        for (int i = 0; i < SZS_AUX_STREAMS; ++i) (void)hipStreamDestroy(engine->aux_streams[i]), (void)hipEventDestroy(engine->aux_done[i]);
+    if (engine->aux_device >= 0) { /* the streams belong to the process-wide pool (szs_aux_streams); the events are this engine's */
+        for (int i = 0; i < SZS_AUX_STREAMS; ++i) (void)hipEventDestroy(engine->aux_done[i]);
         (void)hipEventDestroy(engine->fork_event);
         engine->aux_device = -1;
     }
@@ -430,6 +432,32 @@ static sz_status_t prepare(szs_engine_s *engine, szs_decision_t const *d, int de
 }
 
 /**
+ *  Auxiliary streams, per device, for the whole process: creating a HIP stream costs 7-12 ms on this runtime (a hardware queue
+ *  each, up to GPU_MAX_HW_QUEUES) - seven of them were 85 ms on the first mixed-length call of EVERY engine when engines owned
+ *  theirs.  They are created on demand, as many as a call needs, and live as long as the library.  Engines that share them
+ *  still order their own work with their own events; concurrent calls of different engines merely take turns on a stream.
+ */
+#define SZS_AUX_DEVICES 64
+static struct {
+    pthread_mutex_t lock;
+    hipStream_t streams[SZS_AUX_DEVICES][SZS_AUX_STREAMS];
+    unsigned created[SZS_AUX_DEVICES];
+} aux_pool = {PTHREAD_MUTEX_INITIALIZER, {{0}}, {0}};
+
+static hipError_t szs_aux_streams(int device, unsigned wanted, hipStream_t *streams) {
+    if (device < 0 || device >= SZS_AUX_DEVICES || wanted > SZS_AUX_STREAMS) return hipErrorInvalidValue;
+    hipError_t error = hipSuccess;
+    pthread_mutex_lock(&aux_pool.lock);
+    while (aux_pool.created[device] < wanted && error == hipSuccess) { /* the caller has made `device` current */
+        error = hipStreamCreateWithFlags(&aux_pool.streams[device][aux_pool.created[device]], hipStreamNonBlocking);
+        if (error == hipSuccess) ++aux_pool.created[device];
+    }
+    for (unsigned i = 0; i < wanted && error == hipSuccess; ++i) streams[i] = aux_pool.streams[device][i];
+    pthread_mutex_unlock(&aux_pool.lock);
+    return error;
+}
+
+/**
  *  Lanes per pair for a launch of the long byte widths: two when the launch fills the device anyway (measured on config 5:
  *  13.5 -> 12.5 ms, the state of a 64-word pattern no longer spills), four when it has so few workgroups that its longest
  *  pairs ARE its duration (an eighth of config 5: 5.4 -> 3.5 ms); 24 words split in two only (whole 16-byte Peq chunks per
@@ -493,14 +521,14 @@ static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int dev
     hipError_t error = hipSuccess;
     if (fan_out) {
         if (engine->aux_device != device) {
-            for (int i = 0; i < SZS_AUX_STREAMS && error == hipSuccess; ++i) {
-                error = hipStreamCreateWithFlags(&engine->aux_streams[i], hipStreamNonBlocking);
-                if (error == hipSuccess) error = hipEventCreateWithFlags(&engine->aux_done[i], hipEventDisableTiming);
-            }
+            if (engine->aux_device >= 0) return hipErrorInvalidDevice; /* release_device_state() precedes a change of device */
+            for (int i = 0; i < SZS_AUX_STREAMS && error == hipSuccess; ++i) error = hipEventCreateWithFlags(&engine->aux_done[i], hipEventDisableTiming);
             if (error == hipSuccess) error = hipEventCreateWithFlags(&engine->fork_event, hipEventDisableTiming);
             if (error != hipSuccess) return error;
             engine->aux_device = device;
         }
+        error = szs_aux_streams(device, aux_used, engine->aux_streams);
+        if (error != hipSuccess) return error;
         error = hipEventRecord(engine->fork_event, stream);
         for (unsigned i = 0; i < aux_used && error == hipSuccess; ++i) error = hipStreamWaitEvent(engine->aux_streams[i], engine->fork_event, 0);
         if (error != hipSuccess) return error; /* nothing has been launched on the auxiliary streams */
