@@ -86,7 +86,8 @@ int szs_hip_levenshtein_myers_split(unsigned words, unsigned lanes, szs_string_r
  */
 int szs_hip_levenshtein_myers_runes(szs_string_ref_t const *queries, uint32_t queries_count,
                                     szs_string_ref_t const *candidates, uint32_t candidates_count, uint64_t *results,
-                                    uint64_t results_row_stride, int symmetric, void *stream);
+                                    uint64_t results_row_stride, int symmetric, uint32_t alphabet /* 0, or the size of the batch's renumbered alphabet (szs_hip_alphabet_rename) */,
+    void *stream);
 
 /**
  *  Byte queries of more than 2048 bytes, unit costs: the same recurrence in horizontal strips of 2048 rows; the deltas
@@ -105,7 +106,8 @@ size_t szs_hip_levenshtein_myers_banded_bytes(uint32_t queries_count, uint32_t c
  */
 int szs_hip_levenshtein_myers_runes_split(unsigned words, unsigned lanes, szs_string_ref_t const *queries, uint32_t queries_count,
                                           szs_string_ref_t const *candidates, uint32_t candidates_count, uint64_t *results,
-                                          uint64_t results_row_stride, int symmetric, void *stream);
+                                          uint64_t results_row_stride, int symmetric, uint32_t alphabet /* 0, or the size of the batch's renumbered alphabet (szs_hip_alphabet_rename) */,
+    void *stream);
 
 /**
  *  Codepoint queries of 257 to 2048 runes: `words` is a long launch variant of szs_hip_levenshtein_myers_round_words()
@@ -116,7 +118,8 @@ int szs_hip_levenshtein_myers_runes_split(unsigned words, unsigned lanes, szs_st
  */
 int szs_hip_levenshtein_myers_runes_long(unsigned words, szs_string_ref_t const *queries, uint32_t queries_count,
                                          szs_string_ref_t const *candidates, uint32_t candidates_count, uint64_t *results,
-                                         uint64_t results_row_stride, int symmetric, void *stream);
+                                         uint64_t results_row_stride, int symmetric, uint32_t alphabet /* 0, or the size of the batch's renumbered alphabet (szs_hip_alphabet_rename) */,
+    void *stream);
 
 /**
  *  Codepoint queries of more than 2048 runes, unit costs: the strips of szs_hip_levenshtein_myers_banded with a dense-id
@@ -146,6 +149,7 @@ enum {
     szs_knob_streams_k,     /* -1 automatic | 0: every launch of a call on the scope's one stream */
     szs_knob_reuse_k,       /* -1 automatic | 0: never re-use the refs planned for the previous call of the same tapes */
     szs_knob_split_k,       /* -1 automatic | 0 / 2 / 4: lanes per pair of the long byte kernels (24 ... 64 words) */
+    szs_knob_alphabet_k,    /* -1 automatic | 0 never | 1 always: renumber a codepoint batch's runes (hip/utf8.hip) */
     szs_knob_count_k
 };
 int szs_tuning_get(int knob);
@@ -207,6 +211,19 @@ int szs_hip_plan(szs_plan_side_t const *queries, szs_plan_side_t const *candidat
  */
 int szs_hip_utf8_transcode(szs_string_ref_t const *strings, uint32_t count, uint64_t const *rune_starts, uint32_t *runes,
                            uint32_t *rune_counts, uint32_t *any_multibyte, void *stream);
+
+/**
+ *  Renumbers the runes of a transcoded batch 1 ... A (equal runes, equal ids) in place, when it holds at most `most` distinct
+ *  ones; `alphabet_out[0]` receives the number of distinct runes, `alphabet_out[1]` 1 when the table overflowed (device
+ *  memory; the arrays are renamed iff `alphabet_out[0] <= most && !alphabet_out[1]`).  Does nothing when `*any_multibyte` is 0.
+ *  The codepoint kernels take the alphabet's size and look symbols up in a direct table instead of probing a hash table.
+ */
+#define SZS_ALPHABET_SLOTS (1u << 16)
+#define SZS_ALPHABET_MOST 4095u
+#define SZS_ALPHABET_WORTH_BYTES (1u << 16) /* smaller batches keep their runes: three launches cost more than the probes */
+int szs_hip_alphabet_rename(uint32_t count, uint64_t const *rune_starts, uint32_t const *rune_counts, uint32_t *runes,
+                            uint32_t const *any_multibyte, void *workspace, uint32_t most, uint32_t *alphabet_out, void *stream);
+size_t szs_hip_alphabet_workspace_bytes(void);
 
 /** Scoring model handed to the weighted kernels; lives in device memory, one per engine. */
 typedef struct szs_cost_model_t {

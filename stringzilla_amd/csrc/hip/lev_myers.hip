@@ -155,7 +155,8 @@ template <int words_, int text_dwords_, bool runes_>
 __device__ __forceinline__ void myers_workgroup(u32 *peq, u32 *keys, szs_string_ref_t const query,
                                                 szs_string_ref_t const *__restrict__ candidates, u32 candidates_count,
                                                 u32 candidate_block, u64 *__restrict__ results, u64 results_row_stride,
-                                                int symmetric, szs_ref_guard_t const &guard) {
+                                                int symmetric, szs_ref_guard_t const &guard, u32 alphabet = 0,
+                                                u32 *claimed_rows = nullptr) {
     constexpr int rows = runes_ ? rune_slots_k : byte_rows_k;
     using layout = peq_layout<words_, rows>;
     if (guard.enabled && !ref_is_current(guard, 0, query)) { // refs of an earlier call: this query's no longer holds - uniform
@@ -167,10 +168,28 @@ __device__ __forceinline__ void myers_workgroup(u32 *peq, u32 *keys, szs_string_
 
     // ---- Peq: zero, then scatter the pattern's bits (LDS atomics; a 128-symbol query is 128 ORs per workgroup).
     for (int i = threadIdx.x; i < layout::total_dwords; i += 256) peq[i] = 0;
-    if constexpr (runes_)
-        for (int i = threadIdx.x; i < rune_slots_k; i += 256) keys[i] = rune_slot_empty_k;
-    __syncthreads();
     if constexpr (runes_) {
+        if (alphabet) { // a renumbered batch (utf8.hip): `keys` is a direct table, id -> Peq row (0: not in the pattern)
+            for (u32 i = threadIdx.x; i <= alphabet; i += 256) keys[i] = 0;
+            if (threadIdx.x == 0) *claimed_rows = 0;
+        }
+        else
+            for (int i = threadIdx.x; i < rune_slots_k; i += 256) keys[i] = rune_slot_empty_k;
+    }
+    __syncthreads();
+    if (runes_ && alphabet) {
+        u32 const *pattern = reinterpret_cast<u32 const *>(query.address);
+        for (u32 i = threadIdx.x; i < query_length; i += 256) { // the first thread to meet an id takes the next row for it
+            u32 const id = pattern[i];
+            if (atomicCAS(&keys[id], 0u, ~0u) == 0u) keys[id] = atomicAdd(claimed_rows, 1u) + 1;
+        }
+        __syncthreads();
+        for (u32 i = threadIdx.x; i < query_length; i += 256) {
+            u32 const position = pad + i;
+            atomicOr(&peq[layout::dword_index((int)keys[pattern[i]], (int)(position >> 5))], 1u << (position & 31));
+        }
+    }
+    else if constexpr (runes_) {
         u32 const *pattern = reinterpret_cast<u32 const *>(query.address);
         for (u32 i = threadIdx.x; i < query_length; i += 256) {
             u32 const rune = pattern[i];
@@ -218,7 +237,7 @@ __device__ __forceinline__ void myers_workgroup(u32 *peq, u32 *keys, szs_string_
     // One DP column: the match masks of `symbol` (a byte, or a rune looked up through the rune table) update VP / VN.
     auto take = [&](u32 symbol) {
         u32 eq[words_];
-        load_match_masks<words_, rows>(peq, runes_ ? find_rune_slot(keys, symbol) : symbol, eq);
+        load_match_masks<words_, rows>(peq, !runes_ ? symbol : alphabet ? keys[symbol] : find_rune_slot(keys, symbol), eq);
         myers_column<words_>(vp, vn, eq);
     };
 
@@ -375,9 +394,12 @@ __global__ __launch_bounds__(256, SZS_MYERS_LONG_WAVES) void levenshtein_myers_l
 template <bool runes_>
 __global__ __launch_bounds__(256, SZS_MYERS_SHORT_WAVES) void levenshtein_myers_short_kernel(
     szs_string_ref_t const *__restrict__ queries, szs_string_ref_t const *__restrict__ candidates, u32 candidates_count,
-    u32 candidate_blocks, u64 *__restrict__ results, u64 results_row_stride, int symmetric, szs_ref_guard_t guard) {
+    u32 candidate_blocks, u64 *__restrict__ results, u64 results_row_stride, int symmetric, szs_ref_guard_t guard, u32 alphabet) {
     __shared__ __attribute__((aligned(16))) u32 peq[peq_layout<8, runes_ ? rune_slots_k : byte_rows_k>::total_dwords];
-    __shared__ u32 keys[runes_ ? rune_slots_k : 1];
+    __shared__ u32 slot_keys[runes_ ? rune_slots_k : 1];
+    __shared__ u32 claimed_rows;
+    extern __shared__ u32 rows_of_ids[]; // runes of a renumbered batch: alphabet + 1 dwords of dynamic LDS
+    u32 *const keys = runes_ && alphabet ? rows_of_ids : slot_keys;
     u32 query_slot, candidate_block;
     myers_work_item(candidate_blocks, query_slot, candidate_block);
     szs_string_ref_t const query = queries[query_slot];
@@ -386,7 +408,7 @@ __global__ __launch_bounds__(256, SZS_MYERS_SHORT_WAVES) void levenshtein_myers_
     case W:                                                                                                            \
         myers_workgroup<W, SZS_MYERS_SHORT_TEXT_DWORDS, runes_>(peq, keys, query, candidates, candidates_count,       \
                                                                 candidate_block, results, results_row_stride,         \
-                                                                symmetric, guard);                                    \
+                                                                symmetric, guard, alphabet, &claimed_rows);           \
         break;
     switch (words) {
         SZS_MYERS_BODY(1)
@@ -398,7 +420,8 @@ __global__ __launch_bounds__(256, SZS_MYERS_SHORT_WAVES) void levenshtein_myers_
         SZS_MYERS_BODY(7)
     default: // 8; the host never sends longer queries here
         myers_workgroup<8, SZS_MYERS_SHORT_TEXT_DWORDS, runes_>(peq, keys, query, candidates, candidates_count,
-                                                                candidate_block, results, results_row_stride, symmetric, guard);
+                                                                candidate_block, results, results_row_stride, symmetric, guard,
+                                                                alphabet, &claimed_rows);
         break;
     }
 #undef SZS_MYERS_BODY
@@ -786,20 +809,28 @@ struct rune_masks_t {
     u32 *pool, *entries, *bitmap;
     uint16_t *pointers;
     u32 rune_slots, slot_mask, hash_shift, id_capacity;
+    u32 alphabet; // 0: `entries` is the hash table above; else the batch was renumbered 1 ... alphabet (utf8.hip) and
+                  // `entries[symbol]` is the symbol's id in THIS pattern, directly (0: not in it)
 
-    __device__ __forceinline__ rune_masks_t(u32 *lds, u32 slots, u32 capacity)
+    /** Dwords of the `entries` region (kept even: the pointers behind it are read 8 bytes at a time). */
+    __host__ __device__ static constexpr size_t entry_dwords(size_t slots, size_t alphabet_size) {
+        return alphabet_size ? (alphabet_size + 2) / 2 * 2 : slots;
+    }
+    __device__ __forceinline__ rune_masks_t(u32 *lds, u32 slots, u32 capacity, u32 alphabet_size)
         : pool(lds), entries(lds + pool_dwords), rune_slots(slots), slot_mask(slots - 1), hash_shift(32u - (u32)__builtin_ctz(slots)),
-          id_capacity(capacity) {
-        pointers = reinterpret_cast<uint16_t *>(entries + slots);
+          id_capacity(capacity), alphabet(alphabet_size) {
+        pointers = reinterpret_cast<uint16_t *>(entries + entry_dwords(slots, alphabet_size));
         bitmap = reinterpret_cast<u32 *>(pointers + (size_t)(capacity + 1) * row_stride);
     }
-    __host__ __device__ static constexpr size_t bytes(size_t slots, size_t capacity) {
-        return ((size_t)pool_dwords + slots) * 4 + (capacity + 1) * row_stride * 2 + (((capacity + 1) * chunks + 31) / 32) * 4;
+    __host__ __device__ static constexpr size_t bytes(size_t slots, size_t capacity, size_t alphabet_size) {
+        return ((size_t)pool_dwords + entry_dwords(slots, alphabet_size)) * 4 + (capacity + 1) * row_stride * 2 +
+               (((capacity + 1) * chunks + 31) / 32) * 4;
     }
     __device__ __forceinline__ u32 pointer_index(u32 id, u32 chunk) const {
         return id * row_stride + (chunk / part_chunks) * part_stride + chunk % part_chunks;
     }
     __device__ __forceinline__ u32 id_of(u32 rune) const { // 0: not in the pattern
+        if (alphabet) return entries[rune];
         u32 slot = (rune * 2654435761u) >> hash_shift;
         for (;;) {
             u32 const entry = entries[slot];
@@ -812,12 +843,25 @@ struct rune_masks_t {
     /** All `threads` threads of the workgroup; `counters` are two dwords of static LDS. */
     __device__ __forceinline__ void build(u32 const *pattern, u32 length, u32 pad, u32 threads, u32 *counters) const {
         for (u32 i = threadIdx.x; i < (length + 1) * 4; i += threads) pool[i] = 0;
-        for (u32 i = threadIdx.x; i < rune_slots; i += threads) entries[i] = rune_slot_empty_k;
+        if (alphabet)
+            for (u32 i = threadIdx.x; i <= alphabet; i += threads) entries[i] = 0;
+        else
+            for (u32 i = threadIdx.x; i < rune_slots; i += threads) entries[i] = rune_slot_empty_k;
         u32 const pointer_dwords = (id_capacity + 1) * row_stride / 2, bitmap_dwords = ((id_capacity + 1) * chunks + 31) / 32;
         for (u32 i = threadIdx.x; i < pointer_dwords; i += threads) reinterpret_cast<u32 *>(pointers)[i] = 0;
         for (u32 i = threadIdx.x; i < bitmap_dwords; i += threads) bitmap[i] = 0;
         if (threadIdx.x < 2) counters[threadIdx.x] = 0;
         __syncthreads();
+        if (alphabet) { // the first thread to meet a symbol numbers it
+            for (u32 i = threadIdx.x; i < length; i += threads) {
+                u32 const symbol = pattern[i];
+                if (atomicCAS(&entries[symbol], 0u, ~0u) == 0u) {
+                    u32 const id = atomicAdd(&counters[0], 1u) + 1;
+                    entries[symbol] = id <= id_capacity ? id : rune_sparse_overflow_k;
+                }
+            }
+        }
+        else {
         for (u32 i = threadIdx.x; i < length; i += threads) { // claim a slot per distinct rune: at most 32 words_ runes in twice as many slots
             u32 const rune = pattern[i], key = rune << rune_id_bits_k;
             u32 slot = (rune * 2654435761u) >> hash_shift;
@@ -833,6 +877,7 @@ struct rune_masks_t {
                 u32 const id = atomicAdd(&counters[0], 1u) + 1;
                 entries[slot] |= id <= id_capacity ? id : rune_sparse_overflow_k;
             }
+        }
         __syncthreads();
         for (u32 i = threadIdx.x; i < length; i += threads) { // the first to need (id, chunk) takes the next chunk of the pool
             u32 const id = id_of(pattern[i]), chunk = (pad + i) >> 7;
@@ -874,11 +919,11 @@ struct rune_masks_t {
 };
 
 template <int words_>
-__device__ __forceinline__ void myers_long_runes_workgroup(u32 *lds, u32 rune_slots, u32 id_capacity, szs_string_ref_t const query,
+__device__ __forceinline__ void myers_long_runes_workgroup(u32 *lds, u32 rune_slots, u32 id_capacity, u32 alphabet, szs_string_ref_t const query,
                                                            szs_string_ref_t const *__restrict__ candidates,
                                                            u32 candidates_count, u32 candidate_block,
                                                            u64 *__restrict__ results, u64 results_row_stride, int symmetric) {
-    rune_masks_t<words_, 1> const masks(lds, rune_slots, id_capacity);
+    rune_masks_t<words_, 1> const masks(lds, rune_slots, id_capacity, alphabet);
     __shared__ u32 counters[2];
     u32 const query_length = query.length;
     u32 const pad = 32u * words_ - query_length; // phantom low rows
@@ -955,11 +1000,11 @@ __global__ __launch_bounds__(256) void levenshtein_myers_long_runes_kernel(szs_s
                                                                             szs_string_ref_t const *__restrict__ candidates,
                                                                             u32 candidates_count, u32 candidate_blocks,
                                                                             u64 *__restrict__ results, u64 results_row_stride,
-                                                                            int symmetric, u32 rune_slots, u32 id_capacity) {
+                                                                            int symmetric, u32 rune_slots, u32 id_capacity, u32 alphabet) {
     extern __shared__ __attribute__((aligned(16))) u32 rune_lds[];
     u32 query_slot, candidate_block;
     myers_work_item(candidate_blocks, query_slot, candidate_block);
-    myers_long_runes_workgroup<words_>(rune_lds, rune_slots, id_capacity, queries[query_slot], candidates, candidates_count,
+    myers_long_runes_workgroup<words_>(rune_lds, rune_slots, id_capacity, alphabet, queries[query_slot], candidates, candidates_count,
                                        candidate_block, results, results_row_stride, symmetric);
 }
 
@@ -990,7 +1035,7 @@ static bool rune_lds_plan_dense(unsigned words, u32 &rune_slots, u32 &id_capacit
  *  characters of running text ~600); what overflows takes the slow path, correctly.
  */
 template <int words_, int lanes_>
-static bool rune_lds_plan(u32 &rune_slots, u32 &id_capacity, size_t &bytes) {
+static bool rune_lds_plan(u32 alphabet, u32 &rune_slots, u32 &id_capacity, size_t &bytes) {
     using masks = rune_masks_t<words_, lanes_>;
     rune_slots = 1;
     while (rune_slots < 64u * words_) rune_slots *= 2;
@@ -1002,26 +1047,26 @@ static bool rune_lds_plan(u32 &rune_slots, u32 &id_capacity, size_t &bytes) {
         size_t low = 0, high = rune_sparse_overflow_k - 1;         // the largest capacity whose table fits the budget
         while (low < high) {
             size_t const middle = (low + high + 1) / 2;
-            if (masks::bytes(rune_slots, middle) <= budget) low = middle;
+            if (masks::bytes(rune_slots, middle, alphabet) <= budget) low = middle;
             else high = middle - 1;
         }
-        capacity = masks::bytes(rune_slots, low) <= budget ? low : 0;
+        capacity = masks::bytes(rune_slots, low, alphabet) <= budget ? low : 0;
         if (capacity >= wanted) break;
     }
     if (capacity > most_runes) capacity = most_runes;
     if (forced > 0 && (size_t)forced < capacity) capacity = (size_t)forced;
     if (capacity < 1) return false;
     id_capacity = (u32)capacity;
-    bytes = (masks::bytes(rune_slots, capacity) + 15) / 16 * 16;
+    bytes = (masks::bytes(rune_slots, capacity, alphabet) + 15) / 16 * 16;
     return true;
 }
 
 template <int words_>
 static int launch_long_runes(szs_string_ref_t const *queries, u32 queries_count, szs_string_ref_t const *candidates,
-                             u32 candidates_count, u64 *results, u64 stride, int symmetric, hipStream_t stream) {
+                             u32 candidates_count, u64 *results, u64 stride, int symmetric, u32 alphabet, hipStream_t stream) {
     u32 rune_slots = 0, id_capacity = 0;
     size_t bytes = 0;
-    if (!rune_lds_plan<words_, 1>(rune_slots, id_capacity, bytes)) return (int)hipErrorNotSupported;
+    if (!rune_lds_plan<words_, 1>(alphabet, rune_slots, id_capacity, bytes)) return (int)hipErrorNotSupported;
     static int granted_on[device_slots_k]; // per width and device: has this much dynamic LDS been granted to the kernel?
     int *const granted = &granted_on[device_slot()];
     if (!cached(granted)) {
@@ -1039,7 +1084,7 @@ static int launch_long_runes(szs_string_ref_t const *queries, u32 queries_count,
         u32 const batch = queries_count - first < queries_per_launch ? queries_count - first : queries_per_launch;
         hipLaunchKernelGGL(levenshtein_myers_long_runes_kernel<words_>, dim3(batch * candidate_blocks), dim3(256), bytes, stream,
                            queries + first, candidates, candidates_count, candidate_blocks, results, stride, symmetric,
-                           rune_slots, id_capacity);
+                           rune_slots, id_capacity, alphabet);
         hipError_t const error = hipGetLastError();
         if (error != hipSuccess) return (int)error;
     }
@@ -1063,12 +1108,12 @@ __global__ __launch_bounds__(256 * lanes_) void levenshtein_myers_split_runes_ke
                                                                                       szs_string_ref_t const *__restrict__ candidates,
                                                                                       u32 candidates_count, u32 candidate_blocks,
                                                                                       u64 *__restrict__ results, u64 results_row_stride,
-                                                                                      int symmetric, u32 rune_slots, u32 id_capacity) {
+                                                                                      int symmetric, u32 rune_slots, u32 id_capacity, u32 alphabet) {
     constexpr int words = words_per_lane_ * lanes_;
     constexpr u32 threads = 256u * lanes_;
     static_assert(words_per_lane_ % 4 == 0 && (lanes_ == 2 || lanes_ == 4), "whole 16-byte Peq chunks per lane");
     extern __shared__ __attribute__((aligned(16))) u32 rune_lds[];
-    rune_masks_t<words, lanes_> const masks(rune_lds, rune_slots, id_capacity);
+    rune_masks_t<words, lanes_> const masks(rune_lds, rune_slots, id_capacity, alphabet);
     __shared__ u32 counters[2];
 
     u32 query_slot, candidate_block;
@@ -1151,10 +1196,10 @@ __global__ __launch_bounds__(256 * lanes_) void levenshtein_myers_split_runes_ke
 
 template <int words_per_lane_, int lanes_>
 static int launch_split_runes(szs_string_ref_t const *queries, u32 queries_count, szs_string_ref_t const *candidates, u32 candidates_count,
-                              u64 *results, u64 stride, int symmetric, hipStream_t stream) {
+                              u64 *results, u64 stride, int symmetric, u32 alphabet, hipStream_t stream) {
     u32 rune_slots = 0, id_capacity = 0;
     size_t bytes = 0;
-    if (!rune_lds_plan<words_per_lane_ * lanes_, lanes_>(rune_slots, id_capacity, bytes)) return (int)hipErrorNotSupported;
+    if (!rune_lds_plan<words_per_lane_ * lanes_, lanes_>(alphabet, rune_slots, id_capacity, bytes)) return (int)hipErrorNotSupported;
     static int granted_on[device_slots_k];
     int *const granted = &granted_on[device_slot()];
     if (!cached(granted)) {
@@ -1172,7 +1217,7 @@ static int launch_split_runes(szs_string_ref_t const *queries, u32 queries_count
         u32 const batch = queries_count - first < queries_per_launch ? queries_count - first : queries_per_launch;
         hipLaunchKernelGGL((levenshtein_myers_split_runes_kernel<words_per_lane_, lanes_>), dim3(batch * candidate_blocks), dim3(256u * lanes_),
                            bytes, stream, queries + first, candidates, candidates_count, candidate_blocks, results, stride, symmetric, rune_slots,
-                           id_capacity);
+                           id_capacity, alphabet);
         hipError_t const error = hipGetLastError();
         if (error != hipSuccess) return (int)error;
     }
@@ -1360,10 +1405,10 @@ static u32 banded_runes_grid(u64 work_items, size_t lds_bytes) {
     return (u32)(work_items < (u64)resident ? work_items : (u64)resident);
 }
 
-template <typename kernel_t>
+template <typename kernel_t, typename... extra_t>
 static int launch_myers(kernel_t kernel, szs_string_ref_t const *queries, u32 queries_count,
                         szs_string_ref_t const *candidates, u32 candidates_count, u64 *results, u64 stride, int symmetric,
-                        szs_ref_guard_t const *guard_or_null, hipStream_t stream) {
+                        szs_ref_guard_t const *guard_or_null, hipStream_t stream, size_t dynamic_lds = 0, extra_t... extra) {
     szs_ref_guard_t guard = {};
     if (guard_or_null) guard = *guard_or_null;
     u32 const candidate_blocks = (candidates_count + SZS_CANDIDATES_PER_WORKGROUP - 1) / SZS_CANDIDATES_PER_WORKGROUP;
@@ -1371,8 +1416,8 @@ static int launch_myers(kernel_t kernel, szs_string_ref_t const *queries, u32 qu
     u32 const queries_per_launch = candidate_blocks ? (1u << 30) / candidate_blocks : queries_count;
     for (u32 first = 0; first < queries_count; first += queries_per_launch) {
         u32 const batch = queries_count - first < queries_per_launch ? queries_count - first : queries_per_launch;
-        hipLaunchKernelGGL(kernel, dim3(batch * candidate_blocks), dim3(256), 0, stream, queries + first, candidates,
-                           candidates_count, candidate_blocks, results, stride, symmetric, guard);
+        hipLaunchKernelGGL(kernel, dim3(batch * candidate_blocks), dim3(256), dynamic_lds, stream, queries + first, candidates,
+                           candidates_count, candidate_blocks, results, stride, symmetric, guard, extra...);
         hipError_t const error = hipGetLastError();
         if (error != hipSuccess) return (int)error;
     }
@@ -1395,7 +1440,7 @@ extern "C" int szs_hip_levenshtein_myers(unsigned words, szs_string_ref_t const 
     switch (words) {
     case SZS_MYERS_SHORT_WORDS:
         return launch_myers(levenshtein_myers_short_kernel<false>, queries, queries_count, candidates, candidates_count, results,
-                            results_row_stride, symmetric, guard, s);
+                            results_row_stride, symmetric, guard, s, 0, 0u);
         SZS_MYERS_CASE(10)
         SZS_MYERS_CASE(12)
         SZS_MYERS_CASE(16)
@@ -1432,11 +1477,13 @@ extern "C" int szs_hip_levenshtein_myers_split(unsigned words, unsigned lanes, s
 extern "C" int szs_hip_levenshtein_myers_runes(szs_string_ref_t const *queries, uint32_t queries_count,
                                                szs_string_ref_t const *candidates, uint32_t candidates_count,
                                                uint64_t *results, uint64_t results_row_stride, int symmetric,
-                                               void *stream) {
+                                               uint32_t alphabet, void *stream) {
     using namespace szs_hip;
     if (!queries_count || !candidates_count) return 0;
+    if (alphabet > SZS_ALPHABET_MOST) return (int)hipErrorInvalidValue;
     return launch_myers(levenshtein_myers_short_kernel<true>, queries, queries_count, candidates, candidates_count, results,
-                        results_row_stride, symmetric, nullptr, static_cast<hipStream_t>(stream));
+                        results_row_stride, symmetric, nullptr, static_cast<hipStream_t>(stream),
+                        alphabet ? ((size_t)alphabet + 1) * sizeof(u32) : 0, (u32)alphabet);
 }
 
 extern "C" size_t szs_hip_levenshtein_myers_banded_bytes(uint32_t queries_count, uint32_t candidates_count, uint32_t longest_candidate) {
@@ -1512,13 +1559,14 @@ extern "C" int szs_hip_levenshtein_myers_banded_runes(szs_string_ref_t const *qu
 extern "C" int szs_hip_levenshtein_myers_runes_split(unsigned words, unsigned lanes, szs_string_ref_t const *queries,
                                                      uint32_t queries_count, szs_string_ref_t const *candidates,
                                                      uint32_t candidates_count, uint64_t *results, uint64_t results_row_stride,
-                                                     int symmetric, void *stream) {
+                                                     int symmetric, uint32_t alphabet, void *stream) {
     using namespace szs_hip;
     if (!queries_count || !candidates_count) return 0;
+    if (alphabet > SZS_ALPHABET_MOST) return (int)hipErrorInvalidValue;
     hipStream_t const s = static_cast<hipStream_t>(stream);
 #define SZS_SPLIT_RUNES_CASE(W, L)                                                                                     \
     if (words == W && lanes == L)                                                                                      \
-        return launch_split_runes<W / L, L>(queries, queries_count, candidates, candidates_count, results, results_row_stride, symmetric, s);
+        return launch_split_runes<W / L, L>(queries, queries_count, candidates, candidates_count, results, results_row_stride, symmetric, alphabet, s);
     SZS_SPLIT_RUNES_CASE(24, 2)
     SZS_SPLIT_RUNES_CASE(32, 2)
     SZS_SPLIT_RUNES_CASE(48, 2)
@@ -1533,12 +1581,13 @@ extern "C" int szs_hip_levenshtein_myers_runes_split(unsigned words, unsigned la
 extern "C" int szs_hip_levenshtein_myers_runes_long(unsigned words, szs_string_ref_t const *queries, uint32_t queries_count,
                                                     szs_string_ref_t const *candidates, uint32_t candidates_count,
                                                     uint64_t *results, uint64_t results_row_stride, int symmetric,
-                                                    void *stream) {
+                                                    uint32_t alphabet, void *stream) {
     using namespace szs_hip;
     if (!queries_count || !candidates_count) return 0;
+    if (alphabet > SZS_ALPHABET_MOST) return (int)hipErrorInvalidValue;
     hipStream_t const s = static_cast<hipStream_t>(stream);
 #define SZS_MYERS_RUNES_CASE(W)                                                                                        \
-    case W: return launch_long_runes<W>(queries, queries_count, candidates, candidates_count, results, results_row_stride, symmetric, s);
+    case W: return launch_long_runes<W>(queries, queries_count, candidates, candidates_count, results, results_row_stride, symmetric, alphabet, s);
     switch (words) {
         SZS_MYERS_RUNES_CASE(10)
         SZS_MYERS_RUNES_CASE(12)

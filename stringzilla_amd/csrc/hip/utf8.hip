@@ -111,6 +111,67 @@ __global__ __launch_bounds__(64 * transcode_waves_k) void utf8_transcode_kernel(
     }
 }
 
+
+/* ---- a batch-wide DENSE ALPHABET ---------------------------------------------------------------------------------------------
+ *
+ *  The codepoint kernels key their match masks by rune; a rune has 21 bits, so every column of every pair starts with a hash
+ *  probe into the query's rune table (lev_myers.hip) - a divergent loop around a dependent LDS read, which the compiler cannot
+ *  hoist or overlap (config 5u: 0.62 VALU lane-operations per cell and 12x the scalar instructions of the byte kernels, which
+ *  index a table with the byte).  Only EQUALITY of runes matters to the distance, so the runes of the whole batch are renumbered
+ *  1 ... A once per call - a hash table in global memory, one claim per distinct rune - and the UTF-32 arrays rewritten in
+ *  place.  With A <= SZS_ALPHABET_MOST the kernels then look a symbol up in a direct table (`local[id]`, one LDS read, no loop);
+ *  a richer batch keeps its runes (the second pass does nothing) and the kernels keep probing.
+ */
+constexpr u32 alphabet_slots_k = SZS_ALPHABET_SLOTS, alphabet_empty_k = ~0u;
+
+__device__ __forceinline__ u32 alphabet_slot(u32 rune) { return (rune * 2654435761u) >> (32 - __builtin_ctz(alphabet_slots_k)); }
+
+/** control[0]: distinct runes claimed so far (the alphabet's size), control[1]: 1 when the table ran out of room. */
+__global__ __launch_bounds__(256) void alphabet_claim_kernel(u32 count, u64 const *__restrict__ rune_starts, u32 const *__restrict__ rune_counts,
+                                                             u32 const *__restrict__ runes, u32 const *__restrict__ any_multibyte,
+                                                             u32 *__restrict__ keys, u32 *__restrict__ ids, u32 *__restrict__ control) {
+    if (!*any_multibyte) return; // an ASCII batch goes to the byte engines
+    u32 const lane = threadIdx.x % 64u, waves = gridDim.x * (blockDim.x / 64u);
+    for (u32 i = blockIdx.x * (blockDim.x / 64u) + threadIdx.x / 64u; i < count; i += waves) {
+        u32 const *const text = runes + rune_starts[i];
+        u32 const length = rune_counts[i];
+        for (u32 j = lane; j < length; j += 64) {
+            u32 const rune = text[j];
+            u32 slot = alphabet_slot(rune);
+            for (u32 probes = 0;; ++probes) {
+                u32 key = __atomic_load_n(&keys[slot], __ATOMIC_RELAXED);
+                if (key == alphabet_empty_k) key = atomicCAS(&keys[slot], alphabet_empty_k, rune);
+                if (key == rune) break;
+                if (key == alphabet_empty_k) { // this thread claimed the slot: the rune's id is the next one
+                    u32 const id = atomicAdd(&control[0], 1u) + 1;
+                    ids[slot] = id;
+                    break;
+                }
+                if (probes >= alphabet_slots_k) { control[1] = 1; break; } // table full: the batch keeps its runes
+                slot = (slot + 1) & (alphabet_slots_k - 1);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void alphabet_rename_kernel(u32 count, u64 const *__restrict__ rune_starts, u32 const *__restrict__ rune_counts,
+                                                              u32 *__restrict__ runes, u32 const *__restrict__ any_multibyte,
+                                                              u32 const *__restrict__ keys, u32 const *__restrict__ ids,
+                                                              u32 const *__restrict__ control, u32 most) {
+    if (!*any_multibyte || control[1] || control[0] > most) return;
+    u32 const lane = threadIdx.x % 64u, waves = gridDim.x * (blockDim.x / 64u);
+    for (u32 i = blockIdx.x * (blockDim.x / 64u) + threadIdx.x / 64u; i < count; i += waves) {
+        u32 *const text = runes + rune_starts[i];
+        u32 const length = rune_counts[i];
+        for (u32 j = lane; j < length; j += 64) {
+            u32 const rune = text[j];
+            u32 slot = alphabet_slot(rune);
+            while (keys[slot] != rune) slot = (slot + 1) & (alphabet_slots_k - 1); // every rune of the batch was claimed
+            text[j] = ids[slot];
+        }
+    }
+}
+
 } // namespace szs_hip
 
 extern "C" int szs_hip_utf8_transcode(szs_string_ref_t const *strings, uint32_t count, uint64_t const *rune_starts,
@@ -121,4 +182,25 @@ extern "C" int szs_hip_utf8_transcode(szs_string_ref_t const *strings, uint32_t 
     hipLaunchKernelGGL(utf8_transcode_kernel, dim3(blocks < 65536u ? blocks : 65536u), dim3(64 * transcode_waves_k), 0, static_cast<hipStream_t>(stream),
                        strings, count, rune_starts, runes, rune_counts, any_multibyte);
     return (int)hipGetLastError();
+}
+
+extern "C" size_t szs_hip_alphabet_workspace_bytes(void) { return (size_t)SZS_ALPHABET_SLOTS * 2 * sizeof(uint32_t) + 2 * sizeof(uint32_t); }
+
+extern "C" int szs_hip_alphabet_rename(uint32_t count, uint64_t const *rune_starts, uint32_t const *rune_counts, uint32_t *runes,
+                                       uint32_t const *any_multibyte, void *workspace, uint32_t most, uint32_t *alphabet_out,
+                                       void *stream) {
+    using namespace szs_hip;
+    if (!count) return 0;
+    hipStream_t const s = static_cast<hipStream_t>(stream);
+    u32 *const keys = static_cast<u32 *>(workspace), *const ids = keys + alphabet_slots_k, *const control = ids + alphabet_slots_k;
+    hipError_t error = hipMemsetAsync(keys, 0xFF, (size_t)alphabet_slots_k * sizeof(u32), s);
+    if (error == hipSuccess) error = hipMemsetAsync(control, 0, 2 * sizeof(u32), s);
+    if (error != hipSuccess) return (int)error;
+    u32 const blocks = (count + 3) / 4 < 2048u ? (count + 3) / 4 : 2048u;
+    hipLaunchKernelGGL(alphabet_claim_kernel, dim3(blocks), dim3(256), 0, s, count, rune_starts, rune_counts, runes, any_multibyte, keys, ids, control);
+    hipLaunchKernelGGL(alphabet_rename_kernel, dim3(blocks), dim3(256), 0, s, count, rune_starts, rune_counts, runes, any_multibyte, keys, ids,
+                       control, most);
+    error = hipGetLastError();
+    if (error == hipSuccess) error = hipMemcpyAsync(alphabet_out, control, 2 * sizeof(u32), hipMemcpyDeviceToDevice, s);
+    return (int)error;
 }

@@ -158,12 +158,13 @@ static sz_status_t stage_host_strings(szs_engine_s *engine, hipStream_t stream, 
 static sz_status_t transcode_to_runes(szs_engine_s *engine, int device, hipStream_t stream, int symmetric,
                                       uint64_t *q_addresses, uint32_t *q_lengths, uint32_t q_count,
                                       uint64_t *c_addresses, uint32_t *c_lengths, uint32_t c_count, int *runes,
-                                      char const **error_message) {
+                                      uint32_t *alphabet, char const **error_message) {
     size_t const strings = (size_t)q_count + (symmetric ? 0 : c_count);
-    /* staging layout, host and device alike: [refs][rune starts][rune counts][flag] */
+    /* staging layout, host and device alike: [refs][rune starts][rune counts][flag][distinct runes][alphabet overflow] */
     size_t const refs_at = 0, starts_at = refs_at + strings * sizeof(szs_string_ref_t);
     size_t const counts_at = starts_at + strings * sizeof(uint64_t), flag_at = counts_at + strings * sizeof(uint32_t);
-    size_t const staging_bytes = flag_at + sizeof(uint32_t);
+    size_t const staging_bytes = flag_at + 3 * sizeof(uint32_t);
+    *alphabet = 0;
     sz_status_t status = szs_buffer_reserve(&engine->pinned_transcode, szs_memory_pinned_k, device, staging_bytes, error_message);
     if (status != sz_success_k) return status;
     status = szs_buffer_reserve(&engine->device_transcode, szs_memory_device_k, device, staging_bytes, error_message);
@@ -184,15 +185,28 @@ static sz_status_t transcode_to_runes(szs_engine_s *engine, int device, hipStrea
     *(uint32_t *)(host + flag_at) = 0;
     status = szs_buffer_reserve(&engine->device_runes, szs_memory_device_k, device, (total + 1) * sizeof(uint32_t), error_message);
     if (status != sz_success_k) return status;
+    /* A batch worth the three extra launches gets its runes renumbered 1 ... A (hip/utf8.hip: the codepoint kernels then index a
+     * table instead of probing one); the `alphabet` knob: 0 never, 1 always. */
+    int const alphabet_knob = szs_tuning_get(szs_knob_alphabet_k);
+    int const renumber = alphabet_knob == 0 ? 0 : alphabet_knob > 0 ? 1 : total >= SZS_ALPHABET_WORTH_BYTES;
+    if (renumber) {
+        status = szs_buffer_reserve(&engine->device_alphabet, szs_memory_device_k, device, szs_hip_alphabet_workspace_bytes(), error_message);
+        if (status != sz_success_k) return status;
+    }
 
     hipError_t error = hipMemcpyAsync(remote, host, counts_at, hipMemcpyHostToDevice, stream);
-    if (error == hipSuccess) error = hipMemsetAsync(remote + flag_at, 0, sizeof(uint32_t), stream);
+    if (error == hipSuccess) error = hipMemsetAsync(remote + flag_at, 0, 3 * sizeof(uint32_t), stream);
     if (error == hipSuccess) {
         int const launch_error = szs_hip_utf8_transcode(
             (szs_string_ref_t const *)(remote + refs_at), (uint32_t)strings, (uint64_t const *)(remote + starts_at),
             (uint32_t *)engine->device_runes.pointer, (uint32_t *)(remote + counts_at), (uint32_t *)(remote + flag_at), stream);
         error = (hipError_t)launch_error;
     }
+    if (error == hipSuccess && renumber)
+        error = (hipError_t)szs_hip_alphabet_rename((uint32_t)strings, (uint64_t const *)(remote + starts_at), (uint32_t const *)(remote + counts_at),
+                                                    (uint32_t *)engine->device_runes.pointer, (uint32_t const *)(remote + flag_at),
+                                                    engine->device_alphabet.pointer, SZS_ALPHABET_MOST,
+                                                    (uint32_t *)(remote + flag_at + sizeof(uint32_t)), stream);
     if (error == hipSuccess)
         error = hipMemcpyAsync(host + counts_at, remote + counts_at, staging_bytes - counts_at, hipMemcpyDeviceToHost, stream);
     hipError_t const drained = hipStreamSynchronize(stream); /* also on failure: nothing stays in flight */
@@ -201,6 +215,8 @@ static sz_status_t transcode_to_runes(szs_engine_s *engine, int device, hipStrea
 
     *runes = *(uint32_t const *)(host + flag_at) != 0;
     if (!*runes) return sz_success_k;
+    uint32_t const distinct = ((uint32_t const *)(host + flag_at))[1], overflowed = ((uint32_t const *)(host + flag_at))[2];
+    if (renumber && distinct && distinct <= SZS_ALPHABET_MOST && !overflowed) *alphabet = distinct; /* the arrays now hold ids */
     uint32_t const *counts = (uint32_t const *)(host + counts_at);
     uint64_t const base = (uint64_t)(uintptr_t)engine->device_runes.pointer;
     for (size_t i = 0; i < strings; ++i) {
@@ -245,6 +261,7 @@ static void release_device_state(szs_engine_s *engine) {
     szs_buffer_release(&engine->device_runes);
     szs_buffer_release(&engine->device_transcode);
     szs_buffer_release(&engine->pinned_transcode);
+    szs_buffer_release(&engine->device_alphabet);
     szs_buffer_release(&engine->device_plan_refs);
     szs_buffer_release(&engine->pinned_summary);
     if (engine->events_device >= 0) {
@@ -555,11 +572,11 @@ static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int dev
                 unsigned const lanes = split_lanes_of_runes(split_knob, group->variant, (uint64_t)group->count * candidate_blocks);
                 launch_error = group->variant == SZS_MYERS_SHORT_WORDS
                                    ? szs_hip_levenshtein_myers_runes(queries, count, candidate_refs, d->kc_count, (uint64_t *)device_results,
-                                                                     device_stride, d->layout, target)
+                                                                     device_stride, d->layout, d->alphabet, target)
                                : lanes ? szs_hip_levenshtein_myers_runes_split(group->variant, lanes, queries, count, candidate_refs, d->kc_count,
-                                                                               (uint64_t *)device_results, device_stride, d->layout, target)
+                                                                               (uint64_t *)device_results, device_stride, d->layout, d->alphabet, target)
                                        : szs_hip_levenshtein_myers_runes_long(group->variant, queries, count, candidate_refs, d->kc_count,
-                                                                              (uint64_t *)device_results, device_stride, d->layout, target);
+                                                                              (uint64_t *)device_results, device_stride, d->layout, d->alphabet, target);
                 if (launch_error == (int)hipErrorNotSupported) { /* no LDS for the rune table: the rune-keyed DP kernel, whose
                                                                     workspace is reserved here, on the one path that needs it -
                                                                     and on the scope's stream, like every user of that workspace */
@@ -1024,9 +1041,10 @@ static sz_status_t cross_host_planned(szs_call_t *call) {
      * no string holds a byte >= 0x80 the corpus is ASCII and the byte kernels compute the same distances - the
      * reference takes the same shortcut pair by pair (serial.hpp:2809-2813). */
     int runes = 0;
+    uint32_t alphabet = 0;
     if (engine->family == szs_family_levenshtein_utf8_k) {
         status = transcode_to_runes(engine, device, stream, symmetric, q_addresses, q_lengths, q_count, c_addresses, c_lengths, c_count,
-                                    &runes, error_message);
+                                    &runes, &alphabet, error_message);
         if (status != sz_success_k) return status;
     }
 
@@ -1057,6 +1075,7 @@ static sz_status_t cross_host_planned(szs_call_t *call) {
         szs_decision_t d;
         status = decide(engine, symmetric, runes, attempt > 0, &q_stats, &c_stats, q_variants, c_variants, cells, &d, error_message);
         if (status != sz_success_k) return status;
+        d.alphabet = alphabet;
         /* kernel roles */
         uint64_t *const kq_addresses = d.transposed ? c_addresses : q_addresses, *const kc_addresses = d.transposed ? q_addresses : c_addresses;
         uint32_t *const kq_lengths = d.transposed ? c_lengths : q_lengths, *const kc_lengths = d.transposed ? q_lengths : c_lengths;

@@ -95,6 +95,7 @@ typedef struct szs_engine_s {
     szs_buffer_t pinned_tape;    /* pinned: the host side of that copy */
     szs_buffer_t device_runes;   /* device: UTF-32 transcription of both sides (codepoint-level engine) */
     szs_buffer_t device_transcode; /* device: raw refs, rune starts, rune counts and the multibyte flag of that pass */
+    szs_buffer_t device_alphabet;  /* device: the hash table that renumbers a batch's runes (hip/utf8.hip) */
     szs_buffer_t pinned_transcode; /* pinned: the host's side of the same */
     int model_uploaded_device;
     int model_uploaded_transposed; /* the uploaded class table is the transpose (sides swapped by the planner) */
@@ -186,6 +187,7 @@ typedef struct szs_plan_t {
 typedef struct szs_decision_t {
     int valid;
     int symmetric, runes;
+    uint32_t alphabet;         /* runes: 0, or the size of the batch's renumbered alphabet (the UTF-32 arrays then hold ids) */
     uint32_t q_count, c_count; /* the caller's sides */
     int tier, transposed, layout;
     int use_myers, banded, maximise;

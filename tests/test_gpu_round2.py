@@ -474,3 +474,30 @@ def test_split_lanes_of_codepoints_agree_with_the_oracle(gpu, oracle, lanes, run
         assert np.array_equal(engine(queries, device=gpu), oracle.levenshtein_utf8(queries, queries))
     with knob("split", "0"), knob("tier", "lanes"), knob("swap", "0"):
         assert np.array_equal(engine(queries, candidates, device=gpu), expected)
+
+
+@pytest.mark.parametrize("alphabet,rune_ids", [("1", None), ("0", None), ("1", "3"), (None, None)])
+def test_renumbered_alphabet_agrees_with_the_oracle(gpu, oracle, alphabet, rune_ids):
+    """The codepoint engine with the batch's runes renumbered 1 ... A on the device (hip/utf8.hip; `alphabet` 1) and without
+    (0): every kernel family of the rune path - the short mixed-width launch, the long widths one lane per pair and split over
+    lanes, the strips beyond 2048 runes - on 1 .. 4-byte sequences, empties, symmetric; with `rune_ids` most runes overflow the
+    per-query table.  Then a batch of more distinct runes than the direct tables hold (it must keep its runes and still score)."""
+    rng = random.Random(900 + int(alphabet or 7) + int(rune_ids or 0))
+    letters = [chr(c) for c in list(range(0x30, 0x7B)) + list(range(0x3B1, 0x3C9)) + list(range(0x4E00, 0x4F40)) + list(range(0x1F600, 0x1F620))]
+    text = lambda n, source=letters: "".join(rng.choice(source) for _ in range(n)).encode()
+    lengths = [0, 1, 2, 31, 32, 33, 100, 255, 256, 257, 300, 400, 512, 640, 700, 1000, 1024, 1500, 2047, 2048, 2049, 2300]
+    queries = [text(n) for n in lengths]
+    candidates = [text(rng.randrange(0, 700)) for _ in range(280)] + [text(rng.randrange(1500, 2400)) for _ in range(12)] + [b"", queries[5]]
+    engine = szs.LevenshteinDistancesUTF8(capabilities=gpu)
+    expected = oracle.levenshtein_utf8(queries, candidates)
+    with knob("alphabet", alphabet), knob("rune_ids", rune_ids), knob("tier", "lanes"), knob("swap", "0"):
+        assert np.array_equal(engine(queries, candidates, device=gpu), expected)
+        assert np.array_equal(engine(queries, device=gpu), oracle.levenshtein_utf8(queries, queries))
+        with knob("swap", "1"):
+            assert np.array_equal(engine(queries, candidates, device=gpu), expected)
+    if rune_ids is None:
+        wide = [chr(c) for c in range(0x4E00, 0x4E00 + 6000)]  # 6000 distinct runes: beyond SZS_ALPHABET_MOST
+        queries = [text(n, wide) for n in (10, 200, 300, 900)] + ["".join(wide).encode()]
+        candidates = [text(rng.randrange(0, 500), wide) for _ in range(70)] + ["".join(wide[::-1]).encode()]
+        with knob("alphabet", alphabet), knob("tier", "lanes"):
+            assert np.array_equal(engine(queries, candidates, device=gpu), oracle.levenshtein_utf8(queries, candidates))
