@@ -142,7 +142,7 @@ SZ_API_RUNTIME sz_status_t szs_rocm_node_scores_u64tape(szs_rocm_node_engine_t e
  *  environment spelling ("SZS_ROCM_TIER" ...); `value` NULL, "" or "auto" restores the automatic choice.  No knob changes a
  *  result: they pick among kernels that compute the same scores.
  *
- *  Also at load: `GPU_MAX_HW_QUEUES=8` is exported unless the application has set it - the HIP runtime reads it when it
+ *  Also at load: `GPU_MAX_HW_QUEUES=12` is exported unless the application has set it - the HIP runtime reads it when it
  *  initialises, and the per-width launches of a mixed-length batch run on up to eight streams.
  */
 SZ_API_RUNTIME sz_status_t szs_rocm_tuning_set(char const *knob, char const *value);

@@ -61,10 +61,11 @@ __attribute__((constructor)) static void szs_tuning_load(void) {
     if (knobs[szs_knob_trace_k] < 0) knobs[szs_knob_trace_k] = 0;
     /*  The per-width launches of one call run on up to 8 streams (dispatch.c: enqueue); the HIP runtime multiplexes a process's
      *  streams onto GPU_MAX_HW_QUEUES hardware queues, 4 unless told otherwise, and reads that when it initialises - with a
-     *  first HIP call, normally after this library was loaded.  Eight queues let the width groups of a small (latency-bound)
-     *  batch overlap: an eighth of config 5 takes 2.4 ms instead of 3.0 (profiles/r02/shard_preview.jsonl).  A value the
-     *  application exported is left alone.  */
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+     *  first HIP call, normally after this library was loaded.  With their own queues the width groups of a small
+     *  (latency-bound) batch overlap: an eighth of config 5 takes 2.0 ms on twelve queues, 2.6 on eight (the application's
+     *  own streams take queues too), 3.0 on four (profiles/r02/shard_preview.jsonl).  A value the application exported is
+     *  left alone.  */
+    setenv("GPU_MAX_HW_QUEUES", "12", 0);
 }
 
 int szs_tuning_get(int knob) { return __atomic_load_n(&knobs[knob], __ATOMIC_RELAXED); }
