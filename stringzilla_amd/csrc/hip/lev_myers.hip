@@ -243,22 +243,19 @@ __device__ __forceinline__ void myers_workgroup(u32 *peq, u32 *keys, szs_string_
 
     u32 column = 0;
     if constexpr (runes_) {
-        // ---- codepoints: one aligned dword per column
+        // ---- codepoints: FOUR columns per 16-byte load.  Every lane streams its own string, so a load instruction touches 64
+        //      cache lines whatever its width; a dword per column made the rune kernels wait on the memory pipeline (config 5u:
+        //      135 GB of line traffic per call, VALU issue 56 % busy).  The transcoder starts every string on a 16-byte boundary.
         u32 const *const runes = reinterpret_cast<u32 const *>(candidate.address);
-        auto rune_at = [&](u32 index) -> u32 { return index < text_length ? runes[index] : 0u; };
-        constexpr u32 columns_per_iteration = 2 * text_dwords_ > 4 ? 4 : 2 * text_dwords_; // keep the prefetch window small
-        if (columns_per_iteration <= shortest_in_wave && longest_in_wave) {
-            u32 ahead[columns_per_iteration];
-#pragma unroll
-            for (u32 d = 0; d < columns_per_iteration; ++d) ahead[d] = rune_at(d);
-            for (; column + columns_per_iteration <= shortest_in_wave; column += columns_per_iteration) {
-                u32 symbols[columns_per_iteration];
-#pragma unroll
-                for (u32 d = 0; d < columns_per_iteration; ++d) symbols[d] = ahead[d];
-#pragma unroll
-                for (u32 d = 0; d < columns_per_iteration; ++d) ahead[d] = rune_at(column + columns_per_iteration + d);
-#pragma unroll
-                for (u32 d = 0; d < columns_per_iteration; ++d) take(symbols[d]);
+        auto quad_at = [&](u32 index) -> uint4 { // a multiple of 4; symbols past the text's end are never consumed
+            return index < text_length ? *reinterpret_cast<uint4 const *>(runes + index) : make_uint4(0, 0, 0, 0);
+        };
+        if (4 <= shortest_in_wave && longest_in_wave) {
+            uint4 ahead = quad_at(0);
+            for (; column + 4 <= shortest_in_wave; column += 4) {
+                uint4 const now = ahead;
+                ahead = quad_at(column + 4);
+                take(now.x), take(now.y), take(now.z), take(now.w);
             }
         }
 #pragma unroll 1
@@ -967,16 +964,18 @@ __device__ __forceinline__ void myers_long_runes_workgroup(u32 *lds, u32 rune_sl
         myers_column<words_>(vp, vn, eq);
     };
 
-    // ---- codepoints: one aligned dword per column, two columns per iteration, loaded one iteration early
+    // ---- codepoints: four columns per 16-byte load, loaded one iteration early (see myers_workgroup)
     u32 const *const runes = reinterpret_cast<u32 const *>(candidate.address);
-    auto rune_at = [&](u32 index) -> u32 { return index < text_length ? runes[index] : 0u; };
+    auto quad_at = [&](u32 index) -> uint4 {
+        return index < text_length ? *reinterpret_cast<uint4 const *>(runes + index) : make_uint4(0, 0, 0, 0);
+    };
     u32 column = 0;
-    if (2 <= shortest_in_wave && longest_in_wave) {
-        u32 ahead[2] = {rune_at(0), rune_at(1)};
-        for (; column + 2 <= shortest_in_wave; column += 2) {
-            u32 const first = ahead[0], second = ahead[1];
-            ahead[0] = rune_at(column + 2), ahead[1] = rune_at(column + 3);
-            take(first), take(second);
+    if (4 <= shortest_in_wave && longest_in_wave) {
+        uint4 ahead = quad_at(0);
+        for (; column + 4 <= shortest_in_wave; column += 4) {
+            uint4 const now = ahead;
+            ahead = quad_at(column + 4);
+            take(now.x), take(now.y), take(now.z), take(now.w);
         }
     }
 #pragma unroll 1
@@ -1142,14 +1141,17 @@ __global__ __launch_bounds__(256 * lanes_) void levenshtein_myers_split_runes_ke
         vn[w] = 0;
     }
     u32 const *const runes = reinterpret_cast<u32 const *>(candidate.address);
-    auto rune_at = [&](u32 index) -> u32 { return head && index < text_length ? runes[index] : 0u; };
-    u32 ahead[2] = {rune_at(0), rune_at(1)};
+    auto quad_at = [&](u32 index) -> uint4 { // the head lane's text, four columns per 16-byte load (see myers_workgroup)
+        return head && index < text_length ? *reinterpret_cast<uint4 const *>(runes + index) : make_uint4(0, 0, 0, 0);
+    };
+    uint4 quad = quad_at(0), quad_next = quad_at(4);
     u32 incoming = 0, incoming_rune = 0;
     u32 const steps = longest_in_wave ? longest_in_wave + lanes_ - 1 : 0;
 #pragma unroll 1
     for (u32 step = 0; step < steps; ++step) {
-        u32 const own = ahead[0];
-        ahead[0] = ahead[1], ahead[1] = rune_at(step + 2);
+        u32 const own = quad.x;
+        quad.x = quad.y, quad.y = quad.z, quad.z = quad.w;
+        if ((step & 3u) == 3u) quad = quad_next, quad_next = quad_at(step + 5);
         bool const active = head ? step < text_length : ((incoming >> 18) & 1u) != 0;
         u32 const rune = head ? own : incoming_rune;
         u32 id = incoming & 0xFFFFu;

@@ -180,10 +180,10 @@ static sz_status_t transcode_to_runes(szs_engine_s *engine, int device, hipStrea
         refs[i].address = is_query ? q_addresses[k] : c_addresses[k];
         refs[i].length = is_query ? q_lengths[k] : c_lengths[k];
         refs[i].index = (uint32_t)i;
-        starts[i] = total, total += refs[i].length;
+        starts[i] = total, total += (refs[i].length + 3u) & ~(uint64_t)3; /* 16-byte aligned UTF-32 arrays: the kernels load four runes at once */
     }
     *(uint32_t *)(host + flag_at) = 0;
-    status = szs_buffer_reserve(&engine->device_runes, szs_memory_device_k, device, (total + 1) * sizeof(uint32_t), error_message);
+    status = szs_buffer_reserve(&engine->device_runes, szs_memory_device_k, device, (total + 4) * sizeof(uint32_t), error_message);
     if (status != sz_success_k) return status;
     /* A batch worth the three extra launches gets its runes renumbered 1 ... A (hip/utf8.hip: the codepoint kernels then index a
      * table instead of probing one); the `alphabet` knob: 0 never, 1 always. */
