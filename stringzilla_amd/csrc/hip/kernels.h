@@ -82,7 +82,9 @@ int szs_hip_levenshtein_myers_split(unsigned words, unsigned lanes, szs_string_r
 
 /**
  *  Codepoint-level twin of the short-query bit-parallel kernel: strings are UTF-32 arrays (`address` points at `u32`
- *  runes, `length` counts runes) produced by szs_hip_utf8_transcode; every query has at most 256 runes.
+ *  runes, `length` counts runes) produced by szs_hip_utf8_transcode; every query has at most 256 runes.  This launcher and
+ *  the two below read a candidate's text 16 bytes at a time: every array must START ON A 16-BYTE BOUNDARY and own its
+ *  storage up to the next one (dispatch.c pads the rune offsets accordingly).
  */
 int szs_hip_levenshtein_myers_runes(szs_string_ref_t const *queries, uint32_t queries_count,
                                     szs_string_ref_t const *candidates, uint32_t candidates_count, uint64_t *results,
