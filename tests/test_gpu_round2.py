@@ -501,3 +501,24 @@ def test_renumbered_alphabet_agrees_with_the_oracle(gpu, oracle, alphabet, rune_
         candidates = [text(rng.randrange(0, 500), wide) for _ in range(70)] + ["".join(wide[::-1]).encode()]
         with knob("alphabet", alphabet), knob("tier", "lanes"):
             assert np.array_equal(engine(queries, candidates, device=gpu), oracle.levenshtein_utf8(queries, candidates))
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_codepoint_fuzz(gpu, oracle, seed):
+    """Random shapes through the codepoint engine with the planner free: up to 160 x 300 strings, rune lengths 0 .. 700 (every residue
+    of the four-columns-per-load main loop and its tail), alphabets from 3 to 3000 runes of mixed UTF-8 widths, with the batch's
+    runes renumbered (`alphabet` 1), kept (0) and left to the size rule."""
+    rng = random.Random(4200 + seed)
+    pool = [chr(c) for c in rng.sample(list(range(0x21, 0x7F)) + list(range(0xA1, 0x250)) + list(range(0x400, 0x500)) + list(range(0x4E00, 0x5600)) +
+                                       list(range(0x1F300, 0x1F400)), rng.choice([3, 40, 300, 3000]))]
+    text = lambda n: "".join(rng.choice(pool) for _ in range(n)).encode()
+    high = rng.choice([5, 40, 300, 700])
+    queries = [text(rng.randint(0, high)) for _ in range(rng.randint(1, 160))]
+    candidates = [text(rng.randint(0, high)) for _ in range(rng.randint(1, 300))]
+    engine = szs.LevenshteinDistancesUTF8(capabilities=gpu)
+    expected = oracle.levenshtein_utf8(queries, candidates)
+    for alphabet in ("1", "0", None):
+        with knob("alphabet", alphabet):
+            assert np.array_equal(engine(queries, candidates, device=gpu), expected), (seed, alphabet, len(queries), len(candidates), high, len(pool))
+    with knob("alphabet", "1"):
+        assert np.array_equal(engine(queries, device=gpu), oracle.levenshtein_utf8(queries, queries))
