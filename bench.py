@@ -228,7 +228,9 @@ def roofline(config, profile, kernel_seconds, traffic_override=None):
             "lds_conflict_fraction": round(call["lds_conflict_fraction"], 4) if "lds_conflict_fraction" in call else None,
             "note": "frac = VALU wave-instructions x 64 lanes per second over one full-rate lane-op per lane per cycle (256 CUs x 4 SIMDs "
                     "x 16 lanes x 2.4 GHz); add / logic opcodes issue at up to 1.7x that rate on gfx950, carries, shifts and packed "
-                    "16-bit opcodes at 1x (profiles/r02/valu_peak.json)",
+                    "16-bit opcodes at 1x (profiles/r02/valu_peak.json) - so a mix with fast-class opcodes can read above 1.0: the "
+                    "kernel is then at the issue limit of its mix, and `myers_ceiling` (the same column update on registers only) is "
+                    "the fraction that says how close",
         }
     return record
 
