@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 import stringzilla_amd as szs
-from stringzilla_amd import matrices, workloads
+from stringzilla_amd import _abi, matrices, workloads
 
 parser = argparse.ArgumentParser()
 parser.add_argument("--repeats", type=int, default=3)

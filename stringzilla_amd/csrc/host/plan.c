@@ -163,6 +163,17 @@ double szs_plan_estimate(unsigned bit_parallel_limit, int bit_parallel_chain, in
     int const bit_parallel = bit_parallel_limit && longest_query <= bit_parallel_limit;
     double const waves_per_query = (candidates_count + 63) / 64;
     double lane_waves = queries_count * waves_per_query * scale;
+    /* The long bit-parallel widths (24 ... 64 words) spread a pair over 2 or 4 lanes (dispatch.c: split_lanes_of): that many
+     * times the wavefronts, each pair that many times shorter - 128 x 128 x 1000 B runs at 29 TCUPS on this tier, 15 on the
+     * chain (profiles/r02/shapes.jsonl).  Bytes only: a side of codepoints reaches here with `bit_parallel_limit` = 2048 too,
+     * and its split kernels follow the same rule. */
+    double split = 1.0;
+    if (bit_parallel && longest_query > 640 && longest_query <= 2048 && szs_tuning_get(szs_knob_split_k) != 0) {
+        int const pinned = szs_tuning_get(szs_knob_split_k);
+        double const workgroups = (double)queries_count * ((candidates_count + 255) / 256);
+        split = pinned == 2 || pinned == 4 ? pinned : workgroups < 1024 ? 4.0 : 2.0;
+        lane_waves *= split;
+    }
     if (lane_waves < 1) lane_waves = 1;
     double const fill = lane_waves >= 2 * simds ? 1.0 : lane_waves <= simds ? 0.5 : lane_waves / (2 * simds);
     double const lane_rate = (bit_parallel ? 0.85 : 1.0 / ((affine ? 7.0 : 3.0) * 4.2)) * fill;
@@ -171,7 +182,7 @@ double szs_plan_estimate(unsigned bit_parallel_limit, int bit_parallel_chain, in
      * of neighbouring workgroups do not spread evenly over the SIMDs (4096 x 1 x 128 B measured 2x the model). */
     double const live_waves = waves_per_query < 4 ? waves_per_query : 4;
     lanes_cycles *= 1.0 + 0.5 * (1.0 - live_waves / 4.0);
-    double const largest_pair = (double)longest_query * longest_candidate / lane_rate;
+    double const largest_pair = (double)longest_query * longest_candidate / lane_rate / split;
     if (largest_pair > lanes_cycles) lanes_cycles = largest_pair;
 
     /* systolic: measured on MI355X (profiles/r01/shapes_v6.jsonl): a wavefront-step of 64 lanes x 8 rows x 4 columns
