@@ -276,3 +276,17 @@ def test_node_entry_fails_loudly_without_a_gpu():
     assert failure.value.status_name == "missing_gpu"
     assert _abi.lib.szs_rocm_node_size(None) == 0
     _abi.lib.szs_rocm_node_free(None), _abi.lib.szs_rocm_node_engine_free(None)  # null handles are ignored, like every *_free
+
+
+def test_tier_model_knows_the_lanes_per_pair_split():
+    """128 x 128 strings of 1000 bytes: a launch of 128 workgroups, four lanes per pair (hip/lev_myers.hip:
+    levenshtein_myers_split_kernel) - the lanes tier beats the band chain there (25 vs 15 TCUPS measured), and the model says so.
+    16 x 16 x 4096 (beyond the split widths, 64 wavefronts) stays on the chain."""
+    def tier_of(count, length):
+        lengths = np.full(count, length, dtype=np.uint32)
+        tier, transposed = ctypes.c_int(-1), ctypes.c_int(-1)
+        assert _abi.lib.szs_rocm_orientation_probe(1, 0, 1, 0, lengths.ctypes.data, count, lengths.ctypes.data, count, ctypes.byref(tier),
+                                                   ctypes.byref(transposed)) == 0
+        return tier.value
+    assert tier_of(128, 1000) == 0
+    assert tier_of(16, 4096) == 2
