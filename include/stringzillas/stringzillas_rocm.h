@@ -137,7 +137,8 @@ SZ_API_RUNTIME sz_status_t szs_rocm_node_scores_u64tape(szs_rocm_node_engine_t e
  *  "swap" (0 | 1), "packed" (0), "rune_ids" (n), "chain_waves" (4 | 8 | 16), "trace" (0 | 1), "cells" (64),
  *  "planner" (host | device), "speculate" (0), "streams" (0: one stream), "reuse" (0: never re-use a plan),
  *  "split" (0 | 2 | 4: lanes per pair of the long bit-parallel widths), "alphabet" (0 | 1: never / always renumber the runes
- *  of a codepoint batch on the device), "cpu_requests" (strict | gpu: serve capability
+ *  of a codepoint batch on the device), "merge" (n: candidate blocks per workgroup of the short bit-parallel kernels),
+ *  "cpu_requests" (strict | gpu: serve capability
  *  masks without the GPU bit and CPU device scopes with the GPU engines on device 0 instead of refusing them) - or its
  *  environment spelling ("SZS_ROCM_TIER" ...); `value` NULL, "" or "auto" restores the automatic choice.  No knob changes a
  *  result: they pick among kernels that compute the same scores.

@@ -158,7 +158,7 @@ _KNOBS = {"tier": "SZS_ROCM_TIER", "swap": "SZS_ROCM_SWAP", "packed": "SZS_ROCM_
           "chain_waves": "SZS_ROCM_CHAIN_WAVES", "trace": "SZS_ROCM_TRACE", "cells": "SZS_ROCM_CELLS",
           "planner": "SZS_ROCM_PLANNER", "speculate": "SZS_ROCM_SPECULATE", "cpu_requests": "SZS_ROCM_CPU_REQUESTS",
           "streams": "SZS_ROCM_STREAMS", "reuse": "SZS_ROCM_REUSE",
-          "split": "SZS_ROCM_SPLIT", "alphabet": "SZS_ROCM_ALPHABET"}
+          "split": "SZS_ROCM_SPLIT", "alphabet": "SZS_ROCM_ALPHABET", "merge": "SZS_ROCM_MERGE"}
 _knob_values = {name: os.environ.get(variable) for name, variable in _KNOBS.items()}  # what the library read when it was loaded
 
 

@@ -152,6 +152,7 @@ enum {
     szs_knob_reuse_k,       /* -1 automatic | 0: never re-use the refs planned for the previous call of the same tapes */
     szs_knob_split_k,       /* -1 automatic | 0 / 2 / 4: lanes per pair of the long byte kernels (24 ... 64 words) */
     szs_knob_alphabet_k,    /* -1 automatic | 0 never | 1 always: renumber a codepoint batch's runes (hip/utf8.hip) */
+    szs_knob_merge_k,       /* -1 automatic | n: candidate blocks per workgroup of the short bit-parallel kernels (1: never merge) */
     szs_knob_count_k
 };
 int szs_tuning_get(int knob);

@@ -156,7 +156,7 @@ __device__ __forceinline__ void myers_workgroup(u32 *peq, u32 *keys, szs_string_
                                                 szs_string_ref_t const *__restrict__ candidates, u32 candidates_count,
                                                 u32 candidate_block, u64 *__restrict__ results, u64 results_row_stride,
                                                 int symmetric, szs_ref_guard_t const &guard, u32 alphabet = 0,
-                                                u32 *claimed_rows = nullptr) {
+                                                u32 *claimed_rows = nullptr, u32 blocks_here = 1) {
     constexpr int rows = runes_ ? rune_slots_k : byte_rows_k;
     using layout = peq_layout<words_, rows>;
     if (guard.enabled && !ref_is_current(guard, 0, query)) { // refs of an earlier call: this query's no longer holds - uniform
@@ -212,8 +212,13 @@ __device__ __forceinline__ void myers_workgroup(u32 *peq, u32 *keys, szs_string_
     }
     __syncthreads();
 
+    // ---- `blocks_here` candidate blocks against this table, the heaviest (`candidate_block`) first: when a launch is tens of
+    //      thousands of workgroups of tiny strings, the table and the round trips to the query are shared by several blocks
+    //      (the launcher decides: launch_myers).
+#pragma unroll 1
+    for (u32 block_step = 0; block_step < blocks_here; ++block_step) {
     // ---- this lane's candidate
-    u32 const candidate_slot = candidate_block * SZS_CANDIDATES_PER_WORKGROUP + threadIdx.x;
+    u32 const candidate_slot = (candidate_block - block_step) * SZS_CANDIDATES_PER_WORKGROUP + threadIdx.x;
     bool live = candidate_slot < candidates_count;
     szs_string_ref_t candidate = {0, 0, 0};
     if (live) candidate = candidates[candidate_slot];
@@ -341,6 +346,7 @@ __device__ __forceinline__ void myers_workgroup(u32 *peq, u32 *keys, szs_string_
         if ((symmetric & SZS_LAYOUT_SYMMETRIC) && candidate.index != query.index)
             results[column * results_row_stride + row] = distance;
     }
+    } // the next candidate block
 }
 
 /** Workgroup -> (query, candidate block).  Candidates arrive ascending, so walking the candidate blocks backwards hands out
@@ -391,21 +397,28 @@ __global__ __launch_bounds__(256, SZS_MYERS_LONG_WAVES) void levenshtein_myers_l
 template <bool runes_>
 __global__ __launch_bounds__(256, SZS_MYERS_SHORT_WAVES) void levenshtein_myers_short_kernel(
     szs_string_ref_t const *__restrict__ queries, szs_string_ref_t const *__restrict__ candidates, u32 candidates_count,
-    u32 candidate_blocks, u64 *__restrict__ results, u64 results_row_stride, int symmetric, szs_ref_guard_t guard, u32 alphabet) {
+    u32 candidate_blocks, u64 *__restrict__ results, u64 results_row_stride, int symmetric, szs_ref_guard_t guard, u32 alphabet,
+    u32 blocks_per_group) {
     __shared__ __attribute__((aligned(16))) u32 peq[peq_layout<8, runes_ ? rune_slots_k : byte_rows_k>::total_dwords];
     __shared__ u32 slot_keys[runes_ ? rune_slots_k : 1];
     __shared__ u32 claimed_rows;
     extern __shared__ u32 rows_of_ids[]; // runes of a renumbered batch: alphabet + 1 dwords of dynamic LDS
     u32 *const keys = runes_ && alphabet ? rows_of_ids : slot_keys;
-    u32 query_slot, candidate_block;
-    myers_work_item(candidate_blocks, query_slot, candidate_block);
+    // `candidate_blocks` counts GROUPS of `blocks_per_group` blocks here (1 unless the launcher merged them); group g holds the
+    // blocks [g x n, (g + 1) x n) that exist, and the workgroup walks them downwards from the last
+    u32 query_slot, candidate_group;
+    myers_work_item(candidate_blocks, query_slot, candidate_group);
+    u32 const all_blocks = (candidates_count + SZS_CANDIDATES_PER_WORKGROUP - 1) / SZS_CANDIDATES_PER_WORKGROUP;
+    u32 const first_block = candidate_group * blocks_per_group;
+    u32 const blocks_here = all_blocks - first_block < blocks_per_group ? all_blocks - first_block : blocks_per_group;
+    u32 const candidate_block = first_block + blocks_here - 1;
     szs_string_ref_t const query = queries[query_slot];
     u32 const words = __builtin_amdgcn_readfirstlane(query.length ? (query.length + 31u) / 32u : 1u);
 #define SZS_MYERS_BODY(W)                                                                                              \
     case W:                                                                                                            \
         myers_workgroup<W, SZS_MYERS_SHORT_TEXT_DWORDS, runes_>(peq, keys, query, candidates, candidates_count,       \
                                                                 candidate_block, results, results_row_stride,         \
-                                                                symmetric, guard, alphabet, &claimed_rows);           \
+                                                                symmetric, guard, alphabet, &claimed_rows, blocks_here); \
         break;
     switch (words) {
         SZS_MYERS_BODY(1)
@@ -418,7 +431,7 @@ __global__ __launch_bounds__(256, SZS_MYERS_SHORT_WAVES) void levenshtein_myers_
     default: // 8; the host never sends longer queries here
         myers_workgroup<8, SZS_MYERS_SHORT_TEXT_DWORDS, runes_>(peq, keys, query, candidates, candidates_count,
                                                                 candidate_block, results, results_row_stride, symmetric, guard,
-                                                                alphabet, &claimed_rows);
+                                                                alphabet, &claimed_rows, blocks_here);
         break;
     }
 #undef SZS_MYERS_BODY
@@ -1426,6 +1439,36 @@ static int launch_myers(kernel_t kernel, szs_string_ref_t const *queries, u32 qu
     return 0;
 }
 
+/**
+ *  The mixed-width short kernels.  A launch of tens of thousands of workgroups of tiny strings (4096 x 4096 words of text:
+ *  65,536 workgroups that live ~5 us, most of it round trips to the query and its table) merges candidate blocks: a workgroup
+ *  takes 2, 4 or 8 consecutive blocks as long as 16,384 workgroups remain - config 2 (4096) and config 5 (28,769) never merge.
+ */
+template <typename kernel_t>
+static int launch_myers_short(kernel_t kernel, szs_string_ref_t const *queries, u32 queries_count, szs_string_ref_t const *candidates,
+                              u32 candidates_count, u64 *results, u64 stride, int symmetric, szs_ref_guard_t const *guard_or_null,
+                              hipStream_t stream, size_t dynamic_lds, u32 alphabet) {
+    szs_ref_guard_t guard = {};
+    if (guard_or_null) guard = *guard_or_null;
+    u32 const candidate_blocks = (candidates_count + SZS_CANDIDATES_PER_WORKGROUP - 1) / SZS_CANDIDATES_PER_WORKGROUP;
+    u32 blocks_per_group = 1;
+    int const pinned = szs_tuning_get(szs_knob_merge_k); // a testing aid: blocks per workgroup, 1 = never merge
+    if (pinned > 0) blocks_per_group = (u32)pinned < candidate_blocks ? (u32)pinned : candidate_blocks;
+    else
+        while (blocks_per_group < 8 && (u64)queries_count * ((candidate_blocks + 2 * blocks_per_group - 1) / (2 * blocks_per_group)) >= 16384)
+            blocks_per_group *= 2;
+    u32 const groups = (candidate_blocks + blocks_per_group - 1) / blocks_per_group;
+    u32 const queries_per_launch = groups ? (1u << 30) / groups : queries_count;
+    for (u32 first = 0; first < queries_count; first += queries_per_launch) {
+        u32 const batch = queries_count - first < queries_per_launch ? queries_count - first : queries_per_launch;
+        hipLaunchKernelGGL(kernel, dim3(batch * groups), dim3(256), dynamic_lds, stream, queries + first, candidates, candidates_count, groups,
+                           results, stride, symmetric, guard, alphabet, blocks_per_group);
+        hipError_t const error = hipGetLastError();
+        if (error != hipSuccess) return (int)error;
+    }
+    return 0;
+}
+
 } // namespace szs_hip
 
 extern "C" int szs_hip_levenshtein_myers(unsigned words, szs_string_ref_t const *queries, uint32_t queries_count,
@@ -1441,8 +1484,8 @@ extern "C" int szs_hip_levenshtein_myers(unsigned words, szs_string_ref_t const 
                             results, results_row_stride, symmetric, guard, s);
     switch (words) {
     case SZS_MYERS_SHORT_WORDS:
-        return launch_myers(levenshtein_myers_short_kernel<false>, queries, queries_count, candidates, candidates_count, results,
-                            results_row_stride, symmetric, guard, s, 0, 0u);
+        return launch_myers_short(levenshtein_myers_short_kernel<false>, queries, queries_count, candidates, candidates_count, results,
+                                  results_row_stride, symmetric, guard, s, 0, 0u);
         SZS_MYERS_CASE(10)
         SZS_MYERS_CASE(12)
         SZS_MYERS_CASE(16)
@@ -1483,9 +1526,9 @@ extern "C" int szs_hip_levenshtein_myers_runes(szs_string_ref_t const *queries, 
     using namespace szs_hip;
     if (!queries_count || !candidates_count) return 0;
     if (alphabet > SZS_ALPHABET_MOST) return (int)hipErrorInvalidValue;
-    return launch_myers(levenshtein_myers_short_kernel<true>, queries, queries_count, candidates, candidates_count, results,
-                        results_row_stride, symmetric, nullptr, static_cast<hipStream_t>(stream),
-                        alphabet ? ((size_t)alphabet + 1) * sizeof(u32) : 0, (u32)alphabet);
+    return launch_myers_short(levenshtein_myers_short_kernel<true>, queries, queries_count, candidates, candidates_count, results,
+                              results_row_stride, symmetric, nullptr, static_cast<hipStream_t>(stream),
+                              alphabet ? ((size_t)alphabet + 1) * sizeof(u32) : 0, (u32)alphabet);
 }
 
 extern "C" size_t szs_hip_levenshtein_myers_banded_bytes(uint32_t queries_count, uint32_t candidates_count, uint32_t longest_candidate) {

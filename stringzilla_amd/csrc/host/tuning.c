@@ -34,6 +34,7 @@ static struct {
     [szs_knob_reuse_k] = {"reuse", "SZS_ROCM_REUSE"},
     [szs_knob_split_k] = {"split", "SZS_ROCM_SPLIT"},
     [szs_knob_alphabet_k] = {"alphabet", "SZS_ROCM_ALPHABET"},
+    [szs_knob_merge_k] = {"merge", "SZS_ROCM_MERGE"},
 };
 
 /** Text -> value.  -1 always means "automatic".  Tier names: lanes 0, systolic 1, chain 2; planner: host 0, device 1. */

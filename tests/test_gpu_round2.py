@@ -522,3 +522,24 @@ def test_codepoint_fuzz(gpu, oracle, seed):
             assert np.array_equal(engine(queries, candidates, device=gpu), expected), (seed, alphabet, len(queries), len(candidates), high, len(pool))
     with knob("alphabet", "1"):
         assert np.array_equal(engine(queries, device=gpu), oracle.levenshtein_utf8(queries, queries))
+
+
+@pytest.mark.parametrize("merge", ["1", "3", "8", None])
+def test_merged_candidate_blocks_agree_with_the_oracle(gpu, oracle, merge):
+    """The short bit-parallel kernels with several candidate blocks per workgroup (`merge` pins the number; None: the launcher's
+    rule): 1500 candidates = 6 blocks, the last one ragged, so groups of 3 and of 8 end early; bytes and codepoints, every
+    query width of the short launch, empties, symmetric, plan re-use."""
+    rng = random.Random(5100 + int(merge or 0))
+    queries = [bytes(rng.choice(b"abcdefgh ") for _ in range(n)) for n in [0, 1, 5, 31, 32, 33, 64, 100, 128, 200, 255, 256] + [rng.randint(1, 40) for _ in range(40)]]
+    candidates = _strings(rng, 1500, 0, 60, b"abcdefgh ") + [b"", queries[7]]
+    lev, utf8 = szs.LevenshteinDistances(capabilities=gpu), szs.LevenshteinDistancesUTF8(capabilities=gpu)
+    accented = [q.replace(b"a", "\u00e1".encode()).replace(b"e", "\u20ac".encode()) for q in queries]
+    accented_candidates = [c.replace(b"a", "\u00e1".encode()).replace(b"e", "\u20ac".encode()) for c in candidates]
+    with knob("merge", merge), knob("tier", "lanes"), knob("swap", "0"):
+        expected = oracle.levenshtein(queries, candidates)
+        for _ in range(2):
+            assert np.array_equal(lev(queries, candidates, device=gpu), expected)
+        assert np.array_equal(lev(candidates[:700], device=gpu), oracle.levenshtein(candidates[:700], candidates[:700]))
+        for alphabet in ("0", "1"):
+            with knob("alphabet", alphabet):
+                assert np.array_equal(utf8(accented, accented_candidates, device=gpu), oracle.levenshtein_utf8(accented, accented_candidates))
