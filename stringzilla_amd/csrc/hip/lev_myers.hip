@@ -394,8 +394,8 @@ __global__ __launch_bounds__(256, SZS_MYERS_LONG_WAVES) void levenshtein_myers_l
  *  needs neither one launch per width nor padding to a common width.  All eight byte bodies fit the 64-VGPR budget.
  *  `runes_`: the codepoint-level twin - strings are UTF-32 arrays produced by utf8.hip, Peq is keyed by a rune table.
  */
-template <bool runes_>
-__global__ __launch_bounds__(256, SZS_MYERS_SHORT_WAVES) void levenshtein_myers_short_kernel(
+template <bool runes_, bool merged_>
+__device__ __forceinline__ void myers_short_body(
     szs_string_ref_t const *__restrict__ queries, szs_string_ref_t const *__restrict__ candidates, u32 candidates_count,
     u32 candidate_blocks, u64 *__restrict__ results, u64 results_row_stride, int symmetric, szs_ref_guard_t guard, u32 alphabet,
     u32 blocks_per_group) {
@@ -409,8 +409,9 @@ __global__ __launch_bounds__(256, SZS_MYERS_SHORT_WAVES) void levenshtein_myers_
     u32 query_slot, candidate_group;
     myers_work_item(candidate_blocks, query_slot, candidate_group);
     u32 const all_blocks = (candidates_count + SZS_CANDIDATES_PER_WORKGROUP - 1) / SZS_CANDIDATES_PER_WORKGROUP;
-    u32 const first_block = candidate_group * blocks_per_group;
-    u32 const blocks_here = all_blocks - first_block < blocks_per_group ? all_blocks - first_block : blocks_per_group;
+    u32 const first_block = merged_ ? candidate_group * blocks_per_group : candidate_group;
+    // (a compile-time 1 without merging: the block loop of myers_workgroup folds away - it cost config 2 1.5 % as a real loop)
+    u32 const blocks_here = !merged_ ? 1u : all_blocks - first_block < blocks_per_group ? all_blocks - first_block : blocks_per_group;
     u32 const candidate_block = first_block + blocks_here - 1;
     szs_string_ref_t const query = queries[query_slot];
     u32 const words = __builtin_amdgcn_readfirstlane(query.length ? (query.length + 31u) / 32u : 1u);
@@ -435,6 +436,25 @@ __global__ __launch_bounds__(256, SZS_MYERS_SHORT_WAVES) void levenshtein_myers_
         break;
     }
 #undef SZS_MYERS_BODY
+}
+
+template <bool runes_>
+__global__ __launch_bounds__(256, SZS_MYERS_SHORT_WAVES) void levenshtein_myers_short_kernel(
+    szs_string_ref_t const *__restrict__ queries, szs_string_ref_t const *__restrict__ candidates, u32 candidates_count,
+    u32 candidate_blocks, u64 *__restrict__ results, u64 results_row_stride, int symmetric, szs_ref_guard_t guard, u32 alphabet,
+    u32 blocks_per_group) {
+    myers_short_body<runes_, false>(queries, candidates, candidates_count, candidate_blocks, results, results_row_stride, symmetric, guard,
+                                    alphabet, blocks_per_group);
+}
+
+/** The same with `blocks_per_group` candidate blocks per workgroup (launch_myers_short decides). */
+template <bool runes_>
+__global__ __launch_bounds__(256, SZS_MYERS_SHORT_WAVES) void levenshtein_myers_short_merged_kernel(
+    szs_string_ref_t const *__restrict__ queries, szs_string_ref_t const *__restrict__ candidates, u32 candidates_count,
+    u32 candidate_blocks, u64 *__restrict__ results, u64 results_row_stride, int symmetric, szs_ref_guard_t guard, u32 alphabet,
+    u32 blocks_per_group) {
+    myers_short_body<runes_, true>(queries, candidates, candidates_count, candidate_blocks, results, results_row_stride, symmetric, guard,
+                                   alphabet, blocks_per_group);
 }
 
 /* ---- byte queries of more than 2048 bytes: horizontal strips of 2048 rows --------------------------------------------
@@ -1444,8 +1464,8 @@ static int launch_myers(kernel_t kernel, szs_string_ref_t const *queries, u32 qu
  *  65,536 workgroups that live ~5 us, most of it round trips to the query and its table) merges candidate blocks: a workgroup
  *  takes 2, 4 or 8 consecutive blocks as long as 16,384 workgroups remain - config 2 (4096) and config 5 (28,769) never merge.
  */
-template <typename kernel_t>
-static int launch_myers_short(kernel_t kernel, szs_string_ref_t const *queries, u32 queries_count, szs_string_ref_t const *candidates,
+template <bool runes_>
+static int launch_myers_short(szs_string_ref_t const *queries, u32 queries_count, szs_string_ref_t const *candidates,
                               u32 candidates_count, u64 *results, u64 stride, int symmetric, szs_ref_guard_t const *guard_or_null,
                               hipStream_t stream, size_t dynamic_lds, u32 alphabet) {
     szs_ref_guard_t guard = {};
@@ -1461,8 +1481,12 @@ static int launch_myers_short(kernel_t kernel, szs_string_ref_t const *queries, 
     u32 const queries_per_launch = groups ? (1u << 30) / groups : queries_count;
     for (u32 first = 0; first < queries_count; first += queries_per_launch) {
         u32 const batch = queries_count - first < queries_per_launch ? queries_count - first : queries_per_launch;
-        hipLaunchKernelGGL(kernel, dim3(batch * groups), dim3(256), dynamic_lds, stream, queries + first, candidates, candidates_count, groups,
-                           results, stride, symmetric, guard, alphabet, blocks_per_group);
+        if (blocks_per_group > 1)
+            hipLaunchKernelGGL((levenshtein_myers_short_merged_kernel<runes_>), dim3(batch * groups), dim3(256), dynamic_lds, stream, queries + first,
+                               candidates, candidates_count, groups, results, stride, symmetric, guard, alphabet, blocks_per_group);
+        else
+            hipLaunchKernelGGL((levenshtein_myers_short_kernel<runes_>), dim3(batch * groups), dim3(256), dynamic_lds, stream, queries + first,
+                               candidates, candidates_count, groups, results, stride, symmetric, guard, alphabet, 1u);
         hipError_t const error = hipGetLastError();
         if (error != hipSuccess) return (int)error;
     }
@@ -1484,8 +1508,8 @@ extern "C" int szs_hip_levenshtein_myers(unsigned words, szs_string_ref_t const 
                             results, results_row_stride, symmetric, guard, s);
     switch (words) {
     case SZS_MYERS_SHORT_WORDS:
-        return launch_myers_short(levenshtein_myers_short_kernel<false>, queries, queries_count, candidates, candidates_count, results,
-                                  results_row_stride, symmetric, guard, s, 0, 0u);
+        return launch_myers_short<false>(queries, queries_count, candidates, candidates_count, results, results_row_stride, symmetric, guard, s, 0,
+                                         0u);
         SZS_MYERS_CASE(10)
         SZS_MYERS_CASE(12)
         SZS_MYERS_CASE(16)
@@ -1526,9 +1550,8 @@ extern "C" int szs_hip_levenshtein_myers_runes(szs_string_ref_t const *queries, 
     using namespace szs_hip;
     if (!queries_count || !candidates_count) return 0;
     if (alphabet > SZS_ALPHABET_MOST) return (int)hipErrorInvalidValue;
-    return launch_myers_short(levenshtein_myers_short_kernel<true>, queries, queries_count, candidates, candidates_count, results,
-                              results_row_stride, symmetric, nullptr, static_cast<hipStream_t>(stream),
-                              alphabet ? ((size_t)alphabet + 1) * sizeof(u32) : 0, (u32)alphabet);
+    return launch_myers_short<true>(queries, queries_count, candidates, candidates_count, results, results_row_stride, symmetric, nullptr,
+                                    static_cast<hipStream_t>(stream), alphabet ? ((size_t)alphabet + 1) * sizeof(u32) : 0, (u32)alphabet);
 }
 
 extern "C" size_t szs_hip_levenshtein_myers_banded_bytes(uint32_t queries_count, uint32_t candidates_count, uint32_t longest_candidate) {
