@@ -63,6 +63,9 @@ def parse_args():
     parser.add_argument("--steps", type=int, default=200)
     parser.add_argument("--warmup", type=int, default=20)
     parser.add_argument("--config", type=int, default=2, help="BASELINE.json config index of the headline (2 = the metric's config)")
+    parser.add_argument("--generator", default="numpy", choices=["numpy", "mt19937_64"],
+                        help="where configs 1-4 come from: numpy's default_rng (the committed profiles) or std::mt19937_64 "
+                             "(tests/native/workloads_mt19937.cpp: the same shapes, reproducible from C++)")
     parser.add_argument("--extra-configs", default=None,
                         help="comma-separated configs reported in the `configs` array (default: 3,4,5,6 on one GPU, "
                              "4,5 strong-scaled on several; 'none' to skip)")
@@ -259,7 +262,7 @@ def measure_extra(config, scope, device_index, args, fence, with_cpu):
 
     from stringzilla_amd import workloads
 
-    load = workloads.config(config, scale=args.extra_scale)
+    load = workloads.config(config, scale=args.extra_scale, generator=args.generator if config <= 4 else "numpy")
     engine = make_engine(load, scope)
     queries, candidates = load.queries.to_device(device_index), load.candidates.to_device(device_index)
     results = torch.empty((len(queries), len(candidates)), dtype=torch.int64, device=torch.device("cuda", device_index))
@@ -302,7 +305,7 @@ def measure_strong(config, scope, device_index, args, fence, dist, world, rank, 
 
     from stringzilla_amd import sharded, workloads
 
-    load = workloads.config(config, scale=args.extra_scale)  # seeded: every rank can name the engine; only rank 0's strings are used
+    load = workloads.config(config, scale=args.extra_scale, generator=args.generator if config <= 4 else "numpy")  # seeded: every rank can name the engine; only rank 0's strings are used
     engine = make_engine(load, scope)
     busy, state = [], {}
 
@@ -350,7 +353,7 @@ def measure_c_node(config, devices, args):
 
     if not hasattr(szs, "Node"):
         return None
-    load = workloads.config(config, scale=args.extra_scale)
+    load = workloads.config(config, scale=args.extra_scale, generator=args.generator if config <= 4 else "numpy")
     node = szs.Node(devices)
     engine = node.engine_for(load)
     out = torch.empty((len(load.queries), len(load.candidates)), dtype=torch.int64, device=torch.device("cuda", devices[0]))
@@ -388,7 +391,7 @@ def main():
     where = torch.device("cuda", local_rank)
 
     # ---- the batch: rank r owns query rows [1024 r, 1024 (r + 1)); candidates are shared by all ranks
-    load = workloads.config(args.config)
+    load = workloads.config(args.config, generator=args.generator if args.config <= 4 else "numpy")
     if rank:
         rng = np.random.default_rng(args.config + 1000 * rank)
         low, high = int(load.queries.lengths().min()), int(load.queries.lengths().max())
@@ -538,7 +541,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": load.name, "pairs_per_gpu": rows * columns, "cells_per_gpu": int(profile.cells),
                        "sharding": "query row blocks, candidates replicated" if world > 1 else "single GPU",
-                       "entry_point": ENTRY_POINTS[load.kind]},
+                       "entry_point": ENTRY_POINTS[load.kind], "generator": args.generator},
             "roofline": line_roofline,
             "host_overhead_ms_per_step": round(ms_per_step - kernel * 1e3, 4),
             "planner": {0: "host", 1: "device", 2: "device, launches speculated on the previous call's shape",

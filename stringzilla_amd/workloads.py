@@ -54,6 +54,24 @@ def zipf_utf8_tape(rng: np.random.Generator, count: int, low: int = 8, high: int
     return Strs(strings)
 
 
+def mt19937_64_tape(seed: int, count: int, low: int, high: int, alphabet: np.ndarray) -> Strs:
+    """The same kind of tape from `std::mt19937_64` (tests/native/workloads_mt19937.cpp spells the mapping out), for callers
+    that want to reproduce a batch from C++: SURVEY.md section 8(d) names that generator."""
+    import ctypes
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "native", "bin", "libworkloads_mt19937.so")
+    fill = ctypes.CDLL(path).szs_workload_mt19937_64
+    fill.restype = ctypes.c_uint64
+    fill.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+    alphabet = np.ascontiguousarray(alphabet, dtype=np.uint8)
+    offsets = np.zeros(count + 1, dtype=np.uint32)
+    total = fill(seed, count, low, high, alphabet.ctypes.data, len(alphabet), offsets.ctypes.data, None)
+    data = np.empty(int(total), dtype=np.uint8)
+    fill(seed, count, low, high, alphabet.ctypes.data, len(alphabet), offsets.ctypes.data, data.ctypes.data)
+    return Strs.from_tape(data, offsets)
+
+
 @dataclass
 class Workload:
     name: str
@@ -72,11 +90,21 @@ class Workload:
         return int(self.queries.lengths().sum()) * int(self.candidates.lengths().sum())
 
 
-def config(index: int, scale: float = 1.0) -> Workload:
+def config(index: int, scale: float = 1.0, generator: str = "numpy") -> Workload:
     """The five BASELINE.json configs as concrete, seeded batches.  `scale` < 1 shrinks
-    the matrix side for parity tests that must finish in seconds on the CPU oracle."""
+    the matrix side for parity tests that must finish in seconds on the CPU oracle.  `generator`: "numpy" (the committed
+    profiles and checksums) or "mt19937_64" (configs 1-4: the same shapes from `std::mt19937_64`, reproducible from C++)."""
     rng = np.random.default_rng(index)
     side = lambda n: max(1, int(round(n * scale)))
+    if generator == "mt19937_64" and 1 <= index <= 4:
+        shape = {1: (100, 48, 80, ASCII_PRINTABLE), 2: (1024, 96, 160, ASCII_PRINTABLE), 3: (1024, 384, 640, AMINO_ACIDS),
+                 4: (512, 3072, 5120, NUCLEOTIDES)}[index]
+        template = config(index, 0.01)  # names, kinds and costs of the numpy variant
+        return Workload(template.name + " [std::mt19937_64]", template.kind,
+                        mt19937_64_tape(1000 * index + 0, side(shape[0]), shape[1], shape[2], shape[3]),
+                        mt19937_64_tape(1000 * index + 1, side(shape[0]), shape[1], shape[2], shape[3]), template.costs, template.table)
+    if generator != "numpy":
+        raise ValueError(f"generator {generator!r} has no config {index}")
     if index == 1:
         return Workload("cfg1: 100x100 ASCII len U[48,80], Levenshtein unit", "levenshtein",
                         random_tape(rng, side(100), 48, 80, ASCII_PRINTABLE),

@@ -290,3 +290,27 @@ def test_tier_model_knows_the_lanes_per_pair_split():
         return tier.value
     assert tier_of(128, 1000) == 0
     assert tier_of(16, 4096) == 2
+
+
+def test_mt19937_64_workloads_are_reproducible_and_in_shape():
+    """SURVEY.md section 8(d) names std::mt19937_64: `workloads.config(n, generator="mt19937_64")` builds configs 1-4 from it
+    (tests/native/workloads_mt19937.cpp spells out the mapping).  Same seed, same bytes; lengths and alphabets as specified;
+    the first engine outputs are the standard's (mt19937_64's 10000th output is pinned by [rand.predef])."""
+    import os
+
+    library = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "native", "bin", "libworkloads_mt19937.so")
+    if not os.path.exists(library):
+        pytest.skip("tests/native/bin/libworkloads_mt19937.so is not built")
+    for index, (count, low, high, alphabet) in {1: (100, 48, 80, workloads.ASCII_PRINTABLE), 3: (1024, 384, 640, workloads.AMINO_ACIDS)}.items():
+        once, again = workloads.config(index, generator="mt19937_64"), workloads.config(index, generator="mt19937_64")
+        assert len(once.queries) == len(once.candidates) == count
+        assert np.array_equal(once.queries.data, again.queries.data) and np.array_equal(once.candidates.offsets, again.candidates.offsets)
+        assert not np.array_equal(once.queries.data[:64], once.candidates.data[:64])  # the two sides have their own seeds
+        lengths = once.queries.lengths()
+        assert lengths.min() >= low and lengths.max() <= high and set(np.unique(once.queries.data)) <= set(alphabet.tolist())
+    # the length rule against the standard's own known answer: mt19937_64 seeded with 5489 first yields 14514284786278117030
+    fill = ctypes.CDLL(library).szs_workload_mt19937_64
+    fill.restype = ctypes.c_uint64
+    fill.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+    offsets = np.zeros(2, dtype=np.uint32)
+    assert fill(5489, 1, 7, 7 + (1 << 20) - 1, None, 1, offsets.ctypes.data, None) == 7 + 14514284786278117030 % (1 << 20) == int(offsets[1])
