@@ -764,6 +764,8 @@ static void stamp_refs(szs_decision_t *remembered, void const *const data[2], vo
                        szs_plan_summary_t const *summary) {
     for (int s = 0; s < 2; ++s) remembered->key_data[s] = data[s], remembered->key_offsets[s] = offsets[s], remembered->key_wide[s] = wide[s];
     remembered->summary = *summary;
+    /* the shape was remembered from an earlier batch; the CELLS are this batch's (a re-used plan reports them in its profile) */
+    remembered->plan.cells = remembered->symmetric ? summary->symmetric_cells : summary->side[0].symbols * summary->side[1].symbols;
     remembered->refs_current = 1;
 }
 

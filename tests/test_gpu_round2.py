@@ -543,3 +543,22 @@ def test_merged_candidate_blocks_agree_with_the_oracle(gpu, oracle, merge):
         for alphabet in ("0", "1"):
             with knob("alphabet", alphabet):
                 assert np.array_equal(utf8(accented, accented_candidates, device=gpu), oracle.levenshtein_utf8(accented, accented_candidates))
+
+
+def test_profile_cells_belong_to_the_batch_that_was_scored(gpu):
+    """Two batches of one shape alternate (every call speculated on the other's plan), then one of them repeats (its plan
+    re-used): `cells` in the call profile - what bench.py turns into GCUPS - is always the current batch's, never the one the
+    remembered decision was first made for."""
+    rng = np.random.default_rng(77)
+    first = workloads.random_tape(rng, 64, 96, 160, workloads.ASCII_PRINTABLE).to_device(0), workloads.random_tape(rng, 300, 96, 160, workloads.ASCII_PRINTABLE).to_device(0)
+    second = workloads.random_tape(rng, 64, 96, 160, workloads.ASCII_PRINTABLE).to_device(0), workloads.random_tape(rng, 300, 96, 160, workloads.ASCII_PRINTABLE).to_device(0)
+    cells = lambda pair: int(pair[0].lengths().sum()) * int(pair[1].lengths().sum())
+    assert cells(first) != cells(second)
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+    seen = []
+    for pair in (first, second, first, second, second, second, first, first):
+        engine(pair[0], pair[1], device=gpu)
+        profile = engine.last_call_profile()
+        seen.append(int(profile.planner))
+        assert int(profile.cells) == cells(pair), (seen, int(profile.cells), cells(first), cells(second))
+    assert 2 in seen and 3 in seen  # both the speculated and the re-used path were taken
