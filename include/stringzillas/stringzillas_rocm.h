@@ -31,7 +31,9 @@ typedef struct szs_rocm_call_profile_t {
     sz_u32_t tier;                /* 0: one pair per lane (lev_myers.hip, weighted*.hip); 1: systolic.hip; 2: myers_chain.hip */
     sz_u32_t transposed;          /* 1: the planner swapped the sides (candidates on workgroups, queries on lanes) */
     sz_u32_t cell_bits;           /* width of the DP cells of the last launch: 16 (weighted_packed.hip), 32, 64 (wide.hip), or 0 (bit-parallel) */
-    sz_u32_t planner;             /* 0: planned on the host; 1: on the device (hip/planner.hip); 2: on the device, launches speculated */
+    sz_u32_t planner;             /* 0: planned on the host; 1: on the device (hip/planner.hip); 2: on the device, launches speculated;
+                                     3: the plan of the previous call of the same tapes, re-used behind a guard */
+    sz_u32_t team;                /* 0, or lanes * 10000 + registers * 100 + wavefronts per SIMD of the team tier (weighted_teams.hip) */
 } szs_rocm_call_profile_t;
 
 /** Copies the profile of the most recent call made through `engine` (any of the four engine handle types). */
@@ -138,6 +140,7 @@ SZ_API_RUNTIME sz_status_t szs_rocm_node_scores_u64tape(szs_rocm_node_engine_t e
  *  "planner" (host | device), "speculate" (0), "streams" (0: one stream), "reuse" (0: never re-use a plan),
  *  "split" (0 | 2 | 4: lanes per pair of the long bit-parallel widths), "alphabet" (0 | 1: never / always renumber the runes
  *  of a codepoint batch on the device), "merge" (n: candidate blocks per workgroup of the short bit-parallel kernels),
+ *  "team" (0: never | lanes * 10000 + registers * 100 + waves: that shape of the team tier of the 16-bit weighted scorers),
  *  "cpu_requests" (strict | gpu: serve capability
  *  masks without the GPU bit and CPU device scopes with the GPU engines on device 0 instead of refusing them) - or its
  *  environment spelling ("SZS_ROCM_TIER" ...); `value` NULL, "" or "auto" restores the automatic choice.  No knob changes a
@@ -147,6 +150,9 @@ SZ_API_RUNTIME sz_status_t szs_rocm_node_scores_u64tape(szs_rocm_node_engine_t e
  *  initialises, and the per-width launches of a mixed-length batch run on up to eight streams.
  */
 SZ_API_RUNTIME sz_status_t szs_rocm_tuning_set(char const *knob, char const *value);
+
+/** The `team` shapes this build holds (lanes * 10000 + registers * 100 + wavefronts per SIMD), 0 past the last one. */
+SZ_API_RUNTIME sz_u32_t szs_rocm_team_shape(sz_size_t index);
 
 #ifdef __cplusplus
 }

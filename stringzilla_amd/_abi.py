@@ -54,7 +54,7 @@ class CallProfile(ctypes.Structure):
         ("cells", ctypes.c_uint64), ("pairs", ctypes.c_uint64), ("algorithmic_bytes", ctypes.c_uint64),
         ("unique_bytes", ctypes.c_uint64), ("launches", ctypes.c_uint32), ("longest_query", ctypes.c_uint32),
         ("longest_candidate", ctypes.c_uint32), ("tier", ctypes.c_uint32), ("transposed", ctypes.c_uint32), ("cell_bits", ctypes.c_uint32),
-        ("planner", ctypes.c_uint32),
+        ("planner", ctypes.c_uint32), ("team", ctypes.c_uint32),
     ]
 
 
@@ -112,6 +112,7 @@ SIGNATURES = {
     "szs_rocm_plan_probe": (c_int, [c_int, c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "szs_rocm_orientation_probe": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p]),
     "szs_rocm_tuning_set": (c_int, [c_char_p, c_char_p]),
+    "szs_rocm_team_shape": (ctypes.c_uint32, [c_size_t]),
     "szs_rocm_node_init": (c_int, [c_void_p, c_size_t, ENGINE_OUT, ERR]),
     "szs_rocm_node_size": (c_size_t, [c_void_p]), "szs_rocm_node_free": (None, [c_void_p]),
     "szs_rocm_node_levenshtein_distances_init": (c_int, [c_void_p, c_int8, c_int8, c_int8, c_int8, ENGINE_OUT, ERR]),
@@ -158,7 +159,8 @@ _KNOBS = {"tier": "SZS_ROCM_TIER", "swap": "SZS_ROCM_SWAP", "packed": "SZS_ROCM_
           "chain_waves": "SZS_ROCM_CHAIN_WAVES", "trace": "SZS_ROCM_TRACE", "cells": "SZS_ROCM_CELLS",
           "planner": "SZS_ROCM_PLANNER", "speculate": "SZS_ROCM_SPECULATE", "cpu_requests": "SZS_ROCM_CPU_REQUESTS",
           "streams": "SZS_ROCM_STREAMS", "reuse": "SZS_ROCM_REUSE",
-          "split": "SZS_ROCM_SPLIT", "alphabet": "SZS_ROCM_ALPHABET", "merge": "SZS_ROCM_MERGE"}
+          "split": "SZS_ROCM_SPLIT", "alphabet": "SZS_ROCM_ALPHABET", "merge": "SZS_ROCM_MERGE",
+          "team": "SZS_ROCM_TEAM"}
 _knob_values = {name: os.environ.get(variable) for name, variable in _KNOBS.items()}  # what the library read when it was loaded
 
 
@@ -171,6 +173,15 @@ def tuning_set(knob: str, value=None):
         raise ValueError(f"unknown tuning knob {knob!r}")
     previous, _knob_values[name] = _knob_values[name], None if value is None else str(value)
     return previous
+
+
+def team_shapes():
+    """The compiled instances of the team tier: values for the `team` knob (lanes * 10000 + registers * 100 + waves)."""
+    shapes, index = [], 0
+    while lib.szs_rocm_team_shape(index):
+        shapes.append(int(lib.szs_rocm_team_shape(index)))
+        index += 1
+    return shapes
 
 
 def check(status: int, error: c_char_p) -> None:

@@ -153,6 +153,7 @@ enum {
     szs_knob_split_k,       /* -1 automatic | 0 / 2 / 4: lanes per pair of the long byte kernels (24 ... 64 words) */
     szs_knob_alphabet_k,    /* -1 automatic | 0 never | 1 always: renumber a codepoint batch's runes (hip/utf8.hip) */
     szs_knob_merge_k,       /* -1 automatic | n: candidate blocks per workgroup of the short bit-parallel kernels (1: never merge) */
+    szs_knob_team_k,        /* -1 automatic | 0: never the team tier of the 16-bit weighted scorers | lanes * 10000 + registers * 100 + waves: that shape */
     szs_knob_count_k
 };
 int szs_tuning_get(int knob);
@@ -272,6 +273,23 @@ int szs_hip_weighted_packed_scores(int local, int affine, uint32_t classes, szs_
                                    uint64_t results_row_stride, int symmetric, void *boundary, void *stream);
 size_t szs_hip_weighted_packed_boundary_bytes(int local, int affine, uint32_t classes, uint32_t queries_count,
                                               uint32_t candidates_count, uint32_t longest_candidate);
+
+/**
+ *  The TEAM tier of the same 16-bit scorers (hip/weighted_teams.hip): a (pair of queries, candidate) item is scored by a team
+ *  of `lanes` adjacent lanes, each `registers` query rows deep, strips handed from lane to lane in registers and only the
+ *  bottom row of a whole group of lanes x registers rows parked; two queries share every register (low / high half).
+ *  Same eligibility, cost model, refs (queries longest first, candidates ascending) and result addressing as
+ *  szs_hip_weighted_packed_scores; local scores may reach 60000.  `shape` = lanes * 10000 + registers * 100 + wavefronts per
+ *  SIMD names one of the compiled instances: szs_hip_weighted_team_shape(i) enumerates them (0 past the last one).
+ */
+unsigned szs_hip_weighted_team_shape(unsigned index);
+int szs_hip_weighted_team_has_shape(unsigned shape);
+int szs_hip_weighted_team_scores(int local, int affine, unsigned shape, uint32_t classes, szs_cost_model_t const *model,
+                                 szs_string_ref_t const *queries, uint32_t queries_count, szs_string_ref_t const *candidates,
+                                 uint32_t candidates_count, uint32_t longest_candidate, int64_t *results,
+                                 uint64_t results_row_stride, int symmetric, void *workspace, void *stream);
+size_t szs_hip_weighted_team_workspace_bytes(int local, int affine, unsigned shape, uint32_t classes, uint32_t queries_count,
+                                             uint32_t candidates_count, uint32_t longest_candidate);
 
 /**
  *  The 64-bit cell tier (hip/wide.hip): every objective above on an anti-diagonal walker with int64 cells, one pair per

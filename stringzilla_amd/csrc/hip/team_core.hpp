@@ -1,0 +1,241 @@
+/*
+ *  team_core.hpp - the arithmetic of the TEAM tier of the weighted scorers (hip/weighted_teams.hip), kept apart from the
+ *  kernel so that the very same code is compiled twice: by hipcc into the gfx950 kernel, and by g++ into
+ *  tests/native/team_model.cpp, a lane-by-lane model of the kernel's data flow that is checked against the oracle on the
+ *  CPU (no GPU needed to find an off-by-one in a border, a carry between the halves of a register or a skewed hand-over).
+ *
+ *  The recurrences are the reference's tile_scorer ones (/root/reference/include/stringzillas/similarities/serial.hpp:
+ *  778-876 global linear, 890-988 local linear, 1002-1137 global affine, 1151-1278 local affine) and must give the same
+ *  scores bit for bit.  What is specific to this tier:
+ *
+ *  TWO QUERIES PER REGISTER.  A 32-bit register holds the same DP row index of TWO queries - the low half belongs to query
+ *  2p, the high half to query 2p + 1 of the (longest first) query list - scored against the SAME candidate symbol.  Both
+ *  halves are therefore always at the same column and need the same cost row: one LDS read of a profile keyed by ONE class
+ *  delivers the pair (weighted_packed.hip pairs two columns of one query instead and needs a profile keyed by a PAIR of
+ *  classes: 40 KB per strip for BLOSUM62 where this one takes 3 KB - which is what makes room for sixteen strips at once).
+ *
+ *  BIASED UNSIGNED CELLS, FULL-RATE ADDITIONS.  A cell is stored as `true value + bias` in an unsigned 16-bit half.  With
+ *  every half provably inside [0, 65535] before and after an addition, ONE 32-bit `v_add_u32` adds a (signed) increment to
+ *  both halves at once: the increment pair is stored as `(high << 16) + sign_extended(low)`, i.e. the borrow that a negative
+ *  low increment takes from the high half is paid back in advance.  gfx950 issues v_add_u32 at twice the rate of v_pk_add_i16
+ *  (scripts/valu_peak.hip: 60-70 vs 36-38 T lane-operations/s), so the additions of the recurrence - half of its operations -
+ *  cost half of what they cost weighted_packed.hip; only the maxima (v_pk_max_u16) stay in the slow class.
+ *      global (Needleman-Wunsch): bias 32768; the reach rule (serial.hpp:135-162) < 32000 bounds every H and track value.
+ *      local  (Smith-Waterman, gap costs <= 0): bias 1024; H >= 0 and the gap tracks >= open, so nothing sinks below the
+ *              bias by more than 256; scores stay below 62000.
+ *  A low half can only leave its range in rows BELOW the last row of the longer query (padded rows, global borders running
+ *  on); what it then carries into the high half lands in a row that is padded for the shorter query too.  Carries never run
+ *  downwards (high to low), and v_pk_max_u16 treats the halves separately.
+ *
+ *  TWO TRACKS INSTEAD OF THREE.  weighted_packed.hip keeps H, H + open and E + extend per row; here a row keeps H and
+ *  `e` = the horizontal-gap value ENTERING the next column, max(H + open, E + extend), which is formed from values the step
+ *  has at hand anyway (`H + open` also feeds the vertical track): the same number of operations, a third fewer registers.
+ *  Linear gaps keep ONE track, `g = H + gap`; the `- gap` that the diagonal needs is folded into the cost profile.
+ */
+#ifndef SZS_TEAM_CORE_HPP_
+#define SZS_TEAM_CORE_HPP_
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define SZS_HD __host__ __device__ __forceinline__
+#else
+#define SZS_HD inline
+#endif
+
+namespace szs_team {
+
+using u32 = uint32_t;
+using i32 = int32_t;
+
+/** An INCREMENT (or a value) for both halves of a register: adding it with one 32-bit addition adds `low` to the low half
+ *  and `high` to the high half, as long as the low half stays inside [0, 65535]. */
+SZS_HD u32 pair_of(i32 low, i32 high) { return ((u32)high << 16) + (u32)low; }
+SZS_HD u32 both(i32 value) { return pair_of(value, value); }
+SZS_HD i32 low_of(u32 pair) { return (i32)(pair & 0xFFFFu); }
+SZS_HD i32 high_of(u32 pair) { return (i32)(pair >> 16); }
+
+/** Per-half unsigned maximum: v_pk_max_u16. */
+SZS_HD u32 pair_max(u32 a, u32 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned short pk_u16 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(pk_u16, a), __builtin_bit_cast(pk_u16, b)));
+#else
+    u32 const low = (a & 0xFFFFu) > (b & 0xFFFFu) ? (a & 0xFFFFu) : (b & 0xFFFFu);
+    u32 const high = (a >> 16) > (b >> 16) ? (a >> 16) : (b >> 16);
+    return (high << 16) | low;
+#endif
+}
+
+template <bool local_>
+struct bias_of {
+    static constexpr i32 value = local_ ? 1024 : 32768;
+};
+
+/** The scoring constants of one launch in the representation above. */
+template <bool local_, bool affine_>
+struct team_costs_t {
+    i32 open, extend; // signed, ADDED; linear gaps: open == extend == the gap cost
+    u32 open_pair, extend_pair, zero_pair;
+
+    SZS_HD team_costs_t(i32 gap_open, i32 gap_extend)
+        : open(gap_open), extend(affine_ ? gap_extend : gap_open), open_pair(both(gap_open)),
+          extend_pair(both(affine_ ? gap_extend : gap_open)), zero_pair(both(bias_of<local_>::value)) {}
+
+    /** H(k, 0) = H(0, k): the all-gap border (serial.hpp:821-823,1045-1047); local: 0. */
+    SZS_HD i32 border(u32 k) const {
+        if (local_) return 0;
+        if (affine_) return k ? open + extend * (i32)(k - 1) : 0;
+        return open * (i32)k;
+    }
+    /** The gap track ENTERING the first real column / row next to a border cell of value `edge`: the reference seeds the
+     *  track with the finite "discard" value edge + open + extend (serial.hpp:1049-1056, local: 1195-1201) and the first
+     *  step forms max(edge + open, seed + extend). */
+    SZS_HD i32 entering(i32 edge) const {
+        i32 const fresh = edge + open, carried = edge + open + 2 * extend;
+        return fresh > carried ? fresh : carried;
+    }
+    SZS_HD u32 stored(i32 truth) const { return (u32)(truth + bias_of<local_>::value) & 0xFFFFu; }
+    SZS_HD i32 truth(u32 half) const { return (i32)half - bias_of<local_>::value; }
+};
+
+/** One profile entry: the costs of one candidate class against the same row of the two queries (0 for a padded row).
+ *  Linear gaps: the diagonal is kept as H + gap, so the entry carries `cost - gap`. */
+template <bool local_, bool affine_>
+SZS_HD u32 profile_entry(team_costs_t<local_, affine_> const &k, i32 cost_low, i32 cost_high) {
+    return affine_ ? pair_of(cost_low, cost_high) : pair_of(cost_low - k.open, cost_high - k.open);
+}
+
+/**
+ *  The rows of one strip at one column, per lane.
+ *  affine: h[r] = H(row r, column), e[r] = max(H + open, E + extend) = the horizontal-gap track entering the NEXT column.
+ *  linear: h[r] = H(row r, column) + gap; `e` is unused.
+ */
+template <bool affine_, int R>
+struct team_rows_t {
+    u32 h[R];
+    u32 e[affine_ ? R : 1];
+};
+
+/** What travels from a strip to the strip below it, per column: H of the bottom row (linear: + gap) and, affine, the
+ *  vertical-gap track entering the row below. */
+struct team_edge_t {
+    u32 h, f;
+};
+
+/** Column 0 of the strip whose first DP row (1-based) is `first_row + 1`, for a pair of queries alike. */
+template <bool local_, bool affine_, int R>
+SZS_HD void team_seed(team_costs_t<local_, affine_> const &k, u32 first_row, team_rows_t<affine_, R> &rows, u32 &diagonal) {
+    for (int r = 0; r < R; ++r) {
+        i32 const edge = k.border(first_row + (u32)r + 1);
+        if (affine_) rows.h[r] = both(k.stored(edge)), rows.e[affine_ ? r : 0] = both(k.stored(k.entering(edge)));
+        else rows.h[r] = both(k.stored(edge + k.open));
+    }
+    diagonal = both(k.stored(k.border(first_row) + (affine_ ? 0 : k.open)));
+}
+
+/** What the strip below DP row 0 - the border row - hands down at column `j` (1-based): prefilled into the parked rows. */
+template <bool local_, bool affine_>
+SZS_HD team_edge_t team_border_edge(team_costs_t<local_, affine_> const &k, u32 j) {
+    i32 const edge = k.border(j);
+    team_edge_t out;
+    out.h = both(k.stored(edge + (affine_ ? 0 : k.open)));
+    out.f = affine_ ? both(k.stored(k.entering(edge))) : 0u;
+    return out;
+}
+
+/** Pins a value: no instruction, but the compiler may neither re-associate a maximum through it nor sink its operands.
+ *  max(max(e, substituted), zero) must be formed OFF the row-to-row chain; left alone, hipcc folds the clamp behind the
+ *  maximum with the vertical track and the chain grows by one slow operation and a wait state per row. */
+SZS_HD void settle(u32 &value) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(value));
+#else
+    (void)value;
+#endif
+}
+
+/**
+ *  One step of one lane: the R rows of its strip advance by one column - begin(), rows in order, end().
+ *  `above`: what the strip above handed down at this column; `diagonal`: its `h` of the previous column (replaced).
+ *  `costs`: the profile entries of this column's class for the rows at hand.  `best`: four running maxima of H (local only).
+ *
+ *  Operation count per register = per TWO cells (fast = v_add_u32, slow = v_pk_max_u16):
+ *      global linear 2 fast + 2 slow, local linear 2 + 4, global affine 4 + 4, local affine 4 + 6.
+ *  The maxima are associated so that the chain from one row to the next is one maximum and one addition (linear) or two
+ *  maxima and one addition (affine); everything else hangs off it.
+ */
+template <bool local_, bool affine_, int R>
+struct team_step_t {
+    u32 diag, up; // H of the row above at the previous column; affine: F entering the row, linear: H + gap of the row above
+
+    SZS_HD void begin(team_edge_t const &above, u32 &diagonal) {
+        diag = diagonal, diagonal = above.h;
+        up = affine_ ? above.f : above.h;
+    }
+    /** Row `r`: serial.hpp:1091-1102, 1238-1239 (affine), 846-848, 957-965 (linear). */
+    SZS_HD void row(team_costs_t<local_, affine_> const &k, team_rows_t<affine_, R> &rows, int r, u32 cost, u32 (&best)[4]) {
+        u32 const substituted = diag + cost; // linear: (H(row - 1, column - 1) + gap) + (cost - gap)
+        diag = rows.h[r];
+        u32 inner = pair_max(affine_ ? rows.e[affine_ ? r : 0] : rows.h[r], substituted); // the horizontal branch: E, or left + gap
+        if (local_) inner = pair_max(inner, k.zero_pair); // only the substitution branch needs it; the tracks lose anyway
+        settle(inner);
+        u32 const cell = pair_max(inner, up);
+        if (local_) best[r % 4] = pair_max(best[r % 4], cell);
+        u32 const opened = cell + k.open_pair;
+        if (affine_) {
+            rows.h[r] = cell;
+            rows.e[affine_ ? r : 0] = pair_max(opened, rows.e[affine_ ? r : 0] + k.extend_pair);
+            up = pair_max(opened, up + k.extend_pair);
+        }
+        else rows.h[r] = up = opened;
+    }
+    SZS_HD team_edge_t end(team_rows_t<affine_, R> const &rows) const {
+        team_edge_t below;
+        below.h = rows.h[R - 1], below.f = affine_ ? up : 0u;
+        return below;
+    }
+};
+
+template <bool local_, bool affine_, int R>
+SZS_HD team_edge_t team_advance(team_costs_t<local_, affine_> const &k, team_rows_t<affine_, R> &rows, u32 const *costs,
+                                team_edge_t above, u32 &diagonal, u32 (&best)[4]) {
+    team_step_t<local_, affine_, R> step;
+    step.begin(above, diagonal);
+    for (int r = 0; r < R; ++r) step.row(k, rows, r, costs[r], best);
+    return step.end(rows);
+}
+
+/** Passes over the candidate that a pair of queries needs: the LONGER one decides. */
+template <int L, int R>
+SZS_HD u32 team_passes(u32 longer_query) { return (longer_query + (u32)L * R - 1) / ((u32)L * R); }
+
+/** Where the last DP row of a query of `length` > 0 lives: pass, lane of the team, register. */
+template <int L, int R>
+SZS_HD void team_last_row(u32 length, u32 &pass, u32 &lane, u32 &reg) {
+    u32 const row = length - 1;
+    pass = row / ((u32)L * R), lane = row % ((u32)L * R) / (u32)R, reg = row % (u32)R;
+}
+
+/* ---- the cost profile in LDS ------------------------------------------------------------------------------------------
+ *  One row of R entries (R x 4 bytes) per (strip, class); a lane reads its row with R / 4 `ds_read_b128` at immediate offsets.
+ *  `ds_read_b128` serves a wavefront in four groups of 16 lanes and a group is conflict-free when its lanes' 16-byte
+ *  addresses differ modulo 256.  The lanes of a team read DIFFERENT strips and (mostly) different classes, so the layout
+ *  makes (address / 16) mod 16 a function of the strip alone: the strips are dealt over `blocks` regions whose sizes are
+ *  16 modulo 256, and inside a region the rows of `slots` strips of one class share a block of slots x R x 4 = up to 256
+ *  bytes.  With sixteen strips (L = 16) every lane group holds each strip exactly once: no conflicts whatever the classes. */
+template <int L, int R>
+struct team_profile_layout {
+    static constexpr u32 row_bytes = (u32)R * 4;
+    static constexpr u32 slots = row_bytes >= 256 ? 1 : (256 / row_bytes < (u32)L ? 256 / row_bytes : (u32)L); // strips per class block
+    static constexpr u32 blocks = (u32)L / slots;
+    static constexpr u32 class_bytes = slots > 1 ? 256 : row_bytes; // slots x row_bytes, rounded up to the 256 the argument needs
+    SZS_HD static u32 region_bytes(u32 classes) { return classes * class_bytes + 16; }
+    SZS_HD static u32 total_bytes(u32 classes) { return blocks * region_bytes(classes); }
+    /** Byte offset of the row of strip `k`, class 0; the row of class c lies c x class_bytes further. */
+    SZS_HD static u32 strip_base(u32 k, u32 classes) { return (k % blocks) * region_bytes(classes) + (k / blocks) * row_bytes; }
+};
+
+} // namespace szs_team
+
+#endif /* SZS_TEAM_CORE_HPP_ */

@@ -1,0 +1,436 @@
+/*
+ *  weighted_teams.hip - Needleman-Wunsch and Smith-Waterman scores over a class table (BLOSUM62, NUC.4.4, custom 32 x 32)
+ *  with 16-bit cells: the TEAM tier.  A (pair of queries, candidate) item is scored by a team of L adjacent lanes.
+ *
+ *  Replaces, for the ROCm build, the reference's intra-pair tiers - one warp per pair on an anti-diagonal in shared memory
+ *      score_per_cuda_warp_ / affine_score_per_cuda_warp_   /root/reference/include/stringzillas/similarities/cuda.cuh:1246-1500
+ *  - and must return exactly what the reference's serial scorers return
+ *      needleman_wunsch_score / smith_waterman_score        .../similarities/serial.hpp:2910-3124 (tile_scorer :778-1278).
+ *
+ *  Why (profiles/r02/pmc_configs.json, config 4 = 512 x 512 DNA reads of ~4 KB, Smith-Waterman, affine gaps): the lanes
+ *  tier (weighted_packed.hip, one pair per lane) parks the bottom row of every 32-row strip in HBM and reads it back - 857 GB
+ *  per call for 2.2 GB of strings and results - spends 5.2 VALU lane-operations per cell where the recurrence has 4.5, and
+ *  ONE lane walks a 5120 x 5120 pair alone for 320 ms: the floor of any share of the batch, however many GPUs split it.
+ *
+ *  The shape of this tier (none of it is the reference's anti-diagonal, which moves every cell through shared memory):
+ *
+ *  - TEAM = L lanes of one DPP row (L = 16: the whole row).  Lane k owns strip k of a group of L strips of R query rows;
+ *    it runs ONE COLUMN BEHIND lane k - 1, so what lane k - 1 produced for its bottom row in the previous step is exactly
+ *    what lane k needs as its row above in this one: H, the vertical-gap track and the column's class travel from lane to
+ *    lane in registers (`v_mov_b32_dpp row_shr:1`), never through memory.  Only the bottom row of the whole GROUP (L x R =
+ *    512 rows) is parked for the next pass over the candidate: 1 / 16 of the lanes tier's traffic per cell, and the longest
+ *    pair of a launch takes 1 / 16 of the time.
+ *  - TWO QUERIES PER REGISTER (team_core.hpp): the halves of a register are the same row of two queries against the same
+ *    candidate symbol, so a step's costs come from a profile keyed by ONE class - 128 bytes per class and strip - and the
+ *    sixteen strips of a group fit LDS together (NUC.4.4: 34 KB, BLOSUM62: 51 KB per workgroup).
+ *  - BIASED UNSIGNED CELLS (team_core.hpp): the additions of the recurrence are full-rate 32-bit `v_add_u32` on both
+ *    halves at once; only the maxima are `v_pk_max_u16`.
+ *  - UNPREDICATED MAIN LOOP: the skew means a team's lanes start and end at different steps.  The first L - 1 steps (fill)
+ *    and the steps after the wavefront's shortest candidate ended (drain, ragged lengths) predicate every lane on its own
+ *    column; everything between runs four columns per batch without a single length check, with the head lane's inputs
+ *    (parked row, text dword, classes) fetched one batch ahead.  The first attempt at splitting pairs over lanes predicated
+ *    every column and lost.
+ *
+ *  One workgroup = 256 threads = 256 / L teams = one pair of queries x 256 / L candidates; persistent grid, work items
+ *  (pair of queries, candidate block) drawn heaviest first from one counter.
+ */
+#include "device_common.hpp"
+#include "team_core.hpp"
+
+#include <type_traits>
+
+namespace szs_hip {
+
+using namespace szs_team;
+
+constexpr u32 team_block_threads_k = 256;
+constexpr u32 team_slack_columns_k = 8;      // columns the parked-row prefetch may run past the longest candidate
+constexpr size_t team_header_bytes_k = 256;  // the work counter lives at the head of the workspace
+
+/** What lane k - 1 of the team holds in `value`; the head lane (k = 0) gets `head_value` instead. */
+template <int L>
+__device__ __forceinline__ u32 from_left(u32 head_value, u32 value, bool is_head) {
+    if constexpr (L == 1) return head_value;
+    else {
+        // row_shr:1 - lane 0 of a 16-lane row has no source and keeps `old` = the head's own input
+        u32 const moved = (u32)__builtin_amdgcn_update_dpp((int)head_value, (int)value, 0x111, 0xF, 0xF, false);
+        if constexpr (L == 16) return moved;
+        else return is_head ? head_value : moved;
+    }
+}
+
+template <bool affine_>
+struct parked_edge_t;
+template <>
+struct parked_edge_t<true> {
+    u32 h, f;
+};
+template <>
+struct parked_edge_t<false> {
+    u32 h;
+};
+
+template <bool affine_>
+__device__ __forceinline__ team_edge_t unpark(parked_edge_t<affine_> const &slot) {
+    team_edge_t edge;
+    edge.h = slot.h;
+    if constexpr (affine_) edge.f = slot.f;
+    else edge.f = 0;
+    return edge;
+}
+template <bool affine_>
+__device__ __forceinline__ parked_edge_t<affine_> park_of(team_edge_t const &edge) {
+    parked_edge_t<affine_> slot;
+    slot.h = edge.h;
+    if constexpr (affine_) slot.f = edge.f;
+    return slot;
+}
+
+/**
+ *  @tparam local_   Smith-Waterman with gap costs <= 0 instead of Needleman-Wunsch.
+ *  @tparam affine_  Gotoh's three-track recurrence instead of the single-track linear one.
+ *  @tparam L        lanes per team: 1, 2, 4, 8 or 16.
+ *  @tparam R        registers per track = query rows per lane and pass (a multiple of 4).
+ *  @tparam W        wavefronts per SIMD the registers are allocated for.
+ */
+template <bool local_, bool affine_, int L, int R, int W>
+__global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
+    szs_cost_model_t const *__restrict__ model, szs_string_ref_t const *__restrict__ queries, u32 queries_count,
+    szs_string_ref_t const *__restrict__ candidates, u32 candidates_count, u32 candidate_blocks, i64 *__restrict__ results,
+    u64 results_row_stride, int layout_flags, char *__restrict__ parked_rows, u32 parked_columns, u32 *__restrict__ work_counter,
+    u32 classes) {
+
+    using layout = team_profile_layout<L, R>;
+    using parked_t = parked_edge_t<affine_>;
+    constexpr u32 teams = team_block_threads_k / L; // candidates per workgroup
+    constexpr u32 group_rows = (u32)L * R;          // query rows per pass
+    static_assert(R % 4 == 0 && 16 % L == 0, "whole 16-byte profile chunks; teams inside a DPP row");
+
+    extern __shared__ __attribute__((aligned(16))) char profile[];
+    __shared__ unsigned short class_offset_of_byte[256]; // class x layout::class_bytes: the head lanes' text -> profile row
+    __shared__ u8 group_classes[2][group_rows];          // the classes of the group's rows, both queries; 0xFF: padded
+    __shared__ u32 claimed_work;
+
+    team_costs_t<local_, affine_> const k(model->gap_open, model->gap_extend);
+    int16_t const *const table = model->substitution; // [query class][candidate class], 2 KB, cache-resident
+    for (u32 byte = threadIdx.x; byte < 256; byte += team_block_threads_k)
+        class_offset_of_byte[byte] = (unsigned short)(model->byte_to_class[byte] * layout::class_bytes);
+
+    u32 const lane_in_team = threadIdx.x % L, team = threadIdx.x / L;
+    bool const is_head = lane_in_team == 0, is_tail = lane_in_team == L - 1;
+    u32 const strip_base = layout::strip_base(lane_in_team, classes);
+    // this workgroup's parked rows: [column][team]
+    parked_t *const parked = reinterpret_cast<parked_t *>(parked_rows) + (u64)blockIdx.x * parked_columns * teams + team;
+
+    bool const transposed = (layout_flags & SZS_LAYOUT_TRANSPOSED) != 0, symmetric = (layout_flags & SZS_LAYOUT_SYMMETRIC) != 0;
+    auto write_result = [&](szs_string_ref_t const &query, szs_string_ref_t const &candidate, i64 score) {
+        u64 const row = transposed ? candidate.index : query.index, column = transposed ? query.index : candidate.index;
+        results[row * results_row_stride + column] = score;
+        if (symmetric && candidate.index != query.index) results[column * results_row_stride + row] = score;
+    };
+
+    u32 const pairs = (queries_count + 1) / 2;
+    u32 const work_items = pairs * candidate_blocks;
+    for (;;) {
+        __syncthreads(); // the previous item's LDS (profile, claimed_work) is no longer in use
+        if (threadIdx.x == 0) claimed_work = atomicAdd(work_counter, 1u);
+        __syncthreads();
+        u32 const work = claimed_work;
+        if (work >= work_items) break;
+        // candidate-block-major, heaviest block first (lev_myers.hip: myers_work_item)
+        u32 const pair = work % pairs, block = candidate_blocks - 1 - work / pairs;
+        szs_string_ref_t const query_low = queries[2 * pair];
+        bool const has_high = 2 * pair + 1 < queries_count;
+        szs_string_ref_t query_high = {0, 0, 0};
+        if (has_high) query_high = queries[2 * pair + 1];
+        u32 const candidate_slot = block * teams + team;
+        bool const exists = candidate_slot < candidates_count;
+        szs_string_ref_t candidate = {0, 0, 0};
+        if (exists) candidate = candidates[candidate_slot];
+        bool const live_low = exists && !(symmetric && candidate.index > query_low.index);
+        bool const live_high = exists && has_high && !(symmetric && candidate.index > query_high.index);
+        bool const live = live_low || live_high;
+        u32 const text_length = live ? candidate.length : 0;
+        // wavefront-uniform by construction; said so, they (and the step counters compared with them) live in scalar registers
+        u32 const longest_in_wave = (u32)__builtin_amdgcn_readfirstlane((int)wave_max_u32(text_length));
+        u32 const shortest_in_wave = (u32)__builtin_amdgcn_readfirstlane((int)~wave_max_u32(live ? ~text_length : 0u)); // over live lanes
+        u32 const last_slot = (block + 1) * teams < candidates_count ? (block + 1) * teams - 1 : candidates_count - 1;
+        u32 const longest_in_block = candidates[last_slot].length; // candidates ascend
+        u64 const safe_address = text_length ? candidate.address : (u64)(uintptr_t)parked; // see weighted.hip
+        text_stream_t text(safe_address, text_length);
+        if (!text_length) text.valid_dwords = 1;
+        u32 const longer = query_low.length; // queries descend
+
+        // An empty side never enters the loop (serial.hpp:1366-1373, 1594-1605, 3077-3080).
+        if (is_head) {
+            if (live_low && !query_low.length) write_result(query_low, candidate, (i64)k.border(text_length));
+            if (live_high && !query_high.length) write_result(query_high, candidate, (i64)k.border(text_length));
+        }
+        if (!longer) continue;
+
+        // ---- what DP row 0 hands down, parked like any other group boundary (the passes below then are all alike)
+        for (u32 slot = threadIdx.x; slot < (longest_in_block + 1 + team_slack_columns_k) * teams; slot += team_block_threads_k)
+            (parked - team)[slot] = park_of<affine_>(team_border_edge(k, slot / teams));
+
+        u32 const passes = team_passes<L, R>(longer);
+        team_rows_t<affine_, R> rows;
+        u32 diagonal = 0, best[4] = {k.zero_pair, k.zero_pair, k.zero_pair, k.zero_pair};
+        team_edge_t out = {0, 0};
+        u32 out_row = 0;
+
+        for (u32 pass = 0; pass < passes; ++pass) {
+            u32 const first_row = pass * group_rows;
+            bool const park_this_pass = pass + 1 < passes;
+
+            // ---- the profile of the group's L strips: thread -> (strip, class, chunk of 4 registers)
+            __syncthreads(); // everyone is done with the previous pass's profile; the prefilled rows are written
+            for (u32 slot = threadIdx.x; slot < 2 * group_rows; slot += team_block_threads_k) {
+                szs_string_ref_t const &query = slot < group_rows ? query_low : query_high;
+                u32 const row = first_row + slot % group_rows;
+                group_classes[slot / group_rows][slot % group_rows] =
+                    row < query.length ? model->byte_to_class[reinterpret_cast<u8 const *>(query.address)[row]] : (u8)0xFF;
+            }
+            __syncthreads();
+            for (u32 slot = threadIdx.x; slot < (u32)L * classes * (R / 4); slot += team_block_threads_k) {
+                u32 const chunk = slot % (R / 4), symbol_class = slot / (R / 4) % classes, strip = slot / (R / 4) / classes;
+                u32 entries[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    u32 const low_class = group_classes[0][strip * R + 4 * chunk + r], high_class = group_classes[1][strip * R + 4 * chunk + r];
+                    // cost(query, candidate) = table[class(query)][class(candidate)]: the QUERY picks the row (serial.hpp:199-204)
+                    i32 const low = low_class != 0xFF ? table[low_class * 32 + symbol_class] : 0;
+                    i32 const high = high_class != 0xFF ? table[high_class * 32 + symbol_class] : 0;
+                    entries[r] = profile_entry(k, low, high);
+                }
+                *reinterpret_cast<uint4 *>(profile + layout::strip_base(strip, classes) + symbol_class * layout::class_bytes + chunk * 16) =
+                    make_uint4(entries[0], entries[1], entries[2], entries[3]);
+            }
+            __syncthreads();
+
+            team_seed<local_, affine_, R>(k, first_row + lane_in_team * R, rows, diagonal);
+
+            // One step of this lane at DP column `column`; `head_*`: what the head lane takes instead of a neighbour's output.
+            auto hand_over = [&](team_edge_t const &head_edge, u32 head_row, team_edge_t &in, u32 &in_row) {
+                in.h = from_left<L>(head_edge.h, out.h, is_head);
+                in.f = affine_ ? from_left<L>(head_edge.f, out.f, is_head) : 0u;
+                in_row = from_left<L>(head_row, out_row, is_head);
+            };
+            // The profile row arrives 16 bytes at a time, one chunk ahead of the rows that consume it, and nothing moves across
+            // a chunk: left alone, hipcc hoists every read of all four steps of a batch (4 R registers) above the first row.
+            auto advance = [&](team_edge_t const &in, u32 in_row) {
+                uint4 const *const row = reinterpret_cast<uint4 const *>(profile + strip_base + in_row);
+                team_step_t<local_, affine_, R> step;
+                step.begin(in, diagonal);
+                uint4 next = row[0];
+#pragma unroll
+                for (int chunk = 0; chunk < R / 4; ++chunk) {
+                    uint4 const now = next;
+                    if (chunk + 1 < R / 4) next = row[chunk + 1];
+                    step.row(k, rows, 4 * chunk + 0, now.x, best), step.row(k, rows, 4 * chunk + 1, now.y, best);
+                    step.row(k, rows, 4 * chunk + 2, now.z, best), step.row(k, rows, 4 * chunk + 3, now.w, best);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                out = step.end(rows);
+                out_row = in_row;
+            };
+            // Predicated step `t`: the head's column is t + 1, this lane's is t + 1 - lane_in_team.
+            auto careful_step = [&](u32 t) {
+                u32 const head_column = t + 1;
+                team_edge_t head_edge = {0, 0};
+                u32 head_row = 0;
+                if (head_column <= text_length) {
+                    head_edge = unpark<affine_>(parked[(u64)head_column * teams]);
+                    u32 const at = text.byte_shift + head_column - 1;
+                    head_row = class_offset_of_byte[(text.aligned_base[at / 4] >> (8 * (at % 4))) & 0xFFu];
+                }
+                team_edge_t in;
+                u32 in_row;
+                hand_over(head_edge, head_row, in, in_row);
+                u32 const column = head_column - lane_in_team; // wraps for a lane that has not started
+                if (column - 1 < text_length) {
+                    advance(in, in_row);
+                    if (is_tail && park_this_pass) parked[(u64)column * teams] = park_of<affine_>(out);
+                }
+            };
+
+            if (longest_in_wave) {
+                constexpr u32 fill = (u32)((L - 1 + 3) / 4 * 4); // the first step at which every lane of a team has a column
+                u32 t = 0;
+#pragma unroll 1
+                for (; t < fill && t < longest_in_wave + L - 1; ++t) careful_step(t);
+                // ---- main loop: batches of four steps in which EVERY live lane of the wavefront has a column - no length
+                //      checks, unconditional loads / stores (dead teams run along on their own parked slots).
+                if (t == fill && t + 4 <= shortest_in_wave) {
+                    u32 dword = t / 4; // the head's columns t + 1 ... t + 4 are the text bytes of dword t / 4
+                    u32 raw_low = text.raw_clamped(dword), raw_high = text.raw_clamped(dword + 1);
+                    parked_t ahead[4]; // what the head takes at the steps t ... t + 3; refilled for the next batch as it goes
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) ahead[s] = parked[(u64)(t + 1 + s) * teams];
+                    u32 bytes_now = text.splice(raw_low, raw_high);
+                    raw_low = raw_high, raw_high = text.raw_clamped(dword + 2);
+                    u32 row_next = class_offset_of_byte[bytes_now & 0xFFu]; // looked up one STEP early
+#pragma unroll 1
+                    for (; t + 4 <= shortest_in_wave; t += 4, ++dword) {
+                        // the text of the NEXT batch, one batch early (clamped reads: never past the string)
+                        u32 const bytes_ahead = text.splice(raw_low, raw_high);
+                        raw_low = raw_high, raw_high = text.raw_clamped(dword + 3);
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            team_edge_t const head_edge = unpark<affine_>(ahead[s]);
+                            ahead[s] = parked[(u64)(t + 5 + s) * teams]; // the slack columns make the overrun harmless
+                            u32 const head_row = row_next;
+                            row_next = class_offset_of_byte[(s < 3 ? bytes_now >> (8 * (s + 1)) : bytes_ahead) & 0xFFu];
+                            team_edge_t in;
+                            u32 in_row;
+                            hand_over(head_edge, head_row, in, in_row);
+                            advance(in, in_row);
+                            // the tail's column of step t + s is t + s + 2 - L >= 1: L - 1 <= fill <= t
+                            if (park_this_pass && is_tail) parked[(u64)(t + s + 2 - L) * teams] = park_of<affine_>(out);
+                        }
+                        bytes_now = bytes_ahead;
+                    }
+                }
+                // ---- drain: ragged lengths and the lanes that are still behind their head
+#pragma unroll 1
+                for (; t < longest_in_wave + L - 1; ++t) careful_step(t);
+            }
+
+            // ---- scores that are complete after this pass
+            if constexpr (!local_) {
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    szs_string_ref_t const &query = half ? query_high : query_low;
+                    if (!query.length) continue;
+                    u32 last_pass, last_lane, last_reg;
+                    team_last_row<L, R>(query.length, last_pass, last_lane, last_reg);
+                    if (pass != last_pass || lane_in_team != last_lane || !(half ? live_high : live_low)) continue;
+                    u32 cell = 0;
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        if ((u32)r == last_reg) cell = rows.h[r];
+                    write_result(query, candidate, (i64)(k.truth(half ? (u32)high_of(cell) : (u32)low_of(cell)) - (affine_ ? 0 : k.open)));
+                }
+            }
+        }
+        if constexpr (local_) {
+            u32 both_best = pair_max(pair_max(best[0], best[1]), pair_max(best[2], best[3]));
+#pragma unroll
+            for (int offset = 1; offset < L; offset <<= 1) both_best = pair_max(both_best, (u32)__shfl_xor((int)both_best, offset, 64));
+            if (is_head) {
+                if (live_low) write_result(query_low, candidate, (i64)k.truth((u32)low_of(both_best)));
+                if (live_high && query_high.length) write_result(query_high, candidate, (i64)k.truth((u32)high_of(both_best)));
+            }
+        }
+    }
+}
+
+template <int L, int R>
+static size_t team_profile_bytes(u32 classes) { return team_profile_layout<L, R>::total_bytes(classes); }
+
+/** Workgroups that can be RESIDENT at once for this kernel instance with this profile size. */
+template <bool local_, bool affine_, int L, int R, int W>
+static u32 team_grid(u64 work_items, u32 classes) {
+    static int resident_of[device_slots_k][34]; // per instance, device ordinal and class count
+    int *const slot = &resident_of[device_slot()][classes];
+    int resident = cached(slot);
+    if (!resident) {
+        int device = 0, units = 0, per_unit = 0;
+        size_t const profile_bytes = team_profile_bytes<L, R>(classes);
+        if (hipFuncSetAttribute(reinterpret_cast<void const *>(weighted_team_kernel<local_, affine_, L, R, W>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)team_profile_bytes<L, R>(32)) != hipSuccess ||
+            hipGetDevice(&device) != hipSuccess ||
+            hipDeviceGetAttribute(&units, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_unit, weighted_team_kernel<local_, affine_, L, R, W>,
+                                                         (int)team_block_threads_k, profile_bytes) != hipSuccess ||
+            units <= 0 || per_unit <= 0) {
+            (void)hipGetLastError();
+            units = 256, per_unit = 1;
+        }
+        resident = units * per_unit;
+        remember(slot, resident);
+    }
+    return (u32)(work_items < (u64)resident ? work_items : (u64)resident);
+}
+
+template <int L>
+static u64 team_work_items(u32 queries_count, u32 candidates_count) {
+    u32 const teams = team_block_threads_k / L;
+    return (u64)((queries_count + 1) / 2) * ((candidates_count + teams - 1) / teams);
+}
+
+} // namespace szs_hip
+
+/* The instances that are compiled: (lanes per team, registers per track, wavefronts per SIMD). */
+#ifndef SZS_TEAM_SHAPES
+#define SZS_TEAM_SHAPES(CALL) CALL(16, 32, 2) CALL(16, 32, 3) CALL(16, 24, 3) CALL(16, 16, 4) CALL(4, 32, 2) CALL(2, 32, 2) CALL(1, 32, 2)
+#endif
+
+#define SZS_TEAM_DISPATCH(L, R, W, CALL)                                                                               \
+    if (shape == L * 10000u + R * 100u + W) {                                                                          \
+        if (local && affine) CALL(true, true, L, R, W);                                                                \
+        if (local) CALL(true, false, L, R, W);                                                                         \
+        if (affine) CALL(false, true, L, R, W);                                                                        \
+        CALL(false, false, L, R, W);                                                                                   \
+    }
+
+extern "C" unsigned szs_hip_weighted_team_shape(unsigned index) {
+    unsigned const shapes[] = {
+#define SZS_TEAM_SHAPE_CODE(L, R, W) L * 10000u + R * 100u + W,
+        SZS_TEAM_SHAPES(SZS_TEAM_SHAPE_CODE)
+#undef SZS_TEAM_SHAPE_CODE
+    };
+    return index < sizeof(shapes) / sizeof(shapes[0]) ? shapes[index] : 0;
+}
+
+extern "C" int szs_hip_weighted_team_has_shape(unsigned shape) {
+    for (unsigned index = 0; szs_hip_weighted_team_shape(index); ++index)
+        if (szs_hip_weighted_team_shape(index) == shape) return 1;
+    return 0;
+}
+
+extern "C" size_t szs_hip_weighted_team_workspace_bytes(int local, int affine, unsigned shape, uint32_t classes, uint32_t queries_count,
+                                                        uint32_t candidates_count, uint32_t longest_candidate) {
+    using namespace szs_hip;
+    if (classes > 32) return 0;
+#define SZS_TEAM_BYTES(LOCAL, AFFINE, L, R, W)                                                                         \
+    return team_header_bytes_k + (size_t)team_grid<LOCAL, AFFINE, L, R, W>(team_work_items<L>(queries_count, candidates_count), classes) * \
+                                     (longest_candidate + 1 + team_slack_columns_k) * (team_block_threads_k / L) *     \
+                                     sizeof(parked_edge_t<AFFINE>)
+#define SZS_TEAM_SHAPE_BYTES(L, R, W) SZS_TEAM_DISPATCH(L, R, W, SZS_TEAM_BYTES)
+    SZS_TEAM_SHAPES(SZS_TEAM_SHAPE_BYTES)
+#undef SZS_TEAM_SHAPE_BYTES
+#undef SZS_TEAM_BYTES
+    return 0;
+}
+
+extern "C" int szs_hip_weighted_team_scores(int local, int affine, unsigned shape, uint32_t classes, szs_cost_model_t const *model,
+                                            szs_string_ref_t const *queries, uint32_t queries_count, szs_string_ref_t const *candidates,
+                                            uint32_t candidates_count, uint32_t longest_candidate, int64_t *results,
+                                            uint64_t results_row_stride, int layout_flags, void *workspace, void *stream) {
+    using namespace szs_hip;
+    if (!queries_count || !candidates_count) return 0;
+    if (classes > 32) return (int)hipErrorInvalidValue;
+    u32 *const counter = static_cast<u32 *>(workspace);
+    char *const parked = static_cast<char *>(workspace) + team_header_bytes_k;
+    hipStream_t const s = static_cast<hipStream_t>(stream);
+#define SZS_TEAM_LAUNCH(LOCAL, AFFINE, L, R, W)                                                                        \
+    {                                                                                                                  \
+        u64 const work_items = team_work_items<L>(queries_count, candidates_count);                                    \
+        if (work_items > 0xFFFFFFF0ull) return (int)hipErrorInvalidValue; /* the host cuts larger cross-products */     \
+        hipError_t const error = hipMemsetAsync(counter, 0, sizeof(u32), s);                                           \
+        if (error != hipSuccess) return (int)error;                                                                    \
+        u32 const grid = team_grid<LOCAL, AFFINE, L, R, W>(work_items, classes);                                       \
+        u32 const teams = team_block_threads_k / L;                                                                    \
+        size_t const profile_bytes = team_profile_bytes<L, R>(classes);                                                \
+        hipLaunchKernelGGL((weighted_team_kernel<LOCAL, AFFINE, L, R, W>), dim3(grid), dim3(team_block_threads_k),     \
+                           profile_bytes, s, model, queries, queries_count, candidates,                                \
+                           candidates_count, (candidates_count + teams - 1) / teams, results, results_row_stride,      \
+                           layout_flags, parked, longest_candidate + 1 + team_slack_columns_k, counter, classes);      \
+        return (int)hipGetLastError();                                                                                 \
+    }
+#define SZS_TEAM_SHAPE_LAUNCH(L, R, W) SZS_TEAM_DISPATCH(L, R, W, SZS_TEAM_LAUNCH)
+    SZS_TEAM_SHAPES(SZS_TEAM_SHAPE_LAUNCH)
+#undef SZS_TEAM_SHAPE_LAUNCH
+#undef SZS_TEAM_LAUNCH
+    return (int)hipErrorInvalidValue;
+}

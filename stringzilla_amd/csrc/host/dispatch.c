@@ -294,6 +294,22 @@ void szs_engine_release(szs_engine_s *engine) {
 
 /* ---- the decision: everything that follows from the statistics of the two sides ---------------------------------------- */
 
+/**
+ *  Which instance of the team tier scores a 16-bit class-table call, 0 for the one-pair-per-lane kernel.  A team of L lanes
+ *  x R registers walks the query side in passes of L x R rows, so what it wastes is the padding of the last pass: about
+ *  half a pass per pair of queries.  Sixteen lanes for queries of 2 KB and more (config 4: 6 % padding against 1 / 16 of the
+ *  parked traffic and of the longest pair's critical path).
+ */
+static unsigned team_shape_for(szs_side_stats_t const *queries, szs_side_stats_t const *candidates) {
+    int const knob = szs_tuning_get(szs_knob_team_k);
+    if (knob == 0) return 0;
+    if (knob > 0) return szs_hip_weighted_team_has_shape((unsigned)knob) ? (unsigned)knob : 0;
+    (void)candidates;
+    uint64_t const mean_query = queries->count ? queries->symbols / queries->count : 0;
+    if (mean_query >= 2048 && szs_hip_weighted_team_has_shape(163202)) return 163202;
+    return 0;
+}
+
 static sz_status_t decide(szs_engine_s const *engine, int symmetric, int runes, int force_lanes, szs_side_stats_t const *q_stats,
                           szs_side_stats_t const *c_stats, uint32_t const *q_variants, uint32_t const *c_variants,
                           uint64_t cells, szs_decision_t *d, char const **error_message) {
@@ -353,6 +369,10 @@ static sz_status_t decide(szs_engine_s const *engine, int symmetric, int runes, 
 
     if (d->wide_cells) /* one tier only: the anti-diagonal walker with 64-bit cells, whatever the shape of the batch */
         d->tier = SZS_TIER_LANES, d->packed = 0, d->narrow = 0;
+    /* The team tier (hip/weighted_teams.hip) scores what the packed kernel scores - same bounds, same refs - with a pair
+     * spread over the lanes of a DPP row.  The `team` knob pins a shape or (0) the one-pair-per-lane kernel. */
+    d->team = 0;
+    if (d->packed && d->tier == SZS_TIER_LANES) d->team = team_shape_for(kq, kc);
 
     /* The systolic tier scores every engine family with its weighted recurrences, so it needs the cost model and its
      * own workspace; a job with too many pairs in flight for that workspace stays on the lanes tier. */
@@ -392,6 +412,9 @@ static sz_status_t upload_model(szs_engine_s *engine, szs_decision_t const *d, i
 
 /** Size of the weighted lanes kernels' strip workspace for this decision. */
 static size_t weighted_boundary_bytes(szs_engine_s const *engine, szs_decision_t const *d) {
+    if (d->team)
+        return szs_hip_weighted_team_workspace_bytes(d->packed_local, !engine->is_linear, d->team, d->classes, d->kq_count, d->kc_count,
+                                                     d->plan.longest_candidate);
     return d->packed ? szs_hip_weighted_packed_boundary_bytes(d->packed_local, !engine->is_linear, d->classes, d->kq_count, d->kc_count,
                                                               d->plan.longest_candidate)
                      : szs_hip_weighted_boundary_bytes(d->objective, !engine->is_linear, d->narrow, d->kq_count, d->kc_count,
@@ -622,6 +645,12 @@ static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int dev
                                                            (int64_t *)device_results, device_stride, d->layout, engine->device_boundary.pointer, stream);
                 }
             }
+            else if (d->team) {
+                *cell_bits = 16;
+                launch_error = szs_hip_weighted_team_scores(d->packed_local, !engine->is_linear, d->team, d->classes, model, queries, count,
+                                                            candidate_refs, d->kc_count, d->plan.longest_candidate, (int64_t *)device_results,
+                                                            device_stride, d->layout, engine->device_boundary.pointer, target);
+            }
             else if (d->packed) {
                 *cell_bits = 16;
                 launch_error = szs_hip_weighted_packed_scores(d->packed_local, !engine->is_linear, d->classes, model, queries, count, candidate_refs,
@@ -718,6 +747,7 @@ static sz_status_t finish(szs_call_t *call, szs_decision_t const *d, hipError_t 
     profile->tier = (uint32_t)d->tier;
     profile->transposed = (uint32_t)d->transposed;
     profile->cell_bits = cell_bits;
+    profile->team = cell_bits == 16 ? d->team : 0;
     profile->longest_query = d->longest[0], profile->longest_candidate = d->longest[1];
     profile->host_milliseconds = now_milliseconds() - call->started;
     phase(call, 5);
@@ -813,7 +843,8 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
 
     hipError_t error = hipSuccess;
     int const knobs_automatic = szs_tuning_get(szs_knob_speculate_k) != 0 && szs_tuning_get(szs_knob_tier_k) < 0 &&
-                                szs_tuning_get(szs_knob_swap_k) < 0 && szs_tuning_get(szs_knob_cells_k) < 0 && szs_tuning_get(szs_knob_packed_k) < 0;
+                                szs_tuning_get(szs_knob_swap_k) < 0 && szs_tuning_get(szs_knob_cells_k) < 0 && szs_tuning_get(szs_knob_packed_k) < 0 &&
+                                szs_tuning_get(szs_knob_team_k) < 0;
     void const *const key_data[2] = {call->queries->data, symmetric ? call->queries->data : call->candidates->data};
     void const *const key_offsets[2] = {call->queries->offsets, symmetric ? call->queries->offsets : call->candidates->offsets};
     int const key_wide[2] = {(int)q_side.wide, (int)c_side.wide};

@@ -35,6 +35,7 @@ static struct {
     [szs_knob_split_k] = {"split", "SZS_ROCM_SPLIT"},
     [szs_knob_alphabet_k] = {"alphabet", "SZS_ROCM_ALPHABET"},
     [szs_knob_merge_k] = {"merge", "SZS_ROCM_MERGE"},
+    [szs_knob_team_k] = {"team", "SZS_ROCM_TEAM"},
 };
 
 /** Text -> value.  -1 always means "automatic".  Tier names: lanes 0, systolic 1, chain 2; planner: host 0, device 1. */
@@ -82,3 +83,6 @@ sz_status_t szs_rocm_tuning_set(char const *knob, char const *value) {
         }
     return sz_status_unknown_k;
 }
+
+/** The compiled instances of the team tier (hip/weighted_teams.hip), for tests and tuning scripts: 0 past the last one. */
+sz_u32_t szs_rocm_team_shape(sz_size_t index) { return index < 0xFFFFFFFFu ? szs_hip_weighted_team_shape((unsigned)index) : 0; }

@@ -1,0 +1,109 @@
+"""`-m gpu`, round 3: the TEAM tier of the 16-bit weighted scorers (hip/weighted_teams.hip) against the oracle.
+
+Every compiled shape (lanes per team x registers per lane) x {Needleman-Wunsch, Smith-Waterman} x {linear, affine} x
+{NUC.4.4, BLOSUM62, a 32-class asymmetric table}: query lengths around one, two and two-and-a-half passes, partners of very
+different length (the halves of a register), an odd query count, empty strings on both sides, ragged candidate blocks,
+symmetric mode and swapped sides.  tests/test_team_model.py checks the same arithmetic on the CPU.
+"""
+import contextlib
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import stringzilla_amd as szs  # noqa: E402
+from stringzilla_amd import _abi, matrices  # noqa: E402
+
+
+@contextlib.contextmanager
+def forced_env(name, value):
+    previous = _abi.tuning_set(name, value)
+    try:
+        yield
+    finally:
+        _abi.tuning_set(name, previous)  # nested blocks restore the outer setting, not "automatic"
+
+
+def forced_tier(name):
+    return forced_env("tier", name)
+
+
+def _rand(rng, count, lo, hi, alphabet):
+    return [bytes(rng.choice(alphabet) for _ in range(rng.randint(lo, hi))) for _ in range(count)]
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+
+    assert torch.cuda.is_available(), "the gpu-marked tests need a GPU"
+    return szs.DeviceScope(gpu_device=0)
+
+
+def _tables(rng):
+    asym_map = np.array([rng.randint(0, 31) for _ in range(256)], dtype=np.uint8)
+    asym_map[:32] = np.arange(32, dtype=np.uint8)  # every class in use
+    asym_tab = np.array([[rng.randint(-9, 9) for _ in range(32)] for _ in range(32)], dtype=np.int8)
+    return [(matrices.nuc44(), b"ACGTN"), (matrices.blosum62(), b"ARNDCQEGHILKMFPSTWYVBZX*"), ((asym_map, asym_tab), bytes(range(256)))]
+
+
+def test_team_shapes_are_listed():
+    shapes = _abi.team_shapes()
+    assert shapes and all(shape // 10000 in (1, 2, 4, 8, 16) and shape // 100 % 100 % 4 == 0 for shape in shapes)
+
+
+@pytest.mark.parametrize("kind", ["needleman_wunsch", "smith_waterman"])
+@pytest.mark.parametrize("shape", _abi.team_shapes())
+def test_team_tier_agrees_with_the_oracle(gpu, oracle, kind, shape):
+    lanes, registers = shape // 10000, shape // 100 % 100
+    rows = lanes * registers
+    rng = random.Random(shape * 2 + (kind == "smith_waterman"))
+    cls = szs.NeedlemanWunschScores if kind == "needleman_wunsch" else szs.SmithWatermanScores
+    for table_index, ((byte_to_class, class_costs), alphabet) in enumerate(_tables(rng)):
+        for gaps in [(-4, -4), (-5, -1)] + ([(-2, 0)] if table_index == 0 else []):
+            engine = cls(byte_to_class, class_costs, open=gaps[0], extend=gaps[1], capabilities=gpu)
+            longest = min(2 * rows + rows // 2, 1100)
+            lengths = [0, 1, 2, 3, registers - 1, registers, registers + 1, rows - 1, rows, rows + 1, 2 * rows, longest, longest - 7]
+            lengths += [rng.randint(1, longest) for _ in range(6)]
+            queries = [bytes(rng.choice(alphabet) for _ in range(max(0, length))) for length in lengths]  # an odd count
+            candidates = _rand(rng, 300 // lanes + 5, 0, 120, alphabet) + _rand(rng, 9, 0, 3, alphabet) + [b""]
+            expected = getattr(oracle, kind)(queries, candidates, byte_to_class, class_costs, *gaps)
+            with forced_env("team", shape), forced_tier("lanes"):
+                got = engine(queries, candidates, device=gpu)
+                profile = engine.last_call_profile()
+                assert profile.team == shape and profile.cell_bits == 16, (profile.team, profile.cell_bits)
+                wrong = np.argwhere(got != expected)
+                assert wrong.size == 0, (kind, shape, gaps, table_index, wrong[:5].tolist(), got[tuple(wrong[0])], expected[tuple(wrong[0])],
+                                         len(queries[wrong[0][0]]), len(candidates[wrong[0][1]]))
+                if table_index == 0:
+                    expected_sym = getattr(oracle, kind)(queries, None, byte_to_class, class_costs, *gaps)
+                    assert np.array_equal(engine(queries, device=gpu), expected_sym), (kind, shape, gaps, "symmetric")
+                    with forced_env("SZS_ROCM_SWAP", "1"):
+                        assert np.array_equal(engine(queries, candidates, device=gpu), expected), (kind, shape, gaps, "swapped")
+                        assert engine.last_call_profile().transposed == 1 and engine.last_call_profile().team == shape
+            with forced_env("team", 0), forced_tier("lanes"):  # the knob's other setting: one pair per lane
+                assert np.array_equal(engine(queries, candidates, device=gpu), expected), (kind, gaps, "team off")
+                assert engine.last_call_profile().team == 0
+
+
+@pytest.mark.parametrize("kind", ["needleman_wunsch", "smith_waterman"])
+def test_team_tier_long_candidates(gpu, oracle, kind):
+    """Candidates long enough for the unpredicated main loop to carry most of the columns, lengths ragged inside a wavefront
+    and across the workgroup; more than one candidate block; scores far from the bias."""
+    rng = random.Random(11)
+    cls = szs.NeedlemanWunschScores if kind == "needleman_wunsch" else szs.SmithWatermanScores
+    table, alphabet = (matrices.nuc44(), b"ACGT")
+    for shape in _abi.team_shapes():
+        lanes, registers = shape // 10000, shape // 100 % 100
+        for gaps in [(-4, -1), (-3, -3)]:
+            engine = cls(*table, open=gaps[0], extend=gaps[1], capabilities=gpu)
+            queries = _rand(rng, 5, lanes * registers - 40, lanes * registers + 60, alphabet)
+            candidates = _rand(rng, 256 // lanes + 3, 200, 700, alphabet) + _rand(rng, 3, 17, 40, alphabet)
+            expected = getattr(oracle, kind)(queries, candidates, *table, *gaps)
+            with forced_env("team", shape), forced_tier("lanes"):
+                got = engine(queries, candidates, device=gpu)
+                assert engine.last_call_profile().team == shape
+                wrong = np.argwhere(got != expected)
+                assert wrong.size == 0, (kind, shape, gaps, wrong[:5].tolist())

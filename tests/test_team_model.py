@@ -1,0 +1,110 @@
+"""The TEAM tier's arithmetic and data flow against the oracle, on the CPU.
+
+`tests/native/team_model.cpp` compiles the kernel's own step / seed / border / profile code (csrc/hip/team_core.hpp) with
+g++ and drives it lane by lane the way `weighted_team_kernel` does.  Every engine family, several (lanes, registers)
+shapes, ragged candidate blocks, empty sides, asymmetric tables, queries paired with much shorter partners.
+"""
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import binding
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SOURCE = os.path.join(ROOT, "tests", "native", "team_model.cpp")
+CORE = os.path.join(ROOT, "stringzilla_amd", "csrc", "hip", "team_core.hpp")
+LIBRARY = os.path.join(ROOT, "tests", "native", "bin", "libteam_model.so")
+
+
+@pytest.fixture(scope="module")
+def model():
+    os.makedirs(os.path.dirname(LIBRARY), exist_ok=True)
+    newest = max(os.path.getmtime(SOURCE), os.path.getmtime(CORE))
+    if not os.path.exists(LIBRARY) or os.path.getmtime(LIBRARY) < newest:
+        subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-shared", "-fPIC", SOURCE, "-o", LIBRARY], check=True)
+    library = ctypes.CDLL(LIBRARY)
+    library.team_model_cross.restype = ctypes.c_int
+    return library
+
+
+def run_model(model, local, affine, lanes, registers, queries, candidates, byte_to_class, class_costs, open, extend):
+    q_data, q_off = binding.make_tape(queries)
+    c_data, c_off = binding.make_tape(candidates)
+    results = np.full((len(queries), max(len(candidates), 1)), -777, dtype=np.int64)
+    table = np.ascontiguousarray(class_costs, dtype=np.int8).reshape(-1)
+    classes = np.ascontiguousarray(byte_to_class, dtype=np.uint8)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    status = model.team_model_cross(int(local), int(affine), lanes, registers, p(q_data), p(q_off), len(queries), p(c_data),
+                                    p(c_off), len(candidates), p(classes), p(table), int(open), int(extend), p(results),
+                                    ctypes.c_uint64(results.shape[1]))
+    assert status == 0, "shape not instantiated in team_model.cpp"
+    return results[:, : len(candidates)]
+
+
+def random_strings(rng, count, low, high, alphabet):
+    letters = np.frombuffer(alphabet, dtype=np.uint8)
+    return [letters[rng.integers(0, len(letters), size=int(rng.integers(low, high + 1)))].tobytes() for _ in range(count)]
+
+
+def random_table(rng, classes=9):
+    byte_to_class = np.zeros(256, np.uint8)
+    for letter in range(ord("A"), ord("A") + 26):
+        byte_to_class[letter] = rng.integers(0, classes)
+    table = np.zeros((32, 32), np.int8)
+    table[:classes, :classes] = rng.integers(-9, 12, size=(classes, classes))  # asymmetric on purpose (serial.hpp:199-204)
+    return byte_to_class, table
+
+
+SHAPES = [(16, 32), (16, 16), (16, 24), (8, 32), (4, 32), (4, 8), (2, 16), (1, 32), (1, 4)]
+
+
+@pytest.mark.parametrize("lanes,registers", SHAPES)
+@pytest.mark.parametrize("local,affine", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_model_agrees_with_the_oracle(model, lanes, registers, local, affine):
+    rng = np.random.default_rng(1000 * lanes + 10 * registers + 2 * local + affine)
+    oracle = binding.oracle()
+    rows = lanes * registers
+    for trial in range(4):
+        if trial == 0:
+            table = binding.nuc44()
+            alphabet = b"ACGTN"
+        elif trial == 1:
+            table = binding.blosum62()
+            alphabet = b"ARNDCQEGHILKMFPSTWYVBZX*"
+        else:
+            table = random_table(rng)
+            alphabet = b"ABCDEFGHIJKLMNOPQRSTUVWXYZab"
+        # queries around one, two and a half passes, plus tiny, empty and badly matched partners
+        longest = min(2 * rows + rows // 2, 700)
+        queries = random_strings(rng, 5, max(1, rows - 3), longest, alphabet) + [b"", alphabet[:1], alphabet[:3]]
+        queries += random_strings(rng, 2, 1, 12, alphabet)
+        if trial == 3:
+            queries = queries[:-1]  # an odd count: the last query has no partner
+        candidates = random_strings(rng, 300 // lanes + 3, 0, 90, alphabet) + [b""] + random_strings(rng, 3, 1, 5, alphabet)
+        open, extend = (int(rng.integers(-7, 0)), int(rng.integers(-3, 1))) if affine else (int(rng.integers(-6, 0)),) * 2
+        if trial == 0:
+            open, extend = (-4, -1) if affine else (-4, -4)
+        got = run_model(model, local, affine, lanes, registers, queries, candidates, *table, open, extend)
+        scorer = oracle.smith_waterman if local else oracle.needleman_wunsch
+        expected = scorer(queries, candidates, *table, open, extend)
+        mismatches = np.argwhere(got != expected)
+        assert mismatches.size == 0, (
+            f"trial {trial}: first mismatch at {mismatches[0]}: got {got[tuple(mismatches[0])]}, expected "
+            f"{expected[tuple(mismatches[0])]} (query {len(queries[mismatches[0][0]])} B, candidate {len(candidates[mismatches[0][1]])} B)"
+        )
+
+
+def test_model_positive_gaps_of_a_global_engine(model):
+    """Needleman-Wunsch accepts gap costs of either sign (they are ADDED); the representation must not care."""
+    rng = np.random.default_rng(7)
+    oracle = binding.oracle()
+    table = random_table(rng)
+    queries = random_strings(rng, 6, 1, 150, b"ABCDEFGH")
+    candidates = random_strings(rng, 40, 0, 60, b"ABCDEFGH")
+    for affine, (open, extend) in [(0, (2, 2)), (1, (3, 1)), (1, (-2, 1))]:
+        got = run_model(model, 0, affine, 16, 16, queries, candidates, *table, open, extend)
+        assert np.array_equal(got, oracle.needleman_wunsch(queries, candidates, *table, open, extend))
