@@ -34,6 +34,7 @@ typedef struct szs_rocm_call_profile_t {
     sz_u32_t planner;             /* 0: planned on the host; 1: on the device (hip/planner.hip); 2: on the device, launches speculated;
                                      3: the plan of the previous call of the same tapes, re-used behind a guard */
     sz_u32_t team;                /* 0, or lanes * 10000 + registers * 100 + wavefronts per SIMD of the team tier (weighted_teams.hip) */
+    sz_u32_t team_wide;           /* team tier: 0 cells ordered as half-float patterns (three-input maxima), 1 as unsigned integers */
 } szs_rocm_call_profile_t;
 
 /** Copies the profile of the most recent call made through `engine` (any of the four engine handle types). */

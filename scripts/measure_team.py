@@ -17,17 +17,21 @@ parser.add_argument("--config", type=int, default=4)
 parser.add_argument("--scale", type=float, default=1.0)
 parser.add_argument("--repeats", type=int, default=2)
 parser.add_argument("--shapes", default="")
-parser.add_argument("--rows", type=int, default=0, help="score only the first N query rows (a GPU's share)")
+parser.add_argument("--shards", type=int, default=1, help="score only the query rows LPT deals to GPU 0 of N")
+parser.add_argument("--tier", default="lanes")
 args = parser.parse_args()
 
 gpu = szs.DeviceScope(gpu_device=0)
 load = workloads.config(args.config, scale=args.scale)
 cls = szs.NeedlemanWunschScores if load.kind == "needleman_wunsch" else szs.SmithWatermanScores
 engine = cls(*matrices.by_name(load.table), **load.costs, capabilities=gpu)
-queries = load.queries if not args.rows else [load.queries[i] for i in range(0, len(load.queries), len(load.queries) // args.rows)][: args.rows]
-if not args.rows:
-    load.queries.to_device(0)
+import numpy as np
+from stringzilla_amd import sharded
+shard_of_row, _ = sharded.shard_rows(load.queries.lengths(), args.shards)
+queries = load.queries.select(np.nonzero(shard_of_row == 0)[0]).to_device(0)
 load.candidates.to_device(0)
+if args.tier != "auto":
+    _abi.tuning_set("tier", args.tier)
 out = torch.empty((len(queries), len(load.candidates)), dtype=torch.int64, device="cuda")
 shapes = [int(x) for x in args.shapes.split(",")] if args.shapes else [0] + _abi.team_shapes()
 reference = None
@@ -41,6 +45,6 @@ for shape in shapes:
     profile = engine.last_call_profile()
     checksum = int(out.sum().item())
     reference = checksum if reference is None else reference
-    print(json.dumps({"config": load.name, "rows": len(queries), "team": profile.team, "cell_bits": profile.cell_bits,
+    print(json.dumps({"config": load.name, "rows": len(queries), "tier": profile.tier, "team": profile.team, "cell_bits": profile.cell_bits,
                       "kernel_ms": round(min(kernel), 3), "gcups": round(profile.cells / min(kernel) / 1e6, 1),
                       "checksum": checksum, "agrees": checksum == reference}), flush=True)

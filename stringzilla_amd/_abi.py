@@ -54,7 +54,7 @@ class CallProfile(ctypes.Structure):
         ("cells", ctypes.c_uint64), ("pairs", ctypes.c_uint64), ("algorithmic_bytes", ctypes.c_uint64),
         ("unique_bytes", ctypes.c_uint64), ("launches", ctypes.c_uint32), ("longest_query", ctypes.c_uint32),
         ("longest_candidate", ctypes.c_uint32), ("tier", ctypes.c_uint32), ("transposed", ctypes.c_uint32), ("cell_bits", ctypes.c_uint32),
-        ("planner", ctypes.c_uint32), ("team", ctypes.c_uint32),
+        ("planner", ctypes.c_uint32), ("team", ctypes.c_uint32), ("team_wide", ctypes.c_uint32),
     ]
 
 

@@ -279,16 +279,20 @@ size_t szs_hip_weighted_packed_boundary_bytes(int local, int affine, uint32_t cl
  *  of `lanes` adjacent lanes, each `registers` query rows deep, strips handed from lane to lane in registers and only the
  *  bottom row of a whole group of lanes x registers rows parked; two queries share every register (low / high half).
  *  Same eligibility, cost model, refs (queries longest first, candidates ascending) and result addressing as
- *  szs_hip_weighted_packed_scores; local scores may reach 60000.  `shape` = lanes * 10000 + registers * 100 + wavefronts per
- *  SIMD names one of the compiled instances: szs_hip_weighted_team_shape(i) enumerates them (0 past the last one).
+ *  szs_hip_weighted_packed_scores.  `shape` = lanes * 10000 + registers * 100 + wavefronts per SIMD names one of the
+ *  compiled instances: szs_hip_weighted_team_shape(i) enumerates them (0 past the last one).  `wide` = 0: cells ordered as
+ *  half-float patterns, three-input maxima; = 1: as unsigned integers, two-input maxima.  The caller's bound on every DP value
+ *  (global: the reach of serial.hpp:135-162; local: (shorter side + 3) x largest cost) must stay below
+ *  szs_hip_weighted_team_reach_limit(local, wide): 15000 / 29000 narrow, 32000 / 62000 wide.
  */
 unsigned szs_hip_weighted_team_shape(unsigned index);
 int szs_hip_weighted_team_has_shape(unsigned shape);
-int szs_hip_weighted_team_scores(int local, int affine, unsigned shape, uint32_t classes, szs_cost_model_t const *model,
+uint32_t szs_hip_weighted_team_reach_limit(int local, int wide);
+int szs_hip_weighted_team_scores(int local, int affine, int wide, unsigned shape, uint32_t classes, szs_cost_model_t const *model,
                                  szs_string_ref_t const *queries, uint32_t queries_count, szs_string_ref_t const *candidates,
                                  uint32_t candidates_count, uint32_t longest_candidate, int64_t *results,
                                  uint64_t results_row_stride, int symmetric, void *workspace, void *stream);
-size_t szs_hip_weighted_team_workspace_bytes(int local, int affine, unsigned shape, uint32_t classes, uint32_t queries_count,
+size_t szs_hip_weighted_team_workspace_bytes(int local, int affine, int wide, unsigned shape, uint32_t classes, uint32_t queries_count,
                                              uint32_t candidates_count, uint32_t longest_candidate);
 
 /**

@@ -17,15 +17,25 @@
  *  BIASED UNSIGNED CELLS, FULL-RATE ADDITIONS.  A cell is stored as `true value + bias` in an unsigned 16-bit half.  With
  *  every half provably inside [0, 65535] before and after an addition, ONE 32-bit `v_add_u32` adds a (signed) increment to
  *  both halves at once: the increment pair is stored as `(high << 16) + sign_extended(low)`, i.e. the borrow that a negative
- *  low increment takes from the high half is paid back in advance.  gfx950 issues v_add_u32 at twice the rate of v_pk_add_i16
- *  (scripts/valu_peak.hip: 60-70 vs 36-38 T lane-operations/s), so the additions of the recurrence - half of its operations -
- *  cost half of what they cost weighted_packed.hip; only the maxima (v_pk_max_u16) stay in the slow class.
- *      global (Needleman-Wunsch): bias 32768; the reach rule (serial.hpp:135-162) < 32000 bounds every H and track value.
- *      local  (Smith-Waterman, gap costs <= 0): bias 1024; H >= 0 and the gap tracks >= open, so nothing sinks below the
- *              bias by more than 256; scores stay below 62000.
- *  A low half can only leave its range in rows BELOW the last row of the longer query (padded rows, global borders running
- *  on); what it then carries into the high half lands in a row that is padded for the shorter query too.  Carries never run
- *  downwards (high to low), and v_pk_max_u16 treats the halves separately.
+ *  low increment takes from the high half is paid back in advance.  gfx950 issues v_add_u32 at 59 T lane-operations/s and
+ *  every maximum, packed or not, integer or float, at 35 (profiles/r03/team_ops.json), so the additions of the recurrence
+ *  cost 0.6 of what they cost weighted_packed.hip's v_pk_add_i16.
+ *
+ *  THREE-INPUT MAXIMA ON HALF-FLOAT PATTERNS.  gfx950 has no three-input integer maximum on packed halves, but it has
+ *  `v_pk_maximum3_f16`, at the rate of the two-input ones - and positive NORMAL half floats (bit patterns 0x0400 ... 0x7BFF)
+ *  order exactly like their patterns read as unsigned integers.  Cells kept inside that range are therefore maximised three
+ *  at a time by a floating-point instruction that never sees a float (profiles/r03/team_ops.json: 0 differences from the
+ *  integer maximum on 2^26 triples).  The recurrence's maxima per register (= per two cells) drop from 6 to 4.5 (local
+ *  affine), 4 to 3 (global affine), 2 to 1 (global linear).  `narrow` order, the default:
+ *      global (Needleman-Wunsch): bias 16384; the reach rule (serial.hpp:135-162) must stay below 15000.
+ *      local  (Smith-Waterman, gap costs <= 0): bias 2048; H >= 0 and the gap tracks >= open + 2 extend, so nothing sinks
+ *              below 1792; scores must stay below 29000.
+ *  `wide` order - plain v_pk_max_u16, two inputs, every pattern valid - covers what lies between those bounds and 16 bits:
+ *      global: bias 32768, reach below 32000; local: bias 1024, scores below 62000.
+ *  Garbage is harmless in either order: a half can only leave its range in rows BELOW the last row of the longer query
+ *  (padded rows, global borders running on); what a low half then carries into the high half lands in a row that is padded
+ *  for the shorter query too; carries never run downwards (high to low), the maxima treat the halves separately, and a NaN
+ *  pattern only ever propagates down and to the right, like everything else in the matrix.
  *
  *  TWO TRACKS INSTEAD OF THREE.  weighted_packed.hip keeps H, H + open and E + extend per row; here a row keeps H and
  *  `e` = the horizontal-gap value ENTERING the next column, max(H + open, E + extend), which is formed from values the step
@@ -55,32 +65,66 @@ SZS_HD u32 both(i32 value) { return pair_of(value, value); }
 SZS_HD i32 low_of(u32 pair) { return (i32)(pair & 0xFFFFu); }
 SZS_HD i32 high_of(u32 pair) { return (i32)(pair >> 16); }
 
-/** Per-half unsigned maximum: v_pk_max_u16. */
-SZS_HD u32 pair_max(u32 a, u32 b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef unsigned short pk_u16 __attribute__((ext_vector_type(2)));
-    return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(pk_u16, a), __builtin_bit_cast(pk_u16, b)));
-#else
-    u32 const low = (a & 0xFFFFu) > (b & 0xFFFFu) ? (a & 0xFFFFu) : (b & 0xFFFFu);
-    u32 const high = (a >> 16) > (b >> 16) ? (a >> 16) : (b >> 16);
-    return (high << 16) | low;
-#endif
+#if !defined(__HIP_DEVICE_COMPILE__)
+/** Host model of the IEEE-754 `maximum` on one half-float PATTERN: a NaN in, the canonical NaN out; negative patterns order
+ *  downwards.  The kernel's claims about its value ranges are only as good as a model that breaks when they are wrong. */
+inline u32 model_half_maximum(u32 a, u32 b) {
+    auto const is_nan = [](u32 x) { return (x & 0x7FFFu) > 0x7C00u; };
+    if (is_nan(a) || is_nan(b)) return 0x7E00u;
+    auto const key = [](u32 x) { return (x & 0x8000u) ? -(i32)(x & 0x7FFFu) : (i32)(x & 0x7FFFu); };
+    return key(a) >= key(b) ? a : b;
 }
+#endif
 
-template <bool local_>
-struct bias_of {
-    static constexpr i32 value = local_ ? 1024 : 32768;
+/** The two orders a kernel instance can keep its cells in (see the header). */
+template <bool wide_>
+struct team_order {
+    /** Per-half maximum of two registers: v_pk_max_u16 / v_pk_max_f16. */
+    SZS_HD static u32 max2(u32 a, u32 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (wide_) {
+            typedef unsigned short pk_u16 __attribute__((ext_vector_type(2)));
+            return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(pk_u16, a), __builtin_bit_cast(pk_u16, b)));
+        }
+        // IEEE-754 `maximum` through the compiler's own builtin, NOT inline assembly: a packed result needs a wait state
+        // before its first reader on gfx950, and only instructions the hazard recogniser can see get one.
+        typedef _Float16 pk_f16 __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(u32, __builtin_elementwise_maximum(__builtin_bit_cast(pk_f16, a), __builtin_bit_cast(pk_f16, b)));
+#else
+        if (wide_) {
+            u32 const low = (a & 0xFFFFu) > (b & 0xFFFFu) ? (a & 0xFFFFu) : (b & 0xFFFFu);
+            u32 const high = (a >> 16) > (b >> 16) ? (a >> 16) : (b >> 16);
+            return (high << 16) | low;
+        }
+        return model_half_maximum(a & 0xFFFFu, b & 0xFFFFu) | model_half_maximum(a >> 16, b >> 16) << 16;
+#endif
+    }
+    /** Per-half maximum of three registers: ONE v_pk_maximum3_f16 in the narrow order, two v_pk_max_u16 in the wide one. */
+    SZS_HD static u32 max3(u32 a, u32 b, u32 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (!wide_) { // the nested maxima fold into one v_pk_maximum3_f16
+            typedef _Float16 pk_f16 __attribute__((ext_vector_type(2)));
+            pk_f16 const first = __builtin_elementwise_maximum(__builtin_bit_cast(pk_f16, a), __builtin_bit_cast(pk_f16, b));
+            return __builtin_bit_cast(u32, __builtin_elementwise_maximum(first, __builtin_bit_cast(pk_f16, c)));
+        }
+#endif
+        return max2(max2(a, b), c);
+    }
 };
 
-/** The scoring constants of one launch in the representation above. */
-template <bool local_, bool affine_>
+/** The scoring constants of one launch in the chosen representation. */
+template <bool local_, bool affine_, bool wide_>
 struct team_costs_t {
+    static constexpr bool local = local_, affine = affine_, wide = wide_;
+    static constexpr i32 bias = wide_ ? (local_ ? 1024 : 32768) : (local_ ? 2048 : 16384);
+    using order = team_order<wide_>;
+
     i32 open, extend; // signed, ADDED; linear gaps: open == extend == the gap cost
     u32 open_pair, extend_pair, zero_pair;
 
     SZS_HD team_costs_t(i32 gap_open, i32 gap_extend)
         : open(gap_open), extend(affine_ ? gap_extend : gap_open), open_pair(both(gap_open)),
-          extend_pair(both(affine_ ? gap_extend : gap_open)), zero_pair(both(bias_of<local_>::value)) {}
+          extend_pair(both(affine_ ? gap_extend : gap_open)), zero_pair(both(bias)) {}
 
     /** H(k, 0) = H(0, k): the all-gap border (serial.hpp:821-823,1045-1047); local: 0. */
     SZS_HD i32 border(u32 k) const {
@@ -95,16 +139,19 @@ struct team_costs_t {
         i32 const fresh = edge + open, carried = edge + open + 2 * extend;
         return fresh > carried ? fresh : carried;
     }
-    SZS_HD u32 stored(i32 truth) const { return (u32)(truth + bias_of<local_>::value) & 0xFFFFu; }
-    SZS_HD i32 truth(u32 half) const { return (i32)half - bias_of<local_>::value; }
+    SZS_HD u32 stored(i32 truth) const { return (u32)(truth + bias) & 0xFFFFu; }
+    SZS_HD i32 truth(u32 half) const { return (i32)half - bias; }
+
+    /** One profile entry: the costs of one candidate class against the same row of the two queries (0 for a padded row).
+     *  Linear gaps: the diagonal is kept as H + gap, so the entry carries `cost - gap`. */
+    SZS_HD u32 profile_entry(i32 cost_low, i32 cost_high) const {
+        return affine_ ? pair_of(cost_low, cost_high) : pair_of(cost_low - open, cost_high - open);
+    }
 };
 
-/** One profile entry: the costs of one candidate class against the same row of the two queries (0 for a padded row).
- *  Linear gaps: the diagonal is kept as H + gap, so the entry carries `cost - gap`. */
-template <bool local_, bool affine_>
-SZS_HD u32 profile_entry(team_costs_t<local_, affine_> const &k, i32 cost_low, i32 cost_high) {
-    return affine_ ? pair_of(cost_low, cost_high) : pair_of(cost_low - k.open, cost_high - k.open);
-}
+/** Largest worst-case magnitude a call may have for an instance: the reach of serial.hpp:135-162 (global), or
+ *  (shorter side + 3) x largest cost (local).  The host checks it (dispatch.c). */
+SZS_HD u32 team_reach_limit(bool local, bool wide) { return wide ? (local ? 62000u : 32000u) : (local ? 29000u : 15000u); }
 
 /**
  *  The rows of one strip at one column, per lane.
@@ -124,29 +171,29 @@ struct team_edge_t {
 };
 
 /** Column 0 of the strip whose first DP row (1-based) is `first_row + 1`, for a pair of queries alike. */
-template <bool local_, bool affine_, int R>
-SZS_HD void team_seed(team_costs_t<local_, affine_> const &k, u32 first_row, team_rows_t<affine_, R> &rows, u32 &diagonal) {
+template <typename costs_t, int R>
+SZS_HD void team_seed(costs_t const &k, u32 first_row, team_rows_t<costs_t::affine, R> &rows, u32 &diagonal) {
     for (int r = 0; r < R; ++r) {
         i32 const edge = k.border(first_row + (u32)r + 1);
-        if (affine_) rows.h[r] = both(k.stored(edge)), rows.e[affine_ ? r : 0] = both(k.stored(k.entering(edge)));
+        if (costs_t::affine) rows.h[r] = both(k.stored(edge)), rows.e[costs_t::affine ? r : 0] = both(k.stored(k.entering(edge)));
         else rows.h[r] = both(k.stored(edge + k.open));
     }
-    diagonal = both(k.stored(k.border(first_row) + (affine_ ? 0 : k.open)));
+    diagonal = both(k.stored(k.border(first_row) + (costs_t::affine ? 0 : k.open)));
 }
 
 /** What the strip below DP row 0 - the border row - hands down at column `j` (1-based): prefilled into the parked rows. */
-template <bool local_, bool affine_>
-SZS_HD team_edge_t team_border_edge(team_costs_t<local_, affine_> const &k, u32 j) {
+template <typename costs_t>
+SZS_HD team_edge_t team_border_edge(costs_t const &k, u32 j) {
     i32 const edge = k.border(j);
     team_edge_t out;
-    out.h = both(k.stored(edge + (affine_ ? 0 : k.open)));
-    out.f = affine_ ? both(k.stored(k.entering(edge))) : 0u;
+    out.h = both(k.stored(edge + (costs_t::affine ? 0 : k.open)));
+    out.f = costs_t::affine ? both(k.stored(k.entering(edge))) : 0u;
     return out;
 }
 
 /** Pins a value: no instruction, but the compiler may neither re-associate a maximum through it nor sink its operands.
- *  max(max(e, substituted), zero) must be formed OFF the row-to-row chain; left alone, hipcc folds the clamp behind the
- *  maximum with the vertical track and the chain grows by one slow operation and a wait state per row. */
+ *  What hangs OFF the row-to-row chain must be formed off it; left alone, hipcc folds the clamp behind the maximum with
+ *  the vertical track and the chain grows by one slow operation and a wait state per row. */
 SZS_HD void settle(u32 &value) {
 #if defined(__HIP_DEVICE_COMPILE__)
     asm("" : "+v"(value));
@@ -158,35 +205,54 @@ SZS_HD void settle(u32 &value) {
 /**
  *  One step of one lane: the R rows of its strip advance by one column - begin(), rows in order, end().
  *  `above`: what the strip above handed down at this column; `diagonal`: its `h` of the previous column (replaced).
- *  `costs`: the profile entries of this column's class for the rows at hand.  `best`: four running maxima of H (local only).
+ *  `cost`: the profile entry of this column's class for the row at hand.  `best`: running maxima of H (local only).
  *
- *  Operation count per register = per TWO cells (fast = v_add_u32, slow = v_pk_max_u16):
- *      global linear 2 fast + 2 slow, local linear 2 + 4, global affine 4 + 4, local affine 4 + 6.
- *  The maxima are associated so that the chain from one row to the next is one maximum and one addition (linear) or two
- *  maxima and one addition (affine); everything else hangs off it.
+ *  Operations per register = per TWO cells (additions v_add_u32 + maxima):
+ *                      narrow order                         wide order
+ *      global linear   2 + 1   max3(sub, left, up)          2 + 2
+ *      local  linear   2 + 2.5 max3(sub, left, 0); up; best 2 + 4
+ *      global affine   4 + 3   max3(e, sub, f); e'; f'      4 + 4
+ *      local  affine   4 + 4.5 max3(e, sub, 0); f; e'; f'   4 + 6
+ *  (`best` takes two rows per maximum in the narrow order).  The chain from one row to the next is one maximum and one
+ *  addition (linear) or two maxima and one addition (affine); everything else hangs off it.
  */
-template <bool local_, bool affine_, int R>
+template <typename costs_t, int R>
 struct team_step_t {
+    static constexpr bool local_ = costs_t::local, affine_ = costs_t::affine, wide_ = costs_t::wide;
+    using order = typename costs_t::order;
     u32 diag, up; // H of the row above at the previous column; affine: F entering the row, linear: H + gap of the row above
+    u32 pending;  // local, narrow order: the cell of the even row, waiting for its odd neighbour
 
     SZS_HD void begin(team_edge_t const &above, u32 &diagonal) {
         diag = diagonal, diagonal = above.h;
         up = affine_ ? above.f : above.h;
+        pending = 0;
     }
     /** Row `r`: serial.hpp:1091-1102, 1238-1239 (affine), 846-848, 957-965 (linear). */
-    SZS_HD void row(team_costs_t<local_, affine_> const &k, team_rows_t<affine_, R> &rows, int r, u32 cost, u32 (&best)[4]) {
+    SZS_HD void row(costs_t const &k, team_rows_t<affine_, R> &rows, int r, u32 cost, u32 (&best)[4]) {
         u32 const substituted = diag + cost; // linear: (H(row - 1, column - 1) + gap) + (cost - gap)
         diag = rows.h[r];
-        u32 inner = pair_max(affine_ ? rows.e[affine_ ? r : 0] : rows.h[r], substituted); // the horizontal branch: E, or left + gap
-        if (local_) inner = pair_max(inner, k.zero_pair); // only the substitution branch needs it; the tracks lose anyway
-        settle(inner);
-        u32 const cell = pair_max(inner, up);
-        if (local_) best[r % 4] = pair_max(best[r % 4], cell);
+        u32 const across = affine_ ? rows.e[affine_ ? r : 0] : rows.h[r]; // the horizontal branch: E, or left + gap
+        u32 cell;
+        if (local_) {
+            u32 inner = order::max3(across, substituted, k.zero_pair); // only the substitution branch needs the clamp; the tracks lose anyway
+            settle(inner);
+            cell = order::max2(inner, up);
+            if (wide_) best[r % 4] = order::max2(best[r % 4], cell);
+            else if (r % 2) best[r / 2 % 4] = order::max3(best[r / 2 % 4], pending, cell);
+            else pending = cell;
+        }
+        else if (wide_) {
+            u32 inner = order::max2(across, substituted);
+            settle(inner);
+            cell = order::max2(inner, up);
+        }
+        else cell = order::max3(across, substituted, up);
         u32 const opened = cell + k.open_pair;
         if (affine_) {
             rows.h[r] = cell;
-            rows.e[affine_ ? r : 0] = pair_max(opened, rows.e[affine_ ? r : 0] + k.extend_pair);
-            up = pair_max(opened, up + k.extend_pair);
+            rows.e[affine_ ? r : 0] = order::max2(opened, rows.e[affine_ ? r : 0] + k.extend_pair);
+            up = order::max2(opened, up + k.extend_pair);
         }
         else rows.h[r] = up = opened;
     }
@@ -197,10 +263,10 @@ struct team_step_t {
     }
 };
 
-template <bool local_, bool affine_, int R>
-SZS_HD team_edge_t team_advance(team_costs_t<local_, affine_> const &k, team_rows_t<affine_, R> &rows, u32 const *costs,
-                                team_edge_t above, u32 &diagonal, u32 (&best)[4]) {
-    team_step_t<local_, affine_, R> step;
+template <typename costs_t, int R>
+SZS_HD team_edge_t team_advance(costs_t const &k, team_rows_t<costs_t::affine, R> &rows, u32 const *costs, team_edge_t above,
+                                u32 &diagonal, u32 (&best)[4]) {
+    team_step_t<costs_t, R> step;
     step.begin(above, diagonal);
     for (int r = 0; r < R; ++r) step.row(k, rows, r, costs[r], best);
     return step.end(rows);

@@ -92,8 +92,10 @@ __device__ __forceinline__ parked_edge_t<affine_> park_of(team_edge_t const &edg
  *  @tparam L        lanes per team: 1, 2, 4, 8 or 16.
  *  @tparam R        registers per track = query rows per lane and pass (a multiple of 4).
  *  @tparam W        wavefronts per SIMD the registers are allocated for.
+ *  @tparam wide_    cells ordered as unsigned integers (two-input maxima, 16 bits of range) instead of as half-float
+ *                   patterns (three-input maxima, 15 bits): team_core.hpp.
  */
-template <bool local_, bool affine_, int L, int R, int W>
+template <bool local_, bool affine_, bool wide_, int L, int R, int W>
 __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
     szs_cost_model_t const *__restrict__ model, szs_string_ref_t const *__restrict__ queries, u32 queries_count,
     szs_string_ref_t const *__restrict__ candidates, u32 candidates_count, u32 candidate_blocks, i64 *__restrict__ results,
@@ -111,7 +113,8 @@ __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
     __shared__ u8 group_classes[2][group_rows];          // the classes of the group's rows, both queries; 0xFF: padded
     __shared__ u32 claimed_work;
 
-    team_costs_t<local_, affine_> const k(model->gap_open, model->gap_extend);
+    using costs_t = team_costs_t<local_, affine_, wide_>;
+    costs_t const k(model->gap_open, model->gap_extend);
     int16_t const *const table = model->substitution; // [query class][candidate class], 2 KB, cache-resident
     for (u32 byte = threadIdx.x; byte < 256; byte += team_block_threads_k)
         class_offset_of_byte[byte] = (unsigned short)(model->byte_to_class[byte] * layout::class_bytes);
@@ -200,14 +203,14 @@ __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
                     // cost(query, candidate) = table[class(query)][class(candidate)]: the QUERY picks the row (serial.hpp:199-204)
                     i32 const low = low_class != 0xFF ? table[low_class * 32 + symbol_class] : 0;
                     i32 const high = high_class != 0xFF ? table[high_class * 32 + symbol_class] : 0;
-                    entries[r] = profile_entry(k, low, high);
+                    entries[r] = k.profile_entry(low, high);
                 }
                 *reinterpret_cast<uint4 *>(profile + layout::strip_base(strip, classes) + symbol_class * layout::class_bytes + chunk * 16) =
                     make_uint4(entries[0], entries[1], entries[2], entries[3]);
             }
             __syncthreads();
 
-            team_seed<local_, affine_, R>(k, first_row + lane_in_team * R, rows, diagonal);
+            team_seed<costs_t, R>(k, first_row + lane_in_team * R, rows, diagonal);
 
             // One step of this lane at DP column `column`; `head_*`: what the head lane takes instead of a neighbour's output.
             auto hand_over = [&](team_edge_t const &head_edge, u32 head_row, team_edge_t &in, u32 &in_row) {
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
             // a chunk: left alone, hipcc hoists every read of all four steps of a batch (4 R registers) above the first row.
             auto advance = [&](team_edge_t const &in, u32 in_row) {
                 uint4 const *const row = reinterpret_cast<uint4 const *>(profile + strip_base + in_row);
-                team_step_t<local_, affine_, R> step;
+                team_step_t<costs_t, R> step;
                 step.begin(in, diagonal);
                 uint4 next = row[0];
 #pragma unroll
@@ -313,9 +316,9 @@ __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
             }
         }
         if constexpr (local_) {
-            u32 both_best = pair_max(pair_max(best[0], best[1]), pair_max(best[2], best[3]));
+            u32 both_best = costs_t::order::max2(costs_t::order::max2(best[0], best[1]), costs_t::order::max2(best[2], best[3]));
 #pragma unroll
-            for (int offset = 1; offset < L; offset <<= 1) both_best = pair_max(both_best, (u32)__shfl_xor((int)both_best, offset, 64));
+            for (int offset = 1; offset < L; offset <<= 1) both_best = costs_t::order::max2(both_best, (u32)__shfl_xor((int)both_best, offset, 64));
             if (is_head) {
                 if (live_low) write_result(query_low, candidate, (i64)k.truth((u32)low_of(both_best)));
                 if (live_high && query_high.length) write_result(query_high, candidate, (i64)k.truth((u32)high_of(both_best)));
@@ -328,7 +331,7 @@ template <int L, int R>
 static size_t team_profile_bytes(u32 classes) { return team_profile_layout<L, R>::total_bytes(classes); }
 
 /** Workgroups that can be RESIDENT at once for this kernel instance with this profile size. */
-template <bool local_, bool affine_, int L, int R, int W>
+template <bool local_, bool affine_, bool wide_, int L, int R, int W>
 static u32 team_grid(u64 work_items, u32 classes) {
     static int resident_of[device_slots_k][34]; // per instance, device ordinal and class count
     int *const slot = &resident_of[device_slot()][classes];
@@ -336,11 +339,11 @@ static u32 team_grid(u64 work_items, u32 classes) {
     if (!resident) {
         int device = 0, units = 0, per_unit = 0;
         size_t const profile_bytes = team_profile_bytes<L, R>(classes);
-        if (hipFuncSetAttribute(reinterpret_cast<void const *>(weighted_team_kernel<local_, affine_, L, R, W>),
+        if (hipFuncSetAttribute(reinterpret_cast<void const *>(weighted_team_kernel<local_, affine_, wide_, L, R, W>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)team_profile_bytes<L, R>(32)) != hipSuccess ||
             hipGetDevice(&device) != hipSuccess ||
             hipDeviceGetAttribute(&units, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_unit, weighted_team_kernel<local_, affine_, L, R, W>,
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_unit, weighted_team_kernel<local_, affine_, wide_, L, R, W>,
                                                          (int)team_block_threads_k, profile_bytes) != hipSuccess ||
             units <= 0 || per_unit <= 0) {
             (void)hipGetLastError();
@@ -360,17 +363,21 @@ static u64 team_work_items(u32 queries_count, u32 candidates_count) {
 
 } // namespace szs_hip
 
-/* The instances that are compiled: (lanes per team, registers per track, wavefronts per SIMD). */
+/* The instances that are compiled: (lanes per team, registers per track, wavefronts per SIMD), each in both orders. */
 #ifndef SZS_TEAM_SHAPES
-#define SZS_TEAM_SHAPES(CALL) CALL(16, 32, 2) CALL(16, 32, 3) CALL(16, 24, 3) CALL(16, 16, 4) CALL(4, 32, 2) CALL(2, 32, 2) CALL(1, 32, 2)
+#define SZS_TEAM_SHAPES(CALL) CALL(16, 32, 2) CALL(16, 16, 4) CALL(4, 32, 2) CALL(1, 32, 2)
 #endif
 
 #define SZS_TEAM_DISPATCH(L, R, W, CALL)                                                                               \
     if (shape == L * 10000u + R * 100u + W) {                                                                          \
-        if (local && affine) CALL(true, true, L, R, W);                                                                \
-        if (local) CALL(true, false, L, R, W);                                                                         \
-        if (affine) CALL(false, true, L, R, W);                                                                        \
-        CALL(false, false, L, R, W);                                                                                   \
+        if (local && affine && wide) CALL(true, true, true, L, R, W);                                                  \
+        if (local && affine) CALL(true, true, false, L, R, W);                                                         \
+        if (local && wide) CALL(true, false, true, L, R, W);                                                           \
+        if (local) CALL(true, false, false, L, R, W);                                                                  \
+        if (affine && wide) CALL(false, true, true, L, R, W);                                                          \
+        if (affine) CALL(false, true, false, L, R, W);                                                                 \
+        if (wide) CALL(false, false, true, L, R, W);                                                                   \
+        CALL(false, false, false, L, R, W);                                                                            \
     }
 
 extern "C" unsigned szs_hip_weighted_team_shape(unsigned index) {
@@ -388,12 +395,14 @@ extern "C" int szs_hip_weighted_team_has_shape(unsigned shape) {
     return 0;
 }
 
-extern "C" size_t szs_hip_weighted_team_workspace_bytes(int local, int affine, unsigned shape, uint32_t classes, uint32_t queries_count,
-                                                        uint32_t candidates_count, uint32_t longest_candidate) {
+extern "C" uint32_t szs_hip_weighted_team_reach_limit(int local, int wide) { return szs_team::team_reach_limit(local != 0, wide != 0); }
+
+extern "C" size_t szs_hip_weighted_team_workspace_bytes(int local, int affine, int wide, unsigned shape, uint32_t classes,
+                                                        uint32_t queries_count, uint32_t candidates_count, uint32_t longest_candidate) {
     using namespace szs_hip;
     if (classes > 32) return 0;
-#define SZS_TEAM_BYTES(LOCAL, AFFINE, L, R, W)                                                                         \
-    return team_header_bytes_k + (size_t)team_grid<LOCAL, AFFINE, L, R, W>(team_work_items<L>(queries_count, candidates_count), classes) * \
+#define SZS_TEAM_BYTES(LOCAL, AFFINE, WIDE, L, R, W)                                                                   \
+    return team_header_bytes_k + (size_t)team_grid<LOCAL, AFFINE, WIDE, L, R, W>(team_work_items<L>(queries_count, candidates_count), classes) * \
                                      (longest_candidate + 1 + team_slack_columns_k) * (team_block_threads_k / L) *     \
                                      sizeof(parked_edge_t<AFFINE>)
 #define SZS_TEAM_SHAPE_BYTES(L, R, W) SZS_TEAM_DISPATCH(L, R, W, SZS_TEAM_BYTES)
@@ -403,7 +412,7 @@ extern "C" size_t szs_hip_weighted_team_workspace_bytes(int local, int affine, u
     return 0;
 }
 
-extern "C" int szs_hip_weighted_team_scores(int local, int affine, unsigned shape, uint32_t classes, szs_cost_model_t const *model,
+extern "C" int szs_hip_weighted_team_scores(int local, int affine, int wide, unsigned shape, uint32_t classes, szs_cost_model_t const *model,
                                             szs_string_ref_t const *queries, uint32_t queries_count, szs_string_ref_t const *candidates,
                                             uint32_t candidates_count, uint32_t longest_candidate, int64_t *results,
                                             uint64_t results_row_stride, int layout_flags, void *workspace, void *stream) {
@@ -413,16 +422,16 @@ extern "C" int szs_hip_weighted_team_scores(int local, int affine, unsigned shap
     u32 *const counter = static_cast<u32 *>(workspace);
     char *const parked = static_cast<char *>(workspace) + team_header_bytes_k;
     hipStream_t const s = static_cast<hipStream_t>(stream);
-#define SZS_TEAM_LAUNCH(LOCAL, AFFINE, L, R, W)                                                                        \
+#define SZS_TEAM_LAUNCH(LOCAL, AFFINE, WIDE, L, R, W)                                                                  \
     {                                                                                                                  \
         u64 const work_items = team_work_items<L>(queries_count, candidates_count);                                    \
         if (work_items > 0xFFFFFFF0ull) return (int)hipErrorInvalidValue; /* the host cuts larger cross-products */     \
         hipError_t const error = hipMemsetAsync(counter, 0, sizeof(u32), s);                                           \
         if (error != hipSuccess) return (int)error;                                                                    \
-        u32 const grid = team_grid<LOCAL, AFFINE, L, R, W>(work_items, classes);                                       \
+        u32 const grid = team_grid<LOCAL, AFFINE, WIDE, L, R, W>(work_items, classes);                                 \
         u32 const teams = team_block_threads_k / L;                                                                    \
         size_t const profile_bytes = team_profile_bytes<L, R>(classes);                                                \
-        hipLaunchKernelGGL((weighted_team_kernel<LOCAL, AFFINE, L, R, W>), dim3(grid), dim3(team_block_threads_k),     \
+        hipLaunchKernelGGL((weighted_team_kernel<LOCAL, AFFINE, WIDE, L, R, W>), dim3(grid), dim3(team_block_threads_k), \
                            profile_bytes, s, model, queries, queries_count, candidates,                                \
                            candidates_count, (candidates_count + teams - 1) / teams, results, results_row_stride,      \
                            layout_flags, parked, longest_candidate + 1 + team_slack_columns_k, counter, classes);      \

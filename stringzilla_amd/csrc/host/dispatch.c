@@ -371,8 +371,15 @@ static sz_status_t decide(szs_engine_s const *engine, int symmetric, int runes, 
         d->tier = SZS_TIER_LANES, d->packed = 0, d->narrow = 0;
     /* The team tier (hip/weighted_teams.hip) scores what the packed kernel scores - same bounds, same refs - with a pair
      * spread over the lanes of a DPP row.  The `team` knob pins a shape or (0) the one-pair-per-lane kernel. */
-    d->team = 0;
-    if (d->packed && d->tier == SZS_TIER_LANES) d->team = team_shape_for(kq, kc);
+    d->team = 0, d->team_wide = 0;
+    if (d->maximise && !d->wide_cells && d->classes <= 32 && d->tier == SZS_TIER_LANES && szs_tuning_get(szs_knob_packed_k) != 0 &&
+        (d->objective == szs_objective_global_k || d->objective == szs_objective_local_saturating_k)) {
+        int const local = d->objective == szs_objective_local_saturating_k;
+        uint64_t const bound = local ? (shorter_side + 3) * magnitude : reach; /* what bounds every H and track value */
+        d->team_wide = bound >= szs_hip_weighted_team_reach_limit(local, 0);
+        if (bound < szs_hip_weighted_team_reach_limit(local, d->team_wide)) d->team = team_shape_for(kq, kc);
+        if (d->team) d->packed = 1, d->packed_local = local; /* the profile reports 16-bit cells either way */
+    }
 
     /* The systolic tier scores every engine family with its weighted recurrences, so it needs the cost model and its
      * own workspace; a job with too many pairs in flight for that workspace stays on the lanes tier. */
@@ -413,7 +420,7 @@ static sz_status_t upload_model(szs_engine_s *engine, szs_decision_t const *d, i
 /** Size of the weighted lanes kernels' strip workspace for this decision. */
 static size_t weighted_boundary_bytes(szs_engine_s const *engine, szs_decision_t const *d) {
     if (d->team)
-        return szs_hip_weighted_team_workspace_bytes(d->packed_local, !engine->is_linear, d->team, d->classes, d->kq_count, d->kc_count,
+        return szs_hip_weighted_team_workspace_bytes(d->packed_local, !engine->is_linear, d->team_wide, d->team, d->classes, d->kq_count, d->kc_count,
                                                      d->plan.longest_candidate);
     return d->packed ? szs_hip_weighted_packed_boundary_bytes(d->packed_local, !engine->is_linear, d->classes, d->kq_count, d->kc_count,
                                                               d->plan.longest_candidate)
@@ -647,7 +654,7 @@ static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int dev
             }
             else if (d->team) {
                 *cell_bits = 16;
-                launch_error = szs_hip_weighted_team_scores(d->packed_local, !engine->is_linear, d->team, d->classes, model, queries, count,
+                launch_error = szs_hip_weighted_team_scores(d->packed_local, !engine->is_linear, d->team_wide, d->team, d->classes, model, queries, count,
                                                             candidate_refs, d->kc_count, d->plan.longest_candidate, (int64_t *)device_results,
                                                             device_stride, d->layout, engine->device_boundary.pointer, target);
             }
@@ -748,6 +755,7 @@ static sz_status_t finish(szs_call_t *call, szs_decision_t const *d, hipError_t 
     profile->transposed = (uint32_t)d->transposed;
     profile->cell_bits = cell_bits;
     profile->team = cell_bits == 16 ? d->team : 0;
+    profile->team_wide = profile->team ? (uint32_t)d->team_wide : 0;
     profile->longest_query = d->longest[0], profile->longest_candidate = d->longest[1];
     profile->host_milliseconds = now_milliseconds() - call->started;
     phase(call, 5);

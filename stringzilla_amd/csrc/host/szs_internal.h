@@ -192,6 +192,7 @@ typedef struct szs_decision_t {
     int tier, transposed, layout;
     int use_myers, banded, maximise;
     int objective, narrow, packed, packed_local, wide_cells;
+    int team_wide;             /* the team tier's cell order: 0 half-float patterns (three-input maxima), 1 unsigned (hip/team_core.hpp) */
     unsigned team;             /* 0, or the shape of the team tier that scores the call (hip/kernels.h: lanes * 10000 + registers * 100 + waves) */
     uint32_t classes;
     uint32_t kq_count, kc_count; /* kernel roles */

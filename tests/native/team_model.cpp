@@ -24,11 +24,12 @@ struct text_t {
     uint32_t length;
 };
 
-template <bool local_, bool affine_, int L, int R>
+template <bool local_, bool affine_, bool wide_, int L, int R>
 void score_item(text_t q_low, text_t q_high, bool has_high, std::vector<text_t> const &block, uint8_t const *byte_to_class,
                 int8_t const *class_costs, int open, int extend, int64_t *out_low, int64_t *out_high) {
     constexpr uint32_t teams_per_wave = 64 / L;
-    team_costs_t<local_, affine_> const k(open, extend);
+    using costs_t = team_costs_t<local_, affine_, wide_>;
+    costs_t const k(open, extend);
     uint32_t const teams = (uint32_t)block.size();
     uint32_t const longer = q_low.length; // the queries arrive longest first
     for (uint32_t team = 0; team < teams; ++team) {
@@ -67,12 +68,12 @@ void score_item(text_t q_low, text_t q_high, bool has_high, std::vector<text_t> 
                     uint32_t const row = first_row + strip * R + r;
                     int const low = row < q_low.length && symbol_class < 32 ? class_costs[byte_to_class[q_low.bytes[row]] * 32 + symbol_class] : 0;
                     int const high = has_high && row < q_high.length && symbol_class < 32 ? class_costs[byte_to_class[q_high.bytes[row]] * 32 + symbol_class] : 0;
-                    profile[((size_t)strip * 33 + symbol_class) * R + r] = profile_entry(k, low, high);
+                    profile[((size_t)strip * 33 + symbol_class) * R + r] = k.profile_entry(low, high);
                 }
         for (uint32_t team = 0; team < teams; ++team)
             for (uint32_t lane = 0; lane < (uint32_t)L; ++lane) {
                 lane_t &state = lanes[(size_t)team * L + lane];
-                team_seed<local_, affine_, R>(k, first_row + lane * R, state.rows, state.diagonal);
+                team_seed<costs_t, R>(k, first_row + lane * R, state.rows, state.diagonal);
             }
 
         for (uint32_t wave_first = 0; wave_first < teams; wave_first += teams_per_wave) {
@@ -107,7 +108,7 @@ void score_item(text_t q_low, text_t q_high, bool has_high, std::vector<text_t> 
                             continue;
                         }
                         uint32_t const *costs = &profile[((size_t)lane * 33 + in_class[lane]) * R];
-                        state.out = team_advance<local_, affine_, R>(k, state.rows, costs, in[lane], state.diagonal, state.best);
+                        state.out = team_advance<costs_t, R>(k, state.rows, costs, in[lane], state.diagonal, state.best);
                         state.out_class = in_class[lane];
                         if (lane == (uint32_t)L - 1 && pass + 1 < passes) parked[(size_t)column * teams + team] = state.out;
                     }
@@ -144,7 +145,7 @@ void score_item(text_t q_low, text_t q_high, bool has_high, std::vector<text_t> 
     }
 }
 
-template <bool local_, bool affine_, int L, int R>
+template <bool local_, bool affine_, bool wide_, int L, int R>
 void cross(text_t const *queries, uint32_t queries_count, text_t const *candidates, uint32_t candidates_count,
            uint8_t const *byte_to_class, int8_t const *class_costs, int open, int extend, int64_t *results, uint64_t stride) {
     // the kernel's roles: queries longest first, candidates by ascending length, 256 / L candidates per block
@@ -163,7 +164,7 @@ void cross(text_t const *queries, uint32_t queries_count, text_t const *candidat
             std::vector<text_t> block(count);
             for (uint32_t i = 0; i < count; ++i) block[i] = candidates[c_order[first + i]];
             std::vector<int64_t> out_low(count), out_high(count);
-            score_item<local_, affine_, L, R>(queries[low], queries[high], has_high, block, byte_to_class, class_costs, open, extend,
+            score_item<local_, affine_, wide_, L, R>(queries[low], queries[high], has_high, block, byte_to_class, class_costs, open, extend,
                                               out_low.data(), out_high.data());
             for (uint32_t i = 0; i < count; ++i) {
                 results[(uint64_t)low * stride + c_order[first + i]] = out_low[i];
@@ -177,21 +178,27 @@ void cross(text_t const *queries, uint32_t queries_count, text_t const *candidat
 
 #define TEAM_SHAPES(CALL) CALL(16, 32) CALL(16, 16) CALL(16, 24) CALL(8, 32) CALL(4, 32) CALL(4, 8) CALL(2, 16) CALL(1, 32) CALL(1, 4)
 
-/** Tapes with count + 1 64-bit offsets; results[q * stride + c].  Returns 0, or -1 for a shape that is not instantiated. */
-extern "C" int team_model_cross(int local, int affine, int lanes, int registers, char const *q_data, uint64_t const *q_offsets,
+/** Tapes with count + 1 64-bit offsets; results[q * stride + c].  `wide`: cells ordered as unsigned integers (two-input maxima)
+ *  instead of as half-float patterns.  Returns 0, or -1 for a shape that is not instantiated. */
+extern "C" int team_model_cross(int local, int affine, int wide, int lanes, int registers, char const *q_data, uint64_t const *q_offsets,
                                 uint32_t q_count, char const *c_data, uint64_t const *c_offsets, uint32_t c_count,
                                 uint8_t const *byte_to_class, int8_t const *class_costs, int open, int extend, int64_t *results,
                                 uint64_t stride) {
     std::vector<text_t> queries(q_count), candidates(c_count);
     for (uint32_t i = 0; i < q_count; ++i) queries[i] = {(uint8_t const *)q_data + q_offsets[i], (uint32_t)(q_offsets[i + 1] - q_offsets[i])};
     for (uint32_t i = 0; i < c_count; ++i) candidates[i] = {(uint8_t const *)c_data + c_offsets[i], (uint32_t)(c_offsets[i + 1] - c_offsets[i])};
+#define TEAM_ARGUMENTS queries.data(), q_count, candidates.data(), c_count, byte_to_class, class_costs, open, extend, results, stride
+#define TEAM_ORDER(WIDE, L, R)                                                                                                   \
+    {                                                                                                                            \
+        if (local && affine) cross<true, true, WIDE, L, R>(TEAM_ARGUMENTS);                                                      \
+        else if (local) cross<true, false, WIDE, L, R>(TEAM_ARGUMENTS);                                                          \
+        else if (affine) cross<false, true, WIDE, L, R>(TEAM_ARGUMENTS);                                                         \
+        else cross<false, false, WIDE, L, R>(TEAM_ARGUMENTS);                                                                    \
+        return 0;                                                                                                                \
+    }
 #define TEAM_CALL(L, R)                                                                                                          \
     if (lanes == L && registers == R) {                                                                                          \
-        if (local && affine) cross<true, true, L, R>(queries.data(), q_count, candidates.data(), c_count, byte_to_class, class_costs, open, extend, results, stride); \
-        else if (local) cross<true, false, L, R>(queries.data(), q_count, candidates.data(), c_count, byte_to_class, class_costs, open, extend, results, stride);     \
-        else if (affine) cross<false, true, L, R>(queries.data(), q_count, candidates.data(), c_count, byte_to_class, class_costs, open, extend, results, stride);    \
-        else cross<false, false, L, R>(queries.data(), q_count, candidates.data(), c_count, byte_to_class, class_costs, open, extend, results, stride);               \
-        return 0;                                                                                                                \
+        if (wide) TEAM_ORDER(true, L, R) else TEAM_ORDER(false, L, R)                                                            \
     }
     TEAM_SHAPES(TEAM_CALL)
 #undef TEAM_CALL

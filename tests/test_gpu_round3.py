@@ -107,3 +107,28 @@ def test_team_tier_long_candidates(gpu, oracle, kind):
                 assert engine.last_call_profile().team == shape
                 wrong = np.argwhere(got != expected)
                 assert wrong.size == 0, (kind, shape, gaps, wrong[:5].tolist())
+
+
+@pytest.mark.parametrize("kind", ["needleman_wunsch", "smith_waterman"])
+def test_team_tier_cell_orders(gpu, oracle, kind):
+    """The team tier keeps its cells as half-float patterns (three-input maxima) while every DP value provably stays inside
+    15 bits, as unsigned integers (two-input maxima) up to 16, and leaves the call to the 32-bit kernels beyond
+    (csrc/hip/team_core.hpp).  One batch on each side of both limits, scores near the top of the range included."""
+    rng = random.Random(31)
+    cls = szs.NeedlemanWunschScores if kind == "needleman_wunsch" else szs.SmithWatermanScores
+    table, alphabet = matrices.blosum62(), b"ARNDCQEGHILKMFPSTWYV"  # largest magnitude 11
+    shape = _abi.team_shapes()[0]
+    # global: reach = (rows + columns + 3) x 11; local: (shorter side + 3) x 11
+    sizes = {"needleman_wunsch": [(600, 0, True), (1300, 1, True), (2000, None, False)],
+             "smith_waterman": [(2500, 0, True), (3000, 1, True), (6000, None, False)]}[kind]
+    for length, wide, teamed in sizes:
+        engine = cls(*table, open=-11, extend=-1, capabilities=gpu)
+        core = bytes(rng.choice(alphabet) for _ in range(length))
+        queries = [core, core[: length - 9] + b"WWWWWWWWW", bytes(rng.choice(alphabet) for _ in range(length - 3))]
+        candidates = [core, core[5:] + b"ARNDC"] + _rand(rng, 6, length - 40, length, alphabet) + [b"", b"W"]
+        expected = getattr(oracle, kind)(queries, candidates, *table, -11, -1)
+        with forced_env("team", shape), forced_tier("lanes"):
+            got = engine(queries, candidates, device=gpu)
+            profile = engine.last_call_profile()
+            assert (profile.team == shape) == teamed and (not teamed or profile.team_wide == wide), (length, profile.team, profile.team_wide)
+            assert np.array_equal(got, expected), (kind, length)

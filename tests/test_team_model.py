@@ -31,14 +31,14 @@ def model():
     return library
 
 
-def run_model(model, local, affine, lanes, registers, queries, candidates, byte_to_class, class_costs, open, extend):
+def run_model(model, local, affine, wide, lanes, registers, queries, candidates, byte_to_class, class_costs, open, extend):
     q_data, q_off = binding.make_tape(queries)
     c_data, c_off = binding.make_tape(candidates)
     results = np.full((len(queries), max(len(candidates), 1)), -777, dtype=np.int64)
     table = np.ascontiguousarray(class_costs, dtype=np.int8).reshape(-1)
     classes = np.ascontiguousarray(byte_to_class, dtype=np.uint8)
     p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-    status = model.team_model_cross(int(local), int(affine), lanes, registers, p(q_data), p(q_off), len(queries), p(c_data),
+    status = model.team_model_cross(int(local), int(affine), int(wide), lanes, registers, p(q_data), p(q_off), len(queries), p(c_data),
                                     p(c_off), len(candidates), p(classes), p(table), int(open), int(extend), p(results),
                                     ctypes.c_uint64(results.shape[1]))
     assert status == 0, "shape not instantiated in team_model.cpp"
@@ -63,8 +63,9 @@ SHAPES = [(16, 32), (16, 16), (16, 24), (8, 32), (4, 32), (4, 8), (2, 16), (1, 3
 
 
 @pytest.mark.parametrize("lanes,registers", SHAPES)
+@pytest.mark.parametrize("wide", [0, 1])
 @pytest.mark.parametrize("local,affine", [(0, 0), (0, 1), (1, 0), (1, 1)])
-def test_model_agrees_with_the_oracle(model, lanes, registers, local, affine):
+def test_model_agrees_with_the_oracle(model, lanes, registers, local, affine, wide):
     rng = np.random.default_rng(1000 * lanes + 10 * registers + 2 * local + affine)
     oracle = binding.oracle()
     rows = lanes * registers
@@ -88,7 +89,7 @@ def test_model_agrees_with_the_oracle(model, lanes, registers, local, affine):
         open, extend = (int(rng.integers(-7, 0)), int(rng.integers(-3, 1))) if affine else (int(rng.integers(-6, 0)),) * 2
         if trial == 0:
             open, extend = (-4, -1) if affine else (-4, -4)
-        got = run_model(model, local, affine, lanes, registers, queries, candidates, *table, open, extend)
+        got = run_model(model, local, affine, wide, lanes, registers, queries, candidates, *table, open, extend)
         scorer = oracle.smith_waterman if local else oracle.needleman_wunsch
         expected = scorer(queries, candidates, *table, open, extend)
         mismatches = np.argwhere(got != expected)
@@ -106,5 +107,35 @@ def test_model_positive_gaps_of_a_global_engine(model):
     queries = random_strings(rng, 6, 1, 150, b"ABCDEFGH")
     candidates = random_strings(rng, 40, 0, 60, b"ABCDEFGH")
     for affine, (open, extend) in [(0, (2, 2)), (1, (3, 1)), (1, (-2, 1))]:
-        got = run_model(model, 0, affine, 16, 16, queries, candidates, *table, open, extend)
-        assert np.array_equal(got, oracle.needleman_wunsch(queries, candidates, *table, open, extend))
+        for wide in (0, 1):
+            got = run_model(model, 0, affine, wide, 16, 16, queries, candidates, *table, open, extend)
+            assert np.array_equal(got, oracle.needleman_wunsch(queries, candidates, *table, open, extend))
+
+
+@pytest.mark.parametrize("wide", [0, 1])
+def test_model_at_the_edge_of_its_range(model, wide):
+    """Scores as large as an instance is allowed to see (team_core.hpp: team_reach_limit): long runs of the best-scoring
+    symbol, the largest costs a table can hold, the longest gaps.  The host model orders half-float PATTERNS the way the
+    hardware orders the floats, so a cell that left the normal range would come out wrong here too."""
+    oracle = binding.oracle()
+    byte_to_class = np.zeros(256, np.uint8)
+    byte_to_class[ord("A")], byte_to_class[ord("B")] = 1, 2
+    table = np.zeros((32, 32), np.int8)
+    table[1, 1], table[2, 2], table[1, 2], table[2, 1] = 127, 120, -128, -127
+    # local: (shorter side + 3) x 127 just below the limit
+    limit = 62000 if wide else 29000
+    length = limit // 127 - 3
+    queries = [b"A" * length, b"A" * (length - 5) + b"B" * 5, b"AB" * (length // 2)]
+    candidates = [b"A" * length, b"A" * (length // 2) + b"B" + b"A" * (length // 2 - 1), b"B" * 40]
+    for affine, gaps in [(1, (-128, -1)), (0, (-100, -100))]:
+        got = run_model(model, 1, affine, wide, 16, 16, queries, candidates, byte_to_class, table, *gaps)
+        expected = oracle.smith_waterman(queries, candidates, byte_to_class, table, *gaps)
+        assert np.array_equal(got, expected) and expected.max() > 0.9 * limit
+    # global: reach (rows + columns + 3) x 128 just below the limit, scores at both ends of the range
+    limit = 32000 if wide else 15000
+    length = (limit // 128 - 3) // 2
+    queries = [b"A" * length, b"B" * length, b"AB" * (length // 2)]
+    candidates = [b"A" * length, b"B" * length, b"A", b""]
+    for affine, gaps in [(1, (-128, -128 + 1)), (0, (-128, -128)), (1, (-3, -1))]:
+        got = run_model(model, 0, affine, wide, 16, 16, queries, candidates, byte_to_class, table, *gaps)
+        assert np.array_equal(got, oracle.needleman_wunsch(queries, candidates, byte_to_class, table, *gaps))
