@@ -222,11 +222,12 @@ struct team_step_t {
     using order = typename costs_t::order;
     u32 diag, up; // H of the row above at the previous column; affine: F entering the row, linear: H + gap of the row above
     u32 pending;  // local, narrow order: the cell of the even row, waiting for its odd neighbour
+    u32 bottom;   // what the last row scored hands down as `h`
 
     SZS_HD void begin(team_edge_t const &above, u32 &diagonal) {
         diag = diagonal, diagonal = above.h;
         up = affine_ ? above.f : above.h;
-        pending = 0;
+        pending = 0, bottom = 0;
     }
     /** Row `r`: serial.hpp:1091-1102, 1238-1239 (affine), 846-848, 957-965 (linear). */
     SZS_HD void row(costs_t const &k, team_rows_t<affine_, R> &rows, int r, u32 cost, u32 (&best)[4]) {
@@ -250,37 +251,54 @@ struct team_step_t {
         else cell = order::max3(across, substituted, up);
         u32 const opened = cell + k.open_pair;
         if (affine_) {
-            rows.h[r] = cell;
+            rows.h[r] = bottom = cell;
             rows.e[affine_ ? r : 0] = order::max2(opened, rows.e[affine_ ? r : 0] + k.extend_pair);
             up = order::max2(opened, up + k.extend_pair);
         }
-        else rows.h[r] = up = opened;
+        else rows.h[r] = up = bottom = opened;
     }
-    SZS_HD team_edge_t end(team_rows_t<affine_, R> const &rows) const {
+    /** After the rows that the pass holds - all R of them, or fewer in the last pass (team_pass_registers). */
+    SZS_HD team_edge_t end() const {
         team_edge_t below;
-        below.h = rows.h[R - 1], below.f = affine_ ? up : 0u;
+        below.h = bottom, below.f = affine_ ? up : 0u;
         return below;
     }
 };
 
+/** The first `registers` rows of a strip (a multiple of four, at most R). */
 template <typename costs_t, int R>
 SZS_HD team_edge_t team_advance(costs_t const &k, team_rows_t<costs_t::affine, R> &rows, u32 const *costs, team_edge_t above,
-                                u32 &diagonal, u32 (&best)[4]) {
+                                u32 &diagonal, u32 (&best)[4], u32 registers) {
     team_step_t<costs_t, R> step;
     step.begin(above, diagonal);
-    for (int r = 0; r < R; ++r) step.row(k, rows, r, costs[r], best);
-    return step.end(rows);
+    for (u32 r = 0; r < registers; ++r) step.row(k, rows, (int)r, costs[r], best);
+    return step.end();
 }
+
+/* ---- passes ------------------------------------------------------------------------------------------------------------
+ *  A team walks the longer query of its pair in passes of L x R rows, lane k on the rows [first + k R, first + (k + 1) R).
+ *  The LAST pass rarely has L x R rows left: it deals what is left in chunks of four registers, the same number to every
+ *  lane, so that a pair wastes fewer than 4 L padded rows instead of half a pass on average (config 3's 512-row proteins
+ *  on sixteen lanes x sixteen registers: a quarter of all rows). */
 
 /** Passes over the candidate that a pair of queries needs: the LONGER one decides. */
 template <int L, int R>
 SZS_HD u32 team_passes(u32 longer_query) { return (longer_query + (u32)L * R - 1) / ((u32)L * R); }
 
-/** Where the last DP row of a query of `length` > 0 lives: pass, lane of the team, register. */
+/** Registers (rows per lane) of pass `pass`: R, or in the last pass the rows left over L lanes, rounded up to a chunk. */
 template <int L, int R>
-SZS_HD void team_last_row(u32 length, u32 &pass, u32 &lane, u32 &reg) {
+SZS_HD u32 team_pass_registers(u32 longer_query, u32 pass) {
+    u32 const left = longer_query - pass * (u32)L * R;
+    return left >= (u32)L * R ? (u32)R : (left + 4 * (u32)L - 1) / (4 * (u32)L) * 4;
+}
+
+/** Where the last DP row of a query of `length` > 0 lives when its pair's longer query has `longer_query` rows. */
+template <int L, int R>
+SZS_HD void team_last_row(u32 length, u32 longer_query, u32 &pass, u32 &lane, u32 &reg) {
     u32 const row = length - 1;
-    pass = row / ((u32)L * R), lane = row % ((u32)L * R) / (u32)R, reg = row % (u32)R;
+    pass = row / ((u32)L * R);
+    u32 const registers = team_pass_registers<L, R>(longer_query, pass), within = row - pass * (u32)L * R;
+    lane = within / registers, reg = within % registers;
 }
 
 /* ---- the cost profile in LDS ------------------------------------------------------------------------------------------

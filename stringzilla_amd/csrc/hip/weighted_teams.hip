@@ -185,17 +185,22 @@ __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
             u32 const first_row = pass * group_rows;
             bool const park_this_pass = pass + 1 < passes;
 
+            // Rows per lane in this pass: R, or - last pass - what is left over L lanes in whole chunks of four (team_core.hpp).
+            u32 const registers_now = (u32)__builtin_amdgcn_readfirstlane((int)team_pass_registers<L, R>(longer, pass));
+            u32 const chunks_now = registers_now / 4;
+
             // ---- the profile of the group's L strips: thread -> (strip, class, chunk of 4 registers)
             __syncthreads(); // everyone is done with the previous pass's profile; the prefilled rows are written
-            for (u32 slot = threadIdx.x; slot < 2 * group_rows; slot += team_block_threads_k) {
-                szs_string_ref_t const &query = slot < group_rows ? query_low : query_high;
-                u32 const row = first_row + slot % group_rows;
-                group_classes[slot / group_rows][slot % group_rows] =
+            for (u32 slot = threadIdx.x; slot < 2 * (u32)L * registers_now; slot += team_block_threads_k) {
+                u32 const half = slot / ((u32)L * registers_now), within = slot % ((u32)L * registers_now);
+                szs_string_ref_t const &query = half ? query_high : query_low;
+                u32 const row = first_row + within;
+                group_classes[half][within / registers_now * R + within % registers_now] =
                     row < query.length ? model->byte_to_class[reinterpret_cast<u8 const *>(query.address)[row]] : (u8)0xFF;
             }
             __syncthreads();
-            for (u32 slot = threadIdx.x; slot < (u32)L * classes * (R / 4); slot += team_block_threads_k) {
-                u32 const chunk = slot % (R / 4), symbol_class = slot / (R / 4) % classes, strip = slot / (R / 4) / classes;
+            for (u32 slot = threadIdx.x; slot < (u32)L * classes * chunks_now; slot += team_block_threads_k) {
+                u32 const chunk = slot % chunks_now, symbol_class = slot / chunks_now % classes, strip = slot / chunks_now / classes;
                 u32 entries[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
             }
             __syncthreads();
 
-            team_seed<costs_t, R>(k, first_row + lane_in_team * R, rows, diagonal);
+            team_seed<costs_t, R>(k, first_row + lane_in_team * registers_now, rows, diagonal);
 
             // One step of this lane at DP column `column`; `head_*`: what the head lane takes instead of a neighbour's output.
             auto hand_over = [&](team_edge_t const &head_edge, u32 head_row, team_edge_t &in, u32 &in_row) {
@@ -227,13 +232,15 @@ __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
                 uint4 next = row[0];
 #pragma unroll
                 for (int chunk = 0; chunk < R / 4; ++chunk) {
-                    uint4 const now = next;
-                    if (chunk + 1 < R / 4) next = row[chunk + 1];
-                    step.row(k, rows, 4 * chunk + 0, now.x, best), step.row(k, rows, 4 * chunk + 1, now.y, best);
-                    step.row(k, rows, 4 * chunk + 2, now.z, best), step.row(k, rows, 4 * chunk + 3, now.w, best);
-                    __builtin_amdgcn_sched_barrier(0);
+                    if ((u32)chunk < chunks_now) { // wavefront-uniform: a scalar branch per chunk, taken only in a short last pass
+                        uint4 const now = next;
+                        if (chunk + 1 < R / 4 && (u32)chunk + 1 < chunks_now) next = row[chunk + 1];
+                        step.row(k, rows, 4 * chunk + 0, now.x, best), step.row(k, rows, 4 * chunk + 1, now.y, best);
+                        step.row(k, rows, 4 * chunk + 2, now.z, best), step.row(k, rows, 4 * chunk + 3, now.w, best);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
-                out = step.end(rows);
+                out = step.end();
                 out_row = in_row;
             };
             // Predicated step `t`: the head's column is t + 1, this lane's is t + 1 - lane_in_team.
@@ -305,7 +312,7 @@ __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
                     szs_string_ref_t const &query = half ? query_high : query_low;
                     if (!query.length) continue;
                     u32 last_pass, last_lane, last_reg;
-                    team_last_row<L, R>(query.length, last_pass, last_lane, last_reg);
+                    team_last_row<L, R>(query.length, longer, last_pass, last_lane, last_reg);
                     if (pass != last_pass || lane_in_team != last_lane || !(half ? live_high : live_low)) continue;
                     u32 cell = 0;
 #pragma unroll
@@ -365,7 +372,7 @@ static u64 team_work_items(u32 queries_count, u32 candidates_count) {
 
 /* The instances that are compiled: (lanes per team, registers per track, wavefronts per SIMD), each in both orders. */
 #ifndef SZS_TEAM_SHAPES
-#define SZS_TEAM_SHAPES(CALL) CALL(16, 32, 2) CALL(16, 16, 4) CALL(4, 32, 2) CALL(1, 32, 2)
+#define SZS_TEAM_SHAPES(CALL) CALL(16, 32, 2) CALL(16, 32, 3) CALL(16, 24, 3) CALL(16, 16, 4) CALL(8, 32, 2) CALL(4, 32, 2) CALL(1, 32, 2)
 #endif
 
 #define SZS_TEAM_DISPATCH(L, R, W, CALL)                                                                               \

@@ -60,12 +60,13 @@ void score_item(text_t q_low, text_t q_high, bool has_high, std::vector<text_t> 
 
     for (uint32_t pass = 0; pass < passes; ++pass) {
         uint32_t const first_row = pass * L * R;
+        uint32_t const registers = team_pass_registers<L, R>(longer, pass); // rows per lane in this pass
         // ---- the profile of the L strips: [strip][class][register]
         std::vector<uint32_t> profile((size_t)L * 33 * R);
         for (uint32_t strip = 0; strip < (uint32_t)L; ++strip)
             for (uint32_t symbol_class = 0; symbol_class < 33; ++symbol_class)
                 for (uint32_t r = 0; r < (uint32_t)R; ++r) {
-                    uint32_t const row = first_row + strip * R + r;
+                    uint32_t const row = r < registers ? first_row + strip * registers + r : 0xFFFFFFFFu;
                     int const low = row < q_low.length && symbol_class < 32 ? class_costs[byte_to_class[q_low.bytes[row]] * 32 + symbol_class] : 0;
                     int const high = has_high && row < q_high.length && symbol_class < 32 ? class_costs[byte_to_class[q_high.bytes[row]] * 32 + symbol_class] : 0;
                     profile[((size_t)strip * 33 + symbol_class) * R + r] = k.profile_entry(low, high);
@@ -73,7 +74,7 @@ void score_item(text_t q_low, text_t q_high, bool has_high, std::vector<text_t> 
         for (uint32_t team = 0; team < teams; ++team)
             for (uint32_t lane = 0; lane < (uint32_t)L; ++lane) {
                 lane_t &state = lanes[(size_t)team * L + lane];
-                team_seed<costs_t, R>(k, first_row + lane * R, state.rows, state.diagonal);
+                team_seed<costs_t, R>(k, first_row + lane * registers, state.rows, state.diagonal);
             }
 
         for (uint32_t wave_first = 0; wave_first < teams; wave_first += teams_per_wave) {
@@ -108,7 +109,7 @@ void score_item(text_t q_low, text_t q_high, bool has_high, std::vector<text_t> 
                             continue;
                         }
                         uint32_t const *costs = &profile[((size_t)lane * 33 + in_class[lane]) * R];
-                        state.out = team_advance<costs_t, R>(k, state.rows, costs, in[lane], state.diagonal, state.best);
+                        state.out = team_advance<costs_t, R>(k, state.rows, costs, in[lane], state.diagonal, state.best, registers);
                         state.out_class = in_class[lane];
                         if (lane == (uint32_t)L - 1 && pass + 1 < passes) parked[(size_t)column * teams + team] = state.out;
                     }
@@ -127,7 +128,7 @@ void score_item(text_t q_low, text_t q_high, bool has_high, std::vector<text_t> 
             int64_t *const out = half ? out_high : out_low;
             if (!query.length) continue;
             uint32_t last_pass, last_lane, last_reg;
-            team_last_row<L, R>(query.length, last_pass, last_lane, last_reg);
+            team_last_row<L, R>(query.length, longer, last_pass, last_lane, last_reg);
             if (local_ ? pass + 1 != passes : pass != last_pass) continue;
             for (uint32_t team = 0; team < teams; ++team) {
                 if (local_) {
