@@ -13,6 +13,7 @@ for step in "$@"; do
     team3)      timeout 600 python scripts/measure_team.py --config 3 > "$OUT/team_cfg3.jsonl" 2> "$OUT/team_cfg3.err"; cat "$OUT/team_cfg3.jsonl"; tail -3 "$OUT/team_cfg3.err";;
     share4)     timeout 600 python scripts/measure_team.py --config 4 --shards 8 > "$OUT/team_cfg4_share.jsonl" 2> "$OUT/team_cfg4_share.err"; cat "$OUT/team_cfg4_share.jsonl"; tail -3 "$OUT/team_cfg4_share.err";;
     ops)        timeout 300 scripts/bin/team_ops > "$OUT/team_ops.json" 2> "$OUT/team_ops.err"; cat "$OUT/team_ops.json"; tail -3 "$OUT/team_ops.err";;
+    sweep)      timeout 900 python scripts/measure_team_sweep.py > "$OUT/team_sweep.jsonl" 2> "$OUT/team_sweep.err"; cat "$OUT/team_sweep.jsonl"; tail -3 "$OUT/team_sweep.err";;
     bench)      timeout 600 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; tail -c 3000 "$OUT/bench.json"; tail -3 "$OUT/bench.err";;
     configs)    timeout 600 python scripts/measure_configs.py --configs 2,3,4,5 > "$OUT/configs.jsonl" 2>&1; cat "$OUT/configs.jsonl";;
     *) echo "unknown step $step";;
