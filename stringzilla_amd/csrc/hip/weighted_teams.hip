@@ -380,7 +380,7 @@ static u64 team_work_items(u32 queries_count, u32 candidates_count) {
 
 /* The instances that are compiled: (lanes per team, registers per track, wavefronts per SIMD), each in both orders. */
 #ifndef SZS_TEAM_SHAPES
-#define SZS_TEAM_SHAPES(CALL) CALL(16, 32, 2) CALL(16, 32, 3) CALL(16, 24, 3) CALL(16, 16, 4) CALL(8, 32, 2) CALL(4, 32, 2) CALL(1, 32, 2)
+#define SZS_TEAM_SHAPES(CALL) CALL(16, 32, 2) CALL(16, 16, 4) CALL(4, 32, 2)
 #endif
 
 #define SZS_TEAM_DISPATCH(L, R, W, CALL)                                                                               \

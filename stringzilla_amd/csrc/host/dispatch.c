@@ -295,18 +295,16 @@ void szs_engine_release(szs_engine_s *engine) {
 /* ---- the decision: everything that follows from the statistics of the two sides ---------------------------------------- */
 
 /**
- *  Which instance of the team tier scores a 16-bit class-table call, 0 for the one-pair-per-lane kernel.  A team of L lanes
- *  x R registers walks the query side in passes of L x R rows, so what it wastes is the padding of the last pass: about
- *  half a pass per pair of queries.  Sixteen lanes for queries of 2 KB and more (config 4: 6 % padding against 1 / 16 of the
- *  parked traffic and of the longest pair's critical path).
+ *  Which instance of the team tier scores a 16-bit class-table call, 0 for the one-pair-per-lane kernel: the `team` knob, or
+ *  the lanes-per-item rule of plan.c with the instance compiled for that many lanes.
  */
-static unsigned team_shape_for(szs_side_stats_t const *queries, szs_side_stats_t const *candidates) {
+static unsigned team_shape_for(int affine, szs_side_stats_t const *queries, szs_side_stats_t const *candidates) {
     int const knob = szs_tuning_get(szs_knob_team_k);
     if (knob == 0) return 0;
     if (knob > 0) return szs_hip_weighted_team_has_shape((unsigned)knob) ? (unsigned)knob : 0;
-    (void)candidates;
-    uint64_t const mean_query = queries->count ? queries->symbols / queries->count : 0;
-    if (mean_query >= 2048 && szs_hip_weighted_team_has_shape(163202)) return 163202;
+    unsigned const lanes = szs_plan_team_lanes(affine, queries, candidates);
+    for (unsigned index = 0; lanes && szs_hip_weighted_team_shape(index); ++index) /* the first compiled instance of that width */
+        if (szs_hip_weighted_team_shape(index) / 10000u == lanes) return szs_hip_weighted_team_shape(index);
     return 0;
 }
 
@@ -322,28 +320,10 @@ static sz_status_t decide(szs_engine_s const *engine, int symmetric, int runes, 
     /* bit-parallel at any length (2048-row strips beyond 64 words); `banded` names the byte flavour of the strip kernel */
     d->banded = d->use_myers && !runes;
 
-    /* ---- orientation and tier.  Every kernel puts ONE side on workgroups / band chains (its "queries") and the other
-     * on lanes / columns (its "candidates"); which real side plays which role is free - gap costs apply to both strings
-     * alike and a swapped class table is its transpose - so a cycle model of both tiers (plan.c) is evaluated for both
-     * orientations and the cheaper one runs.  1024 queries x 1 candidate thus become 1 workgroup row of 1024 lanes
-     * instead of 1024 workgroups with one live lane each.  Symmetric calls have nothing to swap. */
-    szs_plan_orient(d->use_myers ? 0xFFFFFFFFu : 0 /* bit-parallel at any length, bytes and codepoints alike */, d->use_myers && !runes, !engine->is_linear,
-                    !d->maximise, symmetric, q_stats, c_stats, szs_hip_systolic_band_rows(), &d->tier, &d->transposed);
-    /* the `tier` knob: `systolic` on a unit-cost engine means the DP recurrences, `chain` the bit-parallel chain */
-    if (d->tier == SZS_TIER_MYERS_CHAIN && szs_tuning_get(szs_knob_tier_k) == SZS_TIER_SYSTOLIC) d->tier = SZS_TIER_SYSTOLIC;
-    if (force_lanes) d->tier = SZS_TIER_LANES;
-
-    szs_side_stats_t const *kq = d->transposed ? c_stats : q_stats, *kc = d->transposed ? q_stats : c_stats;
-    uint32_t const *kq_variants = d->transposed ? c_variants : q_variants;
-    d->kq_count = kq->count, d->kc_count = kc->count;
-    d->layout = (symmetric ? SZS_LAYOUT_SYMMETRIC : 0) | (d->transposed ? SZS_LAYOUT_TRANSPOSED : 0);
-    d->plan.longest_query = kq->longest, d->plan.longest_candidate = kc->longest, d->plan.cells = cells;
-    memcpy(d->variant_counts, kq_variants, sizeof(d->variant_counts));
-    szs_plan_groups(kq_variants, &d->plan);
-
-    /* Cell width (reach rule, serial.hpp:135-162,370-386): 16-bit pairs, 32 bits, or the 64-bit tier (hip/wide.hip). */
-    uint64_t const span = d->maximise ? (uint64_t)d->plan.longest_query + d->plan.longest_candidate
-                                      : (d->plan.longest_query > d->plan.longest_candidate ? d->plan.longest_query : d->plan.longest_candidate);
+    /* ---- cell width (reach rule, serial.hpp:135-162,370-386): 16-bit pairs, 32 bits, or the 64-bit tier (hip/wide.hip).
+     * It follows from the longest string of either side, whichever of them ends up on the workgroups. */
+    uint64_t const span = d->maximise ? (uint64_t)q_stats->longest + c_stats->longest
+                                      : (q_stats->longest > c_stats->longest ? q_stats->longest : c_stats->longest);
     uint64_t const magnitude = engine->magnitude ? engine->magnitude : 1;
     uint64_t const reach = (span + (engine->is_linear ? 1 : 3)) * magnitude;
     /* Unit-cost engines never need wide cells: their distances are bounded by the longer string, below 2^32 by construction. */
@@ -356,7 +336,7 @@ static sz_status_t decide(szs_engine_s const *engine, int symmetric, int runes, 
                                                                    : szs_objective_distance_k;
     /* 16-bit strip boundaries when every parked value provably fits: global scores are bounded by the reach, saturating
      * local ones by (shorter side) x (largest cost) - the reference narrows its cells by the same kind of bound. */
-    uint64_t const shorter_side = d->plan.longest_query < d->plan.longest_candidate ? d->plan.longest_query : d->plan.longest_candidate;
+    uint64_t const shorter_side = q_stats->longest < c_stats->longest ? q_stats->longest : c_stats->longest;
     d->narrow = d->objective == szs_objective_global_k              ? reach < 32000
                 : d->objective == szs_objective_local_saturating_k ? (shorter_side + 3) * magnitude < 32000
                                                                     : 0;
@@ -366,20 +346,42 @@ static sz_status_t decide(szs_engine_s const *engine, int symmetric, int runes, 
         for (int i = 0; i < 256; ++i) d->classes = engine->byte_to_class[i] >= d->classes ? (uint32_t)engine->byte_to_class[i] + 1 : d->classes;
     d->packed = d->maximise && d->narrow && d->classes <= 32 && szs_tuning_get(szs_knob_packed_k) != 0;
     d->packed_local = d->objective == szs_objective_local_saturating_k;
+    /* The team tier (hip/weighted_teams.hip) scores what the packed kernel scores - and local alignments up to twice its
+     * range - with a pair spread over the lanes of a DPP row; its cells are half-float patterns (three-input maxima) while
+     * the bound allows, unsigned integers beyond (hip/team_core.hpp). */
+    int team_capable = 0;
+    if (d->maximise && !d->wide_cells && d->classes <= 32 && szs_tuning_get(szs_knob_packed_k) != 0 &&
+        (d->objective == szs_objective_global_k || d->objective == szs_objective_local_saturating_k)) {
+        uint64_t const bound = d->packed_local ? (shorter_side + 3) * magnitude : reach; /* what bounds every H and track value */
+        d->team_wide = bound >= szs_hip_weighted_team_reach_limit(d->packed_local, 0);
+        team_capable = bound < szs_hip_weighted_team_reach_limit(d->packed_local, d->team_wide);
+    }
+
+    /* ---- orientation and tier.  Every kernel puts ONE side on workgroups / band chains (its "queries") and the other
+     * on lanes / columns (its "candidates"); which real side plays which role is free - gap costs apply to both strings
+     * alike and a swapped class table is its transpose - so a cycle model of both tiers (plan.c) is evaluated for both
+     * orientations and the cheaper one runs.  1024 queries x 1 candidate thus become 1 workgroup row of 1024 lanes
+     * instead of 1024 workgroups with one live lane each.  Symmetric calls have nothing to swap. */
+    szs_plan_orient(d->use_myers ? 0xFFFFFFFFu : 0 /* bit-parallel at any length, bytes and codepoints alike */, d->use_myers && !runes, !engine->is_linear,
+                    !d->maximise, team_capable, symmetric, q_stats, c_stats, szs_hip_systolic_band_rows(), &d->tier, &d->transposed);
+    /* the `tier` knob: `systolic` on a unit-cost engine means the DP recurrences, `chain` the bit-parallel chain */
+    if (d->tier == SZS_TIER_MYERS_CHAIN && szs_tuning_get(szs_knob_tier_k) == SZS_TIER_SYSTOLIC) d->tier = SZS_TIER_SYSTOLIC;
+    if (force_lanes) d->tier = SZS_TIER_LANES;
+
+    szs_side_stats_t const *kq = d->transposed ? c_stats : q_stats, *kc = d->transposed ? q_stats : c_stats;
+    uint32_t const *kq_variants = d->transposed ? c_variants : q_variants;
+    d->kq_count = kq->count, d->kc_count = kc->count;
+    d->layout = (symmetric ? SZS_LAYOUT_SYMMETRIC : 0) | (d->transposed ? SZS_LAYOUT_TRANSPOSED : 0);
+    d->plan.longest_query = kq->longest, d->plan.longest_candidate = kc->longest, d->plan.cells = cells;
+    memcpy(d->variant_counts, kq_variants, sizeof(d->variant_counts));
+    szs_plan_groups(kq_variants, &d->plan);
 
     if (d->wide_cells) /* one tier only: the anti-diagonal walker with 64-bit cells, whatever the shape of the batch */
         d->tier = SZS_TIER_LANES, d->packed = 0, d->narrow = 0;
-    /* The team tier (hip/weighted_teams.hip) scores what the packed kernel scores - same bounds, same refs - with a pair
-     * spread over the lanes of a DPP row.  The `team` knob pins a shape or (0) the one-pair-per-lane kernel. */
-    d->team = 0, d->team_wide = 0;
-    if (d->maximise && !d->wide_cells && d->classes <= 32 && d->tier == SZS_TIER_LANES && szs_tuning_get(szs_knob_packed_k) != 0 &&
-        (d->objective == szs_objective_global_k || d->objective == szs_objective_local_saturating_k)) {
-        int const local = d->objective == szs_objective_local_saturating_k;
-        uint64_t const bound = local ? (shorter_side + 3) * magnitude : reach; /* what bounds every H and track value */
-        d->team_wide = bound >= szs_hip_weighted_team_reach_limit(local, 0);
-        if (bound < szs_hip_weighted_team_reach_limit(local, d->team_wide)) d->team = team_shape_for(kq, kc);
-        if (d->team) d->packed = 1, d->packed_local = local; /* the profile reports 16-bit cells either way */
-    }
+    d->team = 0;
+    if (team_capable && d->tier == SZS_TIER_LANES) d->team = team_shape_for(!engine->is_linear, kq, kc);
+    if (d->team) d->packed = 1; /* the profile reports 16-bit cells either way */
+    else d->team_wide = 0;
 
     /* The systolic tier scores every engine family with its weighted recurrences, so it needs the cost model and its
      * own workspace; a job with too many pairs in flight for that workspace stays on the lanes tier. */

@@ -143,7 +143,17 @@ void szs_plan_build(unsigned myers, int symmetric, uint64_t const *query_address
  *  Inputs are the per-side statistics only (hip/kernels.h: szs_side_stats_t), so that the device planner's summary feeds
  *  the same model as the host planner's length arrays.
  */
-double szs_plan_estimate(unsigned bit_parallel_limit, int bit_parallel_chain, int affine, int uniform, int symmetric,
+unsigned szs_plan_team_lanes(int affine, szs_side_stats_t const *queries, szs_side_stats_t const *candidates) {
+    if (!queries->count || !candidates->count) return 0;
+    double const mean_query = (double)queries->symbols / queries->count, mean_candidate = (double)candidates->symbols / candidates->count;
+    double const items = (double)((queries->count + 1) / 2) * candidates->count; /* (pair of queries, candidate) */
+    if (mean_query < (affine ? 48 : 96)) return 0; /* a few rows per lane: the step's fixed cost takes over */
+    if (mean_query >= 384 && mean_candidate >= 128) return 16;
+    if (items * 4 / 64 < 4096 && mean_query >= 128) return 16; /* four lanes per item would leave SIMDs short of wavefronts */
+    return 4;
+}
+
+double szs_plan_estimate(unsigned bit_parallel_limit, int bit_parallel_chain, int affine, int uniform, int team_capable, int symmetric,
                          szs_side_stats_t const *queries, szs_side_stats_t const *candidates, unsigned band_rows, int *tier) {
     if (bit_parallel_chain) band_rows = SZS_MYERS_CHAIN_BAND_ROWS; /* hip/myers_chain.hip: 64 lanes x 32 rows x 8 columns */
     *tier = SZS_TIER_LANES;
@@ -174,13 +184,22 @@ double szs_plan_estimate(unsigned bit_parallel_limit, int bit_parallel_chain, in
         split = pinned == 2 || pinned == 4 ? pinned : workgroups < 1024 ? 4.0 : 2.0;
         lane_waves *= split;
     }
+    /* The team tier of the 16-bit class-table scorers (hip/weighted_teams.hip): `team` lanes per (pair of queries, candidate),
+     * 0.052 (affine) / 0.12 (linear) cells per lane-cycle on a full device against 0.034 / 0.079 for one pair per lane
+     * (configs 4 and 3: 8.2 and 19.1 TCUPS against 6.0 and 13.2, profiles/r03), the largest pair `team` / 2 times shorter. */
+    unsigned const team = team_capable && !bit_parallel_limit && szs_tuning_get(szs_knob_team_k) != 0
+                              ? (szs_tuning_get(szs_knob_team_k) > 0 ? (unsigned)szs_tuning_get(szs_knob_team_k) / 10000u
+                                                                    : szs_plan_team_lanes(affine, queries, candidates))
+                              : 0;
+    if (team) lane_waves = (double)((queries_count + 1) / 2) * candidates_count * team / 64.0 * scale, split = team / 2.0;
     if (lane_waves < 1) lane_waves = 1;
     double const fill = lane_waves >= 2 * simds ? 1.0 : lane_waves <= simds ? 0.5 : lane_waves / (2 * simds);
-    double const lane_rate = (bit_parallel ? 0.85 : 1.0 / ((affine ? 7.0 : 3.0) * 4.2)) * fill;
-    double lanes_cycles = query_symbols * mean_candidate * waves_per_query * scale / lane_rate / (lane_waves < simds ? lane_waves : simds);
+    double const lane_rate = (bit_parallel ? 0.85 : team ? (affine ? 0.052 : 0.12) : 1.0 / ((affine ? 7.0 : 3.0) * 4.2)) * fill;
+    double lanes_cycles = query_symbols * mean_candidate * (team ? candidates_count / 64.0 : waves_per_query) * scale / lane_rate /
+                          (lane_waves < simds ? lane_waves : simds);
     /* A workgroup is four wavefronts; with fewer than 193 candidates some of them have no pair at all, and the live ones
      * of neighbouring workgroups do not spread evenly over the SIMDs (4096 x 1 x 128 B measured 2x the model). */
-    double const live_waves = waves_per_query < 4 ? waves_per_query : 4;
+    double const live_waves = team || waves_per_query >= 4 ? 4 : waves_per_query;
     lanes_cycles *= 1.0 + 0.5 * (1.0 - live_waves / 4.0);
     double const largest_pair = (double)longest_query * longest_candidate / lane_rate / split;
     if (largest_pair > lanes_cycles) lanes_cycles = largest_pair;
@@ -221,15 +240,15 @@ double szs_plan_estimate(unsigned bit_parallel_limit, int bit_parallel_chain, in
     return systolic_cycles;
 }
 
-void szs_plan_orient(unsigned bit_parallel_limit, int bit_parallel_chain, int affine, int uniform, int symmetric,
+void szs_plan_orient(unsigned bit_parallel_limit, int bit_parallel_chain, int affine, int uniform, int team_capable, int symmetric,
                      szs_side_stats_t const *queries, szs_side_stats_t const *candidates, unsigned band_rows, int *tier,
                      int *transposed) {
     int swapped_tier = SZS_TIER_LANES;
-    double const cycles = szs_plan_estimate(bit_parallel_limit, bit_parallel_chain, affine, uniform, symmetric, queries,
+    double const cycles = szs_plan_estimate(bit_parallel_limit, bit_parallel_chain, affine, uniform, team_capable, symmetric, queries,
                                             candidates, band_rows, tier);
     *transposed = 0;
     if (symmetric) return; /* nothing to swap */
-    double const swapped_cycles = szs_plan_estimate(bit_parallel_limit, bit_parallel_chain, affine, uniform, 0, candidates,
+    double const swapped_cycles = szs_plan_estimate(bit_parallel_limit, bit_parallel_chain, affine, uniform, team_capable, 0, candidates,
                                                     queries, band_rows, &swapped_tier);
     int const forced = szs_tuning_get(szs_knob_swap_k); /* testing aid: 0 | 1 */
     *transposed = forced >= 0 ? forced == 1 : swapped_cycles < 0.6 * cycles;
@@ -282,7 +301,7 @@ sz_status_t szs_rocm_orientation_probe(int unit_cost, int affine, int uniform, i
     szs_side_stats(query_lengths, (uint32_t)queries_count, 0, &query_stats, NULL);
     szs_side_stats(symmetric ? query_lengths : candidate_lengths, (uint32_t)(symmetric ? queries_count : candidates_count), 0,
                    &candidate_stats, NULL);
-    szs_plan_orient(unit_cost ? 0xFFFFFFFFu : 0, unit_cost, affine, uniform, symmetric, &query_stats, &candidate_stats, /* as dispatch.c does for bytes */
+    szs_plan_orient(unit_cost ? 0xFFFFFFFFu : 0, unit_cost, affine, uniform, 0, symmetric, &query_stats, &candidate_stats, /* as dispatch.c does for bytes */
                     SZS_SYSTOLIC_BAND_ROWS, tier, transposed);
     return sz_success_k;
 }

@@ -236,14 +236,21 @@ void szs_plan_groups(uint32_t const *variant_counts, szs_plan_t *plan);
  *  `bit_parallel_limit`: longest query (symbols) the Myers kernels take, 0 for weighted engines; `uniform`:
  *  Levenshtein-family costs.  The `tier` knob (host/tuning.c) forces the tier (testing aid).
  */
-double szs_plan_estimate(unsigned bit_parallel_limit, int bit_parallel_chain, int affine, int uniform, int symmetric,
+double szs_plan_estimate(unsigned bit_parallel_limit, int bit_parallel_chain, int affine, int uniform, int team_capable, int symmetric,
                          szs_side_stats_t const *queries, szs_side_stats_t const *candidates, unsigned band_rows, int *tier);
+
+/**
+ *  Lanes per (pair of queries, candidate) for the team tier of the 16-bit class-table scorers (hip/weighted_teams.hip): 16,
+ *  4, or 0 for the one-pair-per-lane kernel - from the measured sweep profiles/r03/team_sweep_*.jsonl.  `team_capable` above:
+ *  the call may take that tier at all (class table, every DP value within 16 bits).
+ */
+unsigned szs_plan_team_lanes(int affine, szs_side_stats_t const *queries, szs_side_stats_t const *candidates);
 
 /**
  *  The decision itself: evaluates szs_plan_estimate for both orientations and reports the tier to run and whether the
  *  sides are swapped (never for symmetric calls).  The `swap` knob forces the orientation (testing aid).
  */
-void szs_plan_orient(unsigned bit_parallel_limit, int bit_parallel_chain, int affine, int uniform, int symmetric,
+void szs_plan_orient(unsigned bit_parallel_limit, int bit_parallel_chain, int affine, int uniform, int team_capable, int symmetric,
                      szs_side_stats_t const *queries, szs_side_stats_t const *candidates, unsigned band_rows, int *tier,
                      int *transposed);
 
