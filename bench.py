@@ -43,8 +43,13 @@ HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 # The binding resource of this path is integer VALU issue, not HBM.  Its ceiling is MEASURED, not quoted: the Myers
 # column update (the kernel's exact instruction mix) on register-resident match masks, no LDS and no memory, sustains
 # this many DP cells per second at full bit-vector width on one MI355X (scripts/valu_peak.hip -> profiles/).
-PROFILE_DIRS = [os.path.join(ROOT, "profiles", "r02"), os.path.join(ROOT, "profiles", "r01")]
-VALU_LANE_OPS_PEAK = 39.3e12  # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz: one full-rate VALU lane-op per lane per cycle
+PROFILE_DIRS = [os.path.join(ROOT, "profiles", "r03"), os.path.join(ROOT, "profiles", "r02"), os.path.join(ROOT, "profiles", "r01")]
+# VALU issue ceiling, class-weighted: gfx950's SIMDs are 32 lanes wide, a full-rate VALU instruction (32-bit add / sub / logic /
+# right shift / move) takes a wavefront 2 cycles, every other one (maxima, packed 16-bit, carries, funnel shifts, VOP3 three-
+# operand forms, DPP) 4 - MI355X_MICROARCH.md "Wave scheduling", measured per opcode by scripts/valu_peak.hip.  A main loop of F
+# full-rate and H half-rate instructions issues at most (F + H) / (F / 78.6 + H / 39.3) T lane-operations/s; F and H come from
+# the code object's own assembly (scripts/opcode_mix.py -> profiles/r03/opcode_mix.json).
+VALU_FULL_RATE_PEAK, VALU_HALF_RATE_PEAK = 78.6e12, 39.3e12  # 256 CUs x 4 SIMDs x 32 (16) lanes x 2.4 GHz
 
 
 def _profile_json(name):
@@ -165,7 +170,7 @@ def cpu_baseline(load, gpu_matrix, seconds):
     started = time.perf_counter()
     run(rows, columns)
     rate = cells_of(rows, columns) / max(time.perf_counter() - started, 1e-4)
-    budget_cells = rate * seconds
+    budget_cells = rate * seconds / 6  # one run of the sample takes about a sixth of the budget: five or more timed repeats
     # grow the sample towards the budget: first more candidates, then more rows
     take_columns = int(min(len(c_lengths), max(8, budget_cells / max(cells_of(rows, np.arange(len(c_lengths))) / len(c_lengths), 1.0))))
     columns = spaced(len(c_lengths), take_columns)
@@ -179,17 +184,20 @@ def cpu_baseline(load, gpu_matrix, seconds):
     first = time.perf_counter() - started
     expected = gpu_matrix[np.ix_(rows, columns)]
     assert np.array_equal(matrix.view(np.int64), expected.view(np.int64)), "CPU baseline and GPU disagree"
-    repeats = int(max(1, min(50, (seconds - first) / max(first, 1e-3))))
-    started = time.perf_counter()
+    repeats = int(max(5, min(50, (seconds - first) / max(first, 1e-3))))
+    runs = []
     for _ in range(repeats):
+        started = time.perf_counter()
         run(rows, columns)
-    elapsed = (time.perf_counter() - started) / repeats
+        runs.append(time.perf_counter() - started)
+    elapsed = float(np.median(runs))  # the median of >= 5 runs: a 256-thread host shows stragglers, a mean of two runs wandered by 25 %
     what = (f"the full {len(q_lengths)}x{len(c_lengths)} batch of the timed config" if whole else
             f"{len(rows)} evenly spaced query rows x {len(columns)} evenly spaced candidates of the timed config")
     return {
         "value": round(cells_of(rows, columns) / elapsed / 1e9, 2), "unit": "GCUPS", "cores": cores, "kind": kind,
-        "sample": f"{what}, {repeats} repeats, {label} tier, {cores} threads, tape packing included; "
-                  f"the sampled cells verified equal to the GPU's",
+        "spread": [round(cells_of(rows, columns) / max(runs) / 1e9, 2), round(cells_of(rows, columns) / min(runs) / 1e9, 2)],
+        "sample": f"{what}, median of {repeats} runs (`spread`: slowest and fastest run), {label} tier, {cores} threads, tape packing "
+                  f"included; the sampled cells verified equal to the GPU's",
     }
 
 
@@ -219,21 +227,32 @@ def roofline(config, profile, kernel_seconds, traffic_override=None):
                                     f"--pmc passes of this command (raw; wide-stream reads may count double)")
     if "SQ_INSTS_VALU" in call:
         lane_ops = call["SQ_INSTS_VALU"] * 64.0
+        mixes, mix_where = _profile_json("opcode_mix.json")
+        # the ceiling of the call = its kernels' ceilings weighted by their share of the kernel time
+        weights = {name: kernels[name]["share_of_kernel_time"] for name in kernels if (mixes or {}).get(name)}
+        if weights:
+            total = sum(weights.values())
+            ceiling = 1e12 * total / sum(share / mixes[name]["ceiling_Tlane_ops_per_s"] for name, share in weights.items())
+            main = max(weights, key=weights.get)
+            mix = {"kernel": main, "main_loop": mixes[main]["main_loop"], "full_rate_instructions": mixes[main]["full_rate"],
+                   "half_rate_instructions": mixes[main]["half_rate"], "source": mix_where}
+        else:
+            ceiling, mix = VALU_HALF_RATE_PEAK, None
         record["valu"] = {
-            "bound": "integer VALU issue (PMC)", "source": where,
+            "bound": "integer VALU issue (PMC), class-weighted ceiling", "source": where,
             "wave_instructions_per_call": round(call["SQ_INSTS_VALU"]),
             "lane_ops_per_cell": round(lane_ops / max(float(profile.cells), 1.0), 4),
             "achieved_Tlane_ops_per_s": round(lane_ops / kernel_seconds / 1e12, 2),
-            "peak_Tlane_ops_per_s": VALU_LANE_OPS_PEAK / 1e12,
-            "frac": round(lane_ops / kernel_seconds / VALU_LANE_OPS_PEAK, 4),
-            "busy_fraction_under_rocprof": round(call["valu_busy_fraction"], 4) if "valu_busy_fraction" in call else None,
+            "peak_Tlane_ops_per_s": round(ceiling / 1e12, 2),
+            "frac": round(lane_ops / kernel_seconds / ceiling, 4),
+            "opcode_mix": mix,
             "lds_busy_fraction": round(call["lds_busy_fraction"], 4) if "lds_busy_fraction" in call else None,
             "lds_conflict_fraction": round(call["lds_conflict_fraction"], 4) if "lds_conflict_fraction" in call else None,
-            "note": "frac = VALU wave-instructions x 64 lanes per second over one full-rate lane-op per lane per cycle (256 CUs x 4 SIMDs "
-                    "x 16 lanes x 2.4 GHz); add / logic opcodes issue at up to 1.7x that rate on gfx950, carries, shifts and packed "
-                    "16-bit opcodes at 1x (profiles/r02/valu_peak.json) - so a mix with fast-class opcodes can read above 1.0: the "
-                    "kernel is then at the issue limit of its mix, and `myers_ceiling` (the same column update on registers only) is "
-                    "the fraction that says how close",
+            "wave_cycles_waiting_to_issue": round(call["wave_wait_inst_fraction"], 4) if "wave_wait_inst_fraction" in call else None,
+            "wave_cycles_parked": round(call["wave_wait_any_fraction"], 4) if "wave_wait_any_fraction" in call else None,
+            "note": "frac = (VALU wave-instructions of one call x 64 lanes / live kernel seconds) over (F + H) / (F / 78.6 T + H / 39.3 T), "
+                    "F / H = full- / half-rate instructions of the dominant kernels' main loops (time-weighted over the kernels of the "
+                    "call); the instruction count is a committed PMC pass of this command, the kernel time is this run's",
         }
     return record
 
@@ -372,6 +391,10 @@ def measure_c_node(config, devices, args):
 
 def main():
     args = parse_args()
+    # The application's choice, made before HIP initialises: twelve hardware queues, so that the per-width launches of a
+    # mixed-length batch (configs 5 / 5u: up to eight streams) each get their own.  The library itself never writes the
+    # environment; it reads this variable when it is loaded and sizes its fan-out to it (csrc/host/tuning.c).
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
     import torch
     import torch.distributed as dist
 
@@ -443,56 +466,58 @@ def main():
         except Exception as problem:  # an extra record must never cost the headline line
             records.append({"config": config, "error": repr(problem)})
 
-    # ---- the same step on batches the engine has NOT just seen: two different batches of the config's shape, alternating, so
-    # that no call finds the plan of its own tapes on the device (csrc/host/dispatch.c re-uses that plan after validating it
-    # in the kernels; a stream of fresh batches pays for the planner kernel instead).  Reported beside the headline, and
-    # measured right BEFORE it, at least 120 calls long: the first ~50 launches of this kernel after anything else - idling,
-    # NW / SW scoring, GEMMs alike - run ~10 % slower (scripts/kernel_ms_series.py: the power management settles on the new
-    # instruction mix in ~10 ms), so a headline of W = 5 + K = 20 steps started cold measures that transient and nothing a
-    # loaded GPU ever shows.  The headline itself is unchanged: W untimed steps, then exactly K timed ones, fenced.
-    fresh = None
-    if args.config == 2:  # every rank, on its own GPU (rank 0's numbers are the ones reported)
+    # ---- the headline is a STREAM OF FRESH BATCHES: two different batches of the config's shape alternate, so that no call
+    # finds the plan of its own tapes on the device (csrc/host/dispatch.c re-uses that plan after validating it in the kernels -
+    # the best case, which a real stream of batches never meets; round 2's headline measured it).  Every call pays for the
+    # planner kernel, speculated launches behind it.  The re-use path is reported beside it as `same_tapes`, measured first.
+    # Both legs run after the `configs` records: the first ~50 launches of this kernel after anything else - idling, NW / SW
+    # scoring, GEMMs alike - run ~10 % slower (scripts/kernel_ms_series.py: the power management settles on the new instruction
+    # mix in ~10 ms), so the W warm-up steps of a short run would otherwise be timed on that transient.
+    steps_of, cells_of_step, same_tapes = [step], None, None
+    if args.config == 2:  # every rank, on its own GPU
         other = workloads.random_tape(np.random.default_rng(4242 + 10 * rank), len(load.queries), 96, 160, workloads.ASCII_PRINTABLE).to_device(local_rank)
         other_candidates = workloads.random_tape(np.random.default_rng(4243 + 10 * rank), len(load.candidates), 96, 160, workloads.ASCII_PRINTABLE).to_device(local_rank)
         other_step = make_step(engine, scope, load, other, other_candidates, results, local_rank)
-        other_cells = int(other.lengths().sum()) * int(other_candidates.lengths().sum())
-        pairs_of_steps = max(60, args.steps // 2)
+        steps_of.append(other_step)
         for _ in range(max(2, args.warmup // 2)):
-            other_step(), step()
-        headline_cells = int(engine.last_call_profile().cells)
-        planners = set()
-        fence()
-        fresh_started = time.perf_counter()
-        for _ in range(pairs_of_steps):
-            other_step()
-            planners.add(int(engine.last_call_profile().planner))
             step()
-            planners.add(int(engine.last_call_profile().planner))
+        calls = max(60, args.steps)
         fence()
-        fresh_elapsed = time.perf_counter() - fresh_started
-        fresh = {"what": "two different batches of the same shape, alternating: every call plans its tapes afresh on the device",
-                 "ms_per_step": round(fresh_elapsed / (2 * pairs_of_steps) * 1e3, 4),
-                 "value": round((other_cells + headline_cells) * pairs_of_steps / fresh_elapsed / 1e9, 1), "unit": "GCUPS",
-                 "calls": 2 * pairs_of_steps, "planner_modes_seen": sorted(planners)}
+        same_started = time.perf_counter()
+        for _ in range(calls):
+            step()
+        fence()
+        same_elapsed = time.perf_counter() - same_started
+        profile = engine.last_call_profile()
+        same_tapes = {"what": "the same tapes again and again: the plan of the previous call is re-used behind a guard, no planner kernel",
+                      "ms_per_step": round(same_elapsed / calls * 1e3, 4), "value": round(profile.cells * calls / same_elapsed / 1e9, 1),
+                      "unit": "GCUPS", "calls": calls, "planner_mode": int(profile.planner)}
 
-    for _ in range(args.warmup):
-        step()
-    kernel_ms = []
+    for index in range(args.warmup):
+        steps_of[index % len(steps_of)]()
+    cells_of_step = []
+    for one in steps_of:  # cells per call of each batch (untimed; also leaves every plan shape warm)
+        one()
+        cells_of_step.append(float(engine.last_call_profile().cells))
+    kernel_ms, planners, timed_cells = [], set(), 0.0
     fence()
     started = time.perf_counter()
-    for _ in range(args.steps):
-        step()  # synchronous: returns after the scope's stream has drained
+    for index in range(args.steps):
+        steps_of[index % len(steps_of)]()  # synchronous: returns after the scope's stream has drained
         kernel_ms.append(engine.last_call_profile().kernel_milliseconds)
+        planners.add(int(engine.last_call_profile().planner))
+        timed_cells += cells_of_step[index % len(steps_of)]
     fence()
     elapsed = time.perf_counter() - started
     if world > 1:
         slowest = torch.tensor([elapsed], dtype=torch.float64, device=where)
         dist.all_reduce(slowest, op=dist.ReduceOp.MAX)
         elapsed = float(slowest)
+    step()  # untimed: the headline batch's own matrix is what the checksum and the CPU baseline look at
 
     profile = engine.last_call_profile()
 
-    cells_per_rank = torch.tensor([float(profile.cells)], dtype=torch.float64, device=where)
+    cells_per_rank = torch.tensor([timed_cells], dtype=torch.float64, device=where)  # over the K timed steps
     checksum = results.sum().reshape(1).to(torch.float64)
     if world > 1:
         dist.all_reduce(cells_per_rank)
@@ -513,7 +538,7 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = total_cells * args.steps / elapsed / 1e9
+        value = total_cells / elapsed / 1e9
         kernel = float(np.mean(kernel_ms)) * 1e-3  # seconds per launch group, hipEvent pair on the library's stream
         gpu_matrix = results.cpu().numpy()
         valu_table, valu_where = _profile_json("valu_peak.json")
@@ -544,13 +569,16 @@ def main():
                        "entry_point": ENTRY_POINTS[load.kind], "generator": args.generator},
             "roofline": line_roofline,
             "host_overhead_ms_per_step": round(ms_per_step - kernel * 1e3, 4),
-            "planner": {0: "host", 1: "device", 2: "device, launches speculated on the previous call's shape",
-                        3: "plan of the previous call re-used for the same tapes, validated in the kernels"}.get(int(profile.planner)),
+            "planner": " / ".join({0: "host", 1: "device", 2: "device, launches speculated on the previous call's shape",
+                                   3: "plan of the previous call re-used for the same tapes, validated in the kernels"}[mode] for mode in sorted(planners)),
             "results_checksum": float(checksum),
         }
-        if fresh is not None:
-            line["fresh_batches"] = fresh
-        if world == 1 and not args.no_cpu_baseline:
+        line["config"]["stream"] = ("two different batches of this shape alternate: every timed call plans its tapes afresh on the device"
+                                    if len(steps_of) > 1 else "the same batch every step")
+        if same_tapes is not None:
+            line["config"]["same_tapes_gcups"] = same_tapes["value"]  # kept inside `config` so that a truncated record still has it
+            line["same_tapes"] = same_tapes
+        if not args.no_cpu_baseline:  # rank 0, whatever N: the host cores are this box's
             line["cpu_baseline"] = cpu_baseline(load, gpu_matrix, args.cpu_seconds)
             attach_cpu_baselines(records, args.cpu_seconds)
         for record in records:

@@ -35,6 +35,7 @@ typedef struct szs_rocm_call_profile_t {
                                      3: the plan of the previous call of the same tapes, re-used behind a guard */
     sz_u32_t team;                /* 0, or lanes * 10000 + registers * 100 + wavefronts per SIMD of the team tier (weighted_teams.hip) */
     sz_u32_t team_wide;           /* team tier: 0 cells ordered as half-float patterns (three-input maxima), 1 as unsigned integers */
+    sz_u32_t streams;             /* streams the launches of the call were dealt over: 1 ... 8, never more than the `queues` knob */
 } szs_rocm_call_profile_t;
 
 /** Copies the profile of the most recent call made through `engine` (any of the four engine handle types). */
@@ -142,13 +143,17 @@ SZ_API_RUNTIME sz_status_t szs_rocm_node_scores_u64tape(szs_rocm_node_engine_t e
  *  "split" (0 | 2 | 4: lanes per pair of the long bit-parallel widths), "alphabet" (0 | 1: never / always renumber the runes
  *  of a codepoint batch on the device), "merge" (n: candidate blocks per workgroup of the short bit-parallel kernels),
  *  "team" (0: never | lanes * 10000 + registers * 100 + waves: that shape of the team tier of the 16-bit weighted scorers),
+ *  "queues" (see below),
  *  "cpu_requests" (strict | gpu: serve capability
  *  masks without the GPU bit and CPU device scopes with the GPU engines on device 0 instead of refusing them) - or its
  *  environment spelling ("SZS_ROCM_TIER" ...); `value` NULL, "" or "auto" restores the automatic choice.  No knob changes a
  *  result: they pick among kernels that compute the same scores.
  *
- *  Also at load: `GPU_MAX_HW_QUEUES=12` is exported unless the application has set it - the HIP runtime reads it when it
- *  initialises, and the per-width launches of a mixed-length batch run on up to eight streams.
+ *  "queues" (n): hardware queues the process has.  The launches of a mixed-length batch fan out over at most that many
+ *  streams; the HIP runtime gives a process GPU_MAX_HW_QUEUES of them, 4 by default, fixed when HIP initialises.  The library
+ *  never writes the environment: it reads GPU_MAX_HW_QUEUES once, when it is loaded, and an application that wants the wide
+ *  fan-out (a latency-bound share of a batch: 2.0 ms on twelve queues, 3.0 on four) exports GPU_MAX_HW_QUEUES=12
+ *  itself before its first HIP call.  `szs_rocm_call_profile_t.streams` says what a call really used.
  */
 SZ_API_RUNTIME sz_status_t szs_rocm_tuning_set(char const *knob, char const *value);
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Times the BASELINE.json configs at full size on one GPU (kernel = hipEvent pair inside the library, wall = whole
 C-ABI call).  Not the bench line - a working tool for the per-config table in DESIGN.md / profiles/."""
+import os as _os; _os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")  # the application asks for the wide stream fan-out
 import argparse
 import json
 import os

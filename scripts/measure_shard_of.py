@@ -2,6 +2,7 @@
 """What ONE GPU of an N-GPU node would spend on its share of a config: the rows LPT deals to shard 0 of N, scored here.
     python scripts/measure_shard_of.py --config 5 --shards 1,2,4,8
 A one-GPU preview of the strong-scaling curve (replication and the other GPUs' timing jitter aside)."""
+import os as _os; _os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")  # the application asks for the wide stream fan-out (INTEGRATION.md)
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Times one BASELINE.json config (or a share of its query rows) under every compiled shape of the team tier and under the
 one-pair-per-lane kernel (`team` = 0).  A working tool for profiles/ and the shape table in DESIGN.md."""
+import os as _os; _os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")  # the application asks for the wide stream fan-out
 import argparse
 import json
 import os

@@ -7,7 +7,10 @@ kernel time (from the --stats run, NOT from the slower counter runs), and the de
                                                 gfx950 counts wide coalesced streaming reads at half their size - raw values
                                                 are kept and labelled as such
     valu_lane_ops_per_second                    SQ_INSTS_VALU x 64 / duration
-    valu_busy_fraction                          SQ_ACTIVE_INST_VALU x 4 / (SQ_BUSY_CYCLES x SIMDs) when both were collected
+    wave_wait_inst_fraction / wave_wait_any_fraction   SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES (ready, the pipe is busy) and SQ_WAIT_ANY /
+                                                SQ_WAVE_CYCLES (parked on s_waitcnt or a barrier); `valu_busy_fraction` (SQ_ACTIVE_INST_VALU,
+                                                which equals SQ_INSTS_VALU on gfx950: instructions x an assumed 4 cycles) is kept in
+                                                the file but no longer reported by bench.py
     lds_conflict_fraction                       SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
 """
 import csv
@@ -88,6 +91,7 @@ for directory in sorted(glob.glob(os.path.join(root, "cfg*"))):
             per_call = entry.get("_calls", 0) / max(launches_seen, 1) * launches_per_call
             call["kernels"][name.split(":", 1)[1]] = {"launches_per_call": round(per_call, 3), "share_of_kernel_time": round(entry.get("_share", 0.0), 4)}
             for counter in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT",
+                            "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAVES",
                             "hbm_fetch_bytes_raw", "hbm_write_bytes_raw"):
                 if counter in entry:
                     totals[counter] += entry[counter] * per_call
@@ -98,6 +102,10 @@ for directory in sorted(glob.glob(os.path.join(root, "cfg*"))):
             call["valu_lane_ops_per_cell"] = call["SQ_INSTS_VALU"] * 64 / max(call["_cells_per_call"], 1)
         if "SQ_ACTIVE_INST_VALU" in call and seconds:  # quad-cycles summed over 1024 SIMDs against the call's kernel time at 2.4 GHz
             call["valu_busy_fraction"] = call["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (seconds * 2.4e9)
+        if call.get("SQ_WAVE_CYCLES"):  # where a resident wavefront's cycles go (quad-cycles, disjoint buckets: MI355X_MICROARCH.md)
+            call["wave_wait_inst_fraction"] = call.get("SQ_WAIT_INST_ANY", 0.0) / call["SQ_WAVE_CYCLES"]  # ready to issue, pipe busy
+            call["wave_wait_any_fraction"] = call.get("SQ_WAIT_ANY", 0.0) / call["SQ_WAVE_CYCLES"]        # parked on s_waitcnt / barrier
+            call["wavefronts_per_simd"] = call["SQ_WAVE_CYCLES"] * 4 / 1024 / (seconds * 2.4e9)
         if call.get("SQ_LDS_IDX_ACTIVE"):
             call["lds_conflict_fraction"] = call.get("SQ_LDS_BANK_CONFLICT", 0.0) / call["SQ_LDS_IDX_ACTIVE"]
             call["lds_busy_fraction"] = call["SQ_LDS_IDX_ACTIVE"] / 256 / (seconds * 2.4e9)  # cycles summed over 256 CUs

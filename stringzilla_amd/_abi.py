@@ -54,7 +54,7 @@ class CallProfile(ctypes.Structure):
         ("cells", ctypes.c_uint64), ("pairs", ctypes.c_uint64), ("algorithmic_bytes", ctypes.c_uint64),
         ("unique_bytes", ctypes.c_uint64), ("launches", ctypes.c_uint32), ("longest_query", ctypes.c_uint32),
         ("longest_candidate", ctypes.c_uint32), ("tier", ctypes.c_uint32), ("transposed", ctypes.c_uint32), ("cell_bits", ctypes.c_uint32),
-        ("planner", ctypes.c_uint32), ("team", ctypes.c_uint32), ("team_wide", ctypes.c_uint32),
+        ("planner", ctypes.c_uint32), ("team", ctypes.c_uint32), ("team_wide", ctypes.c_uint32), ("streams", ctypes.c_uint32),
     ]
 
 
@@ -160,7 +160,7 @@ _KNOBS = {"tier": "SZS_ROCM_TIER", "swap": "SZS_ROCM_SWAP", "packed": "SZS_ROCM_
           "planner": "SZS_ROCM_PLANNER", "speculate": "SZS_ROCM_SPECULATE", "cpu_requests": "SZS_ROCM_CPU_REQUESTS",
           "streams": "SZS_ROCM_STREAMS", "reuse": "SZS_ROCM_REUSE",
           "split": "SZS_ROCM_SPLIT", "alphabet": "SZS_ROCM_ALPHABET", "merge": "SZS_ROCM_MERGE",
-          "team": "SZS_ROCM_TEAM"}
+          "team": "SZS_ROCM_TEAM", "queues": "SZS_ROCM_QUEUES"}
 _knob_values = {name: os.environ.get(variable) for name, variable in _KNOBS.items()}  # what the library read when it was loaded
 
 

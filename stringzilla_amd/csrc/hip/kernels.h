@@ -154,6 +154,8 @@ enum {
     szs_knob_alphabet_k,    /* -1 automatic | 0 never | 1 always: renumber a codepoint batch's runes (hip/utf8.hip) */
     szs_knob_merge_k,       /* -1 automatic | n: candidate blocks per workgroup of the short bit-parallel kernels (1: never merge) */
     szs_knob_team_k,        /* -1 automatic | 0: never the team tier of the 16-bit weighted scorers | lanes * 10000 + registers * 100 + waves: that shape */
+    szs_knob_queues_k,      /* hardware queues the process has (GPU_MAX_HW_QUEUES when the library was loaded, else 4): the launches of a
+                               call fan out over at most that many streams */
     szs_knob_count_k
 };
 int szs_tuning_get(int knob);

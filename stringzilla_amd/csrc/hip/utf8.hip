@@ -129,10 +129,15 @@ __device__ __forceinline__ u32 alphabet_slot(u32 rune) { return (rune * 26544357
 /** control[0]: distinct runes claimed so far (the alphabet's size), control[1]: 1 when the table ran out of room. */
 __global__ __launch_bounds__(256) void alphabet_claim_kernel(u32 count, u64 const *__restrict__ rune_starts, u32 const *__restrict__ rune_counts,
                                                              u32 const *__restrict__ runes, u32 const *__restrict__ any_multibyte,
-                                                             u32 *__restrict__ keys, u32 *__restrict__ ids, u32 *__restrict__ control) {
+                                                             u32 *__restrict__ keys, u32 *__restrict__ ids, u32 *__restrict__ control, u32 most) {
     if (!*any_multibyte) return; // an ASCII batch goes to the byte engines
     u32 const lane = threadIdx.x % 64u, waves = gridDim.x * (blockDim.x / 64u);
     for (u32 i = blockIdx.x * (blockDim.x / 64u) + threadIdx.x / 64u; i < count; i += waves) {
+        // Once the alphabet has outgrown `most` (or the table) nothing will be renamed: stop claiming.  A batch of high-entropy
+        // bytes decoded unchecked would otherwise fill all 65536 slots and every later rune would probe the whole table
+        // (seconds on a large batch, for a result that is thrown away).  The counter only grows, so every wavefront that looks
+        // after the threshold was crossed leaves, and the renaming pass reads the same words and skips.
+        if (__atomic_load_n(&control[0], __ATOMIC_RELAXED) > most || __atomic_load_n(&control[1], __ATOMIC_RELAXED)) return;
         u32 const *const text = runes + rune_starts[i];
         u32 const length = rune_counts[i];
         for (u32 j = lane; j < length; j += 64) {
@@ -197,7 +202,7 @@ extern "C" int szs_hip_alphabet_rename(uint32_t count, uint64_t const *rune_star
     if (error == hipSuccess) error = hipMemsetAsync(control, 0, 2 * sizeof(u32), s);
     if (error != hipSuccess) return (int)error;
     u32 const blocks = (count + 3) / 4 < 2048u ? (count + 3) / 4 : 2048u;
-    hipLaunchKernelGGL(alphabet_claim_kernel, dim3(blocks), dim3(256), 0, s, count, rune_starts, rune_counts, runes, any_multibyte, keys, ids, control);
+    hipLaunchKernelGGL(alphabet_claim_kernel, dim3(blocks), dim3(256), 0, s, count, rune_starts, rune_counts, runes, any_multibyte, keys, ids, control, most);
     hipLaunchKernelGGL(alphabet_rename_kernel, dim3(blocks), dim3(256), 0, s, count, rune_starts, rune_counts, runes, any_multibyte, keys, ids,
                        control, most);
     error = hipGetLastError();

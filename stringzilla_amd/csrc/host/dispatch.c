@@ -566,7 +566,11 @@ static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int dev
      * cells), so they fan out over the engine's auxiliary streams and fill each other's tails; only the launches that
      * share the strip workspace (`device_boundary`) stay on the scope's stream, in order. */
     int const fan_out = d->plan.groups_count > 1 && szs_tuning_get(szs_knob_streams_k) != 0;
-    unsigned const aux_used = !fan_out ? 0u : d->plan.groups_count - 1 < SZS_AUX_STREAMS ? d->plan.groups_count - 1 : (unsigned)SZS_AUX_STREAMS;
+    /* no more streams than the process has hardware queues (tuning.c): streams that share a queue run in the queue's order */
+    unsigned const queues = (unsigned)szs_tuning_get(szs_knob_queues_k);
+    unsigned const most_aux = queues ? (queues - 1 < SZS_AUX_STREAMS ? queues - 1 : (unsigned)SZS_AUX_STREAMS) : 0u;
+    unsigned const aux_used = !fan_out ? 0u : d->plan.groups_count - 1 < most_aux ? d->plan.groups_count - 1 : most_aux;
+    engine->last_streams = aux_used + 1;
     hipError_t error = hipSuccess;
     if (fan_out) {
         if (engine->aux_device != device) {
@@ -758,6 +762,7 @@ static sz_status_t finish(szs_call_t *call, szs_decision_t const *d, hipError_t 
     profile->cell_bits = cell_bits;
     profile->team = cell_bits == 16 ? d->team : 0;
     profile->team_wide = profile->team ? (uint32_t)d->team_wide : 0;
+    profile->streams = engine->last_streams ? engine->last_streams : 1;
     profile->longest_query = d->longest[0], profile->longest_candidate = d->longest[1];
     profile->host_milliseconds = now_milliseconds() - call->started;
     phase(call, 5);
@@ -827,7 +832,12 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
     char const **error_message = call->error_message;
 
     size_t const refs_bytes = 2 * ((size_t)q_count + (symmetric ? 0 : c_count)) * sizeof(szs_string_ref_t);
+    void *const refs_before = engine->device_plan_refs.pointer;
     sz_status_t status = szs_buffer_reserve(&engine->device_plan_refs, szs_memory_device_k, device, refs_bytes, error_message);
+    /* The refs of the previous call live in that buffer.  If the reserve moved it (or failed), the remembered plan describes
+     * memory that is gone: forget it HERE, before any path below could re-use it behind nothing but the in-kernel guard. */
+    if (engine->remembered && (status != sz_success_k || engine->device_plan_refs.pointer != refs_before))
+        engine->remembered->refs_current = 0, engine->remembered->valid = 0;
     if (status != sz_success_k) return status;
     szs_string_ref_t *const base = (szs_string_ref_t *)engine->device_plan_refs.pointer;
     szs_plan_side_t q_side = {call->queries->offsets, (uint64_t)(uintptr_t)call->queries->data, q_count,

@@ -39,6 +39,8 @@ static double node_now_milliseconds(void) {
 
 typedef struct szs_node_s {
     uint32_t magic;
+    uint32_t references; /* the handle the caller holds + one per engine of the node: an engine may outlive szs_rocm_node_free */
+    uint32_t released;   /* szs_rocm_node_free was called: the handle is no longer the caller's to use */
     size_t count;
     int devices[SZS_ROCM_NODE_MOST_GPUS];
     szs_scope_s *scopes[SZS_ROCM_NODE_MOST_GPUS];
@@ -72,7 +74,7 @@ sz_status_t szs_rocm_node_init(sz_size_t const *gpu_devices, sz_size_t count, sz
     if (count > SZS_ROCM_NODE_MOST_GPUS) return szs_report(sz_unexpected_dimensions_k, error_message, "Too many GPUs for one node");
     szs_node_s *node = (szs_node_s *)calloc(1, sizeof(szs_node_s));
     if (!node) return szs_report(sz_bad_alloc_k, error_message, NULL);
-    node->magic = SZS_NODE_MAGIC, node->count = count;
+    node->magic = SZS_NODE_MAGIC, node->count = count, node->references = 1;
     for (size_t i = 0; i < count; ++i) {
         size_t const ordinal = gpu_devices ? gpu_devices[i] : i;
         szs_device_scope_t scope = NULL;
@@ -92,25 +94,34 @@ sz_size_t szs_rocm_node_size(szs_rocm_node_t handle) {
     return node && node->magic == SZS_NODE_MAGIC ? node->count : 0;
 }
 
-void szs_rocm_node_free(szs_rocm_node_t handle) {
-    szs_node_s *node = (szs_node_s *)handle;
-    if (!node || node->magic != SZS_NODE_MAGIC) return;
+/** Drops one reference; the scopes and the node itself go with the last one. */
+static void node_unreference(szs_node_s *node) {
+    if (__atomic_sub_fetch(&node->references, 1u, __ATOMIC_ACQ_REL)) return;
     for (size_t i = 0; i < node->count; ++i)
         if (node->scopes[i]) szs_device_scope_free(node->scopes[i]);
     node->magic = 0;
     free(node);
 }
 
+void szs_rocm_node_free(szs_rocm_node_t handle) {
+    szs_node_s *node = (szs_node_s *)handle;
+    if (!node || node->magic != SZS_NODE_MAGIC) return;
+    if (__atomic_exchange_n(&node->released, 1u, __ATOMIC_ACQ_REL)) return; /* freed twice: the second call is ignored */
+    node_unreference(node); /* engines created from the node keep it alive until they are freed themselves */
+}
+
 /* ---- engines of a node ---------------------------------------------------------------------------------------------------- */
 
 static sz_status_t node_engine_new(szs_rocm_node_t handle, szs_node_engine_s **created, szs_rocm_node_engine_t *out, char const **error_message) {
     szs_node_s *node = (szs_node_s *)handle;
-    if (!node || node->magic != SZS_NODE_MAGIC) return szs_report(sz_status_unknown_k, error_message, "Node must be initialized");
+    if (!node || node->magic != SZS_NODE_MAGIC || __atomic_load_n(&node->released, __ATOMIC_ACQUIRE))
+        return szs_report(sz_status_unknown_k, error_message, "Node must be initialized");
     if (!out) return szs_report(sz_status_unknown_k, error_message, "Engine must not be null");
     if (*out) return szs_report(sz_status_unknown_k, error_message, "Engine must be uninitialized");
     szs_node_engine_s *engine = (szs_node_engine_s *)calloc(1, sizeof(szs_node_engine_s));
     if (!engine) return szs_report(sz_bad_alloc_k, error_message, NULL);
     engine->magic = SZS_NODE_ENGINE_MAGIC, engine->node = node;
+    __atomic_add_fetch(&node->references, 1u, __ATOMIC_ACQ_REL);
     *created = engine, *out = engine;
     return sz_success_k;
 }
@@ -130,6 +141,7 @@ void szs_rocm_node_engine_free(szs_rocm_node_engine_t handle) {
     (void)hipSetDevice(previous);
     szs_buffer_release(&engine->offsets_copy), szs_buffer_release(&engine->shard_of_row), szs_buffer_release(&engine->weights);
     szs_buffer_release(&engine->row_lists), szs_buffer_release(&engine->row_addresses), szs_buffer_release(&engine->row_lengths);
+    node_unreference(engine->node);
     engine->magic = 0;
     free(engine);
 }
@@ -317,6 +329,10 @@ static sz_status_t node_cross(szs_node_engine_s *engine, int wide, char const *q
     void *const candidate_landing = (char *)engine->offsets_copy.pointer + ((q_offsets_bytes + 7) & ~(size_t)7);
     status = node_offsets(candidate_offsets_raw, c_offsets_bytes, candidate_landing, &candidate_offsets, error_message);
     if (status != sz_success_k) return status;
+    for (size_t i = 0; i < candidates_count; ++i) /* before anything is derived from them: a descending tape is a caller's error, not an allocation failure */
+        if (offset_at(candidate_offsets, wide, i + 1) < offset_at(candidate_offsets, wide, i) ||
+            offset_at(candidate_offsets, wide, i + 1) - offset_at(candidate_offsets, wide, i) > 0xFFFFFFFFull)
+            return szs_report(sz_unexpected_dimensions_k, error_message, "Tape offsets must ascend");
     /* the candidates' offsets, rebased to start at zero, in OUR buffer (the caller's array is never written) */
     uint64_t const candidate_first = offset_at(candidate_offsets, wide, 0);
     uint64_t const candidate_bytes = offset_at(candidate_offsets, wide, candidates_count) - candidate_first;

@@ -106,6 +106,7 @@ typedef struct szs_engine_s {
 #ifndef SZS_AUX_STREAMS
 #define SZS_AUX_STREAMS 7
 #endif
+    unsigned last_streams;       /* streams the launches of the last call were dealt over (call profile) */
     hipStream_t aux_streams[SZS_AUX_STREAMS];
     hipEvent_t aux_done[SZS_AUX_STREAMS], fork_event;
     int aux_device; /* device the auxiliary streams live on, -1: none yet */

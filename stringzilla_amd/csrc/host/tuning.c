@@ -36,6 +36,7 @@ static struct {
     [szs_knob_alphabet_k] = {"alphabet", "SZS_ROCM_ALPHABET"},
     [szs_knob_merge_k] = {"merge", "SZS_ROCM_MERGE"},
     [szs_knob_team_k] = {"team", "SZS_ROCM_TEAM"},
+    [szs_knob_queues_k] = {"queues", "SZS_ROCM_QUEUES"},
 };
 
 /** Text -> value.  -1 always means "automatic".  Tier names: lanes 0, systolic 1, chain 2; planner: host 0, device 1. */
@@ -61,13 +62,17 @@ __attribute__((constructor)) static void szs_tuning_load(void) {
     for (int knob = 0; knob < szs_knob_count_k; ++knob)
         knobs[knob] = parse_knob(knob, getenv(knob_names[knob].environment));
     if (knobs[szs_knob_trace_k] < 0) knobs[szs_knob_trace_k] = 0;
-    /*  The per-width launches of one call run on up to 8 streams (dispatch.c: enqueue); the HIP runtime multiplexes a process's
-     *  streams onto GPU_MAX_HW_QUEUES hardware queues, 4 unless told otherwise, and reads that when it initialises - with a
-     *  first HIP call, normally after this library was loaded.  With their own queues the width groups of a small
-     *  (latency-bound) batch overlap: an eighth of config 5 takes 2.0 ms on twelve queues, 2.6 on eight (the application's
-     *  own streams take queues too), 3.0 on four (profiles/r02/shard_preview.jsonl).  A value the application exported is
-     *  left alone.  */
-    setenv("GPU_MAX_HW_QUEUES", "12", 0);
+    /*  The per-width launches of one call fan out over streams (dispatch.c: enqueue), and the HIP runtime multiplexes a process's
+     *  streams onto GPU_MAX_HW_QUEUES hardware queues - 4 unless the APPLICATION says otherwise before HIP initialises.  The
+     *  library only READS that variable, once, here (round 2 exported it from this constructor: a write to the environment
+     *  of a process that may already have threads, and a change of queue allocation for every other HIP user in it).  The
+     *  fan-out is sized to the queues the process really has: more streams than queues would share queues in an order the
+     *  library does not control.  `queues` knob / SZS_ROCM_QUEUES: the queue count to assume; automatic = GPU_MAX_HW_QUEUES, or 4. */
+    if (knobs[szs_knob_queues_k] < 0) {
+        char const *const exported = getenv("GPU_MAX_HW_QUEUES");
+        int const queues = exported ? atoi(exported) : 0;
+        knobs[szs_knob_queues_k] = queues > 0 ? queues : 4;
+    }
 }
 
 int szs_tuning_get(int knob) { return __atomic_load_n(&knobs[knob], __ATOMIC_RELAXED); }
@@ -78,6 +83,7 @@ sz_status_t szs_rocm_tuning_set(char const *knob, char const *value) {
         if (!strcmp(knob, knob_names[k].name) || !strcmp(knob, knob_names[k].environment)) {
             int parsed = parse_knob(k, value);
             if (k == szs_knob_trace_k && parsed < 0) parsed = 0;
+            if (k == szs_knob_queues_k && parsed <= 0) parsed = 4; /* the runtime's default */
             __atomic_store_n(&knobs[k], parsed, __ATOMIC_RELAXED);
             return sz_success_k;
         }

@@ -246,7 +246,7 @@ def test_tuning_knobs_are_set_by_call_not_by_environment():
 
     assert _abi.tuning_set("tier", "lanes") in (None, os.environ.get("SZS_ROCM_TIER"))
     assert _abi.tuning_set("SZS_ROCM_TIER", None) == "lanes"      # the environment spelling names the same knob
-    for knob in ("swap", "packed", "rune_ids", "chain_waves", "trace", "cells", "planner", "speculate", "cpu_requests", "streams", "reuse", "split", "alphabet", "merge"):
+    for knob in ("swap", "packed", "rune_ids", "chain_waves", "trace", "cells", "planner", "speculate", "cpu_requests", "streams", "reuse", "split", "alphabet", "merge", "team", "queues"):
         previous = _abi.tuning_set(knob, "1")
         _abi.tuning_set(knob, previous)
     with pytest.raises(ValueError):
@@ -264,6 +264,18 @@ def test_tuning_knobs_are_set_by_call_not_by_environment():
                                                ctypes.byref(transposed)) == 0
     _abi.tuning_set("tier", None)
     assert tier.value == 0 and with_env_ignored in (0, 1, 2)
+
+
+def test_loading_the_library_leaves_the_environment_alone():
+    """Round 2's constructor exported GPU_MAX_HW_QUEUES=12: a write to the environment of a process that may
+    already run threads.  The library now only READS the variable, once, to size its stream fan-out."""
+    import subprocess
+    import sys
+
+    script = ("import os, ctypes; before = dict(os.environ); ctypes.CDLL(%r); after = dict(os.environ); "
+              "import sys; sys.exit(0 if before == after and 'GPU_MAX_HW_QUEUES' not in after else 1)") % _abi.LIBRARY_PATH
+    environment = {key: value for key, value in os.environ.items() if key != "GPU_MAX_HW_QUEUES"}
+    assert subprocess.run([sys.executable, "-c", script], env=environment).returncode == 0
 
 
 def test_node_entry_fails_loudly_without_a_gpu():
