@@ -75,7 +75,7 @@ def parse_args():
                         help="comma-separated configs reported in the `configs` array (default: 3,4,5,6 on one GPU, "
                              "4,5 strong-scaled on several; 'none' to skip)")
     parser.add_argument("--extra-seconds", type=float, default=4.0, help="GPU time budget per extra config")
-    parser.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU time budget per cpu_baseline sample")
+    parser.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget per cpu_baseline sample")
     parser.add_argument("--extra-scale", type=float, default=1.0,
                         help="testing aid: shrinks the matrix side of the `configs` records (1.0 = BASELINE.json's sizes)")
     parser.add_argument("--no-cpu-baseline", action="store_true")
@@ -164,15 +164,19 @@ def cpu_baseline(load, gpu_matrix, seconds):
     spaced = lambda count, take: np.unique(np.linspace(0, count - 1, num=max(1, min(count, take))).round().astype(np.int64))
     cells_of = lambda rows, columns: float(q_lengths[rows].sum()) * float(c_lengths[columns].sum())
 
-    # calibration: one row per thread (the shim deals contiguous row blocks to threads) x a few candidates
+    # calibration: one row per thread (the shim deals contiguous row blocks to threads) x 64 candidates - the reference's SIMD
+    # engines score one query against 16 / 32 / 64 candidates at once, one per lane, so a sample's candidates come in whole
+    # multiples of 64 (round 2's config-4 sample of 26 candidates left a third of the lanes empty and read 26 GCUPS for ~32)
+    lanes = 64
     rows = spaced(len(q_lengths), max(cores, 1))
-    columns = spaced(len(c_lengths), 8)
+    columns = spaced(len(c_lengths), lanes)
     started = time.perf_counter()
     run(rows, columns)
     rate = cells_of(rows, columns) / max(time.perf_counter() - started, 1e-4)
-    budget_cells = rate * seconds / 6  # one run of the sample takes about a sixth of the budget: five or more timed repeats
-    # grow the sample towards the budget: first more candidates, then more rows
-    take_columns = int(min(len(c_lengths), max(8, budget_cells / max(cells_of(rows, np.arange(len(c_lengths))) / len(c_lengths), 1.0))))
+    budget_cells = rate * seconds / 5  # one run of the sample takes about a fifth of the budget: five or more timed repeats
+    # grow the sample towards the budget: first more candidates (whole lane groups), then more rows
+    per_column = cells_of(rows, np.arange(len(c_lengths))) / len(c_lengths)
+    take_columns = int(min(len(c_lengths), max(lanes, budget_cells / max(per_column, 1.0) // lanes * lanes)))
     columns = spaced(len(c_lengths), take_columns)
     if take_columns == len(c_lengths):
         per_row = cells_of(np.arange(len(q_lengths)), columns) / len(q_lengths)
@@ -184,13 +188,15 @@ def cpu_baseline(load, gpu_matrix, seconds):
     first = time.perf_counter() - started
     expected = gpu_matrix[np.ix_(rows, columns)]
     assert np.array_equal(matrix.view(np.int64), expected.view(np.int64)), "CPU baseline and GPU disagree"
-    repeats = int(max(5, min(50, (seconds - first) / max(first, 1e-3))))
+    # five or more runs when the budget allows; a batch whose SMALLEST fair sample (a row per thread x one lane group) already
+    # takes seconds per run - config 4 - gets three
+    repeats = int(max(3 if first > seconds / 5 else 5, min(50, (seconds - first) / max(first, 1e-3))))
     runs = []
     for _ in range(repeats):
         started = time.perf_counter()
         run(rows, columns)
         runs.append(time.perf_counter() - started)
-    elapsed = float(np.median(runs))  # the median of >= 5 runs: a 256-thread host shows stragglers, a mean of two runs wandered by 25 %
+    elapsed = float(np.median(runs))  # the median: a 256-thread host shows stragglers, a mean of two runs wandered by 25 %
     what = (f"the full {len(q_lengths)}x{len(c_lengths)} batch of the timed config" if whole else
             f"{len(rows)} evenly spaced query rows x {len(columns)} evenly spaced candidates of the timed config")
     return {
