@@ -17,7 +17,8 @@ Line   : rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel aga
          hipEvent-measured kernel time the library records on its own stream.  `cpu_baseline` times the reference's own
          SIMD engines (oracle/_ref, built from /root/reference) on this box's host cores - a reported baseline only.
 configs: the same line carries a `configs` array - one record per other BASELINE.json config (3: NW BLOSUM62, 4: SW
-         affine NUC.4.4, 5: byte-level Levenshtein on Zipf UTF-8, 5u: the same at the codepoint level), each timed
+         affine NUC.4.4, 5: byte-level Levenshtein on Zipf UTF-8, 5u: the same at the codepoint level, 7 / 8: config 2's batch
+         under non-unit costs, linear 1/3/3 and affine 0/1/4/2), each timed
          through its own C-ABI entry point with its kernel and wall GCUPS, checksum, HBM roofline, the VALU counters of
          its dominant kernel (profiles/r02, committed PMC passes) and the reference's Ice Lake engine as `cpu_baseline`
          on a stated sample whose cells are also compared with the GPU's.  With N > 1 configs 4 and 5 are STRONG-scaled
@@ -72,7 +73,7 @@ def parse_args():
                         help="where configs 1-4 come from: numpy's default_rng (the committed profiles) or std::mt19937_64 "
                              "(tests/native/workloads_mt19937.cpp: the same shapes, reproducible from C++)")
     parser.add_argument("--extra-configs", default=None,
-                        help="comma-separated configs reported in the `configs` array (default: 3,4,5,6 on one GPU, "
+                        help="comma-separated configs reported in the `configs` array (default: 3,4,5,6,7,8 on one GPU, "
                              "4,5 strong-scaled on several; 'none' to skip)")
     parser.add_argument("--extra-seconds", type=float, default=4.0, help="GPU time budget per extra config")
     parser.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget per cpu_baseline sample")
@@ -455,7 +456,7 @@ def main():
     # of NW / SW scoring the clocks are where a busy GPU keeps them.  The headline itself is unchanged: W untimed steps, then
     # exactly K timed ones.  (The single-process C driver of N > 1 runs last, while the other ranks wait.)
     if args.extra_configs is None:
-        extras = [3, 4, 5, 6] if world == 1 else [4, 5]
+        extras = [3, 4, 5, 6, 7, 8] if world == 1 else [4, 5]
     else:
         extras = [] if args.extra_configs.strip().lower() in ("", "none") else [int(x) for x in args.extra_configs.split(",")]
     records = []

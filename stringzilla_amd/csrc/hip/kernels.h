@@ -284,17 +284,23 @@ size_t szs_hip_weighted_packed_boundary_bytes(int local, int affine, uint32_t cl
  *  szs_hip_weighted_packed_scores.  `shape` = lanes * 10000 + registers * 100 + wavefronts per SIMD names one of the
  *  compiled instances: szs_hip_weighted_team_shape(i) enumerates them (0 past the last one).  `wide` = 0: cells ordered as
  *  half-float patterns, three-input maxima; = 1: as unsigned integers, two-input maxima.  The caller's bound on every DP value
- *  (global: the reach of serial.hpp:135-162; local: (shorter side + 3) x largest cost) must stay below
- *  szs_hip_weighted_team_reach_limit(local, wide): 15000 / 29000 narrow, 32000 / 62000 wide.
+ *  (global / distance: the reach of serial.hpp:135-162; local: (shorter side + 3) x largest cost) must stay below
+ *  szs_hip_weighted_team_reach_limit(objective, wide): 15000 / 29000 / 30000 narrow, 32000 / 62000 / 64000 wide.
+ *  `objective`: 0 Needleman-Wunsch, 1 Smith-Waterman with gap costs <= 0, 2 Levenshtein with uniform costs - the model then
+ *  holds the NEGATED costs, `byte_to_class` the dense alphabet of the batch (up to 256 classes; szs_hip_byte_presence), and
+ *  results are distances.
  */
 unsigned szs_hip_weighted_team_shape(unsigned index);
 int szs_hip_weighted_team_has_shape(unsigned shape);
-uint32_t szs_hip_weighted_team_reach_limit(int local, int wide);
-int szs_hip_weighted_team_scores(int local, int affine, int wide, unsigned shape, uint32_t classes, szs_cost_model_t const *model,
+uint32_t szs_hip_weighted_team_reach_limit(int objective, int wide);
+int szs_hip_weighted_team_fits(unsigned shape, uint32_t classes);
+/** OR-s into `presence[8]` (device memory, zeroed by the caller) one bit per byte value that occurs in the tape's strings. */
+int szs_hip_byte_presence(void const *data, void const *offsets, uint32_t count, int wide, uint32_t *presence, void *stream);
+int szs_hip_weighted_team_scores(int objective, int affine, int wide, unsigned shape, uint32_t classes, szs_cost_model_t const *model,
                                  szs_string_ref_t const *queries, uint32_t queries_count, szs_string_ref_t const *candidates,
                                  uint32_t candidates_count, uint32_t longest_candidate, int64_t *results,
                                  uint64_t results_row_stride, int symmetric, void *workspace, void *stream);
-size_t szs_hip_weighted_team_workspace_bytes(int local, int affine, int wide, unsigned shape, uint32_t classes, uint32_t queries_count,
+size_t szs_hip_weighted_team_workspace_bytes(int objective, int affine, int wide, unsigned shape, uint32_t classes, uint32_t queries_count,
                                              uint32_t candidates_count, uint32_t longest_candidate);
 
 /**

@@ -112,11 +112,14 @@ struct team_order {
     }
 };
 
-/** The scoring constants of one launch in the chosen representation. */
-template <bool local_, bool affine_, bool wide_>
+/** The scoring constants of one launch in the chosen representation.
+ *  `distance_`: a Levenshtein engine - global alignment over NEGATED non-negative costs, so every value lies in [-reach, 0]
+ *  and the bias sits at the top of the range: twice the reach of a Needleman-Wunsch engine in the same bits. */
+template <bool local_, bool affine_, bool wide_, bool distance_ = false>
 struct team_costs_t {
-    static constexpr bool local = local_, affine = affine_, wide = wide_;
-    static constexpr i32 bias = wide_ ? (local_ ? 1024 : 32768) : (local_ ? 2048 : 16384);
+    static_assert(!(local_ && distance_), "a distance is a global objective");
+    static constexpr bool local = local_, affine = affine_, wide = wide_, distance = distance_;
+    static constexpr i32 bias = wide_ ? (distance_ ? 65024 : local_ ? 1024 : 32768) : (distance_ ? 31232 : local_ ? 2048 : 16384);
     using order = team_order<wide_>;
 
     i32 open, extend; // signed, ADDED; linear gaps: open == extend == the gap cost
@@ -149,9 +152,11 @@ struct team_costs_t {
     }
 };
 
-/** Largest worst-case magnitude a call may have for an instance: the reach of serial.hpp:135-162 (global), or
- *  (shorter side + 3) x largest cost (local).  The host checks it (dispatch.c). */
-SZS_HD u32 team_reach_limit(bool local, bool wide) { return wide ? (local ? 62000u : 32000u) : (local ? 29000u : 15000u); }
+/** Largest worst-case magnitude a call may have for an instance: the reach of serial.hpp:135-162 (global, distance), or
+ *  (shorter side + 3) x largest cost (local).  The host checks it (dispatch.c).  `objective`: 0 global, 1 local, 2 distance. */
+SZS_HD u32 team_reach_limit(int objective, bool wide) {
+    return wide ? (objective == 2 ? 64000u : objective == 1 ? 62000u : 32000u) : (objective == 2 ? 30000u : objective == 1 ? 29000u : 15000u);
+}
 
 /**
  *  The rows of one strip at one column, per lane.

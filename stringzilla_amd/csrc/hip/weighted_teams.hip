@@ -46,6 +46,7 @@ using namespace szs_team;
 constexpr u32 team_block_threads_k = 256;
 constexpr u32 team_slack_columns_k = 8;      // columns the parked-row prefetch may run past the longest candidate
 constexpr size_t team_header_bytes_k = 256;  // the work counter lives at the head of the workspace
+constexpr size_t team_most_profile_bytes_k = 160 * 1024 - 4096; // a CU's LDS less the static arrays of the kernel
 
 /** What lane k - 1 of the team holds in `value`; the head lane (k = 0) gets `head_value` instead. */
 template <int L>
@@ -94,8 +95,13 @@ __device__ __forceinline__ parked_edge_t<affine_> park_of(team_edge_t const &edg
  *  @tparam W        wavefronts per SIMD the registers are allocated for.
  *  @tparam wide_    cells ordered as unsigned integers (two-input maxima, 16 bits of range) instead of as half-float
  *                   patterns (three-input maxima, 15 bits): team_core.hpp.
+ *  @tparam distance_ a Levenshtein engine with non-unit UNIFORM costs: global alignment over the negated costs, the result
+ *                   negated back; the profile comes from class EQUALITY (`model->uniform_match / uniform_mismatch`, negated)
+ *                   instead of a 32 x 32 table, and `byte_to_class` is the batch's own dense alphabet of up to 256 bytes
+ *                   (byte_presence_kernel below + host/dispatch.c).  Reference: levenshtein_distance, serial.hpp:2527-2693;
+ *                   its narrow register kernels cuda.cuh:2939-3128.
  */
-template <bool local_, bool affine_, bool wide_, int L, int R, int W>
+template <bool local_, bool affine_, bool wide_, bool distance_, int L, int R, int W>
 __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
     szs_cost_model_t const *__restrict__ model, szs_string_ref_t const *__restrict__ queries, u32 queries_count,
     szs_string_ref_t const *__restrict__ candidates, u32 candidates_count, u32 candidate_blocks, i64 *__restrict__ results,
@@ -110,10 +116,10 @@ __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
 
     extern __shared__ __attribute__((aligned(16))) char profile[];
     __shared__ unsigned short class_offset_of_byte[256]; // class x layout::class_bytes: the head lanes' text -> profile row
-    __shared__ u8 group_classes[2][group_rows];          // the classes of the group's rows, both queries; 0xFF: padded
+    __shared__ unsigned short group_classes[2][group_rows]; // the classes of the group's rows, both queries; 0xFFFF: padded
     __shared__ u32 claimed_work;
 
-    using costs_t = team_costs_t<local_, affine_, wide_>;
+    using costs_t = team_costs_t<local_, affine_, wide_, distance_>;
     costs_t const k(model->gap_open, model->gap_extend);
     int16_t const *const table = model->substitution; // [query class][candidate class], 2 KB, cache-resident
     for (u32 byte = threadIdx.x; byte < 256; byte += team_block_threads_k)
@@ -127,6 +133,7 @@ __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
 
     bool const transposed = (layout_flags & SZS_LAYOUT_TRANSPOSED) != 0, symmetric = (layout_flags & SZS_LAYOUT_SYMMETRIC) != 0;
     auto write_result = [&](szs_string_ref_t const &query, szs_string_ref_t const &candidate, i64 score) {
+        if constexpr (distance_) score = -score; // a distance is the negated score of the negated costs
         u64 const row = transposed ? candidate.index : query.index, column = transposed ? query.index : candidate.index;
         results[row * results_row_stride + column] = score;
         if (symmetric && candidate.index != query.index) results[column * results_row_stride + row] = score;
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
                 szs_string_ref_t const &query = half ? query_high : query_low;
                 u32 const row = first_row + within;
                 group_classes[half][within / registers_now * R + within % registers_now] =
-                    row < query.length ? model->byte_to_class[reinterpret_cast<u8 const *>(query.address)[row]] : (u8)0xFF;
+                    row < query.length ? (unsigned short)model->byte_to_class[reinterpret_cast<u8 const *>(query.address)[row]] : (unsigned short)0xFFFF;
             }
             __syncthreads();
             for (u32 slot = threadIdx.x; slot < (u32)L * classes * chunks_now; slot += team_block_threads_k) {
@@ -205,9 +212,15 @@ __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     u32 const low_class = group_classes[0][strip * R + 4 * chunk + r], high_class = group_classes[1][strip * R + 4 * chunk + r];
-                    // cost(query, candidate) = table[class(query)][class(candidate)]: the QUERY picks the row (serial.hpp:199-204)
-                    i32 const low = low_class != 0xFF ? table[low_class * 32 + symbol_class] : 0;
-                    i32 const high = high_class != 0xFF ? table[high_class * 32 + symbol_class] : 0;
+                    i32 low, high;
+                    if constexpr (distance_) { // uniform costs: equal bytes have equal classes (serial.hpp:106-115)
+                        low = low_class == 0xFFFF ? 0 : low_class == symbol_class ? model->uniform_match : model->uniform_mismatch;
+                        high = high_class == 0xFFFF ? 0 : high_class == symbol_class ? model->uniform_match : model->uniform_mismatch;
+                    }
+                    else { // cost(query, candidate) = table[class(query)][class(candidate)]: the QUERY picks the row (serial.hpp:199-204)
+                        low = low_class != 0xFFFF ? table[low_class * 32 + symbol_class] : 0;
+                        high = high_class != 0xFFFF ? table[high_class * 32 + symbol_class] : 0;
+                    }
                     entries[r] = k.profile_entry(low, high);
                 }
                 *reinterpret_cast<uint4 *>(profile + layout::strip_base(strip, classes) + symbol_class * layout::class_bytes + chunk * 16) =
@@ -342,23 +355,51 @@ __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
     }
 }
 
+/**
+ *  Which byte values occur in a tape: 256 bits.  A Levenshtein engine's costs are uniform - only EQUALITY of symbols matters -
+ *  so the host numbers the bytes that actually occur 0 ... A - 1 and the team kernel keys its profile by those classes: 95
+ *  rows for printable ASCII, 4 for DNA, instead of 256.  One pass over the bytes at L2 / HBM speed, enqueued beside the planner.
+ */
+__global__ __launch_bounds__(256) void byte_presence_kernel(u8 const *__restrict__ data, void const *__restrict__ offsets, u32 count, u32 wide,
+                                                            u32 *__restrict__ presence) {
+    __shared__ u32 seen[8];
+    if (threadIdx.x < 8) seen[threadIdx.x] = 0;
+    __syncthreads();
+    u64 const first = wide ? static_cast<u64 const *>(offsets)[0] : static_cast<u32 const *>(offsets)[0];
+    u64 const last = wide ? static_cast<u64 const *>(offsets)[count] : static_cast<u32 const *>(offsets)[count];
+    u32 mine[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (u64 at = first + (u64)blockIdx.x * blockDim.x + threadIdx.x; at < last; at += (u64)gridDim.x * blockDim.x) {
+        u32 const byte = data[at];
+#pragma unroll
+        for (int word = 0; word < 8; ++word) mine[word] |= (byte >> 5) == (u32)word ? 1u << (byte & 31) : 0u;
+    }
+#pragma unroll
+    for (int word = 0; word < 8; ++word)
+        if (mine[word]) atomicOr(&seen[word], mine[word]);
+    __syncthreads();
+    if (threadIdx.x < 8 && seen[threadIdx.x]) atomicOr(&presence[threadIdx.x], seen[threadIdx.x]);
+}
+
 template <int L, int R>
 static size_t team_profile_bytes(u32 classes) { return team_profile_layout<L, R>::total_bytes(classes); }
 
 /** Workgroups that can be RESIDENT at once for this kernel instance with this profile size. */
-template <bool local_, bool affine_, bool wide_, int L, int R, int W>
+template <bool local_, bool affine_, bool wide_, bool distance_, int L, int R, int W>
 static u32 team_grid(u64 work_items, u32 classes) {
-    static int resident_of[device_slots_k][34]; // per instance, device ordinal and class count
+    static int resident_of[device_slots_k][258]; // per instance, device ordinal and class count
     int *const slot = &resident_of[device_slot()][classes];
     int resident = cached(slot);
     if (!resident) {
         int device = 0, units = 0, per_unit = 0;
         size_t const profile_bytes = team_profile_bytes<L, R>(classes);
-        if (hipFuncSetAttribute(reinterpret_cast<void const *>(weighted_team_kernel<local_, affine_, wide_, L, R, W>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)team_profile_bytes<L, R>(32)) != hipSuccess ||
+        // the attribute is per function, not per launch: the most this instance may ever ask for, set once
+        size_t const most = team_profile_bytes<L, R>(distance_ ? 256 : 32) < team_most_profile_bytes_k ? team_profile_bytes<L, R>(distance_ ? 256 : 32)
+                                                                                                      : team_most_profile_bytes_k;
+        if (hipFuncSetAttribute(reinterpret_cast<void const *>(weighted_team_kernel<local_, affine_, wide_, distance_, L, R, W>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)most) != hipSuccess ||
             hipGetDevice(&device) != hipSuccess ||
             hipDeviceGetAttribute(&units, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_unit, weighted_team_kernel<local_, affine_, wide_, L, R, W>,
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_unit, weighted_team_kernel<local_, affine_, wide_, distance_, L, R, W>,
                                                          (int)team_block_threads_k, profile_bytes) != hipSuccess ||
             units <= 0 || per_unit <= 0) {
             (void)hipGetLastError();
@@ -383,16 +424,21 @@ static u64 team_work_items(u32 queries_count, u32 candidates_count) {
 #define SZS_TEAM_SHAPES(CALL) CALL(16, 32, 2) CALL(16, 16, 4) CALL(4, 32, 2)
 #endif
 
+/* `objective`: 0 global (Needleman-Wunsch), 1 local (Smith-Waterman, gaps <= 0), 2 distance (Levenshtein, uniform costs). */
 #define SZS_TEAM_DISPATCH(L, R, W, CALL)                                                                               \
     if (shape == L * 10000u + R * 100u + W) {                                                                          \
-        if (local && affine && wide) CALL(true, true, true, L, R, W);                                                  \
-        if (local && affine) CALL(true, true, false, L, R, W);                                                         \
-        if (local && wide) CALL(true, false, true, L, R, W);                                                           \
-        if (local) CALL(true, false, false, L, R, W);                                                                  \
-        if (affine && wide) CALL(false, true, true, L, R, W);                                                          \
-        if (affine) CALL(false, true, false, L, R, W);                                                                 \
-        if (wide) CALL(false, false, true, L, R, W);                                                                   \
-        CALL(false, false, false, L, R, W);                                                                            \
+        if (objective == 2 && affine && wide) CALL(false, true, true, true, L, R, W);                                  \
+        if (objective == 2 && affine) CALL(false, true, false, true, L, R, W);                                         \
+        if (objective == 2 && wide) CALL(false, false, true, true, L, R, W);                                           \
+        if (objective == 2) CALL(false, false, false, true, L, R, W);                                                  \
+        if (objective == 1 && affine && wide) CALL(true, true, true, false, L, R, W);                                  \
+        if (objective == 1 && affine) CALL(true, true, false, false, L, R, W);                                         \
+        if (objective == 1 && wide) CALL(true, false, true, false, L, R, W);                                           \
+        if (objective == 1) CALL(true, false, false, false, L, R, W);                                                  \
+        if (affine && wide) CALL(false, true, true, false, L, R, W);                                                   \
+        if (affine) CALL(false, true, false, false, L, R, W);                                                          \
+        if (wide) CALL(false, false, true, false, L, R, W);                                                            \
+        CALL(false, false, false, false, L, R, W);                                                                     \
     }
 
 extern "C" unsigned szs_hip_weighted_team_shape(unsigned index) {
@@ -410,14 +456,24 @@ extern "C" int szs_hip_weighted_team_has_shape(unsigned shape) {
     return 0;
 }
 
-extern "C" uint32_t szs_hip_weighted_team_reach_limit(int local, int wide) { return szs_team::team_reach_limit(local != 0, wide != 0); }
+extern "C" uint32_t szs_hip_weighted_team_reach_limit(int objective, int wide) { return szs_team::team_reach_limit(objective, wide != 0); }
 
-extern "C" size_t szs_hip_weighted_team_workspace_bytes(int local, int affine, int wide, unsigned shape, uint32_t classes,
+/** Does the profile of `classes` classes fit a CU's LDS for this shape?  (Sixteen lanes x 32 registers: up to 77 classes.) */
+extern "C" int szs_hip_weighted_team_fits(unsigned shape, uint32_t classes) {
+    using namespace szs_hip;
+#define SZS_TEAM_SHAPE_FITS(L, R, W)                                                                                   \
+    if (shape == L * 10000u + R * 100u + W) return team_profile_bytes<L, R>(classes) <= team_most_profile_bytes_k;
+    SZS_TEAM_SHAPES(SZS_TEAM_SHAPE_FITS)
+#undef SZS_TEAM_SHAPE_FITS
+    return 0;
+}
+
+extern "C" size_t szs_hip_weighted_team_workspace_bytes(int objective, int affine, int wide, unsigned shape, uint32_t classes,
                                                         uint32_t queries_count, uint32_t candidates_count, uint32_t longest_candidate) {
     using namespace szs_hip;
-    if (classes > 32) return 0;
-#define SZS_TEAM_BYTES(LOCAL, AFFINE, WIDE, L, R, W)                                                                   \
-    return team_header_bytes_k + (size_t)team_grid<LOCAL, AFFINE, WIDE, L, R, W>(team_work_items<L>(queries_count, candidates_count), classes) * \
+    if (classes > (objective == 2 ? 256u : 32u) || !szs_hip_weighted_team_fits(shape, classes)) return 0;
+#define SZS_TEAM_BYTES(LOCAL, AFFINE, WIDE, DISTANCE, L, R, W)                                                         \
+    return team_header_bytes_k + (size_t)team_grid<LOCAL, AFFINE, WIDE, DISTANCE, L, R, W>(team_work_items<L>(queries_count, candidates_count), classes) * \
                                      (longest_candidate + 1 + team_slack_columns_k) * (team_block_threads_k / L) *     \
                                      sizeof(parked_edge_t<AFFINE>)
 #define SZS_TEAM_SHAPE_BYTES(L, R, W) SZS_TEAM_DISPATCH(L, R, W, SZS_TEAM_BYTES)
@@ -427,26 +483,26 @@ extern "C" size_t szs_hip_weighted_team_workspace_bytes(int local, int affine, i
     return 0;
 }
 
-extern "C" int szs_hip_weighted_team_scores(int local, int affine, int wide, unsigned shape, uint32_t classes, szs_cost_model_t const *model,
+extern "C" int szs_hip_weighted_team_scores(int objective, int affine, int wide, unsigned shape, uint32_t classes, szs_cost_model_t const *model,
                                             szs_string_ref_t const *queries, uint32_t queries_count, szs_string_ref_t const *candidates,
                                             uint32_t candidates_count, uint32_t longest_candidate, int64_t *results,
                                             uint64_t results_row_stride, int layout_flags, void *workspace, void *stream) {
     using namespace szs_hip;
     if (!queries_count || !candidates_count) return 0;
-    if (classes > 32) return (int)hipErrorInvalidValue;
+    if (classes > (objective == 2 ? 256u : 32u) || !szs_hip_weighted_team_fits(shape, classes)) return (int)hipErrorInvalidValue;
     u32 *const counter = static_cast<u32 *>(workspace);
     char *const parked = static_cast<char *>(workspace) + team_header_bytes_k;
     hipStream_t const s = static_cast<hipStream_t>(stream);
-#define SZS_TEAM_LAUNCH(LOCAL, AFFINE, WIDE, L, R, W)                                                                  \
+#define SZS_TEAM_LAUNCH(LOCAL, AFFINE, WIDE, DISTANCE, L, R, W)                                                                  \
     {                                                                                                                  \
         u64 const work_items = team_work_items<L>(queries_count, candidates_count);                                    \
         if (work_items > 0xFFFFFFF0ull) return (int)hipErrorInvalidValue; /* the host cuts larger cross-products */     \
         hipError_t const error = hipMemsetAsync(counter, 0, sizeof(u32), s);                                           \
         if (error != hipSuccess) return (int)error;                                                                    \
-        u32 const grid = team_grid<LOCAL, AFFINE, WIDE, L, R, W>(work_items, classes);                                 \
+        u32 const grid = team_grid<LOCAL, AFFINE, WIDE, DISTANCE, L, R, W>(work_items, classes);                                 \
         u32 const teams = team_block_threads_k / L;                                                                    \
         size_t const profile_bytes = team_profile_bytes<L, R>(classes);                                                \
-        hipLaunchKernelGGL((weighted_team_kernel<LOCAL, AFFINE, WIDE, L, R, W>), dim3(grid), dim3(team_block_threads_k), \
+        hipLaunchKernelGGL((weighted_team_kernel<LOCAL, AFFINE, WIDE, DISTANCE, L, R, W>), dim3(grid), dim3(team_block_threads_k), \
                            profile_bytes, s, model, queries, queries_count, candidates,                                \
                            candidates_count, (candidates_count + teams - 1) / teams, results, results_row_stride,      \
                            layout_flags, parked, longest_candidate + 1 + team_slack_columns_k, counter, classes);      \
@@ -457,4 +513,12 @@ extern "C" int szs_hip_weighted_team_scores(int local, int affine, int wide, uns
 #undef SZS_TEAM_SHAPE_LAUNCH
 #undef SZS_TEAM_LAUNCH
     return (int)hipErrorInvalidValue;
+}
+
+extern "C" int szs_hip_byte_presence(void const *data, void const *offsets, uint32_t count, int wide, uint32_t *presence, void *stream) {
+    using namespace szs_hip;
+    if (!count) return 0;
+    hipLaunchKernelGGL(byte_presence_kernel, dim3(512), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<u8 const *>(data), offsets,
+                       count, (u32)(wide != 0), presence);
+    return (int)hipGetLastError();
 }

@@ -237,6 +237,7 @@ static void fill_cost_model(szs_engine_s const *engine, int transposed, szs_cost
         /* Minimising non-negative costs == maximising their negation; the kernel negates the result back. */
         model->uniform_match = -(int32_t)engine->match, model->uniform_mismatch = -(int32_t)engine->mismatch;
         model->gap_open = -(int32_t)engine->open, model->gap_extend = -(int32_t)engine->extend;
+        if (engine->uniform_classes) memcpy(model->byte_to_class, engine->uniform_byte_to_class, 256); /* the team tier's dense alphabet */
     }
     else {
         /* cost(query, candidate) = table[class(query)][class(candidate)] (serial.hpp:199-204): when the planner swapped
@@ -263,6 +264,7 @@ static void release_device_state(szs_engine_s *engine) {
     szs_buffer_release(&engine->pinned_transcode);
     szs_buffer_release(&engine->device_alphabet);
     szs_buffer_release(&engine->device_plan_refs);
+    szs_buffer_release(&engine->device_presence);
     szs_buffer_release(&engine->pinned_summary);
     if (engine->events_device >= 0) {
         (void)hipEventDestroy(engine->event_start);
@@ -298,13 +300,15 @@ void szs_engine_release(szs_engine_s *engine) {
  *  Which instance of the team tier scores a 16-bit class-table call, 0 for the one-pair-per-lane kernel: the `team` knob, or
  *  the lanes-per-item rule of plan.c with the instance compiled for that many lanes.
  */
-static unsigned team_shape_for(int affine, szs_side_stats_t const *queries, szs_side_stats_t const *candidates) {
+static unsigned team_shape_for(int affine, uint32_t classes, szs_side_stats_t const *queries, szs_side_stats_t const *candidates) {
     int const knob = szs_tuning_get(szs_knob_team_k);
     if (knob == 0) return 0;
-    if (knob > 0) return szs_hip_weighted_team_has_shape((unsigned)knob) ? (unsigned)knob : 0;
-    unsigned const lanes = szs_plan_team_lanes(affine, queries, candidates);
-    for (unsigned index = 0; lanes && szs_hip_weighted_team_shape(index); ++index) /* the first compiled instance of that width */
-        if (szs_hip_weighted_team_shape(index) / 10000u == lanes) return szs_hip_weighted_team_shape(index);
+    if (knob > 0) return szs_hip_weighted_team_has_shape((unsigned)knob) && szs_hip_weighted_team_fits((unsigned)knob, classes) ? (unsigned)knob : 0;
+    unsigned lanes = szs_plan_team_lanes(affine, queries, candidates);
+    for (; lanes; lanes = lanes > 4 ? 4 : 0) /* sixteen strips of a rich alphabet (text: ~95 classes) do not fit a CU's LDS: four do */
+        for (unsigned index = 0; szs_hip_weighted_team_shape(index); ++index) /* the first compiled instance of that width */
+            if (szs_hip_weighted_team_shape(index) / 10000u == lanes && szs_hip_weighted_team_fits(szs_hip_weighted_team_shape(index), classes))
+                return szs_hip_weighted_team_shape(index);
     return 0;
 }
 
@@ -353,8 +357,19 @@ static sz_status_t decide(szs_engine_s const *engine, int symmetric, int runes, 
     if (d->maximise && !d->wide_cells && d->classes <= 32 && szs_tuning_get(szs_knob_packed_k) != 0 &&
         (d->objective == szs_objective_global_k || d->objective == szs_objective_local_saturating_k)) {
         uint64_t const bound = d->packed_local ? (shorter_side + 3) * magnitude : reach; /* what bounds every H and track value */
-        d->team_wide = bound >= szs_hip_weighted_team_reach_limit(d->packed_local, 0);
-        team_capable = bound < szs_hip_weighted_team_reach_limit(d->packed_local, d->team_wide);
+        d->team_objective = d->packed_local;
+        d->team_wide = bound >= szs_hip_weighted_team_reach_limit(d->team_objective, 0);
+        team_capable = bound < szs_hip_weighted_team_reach_limit(d->team_objective, d->team_wide);
+    }
+    /* A Levenshtein engine with non-unit costs over bytes: the same tier over the negated costs, keyed by the batch's own dense
+     * alphabet (engine->uniform_classes, counted on the device for this very call - 0 when the inputs were not tapes), with
+     * 16-bit cells up to a reach of 64000 where the 32-bit kernel of weighted.hip spends 3 / 7 VALU operations per cell
+     * (the reference: 4 x u8 / 2 x u16 register kernels and u8 / u16 warp cells, cuda.cuh:2939-3128, tiers :1842-1854). */
+    if (d->objective == szs_objective_distance_k && !d->use_myers && !d->wide_cells && engine->uniform_classes &&
+        szs_tuning_get(szs_knob_packed_k) != 0) {
+        d->team_objective = 2, d->classes = engine->uniform_classes;
+        d->team_wide = reach >= szs_hip_weighted_team_reach_limit(2, 0);
+        team_capable = reach < szs_hip_weighted_team_reach_limit(2, d->team_wide);
     }
 
     /* ---- orientation and tier.  Every kernel puts ONE side on workgroups / band chains (its "queries") and the other
@@ -379,9 +394,9 @@ static sz_status_t decide(szs_engine_s const *engine, int symmetric, int runes, 
     if (d->wide_cells) /* one tier only: the anti-diagonal walker with 64-bit cells, whatever the shape of the batch */
         d->tier = SZS_TIER_LANES, d->packed = 0, d->narrow = 0;
     d->team = 0;
-    if (team_capable && d->tier == SZS_TIER_LANES) d->team = team_shape_for(!engine->is_linear, kq, kc);
-    if (d->team) d->packed = 1; /* the profile reports 16-bit cells either way */
-    else d->team_wide = 0;
+    if (team_capable && d->tier == SZS_TIER_LANES) d->team = team_shape_for(!engine->is_linear, d->classes, kq, kc);
+    if (d->team) d->packed = 1, d->packed_local = d->team_objective == 1; /* the profile reports 16-bit cells either way */
+    else d->team_wide = 0, d->team_objective = 0;
 
     /* The systolic tier scores every engine family with its weighted recurrences, so it needs the cost model and its
      * own workspace; a job with too many pairs in flight for that workspace stays on the lanes tier. */
@@ -409,20 +424,21 @@ static int has_group_of_variant_zero(szs_decision_t const *d) {
 
 static sz_status_t upload_model(szs_engine_s *engine, szs_decision_t const *d, int device, hipStream_t stream,
                                 char const **error_message) {
-    if (engine->model_uploaded_device == device && engine->model_uploaded_transposed == d->transposed) return sz_success_k;
+    int const per_call = d->team && d->team_objective == 2; /* the byte classes are the batch's: a new model every call */
+    if (!per_call && engine->model_uploaded_device == device && engine->model_uploaded_transposed == d->transposed) return sz_success_k;
     sz_status_t const status = szs_buffer_reserve(&engine->device_model, szs_memory_device_k, device, sizeof(szs_cost_model_t), error_message);
     if (status != sz_success_k) return status;
     fill_cost_model(engine, d->transposed, &engine->host_model); /* lives in the engine: the copy may complete later */
     hipError_t const error = hipMemcpyAsync(engine->device_model.pointer, &engine->host_model, sizeof(szs_cost_model_t), hipMemcpyHostToDevice, stream);
     if (error != hipSuccess) return szs_report_hip(error, error_message);
-    engine->model_uploaded_device = device, engine->model_uploaded_transposed = d->transposed;
+    engine->model_uploaded_device = per_call ? -1 : device, engine->model_uploaded_transposed = d->transposed;
     return sz_success_k;
 }
 
 /** Size of the weighted lanes kernels' strip workspace for this decision. */
 static size_t weighted_boundary_bytes(szs_engine_s const *engine, szs_decision_t const *d) {
     if (d->team)
-        return szs_hip_weighted_team_workspace_bytes(d->packed_local, !engine->is_linear, d->team_wide, d->team, d->classes, d->kq_count, d->kc_count,
+        return szs_hip_weighted_team_workspace_bytes(d->team_objective, !engine->is_linear, d->team_wide, d->team, d->classes, d->kq_count, d->kc_count,
                                                      d->plan.longest_candidate);
     return d->packed ? szs_hip_weighted_packed_boundary_bytes(d->packed_local, !engine->is_linear, d->classes, d->kq_count, d->kc_count,
                                                               d->plan.longest_candidate)
@@ -660,7 +676,7 @@ static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int dev
             }
             else if (d->team) {
                 *cell_bits = 16;
-                launch_error = szs_hip_weighted_team_scores(d->packed_local, !engine->is_linear, d->team_wide, d->team, d->classes, model, queries, count,
+                launch_error = szs_hip_weighted_team_scores(d->team_objective, !engine->is_linear, d->team_wide, d->team, d->classes, model, queries, count,
                                                             candidate_refs, d->kc_count, d->plan.longest_candidate, (int64_t *)device_results,
                                                             device_stride, d->layout, engine->device_boundary.pointer, target);
             }
@@ -911,9 +927,34 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
         remembered->refs_current = 0;                      /* the tapes changed under the same pointers: plan them afresh */
     }
 
+    /* ---- a Levenshtein engine with non-unit costs: which bytes occur in this batch?  One pass over both tapes, enqueued ahead
+     * of the planner and read after the planner's own wait; the team tier keys its profile by the classes the host numbers
+     * from it (decide()).  Such a call is not speculated: its launch depends on what the scan finds. */
+    int const uniform_bytes = engine->family == szs_family_levenshtein_k && !engine->is_unit_cost && szs_tuning_get(szs_knob_packed_k) != 0 &&
+                              szs_tuning_get(szs_knob_team_k) != 0;
+    uint32_t volatile *const presence = (uint32_t volatile *)((char *)engine->pinned_summary.pointer + 896);
+    engine->uniform_classes = 0;
+    if (uniform_bytes) {
+        status = szs_buffer_reserve(&engine->device_presence, szs_memory_device_k, device, 8 * sizeof(uint32_t), error_message);
+        if (status != sz_success_k) return status;
+        error = hipMemsetAsync(engine->device_presence.pointer, 0, 8 * sizeof(uint32_t), stream);
+        if (error == hipSuccess)
+            error = (hipError_t)szs_hip_byte_presence(call->queries->data, call->queries->offsets, q_count, (int)q_side.wide,
+                                                      (uint32_t *)engine->device_presence.pointer, stream);
+        if (error == hipSuccess && !symmetric)
+            error = (hipError_t)szs_hip_byte_presence(call->candidates->data, call->candidates->offsets, c_count, (int)c_side.wide,
+                                                      (uint32_t *)engine->device_presence.pointer, stream);
+        if (error == hipSuccess)
+            error = hipMemcpyAsync((void *)presence, engine->device_presence.pointer, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+        if (error != hipSuccess) {
+            (void)hipStreamSynchronize(stream);
+            return szs_report_hip(error, error_message);
+        }
+    }
+
     /* ---- speculate: launches shaped like the previous call go in right behind the planner */
     int const speculate = remembered->valid && remembered->tier == SZS_TIER_LANES && remembered->q_count == q_count &&
-                          remembered->c_count == c_count && remembered->symmetric == symmetric && knobs_automatic;
+                          remembered->c_count == c_count && remembered->symmetric == symmetric && knobs_automatic && !uniform_bytes;
     szs_plan_summary_t seen;
     int have_summary = 0;
     if (speculate) {
@@ -978,6 +1019,12 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
     if (seen.status & SZS_PLAN_STATUS_DESCENDING) return szs_report(sz_unexpected_dimensions_k, error_message, "Tape offsets must ascend");
     if (seen.status & SZS_PLAN_STATUS_OVERFLOW) return szs_report(sz_overflow_risk_k, error_message, NULL);
     if (seen.status & SZS_PLAN_STATUS_UNSORTED) return SZS_NOT_DEVICE_PLANNABLE; /* strings beyond the planner's histogram */
+    if (uniform_bytes) { /* the scan has landed (the planner's wait covered it): number the bytes that occur 0 ... A - 1 */
+        uint32_t classes = 0;
+        for (unsigned byte = 0; byte < 256; ++byte)
+            engine->uniform_byte_to_class[byte] = (presence[byte / 32] >> (byte % 32)) & 1u ? (uint8_t)classes++ : 0;
+        engine->uniform_classes = classes ? classes : 1; /* a batch of empty strings: one class nobody belongs to */
+    }
     phase(call, 1);
 
     for (int attempt = 0; attempt < 2; ++attempt) { /* second round: a stalled band chain is re-run on the lanes tier */

@@ -100,6 +100,11 @@ typedef struct szs_engine_s {
     int model_uploaded_device;
     int model_uploaded_transposed; /* the uploaded class table is the transpose (sides swapped by the planner) */
     szs_cost_model_t host_model;   /* what was uploaded: lives as long as the engine, so the upload needs no wait */
+    /* non-unit Levenshtein engines over byte tapes: the dense alphabet of the CURRENT call's batch (hip/weighted_teams.hip:
+     * byte_presence_kernel), 0 classes when the call's inputs are not tapes the device can scan */
+    uint32_t uniform_classes;
+    uint8_t uniform_byte_to_class[256];
+    szs_buffer_t device_presence;  /* device: the 256 presence bits */
     hipEvent_t event_start, event_stop;
     int events_device;
     /* launches of different bit-vector widths fan out over these and fill each other's tails (dispatch.c: enqueue) */
@@ -193,6 +198,7 @@ typedef struct szs_decision_t {
     int tier, transposed, layout;
     int use_myers, banded, maximise;
     int objective, narrow, packed, packed_local, wide_cells;
+    int team_objective;        /* the team tier's objective: 0 global, 1 local, 2 distance (uniform-cost Levenshtein) */
     int team_wide;             /* the team tier's cell order: 0 half-float patterns (three-input maxima), 1 unsigned (hip/team_core.hpp) */
     unsigned team;             /* 0, or the shape of the team tier that scores the call (hip/kernels.h: lanes * 10000 + registers * 100 + waves) */
     uint32_t classes;

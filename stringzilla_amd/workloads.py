@@ -130,6 +130,12 @@ def config(index: int, scale: float = 1.0, generator: str = "numpy") -> Workload
         return Workload("cfg5u: 3163x3163 UTF-8 Zipf(1.1) bytes [8,2048], codepoint-level Levenshtein unit",
                         "levenshtein_utf8", zipf_utf8_tape(rng, side(3163)), zipf_utf8_tape(rng, side(3163)),
                         dict(match=0, mismatch=1, open=1, extend=1))
+    if index in (7, 8):  # config 2's batch under NON-UNIT costs (a north_star function: szs_levenshtein_distances_init takes all four):
+        rng = np.random.default_rng(2)  # 7: linear gaps, match 1 / mismatch 3 / gap 3; 8: affine gaps, mismatch 1 / open 4 / extend 2
+        costs = dict(match=1, mismatch=3, open=3, extend=3) if index == 7 else dict(match=0, mismatch=1, open=4, extend=2)
+        gaps = "linear 1/3/3" if index == 7 else "affine 0/1/4/2"
+        return Workload(f"cfg2w{'l' if index == 7 else 'a'}: 1024x1024 ASCII len U[96,160], Levenshtein {gaps}", "levenshtein",
+                        random_tape(rng, side(1024), 96, 160, ASCII_PRINTABLE), random_tape(rng, side(1024), 96, 160, ASCII_PRINTABLE), costs)
     raise ValueError(f"unknown config {index}")
 
 

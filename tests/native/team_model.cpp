@@ -24,11 +24,11 @@ struct text_t {
     uint32_t length;
 };
 
-template <bool local_, bool affine_, bool wide_, int L, int R>
+template <bool local_, bool affine_, bool wide_, bool distance_, int L, int R>
 void score_item(text_t q_low, text_t q_high, bool has_high, std::vector<text_t> const &block, uint8_t const *byte_to_class,
                 int8_t const *class_costs, int open, int extend, int64_t *out_low, int64_t *out_high) {
     constexpr uint32_t teams_per_wave = 64 / L;
-    using costs_t = team_costs_t<local_, affine_, wide_>;
+    using costs_t = team_costs_t<local_, affine_, wide_, distance_>;
     costs_t const k(open, extend);
     uint32_t const teams = (uint32_t)block.size();
     uint32_t const longer = q_low.length; // the queries arrive longest first
@@ -146,7 +146,7 @@ void score_item(text_t q_low, text_t q_high, bool has_high, std::vector<text_t> 
     }
 }
 
-template <bool local_, bool affine_, bool wide_, int L, int R>
+template <bool local_, bool affine_, bool wide_, bool distance_, int L, int R>
 void cross(text_t const *queries, uint32_t queries_count, text_t const *candidates, uint32_t candidates_count,
            uint8_t const *byte_to_class, int8_t const *class_costs, int open, int extend, int64_t *results, uint64_t stride) {
     // the kernel's roles: queries longest first, candidates by ascending length, 256 / L candidates per block
@@ -165,7 +165,7 @@ void cross(text_t const *queries, uint32_t queries_count, text_t const *candidat
             std::vector<text_t> block(count);
             for (uint32_t i = 0; i < count; ++i) block[i] = candidates[c_order[first + i]];
             std::vector<int64_t> out_low(count), out_high(count);
-            score_item<local_, affine_, wide_, L, R>(queries[low], queries[high], has_high, block, byte_to_class, class_costs, open, extend,
+            score_item<local_, affine_, wide_, distance_, L, R>(queries[low], queries[high], has_high, block, byte_to_class, class_costs, open, extend,
                                               out_low.data(), out_high.data());
             for (uint32_t i = 0; i < count; ++i) {
                 results[(uint64_t)low * stride + c_order[first + i]] = out_low[i];
@@ -180,7 +180,9 @@ void cross(text_t const *queries, uint32_t queries_count, text_t const *candidat
 #define TEAM_SHAPES(CALL) CALL(16, 32) CALL(16, 16) CALL(16, 24) CALL(8, 32) CALL(4, 32) CALL(4, 8) CALL(2, 16) CALL(1, 32) CALL(1, 4)
 
 /** Tapes with count + 1 64-bit offsets; results[q * stride + c].  `wide`: cells ordered as unsigned integers (two-input maxima)
- *  instead of as half-float patterns.  Returns 0, or -1 for a shape that is not instantiated. */
+ *  instead of as half-float patterns.  `local` = 2: a DISTANCE engine - the caller passes negated costs (a 256-class identity map
+ *  and a table of -match / -mismatch stand in for uniform costs) and negates the scores back.  Returns 0, or -1 for a shape that
+ *  is not instantiated. */
 extern "C" int team_model_cross(int local, int affine, int wide, int lanes, int registers, char const *q_data, uint64_t const *q_offsets,
                                 uint32_t q_count, char const *c_data, uint64_t const *c_offsets, uint32_t c_count,
                                 uint8_t const *byte_to_class, int8_t const *class_costs, int open, int extend, int64_t *results,
@@ -191,10 +193,12 @@ extern "C" int team_model_cross(int local, int affine, int wide, int lanes, int 
 #define TEAM_ARGUMENTS queries.data(), q_count, candidates.data(), c_count, byte_to_class, class_costs, open, extend, results, stride
 #define TEAM_ORDER(WIDE, L, R)                                                                                                   \
     {                                                                                                                            \
-        if (local && affine) cross<true, true, WIDE, L, R>(TEAM_ARGUMENTS);                                                      \
-        else if (local) cross<true, false, WIDE, L, R>(TEAM_ARGUMENTS);                                                          \
-        else if (affine) cross<false, true, WIDE, L, R>(TEAM_ARGUMENTS);                                                         \
-        else cross<false, false, WIDE, L, R>(TEAM_ARGUMENTS);                                                                    \
+        if (local == 2 && affine) cross<false, true, WIDE, true, L, R>(TEAM_ARGUMENTS);                                          \
+        else if (local == 2) cross<false, false, WIDE, true, L, R>(TEAM_ARGUMENTS);                                              \
+        else if (local && affine) cross<true, true, WIDE, false, L, R>(TEAM_ARGUMENTS);                                          \
+        else if (local) cross<true, false, WIDE, false, L, R>(TEAM_ARGUMENTS);                                                   \
+        else if (affine) cross<false, true, WIDE, false, L, R>(TEAM_ARGUMENTS);                                                  \
+        else cross<false, false, WIDE, false, L, R>(TEAM_ARGUMENTS);                                                             \
         return 0;                                                                                                                \
     }
 #define TEAM_CALL(L, R)                                                                                                          \

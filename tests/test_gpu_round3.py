@@ -132,3 +132,42 @@ def test_team_tier_cell_orders(gpu, oracle, kind):
             profile = engine.last_call_profile()
             assert (profile.team == shape) == teamed and (not teamed or profile.team_wide == wide), (length, profile.team, profile.team_wide)
             assert np.array_equal(got, expected), (kind, length)
+
+
+@pytest.mark.parametrize("costs", [(1, 3, 3, 3), (0, 1, 4, 2), (0, 4, 3, 2), (2, 5, 4, 1), (0, 1, 2, 2)])
+def test_weighted_levenshtein_on_the_team_tier(gpu, oracle, costs):
+    """Non-unit Levenshtein costs over byte tapes: the team tier over the negated costs, its profile keyed by the dense
+    alphabet of the batch (counted on the device per call), 16-bit cells - against the oracle, with the knob both ways, for
+    alphabets of 4, 95 and 256 byte values (sixteen strips of 256 classes do not fit a CU's LDS: four lanes take those)."""
+    rng = random.Random(hash(costs) & 0xFFFF)
+    engine = szs.LevenshteinDistances(*costs, capabilities=gpu)
+    for alphabet, q_low, q_high, q_count, c_count, c_high in [
+        (b"ACGT", 90, 700, 9, 130, 300), (bytes(range(32, 127)), 96, 160, 12, 300, 160), (bytes(range(256)), 100, 1200, 7, 70, 200),
+        (b"AB", 1, 60, 9, 40, 50),
+    ]:
+        queries = _rand(rng, q_count, q_low, q_high, alphabet) + [b"", alphabet[:1]]
+        candidates = _rand(rng, c_count, 0, c_high, alphabet) + [b""]
+        expected = oracle.levenshtein(queries, candidates, *costs)
+        expected_sym = oracle.levenshtein(queries, None, *costs)
+        with forced_tier("lanes"):
+            got = engine(queries, candidates, device=gpu)
+            automatic = engine.last_call_profile()
+            assert np.array_equal(got, expected), (costs, len(alphabet), automatic.team)
+            assert np.array_equal(engine(queries, device=gpu), expected_sym), (costs, len(alphabet), "symmetric")
+            for shape in _abi.team_shapes():
+                with forced_env("team", shape):
+                    assert np.array_equal(engine(queries, candidates, device=gpu), expected), (costs, len(alphabet), shape)
+                    profile = engine.last_call_profile()
+                    fits = len(alphabet) <= 64 or shape // 10000 <= 4
+                    assert (profile.team == shape and profile.cell_bits == 16) if fits else profile.cell_bits == 32, (shape, profile.team, profile.cell_bits)
+            with forced_env("team", 0):
+                assert np.array_equal(engine(queries, candidates, device=gpu), expected), (costs, len(alphabet), "team off")
+                assert engine.last_call_profile().team == 0 and engine.last_call_profile().cell_bits == 32
+    # the long, costly end of the 16-bit range and just beyond it (reach = (longest + 1 or 3) x largest cost)
+    queries, candidates = _rand(rng, 3, 5000, 6000, b"ACGT"), _rand(rng, 20, 3000, 6000, b"ACGT")
+    expected = oracle.levenshtein(queries, candidates, *costs)
+    with forced_tier("lanes"), forced_env("team", _abi.team_shapes()[0]):
+        assert np.array_equal(engine(queries, candidates, device=gpu), expected), (costs, "long")
+        reach = (6000 + 3) * max(costs)
+        profile = engine.last_call_profile()
+        assert profile.team_wide == (1 if reach >= 30000 else 0) or profile.team == 0, (reach, profile.team, profile.team_wide)

@@ -139,3 +139,36 @@ def test_model_at_the_edge_of_its_range(model, wide):
     for affine, gaps in [(1, (-128, -128 + 1)), (0, (-128, -128)), (1, (-3, -1))]:
         got = run_model(model, 0, affine, wide, 16, 16, queries, candidates, byte_to_class, table, *gaps)
         assert np.array_equal(got, oracle.needleman_wunsch(queries, candidates, byte_to_class, table, *gaps))
+
+
+@pytest.mark.parametrize("wide", [0, 1])
+@pytest.mark.parametrize("lanes,registers", [(16, 32), (4, 32), (16, 16)])
+def test_model_scores_weighted_levenshtein(model, lanes, registers, wide):
+    """A Levenshtein engine with non-unit costs is the global recurrence over NEGATED costs with the bias at the top of the
+    range (team_core.hpp: `distance_`): distances up to 30000 / 64000 in 16 bits.  Uniform costs stand as an identity class
+    table here; the kernel builds its profile from class equality instead (GPU tests)."""
+    rng = np.random.default_rng(40 + lanes + wide)
+    oracle = binding.oracle()
+    alphabet = b"ABCDEFGHIJKLMNOPQRSTUVWXYZabcde"
+    byte_to_class = np.zeros(256, np.uint8)
+    for index, letter in enumerate(alphabet):
+        byte_to_class[letter] = index + 1
+    for match, mismatch, open, extend in [(0, 1, 1, 1), (1, 3, 3, 3), (0, 1, 4, 2), (0, 4, 3, 2), (2, 5, 4, 1)]:
+        table = np.full((32, 32), -mismatch, np.int8)
+        np.fill_diagonal(table, -match)
+        rows = lanes * registers
+        queries = random_strings(rng, 5, 1, min(2 * rows, 600), alphabet) + [b"", alphabet[:2]]
+        candidates = random_strings(rng, 300 // lanes + 3, 0, 90, alphabet) + [b""]
+        got = run_model(model, 2, open != extend, wide, lanes, registers, queries, candidates, byte_to_class, table, -open, -extend)
+        expected = oracle.levenshtein(queries, candidates, match, mismatch, open, extend)
+        assert np.array_equal(-got, expected.astype(np.int64)), (match, mismatch, open, extend)
+    # at the edge of the range: long strings, the largest costs
+    limit = 64000 if wide else 30000
+    length = limit // 127 - 3
+    queries, candidates = [b"A" * length, b"AB" * (length // 2)], [b"B" * length, b"A" * (length - 7), b""]
+    for match, mismatch, open, extend in [(0, 127, 127, 127), (3, 127, 127, 126)]:
+        table = np.full((32, 32), -mismatch, np.int8)
+        np.fill_diagonal(table, -match)
+        got = run_model(model, 2, open != extend, wide, 16, 16, queries, candidates, byte_to_class, table, -open, -extend)
+        expected = oracle.levenshtein(queries, candidates, match, mismatch, open, extend)
+        assert np.array_equal(-got, expected.astype(np.int64)) and expected.max() > 0.9 * limit
