@@ -134,6 +134,15 @@ def test_team_tier_cell_orders(gpu, oracle, kind):
             assert np.array_equal(got, expected), (kind, length)
 
 
+def _profile_fits(shape, classes):
+    """csrc/hip/team_core.hpp: team_profile_layout - does the cost profile of `classes` classes fit a CU's LDS?"""
+    lanes, registers = shape // 10000, shape // 100 % 100
+    row_bytes = 4 * registers
+    slots = 1 if row_bytes >= 256 else min(256 // row_bytes, lanes)
+    blocks, class_bytes = lanes // slots, 256 if slots > 1 else row_bytes
+    return blocks * (classes * class_bytes + 16) <= 160 * 1024 - 4096
+
+
 @pytest.mark.parametrize("costs", [(1, 3, 3, 3), (0, 1, 4, 2), (0, 4, 3, 2), (2, 5, 4, 1), (0, 1, 2, 2)])
 def test_weighted_levenshtein_on_the_team_tier(gpu, oracle, costs):
     """Non-unit Levenshtein costs over byte tapes: the team tier over the negated costs, its profile keyed by the dense
@@ -158,7 +167,7 @@ def test_weighted_levenshtein_on_the_team_tier(gpu, oracle, costs):
                 with forced_env("team", shape):
                     assert np.array_equal(engine(queries, candidates, device=gpu), expected), (costs, len(alphabet), shape)
                     profile = engine.last_call_profile()
-                    fits = len(alphabet) <= 64 or shape // 10000 <= 4
+                    fits = _profile_fits(shape, len(alphabet))
                     assert (profile.team == shape and profile.cell_bits == 16) if fits else profile.cell_bits == 32, (shape, profile.team, profile.cell_bits)
             with forced_env("team", 0):
                 assert np.array_equal(engine(queries, candidates, device=gpu), expected), (costs, len(alphabet), "team off")
@@ -168,6 +177,7 @@ def test_weighted_levenshtein_on_the_team_tier(gpu, oracle, costs):
     expected = oracle.levenshtein(queries, candidates, *costs)
     with forced_tier("lanes"), forced_env("team", _abi.team_shapes()[0]):
         assert np.array_equal(engine(queries, candidates, device=gpu), expected), (costs, "long")
-        reach = (6000 + 3) * max(costs)
+        longest = max(len(s) for s in queries + candidates)
+        reach = (longest + (1 if costs[2] == costs[3] else 3)) * max(costs)  # serial.hpp:135-162, minimising
         profile = engine.last_call_profile()
         assert profile.team_wide == (1 if reach >= 30000 else 0) or profile.team == 0, (reach, profile.team, profile.team_wide)
