@@ -143,7 +143,8 @@ SZ_API_RUNTIME sz_status_t szs_rocm_node_scores_u64tape(szs_rocm_node_engine_t e
  *  "split" (0 | 2 | 4: lanes per pair of the long bit-parallel widths), "alphabet" (0 | 1: never / always renumber the runes
  *  of a codepoint batch on the device), "merge" (n: candidate blocks per workgroup of the short bit-parallel kernels),
  *  "team" (0: never | lanes * 10000 + registers * 100 + waves: that shape of the team tier of the 16-bit weighted scorers),
- *  "queues" (see below),
+ *  "queues" (see below), "roctx" (1: the host phases of every call - plan, decide, enqueue, wait - as roctx ranges for a
+ *  `rocprofv3 --marker-trace` timeline; the marker library is looked up at run time, never linked),
  *  "cpu_requests" (strict | gpu: serve capability
  *  masks without the GPU bit and CPU device scopes with the GPU engines on device 0 instead of refusing them) - or its
  *  environment spelling ("SZS_ROCM_TIER" ...); `value` NULL, "" or "auto" restores the automatic choice.  No knob changes a

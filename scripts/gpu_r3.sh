@@ -14,6 +14,15 @@ for step in "$@"; do
     share4)     timeout 600 python scripts/measure_team.py --config 4 --shards 8 > "$OUT/team_cfg4_share.jsonl" 2> "$OUT/team_cfg4_share.err"; cat "$OUT/team_cfg4_share.jsonl"; tail -3 "$OUT/team_cfg4_share.err";;
     ops)        timeout 300 scripts/bin/team_ops > "$OUT/team_ops.json" 2> "$OUT/team_ops.err"; cat "$OUT/team_ops.json"; tail -3 "$OUT/team_ops.err";;
     sweep)      timeout 900 python scripts/measure_team_sweep.py > "$OUT/team_sweep.jsonl" 2> "$OUT/team_sweep.err"; cat "$OUT/team_sweep.jsonl"; tail -3 "$OUT/team_sweep.err";;
+    asan)       # the C host under ASan + UBSan, driven by the torch-free probes: every family, the chained tiers, the node driver
+                # (use_sigaltstack=0: the HIP runtime pins pages the sanitizer wants to unmap when a worker thread exits)
+                export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:use_sigaltstack=0 UBSAN_OPTIONS=print_stacktrace=1 PROBE_ALARM=120
+                { for args in "lev 40 300 50 700 1" "levw 40 300 50 700 1" "nw 40 300 50 700 1" "sw 40 300 50 700 1" "nw 9 300 900 1100 1 -4 -1" "lev 3 4 2040 2100 1" "lev 1 1 30000 40000 1" "nw 1 1 30000 40000 1"; do
+                    echo "--- systolic_probe $args"; timeout 300 tests/native/bin/systolic_probe_asan $args 2>&1 | grep -v "^    #" | tail -6; done
+                  for args in "lev 70 300 10 400 0 0" "nw 33 200 100 600 0 0 0" "sw 20 100 500 900 0"; do
+                    echo "--- node_probe $args"; timeout 300 tests/native/bin/node_probe_asan $args 2>&1 | grep -v "^    #" | tail -6; done
+                  echo "--- fingerprints_probe"; timeout 300 tests/native/bin/fingerprints_probe_asan 64 50 100 5000 1 2>&1 | tail -4; } > "$OUT/asan.log" 2>&1
+                grep -c "ERROR: AddressSanitizer\|runtime error" "$OUT/asan.log"; tail -40 "$OUT/asan.log";;
     bench)      timeout 600 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; tail -c 3000 "$OUT/bench.json"; tail -3 "$OUT/bench.err";;
     configs)    timeout 600 python scripts/measure_configs.py --configs 2,3,4,5 > "$OUT/configs.jsonl" 2>&1; cat "$OUT/configs.jsonl";;
     *) echo "unknown step $step";;

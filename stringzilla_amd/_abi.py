@@ -160,7 +160,7 @@ _KNOBS = {"tier": "SZS_ROCM_TIER", "swap": "SZS_ROCM_SWAP", "packed": "SZS_ROCM_
           "planner": "SZS_ROCM_PLANNER", "speculate": "SZS_ROCM_SPECULATE", "cpu_requests": "SZS_ROCM_CPU_REQUESTS",
           "streams": "SZS_ROCM_STREAMS", "reuse": "SZS_ROCM_REUSE",
           "split": "SZS_ROCM_SPLIT", "alphabet": "SZS_ROCM_ALPHABET", "merge": "SZS_ROCM_MERGE",
-          "team": "SZS_ROCM_TEAM", "queues": "SZS_ROCM_QUEUES"}
+          "team": "SZS_ROCM_TEAM", "queues": "SZS_ROCM_QUEUES", "roctx": "SZS_ROCM_ROCTX"}
 _knob_values = {name: os.environ.get(variable) for name, variable in _KNOBS.items()}  # what the library read when it was loaded
 
 

@@ -156,6 +156,7 @@ enum {
     szs_knob_team_k,        /* -1 automatic | 0: never the team tier of the 16-bit weighted scorers | lanes * 10000 + registers * 100 + waves: that shape */
     szs_knob_queues_k,      /* hardware queues the process has (GPU_MAX_HW_QUEUES when the library was loaded, else 4): the launches of a
                                call fan out over at most that many streams */
+    szs_knob_roctx_k,       /* 0 | 1: the host phases of every call as roctx ranges (rocprofv3 --marker-trace) */
     szs_knob_count_k
 };
 int szs_tuning_get(int knob);

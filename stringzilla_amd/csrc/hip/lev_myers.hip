@@ -675,7 +675,7 @@ __global__ __launch_bounds__(split_threads_k<lanes_>) void levenshtein_myers_spl
     constexpr int words = words_per_lane_ * lanes_;
     constexpr u32 threads = split_threads_k<lanes_>, pairs_per_block = threads / lanes_;
     constexpr int chunks_per_lane = words_per_lane_ / 4;
-    static_assert(words_per_lane_ % 4 == 0 && (lanes_ == 2 || lanes_ == 4), "whole 16-byte Peq chunks per lane");
+    static_assert(words_per_lane_ % 4 == 0 && (lanes_ == 2 || lanes_ == 4 || lanes_ == 8), "whole 16-byte Peq chunks per lane");
     using layout = peq_layout<words>;
     __shared__ __attribute__((aligned(16))) u32 peq[layout::total_dwords];
 
@@ -1143,7 +1143,7 @@ __global__ __launch_bounds__(256 * lanes_) void levenshtein_myers_split_runes_ke
                                                                                       int symmetric, u32 rune_slots, u32 id_capacity, u32 alphabet) {
     constexpr int words = words_per_lane_ * lanes_;
     constexpr u32 threads = 256u * lanes_;
-    static_assert(words_per_lane_ % 4 == 0 && (lanes_ == 2 || lanes_ == 4), "whole 16-byte Peq chunks per lane");
+    static_assert(words_per_lane_ % 4 == 0 && (lanes_ == 2 || lanes_ == 4 || lanes_ == 8), "whole 16-byte Peq chunks per lane");
     extern __shared__ __attribute__((aligned(16))) u32 rune_lds[];
     rune_masks_t<words, lanes_> const masks(rune_lds, rune_slots, id_capacity, alphabet);
     __shared__ u32 counters[2];
@@ -1539,6 +1539,8 @@ extern "C" int szs_hip_levenshtein_myers_split(unsigned words, unsigned lanes, s
     SZS_SPLIT_CASE(32, 4)
     SZS_SPLIT_CASE(48, 4)
     SZS_SPLIT_CASE(64, 4)
+    SZS_SPLIT_CASE(32, 8)
+    SZS_SPLIT_CASE(64, 8)
 #undef SZS_SPLIT_CASE
     return (int)hipErrorInvalidValue;
 }

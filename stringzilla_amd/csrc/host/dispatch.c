@@ -21,6 +21,7 @@
  */
 #include "szs_internal.h"
 
+#include <dlfcn.h>
 #include <pthread.h>
 
 #include <stdio.h>
@@ -530,15 +531,17 @@ static hipError_t szs_aux_streams(int device, unsigned wanted, hipStream_t *stre
  */
 static unsigned split_lanes_of(int knob, unsigned variant, uint64_t workgroups_unsplit) {
     if (variant != 24 && variant != 32 && variant != 48 && variant != 64) return 0;
-    unsigned lanes = knob == 0 ? 0u : knob == 2 || knob == 4 ? (unsigned)knob : workgroups_unsplit < 1024 ? 4u : 2u;
-    if (variant == 24 && lanes == 4) lanes = 2;
+    unsigned lanes = knob == 0 ? 0u : knob == 2 || knob == 4 || knob == 8 ? (unsigned)knob : workgroups_unsplit < 256 ? 8u : workgroups_unsplit < 1024 ? 4u : 2u;
+    if (variant == 24 && lanes >= 4) lanes = 2;
+    if (variant == 48 && lanes == 8) lanes = 4; /* six words per lane are not whole 16-byte chunks */
     return lanes;
 }
 
 /** The same for codepoints: 48 and 64 words always over four lanes - their rune table leaves room for one workgroup per CU,
  *  and only the split kernel puts more than one wavefront per SIMD behind it (lev_myers.hip). */
 static unsigned split_lanes_of_runes(int knob, unsigned variant, uint64_t workgroups_unsplit) {
-    unsigned const lanes = split_lanes_of(knob, variant, workgroups_unsplit);
+    unsigned lanes = split_lanes_of(knob, variant, workgroups_unsplit);
+    if (lanes == 8) lanes = 4; /* the rune kernels are instantiated for two and four lanes */
     return lanes && knob < 0 && variant >= 48 ? 4u : lanes;
 }
 
@@ -723,10 +726,54 @@ typedef struct szs_call_t {
     size_t device_stride;
     double started, phase_started, phases[6];
     int trace;
+    int ranges; /* roctx ranges currently open for this call: 0, 1 (the call) or 2 (the call and a phase) */
     char const **error_message;
 } szs_call_t;
 
+/* ---- roctx ranges (`roctx` knob): the host phases of a call as nested ranges a `rocprofv3 --marker-trace` timeline shows
+ *      next to the kernels - the counterpart of the reference's NVTX-free but timer-instrumented executors.
+ *      The marker library is looked up at run time: the product library does not link it, and without the knob nothing is
+ *      loaded and a call pays one relaxed load. */
+static struct {
+    pthread_once_t once;
+    int (*push)(char const *);
+    int (*pop)(void);
+} roctx = {PTHREAD_ONCE_INIT, NULL, NULL};
+
+static void roctx_resolve(void) {
+    char const *const names[] = {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"};
+    for (unsigned i = 0; i < sizeof(names) / sizeof(names[0]) && !roctx.push; ++i) {
+        void *const library = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+        if (!library) continue;
+        roctx.push = (int (*)(char const *))dlsym(library, "roctxRangePushA");
+        roctx.pop = (int (*)(void))dlsym(library, "roctxRangePop");
+        if (!roctx.push || !roctx.pop) roctx.push = NULL, roctx.pop = NULL;
+    }
+}
+
+static char const *const phase_names[6] = {"szs: inputs and buffers", "szs: plan", "szs: decide and prepare", "szs: enqueue",
+                                           "szs: wait for the device", "szs: profile"};
+
+static void ranges_begin(szs_call_t *call) {
+    call->ranges = 0;
+    if (szs_tuning_get(szs_knob_roctx_k) <= 0) return;
+    (void)pthread_once(&roctx.once, roctx_resolve);
+    if (!roctx.push) return;
+    (void)roctx.push("szs_engine_cross"), (void)roctx.push(phase_names[0]);
+    call->ranges = 2;
+}
+
+static void ranges_end(szs_call_t *call) {
+    for (; call->ranges > 0; --call->ranges) (void)roctx.pop();
+}
+
+/** The END of phase `index`: accounts its time (`trace` knob) and opens the next phase's range (`roctx` knob). */
 static void phase(szs_call_t *call, int index) {
+    if (call->ranges == 2) {
+        (void)roctx.pop();
+        if (index + 1 < 6) (void)roctx.push(phase_names[index + 1]);
+        else call->ranges = 1;
+    }
     if (!call->trace) return;
     double const now = now_milliseconds();
     call->phases[index] += now - call->phase_started, call->phase_started = now;
@@ -1260,10 +1307,15 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
     call.results = results, call.results_row_stride = results_row_stride, call.error_message = error_message;
 
     int const planner = szs_tuning_get(szs_knob_planner_k);
+    ranges_begin(&call);
+    status = SZS_NOT_DEVICE_PLANNABLE;
     if (planner != 0 && engine->family != szs_family_levenshtein_utf8_k && device_plannable(engine, queries) &&
-        (symmetric || device_plannable(engine, candidates))) {
+        (symmetric || device_plannable(engine, candidates)))
         status = cross_device_planned(&call);
-        if (status != SZS_NOT_DEVICE_PLANNABLE) return status;
+    if (status == SZS_NOT_DEVICE_PLANNABLE) {
+        if (call.ranges) ranges_end(&call), ranges_begin(&call); /* the phases start over */
+        status = cross_host_planned(&call);
     }
-    return cross_host_planned(&call);
+    ranges_end(&call);
+    return status;
 }

@@ -37,6 +37,7 @@ static struct {
     [szs_knob_merge_k] = {"merge", "SZS_ROCM_MERGE"},
     [szs_knob_team_k] = {"team", "SZS_ROCM_TEAM"},
     [szs_knob_queues_k] = {"queues", "SZS_ROCM_QUEUES"},
+    [szs_knob_roctx_k] = {"roctx", "SZS_ROCM_ROCTX"},
 };
 
 /** Text -> value.  -1 always means "automatic".  Tier names: lanes 0, systolic 1, chain 2; planner: host 0, device 1. */

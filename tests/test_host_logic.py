@@ -246,7 +246,7 @@ def test_tuning_knobs_are_set_by_call_not_by_environment():
 
     assert _abi.tuning_set("tier", "lanes") in (None, os.environ.get("SZS_ROCM_TIER"))
     assert _abi.tuning_set("SZS_ROCM_TIER", None) == "lanes"      # the environment spelling names the same knob
-    for knob in ("swap", "packed", "rune_ids", "chain_waves", "trace", "cells", "planner", "speculate", "cpu_requests", "streams", "reuse", "split", "alphabet", "merge", "team", "queues"):
+    for knob in ("swap", "packed", "rune_ids", "chain_waves", "trace", "cells", "planner", "speculate", "cpu_requests", "streams", "reuse", "split", "alphabet", "merge", "team", "queues", "roctx"):
         previous = _abi.tuning_set(knob, "1")
         _abi.tuning_set(knob, previous)
     with pytest.raises(ValueError):
