@@ -5,13 +5,17 @@
 #   stringzillas  : python/stringzillas/*.c, linked against OUR libstringzillas_rocm_shared.so instead of the
 #                   reference's c/stringzillas/*.cpp|.cu shim units - i.e. the `stringzillas-rocm` target the reference
 #                   declares in setup.py:863-865 but never defines.
-# Output: oracle/_ref/pybinding/ (git-ignored, travels to the GPU box with the snapshot).  Test infrastructure: it
-# exists so that tests/test_reference_binding.py can drive the product through the reference's own Python API.
+# This IS the drop-in at the Python level: the reference's binding sources, unmodified, over this library's C-ABI.
+#   usage: build_reference_binding.sh [OUT_DIR]      (REFERENCE=/path/to/StringZilla, default /root/reference)
+# CMake drives it as the optional target `stringzillas_rocm_python` (-DSTRINGZILLAS_ROCM_REFERENCE_ROOT=...); the test
+# suite calls it with OUT_DIR = oracle/_ref/pybinding (git-ignored, travels to the GPU box with the snapshot), where
+# tests/test_reference_binding.py and tests/test_reference_suite.py drive the product through the reference's own Python API.
 set -eu
 HERE=$(cd "$(dirname "$0")" && pwd)
-ROOT=$(cd "$HERE/.." && pwd)
+ROOT=$(cd "$HERE/../.." && pwd)
 REFERENCE=${REFERENCE:-/root/reference}
-OUT=$HERE/_ref/pybinding
+OUT=${1:-$ROOT/oracle/_ref/pybinding}
+LIBDIR=${STRINGZILLAS_ROCM_LIBDIR:-$ROOT/stringzilla_amd/lib}
 if [ ! -d "$REFERENCE/python/stringzillas" ]; then echo "reference tree $REFERENCE absent: keeping prebuilt $OUT (if any)"; exit 0; fi
 mkdir -p "$OUT/obj"
 PYINC=$(python3 -c "import sysconfig; print(sysconfig.get_paths()['include'])")
@@ -39,14 +43,16 @@ if [ ! -f "$OUT/stringzilla$SUFFIX" ]; then
 fi
 EXTRA="-I$REFERENCE/c/stringzillas -DSZ_USE_CUDA=1 -DFU_WITH_TOPOLOGY=0"
 compile szs python/stringzillas/stringzillas.c python/stringzillas/device_scope.c python/stringzillas/similarities.c python/stringzillas/fingerprints.c
-gcc -shared -fPIC "$OUT"/obj/szs_*.o -o "$OUT/stringzillas$SUFFIX" -L"$ROOT/stringzilla_amd/lib" -lstringzillas_rocm_shared \
-    -Wl,-rpath,'$ORIGIN/../../../stringzilla_amd/lib'
+gcc -shared -fPIC "$OUT"/obj/szs_*.o -o "$OUT/stringzillas$SUFFIX" -L"$LIBDIR" -lstringzillas_rocm_shared \
+    -Wl,-rpath,"$LIBDIR" -Wl,-rpath,'$ORIGIN/../../../stringzilla_amd/lib'
 rm -rf "$OUT/obj"
 # The reference's OWN Python test suite for this path (test/similarities.py and the two helper modules it imports) is
 # carried along the same way - into oracle/_ref/, which is git-ignored: reference-derived, never in this repository's
 # history, but it travels to the GPU box with the snapshot, where /root/reference does not exist.
 # tests/test_reference_suite.py runs it, unmodified, against the binding built above.
-SUITE=$HERE/_ref/reference_tests/test
-mkdir -p "$SUITE"
-for file in __init__.py similarities.py sz_helpers.py szs_helpers.py; do cp "$REFERENCE/test/$file" "$SUITE/$file"; done
+if [ "$OUT" = "$ROOT/oracle/_ref/pybinding" ]; then
+    SUITE=$ROOT/oracle/_ref/reference_tests/test
+    mkdir -p "$SUITE"
+    for file in __init__.py similarities.py sz_helpers.py szs_helpers.py; do cp "$REFERENCE/test/$file" "$SUITE/$file"; done
+fi
 echo "built $OUT/stringzilla$SUFFIX and $OUT/stringzillas$SUFFIX against libstringzillas_rocm_shared.so"

@@ -1,5 +1,5 @@
 #!/bin/bash
-# gpu_r3.sh TAG STEP... - round 3's GPU visits; every step under its own `timeout` so a hung kernel cannot hold the box.
+# gpu_visit.sh TAG STEP... - the GPU visits of a round; every step under its own `timeout` so a hung kernel cannot hold the box.
 #   team-tests | all-tests | team4 | team3 | share4 | bench | configs
 set -u
 TAG=${1:-r3}; shift

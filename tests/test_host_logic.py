@@ -278,6 +278,22 @@ def test_loading_the_library_leaves_the_environment_alone():
     assert subprocess.run([sys.executable, "-c", script], env=environment).returncode == 0
 
 
+def test_cmake_project_configures():
+    """The top-level CMakeLists.txt defines `stringzillas_rocm_shared` - the target name the reference reserves
+    (CMakeLists.txt:14,819).  Configure only: the build itself is what `make -C stringzilla_amd/csrc` does."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    if not shutil.which("cmake") or not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("cmake or the ROCm compiler is not installed")
+    with tempfile.TemporaryDirectory() as build:
+        done = subprocess.run(["cmake", "-S", ROOT, "-B", build], capture_output=True, text=True)
+        assert done.returncode == 0, done.stderr[-2000:]
+        listing = subprocess.run(["cmake", "--build", build, "--target", "help"], capture_output=True, text=True).stdout
+        assert "stringzillas_rocm_shared" in listing
+
+
 def test_node_entry_fails_loudly_without_a_gpu():
     import torch
 

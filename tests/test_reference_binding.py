@@ -1,6 +1,6 @@
 """The product driven through the REFERENCE'S OWN Python binding.
 
-`oracle/build_reference_binding.sh` compiles the reference's CPython modules - `stringzilla` (Str / Strs) and
+`bindings/python/build_reference_binding.sh` compiles the reference's CPython modules - `stringzilla` (Str / Strs) and
 `stringzillas` (python/stringzillas/*.c: DeviceScope, LevenshteinDistances, ...) - from the sources under /root/reference
 and links the latter against `libstringzillas_rocm_shared.so` in place of the reference's own shim: the `stringzillas-rocm`
 wheel target its setup.py:863-865 names but never defines.  Nothing of this repository's Python layer is involved: if these
@@ -27,7 +27,7 @@ def _available():
 
 
 if not _available() and os.path.isdir("/root/reference"):
-    subprocess.run(["bash", os.path.join(ROOT, "oracle", "build_reference_binding.sh")], check=False, capture_output=True)
+    subprocess.run(["bash", os.path.join(ROOT, "bindings", "python", "build_reference_binding.sh")], check=False, capture_output=True)
 
 needs_binding = pytest.mark.skipif(not _available(), reason="reference binding not built (no /root/reference here)")
 

@@ -6,7 +6,7 @@ independent Gotoh baseline, the backend-differential sweep over degenerate corpo
 inputs `:975`, `to_device` `:1008`) is run in a subprocess against
 
   * the reference's own CPython binding (`python/stringzillas/*.c`), compiled from the reference tree and linked against
-    THIS repository's `libstringzillas_rocm_shared.so` (oracle/build_reference_binding.sh) - so every score the suite
+    THIS repository's `libstringzillas_rocm_shared.so` (bindings/python/build_reference_binding.sh) - so every score the suite
     checks is computed by the gfx950 kernels behind the C-ABI;
   * `tests/reference_suite/affine_gaps.py`, a stand-in for the `affine_gaps` PyPI package the suite uses as its NW / SW
     baseline (not installable here: no network), answering with this repository's CPU oracle.
@@ -39,7 +39,7 @@ def _available():
 
 
 if not _available() and os.path.isdir("/root/reference"):
-    subprocess.run(["bash", os.path.join(ROOT, "oracle", "build_reference_binding.sh")], check=False, capture_output=True)
+    subprocess.run(["bash", os.path.join(ROOT, "bindings", "python", "build_reference_binding.sh")], check=False, capture_output=True)
 
 
 @pytest.mark.gpu
