@@ -180,9 +180,13 @@ typedef struct szs_side_stats_t {
 /** One side of the planner's input and output: a tape (32- or 64-bit offsets, device-accessible) and two ref arrays. */
 typedef struct szs_plan_side_t {
     void const *offsets;
-    uint64_t base; /* address of the tape's bytes */
+    uint64_t base; /* address of the tape's bytes - or, with `lengths`, of the UTF-32 scratch tape */
     uint32_t count, wide;
     szs_string_ref_t *ascending, *descending;
+    /* codepoint engines: string i is `lengths[i]` runes at `base + 4 * starts[i]` (szs_hip_utf8_transcode_tape wrote both);
+     * the offsets are still checked (descending tapes are reported, never scored).  NULL: a byte tape. */
+    uint32_t const *lengths;
+    uint64_t const *starts;
 } szs_plan_side_t;
 
 /** The launch shape the host has ALREADY enqueued scoring kernels for (speculation on the previous call's shape). */
@@ -218,6 +222,16 @@ int szs_hip_plan(szs_plan_side_t const *queries, szs_plan_side_t const *candidat
  */
 int szs_hip_utf8_transcode(szs_string_ref_t const *strings, uint32_t count, uint64_t const *rune_starts, uint32_t *runes,
                            uint32_t *rune_counts, uint32_t *any_multibyte, void *stream);
+
+/**
+ *  The same from a TAPE whose offsets the host has not read (the device-planned codepoint path): string i's runes start at
+ *  side_base + align4(offsets[i] - offsets[0]) + 8 i, side_base = 0 or the span of the `before` tape; the starts are written to
+ *  `rune_starts` (for szs_hip_alphabet_rename and the planner).  Strings whose slot would pass `capacity` runes are skipped
+ *  and `*needed` (device memory) receives the runes the buffer must hold: the caller compares, grows and repeats.
+ */
+int szs_hip_utf8_transcode_tape(void const *data, void const *offsets, uint32_t count, int wide, void const *before_offsets,
+                                uint32_t before_count, int before_wide, uint64_t capacity, uint32_t *runes, uint64_t *rune_starts,
+                                uint32_t *rune_counts, uint32_t *any_multibyte, uint64_t *needed, void *stream);
 
 /**
  *  Renumbers the runes of a transcoded batch 1 ... A (equal runes, equal ids) in place, when it holds at most `most` distinct

@@ -97,6 +97,11 @@ __global__ __launch_bounds__(plan_threads_k) void plan_kernel(szs_plan_side_t qu
         if (i == tid) from = first_from[s], to = first_to[s];
         else from = tape_offset(side_of[s]->offsets, side_of[s]->wide, i), to = tape_offset(side_of[s]->offsets, side_of[s]->wide, (u64)i + 1);
     };
+    // codepoint engines: a string's length is its RUNE count and its symbols live in the UTF-32 scratch tape (kernels.h)
+    auto length_of = [&](int s, u32 i, u64 from, u64 to) -> u64 { return side_of[s]->lengths ? (u64)side_of[s]->lengths[i] : to - from; };
+    auto address_of = [&](int s, u32 i, u64 from) -> u64 {
+        return side_of[s]->lengths ? side_of[s]->base + 4 * side_of[s]->starts[i] : side_of[s]->base + from;
+    };
 
     // ---- phase 1: the histogram of the lengths; malformed or over-long strings only raise a flag (the host takes over)
     u32 status = 0;
@@ -106,8 +111,8 @@ __global__ __launch_bounds__(plan_threads_k) void plan_kernel(szs_plan_side_t qu
             span_of(s, i, from, to);
             if (to < from) status |= SZS_PLAN_STATUS_DESCENDING;
             else if (to - from > 0xFFFFFFFFull) status |= SZS_PLAN_STATUS_OVERFLOW;
-            else if (to - from >= plan_bins_k) status |= SZS_PLAN_STATUS_UNSORTED;
-            else atomicAdd(&histogram[s][(u32)(to - from)], 1u); // per-lane addresses: a plain ds_add
+            else if (length_of(s, i, from, to) >= plan_bins_k) status |= SZS_PLAN_STATUS_UNSORTED;
+            else atomicAdd(&histogram[s][(u32)length_of(s, i, from, to)], 1u); // per-lane addresses: a plain ds_add
         }
 #pragma unroll
     for (int offset = 32; offset >= 1; offset >>= 1) status |= (u32)__shfl_xor((int)status, offset, 64);
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(plan_threads_k) void plan_kernel(szs_plan_side_t qu
         u32 const last = first + chunk < queries.count ? first + chunk : queries.count;
         u64 mine = 0;
         for (u32 i = first; i < last; ++i)
-            mine += tape_offset(queries.offsets, queries.wide, (u64)i + 1) - tape_offset(queries.offsets, queries.wide, i);
+            mine += length_of(0, i, tape_offset(queries.offsets, queries.wide, i), tape_offset(queries.offsets, queries.wide, (u64)i + 1));
         chunk_sums[tid] = mine; // prefix of the chunk sums: 64-bit; a serial pass by one thread is 1024 additions
         __syncthreads();
         if (tid == 0) {
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(plan_threads_k) void plan_kernel(szs_plan_side_t qu
         __syncthreads();
         u64 running = chunk_sums[tid], cells = 0;
         for (u32 i = first; i < last; ++i) {
-            u64 const length = tape_offset(queries.offsets, queries.wide, (u64)i + 1) - tape_offset(queries.offsets, queries.wide, i);
+            u64 const length = length_of(0, i, tape_offset(queries.offsets, queries.wide, i), tape_offset(queries.offsets, queries.wide, (u64)i + 1));
             running += length, cells += length * running;
         }
 #pragma unroll
@@ -257,10 +262,10 @@ __global__ __launch_bounds__(plan_threads_k) void plan_kernel(szs_plan_side_t qu
             for (u32 i = tid; i < side_of[s]->count; i += plan_threads_k) {
                 u64 from, to;
                 span_of(s, i, from, to);
-                u32 const length = (u32)(to - from);
+                u32 const length = (u32)length_of(s, i, from, to);
                 u32 const position = atomicAdd(&histogram[s][length], 1u); // equal lengths: any order scores the same matrix
                 szs_string_ref_t ref;
-                ref.address = side_of[s]->base + from, ref.length = blank ? 0u : length, ref.index = i;
+                ref.address = address_of(s, i, from), ref.length = blank ? 0u : length, ref.index = i;
                 side_of[s]->ascending[position] = ref;
                 side_of[s]->descending[side_of[s]->count - 1 - position] = ref;
             }

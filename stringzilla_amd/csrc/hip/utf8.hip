@@ -35,18 +35,65 @@ namespace szs_hip {
  */
 constexpr int transcode_waves_k = 4; // wavefronts (strings in flight) per workgroup
 
-__global__ __launch_bounds__(64 * transcode_waves_k) void utf8_transcode_kernel(szs_string_ref_t const *__restrict__ strings, u32 count,
-                                                                                u64 const *__restrict__ rune_starts,
-                                                                                u32 *__restrict__ runes, u32 *__restrict__ rune_counts,
+/** Where string i lies and where its runes go - from refs and host-made starts (the host-planned path) ... */
+struct transcode_refs_t {
+    szs_string_ref_t const *strings;
+    u64 const *rune_starts;
+    __device__ __forceinline__ void locate(u32 i, u8 const *&bytes, u32 &length, u64 &start) const {
+        bytes = reinterpret_cast<u8 const *>(strings[i].address), length = strings[i].length, start = rune_starts[i];
+    }
+};
+
+/**
+ *  ... or straight from a TAPE the host has never read (the device-planned path): string i's runes start at
+ *      side_base + align4(offset[i] - offset[0]) + 8 i
+ *  - a string never has more runes than bytes and its slot is its byte span rounded up to four plus eight, so slots cannot
+ *  collide, every array starts on a 16-byte boundary and owns its storage up to the next one (what the codepoint kernels'
+ *  four-rune loads need), and no scan is needed.  `side_base` of the candidates is the span of the queries, worked out here
+ *  from the queries' own offsets.  The starts are WRITTEN (`starts_out`) for the renumbering pass and the planner.  A string
+ *  whose offsets descend, or whose slot would pass `capacity` runes (the buffer was sized by an earlier call), is skipped:
+ *  the planner reports the former, `*needed` (runes) lets the host grow the buffer and come back for the latter.
+ */
+struct transcode_tape_t {
+    u8 const *data;
+    void const *offsets, *before_offsets; // `before`: the tape whose runes come first in the buffer (NULL: none)
+    u32 count, wide, before_count, before_wide;
+    u64 capacity;
+    u64 *starts_out, *needed;
+    __device__ __forceinline__ static u64 at(void const *offsets, u32 wide, u64 index) {
+        return wide ? static_cast<u64 const *>(offsets)[index] : (u64) static_cast<u32 const *>(offsets)[index];
+    }
+    __device__ __forceinline__ static u64 span(void const *offsets, u32 wide, u32 count) {
+        u64 const first = at(offsets, wide, 0), last = at(offsets, wide, count);
+        return last >= first ? ((last - first + 3) & ~(u64)3) + 8ull * count + 4 : 0; // runes
+    }
+    __device__ __forceinline__ void locate(u32 i, u8 const *&bytes, u32 &length, u64 &start) const {
+        u64 const first = at(offsets, wide, 0), from = at(offsets, wide, i), to = at(offsets, wide, (u64)i + 1);
+        u64 const side_base = before_offsets ? span(before_offsets, before_wide, before_count) : 0;
+        bool const sound = from >= first && to >= from && to - from <= 0xFFFFFFFFull;
+        start = side_base + (sound ? ((from - first + 3) & ~(u64)3) + 8ull * i : 0);
+        length = sound ? (u32)(to - from) : 0u;
+        if (start + (((u64)length + 3) & ~(u64)3) > capacity) length = 0; // the host finds `needed` above `capacity` and returns
+        bytes = data + from;
+        starts_out[i] = start;
+        if (i == 0 && needed) *needed = side_base + span(offsets, wide, count);
+    }
+};
+
+template <typename source_t>
+__global__ __launch_bounds__(64 * transcode_waves_k) void utf8_transcode_kernel(source_t source, u32 count, u32 *__restrict__ runes,
+                                                                                u32 *__restrict__ rune_counts,
                                                                                 u32 *__restrict__ any_multibyte) {
     __shared__ u8 reached[transcode_waves_k][64];
     u32 const lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     u8 volatile *const mine = reached[wave];
     u64 const below = (1ull << lane) - 1; // lanes before this one
     for (u32 i = blockIdx.x * transcode_waves_k + wave; i < count; i += gridDim.x * transcode_waves_k) {
-        u8 const *const bytes = reinterpret_cast<u8 const *>(strings[i].address);
-        u32 const length = strings[i].length;
-        u32 *const out = runes + rune_starts[i];
+        u8 const *bytes;
+        u32 length;
+        u64 start;
+        source.locate(i, bytes, length, start);
+        u32 *const out = runes + start;
         u32 produced = 0, hanging = 0; // `hanging`: bytes at the head of the chunk that belong to the previous chunk's last rune
         bool multibyte = false;
         u32 ahead = lane < length ? bytes[lane] : 0u; // the chunk after the current one, loaded one step early
@@ -184,8 +231,23 @@ extern "C" int szs_hip_utf8_transcode(szs_string_ref_t const *strings, uint32_t 
     using namespace szs_hip;
     if (!count) return 0;
     u32 const blocks = (count + transcode_waves_k - 1) / transcode_waves_k;
-    hipLaunchKernelGGL(utf8_transcode_kernel, dim3(blocks < 65536u ? blocks : 65536u), dim3(64 * transcode_waves_k), 0, static_cast<hipStream_t>(stream),
-                       strings, count, rune_starts, runes, rune_counts, any_multibyte);
+    transcode_refs_t const source = {strings, rune_starts};
+    hipLaunchKernelGGL(utf8_transcode_kernel<transcode_refs_t>, dim3(blocks < 65536u ? blocks : 65536u), dim3(64 * transcode_waves_k), 0,
+                       static_cast<hipStream_t>(stream), source, count, runes, rune_counts, any_multibyte);
+    return (int)hipGetLastError();
+}
+
+extern "C" int szs_hip_utf8_transcode_tape(void const *data, void const *offsets, uint32_t count, int wide, void const *before_offsets,
+                                           uint32_t before_count, int before_wide, uint64_t capacity, uint32_t *runes,
+                                           uint64_t *rune_starts, uint32_t *rune_counts, uint32_t *any_multibyte, uint64_t *needed,
+                                           void *stream) {
+    using namespace szs_hip;
+    if (!count) return 0;
+    u32 const blocks = (count + transcode_waves_k - 1) / transcode_waves_k;
+    transcode_tape_t const source = {static_cast<u8 const *>(data), offsets, before_offsets, count, (u32)(wide != 0), before_count,
+                                     (u32)(before_wide != 0), capacity, rune_starts, needed};
+    hipLaunchKernelGGL(utf8_transcode_kernel<transcode_tape_t>, dim3(blocks < 65536u ? blocks : 65536u), dim3(64 * transcode_waves_k), 0,
+                       static_cast<hipStream_t>(stream), source, count, runes, rune_counts, any_multibyte);
     return (int)hipGetLastError();
 }
 

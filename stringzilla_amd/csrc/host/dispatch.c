@@ -904,16 +904,17 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
     if (status != sz_success_k) return status;
     szs_string_ref_t *const base = (szs_string_ref_t *)engine->device_plan_refs.pointer;
     szs_plan_side_t q_side = {call->queries->offsets, (uint64_t)(uintptr_t)call->queries->data, q_count,
-                              call->queries->kind == szs_input_u64tape_k, base, base + q_count};
+                              call->queries->kind == szs_input_u64tape_k, base, base + q_count, NULL, NULL};
     szs_plan_side_t c_side = q_side;
     if (!symmetric) {
         szs_plan_side_t const other = {call->candidates->offsets, (uint64_t)(uintptr_t)call->candidates->data, c_count,
                                        call->candidates->kind == szs_input_u64tape_k, base + 2 * (size_t)q_count,
-                                       base + 2 * (size_t)q_count + c_count};
+                                       base + 2 * (size_t)q_count + c_count, NULL, NULL};
         c_side = other;
     }
     szs_plan_summary_t volatile *const summary = (szs_plan_summary_t volatile *)engine->pinned_summary.pointer;
-    int const use_myers = engine->is_unit_cost && engine->family == szs_family_levenshtein_k;
+    /* (the codepoint family gets here with an ASCII corpus: its runes are its bytes) */
+    int const use_myers = engine->is_unit_cost && (engine->family == szs_family_levenshtein_k || engine->family == szs_family_levenshtein_utf8_k);
     unsigned const myers_words = use_myers ? SZS_MYERS_MAX_WORDS : 0;
     if (!engine->remembered) {
         engine->remembered = (szs_decision_t *)calloc(1, sizeof(szs_decision_t));
@@ -977,7 +978,8 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
     /* ---- a Levenshtein engine with non-unit costs: which bytes occur in this batch?  One pass over both tapes, enqueued ahead
      * of the planner and read after the planner's own wait; the team tier keys its profile by the classes the host numbers
      * from it (decide()).  Such a call is not speculated: its launch depends on what the scan finds. */
-    int const uniform_bytes = engine->family == szs_family_levenshtein_k && !engine->is_unit_cost && szs_tuning_get(szs_knob_packed_k) != 0 &&
+    int const uniform_bytes = (engine->family == szs_family_levenshtein_k || engine->family == szs_family_levenshtein_utf8_k) &&
+                              !engine->is_unit_cost && szs_tuning_get(szs_knob_packed_k) != 0 &&
                               szs_tuning_get(szs_knob_team_k) != 0;
     uint32_t volatile *const presence = (uint32_t volatile *)((char *)engine->pinned_summary.pointer + 896);
     engine->uniform_classes = 0;
@@ -1108,6 +1110,135 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
             stamp_refs(remembered, key_data, key_offsets, key_wide, &seen);
             return sz_success_k;
         }
+    }
+    return szs_report(sz_status_unknown_k, error_message, "Systolic pipeline stalled");
+}
+
+/* ---- device-planned codepoint calls --------------------------------------------------------------------------------------- */
+
+#define SZS_RUNES_ARE_BYTES ((sz_status_t)2) /* internal: the corpus is ASCII - the byte engines compute the same distances */
+
+/**
+ *  The codepoint engine over tapes the device can read, without the host reading a single offset (round 2 planned these calls
+ *  on the host: offsets downloaded, strings gathered and re-addressed in O(Q + C) host loops, a wait between transcoding and
+ *  planning - a third of the wall time of a batch of short words).  One stream, one wait:
+ *      transcode both tapes (hip/utf8.hip: rune starts follow from the byte offsets alone, no scan) -> renumber the runes
+ *      -> plan on RUNE counts (hip/planner.hip) -> wait -> decide -> launch.
+ *  The UTF-32 buffer is sized by the previous calls; a batch that needs more says so (`needed`) and is transcoded again.
+ *  An ASCII corpus goes to the byte engines (serial.hpp:2809-2813, applied per call).
+ */
+static sz_status_t cross_device_planned_runes(szs_call_t *call) {
+    szs_engine_s *engine = call->engine;
+    hipStream_t const stream = call->stream;
+    int const device = call->device, symmetric = call->symmetric;
+    uint32_t const q_count = call->q_count, c_count = call->c_count;
+    char const **error_message = call->error_message;
+    size_t const strings = (size_t)q_count + (symmetric ? 0 : c_count);
+
+    /* device staging: [rune starts, u64][rune counts, u32][any_multibyte, distinct runes, alphabet overflow, pad][needed, u64] */
+    size_t const starts_at = 0, counts_at = strings * sizeof(uint64_t);
+    size_t const flags_at = (counts_at + strings * sizeof(uint32_t) + 7) & ~(size_t)7, needed_at = flags_at + 4 * sizeof(uint32_t);
+    size_t const staging_bytes = needed_at + sizeof(uint64_t);
+    sz_status_t status = szs_buffer_reserve(&engine->device_transcode, szs_memory_device_k, device, staging_bytes, error_message);
+    if (status == sz_success_k) status = szs_buffer_reserve(&engine->pinned_transcode, szs_memory_pinned_k, device, 64, error_message);
+    void *const refs_before = engine->device_plan_refs.pointer;
+    if (status == sz_success_k)
+        status = szs_buffer_reserve(&engine->device_plan_refs, szs_memory_device_k, device, 2 * strings * sizeof(szs_string_ref_t), error_message);
+    if (engine->remembered && (status != sz_success_k || engine->device_plan_refs.pointer != refs_before))
+        engine->remembered->refs_current = 0, engine->remembered->valid = 0;
+    if (status == sz_success_k && engine->device_runes.capacity < ((size_t)1 << 20))
+        status = szs_buffer_reserve(&engine->device_runes, szs_memory_device_k, device, (size_t)1 << 20, error_message);
+    int const alphabet_knob = szs_tuning_get(szs_knob_alphabet_k);
+    int const renumber = alphabet_knob == 0 ? 0 : alphabet_knob > 0 ? 1 : strings >= 256; /* worth three more launches */
+    if (status == sz_success_k && renumber)
+        status = szs_buffer_reserve(&engine->device_alphabet, szs_memory_device_k, device, szs_hip_alphabet_workspace_bytes(), error_message);
+    if (status == sz_success_k) status = place_results(call);
+    if (status != sz_success_k) return status;
+    if (engine->remembered) engine->remembered->refs_current = 0; /* the planner is about to overwrite the refs */
+    phase(call, 0);
+
+    char *const remote = (char *)engine->device_transcode.pointer;
+    uint32_t volatile *const flags = (uint32_t volatile *)engine->pinned_transcode.pointer; /* 4 flags, then `needed` */
+    szs_string_ref_t *const base = (szs_string_ref_t *)engine->device_plan_refs.pointer;
+    szs_plan_summary_t volatile *const summary = (szs_plan_summary_t volatile *)engine->pinned_summary.pointer;
+    szs_plan_summary_t seen;
+    szs_plan_side_t q_side, c_side;
+    for (int round = 0;; ++round) {
+        uint64_t const capacity = engine->device_runes.capacity / sizeof(uint32_t);
+        uint64_t *const starts = (uint64_t *)(remote + starts_at);
+        uint32_t *const counts = (uint32_t *)(remote + counts_at), *const device_flags = (uint32_t *)(remote + flags_at);
+        hipError_t error = hipMemsetAsync(remote + flags_at, 0, staging_bytes - flags_at, stream);
+        if (error == hipSuccess)
+            error = (hipError_t)szs_hip_utf8_transcode_tape(call->queries->data, call->queries->offsets, q_count,
+                                                            call->queries->kind == szs_input_u64tape_k, NULL, 0, 0, capacity,
+                                                            (uint32_t *)engine->device_runes.pointer, starts, counts, device_flags,
+                                                            symmetric ? (uint64_t *)(remote + needed_at) : NULL, stream);
+        if (error == hipSuccess && !symmetric)
+            error = (hipError_t)szs_hip_utf8_transcode_tape(call->candidates->data, call->candidates->offsets, c_count,
+                                                            call->candidates->kind == szs_input_u64tape_k, call->queries->offsets, q_count,
+                                                            call->queries->kind == szs_input_u64tape_k, capacity,
+                                                            (uint32_t *)engine->device_runes.pointer, starts + q_count, counts + q_count,
+                                                            device_flags, (uint64_t *)(remote + needed_at), stream);
+        if (error == hipSuccess && renumber)
+            error = (hipError_t)szs_hip_alphabet_rename((uint32_t)strings, starts, counts, (uint32_t *)engine->device_runes.pointer, device_flags,
+                                                        engine->device_alphabet.pointer, SZS_ALPHABET_MOST, device_flags + 1, stream);
+        szs_plan_side_t const queries_side = {call->queries->offsets, (uint64_t)(uintptr_t)engine->device_runes.pointer, q_count,
+                                              call->queries->kind == szs_input_u64tape_k, base, base + q_count, counts, starts};
+        q_side = queries_side, c_side = queries_side;
+        if (!symmetric) {
+            szs_plan_side_t const other = {call->candidates->offsets, (uint64_t)(uintptr_t)engine->device_runes.pointer, c_count,
+                                           call->candidates->kind == szs_input_u64tape_k, base + 2 * (size_t)q_count,
+                                           base + 2 * (size_t)q_count + c_count, counts + q_count, starts + q_count};
+            c_side = other;
+        }
+        szs_plan_expectation_t none;
+        memset(&none, 0, sizeof(none));
+        none.sequence = ++engine->plan_sequence;
+        if (error == hipSuccess)
+            error = (hipError_t)szs_hip_plan(&q_side, symmetric ? NULL : &c_side, SZS_MYERS_MAX_WORDS * (unsigned)(engine->is_unit_cost != 0), &none,
+                                             (szs_plan_summary_t *)summary, stream);
+        if (error == hipSuccess) error = hipMemcpyAsync((void *)flags, remote + flags_at, staging_bytes - flags_at, hipMemcpyDeviceToHost, stream);
+        hipError_t const drained = hipStreamSynchronize(stream); /* THE wait of the planning half; also on failure */
+        if (error == hipSuccess) error = drained;
+        if (error != hipSuccess) return szs_report_hip(error, error_message);
+        memcpy(&seen, (void const *)summary, sizeof(seen));
+        if (seen.sequence != none.sequence) return szs_report(sz_status_unknown_k, error_message, "The device planner did not report");
+        if (seen.status & SZS_PLAN_STATUS_DESCENDING) return szs_report(sz_unexpected_dimensions_k, error_message, "Tape offsets must ascend");
+        if (seen.status & SZS_PLAN_STATUS_OVERFLOW) return szs_report(sz_overflow_risk_k, error_message, NULL);
+        uint64_t const needed = *(uint64_t const volatile *)(flags + 4);
+        if (needed <= capacity) break;
+        if (round) return szs_report(sz_status_unknown_k, error_message, "The UTF-32 buffer did not settle");
+        status = szs_buffer_reserve(&engine->device_runes, szs_memory_device_k, device, (size_t)(needed + needed / 4 + 4) * sizeof(uint32_t), error_message);
+        if (status != sz_success_k) return status; /* grown: transcode again, every string fits now */
+    }
+    if (!flags[0]) return SZS_RUNES_ARE_BYTES;
+    if (seen.status & SZS_PLAN_STATUS_UNSORTED) return SZS_NOT_DEVICE_PLANNABLE; /* strings beyond the planner's histogram */
+    uint32_t const distinct = flags[1], overflowed = flags[2];
+    uint32_t const alphabet = renumber && distinct && distinct <= SZS_ALPHABET_MOST && !overflowed ? distinct : 0; /* the arrays hold ids */
+    phase(call, 1);
+
+    for (int attempt = 0; attempt < 2; ++attempt) { /* second round: a stalled band chain is re-run on the lanes tier */
+        szs_decision_t d;
+        uint64_t const cells = symmetric ? seen.symmetric_cells : seen.side[0].symbols * seen.side[1].symbols;
+        status = decide(engine, symmetric, 1, attempt > 0, &seen.side[0], &seen.side[1], seen.variant_counts[0], seen.variant_counts[1], cells, &d,
+                        error_message);
+        if (status != sz_success_k) return status;
+        d.alphabet = alphabet;
+        status = prepare(engine, &d, device, stream, error_message);
+        if (status != sz_success_k) return status;
+        phase(call, 2);
+        uint32_t launches = 0, cell_bits = 0;
+        hipError_t error = hipEventRecord(engine->event_start, stream);
+        szs_string_ref_t const *const query_refs = d.transposed ? c_side.descending : q_side.descending;
+        szs_string_ref_t const *const candidate_refs = d.transposed ? q_side.ascending : c_side.ascending;
+        sz_status_t enqueue_status = sz_success_k;
+        if (error == hipSuccess)
+            error = enqueue(engine, &d, device, query_refs, candidate_refs, call->device_results, call->device_stride, stream, NULL, &launches,
+                            &cell_bits, &enqueue_status, error_message);
+        int stalled = 0;
+        engine->last_profile.planner = 1;
+        status = finish(call, &d, error, enqueue_status, launches, cell_bits, seen.side[0].symbols, seen.side[1].symbols, &stalled);
+        if (status != sz_success_k || !stalled) return status;
     }
     return szs_report(sz_status_unknown_k, error_message, "Systolic pipeline stalled");
 }
@@ -1309,9 +1440,13 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
     int const planner = szs_tuning_get(szs_knob_planner_k);
     ranges_begin(&call);
     status = SZS_NOT_DEVICE_PLANNABLE;
-    if (planner != 0 && engine->family != szs_family_levenshtein_utf8_k && device_plannable(engine, queries) &&
-        (symmetric || device_plannable(engine, candidates)))
-        status = cross_device_planned(&call);
+    if (planner != 0 && device_plannable(engine, queries) && (symmetric || device_plannable(engine, candidates))) {
+        status = engine->family == szs_family_levenshtein_utf8_k ? cross_device_planned_runes(&call) : SZS_RUNES_ARE_BYTES;
+        if (status == SZS_RUNES_ARE_BYTES) {
+            if (call.ranges) ranges_end(&call), ranges_begin(&call);
+            status = cross_device_planned(&call);
+        }
+    }
     if (status == SZS_NOT_DEVICE_PLANNABLE) {
         if (call.ranges) ranges_end(&call), ranges_begin(&call); /* the phases start over */
         status = cross_host_planned(&call);

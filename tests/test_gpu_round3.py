@@ -181,3 +181,39 @@ def test_weighted_levenshtein_on_the_team_tier(gpu, oracle, costs):
         reach = (longest + (1 if costs[2] == costs[3] else 3)) * max(costs)  # serial.hpp:135-162, minimising
         profile = engine.last_call_profile()
         assert profile.team_wide == (1 if reach >= 30000 else 0) or profile.team == 0, (reach, profile.team, profile.team_wide)
+
+
+@pytest.mark.parametrize("costs", [(0, 1, 1, 1), (1, 3, 3, 3), (0, 1, 4, 2)])
+def test_codepoint_engine_planned_on_the_device(gpu, oracle, costs):
+    """Round 3 plans codepoint calls over tapes on the device too: both tapes are transcoded without the host reading an
+    offset, the planner sorts by RUNE count, one wait (csrc/host/dispatch.c: cross_device_planned_runes).  Against the oracle
+    and against the host-planned path (`planner` knob), for: mixed scripts, an ASCII corpus (byte engines), symmetric calls, a
+    batch that outgrows the UTF-32 buffer of the call before, strings longer than the planner's histogram, 64-bit tapes."""
+    rng = random.Random(hash(costs) & 0xFFF)
+    pools = ["AÉ中😀", "abc абв", "aé中😀bñ語🚀 ", "".join(chr(0x4E00 + i) for i in range(400))]
+    engine = szs.LevenshteinDistancesUTF8(*costs, capabilities=gpu)  # one engine: buffers persist from call to call
+    for round_, (low, high, q_count, c_count) in enumerate([(0, 48, 7, 300), (1, 20, 64, 5), (200, 300, 3, 70), (900, 1200, 2, 30)]):
+        for pool in pools:
+            text = lambda: "".join(rng.choice(pool) for _ in range(rng.randint(low, high))).encode()
+            queries, candidates = [text() for _ in range(q_count)] + [b""], [text() for _ in range(c_count)] + [b"", "é".encode()]
+            expected = oracle.levenshtein_utf8(queries, candidates, *costs)
+            got = engine(queries, candidates, device=gpu)
+            assert np.array_equal(got, expected), (pool[:4], low, high, "device-planned")
+            assert engine.last_call_profile().planner == 1
+            with forced_env("planner", "host"):
+                assert np.array_equal(engine(queries, candidates, device=gpu), expected), (pool[:4], low, high, "host-planned")
+                assert engine.last_call_profile().planner == 0
+            if round_ == 0:
+                assert np.array_equal(engine(queries, device=gpu), oracle.levenshtein_utf8(queries, None, *costs)), (pool[:4], "symmetric")
+    # an ASCII corpus through the codepoint engine: the byte kernels take over
+    strings = [bytes(rng.choice(b"ACGT ") for _ in range(rng.randint(0, 90))) for _ in range(40)]
+    assert np.array_equal(engine(strings, device=gpu), oracle.levenshtein(strings, None, *costs))
+    # beyond the planner's histogram (6143 symbols): the host planner takes over
+    long_queries = ["".join(rng.choice("aé中") for _ in range(6500)).encode(), "é".encode() * 300]
+    long_candidates = ["".join(rng.choice("aé中") for _ in range(length)).encode() for length in (6400, 100, 0)]
+    assert np.array_equal(engine(long_queries, long_candidates, device=gpu), oracle.levenshtein_utf8(long_queries, long_candidates, *costs))
+    # a large batch right after small ones: the UTF-32 buffer grows inside the call
+    big = ["".join(rng.choice("abcdé語") for _ in range(rng.randint(50, 400))).encode() for _ in range(700)]
+    fresh = szs.LevenshteinDistancesUTF8(*costs, capabilities=gpu)
+    fresh([b"a"], [b"b"], device=gpu)
+    assert np.array_equal(fresh(big[:40], big, device=gpu), oracle.levenshtein_utf8(big[:40], big, *costs))
