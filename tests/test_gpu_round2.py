@@ -72,13 +72,15 @@ def test_device_and_host_planners_score_the_same_matrices(gpu, oracle):
         second = engine(q, c, device=gpu).view(np.int64)
         profile = engine.last_call_profile()
         # lanes tier: the same tapes again need no planner when the kernels can validate the refs themselves (unit-cost
-        # bytes); otherwise the launches go in behind the planner
-        assert profile.planner == ((3 if name == "lev_unit" else 2) if profile.tier == 0 else 1), name
+        # bytes); otherwise the launches go in behind the planner - except non-unit Levenshtein costs over bytes (round 3),
+        # whose launch depends on the byte alphabet the device counts for this very call: planned, never speculated
+        speculated = 1 if name == "lev_weighted" else 2
+        assert profile.planner == ((3 if name == "lev_unit" else speculated) if profile.tier == 0 else 1), name
         assert np.array_equal(second, expected), name
         with knob("reuse", "0"):
             again = engine(q, c, device=gpu).view(np.int64)
             profile = engine.last_call_profile()
-            assert profile.planner == (2 if profile.tier == 0 else 1), name
+            assert profile.planner == (speculated if profile.tier == 0 else 1), name
         assert np.array_equal(again, expected), name
         with knob("planner", "host"):
             third = engine(q, c, device=gpu).view(np.int64)
