@@ -74,7 +74,7 @@ def test_device_and_host_planners_score_the_same_matrices(gpu, oracle):
         # lanes tier: the same tapes again need no planner when the kernels can validate the refs themselves (unit-cost
         # bytes); otherwise the launches go in behind the planner - except non-unit Levenshtein costs over bytes (round 3),
         # whose launch depends on the byte alphabet the device counts for this very call: planned, never speculated
-        speculated = 1 if name == "lev_weighted" else 2
+        speculated = 1 if name in ("lev_weighted", "lev_affine") else 2
         assert profile.planner == ((3 if name == "lev_unit" else speculated) if profile.tier == 0 else 1), name
         assert np.array_equal(second, expected), name
         with knob("reuse", "0"):
