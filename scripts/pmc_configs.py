@@ -83,7 +83,8 @@ for directory in sorted(glob.glob(os.path.join(root, "cfg*"))):
                 "_cells_per_call": line["config"]["cells_per_gpu"], "kernels": {}}
         totals = defaultdict(float)
         scoring = {name: entry for name, entry in summary.items()
-                   if entry.get("_config") == config and not name.endswith(":__call__") and "plan_kernel" not in name and "utf8_transcode" not in name}
+                   if entry.get("_config") == config and not name.endswith(":__call__") and
+                   not any(helper in name for helper in ("plan_kernel", "utf8_transcode", "byte_presence", "alphabet_"))}  # not scoring launches
         launches_seen = sum(entry.get("_calls", 0) for entry in scoring.values())
         launches_per_call = line["roofline"].get("launches_per_step", 1)
         for name, entry in scoring.items():

@@ -81,12 +81,15 @@ __global__ __launch_bounds__(plan_threads_k) void plan_kernel(szs_plan_side_t qu
 
     // ---- phase 0: both histograms cleared; each thread's first string of each side fetched (one round trip for the kernel
     //      when a side has at most 1024 strings: every later phase reads registers)
-    u64 first_from[2] = {0, 0}, first_to[2] = {0, 0};
+    u64 first_from[2] = {0, 0}, first_to[2] = {0, 0}, first_start[2] = {0, 0};
+    u32 first_length[2] = {0, 0};
 #pragma unroll
     for (int s = 0; s < 2; ++s)
-        if (s < sides && tid < side_of[s]->count)
+        if (s < sides && tid < side_of[s]->count) {
             first_from[s] = tape_offset(side_of[s]->offsets, side_of[s]->wide, tid),
             first_to[s] = tape_offset(side_of[s]->offsets, side_of[s]->wide, (u64)tid + 1);
+            if (side_of[s]->lengths) first_length[s] = side_of[s]->lengths[tid], first_start[s] = side_of[s]->starts[tid];
+        }
     for (int s = 0; s < sides; ++s)
 #pragma unroll
         for (u32 k = 0; k < plan_chunk_k; ++k) histogram[s][k * plan_threads_k + tid] = 0;
@@ -98,9 +101,11 @@ __global__ __launch_bounds__(plan_threads_k) void plan_kernel(szs_plan_side_t qu
         else from = tape_offset(side_of[s]->offsets, side_of[s]->wide, i), to = tape_offset(side_of[s]->offsets, side_of[s]->wide, (u64)i + 1);
     };
     // codepoint engines: a string's length is its RUNE count and its symbols live in the UTF-32 scratch tape (kernels.h)
-    auto length_of = [&](int s, u32 i, u64 from, u64 to) -> u64 { return side_of[s]->lengths ? (u64)side_of[s]->lengths[i] : to - from; };
+    auto length_of = [&](int s, u32 i, u64 from, u64 to) -> u64 {
+        return !side_of[s]->lengths ? to - from : i == tid ? (u64)first_length[s] : (u64)side_of[s]->lengths[i];
+    };
     auto address_of = [&](int s, u32 i, u64 from) -> u64 {
-        return side_of[s]->lengths ? side_of[s]->base + 4 * side_of[s]->starts[i] : side_of[s]->base + from;
+        return !side_of[s]->lengths ? side_of[s]->base + from : side_of[s]->base + 4 * (i == tid ? first_start[s] : side_of[s]->starts[i]);
     };
 
     // ---- phase 1: the histogram of the lengths; malformed or over-long strings only raise a flag (the host takes over)

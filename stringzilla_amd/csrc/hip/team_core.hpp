@@ -309,20 +309,29 @@ SZS_HD void team_last_row(u32 length, u32 longer_query, u32 &pass, u32 &lane, u3
 /* ---- the cost profile in LDS ------------------------------------------------------------------------------------------
  *  One row of R entries (R x 4 bytes) per (strip, class); a lane reads its row with R / 4 `ds_read_b128` at immediate offsets.
  *  `ds_read_b128` serves a wavefront in four groups of 16 lanes and a group is conflict-free when its lanes' 16-byte
- *  addresses differ modulo 256.  The lanes of a team read DIFFERENT strips and (mostly) different classes, so the layout
- *  makes (address / 16) mod 16 a function of the strip alone: the strips are dealt over `blocks` regions whose sizes are
- *  16 modulo 256, and inside a region the rows of `slots` strips of one class share a block of slots x R x 4 = up to 256
- *  bytes.  With sixteen strips (L = 16) every lane group holds each strip exactly once: no conflicts whatever the classes. */
+ *  addresses differ modulo 256 (identical addresses broadcast).  The lanes of a team read DIFFERENT strips and teams (mostly)
+ *  different classes:
+ *    L = 16  a lane group holds each strip exactly once, so (address / 16) mod 16 is made a function of the strip alone: the
+ *            strips are dealt over `blocks` regions whose sizes are 16 modulo 256, and inside a region the rows of `slots`
+ *            strips of one class share a block of 256 bytes.  No conflicts whatever the classes (PMC, config 4: 0.0 %).
+ *    L < 16  a lane group holds 16 / L teams with a class each.  Rows of R x 4 + 16 bytes, classes L rows + 16 bytes apart:
+ *            the lanes of one team never collide, two teams collide on a lane or two for some class differences - the first
+ *            layout (classes 256 bytes apart) had every team of a group on the SAME banks: 72 % of the LDS cycles of a
+ *            four-lane launch were conflicts, and the launch was LDS-bound (profiles/r03/pmc_configs.json, cfg7). */
 template <int L, int R>
 struct team_profile_layout {
     static constexpr u32 row_bytes = (u32)R * 4;
-    static constexpr u32 slots = row_bytes >= 256 ? 1 : (256 / row_bytes < (u32)L ? 256 / row_bytes : (u32)L); // strips per class block
-    static constexpr u32 blocks = (u32)L / slots;
-    static constexpr u32 class_bytes = slots > 1 ? 256 : row_bytes; // slots x row_bytes, rounded up to the 256 the argument needs
+    static constexpr bool whole_row = L == 16; // every strip once per lane group
+    static constexpr u32 slots = !whole_row ? 1 : row_bytes >= 256 ? 1 : (256 / row_bytes < (u32)L ? 256 / row_bytes : (u32)L); // strips per class block
+    static constexpr u32 blocks = whole_row ? (u32)L / slots : 1;
+    static constexpr u32 strip_bytes = row_bytes + 16; // L < 16
+    static constexpr u32 class_bytes = !whole_row ? (u32)L * strip_bytes + 16 : slots > 1 ? 256 : row_bytes;
     SZS_HD static u32 region_bytes(u32 classes) { return classes * class_bytes + 16; }
     SZS_HD static u32 total_bytes(u32 classes) { return blocks * region_bytes(classes); }
     /** Byte offset of the row of strip `k`, class 0; the row of class c lies c x class_bytes further. */
-    SZS_HD static u32 strip_base(u32 k, u32 classes) { return (k % blocks) * region_bytes(classes) + (k / blocks) * row_bytes; }
+    SZS_HD static u32 strip_base(u32 k, u32 classes) {
+        return whole_row ? (k % blocks) * region_bytes(classes) + (k / blocks) * row_bytes : k * strip_bytes;
+    }
 };
 
 } // namespace szs_team

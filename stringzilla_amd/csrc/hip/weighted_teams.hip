@@ -115,7 +115,7 @@ __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
     static_assert(R % 4 == 0 && 16 % L == 0, "whole 16-byte profile chunks; teams inside a DPP row");
 
     extern __shared__ __attribute__((aligned(16))) char profile[];
-    __shared__ unsigned short class_offset_of_byte[256]; // class x layout::class_bytes: the head lanes' text -> profile row
+    __shared__ u32 class_offset_of_byte[256]; // class x layout::class_bytes: the head lanes' text -> profile row
     __shared__ unsigned short group_classes[2][group_rows]; // the classes of the group's rows, both queries; 0xFFFF: padded
     __shared__ u32 claimed_work;
 
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
     costs_t const k(model->gap_open, model->gap_extend);
     int16_t const *const table = model->substitution; // [query class][candidate class], 2 KB, cache-resident
     for (u32 byte = threadIdx.x; byte < 256; byte += team_block_threads_k)
-        class_offset_of_byte[byte] = (unsigned short)(model->byte_to_class[byte] * layout::class_bytes);
+        class_offset_of_byte[byte] = (u32)model->byte_to_class[byte] * layout::class_bytes;
 
     u32 const lane_in_team = threadIdx.x % L, team = threadIdx.x / L;
     bool const is_head = lane_in_team == 0, is_tail = lane_in_team == L - 1;

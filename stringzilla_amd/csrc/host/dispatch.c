@@ -1148,8 +1148,10 @@ static sz_status_t cross_device_planned_runes(szs_call_t *call) {
         engine->remembered->refs_current = 0, engine->remembered->valid = 0;
     if (status == sz_success_k && engine->device_runes.capacity < ((size_t)1 << 20))
         status = szs_buffer_reserve(&engine->device_runes, szs_memory_device_k, device, (size_t)1 << 20, error_message);
+    /* Renumbering the runes costs three more launches (~75 us): worth it for a batch of 64 KB or more (hip/utf8.hip).  The host
+     * has not read an offset, so it goes by what the PREVIOUS call of this engine needed - a stream of batches settles at once. */
     int const alphabet_knob = szs_tuning_get(szs_knob_alphabet_k);
-    int const renumber = alphabet_knob == 0 ? 0 : alphabet_knob > 0 ? 1 : strings >= 256; /* worth three more launches */
+    int const renumber = alphabet_knob == 0 ? 0 : alphabet_knob > 0 ? 1 : engine->runes_needed >= SZS_ALPHABET_WORTH_BYTES;
     if (status == sz_success_k && renumber)
         status = szs_buffer_reserve(&engine->device_alphabet, szs_memory_device_k, device, szs_hip_alphabet_workspace_bytes(), error_message);
     if (status == sz_success_k) status = place_results(call);
@@ -1206,6 +1208,7 @@ static sz_status_t cross_device_planned_runes(szs_call_t *call) {
         if (seen.status & SZS_PLAN_STATUS_DESCENDING) return szs_report(sz_unexpected_dimensions_k, error_message, "Tape offsets must ascend");
         if (seen.status & SZS_PLAN_STATUS_OVERFLOW) return szs_report(sz_overflow_risk_k, error_message, NULL);
         uint64_t const needed = *(uint64_t const volatile *)(flags + 4);
+        engine->runes_needed = needed;
         if (needed <= capacity) break;
         if (round) return szs_report(sz_status_unknown_k, error_message, "The UTF-32 buffer did not settle");
         status = szs_buffer_reserve(&engine->device_runes, szs_memory_device_k, device, (size_t)(needed + needed / 4 + 4) * sizeof(uint32_t), error_message);

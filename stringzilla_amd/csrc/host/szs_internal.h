@@ -94,6 +94,7 @@ typedef struct szs_engine_s {
     szs_buffer_t device_tape;    /* device: packed copy of strings living in plain host memory (`cpu_requests = gpu` only) */
     szs_buffer_t pinned_tape;    /* pinned: the host side of that copy */
     szs_buffer_t device_runes;   /* device: UTF-32 transcription of both sides (codepoint-level engine) */
+    uint64_t runes_needed;       /* runes the last device-planned codepoint call needed in that buffer (~ the bytes of its batch) */
     szs_buffer_t device_transcode; /* device: raw refs, rune starts, rune counts and the multibyte flag of that pass */
     szs_buffer_t device_alphabet;  /* device: the hash table that renumbers a batch's runes (hip/utf8.hip) */
     szs_buffer_t pinned_transcode; /* pinned: the host's side of the same */

@@ -138,6 +138,8 @@ def _profile_fits(shape, classes):
     """csrc/hip/team_core.hpp: team_profile_layout - does the cost profile of `classes` classes fit a CU's LDS?"""
     lanes, registers = shape // 10000, shape // 100 % 100
     row_bytes = 4 * registers
+    if lanes < 16:
+        return classes * (lanes * (row_bytes + 16) + 16) + 16 <= 160 * 1024 - 4096
     slots = 1 if row_bytes >= 256 else min(256 // row_bytes, lanes)
     blocks, class_bytes = lanes // slots, 256 if slots > 1 else row_bytes
     return blocks * (classes * class_bytes + 16) <= 160 * 1024 - 4096
