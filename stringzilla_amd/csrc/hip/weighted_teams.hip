@@ -115,15 +115,20 @@ __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
     static_assert(R % 4 == 0 && 16 % L == 0, "whole 16-byte profile chunks; teams inside a DPP row");
 
     extern __shared__ __attribute__((aligned(16))) char profile[];
-    __shared__ u32 class_offset_of_byte[256]; // class x layout::class_bytes: the head lanes' text -> profile row
-    __shared__ unsigned short group_classes[2][group_rows]; // the classes of the group's rows, both queries; 0xFFFF: padded
+    // Static LDS is kept small on purpose: BLOSUM62's sixteen strips are 51,328 bytes of profile, and THREE workgroups fit a CU
+    // only while the rest stays under ~3 KB (a kilobyte more took config 3 from 14.5 to 18.2 ms).
+    using class_offset_t = std::conditional_t<(255u * layout::class_bytes > 65535u), u32, unsigned short>;
+    using row_class_t = std::conditional_t<distance_, unsigned short, u8>; // up to 256 classes only for uniform costs
+    constexpr u32 padded_row_k = distance_ ? 0xFFFFu : 0xFFu;
+    __shared__ class_offset_t class_offset_of_byte[256]; // class x layout::class_bytes: the head lanes' text -> profile row
+    __shared__ row_class_t group_classes[2][group_rows]; // the classes of the group's rows, both queries; all ones: padded
     __shared__ u32 claimed_work;
 
     using costs_t = team_costs_t<local_, affine_, wide_, distance_>;
     costs_t const k(model->gap_open, model->gap_extend);
     int16_t const *const table = model->substitution; // [query class][candidate class], 2 KB, cache-resident
     for (u32 byte = threadIdx.x; byte < 256; byte += team_block_threads_k)
-        class_offset_of_byte[byte] = (u32)model->byte_to_class[byte] * layout::class_bytes;
+        class_offset_of_byte[byte] = (class_offset_t)((u32)model->byte_to_class[byte] * layout::class_bytes);
 
     u32 const lane_in_team = threadIdx.x % L, team = threadIdx.x / L;
     bool const is_head = lane_in_team == 0, is_tail = lane_in_team == L - 1;
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
                 szs_string_ref_t const &query = half ? query_high : query_low;
                 u32 const row = first_row + within;
                 group_classes[half][within / registers_now * R + within % registers_now] =
-                    row < query.length ? (unsigned short)model->byte_to_class[reinterpret_cast<u8 const *>(query.address)[row]] : (unsigned short)0xFFFF;
+                    row < query.length ? (row_class_t)model->byte_to_class[reinterpret_cast<u8 const *>(query.address)[row]] : (row_class_t)padded_row_k;
             }
             __syncthreads();
             for (u32 slot = threadIdx.x; slot < (u32)L * classes * chunks_now; slot += team_block_threads_k) {
@@ -214,12 +219,12 @@ __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
                     u32 const low_class = group_classes[0][strip * R + 4 * chunk + r], high_class = group_classes[1][strip * R + 4 * chunk + r];
                     i32 low, high;
                     if constexpr (distance_) { // uniform costs: equal bytes have equal classes (serial.hpp:106-115)
-                        low = low_class == 0xFFFF ? 0 : low_class == symbol_class ? model->uniform_match : model->uniform_mismatch;
-                        high = high_class == 0xFFFF ? 0 : high_class == symbol_class ? model->uniform_match : model->uniform_mismatch;
+                        low = low_class == padded_row_k ? 0 : low_class == symbol_class ? model->uniform_match : model->uniform_mismatch;
+                        high = high_class == padded_row_k ? 0 : high_class == symbol_class ? model->uniform_match : model->uniform_mismatch;
                     }
                     else { // cost(query, candidate) = table[class(query)][class(candidate)]: the QUERY picks the row (serial.hpp:199-204)
-                        low = low_class != 0xFFFF ? table[low_class * 32 + symbol_class] : 0;
-                        high = high_class != 0xFFFF ? table[high_class * 32 + symbol_class] : 0;
+                        low = low_class != padded_row_k ? table[low_class * 32 + symbol_class] : 0;
+                        high = high_class != padded_row_k ? table[high_class * 32 + symbol_class] : 0;
                     }
                     entries[r] = k.profile_entry(low, high);
                 }
