@@ -73,6 +73,15 @@ SZ_API_RUNTIME sz_status_t szs_rocm_orientation_probe(int unit_cost, int affine,
                                                       sz_u32_t const *candidate_lengths, sz_size_t candidates_count,
                                                       int *tier, int *transposed);
 
+/**
+ *  The same decision for a class-table engine whose DP values fit 16 bits - the calls the team tier (hip/weighted_teams.hip)
+ *  may take: `*lanes` receives the lanes per (pair of queries, candidate) the planner deals, 16 or 4, or 0 for the
+ *  one-pair-per-lane kernel (also when `*tier` is not 0).
+ */
+SZ_API_RUNTIME sz_status_t szs_rocm_team_orientation_probe(int affine, int symmetric, sz_u32_t const *query_lengths,
+                                                           sz_size_t queries_count, sz_u32_t const *candidate_lengths,
+                                                           sz_size_t candidates_count, int *tier, int *transposed, sz_u32_t *lanes);
+
 /* ---- one cross-product over the N GPUs of a host (csrc/host/node.c) ------------------------------
  *
  *  The reference's C-ABI is one device per call (stringzillas.h:137) and has no multi-GPU path; what its threading rules

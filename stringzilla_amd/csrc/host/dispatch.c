@@ -940,7 +940,11 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
      * up to 2048 bytes - the calls short enough for 25 us of planning to matter. */
     if (remembered->valid && remembered->refs_current && knobs_automatic && szs_tuning_get(szs_knob_reuse_k) != 0 &&
         remembered->tier == SZS_TIER_LANES && remembered->use_myers && !remembered->runes && !remembered->wide_cells &&
-        !has_group_of_variant_zero(remembered) && remembered->q_count == q_count && remembered->c_count == c_count &&
+        !has_group_of_variant_zero(remembered) && remembered->plan.groups_count == 1 &&
+        remembered->plan.groups[0].variant == SZS_MYERS_SHORT_WORDS /* every query <= 256 bytes: ONE launch of ~0.2 ms, where 25 us of
+           planning matter; with longer queries the guarded launches were slower than planning (128 x 128 x 1 KB over eight lanes per
+           pair: 0.67 ms behind the guard, 0.50 ms planned - profiles/r03) */ &&
+        remembered->q_count == q_count && remembered->c_count == c_count &&
         remembered->symmetric == symmetric && remembered->key_data[0] == key_data[0] && remembered->key_data[1] == key_data[1] &&
         remembered->key_offsets[0] == key_offsets[0] && remembered->key_offsets[1] == key_offsets[1] &&
         remembered->key_wide[0] == key_wide[0] && remembered->key_wide[1] == key_wide[1]) {

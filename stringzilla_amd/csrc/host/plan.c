@@ -201,6 +201,9 @@ double szs_plan_estimate(unsigned bit_parallel_limit, int bit_parallel_chain, in
      * of neighbouring workgroups do not spread evenly over the SIMDs (4096 x 1 x 128 B measured 2x the model). */
     double const live_waves = team || waves_per_query >= 4 ? 4 : waves_per_query;
     lanes_cycles *= 1.0 + 0.5 * (1.0 - live_waves / 4.0);
+    /* A team workgroup is one pair of queries x 256 / team candidates: with fewer candidates than that its other teams idle
+     * (32768 x 8 scored 1.3 TCUPS in the caller's orientation, 7.0 on its side: profiles/r03/shapes.jsonl). */
+    if (team && candidates_count < 256u / team) lanes_cycles *= (256.0 / team) / candidates_count;
     double const largest_pair = (double)longest_query * longest_candidate / lane_rate / split;
     if (largest_pair > lanes_cycles) lanes_cycles = largest_pair;
 
@@ -289,6 +292,21 @@ sz_status_t szs_rocm_plan_probe(int unit_cost, int symmetric, sz_u32_t const *qu
                 query_variant[plan.groups[g].first + i] = plan.groups[g].variant;
     if (cells) *cells = plan.cells;
     free(addresses), free(query_refs), free(candidate_refs), free(keys), free(scratch);
+    return sz_success_k;
+}
+
+sz_status_t szs_rocm_team_orientation_probe(int affine, int symmetric, sz_u32_t const *query_lengths, sz_size_t queries_count,
+                                            sz_u32_t const *candidate_lengths, sz_size_t candidates_count, int *tier, int *transposed,
+                                            sz_u32_t *lanes) {
+    if (queries_count > 0xFFFFFFFFu || candidates_count > 0xFFFFFFFFu || !tier || !transposed || !lanes) return sz_overflow_risk_k;
+    szs_side_stats_t query_stats, candidate_stats;
+    szs_side_stats(query_lengths, (uint32_t)queries_count, 0, &query_stats, NULL);
+    szs_side_stats(symmetric ? query_lengths : candidate_lengths, (uint32_t)(symmetric ? queries_count : candidates_count), 0,
+                   &candidate_stats, NULL);
+    szs_plan_orient(0, 0, affine, 0, 1, symmetric, &query_stats, &candidate_stats, SZS_SYSTOLIC_BAND_ROWS, tier, transposed);
+    *lanes = *tier == SZS_TIER_LANES ? szs_plan_team_lanes(affine, *transposed ? &candidate_stats : &query_stats,
+                                                           *transposed ? &query_stats : &candidate_stats)
+                                     : 0;
     return sz_success_k;
 }
 

@@ -134,6 +134,28 @@ def _orientation(unit, affine, uniform, symmetric, q, c):
     return tier.value, transposed.value
 
 
+def _team_orientation(affine, q, c):
+    q, c = np.asarray(q, dtype=np.uint32), np.asarray(c, dtype=np.uint32)
+    tier, transposed, lanes = ctypes.c_int(-1), ctypes.c_int(-1), ctypes.c_uint32(99)
+    status = _abi.lib.szs_rocm_team_orientation_probe(affine, 0, q.ctypes.data, len(q), c.ctypes.data, len(c), ctypes.addressof(tier),
+                                                      ctypes.addressof(transposed), ctypes.addressof(lanes))
+    assert status == 0
+    return tier.value, transposed.value, lanes.value
+
+
+def test_planner_deals_lanes_to_the_team_tier():
+    """Round 3: 16-bit class-table calls go to the team tier (hip/weighted_teams.hip) - sixteen lanes per (pair of queries,
+    candidate) for long queries, four for short ones, one pair per lane for a few dozen rows; a side of eight strings still
+    goes on the lanes (a team workgroup is 256 / lanes candidates wide)."""
+    assert _team_orientation(0, [512] * 1024, [512] * 1024) == (0, 0, 16)   # config 3
+    assert _team_orientation(1, [4096] * 512, [4096] * 512) == (0, 0, 16)   # config 4
+    assert _team_orientation(1, [4096] * 64, [4096] * 512) == (0, 0, 16)    # an eighth of config 4 stays on the lanes
+    assert _team_orientation(0, [128] * 1024, [128] * 1024) == (0, 0, 4)
+    assert _team_orientation(0, [40] * 1024, [300] * 1024)[2] == 0
+    tier, transposed, lanes = _team_orientation(0, [128] * 32768, [128] * 8)
+    assert (tier, transposed) == (0, 1) and lanes == 4                       # eight candidates: turned on its side
+
+
 def test_planner_picks_tier_and_orientation():
     """The cycle model of csrc/host/plan.c: BASELINE.json's big cross-products stay one-pair-per-lane, a handful of long
     pairs go to the systolic tier, and a tall-and-thin cross-product is turned on its side."""
