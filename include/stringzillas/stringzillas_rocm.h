@@ -149,7 +149,7 @@ SZ_API_RUNTIME sz_status_t szs_rocm_node_scores_u64tape(szs_rocm_node_engine_t e
  *  is loaded; afterwards a knob changes only through this call.  `knob` is one of "tier" (lanes | systolic | chain),
  *  "swap" (0 | 1), "packed" (0), "rune_ids" (n), "chain_waves" (4 | 8 | 16), "trace" (0 | 1), "cells" (64),
  *  "planner" (host | device), "speculate" (0), "streams" (0: one stream), "reuse" (0: never re-use a plan),
- *  "split" (0 | 2 | 4: lanes per pair of the long bit-parallel widths), "alphabet" (0 | 1: never / always renumber the runes
+ *  "split" (0 | 2 | 4 | 8: lanes per pair of the bit-parallel widths of 16 words and more), "alphabet" (0 | 1: never / always renumber the runes
  *  of a codepoint batch on the device), "merge" (n: candidate blocks per workgroup of the short bit-parallel kernels),
  *  "team" (0: never | lanes * 10000 + registers * 100 + waves: that shape of the team tier of the 16-bit weighted scorers),
  *  "queues" (see below), "roctx" (1: the host phases of every call - plan, decide, enqueue, wait - as roctx ranges for a

@@ -1,6 +1,6 @@
 #!/bin/bash
 # gpu_visit.sh TAG STEP... - the GPU visits of a round; every step under its own `timeout` so a hung kernel cannot hold the box.
-#   team-tests | all-tests | team4 | team3 | share4 | bench | configs
+#   team-tests | all-tests | team4 | team3 | share4 | sweep | ops | asan | bench | configs | timeline5 | timeline6 | shapes | realtext | previews
 set -u
 TAG=${1:-r3}; shift
 OUT=gpurun_out/$TAG
@@ -25,6 +25,11 @@ for step in "$@"; do
                 grep -c "ERROR: AddressSanitizer\|runtime error" "$OUT/asan.log"; tail -40 "$OUT/asan.log";;
     bench)      timeout 600 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; tail -c 3000 "$OUT/bench.json"; tail -3 "$OUT/bench.err";;
     configs)    timeout 600 python scripts/measure_configs.py --configs 2,3,4,5 > "$OUT/configs.jsonl" 2>&1; cat "$OUT/configs.jsonl";;
+    timeline5)  timeout 300 bash scripts/gpu_timeline.sh 5 8 > "$OUT/timeline_cfg5_eighth.txt" 2>&1; tail -30 "$OUT/timeline_cfg5_eighth.txt";;
+    timeline6)  timeout 300 bash scripts/gpu_timeline.sh 6 8 > "$OUT/timeline_cfg6_eighth.txt" 2>&1; tail -30 "$OUT/timeline_cfg6_eighth.txt";;
+    shapes)     timeout 900 python scripts/measure_shapes.py > "$OUT/shapes.jsonl" 2> "$OUT/shapes.err"; cat "$OUT/shapes.jsonl"; tail -3 "$OUT/shapes.err";;
+    realtext)   rm -f gpurun_out/real_text/real_text.jsonl; timeout 600 bash scripts/run_real_text.sh > "$OUT/real_text.log" 2>&1; cp gpurun_out/real_text/real_text.jsonl "$OUT/real_text.jsonl"; cat "$OUT/real_text.jsonl";;
+    previews)   for config in 3 4 5 6; do timeout 300 python scripts/measure_shard_of.py --config $config --shards 1,2,4,8; done > "$OUT/shard_preview.jsonl" 2> "$OUT/shard_preview.err"; cat "$OUT/shard_preview.jsonl";;
     *) echo "unknown step $step";;
   esac
 done

@@ -196,6 +196,13 @@ typedef struct szs_plan_expectation_t {
     uint32_t longest[2];  /* upper bounds the workspaces and cell widths were chosen for: queries, candidates */
     uint32_t variant_counts[SZS_PLAN_VARIANTS]; /* strings per launch variant on the query side: must match exactly */
     uint32_t sequence;    /* echoed into the summary, so that a stale summary is never mistaken for this call's */
+    /* codepoint calls (round 3): what the transcoder and the renumbering pass, enqueued AHEAD of the planner on the same
+     * stream, left in device memory - the speculated launches were shaped for a UTF-32 buffer of `runes_capacity` and for
+     * symbols 1 ... `alphabet`; NULL / 0 where that does not apply */
+    uint64_t const *runes_needed; /* runes the buffer must hold for this batch (utf8.hip: strings beyond the capacity were skipped) */
+    uint64_t runes_capacity;
+    uint32_t const *alphabet_flags; /* [any_multibyte, distinct runes, table overflowed] of szs_hip_alphabet_rename */
+    uint32_t alphabet;              /* > 0: the kernels index a direct table of alphabet + 1 rows with the symbols */
 } szs_plan_expectation_t;
 
 typedef struct szs_plan_summary_t {
@@ -232,6 +239,12 @@ int szs_hip_utf8_transcode(szs_string_ref_t const *strings, uint32_t count, uint
 int szs_hip_utf8_transcode_tape(void const *data, void const *offsets, uint32_t count, int wide, void const *before_offsets,
                                 uint32_t before_count, int before_wide, uint64_t capacity, uint32_t *runes, uint64_t *rune_starts,
                                 uint32_t *rune_counts, uint32_t *any_multibyte, uint64_t *needed, void *stream);
+/** Both tapes of a call in one launch: the second tape's runes follow the first's (`rune_starts` / `rune_counts`: first_count
+ *  entries, then second_count); second_count 0: the first tape alone. */
+int szs_hip_utf8_transcode_tapes(void const *first_data, void const *first_offsets, uint32_t first_count, int first_wide,
+                                 void const *second_data, void const *second_offsets, uint32_t second_count, int second_wide,
+                                 uint64_t capacity, uint32_t *runes, uint64_t *rune_starts, uint32_t *rune_counts,
+                                 uint32_t *any_multibyte, uint64_t *needed, void *stream);
 
 /**
  *  Renumbers the runes of a transcoded batch 1 ... A (equal runes, equal ids) in place, when it holds at most `most` distinct

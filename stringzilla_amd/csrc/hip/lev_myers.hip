@@ -1532,6 +1532,8 @@ extern "C" int szs_hip_levenshtein_myers_split(unsigned words, unsigned lanes, s
 #define SZS_SPLIT_CASE(W, L)                                                                                           \
     if (words == W && lanes == L)                                                                                      \
         return launch_myers_split<W / L, L>(queries, queries_count, candidates, candidates_count, results, results_row_stride, symmetric, guard, s);
+    SZS_SPLIT_CASE(16, 2) /* 16 words: only in launches of a few workgroups (host/dispatch.c: myers_shape_of) */
+    SZS_SPLIT_CASE(16, 4)
     SZS_SPLIT_CASE(24, 2)
     SZS_SPLIT_CASE(32, 2)
     SZS_SPLIT_CASE(48, 2)
@@ -1637,6 +1639,8 @@ extern "C" int szs_hip_levenshtein_myers_runes_split(unsigned words, unsigned la
 #define SZS_SPLIT_RUNES_CASE(W, L)                                                                                     \
     if (words == W && lanes == L)                                                                                      \
         return launch_split_runes<W / L, L>(queries, queries_count, candidates, candidates_count, results, results_row_stride, symmetric, alphabet, s);
+    SZS_SPLIT_RUNES_CASE(16, 2)
+    SZS_SPLIT_RUNES_CASE(16, 4)
     SZS_SPLIT_RUNES_CASE(24, 2)
     SZS_SPLIT_RUNES_CASE(32, 2)
     SZS_SPLIT_RUNES_CASE(48, 2)

@@ -246,6 +246,10 @@ __global__ __launch_bounds__(plan_threads_k) void plan_kernel(szs_plan_side_t qu
             held &= side_longest[0] <= expected.longest[0];
             held &= side_longest[symmetric ? 0 : 1] <= expected.longest[1];
         }
+        // codepoints: every string was transcoded (none skipped for want of room) and the arrays hold what the launches index with
+        if (held && expected.runes_needed) held &= *expected.runes_needed <= expected.runes_capacity;
+        if (held && expected.alphabet)
+            held &= expected.alphabet_flags[0] != 0 && expected.alphabet_flags[2] == 0 && expected.alphabet_flags[1] <= expected.alphabet;
         shared_held = held;
     }
     __syncthreads();

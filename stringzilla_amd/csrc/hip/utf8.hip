@@ -80,6 +80,16 @@ struct transcode_tape_t {
     }
 };
 
+/** Both tapes of a call in ONE launch (round 3: every launch ahead of the planner is ~5 us of a short call): strings
+ *  0 ... first.count - 1 are the first tape's, the rest the second's; the counts land in one array, side by side. */
+struct transcode_tapes_t {
+    transcode_tape_t first, second;
+    __device__ __forceinline__ void locate(u32 i, u8 const *&bytes, u32 &length, u64 &start) const {
+        if (i < first.count) first.locate(i, bytes, length, start);
+        else second.locate(i - first.count, bytes, length, start);
+    }
+};
+
 template <typename source_t>
 __global__ __launch_bounds__(64 * transcode_waves_k) void utf8_transcode_kernel(source_t source, u32 count, u32 *__restrict__ runes,
                                                                                 u32 *__restrict__ rune_counts,
@@ -169,7 +179,7 @@ __global__ __launch_bounds__(64 * transcode_waves_k) void utf8_transcode_kernel(
  *  place.  With A <= SZS_ALPHABET_MOST the kernels then look a symbol up in a direct table (`local[id]`, one LDS read, no loop);
  *  a richer batch keeps its runes (the second pass does nothing) and the kernels keep probing.
  */
-constexpr u32 alphabet_slots_k = SZS_ALPHABET_SLOTS, alphabet_empty_k = ~0u;
+constexpr u32 alphabet_slots_k = SZS_ALPHABET_SLOTS, alphabet_empty_k = ~0u, alphabet_seen_lines_k = 2048;
 
 __device__ __forceinline__ u32 alphabet_slot(u32 rune) { return (rune * 2654435761u) >> (32 - __builtin_ctz(alphabet_slots_k)); }
 
@@ -178,6 +188,12 @@ __global__ __launch_bounds__(256) void alphabet_claim_kernel(u32 count, u64 cons
                                                              u32 const *__restrict__ runes, u32 const *__restrict__ any_multibyte,
                                                              u32 *__restrict__ keys, u32 *__restrict__ ids, u32 *__restrict__ control, u32 most) {
     if (!*any_multibyte) return; // an ASCII batch goes to the byte engines
+    // Text repeats its runes: a workgroup remembers in LDS which runes it has SEEN claimed (a direct-mapped filter, one rune
+    // per line; a stale or lost line only costs the probe below) and goes to the table in global memory - an atomic load per
+    // rune, 66 us for 4.5 M runes - only for the others: a few hundred probes per workgroup instead of tens of thousands.
+    __shared__ u32 seen[alphabet_seen_lines_k];
+    for (u32 line = threadIdx.x; line < alphabet_seen_lines_k; line += blockDim.x) seen[line] = alphabet_empty_k;
+    __syncthreads();
     u32 const lane = threadIdx.x % 64u, waves = gridDim.x * (blockDim.x / 64u);
     for (u32 i = blockIdx.x * (blockDim.x / 64u) + threadIdx.x / 64u; i < count; i += waves) {
         // Once the alphabet has outgrown `most` (or the table) nothing will be renamed: stop claiming.  A batch of high-entropy
@@ -190,13 +206,16 @@ __global__ __launch_bounds__(256) void alphabet_claim_kernel(u32 count, u64 cons
         for (u32 j = lane; j < length; j += 64) {
             u32 const rune = text[j];
             u32 slot = alphabet_slot(rune);
+            u32 const line = slot & (alphabet_seen_lines_k - 1);
+            if (seen[line] == rune) continue; // (no rune is alphabet_empty_k: 21 bits, or an unchecked 4-byte sequence's 21)
             for (u32 probes = 0;; ++probes) {
                 u32 key = __atomic_load_n(&keys[slot], __ATOMIC_RELAXED);
                 if (key == alphabet_empty_k) key = atomicCAS(&keys[slot], alphabet_empty_k, rune);
-                if (key == rune) break;
+                if (key == rune) { seen[line] = rune; break; }
                 if (key == alphabet_empty_k) { // this thread claimed the slot: the rune's id is the next one
                     u32 const id = atomicAdd(&control[0], 1u) + 1;
                     ids[slot] = id;
+                    seen[line] = rune;
                     break;
                 }
                 if (probes >= alphabet_slots_k) { control[1] = 1; break; } // table full: the batch keeps its runes
@@ -209,7 +228,8 @@ __global__ __launch_bounds__(256) void alphabet_claim_kernel(u32 count, u64 cons
 __global__ __launch_bounds__(256) void alphabet_rename_kernel(u32 count, u64 const *__restrict__ rune_starts, u32 const *__restrict__ rune_counts,
                                                               u32 *__restrict__ runes, u32 const *__restrict__ any_multibyte,
                                                               u32 const *__restrict__ keys, u32 const *__restrict__ ids,
-                                                              u32 const *__restrict__ control, u32 most) {
+                                                              u32 const *__restrict__ control, u32 most, u32 *__restrict__ alphabet_out) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) alphabet_out[0] = control[0], alphabet_out[1] = control[1]; // distinct runes, overflow
     if (!*any_multibyte || control[1] || control[0] > most) return;
     u32 const lane = threadIdx.x % 64u, waves = gridDim.x * (blockDim.x / 64u);
     for (u32 i = blockIdx.x * (blockDim.x / 64u) + threadIdx.x / 64u; i < count; i += waves) {
@@ -251,6 +271,29 @@ extern "C" int szs_hip_utf8_transcode_tape(void const *data, void const *offsets
     return (int)hipGetLastError();
 }
 
+extern "C" int szs_hip_utf8_transcode_tapes(void const *first_data, void const *first_offsets, uint32_t first_count, int first_wide,
+                                            void const *second_data, void const *second_offsets, uint32_t second_count, int second_wide,
+                                            uint64_t capacity, uint32_t *runes, uint64_t *rune_starts, uint32_t *rune_counts,
+                                            uint32_t *any_multibyte, uint64_t *needed, void *stream) {
+    using namespace szs_hip;
+    if (!second_count)
+        return szs_hip_utf8_transcode_tape(first_data, first_offsets, first_count, first_wide, nullptr, 0, 0, capacity, runes, rune_starts,
+                                           rune_counts, any_multibyte, needed, stream);
+    if (!first_count)
+        return szs_hip_utf8_transcode_tape(second_data, second_offsets, second_count, second_wide, first_offsets, 0, first_wide, capacity, runes,
+                                           rune_starts, rune_counts, any_multibyte, needed, stream);
+    u64 const count = (u64)first_count + second_count;
+    if (count > 0xFFFFFFFFull) return (int)hipErrorInvalidValue;
+    u64 const blocks = (count + transcode_waves_k - 1) / transcode_waves_k;
+    transcode_tapes_t const source = {
+        {static_cast<u8 const *>(first_data), first_offsets, nullptr, first_count, (u32)(first_wide != 0), 0u, 0u, capacity, rune_starts, nullptr},
+        {static_cast<u8 const *>(second_data), second_offsets, first_offsets, second_count, (u32)(second_wide != 0), first_count,
+         (u32)(first_wide != 0), capacity, rune_starts + first_count, needed}};
+    hipLaunchKernelGGL(utf8_transcode_kernel<transcode_tapes_t>, dim3(blocks < 65536u ? (u32)blocks : 65536u), dim3(64 * transcode_waves_k), 0,
+                       static_cast<hipStream_t>(stream), source, (u32)count, runes, rune_counts, any_multibyte);
+    return (int)hipGetLastError();
+}
+
 extern "C" size_t szs_hip_alphabet_workspace_bytes(void) { return (size_t)SZS_ALPHABET_SLOTS * 2 * sizeof(uint32_t) + 2 * sizeof(uint32_t); }
 
 extern "C" int szs_hip_alphabet_rename(uint32_t count, uint64_t const *rune_starts, uint32_t const *rune_counts, uint32_t *runes,
@@ -266,8 +309,6 @@ extern "C" int szs_hip_alphabet_rename(uint32_t count, uint64_t const *rune_star
     u32 const blocks = (count + 3) / 4 < 2048u ? (count + 3) / 4 : 2048u;
     hipLaunchKernelGGL(alphabet_claim_kernel, dim3(blocks), dim3(256), 0, s, count, rune_starts, rune_counts, runes, any_multibyte, keys, ids, control, most);
     hipLaunchKernelGGL(alphabet_rename_kernel, dim3(blocks), dim3(256), 0, s, count, rune_starts, rune_counts, runes, any_multibyte, keys, ids,
-                       control, most);
-    error = hipGetLastError();
-    if (error == hipSuccess) error = hipMemcpyAsync(alphabet_out, control, 2 * sizeof(u32), hipMemcpyDeviceToDevice, s);
-    return (int)error;
+                       control, most, alphabet_out);
+    return (int)hipGetLastError();
 }

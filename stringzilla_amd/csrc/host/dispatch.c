@@ -523,26 +523,40 @@ static hipError_t szs_aux_streams(int device, unsigned wanted, hipStream_t *stre
     return error;
 }
 
-/**
- *  Lanes per pair for a launch of the long byte widths: two when the launch fills the device anyway (measured on config 5:
- *  13.5 -> 12.5 ms, the state of a 64-word pattern no longer spills), four when it has so few workgroups that its longest
- *  pairs ARE its duration (an eighth of config 5: 5.4 -> 3.5 ms); 24 words split in two only (whole 16-byte Peq chunks per
- *  lane).  The `split` knob pins 0, 2 or 4.
- */
-static unsigned split_lanes_of(int knob, unsigned variant, uint64_t workgroups_unsplit) {
-    if (variant != 24 && variant != 32 && variant != 48 && variant != 64) return 0;
-    unsigned lanes = knob == 0 ? 0u : knob == 2 || knob == 4 || knob == 8 ? (unsigned)knob : workgroups_unsplit < 256 ? 8u : workgroups_unsplit < 1024 ? 4u : 2u;
-    if (variant == 24 && lanes >= 4) lanes = 2;
-    if (variant == 48 && lanes == 8) lanes = 4; /* six words per lane are not whole 16-byte chunks */
-    return lanes;
-}
+/** The launch of one width group of the bit-parallel kernels: `words` of the kernel that takes it (>= the group's variant:
+ *  patterns are right-aligned over phantom low rows, so a wider kernel scores a narrower query exactly) and `lanes` per pair
+ *  (0: one lane per pair, the long kernels).
+ *
+ *  24 ... 64 words always spread a pair over lanes (hip/lev_myers.hip: levenshtein_myers_split_kernel): 2 when the launch
+ *  fills the device anyway, 4 under 1024 workgroups, 8 under 256 - its longest pairs ARE its duration.  16 and 20 words join
+ *  them only in a launch of fewer than 256 workgroups (round 3): an eighth of config 5 on each of eight GPUs is nine launches
+ *  of ~200 workgroups, and the 20-word one - 2048 columns x 20 words x 10.5 instructions in ONE lane, 1.4 ms however idle
+ *  the chip - ended the call at 2.0 ms for 1.2 ms of work (profiles/r03/timeline_cfg5_eighth_v1.txt).  Ten words per lane
+ *  are not whole 16-byte Peq chunks: 20 words run as 24 over two lanes.  The `split` knob pins 0 / 2 / 4 / 8. */
+typedef struct myers_shape_t {
+    unsigned words, lanes;
+} myers_shape_t;
 
-/** The same for codepoints: 48 and 64 words always over four lanes - their rune table leaves room for one workgroup per CU,
- *  and only the split kernel puts more than one wavefront per SIMD behind it (lev_myers.hip). */
-static unsigned split_lanes_of_runes(int knob, unsigned variant, uint64_t workgroups_unsplit) {
-    unsigned lanes = split_lanes_of(knob, variant, workgroups_unsplit);
-    if (lanes == 8) lanes = 4; /* the rune kernels are instantiated for two and four lanes */
-    return lanes && knob < 0 && variant >= 48 ? 4u : lanes;
+static myers_shape_t myers_shape_of(int knob, unsigned variant, uint64_t workgroups_unsplit, int runes) {
+    myers_shape_t shape = {variant, 0};
+    if (knob == 0 || variant < 16 || variant == SZS_MYERS_SHORT_WORDS) return shape;
+    int const pinned = knob == 2 || knob == 4 || knob == 8;
+    unsigned lanes = pinned ? (unsigned)knob : workgroups_unsplit < 256 ? 8u : workgroups_unsplit < 1024 ? 4u : 2u;
+    if (variant < 24) {
+        if (!pinned && workgroups_unsplit >= 256) return shape;
+        if (variant == 20) shape.words = 24;
+        else lanes = pinned && lanes >= 4 ? 4u : 2u; /* eight words per lane are as short as the other launches' pairs */
+    }
+    if (shape.words == 24 && lanes >= 4) lanes = 2;
+    if (shape.words == 48 && lanes == 8) lanes = 4; /* six words per lane are not whole chunks either */
+    if (runes) {
+        if (lanes == 8) lanes = 4; /* the rune kernels are instantiated for two and four lanes */
+        /* 48 and 64 words always over four lanes: their rune table leaves room for one workgroup per CU, and only the split
+         * kernel puts more than one wavefront per SIMD behind it (lev_myers.hip) */
+        if (!pinned && variant >= 48) lanes = 4;
+    }
+    shape.lanes = lanes;
+    return shape;
 }
 
 /** Launches of one decision over device refs in kernel roles.  Returns the first launch error; counts launches. */
@@ -605,14 +619,30 @@ static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int dev
         for (unsigned i = 0; i < aux_used && error == hipSuccess; ++i) error = hipStreamWaitEvent(engine->aux_streams[i], engine->fork_event, 0);
         if (error != hipSuccess) return error; /* nothing has been launched on the auxiliary streams */
     }
-    /* Lanes per pair of the long byte kernels (lev_myers.hip: levenshtein_myers_split_kernel): 1 / L of the floor that the
-     * longest pair puts under a launch, for the same work. */
+    /* Every width group's launch shape, and the order the launches go out in: LONGEST PAIR FIRST.  What a launch cannot go
+     * under is its longest pair - columns x words PER LANE, one dependent instruction after the other - and the first launch
+     * submitted takes every free wavefront slot: the widest group (64 words over eight lanes: many workgroups, short pairs)
+     * used to go first and the 20-word launch - one lane per pair, the longest pairs of all - got its first wavefront 0.4 ms
+     * into a 2 ms call.  Groups that need the workspace keep their place at the front, in order, on the scope's stream; the
+     * short launch (thousands of workgroups that live microseconds) goes last and fills what the others leave. */
     int const split_knob = szs_tuning_get(szs_knob_split_k);
-    /* Launches that need no workspace are dealt over {scope's stream, auxiliary streams} back and forth (0 .. n, n .. 0, ...):
-     * the groups come widest - slowest - first, so the second launch of a lane is the lightest one left. */
-    unsigned next_lane = 0;
-    for (unsigned g = 0; g < d->plan.groups_count && !launch_error && *status == sz_success_k; ++g) {
+    myers_shape_t shapes[SZS_PLAN_MAX_GROUPS];
+    unsigned order[SZS_PLAN_MAX_GROUPS], urgency[SZS_PLAN_MAX_GROUPS];
+    for (unsigned g = 0; g < d->plan.groups_count; ++g) {
         szs_plan_group_t const *group = &d->plan.groups[g];
+        shapes[g] = myers_shape_of(d->use_myers ? split_knob : 0, group->variant, (uint64_t)group->count * candidate_blocks, d->runes);
+        urgency[g] = group->variant == 0 ? ~0u : group->variant == SZS_MYERS_SHORT_WORDS ? 0u : shapes[g].words / (shapes[g].lanes ? shapes[g].lanes : 1u);
+        unsigned at = g;
+        for (; at > 0 && urgency[order[at - 1]] < urgency[g]; --at) order[at] = order[at - 1]; /* stable: ties stay widest first */
+        order[at] = g;
+    }
+    /* Launches that need no workspace are dealt over {scope's stream, auxiliary streams} back and forth (0 .. n, n .. 0, ...):
+     * the second launch of a stream is the lightest one left. */
+    unsigned next_lane = 0;
+    for (unsigned turn_of = 0; turn_of < d->plan.groups_count && !launch_error && *status == sz_success_k; ++turn_of) {
+        unsigned const g = order[turn_of];
+        szs_plan_group_t const *group = &d->plan.groups[g];
+        myers_shape_t const shape = shapes[g];
         int const uses_workspace = group->variant == 0;
         unsigned lane = 0;
         if (fan_out && !uses_workspace) {
@@ -624,11 +654,10 @@ static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int dev
             szs_string_ref_t const *const queries = query_refs + group->first + done;
             uint32_t const count = group->count - done < queries_per_launch ? group->count - done : queries_per_launch;
             if (group->variant && d->runes) {
-                unsigned const lanes = split_lanes_of_runes(split_knob, group->variant, (uint64_t)group->count * candidate_blocks);
                 launch_error = group->variant == SZS_MYERS_SHORT_WORDS
                                    ? szs_hip_levenshtein_myers_runes(queries, count, candidate_refs, d->kc_count, (uint64_t *)device_results,
                                                                      device_stride, d->layout, d->alphabet, target)
-                               : lanes ? szs_hip_levenshtein_myers_runes_split(group->variant, lanes, queries, count, candidate_refs, d->kc_count,
+                               : shape.lanes ? szs_hip_levenshtein_myers_runes_split(shape.words, shape.lanes, queries, count, candidate_refs, d->kc_count,
                                                                                (uint64_t *)device_results, device_stride, d->layout, d->alphabet, target)
                                        : szs_hip_levenshtein_myers_runes_long(group->variant, queries, count, candidate_refs, d->kc_count,
                                                                               (uint64_t *)device_results, device_stride, d->layout, d->alphabet, target);
@@ -648,9 +677,8 @@ static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int dev
                                                            (int64_t *)device_results, device_stride, d->layout, engine->device_boundary.pointer, stream);
                 }
             }
-            else if (group->variant >= 24 && split_lanes_of(split_knob, group->variant, (uint64_t)group->count * candidate_blocks))
-                launch_error = szs_hip_levenshtein_myers_split(group->variant, split_lanes_of(split_knob, group->variant, (uint64_t)group->count * candidate_blocks),
-                                                               queries, count, candidate_refs, d->kc_count,
+            else if (group->variant && shape.lanes)
+                launch_error = szs_hip_levenshtein_myers_split(shape.words, shape.lanes, queries, count, candidate_refs, d->kc_count,
                                                                (uint64_t *)device_results, device_stride, d->layout, guard, target);
             else if (group->variant)
                 launch_error = szs_hip_levenshtein_myers(group->variant, queries, count, candidate_refs, d->kc_count, (uint64_t *)device_results,
@@ -1006,8 +1034,13 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
     }
 
     /* ---- speculate: launches shaped like the previous call go in right behind the planner */
-    int const speculate = remembered->valid && remembered->tier == SZS_TIER_LANES && remembered->q_count == q_count &&
-                          remembered->c_count == c_count && remembered->symmetric == symmetric && knobs_automatic && !uniform_bytes;
+    /* (round 3: only calls of ONE launch.  The launches of a mixed-length batch leave the host one after the other, longest
+     * pairs first, and reach the device in that order; enqueued behind the planner they are all released by the same event
+     * and the device takes them as it likes - the short launch's thousands of workgroups first, the long pairs late.
+     * Config 5: 9.68 ms speculated, 9.60 planned-and-waited-for; an eighth of it 1.95 / 1.85; codepoints 8.4 / 7.1.) */
+    int const speculate = remembered->valid && !remembered->runes && remembered->tier == SZS_TIER_LANES && remembered->q_count == q_count &&
+                          remembered->c_count == c_count && remembered->symmetric == symmetric && knobs_automatic && !uniform_bytes &&
+                          remembered->plan.groups_count == 1;
     szs_plan_summary_t seen;
     int have_summary = 0;
     if (speculate) {
@@ -1131,6 +1164,37 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
  *  The UTF-32 buffer is sized by the previous calls; a batch that needs more says so (`needed`) and is transcoded again.
  *  An ASCII corpus goes to the byte engines (serial.hpp:2809-2813, applied per call).
  */
+/** Both tapes into the engine's UTF-32 buffer and, with `renumber`, their runes into ids: launches only, no wait. */
+static hipError_t enqueue_transcoding(szs_call_t *call, char *remote, size_t flags_at, size_t needed_at, size_t staging_bytes, uint64_t *starts,
+                                      uint32_t *counts, int renumber) {
+    szs_engine_s *engine = call->engine;
+    hipStream_t const stream = call->stream;
+    uint32_t const q_count = call->q_count, c_count = call->c_count;
+    uint64_t const capacity = engine->device_runes.capacity / sizeof(uint32_t);
+    uint32_t *const device_flags = (uint32_t *)(remote + flags_at);
+    size_t const strings = (size_t)q_count + (call->symmetric ? 0 : c_count);
+    hipError_t error = hipMemsetAsync(remote + flags_at, 0, staging_bytes - flags_at, stream);
+    if (error == hipSuccess)
+        error = (hipError_t)szs_hip_utf8_transcode_tapes(call->queries->data, call->queries->offsets, q_count, call->queries->kind == szs_input_u64tape_k,
+                                                         call->symmetric ? NULL : call->candidates->data,
+                                                         call->symmetric ? NULL : call->candidates->offsets, call->symmetric ? 0u : c_count,
+                                                         !call->symmetric && call->candidates->kind == szs_input_u64tape_k, capacity,
+                                                         (uint32_t *)engine->device_runes.pointer, starts, counts, device_flags,
+                                                         (uint64_t *)(remote + needed_at), stream);
+    if (error == hipSuccess && renumber)
+        error = (hipError_t)szs_hip_alphabet_rename((uint32_t)strings, starts, counts, (uint32_t *)engine->device_runes.pointer, device_flags,
+                                                    engine->device_alphabet.pointer, SZS_ALPHABET_MOST, device_flags + 1, stream);
+    return error;
+}
+
+/** The size of the direct tables the codepoint kernels are launched with for a batch of `distinct` renumbered runes: some
+ *  room above it, so that the NEXT batch of the stream - launched on this one's shape before anyone has counted its runes -
+ *  still fits when it holds a few more (a table row is 4 bytes of LDS). */
+static uint32_t alphabet_with_room(uint32_t distinct) {
+    uint32_t const roomy = distinct + distinct / 8 + 8;
+    return roomy < SZS_ALPHABET_MOST ? roomy : SZS_ALPHABET_MOST;
+}
+
 static sz_status_t cross_device_planned_runes(szs_call_t *call) {
     szs_engine_s *engine = call->engine;
     hipStream_t const stream = call->stream;
@@ -1159,50 +1223,110 @@ static sz_status_t cross_device_planned_runes(szs_call_t *call) {
     if (status == sz_success_k && renumber)
         status = szs_buffer_reserve(&engine->device_alphabet, szs_memory_device_k, device, szs_hip_alphabet_workspace_bytes(), error_message);
     if (status == sz_success_k) status = place_results(call);
+    if (status == sz_success_k && !engine->remembered) {
+        engine->remembered = (szs_decision_t *)calloc(1, sizeof(szs_decision_t));
+        if (!engine->remembered) status = szs_report(sz_bad_alloc_k, error_message, NULL);
+    }
     if (status != sz_success_k) return status;
-    if (engine->remembered) engine->remembered->refs_current = 0; /* the planner is about to overwrite the refs */
+    szs_decision_t *const remembered = engine->remembered;
+    remembered->refs_current = 0; /* the planner is about to overwrite the refs */
     phase(call, 0);
 
     char *const remote = (char *)engine->device_transcode.pointer;
     uint32_t volatile *const flags = (uint32_t volatile *)engine->pinned_transcode.pointer; /* 4 flags, then `needed` */
     szs_string_ref_t *const base = (szs_string_ref_t *)engine->device_plan_refs.pointer;
     szs_plan_summary_t volatile *const summary = (szs_plan_summary_t volatile *)engine->pinned_summary.pointer;
+    uint64_t *const starts = (uint64_t *)(remote + starts_at);
+    uint32_t *const counts = (uint32_t *)(remote + counts_at);
+    unsigned const myers_words = SZS_MYERS_MAX_WORDS * (unsigned)(engine->is_unit_cost != 0);
     szs_plan_summary_t seen;
     szs_plan_side_t q_side, c_side;
+    /* (the UTF-32 buffer may move when it grows: the sides are rebuilt from it for every round) */
+#define SZS_RUNE_SIDES()                                                                                                                  \
+    do {                                                                                                                                  \
+        szs_plan_side_t const queries_side = {call->queries->offsets, (uint64_t)(uintptr_t)engine->device_runes.pointer, q_count,        \
+                                              call->queries->kind == szs_input_u64tape_k, base, base + q_count, counts, starts};         \
+        q_side = queries_side, c_side = queries_side;                                                                                    \
+        if (!symmetric) {                                                                                                                 \
+            szs_plan_side_t const other = {call->candidates->offsets, (uint64_t)(uintptr_t)engine->device_runes.pointer, c_count,        \
+                                           call->candidates->kind == szs_input_u64tape_k, base + 2 * (size_t)q_count,                    \
+                                           base + 2 * (size_t)q_count + c_count, counts + q_count, starts + q_count};                    \
+            c_side = other;                                                                                                               \
+        }                                                                                                                                 \
+    } while (0)
+
+    /* ---- speculate (round 3): a stream of batches of one shape - the same counts, the same strings per launch width, no longer
+     * longest strings, no more runes than the buffer holds, no more distinct ones than the tables have rows - is transcoded,
+     * renumbered, planned AND scored without the host waiting in between: the launches of the previous call go in right behind
+     * the planner, which blanks every ref if this batch does not fit them (hip/planner.hip; the byte engines' speculation, with
+     * the two conditions only the device can check added to the expectation).  4096 x 4096 words of prose: the planning half
+     * was as long as the scoring (profiles/r03/real_text.jsonl). */
+    int const knobs_automatic = szs_tuning_get(szs_knob_speculate_k) != 0 && szs_tuning_get(szs_knob_tier_k) < 0 &&
+                                szs_tuning_get(szs_knob_swap_k) < 0 && szs_tuning_get(szs_knob_cells_k) < 0 && szs_tuning_get(szs_knob_packed_k) < 0 &&
+                                szs_tuning_get(szs_knob_team_k) < 0 && szs_tuning_get(szs_knob_rune_ids_k) < 0;
+    if (remembered->valid && remembered->runes && remembered->tier == SZS_TIER_LANES && remembered->use_myers && remembered->q_count == q_count &&
+        remembered->c_count == c_count && remembered->symmetric == symmetric && knobs_automatic && (!remembered->alphabet || renumber) &&
+        remembered->plan.groups_count == 1 /* one launch: see cross_device_planned */) {
+        szs_decision_t const *d = remembered;
+        SZS_RUNE_SIDES();
+        szs_plan_expectation_t expected;
+        memset(&expected, 0, sizeof(expected));
+        expected.enabled = 1, expected.query_side = (uint32_t)d->transposed;
+        expected.longest[0] = d->longest[0], expected.longest[1] = d->longest[1];
+        memcpy(expected.variant_counts, d->variant_counts, sizeof(expected.variant_counts));
+        expected.sequence = ++engine->plan_sequence;
+        expected.runes_needed = (uint64_t const *)(remote + needed_at), expected.runes_capacity = engine->device_runes.capacity / sizeof(uint32_t);
+        expected.alphabet_flags = (uint32_t const *)(remote + flags_at), expected.alphabet = d->alphabet;
+        status = prepare(engine, d, device, stream, error_message); /* buffers of the previous call: nothing to allocate */
+        if (status != sz_success_k) return status;
+        phase(call, 2);
+        hipError_t error = enqueue_transcoding(call, remote, flags_at, needed_at, staging_bytes, starts, counts, renumber);
+        if (error == hipSuccess)
+            error = (hipError_t)szs_hip_plan(&q_side, symmetric ? NULL : &c_side, myers_words, &expected, (szs_plan_summary_t *)summary, stream);
+        if (error == hipSuccess) error = hipMemcpyAsync((void *)flags, remote + flags_at, staging_bytes - flags_at, hipMemcpyDeviceToHost, stream);
+        if (error != hipSuccess) {
+            (void)hipStreamSynchronize(stream);
+            return szs_report_hip(error, error_message); /* no scoring launch has been enqueued */
+        }
+        uint32_t launches = 0, cell_bits = 0;
+        error = hipEventRecord(engine->event_start, stream);
+        szs_string_ref_t const *const query_refs = d->transposed ? c_side.descending : q_side.descending;
+        szs_string_ref_t const *const candidate_refs = d->transposed ? q_side.ascending : c_side.ascending;
+        sz_status_t enqueue_status = sz_success_k;
+        if (error == hipSuccess)
+            error = enqueue(engine, d, device, query_refs, candidate_refs, call->device_results, call->device_stride, stream, NULL, &launches,
+                            &cell_bits, &enqueue_status, error_message);
+        int stalled = 0;
+        szs_decision_t scored = *d;
+        engine->last_profile.planner = 2;
+        status = finish(call, &scored, error, enqueue_status, launches, cell_bits, 0, 0, &stalled);
+        if (status != sz_success_k) return status;
+        memcpy(&seen, (void const *)summary, sizeof(seen));
+        if (seen.sequence == expected.sequence && !seen.status && seen.speculation_held) {
+            szs_rocm_call_profile_t *profile = &engine->last_profile;
+            uint64_t const pairs = profile->pairs;
+            profile->cells = symmetric ? seen.symmetric_cells : seen.side[0].symbols * seen.side[1].symbols;
+            profile->algorithmic_bytes = (symmetric ? ((uint64_t)q_count + 1) * seen.side[0].symbols
+                                                    : (uint64_t)c_count * seen.side[0].symbols + (uint64_t)q_count * seen.side[1].symbols) + pairs * 16;
+            profile->unique_bytes += seen.side[0].symbols + (symmetric ? 0 : seen.side[1].symbols);
+            profile->longest_query = seen.side[0].longest, profile->longest_candidate = seen.side[1].longest;
+            engine->runes_needed = *(uint64_t const volatile *)(flags + 4);
+            remembered->summary = seen;
+            remembered->plan.cells = profile->cells;
+            return szs_report(sz_success_k, error_message, NULL);
+        }
+        /* the batch has another shape, more runes or a richer alphabet: every ref was blanked, nothing real was scored */
+    }
+
     for (int round = 0;; ++round) {
         uint64_t const capacity = engine->device_runes.capacity / sizeof(uint32_t);
-        uint64_t *const starts = (uint64_t *)(remote + starts_at);
-        uint32_t *const counts = (uint32_t *)(remote + counts_at), *const device_flags = (uint32_t *)(remote + flags_at);
-        hipError_t error = hipMemsetAsync(remote + flags_at, 0, staging_bytes - flags_at, stream);
-        if (error == hipSuccess)
-            error = (hipError_t)szs_hip_utf8_transcode_tape(call->queries->data, call->queries->offsets, q_count,
-                                                            call->queries->kind == szs_input_u64tape_k, NULL, 0, 0, capacity,
-                                                            (uint32_t *)engine->device_runes.pointer, starts, counts, device_flags,
-                                                            symmetric ? (uint64_t *)(remote + needed_at) : NULL, stream);
-        if (error == hipSuccess && !symmetric)
-            error = (hipError_t)szs_hip_utf8_transcode_tape(call->candidates->data, call->candidates->offsets, c_count,
-                                                            call->candidates->kind == szs_input_u64tape_k, call->queries->offsets, q_count,
-                                                            call->queries->kind == szs_input_u64tape_k, capacity,
-                                                            (uint32_t *)engine->device_runes.pointer, starts + q_count, counts + q_count,
-                                                            device_flags, (uint64_t *)(remote + needed_at), stream);
-        if (error == hipSuccess && renumber)
-            error = (hipError_t)szs_hip_alphabet_rename((uint32_t)strings, starts, counts, (uint32_t *)engine->device_runes.pointer, device_flags,
-                                                        engine->device_alphabet.pointer, SZS_ALPHABET_MOST, device_flags + 1, stream);
-        szs_plan_side_t const queries_side = {call->queries->offsets, (uint64_t)(uintptr_t)engine->device_runes.pointer, q_count,
-                                              call->queries->kind == szs_input_u64tape_k, base, base + q_count, counts, starts};
-        q_side = queries_side, c_side = queries_side;
-        if (!symmetric) {
-            szs_plan_side_t const other = {call->candidates->offsets, (uint64_t)(uintptr_t)engine->device_runes.pointer, c_count,
-                                           call->candidates->kind == szs_input_u64tape_k, base + 2 * (size_t)q_count,
-                                           base + 2 * (size_t)q_count + c_count, counts + q_count, starts + q_count};
-            c_side = other;
-        }
+        hipError_t error = enqueue_transcoding(call, remote, flags_at, needed_at, staging_bytes, starts, counts, renumber);
+        SZS_RUNE_SIDES();
         szs_plan_expectation_t none;
         memset(&none, 0, sizeof(none));
         none.sequence = ++engine->plan_sequence;
         if (error == hipSuccess)
-            error = (hipError_t)szs_hip_plan(&q_side, symmetric ? NULL : &c_side, SZS_MYERS_MAX_WORDS * (unsigned)(engine->is_unit_cost != 0), &none,
-                                             (szs_plan_summary_t *)summary, stream);
+            error = (hipError_t)szs_hip_plan(&q_side, symmetric ? NULL : &c_side, myers_words, &none, (szs_plan_summary_t *)summary, stream);
         if (error == hipSuccess) error = hipMemcpyAsync((void *)flags, remote + flags_at, staging_bytes - flags_at, hipMemcpyDeviceToHost, stream);
         hipError_t const drained = hipStreamSynchronize(stream); /* THE wait of the planning half; also on failure */
         if (error == hipSuccess) error = drained;
@@ -1218,10 +1342,13 @@ static sz_status_t cross_device_planned_runes(szs_call_t *call) {
         status = szs_buffer_reserve(&engine->device_runes, szs_memory_device_k, device, (size_t)(needed + needed / 4 + 4) * sizeof(uint32_t), error_message);
         if (status != sz_success_k) return status; /* grown: transcode again, every string fits now */
     }
+#undef SZS_RUNE_SIDES
+    if (remembered->runes) remembered->valid = 0; /* whatever happens below, the next call is not launched on an older codepoint shape */
     if (!flags[0]) return SZS_RUNES_ARE_BYTES;
     if (seen.status & SZS_PLAN_STATUS_UNSORTED) return SZS_NOT_DEVICE_PLANNABLE; /* strings beyond the planner's histogram */
     uint32_t const distinct = flags[1], overflowed = flags[2];
-    uint32_t const alphabet = renumber && distinct && distinct <= SZS_ALPHABET_MOST && !overflowed ? distinct : 0; /* the arrays hold ids */
+    /* the arrays hold ids 1 ... distinct: the kernels index direct tables with them */
+    uint32_t const alphabet = renumber && distinct && distinct <= SZS_ALPHABET_MOST && !overflowed ? alphabet_with_room(distinct) : 0;
     phase(call, 1);
 
     for (int attempt = 0; attempt < 2; ++attempt) { /* second round: a stalled band chain is re-run on the lanes tier */
@@ -1245,7 +1372,12 @@ static sz_status_t cross_device_planned_runes(szs_call_t *call) {
         int stalled = 0;
         engine->last_profile.planner = 1;
         status = finish(call, &d, error, enqueue_status, launches, cell_bits, seen.side[0].symbols, seen.side[1].symbols, &stalled);
-        if (status != sz_success_k || !stalled) return status;
+        if (status != sz_success_k) return status;
+        if (!stalled) {
+            *remembered = d; /* the next batch of this shape goes in behind its own planner, unseen by the host */
+            remembered->summary = seen, remembered->refs_current = 0;
+            return sz_success_k;
+        }
     }
     return szs_report(sz_status_unknown_k, error_message, "Systolic pipeline stalled");
 }

@@ -173,7 +173,7 @@ double szs_plan_estimate(unsigned bit_parallel_limit, int bit_parallel_chain, in
     int const bit_parallel = bit_parallel_limit && longest_query <= bit_parallel_limit;
     double const waves_per_query = (candidates_count + 63) / 64;
     double lane_waves = queries_count * waves_per_query * scale;
-    /* The long bit-parallel widths (24 ... 64 words) spread a pair over 2 or 4 lanes (dispatch.c: split_lanes_of): that many
+    /* The long bit-parallel widths (24 ... 64 words) spread a pair over 2 or 4 lanes (dispatch.c: myers_shape_of): that many
      * times the wavefronts, each pair that many times shorter - 128 x 128 x 1000 B runs at 29 TCUPS on this tier, 15 on the
      * chain (profiles/r02/shapes.jsonl).  Bytes only: a side of codepoints reaches here with `bit_parallel_limit` = 2048 too,
      * and its split kernels follow the same rule. */

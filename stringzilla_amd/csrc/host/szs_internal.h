@@ -110,7 +110,9 @@ typedef struct szs_engine_s {
     int events_device;
     /* launches of different bit-vector widths fan out over these and fill each other's tails (dispatch.c: enqueue) */
 #ifndef SZS_AUX_STREAMS
-#define SZS_AUX_STREAMS 7
+#define SZS_AUX_STREAMS 7 /* eight streams for up to nine width groups: the short launch - thousands of workgroups that live
+                             microseconds - goes LAST on the stream of the lightest long one and fills the others' tails; on a
+                             stream of its own it takes the slots first (config 5: 9.90 ms on nine streams, 9.60 on eight) */
 #endif
     unsigned last_streams;       /* streams the launches of the last call were dealt over (call profile) */
     hipStream_t aux_streams[SZS_AUX_STREAMS];

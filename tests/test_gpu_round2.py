@@ -75,12 +75,14 @@ def test_device_and_host_planners_score_the_same_matrices(gpu, oracle):
         # bytes); otherwise the launches go in behind the planner - except non-unit Levenshtein costs over bytes (round 3),
         # whose launch depends on the byte alphabet the device counts for this very call: planned, never speculated
         speculated = 1 if name in ("lev_weighted", "lev_affine") else 2
-        assert profile.planner == ((3 if name == "lev_unit" else speculated) if profile.tier == 0 else 1), name
+        # (a re-used plan, 3, and - round 3 - speculation, 2, only where the whole call is ONE launch: this batch's queries of
+        # up to 300 bytes are two width groups of the bit-parallel kernels, planned and waited for: 1)
+        assert profile.planner in (((1, 2, 3) if name == "lev_unit" else (speculated,)) if profile.tier == 0 else (1,)), name
         assert np.array_equal(second, expected), name
         with knob("reuse", "0"):
             again = engine(q, c, device=gpu).view(np.int64)
             profile = engine.last_call_profile()
-            assert profile.planner == (speculated if profile.tier == 0 else 1), name
+            assert profile.planner in (((1, 2) if name == "lev_unit" else (speculated,)) if profile.tier == 0 else (1,)), name
         assert np.array_equal(again, expected), name
         with knob("planner", "host"):
             third = engine(q, c, device=gpu).view(np.int64)
@@ -440,12 +442,13 @@ def test_real_text_tokens_match_the_oracle(gpu, oracle, tokens):
 # ---- several lanes per pair for the long byte widths (lev_myers.hip: levenshtein_myers_split_kernel) ----------------------
 
 
-@pytest.mark.parametrize("lanes", ["2", "4", None])
+@pytest.mark.parametrize("lanes", ["2", "4", "8", None])
 def test_split_lanes_agree_with_the_oracle(gpu, oracle, lanes):
-    """Queries of 641 .. 2048 bytes (launch variants 24, 32, 48, 64 words) with every pair spread over 2 or 4 lanes: every width
-    boundary, ragged candidates from empty to longer than the queries, more candidates than one workgroup takes, symmetric."""
+    """Queries of 385 .. 2048 bytes (launch variants 16, 20 - round 3: 20 words run in the 24-word kernel - 24, 32, 48, 64 words)
+    with every pair spread over 2, 4 or 8 lanes: every width boundary, ragged candidates from empty to longer than the queries,
+    more candidates than one workgroup takes, symmetric."""
     rng = random.Random(64 + int(lanes or 0))
-    lengths = (641, 700, 768, 769, 800, 1023, 1024, 1025, 1100, 1500, 1536, 1537, 1600, 2000, 2047, 2048)
+    lengths = (385, 450, 512, 513, 600, 640, 641, 700, 768, 769, 800, 1023, 1024, 1025, 1100, 1500, 1536, 1537, 1600, 2000, 2047, 2048)
     queries = [bytes(rng.choice(b"ACGTN") for _ in range(n)) for n in lengths]
     candidates = _strings(rng, 150, 0, 2300, b"ACGTN") + [b"", b"A", queries[3], queries[-1][:-1]]
     engine = szs.LevenshteinDistances(capabilities=gpu)
@@ -460,12 +463,12 @@ def test_split_lanes_agree_with_the_oracle(gpu, oracle, lanes):
 
 @pytest.mark.parametrize("lanes,rune_ids", [("2", None), ("4", None), (None, None), ("4", "40"), ("2", "3")])
 def test_split_lanes_of_codepoints_agree_with_the_oracle(gpu, oracle, lanes, rune_ids):
-    """The codepoint twin: queries of 641 .. 2048 runes from a 300-rune alphabet of 1 .. 4-byte sequences, pairs over 2 or 4
+    """The codepoint twin: queries of 385 .. 2048 runes from a 300-rune alphabet of 1 .. 4-byte sequences, pairs over 2 or 4
     lanes; with `rune_ids` the match-mask table is shrunk so that most runes overflow it and travel beside the deltas."""
     rng = random.Random(640 + int(lanes or 0) + int(rune_ids or 0))
     alphabet = [chr(c) for c in list(range(0x41, 0x5B)) + list(range(0x3B1, 0x3C9)) + list(range(0x4E00, 0x4EF0)) + list(range(0x1F600, 0x1F60A))]
     text = lambda n: "".join(rng.choice(alphabet) for _ in range(n)).encode()
-    lengths = (641, 768, 769, 1023, 1024, 1025, 1536, 1537, 2000, 2047, 2048)
+    lengths = (385, 512, 513, 640, 641, 768, 769, 1023, 1024, 1025, 1536, 1537, 2000, 2047, 2048)
     queries = [text(n) for n in lengths]
     candidates = [text(rng.randrange(0, 2300)) for _ in range(140)] + [b"", "\u03b1".encode(), queries[3], queries[-1][:-4]]
     engine = szs.LevenshteinDistancesUTF8(capabilities=gpu)
