@@ -102,14 +102,14 @@ int szs_hip_levenshtein_myers_banded(szs_string_ref_t const *queries, uint32_t q
 size_t szs_hip_levenshtein_myers_banded_bytes(uint32_t queries_count, uint32_t candidates_count, uint32_t longest_candidate);
 
 /**
- *  The long rune widths (24 (2 lanes only), 32, 48, 64 words) with every pair spread over `lanes` = 2 or 4 adjacent lanes and
- *  256 pairs - 256 x lanes threads - per workgroup: the rune table of a 48- or 64-word query fills a CU's LDS, and this way
+ *  The long rune widths (16, 24 (2 lanes only), 32, 48, 64 words) with every pair spread over `lanes` = 2 or 4 adjacent lanes and
+ *  `pairs_per_workgroup` pairs - that many x lanes threads - per workgroup: the rune table of a 48- or 64-word query fills a CU's LDS, and this way
  *  it serves `lanes` wavefronts per SIMD instead of one.  hipErrorNotSupported like szs_hip_levenshtein_myers_runes_long.
  */
 int szs_hip_levenshtein_myers_runes_split(unsigned words, unsigned lanes, szs_string_ref_t const *queries, uint32_t queries_count,
                                           szs_string_ref_t const *candidates, uint32_t candidates_count, uint64_t *results,
                                           uint64_t results_row_stride, int symmetric, uint32_t alphabet /* 0, or the size of the batch's renumbered alphabet (szs_hip_alphabet_rename) */,
-    void *stream);
+                                          uint32_t pairs_per_workgroup /* 256, or 64 for a launch of a few workgroups */, void *stream);
 
 /**
  *  Codepoint queries of 257 to 2048 runes: `words` is a long launch variant of szs_hip_levenshtein_myers_round_words()

@@ -1142,7 +1142,10 @@ __global__ __launch_bounds__(256 * lanes_) void levenshtein_myers_split_runes_ke
                                                                                       u64 *__restrict__ results, u64 results_row_stride,
                                                                                       int symmetric, u32 rune_slots, u32 id_capacity, u32 alphabet) {
     constexpr int words = words_per_lane_ * lanes_;
-    constexpr u32 threads = 256u * lanes_;
+    // 256 pairs per workgroup when the launch fills the device (one table serves L wavefronts per SIMD); 64 in a launch of a few
+    // workgroups, whose pairs are its duration: sixteen wavefronts on a CU take turns on its SIMDs while other CUs idle
+    // (real-text lines: three 32-word queries were 48 workgroups and 3.2 ms - profiles/r03/timeline_lines_utf8_v1.txt)
+    u32 const threads = blockDim.x, pairs_per_block = threads / lanes_;
     static_assert(words_per_lane_ % 4 == 0 && (lanes_ == 2 || lanes_ == 4 || lanes_ == 8), "whole 16-byte Peq chunks per lane");
     extern __shared__ __attribute__((aligned(16))) u32 rune_lds[];
     rune_masks_t<words, lanes_> const masks(rune_lds, rune_slots, id_capacity, alphabet);
@@ -1157,7 +1160,7 @@ __global__ __launch_bounds__(256 * lanes_) void levenshtein_myers_split_runes_ke
     masks.build(pattern, query_length, pad, threads, counters);
 
     u32 const part = threadIdx.x % lanes_, pair = threadIdx.x / lanes_;
-    u32 const candidate_slot = candidate_block * 256u + pair;
+    u32 const candidate_slot = candidate_block * pairs_per_block + pair;
     bool live = candidate_slot < candidates_count;
     szs_string_ref_t candidate = {0, 0, 0};
     if (live) candidate = candidates[candidate_slot];
@@ -1231,7 +1234,7 @@ __global__ __launch_bounds__(256 * lanes_) void levenshtein_myers_split_runes_ke
 
 template <int words_per_lane_, int lanes_>
 static int launch_split_runes(szs_string_ref_t const *queries, u32 queries_count, szs_string_ref_t const *candidates, u32 candidates_count,
-                              u64 *results, u64 stride, int symmetric, u32 alphabet, hipStream_t stream) {
+                              u64 *results, u64 stride, int symmetric, u32 alphabet, u32 pairs_per_block, hipStream_t stream) {
     u32 rune_slots = 0, id_capacity = 0;
     size_t bytes = 0;
     if (!rune_lds_plan<words_per_lane_ * lanes_, lanes_>(alphabet, rune_slots, id_capacity, bytes)) return (int)hipErrorNotSupported;
@@ -1246,11 +1249,12 @@ static int launch_split_runes(szs_string_ref_t const *queries, u32 queries_count
         }
         remember(granted, 1);
     }
-    u32 const candidate_blocks = (candidates_count + 255u) / 256u;
+    if (pairs_per_block != 64u) pairs_per_block = 256u;
+    u32 const candidate_blocks = (candidates_count + pairs_per_block - 1) / pairs_per_block;
     u32 const queries_per_launch = candidate_blocks ? (1u << 30) / candidate_blocks : queries_count;
     for (u32 first = 0; first < queries_count; first += queries_per_launch) {
         u32 const batch = queries_count - first < queries_per_launch ? queries_count - first : queries_per_launch;
-        hipLaunchKernelGGL((levenshtein_myers_split_runes_kernel<words_per_lane_, lanes_>), dim3(batch * candidate_blocks), dim3(256u * lanes_),
+        hipLaunchKernelGGL((levenshtein_myers_split_runes_kernel<words_per_lane_, lanes_>), dim3(batch * candidate_blocks), dim3(pairs_per_block * lanes_),
                            bytes, stream, queries + first, candidates, candidates_count, candidate_blocks, results, stride, symmetric, rune_slots,
                            id_capacity, alphabet);
         hipError_t const error = hipGetLastError();
@@ -1631,14 +1635,15 @@ extern "C" int szs_hip_levenshtein_myers_banded_runes(szs_string_ref_t const *qu
 extern "C" int szs_hip_levenshtein_myers_runes_split(unsigned words, unsigned lanes, szs_string_ref_t const *queries,
                                                      uint32_t queries_count, szs_string_ref_t const *candidates,
                                                      uint32_t candidates_count, uint64_t *results, uint64_t results_row_stride,
-                                                     int symmetric, uint32_t alphabet, void *stream) {
+                                                     int symmetric, uint32_t alphabet, uint32_t pairs_per_workgroup, void *stream) {
     using namespace szs_hip;
     if (!queries_count || !candidates_count) return 0;
     if (alphabet > SZS_ALPHABET_MOST) return (int)hipErrorInvalidValue;
     hipStream_t const s = static_cast<hipStream_t>(stream);
 #define SZS_SPLIT_RUNES_CASE(W, L)                                                                                     \
     if (words == W && lanes == L)                                                                                      \
-        return launch_split_runes<W / L, L>(queries, queries_count, candidates, candidates_count, results, results_row_stride, symmetric, alphabet, s);
+        return launch_split_runes<W / L, L>(queries, queries_count, candidates, candidates_count, results, results_row_stride, symmetric, alphabet, \
+                                            pairs_per_workgroup, s);
     SZS_SPLIT_RUNES_CASE(16, 2)
     SZS_SPLIT_RUNES_CASE(16, 4)
     SZS_SPLIT_RUNES_CASE(24, 2)

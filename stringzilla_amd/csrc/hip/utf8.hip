@@ -179,43 +179,50 @@ __global__ __launch_bounds__(64 * transcode_waves_k) void utf8_transcode_kernel(
  *  place.  With A <= SZS_ALPHABET_MOST the kernels then look a symbol up in a direct table (`local[id]`, one LDS read, no loop);
  *  a richer batch keeps its runes (the second pass does nothing) and the kernels keep probing.
  */
-constexpr u32 alphabet_slots_k = SZS_ALPHABET_SLOTS, alphabet_empty_k = ~0u, alphabet_seen_lines_k = 2048;
+constexpr u32 alphabet_slots_k = SZS_ALPHABET_SLOTS, alphabet_empty_k = ~0u, alphabet_seen_lines_k = 4096;
 
 __device__ __forceinline__ u32 alphabet_slot(u32 rune) { return (rune * 2654435761u) >> (32 - __builtin_ctz(alphabet_slots_k)); }
 
-/** control[0]: distinct runes claimed so far (the alphabet's size), control[1]: 1 when the table ran out of room. */
-__global__ __launch_bounds__(256) void alphabet_claim_kernel(u32 count, u64 const *__restrict__ rune_starts, u32 const *__restrict__ rune_counts,
-                                                             u32 const *__restrict__ runes, u32 const *__restrict__ any_multibyte,
-                                                             u32 *__restrict__ keys, u32 *__restrict__ ids, u32 *__restrict__ control, u32 most) {
+/** control[0]: distinct runes claimed so far (the alphabet's size), control[1]: 1 when the table ran out of room.
+ *
+ *  Text repeats its runes, and a claim is an atomic on a table in global memory: 8192 wavefronts that all meet ' ' in their
+ *  first sixty-four runes are 100,000 compare-and-swaps on ONE address, serialised at the memory side - 0.62 ms for 4096 + 4096
+ *  lines of prose (profiles/r03: the claim kernel was longer than any scoring launch of that call).  So a workgroup claims in
+ *  LDS first: a direct-mapped table of the runes somebody in THIS workgroup has taken charge of; only the lane that installs a
+ *  rune there (or finds its line taken by another rune) goes to the global table.  Few, large, persistent workgroups - one per
+ *  CU at most, sixteen wavefronts each - so that "once per workgroup" is a few hundred global claims per distinct rune, not
+ *  thousands. */
+constexpr u32 alphabet_claim_threads_k = 1024;
+
+__global__ __launch_bounds__(alphabet_claim_threads_k) void alphabet_claim_kernel(u32 count, u64 const *__restrict__ rune_starts,
+                                                                                  u32 const *__restrict__ rune_counts, u32 const *__restrict__ runes,
+                                                                                  u32 const *__restrict__ any_multibyte, u32 *__restrict__ keys,
+                                                                                  u32 *__restrict__ ids, u32 *__restrict__ control, u32 most) {
     if (!*any_multibyte) return; // an ASCII batch goes to the byte engines
-    // Text repeats its runes: a workgroup remembers in LDS which runes it has SEEN claimed (a direct-mapped filter, one rune
-    // per line; a stale or lost line only costs the probe below) and goes to the table in global memory - an atomic load per
-    // rune, 66 us for 4.5 M runes - only for the others: a few hundred probes per workgroup instead of tens of thousands.
-    __shared__ u32 seen[alphabet_seen_lines_k];
-    for (u32 line = threadIdx.x; line < alphabet_seen_lines_k; line += blockDim.x) seen[line] = alphabet_empty_k;
+    __shared__ u32 taken[alphabet_seen_lines_k];
+    for (u32 line = threadIdx.x; line < alphabet_seen_lines_k; line += blockDim.x) taken[line] = alphabet_empty_k;
     __syncthreads();
     u32 const lane = threadIdx.x % 64u, waves = gridDim.x * (blockDim.x / 64u);
     for (u32 i = blockIdx.x * (blockDim.x / 64u) + threadIdx.x / 64u; i < count; i += waves) {
-        // Once the alphabet has outgrown `most` (or the table) nothing will be renamed: stop claiming.  A batch of high-entropy
-        // bytes decoded unchecked would otherwise fill all 65536 slots and every later rune would probe the whole table
-        // (seconds on a large batch, for a result that is thrown away).  The counter only grows, so every wavefront that looks
-        // after the threshold was crossed leaves, and the renaming pass reads the same words and skips.
-        if (__atomic_load_n(&control[0], __ATOMIC_RELAXED) > most || __atomic_load_n(&control[1], __ATOMIC_RELAXED)) return;
         u32 const *const text = runes + rune_starts[i];
         u32 const length = rune_counts[i];
         for (u32 j = lane; j < length; j += 64) {
-            u32 const rune = text[j];
+            u32 const rune = text[j]; // (never alphabet_empty_k: a decoded sequence has 21 bits)
             u32 slot = alphabet_slot(rune);
             u32 const line = slot & (alphabet_seen_lines_k - 1);
-            if (seen[line] == rune) continue; // (no rune is alphabet_empty_k: 21 bits, or an unchecked 4-byte sequence's 21)
+            if (taken[line] == rune || atomicCAS(&taken[line], alphabet_empty_k, rune) == rune) continue;
+            // Once the alphabet has outgrown `most` (or the table) nothing will be renamed: stop claiming.  A batch of
+            // high-entropy bytes decoded unchecked would otherwise fill all 65536 slots and every later rune would probe the
+            // whole table (seconds on a large batch, for a result that is thrown away).  The counter only grows, and the
+            // renaming pass reads the same words and skips.
+            if (__atomic_load_n(&control[0], __ATOMIC_RELAXED) > most || __atomic_load_n(&control[1], __ATOMIC_RELAXED)) return;
             for (u32 probes = 0;; ++probes) {
-                u32 key = __atomic_load_n(&keys[slot], __ATOMIC_RELAXED);
+                u32 key = keys[slot]; // a slot is written once: a stale line can only read as empty, and then the swap decides
                 if (key == alphabet_empty_k) key = atomicCAS(&keys[slot], alphabet_empty_k, rune);
-                if (key == rune) { seen[line] = rune; break; }
+                if (key == rune) break;
                 if (key == alphabet_empty_k) { // this thread claimed the slot: the rune's id is the next one
                     u32 const id = atomicAdd(&control[0], 1u) + 1;
                     ids[slot] = id;
-                    seen[line] = rune;
                     break;
                 }
                 if (probes >= alphabet_slots_k) { control[1] = 1; break; } // table full: the batch keeps its runes
@@ -307,7 +314,9 @@ extern "C" int szs_hip_alphabet_rename(uint32_t count, uint64_t const *rune_star
     if (error == hipSuccess) error = hipMemsetAsync(control, 0, 2 * sizeof(u32), s);
     if (error != hipSuccess) return (int)error;
     u32 const blocks = (count + 3) / 4 < 2048u ? (count + 3) / 4 : 2048u;
-    hipLaunchKernelGGL(alphabet_claim_kernel, dim3(blocks), dim3(256), 0, s, count, rune_starts, rune_counts, runes, any_multibyte, keys, ids, control, most);
+    u32 const claim_waves = alphabet_claim_threads_k / 64u, claim_blocks = (count + claim_waves - 1) / claim_waves;
+    hipLaunchKernelGGL(alphabet_claim_kernel, dim3(claim_blocks < 256u ? claim_blocks : 256u), dim3(alphabet_claim_threads_k), 0, s, count, rune_starts,
+                       rune_counts, runes, any_multibyte, keys, ids, control, most);
     hipLaunchKernelGGL(alphabet_rename_kernel, dim3(blocks), dim3(256), 0, s, count, rune_starts, rune_counts, runes, any_multibyte, keys, ids,
                        control, most, alphabet_out);
     return (int)hipGetLastError();

@@ -544,6 +544,7 @@ static myers_shape_t myers_shape_of(int knob, unsigned variant, uint64_t workgro
     unsigned lanes = pinned ? (unsigned)knob : workgroups_unsplit < 256 ? 8u : workgroups_unsplit < 1024 ? 4u : 2u;
     if (variant < 24) {
         if (!pinned && workgroups_unsplit >= 256) return shape;
+        if (runes) return shape; /* codepoints: measured slower (real-text lines 50.9 against 55.7 T cells/s, an eighth of config 5u 1.88 / 1.85 ms) */
         if (variant == 20) shape.words = 24;
         else lanes = pinned && lanes >= 4 ? 4u : 2u; /* eight words per lane are as short as the other launches' pairs */
     }
@@ -658,7 +659,8 @@ static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int dev
                                    ? szs_hip_levenshtein_myers_runes(queries, count, candidate_refs, d->kc_count, (uint64_t *)device_results,
                                                                      device_stride, d->layout, d->alphabet, target)
                                : shape.lanes ? szs_hip_levenshtein_myers_runes_split(shape.words, shape.lanes, queries, count, candidate_refs, d->kc_count,
-                                                                               (uint64_t *)device_results, device_stride, d->layout, d->alphabet, target)
+                                                                               (uint64_t *)device_results, device_stride, d->layout, d->alphabet,
+                                                                               (uint64_t)group->count * candidate_blocks < 256 ? 64u : 256u, target)
                                        : szs_hip_levenshtein_myers_runes_long(group->variant, queries, count, candidate_refs, d->kc_count,
                                                                               (uint64_t *)device_results, device_stride, d->layout, d->alphabet, target);
                 if (launch_error == (int)hipErrorNotSupported) { /* no LDS for the rune table: the rune-keyed DP kernel, whose
@@ -1216,10 +1218,15 @@ static sz_status_t cross_device_planned_runes(szs_call_t *call) {
         engine->remembered->refs_current = 0, engine->remembered->valid = 0;
     if (status == sz_success_k && engine->device_runes.capacity < ((size_t)1 << 20))
         status = szs_buffer_reserve(&engine->device_runes, szs_memory_device_k, device, (size_t)1 << 20, error_message);
-    /* Renumbering the runes costs three more launches (~75 us): worth it for a batch of 64 KB or more (hip/utf8.hip).  The host
-     * has not read an offset, so it goes by what the PREVIOUS call of this engine needed - a stream of batches settles at once. */
+    /* Renumbering the runes (hip/utf8.hip) is four more operations ahead of the planner - ~80 us and a pass over every rune -
+     * and makes the scoring kernels ~15 % faster (one LDS read per column instead of a hash probe): worth it when the CELLS of
+     * the call outweigh its runes by far.  4096 x 4096 words of prose (6e8 cells): 0.39 ms renumbered, 0.31 not; config 5u
+     * (4.4e11 cells): 7.1 against 8.4 ms.  The host has not read an offset, so it goes by the PREVIOUS call of this engine -
+     * a stream of batches settles at once. */
     int const alphabet_knob = szs_tuning_get(szs_knob_alphabet_k);
-    int const renumber = alphabet_knob == 0 ? 0 : alphabet_knob > 0 ? 1 : engine->runes_needed >= SZS_ALPHABET_WORTH_BYTES;
+    int const renumber = alphabet_knob == 0  ? 0
+                         : alphabet_knob > 0 ? 1
+                                             : engine->last_profile.cells >= 80000000000ull + 20000ull * engine->runes_needed && engine->runes_needed > 0;
     if (status == sz_success_k && renumber)
         status = szs_buffer_reserve(&engine->device_alphabet, szs_memory_device_k, device, szs_hip_alphabet_workspace_bytes(), error_message);
     if (status == sz_success_k) status = place_results(call);
