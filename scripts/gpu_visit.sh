@@ -30,6 +30,8 @@ for step in "$@"; do
     shapes)     timeout 900 python scripts/measure_shapes.py > "$OUT/shapes.jsonl" 2> "$OUT/shapes.err"; cat "$OUT/shapes.jsonl"; tail -3 "$OUT/shapes.err";;
     realtext)   rm -f gpurun_out/real_text/real_text.jsonl; timeout 600 bash scripts/run_real_text.sh > "$OUT/real_text.log" 2>&1; cp gpurun_out/real_text/real_text.jsonl "$OUT/real_text.jsonl"; cat "$OUT/real_text.jsonl";;
     previews)   for config in 3 4 5 6; do timeout 300 python scripts/measure_shard_of.py --config $config --shards 1,2,4,8; done > "$OUT/shard_preview.jsonl" 2> "$OUT/shard_preview.err"; cat "$OUT/shard_preview.jsonl";;
+    bench20)    timeout 600 python bench.py --steps 20 --warmup 5 > "$OUT/bench_20.json" 2> "$OUT/bench_20.err"; tail -c 1500 "$OUT/bench_20.json"; tail -3 "$OUT/bench_20.err";;
+    pmc)        timeout 1500 bash scripts/profile_configs.sh $TAG/pmc 2 3 4 5 6 7 8 > "$OUT/pmc.log" 2>&1; tail -5 "$OUT/pmc.log";;
     *) echo "unknown step $step";;
   esac
 done

@@ -1218,15 +1218,15 @@ static sz_status_t cross_device_planned_runes(szs_call_t *call) {
         engine->remembered->refs_current = 0, engine->remembered->valid = 0;
     if (status == sz_success_k && engine->device_runes.capacity < ((size_t)1 << 20))
         status = szs_buffer_reserve(&engine->device_runes, szs_memory_device_k, device, (size_t)1 << 20, error_message);
-    /* Renumbering the runes (hip/utf8.hip) is four more operations ahead of the planner - ~80 us and a pass over every rune -
-     * and makes the scoring kernels ~15 % faster (one LDS read per column instead of a hash probe): worth it when the CELLS of
-     * the call outweigh its runes by far.  4096 x 4096 words of prose (6e8 cells): 0.39 ms renumbered, 0.31 not; config 5u
-     * (4.4e11 cells): 7.1 against 8.4 ms.  The host has not read an offset, so it goes by the PREVIOUS call of this engine -
-     * a stream of batches settles at once. */
+    /* Renumbering the runes (hip/utf8.hip) is four more operations ahead of the planner - ~60 us and a pass over every rune,
+     * ~15 ps each - and makes the scoring kernels ~15 % faster (one LDS read per column instead of a hash probe, ~3 fs per
+     * cell): worth it when the CELLS of the call outweigh its runes.  4096 x 4096 words of prose (6e8 cells): 0.39 ms
+     * renumbered, 0.31 not; config 5u (4.4e11 cells): 7.1 against 8.4 ms, an eighth of it 1.82 / 2.16.  The host has not read
+     * an offset, so it goes by the PREVIOUS call of this engine - a stream of batches settles at once. */
     int const alphabet_knob = szs_tuning_get(szs_knob_alphabet_k);
     int const renumber = alphabet_knob == 0  ? 0
                          : alphabet_knob > 0 ? 1
-                                             : engine->last_profile.cells >= 80000000000ull + 20000ull * engine->runes_needed && engine->runes_needed > 0;
+                                             : engine->cells_before >= 20000000000ull + 5000ull * engine->runes_needed && engine->runes_needed > 0;
     if (status == sz_success_k && renumber)
         status = szs_buffer_reserve(&engine->device_alphabet, szs_memory_device_k, device, szs_hip_alphabet_workspace_bytes(), error_message);
     if (status == sz_success_k) status = place_results(call);
@@ -1553,6 +1553,7 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
     int const symmetric = candidates == NULL;
     size_t const queries_count = queries->count;
     size_t const candidates_count = symmetric ? queries_count : candidates->count;
+    engine->cells_before = engine->last_profile.cells;
     memset(&engine->last_profile, 0, sizeof(engine->last_profile));
     if (!queries_count || !candidates_count) return szs_report(sz_success_k, error_message, NULL); /* cuda.cuh:4257 */
     if (queries_count > 0xFFFFFFFFull || candidates_count > 0xFFFFFFFFull)

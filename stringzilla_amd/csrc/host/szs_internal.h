@@ -95,6 +95,7 @@ typedef struct szs_engine_s {
     szs_buffer_t pinned_tape;    /* pinned: the host side of that copy */
     szs_buffer_t device_runes;   /* device: UTF-32 transcription of both sides (codepoint-level engine) */
     uint64_t runes_needed;       /* runes the last device-planned codepoint call needed in that buffer (~ the bytes of its batch) */
+    uint64_t cells_before;       /* cells of the previous call of this engine (the call profile is cleared when a call begins) */
     szs_buffer_t device_transcode; /* device: raw refs, rune starts, rune counts and the multibyte flag of that pass */
     szs_buffer_t device_alphabet;  /* device: the hash table that renumbers a batch's runes (hip/utf8.hip) */
     szs_buffer_t pinned_transcode; /* pinned: the host's side of the same */
