@@ -8,9 +8,10 @@ kernel time (from the --stats run, NOT from the slower counter runs), and the de
                                                 are kept and labelled as such
     valu_lane_ops_per_second                    SQ_INSTS_VALU x 64 / duration
     wave_wait_inst_fraction / wave_wait_any_fraction   SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES (ready, the pipe is busy) and SQ_WAIT_ANY /
-                                                SQ_WAVE_CYCLES (parked on s_waitcnt or a barrier); `valu_busy_fraction` (SQ_ACTIVE_INST_VALU,
-                                                which equals SQ_INSTS_VALU on gfx950: instructions x an assumed 4 cycles) is kept in
-                                                the file but no longer reported by bench.py
+                                                SQ_WAVE_CYCLES (parked on s_waitcnt or a barrier).  (Round 2 also derived a "VALU busy" fraction
+                                                from SQ_ACTIVE_INST_VALU; on gfx950 that counter equals SQ_INSTS_VALU - instructions,
+                                                not cycles - so the figure was instructions x an assumed 4 cycles and read above 1.
+                                                It is gone; the raw counter stays.)
     lds_conflict_fraction                       SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
 """
 import csv
@@ -69,9 +70,6 @@ for directory in sorted(glob.glob(os.path.join(root, "cfg*"))):
             entry["valu_lane_ops_per_second"] = entry["SQ_INSTS_VALU"] * 64 / entry["_duration_seconds"]
         if entry.get("SQ_LDS_IDX_ACTIVE"):
             entry["lds_conflict_fraction"] = entry.get("SQ_LDS_BANK_CONFLICT", 0.0) / entry["SQ_LDS_IDX_ACTIVE"]
-        if entry.get("SQ_BUSY_CYCLES") and "SQ_ACTIVE_INST_VALU" in entry:
-            # SQ_ACTIVE_INST_VALU counts quad-cycles summed over SIMDs; SQ_BUSY_CYCLES is summed over shader engines
-            entry["valu_active_over_busy"] = entry["SQ_ACTIVE_INST_VALU"] / entry["SQ_BUSY_CYCLES"]
         summary[f"cfg{config}:{kernel}"] = entry
     # ---- the whole call: what one C-ABI call of this config issues and moves, summed over its kernels (which may overlap on
     #      several streams: per-kernel durations then add up to more than the call)
@@ -101,8 +99,6 @@ for directory in sorted(glob.glob(os.path.join(root, "cfg*"))):
         if "SQ_INSTS_VALU" in call and seconds:
             call["valu_lane_ops_per_second"] = call["SQ_INSTS_VALU"] * 64 / seconds
             call["valu_lane_ops_per_cell"] = call["SQ_INSTS_VALU"] * 64 / max(call["_cells_per_call"], 1)
-        if "SQ_ACTIVE_INST_VALU" in call and seconds:  # quad-cycles summed over 1024 SIMDs against the call's kernel time at 2.4 GHz
-            call["valu_busy_fraction"] = call["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (seconds * 2.4e9)
         if call.get("SQ_WAVE_CYCLES"):  # where a resident wavefront's cycles go (quad-cycles, disjoint buckets: MI355X_MICROARCH.md)
             call["wave_wait_inst_fraction"] = call.get("SQ_WAIT_INST_ANY", 0.0) / call["SQ_WAVE_CYCLES"]  # ready to issue, pipe busy
             call["wave_wait_any_fraction"] = call.get("SQ_WAIT_ANY", 0.0) / call["SQ_WAVE_CYCLES"]        # parked on s_waitcnt / barrier
