@@ -191,19 +191,23 @@ def cpu_baseline(load, gpu_matrix, seconds):
     assert np.array_equal(matrix.view(np.int64), expected.view(np.int64)), "CPU baseline and GPU disagree"
     # five or more runs when the budget allows; a batch whose SMALLEST fair sample (a row per thread x one lane group) already
     # takes seconds per run - config 4 - gets three
-    repeats = int(max(3 if first > seconds / 5 else 5, min(50, (seconds - first) / max(first, 1e-3))))
+    # ... and a run lasts a quarter of a second or more: a batch the CPU finishes in 30 ms (configs 2, 7, 8) is passed several
+    # times back to back per run - timed one pass at a time, 256 threads starting up made the median wander between 340 and 580
+    passes = 1 if first >= 0.25 else int(min(64, np.ceil(0.25 / max(first, 1e-4))))
+    repeats = int(max(3 if first * passes > seconds / 5 else 5, min(20, (seconds - first) / max(first * passes, 1e-3))))
     runs = []
     for _ in range(repeats):
         started = time.perf_counter()
-        run(rows, columns)
-        runs.append(time.perf_counter() - started)
+        for _ in range(passes):
+            run(rows, columns)
+        runs.append((time.perf_counter() - started) / passes)
     elapsed = float(np.median(runs))  # the median: a 256-thread host shows stragglers, a mean of two runs wandered by 25 %
     what = (f"the full {len(q_lengths)}x{len(c_lengths)} batch of the timed config" if whole else
             f"{len(rows)} evenly spaced query rows x {len(columns)} evenly spaced candidates of the timed config")
     return {
         "value": round(cells_of(rows, columns) / elapsed / 1e9, 2), "unit": "GCUPS", "cores": cores, "kind": kind,
         "spread": [round(cells_of(rows, columns) / max(runs) / 1e9, 2), round(cells_of(rows, columns) / min(runs) / 1e9, 2)],
-        "sample": f"{what}, median of {repeats} runs (`spread`: slowest and fastest run), {label} tier, {cores} threads, tape packing "
+        "sample": f"{what}, median of {repeats} runs{f' of {passes} passes each' if passes > 1 else ''} (`spread`: slowest and fastest run), {label} tier, {cores} threads, tape packing "
                   f"included; the sampled cells verified equal to the GPU's",
     }
 
@@ -227,7 +231,7 @@ def roofline(config, profile, kernel_seconds, traffic_override=None):
     kernels = call.get("kernels", {})
     if kernels:
         dominant = max(kernels, key=lambda name: kernels[name]["share_of_kernel_time"])
-        record["kernel"] = dominant if len(kernels) == 1 else f"{dominant} + {len(kernels) - 1} more (launches of different widths overlap on four streams)"
+        record["kernel"] = dominant if len(kernels) == 1 else f"{dominant} + {len(kernels) - 1} more (launches of different widths overlap on {int(getattr(profile, 'streams', 0)) or 'several'} streams)"
     if traffic_override is None and "hbm_fetch_bytes_raw" in call and "hbm_write_bytes_raw" in call:
         record["traffic"] = round(call["hbm_fetch_bytes_raw"] + call["hbm_write_bytes_raw"])
         record["traffic_source"] = (f"{where}: (FETCH_SIZE + WRITE_SIZE) x 1024 summed over the kernels of one call, committed rocprofv3 "
