@@ -82,6 +82,17 @@ SZ_API_RUNTIME sz_status_t szs_rocm_team_orientation_probe(int affine, int symme
                                                            sz_size_t queries_count, sz_u32_t const *candidate_lengths,
                                                            sz_size_t candidates_count, int *tier, int *transposed, sz_u32_t *lanes);
 
+/**
+ *  The launches of a unit-cost Levenshtein call over queries of these lengths (bytes, or runes with `runes` != 0) against
+ *  `candidates_count` candidates, in the order they leave the host - longest pair first, the short launch last
+ *  (DESIGN.md section 4.1): per launch the width group's variant (8: the short kernel; 10 ... 64 words; 0: longer queries),
+ *  the words of the kernel that takes it and the lanes per pair (0: one).  `*launches` receives the number of groups; at
+ *  most `capacity` entries are written.  No GPU involved.
+ */
+SZ_API_RUNTIME sz_status_t szs_rocm_launch_order_probe(int runes, sz_u32_t const *query_lengths, sz_size_t queries_count,
+                                                       sz_size_t candidates_count, sz_u32_t *variants, sz_u32_t *words, sz_u32_t *lanes,
+                                                       sz_size_t capacity, sz_size_t *launches);
+
 /* ---- one cross-product over the N GPUs of a host (csrc/host/node.c) ------------------------------
  *
  *  The reference's C-ABI is one device per call (stringzillas.h:137) and has no multi-GPU path; what its threading rules

@@ -523,43 +523,6 @@ static hipError_t szs_aux_streams(int device, unsigned wanted, hipStream_t *stre
     return error;
 }
 
-/** The launch of one width group of the bit-parallel kernels: `words` of the kernel that takes it (>= the group's variant:
- *  patterns are right-aligned over phantom low rows, so a wider kernel scores a narrower query exactly) and `lanes` per pair
- *  (0: one lane per pair, the long kernels).
- *
- *  24 ... 64 words always spread a pair over lanes (hip/lev_myers.hip: levenshtein_myers_split_kernel): 2 when the launch
- *  fills the device anyway, 4 under 1024 workgroups, 8 under 256 - its longest pairs ARE its duration.  16 and 20 words join
- *  them only in a launch of fewer than 256 workgroups (round 3): an eighth of config 5 on each of eight GPUs is nine launches
- *  of ~200 workgroups, and the 20-word one - 2048 columns x 20 words x 10.5 instructions in ONE lane, 1.4 ms however idle
- *  the chip - ended the call at 2.0 ms for 1.2 ms of work (profiles/r03/timeline_cfg5_eighth_v1.txt).  Ten words per lane
- *  are not whole 16-byte Peq chunks: 20 words run as 24 over two lanes.  The `split` knob pins 0 / 2 / 4 / 8. */
-typedef struct myers_shape_t {
-    unsigned words, lanes;
-} myers_shape_t;
-
-static myers_shape_t myers_shape_of(int knob, unsigned variant, uint64_t workgroups_unsplit, int runes) {
-    myers_shape_t shape = {variant, 0};
-    if (knob == 0 || variant < 16 || variant == SZS_MYERS_SHORT_WORDS) return shape;
-    int const pinned = knob == 2 || knob == 4 || knob == 8;
-    unsigned lanes = pinned ? (unsigned)knob : workgroups_unsplit < 256 ? 8u : workgroups_unsplit < 1024 ? 4u : 2u;
-    if (variant < 24) {
-        if (!pinned && workgroups_unsplit >= 256) return shape;
-        if (runes) return shape; /* codepoints: measured slower (real-text lines 50.9 against 55.7 T cells/s, an eighth of config 5u 1.88 / 1.85 ms) */
-        if (variant == 20) shape.words = 24;
-        else lanes = pinned && lanes >= 4 ? 4u : 2u; /* eight words per lane are as short as the other launches' pairs */
-    }
-    if (shape.words == 24 && lanes >= 4) lanes = 2;
-    if (shape.words == 48 && lanes == 8) lanes = 4; /* six words per lane are not whole chunks either */
-    if (runes) {
-        if (lanes == 8) lanes = 4; /* the rune kernels are instantiated for two and four lanes */
-        /* 48 and 64 words always over four lanes: their rune table leaves room for one workgroup per CU, and only the split
-         * kernel puts more than one wavefront per SIMD behind it (lev_myers.hip) */
-        if (!pinned && variant >= 48) lanes = 4;
-    }
-    shape.lanes = lanes;
-    return shape;
-}
-
 /** Launches of one decision over device refs in kernel roles.  Returns the first launch error; counts launches. */
 static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int device, szs_string_ref_t const *query_refs,
                           szs_string_ref_t const *candidate_refs, void *device_results, size_t device_stride, hipStream_t stream,
@@ -626,24 +589,16 @@ static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int dev
      * used to go first and the 20-word launch - one lane per pair, the longest pairs of all - got its first wavefront 0.4 ms
      * into a 2 ms call.  Groups that need the workspace keep their place at the front, in order, on the scope's stream; the
      * short launch (thousands of workgroups that live microseconds) goes last and fills what the others leave. */
-    int const split_knob = szs_tuning_get(szs_knob_split_k);
-    myers_shape_t shapes[SZS_PLAN_MAX_GROUPS];
-    unsigned order[SZS_PLAN_MAX_GROUPS], urgency[SZS_PLAN_MAX_GROUPS];
-    for (unsigned g = 0; g < d->plan.groups_count; ++g) {
-        szs_plan_group_t const *group = &d->plan.groups[g];
-        shapes[g] = myers_shape_of(d->use_myers ? split_knob : 0, group->variant, (uint64_t)group->count * candidate_blocks, d->runes);
-        urgency[g] = group->variant == 0 ? ~0u : group->variant == SZS_MYERS_SHORT_WORDS ? 0u : shapes[g].words / (shapes[g].lanes ? shapes[g].lanes : 1u);
-        unsigned at = g;
-        for (; at > 0 && urgency[order[at - 1]] < urgency[g]; --at) order[at] = order[at - 1]; /* stable: ties stay widest first */
-        order[at] = g;
-    }
+    szs_launch_shape_t shapes[SZS_PLAN_MAX_GROUPS];
+    unsigned order[SZS_PLAN_MAX_GROUPS];
+    szs_plan_launch_order(&d->plan, d->use_myers, d->runes, candidate_blocks, szs_tuning_get(szs_knob_split_k), shapes, order);
     /* Launches that need no workspace are dealt over {scope's stream, auxiliary streams} back and forth (0 .. n, n .. 0, ...):
      * the second launch of a stream is the lightest one left. */
     unsigned next_lane = 0;
     for (unsigned turn_of = 0; turn_of < d->plan.groups_count && !launch_error && *status == sz_success_k; ++turn_of) {
         unsigned const g = order[turn_of];
         szs_plan_group_t const *group = &d->plan.groups[g];
-        myers_shape_t const shape = shapes[g];
+        szs_launch_shape_t const shape = shapes[g];
         int const uses_workspace = group->variant == 0;
         unsigned lane = 0;
         if (fan_out && !uses_workspace) {

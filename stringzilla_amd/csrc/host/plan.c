@@ -173,7 +173,7 @@ double szs_plan_estimate(unsigned bit_parallel_limit, int bit_parallel_chain, in
     int const bit_parallel = bit_parallel_limit && longest_query <= bit_parallel_limit;
     double const waves_per_query = (candidates_count + 63) / 64;
     double lane_waves = queries_count * waves_per_query * scale;
-    /* The long bit-parallel widths (24 ... 64 words) spread a pair over 2 or 4 lanes (dispatch.c: myers_shape_of): that many
+    /* The long bit-parallel widths (24 ... 64 words) spread a pair over 2 or 4 lanes (plan.c: szs_plan_myers_shape): that many
      * times the wavefronts, each pair that many times shorter - 128 x 128 x 1000 B runs at 29 TCUPS on this tier, 15 on the
      * chain (profiles/r02/shapes.jsonl).  Bytes only: a side of codepoints reaches here with `bit_parallel_limit` = 2048 too,
      * and its split kernels follow the same rule. */
@@ -292,6 +292,80 @@ sz_status_t szs_rocm_plan_probe(int unit_cost, int symmetric, sz_u32_t const *qu
                 query_variant[plan.groups[g].first + i] = plan.groups[g].variant;
     if (cells) *cells = plan.cells;
     free(addresses), free(query_refs), free(candidate_refs), free(keys), free(scratch);
+    return sz_success_k;
+}
+
+/** The launch of one width group of the bit-parallel kernels: `words` of the kernel that takes it (>= the group's variant:
+ *  patterns are right-aligned over phantom low rows, so a wider kernel scores a narrower query exactly) and `lanes` per pair
+ *  (0: one lane per pair, the long kernels).
+ *
+ *  24 ... 64 words always spread a pair over lanes (hip/lev_myers.hip: levenshtein_myers_split_kernel): 2 when the launch
+ *  fills the device anyway, 4 under 1024 workgroups, 8 under 256 - its longest pairs ARE its duration.  16 and 20 words join
+ *  them only in a launch of fewer than 256 workgroups (round 3): an eighth of config 5 on each of eight GPUs is nine launches
+ *  of ~200 workgroups, and the 20-word one - 2048 columns x 20 words x 10.5 instructions in ONE lane, 1.4 ms however idle
+ *  the chip - ended the call at 2.0 ms for 1.2 ms of work (profiles/r03/timeline_cfg5_eighth_v1.txt).  Ten words per lane
+ *  are not whole 16-byte Peq chunks: 20 words run as 24 over two lanes.  The `split` knob pins 0 / 2 / 4 / 8. */
+szs_launch_shape_t szs_plan_myers_shape(int knob, unsigned variant, uint64_t workgroups_unsplit, int runes) {
+    szs_launch_shape_t shape = {variant, 0};
+    if (knob == 0 || variant < 16 || variant == SZS_MYERS_SHORT_WORDS) return shape;
+    int const pinned = knob == 2 || knob == 4 || knob == 8;
+    unsigned lanes = pinned ? (unsigned)knob : workgroups_unsplit < 256 ? 8u : workgroups_unsplit < 1024 ? 4u : 2u;
+    if (variant < 24) {
+        if (!pinned && workgroups_unsplit >= 256) return shape;
+        if (runes) return shape; /* codepoints: measured slower (real-text lines 50.9 against 55.7 T cells/s, an eighth of config 5u 1.88 / 1.85 ms) */
+        if (variant == 20) shape.words = 24;
+        else lanes = pinned && lanes >= 4 ? 4u : 2u; /* eight words per lane are as short as the other launches' pairs */
+    }
+    if (shape.words == 24 && lanes >= 4) lanes = 2;
+    if (shape.words == 48 && lanes == 8) lanes = 4; /* six words per lane are not whole chunks either */
+    if (runes) {
+        if (lanes == 8) lanes = 4; /* the rune kernels are instantiated for two and four lanes */
+        /* 48 and 64 words always over four lanes: their rune table leaves room for one workgroup per CU, and only the split
+         * kernel puts more than one wavefront per SIMD behind it (lev_myers.hip) */
+        if (!pinned && variant >= 48) lanes = 4;
+    }
+    shape.lanes = lanes;
+    return shape;
+}
+
+/** Every width group's launch shape, and the order the launches go out in: LONGEST PAIR FIRST.  What a launch cannot go
+ *  under is its longest pair - columns x words PER LANE, one dependent instruction after the other - and the first launch
+ *  submitted takes every free wavefront slot: the widest group (64 words over eight lanes: many workgroups, short pairs)
+ *  used to go first and the 20-word launch - one lane per pair, the longest pairs of all - got its first wavefront 0.4 ms
+ *  into a 2 ms call.  Groups that need the workspace (variant 0) keep their place at the front, in order; the short launch
+ *  goes last, behind the lightest long one on its stream (dispatch.c: enqueue). */
+void szs_plan_launch_order(szs_plan_t const *plan, int use_myers, int runes, uint64_t candidate_blocks, int split_knob,
+                           szs_launch_shape_t *shapes, unsigned *order) {
+    unsigned urgency[SZS_PLAN_MAX_GROUPS];
+    for (unsigned g = 0; g < plan->groups_count; ++g) {
+        szs_plan_group_t const *group = &plan->groups[g];
+        shapes[g] = szs_plan_myers_shape(use_myers ? split_knob : 0, group->variant, (uint64_t)group->count * candidate_blocks, runes);
+        urgency[g] = group->variant == 0 ? ~0u : group->variant == SZS_MYERS_SHORT_WORDS ? 0u : shapes[g].words / (shapes[g].lanes ? shapes[g].lanes : 1u);
+        unsigned at = g;
+        for (; at > 0 && urgency[order[at - 1]] < urgency[g]; --at) order[at] = order[at - 1]; /* stable: ties stay widest first */
+        order[at] = g;
+    }
+}
+
+sz_status_t szs_rocm_launch_order_probe(int runes, sz_u32_t const *query_lengths, sz_size_t queries_count, sz_size_t candidates_count,
+                                        sz_u32_t *variants, sz_u32_t *words, sz_u32_t *lanes, sz_size_t capacity, sz_size_t *launches) {
+    if (queries_count > 0xFFFFFFFFu || candidates_count > 0xFFFFFFFFu || !launches) return sz_overflow_risk_k;
+    szs_side_stats_t stats;
+    uint32_t variant_counts[SZS_PLAN_VARIANTS];
+    szs_side_stats(query_lengths, (uint32_t)queries_count, SZS_MYERS_MAX_WORDS, &stats, variant_counts);
+    szs_plan_t plan;
+    memset(&plan, 0, sizeof(plan));
+    szs_plan_groups(variant_counts, &plan);
+    szs_launch_shape_t shapes[SZS_PLAN_MAX_GROUPS];
+    unsigned order[SZS_PLAN_MAX_GROUPS];
+    uint64_t const candidate_blocks = ((uint64_t)candidates_count + SZS_CANDIDATES_PER_WORKGROUP - 1) / SZS_CANDIDATES_PER_WORKGROUP;
+    szs_plan_launch_order(&plan, 1, runes, candidate_blocks, szs_tuning_get(szs_knob_split_k), shapes, order);
+    *launches = plan.groups_count;
+    for (unsigned turn = 0; turn < plan.groups_count && turn < capacity; ++turn) {
+        if (variants) variants[turn] = plan.groups[order[turn]].variant;
+        if (words) words[turn] = shapes[order[turn]].words;
+        if (lanes) lanes[turn] = shapes[order[turn]].lanes;
+    }
     return sz_success_k;
 }
 

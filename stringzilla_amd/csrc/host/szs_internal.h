@@ -236,6 +236,15 @@ void szs_side_stats(uint32_t const *lengths, uint32_t count, unsigned myers, szs
 /** Launch groups of queries sorted longest first, from their per-variant counts (hip/kernels.h: SZS_PLAN_VARIANTS). */
 void szs_plan_groups(uint32_t const *variant_counts, szs_plan_t *plan);
 
+/** The launch of one width group of the bit-parallel kernels (plan.c): the kernel's words (>= the group's variant) and the
+ *  lanes per pair (0: one lane per pair), and the order the groups' launches leave the host in. */
+typedef struct szs_launch_shape_t {
+    unsigned words, lanes;
+} szs_launch_shape_t;
+szs_launch_shape_t szs_plan_myers_shape(int knob, unsigned variant, uint64_t workgroups_unsplit, int runes);
+void szs_plan_launch_order(szs_plan_t const *plan, int use_myers, int runes, uint64_t candidate_blocks, int split_knob,
+                           szs_launch_shape_t *shapes, unsigned *order);
+
 #define SZS_TIER_LANES 0    /* one pair per lane: lev_myers.hip, weighted.hip */
 #define SZS_TIER_SYSTOLIC 1 /* one pair per chain of wavefronts: systolic.hip */
 #define SZS_TIER_MYERS_CHAIN 2 /* the same chain with the bit-parallel recurrence: myers_chain.hip (unit-cost bytes) */

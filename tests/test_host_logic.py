@@ -156,6 +156,36 @@ def test_planner_deals_lanes_to_the_team_tier():
     assert (tier, transposed) == (0, 1) and lanes == 4                       # eight candidates: turned on its side
 
 
+def _launch_order(lengths, candidates, runes=0):
+    lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+    variants, words, lanes = (np.zeros(24, dtype=np.uint32) for _ in range(3))
+    launches = ctypes.c_size_t()
+    status = _abi.lib.szs_rocm_launch_order_probe(runes, lengths.ctypes.data, lengths.size, candidates, variants.ctypes.data, words.ctypes.data,
+                                                  lanes.ctypes.data, 24, ctypes.byref(launches))
+    assert status == 0
+    n = launches.value
+    return [(int(variants[i]), int(words[i]), int(lanes[i])) for i in range(n)]
+
+
+def test_launches_leave_longest_pair_first():
+    """Round 3 (csrc/host/plan.c: szs_plan_launch_order): the width groups of a mixed-length unit-cost batch are launched by
+    words PER LANE, most first, the short launch last; a launch of a few workgroups spreads its pairs over more lanes - and 16
+    / 20 words join the split kernels there (bytes only), 20 words running in the 24-word kernel."""
+    one_per_variant = [100, 300, 380, 500, 600, 700, 1000, 1500, 2000]   # variants 8, 10, 12, 16, 20, 24, 32, 48, 64
+    # a launch that fills the device: 256 queries per width x 16 candidate blocks = 4096 workgroups -> two lanes, narrow widths whole
+    full = _launch_order(np.repeat(one_per_variant, 256), 4096)
+    assert full == [(64, 64, 2), (48, 48, 2), (20, 20, 0), (32, 32, 2), (16, 16, 0), (24, 24, 2), (12, 12, 0), (10, 10, 0), (8, 8, 0)]
+    # an eighth of such a batch: 8 queries per width x 16 blocks = 128 workgroups -> eight / four lanes, 16 and 20 words over two
+    eighth = _launch_order(np.repeat(one_per_variant, 8), 4096)
+    assert eighth == [(48, 48, 4), (24, 24, 2), (20, 24, 2), (12, 12, 0), (10, 10, 0), (64, 64, 8), (16, 16, 2), (32, 32, 8), (8, 8, 0)]
+    # codepoints: the rune kernels take two or four lanes, and the narrow widths stay whole (measured slower split)
+    runes = _launch_order(np.repeat(one_per_variant, 8), 4096, runes=1)
+    assert runes == [(20, 20, 0), (64, 64, 4), (16, 16, 0), (48, 48, 4), (24, 24, 2), (12, 12, 0), (10, 10, 0), (32, 32, 4), (8, 8, 0)]
+    # queries beyond the bit-parallel widths (variant 0) keep the front: they share the strip workspace on the scope's stream
+    assert _launch_order([5000, 3000, 100, 700], 300)[0][0] == 0
+    assert _launch_order([100] * 50, 1000) == [(8, 8, 0)]
+
+
 def test_planner_picks_tier_and_orientation():
     """The cycle model of csrc/host/plan.c: BASELINE.json's big cross-products stay one-pair-per-lane, a handful of long
     pairs go to the systolic tier, and a tall-and-thin cross-product is turned on its side."""
