@@ -1536,7 +1536,7 @@ extern "C" int szs_hip_levenshtein_myers_split(unsigned words, unsigned lanes, s
 #define SZS_SPLIT_CASE(W, L)                                                                                           \
     if (words == W && lanes == L)                                                                                      \
         return launch_myers_split<W / L, L>(queries, queries_count, candidates, candidates_count, results, results_row_stride, symmetric, guard, s);
-    SZS_SPLIT_CASE(16, 2) /* 16 words: only in launches of a few workgroups (host/dispatch.c: myers_shape_of) */
+    SZS_SPLIT_CASE(16, 2) /* 16 words: only in launches of a few workgroups (host/plan.c: szs_plan_myers_shape) */
     SZS_SPLIT_CASE(16, 4)
     SZS_SPLIT_CASE(24, 2)
     SZS_SPLIT_CASE(32, 2)
