@@ -225,19 +225,23 @@ template <typename costs_t, int R>
 struct team_step_t {
     static constexpr bool local_ = costs_t::local, affine_ = costs_t::affine, wide_ = costs_t::wide;
     using order = typename costs_t::order;
-    u32 diag, up; // H of the row above at the previous column; affine: F entering the row, linear: H + gap of the row above
+    u32 entering; // the substitution branch of the row about to be scored: H of the row above at the previous column + its cost
+    u32 up;       // affine: F entering the row, linear: H + gap of the row above
     u32 pending;  // local, narrow order: the cell of the even row, waiting for its odd neighbour
     u32 bottom;   // what the last row scored hands down as `h`
 
-    SZS_HD void begin(team_edge_t const &above, u32 &diagonal) {
-        diag = diagonal, diagonal = above.h;
+    SZS_HD void begin(team_edge_t const &above, u32 &diagonal, u32 first_cost) {
+        entering = diagonal + first_cost, diagonal = above.h;
         up = affine_ ? above.f : above.h;
         pending = 0, bottom = 0;
     }
-    /** Row `r`: serial.hpp:1091-1102, 1238-1239 (affine), 846-848, 957-965 (linear). */
-    SZS_HD void row(costs_t const &k, team_rows_t<affine_, R> &rows, int r, u32 cost, u32 (&best)[4]) {
-        u32 const substituted = diag + cost; // linear: (H(row - 1, column - 1) + gap) + (cost - gap)
-        diag = rows.h[r];
+    /** Row `r`: serial.hpp:1091-1102, 1238-1239 (affine), 846-848, 957-965 (linear).  `next_cost` is the cost of row r + 1
+     *  (anything for the last row): the NEXT row's substitution branch is formed here, from this row's H of the previous
+     *  column, before that register is overwritten - kept for the next row instead (round 3's first version), every row cost
+     *  a `v_mov_b32`: 42 of the 146 VALU instructions of a linear step. */
+    SZS_HD void row(costs_t const &k, team_rows_t<affine_, R> &rows, int r, u32 next_cost, u32 (&best)[4]) {
+        u32 const substituted = entering; // linear: (H(row - 1, column - 1) + gap) + (cost - gap)
+        if (r + 1 < R) entering = rows.h[r] + next_cost;
         u32 const across = affine_ ? rows.e[affine_ ? r : 0] : rows.h[r]; // the horizontal branch: E, or left + gap
         u32 cell;
         if (local_) {
@@ -275,8 +279,8 @@ template <typename costs_t, int R>
 SZS_HD team_edge_t team_advance(costs_t const &k, team_rows_t<costs_t::affine, R> &rows, u32 const *costs, team_edge_t above,
                                 u32 &diagonal, u32 (&best)[4], u32 registers) {
     team_step_t<costs_t, R> step;
-    step.begin(above, diagonal);
-    for (u32 r = 0; r < registers; ++r) step.row(k, rows, (int)r, costs[r], best);
+    step.begin(above, diagonal, costs[0]);
+    for (u32 r = 0; r < registers; ++r) step.row(k, rows, (int)r, r + 1 < registers ? costs[r + 1] : 0u, best);
     return step.end();
 }
 

@@ -249,17 +249,20 @@ __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
                 constexpr bool whole_ = decltype(whole)::value;
                 uint4 const *const row = reinterpret_cast<uint4 const *>(profile + strip_base + in_row);
                 team_step_t<costs_t, R> step;
-                step.begin(in, diagonal);
                 uint4 next = row[0];
+                step.begin(in, diagonal, next.x);
 #pragma unroll
                 for (int chunk = 0; chunk < R / 4; ++chunk) {
                     // one way OUT per chunk, not a way AROUND it: the rows of a skipped chunk then need no copies to meet
                     // the rows of a scored one again (a guard around every chunk cost ten v_mov per four rows)
                     if (!whole_ && (u32)chunk >= chunks_now) break;
                     uint4 const now = next;
-                    if (chunk + 1 < R / 4) next = row[chunk + 1]; // one chunk past the last one of a short pass: inside the profile, unused
-                    step.row(k, rows, 4 * chunk + 0, now.x, best), step.row(k, rows, 4 * chunk + 1, now.y, best);
-                    step.row(k, rows, 4 * chunk + 2, now.z, best), step.row(k, rows, 4 * chunk + 3, now.w, best);
+                    // one chunk past the last one of a short pass: inside the profile, unused.  (TWO chunks ahead measured the
+                    // same within a percent - 14.27 / 525 ms against 14.10 / 529 on configs 3 / 4: it is not the LDS round trip.)
+                    if (chunk + 1 < R / 4) next = row[chunk + 1];
+                    // (a row is handed the cost of the row BELOW it: team_step_t::row)
+                    step.row(k, rows, 4 * chunk + 0, now.y, best), step.row(k, rows, 4 * chunk + 1, now.z, best);
+                    step.row(k, rows, 4 * chunk + 2, now.w, best), step.row(k, rows, 4 * chunk + 3, next.x, best);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 out = step.end();
