@@ -245,11 +245,16 @@ __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
             // a chunk: left alone, hipcc hoists every read of all four steps of a batch (4 R registers) above the first row.
             // `whole` passes take all R registers without a question; the last pass of a pair (fewer rows per lane) asks a
             // wavefront-uniform question per chunk - measured 14 % slower per step, so it gets its own copy of the loops.
-            auto advance = [&](auto whole, team_edge_t const &in, u32 in_row) {
-                constexpr bool whole_ = decltype(whole)::value;
+            // `opening`: in the main loop a lane knows its row of the NEXT step when this one begins (it is its left neighbour's
+            // row of this step), so the first chunk of every step is fetched a whole step early (`row_after` -> `opening`); a
+            // predicated step fetches its own.
+            uint4 opening = make_uint4(0, 0, 0, 0);
+            auto advance = [&](auto whole, auto pipelined, team_edge_t const &in, u32 in_row, u32 row_after) {
+                constexpr bool whole_ = decltype(whole)::value, pipelined_ = decltype(pipelined)::value;
                 uint4 const *const row = reinterpret_cast<uint4 const *>(profile + strip_base + in_row);
                 team_step_t<costs_t, R> step;
-                uint4 next = row[0];
+                uint4 next = pipelined_ ? opening : row[0];
+                if constexpr (pipelined_) opening = *reinterpret_cast<uint4 const *>(profile + strip_base + row_after);
                 step.begin(in, diagonal, next.x);
 #pragma unroll
                 for (int chunk = 0; chunk < R / 4; ++chunk) {
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
                 hand_over(head_edge, head_row, in, in_row);
                 u32 const column = head_column - lane_in_team; // wraps for a lane that has not started
                 if (column - 1 < text_length) {
-                    advance(whole, in, in_row);
+                    advance(whole, std::false_type {}, in, in_row, 0u);
                     if (is_tail && park_this_pass) parked[(u64)column * teams] = park_of<affine_>(out);
                 }
             };
@@ -303,7 +308,10 @@ __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
                     for (int s = 0; s < 4; ++s) ahead[s] = parked[(u64)(t + 1 + s) * teams];
                     u32 bytes_now = text.splice(raw_low, raw_high);
                     raw_low = raw_high, raw_high = text.raw_clamped(dword + 2);
-                    u32 row_next = class_offset_of_byte[bytes_now & 0xFFu]; // looked up one STEP early
+                    // rows travel one step AHEAD of the cells: this lane's row of the first step of the loop ...
+                    u32 my_row = from_left<L>(class_offset_of_byte[bytes_now & 0xFFu], out_row, is_head);
+                    opening = *reinterpret_cast<uint4 const *>(profile + strip_base + my_row);
+                    u32 head_row_after = class_offset_of_byte[(bytes_now >> 8) & 0xFFu]; // ... the head's of the step after, looked up two steps early
 #pragma unroll 1
                     for (; t + 4 <= shortest_in_wave; t += 4, ++dword) {
                         // the text of the NEXT batch, one batch early (clamped reads: never past the string)
@@ -313,12 +321,13 @@ __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
                         for (int s = 0; s < 4; ++s) {
                             team_edge_t const head_edge = unpark<affine_>(ahead[s]);
                             ahead[s] = parked[(u64)(t + 5 + s) * teams]; // the slack columns make the overrun harmless
-                            u32 const head_row = row_next;
-                            row_next = class_offset_of_byte[(s < 3 ? bytes_now >> (8 * (s + 1)) : bytes_ahead) & 0xFFu];
+                            u32 const my_row_after = from_left<L>(head_row_after, my_row, is_head);
+                            head_row_after = class_offset_of_byte[(s < 2 ? bytes_now >> (8 * (s + 2)) : bytes_ahead >> (8 * (s - 2))) & 0xFFu];
                             team_edge_t in;
-                            u32 in_row;
-                            hand_over(head_edge, head_row, in, in_row);
-                            advance(whole, in, in_row);
+                            in.h = from_left<L>(head_edge.h, out.h, is_head);
+                            in.f = affine_ ? from_left<L>(head_edge.f, out.f, is_head) : 0u;
+                            advance(whole, std::true_type {}, in, my_row, my_row_after);
+                            my_row = my_row_after;
                             // the tail's column of step t + s is t + s + 2 - L >= 1: L - 1 <= fill <= t
                             if (park_this_pass && is_tail) parked[(u64)(t + s + 2 - L) * teams] = park_of<affine_>(out);
                         }
