@@ -615,7 +615,9 @@ static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int dev
                                                                      device_stride, d->layout, d->alphabet, target)
                                : shape.lanes ? szs_hip_levenshtein_myers_runes_split(shape.words, shape.lanes, queries, count, candidate_refs, d->kc_count,
                                                                                (uint64_t *)device_results, device_stride, d->layout, d->alphabet,
-                                                                               (uint64_t)group->count * candidate_blocks < 256 ? 64u : 256u, target)
+                                                                               (uint64_t)group->count * candidate_blocks < 1024 ? 64u : 256u /* measured: an eighth of config
+                                                                               5u 2.01 -> 1.72 ms, a quarter 2.77 -> 2.36, the whole unchanged; under
+                                                                               4096 the whole of it loses 12 % */, target)
                                        : szs_hip_levenshtein_myers_runes_long(group->variant, queries, count, candidate_refs, d->kc_count,
                                                                               (uint64_t *)device_results, device_stride, d->layout, d->alphabet, target);
                 if (launch_error == (int)hipErrorNotSupported) { /* no LDS for the rune table: the rune-keyed DP kernel, whose
