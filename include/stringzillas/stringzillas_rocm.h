@@ -7,7 +7,11 @@
  *    (/root/reference/include/stringzillas/types.cuh:280-298,482-534; bench/similarities.cuh:303-308).
  *  - szs_rocm_shard_rows        : longest-processing-time assignment of query rows to N GPUs;
  *    the reference has no multi-GPU path at all (one engine call = one device, stringzillas.h:137).
- *  - szs_rocm_plan_probe, szs_rocm_orientation_probe : expose the host planner so it can be unit-tested without a GPU.
+ *  - szs_rocm_plan_probe, szs_rocm_orientation_probe, szs_rocm_team_orientation_probe, szs_rocm_launch_order_probe : expose
+ *    the host planner - refs, tier and orientation, lanes per item, launch shapes and order - so that it is unit-tested
+ *    without a GPU (tests/test_host_logic.py).
+ *  - szs_rocm_node_*            : one cross-product over the N GPUs of a host, in C (csrc/host/node.c).
+ *  - szs_rocm_tuning_set        : the tuning / testing knobs.
  */
 #ifndef STRINGZILLAS_ROCM_H_
 #define STRINGZILLAS_ROCM_H_
