@@ -24,8 +24,11 @@ args = parser.parse_args()
 
 gpu = szs.DeviceScope(gpu_device=0)
 load = workloads.config(args.config, scale=args.scale)
-cls = szs.NeedlemanWunschScores if load.kind == "needleman_wunsch" else szs.SmithWatermanScores
-engine = cls(*matrices.by_name(load.table), **load.costs, capabilities=gpu)
+if load.kind == "levenshtein":  # configs 7 / 8: non-unit costs, the team tier's `distance` objective
+    engine = szs.LevenshteinDistances(**load.costs, capabilities=gpu)
+else:
+    cls = szs.NeedlemanWunschScores if load.kind == "needleman_wunsch" else szs.SmithWatermanScores
+    engine = cls(*matrices.by_name(load.table), **load.costs, capabilities=gpu)
 import numpy as np
 from stringzilla_amd import sharded
 shard_of_row, _ = sharded.shard_rows(load.queries.lengths(), args.shards)

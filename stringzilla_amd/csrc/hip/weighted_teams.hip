@@ -438,7 +438,7 @@ static u64 team_work_items(u32 queries_count, u32 candidates_count) {
 
 /* The instances that are compiled: (lanes per team, registers per track, wavefronts per SIMD), each in both orders. */
 #ifndef SZS_TEAM_SHAPES
-#define SZS_TEAM_SHAPES(CALL) CALL(16, 32, 2) CALL(16, 16, 4) CALL(4, 32, 2)
+#define SZS_TEAM_SHAPES(CALL) CALL(16, 32, 2) CALL(16, 16, 4) CALL(4, 32, 2) CALL(4, 16, 4)
 #endif
 
 /* `objective`: 0 global (Needleman-Wunsch), 1 local (Smith-Waterman, gaps <= 0), 2 distance (Levenshtein, uniform costs). */

@@ -306,10 +306,22 @@ static unsigned team_shape_for(int affine, uint32_t classes, szs_side_stats_t co
     if (knob == 0) return 0;
     if (knob > 0) return szs_hip_weighted_team_has_shape((unsigned)knob) && szs_hip_weighted_team_fits((unsigned)knob, classes) ? (unsigned)knob : 0;
     unsigned lanes = szs_plan_team_lanes(affine, queries, candidates);
-    for (; lanes; lanes = lanes > 4 ? 4 : 0) /* sixteen strips of a rich alphabet (text: ~95 classes) do not fit a CU's LDS: four do */
-        for (unsigned index = 0; szs_hip_weighted_team_shape(index); ++index) /* the first compiled instance of that width */
-            if (szs_hip_weighted_team_shape(index) / 10000u == lanes && szs_hip_weighted_team_fits(szs_hip_weighted_team_shape(index), classes))
-                return szs_hip_weighted_team_shape(index);
+    for (; lanes; lanes = lanes > 4 ? 4 : 0) { /* sixteen strips of a rich alphabet (text: ~95 classes) do not fit a CU's LDS: four do */
+        /* Rows per lane: 16 (four wavefronts per SIMD, half the profile) when the longest query fits ONE pass of that shape
+         * anyway - 4 x 16 rows: +17 ... 20 % at 24 ... 48 rows; 16 x 16: +4 ... 21 % at 192 ... 256 - or when the alphabet is
+         * rich: four strips of 95 classes are 55 KB at 32 rows, two workgroups per CU (non-unit Levenshtein costs over text:
+         * 12.3 -> 15.3 TCUPS at 16).  Else 32: half the passes over the candidates.  (team_sweep_v2.jsonl) */
+        unsigned const short_rows = lanes == 4 ? 80u : affine ? 240u : 320u;
+        unsigned const wanted_registers = queries->longest <= short_rows || (lanes == 4 && classes > 48) ? 16u : 32u;
+        unsigned fallback = 0;
+        for (unsigned index = 0; szs_hip_weighted_team_shape(index); ++index) {
+            unsigned const shape = szs_hip_weighted_team_shape(index);
+            if (shape / 10000u != lanes || !szs_hip_weighted_team_fits(shape, classes)) continue;
+            if (shape / 100u % 100u == wanted_registers) return shape;
+            if (!fallback) fallback = shape; /* the first compiled instance of that width */
+        }
+        if (fallback) return fallback;
+    }
     return 0;
 }
 

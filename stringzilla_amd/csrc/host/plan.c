@@ -147,8 +147,11 @@ unsigned szs_plan_team_lanes(int affine, szs_side_stats_t const *queries, szs_si
     if (!queries->count || !candidates->count) return 0;
     double const mean_query = (double)queries->symbols / queries->count, mean_candidate = (double)candidates->symbols / candidates->count;
     double const items = (double)((queries->count + 1) / 2) * candidates->count; /* (pair of queries, candidate) */
-    if (mean_query < (affine ? 48 : 96)) return 0; /* a few rows per lane: the step's fixed cost takes over */
-    if (mean_query >= 384 && mean_candidate >= 128) return 16;
+    /* profiles/r03/team_sweep_v2.jsonl (query rows 24 ... 512 x candidate columns 128 / 512, every compiled shape):
+     * four lanes beat one pair per lane from 24 rows (linear: +8 % there, +50 % at 48) / 40 rows (affine) up; sixteen lanes pay
+     * their fifteen fill and drain steps back only over candidates of a few hundred columns, from ~190 query rows. */
+    if (mean_query < (affine ? 40 : 24)) return 0; /* a few rows per lane: the step's fixed cost takes over */
+    if (mean_query >= 192 && mean_candidate >= 256) return 16;
     if (items * 4 / 64 < 4096 && mean_query >= 128) return 16; /* four lanes per item would leave SIMDs short of wavefronts */
     return 4;
 }

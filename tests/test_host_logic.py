@@ -151,7 +151,9 @@ def test_planner_deals_lanes_to_the_team_tier():
     assert _team_orientation(1, [4096] * 512, [4096] * 512) == (0, 0, 16)   # config 4
     assert _team_orientation(1, [4096] * 64, [4096] * 512) == (0, 0, 16)    # an eighth of config 4 stays on the lanes
     assert _team_orientation(0, [128] * 1024, [128] * 1024) == (0, 0, 4)
-    assert _team_orientation(0, [40] * 1024, [300] * 1024)[2] == 0
+    assert _team_orientation(0, [40] * 1024, [300] * 1024)[2] == 4           # round 3's second sweep: four lanes pay from 24 rows
+    assert _team_orientation(0, [16] * 1024, [300] * 1024)[2] == 0 and _team_orientation(1, [32] * 1024, [300] * 1024)[2] == 0
+    assert _team_orientation(0, [256] * 512, [600] * 512)[2] == 16 and _team_orientation(0, [512] * 512, [128] * 512)[2] == 4
     tier, transposed, lanes = _team_orientation(0, [128] * 32768, [128] * 8)
     assert (tier, transposed) == (0, 1) and lanes == 4                       # eight candidates: turned on its side
 
