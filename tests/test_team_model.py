@@ -59,7 +59,7 @@ def random_table(rng, classes=9):
     return byte_to_class, table
 
 
-SHAPES = [(16, 32), (16, 16), (16, 24), (8, 32), (4, 32), (4, 8), (2, 16), (1, 32), (1, 4)]
+SHAPES = [(16, 32), (16, 16), (16, 24), (8, 32), (4, 32), (4, 16), (4, 8), (2, 16), (1, 32), (1, 4)]
 
 
 @pytest.mark.parametrize("lanes,registers", SHAPES)
