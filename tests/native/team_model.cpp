@@ -177,7 +177,7 @@ void cross(text_t const *queries, uint32_t queries_count, text_t const *candidat
 
 } // namespace
 
-#define TEAM_SHAPES(CALL) CALL(16, 32) CALL(16, 16) CALL(16, 24) CALL(8, 32) CALL(4, 32) CALL(4, 8) CALL(2, 16) CALL(1, 32) CALL(1, 4)
+#define TEAM_SHAPES(CALL) CALL(16, 32) CALL(16, 16) CALL(16, 24) CALL(8, 32) CALL(4, 32) CALL(4, 16) CALL(4, 8) CALL(2, 16) CALL(1, 32) CALL(1, 4)
 
 /** Tapes with count + 1 64-bit offsets; results[q * stride + c].  `wide`: cells ordered as unsigned integers (two-input maxima)
  *  instead of as half-float patterns.  `local` = 2: a DISTANCE engine - the caller passes negated costs (a 256-class identity map
