@@ -7,7 +7,8 @@
  *    (/root/reference/include/stringzillas/types.cuh:280-298,482-534; bench/similarities.cuh:303-308).
  *  - szs_rocm_shard_rows        : longest-processing-time assignment of query rows to N GPUs;
  *    the reference has no multi-GPU path at all (one engine call = one device, stringzillas.h:137).
- *  - szs_rocm_plan_probe, szs_rocm_orientation_probe, szs_rocm_team_orientation_probe, szs_rocm_launch_order_probe : expose
+ *  - szs_rocm_plan_probe, szs_rocm_orientation_probe, szs_rocm_team_orientation_probe, szs_rocm_launch_order_probe,
+ *    szs_rocm_queue_probe : expose
  *    the host planner - refs, tier and orientation, lanes per item, launch shapes and order - so that it is unit-tested
  *    without a GPU (tests/test_host_logic.py).
  *  - szs_rocm_node_*            : one cross-product over the N GPUs of a host, in C (csrc/host/node.c).
@@ -40,6 +41,8 @@ typedef struct szs_rocm_call_profile_t {
     sz_u32_t team;                /* 0, or lanes * 10000 + registers * 100 + wavefronts per SIMD of the team tier (weighted_teams.hip) */
     sz_u32_t team_wide;           /* team tier: 0 cells ordered as half-float patterns (three-input maxima), 1 as unsigned integers */
     sz_u32_t streams;             /* streams the launches of the call were dealt over: 1 ... 8, never more than the `queues` knob */
+    sz_u32_t queue_items;         /* 0, or the work items of the ONE persistent launch that scored every bit-parallel width of the call (myers_queue.hip) */
+    sz_u32_t queue_tiles;         /* ... and the (query slice) x (candidate column) tiles its queue was ordered by */
 } szs_rocm_call_profile_t;
 
 /** Copies the profile of the most recent call made through `engine` (any of the four engine handle types). */
@@ -96,6 +99,18 @@ SZ_API_RUNTIME sz_status_t szs_rocm_team_orientation_probe(int affine, int symme
 SZ_API_RUNTIME sz_status_t szs_rocm_launch_order_probe(int runes, sz_u32_t const *query_lengths, sz_size_t queries_count,
                                                        sz_size_t candidates_count, sz_u32_t *variants, sz_u32_t *words, sz_u32_t *lanes,
                                                        sz_size_t capacity, sz_size_t *launches);
+
+/**
+ *  The work queue of the ONE persistent launch that scores every bit-vector width of a unit-cost byte call
+ *  (hip/myers_queue.hip; host/plan.c: szs_plan_queue), planned from bare length arrays - no GPU involved.  Queries are taken
+ *  longest first, candidates shortest first (szs_rocm_plan_probe gives both orders).  `tiles` receives 8 values per tile, in
+ *  queue order: items of all tiles before it, first query and queries of its slice, first and one-past-last candidate of its
+ *  column, candidates per work item, words per lane (0: the query's own width on one lane) and lanes per pair.  Work item j
+ *  of a tile scores query `first + j % queries` against the candidates of block `j / queries`, blocks cut from the column's end.
+ */
+SZ_API_RUNTIME sz_status_t szs_rocm_queue_probe(int symmetric, sz_u32_t const *query_lengths, sz_size_t queries_count,
+                                                sz_u32_t const *candidate_lengths, sz_size_t candidates_count, sz_u32_t *tiles,
+                                                sz_size_t capacity, sz_size_t *tiles_count, sz_u64_t *items_total);
 
 /* ---- one cross-product over the N GPUs of a host (csrc/host/node.c) ------------------------------
  *
@@ -167,6 +182,9 @@ SZ_API_RUNTIME sz_status_t szs_rocm_node_scores_u64tape(szs_rocm_node_engine_t e
  *  "split" (0 | 2 | 4 | 8: lanes per pair of the bit-parallel widths of 16 words and more), "alphabet" (0 | 1: never / always renumber the runes
  *  of a codepoint batch on the device), "merge" (n: candidate blocks per workgroup of the short bit-parallel kernels),
  *  "team" (0: never | lanes * 10000 + registers * 100 + waves: that shape of the team tier of the 16-bit weighted scorers),
+ *  "queue" (0: never | 1: every unit-cost byte call - the one persistent launch of hip/myers_queue.hip; automatic: calls of two or
+ *  more bit-vector widths), "queue_words" (4 | 8 | 12 | 16: the most words of a pattern one lane holds there), "queue_rounds" (n:
+ *  candidates per work item in rounds of eight wavefronts),
  *  "queues" (see below), "roctx" (1: the host phases of every call - plan, decide, enqueue, wait - as roctx ranges for a
  *  `rocprofv3 --marker-trace` timeline; the marker library is looked up at run time, never linked),
  *  "cpu_requests" (strict | gpu: serve capability

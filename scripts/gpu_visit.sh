@@ -32,6 +32,9 @@ for step in "$@"; do
     previews)   for config in 3 4 5 6; do timeout 300 python scripts/measure_shard_of.py --config $config --shards 1,2,4,8; done > "$OUT/shard_preview.jsonl" 2> "$OUT/shard_preview.err"; cat "$OUT/shard_preview.jsonl";;
     bench20)    timeout 600 python bench.py --steps 20 --warmup 5 > "$OUT/bench_20.json" 2> "$OUT/bench_20.err"; tail -c 1500 "$OUT/bench_20.json"; tail -3 "$OUT/bench_20.err";;
     pmc)        timeout 1500 bash scripts/profile_configs.sh $TAG/pmc 2 3 4 5 6 7 8 > "$OUT/pmc.log" 2>&1; tail -5 "$OUT/pmc.log";;
+    queue-tests) timeout 1200 python -m pytest tests/test_gpu_round4.py -m gpu -q -x --durations=5 > "$OUT/queue_tests.log" 2>&1; echo "exit $?" >> "$OUT/queue_tests.log"; tail -40 "$OUT/queue_tests.log";;
+    lev-tests)  timeout 1200 python -m pytest tests/test_gpu_parity.py -m gpu -q --maxfail=5 -k "levenshtein or config or known or golden or cross_product or symmetric or closed or input_formats or callback" --durations=5 > "$OUT/lev_tests.log" 2>&1; echo "exit $?" >> "$OUT/lev_tests.log"; tail -30 "$OUT/lev_tests.log";;
+    queue5)     timeout 600 python scripts/measure_queue.py --config 5 --shards 1,8 > "$OUT/queue_cfg5.jsonl" 2> "$OUT/queue_cfg5.err"; cat "$OUT/queue_cfg5.jsonl"; tail -3 "$OUT/queue_cfg5.err";;
     *) echo "unknown step $step";;
   esac
 done

@@ -55,6 +55,7 @@ class CallProfile(ctypes.Structure):
         ("unique_bytes", ctypes.c_uint64), ("launches", ctypes.c_uint32), ("longest_query", ctypes.c_uint32),
         ("longest_candidate", ctypes.c_uint32), ("tier", ctypes.c_uint32), ("transposed", ctypes.c_uint32), ("cell_bits", ctypes.c_uint32),
         ("planner", ctypes.c_uint32), ("team", ctypes.c_uint32), ("team_wide", ctypes.c_uint32), ("streams", ctypes.c_uint32),
+        ("queue_items", ctypes.c_uint32), ("queue_tiles", ctypes.c_uint32),
     ]
 
 
@@ -113,6 +114,7 @@ SIGNATURES = {
     "szs_rocm_orientation_probe": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p]),
     "szs_rocm_team_orientation_probe": (c_int, [c_int, c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "szs_rocm_launch_order_probe": (c_int, [c_int, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "szs_rocm_queue_probe": (c_int, [c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p]),
     "szs_rocm_tuning_set": (c_int, [c_char_p, c_char_p]),
     "szs_rocm_team_shape": (ctypes.c_uint32, [c_size_t]),
     "szs_rocm_node_init": (c_int, [c_void_p, c_size_t, ENGINE_OUT, ERR]),
@@ -162,7 +164,8 @@ _KNOBS = {"tier": "SZS_ROCM_TIER", "swap": "SZS_ROCM_SWAP", "packed": "SZS_ROCM_
           "planner": "SZS_ROCM_PLANNER", "speculate": "SZS_ROCM_SPECULATE", "cpu_requests": "SZS_ROCM_CPU_REQUESTS",
           "streams": "SZS_ROCM_STREAMS", "reuse": "SZS_ROCM_REUSE",
           "split": "SZS_ROCM_SPLIT", "alphabet": "SZS_ROCM_ALPHABET", "merge": "SZS_ROCM_MERGE",
-          "team": "SZS_ROCM_TEAM", "queues": "SZS_ROCM_QUEUES", "roctx": "SZS_ROCM_ROCTX"}
+          "team": "SZS_ROCM_TEAM", "queues": "SZS_ROCM_QUEUES", "roctx": "SZS_ROCM_ROCTX",
+          "queue": "SZS_ROCM_QUEUE", "queue_words": "SZS_ROCM_QUEUE_WORDS", "queue_rounds": "SZS_ROCM_QUEUE_ROUNDS"}
 _knob_values = {name: os.environ.get(variable) for name, variable in _KNOBS.items()}  # what the library read when it was loaded
 
 

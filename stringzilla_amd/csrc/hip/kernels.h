@@ -134,6 +134,37 @@ int szs_hip_levenshtein_myers_banded_runes(szs_string_ref_t const *queries, uint
                                            uint64_t results_row_stride, int symmetric, void *workspace, void *stream);
 size_t szs_hip_levenshtein_myers_banded_runes_bytes(uint32_t queries_count, uint32_t candidates_count, uint32_t longest_candidate);
 
+/**
+ *  ONE persistent launch for a unit-cost byte-level call whose queries span several bit-vector widths (hip/myers_queue.hip):
+ *  work items (one query, `candidates_per_item` consecutive candidates) are drawn from a ticket counter in the order the host
+ *  planned (host/plan.c: szs_plan_queue) - TILES of (a slice of the queries, longest first) x (a column of the candidates,
+ *  ascending), sorted by how long one of their items holds a workgroup.  Inside a tile the blocks of a column are taken from
+ *  its end (heaviest first), every query of the slice against one block before the next block.
+ *  A tile's shape: `lanes` = 1 scores a pair on one lane at the query's own width (queries of up to 16 words = 512 bytes);
+ *  `lanes` = 2 ... 16 spreads it over that many adjacent lanes of `words_per_lane` = 4, 8, 12 or 16 words.  A query that does
+ *  not fit its tile's shape is scored at a shape that takes it (the kernel never trusts the plan with correctness).
+ */
+#define SZS_QUEUE_MOST_TILES 96u
+typedef struct szs_queue_tile_t {
+    uint32_t first_item;                     /* items of all tiles before this one */
+    uint32_t query_first, query_count;       /* slice of the query refs (longest first) */
+    uint32_t candidate_first, candidate_end; /* column of the candidate refs (ascending) */
+    uint32_t candidates_per_item;            /* S: the masks of a query are built once per S candidates */
+    uint16_t words_per_lane, lanes;
+} szs_queue_tile_t;
+typedef struct szs_queue_plan_t {
+    uint32_t tiles_count, items_total;
+    szs_queue_tile_t tiles[SZS_QUEUE_MOST_TILES];
+} szs_queue_plan_t;
+/**
+ *  `tickets`: one dword of device memory, zeroed when allocated and never again; `ticket_base`: its value when this launch
+ *  begins; `*tickets_taken` receives what the launch adds to it (items + workgroups: every workgroup stops at the first
+ *  ticket past the end), so the caller tracks the counter without reading it back.
+ */
+int szs_hip_levenshtein_myers_queue(szs_queue_plan_t const *plan, szs_string_ref_t const *queries, szs_string_ref_t const *candidates,
+                                    uint64_t *results, uint64_t results_row_stride, int layout, uint32_t *tickets, uint32_t ticket_base,
+                                    uint32_t *tickets_taken, void *stream);
+
 /* ---- tuning knobs (host/tuning.c): read from the environment ONCE at load, changed only by szs_rocm_tuning_set -------- */
 
 enum {
@@ -157,6 +188,10 @@ enum {
     szs_knob_queues_k,      /* hardware queues the process has (GPU_MAX_HW_QUEUES when the library was loaded, else 4): the launches of a
                                call fan out over at most that many streams */
     szs_knob_roctx_k,       /* 0 | 1: the host phases of every call as roctx ranges (rocprofv3 --marker-trace) */
+    szs_knob_queue_k,       /* -1 automatic (unit-cost byte calls of two or more width groups) | 0 never | 1 every unit-cost byte call:
+                               the ONE persistent launch of hip/myers_queue.hip instead of a launch per width */
+    szs_knob_queue_words_k, /* -1 automatic | 4 / 8 / 12 / 16: the most words of a pattern one lane may hold in that launch */
+    szs_knob_queue_rounds_k,/* -1 automatic | n: candidates per work item, in rounds of the workgroup's eight wavefronts */
     szs_knob_count_k
 };
 int szs_tuning_get(int knob);
@@ -205,6 +240,7 @@ typedef struct szs_plan_expectation_t {
     uint32_t alphabet;              /* > 0: the kernels index a direct table of alphabet + 1 rows with the symbols */
 } szs_plan_expectation_t;
 
+#define SZS_PLAN_RANK_SAMPLES 32u /* the length distribution of a side, for the queue order of hip/myers_queue.hip (host/plan.c) */
 typedef struct szs_plan_summary_t {
     uint32_t status;           /* SZS_PLAN_STATUS_* bits; 0 = both sides planned */
     uint32_t speculation_held; /* the batch fits the expectation: the speculated launches scored it */
@@ -212,6 +248,9 @@ typedef struct szs_plan_summary_t {
     uint32_t variant_counts[2][SZS_PLAN_VARIANTS];
     uint64_t symmetric_cells;  /* symmetric calls: cells of the lower triangle */
     uint32_t sequence;
+    /* rank_lengths[side][k]: the length of the string at ASCENDING rank k (count - 1) / SZS_PLAN_RANK_SAMPLES of that side -
+     * [0] the shortest, [SZS_PLAN_RANK_SAMPLES] the longest; every string of a lower rank is no longer than the sample */
+    uint32_t rank_lengths[2][SZS_PLAN_RANK_SAMPLES + 1];
 } szs_plan_summary_t;
 
 /**

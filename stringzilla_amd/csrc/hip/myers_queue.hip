@@ -1,0 +1,360 @@
+/*
+ *  myers_queue.hip - unit-cost byte-level Levenshtein distances of a MIXED-LENGTH batch in ONE persistent launch (round 4).
+ *
+ *  The reference runs every size tier of a call behind one trampoline with a single trailing synchronisation and cuts rows
+ *  into (query, segment) work units so that the device stays full
+ *      /root/reference/include/stringzillas/similarities/cuda.cuh:4435-4741 (trampoline), :2580-2586 (work units).
+ *  Rounds 1-3 of this build launched one kernel per bit-vector width (hip/lev_myers.hip: up to nine launches over eight
+ *  streams for a Zipf-length batch) and every launch ended in a tail of its own - an eighth of config 5, one GPU's share of
+ *  eight, took 1.85 ms where 1.2 ms was the work (profiles/r03/shard_preview.jsonl).  Here:
+ *
+ *  - ONE launch, one persistent grid (two workgroups of 512 threads per CU: four wavefronts per SIMD, 64 KB of match masks
+ *    each), one queue of work items in device memory: a ticket counter the workgroups draw from.
+ *  - A work ITEM is (one query, S consecutive candidates of the length-sorted candidate array).  The workgroup builds the
+ *    query's match masks once, then its eight WAVEFRONTS draw blocks of candidates from a counter in LDS - longest block
+ *    first - so that a wavefront whose texts ended early takes the next block instead of waiting at a barrier for the
+ *    wavefront with the longest texts (sorted Zipf lengths spread 2x over 512 neighbours).
+ *  - The ORDER of the queue is planned on the host (host/plan.c: szs_plan_queue) from what the planner reports about the two
+ *    sides - strings per width class, and the lengths at 33 ranks of each side: the (query slice) x (candidate column) TILES
+ *    of the cross-product are sorted by the time one of their items holds a workgroup, longest first (longest-processing-time
+ *    list scheduling), and handed to the kernel as an argument - 96 tiles x 28 bytes, no upload, no table in LDS.
+ *  - The WIDTH is a per-item scalar decision, as in the short kernel of lev_myers.hip: up to 16 words a pair is one lane
+ *    (bodies of exactly 1 ... 8, 10, 12, 16 words); wider patterns - or, in a call so short that one pair's columns would
+ *    be a large part of it, any pattern - are spread over L = 2 ... 16 adjacent lanes of 4, 8, 12 or 16 words each, the
+ *    strip pipeline of levenshtein_myers_split_kernel with L a run-time value (any L: 5 lanes x 4 words take a 20-word
+ *    pattern exactly).  Every body stays under 128 registers, so all of them share the four wavefronts per SIMD.
+ *
+ *  Results are bit-identical to every other unit-cost kernel of this library and to the reference's serial scorer
+ *  (levenshtein_distance_myers<char, serial>, serial.hpp:2073-2314): the same column update (hip/myers_core.hpp), the same
+ *  right-aligned pattern over phantom rows, the same telescoped distance.
+ */
+#include "myers_core.hpp"
+
+namespace szs_hip {
+
+constexpr u32 queue_threads_k = 512;        // eight wavefronts share one query's match masks
+constexpr int queue_widest_k = 64;          // words of the widest pattern: 2048 bytes, 64 KB of masks
+constexpr u32 queue_pattern_reads_k = (32u * queue_widest_k + queue_threads_k - 1) / queue_threads_k; // pattern bytes per thread
+
+/** dword index of word `w` of byte `row`'s mask: rows of `row_words` = 1, 2 or 4 words, chunk-major (peq_layout). */
+__device__ __forceinline__ u32 queue_mask_index(u32 row_words, u32 row, u32 w) {
+    return row_words == 4 ? (((w >> 2) * (u32)byte_rows_k + row) << 2) + (w & 3u) : row * row_words + w;
+}
+
+/**
+ *  One wavefront, one candidate per lane: candidates [lo, hi) of the sorted array (at most 64) against the query whose masks
+ *  are in `peq`.  The lane loop of lev_myers.hip's myers_workgroup: unpredicated batches while every live lane still has a
+ *  whole batch of columns, then a tail predicated on each lane's own length.  `unroll_`: columns per copy of the column body.
+ */
+template <int words_, int text_dwords_, int unroll_ = 4 * text_dwords_>
+__device__ __forceinline__ void queue_lanes(u32 const *peq, szs_string_ref_t const query, szs_string_ref_t const *__restrict__ candidates,
+                                            u32 lo, u32 hi, u64 *__restrict__ results, u64 results_row_stride, int layout) {
+    u32 const slot = lo + (threadIdx.x & 63u);
+    bool live = slot < hi;
+    szs_string_ref_t candidate = {0, 0, 0};
+    if (live) candidate = candidates[slot];
+    if ((layout & SZS_LAYOUT_SYMMETRIC) && candidate.index > query.index) live = false; // upper triangle: mirrored from below
+    u32 const query_length = query.length;
+    u32 const pad = 32u * words_ - query_length; // phantom low rows
+    u32 const text_length = live ? candidate.length : 0;
+    u32 const longest_in_wave = wave_max_u32(text_length);
+    u32 const shortest_in_wave = ~wave_max_u32(live ? ~text_length : 0u); // over live lanes; no live lane: ~0, unused
+
+    u32 vp[words_], vn[words_];
+#pragma unroll
+    for (int w = 0; w < words_; ++w) {
+        u32 const first_bit = 32u * w;
+        vp[w] = first_bit >= pad ? ~0u : (first_bit + 32u <= pad ? 0u : (~0u << (pad - first_bit)));
+        vn[w] = 0;
+    }
+    auto take = [&](u32 symbol) {
+        u32 eq[words_];
+        load_match_masks<words_, byte_rows_k>(peq, symbol, eq);
+        myers_column<words_>(vp, vn, eq);
+    };
+
+    // Lanes without a text stream from the query instead (always-valid memory; their symbols are never consumed)
+    u64 const safe_address = text_length ? candidate.address : query.address;
+    text_stream_t text(safe_address, text_length);
+    if (!text_length) text.valid_dwords = query_length ? 1 : 0;
+    u32 raw_low = text.raw(0);
+    u32 column = 0, dword = 0;
+    constexpr u32 columns_per_iteration = 4 * text_dwords_;
+    constexpr bool clamped_reads = text_dwords_ == 1; // as measured for the one-dword loops of the long kernels
+    if (columns_per_iteration <= shortest_in_wave && longest_in_wave && query_length) {
+        u32 ahead[text_dwords_];
+#pragma unroll
+        for (int d = 0; d < text_dwords_; ++d) ahead[d] = clamped_reads ? text.raw_clamped(1 + d) : text.raw(1 + d);
+        for (; column + columns_per_iteration <= shortest_in_wave; column += columns_per_iteration, dword += text_dwords_) {
+            u32 symbols[text_dwords_];
+            symbols[0] = text.splice(raw_low, ahead[0]);
+#pragma unroll
+            for (int d = 1; d < text_dwords_; ++d) symbols[d] = text.splice(ahead[d - 1], ahead[d]);
+            raw_low = ahead[text_dwords_ - 1];
+#pragma unroll
+            for (int d = 0; d < text_dwords_; ++d)
+                ahead[d] = clamped_reads ? text.raw_clamped(dword + text_dwords_ + 1 + d) : text.raw(dword + text_dwords_ + 1 + d);
+            // (the widest bodies take their columns one or two at a time: unrolled by four, hipcc hoists the mask reads of all
+            //  four columns and the 16-word body spills 29 registers of the 128 that four wavefronts per SIMD leave a lane)
+#pragma unroll unroll_
+            for (int step = 0; step < 4 * text_dwords_; ++step) take((symbols[step / 4] >> (8 * (step % 4))) & 0xFFu);
+        }
+    }
+    if (column < longest_in_wave) { // ragged tail: one dword per iteration, each column predicated on this lane's own length
+        u32 next = text.raw(dword + 1);
+#pragma unroll 1
+        for (; column < longest_in_wave; column += 4, ++dword) {
+            u32 const after = text.raw(dword + 2);
+            u32 const symbols = text.splice(raw_low, next);
+            raw_low = next, next = after;
+#pragma unroll
+            for (int step = 0; step < 4; ++step)
+                if (column + step < text_length) take((symbols >> (8 * step)) & 0xFFu);
+        }
+    }
+
+    if (live) {
+        u32 distance = text_length;
+#pragma unroll
+        for (int w = 0; w < words_; ++w) distance += (u32)__builtin_popcount(vp[w]) - (u32)__builtin_popcount(vn[w]);
+        bool const transposed = (layout & SZS_LAYOUT_TRANSPOSED) != 0; // kernel roles swapped by the host
+        u64 const row = transposed ? candidate.index : query.index, column_of = transposed ? query.index : candidate.index;
+        results[row * results_row_stride + column_of] = distance;
+        if ((layout & SZS_LAYOUT_SYMMETRIC) && candidate.index != query.index) results[column_of * results_row_stride + row] = distance;
+    }
+}
+
+/**
+ *  One wavefront, `lanes` adjacent lanes per pair (2 ... 16, any value: a DPP row of 16 lanes holds 16 / lanes teams, the rest
+ *  of the row idles): lane k of a team holds words [k w, (k + 1) w) of the pattern's bit-vector and runs k columns behind lane
+ *  k - 1; the horizontal deltas under its last row travel with the text byte in one `v_mov_b32_dpp row_shr:1` per column
+ *  (lev_myers.hip: levenshtein_myers_split_kernel, with the lane count a run-time value).  Candidates [lo, hi): at most
+ *  4 x (16 / lanes) of them.
+ */
+template <int words_per_lane_>
+__device__ __forceinline__ void queue_team(u32 const *peq, u32 lanes, szs_string_ref_t const query,
+                                           szs_string_ref_t const *__restrict__ candidates, u32 lo, u32 hi,
+                                           u64 *__restrict__ results, u64 results_row_stride, int layout) {
+    static_assert(words_per_lane_ % 4 == 0, "whole 16-byte chunks of the masks per lane");
+    constexpr int chunks_per_lane = words_per_lane_ / 4;
+    u32 const lane = threadIdx.x & 63u, row_lane = lane & 15u;
+    u32 const teams_per_row = 16u / lanes;
+    u32 const team_in_row = row_lane / lanes, part = row_lane - team_in_row * lanes;
+    u32 const slot = lo + (lane >> 4) * teams_per_row + team_in_row;
+    bool live = team_in_row < teams_per_row && slot < hi;
+    szs_string_ref_t candidate = {0, 0, 0};
+    if (live) candidate = candidates[slot];
+    if ((layout & SZS_LAYOUT_SYMMETRIC) && candidate.index > query.index) live = false;
+    u32 const query_length = query.length;
+    u32 const pad = 32u * words_per_lane_ * lanes - query_length; // phantom low rows: whole lanes of them are inert too
+    u32 const text_length = live ? candidate.length : 0;
+    u32 const longest_in_wave = wave_max_u32(text_length);
+    bool const head = part == 0;
+
+    u32 vp[words_per_lane_], vn[words_per_lane_];
+#pragma unroll
+    for (int w = 0; w < words_per_lane_; ++w) {
+        u32 const first_bit = 32u * (part * words_per_lane_ + w);
+        vp[w] = first_bit >= pad ? ~0u : (first_bit + 32u <= pad ? 0u : (~0u << (pad - first_bit)));
+        vn[w] = 0;
+    }
+    // this lane's chunks of the masks: chunk c of byte s at uint4 index c * 256 + s
+    uint4 const *const my_rows = reinterpret_cast<uint4 const *>(peq) + part * chunks_per_lane * byte_rows_k;
+
+    // only the head lane of a team reads the text; the others receive every byte from their neighbour
+    text_stream_t text(candidate.address, head ? text_length : 0u);
+    u32 raw_low = text.raw(0), next = text.raw(1);
+    u32 incoming = 0; // from the lane below: symbol (8 bits) | hp << 8 | hn << 9 | valid << 10 of the column it has just finished
+    u32 const steps = longest_in_wave ? longest_in_wave + lanes - 1 : 0;
+#pragma unroll 1
+    for (u32 step = 0, dword = 0; step < steps; step += 4, ++dword) {
+        u32 const symbols = text.splice(raw_low, next);
+        raw_low = next, next = text.raw(dword + 2);
+#pragma unroll
+        for (u32 sub = 0; sub < 4; ++sub) {
+            u32 const symbol = head ? (symbols >> (8 * sub)) & 0xFFu : incoming & 0xFFu;
+            u32 const hp_in = head ? 1u : (incoming >> 8) & 1u; // DP row 0 grows by one per column
+            u32 const hn_in = head ? 0u : (incoming >> 9) & 1u;
+            bool const active = head ? step + sub < text_length : ((incoming >> 10) & 1u) != 0;
+            u32 outgoing = 0;
+            if (active) {
+                u32 eq[words_per_lane_];
+#pragma unroll
+                for (int chunk = 0; chunk < chunks_per_lane; ++chunk) {
+                    uint4 const row = my_rows[chunk * byte_rows_k + symbol];
+                    eq[chunk * 4 + 0] = row.x, eq[chunk * 4 + 1] = row.y, eq[chunk * 4 + 2] = row.z, eq[chunk * 4 + 3] = row.w;
+                }
+                outgoing = symbol | (myers_strip_column<words_per_lane_>(vp, vn, eq, hp_in, hn_in) << 8) | (1u << 10);
+            }
+            // row_shr:1 - every lane takes its lower neighbour's word; the first lane of a row of 16 (always a head) takes zero
+            incoming = (u32)__builtin_amdgcn_update_dpp(0, (int)outgoing, 0x111, 0xF, 0xF, true);
+        }
+    }
+
+    i32 const mine = [&] {
+        i32 delta = 0;
+#pragma unroll
+        for (int w = 0; w < words_per_lane_; ++w) delta += (i32)__builtin_popcount(vp[w]) - (i32)__builtin_popcount(vn[w]);
+        return delta;
+    }();
+    i32 delta = mine;
+    for (u32 k = 1; k < lanes; ++k) delta += __shfl_down(mine, k, 64); // the head adds up its team (same row, lanes above it)
+    if (live && head) {
+        u64 const distance = (u64)((i64)text_length + delta);
+        bool const transposed = (layout & SZS_LAYOUT_TRANSPOSED) != 0;
+        u64 const row = transposed ? candidate.index : query.index, column_of = transposed ? query.index : candidate.index;
+        results[row * results_row_stride + column_of] = distance;
+        if ((layout & SZS_LAYOUT_SYMMETRIC) && candidate.index != query.index) results[column_of * results_row_stride + row] = distance;
+    }
+}
+
+/**
+ *  The persistent kernel.  `tickets` is a counter in device memory that is never reset: the host passes the value it holds when
+ *  the launch begins (`ticket_base`; a launch takes exactly plan.items_total + gridDim.x tickets - every workgroup stops at
+ *  the first ticket past the queue's end - so the host knows it without asking).
+ */
+__global__ __launch_bounds__(queue_threads_k, 4 /* wavefronts per SIMD: two workgroups per CU */) void levenshtein_myers_queue_kernel(
+    szs_string_ref_t const *__restrict__ queries, szs_string_ref_t const *__restrict__ candidates, u64 *__restrict__ results,
+    u64 results_row_stride, int layout, u32 *__restrict__ tickets, u32 ticket_base, szs_queue_plan_t plan) {
+    __shared__ __attribute__((aligned(16))) u32 peq[peq_layout<queue_widest_k>::total_dwords];
+    __shared__ u32 next_ticket, wave_ticket;
+
+    u32 const tid = threadIdx.x;
+    if (tid == 0) next_ticket = atomicAdd(tickets, 1u) - ticket_base;
+    __syncthreads();
+    u32 tile_index = 0;
+    for (;;) {
+        u32 const item = __builtin_amdgcn_readfirstlane(next_ticket);
+        if (item >= plan.items_total) break;
+        // ---- ticket -> tile -> (query, candidates [c_lo, c_hi)): tickets only grow, so the tile index only moves forward
+        while (tile_index + 1 < plan.tiles_count && item >= plan.tiles[tile_index + 1].first_item) ++tile_index;
+        szs_queue_tile_t const tile = plan.tiles[tile_index];
+        u32 const local = item - tile.first_item;
+        u32 const block = local / tile.query_count; // blocks of S candidates are cut from the column's END: heaviest first
+        szs_string_ref_t const query = queries[tile.query_first + (local - block * tile.query_count)];
+        u32 const c_hi = tile.candidate_end - block * tile.candidates_per_item;
+        u32 const c_lo = c_hi - tile.candidate_first > tile.candidates_per_item ? c_hi - tile.candidates_per_item : tile.candidate_first;
+
+        // ---- the body: the tile's shape, widened when the query does not fit it (a plan made for another batch)
+        u32 const query_length = query.length;
+        u32 const needed_words = __builtin_amdgcn_readfirstlane(query_length ? (query_length + 31u) / 32u : 1u);
+        u32 lanes = tile.lanes ? tile.lanes : 1u, words_per_lane = tile.words_per_lane;
+        if (lanes > 16u) lanes = 16u;
+        if (lanes == 1u && needed_words > 16u) lanes = (needed_words + 15u) / 16u, words_per_lane = 16u;
+        if (lanes > 1u) {
+            words_per_lane = words_per_lane <= 4u ? 4u : words_per_lane <= 8u ? 8u : words_per_lane <= 12u ? 12u : 16u;
+            if (words_per_lane * lanes < needed_words) words_per_lane = 16u, lanes = (needed_words + 15u) / 16u;
+        }
+        // words of the masks as the body sees them: the exact width for one lane per pair (10, 12, 16 beyond 8 words)
+        u32 const body_words = lanes > 1u            ? words_per_lane * lanes
+                               : needed_words <= 8u  ? needed_words
+                               : needed_words <= 10u ? 10u
+                               : needed_words <= 12u ? 12u
+                                                     : 16u;
+        u32 const row_words = body_words >= 3u ? 4u : body_words;
+        u32 const mask_dwords = row_words == 4u ? ((body_words + 3u) / 4u) * (u32)byte_rows_k * 4u : (u32)byte_rows_k * row_words;
+        u32 const pad = 32u * body_words - query_length;
+
+        // ---- the query's match masks: this thread's pattern bytes are in flight while the table is cleared
+        u8 const *const pattern = reinterpret_cast<u8 const *>(query.address);
+        u32 mine[queue_pattern_reads_k];
+#pragma unroll
+        for (u32 k = 0; k < queue_pattern_reads_k; ++k) {
+            u32 const i = tid + k * queue_threads_k;
+            mine[k] = i < query_length ? pattern[i] : 0u;
+        }
+        for (u32 i = tid * 4u; i < mask_dwords; i += queue_threads_k * 4u) // (every table size is a multiple of 4 dwords)
+            *reinterpret_cast<uint4 *>(peq + i) = make_uint4(0, 0, 0, 0);
+        __syncthreads(); // A: the table is clear, and everybody has read `next_ticket`
+        u32 ahead = 0; // the next item's ticket: drawn now, looked at after this item is scored - the round trip is hidden
+        if (tid == 0) ahead = atomicAdd(tickets, 1u), wave_ticket = 0;
+#pragma unroll
+        for (u32 k = 0; k < queue_pattern_reads_k; ++k) {
+            u32 const i = tid + k * queue_threads_k;
+            if (i < query_length) {
+                u32 const position = pad + i;
+                atomicOr(&peq[queue_mask_index(row_words, mine[k], position >> 5)], 1u << (position & 31u));
+            }
+        }
+        __syncthreads(); // B: the table is complete
+
+        // ---- the wavefronts draw blocks of candidates, longest first, until the item's candidates are gone
+        u32 const pairs_per_wave = lanes > 1u ? 4u * (16u / lanes) : 64u;
+        u32 const wave_blocks = (c_hi - c_lo + pairs_per_wave - 1u) / pairs_per_wave;
+        for (;;) {
+            u32 drawn = 0;
+            if ((tid & 63u) == 0) drawn = atomicAdd(&wave_ticket, 1u);
+            drawn = __builtin_amdgcn_readfirstlane(drawn);
+            if (drawn >= wave_blocks) break;
+            u32 const hi = c_hi - drawn * pairs_per_wave;
+            u32 const lo = hi - c_lo > pairs_per_wave ? hi - pairs_per_wave : c_lo;
+#define SZS_QUEUE_LANES(W, D, ...) queue_lanes<W, D, ##__VA_ARGS__>(peq, query, candidates, lo, hi, results, results_row_stride, layout)
+#define SZS_QUEUE_TEAM(W) queue_team<W>(peq, lanes, query, candidates, lo, hi, results, results_row_stride, layout)
+            if (lanes > 1u) {
+                switch (words_per_lane) {
+                case 4: SZS_QUEUE_TEAM(4); break;
+                case 8: SZS_QUEUE_TEAM(8); break;
+                case 12: SZS_QUEUE_TEAM(12); break;
+                default: SZS_QUEUE_TEAM(16); break;
+                }
+            }
+            else {
+                switch (body_words) {
+                case 1: SZS_QUEUE_LANES(1, 2); break;
+                case 2: SZS_QUEUE_LANES(2, 2); break;
+                case 3: SZS_QUEUE_LANES(3, 2); break;
+                case 4: SZS_QUEUE_LANES(4, 2); break;
+                case 5: SZS_QUEUE_LANES(5, 2); break;
+                case 6: SZS_QUEUE_LANES(6, 2); break;
+                case 7: SZS_QUEUE_LANES(7, 2); break;
+                case 8: SZS_QUEUE_LANES(8, 2); break;
+                case 10: SZS_QUEUE_LANES(10, 1); break;
+                case 12: SZS_QUEUE_LANES(12, 1, 2); break;
+                default: SZS_QUEUE_LANES(16, 1, 1); break;
+                }
+            }
+#undef SZS_QUEUE_LANES
+#undef SZS_QUEUE_TEAM
+        }
+        if (tid == 0) next_ticket = ahead - ticket_base;
+        __syncthreads(); // C: nobody reads the table any more; the next ticket is visible
+    }
+}
+
+/** Workgroups the device keeps resident (two per CU with 64 KB of LDS each), per device ordinal. */
+static u32 queue_grid(u64 items) {
+    static int resident_of[device_slots_k];
+    int *const slot = &resident_of[device_slot()];
+    int resident = cached(slot);
+    if (!resident) {
+        int device = 0, units = 0, per_unit = 0;
+        if (hipGetDevice(&device) != hipSuccess ||
+            hipDeviceGetAttribute(&units, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_unit, levenshtein_myers_queue_kernel, (int)queue_threads_k, 0) != hipSuccess ||
+            units <= 0 || per_unit <= 0) {
+            (void)hipGetLastError();
+            units = 256, per_unit = 2;
+        }
+        resident = units * per_unit;
+        remember(slot, resident);
+    }
+    return (u32)(items < (u64)resident ? items : (u64)resident);
+}
+
+} // namespace szs_hip
+
+extern "C" int szs_hip_levenshtein_myers_queue(szs_queue_plan_t const *plan, szs_string_ref_t const *queries,
+                                               szs_string_ref_t const *candidates, uint64_t *results, uint64_t results_row_stride,
+                                               int layout, uint32_t *tickets, uint32_t ticket_base, uint32_t *tickets_taken,
+                                               void *stream) {
+    using namespace szs_hip;
+    *tickets_taken = 0;
+    if (!plan->items_total) return 0;
+    if (plan->tiles_count > SZS_QUEUE_MOST_TILES) return (int)hipErrorInvalidValue;
+    u32 const grid = queue_grid(plan->items_total);
+    hipLaunchKernelGGL(levenshtein_myers_queue_kernel, dim3(grid), dim3(queue_threads_k), 0, static_cast<hipStream_t>(stream), queries,
+                       candidates, results, results_row_stride, layout, tickets, ticket_base, *plan);
+    hipError_t const error = hipGetLastError();
+    if (error == hipSuccess) *tickets_taken = plan->items_total + grid;
+    return (int)error;
+}

@@ -65,14 +65,15 @@ __global__ __launch_bounds__(plan_threads_k) void plan_kernel(szs_plan_side_t qu
     __shared__ u32 wave_counts[2][plan_waves_k], wave_symbols[2][plan_waves_k], wave_bands_systolic[2][plan_waves_k],
         wave_bands_chain[2][plan_waves_k], wave_longest[2][plan_waves_k], wave_status[plan_waves_k];
     __shared__ u32 side_count_before_wave[2][plan_waves_k], side_symbols[2], side_bands_systolic[2], side_bands_chain[2],
-        side_longest[2], side_strings[2], variants[2][SZS_PLAN_VARIANTS], shared_status, shared_held;
+        side_longest[2], side_strings[2], variants[2][SZS_PLAN_VARIANTS], shared_status, shared_held,
+        rank_lengths[2][SZS_PLAN_RANK_SAMPLES + 1];
     __shared__ unsigned long long chunk_sums[plan_threads_k], shared_cells;
 
     u32 const tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     int const sides = symmetric ? 1 : 2;
     szs_plan_side_t const *const side_of[2] = {&queries, &candidates};
 #ifdef SZS_PLAN_TIMESTAMPS // measuring aid (build variant): 100 MHz timestamps of the phases, behind the summary, for the trace
-    unsigned long long *const stamps = reinterpret_cast<unsigned long long *>(summary) + 40;
+    unsigned long long *const stamps = reinterpret_cast<unsigned long long *>(summary) + 56;
 #define SZS_PLAN_STAMP(K) do { if (tid == 0) stamps[K] = wall_clock64(); } while (0)
 #else
 #define SZS_PLAN_STAMP(K) do {} while (0)
@@ -198,6 +199,25 @@ __global__ __launch_bounds__(plan_threads_k) void plan_kernel(szs_plan_side_t qu
         else strings = strings_shorter_than(variant_longest(slot) + 1) - (slot == 1 ? 0 : strings_shorter_than(variant_longest(slot - 1) + 1));
         variants[s][slot] = strings;
     }
+    // ---- the length at 33 ranks of each side (the queue order of hip/myers_queue.hip is planned from them, host/plan.c): strings
+    //      of length l hold the ascending ranks [positions[l], positions[l + 1]), so the string at rank r is as long as the LARGEST
+    //      l whose position is <= r - a binary search of the positions by one thread per sample, beside the threads above
+    if (tid >= 64 && tid < 64 + (u32)sides * (SZS_PLAN_RANK_SAMPLES + 1)) {
+        int const s = (int)((tid - 64) / (SZS_PLAN_RANK_SAMPLES + 1));
+        u32 const k = (tid - 64) % (SZS_PLAN_RANK_SAMPLES + 1), total = side_strings[s];
+        u32 length = 0;
+        if (total) {
+            u32 const rank = (u32)((u64)k * (total - 1) / SZS_PLAN_RANK_SAMPLES);
+            u32 low = 0, high = plan_bins_k - 1;
+            while (low < high) {
+                u32 const middle = (low + high + 1) / 2;
+                if (histogram[s][middle] <= rank) low = middle;
+                else high = middle - 1;
+            }
+            length = low;
+        }
+        rank_lengths[s][k] = length;
+    }
     __syncthreads();
 
     // ---- symmetric calls: cells of the lower triangle = sum_i len_i * sum_{j <= i} len_j, in the caller's order
@@ -292,6 +312,7 @@ __global__ __launch_bounds__(plan_threads_k) void plan_kernel(szs_plan_side_t qu
             report.side[s].bands_systolic = side_bands_systolic[from];
             report.side[s].bands_chain = side_bands_chain[from];
             for (u32 v = 0; v < SZS_PLAN_VARIANTS; ++v) report.variant_counts[s][v] = variants[from][v];
+            for (u32 k = 0; k <= SZS_PLAN_RANK_SAMPLES; ++k) report.rank_lengths[s][k] = rank_lengths[from][k];
         }
         report.symmetric_cells = shared_cells;
         report.sequence = expected.sequence; // the host can tell a fresh summary from a stale one

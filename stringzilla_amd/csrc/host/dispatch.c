@@ -266,6 +266,8 @@ static void release_device_state(szs_engine_s *engine) {
     szs_buffer_release(&engine->device_alphabet);
     szs_buffer_release(&engine->device_plan_refs);
     szs_buffer_release(&engine->device_presence);
+    szs_buffer_release(&engine->device_queue);
+    engine->queue_zeroed = NULL;
     szs_buffer_release(&engine->pinned_summary);
     if (engine->events_device >= 0) {
         (void)hipEventDestroy(engine->event_start);
@@ -327,6 +329,7 @@ static unsigned team_shape_for(int affine, uint32_t classes, szs_side_stats_t co
 
 static sz_status_t decide(szs_engine_s const *engine, int symmetric, int runes, int force_lanes, szs_side_stats_t const *q_stats,
                           szs_side_stats_t const *c_stats, uint32_t const *q_variants, uint32_t const *c_variants,
+                          uint32_t const (*ranks)[SZS_PLAN_RANK_SAMPLES + 1] /* the caller's sides, or NULL: not known yet */,
                           uint64_t cells, szs_decision_t *d, char const **error_message) {
     memset(d, 0, sizeof(*d));
     d->symmetric = symmetric, d->runes = runes;
@@ -423,6 +426,19 @@ static sz_status_t decide(szs_engine_s const *engine, int symmetric, int runes, 
                                               &d->systolic_control_bytes, &d->systolic_parked_bytes) ||
          d->systolic_control_bytes + d->systolic_parked_bytes > ((size_t)32 << 30)))
         d->tier = SZS_TIER_LANES;
+    /* ---- the bit-parallel width groups of a unit-cost byte call as ONE persistent launch (hip/myers_queue.hip): whenever there
+     * are two or more of them - each used to be a launch with a tail of its own (the `queue` knob: 0 never, 1 also for one) */
+    int const queue_knob = szs_tuning_get(szs_knob_queue_k);
+    unsigned bit_parallel_groups = 0;
+    for (unsigned g = 0; g < d->plan.groups_count; ++g) bit_parallel_groups += d->plan.groups[g].variant != 0;
+    d->use_queue = d->use_myers && !runes && d->tier == SZS_TIER_LANES && !d->wide_cells && queue_knob != 0 &&
+                   bit_parallel_groups >= (queue_knob > 0 ? 1u : 2u);
+    if (d->use_queue && ranks) {
+        d->plan.has_ranks = 1;
+        memcpy(d->plan.rank_lengths[0], ranks[d->transposed ? 1 : 0], sizeof(d->plan.rank_lengths[0]));
+        memcpy(d->plan.rank_lengths[1], ranks[d->transposed ? 0 : 1], sizeof(d->plan.rank_lengths[1]));
+        szs_plan_queue(&d->plan, d->kq_count, d->kc_count, &d->queue);
+    }
     (void)error_message;
     d->valid = 1;
     return sz_success_k;
@@ -492,6 +508,15 @@ static sz_status_t prepare(szs_engine_s *engine, szs_decision_t const *d, int de
         status = szs_buffer_reserve(&engine->device_boundary, szs_memory_device_k, device, bytes, error_message);
         if (status != sz_success_k) return status;
         return upload_model(engine, d, device, stream, error_message);
+    }
+    if (d->use_queue) { /* the ticket counter of the persistent launch: zeroed when allocated, then only ever counted up */
+        status = szs_buffer_reserve(&engine->device_queue, szs_memory_device_k, device, 256, error_message);
+        if (status != sz_success_k) return status;
+        if (engine->queue_zeroed != engine->device_queue.pointer) {
+            error = hipMemsetAsync(engine->device_queue.pointer, 0, 256, stream);
+            if (error != hipSuccess) return szs_report_hip(error, error_message);
+            engine->queue_zeroed = engine->device_queue.pointer, engine->queue_tickets = 0;
+        }
     }
     int const variant_zero = has_group_of_variant_zero(d);
     size_t boundary_bytes = 0;
@@ -574,7 +599,10 @@ static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int dev
      * of a wavefront per SIMD resident (profiles/r02/pmc_configs.json).  The launches are independent (disjoint result
      * cells), so they fan out over the engine's auxiliary streams and fill each other's tails; only the launches that
      * share the strip workspace (`device_boundary`) stay on the scope's stream, in order. */
-    int const fan_out = d->plan.groups_count > 1 && szs_tuning_get(szs_knob_streams_k) != 0;
+    /* Unit-cost byte calls of several widths: ONE persistent launch scores every bit-parallel group (hip/myers_queue.hip); what
+     * is left for the loop below is the strip kernel's group, if any.  (Not behind a guard: re-used plans are one short launch.) */
+    int const queued = d->use_queue && !guard && d->queue.items_total != 0;
+    int const fan_out = d->plan.groups_count > 1 && szs_tuning_get(szs_knob_streams_k) != 0 && !queued;
     /* no more streams than the process has hardware queues (tuning.c): streams that share a queue run in the queue's order */
     unsigned const queues = (unsigned)szs_tuning_get(szs_knob_queues_k);
     unsigned const most_aux = queues ? (queues - 1 < SZS_AUX_STREAMS ? queues - 1 : (unsigned)SZS_AUX_STREAMS) : 0u;
@@ -612,6 +640,7 @@ static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int dev
         szs_plan_group_t const *group = &d->plan.groups[g];
         szs_launch_shape_t const shape = shapes[g];
         int const uses_workspace = group->variant == 0;
+        if (queued && group->variant) continue; /* in the queue */
         unsigned lane = 0;
         if (fan_out && !uses_workspace) {
             unsigned const turn = next_lane / (aux_used + 1), place = next_lane % (aux_used + 1);
@@ -696,6 +725,13 @@ static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int dev
             }
             if (!launch_error) ++*launches;
         }
+    }
+    if (queued && !launch_error && *status == sz_success_k) {
+        uint32_t taken = 0;
+        launch_error = szs_hip_levenshtein_myers_queue(&d->queue, query_refs, candidate_refs, (uint64_t *)device_results, device_stride, d->layout,
+                                                       (uint32_t *)engine->device_queue.pointer, engine->queue_tickets, &taken, stream);
+        engine->queue_tickets += taken; /* wraps with the counter */
+        if (!launch_error) ++*launches;
     }
     if (fan_out) /* join, also after a failed launch: whatever was enqueued anywhere is drained by the wait on the scope's stream */
         for (unsigned i = 0; i < aux_used; ++i) {
@@ -825,12 +861,13 @@ static sz_status_t finish(szs_call_t *call, szs_decision_t const *d, hipError_t 
     profile->team = cell_bits == 16 ? d->team : 0;
     profile->team_wide = profile->team ? (uint32_t)d->team_wide : 0;
     profile->streams = engine->last_streams ? engine->last_streams : 1;
+    profile->queue_items = d->use_queue && launches ? d->queue.items_total : 0, profile->queue_tiles = profile->queue_items ? d->queue.tiles_count : 0;
     profile->longest_query = d->longest[0], profile->longest_candidate = d->longest[1];
     profile->host_milliseconds = now_milliseconds() - call->started;
     phase(call, 5);
 #ifdef SZS_PLAN_TIMESTAMPS
     if (call->trace) {
-        unsigned long long const *stamps = (unsigned long long const *)engine->pinned_summary.pointer + 40;
+        unsigned long long const *stamps = (unsigned long long const *)engine->pinned_summary.pointer + 56;
         fprintf(stderr, "planner phases (10 ns ticks):");
         for (int k = 1; k < 8; ++k) fprintf(stderr, " %lld", (long long)(stamps[k] - stamps[k - 1]));
         fprintf(stderr, "\n");
@@ -927,7 +964,7 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
     hipError_t error = hipSuccess;
     int const knobs_automatic = szs_tuning_get(szs_knob_speculate_k) != 0 && szs_tuning_get(szs_knob_tier_k) < 0 &&
                                 szs_tuning_get(szs_knob_swap_k) < 0 && szs_tuning_get(szs_knob_cells_k) < 0 && szs_tuning_get(szs_knob_packed_k) < 0 &&
-                                szs_tuning_get(szs_knob_team_k) < 0;
+                                szs_tuning_get(szs_knob_team_k) < 0 && szs_tuning_get(szs_knob_queue_k) < 0;
     void const *const key_data[2] = {call->queries->data, symmetric ? call->queries->data : call->candidates->data};
     void const *const key_offsets[2] = {call->queries->offsets, symmetric ? call->queries->offsets : call->candidates->offsets};
     int const key_wide[2] = {(int)q_side.wide, (int)c_side.wide};
@@ -1087,8 +1124,8 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
     for (int attempt = 0; attempt < 2; ++attempt) { /* second round: a stalled band chain is re-run on the lanes tier */
         szs_decision_t d;
         uint64_t const cells = symmetric ? seen.symmetric_cells : seen.side[0].symbols * seen.side[1].symbols;
-        status = decide(engine, symmetric, 0, attempt > 0, &seen.side[0], &seen.side[1], seen.variant_counts[0], seen.variant_counts[1], cells,
-                        &d, error_message);
+        status = decide(engine, symmetric, 0, attempt > 0, &seen.side[0], &seen.side[1], seen.variant_counts[0], seen.variant_counts[1],
+                        seen.rank_lengths, cells, &d, error_message);
         if (status != sz_success_k) return status;
         status = prepare(engine, &d, device, stream, error_message);
         if (status != sz_success_k) return status;
@@ -1330,8 +1367,8 @@ static sz_status_t cross_device_planned_runes(szs_call_t *call) {
     for (int attempt = 0; attempt < 2; ++attempt) { /* second round: a stalled band chain is re-run on the lanes tier */
         szs_decision_t d;
         uint64_t const cells = symmetric ? seen.symmetric_cells : seen.side[0].symbols * seen.side[1].symbols;
-        status = decide(engine, symmetric, 1, attempt > 0, &seen.side[0], &seen.side[1], seen.variant_counts[0], seen.variant_counts[1], cells, &d,
-                        error_message);
+        status = decide(engine, symmetric, 1, attempt > 0, &seen.side[0], &seen.side[1], seen.variant_counts[0], seen.variant_counts[1],
+                        seen.rank_lengths, cells, &d, error_message);
         if (status != sz_success_k) return status;
         d.alphabet = alphabet;
         status = prepare(engine, &d, device, stream, error_message);
@@ -1466,7 +1503,8 @@ static sz_status_t cross_host_planned(szs_call_t *call) {
 
     for (int attempt = 0; attempt < 2; ++attempt) { /* second round: a stalled band chain is re-run on the lanes tier */
         szs_decision_t d;
-        status = decide(engine, symmetric, runes, attempt > 0, &q_stats, &c_stats, q_variants, c_variants, cells, &d, error_message);
+        status = decide(engine, symmetric, runes, attempt > 0, &q_stats, &c_stats, q_variants, c_variants, NULL /* ranks: after the sort below */,
+                        cells, &d, error_message);
         if (status != sz_success_k) return status;
         d.alphabet = alphabet;
         /* kernel roles */
@@ -1479,6 +1517,11 @@ static sz_status_t cross_host_planned(szs_call_t *call) {
         szs_plan_t sorted;
         szs_plan_build(myers_words, symmetric, kq_addresses, kq_lengths, d.kq_count, kc_addresses, kc_lengths, d.kc_count, host_query_refs,
                        host_candidate_refs, keys, scratch, &sorted);
+        if (d.use_queue) { /* the queue of the one-launch kernel is ordered by the sorted lengths (kernel roles already) */
+            d.plan.has_ranks = 1;
+            memcpy(d.plan.rank_lengths, sorted.rank_lengths, sizeof(d.plan.rank_lengths));
+            szs_plan_queue(&d.plan, d.kq_count, d.kc_count, &d.queue);
+        }
         phase(call, 1); /* gathering strings, transcoding, orientation, planning */
 
         status = prepare(engine, &d, device, stream, error_message);
@@ -1524,6 +1567,10 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
     size_t const candidates_count = symmetric ? queries_count : candidates->count;
     engine->cells_before = engine->last_profile.cells;
     memset(&engine->last_profile, 0, sizeof(engine->last_profile));
+    /* The dense byte alphabet of a non-unit Levenshtein engine belongs to ONE call: only the device-planned path scans the
+     * tapes and fills it, and decide() / fill_cost_model() read it on every path - a host-planned call after a device-planned
+     * one must not score with the previous batch's byte-to-class map (bytes that batch lacked would all share class 0). */
+    engine->uniform_classes = 0;
     if (!queries_count || !candidates_count) return szs_report(sz_success_k, error_message, NULL); /* cuda.cuh:4257 */
     if (queries_count > 0xFFFFFFFFull || candidates_count > 0xFFFFFFFFull)
         return szs_report(sz_overflow_risk_k, error_message, NULL);

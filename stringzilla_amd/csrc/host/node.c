@@ -106,7 +106,9 @@ static void node_unreference(szs_node_s *node) {
 void szs_rocm_node_free(szs_rocm_node_t handle) {
     szs_node_s *node = (szs_node_s *)handle;
     if (!node || node->magic != SZS_NODE_MAGIC) return;
-    if (__atomic_exchange_n(&node->released, 1u, __ATOMIC_ACQ_REL)) return; /* freed twice: the second call is ignored */
+    /* A second free is recognised (and ignored) only while engines created from the node still keep it alive; once the last
+     * reference is gone the memory has been returned and the handle must not be used again - as with every other handle here. */
+    if (__atomic_exchange_n(&node->released, 1u, __ATOMIC_ACQ_REL)) return;
     node_unreference(node); /* engines created from the node keep it alive until they are freed themselves */
 }
 

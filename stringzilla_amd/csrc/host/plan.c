@@ -125,6 +125,180 @@ void szs_plan_build(unsigned myers, int symmetric, uint64_t const *query_address
         query_refs[slot].index = q;
     }
     szs_plan_groups(variant_counts, plan);
+    /* the lengths at 33 ranks of each side, as the device planner reports them (hip/planner.hip): the queue of the one-launch
+     * bit-parallel kernel is ordered by them (szs_plan_queue) */
+    plan->has_ranks = 1;
+    for (unsigned k = 0; k <= SZS_PLAN_RANK_SAMPLES; ++k) {
+        plan->rank_lengths[0][k] = queries_count ? query_refs[queries_count - 1 - (uint32_t)((uint64_t)k * (queries_count - 1) / SZS_PLAN_RANK_SAMPLES)].length : 0;
+        plan->rank_lengths[1][k] = candidates_count ? candidate_refs[(uint32_t)((uint64_t)k * (candidates_count - 1) / SZS_PLAN_RANK_SAMPLES)].length : 0;
+    }
+}
+
+/* ---- the work queue of the one-launch bit-parallel kernel (hip/myers_queue.hip) ------------------------------------------- */
+
+/*
+ *  The model.  A workgroup of the persistent kernel is eight wavefronts behind one query's match masks; one of its work items
+ *  is that query against S candidates.  A lane that holds `w` words of a pattern takes ~`SZS_QUEUE_WORD_COLUMN_NS` per text
+ *  column and word on a busy device (10.5 instructions, four wavefronts taking turns on a SIMD: profiles/r04), so
+ *      one round of an item ~ w x (longest candidate of its column) x that,
+ *  and nothing shortens it but more lanes per pair.  The call as a whole takes ~cells / SZS_QUEUE_CELLS_PER_NS.  A round must be a
+ *  small part of that - a third at most - or the call ends waiting for it: that bounds the words per lane (16, 12, 8, 4: a
+ *  whole-device batch keeps 16, one GPU's eighth of a Zipf batch goes down to 4 - sixteen lanes for a 2048-byte query).  An
+ *  item is several rounds while it stays under a sixteenth of the call (the masks are built once per item, and eight
+ *  wavefronts that draw several rounds of candidate blocks balance each other: more is better while the queue's end stays
+ *  fine-grained).  Tiles are sorted by rounds x words per lane x longest candidate: longest-processing-time-first list
+ *  scheduling of the workgroup slots.
+ */
+#define SZS_QUEUE_WORD_COLUMN_NS 60.0
+#define SZS_QUEUE_CELLS_PER_NS 9.0e4 /* 90 TCUPS */
+#define SZS_QUEUE_MOST_SLICES 12u
+#define SZS_QUEUE_MOST_COLUMNS 8u
+#define SZS_QUEUE_MOST_ROUNDS 8u
+#define SZS_QUEUE_LANE_OVERHEAD 14.0 /* instructions per column a lane of a team spends on the hand-over, beside 10.5 per word */
+
+typedef struct {
+    uint32_t first, count, bound; /* queries [first, first + count) of the descending array, none longer than `bound` symbols */
+    unsigned words_per_lane, lanes;
+} queue_slice_t;
+
+static unsigned words_of(uint32_t length) { return length ? (length + 31u) / 32u : 1u; }
+
+/** Lanes per pair and words per lane for patterns of up to `words` words when a lane may hold `most` (4 / 8 / 12 / 16) of them. */
+static void queue_shape(unsigned words, unsigned most, unsigned *words_per_lane, unsigned *lanes) {
+    if (words <= most && words <= 16u) { /* one lane per pair, at each query's own width */
+        *words_per_lane = 0, *lanes = 1;
+        return;
+    }
+    double best = -1;
+    for (unsigned w = 4; w <= most; w += 4) {
+        unsigned const l = (words + w - 1) / w;
+        if (l > 16u) continue;
+        unsigned const team = l < 2u ? 2u : l; /* (a pattern narrower than `most` still gets two lanes here: callers ask for teams) */
+        double const width_used = (double)words / (double)(w * team);
+        double const lanes_used = (double)(team * (16u / team)) / 16.0;
+        double const issue_used = 10.5 * w / (10.5 * w + SZS_QUEUE_LANE_OVERHEAD);
+        double const efficiency = width_used * lanes_used * issue_used;
+        if (efficiency > best) best = efficiency, *words_per_lane = w, *lanes = team;
+    }
+    if (best < 0) *words_per_lane = 16, *lanes = (words + 15u) / 16u; /* more than 16 x `most` words: as wide as it takes */
+}
+
+void szs_plan_queue(szs_plan_t const *plan, uint32_t queries_count, uint32_t candidates_count, szs_queue_plan_t *queue) {
+    memset(queue, 0, sizeof(*queue));
+    if (!queries_count || !candidates_count) return;
+    uint32_t const longest_candidate = plan->longest_candidate ? plan->longest_candidate : 1u;
+    double const call_ns = (double)plan->cells / SZS_QUEUE_CELLS_PER_NS;
+    double const round_ns = call_ns / 3.0;
+    /* the most words one lane may hold: the largest of 16 / 12 / 8 / 4 whose round against the longest candidate fits */
+    int const words_knob = szs_tuning_get(szs_knob_queue_words_k);
+    double const fitting = round_ns / (SZS_QUEUE_WORD_COLUMN_NS * longest_candidate);
+    unsigned most = fitting >= 16 ? 16u : fitting >= 12 ? 12u : fitting >= 8 ? 8u : 4u;
+    if (words_knob == 4 || words_knob == 8 || words_knob == 12 || words_knob == 16) most = (unsigned)words_knob;
+
+    /* ---- slices of the queries: every width group of the plan, cut further where the sampled lengths fall by a quarter */
+    queue_slice_t slices[SZS_QUEUE_MOST_SLICES];
+    unsigned slices_count = 0, groups_left = 0;
+    for (unsigned g = 0; g < plan->groups_count; ++g) groups_left += plan->groups[g].variant != 0;
+    for (unsigned g = 0; g < plan->groups_count && slices_count < SZS_QUEUE_MOST_SLICES; ++g) {
+        szs_plan_group_t const *group = &plan->groups[g];
+        if (!group->variant || !group->count) continue;
+        --groups_left;
+        uint32_t bound = group->variant * 32u;
+        if (bound > plan->longest_query) bound = plan->longest_query;
+        queue_slice_t *slice = &slices[slices_count++];
+        slice->first = group->first, slice->count = group->count, slice->bound = bound;
+        if (!plan->has_ranks) continue;
+        /* samples in descending order of length = ascending position in the descending query array */
+        for (int k = (int)SZS_PLAN_RANK_SAMPLES; k >= 0 && slices_count + groups_left < SZS_QUEUE_MOST_SLICES; --k) {
+            uint32_t const position = queries_count - 1 - (uint32_t)((uint64_t)k * (queries_count - 1) / SZS_PLAN_RANK_SAMPLES);
+            if (position <= slice->first || position >= group->first + group->count) continue;
+            uint32_t const sampled = plan->rank_lengths[0][k];
+            if (words_of(sampled) * 4u > words_of(slice->bound) * 3u) continue; /* not yet a quarter narrower */
+            queue_slice_t *next = &slices[slices_count++];
+            next->first = position, next->count = slice->first + slice->count - position, next->bound = sampled;
+            slice->count = position - slice->first;
+            slice = next;
+        }
+    }
+    if (!slices_count) return;
+    for (unsigned i = 0; i < slices_count; ++i) queue_shape(words_of(slices[i].bound), most, &slices[i].words_per_lane, &slices[i].lanes);
+
+    /* ---- columns of the candidates: cut where the sampled lengths have fallen to 0.6 of the column's longest, so that the
+     * items of a tile are alike (equal counts would put 700 ... 1900-byte texts of a Zipf batch into one column) */
+    unsigned columns_most = SZS_QUEUE_MOST_TILES / slices_count;
+    if (columns_most > SZS_QUEUE_MOST_COLUMNS) columns_most = SZS_QUEUE_MOST_COLUMNS;
+    uint32_t column_begin[SZS_QUEUE_MOST_COLUMNS], column_end[SZS_QUEUE_MOST_COLUMNS], column_longest[SZS_QUEUE_MOST_COLUMNS];
+    unsigned columns = 0;
+    {
+        uint32_t end = candidates_count, top = longest_candidate;
+        if (plan->has_ranks && candidates_count > 1)
+            for (int k = (int)SZS_PLAN_RANK_SAMPLES - 1; k >= 0 && columns + 1 < columns_most; --k) {
+                uint32_t const rank = (uint32_t)((uint64_t)k * (candidates_count - 1) / SZS_PLAN_RANK_SAMPLES), sampled = plan->rank_lengths[1][k];
+                if (rank + 1 >= end || (uint64_t)sampled * 10u > (uint64_t)top * 6u) continue;
+                column_begin[columns] = rank + 1, column_end[columns] = end, column_longest[columns] = top ? top : 1u, ++columns;
+                end = rank + 1, top = sampled; /* every candidate of a rank up to `rank` is no longer than the sample there */
+            }
+        column_begin[columns] = 0, column_end[columns] = end, column_longest[columns] = top ? top : 1u, ++columns;
+    }
+
+    /* ---- tiles, their shapes and their keys */
+    int const rounds_knob = szs_tuning_get(szs_knob_queue_rounds_k);
+    double const item_ns = call_ns / 16.0; /* what one item may hold a workgroup for: the queue's granularity at its end */
+    double keys[SZS_QUEUE_MOST_TILES];
+    unsigned tiles = 0;
+    for (unsigned column = 0; column < columns; ++column) {
+        uint32_t const begin = column_begin[column], end = column_end[column], longest = column_longest[column];
+        for (unsigned i = 0; i < slices_count; ++i) {
+            queue_slice_t const *slice = &slices[i];
+            szs_queue_tile_t *tile = &queue->tiles[tiles];
+            unsigned const lane_words = slice->lanes > 1 ? slice->words_per_lane : words_of(slice->bound);
+            uint32_t const pairs_per_round = slice->lanes > 1 ? 8u * 4u * (16u / slice->lanes) : 8u * 64u;
+            double const one_round_ns = SZS_QUEUE_WORD_COLUMN_NS * lane_words * longest;
+            unsigned rounds = one_round_ns >= item_ns ? 1u : (unsigned)(item_ns / one_round_ns);
+            if (rounds > SZS_QUEUE_MOST_ROUNDS) rounds = SZS_QUEUE_MOST_ROUNDS;
+            if (rounds_knob > 0) rounds = (unsigned)rounds_knob;
+            uint64_t per_item = (uint64_t)pairs_per_round * rounds;
+            if (per_item > end - begin) per_item = end - begin;
+            tile->query_first = slice->first, tile->query_count = slice->count;
+            tile->candidate_first = begin, tile->candidate_end = end;
+            tile->candidates_per_item = (uint32_t)per_item;
+            tile->words_per_lane = (uint16_t)slice->words_per_lane, tile->lanes = (uint16_t)slice->lanes;
+            keys[tiles] = (double)((per_item + pairs_per_round - 1) / pairs_per_round) * lane_words * longest;
+            ++tiles;
+        }
+    }
+    /* a queue of more than 2^31 items: coarser items (the kernel addresses them with 32 bits) */
+    for (;;) {
+        uint64_t items = 0;
+        for (unsigned t = 0; t < tiles; ++t) {
+            szs_queue_tile_t const *tile = &queue->tiles[t];
+            uint32_t const span = tile->candidate_end - tile->candidate_first;
+            items += (uint64_t)tile->query_count * ((span + tile->candidates_per_item - 1) / tile->candidates_per_item);
+        }
+        if (items < (1ull << 31)) break;
+        for (unsigned t = 0; t < tiles; ++t) {
+            szs_queue_tile_t *tile = &queue->tiles[t];
+            uint32_t const span = tile->candidate_end - tile->candidate_first;
+            tile->candidates_per_item = tile->candidates_per_item * 2u < span ? tile->candidates_per_item * 2u : span;
+            keys[t] *= 2;
+        }
+    }
+    /* ---- longest first (stable: equal keys keep widest-slice-first, lightest column first), then the tiles' places in the queue */
+    for (unsigned t = 1; t < tiles; ++t) {
+        szs_queue_tile_t const moved = queue->tiles[t];
+        double const key = keys[t];
+        unsigned at = t;
+        for (; at > 0 && keys[at - 1] < key; --at) queue->tiles[at] = queue->tiles[at - 1], keys[at] = keys[at - 1];
+        queue->tiles[at] = moved, keys[at] = key;
+    }
+    uint32_t items = 0;
+    for (unsigned t = 0; t < tiles; ++t) {
+        szs_queue_tile_t *tile = &queue->tiles[t];
+        uint32_t const span = tile->candidate_end - tile->candidate_first;
+        tile->first_item = items;
+        items += tile->query_count * ((span + tile->candidates_per_item - 1) / tile->candidates_per_item);
+    }
+    queue->tiles_count = tiles, queue->items_total = items;
 }
 
 /* ---- tier and orientation choice ------------------------------------------------------------------------------------ */
@@ -348,6 +522,39 @@ void szs_plan_launch_order(szs_plan_t const *plan, int use_myers, int runes, uin
         for (; at > 0 && urgency[order[at - 1]] < urgency[g]; --at) order[at] = order[at - 1]; /* stable: ties stay widest first */
         order[at] = g;
     }
+}
+
+sz_status_t szs_rocm_queue_probe(int symmetric, sz_u32_t const *query_lengths, sz_size_t queries_count, sz_u32_t const *candidate_lengths,
+                                 sz_size_t candidates_count, sz_u32_t *tiles, sz_size_t capacity, sz_size_t *tiles_count, sz_u64_t *items_total) {
+    if (queries_count > 0xFFFFFFFFu || candidates_count > 0xFFFFFFFFu || !tiles_count || !items_total) return sz_overflow_risk_k;
+    uint32_t const q = (uint32_t)queries_count, c = (uint32_t)candidates_count;
+    size_t const most = q > c ? q : c;
+    uint64_t *addresses = (uint64_t *)calloc(most + 1, sizeof(uint64_t));
+    szs_string_ref_t *query_refs = (szs_string_ref_t *)calloc((size_t)q + 1, sizeof(szs_string_ref_t));
+    szs_string_ref_t *candidate_refs = (szs_string_ref_t *)calloc((size_t)c + 1, sizeof(szs_string_ref_t));
+    uint32_t *keys = (uint32_t *)calloc(most + 1, sizeof(uint32_t));
+    uint32_t longest = 0;
+    for (uint32_t i = 0; i < q; ++i) longest = query_lengths[i] > longest ? query_lengths[i] : longest;
+    for (uint32_t i = 0; i < c; ++i) longest = candidate_lengths[i] > longest ? candidate_lengths[i] : longest;
+    void *scratch = malloc(szs_plan_scratch_bytes((uint32_t)most, longest));
+    szs_queue_plan_t *queue = (szs_queue_plan_t *)calloc(1, sizeof(szs_queue_plan_t));
+    if (!addresses || !query_refs || !candidate_refs || !keys || !scratch || !queue) {
+        free(addresses), free(query_refs), free(candidate_refs), free(keys), free(scratch), free(queue);
+        return sz_bad_alloc_k;
+    }
+    szs_plan_t plan;
+    szs_plan_build(SZS_MYERS_MAX_WORDS, symmetric, addresses, query_lengths, q, addresses, candidate_lengths, c, query_refs, candidate_refs, keys,
+                   scratch, &plan);
+    szs_plan_queue(&plan, q, c, queue);
+    *tiles_count = queue->tiles_count, *items_total = queue->items_total;
+    for (unsigned t = 0; t < queue->tiles_count && t < capacity && tiles; ++t) {
+        szs_queue_tile_t const *tile = &queue->tiles[t];
+        uint32_t const row[8] = {tile->first_item, tile->query_first, tile->query_count, tile->candidate_first, tile->candidate_end,
+                                 tile->candidates_per_item, tile->words_per_lane, tile->lanes};
+        memcpy(tiles + 8 * (size_t)t, row, sizeof(row));
+    }
+    free(addresses), free(query_refs), free(candidate_refs), free(keys), free(scratch), free(queue);
+    return sz_success_k;
 }
 
 sz_status_t szs_rocm_launch_order_probe(int runes, sz_u32_t const *query_lengths, sz_size_t queries_count, sz_size_t candidates_count,

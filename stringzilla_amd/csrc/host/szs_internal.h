@@ -107,6 +107,9 @@ typedef struct szs_engine_s {
     uint32_t uniform_classes;
     uint8_t uniform_byte_to_class[256];
     szs_buffer_t device_presence;  /* device: the 256 presence bits */
+    szs_buffer_t device_queue;     /* device: the ticket counter of hip/myers_queue.hip - zeroed when allocated, never again */
+    void *queue_zeroed;            /* the allocation of `device_queue` that was zeroed: another pointer means a fresh buffer */
+    uint32_t queue_tickets;        /* the counter's value when the next launch begins (every launch says what it takes) */
     hipEvent_t event_start, event_stop;
     int events_device;
     /* launches of different bit-vector widths fan out over these and fill each other's tails (dispatch.c: enqueue) */
@@ -185,6 +188,10 @@ typedef struct szs_plan_t {
     uint64_t cells; /* sum over live pairs of len(q) * len(c): the GCUPS numerator (bench/similarities.cuh:344-366) */
     unsigned groups_count;
     szs_plan_group_t groups[SZS_PLAN_MAX_GROUPS];
+    /* the lengths at SZS_PLAN_RANK_SAMPLES + 1 ascending ranks of the kernels' query side [0] and candidate side [1]
+     * (hip/kernels.h: szs_plan_summary_t::rank_lengths), when `has_ranks`: what the queue of hip/myers_queue.hip is ordered by */
+    int has_ranks;
+    uint32_t rank_lengths[2][SZS_PLAN_RANK_SAMPLES + 1];
 } szs_plan_t;
 
 /**
@@ -211,6 +218,8 @@ typedef struct szs_decision_t {
     szs_plan_t plan;             /* kernel roles: groups of the query side, longest strings, cells */
     size_t systolic_control_bytes, systolic_parked_bytes;
     uint32_t variant_counts[SZS_PLAN_VARIANTS]; /* of the kernels' query side */
+    int use_queue;             /* the bit-parallel width groups of the call are ONE persistent launch (hip/myers_queue.hip) */
+    szs_queue_plan_t queue;    /* its tiles, in the order the workgroups draw them */
     /* what the refs on the device were planned FROM (device-planned calls): the key of the guarded re-use, dispatch.c */
     int refs_current;          /* engine->device_plan_refs holds the complete plan of exactly these tapes */
     void const *key_data[2], *key_offsets[2];
@@ -244,6 +253,14 @@ typedef struct szs_launch_shape_t {
 szs_launch_shape_t szs_plan_myers_shape(int knob, unsigned variant, uint64_t workgroups_unsplit, int runes);
 void szs_plan_launch_order(szs_plan_t const *plan, int use_myers, int runes, uint64_t candidate_blocks, int split_knob,
                            szs_launch_shape_t *shapes, unsigned *order);
+
+/**
+ *  The work queue of the ONE persistent launch that scores every bit-parallel width group of a unit-cost byte call
+ *  (hip/myers_queue.hip): tiles of (a slice of the queries) x (a column of the candidates), each with its shape - lanes per
+ *  pair, words per lane, candidates per work item - sorted by the time one of their items holds a workgroup, longest first.
+ *  From the plan's groups (variant 0, the strip kernel's, is left out), its rank samples and its cells; plan.c has the model.
+ */
+void szs_plan_queue(szs_plan_t const *plan, uint32_t queries_count, uint32_t candidates_count, szs_queue_plan_t *queue);
 
 #define SZS_TIER_LANES 0    /* one pair per lane: lev_myers.hip, weighted.hip */
 #define SZS_TIER_SYSTOLIC 1 /* one pair per chain of wavefronts: systolic.hip */

@@ -38,6 +38,9 @@ static struct {
     [szs_knob_team_k] = {"team", "SZS_ROCM_TEAM"},
     [szs_knob_queues_k] = {"queues", "SZS_ROCM_QUEUES"},
     [szs_knob_roctx_k] = {"roctx", "SZS_ROCM_ROCTX"},
+    [szs_knob_queue_k] = {"queue", "SZS_ROCM_QUEUE"},
+    [szs_knob_queue_words_k] = {"queue_words", "SZS_ROCM_QUEUE_WORDS"},
+    [szs_knob_queue_rounds_k] = {"queue_rounds", "SZS_ROCM_QUEUE_ROUNDS"},
 };
 
 /** Text -> value.  -1 always means "automatic".  Tier names: lanes 0, systolic 1, chain 2; planner: host 0, device 1. */
@@ -71,8 +74,8 @@ __attribute__((constructor)) static void szs_tuning_load(void) {
      *  library does not control.  `queues` knob / SZS_ROCM_QUEUES: the queue count to assume; automatic = GPU_MAX_HW_QUEUES, or 4. */
     if (knobs[szs_knob_queues_k] < 0) {
         char const *const exported = getenv("GPU_MAX_HW_QUEUES");
-        int const queues = exported ? atoi(exported) : 0;
-        knobs[szs_knob_queues_k] = queues > 0 ? queues : 4;
+        long const queues = exported ? strtol(exported, NULL, 10) : 0;
+        knobs[szs_knob_queues_k] = queues > 0 ? (int)(queues < 64 ? queues : 64) : 4; /* anything unparsable or absurd: the runtime's default */
     }
 }
 
@@ -85,6 +88,7 @@ sz_status_t szs_rocm_tuning_set(char const *knob, char const *value) {
             int parsed = parse_knob(k, value);
             if (k == szs_knob_trace_k && parsed < 0) parsed = 0;
             if (k == szs_knob_queues_k && parsed <= 0) parsed = 4; /* the runtime's default */
+            if (k == szs_knob_queues_k && parsed > 64) parsed = 64;
             __atomic_store_n(&knobs[k], parsed, __ATOMIC_RELAXED);
             return sz_success_k;
         }

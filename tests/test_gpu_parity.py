@@ -125,19 +125,24 @@ def test_levenshtein_fuzz(gpu, oracle, costs):
 def test_levenshtein_every_kernel_width(gpu, oracle):
     """Queries at both edges of every bit-parallel width (1..8 words inside the mixed-width short kernel, then each
     instantiated long width up to 64 words), plus queries beyond 2048 bytes that take the strip kernel - all in ONE call,
-    so the planner's grouping is exercised too: 1 short + 8 long + 1 strip launch."""
+    so the planner's grouping is exercised too: 1 short + 8 long + 1 strip launch with the `queue` knob at 0, and since round 4
+    ONE persistent launch for the nine bit-parallel widths (hip/myers_queue.hip) + the strip launch."""
     rng = random.Random(77)
     edges = [0, 1, 31, 32, 33, 64, 65, 96, 97, 128, 129, 160, 161, 192, 224, 225, 256, 257, 320, 321, 384, 385, 512, 513,
              640, 768, 769, 1024, 1025, 1536, 1537, 2048, 2049, 2500]
     queries = [bytes(rng.choice(b"ACGT") for _ in range(n)) for n in edges]
     candidates = _rand(rng, 70, 0, 300, b"ACGT") + [queries[9], queries[-1][:2100]]
     engine = szs.LevenshteinDistances(capabilities=gpu)
+    expected = oracle.levenshtein(queries, candidates)
     with forced_tier("lanes"):  # 34 x 72 pairs: left alone, the planner would hand this batch to the systolic tier
         got = engine(queries, candidates, device=gpu)
-    assert np.array_equal(got, oracle.levenshtein(queries, candidates))
-    profile = engine.last_call_profile()
-    assert profile.launches == 10, profile.launches
-    assert profile.cells == sum(map(len, queries)) * sum(map(len, candidates))
+        assert np.array_equal(got, expected)
+        profile = engine.last_call_profile()
+        assert profile.launches == 2 and profile.queue_items > 0, profile.launches
+        assert profile.cells == sum(map(len, queries)) * sum(map(len, candidates))
+        with forced_env("queue", 0):
+            assert np.array_equal(engine(queries, candidates, device=gpu), expected)
+            assert engine.last_call_profile().launches == 10, engine.last_call_profile().launches
 
 
 def test_levenshtein_beyond_2048_bytes_in_strips(gpu, oracle):

@@ -1,0 +1,146 @@
+"""`-m gpu`, round 4: the ONE persistent launch for unit-cost byte calls of mixed lengths (hip/myers_queue.hip) against the oracle.
+
+The reference runs every size tier of a call behind one trampoline (cuda.cuh:4435-4741); rounds 1-3 here launched one kernel
+per bit-vector width.  These tests pin: a mixed-width call IS one launch (`profile.launches == 1`, two with the strip kernel's
+queries beyond 2048 bytes); every body of the kernel - one lane per pair at 1 ... 8, 10, 12 and 16 words, teams of 2 ... 16
+lanes at 4 / 8 / 12 / 16 words per lane - at the edges of its width; candidates per work item from one wave block to several
+rounds of the workgroup; symmetric and swapped layouts; both planners; a stream of calls on one engine (the ticket counter is
+never reset); and the per-width launches (`queue` knob 0) still agreeing with it cell for cell.
+"""
+import contextlib
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import stringzilla_amd as szs  # noqa: E402
+from stringzilla_amd import _abi, workloads  # noqa: E402
+
+
+@contextlib.contextmanager
+def knob(name, value):
+    previous = _abi.tuning_set(name, value)
+    try:
+        yield
+    finally:
+        _abi.tuning_set(name, previous)
+
+
+def _rand(rng, count, lo, hi, alphabet):
+    return [bytes(rng.choice(alphabet) for _ in range(rng.randint(lo, hi))) for _ in range(count)]
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+
+    assert torch.cuda.is_available(), "the gpu-marked tests need a GPU"
+    return szs.DeviceScope(gpu_device=0)
+
+
+EDGES = [0, 1, 31, 32, 33, 64, 65, 96, 97, 128, 129, 160, 161, 192, 224, 225, 256, 257, 288, 320, 321, 352, 384, 385, 416, 448, 512, 513,
+         640, 641, 768, 769, 1024, 1025, 1536, 1537, 2047, 2048]
+
+
+def test_a_mixed_width_call_is_one_launch(gpu, oracle):
+    rng = random.Random(404)
+    queries = [bytes(rng.choice(b"ACGT") for _ in range(n)) for n in EDGES]
+    candidates = _rand(rng, 70, 0, 300, b"ACGT") + [queries[9], queries[-1][:1900], b""]
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+    expected = oracle.levenshtein(queries, candidates)
+    with knob("tier", "lanes"):  # 38 x 73 pairs: left alone, the planner would hand this batch to the chained tier
+        got = engine(queries, candidates, device=gpu)
+        profile = engine.last_call_profile()
+        assert np.array_equal(got, expected), np.argwhere(got != expected)[:5].tolist()
+        assert profile.launches == 1 and profile.queue_items > 0 and profile.queue_tiles > 0, (profile.launches, profile.queue_items)
+        assert profile.cells == sum(map(len, queries)) * sum(map(len, candidates))
+        # queries beyond 2048 bytes keep the strip kernel: one more launch, not one per width
+        longer = queries + [bytes(rng.choice(b"ACGT") for _ in range(n)) for n in (2049, 2600)]
+        assert np.array_equal(engine(longer, candidates, device=gpu), oracle.levenshtein(longer, candidates))
+        assert engine.last_call_profile().launches == 2
+        # the per-width launches score the same cells
+        with knob("queue", 0):
+            assert np.array_equal(engine(queries, candidates, device=gpu), expected)
+            assert engine.last_call_profile().launches == 9 and engine.last_call_profile().queue_items == 0
+        # a call of ONE width is not queued by itself, but can be
+        narrow = [q for q in queries if len(q) <= 256]
+        assert np.array_equal(engine(narrow, candidates, device=gpu), oracle.levenshtein(narrow, candidates))
+        assert engine.last_call_profile().queue_items == 0
+        with knob("queue", 1):
+            assert np.array_equal(engine(narrow, candidates, device=gpu), oracle.levenshtein(narrow, candidates))
+            assert engine.last_call_profile().queue_items > 0 and engine.last_call_profile().launches == 1
+
+
+@pytest.mark.parametrize("words", [4, 8, 12, 16])
+def test_every_body_of_the_queue_kernel(gpu, oracle, words):
+    """`queue_words` caps the words one lane holds: at 4 a 2048-byte query is a team of sixteen lanes and every lane count
+    from 2 to 16 occurs (9 ... 64 words), at 16 the one-lane bodies of 10, 12 and 16 words run."""
+    rng = random.Random(words)
+    lengths = sorted(set(EDGES + [32 * k for k in range(1, 65)] + [32 * k + 1 for k in range(0, 64)] + [rng.randint(1, 2048) for _ in range(20)]))
+    queries = [bytes(rng.choice(b"AB") for _ in range(n)) for n in lengths]
+    candidates = _rand(rng, 90, 0, 260, b"AB") + _rand(rng, 6, 600, 700, b"AB") + [b"", queries[40]]
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+    expected = oracle.levenshtein(queries, candidates)
+    with knob("tier", "lanes"), knob("queue_words", words):
+        got = engine(queries, candidates, device=gpu)
+        assert engine.last_call_profile().launches == 1 and engine.last_call_profile().queue_items > 0
+        wrong = np.argwhere(got != expected)
+        assert wrong.size == 0, (words, [(len(queries[q]), len(candidates[c]), int(got[q, c]), int(expected[q, c])) for q, c in wrong[:6]])
+        with knob("swap", 1):  # the candidates on the workgroups, the results transposed back
+            assert np.array_equal(engine(candidates, queries, device=gpu), expected.T)
+        self_expected = oracle.levenshtein(queries[::3], None)
+        got = engine(queries[::3], device=gpu)  # symmetric: the lower triangle, mirrored
+        assert np.array_equal(got, self_expected)
+
+
+@pytest.mark.parametrize("rounds", [1, 2, 5])
+def test_work_items_of_several_rounds_and_ragged_columns(gpu, oracle, rounds):
+    """More candidates than one round of a workgroup: the wavefronts draw wave blocks from the item's counter; columns and
+    items that end on no boundary at all; bytes >= 0x80; both planners."""
+    rng = random.Random(rounds)
+    queries = _rand(rng, 9, 0, 40, bytes(range(256))) + _rand(rng, 5, 257, 700, bytes(range(256))) + _rand(rng, 3, 1025, 1300, bytes(range(256)))
+    candidates = _rand(rng, 1337, 0, 48, bytes(range(256))) + _rand(rng, 50, 100, 130, bytes(range(256)))
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+    expected = oracle.levenshtein(queries, candidates)
+    for planner in ("device", "host"):
+        with knob("tier", "lanes"), knob("swap", 0), knob("queue_rounds", rounds), knob("planner", planner):
+            got = engine(szs.Strs(queries), szs.Strs(candidates), device=gpu)
+            profile = engine.last_call_profile()
+            assert profile.launches == 1 and profile.queue_items > 0 and profile.planner == (1 if planner == "device" else 0), (profile.launches, profile.planner)
+            wrong = np.argwhere(got != expected)
+            assert wrong.size == 0, (rounds, planner, wrong[:5].tolist())
+
+
+def test_a_stream_of_calls_on_one_engine(gpu, oracle):
+    """The ticket counter lives in device memory and is never reset: every launch starts where the host knows the last one
+    ended.  Batches of other shapes, queued and not, in between."""
+    rng = random.Random(9)
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+    with knob("tier", "lanes"):
+        for step in range(12):
+            if step % 4 == 3:
+                queries, candidates = _rand(rng, 20, 90, 160, b"ACGT"), _rand(rng, 300, 90, 160, b"ACGT")  # one width: the short kernel
+            else:
+                queries = _rand(rng, rng.randint(3, 40), 0, 200, b"ACGT") + _rand(rng, rng.randint(1, 6), 300, 2048, b"ACGT")
+                candidates = _rand(rng, rng.randint(1, 700), 0, rng.choice([20, 300]), b"ACGT")
+            got = engine(queries, candidates, device=gpu)
+            assert np.array_equal(got, oracle.levenshtein(queries, candidates)), step
+            assert engine.last_call_profile().launches == 1
+
+
+def test_config5_scaled_both_ways(gpu, oracle):
+    """Config 5 (Zipf lengths 8 ... 2048) at 1 / 12 of its side: the queue against the per-width launches and the oracle."""
+    load = workloads.config(5, scale=1 / 12)
+    queries = [load.queries[i] for i in range(len(load.queries))]
+    candidates = [load.candidates[i] for i in range(len(load.candidates))]
+    expected = oracle.levenshtein(queries, candidates)
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+    with knob("tier", "lanes"):
+        got = engine(load.queries, load.candidates, device=gpu)
+        assert engine.last_call_profile().launches == 1
+        assert np.array_equal(got, expected)
+        with knob("queue", 0):
+            assert np.array_equal(engine(load.queries, load.candidates, device=gpu), expected)
+            assert engine.last_call_profile().launches > 1

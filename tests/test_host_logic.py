@@ -42,7 +42,7 @@ def test_version_and_capabilities_without_gpu():
 
 def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(_abi.U32Tape) == 24 and ctypes.sizeof(_abi.U64Tape) == 24 and ctypes.sizeof(_abi.Sequence) == 32
-    assert ctypes.sizeof(_abi.CallProfile) == 88
+    assert ctypes.sizeof(_abi.CallProfile) == 96
 
 
 def test_engines_refuse_cpu_capabilities_loudly():

@@ -1,0 +1,133 @@
+"""`-m "not gpu"`: the work queue of the one-launch bit-parallel kernel (hip/myers_queue.hip) as host/plan.c plans it.
+
+`szs_rocm_queue_probe` runs the host planner and `szs_plan_queue` on bare length arrays; this file walks the tickets exactly
+the way the kernel does (ticket -> tile -> query, block of candidates cut from the column's end -> wave blocks) and checks
+that every (query, candidate) cell of the cross-product is scored exactly once, that every tile's shape takes the queries of
+its slice, that the tiles come longest first, and that the shapes follow the size of the call (whole-device batches keep wide
+lanes, a short call spreads its pairs)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from stringzilla_amd import _abi
+
+
+def plan(query_lengths, candidate_lengths, symmetric=False):
+    queries = np.ascontiguousarray(query_lengths, dtype=np.uint32)
+    candidates = np.ascontiguousarray(candidate_lengths, dtype=np.uint32)
+    tiles = np.zeros((96, 8), dtype=np.uint32)
+    count, items = ctypes.c_size_t(), ctypes.c_uint64()
+    status = _abi.lib.szs_rocm_queue_probe(int(symmetric), queries.ctypes.data, len(queries), candidates.ctypes.data, len(candidates),
+                                           tiles.ctypes.data, 96, ctypes.byref(count), ctypes.byref(items))
+    assert status == 0
+    assert count.value <= 96
+    return tiles[: count.value].astype(np.int64), int(items.value)
+
+
+def words_of(length):
+    return max(1, -(-int(length) // 32))
+
+
+def walk(tiles, items, query_lengths, candidate_lengths):
+    """The kernel's own arithmetic.  Returns the coverage matrix [query position (longest first)][candidate position (ascending)]."""
+    sorted_queries = np.sort(np.asarray(query_lengths))[::-1]
+    covered = np.zeros((len(query_lengths), len(candidate_lengths)), dtype=np.int32)
+    expected_first = 0
+    for first_item, query_first, query_count, c_first, c_end, per_item, words_per_lane, lanes in tiles:
+        assert first_item == expected_first and query_count > 0 and c_end > c_first and per_item > 0
+        blocks = -(-(c_end - c_first) // per_item)
+        expected_first += query_count * blocks
+        longest = int(sorted_queries[query_first])  # slices are cut from the descending array: its first query is its longest
+        assert lanes >= 1 and lanes <= 16
+        if lanes == 1:
+            assert words_of(longest) <= 16, (longest, "one lane per pair takes up to 16 words")
+        else:
+            assert words_per_lane in (4, 8, 12, 16) and words_per_lane * lanes >= words_of(longest), (longest, words_per_lane, lanes)
+        for local in range(query_count * blocks):
+            block, query = divmod(local, query_count)
+            c_hi = c_end - block * per_item
+            c_lo = c_hi - per_item if c_hi - c_first > per_item else c_first
+            pairs_per_wave = 64 if lanes == 1 else 4 * (16 // lanes)
+            wave_blocks = -(-(c_hi - c_lo) // pairs_per_wave)
+            for drawn in range(wave_blocks):
+                hi = c_hi - drawn * pairs_per_wave
+                lo = hi - pairs_per_wave if hi - c_lo > pairs_per_wave else c_lo
+                covered[query_first + query, lo:hi] += 1
+    assert expected_first == items
+    return covered
+
+
+def zipf_lengths(rng, count, low=8, high=2048, exponent=1.1):
+    ranks = np.arange(low, high + 1, dtype=np.float64)
+    weights = ranks ** (-exponent)
+    return rng.choice(np.arange(low, high + 1), size=count, p=weights / weights.sum())
+
+
+@pytest.mark.parametrize("shape", ["config5", "eighth", "uniform", "few_candidates", "one_each", "ragged", "symmetric"])
+def test_every_cell_is_scored_exactly_once(shape):
+    rng = np.random.default_rng(len(shape))
+    if shape == "config5":
+        queries, candidates = zipf_lengths(rng, 3163), zipf_lengths(rng, 3163)
+    elif shape == "eighth":
+        queries, candidates = zipf_lengths(rng, 395), zipf_lengths(rng, 3163)
+    elif shape == "uniform":
+        queries, candidates = rng.integers(0, 700, 300), rng.integers(0, 300, 1000)
+    elif shape == "few_candidates":
+        queries, candidates = rng.integers(1, 2049, 500), rng.integers(0, 2049, 7)
+    elif shape == "one_each":
+        queries, candidates = np.array([2048]), np.array([5])
+    elif shape == "ragged":
+        queries = np.concatenate([np.zeros(3, dtype=np.int64), rng.integers(1, 40, 50), [2048, 2047, 1025, 513, 512, 511, 257, 256, 33, 32]])
+        candidates = np.concatenate([np.zeros(2, dtype=np.int64), rng.integers(1, 2049, 321)])
+    else:
+        queries = candidates = zipf_lengths(rng, 700)
+    tiles, items = plan(queries, candidates, symmetric=shape == "symmetric")
+    covered = walk(tiles, items, queries, candidates)
+    assert covered.min() == 1 and covered.max() == 1, (shape, np.argwhere(covered != 1)[:5].tolist())
+
+
+def test_tiles_come_longest_first_and_shapes_follow_the_call():
+    rng = np.random.default_rng(5)
+    queries, candidates = zipf_lengths(rng, 3163), zipf_lengths(rng, 3163)
+    whole, _ = plan(queries, candidates)
+    eighth, _ = plan(np.sort(queries)[::-1][::8], candidates)  # every eighth query, longest first: one GPU's share of eight
+    ascending = np.sort(candidates)
+
+    def key(tile):
+        _, query_first, _, c_first, c_end, per_item, words_per_lane, lanes = tile
+        pairs_per_round = 512 if lanes == 1 else 8 * 4 * (16 // lanes)
+        return -(-per_item // pairs_per_round) * (words_per_lane if lanes > 1 else 1) * int(ascending[c_end - 1])
+
+    for tiles in (whole, eighth):
+        team_tiles = [tile for tile in tiles if tile[7] > 1]
+        assert team_tiles, "2048-byte queries are spread over lanes"
+        # (one-lane tiles are keyed by their slice's bound, which the probe does not return: check the team tiles' order)
+        keys = [key(tile) for tile in team_tiles if tile[4] - tile[3] > 0]
+        assert all(earlier * 1.6 >= later for earlier, later in zip(keys, keys[1:])), keys  # sampled lengths: nearly sorted
+    widest = lambda tiles: max(tile[6] for tile in tiles if tile[7] > 1)
+    assert widest(whole) >= 12 and widest(eighth) <= 8, (widest(whole), widest(eighth))  # a short call spreads its pairs wider
+    most_lanes = lambda tiles: max(tile[7] for tile in tiles)
+    assert most_lanes(eighth) > most_lanes(whole)
+
+
+def test_knobs_pin_the_shape():
+    rng = np.random.default_rng(7)
+    queries, candidates = zipf_lengths(rng, 500), zipf_lengths(rng, 900)
+    for words in (4, 8, 12, 16):
+        previous = _abi.tuning_set("queue_words", words)
+        try:
+            tiles, items = plan(queries, candidates)
+        finally:
+            _abi.tuning_set("queue_words", previous)
+        assert all(tile[6] <= words for tile in tiles if tile[7] > 1)
+        covered = walk(tiles, items, queries, candidates)
+        assert covered.min() == 1 and covered.max() == 1
+    previous = _abi.tuning_set("queue_rounds", 3)
+    try:
+        tiles, items = plan(queries, candidates)
+    finally:
+        _abi.tuning_set("queue_rounds", previous)
+    for tile in tiles:
+        pairs_per_round = 512 if tile[7] == 1 else 8 * 4 * (16 // tile[7])
+        assert tile[5] == min(3 * pairs_per_round, tile[4] - tile[3])
