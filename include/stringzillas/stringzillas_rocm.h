@@ -103,10 +103,11 @@ SZ_API_RUNTIME sz_status_t szs_rocm_launch_order_probe(int runes, sz_u32_t const
 /**
  *  The work queue of the ONE persistent launch that scores every bit-vector width of a unit-cost byte call
  *  (hip/myers_queue.hip; host/plan.c: szs_plan_queue), planned from bare length arrays - no GPU involved.  Queries are taken
- *  longest first, candidates shortest first (szs_rocm_plan_probe gives both orders).  `tiles` receives 8 values per tile, in
+ *  longest first, candidates shortest first (szs_rocm_plan_probe gives both orders).  `tiles` receives 9 values per tile, in
  *  queue order: items of all tiles before it, first query and queries of its slice, first and one-past-last candidate of its
- *  column, candidates per work item, words per lane (0: the query's own width on one lane) and lanes per pair.  Work item j
- *  of a tile scores query `first + j % queries` against the candidates of block `j / queries`, blocks cut from the column's end.
+ *  column, candidates per work item, words per lane (0: the query's own width on one lane), lanes per pair and queries per
+ *  work item G.  With `groups` = ceil(queries / G), work item j of a tile scores the queries of group `j % groups` against the
+ *  candidates of block `j / groups`, blocks cut from the column's end.
  */
 SZ_API_RUNTIME sz_status_t szs_rocm_queue_probe(int symmetric, sz_u32_t const *query_lengths, sz_size_t queries_count,
                                                 sz_u32_t const *candidate_lengths, sz_size_t candidates_count, sz_u32_t *tiles,

@@ -35,6 +35,7 @@ for step in "$@"; do
     queue-tests) timeout 1200 python -m pytest tests/test_gpu_round4.py -m gpu -q -x --durations=5 > "$OUT/queue_tests.log" 2>&1; echo "exit $?" >> "$OUT/queue_tests.log"; tail -40 "$OUT/queue_tests.log";;
     lev-tests)  timeout 1200 python -m pytest tests/test_gpu_parity.py -m gpu -q --maxfail=5 -k "levenshtein or config or known or golden or cross_product or symmetric or closed or input_formats or callback" --durations=5 > "$OUT/lev_tests.log" 2>&1; echo "exit $?" >> "$OUT/lev_tests.log"; tail -30 "$OUT/lev_tests.log";;
     queue5)     timeout 600 python scripts/measure_queue.py --config 5 --shards 1,8 > "$OUT/queue_cfg5.jsonl" 2> "$OUT/queue_cfg5.err"; cat "$OUT/queue_cfg5.jsonl"; tail -3 "$OUT/queue_cfg5.err";;
+    queue-shapes) timeout 600 python scripts/measure_queue_shapes.py > "$OUT/queue_shapes.jsonl" 2> "$OUT/queue_shapes.err"; cat "$OUT/queue_shapes.jsonl"; tail -3 "$OUT/queue_shapes.err";;
     *) echo "unknown step $step";;
   esac
 done

@@ -136,10 +136,10 @@ size_t szs_hip_levenshtein_myers_banded_runes_bytes(uint32_t queries_count, uint
 
 /**
  *  ONE persistent launch for a unit-cost byte-level call whose queries span several bit-vector widths (hip/myers_queue.hip):
- *  work items (one query, `candidates_per_item` consecutive candidates) are drawn from a ticket counter in the order the host
- *  planned (host/plan.c: szs_plan_queue) - TILES of (a slice of the queries, longest first) x (a column of the candidates,
- *  ascending), sorted by how long one of their items holds a workgroup.  Inside a tile the blocks of a column are taken from
- *  its end (heaviest first), every query of the slice against one block before the next block.
+ *  work items (`queries_per_item` consecutive queries, `candidates_per_item` consecutive candidates) are drawn from a ticket
+ *  counter in the order the host planned (host/plan.c: szs_plan_queue) - TILES of (a slice of the queries, longest first) x (a
+ *  column of the candidates, ascending), sorted by how long one of their items holds a workgroup.  Inside a tile the blocks of
+ *  a column are taken from its end (heaviest first), every group of queries of the slice against one block before the next.
  *  A tile's shape: `lanes` = 1 scores a pair on one lane at the query's own width (queries of up to 16 words = 512 bytes);
  *  `lanes` = 2 ... 16 spreads it over that many adjacent lanes of `words_per_lane` = 4, 8, 12 or 16 words.  A query that does
  *  not fit its tile's shape is scored at a shape that takes it (the kernel never trusts the plan with correctness).
@@ -150,7 +150,9 @@ typedef struct szs_queue_tile_t {
     uint32_t query_first, query_count;       /* slice of the query refs (longest first) */
     uint32_t candidate_first, candidate_end; /* column of the candidate refs (ascending) */
     uint32_t candidates_per_item;            /* S: the masks of a query are built once per S candidates */
-    uint16_t words_per_lane, lanes;
+    uint8_t words_per_lane, lanes;
+    uint16_t queries_per_item;               /* G: the masks of G queries side by side in the workgroup's 64-word table (G x
+                                                the words a query of the slice needs <= 64); the slice's last item may hold fewer */
 } szs_queue_tile_t;
 typedef struct szs_queue_plan_t {
     uint32_t tiles_count, items_total;

@@ -208,10 +208,19 @@ __device__ __forceinline__ void queue_team(u32 const *peq, u32 lanes, szs_string
     }
 }
 
+/** Words of the masks as the one-lane bodies see a pattern of `needed` words: its exact width up to 8, then 10, 12, 16. */
+__device__ __forceinline__ u32 queue_body_words(u32 needed) { return needed <= 8u ? needed : needed <= 10u ? 10u : needed <= 12u ? 12u : 16u; }
+
 /**
  *  The persistent kernel.  `tickets` is a counter in device memory that is never reset: the host passes the value it holds when
  *  the launch begins (`ticket_base`; a launch takes exactly plan.items_total + gridDim.x tickets - every workgroup stops at
  *  the first ticket past the queue's end - so the host knows it without asking).
+ *
+ *  A work item is G queries x S candidates: the masks of all G queries are built side by side (64 / G words of the table
+ *  each), and the eight wavefronts draw (candidate block, query) pairs - candidate blocks from the longest down, every query
+ *  of the group against one block before the next.  A wavefront whose texts end early draws again instead of waiting: with
+ *  one query per item a workgroup's wavefronts idled through two fifths of the top column of a Zipf batch.  A group whose
+ *  queries do not fit the tile's shape (a plan made for another batch) is scored one query at a time, at a shape that takes it.
  */
 __global__ __launch_bounds__(queue_threads_k, 4 /* wavefronts per SIMD: two workgroups per CU */) void levenshtein_myers_queue_kernel(
     szs_string_ref_t const *__restrict__ queries, szs_string_ref_t const *__restrict__ candidates, u64 *__restrict__ results,
@@ -226,98 +235,120 @@ __global__ __launch_bounds__(queue_threads_k, 4 /* wavefronts per SIMD: two work
     for (;;) {
         u32 const item = __builtin_amdgcn_readfirstlane(next_ticket);
         if (item >= plan.items_total) break;
-        // ---- ticket -> tile -> (query, candidates [c_lo, c_hi)): tickets only grow, so the tile index only moves forward
+        // ---- ticket -> tile -> (queries [q_first, q_first + q_count), candidates [c_lo, c_hi)): tickets only grow, so the tile
+        //      index only moves forward
         while (tile_index + 1 < plan.tiles_count && item >= plan.tiles[tile_index + 1].first_item) ++tile_index;
         szs_queue_tile_t const tile = plan.tiles[tile_index];
+        u32 const per_group = tile.queries_per_item ? (tile.queries_per_item < 16u ? tile.queries_per_item : 16u) : 1u;
+        u32 const groups = (tile.query_count + per_group - 1u) / per_group;
         u32 const local = item - tile.first_item;
-        u32 const block = local / tile.query_count; // blocks of S candidates are cut from the column's END: heaviest first
-        szs_string_ref_t const query = queries[tile.query_first + (local - block * tile.query_count)];
+        u32 const block = local / groups; // blocks of S candidates are cut from the column's END: heaviest first
+        u32 const q_first = tile.query_first + (local - block * groups) * per_group;
+        u32 const q_count = tile.query_first + tile.query_count - q_first < per_group ? tile.query_first + tile.query_count - q_first : per_group;
         u32 const c_hi = tile.candidate_end - block * tile.candidates_per_item;
         u32 const c_lo = c_hi - tile.candidate_first > tile.candidates_per_item ? c_hi - tile.candidates_per_item : tile.candidate_first;
+        u32 tile_lanes = tile.lanes ? (tile.lanes < 16u ? tile.lanes : 16u) : 1u;
+        u32 tile_words = tile.words_per_lane <= 4u ? 4u : tile.words_per_lane <= 8u ? 8u : tile.words_per_lane <= 12u ? 12u : 16u;
 
-        // ---- the body: the tile's shape, widened when the query does not fit it (a plan made for another batch)
-        u32 const query_length = query.length;
-        u32 const needed_words = __builtin_amdgcn_readfirstlane(query_length ? (query_length + 31u) / 32u : 1u);
-        u32 lanes = tile.lanes ? tile.lanes : 1u, words_per_lane = tile.words_per_lane;
-        if (lanes > 16u) lanes = 16u;
-        if (lanes == 1u && needed_words > 16u) lanes = (needed_words + 15u) / 16u, words_per_lane = 16u;
-        if (lanes > 1u) {
-            words_per_lane = words_per_lane <= 4u ? 4u : words_per_lane <= 8u ? 8u : words_per_lane <= 12u ? 12u : 16u;
-            if (words_per_lane * lanes < needed_words) words_per_lane = 16u, lanes = (needed_words + 15u) / 16u;
-        }
-        // words of the masks as the body sees them: the exact width for one lane per pair (10, 12, 16 beyond 8 words)
-        u32 const body_words = lanes > 1u            ? words_per_lane * lanes
-                               : needed_words <= 8u  ? needed_words
-                               : needed_words <= 10u ? 10u
-                               : needed_words <= 12u ? 12u
-                                                     : 16u;
-        u32 const row_words = body_words >= 3u ? 4u : body_words;
-        u32 const mask_dwords = row_words == 4u ? ((body_words + 3u) / 4u) * (u32)byte_rows_k * 4u : (u32)byte_rows_k * row_words;
-        u32 const pad = 32u * body_words - query_length;
-
-        // ---- the query's match masks: this thread's pattern bytes are in flight while the table is cleared
-        u8 const *const pattern = reinterpret_cast<u8 const *>(query.address);
-        u32 mine[queue_pattern_reads_k];
-#pragma unroll
-        for (u32 k = 0; k < queue_pattern_reads_k; ++k) {
-            u32 const i = tid + k * queue_threads_k;
-            mine[k] = i < query_length ? pattern[i] : 0u;
-        }
-        for (u32 i = tid * 4u; i < mask_dwords; i += queue_threads_k * 4u) // (every table size is a multiple of 4 dwords)
-            *reinterpret_cast<uint4 *>(peq + i) = make_uint4(0, 0, 0, 0);
-        __syncthreads(); // A: the table is clear, and everybody has read `next_ticket`
-        u32 ahead = 0; // the next item's ticket: drawn now, looked at after this item is scored - the round trip is hidden
-        if (tid == 0) ahead = atomicAdd(tickets, 1u), wave_ticket = 0;
-#pragma unroll
-        for (u32 k = 0; k < queue_pattern_reads_k; ++k) {
-            u32 const i = tid + k * queue_threads_k;
-            if (i < query_length) {
-                u32 const position = pad + i;
-                atomicOr(&peq[queue_mask_index(row_words, mine[k], position >> 5)], 1u << (position & 31u));
+        u32 ahead = 0; // the next item's ticket: drawn while this one is scored, looked at afterwards - the round trip is hidden
+        bool drawn_ahead = false, alone = false;
+        u32 done = 0; // queries of the group that have been scored
+        while (done < q_count) {
+            // ---- this pass: the whole group side by side, or - when that did not fit - one query at a shape of its own
+            u32 const together = alone ? 1u : q_count;
+            u32 lanes = tile_lanes, words_per_lane = tile_words;
+            u32 slot_words = ((u32)queue_widest_k / (alone ? 1u : per_group)) & ~3u; // words of the table each query of the pass gets
+            if (alone) {
+                u32 const needed = __builtin_amdgcn_readfirstlane((queries[q_first + done].length + 31u) / 32u);
+                if (lanes == 1u && needed > 16u) lanes = (needed + 15u) / 16u, words_per_lane = 16u;
+                if (lanes > 1u && words_per_lane * lanes < needed) words_per_lane = 16u, lanes = (needed + 15u) / 16u;
             }
-        }
-        __syncthreads(); // B: the table is complete
+            u32 const slot_dwords = slot_words * (u32)byte_rows_k, slot_bytes = slot_words * 32u;
 
-        // ---- the wavefronts draw blocks of candidates, longest first, until the item's candidates are gone
-        u32 const pairs_per_wave = lanes > 1u ? 4u * (16u / lanes) : 64u;
-        u32 const wave_blocks = (c_hi - c_lo + pairs_per_wave - 1u) / pairs_per_wave;
-        for (;;) {
-            u32 drawn = 0;
-            if ((tid & 63u) == 0) drawn = atomicAdd(&wave_ticket, 1u);
-            drawn = __builtin_amdgcn_readfirstlane(drawn);
-            if (drawn >= wave_blocks) break;
-            u32 const hi = c_hi - drawn * pairs_per_wave;
-            u32 const lo = hi - c_lo > pairs_per_wave ? hi - pairs_per_wave : c_lo;
-#define SZS_QUEUE_LANES(W, D, ...) queue_lanes<W, D, ##__VA_ARGS__>(peq, query, candidates, lo, hi, results, results_row_stride, layout)
-#define SZS_QUEUE_TEAM(W) queue_team<W>(peq, lanes, query, candidates, lo, hi, results, results_row_stride, layout)
-            if (lanes > 1u) {
-                switch (words_per_lane) {
-                case 4: SZS_QUEUE_TEAM(4); break;
-                case 8: SZS_QUEUE_TEAM(8); break;
-                case 12: SZS_QUEUE_TEAM(12); break;
-                default: SZS_QUEUE_TEAM(16); break;
+            // ---- the match masks of the pass: every thread's pattern bytes are in flight while the table is cleared
+            u32 mine[queue_pattern_reads_k], position_of[queue_pattern_reads_k], table_of[queue_pattern_reads_k];
+            bool misfit = false;
+#pragma unroll
+            for (u32 k = 0; k < queue_pattern_reads_k; ++k) {
+                u32 const v = tid + k * queue_threads_k, g = v / slot_bytes, i = v - g * slot_bytes;
+                position_of[k] = ~0u;
+                if (g >= together) continue;
+                szs_string_ref_t const query = queries[q_first + done + g];
+                u32 const needed = query.length ? (query.length + 31u) / 32u : 1u;
+                u32 const body_words = lanes > 1u ? words_per_lane * lanes : queue_body_words(needed);
+                if (body_words > slot_words || needed > body_words) misfit = true;
+                else if (i < query.length) {
+                    mine[k] = reinterpret_cast<u8 const *>(query.address)[i];
+                    position_of[k] = 32u * body_words - query.length + i; // right-aligned over phantom low rows
+                    table_of[k] = g * slot_dwords | (body_words >= 3u ? 4u : body_words) << 28;
                 }
             }
-            else {
-                switch (body_words) {
-                case 1: SZS_QUEUE_LANES(1, 2); break;
-                case 2: SZS_QUEUE_LANES(2, 2); break;
-                case 3: SZS_QUEUE_LANES(3, 2); break;
-                case 4: SZS_QUEUE_LANES(4, 2); break;
-                case 5: SZS_QUEUE_LANES(5, 2); break;
-                case 6: SZS_QUEUE_LANES(6, 2); break;
-                case 7: SZS_QUEUE_LANES(7, 2); break;
-                case 8: SZS_QUEUE_LANES(8, 2); break;
-                case 10: SZS_QUEUE_LANES(10, 1); break;
-                case 12: SZS_QUEUE_LANES(12, 1, 2); break;
-                default: SZS_QUEUE_LANES(16, 1, 1); break;
-                }
+            u32 const clear_dwords = together * slot_dwords;
+            for (u32 i = tid * 4u; i < clear_dwords; i += queue_threads_k * 4u) *reinterpret_cast<uint4 *>(peq + i) = make_uint4(0, 0, 0, 0);
+            bool const unfit = __syncthreads_or(misfit) != 0; // A: the table is clear, everybody has read `next_ticket`
+            if (unfit && !alone) { // a group that does not fit side by side is scored query by query instead
+                alone = true;
+                continue;
             }
+            if (tid == 0) {
+                if (!drawn_ahead) ahead = atomicAdd(tickets, 1u);
+                wave_ticket = 0;
+            }
+            drawn_ahead = true;
+            if (!unfit) { // (a query no shape takes - beyond 2048 bytes - is not this kernel's: the host never queues one; it is left alone)
+#pragma unroll
+            for (u32 k = 0; k < queue_pattern_reads_k; ++k)
+                if (position_of[k] != ~0u)
+                    atomicOr(&peq[(table_of[k] & 0x0FFFFFFFu) + queue_mask_index(table_of[k] >> 28, mine[k], position_of[k] >> 5)],
+                             1u << (position_of[k] & 31u));
+            __syncthreads(); // B: the tables are complete
+
+            // ---- the wavefronts draw (candidate block, query) pairs, longest block first, until the pass is through
+            u32 const pairs_per_wave = lanes > 1u ? 4u * (16u / lanes) : 64u;
+            u32 const wave_blocks = ((c_hi - c_lo + pairs_per_wave - 1u) / pairs_per_wave) * together;
+            for (;;) {
+                u32 drawn = 0;
+                if ((tid & 63u) == 0) drawn = atomicAdd(&wave_ticket, 1u);
+                drawn = __builtin_amdgcn_readfirstlane(drawn);
+                if (drawn >= wave_blocks) break;
+                u32 const candidate_block = drawn / together, g = drawn - candidate_block * together;
+                u32 const hi = c_hi - candidate_block * pairs_per_wave;
+                u32 const lo = hi - c_lo > pairs_per_wave ? hi - pairs_per_wave : c_lo;
+                szs_string_ref_t const query = queries[q_first + done + g];
+                u32 const *const table = peq + g * slot_dwords;
+#define SZS_QUEUE_LANES(W, D, ...) queue_lanes<W, D, ##__VA_ARGS__>(table, query, candidates, lo, hi, results, results_row_stride, layout)
+#define SZS_QUEUE_TEAM(W) queue_team<W>(table, lanes, query, candidates, lo, hi, results, results_row_stride, layout)
+                if (lanes > 1u) {
+                    switch (words_per_lane) {
+                    case 4: SZS_QUEUE_TEAM(4); break;
+                    case 8: SZS_QUEUE_TEAM(8); break;
+                    case 12: SZS_QUEUE_TEAM(12); break;
+                    default: SZS_QUEUE_TEAM(16); break;
+                    }
+                }
+                else {
+                    switch (queue_body_words(__builtin_amdgcn_readfirstlane(query.length ? (query.length + 31u) / 32u : 1u))) {
+                    case 1: SZS_QUEUE_LANES(1, 2); break;
+                    case 2: SZS_QUEUE_LANES(2, 2); break;
+                    case 3: SZS_QUEUE_LANES(3, 2); break;
+                    case 4: SZS_QUEUE_LANES(4, 2); break;
+                    case 5: SZS_QUEUE_LANES(5, 2); break;
+                    case 6: SZS_QUEUE_LANES(6, 2); break;
+                    case 7: SZS_QUEUE_LANES(7, 2); break;
+                    case 8: SZS_QUEUE_LANES(8, 2); break;
+                    case 10: SZS_QUEUE_LANES(10, 1); break;
+                    case 12: SZS_QUEUE_LANES(12, 1, 2); break;
+                    default: SZS_QUEUE_LANES(16, 1, 1); break;
+                    }
+                }
 #undef SZS_QUEUE_LANES
 #undef SZS_QUEUE_TEAM
+            }
+            } // fit
+            done += together;
+            if (done >= q_count && tid == 0) next_ticket = ahead - ticket_base;
+            __syncthreads(); // C: nobody reads the tables any more; after the last pass the next ticket is visible
         }
-        if (tid == 0) next_ticket = ahead - ticket_base;
-        __syncthreads(); // C: nobody reads the table any more; the next ticket is visible
     }
 }
 

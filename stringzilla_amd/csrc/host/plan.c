@@ -145,8 +145,8 @@ void szs_plan_build(unsigned myers, int symmetric, uint64_t const *query_address
  *  small part of that - a third at most - or the call ends waiting for it: that bounds the words per lane (16, 12, 8, 4: a
  *  whole-device batch keeps 16, one GPU's eighth of a Zipf batch goes down to 4 - sixteen lanes for a 2048-byte query).  An
  *  item is several rounds while it stays under a sixteenth of the call (the masks are built once per item, and eight
- *  wavefronts that draw several rounds of candidate blocks balance each other: more is better while the queue's end stays
- *  fine-grained).  Tiles are sorted by rounds x words per lane x longest candidate: longest-processing-time-first list
+ *  wavefronts that draw several rounds of (candidate block, query) pairs balance each other: more is better while the queue's
+ *  end stays fine-grained) - first as many QUERIES as the 64-word table of a workgroup takes side by side, then candidates.  Tiles are sorted by rounds x words per lane x longest candidate: longest-processing-time-first list
  *  scheduling of the workgroup slots.
  */
 #define SZS_QUEUE_WORD_COLUMN_NS 60.0
@@ -241,7 +241,9 @@ void szs_plan_queue(szs_plan_t const *plan, uint32_t queries_count, uint32_t can
         column_begin[columns] = 0, column_end[columns] = end, column_longest[columns] = top ? top : 1u, ++columns;
     }
 
-    /* ---- tiles, their shapes and their keys */
+    /* ---- tiles, their shapes and their keys.  An item is G queries x S candidates = G x (S / pairs per wave block) wave blocks
+     * for the workgroup's eight wavefronts: as many queries as the 64-word table takes side by side, then as many candidate
+     * blocks as keep the item under its share of the call. */
     int const rounds_knob = szs_tuning_get(szs_knob_queue_rounds_k);
     double const item_ns = call_ns / 16.0; /* what one item may hold a workgroup for: the queue's granularity at its end */
     double keys[SZS_QUEUE_MOST_TILES];
@@ -251,30 +253,40 @@ void szs_plan_queue(szs_plan_t const *plan, uint32_t queries_count, uint32_t can
         for (unsigned i = 0; i < slices_count; ++i) {
             queue_slice_t const *slice = &slices[i];
             szs_queue_tile_t *tile = &queue->tiles[tiles];
-            unsigned const lane_words = slice->lanes > 1 ? slice->words_per_lane : words_of(slice->bound);
-            uint32_t const pairs_per_round = slice->lanes > 1 ? 8u * 4u * (16u / slice->lanes) : 8u * 64u;
-            double const one_round_ns = SZS_QUEUE_WORD_COLUMN_NS * lane_words * longest;
+            unsigned const bound_words = words_of(slice->bound);
+            unsigned const lane_words = slice->lanes > 1 ? slice->words_per_lane : bound_words;
+            unsigned const table_words = slice->lanes > 1 ? slice->words_per_lane * slice->lanes /* one-lane bodies: 1 ... 8, 10, 12, 16 */
+                                         : bound_words <= 8 ? bound_words : bound_words <= 10 ? 10u : bound_words <= 12 ? 12u : 16u;
+            unsigned side_by_side = 1;
+            for (unsigned g = 16; g > 1; --g)
+                if (((64u / g) & ~3u) >= table_words) { side_by_side = g; break; }
+            uint32_t const pairs_per_wave = slice->lanes > 1 ? 4u * (16u / slice->lanes) : 64u;
+            double const one_round_ns = SZS_QUEUE_WORD_COLUMN_NS * lane_words * longest; /* eight wave blocks, one per wavefront */
             unsigned rounds = one_round_ns >= item_ns ? 1u : (unsigned)(item_ns / one_round_ns);
             if (rounds > SZS_QUEUE_MOST_ROUNDS) rounds = SZS_QUEUE_MOST_ROUNDS;
             if (rounds_knob > 0) rounds = (unsigned)rounds_knob;
-            uint64_t per_item = (uint64_t)pairs_per_round * rounds;
+            unsigned const wave_blocks = 8u * rounds;
+            if (side_by_side > wave_blocks) side_by_side = wave_blocks;
+            if (side_by_side > slice->count) side_by_side = slice->count;
+            uint64_t per_item = (uint64_t)(wave_blocks / side_by_side ? wave_blocks / side_by_side : 1u) * pairs_per_wave;
             if (per_item > end - begin) per_item = end - begin;
             tile->query_first = slice->first, tile->query_count = slice->count;
             tile->candidate_first = begin, tile->candidate_end = end;
             tile->candidates_per_item = (uint32_t)per_item;
-            tile->words_per_lane = (uint16_t)slice->words_per_lane, tile->lanes = (uint16_t)slice->lanes;
-            keys[tiles] = (double)((per_item + pairs_per_round - 1) / pairs_per_round) * lane_words * longest;
+            tile->words_per_lane = (uint8_t)slice->words_per_lane, tile->lanes = (uint8_t)slice->lanes;
+            tile->queries_per_item = (uint16_t)side_by_side;
+            uint64_t const blocks_of_item = side_by_side * ((per_item + pairs_per_wave - 1) / pairs_per_wave);
+            keys[tiles] = (double)((blocks_of_item + 7u) / 8u) * lane_words * longest;
             ++tiles;
         }
     }
+#define SZS_QUEUE_ITEMS_OF(TILE)                                                                                                          \
+    ((uint64_t)(((TILE)->query_count + (TILE)->queries_per_item - 1) / (TILE)->queries_per_item) *                                        \
+     (((TILE)->candidate_end - (TILE)->candidate_first + (TILE)->candidates_per_item - 1) / (TILE)->candidates_per_item))
     /* a queue of more than 2^31 items: coarser items (the kernel addresses them with 32 bits) */
     for (;;) {
         uint64_t items = 0;
-        for (unsigned t = 0; t < tiles; ++t) {
-            szs_queue_tile_t const *tile = &queue->tiles[t];
-            uint32_t const span = tile->candidate_end - tile->candidate_first;
-            items += (uint64_t)tile->query_count * ((span + tile->candidates_per_item - 1) / tile->candidates_per_item);
-        }
+        for (unsigned t = 0; t < tiles; ++t) items += SZS_QUEUE_ITEMS_OF(&queue->tiles[t]);
         if (items < (1ull << 31)) break;
         for (unsigned t = 0; t < tiles; ++t) {
             szs_queue_tile_t *tile = &queue->tiles[t];
@@ -294,10 +306,10 @@ void szs_plan_queue(szs_plan_t const *plan, uint32_t queries_count, uint32_t can
     uint32_t items = 0;
     for (unsigned t = 0; t < tiles; ++t) {
         szs_queue_tile_t *tile = &queue->tiles[t];
-        uint32_t const span = tile->candidate_end - tile->candidate_first;
         tile->first_item = items;
-        items += tile->query_count * ((span + tile->candidates_per_item - 1) / tile->candidates_per_item);
+        items += (uint32_t)SZS_QUEUE_ITEMS_OF(tile);
     }
+#undef SZS_QUEUE_ITEMS_OF
     queue->tiles_count = tiles, queue->items_total = items;
 }
 
@@ -549,9 +561,9 @@ sz_status_t szs_rocm_queue_probe(int symmetric, sz_u32_t const *query_lengths, s
     *tiles_count = queue->tiles_count, *items_total = queue->items_total;
     for (unsigned t = 0; t < queue->tiles_count && t < capacity && tiles; ++t) {
         szs_queue_tile_t const *tile = &queue->tiles[t];
-        uint32_t const row[8] = {tile->first_item, tile->query_first, tile->query_count, tile->candidate_first, tile->candidate_end,
-                                 tile->candidates_per_item, tile->words_per_lane, tile->lanes};
-        memcpy(tiles + 8 * (size_t)t, row, sizeof(row));
+        uint32_t const row[9] = {tile->first_item, tile->query_first, tile->query_count, tile->candidate_first, tile->candidate_end,
+                                 tile->candidates_per_item, tile->words_per_lane, tile->lanes, tile->queries_per_item};
+        memcpy(tiles + 9 * (size_t)t, row, sizeof(row));
     }
     free(addresses), free(query_refs), free(candidate_refs), free(keys), free(scratch), free(queue);
     return sz_success_k;

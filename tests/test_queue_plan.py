@@ -16,7 +16,7 @@ from stringzilla_amd import _abi
 def plan(query_lengths, candidate_lengths, symmetric=False):
     queries = np.ascontiguousarray(query_lengths, dtype=np.uint32)
     candidates = np.ascontiguousarray(candidate_lengths, dtype=np.uint32)
-    tiles = np.zeros((96, 8), dtype=np.uint32)
+    tiles = np.zeros((96, 9), dtype=np.uint32)
     count, items = ctypes.c_size_t(), ctypes.c_uint64()
     status = _abi.lib.szs_rocm_queue_probe(int(symmetric), queries.ctypes.data, len(queries), candidates.ctypes.data, len(candidates),
                                            tiles.ctypes.data, 96, ctypes.byref(count), ctypes.byref(items))
@@ -34,26 +34,32 @@ def walk(tiles, items, query_lengths, candidate_lengths):
     sorted_queries = np.sort(np.asarray(query_lengths))[::-1]
     covered = np.zeros((len(query_lengths), len(candidate_lengths)), dtype=np.int32)
     expected_first = 0
-    for first_item, query_first, query_count, c_first, c_end, per_item, words_per_lane, lanes in tiles:
-        assert first_item == expected_first and query_count > 0 and c_end > c_first and per_item > 0
-        blocks = -(-(c_end - c_first) // per_item)
-        expected_first += query_count * blocks
+    for first_item, query_first, query_count, c_first, c_end, per_item, words_per_lane, lanes, per_group in tiles:
+        assert first_item == expected_first and query_count > 0 and c_end > c_first and per_item > 0 and 1 <= per_group <= 16
+        blocks, groups = -(-(c_end - c_first) // per_item), -(-query_count // per_group)
+        expected_first += groups * blocks
         longest = int(sorted_queries[query_first])  # slices are cut from the descending array: its first query is its longest
         assert lanes >= 1 and lanes <= 16
+        slot_words = (64 // per_group) & ~3  # words of the workgroup's table each query of a group gets
         if lanes == 1:
-            assert words_of(longest) <= 16, (longest, "one lane per pair takes up to 16 words")
+            needed = words_of(longest)
+            assert needed <= 16, (longest, "one lane per pair takes up to 16 words")
+            assert (needed if needed <= 8 else 10 if needed <= 10 else 12 if needed <= 12 else 16) <= slot_words, (longest, per_group)
         else:
-            assert words_per_lane in (4, 8, 12, 16) and words_per_lane * lanes >= words_of(longest), (longest, words_per_lane, lanes)
-        for local in range(query_count * blocks):
-            block, query = divmod(local, query_count)
+            assert words_per_lane in (4, 8, 12, 16) and words_of(longest) <= words_per_lane * lanes <= slot_words, (longest, words_per_lane, lanes, per_group)
+        for local in range(groups * blocks):
+            block, group = divmod(local, groups)
+            q_first = query_first + group * per_group
+            q_count = min(per_group, query_first + query_count - q_first)
             c_hi = c_end - block * per_item
             c_lo = c_hi - per_item if c_hi - c_first > per_item else c_first
             pairs_per_wave = 64 if lanes == 1 else 4 * (16 // lanes)
-            wave_blocks = -(-(c_hi - c_lo) // pairs_per_wave)
+            wave_blocks = -(-(c_hi - c_lo) // pairs_per_wave) * q_count
             for drawn in range(wave_blocks):
-                hi = c_hi - drawn * pairs_per_wave
+                candidate_block, g = divmod(drawn, q_count)
+                hi = c_hi - candidate_block * pairs_per_wave
                 lo = hi - pairs_per_wave if hi - c_lo > pairs_per_wave else c_lo
-                covered[query_first + query, lo:hi] += 1
+                covered[q_first + g, lo:hi] += 1
     assert expected_first == items
     return covered
 
@@ -95,9 +101,10 @@ def test_tiles_come_longest_first_and_shapes_follow_the_call():
     ascending = np.sort(candidates)
 
     def key(tile):
-        _, query_first, _, c_first, c_end, per_item, words_per_lane, lanes = tile
-        pairs_per_round = 512 if lanes == 1 else 8 * 4 * (16 // lanes)
-        return -(-per_item // pairs_per_round) * (words_per_lane if lanes > 1 else 1) * int(ascending[c_end - 1])
+        _, query_first, _, c_first, c_end, per_item, words_per_lane, lanes, per_group = tile
+        pairs_per_wave = 64 if lanes == 1 else 4 * (16 // lanes)
+        wave_blocks = per_group * -(-per_item // pairs_per_wave)
+        return -(-wave_blocks // 8) * (words_per_lane if lanes > 1 else 1) * int(ascending[c_end - 1])
 
     for tiles in (whole, eighth):
         team_tiles = [tile for tile in tiles if tile[7] > 1]
@@ -129,5 +136,5 @@ def test_knobs_pin_the_shape():
     finally:
         _abi.tuning_set("queue_rounds", previous)
     for tile in tiles:
-        pairs_per_round = 512 if tile[7] == 1 else 8 * 4 * (16 // tile[7])
-        assert tile[5] == min(3 * pairs_per_round, tile[4] - tile[3])
+        pairs_per_wave = 64 if tile[7] == 1 else 4 * (16 // tile[7])
+        assert tile[8] <= 24 and tile[5] == min(max(1, 24 // tile[8]) * pairs_per_wave, tile[4] - tile[3]), tile.tolist()
