@@ -44,9 +44,8 @@ __device__ __forceinline__ u32 queue_mask_index(u32 row_words, u32 row, u32 w) {
 /**
  *  One wavefront, one candidate per lane: candidates [lo, hi) of the sorted array (at most 64) against the query whose masks
  *  are in `peq`.  The lane loop of lev_myers.hip's myers_workgroup: unpredicated batches while every live lane still has a
- *  whole batch of columns, then a tail predicated on each lane's own length.  `unroll_`: columns per copy of the column body.
- */
-template <int words_, int text_dwords_, int unroll_ = 4 * text_dwords_>
+ *  whole batch of columns, then a tail predicated on each lane's own length. */
+template <int words_, int text_dwords_>
 __device__ __forceinline__ void queue_lanes(u32 const *peq, szs_string_ref_t const query, szs_string_ref_t const *__restrict__ candidates,
                                             u32 lo, u32 hi, u64 *__restrict__ results, u64 results_row_stride, int layout) {
     u32 const slot = lo + (threadIdx.x & 63u);
@@ -94,10 +93,37 @@ __device__ __forceinline__ void queue_lanes(u32 const *peq, szs_string_ref_t con
 #pragma unroll
             for (int d = 0; d < text_dwords_; ++d)
                 ahead[d] = clamped_reads ? text.raw_clamped(dword + text_dwords_ + 1 + d) : text.raw(dword + text_dwords_ + 1 + d);
-            // (the widest bodies take their columns one or two at a time: unrolled by four, hipcc hoists the mask reads of all
-            //  four columns and the 16-word body spills 29 registers of the 128 that four wavefronts per SIMD leave a lane)
-#pragma unroll unroll_
-            for (int step = 0; step < 4 * text_dwords_; ++step) take((symbols[step / 4] >> (8 * (step % 4))) & 0xFFu);
+            if constexpr (words_ <= 8) {
+#pragma unroll
+                for (int step = 0; step < 4 * text_dwords_; ++step) take((symbols[step / 4] >> (8 * (step % 4))) & 0xFFu);
+            }
+            else {
+                // Ten words and more: left alone, hipcc hoists the mask reads of all four columns and the 16-word body spills 29 of
+                // the 128 registers that four wavefronts per SIMD leave a lane; fenced column by column the reads wait for nothing
+                // but also overlap nothing.  So only the FIRST chunk of the next column is fetched ahead (the carry chain starts
+                // there); the other chunks are issued when the column begins and arrive under its first words.
+                static_assert(text_dwords_ == 1, "four columns per iteration");
+                uint4 const *const rows = reinterpret_cast<uint4 const *>(peq);
+                constexpr int chunks = peq_layout<words_>::chunks;
+                uint4 first = rows[symbols[0] & 0xFFu];
+#pragma unroll
+                for (int step = 0; step < 4; ++step) {
+                    u32 const symbol = (symbols[0] >> (8 * step)) & 0xFFu;
+                    u32 eq[words_];
+                    eq[0] = first.x, eq[1] = first.y, eq[2] = first.z, eq[3] = first.w;
+#pragma unroll
+                    for (int chunk = 1; chunk < chunks; ++chunk) {
+                        uint4 const row = rows[chunk * byte_rows_k + symbol];
+                        if (chunk * 4 + 0 < words_) eq[chunk * 4 + 0] = row.x;
+                        if (chunk * 4 + 1 < words_) eq[chunk * 4 + 1] = row.y;
+                        if (chunk * 4 + 2 < words_) eq[chunk * 4 + 2] = row.z;
+                        if (chunk * 4 + 3 < words_) eq[chunk * 4 + 3] = row.w;
+                    }
+                    if (step < 3) first = rows[(symbols[0] >> (8 * (step + 1))) & 0xFFu];
+                    myers_column<words_>(vp, vn, eq);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
     }
     if (column < longest_in_wave) { // ragged tail: one dword per iteration, each column predicated on this lane's own length
@@ -125,11 +151,37 @@ __device__ __forceinline__ void queue_lanes(u32 const *peq, szs_string_ref_t con
 }
 
 /**
+ *  The text of a lane that runs `delay` columns behind its team's first lane: the string as if it began `delay` bytes earlier.
+ *  Only aligned dwords that hold at least one byte of the string are ever loaded (text_stream_t's rule: such a dword lies in a
+ *  page the caller owns); the bytes "before" the string read as zero and belong to columns the lane does not score.
+ */
+struct delayed_text_t {
+    u32 const *aligned_base;
+    u32 byte_shift, first_valid, valid_dwords;
+    __device__ __forceinline__ delayed_text_t(u64 address, u32 length, u32 delay) {
+        u64 const from = address - delay;
+        aligned_base = reinterpret_cast<u32 const *>(from & ~(u64)3);
+        byte_shift = (u32)(from & 3);
+        first_valid = (u32)(((address & ~(u64)3) - (from & ~(u64)3)) >> 2);
+        valid_dwords = length ? (byte_shift + delay + length + 3) / 4 : 0;
+    }
+    __device__ __forceinline__ u32 raw(u32 dword_index) const {
+        return dword_index >= first_valid && dword_index < valid_dwords ? aligned_base[dword_index] : 0u;
+    }
+    __device__ __forceinline__ u32 splice(u32 raw_low, u32 raw_high) const { return __builtin_amdgcn_alignbyte(raw_high, raw_low, byte_shift); }
+};
+
+/**
  *  One wavefront, `lanes` adjacent lanes per pair (2 ... 16, any value: a DPP row of 16 lanes holds 16 / lanes teams, the rest
  *  of the row idles): lane k of a team holds words [k w, (k + 1) w) of the pattern's bit-vector and runs k columns behind lane
- *  k - 1; the horizontal deltas under its last row travel with the text byte in one `v_mov_b32_dpp row_shr:1` per column
- *  (lev_myers.hip: levenshtein_myers_split_kernel, with the lane count a run-time value).  Candidates [lo, hi): at most
- *  4 x (16 / lanes) of them.
+ *  k - 1 - a systolic strip pipeline inside the wavefront, as in lev_myers.hip's levenshtein_myers_split_kernel.  What differs:
+ *   - every lane reads the text itself, `k` bytes behind (delayed_text_t; the team's lanes hit the same cache lines), so only
+ *     the two delta bits under a strip's last row travel - one `v_mov_b32_dpp row_shr:1` of a 2-bit value per column, no symbol,
+ *     no valid flag, nothing to pack or unpack;
+ *   - while EVERY lane of the wavefront is inside its text (from step lanes - 1 to the shortest text) four columns run without
+ *     a predicate or a branch, their mask reads ahead of the arithmetic; only the fill and the drain test each column.
+ *  With four words per lane the old form spent as many instructions on the hand-over as on the column (profiles/r04).
+ *  Candidates [lo, hi): at most 4 x (16 / lanes) of them.
  */
 template <int words_per_lane_>
 __device__ __forceinline__ void queue_team(u32 const *peq, u32 lanes, szs_string_ref_t const query,
@@ -149,6 +201,7 @@ __device__ __forceinline__ void queue_team(u32 const *peq, u32 lanes, szs_string
     u32 const pad = 32u * words_per_lane_ * lanes - query_length; // phantom low rows: whole lanes of them are inert too
     u32 const text_length = live ? candidate.length : 0;
     u32 const longest_in_wave = wave_max_u32(text_length);
+    u32 const shortest_in_wave = ~wave_max_u32(live ? ~text_length : 0u); // over live lanes; no live lane: ~0, unused
     bool const head = part == 0;
 
     u32 vp[words_per_lane_], vn[words_per_lane_];
@@ -160,34 +213,68 @@ __device__ __forceinline__ void queue_team(u32 const *peq, u32 lanes, szs_string
     }
     // this lane's chunks of the masks: chunk c of byte s at uint4 index c * 256 + s
     uint4 const *const my_rows = reinterpret_cast<uint4 const *>(peq) + part * chunks_per_lane * byte_rows_k;
+    auto masks_of = [&](u32 symbol, u32 (&eq)[words_per_lane_]) {
+#pragma unroll
+        for (int chunk = 0; chunk < chunks_per_lane; ++chunk) {
+            uint4 const row = my_rows[chunk * byte_rows_k + symbol];
+            eq[chunk * 4 + 0] = row.x, eq[chunk * 4 + 1] = row.y, eq[chunk * 4 + 2] = row.z, eq[chunk * 4 + 3] = row.w;
+        }
+    };
 
-    // only the head lane of a team reads the text; the others receive every byte from their neighbour
-    text_stream_t text(candidate.address, head ? text_length : 0u);
+    delayed_text_t const text(candidate.address, text_length, part);
     u32 raw_low = text.raw(0), next = text.raw(1);
-    u32 incoming = 0; // from the lane below: symbol (8 bits) | hp << 8 | hn << 9 | valid << 10 of the column it has just finished
+    u32 incoming = 0; // the two delta bits (hp | hn << 1) the lane below produced for the column this lane takes next
     u32 const steps = longest_in_wave ? longest_in_wave + lanes - 1 : 0;
 #pragma unroll 1
     for (u32 step = 0, dword = 0; step < steps; step += 4, ++dword) {
         u32 const symbols = text.splice(raw_low, next);
         raw_low = next, next = text.raw(dword + 2);
+        if (step + 1 >= lanes && step + 4 <= shortest_in_wave) { // every lane of every live team is inside its text: no tests
+            auto column = [&](u32 const (&eq)[words_per_lane_]) {
+                u32 const entering = head ? 1u : incoming; // DP row 0 grows by one per column
+                u32 const leaving = myers_strip_column<words_per_lane_>(vp, vn, eq, entering & 1u, entering >> 1);
+                // row_shr:1 - every lane takes its lower neighbour's bits; the first lane of a row of 16 (always a head) takes zero
+                incoming = (u32)__builtin_amdgcn_update_dpp(0, (int)leaving, 0x111, 0xF, 0xF, true);
+            };
+            if constexpr (words_per_lane_ <= 8) { // few enough registers: all four columns' masks ahead of the arithmetic
+                u32 eq[4][words_per_lane_];
 #pragma unroll
-        for (u32 sub = 0; sub < 4; ++sub) {
-            u32 const symbol = head ? (symbols >> (8 * sub)) & 0xFFu : incoming & 0xFFu;
-            u32 const hp_in = head ? 1u : (incoming >> 8) & 1u; // DP row 0 grows by one per column
-            u32 const hn_in = head ? 0u : (incoming >> 9) & 1u;
-            bool const active = head ? step + sub < text_length : ((incoming >> 10) & 1u) != 0;
-            u32 outgoing = 0;
-            if (active) {
-                u32 eq[words_per_lane_];
+                for (u32 sub = 0; sub < 4; ++sub) masks_of((symbols >> (8 * sub)) & 0xFFu, eq[sub]);
 #pragma unroll
-                for (int chunk = 0; chunk < chunks_per_lane; ++chunk) {
-                    uint4 const row = my_rows[chunk * byte_rows_k + symbol];
-                    eq[chunk * 4 + 0] = row.x, eq[chunk * 4 + 1] = row.y, eq[chunk * 4 + 2] = row.z, eq[chunk * 4 + 3] = row.w;
-                }
-                outgoing = symbol | (myers_strip_column<words_per_lane_>(vp, vn, eq, hp_in, hn_in) << 8) | (1u << 10);
+                for (u32 sub = 0; sub < 4; ++sub) column(eq[sub]);
             }
-            // row_shr:1 - every lane takes its lower neighbour's word; the first lane of a row of 16 (always a head) takes zero
-            incoming = (u32)__builtin_amdgcn_update_dpp(0, (int)outgoing, 0x111, 0xF, 0xF, true);
+            else { // twelve and sixteen words: only the FIRST chunk of the next column's masks is fetched ahead (the carry chain
+                   // starts there; the other chunks arrive under it) - left alone, hipcc hoists the reads of all four columns
+                   // and spills 41 / 86 registers; a whole column ahead still spills 26 / 81
+                uint4 first = my_rows[symbols & 0xFFu];
+#pragma unroll
+                for (u32 sub = 0; sub < 4; ++sub) {
+                    u32 const symbol = (symbols >> (8 * sub)) & 0xFFu;
+                    u32 eq[words_per_lane_];
+                    eq[0] = first.x, eq[1] = first.y, eq[2] = first.z, eq[3] = first.w;
+#pragma unroll
+                    for (int chunk = 1; chunk < chunks_per_lane; ++chunk) {
+                        uint4 const row = my_rows[chunk * byte_rows_k + symbol];
+                        eq[chunk * 4 + 0] = row.x, eq[chunk * 4 + 1] = row.y, eq[chunk * 4 + 2] = row.z, eq[chunk * 4 + 3] = row.w;
+                    }
+                    if (sub < 3) first = my_rows[(symbols >> (8 * (sub + 1))) & 0xFFu];
+                    column(eq);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        else {
+#pragma unroll
+            for (u32 sub = 0; sub < 4; ++sub) {
+                u32 leaving = 0;
+                if (step + sub - part < text_length) { // this lane's column: step + sub - part (unsigned: not before its first)
+                    u32 eq[words_per_lane_];
+                    masks_of((symbols >> (8 * sub)) & 0xFFu, eq);
+                    u32 const entering = head ? 1u : incoming;
+                    leaving = myers_strip_column<words_per_lane_>(vp, vn, eq, entering & 1u, entering >> 1);
+                }
+                incoming = (u32)__builtin_amdgcn_update_dpp(0, (int)leaving, 0x111, 0xF, 0xF, true);
+            }
         }
     }
 
@@ -316,7 +403,7 @@ __global__ __launch_bounds__(queue_threads_k, 4 /* wavefronts per SIMD: two work
                 u32 const lo = hi - c_lo > pairs_per_wave ? hi - pairs_per_wave : c_lo;
                 szs_string_ref_t const query = queries[q_first + done + g];
                 u32 const *const table = peq + g * slot_dwords;
-#define SZS_QUEUE_LANES(W, D, ...) queue_lanes<W, D, ##__VA_ARGS__>(table, query, candidates, lo, hi, results, results_row_stride, layout)
+#define SZS_QUEUE_LANES(W, D) queue_lanes<W, D>(table, query, candidates, lo, hi, results, results_row_stride, layout)
 #define SZS_QUEUE_TEAM(W) queue_team<W>(table, lanes, query, candidates, lo, hi, results, results_row_stride, layout)
                 if (lanes > 1u) {
                     switch (words_per_lane) {
@@ -337,8 +424,8 @@ __global__ __launch_bounds__(queue_threads_k, 4 /* wavefronts per SIMD: two work
                     case 7: SZS_QUEUE_LANES(7, 2); break;
                     case 8: SZS_QUEUE_LANES(8, 2); break;
                     case 10: SZS_QUEUE_LANES(10, 1); break;
-                    case 12: SZS_QUEUE_LANES(12, 1, 2); break;
-                    default: SZS_QUEUE_LANES(16, 1, 1); break;
+                    case 12: SZS_QUEUE_LANES(12, 1); break;
+                    default: SZS_QUEUE_LANES(16, 1); break;
                     }
                 }
 #undef SZS_QUEUE_LANES

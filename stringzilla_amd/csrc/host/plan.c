@@ -138,18 +138,19 @@ void szs_plan_build(unsigned myers, int symmetric, uint64_t const *query_address
 
 /*
  *  The model.  A workgroup of the persistent kernel is eight wavefronts behind one query's match masks; one of its work items
- *  is that query against S candidates.  A lane that holds `w` words of a pattern takes ~`SZS_QUEUE_WORD_COLUMN_NS` per text
+ *  is a few queries against S candidates.  A lane that holds `w` words of a pattern takes ~`SZS_QUEUE_WORD_COLUMN_NS` per text
  *  column and word on a busy device (10.5 instructions, four wavefronts taking turns on a SIMD: profiles/r04), so
- *      one round of an item ~ w x (longest candidate of its column) x that,
- *  and nothing shortens it but more lanes per pair.  The call as a whole takes ~cells / SZS_QUEUE_CELLS_PER_NS.  A round must be a
- *  small part of that - a third at most - or the call ends waiting for it: that bounds the words per lane (16, 12, 8, 4: a
- *  whole-device batch keeps 16, one GPU's eighth of a Zipf batch goes down to 4 - sixteen lanes for a 2048-byte query).  An
+ *      one wave block ~ w x (longest candidate of its column) x that,
+ *  and nothing shortens it but more lanes per pair.  The call as a whole takes ~cells / SZS_QUEUE_CELLS_PER_NS.  A wave block
+ *  must stay under 0.6 of that even when it starts first, or the call ends waiting for it: that bounds the words per lane,
+ *  column by column (16, 12, 8, 4: a whole-device batch keeps 16 everywhere; one GPU's eighth of a Zipf batch goes down to 4 -
+ *  sixteen lanes for a 2048-byte query - against its longest candidates only).  An
  *  item is several rounds while it stays under a sixteenth of the call (the masks are built once per item, and eight
  *  wavefronts that draw several rounds of (candidate block, query) pairs balance each other: more is better while the queue's
  *  end stays fine-grained) - first as many QUERIES as the 64-word table of a workgroup takes side by side, then candidates.  Tiles are sorted by rounds x words per lane x longest candidate: longest-processing-time-first list
  *  scheduling of the workgroup slots.
  */
-#define SZS_QUEUE_WORD_COLUMN_NS 60.0
+#define SZS_QUEUE_WORD_COLUMN_NS 90.0
 #define SZS_QUEUE_CELLS_PER_NS 9.0e4 /* 90 TCUPS */
 #define SZS_QUEUE_MOST_SLICES 12u
 #define SZS_QUEUE_MOST_COLUMNS 8u
@@ -188,12 +189,10 @@ void szs_plan_queue(szs_plan_t const *plan, uint32_t queries_count, uint32_t can
     if (!queries_count || !candidates_count) return;
     uint32_t const longest_candidate = plan->longest_candidate ? plan->longest_candidate : 1u;
     double const call_ns = (double)plan->cells / SZS_QUEUE_CELLS_PER_NS;
-    double const round_ns = call_ns / 3.0;
-    /* the most words one lane may hold: the largest of 16 / 12 / 8 / 4 whose round against the longest candidate fits */
+    /* what one wave block may take of the call: the words one lane holds x the longest candidate of the tile's column, at the
+     * per-word-column time of a busy device, must stay under it (the `queue_words` knob pins the words instead) */
+    double const round_ns = call_ns * 0.6;
     int const words_knob = szs_tuning_get(szs_knob_queue_words_k);
-    double const fitting = round_ns / (SZS_QUEUE_WORD_COLUMN_NS * longest_candidate);
-    unsigned most = fitting >= 16 ? 16u : fitting >= 12 ? 12u : fitting >= 8 ? 8u : 4u;
-    if (words_knob == 4 || words_knob == 8 || words_knob == 12 || words_knob == 16) most = (unsigned)words_knob;
 
     /* ---- slices of the queries: every width group of the plan, cut further where the sampled lengths fall by a quarter */
     queue_slice_t slices[SZS_QUEUE_MOST_SLICES];
@@ -221,7 +220,6 @@ void szs_plan_queue(szs_plan_t const *plan, uint32_t queries_count, uint32_t can
         }
     }
     if (!slices_count) return;
-    for (unsigned i = 0; i < slices_count; ++i) queue_shape(words_of(slices[i].bound), most, &slices[i].words_per_lane, &slices[i].lanes);
 
     /* ---- columns of the candidates: cut where the sampled lengths have fallen to 0.6 of the column's longest, so that the
      * items of a tile are alike (equal counts would put 700 ... 1900-byte texts of a Zipf batch into one column) */
@@ -250,8 +248,15 @@ void szs_plan_queue(szs_plan_t const *plan, uint32_t queries_count, uint32_t can
     unsigned tiles = 0;
     for (unsigned column = 0; column < columns; ++column) {
         uint32_t const begin = column_begin[column], end = column_end[column], longest = column_longest[column];
+        /* the most words one lane may hold against THIS column: the largest of 16 / 12 / 8 / 4 whose wave block fits.  The shape
+         * follows the column - an eighth of a Zipf batch spreads a 2048-byte query over sixteen lanes against its 2000-byte
+         * candidates only, and keeps four lanes of sixteen words (a third fewer instructions) against the short ones */
+        double const fitting = round_ns / (SZS_QUEUE_WORD_COLUMN_NS * longest);
+        unsigned most = fitting >= 16 ? 16u : fitting >= 12 ? 12u : fitting >= 8 ? 8u : 4u;
+        if (words_knob == 4 || words_knob == 8 || words_knob == 12 || words_knob == 16) most = (unsigned)words_knob;
         for (unsigned i = 0; i < slices_count; ++i) {
-            queue_slice_t const *slice = &slices[i];
+            queue_slice_t *slice = &slices[i];
+            queue_shape(words_of(slice->bound), most, &slice->words_per_lane, &slice->lanes);
             szs_queue_tile_t *tile = &queue->tiles[tiles];
             unsigned const bound_words = words_of(slice->bound);
             unsigned const lane_words = slice->lanes > 1 ? slice->words_per_lane : bound_words;

@@ -112,10 +112,13 @@ def test_tiles_come_longest_first_and_shapes_follow_the_call():
         # (one-lane tiles are keyed by their slice's bound, which the probe does not return: check the team tiles' order)
         keys = [key(tile) for tile in team_tiles if tile[4] - tile[3] > 0]
         assert all(earlier * 1.6 >= later for earlier, later in zip(keys, keys[1:])), keys  # sampled lengths: nearly sorted
-    widest = lambda tiles: max(tile[6] for tile in tiles if tile[7] > 1)
-    assert widest(whole) >= 12 and widest(eighth) <= 8, (widest(whole), widest(eighth))  # a short call spreads its pairs wider
-    most_lanes = lambda tiles: max(tile[7] for tile in tiles)
-    assert most_lanes(eighth) > most_lanes(whole)
+    # the shape follows the size of the call AND the column: against its longest candidates a short call spreads a pair over
+    # more lanes of fewer words; against short candidates it keeps the wide lanes (a third fewer instructions)
+    top = lambda tiles: [tile for tile in tiles if tile[7] > 1 and tile[4] == len(candidates)]
+    low = lambda tiles: [tile for tile in tiles if tile[7] > 1 and int(ascending[tile[4] - 1]) < 100]
+    assert max(tile[6] for tile in top(whole)) >= 12 and max(tile[6] for tile in top(eighth)) <= 8
+    assert max(tile[7] for tile in top(eighth)) > max(tile[7] for tile in top(whole))
+    assert low(eighth) and min(tile[6] for tile in low(eighth)) >= 12
 
 
 def test_knobs_pin_the_shape():
