@@ -32,8 +32,19 @@
 
 namespace szs_hip {
 
+/** The workgroup's match-mask table: 64 words x 256 rows x 4 bytes of DYNAMIC LDS, so that the bodies below - functions of
+ *  their own, see queue_lanes - address it as LDS (`ds_read_b128`) without being handed a generic pointer. */
+extern __shared__ __attribute__((aligned(16))) u32 queue_arena[];
+
+__device__ __forceinline__ u32 uniform(u32 value) { return __builtin_amdgcn_readfirstlane(value); }
+__device__ __forceinline__ u64 uniform(u64 value) { return ((u64)uniform((u32)(value >> 32)) << 32) | uniform((u32)value); }
+template <typename pointee_> __device__ __forceinline__ pointee_ *uniform(pointee_ *pointer) {
+    return reinterpret_cast<pointee_ *>(uniform((u64) reinterpret_cast<uintptr_t>(pointer)));
+}
+
 constexpr u32 queue_threads_k = 512;        // eight wavefronts share one query's match masks
 constexpr int queue_widest_k = 64;          // words of the widest pattern: 2048 bytes, 64 KB of masks
+constexpr size_t queue_arena_bytes_k = (size_t)queue_widest_k * byte_rows_k * sizeof(u32);
 constexpr u32 queue_pattern_reads_k = (32u * queue_widest_k + queue_threads_k - 1) / queue_threads_k; // pattern bytes per thread
 
 /** dword index of word `w` of byte `row`'s mask: rows of `row_words` = 1, 2 or 4 words, chunk-major (peq_layout). */
@@ -46,8 +57,15 @@ __device__ __forceinline__ u32 queue_mask_index(u32 row_words, u32 row, u32 w) {
  *  are in `peq`.  The lane loop of lev_myers.hip's myers_workgroup: unpredicated batches while every live lane still has a
  *  whole batch of columns, then a tail predicated on each lane's own length. */
 template <int words_, int text_dwords_>
-__device__ __forceinline__ void queue_lanes(u32 const *peq, szs_string_ref_t const query, szs_string_ref_t const *__restrict__ candidates,
-                                            u32 lo, u32 hi, u64 *__restrict__ results, u64 results_row_stride, int layout) {
+__device__ __attribute__((noinline)) void queue_lanes(u32 table_offset, szs_string_ref_t query, szs_string_ref_t const *__restrict__ candidates,
+                                                      u32 lo, u32 hi, u64 *__restrict__ results, u64 results_row_stride, int layout) {
+    // A FUNCTION, not inlined: inside the persistent kernel the fifteen bodies shared one register allocation, and what the widest
+    // of them needed spilled in the loops of the narrowest (1024 x 1024 x 128 bytes: 77 -> 56 TCUPS when the team bodies grew).
+    // Arguments arrive in vector registers; what is uniform goes back to scalars here.
+    u32 const *const peq = queue_arena + uniform(table_offset);
+    query.address = uniform(query.address), query.length = uniform(query.length), query.index = uniform(query.index);
+    candidates = uniform(candidates), results = uniform(results), results_row_stride = uniform(results_row_stride);
+    lo = uniform(lo), hi = uniform(hi), layout = (int)uniform((u32)layout);
     u32 const slot = lo + (threadIdx.x & 63u);
     bool live = slot < hi;
     szs_string_ref_t candidate = {0, 0, 0};
@@ -184,10 +202,14 @@ struct delayed_text_t {
  *  Candidates [lo, hi): at most 4 x (16 / lanes) of them.
  */
 template <int words_per_lane_>
-__device__ __forceinline__ void queue_team(u32 const *peq, u32 lanes, szs_string_ref_t const query,
-                                           szs_string_ref_t const *__restrict__ candidates, u32 lo, u32 hi,
-                                           u64 *__restrict__ results, u64 results_row_stride, int layout) {
+__device__ __attribute__((noinline)) void queue_team(u32 table_offset, u32 lanes, szs_string_ref_t query,
+                                                     szs_string_ref_t const *__restrict__ candidates, u32 lo, u32 hi,
+                                                     u64 *__restrict__ results, u64 results_row_stride, int layout) {
     static_assert(words_per_lane_ % 4 == 0, "whole 16-byte chunks of the masks per lane");
+    u32 const *const peq = queue_arena + uniform(table_offset); // (a function of its own: see queue_lanes)
+    query.address = uniform(query.address), query.length = uniform(query.length), query.index = uniform(query.index);
+    candidates = uniform(candidates), results = uniform(results), results_row_stride = uniform(results_row_stride);
+    lo = uniform(lo), hi = uniform(hi), layout = (int)uniform((u32)layout), lanes = uniform(lanes);
     constexpr int chunks_per_lane = words_per_lane_ / 4;
     u32 const lane = threadIdx.x & 63u, row_lane = lane & 15u;
     u32 const teams_per_row = 16u / lanes;
@@ -312,7 +334,7 @@ __device__ __forceinline__ u32 queue_body_words(u32 needed) { return needed <= 8
 __global__ __launch_bounds__(queue_threads_k, 4 /* wavefronts per SIMD: two workgroups per CU */) void levenshtein_myers_queue_kernel(
     szs_string_ref_t const *__restrict__ queries, szs_string_ref_t const *__restrict__ candidates, u64 *__restrict__ results,
     u64 results_row_stride, int layout, u32 *__restrict__ tickets, u32 ticket_base, szs_queue_plan_t plan) {
-    __shared__ __attribute__((aligned(16))) u32 peq[peq_layout<queue_widest_k>::total_dwords];
+    u32 *const peq = queue_arena; // peq_layout<queue_widest_k>::total_dwords dwords of dynamic LDS
     __shared__ u32 next_ticket, wave_ticket;
 
     u32 const tid = threadIdx.x;
@@ -402,7 +424,7 @@ __global__ __launch_bounds__(queue_threads_k, 4 /* wavefronts per SIMD: two work
                 u32 const hi = c_hi - candidate_block * pairs_per_wave;
                 u32 const lo = hi - c_lo > pairs_per_wave ? hi - pairs_per_wave : c_lo;
                 szs_string_ref_t const query = queries[q_first + done + g];
-                u32 const *const table = peq + g * slot_dwords;
+                u32 const table = g * slot_dwords;
 #define SZS_QUEUE_LANES(W, D) queue_lanes<W, D>(table, query, candidates, lo, hi, results, results_row_stride, layout)
 #define SZS_QUEUE_TEAM(W) queue_team<W>(table, lanes, query, candidates, lo, hi, results, results_row_stride, layout)
                 if (lanes > 1u) {
@@ -448,7 +470,9 @@ static u32 queue_grid(u64 items) {
         int device = 0, units = 0, per_unit = 0;
         if (hipGetDevice(&device) != hipSuccess ||
             hipDeviceGetAttribute(&units, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_unit, levenshtein_myers_queue_kernel, (int)queue_threads_k, 0) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<void const *>(levenshtein_myers_queue_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)queue_arena_bytes_k) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_unit, levenshtein_myers_queue_kernel, (int)queue_threads_k, queue_arena_bytes_k) != hipSuccess ||
             units <= 0 || per_unit <= 0) {
             (void)hipGetLastError();
             units = 256, per_unit = 2;
@@ -470,7 +494,7 @@ extern "C" int szs_hip_levenshtein_myers_queue(szs_queue_plan_t const *plan, szs
     if (!plan->items_total) return 0;
     if (plan->tiles_count > SZS_QUEUE_MOST_TILES) return (int)hipErrorInvalidValue;
     u32 const grid = queue_grid(plan->items_total);
-    hipLaunchKernelGGL(levenshtein_myers_queue_kernel, dim3(grid), dim3(queue_threads_k), 0, static_cast<hipStream_t>(stream), queries,
+    hipLaunchKernelGGL(levenshtein_myers_queue_kernel, dim3(grid), dim3(queue_threads_k), queue_arena_bytes_k, static_cast<hipStream_t>(stream), queries,
                        candidates, results, results_row_stride, layout, tickets, ticket_base, *plan);
     hipError_t const error = hipGetLastError();
     if (error == hipSuccess) *tickets_taken = plan->items_total + grid;

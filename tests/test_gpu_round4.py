@@ -50,7 +50,8 @@ def test_a_mixed_width_call_is_one_launch(gpu, oracle):
     candidates = _rand(rng, 70, 0, 300, b"ACGT") + [queries[9], queries[-1][:1900], b""]
     engine = szs.LevenshteinDistances(capabilities=gpu)
     expected = oracle.levenshtein(queries, candidates)
-    with knob("tier", "lanes"):  # 38 x 73 pairs: left alone, the planner would hand this batch to the chained tier
+    # 38 x 73 pairs: left alone, the planner would hand this batch to the chained tier, or put the 73 candidates on the workgroups
+    with knob("tier", "lanes"), knob("swap", 0):
         got = engine(queries, candidates, device=gpu)
         profile = engine.last_call_profile()
         assert np.array_equal(got, expected), np.argwhere(got != expected)[:5].tolist()
@@ -58,9 +59,8 @@ def test_a_mixed_width_call_is_one_launch(gpu, oracle):
         assert profile.cells == sum(map(len, queries)) * sum(map(len, candidates))
         # queries beyond 2048 bytes keep the strip kernel: one more launch, not one per width
         longer = queries + [bytes(rng.choice(b"ACGT") for _ in range(n)) for n in (2049, 2600)]
-        with knob("swap", 0):  # (left alone, the planner would put the 73 candidates - none beyond 2048 bytes - on the workgroups)
-            assert np.array_equal(engine(longer, candidates, device=gpu), oracle.levenshtein(longer, candidates))
-            assert engine.last_call_profile().launches == 2
+        assert np.array_equal(engine(longer, candidates, device=gpu), oracle.levenshtein(longer, candidates))
+        assert engine.last_call_profile().launches == 2
         # the per-width launches score the same cells
         with knob("queue", 0):
             assert np.array_equal(engine(queries, candidates, device=gpu), expected)
