@@ -165,7 +165,10 @@ typedef struct szs_queue_plan_t {
  */
 int szs_hip_levenshtein_myers_queue(szs_queue_plan_t const *plan, szs_string_ref_t const *queries, szs_string_ref_t const *candidates,
                                     uint64_t *results, uint64_t results_row_stride, int layout, uint32_t *tickets, uint32_t ticket_base,
-                                    uint32_t *tickets_taken, void *stream);
+                                    uint32_t *tickets_taken, uint64_t *trace /* NULL, or 3 x szs_hip_levenshtein_myers_queue_grid(items)
+                                    qwords of device memory: per workgroup its first and last 100 MHz tick and the items it took */,
+                                    void *stream);
+unsigned szs_hip_levenshtein_myers_queue_grid(uint64_t items);
 
 /* ---- tuning knobs (host/tuning.c): read from the environment ONCE at load, changed only by szs_rocm_tuning_set -------- */
 

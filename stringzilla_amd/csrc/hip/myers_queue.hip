@@ -190,16 +190,18 @@ struct delayed_text_t {
 };
 
 /**
- *  One wavefront, `lanes` adjacent lanes per pair (2 ... 16, any value: a DPP row of 16 lanes holds 16 / lanes teams, the rest
- *  of the row idles): lane k of a team holds words [k w, (k + 1) w) of the pattern's bit-vector and runs k columns behind lane
- *  k - 1 - a systolic strip pipeline inside the wavefront, as in lev_myers.hip's levenshtein_myers_split_kernel.  What differs:
+ *  One wavefront, `lanes` adjacent lanes per pair (2 ... 16, any value: the wavefront holds 64 / lanes teams, whatever is left
+ *  over idles - the deltas move by `wave_shr:1`, which crosses the rows of 16 that `row_shr` stops at, so a team of 12 lanes
+ *  wastes 4 lanes of 64, not 4 of 16): lane k of a team holds words [k w, (k + 1) w) of the pattern's bit-vector and runs k
+ *  columns behind lane k - 1 - a systolic strip pipeline inside the wavefront, as in lev_myers.hip's
+ *  levenshtein_myers_split_kernel.  What differs:
  *   - every lane reads the text itself, `k` bytes behind (delayed_text_t; the team's lanes hit the same cache lines), so only
  *     the two delta bits under a strip's last row travel - one `v_mov_b32_dpp row_shr:1` of a 2-bit value per column, no symbol,
  *     no valid flag, nothing to pack or unpack;
  *   - while EVERY lane of the wavefront is inside its text (from step lanes - 1 to the shortest text) four columns run without
  *     a predicate or a branch, their mask reads ahead of the arithmetic; only the fill and the drain test each column.
  *  With four words per lane the old form spent as many instructions on the hand-over as on the column (profiles/r04).
- *  Candidates [lo, hi): at most 4 x (16 / lanes) of them.
+ *  Candidates [lo, hi): at most 64 / lanes of them.
  */
 template <int words_per_lane_>
 __device__ __attribute__((noinline)) void queue_team(u32 table_offset, u32 lanes, szs_string_ref_t query,
@@ -211,11 +213,11 @@ __device__ __attribute__((noinline)) void queue_team(u32 table_offset, u32 lanes
     candidates = uniform(candidates), results = uniform(results), results_row_stride = uniform(results_row_stride);
     lo = uniform(lo), hi = uniform(hi), layout = (int)uniform((u32)layout), lanes = uniform(lanes);
     constexpr int chunks_per_lane = words_per_lane_ / 4;
-    u32 const lane = threadIdx.x & 63u, row_lane = lane & 15u;
-    u32 const teams_per_row = 16u / lanes;
-    u32 const team_in_row = row_lane / lanes, part = row_lane - team_in_row * lanes;
-    u32 const slot = lo + (lane >> 4) * teams_per_row + team_in_row;
-    bool live = team_in_row < teams_per_row && slot < hi;
+    u32 const lane = threadIdx.x & 63u;
+    u32 const teams_per_wave = 64u / lanes;
+    u32 const team = lane / lanes, part = lane - team * lanes;
+    u32 const slot = lo + team;
+    bool live = team < teams_per_wave && slot < hi;
     szs_string_ref_t candidate = {0, 0, 0};
     if (live) candidate = candidates[slot];
     if ((layout & SZS_LAYOUT_SYMMETRIC) && candidate.index > query.index) live = false;
@@ -255,8 +257,8 @@ __device__ __attribute__((noinline)) void queue_team(u32 table_offset, u32 lanes
             auto column = [&](u32 const (&eq)[words_per_lane_]) {
                 u32 const entering = head ? 1u : incoming; // DP row 0 grows by one per column
                 u32 const leaving = myers_strip_column<words_per_lane_>(vp, vn, eq, entering & 1u, entering >> 1);
-                // row_shr:1 - every lane takes its lower neighbour's bits; the first lane of a row of 16 (always a head) takes zero
-                incoming = (u32)__builtin_amdgcn_update_dpp(0, (int)leaving, 0x111, 0xF, 0xF, true);
+                // wave_shr:1 - every lane takes its lower neighbour's bits; lane 0 (always a head) takes zero
+                incoming = (u32)__builtin_amdgcn_update_dpp(0, (int)leaving, 0x138, 0xF, 0xF, true);
             };
             if constexpr (words_per_lane_ <= 8) { // few enough registers: all four columns' masks ahead of the arithmetic
                 u32 eq[4][words_per_lane_];
@@ -295,7 +297,7 @@ __device__ __attribute__((noinline)) void queue_team(u32 table_offset, u32 lanes
                     u32 const entering = head ? 1u : incoming;
                     leaving = myers_strip_column<words_per_lane_>(vp, vn, eq, entering & 1u, entering >> 1);
                 }
-                incoming = (u32)__builtin_amdgcn_update_dpp(0, (int)leaving, 0x111, 0xF, 0xF, true);
+                incoming = (u32)__builtin_amdgcn_update_dpp(0, (int)leaving, 0x138, 0xF, 0xF, true);
             }
         }
     }
@@ -307,7 +309,7 @@ __device__ __attribute__((noinline)) void queue_team(u32 table_offset, u32 lanes
         return delta;
     }();
     i32 delta = mine;
-    for (u32 k = 1; k < lanes; ++k) delta += __shfl_down(mine, k, 64); // the head adds up its team (same row, lanes above it)
+    for (u32 k = 1; k < lanes; ++k) delta += __shfl_down(mine, k, 64); // the head adds up its team (the lanes above it)
     if (live && head) {
         u64 const distance = (u64)((i64)text_length + delta);
         bool const transposed = (layout & SZS_LAYOUT_TRANSPOSED) != 0;
@@ -333,17 +335,21 @@ __device__ __forceinline__ u32 queue_body_words(u32 needed) { return needed <= 8
  */
 __global__ __launch_bounds__(queue_threads_k, 4 /* wavefronts per SIMD: two workgroups per CU */) void levenshtein_myers_queue_kernel(
     szs_string_ref_t const *__restrict__ queries, szs_string_ref_t const *__restrict__ candidates, u64 *__restrict__ results,
-    u64 results_row_stride, int layout, u32 *__restrict__ tickets, u32 ticket_base, szs_queue_plan_t plan) {
+    u64 results_row_stride, int layout, u32 *__restrict__ tickets, u32 ticket_base, u64 *__restrict__ trace, szs_queue_plan_t plan) {
     u32 *const peq = queue_arena; // peq_layout<queue_widest_k>::total_dwords dwords of dynamic LDS
     __shared__ u32 next_ticket, wave_ticket;
 
     u32 const tid = threadIdx.x;
+    // measuring aid (`trace` knob): when every workgroup began and ended, in 100 MHz ticks, and how many items it took
+    u64 const began = trace ? wall_clock64() : 0;
+    u32 items_taken = 0;
     if (tid == 0) next_ticket = atomicAdd(tickets, 1u) - ticket_base;
     __syncthreads();
     u32 tile_index = 0;
     for (;;) {
         u32 const item = __builtin_amdgcn_readfirstlane(next_ticket);
         if (item >= plan.items_total) break;
+        ++items_taken;
         // ---- ticket -> tile -> (queries [q_first, q_first + q_count), candidates [c_lo, c_hi)): tickets only grow, so the tile
         //      index only moves forward
         while (tile_index + 1 < plan.tiles_count && item >= plan.tiles[tile_index + 1].first_item) ++tile_index;
@@ -413,7 +419,7 @@ __global__ __launch_bounds__(queue_threads_k, 4 /* wavefronts per SIMD: two work
             __syncthreads(); // B: the tables are complete
 
             // ---- the wavefronts draw (candidate block, query) pairs, longest block first, until the pass is through
-            u32 const pairs_per_wave = lanes > 1u ? 4u * (16u / lanes) : 64u;
+            u32 const pairs_per_wave = 64u / lanes;
             u32 const wave_blocks = ((c_hi - c_lo + pairs_per_wave - 1u) / pairs_per_wave) * together;
             for (;;) {
                 u32 drawn = 0;
@@ -459,6 +465,7 @@ __global__ __launch_bounds__(queue_threads_k, 4 /* wavefronts per SIMD: two work
             __syncthreads(); // C: nobody reads the tables any more; after the last pass the next ticket is visible
         }
     }
+    if (trace && tid == 0) trace[3 * blockIdx.x] = began, trace[3 * blockIdx.x + 1] = wall_clock64(), trace[3 * blockIdx.x + 2] = items_taken;
 }
 
 /** Workgroups the device keeps resident (two per CU with 64 KB of LDS each), per device ordinal. */
@@ -485,17 +492,19 @@ static u32 queue_grid(u64 items) {
 
 } // namespace szs_hip
 
+extern "C" unsigned szs_hip_levenshtein_myers_queue_grid(uint64_t items) { return szs_hip::queue_grid(items); }
+
 extern "C" int szs_hip_levenshtein_myers_queue(szs_queue_plan_t const *plan, szs_string_ref_t const *queries,
                                                szs_string_ref_t const *candidates, uint64_t *results, uint64_t results_row_stride,
                                                int layout, uint32_t *tickets, uint32_t ticket_base, uint32_t *tickets_taken,
-                                               void *stream) {
+                                               uint64_t *trace, void *stream) {
     using namespace szs_hip;
     *tickets_taken = 0;
     if (!plan->items_total) return 0;
     if (plan->tiles_count > SZS_QUEUE_MOST_TILES) return (int)hipErrorInvalidValue;
     u32 const grid = queue_grid(plan->items_total);
     hipLaunchKernelGGL(levenshtein_myers_queue_kernel, dim3(grid), dim3(queue_threads_k), queue_arena_bytes_k, static_cast<hipStream_t>(stream), queries,
-                       candidates, results, results_row_stride, layout, tickets, ticket_base, *plan);
+                       candidates, results, results_row_stride, layout, tickets, ticket_base, trace, *plan);
     hipError_t const error = hipGetLastError();
     if (error == hipSuccess) *tickets_taken = plan->items_total + grid;
     return (int)error;

@@ -267,6 +267,7 @@ static void release_device_state(szs_engine_s *engine) {
     szs_buffer_release(&engine->device_plan_refs);
     szs_buffer_release(&engine->device_presence);
     szs_buffer_release(&engine->device_queue);
+    szs_buffer_release(&engine->device_queue_trace);
     engine->queue_zeroed = NULL;
     szs_buffer_release(&engine->pinned_summary);
     if (engine->events_device >= 0) {
@@ -728,8 +729,13 @@ static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int dev
     }
     if (queued && !launch_error && *status == sz_success_k) {
         uint32_t taken = 0;
+        uint64_t *trace = NULL; /* `trace` knob: where every workgroup's begin / end ticks go (finish() prints their spread) */
+        if (szs_tuning_get(szs_knob_trace_k) > 0 &&
+            szs_buffer_reserve(&engine->device_queue_trace, szs_memory_device_k, device,
+                               3 * sizeof(uint64_t) * (size_t)szs_hip_levenshtein_myers_queue_grid(d->queue.items_total), NULL) == sz_success_k)
+            trace = (uint64_t *)engine->device_queue_trace.pointer;
         launch_error = szs_hip_levenshtein_myers_queue(&d->queue, query_refs, candidate_refs, (uint64_t *)device_results, device_stride, d->layout,
-                                                       (uint32_t *)engine->device_queue.pointer, engine->queue_tickets, &taken, stream);
+                                                       (uint32_t *)engine->device_queue.pointer, engine->queue_tickets, &taken, trace, stream);
         engine->queue_tickets += taken; /* wraps with the counter */
         if (!launch_error) ++*launches;
     }
@@ -873,6 +879,25 @@ static sz_status_t finish(szs_call_t *call, szs_decision_t const *d, hipError_t 
         fprintf(stderr, "\n");
     }
 #endif
+    if (call->trace && profile->queue_items && engine->device_queue_trace.pointer) { /* the persistent launch, workgroup by workgroup */
+        unsigned const grid = szs_hip_levenshtein_myers_queue_grid(profile->queue_items);
+        uint64_t *const ticks = (uint64_t *)malloc(3 * sizeof(uint64_t) * (size_t)grid);
+        if (ticks && hipMemcpy(ticks, engine->device_queue_trace.pointer, 3 * sizeof(uint64_t) * (size_t)grid, hipMemcpyDeviceToHost) == hipSuccess) {
+            uint64_t first = ~0ull, last = 0, busy = 0, latest_begin = 0;
+            for (unsigned w = 0; w < grid; ++w) {
+                first = ticks[3 * w] < first ? ticks[3 * w] : first, last = ticks[3 * w + 1] > last ? ticks[3 * w + 1] : last;
+                latest_begin = ticks[3 * w] > latest_begin ? ticks[3 * w] : latest_begin, busy += ticks[3 * w + 1] - ticks[3 * w];
+            }
+            unsigned done_by[10] = {0}; /* workgroups that had ended by k / 10 of the launch */
+            for (unsigned w = 0; w < grid; ++w)
+                for (unsigned k = 0; k < 10; ++k) done_by[k] += (ticks[3 * w + 1] - first) * 10 <= (uint64_t)(k + 1) * (last - first);
+            fprintf(stderr, "queue launch: %u workgroups, %.1f us from the first begin to the last end (last begin at %.1f us), mean busy %.3f | ended by tenth:",
+                    grid, (last - first) * 1e-2, (latest_begin - first) * 1e-2, (double)busy / ((double)(last - first) * grid));
+            for (unsigned k = 0; k < 10; ++k) fprintf(stderr, " %u", done_by[k]);
+            fprintf(stderr, "\n");
+        }
+        free(ticks);
+    }
     if (call->trace)
         fprintf(stderr, "szs call: %.1f us = setup %.1f + plan %.1f + prepare %.1f + launch %.1f + wait %.1f + wrap %.1f | kernel %.1f us | %s\n",
                 profile->host_milliseconds * 1e3, call->phases[0] * 1e3, call->phases[1] * 1e3, call->phases[2] * 1e3,

@@ -176,7 +176,7 @@ static void queue_shape(unsigned words, unsigned most, unsigned *words_per_lane,
         if (l > 16u) continue;
         unsigned const team = l < 2u ? 2u : l; /* (a pattern narrower than `most` still gets two lanes here: callers ask for teams) */
         double const width_used = (double)words / (double)(w * team);
-        double const lanes_used = (double)(team * (16u / team)) / 16.0;
+        double const lanes_used = (double)(team * (64u / team)) / 64.0;
         double const issue_used = 10.5 * w / (10.5 * w + SZS_QUEUE_LANE_OVERHEAD);
         double const efficiency = width_used * lanes_used * issue_used;
         if (efficiency > best) best = efficiency, *words_per_lane = w, *lanes = team;
@@ -265,7 +265,7 @@ void szs_plan_queue(szs_plan_t const *plan, uint32_t queries_count, uint32_t can
             unsigned side_by_side = 1;
             for (unsigned g = 16; g > 1; --g)
                 if (((64u / g) & ~3u) >= table_words) { side_by_side = g; break; }
-            uint32_t const pairs_per_wave = slice->lanes > 1 ? 4u * (16u / slice->lanes) : 64u;
+            uint32_t const pairs_per_wave = 64u / slice->lanes;
             double const one_round_ns = SZS_QUEUE_WORD_COLUMN_NS * lane_words * longest; /* eight wave blocks, one per wavefront */
             unsigned rounds = one_round_ns >= item_ns ? 1u : (unsigned)(item_ns / one_round_ns);
             if (rounds > SZS_QUEUE_MOST_ROUNDS) rounds = SZS_QUEUE_MOST_ROUNDS;

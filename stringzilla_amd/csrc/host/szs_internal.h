@@ -108,6 +108,7 @@ typedef struct szs_engine_s {
     uint8_t uniform_byte_to_class[256];
     szs_buffer_t device_presence;  /* device: the 256 presence bits */
     szs_buffer_t device_queue;     /* device: the ticket counter of hip/myers_queue.hip - zeroed when allocated, never again */
+    szs_buffer_t device_queue_trace; /* device: per-workgroup begin / end ticks of that launch (`trace` knob only) */
     void *queue_zeroed;            /* the allocation of `device_queue` that was zeroed: another pointer means a fresh buffer */
     uint32_t queue_tickets;        /* the counter's value when the next launch begins (every launch says what it takes) */
     hipEvent_t event_start, event_stop;

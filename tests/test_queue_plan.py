@@ -53,7 +53,7 @@ def walk(tiles, items, query_lengths, candidate_lengths):
             q_count = min(per_group, query_first + query_count - q_first)
             c_hi = c_end - block * per_item
             c_lo = c_hi - per_item if c_hi - c_first > per_item else c_first
-            pairs_per_wave = 64 if lanes == 1 else 4 * (16 // lanes)
+            pairs_per_wave = 64 // lanes
             wave_blocks = -(-(c_hi - c_lo) // pairs_per_wave) * q_count
             for drawn in range(wave_blocks):
                 candidate_block, g = divmod(drawn, q_count)
@@ -102,7 +102,7 @@ def test_tiles_come_longest_first_and_shapes_follow_the_call():
 
     def key(tile):
         _, query_first, _, c_first, c_end, per_item, words_per_lane, lanes, per_group = tile
-        pairs_per_wave = 64 if lanes == 1 else 4 * (16 // lanes)
+        pairs_per_wave = 64 // lanes
         wave_blocks = per_group * -(-per_item // pairs_per_wave)
         return -(-wave_blocks // 8) * (words_per_lane if lanes > 1 else 1) * int(ascending[c_end - 1])
 
@@ -139,5 +139,5 @@ def test_knobs_pin_the_shape():
     finally:
         _abi.tuning_set("queue_rounds", previous)
     for tile in tiles:
-        pairs_per_wave = 64 if tile[7] == 1 else 4 * (16 // tile[7])
+        pairs_per_wave = 64 // tile[7]
         assert tile[8] <= 24 and tile[5] == min(max(1, 24 // tile[8]) * pairs_per_wave, tile[4] - tile[3]), tile.tolist()
