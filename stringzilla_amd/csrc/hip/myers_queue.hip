@@ -319,8 +319,10 @@ __device__ __attribute__((noinline)) void queue_team(u32 table_offset, u32 lanes
     }
 }
 
-/** Words of the masks as the one-lane bodies see a pattern of `needed` words: its exact width up to 8, then 10, 12, 16. */
-__device__ __forceinline__ u32 queue_body_words(u32 needed) { return needed <= 8u ? needed : needed <= 10u ? 10u : needed <= 12u ? 12u : 16u; }
+/** Words of the masks as the one-lane bodies see a pattern of `needed` words: its exact width up to 8, then 10, 12, 16, 20. */
+__device__ __forceinline__ u32 queue_body_words(u32 needed) {
+    return needed <= 8u ? needed : needed <= 10u ? 10u : needed <= 12u ? 12u : needed <= 16u ? 16u : 20u;
+}
 
 /**
  *  The persistent kernel.  `tickets` is a counter in device memory that is never reset: the host passes the value it holds when
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(queue_threads_k, 4 /* wavefronts per SIMD: two work
             u32 slot_words = ((u32)queue_widest_k / (alone ? 1u : per_group)) & ~3u; // words of the table each query of the pass gets
             if (alone) {
                 u32 const needed = __builtin_amdgcn_readfirstlane((queries[q_first + done].length + 31u) / 32u);
-                if (lanes == 1u && needed > 16u) lanes = (needed + 15u) / 16u, words_per_lane = 16u;
+                if (lanes == 1u && needed > 20u) lanes = (needed + 15u) / 16u, words_per_lane = 16u;
                 if (lanes > 1u && words_per_lane * lanes < needed) words_per_lane = 16u, lanes = (needed + 15u) / 16u;
             }
             u32 const slot_dwords = slot_words * (u32)byte_rows_k, slot_bytes = slot_words * 32u;
@@ -453,7 +455,8 @@ __global__ __launch_bounds__(queue_threads_k, 4 /* wavefronts per SIMD: two work
                     case 8: SZS_QUEUE_LANES(8, 2); break;
                     case 10: SZS_QUEUE_LANES(10, 1); break;
                     case 12: SZS_QUEUE_LANES(12, 1); break;
-                    default: SZS_QUEUE_LANES(16, 1); break;
+                    case 16: SZS_QUEUE_LANES(16, 1); break;
+                    default: SZS_QUEUE_LANES(20, 1); break;
                     }
                 }
 #undef SZS_QUEUE_LANES

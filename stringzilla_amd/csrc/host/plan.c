@@ -166,7 +166,7 @@ static unsigned words_of(uint32_t length) { return length ? (length + 31u) / 32u
 
 /** Lanes per pair and words per lane for patterns of up to `words` words when a lane may hold `most` (4 / 8 / 12 / 16) of them. */
 static void queue_shape(unsigned words, unsigned most, unsigned *words_per_lane, unsigned *lanes) {
-    if (words <= most && words <= 16u) { /* one lane per pair, at each query's own width */
+    if (words <= (most == 16u ? 20u : most)) { /* one lane per pair, at each query's own width (a body of 20 words exists too) */
         *words_per_lane = 0, *lanes = 1;
         return;
     }
@@ -233,8 +233,14 @@ void szs_plan_queue(szs_plan_t const *plan, uint32_t queries_count, uint32_t can
             for (int k = (int)SZS_PLAN_RANK_SAMPLES - 1; k >= 0 && columns + 1 < columns_most; --k) {
                 uint32_t const rank = (uint32_t)((uint64_t)k * (candidates_count - 1) / SZS_PLAN_RANK_SAMPLES), sampled = plan->rank_lengths[1][k];
                 if (rank + 1 >= end || (uint64_t)sampled * 10u > (uint64_t)top * 6u) continue;
-                column_begin[columns] = rank + 1, column_end[columns] = end, column_longest[columns] = top ? top : 1u, ++columns;
-                end = rank + 1, top = sampled; /* every candidate of a rank up to `rank` is no longer than the sample there */
+                /* the cut goes DOWN to a whole number of wavefronts (64 candidates) below the end of the array: wave blocks are
+                 * counted from a column's end, and a cut anywhere else leaves every query a half-empty wave block per column -
+                 * a twelfth of config 5's wave blocks, and of its instructions (profiles/r04) */
+                uint32_t const cut = candidates_count - (candidates_count - (rank + 1) + 63u) / 64u * 64u < candidates_count
+                                         ? candidates_count - (candidates_count - (rank + 1) + 63u) / 64u * 64u : 0u;
+                if (!cut || cut >= end) continue;
+                column_begin[columns] = cut, column_end[columns] = end, column_longest[columns] = top ? top : 1u, ++columns;
+                end = cut, top = sampled; /* every candidate of a rank up to `rank` (so: below `cut`) is no longer than the sample there */
             }
         column_begin[columns] = 0, column_end[columns] = end, column_longest[columns] = top ? top : 1u, ++columns;
     }
@@ -260,8 +266,8 @@ void szs_plan_queue(szs_plan_t const *plan, uint32_t queries_count, uint32_t can
             szs_queue_tile_t *tile = &queue->tiles[tiles];
             unsigned const bound_words = words_of(slice->bound);
             unsigned const lane_words = slice->lanes > 1 ? slice->words_per_lane : bound_words;
-            unsigned const table_words = slice->lanes > 1 ? slice->words_per_lane * slice->lanes /* one-lane bodies: 1 ... 8, 10, 12, 16 */
-                                         : bound_words <= 8 ? bound_words : bound_words <= 10 ? 10u : bound_words <= 12 ? 12u : 16u;
+            unsigned const table_words = slice->lanes > 1 ? slice->words_per_lane * slice->lanes /* one-lane bodies: 1 ... 8, 10, 12, 16, 20 */
+                                         : bound_words <= 8 ? bound_words : bound_words <= 10 ? 10u : bound_words <= 12 ? 12u : bound_words <= 16 ? 16u : 20u;
             unsigned side_by_side = 1;
             for (unsigned g = 16; g > 1; --g)
                 if (((64u / g) & ~3u) >= table_words) { side_by_side = g; break; }

@@ -43,8 +43,8 @@ def walk(tiles, items, query_lengths, candidate_lengths):
         slot_words = (64 // per_group) & ~3  # words of the workgroup's table each query of a group gets
         if lanes == 1:
             needed = words_of(longest)
-            assert needed <= 16, (longest, "one lane per pair takes up to 16 words")
-            assert (needed if needed <= 8 else 10 if needed <= 10 else 12 if needed <= 12 else 16) <= slot_words, (longest, per_group)
+            assert needed <= 20, (longest, "one lane per pair takes up to 20 words")
+            assert (needed if needed <= 8 else 10 if needed <= 10 else 12 if needed <= 12 else 16 if needed <= 16 else 20) <= slot_words, (longest, per_group)
         else:
             assert words_per_lane in (4, 8, 12, 16) and words_of(longest) <= words_per_lane * lanes <= slot_words, (longest, words_per_lane, lanes, per_group)
         for local in range(groups * blocks):
