@@ -432,8 +432,13 @@ static sz_status_t decide(szs_engine_s const *engine, int symmetric, int runes, 
     int const queue_knob = szs_tuning_get(szs_knob_queue_k);
     unsigned bit_parallel_groups = 0;
     for (unsigned g = 0; g < d->plan.groups_count; ++g) bit_parallel_groups += d->plan.groups[g].variant != 0;
+    /* Automatic: batches of SKEWED lengths - the longest query at least 2.5 times the mean, two width groups or more.  Those are
+     * the calls whose per-width launches end in tails (config 5, its shares on several GPUs, lines of text).  A batch of one
+     * length class that merely straddles two or three widths keeps its launches: its work items would all be alike, a handful
+     * per workgroup, and the last round of them runs the device half empty (1024 x 1024 x 500 bytes: 112 against 90 TCUPS). */
+    int const skewed = kq->count && (uint64_t)kq->longest * kq->count * 2u >= kq->symbols * 5u;
     d->use_queue = d->use_myers && !runes && d->tier == SZS_TIER_LANES && !d->wide_cells && queue_knob != 0 &&
-                   bit_parallel_groups >= (queue_knob > 0 ? 1u : 2u);
+                   (queue_knob > 0 ? bit_parallel_groups >= 1u : bit_parallel_groups >= 2u && skewed);
     if (d->use_queue && ranks) {
         d->plan.has_ranks = 1;
         memcpy(d->plan.rank_lengths[0], ranks[d->transposed ? 1 : 0], sizeof(d->plan.rank_lengths[0]));

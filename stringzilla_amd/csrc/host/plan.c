@@ -165,13 +165,13 @@ typedef struct {
 static unsigned words_of(uint32_t length) { return length ? (length + 31u) / 32u : 1u; }
 
 /** Lanes per pair and words per lane for patterns of up to `words` words when a lane may hold `most` (4 / 8 / 12 / 16) of them. */
-static void queue_shape(unsigned words, unsigned most, unsigned *words_per_lane, unsigned *lanes) {
+static void queue_shape(unsigned words, unsigned most, unsigned team_most, unsigned *words_per_lane, unsigned *lanes) {
     if (words <= (most == 16u ? 20u : most)) { /* one lane per pair, at each query's own width (a body of 20 words exists too) */
         *words_per_lane = 0, *lanes = 1;
         return;
     }
     double best = -1;
-    for (unsigned w = 4; w <= most; w += 4) {
+    for (unsigned w = 4; w <= team_most; w += 4) {
         unsigned const l = (words + w - 1) / w;
         if (l > 16u) continue;
         unsigned const team = l < 2u ? 2u : l; /* (a pattern narrower than `most` still gets two lanes here: callers ask for teams) */
@@ -259,10 +259,13 @@ void szs_plan_queue(szs_plan_t const *plan, uint32_t queries_count, uint32_t can
          * candidates only, and keeps four lanes of sixteen words (a third fewer instructions) against the short ones */
         double const fitting = round_ns / (SZS_QUEUE_WORD_COLUMN_NS * longest);
         unsigned most = fitting >= 16 ? 16u : fitting >= 12 ? 12u : fitting >= 8 ? 8u : 4u;
-        if (words_knob == 4 || words_knob == 8 || words_knob == 12 || words_knob == 16) most = (unsigned)words_knob;
+        /* teams stop at twelve words per lane: the sixteen-word team body fills its 128 registers and config 5 runs 1.7 % slower with
+         * it (9.69 against 9.52 ms, profiles/r04); ONE lane still takes up to twenty words when the budget allows sixteen */
+        unsigned team_most = most < 12u ? most : 12u;
+        if (words_knob == 4 || words_knob == 8 || words_knob == 12 || words_knob == 16) most = team_most = (unsigned)words_knob;
         for (unsigned i = 0; i < slices_count; ++i) {
             queue_slice_t *slice = &slices[i];
-            queue_shape(words_of(slice->bound), most, &slice->words_per_lane, &slice->lanes);
+            queue_shape(words_of(slice->bound), most, team_most, &slice->words_per_lane, &slice->lanes);
             szs_queue_tile_t *tile = &queue->tiles[tiles];
             unsigned const bound_words = words_of(slice->bound);
             unsigned const lane_words = slice->lanes > 1 ? slice->words_per_lane : bound_words;

@@ -65,6 +65,10 @@ def test_a_mixed_width_call_is_one_launch(gpu, oracle):
         with knob("queue", 0):
             assert np.array_equal(engine(queries, candidates, device=gpu), expected)
             assert engine.last_call_profile().launches == 9 and engine.last_call_profile().queue_items == 0
+        # a batch of one length class that straddles two widths is not skewed: it keeps its two launches
+        flat = _rand(rng, 40, 230, 300, b"ACGT")
+        assert np.array_equal(engine(flat, candidates, device=gpu), oracle.levenshtein(flat, candidates))
+        assert engine.last_call_profile().queue_items == 0 and engine.last_call_profile().launches == 2
         # a call of ONE width is not queued by itself, but can be
         narrow = [q for q in queries if len(q) <= 256]
         assert np.array_equal(engine(narrow, candidates, device=gpu), oracle.levenshtein(narrow, candidates))
@@ -84,7 +88,8 @@ def test_every_body_of_the_queue_kernel(gpu, oracle, words):
     candidates = _rand(rng, 90, 0, 260, b"AB") + _rand(rng, 6, 600, 700, b"AB") + [b"", queries[40]]
     engine = szs.LevenshteinDistances(capabilities=gpu)
     expected = oracle.levenshtein(queries, candidates)
-    with knob("tier", "lanes"), knob("queue_words", words):
+    # (lengths spread evenly up to 2048 are not "skewed": left alone this call keeps its per-width launches, see decide())
+    with knob("tier", "lanes"), knob("queue", 1), knob("queue_words", words):
         got = engine(queries, candidates, device=gpu)
         assert engine.last_call_profile().launches == 1 and engine.last_call_profile().queue_items > 0
         wrong = np.argwhere(got != expected)
@@ -126,9 +131,11 @@ def test_a_stream_of_calls_on_one_engine(gpu, oracle):
             else:
                 queries = _rand(rng, rng.randint(3, 40), 0, 200, b"ACGT") + _rand(rng, rng.randint(1, 6), 300, 2048, b"ACGT")
                 candidates = _rand(rng, rng.randint(1, 700), 0, rng.choice([20, 300]), b"ACGT")
-            got = engine(queries, candidates, device=gpu)
+            with knob("queue", None if step % 2 else 1):  # automatic (skewed batches only) and forced, in turns
+                got = engine(queries, candidates, device=gpu)
             assert np.array_equal(got, oracle.levenshtein(queries, candidates)), step
-            assert engine.last_call_profile().launches == 1
+            profile = engine.last_call_profile()
+            assert profile.launches == 1 or not profile.queue_items, (step, profile.launches, profile.queue_items)
 
 
 def test_config5_scaled_both_ways(gpu, oracle):

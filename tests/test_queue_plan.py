@@ -116,9 +116,9 @@ def test_tiles_come_longest_first_and_shapes_follow_the_call():
     # more lanes of fewer words; against short candidates it keeps the wide lanes (a third fewer instructions)
     top = lambda tiles: [tile for tile in tiles if tile[7] > 1 and tile[4] == len(candidates)]
     low = lambda tiles: [tile for tile in tiles if tile[7] > 1 and int(ascending[tile[4] - 1]) < 100]
-    assert max(tile[6] for tile in top(whole)) >= 12 and max(tile[6] for tile in top(eighth)) <= 8
+    assert max(tile[6] for tile in top(whole)) >= 12 and max(tile[6] for tile in top(eighth)) <= 4
     assert max(tile[7] for tile in top(eighth)) > max(tile[7] for tile in top(whole))
-    assert low(eighth) and min(tile[6] for tile in low(eighth)) >= 12
+    assert low(eighth) and min(tile[6] for tile in low(eighth)) >= 8 and max(tile[6] for tile in low(eighth)) >= 12
 
 
 def test_knobs_pin_the_shape():
