@@ -103,13 +103,15 @@ SZ_API_RUNTIME sz_status_t szs_rocm_launch_order_probe(int runes, sz_u32_t const
 /**
  *  The work queue of the ONE persistent launch that scores every bit-vector width of a unit-cost byte call
  *  (hip/myers_queue.hip; host/plan.c: szs_plan_queue), planned from bare length arrays - no GPU involved.  Queries are taken
- *  longest first, candidates shortest first (szs_rocm_plan_probe gives both orders).  `tiles` receives 9 values per tile, in
+ *  longest first, candidates shortest first (szs_rocm_plan_probe gives both orders).  `alphabet` 0: byte strings; A: lengths
+ *  count codepoints of a batch renumbered 1 ... A (hip/utf8.hip), whose tables have A + 1 rows - `*items_total` 0 when such an
+ *  alphabet leaves some query no table (the per-width launches score those calls).  `tiles` receives 10 values per tile, in
  *  queue order: items of all tiles before it, first query and queries of its slice, first and one-past-last candidate of its
- *  column, candidates per work item, words per lane (0: the query's own width on one lane), lanes per pair and queries per
- *  work item G.  With `groups` = ceil(queries / G), work item j of a tile scores the queries of group `j % groups` against the
+ *  column, candidates per work item, words per lane (0: the query's own width on one lane), lanes per pair, queries per
+ *  work item G and flags (1: sparse tables).  With `groups` = ceil(queries / G), work item j of a tile scores the queries of group `j % groups` against the
  *  candidates of block `j / groups`, blocks cut from the column's end.
  */
-SZ_API_RUNTIME sz_status_t szs_rocm_queue_probe(int symmetric, sz_u32_t const *query_lengths, sz_size_t queries_count,
+SZ_API_RUNTIME sz_status_t szs_rocm_queue_probe(int symmetric, sz_u32_t alphabet, sz_u32_t const *query_lengths, sz_size_t queries_count,
                                                 sz_u32_t const *candidate_lengths, sz_size_t candidates_count, sz_u32_t *tiles,
                                                 sz_size_t capacity, sz_size_t *tiles_count, sz_u64_t *items_total);
 

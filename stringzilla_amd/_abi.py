@@ -114,7 +114,7 @@ SIGNATURES = {
     "szs_rocm_orientation_probe": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p]),
     "szs_rocm_team_orientation_probe": (c_int, [c_int, c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "szs_rocm_launch_order_probe": (c_int, [c_int, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "szs_rocm_queue_probe": (c_int, [c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "szs_rocm_queue_probe": (c_int, [c_int, ctypes.c_uint32, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p]),
     "szs_rocm_tuning_set": (c_int, [c_char_p, c_char_p]),
     "szs_rocm_team_shape": (ctypes.c_uint32, [c_size_t]),
     "szs_rocm_node_init": (c_int, [c_void_p, c_size_t, ENGINE_OUT, ERR]),

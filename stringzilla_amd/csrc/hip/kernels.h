@@ -151,9 +151,11 @@ typedef struct szs_queue_tile_t {
     uint32_t candidate_first, candidate_end; /* column of the candidate refs (ascending) */
     uint32_t candidates_per_item;            /* S: the masks of a query are built once per S candidates */
     uint8_t words_per_lane, lanes;
-    uint16_t queries_per_item;               /* G: the masks of G queries side by side in the workgroup's 64-word table (G x
-                                                the words a query of the slice needs <= 64); the slice's last item may hold fewer */
+    uint8_t queries_per_item;                /* G <= 16: the masks of G queries side by side in the workgroup's table (each gets 1 / G
+                                                of it); the slice's last item may hold fewer */
+    uint8_t flags;                           /* SZS_QUEUE_TILE_SPARSE */
 } szs_queue_tile_t;
+#define SZS_QUEUE_TILE_SPARSE 1u /* codepoints: the tile's tables are pointers + a pool of non-zero chunks (hip/myers_queue.hip) */
 typedef struct szs_queue_plan_t {
     uint32_t tiles_count, items_total;
     szs_queue_tile_t tiles[SZS_QUEUE_MOST_TILES];
@@ -167,8 +169,13 @@ int szs_hip_levenshtein_myers_queue(szs_queue_plan_t const *plan, szs_string_ref
                                     uint64_t *results, uint64_t results_row_stride, int layout, uint32_t *tickets, uint32_t ticket_base,
                                     uint32_t *tickets_taken, uint64_t *trace /* NULL, or 3 x szs_hip_levenshtein_myers_queue_grid(items)
                                     qwords of device memory: per workgroup its first and last 100 MHz tick and the items it took */,
-                                    void *stream);
-unsigned szs_hip_levenshtein_myers_queue_grid(uint64_t items);
+                                    uint32_t alphabet /* 0: byte strings; A: UTF-32 arrays of ids 1 ... A (szs_hip_alphabet_rename) */,
+                                    uint32_t *unfit_flag /* pinned host memory, or NULL: receives `unfit_sequence` when a query fits no
+                                    table of the kernel (the plan's job to prevent; the host then scores the call another way) */,
+                                    uint32_t unfit_sequence, void *stream);
+unsigned szs_hip_levenshtein_myers_queue_grid(uint64_t items, int runes);
+/** Bytes of LDS a workgroup's tables share: 64 KB for bytes, 72 KB for codepoints (what szs_plan_queue fits its tiles into). */
+size_t szs_hip_levenshtein_myers_queue_table_bytes(int runes);
 
 /* ---- tuning knobs (host/tuning.c): read from the environment ONCE at load, changed only by szs_rocm_tuning_set -------- */
 

@@ -427,27 +427,37 @@ static sz_status_t decide(szs_engine_s const *engine, int symmetric, int runes, 
                                               &d->systolic_control_bytes, &d->systolic_parked_bytes) ||
          d->systolic_control_bytes + d->systolic_parked_bytes > ((size_t)32 << 30)))
         d->tier = SZS_TIER_LANES;
-    /* ---- the bit-parallel width groups of a unit-cost byte call as ONE persistent launch (hip/myers_queue.hip): whenever there
-     * are two or more of them - each used to be a launch with a tail of its own (the `queue` knob: 0 never, 1 also for one) */
-    int const queue_knob = szs_tuning_get(szs_knob_queue_k);
-    unsigned bit_parallel_groups = 0;
-    for (unsigned g = 0; g < d->plan.groups_count; ++g) bit_parallel_groups += d->plan.groups[g].variant != 0;
-    /* Automatic: batches of SKEWED lengths - the longest query at least 2.5 times the mean, two width groups or more.  Those are
-     * the calls whose per-width launches end in tails (config 5, its shares on several GPUs, lines of text).  A batch of one
-     * length class that merely straddles two or three widths keeps its launches: its work items would all be alike, a handful
-     * per workgroup, and the last round of them runs the device half empty (1024 x 1024 x 500 bytes: 112 against 90 TCUPS). */
-    int const skewed = kq->count && (uint64_t)kq->longest * kq->count * 2u >= kq->symbols * 5u;
-    d->use_queue = d->use_myers && !runes && d->tier == SZS_TIER_LANES && !d->wide_cells && queue_knob != 0 &&
-                   (queue_knob > 0 ? bit_parallel_groups >= 1u : bit_parallel_groups >= 2u && skewed);
-    if (d->use_queue && ranks) {
-        d->plan.has_ranks = 1;
-        memcpy(d->plan.rank_lengths[0], ranks[d->transposed ? 1 : 0], sizeof(d->plan.rank_lengths[0]));
-        memcpy(d->plan.rank_lengths[1], ranks[d->transposed ? 0 : 1], sizeof(d->plan.rank_lengths[1]));
-        szs_plan_queue(&d->plan, d->kq_count, d->kc_count, &d->queue);
-    }
+    d->kq_symbols = kq->symbols;
+    (void)ranks;
     (void)error_message;
     d->valid = 1;
     return sz_success_k;
+}
+
+/**
+ *  The bit-parallel width groups of a unit-cost call as ONE persistent launch (hip/myers_queue.hip) - each used to be a launch
+ *  with a tail of its own.  Bytes always can; codepoints when the device renumbered the batch (`d->alphabet`) and the alphabet
+ *  leaves every query a table.  `ranks`: the lengths at 33 ranks of the CALLER's sides (the device planner's summary), or NULL
+ *  when the host planner has yet to sort (it plans the queue itself afterwards).  The `queue` knob: 0 never, 1 whenever possible.
+ *
+ *  Automatic: batches of SKEWED lengths - the longest query at least 2.5 times the mean, two width groups or more.  Those are
+ *  the calls whose per-width launches end in tails (config 5, its shares on several GPUs, lines of text).  A batch of one
+ *  length class that merely straddles two or three widths keeps its launches: its work items would all be alike, a handful
+ *  per workgroup, and the last round of them runs the device half empty (1024 x 1024 x 500 bytes: 112 against 90 TCUPS).
+ */
+static void decide_queue(szs_engine_s const *engine, szs_decision_t *d, uint32_t const (*ranks)[SZS_PLAN_RANK_SAMPLES + 1]) {
+    int const queue_knob = szs_tuning_get(szs_knob_queue_k);
+    unsigned bit_parallel_groups = 0;
+    for (unsigned g = 0; g < d->plan.groups_count; ++g) bit_parallel_groups += d->plan.groups[g].variant != 0;
+    int const skewed = d->kq_count && (uint64_t)d->plan.longest_query * d->kq_count * 2u >= d->kq_symbols * 5u;
+    d->use_queue = d->use_myers && (!d->runes || d->alphabet) && d->tier == SZS_TIER_LANES && !d->wide_cells && queue_knob != 0 &&
+                   !engine->queue_refused && (queue_knob > 0 ? bit_parallel_groups >= 1u : bit_parallel_groups >= 2u && skewed);
+    if (!d->use_queue || !ranks) return;
+    d->plan.has_ranks = 1;
+    memcpy(d->plan.rank_lengths[0], ranks[d->transposed ? 1 : 0], sizeof(d->plan.rank_lengths[0]));
+    memcpy(d->plan.rank_lengths[1], ranks[d->transposed ? 0 : 1], sizeof(d->plan.rank_lengths[1]));
+    szs_plan_queue(&d->plan, d->kq_count, d->kc_count, d->runes ? d->alphabet : 0u, szs_hip_levenshtein_myers_queue_table_bytes(d->runes), &d->queue);
+    if (!d->queue.items_total) d->use_queue = 0; /* an alphabet too rich for the tables: the per-width launches */
 }
 
 /** Does the lanes tier of this decision run a kernel that reads the cost model / the weighted strip workspace? */
@@ -737,10 +747,15 @@ static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int dev
         uint64_t *trace = NULL; /* `trace` knob: where every workgroup's begin / end ticks go (finish() prints their spread) */
         if (szs_tuning_get(szs_knob_trace_k) > 0 &&
             szs_buffer_reserve(&engine->device_queue_trace, szs_memory_device_k, device,
-                               3 * sizeof(uint64_t) * (size_t)szs_hip_levenshtein_myers_queue_grid(d->queue.items_total), NULL) == sz_success_k)
+                               3 * sizeof(uint64_t) * (size_t)szs_hip_levenshtein_myers_queue_grid(d->queue.items_total, d->runes), NULL) == sz_success_k)
             trace = (uint64_t *)engine->device_queue_trace.pointer;
+        /* a query that fits no table of the kernel (the plan's job to prevent) raises this flag in pinned memory: szs_engine_cross
+         * looks after the call's wait and scores the batch with the per-width launches instead */
+        uint32_t *const unfit = (uint32_t *)((char *)engine->pinned_summary.pointer + 960);
+        engine->queue_unfit_sequence = ++engine->plan_sequence;
         launch_error = szs_hip_levenshtein_myers_queue(&d->queue, query_refs, candidate_refs, (uint64_t *)device_results, device_stride, d->layout,
-                                                       (uint32_t *)engine->device_queue.pointer, engine->queue_tickets, &taken, trace, stream);
+                                                       (uint32_t *)engine->device_queue.pointer, engine->queue_tickets, &taken, trace,
+                                                       d->runes ? d->alphabet : 0u, unfit, engine->queue_unfit_sequence, stream);
         engine->queue_tickets += taken; /* wraps with the counter */
         if (!launch_error) ++*launches;
     }
@@ -885,7 +900,7 @@ static sz_status_t finish(szs_call_t *call, szs_decision_t const *d, hipError_t 
     }
 #endif
     if (call->trace && profile->queue_items && engine->device_queue_trace.pointer) { /* the persistent launch, workgroup by workgroup */
-        unsigned const grid = szs_hip_levenshtein_myers_queue_grid(profile->queue_items);
+        unsigned const grid = szs_hip_levenshtein_myers_queue_grid(profile->queue_items, d->runes);
         uint64_t *const ticks = (uint64_t *)malloc(3 * sizeof(uint64_t) * (size_t)grid);
         if (ticks && hipMemcpy(ticks, engine->device_queue_trace.pointer, 3 * sizeof(uint64_t) * (size_t)grid, hipMemcpyDeviceToHost) == hipSuccess) {
             uint64_t first = ~0ull, last = 0, busy = 0, latest_begin = 0;
@@ -1157,6 +1172,7 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
         status = decide(engine, symmetric, 0, attempt > 0, &seen.side[0], &seen.side[1], seen.variant_counts[0], seen.variant_counts[1],
                         seen.rank_lengths, cells, &d, error_message);
         if (status != sz_success_k) return status;
+        decide_queue(engine, &d, seen.rank_lengths);
         status = prepare(engine, &d, device, stream, error_message);
         if (status != sz_success_k) return status;
         phase(call, 2);
@@ -1401,6 +1417,7 @@ static sz_status_t cross_device_planned_runes(szs_call_t *call) {
                         seen.rank_lengths, cells, &d, error_message);
         if (status != sz_success_k) return status;
         d.alphabet = alphabet;
+        decide_queue(engine, &d, seen.rank_lengths);
         status = prepare(engine, &d, device, stream, error_message);
         if (status != sz_success_k) return status;
         phase(call, 2);
@@ -1537,6 +1554,7 @@ static sz_status_t cross_host_planned(szs_call_t *call) {
                         cells, &d, error_message);
         if (status != sz_success_k) return status;
         d.alphabet = alphabet;
+        decide_queue(engine, &d, NULL); /* planned below, once the lengths are sorted */
         /* kernel roles */
         uint64_t *const kq_addresses = d.transposed ? c_addresses : q_addresses, *const kc_addresses = d.transposed ? q_addresses : c_addresses;
         uint32_t *const kq_lengths = d.transposed ? c_lengths : q_lengths, *const kc_lengths = d.transposed ? q_lengths : c_lengths;
@@ -1550,7 +1568,8 @@ static sz_status_t cross_host_planned(szs_call_t *call) {
         if (d.use_queue) { /* the queue of the one-launch kernel is ordered by the sorted lengths (kernel roles already) */
             d.plan.has_ranks = 1;
             memcpy(d.plan.rank_lengths, sorted.rank_lengths, sizeof(d.plan.rank_lengths));
-            szs_plan_queue(&d.plan, d.kq_count, d.kc_count, &d.queue);
+            szs_plan_queue(&d.plan, d.kq_count, d.kc_count, d.runes ? d.alphabet : 0u, szs_hip_levenshtein_myers_queue_table_bytes(d.runes), &d.queue);
+            if (!d.queue.items_total) d.use_queue = 0;
         }
         phase(call, 1); /* gathering strings, transcoding, orientation, planning */
 
@@ -1631,19 +1650,28 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
     call.results = results, call.results_row_stride = results_row_stride, call.error_message = error_message;
 
     int const planner = szs_tuning_get(szs_knob_planner_k);
-    ranges_begin(&call);
-    status = SZS_NOT_DEVICE_PLANNABLE;
-    if (planner != 0 && device_plannable(engine, queries) && (symmetric || device_plannable(engine, candidates))) {
-        status = engine->family == szs_family_levenshtein_utf8_k ? cross_device_planned_runes(&call) : SZS_RUNES_ARE_BYTES;
-        if (status == SZS_RUNES_ARE_BYTES) {
-            if (call.ranges) ranges_end(&call), ranges_begin(&call);
-            status = cross_device_planned(&call);
+    engine->queue_refused = 0;
+    for (int round = 0; round < 2; ++round) { /* second round: the one-launch kernel met a query it has no table for (see enqueue) */
+        ranges_begin(&call);
+        engine->queue_unfit_sequence = 0;
+        status = SZS_NOT_DEVICE_PLANNABLE;
+        if (planner != 0 && device_plannable(engine, queries) && (symmetric || device_plannable(engine, candidates))) {
+            status = engine->family == szs_family_levenshtein_utf8_k ? cross_device_planned_runes(&call) : SZS_RUNES_ARE_BYTES;
+            if (status == SZS_RUNES_ARE_BYTES) {
+                if (call.ranges) ranges_end(&call), ranges_begin(&call);
+                status = cross_device_planned(&call);
+            }
         }
+        if (status == SZS_NOT_DEVICE_PLANNABLE) {
+            if (call.ranges) ranges_end(&call), ranges_begin(&call); /* the phases start over */
+            status = cross_host_planned(&call);
+        }
+        ranges_end(&call);
+        uint32_t const raised = *(uint32_t const volatile *)((char const *)engine->pinned_summary.pointer + 960);
+        if (status != sz_success_k || !engine->queue_unfit_sequence || raised != engine->queue_unfit_sequence) break;
+        engine->queue_refused = 1; /* the per-width launches score every cell again */
+        if (engine->remembered) engine->remembered->valid = 0;
     }
-    if (status == SZS_NOT_DEVICE_PLANNABLE) {
-        if (call.ranges) ranges_end(&call), ranges_begin(&call); /* the phases start over */
-        status = cross_host_planned(&call);
-    }
-    ranges_end(&call);
+    engine->queue_refused = 0;
     return status;
 }

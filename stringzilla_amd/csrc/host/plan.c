@@ -164,29 +164,67 @@ typedef struct {
 
 static unsigned words_of(uint32_t length) { return length ? (length + 31u) / 32u : 1u; }
 
-/** Lanes per pair and words per lane for patterns of up to `words` words when a lane may hold `most` (4 / 8 / 12 / 16) of them. */
-static void queue_shape(unsigned words, unsigned most, unsigned team_most, unsigned *words_per_lane, unsigned *lanes) {
-    if (words <= (most == 16u ? 20u : most)) { /* one lane per pair, at each query's own width (a body of 20 words exists too) */
-        *words_per_lane = 0, *lanes = 1;
-        return;
+/** What bounds a tile's tables (hip/myers_queue.hip): bytes have 256 rows and a 64 KB table per workgroup; codepoints of a
+ *  renumbered batch have alphabet + 1 rows and 72 KB, and tables that do not fit as rows fit as pointers + a pool. */
+typedef struct {
+    int runes;
+    uint32_t rows;         /* symbols + 1 */
+    uint32_t arena_dwords; /* the workgroup's LDS for tables */
+} queue_tables_t;
+
+static uint32_t queue_pointer_bytes(unsigned words_per_lane) { return words_per_lane <= 4 ? 2u : words_per_lane <= 8 ? 4u : 8u; }
+
+/** Dwords of LDS the table of a query of `length` symbols takes in a shape, as the kernel computes them: 0 = not at all. */
+static uint32_t queue_table_dwords(queue_tables_t const *tables, uint32_t length, unsigned words_per_lane, unsigned lanes, int *sparse) {
+    unsigned const needed = words_of(length);
+    *sparse = 0;
+    if (!tables->runes) { /* rows of 1, 2 or 4 words: [chunk][256][4] */
+        unsigned const body = lanes > 1 ? words_per_lane * lanes : needed <= 8 ? needed : needed <= 10 ? 10u : needed <= 12 ? 12u : needed <= 16 ? 16u : 20u;
+        return body >= 3 ? 256u * ((body + 3u) & ~3u) : 256u * body;
     }
-    double best = -1;
-    for (unsigned w = 4; w <= team_most; w += 4) {
-        unsigned const l = (words + w - 1) / w;
-        if (l > 16u) continue;
-        unsigned const team = l < 2u ? 2u : l; /* (a pattern narrower than `most` still gets two lanes here: callers ask for teams) */
-        double const width_used = (double)words / (double)(w * team);
-        double const lanes_used = (double)(team * (64u / team)) / 64.0;
-        double const issue_used = 10.5 * w / (10.5 * w + SZS_QUEUE_LANE_OVERHEAD);
-        double const efficiency = width_used * lanes_used * issue_used;
-        if (efficiency > best) best = efficiency, *words_per_lane = w, *lanes = team;
-    }
-    if (best < 0) *words_per_lane = 16, *lanes = (words + 15u) / 16u; /* more than 16 x `most` words: as wide as it takes */
+    unsigned const body = lanes > 1 ? words_per_lane * lanes : needed <= 8 ? needed : needed <= 12 ? 12u : 16u;
+    uint64_t const direct = (uint64_t)tables->rows * ((body + 3u) & ~3u);
+    if (direct <= tables->arena_dwords) return (uint32_t)direct;
+    if (lanes < 2) return 0; /* one lane per pair reads rows */
+    uint64_t const pointers = ((uint64_t)tables->rows * lanes * queue_pointer_bytes(words_per_lane) + 15u) / 16u * 4u;
+    uint64_t const pooled = pointers + ((uint64_t)length + 1u) * 4u;
+    *sparse = 1;
+    return pooled <= tables->arena_dwords ? (uint32_t)pooled : 0u;
 }
 
-void szs_plan_queue(szs_plan_t const *plan, uint32_t queries_count, uint32_t candidates_count, szs_queue_plan_t *queue) {
+/**
+ *  Lanes per pair and words per lane for patterns of up to `bound` symbols when a lane may hold `most` (4 / 8 / 12 / 16) words
+ *  of them, one lane at most `most_alone`, a lane of a team at most `team_most`.  Returns 0 when no shape's table fits.
+ */
+static int queue_shape(queue_tables_t const *tables, uint32_t bound, unsigned most_alone, unsigned team_most, unsigned *words_per_lane,
+                       unsigned *lanes, int *sparse) {
+    unsigned const words = words_of(bound);
+    if (words <= most_alone && queue_table_dwords(tables, bound, 0, 1, sparse)) { /* one lane per pair, at each query's own width */
+        *words_per_lane = 0, *lanes = 1;
+        return 1;
+    }
+    double best = -1;
+    for (unsigned attempt = 0; attempt < 2 && best < 0; ++attempt) /* second round: any width, when the budget's shapes have no table */
+        for (unsigned w = 4; w <= (attempt ? 16u : team_most); w += 4) {
+            unsigned const l = (words + w - 1) / w;
+            if (l > 16u) continue;
+            unsigned const team = l < 2u ? 2u : l;
+            int as_pool = 0;
+            if (!queue_table_dwords(tables, bound, w, team, &as_pool)) continue;
+            double const width_used = (double)words / (double)(w * team);
+            double const lanes_used = (double)(team * (64u / team)) / 64.0;
+            double const issue_used = 10.5 * w / (10.5 * w + SZS_QUEUE_LANE_OVERHEAD + (as_pool ? 2.0 * (w / 4) : 0.0));
+            double const efficiency = width_used * lanes_used * issue_used;
+            if (efficiency > best) best = efficiency, *words_per_lane = w, *lanes = team, *sparse = as_pool;
+        }
+    return best >= 0;
+}
+
+void szs_plan_queue(szs_plan_t const *plan, uint32_t queries_count, uint32_t candidates_count, uint32_t alphabet, size_t table_bytes,
+                    szs_queue_plan_t *queue) {
     memset(queue, 0, sizeof(*queue));
     if (!queries_count || !candidates_count) return;
+    queue_tables_t const tables = {alphabet != 0, alphabet ? alphabet + 1u : 256u, (uint32_t)(table_bytes / 4)};
     uint32_t const longest_candidate = plan->longest_candidate ? plan->longest_candidate : 1u;
     double const call_ns = (double)plan->cells / SZS_QUEUE_CELLS_PER_NS;
     /* what one wave block may take of the call: the words one lane holds x the longest candidate of the tile's column, at the
@@ -265,15 +303,23 @@ void szs_plan_queue(szs_plan_t const *plan, uint32_t queries_count, uint32_t can
         if (words_knob == 4 || words_knob == 8 || words_knob == 12 || words_knob == 16) most = team_most = (unsigned)words_knob;
         for (unsigned i = 0; i < slices_count; ++i) {
             queue_slice_t *slice = &slices[i];
-            queue_shape(words_of(slice->bound), most, team_most, &slice->words_per_lane, &slice->lanes);
+            int sparse = 0;
+            /* one lane per pair: up to 20 words of bytes (16 of codepoints) when the budget allows sixteen, else what it allows */
+            if (!queue_shape(&tables, slice->bound, most == 16u ? (tables.runes ? 16u : 20u) : most, team_most, &slice->words_per_lane, &slice->lanes,
+                             &sparse)) {
+                memset(queue, 0, sizeof(*queue)); /* codepoints whose alphabet leaves this slice no table: not a call for this kernel */
+                return;
+            }
             szs_queue_tile_t *tile = &queue->tiles[tiles];
             unsigned const bound_words = words_of(slice->bound);
             unsigned const lane_words = slice->lanes > 1 ? slice->words_per_lane : bound_words;
-            unsigned const table_words = slice->lanes > 1 ? slice->words_per_lane * slice->lanes /* one-lane bodies: 1 ... 8, 10, 12, 16, 20 */
-                                         : bound_words <= 8 ? bound_words : bound_words <= 10 ? 10u : bound_words <= 12 ? 12u : bound_words <= 16 ? 16u : 20u;
+            /* as many queries side by side as have room for their symbols (64 words of pattern between them, the kernel's
+             * indexing) and for their tables (an equal share of the workgroup's LDS each) */
+            uint32_t const table_dwords = queue_table_dwords(&tables, slice->bound, slice->words_per_lane, slice->lanes, &sparse);
+            unsigned const pattern_words = slice->lanes > 1 ? slice->words_per_lane * slice->lanes : bound_words;
             unsigned side_by_side = 1;
             for (unsigned g = 16; g > 1; --g)
-                if (((64u / g) & ~3u) >= table_words) { side_by_side = g; break; }
+                if (((64u / g) & ~3u) >= pattern_words && ((tables.arena_dwords / g) & ~3u) >= table_dwords) { side_by_side = g; break; }
             uint32_t const pairs_per_wave = 64u / slice->lanes;
             double const one_round_ns = SZS_QUEUE_WORD_COLUMN_NS * lane_words * longest; /* eight wave blocks, one per wavefront */
             unsigned rounds = one_round_ns >= item_ns ? 1u : (unsigned)(item_ns / one_round_ns);
@@ -288,7 +334,7 @@ void szs_plan_queue(szs_plan_t const *plan, uint32_t queries_count, uint32_t can
             tile->candidate_first = begin, tile->candidate_end = end;
             tile->candidates_per_item = (uint32_t)per_item;
             tile->words_per_lane = (uint8_t)slice->words_per_lane, tile->lanes = (uint8_t)slice->lanes;
-            tile->queries_per_item = (uint16_t)side_by_side;
+            tile->queries_per_item = (uint8_t)side_by_side, tile->flags = sparse ? SZS_QUEUE_TILE_SPARSE : 0;
             uint64_t const blocks_of_item = side_by_side * ((per_item + pairs_per_wave - 1) / pairs_per_wave);
             keys[tiles] = (double)((blocks_of_item + 7u) / 8u) * lane_words * longest;
             ++tiles;
@@ -550,8 +596,9 @@ void szs_plan_launch_order(szs_plan_t const *plan, int use_myers, int runes, uin
     }
 }
 
-sz_status_t szs_rocm_queue_probe(int symmetric, sz_u32_t const *query_lengths, sz_size_t queries_count, sz_u32_t const *candidate_lengths,
-                                 sz_size_t candidates_count, sz_u32_t *tiles, sz_size_t capacity, sz_size_t *tiles_count, sz_u64_t *items_total) {
+sz_status_t szs_rocm_queue_probe(int symmetric, sz_u32_t alphabet, sz_u32_t const *query_lengths, sz_size_t queries_count,
+                                 sz_u32_t const *candidate_lengths, sz_size_t candidates_count, sz_u32_t *tiles, sz_size_t capacity,
+                                 sz_size_t *tiles_count, sz_u64_t *items_total) {
     if (queries_count > 0xFFFFFFFFu || candidates_count > 0xFFFFFFFFu || !tiles_count || !items_total) return sz_overflow_risk_k;
     uint32_t const q = (uint32_t)queries_count, c = (uint32_t)candidates_count;
     size_t const most = q > c ? q : c;
@@ -571,13 +618,13 @@ sz_status_t szs_rocm_queue_probe(int symmetric, sz_u32_t const *query_lengths, s
     szs_plan_t plan;
     szs_plan_build(SZS_MYERS_MAX_WORDS, symmetric, addresses, query_lengths, q, addresses, candidate_lengths, c, query_refs, candidate_refs, keys,
                    scratch, &plan);
-    szs_plan_queue(&plan, q, c, queue);
+    szs_plan_queue(&plan, q, c, alphabet, alphabet ? 72u << 10 : 64u << 10, queue);
     *tiles_count = queue->tiles_count, *items_total = queue->items_total;
     for (unsigned t = 0; t < queue->tiles_count && t < capacity && tiles; ++t) {
         szs_queue_tile_t const *tile = &queue->tiles[t];
-        uint32_t const row[9] = {tile->first_item, tile->query_first, tile->query_count, tile->candidate_first, tile->candidate_end,
-                                 tile->candidates_per_item, tile->words_per_lane, tile->lanes, tile->queries_per_item};
-        memcpy(tiles + 9 * (size_t)t, row, sizeof(row));
+        uint32_t const row[10] = {tile->first_item, tile->query_first, tile->query_count, tile->candidate_first, tile->candidate_end,
+                                  tile->candidates_per_item, tile->words_per_lane, tile->lanes, tile->queries_per_item, tile->flags};
+        memcpy(tiles + 10 * (size_t)t, row, sizeof(row));
     }
     free(addresses), free(query_refs), free(candidate_refs), free(keys), free(scratch), free(queue);
     return sz_success_k;

@@ -111,6 +111,8 @@ typedef struct szs_engine_s {
     szs_buffer_t device_queue_trace; /* device: per-workgroup begin / end ticks of that launch (`trace` knob only) */
     void *queue_zeroed;            /* the allocation of `device_queue` that was zeroed: another pointer means a fresh buffer */
     uint32_t queue_tickets;        /* the counter's value when the next launch begins (every launch says what it takes) */
+    uint32_t queue_unfit_sequence; /* what the current call's queue launch writes to pinned memory if a query fits none of its tables; 0: no such launch */
+    int queue_refused;             /* this call is being scored again without the queue */
     hipEvent_t event_start, event_stop;
     int events_device;
     /* launches of different bit-vector widths fan out over these and fill each other's tails (dispatch.c: enqueue) */
@@ -215,6 +217,7 @@ typedef struct szs_decision_t {
     unsigned team;             /* 0, or the shape of the team tier that scores the call (hip/kernels.h: lanes * 10000 + registers * 100 + waves) */
     uint32_t classes;
     uint32_t kq_count, kc_count; /* kernel roles */
+    uint64_t kq_symbols;         /* symbols of the kernels' query side (with longest_query: how skewed the lengths are) */
     uint32_t longest[2];         /* the caller's sides: queries, candidates */
     szs_plan_t plan;             /* kernel roles: groups of the query side, longest strings, cells */
     size_t systolic_control_bytes, systolic_parked_bytes;
@@ -260,8 +263,11 @@ void szs_plan_launch_order(szs_plan_t const *plan, int use_myers, int runes, uin
  *  (hip/myers_queue.hip): tiles of (a slice of the queries) x (a column of the candidates), each with its shape - lanes per
  *  pair, words per lane, candidates per work item - sorted by the time one of their items holds a workgroup, longest first.
  *  From the plan's groups (variant 0, the strip kernel's, is left out), its rank samples and its cells; plan.c has the model.
+ *  Strings are bytes, or - for a codepoint batch the device renumbered (hip/utf8.hip) - ids of an alphabet of `alphabet` runes.
  */
-void szs_plan_queue(szs_plan_t const *plan, uint32_t queries_count, uint32_t candidates_count, szs_queue_plan_t *queue);
+void szs_plan_queue(szs_plan_t const *plan, uint32_t queries_count, uint32_t candidates_count,
+                    uint32_t alphabet /* 0: bytes; A: codepoints renumbered 1 ... A */, size_t table_bytes /* LDS of a workgroup's tables */,
+                    szs_queue_plan_t *queue /* items_total 0: nothing to queue, or (codepoints) an alphabet too rich for its tables */);
 
 #define SZS_TIER_LANES 0    /* one pair per lane: lev_myers.hip, weighted.hip */
 #define SZS_TIER_SYSTOLIC 1 /* one pair per chain of wavefronts: systolic.hip */

@@ -152,3 +152,74 @@ def test_config5_scaled_both_ways(gpu, oracle):
         with knob("queue", 0):
             assert np.array_equal(engine(load.queries, load.candidates, device=gpu), expected)
             assert engine.last_call_profile().launches > 1
+
+
+def _text(rng, count, lo, hi, pools):
+    """UTF-8 strings of lo ... hi codepoints drawn from `pools` (lists of characters), as bytes."""
+    alphabet = [c for pool in pools for c in pool]
+    return ["".join(rng.choice(alphabet) for _ in range(rng.randint(lo, hi))).encode() for _ in range(count)]
+
+
+ASCII = [chr(c) for c in range(0x20, 0x7F)]
+CYRILLIC = [chr(c) for c in range(0x410, 0x450)]
+LATIN = [chr(c) for c in range(0xC0, 0x17F)]
+HAN = [chr(c) for c in range(0x4E00, 0x4E00 + 600)]
+HAN_MANY = [chr(c) for c in range(0x4E00, 0x4E00 + 3000)]
+EMOJI = [chr(c) for c in range(0x1F600, 0x1F640)]
+
+
+@pytest.mark.parametrize("words", [None, 4, 8, 12, 16])
+@pytest.mark.parametrize("pools", ["small", "medium"])
+def test_codepoint_calls_through_the_queue(gpu, oracle, pools, words):
+    """The codepoint engine over a batch the device renumbered: ONE scoring launch, tables of alphabet + 1 rows - rows of masks
+    for short queries and small alphabets, pointers + a pool of the non-zero chunks for long queries over a rich one."""
+    rng = random.Random(len(pools) * 100 + (words or 0))
+    chosen = [ASCII, CYRILLIC] if pools == "small" else [ASCII, CYRILLIC, LATIN, HAN, EMOJI]
+    queries = _text(rng, 12, 0, 60, chosen) + _text(rng, 6, 250, 700, chosen) + _text(rng, 4, 1000, 2048, chosen) + [b"", "я".encode()]
+    queries += ["".join(rng.choice(ASCII + CYRILLIC) for _ in range(n)).encode() for n in (255, 256, 257, 384, 385, 512, 513, 2047, 2048)]
+    candidates = _text(rng, 150, 0, 90, chosen) + _text(rng, 12, 300, 800, chosen) + [b"", queries[20]]
+    engine = szs.LevenshteinDistancesUTF8(capabilities=gpu)
+    expected = oracle.levenshtein_utf8(queries, candidates)
+    with knob("tier", "lanes"), knob("swap", 0), knob("alphabet", 1), knob("queue", 1), knob("queue_words", words):
+        got = engine(queries, candidates, device=gpu)
+        profile = engine.last_call_profile()
+        wrong = np.argwhere(got != expected)
+        assert wrong.size == 0, (pools, words, [(len(queries[q].decode()), len(candidates[c].decode()), int(got[q, c]), int(expected[q, c])) for q, c in wrong[:6]])
+        assert profile.launches == 1 and profile.queue_items > 0, (profile.launches, profile.queue_items)
+        self_expected = oracle.levenshtein_utf8(queries[::2], None)
+        assert np.array_equal(engine(queries[::2], device=gpu), self_expected)
+        with knob("swap", 1):
+            assert np.array_equal(engine(candidates, queries, device=gpu), expected.T)
+    with knob("tier", "lanes"), knob("swap", 0), knob("alphabet", 1), knob("queue", 0):  # the per-width codepoint launches agree
+        assert np.array_equal(engine(queries, candidates, device=gpu), expected)
+        assert engine.last_call_profile().queue_items == 0
+
+
+def test_an_alphabet_too_rich_for_the_tables_keeps_the_per_width_launches(gpu, oracle):
+    """3,000 distinct runes and a 2,000-rune query: 16 lanes x (3001 x 2 bytes of pointers) + a 32 KB pool is more LDS than a
+    workgroup has - the plan says so, the queue stays empty, the per-width kernels (three-level tables) score the call."""
+    rng = random.Random(3000)
+    queries = _text(rng, 8, 0, 80, [ASCII, HAN_MANY]) + _text(rng, 3, 1900, 2048, [HAN_MANY])
+    candidates = _text(rng, 90, 0, 200, [ASCII, HAN_MANY]) + _text(rng, 3, 600, 2048, [HAN_MANY])
+    engine = szs.LevenshteinDistancesUTF8(capabilities=gpu)
+    with knob("tier", "lanes"), knob("swap", 0), knob("alphabet", 1), knob("queue", 1):
+        got = engine(queries, candidates, device=gpu)
+        assert np.array_equal(got, oracle.levenshtein_utf8(queries, candidates))
+        assert engine.last_call_profile().queue_items == 0 and engine.last_call_profile().launches > 1
+
+
+def test_config5_codepoints_scaled(gpu, oracle):
+    """Config 5 at the codepoint level, 1 / 12 of its side, left to itself (renumbering is automatic from the second call of
+    a stream on: the engine goes by the cells of its previous call) and with the renumbering pinned."""
+    load = workloads.config(6, scale=1 / 12)
+    queries = [load.queries[i] for i in range(len(load.queries))]
+    candidates = [load.candidates[i] for i in range(len(load.candidates))]
+    expected = oracle.levenshtein_utf8(queries, candidates)
+    engine = szs.LevenshteinDistancesUTF8(capabilities=gpu)
+    with knob("tier", "lanes"):
+        for _ in range(2):
+            assert np.array_equal(engine(load.queries, load.candidates, device=gpu), expected)
+        with knob("alphabet", 1):
+            assert np.array_equal(engine(load.queries, load.candidates, device=gpu), expected)
+            profile = engine.last_call_profile()
+            assert profile.launches == 1 and profile.queue_items > 0, (profile.launches, profile.queue_items)

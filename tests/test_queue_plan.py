@@ -13,12 +13,12 @@ import pytest
 from stringzilla_amd import _abi
 
 
-def plan(query_lengths, candidate_lengths, symmetric=False):
+def plan(query_lengths, candidate_lengths, symmetric=False, alphabet=0):
     queries = np.ascontiguousarray(query_lengths, dtype=np.uint32)
     candidates = np.ascontiguousarray(candidate_lengths, dtype=np.uint32)
-    tiles = np.zeros((96, 9), dtype=np.uint32)
+    tiles = np.zeros((96, 10), dtype=np.uint32)
     count, items = ctypes.c_size_t(), ctypes.c_uint64()
-    status = _abi.lib.szs_rocm_queue_probe(int(symmetric), queries.ctypes.data, len(queries), candidates.ctypes.data, len(candidates),
+    status = _abi.lib.szs_rocm_queue_probe(int(symmetric), alphabet, queries.ctypes.data, len(queries), candidates.ctypes.data, len(candidates),
                                            tiles.ctypes.data, 96, ctypes.byref(count), ctypes.byref(items))
     assert status == 0
     assert count.value <= 96
@@ -29,24 +29,34 @@ def words_of(length):
     return max(1, -(-int(length) // 32))
 
 
-def walk(tiles, items, query_lengths, candidate_lengths):
+def walk(tiles, items, query_lengths, candidate_lengths, alphabet=0):
     """The kernel's own arithmetic.  Returns the coverage matrix [query position (longest first)][candidate position (ascending)]."""
     sorted_queries = np.sort(np.asarray(query_lengths))[::-1]
     covered = np.zeros((len(query_lengths), len(candidate_lengths)), dtype=np.int32)
     expected_first = 0
-    for first_item, query_first, query_count, c_first, c_end, per_item, words_per_lane, lanes, per_group in tiles:
+    rows, arena_dwords = (alphabet + 1, 72 * 256) if alphabet else (256, 64 * 256)
+    for first_item, query_first, query_count, c_first, c_end, per_item, words_per_lane, lanes, per_group, flags in tiles:
         assert first_item == expected_first and query_count > 0 and c_end > c_first and per_item > 0 and 1 <= per_group <= 16
         blocks, groups = -(-(c_end - c_first) // per_item), -(-query_count // per_group)
         expected_first += groups * blocks
         longest = int(sorted_queries[query_first])  # slices are cut from the descending array: its first query is its longest
         assert lanes >= 1 and lanes <= 16
-        slot_words = (64 // per_group) & ~3  # words of the workgroup's table each query of a group gets
+        slot_words = (64 // per_group) & ~3  # words of pattern each query of a group may hold
+        slot_dwords = (arena_dwords // per_group) & ~3  # dwords of LDS each query's table gets
+        needed = words_of(longest)
         if lanes == 1:
-            needed = words_of(longest)
-            assert needed <= 20, (longest, "one lane per pair takes up to 20 words")
-            assert (needed if needed <= 8 else 10 if needed <= 10 else 12 if needed <= 12 else 16 if needed <= 16 else 20) <= slot_words, (longest, per_group)
+            assert needed <= (16 if alphabet else 20), (longest, "one lane per pair takes up to 20 words (16 of codepoints)")
+            body = needed if needed <= 8 else (12 if needed <= 12 else 16) if alphabet else 10 if needed <= 10 else 12 if needed <= 12 else 16 if needed <= 16 else 20
+            table = rows * ((body + 3) & ~3) if alphabet or body >= 3 else rows * body
+            assert body <= slot_words and not flags
         else:
-            assert words_per_lane in (4, 8, 12, 16) and words_of(longest) <= words_per_lane * lanes <= slot_words, (longest, words_per_lane, lanes, per_group)
+            assert words_per_lane in (4, 8, 12, 16) and needed <= words_per_lane * lanes <= slot_words, (longest, words_per_lane, lanes, per_group)
+            if flags & 1:  # pointers (16 bits per chunk of a lane, padded to one read) + a pool of the non-zero chunks
+                assert alphabet
+                table = -(-(rows * lanes * (2 if words_per_lane <= 4 else 4 if words_per_lane <= 8 else 8)) // 16) * 4 + (longest + 1) * 4
+            else:
+                table = rows * words_per_lane * lanes
+        assert table <= slot_dwords, (longest, lanes, words_per_lane, per_group, flags, table, slot_dwords)
         for local in range(groups * blocks):
             block, group = divmod(local, groups)
             q_first = query_first + group * per_group
@@ -101,7 +111,7 @@ def test_tiles_come_longest_first_and_shapes_follow_the_call():
     ascending = np.sort(candidates)
 
     def key(tile):
-        _, query_first, _, c_first, c_end, per_item, words_per_lane, lanes, per_group = tile
+        _, query_first, _, c_first, c_end, per_item, words_per_lane, lanes, per_group, _ = tile
         pairs_per_wave = 64 // lanes
         wave_blocks = per_group * -(-per_item // pairs_per_wave)
         return -(-wave_blocks // 8) * (words_per_lane if lanes > 1 else 1) * int(ascending[c_end - 1])
@@ -141,3 +151,24 @@ def test_knobs_pin_the_shape():
     for tile in tiles:
         pairs_per_wave = 64 // tile[7]
         assert tile[8] <= 24 and tile[5] == min(max(1, 24 // tile[8]) * pairs_per_wave, tile[4] - tile[3]), tile.tolist()
+
+
+@pytest.mark.parametrize("alphabet", [60, 255, 926, 1500, 4095])
+def test_codepoint_batches_get_tables_that_fit(alphabet):
+    """Codepoints of a renumbered batch: tables have alphabet + 1 rows; what does not fit as rows (a 2048-rune query at 926
+    symbols would be 237 KB) is pointers + a pool of the non-zero chunks, on teams only; an alphabet too rich for even that
+    leaves the queue empty and the call to the per-width launches."""
+    rng = np.random.default_rng(alphabet)
+    queries, candidates = zipf_lengths(rng, 700), zipf_lengths(rng, 900)
+    tiles, items = plan(queries, candidates, alphabet=alphabet)
+    longest = int(queries.max())
+    pool_fits = lambda lanes, words: -(-((alphabet + 1) * lanes * (2 if words <= 4 else 4 if words <= 8 else 8)) // 16) * 16 + (longest + 1) * 16 <= 72 << 10
+    if not items:  # no team shape of the longest query has a table
+        assert not any(pool_fits(-(-words_of(longest) // words), words) for words in (4, 8, 12, 16) if -(-words_of(longest) // words) <= 16)
+        return
+    covered = walk(tiles, items, queries, candidates, alphabet=alphabet)
+    assert covered.min() == 1 and covered.max() == 1
+    if alphabet >= 926:
+        assert any(tile[9] & 1 for tile in tiles), "long codepoint queries over a rich alphabet take the sparse tables"
+    if alphabet <= 255:
+        assert not any(tile[9] & 1 for tile in tiles), "a small alphabet's tables are rows, like the byte tables"
