@@ -57,6 +57,15 @@ SZ_API_RUNTIME sz_status_t szs_rocm_shard_rows(sz_size_t const *row_weights, sz_
                                                sz_u32_t *shard_of_row, sz_u64_t *shard_loads);
 
 /**
+ *  Deals the rows of a SYMMETRIC call's lower triangle to `shards` devices as contiguous bands of equal weight - row i weighs
+ *  (len_i + 1) x sum_{j <= i} (len_j + 1), its cells - band g = rows [band_first[g], band_first[g + 1]);
+ *  `band_first` holds shards + 1 entries, `band_weights` (optional) the weights dealt.  A band is its rows against every string
+ *  before it (a rectangle) plus the triangle of its own rows: two ordinary calls of a single-GPU engine.
+ */
+SZ_API_RUNTIME sz_status_t szs_rocm_shard_triangle(sz_size_t const *lengths, sz_size_t rows, sz_size_t shards, sz_size_t *band_first,
+                                                   sz_u64_t *band_weights);
+
+/**
  *  Runs the host planner on bare length arrays.  Outputs (all optional):
  *    candidate_order[c]  - candidate indices by ascending length (stable);
  *    query_order[q]      - query indices grouped by kernel variant;
@@ -136,6 +145,10 @@ typedef struct szs_rocm_node_stats_t {
     sz_u64_t cells[SZS_ROCM_NODE_MOST_GPUS];              /* per GPU: DP cells scored */
     sz_u64_t row_weights[SZS_ROCM_NODE_MOST_GPUS];        /* per GPU: sum of (len(query) + 1) over its rows - what LPT balances */
     sz_u32_t rows[SZS_ROCM_NODE_MOST_GPUS];               /* per GPU: query rows dealt to it */
+    sz_u32_t peer_copies[SZS_ROCM_NODE_MOST_GPUS];        /* per GPU: tape replicas that came straight from another GPU's memory (peer access over xGMI) */
+    sz_u32_t staged_copies[SZS_ROCM_NODE_MOST_GPUS];      /* per GPU: replicas staged through pinned host memory (no peer access to the source GPU), or from host memory */
+    sz_u32_t peer_pairs;                                  /* ordered pairs of the node's GPUs with peer access enabled (szs_rocm_node_init) */
+    sz_u32_t symmetric;                                   /* 1: the call sharded the lower triangle (bands of rows) and mirrored it */
 } szs_rocm_node_stats_t;
 
 /** `gpu_devices` NULL or `count` 0: every visible GPU.  `*node` receives the handle. */
@@ -164,7 +177,9 @@ SZ_API_RUNTIME sz_status_t szs_rocm_node_smith_waterman_scores_init(szs_rocm_nod
 SZ_API_RUNTIME void szs_rocm_node_engine_free(szs_rocm_node_engine_t engine);
 
 /**
- *  Scores all `queries x candidates` (`candidates` NULL: queries against themselves) into `results[q * stride + c]`, 8-byte
+ *  Scores all `queries x candidates` into `results[q * stride + c]`, 8-byte cells.  `candidates` NULL: queries against themselves
+ *  - the lower triangle is scored ONCE, in bands of rows of equal weight (szs_rocm_shard_triangle), and mirrored, as the
+ *  single-GPU engines do (serial.hpp:3169-3182).  8-byte
  *  cells (`sz_size_t` distances / `sz_ssize_t` scores).  Tapes may live in host, pinned, unified or any GPU's memory;
  *  so may `results`.  Synchronous.  `stats` (optional) receives the per-GPU timing the multi-GPU configs ask to report.
  */

@@ -477,6 +477,8 @@ class NodeEngine:
             "gpus": gpus, "wall_ms": float(stats.wall_milliseconds), "busy_ms": [float(stats.busy_milliseconds[i]) for i in range(gpus)],
             "kernel_ms": [float(stats.kernel_milliseconds[i]) for i in range(gpus)], "cells": [int(stats.cells[i]) for i in range(gpus)],
             "rows": [int(stats.rows[i]) for i in range(gpus)], "row_weights": [int(stats.row_weights[i]) for i in range(gpus)],
+            "peer_copies": [int(stats.peer_copies[i]) for i in range(gpus)], "staged_copies": [int(stats.staged_copies[i]) for i in range(gpus)],
+            "peer_pairs": int(stats.peer_pairs), "symmetric": bool(stats.symmetric),
         }
         if out is None:
             return results.view(np.int64 if self._signed else np.uint64)

@@ -68,6 +68,8 @@ class NodeStats(ctypes.Structure):
         ("busy_milliseconds", ctypes.c_double * NODE_MOST_GPUS), ("kernel_milliseconds", ctypes.c_double * NODE_MOST_GPUS),
         ("cells", ctypes.c_uint64 * NODE_MOST_GPUS), ("row_weights", ctypes.c_uint64 * NODE_MOST_GPUS),
         ("rows", ctypes.c_uint32 * NODE_MOST_GPUS),
+        ("peer_copies", ctypes.c_uint32 * NODE_MOST_GPUS), ("staged_copies", ctypes.c_uint32 * NODE_MOST_GPUS),
+        ("peer_pairs", ctypes.c_uint32), ("symmetric", ctypes.c_uint32),
     ]
 
 
@@ -110,6 +112,7 @@ SIGNATURES = {
     # ROCm-only additions (include/stringzillas/stringzillas_rocm.h)
     "szs_rocm_last_call_profile": (c_int, [c_void_p, ctypes.POINTER(CallProfile)]),
     "szs_rocm_shard_rows": (c_int, [c_void_p, c_size_t, c_size_t, c_void_p, c_void_p]),
+    "szs_rocm_shard_triangle": (c_int, [c_void_p, c_size_t, c_size_t, c_void_p, c_void_p]),
     "szs_rocm_plan_probe": (c_int, [c_int, c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "szs_rocm_orientation_probe": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p]),
     "szs_rocm_team_orientation_probe": (c_int, [c_int, c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),

@@ -177,6 +177,12 @@ unsigned szs_hip_levenshtein_myers_queue_grid(uint64_t items, int runes);
 /** Bytes of LDS a workgroup's tables share: 64 KB for bytes, 72 KB for codepoints (what szs_plan_queue fits its tiles into). */
 size_t szs_hip_levenshtein_myers_queue_table_bytes(int runes);
 
+/**
+ *  Fills the cells above the diagonal of a `side` x `side` matrix of 8-byte values from the ones below it (hip/mirror.hip): what a
+ *  symmetric call sharded over several GPUs by bands of rows (host/node.c) needs once every band has landed.
+ */
+int szs_hip_mirror_lower(uint64_t *matrix, uint32_t side, uint64_t row_stride, void *stream);
+
 /* ---- tuning knobs (host/tuning.c): read from the environment ONCE at load, changed only by szs_rocm_tuning_set -------- */
 
 enum {

@@ -8,14 +8,23 @@
  *
  *    deal       query ROWS are dealt to the GPUs by longest-processing-time on len(query) (szs_rocm_shard_rows): cells are
  *               independent, every GPU writes a disjoint set of result rows, ragged batches (config 5) stay balanced;
- *    replicate  each GPU receives both tapes' bytes once (`hipMemcpyAsync`, kind default: peer-to-peer over xGMI when the
- *               source lives on another GPU, over the host link when it lives in host memory; skipped when the bytes are
- *               already resident on that GPU) - a few MB against seconds of scoring;
+ *    replicate  each GPU receives both tapes' bytes once (peer-to-peer over xGMI when the source lives on another GPU the node
+ *               enabled peer access to, staged through pinned memory otherwise, over the host link when it lives in host
+ *               memory; skipped when the bytes are already resident on that GPU) - a few MB against seconds of scoring;
  *    score      one host thread per GPU calls the ordinary single-GPU engine (dispatch.c) on `its rows x all candidates`:
  *               its rows as a callback sequence over the replica, the candidates as a tape over the replica, results into
  *               a dense block in that GPU's HBM.  No collective, no cross-GPU traffic while scoring;
  *    place      every result row goes from the block to its place in the caller's matrix (`hipMemcpyAsync` per run of
  *               consecutive rows; the matrix may live in host, pinned, unified or any GPU's memory).
+ *
+ *  A SYMMETRIC call (candidates NULL) shards the LOWER TRIANGLE instead (round 4; round 3 scored the full square, twice the
+ *  single-GPU engines' work): contiguous bands of rows of equal weight - row i weighs len_i x sum_{j <= i} len_j
+ *  (szs_rocm_shard_triangle) - each band a rectangle (its rows x everything before it) plus the triangle of
+ *  its own rows, two ordinary engine calls; the cells above the diagonal are mirrored once every band has landed (hip/mirror.hip).
+ *
+ *  Peer access is arranged, not assumed (round 4): szs_rocm_node_init asks `hipDeviceCanAccessPeer` for every ordered pair of the
+ *  node's GPUs and enables what it can; a replica then crosses xGMI in one `hipMemcpyPeerAsync`, and a pair without peer
+ *  access is staged through pinned host memory.  Both are counted in szs_rocm_node_stats_t.
  *
  *  The per-GPU engines are the same objects `szs_*_init` creates: same kernels, same planner, bit-identical scores.
  */
@@ -44,6 +53,10 @@ typedef struct szs_node_s {
     size_t count;
     int devices[SZS_ROCM_NODE_MOST_GPUS];
     szs_scope_s *scopes[SZS_ROCM_NODE_MOST_GPUS];
+    /* peer[i][j]: GPU i of the node reads GPU j's memory directly (hipDeviceEnablePeerAccess succeeded): a replica then comes over
+     * xGMI in one copy; without it the bytes are staged through pinned host memory */
+    uint8_t peer[SZS_ROCM_NODE_MOST_GPUS][SZS_ROCM_NODE_MOST_GPUS];
+    uint32_t peer_pairs;
 } szs_node_s;
 
 typedef struct {
@@ -57,6 +70,7 @@ typedef struct szs_node_engine_s {
     void *engines[SZS_ROCM_NODE_MOST_GPUS]; /* ordinary single-GPU engines, one per GPU */
     /* per-GPU replicas and blocks, grow-only */
     szs_buffer_t query_bytes[SZS_ROCM_NODE_MOST_GPUS], candidate_bytes[SZS_ROCM_NODE_MOST_GPUS], blocks[SZS_ROCM_NODE_MOST_GPUS];
+    szs_buffer_t staging[SZS_ROCM_NODE_MOST_GPUS]; /* pinned: replicas from a GPU this one has no peer access to */
     /* host scratch of one call */
     szs_buffer_t offsets_copy, shard_of_row, weights, row_lists, row_addresses, row_lengths;
 } szs_node_engine_s;
@@ -85,6 +99,26 @@ sz_status_t szs_rocm_node_init(sz_size_t const *gpu_devices, sz_size_t count, sz
         }
         node->devices[i] = (int)ordinal, node->scopes[i] = (szs_scope_s *)scope; /* the same GPU may appear twice (testing) */
     }
+    /* Peer access, once per ordered pair of distinct GPUs: the replicas of a call then travel GPU to GPU over xGMI.  A pair the
+     * runtime refuses is not an error - its copies are staged through pinned host memory (node_replicate) - it is REPORTED
+     * (szs_rocm_node_stats_t.peer_pairs, peer_copies, staged_copies). */
+    int previous = 0;
+    (void)hipGetDevice(&previous);
+    for (size_t i = 0; i < count; ++i)
+        for (size_t j = 0; j < count; ++j) {
+            if (node->devices[i] == node->devices[j]) continue;
+            int reachable = 0;
+            if (hipDeviceCanAccessPeer(&reachable, node->devices[i], node->devices[j]) != hipSuccess || !reachable) {
+                (void)hipGetLastError();
+                continue;
+            }
+            hipError_t error = hipSetDevice(node->devices[i]);
+            if (error == hipSuccess) error = hipDeviceEnablePeerAccess(node->devices[j], 0);
+            if (error == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError(), error = hipSuccess;
+            if (error == hipSuccess) node->peer[i][j] = 1, node->peer_pairs++;
+            else (void)hipGetLastError();
+        }
+    (void)hipSetDevice(previous);
     *out = node;
     return szs_report(sz_success_k, error_message, NULL);
 }
@@ -138,6 +172,7 @@ void szs_rocm_node_engine_free(szs_rocm_node_engine_t handle) {
         szs_buffer_release(&engine->query_bytes[i]);
         szs_buffer_release(&engine->candidate_bytes[i]);
         szs_buffer_release(&engine->blocks[i]);
+        szs_buffer_release(&engine->staging[i]);
         if (engine->engines[i]) szs_levenshtein_distances_free(engine->engines[i]); /* every family frees the same object */
     }
     (void)hipSetDevice(previous);
@@ -211,6 +246,9 @@ typedef struct {
     size_t queries_count, candidates_count;
     uint32_t const *rows; /* global query rows of this shard, ascending */
     size_t rows_count;
+    int symmetric;        /* the shard is the band of rows [band_first, band_first + rows_count) of the lower triangle */
+    size_t band_first;
+    uint32_t peer_copies, staged_copies;
     uint64_t *row_addresses;
     uint32_t *row_lengths;
     void *results;
@@ -225,23 +263,82 @@ typedef struct {
 /** Bytes [first, first + bytes) of a tape on the GPU of this task: in place when they already live there, else replicated
  *  once per call.  `*base` addresses byte `first` of the tape - offsets are REBASED by the caller to start at zero, so that
  *  every address handed to the engine lies inside a real allocation. */
-static sz_status_t node_replicate(szs_buffer_t *replica, int device, hipStream_t stream, char const *data, uint64_t first, uint64_t bytes,
-                                  char const **base, char const **error_message) {
+static sz_status_t node_replicate(szs_node_engine_s *engine, size_t shard, szs_buffer_t *replica, int device, hipStream_t stream,
+                                  char const *data, uint64_t first, uint64_t bytes, char const **base, uint32_t *peer_copies,
+                                  uint32_t *staged_copies, char const **error_message) {
     *base = data + first;
     if (!bytes) return sz_success_k;
+    szs_node_s const *node = engine->node;
     hipPointerAttribute_t attributes;
     memset(&attributes, 0, sizeof(attributes));
+    int source_device = -1; /* the GPU the bytes live on, -1: host memory */
     if (hipPointerGetAttributes(&attributes, data + first) == hipSuccess) {
         if ((attributes.type == hipMemoryTypeDevice && attributes.device == device) || attributes.type == hipMemoryTypeManaged)
             return sz_success_k; /* resident on this GPU, or migrating on demand: nothing to copy */
+        if (attributes.type == hipMemoryTypeDevice) source_device = attributes.device;
     }
     else (void)hipGetLastError();
-    sz_status_t const status = szs_buffer_reserve(replica, szs_memory_device_k, device, bytes, error_message);
+    sz_status_t status = szs_buffer_reserve(replica, szs_memory_device_k, device, bytes, error_message);
     if (status != sz_success_k) return status;
-    hipError_t const error = hipMemcpyAsync(replica->pointer, data + first, bytes, hipMemcpyDefault, stream);
+    /* From another GPU: straight over xGMI when szs_rocm_node_init enabled peer access for the pair; else through pinned host
+     * memory, explicitly - what the runtime would do behind `hipMemcpyDefault` anyway, but counted. */
+    int direct = source_device < 0;
+    for (size_t j = 0; j < node->count && !direct; ++j) direct = node->devices[j] == source_device && node->peer[shard][j];
+    hipError_t error;
+    if (direct) {
+        error = source_device < 0 ? hipMemcpyAsync(replica->pointer, data + first, bytes, hipMemcpyDefault, stream)
+                                  : hipMemcpyPeerAsync(replica->pointer, device, data + first, source_device, bytes, stream);
+        if (source_device < 0) ++*staged_copies; /* from host memory: over the host link, by definition */
+        else ++*peer_copies;
+    }
+    else {
+        status = szs_buffer_reserve(&engine->staging[shard], szs_memory_pinned_k, device, bytes, error_message);
+        if (status != sz_success_k) return status;
+        error = hipMemcpy(engine->staging[shard].pointer, data + first, bytes, hipMemcpyDeviceToHost);
+        if (error == hipSuccess) error = hipMemcpyAsync(replica->pointer, engine->staging[shard].pointer, bytes, hipMemcpyHostToDevice, stream);
+        ++*staged_copies;
+    }
     if (error != hipSuccess) return szs_report_hip(error, error_message);
     *base = (char const *)replica->pointer;
     return sz_success_k;
+}
+
+/**
+ *  One band of a SYMMETRIC call: rows [a, b) of the lower triangle = (rows [a, b) x strings [0, a)), a rectangle, + the triangle
+ *  of the rows themselves - two ordinary calls of this GPU's engine on slices of ONE tape (the rebased offsets of the call),
+ *  results into one block [b - a][b] of this GPU's HBM, then one 2-D copy to the caller's rows.  The cells above the diagonal
+ *  that belong to other bands are mirrored after every band has landed (node_cross).  Scores what the single-GPU engines score:
+ *  the lower triangle, once (serial.hpp:3169-3182).
+ */
+static void node_band(node_task_t *task, int device, hipStream_t stream, char const *base) {
+    szs_node_engine_s *engine = task->engine;
+    size_t const shard = task->shard, first = task->band_first, rows = task->rows_count, end = first + rows;
+    task->status = szs_buffer_reserve(&engine->blocks[shard], szs_memory_device_k, device, rows * end * sizeof(uint64_t), &task->message);
+    if (task->status != sz_success_k) {
+        (void)hipStreamSynchronize(stream);
+        return;
+    }
+    size_t const offset_size = task->wide ? 8 : 4;
+    szs_input_kind_t const kind = task->wide ? szs_input_u64tape_k : szs_input_u32tape_k;
+    /* `query_offsets` were rebased to the replica by node_cross: slices of them are tapes over `base` */
+    szs_input_t const band = {kind, rows, base, (char const *)task->query_offsets + first * offset_size, NULL};
+    szs_input_t const before = {kind, first, base, task->query_offsets, NULL};
+    szs_engine_s *const single = (szs_engine_s *)engine->engines[shard];
+    uint64_t *const block = (uint64_t *)engine->blocks[shard].pointer;
+    if (first) { /* the rectangle: columns [0, first) of the block */
+        task->status = szs_engine_cross(single, engine->node->scopes[shard], &band, &before, block, end, &task->message);
+        if (task->status != sz_success_k) return;
+        task->kernel_milliseconds += single->last_profile.kernel_milliseconds, task->cells += single->last_profile.cells;
+    }
+    /* the triangle: columns [first, end) of the block, both halves of it (the engine mirrors inside its own square) */
+    task->status = szs_engine_cross(single, engine->node->scopes[shard], &band, NULL, block + first, end, &task->message);
+    if (task->status != sz_success_k) return;
+    task->kernel_milliseconds += single->last_profile.kernel_milliseconds, task->cells += single->last_profile.cells;
+    hipError_t error = hipMemcpy2DAsync((uint64_t *)task->results + first * task->results_row_stride, task->results_row_stride * sizeof(uint64_t),
+                                        block, end * sizeof(uint64_t), end * sizeof(uint64_t), rows, hipMemcpyDefault, stream);
+    hipError_t const drained = hipStreamSynchronize(stream);
+    if (error == hipSuccess) error = drained;
+    if (error != hipSuccess) task->status = szs_report_hip(error, &task->message);
 }
 
 static void *node_worker(void *argument) {
@@ -259,11 +356,17 @@ static void *node_worker(void *argument) {
     if (task->status != sz_success_k) return NULL;
 
     char const *query_base = NULL, *candidate_base = NULL;
-    task->status = node_replicate(&engine->query_bytes[shard], device, stream, task->query_data, task->query_first, task->query_bytes,
-                                  &query_base, &task->message);
+    task->status = node_replicate(engine, shard, &engine->query_bytes[shard], device, stream, task->query_data, task->query_first,
+                                  task->query_bytes, &query_base, &task->peer_copies, &task->staged_copies, &task->message);
+    if (task->symmetric) { /* one tape plays both roles: see node_band */
+        if (task->status == sz_success_k) node_band(task, device, stream, query_base);
+        else (void)hipStreamSynchronize(stream);
+        task->busy_milliseconds = node_now_milliseconds() - started;
+        return NULL;
+    }
     if (task->status == sz_success_k)
-        task->status = node_replicate(&engine->candidate_bytes[shard], device, stream, task->candidate_data, task->candidate_first,
-                                      task->candidate_bytes, &candidate_base, &task->message);
+        task->status = node_replicate(engine, shard, &engine->candidate_bytes[shard], device, stream, task->candidate_data, task->candidate_first,
+                                      task->candidate_bytes, &candidate_base, &task->peer_copies, &task->staged_copies, &task->message);
     if (task->status == sz_success_k)
         task->status = szs_buffer_reserve(&engine->blocks[shard], szs_memory_device_k, device,
                                           task->rows_count * task->candidates_count * sizeof(uint64_t), &task->message);
@@ -308,13 +411,40 @@ static void *node_worker(void *argument) {
     return NULL;
 }
 
-static sz_status_t node_cross(szs_node_engine_s *engine, int wide, char const *query_data, void const *query_offsets_raw, size_t queries_count,
-                              char const *candidate_data, void const *candidate_offsets_raw, size_t candidates_count, void *results,
-                              size_t results_row_stride, szs_rocm_node_stats_t *stats, char const **error_message) {
+/** Fills the cells above the diagonal from the ones below: on the device when it can reach the matrix, on the host otherwise. */
+static sz_status_t node_mirror(szs_node_s *node, void *results, size_t side, size_t stride, char const **error_message) {
+    szs_pointer_traits_t const traits = szs_classify_pointer(results);
+    if (!traits.device_accessible) {
+        uint64_t *const matrix = (uint64_t *)results;
+        for (size_t i = 1; i < side; ++i)
+            for (size_t j = 0; j < i; ++j) matrix[j * stride + i] = matrix[i * stride + j];
+        return sz_success_k;
+    }
+    size_t shard = 0; /* the GPU that owns the matrix, when it is one of the node's; else the first */
+    hipPointerAttribute_t attributes;
+    memset(&attributes, 0, sizeof(attributes));
+    if (hipPointerGetAttributes(&attributes, results) == hipSuccess && attributes.type == hipMemoryTypeDevice) {
+        for (size_t s = 0; s < node->count; ++s)
+            if (node->devices[s] == attributes.device) { shard = s; break; }
+    }
+    else (void)hipGetLastError();
+    int device = 0;
+    hipStream_t stream = NULL;
+    sz_status_t const status = szs_scope_bind_gpu(node->scopes[shard], &device, &stream, error_message);
+    if (status != sz_success_k) return status;
+    hipError_t error = (hipError_t)szs_hip_mirror_lower((uint64_t *)results, (uint32_t)side, stride, stream);
+    hipError_t const drained = hipStreamSynchronize(stream);
+    if (error == hipSuccess) error = drained;
+    return error == hipSuccess ? sz_success_k : szs_report_hip(error, error_message);
+}
+
+static sz_status_t node_cross(szs_node_engine_s *engine, int wide, int symmetric, char const *query_data, void const *query_offsets_raw,
+                              size_t queries_count, char const *candidate_data, void const *candidate_offsets_raw, size_t candidates_count,
+                              void *results, size_t results_row_stride, szs_rocm_node_stats_t *stats, char const **error_message) {
     if (!engine || engine->magic != SZS_NODE_ENGINE_MAGIC) return szs_report(sz_status_unknown_k, error_message, "Engine must be initialized");
     double const started = node_now_milliseconds();
     szs_node_s *node = engine->node;
-    if (stats) memset(stats, 0, sizeof(*stats)), stats->gpus = node->count;
+    if (stats) memset(stats, 0, sizeof(*stats)), stats->gpus = node->count, stats->peer_pairs = node->peer_pairs, stats->symmetric = symmetric != 0;
     if (!queries_count || !candidates_count) return szs_report(sz_success_k, error_message, NULL);
     if (queries_count > 0xFFFFFFFFull || candidates_count > 0xFFFFFFFFull) return szs_report(sz_overflow_risk_k, error_message, NULL);
     if (!results) return szs_report(sz_status_unknown_k, error_message, "Results must not be null");
@@ -349,8 +479,64 @@ static sz_status_t node_cross(szs_node_engine_s *engine, int wide, char const *q
             offset_at(query_offsets, wide, i + 1) - offset_at(query_offsets, wide, i) > 0xFFFFFFFFull)
             return szs_report(sz_unexpected_dimensions_k, error_message, "Tape offsets must ascend");
 
-    /* ---- deal the rows: LPT on len(query) + 1 */
     size_t const shards = node->count;
+    size_t band_first[SZS_ROCM_NODE_MOST_GPUS + 1] = {0};
+    sz_u64_t band_weights[SZS_ROCM_NODE_MOST_GPUS] = {0};
+    if (symmetric) {
+        /* ---- one tape in both roles: the LOWER TRIANGLE in contiguous bands of rows of equal weight (szs_rocm_shard_triangle),
+         * scored once - the full square would be twice the work of the single-GPU engines (serial.hpp:3169-3182).  The band
+         * calls read slices of the query offsets, rebased to the replica: in OUR buffer, the caller's array is never written. */
+        uint64_t const first = offset_at(query_offsets, wide, 0);
+        void *const landing = engine->offsets_copy.pointer;
+        if (query_offsets != landing) memmove(landing, query_offsets, q_offsets_bytes);
+        for (size_t i = 0; i <= queries_count; ++i) {
+            if (wide) ((uint64_t *)landing)[i] -= first;
+            else ((uint32_t *)landing)[i] -= (uint32_t)first;
+        }
+        sz_status_t dealt = szs_buffer_reserve(&engine->weights, szs_memory_host_k, 0, queries_count * sizeof(sz_size_t), error_message);
+        if (dealt != sz_success_k) return dealt;
+        sz_size_t *const lengths = (sz_size_t *)engine->weights.pointer;
+        for (size_t i = 0; i < queries_count; ++i) lengths[i] = (sz_size_t)(offset_at(landing, wide, i + 1) - offset_at(landing, wide, i));
+        dealt = szs_rocm_shard_triangle(lengths, queries_count, shards, band_first, band_weights);
+        if (dealt != sz_success_k) return szs_report(dealt, error_message, NULL);
+        node_task_t tasks[SZS_ROCM_NODE_MOST_GPUS];
+        pthread_t threads[SZS_ROCM_NODE_MOST_GPUS];
+        int started_threads[SZS_ROCM_NODE_MOST_GPUS] = {0};
+        memset(tasks, 0, sizeof(tasks));
+        for (size_t s = 0; s < shards; ++s) {
+            node_task_t *task = &tasks[s];
+            task->engine = engine, task->shard = s, task->wide = wide, task->symmetric = 1;
+            task->query_data = query_data, task->query_offsets = landing, task->query_first = first;
+            task->query_bytes = offset_at(landing, wide, queries_count);
+            task->queries_count = task->candidates_count = queries_count;
+            task->band_first = band_first[s], task->rows_count = band_first[s + 1] - band_first[s];
+            task->results = results, task->results_row_stride = results_row_stride;
+            if (shards == 1) node_worker(task);
+            else if (pthread_create(&threads[s], NULL, node_worker, task) == 0) started_threads[s] = 1;
+            else node_worker(task);
+        }
+        for (size_t s = 0; s < shards; ++s)
+            if (started_threads[s]) pthread_join(threads[s], NULL);
+        status = sz_success_k;
+        for (size_t s = 0; s < shards; ++s) {
+            if (tasks[s].status != sz_success_k && status == sz_success_k) {
+                status = tasks[s].status;
+                if (error_message) *error_message = tasks[s].message;
+            }
+            if (stats) {
+                stats->busy_milliseconds[s] = tasks[s].busy_milliseconds, stats->kernel_milliseconds[s] = tasks[s].kernel_milliseconds;
+                stats->cells[s] = tasks[s].cells, stats->rows[s] = (sz_u32_t)tasks[s].rows_count, stats->row_weights[s] = band_weights[s];
+                stats->peer_copies[s] = tasks[s].peer_copies, stats->staged_copies[s] = tasks[s].staged_copies;
+            }
+        }
+        /* every band has landed: the cells above the diagonal that belong to other bands' rows */
+        if (status == sz_success_k && shards > 1) status = node_mirror(node, results, queries_count, results_row_stride, error_message);
+        if (stats) stats->wall_milliseconds = node_now_milliseconds() - started;
+        if (status == sz_success_k && error_message) *error_message = NULL;
+        return status;
+    }
+
+    /* ---- deal the rows: LPT on len(query) + 1 */
     status = szs_buffer_reserve(&engine->weights, szs_memory_host_k, 0, queries_count * sizeof(sz_size_t), error_message);
     if (status == sz_success_k) status = szs_buffer_reserve(&engine->shard_of_row, szs_memory_host_k, 0, queries_count * sizeof(uint32_t), error_message);
     if (status == sz_success_k) status = szs_buffer_reserve(&engine->row_lists, szs_memory_host_k, 0, queries_count * sizeof(uint32_t), error_message);
@@ -404,6 +590,7 @@ static sz_status_t node_cross(szs_node_engine_s *engine, int wide, char const *q
         if (stats) {
             stats->busy_milliseconds[s] = tasks[s].busy_milliseconds, stats->kernel_milliseconds[s] = tasks[s].kernel_milliseconds;
             stats->cells[s] = tasks[s].cells, stats->rows[s] = (sz_u32_t)counts[s], stats->row_weights[s] = loads[s];
+            stats->peer_copies[s] = tasks[s].peer_copies, stats->staged_copies[s] = tasks[s].staged_copies;
         }
     }
     if (stats) stats->wall_milliseconds = node_now_milliseconds() - started;
@@ -415,16 +602,18 @@ sz_status_t szs_rocm_node_scores_u32tape(szs_rocm_node_engine_t engine, sz_seque
                                          sz_sequence_u32tape_t const *candidates, void *results, sz_size_t results_row_stride,
                                          szs_rocm_node_stats_t *stats, char const **error_message) {
     if (!queries) return szs_report(sz_status_unknown_k, error_message, "Queries must not be null");
-    if (!candidates) candidates = queries; /* self-similarity: the full square, rows dealt like any other batch */
-    return node_cross((szs_node_engine_s *)engine, 0, queries->data, queries->offsets, queries->count, candidates->data, candidates->offsets,
-                      candidates->count, results, results_row_stride, stats, error_message);
+    int const symmetric = candidates == NULL; /* self-similarity: the lower triangle in bands of rows, mirrored */
+    if (symmetric) candidates = queries;
+    return node_cross((szs_node_engine_s *)engine, 0, symmetric, queries->data, queries->offsets, queries->count, candidates->data,
+                      candidates->offsets, candidates->count, results, results_row_stride, stats, error_message);
 }
 
 sz_status_t szs_rocm_node_scores_u64tape(szs_rocm_node_engine_t engine, sz_sequence_u64tape_t const *queries,
                                          sz_sequence_u64tape_t const *candidates, void *results, sz_size_t results_row_stride,
                                          szs_rocm_node_stats_t *stats, char const **error_message) {
     if (!queries) return szs_report(sz_status_unknown_k, error_message, "Queries must not be null");
-    if (!candidates) candidates = queries;
-    return node_cross((szs_node_engine_s *)engine, 1, queries->data, queries->offsets, queries->count, candidates->data, candidates->offsets,
-                      candidates->count, results, results_row_stride, stats, error_message);
+    int const symmetric = candidates == NULL;
+    if (symmetric) candidates = queries;
+    return node_cross((szs_node_engine_s *)engine, 1, symmetric, queries->data, queries->offsets, queries->count, candidates->data,
+                      candidates->offsets, candidates->count, results, results_row_stride, stats, error_message);
 }

@@ -692,6 +692,37 @@ static int compare_rows_descending(void const *a, void const *b) {
     return x->row < y->row ? -1 : x->row > y->row;
 }
 
+sz_status_t szs_rocm_shard_triangle(sz_size_t const *lengths, sz_size_t rows, sz_size_t shards, sz_size_t *band_first, sz_u64_t *band_weights) {
+    /* Row i of the lower triangle meets the strings 0 ... i: weight (len_i + 1) x sum_{j <= i} (len_j + 1) - cells, plus one per
+     * string so that empty strings still count as pairs.  Bands are CONTIGUOUS (band g = rows [first[g], first[g + 1])): a band
+     * is then a rectangle - its rows against everything before it - and a square triangle of its own, two ordinary engine calls.
+     * The cuts go where the running weight crosses g / shards of the total; a row is at most 2 / rows of it. */
+    if (!shards || !band_first || (rows && !lengths)) return sz_unexpected_dimensions_k;
+    long double total = 0, prefix = 0;
+    for (size_t i = 0; i < rows; ++i) prefix += (long double)lengths[i] + 1, total += ((long double)lengths[i] + 1) * prefix;
+    size_t band = 0;
+    long double running = 0, before = 0;
+    prefix = 0;
+    band_first[0] = 0;
+    for (size_t i = 0; i < rows; ++i) {
+        prefix += (long double)lengths[i] + 1;
+        long double const weight = ((long double)lengths[i] + 1) * prefix;
+        /* row i opens the next band when the bands so far hold their share (the row goes to whichever side leaves them closer) */
+        while (band + 1 < shards && running + weight / 2 >= total * (long double)(band + 1) / (long double)shards) {
+            if (band_weights) band_weights[band] = (sz_u64_t)(running - before);
+            before = running, band_first[++band] = i;
+        }
+        running += weight;
+    }
+    if (band_weights) band_weights[band] = (sz_u64_t)(running - before);
+    while (band + 1 < shards) { /* fewer rows than shards: the remaining bands are empty */
+        band_first[++band] = rows;
+        if (band_weights) band_weights[band] = 0;
+    }
+    band_first[shards] = rows;
+    return sz_success_k;
+}
+
 sz_status_t szs_rocm_shard_rows(sz_size_t const *row_weights, sz_size_t rows, sz_size_t shards, sz_u32_t *shard_of_row,
                                 sz_u64_t *shard_loads) {
     if (!shards || !shard_of_row || (rows && !row_weights) || rows > 0xFFFFFFFFu) return sz_unexpected_dimensions_k;

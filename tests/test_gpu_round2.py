@@ -341,8 +341,8 @@ def test_node_engines_match_the_oracle(oracle, devices):
         engine(q, c, out=out[:, :len(candidates)])                                         # device tapes, padded device matrix
         assert np.array_equal(out[:, :len(candidates)].cpu().numpy(), expected) and bool((out[:, len(candidates):] == -9).all())
         assert np.array_equal(engine(q, c).view(np.int64), expected)                       # again: replicas and blocks reused
-    symmetric = node.levenshtein_distances()(queries)                                      # candidates omitted: the full square
-    assert np.array_equal(symmetric, oracle.levenshtein(queries, queries))
+    symmetric = node.levenshtein_distances()(queries)                                      # candidates omitted: the lower triangle, mirrored
+    assert np.array_equal(symmetric, oracle.levenshtein(queries, queries))                 # (tests/test_gpu_round4.py has the bands)
     utf8 = node.levenshtein_distances_utf8()
     words = [w.encode() for w in ["naïve", "façade", "日本語", "😀 smile", "", "plain", "naive", "facade"]]
     assert np.array_equal(utf8(words, words), oracle.levenshtein_utf8(words, words))
@@ -358,7 +358,7 @@ def test_node_probe_from_plain_c():
     if not os.path.exists(probe):
         pytest.skip("tests/native/bin/node_probe is not built")
     for family, arguments in [("lev", ["90", "130", "0", "400"]), ("nw", ["40", "70", "0", "200"]), ("sw", ["33", "300", "5", "150"])]:
-        for gpus in (["0"], ["0", "0"]):
+        for gpus in (["0"], ["0", "0"], ["0"] * 8):  # eight "GPUs": the world size BASELINE.json's curve ends at
             done = subprocess.run([probe, family, *arguments, *gpus], capture_output=True, text=True, timeout=300)
             assert done.returncode == 0, (family, gpus, done.stdout, done.stderr)
             report = json.loads(done.stdout.strip().splitlines()[-1])

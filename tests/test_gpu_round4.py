@@ -16,7 +16,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 import stringzilla_amd as szs  # noqa: E402
-from stringzilla_amd import _abi, workloads  # noqa: E402
+from stringzilla_amd import _abi, matrices, workloads  # noqa: E402
 
 
 @contextlib.contextmanager
@@ -223,3 +223,47 @@ def test_config5_codepoints_scaled(gpu, oracle):
             assert np.array_equal(engine(load.queries, load.candidates, device=gpu), expected)
             profile = engine.last_call_profile()
             assert profile.launches == 1 and profile.queue_items > 0, (profile.launches, profile.queue_items)
+
+
+# ---- several GPUs: symmetric calls shard the lower triangle; eight "GPUs" on whatever this box has ------------------------------
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0], [0] * 8])
+def test_node_symmetric_calls_score_the_triangle_once(gpu, oracle, devices):
+    """`szs_rocm_node_*` with candidates omitted: contiguous bands of rows of equal weight, each a rectangle plus a triangle of its
+    own, mirrored after every band has landed - the SAME matrix and the SAME cells as the single-GPU symmetric call (round 3
+    scored the full square: twice the work).  The same GPU named eight times rehearses the eight threads, bands and replicas."""
+    import torch
+
+    rng = random.Random(len(devices))
+    strings = _rand(rng, 150, 0, 300, b"ACGT") + _rand(rng, 6, 600, 2100, b"ACGT") + [b""]
+    rng.shuffle(strings)
+    node = szs.Node(devices)
+    single = szs.LevenshteinDistances(capabilities=gpu)
+    expected = single(strings, device=gpu)
+    triangle_cells = int(single.last_call_profile().cells)
+    assert np.array_equal(expected, oracle.levenshtein(strings, None))
+    engine = node.levenshtein_distances()
+    assert np.array_equal(engine(strings), expected)  # host tape, host matrix: mirrored on the host
+    stats = engine.last_stats
+    assert stats["symmetric"] and stats["gpus"] == len(devices) and sum(stats["rows"]) == len(strings)
+    assert sum(stats["cells"]) == triangle_cells, (sum(stats["cells"]), triangle_cells)  # the triangle, not the square
+    if len(devices) > 1:
+        assert max(stats["row_weights"]) <= 1.3 * (sum(stats["row_weights"]) / len(devices))
+    tape = szs.Strs(strings).to_device(0)
+    out = torch.full((len(strings), len(strings) + 3), -7, dtype=torch.int64, device="cuda")
+    engine(tape, out=out[:, :len(strings)])  # device tape, padded device matrix: mirrored by hip/mirror.hip
+    assert np.array_equal(out[:, :len(strings)].cpu().numpy().view(np.uint64), expected) and bool((out[:, len(strings):] == -7).all())
+    nuc = matrices.nuc44()
+    dna = [s for s in strings if len(s) < 700]
+    scores = node.smith_waterman_scores(*nuc, open=-4, extend=-1)
+    assert np.array_equal(scores(dna).view(np.int64), oracle.smith_waterman(dna, None, *nuc, -4, -1).view(np.int64))
+    # fewer rows than GPUs: some bands are empty
+    few = strings[:5]
+    assert np.array_equal(engine(few), oracle.levenshtein(few, None))
+    assert sum(engine.last_stats["rows"]) == 5 and (len(devices) < 8 or 0 in engine.last_stats["rows"])
+    # and the ordinary (two-sided) call over the same node, rows dealt by LPT, fewer rows than GPUs included
+    others = _rand(rng, 70, 0, 200, b"ACGT")
+    assert np.array_equal(engine(strings, others), oracle.levenshtein(strings, others))
+    assert np.array_equal(engine(few[:3], others), oracle.levenshtein(few[:3], others))
+    assert "peer_pairs" in engine.last_stats and engine.last_stats["peer_pairs"] == 0  # one physical GPU: no pair to enable
