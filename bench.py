@@ -16,7 +16,8 @@ Line   : rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel aga
          (272 B per pair at len 128: len(q) + len(c) + 2 offsets + one 8-byte result) over the
          hipEvent-measured kernel time the library records on its own stream.  `cpu_baseline` times the reference's own
          SIMD engines (oracle/_ref, built from /root/reference) on this box's host cores - a reported baseline only.
-configs: the same line carries a `configs` array - one record per other BASELINE.json config (3: NW BLOSUM62, 4: SW
+configs: the same line carries a `configs` array - one record per other BASELINE.json config (9: config 2 at a fixed 128 bytes,
+         its "peak" variant; 3: NW BLOSUM62, 4: SW
          affine NUC.4.4, 5: byte-level Levenshtein on Zipf UTF-8, 5u: the same at the codepoint level, 7 / 8: config 2's batch
          under non-unit costs, linear 1/3/3 and affine 0/1/4/2), each timed
          through its own C-ABI entry point with its kernel and wall GCUPS, checksum, HBM roofline, the VALU counters of
@@ -44,7 +45,7 @@ HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 # The binding resource of this path is integer VALU issue, not HBM.  Its ceiling is MEASURED, not quoted: the Myers
 # column update (the kernel's exact instruction mix) on register-resident match masks, no LDS and no memory, sustains
 # this many DP cells per second at full bit-vector width on one MI355X (scripts/valu_peak.hip -> profiles/).
-PROFILE_DIRS = [os.path.join(ROOT, "profiles", "r03"), os.path.join(ROOT, "profiles", "r02"), os.path.join(ROOT, "profiles", "r01")]
+PROFILE_DIRS = [os.path.join(ROOT, "profiles", name) for name in ("r04", "r03", "r02", "r01")]
 # VALU issue ceiling, class-weighted: gfx950's SIMDs are 32 lanes wide, a full-rate VALU instruction (32-bit add / sub / logic /
 # right shift / move) takes a wavefront 2 cycles, every other one (maxima, packed 16-bit, carries, funnel shifts, VOP3 three-
 # operand forms, DPP) 4 - MI355X_MICROARCH.md "Wave scheduling", measured per opcode by scripts/valu_peak.hip.  A main loop of F
@@ -69,9 +70,11 @@ def parse_args():
     parser.add_argument("--steps", type=int, default=200)
     parser.add_argument("--warmup", type=int, default=20)
     parser.add_argument("--config", type=int, default=2, help="BASELINE.json config index of the headline (2 = the metric's config)")
-    parser.add_argument("--generator", default="numpy", choices=["numpy", "mt19937_64"],
-                        help="where configs 1-4 come from: numpy's default_rng (the committed profiles) or std::mt19937_64 "
-                             "(tests/native/workloads_mt19937.cpp: the same shapes, reproducible from C++)")
+    parser.add_argument("--generator", default="mt19937_64", choices=["numpy", "mt19937_64"],
+                        help="where configs 1-4 come from: std::mt19937_64, the generator SURVEY.md section 8(d) names "
+                             "(tests/native/workloads_mt19937.cpp spells the mapping out; reproducible from C++), or numpy's "
+                             "default_rng (the batches rounds 1-3 were profiled on: the same shapes, other strings).  Configs 5 / 5u "
+                             "(Zipf UTF-8) exist in numpy only.  Falls back to numpy, and says so, when the helper library is not built")
     parser.add_argument("--extra-configs", default=None,
                         help="comma-separated configs reported in the `configs` array (default: 3,4,5,6,7,8 on one GPU, "
                              "4,5 strong-scaled on several; 'none' to skip)")
@@ -88,6 +91,57 @@ def parse_args():
                         help="HBM bytes per launch from a separate rocprofv3 --pmc pass; default: the committed summary "
                              "profiles/rNN/pmc_summary.json of this same command (scripts/profile_gpu.sh)")
     return parser.parse_args()
+
+
+def resolve_generator(wanted):
+    """`mt19937_64` needs tests/native/bin/libworkloads_mt19937.so (built by __graft_entry__.build()); without it: numpy."""
+    if wanted == "mt19937_64" and not os.path.exists(os.path.join(ROOT, "tests", "native", "bin", "libworkloads_mt19937.so")):
+        return "numpy"
+    return wanted
+
+
+def fresh_tape(generator, seed, count, low, high):
+    """Another batch of printable ASCII from the run's generator (the headline alternates two batches)."""
+    from stringzilla_amd import workloads
+
+    if generator == "mt19937_64":
+        return workloads.mt19937_64_tape(seed, count, low, high, workloads.ASCII_PRINTABLE)
+    return workloads.random_tape(np.random.default_rng(seed), count, low, high, workloads.ASCII_PRINTABLE)
+
+
+def library_digest():
+    """sha256 of the code the run executes: committed PMC passes carry the digest of the library they counted (scripts/
+    pmc_configs.py); when it differs, instruction counts joined to this run's kernel times are flagged stale."""
+    import hashlib
+
+    from stringzilla_amd import _abi
+
+    with open(_abi.LIBRARY_PATH, "rb") as handle:
+        return hashlib.sha256(handle.read()).hexdigest()
+
+
+def measured_hbm_peak(where):
+    """What this box's HBM delivers to a plain device-to-device copy of 1 GiB (read + write bytes over the time of the copy,
+    best of five): the measured peak beside the 8 TB/s of the data sheet (SURVEY.md section 8d asks for both)."""
+    import torch
+
+    size = 1 << 30
+    source = torch.empty(size, dtype=torch.uint8, device=where)
+    target = torch.empty(size, dtype=torch.uint8, device=where)
+    source.fill_(1)
+    target.copy_(source)
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(5):
+        begin, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        begin.record()
+        target.copy_(source)
+        end.record()
+        torch.cuda.synchronize()
+        seconds = begin.elapsed_time(end) * 1e-3
+        best = seconds if best is None else min(best, seconds)
+    del source, target
+    return round(2.0 * size / best / 1e9, 1)
 
 
 # ---- engines and entry points per workload kind -------------------------------------------------------------------------
@@ -202,6 +256,36 @@ def cpu_baseline(load, gpu_matrix, seconds):
             run(rows, columns)
         runs.append((time.perf_counter() - started) / passes)
     elapsed = float(np.median(runs))  # the median: a 256-thread host shows stragglers, a mean of two runs wandered by 25 %
+    # the reference reports its Serial engine beside the SIMD tiers (similarities/README.md:21-24): ONE thread of the serial tier
+    # on a sample of about a second (a row per eight of the SIMD sample's, one lane group of candidates)
+    serial = None
+    if kind == "reference":
+        try:
+            plain = binding.reference(tier=0, threads=1)
+            serial_rows, serial_columns = spaced(len(q_lengths), 4), spaced(len(c_lengths), lanes)
+            def run_serial():
+                queries = [load.queries[int(i)] for i in serial_rows]
+                candidates = [load.candidates[int(j)] for j in serial_columns]
+                if load.kind == "levenshtein":
+                    return plain.levenshtein(queries, candidates, **load.costs)
+                if load.kind == "levenshtein_utf8":
+                    return plain.levenshtein_utf8(queries, candidates, **load.costs)
+                scorer = plain.needleman_wunsch if load.kind == "needleman_wunsch" else plain.smith_waterman
+                return scorer(queries, candidates, *matrices.by_name(load.table), **load.costs)
+            started = time.perf_counter()
+            got = run_serial()
+            once = time.perf_counter() - started
+            assert np.array_equal(got.view(np.int64), gpu_matrix[np.ix_(serial_rows, serial_columns)].view(np.int64)), "serial CPU baseline and GPU disagree"
+            again = int(max(1, min(50, 1.0 / max(once, 1e-4))))
+            started = time.perf_counter()
+            for _ in range(again):
+                run_serial()
+            serial = {"value": round(cells_of(serial_rows, serial_columns) * again / (time.perf_counter() - started) / 1e9, 3), "unit": "GCUPS",
+                      "cores": 1, "sample": f"{len(serial_rows)} query rows x {len(serial_columns)} candidates, {again} passes, serial tier, cells verified equal"}
+        except AssertionError:
+            raise
+        except Exception as problem:
+            serial = {"error": repr(problem)}
     what = (f"the full {len(q_lengths)}x{len(c_lengths)} batch of the timed config" if whole else
             f"{len(rows)} evenly spaced query rows x {len(columns)} evenly spaced candidates of the timed config")
     return {
@@ -209,6 +293,7 @@ def cpu_baseline(load, gpu_matrix, seconds):
         "spread": [round(cells_of(rows, columns) / max(runs) / 1e9, 2), round(cells_of(rows, columns) / min(runs) / 1e9, 2)],
         "sample": f"{what}, median of {repeats} runs{f' of {passes} passes each' if passes > 1 else ''} (`spread`: slowest and fastest run), {label} tier, {cores} threads, tape packing "
                   f"included; the sampled cells verified equal to the GPU's",
+        "serial_1_thread": serial,
     }
 
 
@@ -225,6 +310,9 @@ def roofline(config, profile, kernel_seconds, traffic_override=None):
               "kernel_gcups": round(profile.cells / kernel_seconds / 1e9, 1)}
     summary, where = _profile_json("pmc_configs.json")  # "cfgN:kernel" and "cfgN:__call__" (scripts/pmc_configs.py)
     call = (summary or {}).get(f"cfg{config}:__call__")
+    counted_on = (summary or {}).get("_library_sha256")
+    record["pmc_library_sha256"] = counted_on
+    record["pmc_stale"] = None if not counted_on else counted_on != library_digest()  # True: the counters below were taken on other code
     if not call:
         record["traffic_source"] = "no committed PMC pass for this config" if traffic_override is None else "from --hbm-traffic-bytes"
         return record
@@ -292,7 +380,7 @@ def measure_extra(config, scope, device_index, args, fence, with_cpu):
 
     from stringzilla_amd import workloads
 
-    load = workloads.config(config, scale=args.extra_scale, generator=args.generator if config <= 4 else "numpy")
+    load = workloads.config(config, scale=args.extra_scale, generator=args.generator if config <= 4 or config == 9 else "numpy")
     engine = make_engine(load, scope)
     queries, candidates = load.queries.to_device(device_index), load.candidates.to_device(device_index)
     results = torch.empty((len(queries), len(candidates)), dtype=torch.int64, device=torch.device("cuda", device_index))
@@ -312,6 +400,44 @@ def measure_extra(config, scope, device_index, args, fence, with_cpu):
         # matrix stays in HBM until then - downloading 80 MB here would idle the shader engines right before the headline
         record["_cpu_baseline_inputs"] = (load, results)
     return record
+
+
+def measure_fingerprints(scope, device_index, args, fence):
+    """`szs_fingerprints_u32tape`: rolling MinHash over 1024 documents of ~10 KB, 1024 dimensions of the
+    reference's default window widths - bytes of text per second and byte-dimensions per second of the whole C-ABI call.  The
+    kernel's work is 25 instructions per byte and dimension: VALU-bound, the text is read once per 256
+    dimensions from LDS."""
+    import torch
+
+    import stringzilla_amd as szs
+    from stringzilla_amd import workloads
+
+    dimensions = 1024
+    texts = workloads.random_tape(np.random.default_rng(11), 1024, 8192, 12288, workloads.ASCII_PRINTABLE).to_device(device_index)
+    engine = szs.Fingerprints(dimensions, capabilities=scope)
+    engine(texts, device=scope)
+    fence()
+    started = time.perf_counter()
+    engine(texts, device=scope)
+    once = time.perf_counter() - started
+    repeats = int(max(3, min(50, args.extra_seconds / max(once, 1e-4))))
+    fence()
+    started = time.perf_counter()
+    for _ in range(repeats):
+        hashes, counts = engine(texts, device=scope)
+    fence()
+    wall = (time.perf_counter() - started) / repeats
+    text_bytes = int(texts.lengths().sum())
+    lane_ops = 25.0 * text_bytes * dimensions  # instructions per byte and dimension x lanes
+    return {"config": "fingerprints", "workload": "1024 ASCII documents of 8-12 KB, 1024 dimensions, default window widths",
+            "entry_point": "szs_fingerprints_u32tape", "n_gpus": 1, "steps": repeats, "ms_per_step": round(wall * 1e3, 3),
+            "value": round(text_bytes * dimensions / wall / 1e12, 3), "unit": "10^12 byte-dimensions/s",
+            "text_gb_s": round(text_bytes / wall / 1e9, 2), "results_checksum": int(hashes.astype(np.uint64).sum() % (1 << 53)),
+            "roofline": {"bound": "integer / fp64 VALU issue (estimated from the kernel's 25 instructions per byte and dimension)",
+                         "achieved_Tlane_ops_per_s": round(lane_ops / wall / 1e12, 2), "peak_Tlane_ops_per_s": round(VALU_HALF_RATE_PEAK / 1e12, 1),
+                         "frac": round(lane_ops / wall / VALU_HALF_RATE_PEAK, 4),
+                         "hbm": {"algorithmic_bytes": text_bytes + 8 * dimensions * len(texts), "achieved_gb_s": round((text_bytes + 8 * dimensions * len(texts)) / wall / 1e9, 2),
+                                 "peak": HBM_PEAK_GBPS}}}
 
 
 def attach_cpu_baselines(records, seconds):
@@ -335,7 +461,7 @@ def measure_strong(config, scope, device_index, args, fence, dist, world, rank, 
 
     from stringzilla_amd import sharded, workloads
 
-    load = workloads.config(config, scale=args.extra_scale, generator=args.generator if config <= 4 else "numpy")  # seeded: every rank can name the engine; only rank 0's strings are used
+    load = workloads.config(config, scale=args.extra_scale, generator=args.generator if config <= 4 or config == 9 else "numpy")  # seeded: every rank can name the engine; only rank 0's strings are used
     engine = make_engine(load, scope)
     busy, state = [], {}
 
@@ -383,19 +509,22 @@ def measure_c_node(config, devices, args):
 
     if not hasattr(szs, "Node"):
         return None
-    load = workloads.config(config, scale=args.extra_scale, generator=args.generator if config <= 4 else "numpy")
+    load = workloads.config(config, scale=args.extra_scale, generator=args.generator if config <= 4 or config == 9 else "numpy")
     node = szs.Node(devices)
     engine = node.engine_for(load)
     out = torch.empty((len(load.queries), len(load.candidates)), dtype=torch.int64, device=torch.device("cuda", devices[0]))
     load.queries.to_device(devices[0]), load.candidates.to_device(devices[0])
     engine(load.queries, load.candidates, out=out)
     started = time.perf_counter()
-    repeats = 2
+    engine(load.queries, load.candidates, out=out)
+    repeats = int(max(5, min(20, args.extra_seconds / max(time.perf_counter() - started, 1e-3))))
+    started = time.perf_counter()
     for _ in range(repeats):
         stats = engine(load.queries, load.candidates, out=out)
     wall = (time.perf_counter() - started) / repeats
-    return {"config": config, "entry_point": "szs_rocm_node_scores_u32tape", "n_gpus": len(devices), "scaling": "strong",
+    return {"config": config, "entry_point": "szs_rocm_node_scores_u32tape", "n_gpus": len(devices), "scaling": "strong", "steps": repeats,
             "value": round(load.cells / wall / 1e9, 1), "unit": "GCUPS", "ms_per_step": round(wall * 1e3, 3),
+            "peer_pairs": stats.get("peer_pairs"), "peer_copies": stats.get("peer_copies"), "staged_copies": stats.get("staged_copies"),
             "busy_ms_per_gpu": [round(x, 3) for x in stats["busy_ms"]], "rows_per_gpu": stats["rows"],
             "results_checksum": int(out.sum().item())}
 
@@ -425,12 +554,12 @@ def main():
     where = torch.device("cuda", local_rank)
 
     # ---- the batch: rank r owns query rows [1024 r, 1024 (r + 1)); candidates are shared by all ranks
+    args.generator = resolve_generator(args.generator)
     load = workloads.config(args.config, generator=args.generator if args.config <= 4 else "numpy")
     if rank:
-        rng = np.random.default_rng(args.config + 1000 * rank)
         low, high = int(load.queries.lengths().min()), int(load.queries.lengths().max())
-        load.queries = workloads.random_tape(rng, len(load.queries), 96 if args.config == 2 else low,
-                                             160 if args.config == 2 else high, workloads.ASCII_PRINTABLE)
+        load.queries = fresh_tape(args.generator, args.config + 1000 * rank, len(load.queries), 96 if args.config == 2 else low,
+                                  160 if args.config == 2 else high)
     queries = load.queries.to_device(local_rank)
     if world > 1:  # the one exchange step of the path: replicate the candidates tape over RCCL / xGMI, before timing;
         # the received tape stays in HBM (only its offsets are mirrored on the host)
@@ -460,7 +589,7 @@ def main():
     # of NW / SW scoring the clocks are where a busy GPU keeps them.  The headline itself is unchanged: W untimed steps, then
     # exactly K timed ones.  (The single-process C driver of N > 1 runs last, while the other ranks wait.)
     if args.extra_configs is None:
-        extras = [3, 4, 5, 6, 7, 8] if world == 1 else [4, 5]
+        extras = [9, 3, 4, 5, 6, 7, 8] if world == 1 else [4, 5]
     else:
         extras = [] if args.extra_configs.strip().lower() in ("", "none") else [int(x) for x in args.extra_configs.split(",")]
     records = []
@@ -477,6 +606,12 @@ def main():
         except Exception as problem:  # an extra record must never cost the headline line
             records.append({"config": config, "error": repr(problem)})
 
+    if world == 1 and args.extra_configs is None:
+        try:
+            records.append(measure_fingerprints(scope, local_rank, args, fence))
+        except Exception as problem:
+            records.append({"config": "fingerprints", "error": repr(problem)})
+
     # ---- the headline is a STREAM OF FRESH BATCHES: two different batches of the config's shape alternate, so that no call
     # finds the plan of its own tapes on the device (csrc/host/dispatch.c re-uses that plan after validating it in the kernels -
     # the best case, which a real stream of batches never meets; round 2's headline measured it).  Every call pays for the
@@ -486,8 +621,8 @@ def main():
     # mix in ~10 ms), so the W warm-up steps of a short run would otherwise be timed on that transient.
     steps_of, cells_of_step, same_tapes = [step], None, None
     if args.config == 2:  # every rank, on its own GPU
-        other = workloads.random_tape(np.random.default_rng(4242 + 10 * rank), len(load.queries), 96, 160, workloads.ASCII_PRINTABLE).to_device(local_rank)
-        other_candidates = workloads.random_tape(np.random.default_rng(4243 + 10 * rank), len(load.candidates), 96, 160, workloads.ASCII_PRINTABLE).to_device(local_rank)
+        other = fresh_tape(args.generator, 4242 + 10 * rank, len(load.queries), 96, 160).to_device(local_rank)
+        other_candidates = fresh_tape(args.generator, 4243 + 10 * rank, len(load.candidates), 96, 160).to_device(local_rank)
         other_step = make_step(engine, scope, load, other, other_candidates, results, local_rank)
         steps_of.append(other_step)
         for _ in range(max(2, args.warmup // 2)):
@@ -557,6 +692,13 @@ def main():
         lengths = load.queries.lengths().astype(np.int64)
         padded_cells = float((np.maximum(1, -(-lengths // 32)) * 32).sum()) * float(load.candidates.lengths().sum())
         line_roofline = roofline(args.config, profile, kernel, args.hbm_traffic_bytes)
+        try:
+            line_roofline["peak_measured"] = measured_hbm_peak(where)
+            line_roofline["frac_of_measured_peak"] = round(line_roofline["achieved"] / line_roofline["peak_measured"], 6)
+            line_roofline["peak_measured_how"] = "device-to-device copy of 1 GiB on this box, read + write bytes over the best of five (torch, HIP events)"
+        except Exception as problem:
+            line_roofline["peak_measured"] = None
+            line_roofline["peak_measured_how"] = repr(problem)
         line_roofline["note"] = ("integer-VALU bound by construction (HBM traffic is a few % of the algorithmic bytes: tapes are "
                                  "L2-resident); the HBM fraction is reported because the metric asks for it, the `valu` and "
                                  "`myers_ceiling` objects are the rooflines that say something about the kernel")
@@ -583,6 +725,11 @@ def main():
             "planner": " / ".join({0: "host", 1: "device", 2: "device, launches speculated on the previous call's shape",
                                    3: "plan of the previous call re-used for the same tapes, validated in the kernels"}[mode] for mode in sorted(planners)),
             "results_checksum": float(checksum),
+            # the three figures the reference's own bench prints per engine (bench/similarities.cuh:344-366: bytes passed, operations =
+            # cells, inputs processed, and the device-measured "Kernel" line :303-308)
+            "reference_style": {"throughput_gb_s": round(float(load.queries.lengths().sum() * columns + load.candidates.lengths().sum() * rows) * world / (elapsed / args.steps) / 1e9, 1),
+                                "efficiency_gops_s": round(value, 1), "pairs_per_second": round(rows * columns * world / (elapsed / args.steps), 0),
+                                "kernel_gcups": round(float(profile.cells) / kernel / 1e9, 1), "kernel_ms": round(kernel * 1e3, 4)},
         }
         line["config"]["stream"] = ("two different batches of this shape alternate: every timed call plans its tapes afresh on the device"
                                     if len(steps_of) > 1 else "the same batch every step")

@@ -109,4 +109,13 @@ for directory in sorted(glob.glob(os.path.join(root, "cfg*"))):
         summary[f"cfg{config}:__call__"] = call
     except (OSError, ValueError, KeyError, IndexError) as problem:
         print(f"cfg{config}: no call-level record ({problem})", file=sys.stderr)
+# the digest of the library these counters were taken on: bench.py joins the instruction counts to ITS run's kernel times and
+# flags them stale when the code has changed since (`roofline.pmc_stale`)
+try:
+    import hashlib
+    library = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "stringzilla_amd", "lib", "libstringzillas_rocm_shared.so")
+    with open(library, "rb") as handle:
+        summary["_library_sha256"] = hashlib.sha256(handle.read()).hexdigest()
+except OSError as problem:
+    print(f"no library digest ({problem})", file=sys.stderr)
 print(json.dumps(summary, indent=1))

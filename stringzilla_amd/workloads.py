@@ -96,9 +96,9 @@ def config(index: int, scale: float = 1.0, generator: str = "numpy") -> Workload
     profiles and checksums) or "mt19937_64" (configs 1-4: the same shapes from `std::mt19937_64`, reproducible from C++)."""
     rng = np.random.default_rng(index)
     side = lambda n: max(1, int(round(n * scale)))
-    if generator == "mt19937_64" and 1 <= index <= 4:
+    if generator == "mt19937_64" and index in (1, 2, 3, 4, 9):
         shape = {1: (100, 48, 80, ASCII_PRINTABLE), 2: (1024, 96, 160, ASCII_PRINTABLE), 3: (1024, 384, 640, AMINO_ACIDS),
-                 4: (512, 3072, 5120, NUCLEOTIDES)}[index]
+                 4: (512, 3072, 5120, NUCLEOTIDES), 9: (1024, 128, 128, ASCII_PRINTABLE)}[index]
         template = config(index, 0.01)  # names, kinds and costs of the numpy variant
         return Workload(template.name + " [std::mt19937_64]", template.kind,
                         mt19937_64_tape(1000 * index + 0, side(shape[0]), shape[1], shape[2], shape[3]),
@@ -129,6 +129,11 @@ def config(index: int, scale: float = 1.0, generator: str = "numpy") -> Workload
         rng = np.random.default_rng(5)
         return Workload("cfg5u: 3163x3163 UTF-8 Zipf(1.1) bytes [8,2048], codepoint-level Levenshtein unit",
                         "levenshtein_utf8", zipf_utf8_tape(rng, side(3163)), zipf_utf8_tape(rng, side(3163)),
+                        dict(match=0, mismatch=1, open=1, extend=1))
+    if index == 9:  # config 2's "peak" variant: every string exactly 128 bytes - no ragged lanes, no phantom rows
+        rng = np.random.default_rng(2)
+        return Workload("cfg2p: 1024x1024 ASCII len 128 exactly, Levenshtein unit", "levenshtein",
+                        random_tape(rng, side(1024), 128, 128, ASCII_PRINTABLE), random_tape(rng, side(1024), 128, 128, ASCII_PRINTABLE),
                         dict(match=0, mismatch=1, open=1, extend=1))
     if index in (7, 8):  # config 2's batch under NON-UNIT costs (a north_star function: szs_levenshtein_distances_init takes all four):
         rng = np.random.default_rng(2)  # 7: linear gaps, match 1 / mismatch 3 / gap 3; 8: affine gaps, mismatch 1 / open 4 / extend 2
