@@ -267,3 +267,84 @@ def test_node_symmetric_calls_score_the_triangle_once(gpu, oracle, devices):
     assert np.array_equal(engine(strings, others), oracle.levenshtein(strings, others))
     assert np.array_equal(engine(few[:3], others), oracle.levenshtein(few[:3], others))
     assert "peer_pairs" in engine.last_stats and engine.last_stats["peer_pairs"] == 0  # one physical GPU: no pair to enable
+
+
+# ---- one engine handle through every size and tier (the reference: test/similarities.cuh:2125-2219), and the team tier's limits ---
+
+
+def test_engines_are_reused_across_sizes_and_tiers(gpu, oracle):
+    """ONE handle per family, lengths 128 ... 8192 and back down, batch shapes alternating, ten rounds: the workspaces grow and are
+    re-used, the tier changes under the same engine (team <-> packed <-> 32-bit cells, lanes <-> chained, 64-bit cells once by
+    knob), and every matrix is checked against the oracle.  The reference sweeps its engines the same way."""
+    rng = random.Random(2125)
+    nuc, blosum = matrices.nuc44(), matrices.blosum62()
+    engines = [
+        ("needleman_wunsch", szs.NeedlemanWunschScores(*blosum, open=-4, extend=-4, capabilities=gpu), b"ARNDCQEGHILKMFPSTWYV", (blosum, -4, -4)),
+        ("smith_waterman", szs.SmithWatermanScores(*nuc, open=-4, extend=-1, capabilities=gpu), b"ACGT", (nuc, -4, -1)),
+        ("levenshtein", szs.LevenshteinDistances(1, 3, 3, 3, capabilities=gpu), b"ACGT", None),
+        ("levenshtein", szs.LevenshteinDistances(capabilities=gpu), b"ACGT", None),
+    ]
+    sizes = [128, 256, 512, 1024, 2048, 4096, 8192, 4096, 1024, 256, 128, 8192, 128]
+    seen = set()
+    for round_index, size in enumerate(sizes):
+        wide_batch = round_index % 2 == 0  # alternate: a few long pairs / many candidates
+        for kind, engine, alphabet, extra in engines:
+            queries = _rand(rng, 2 if wide_batch else 5, size // 2, size, alphabet) + [b""]
+            candidates = _rand(rng, 3 if wide_batch else 70, size // 3, size, alphabet)
+            if kind == "levenshtein":
+                costs = (1, 3, 3, 3) if engine is engines[2][1] else (0, 1, 1, 1)
+                expected = oracle.levenshtein(queries, candidates, *costs)
+            else:
+                expected = getattr(oracle, kind)(queries, candidates, *extra[0], extra[1], extra[2])
+            with knob("cells", 64 if round_index == 5 and kind != "levenshtein" else None):
+                got = engine(queries, candidates, device=gpu)
+            profile = engine.last_call_profile()
+            seen.add((kind, int(profile.tier), int(profile.cell_bits), int(profile.team) // 10000))
+            assert np.array_equal(got.view(np.int64), expected.view(np.int64)), (round_index, size, kind, profile.tier, profile.cell_bits, profile.team)
+    tiers = {(kind, bits) for kind, _, bits, _ in seen}
+    assert {("needleman_wunsch", 16), ("needleman_wunsch", 32), ("needleman_wunsch", 64), ("smith_waterman", 16), ("levenshtein", 0)} <= tiers, sorted(seen)
+    assert any(tier != 0 for _, tier, _, _ in seen), "a few long pairs take a chained tier"
+
+
+@pytest.mark.parametrize("case", ["global_narrow", "global_wide", "local_narrow", "local_wide", "distance_narrow", "distance_wide"])
+def test_team_tier_limits_are_straddled(gpu, oracle, case):
+    """Each of the six `team_reach_limit` values (hip/team_core.hpp: 15000 / 29000 / 30000 for cells kept as half-float patterns,
+    32000 / 62000 / 64000 as unsigned integers) with the caller's bound one cost step BELOW it and exactly AT it: the host must
+    pick the narrow order, the wide one or the 32-bit kernels accordingly, and every score must match the oracle - the only
+    guard against a value leaving the range in which `v_pk_maximum3_f16` orders patterns like integers is this bound."""
+    rng = random.Random(len(case))
+    nuc = matrices.nuc44()  # largest magnitude 5
+    objective, wide = case.split("_")
+    limit = {"global": (15000, 32000), "local": (29000, 62000), "distance": (30000, 64000)}[objective][wide == "wide"]
+    shape = _abi.team_shapes()[0]
+    for at_limit in (False, True):
+        if objective == "global":  # reach = (rows + columns + 3) x 5, affine gaps
+            total = limit // 5 - 3 - (0 if at_limit else 1)
+            queries = [bytes(rng.choice(b"ACGT") for _ in range(total // 2))]
+            candidates = [bytes(rng.choice(b"ACGT") for _ in range(total - total // 2)), queries[0][: total - total // 2]]
+            engine = szs.NeedlemanWunschScores(*nuc, open=-5, extend=-1, capabilities=gpu)
+            expected = oracle.needleman_wunsch(queries, candidates, *nuc, -5, -1)
+        elif objective == "local":  # bound = (shorter side + 3) x 5
+            shorter = limit // 5 - 3 - (0 if at_limit else 1)
+            core = bytes(rng.choice(b"ACGT") for _ in range(shorter + 40))
+            queries = [core[:shorter]]  # matches its own candidate end to end: the score reaches 5 x shorter, the top of the range
+            candidates = [core, bytes(rng.choice(b"ACGT") for _ in range(shorter + 7))]
+            engine = szs.SmithWatermanScores(*nuc, open=-5, extend=-1, capabilities=gpu)
+            expected = oracle.smith_waterman(queries, candidates, *nuc, -5, -1)
+        else:  # reach = (longer side + 1) x 3, costs 1 / 3 / 3 (narrow) or (longer + 3) x 4, costs 0 / 1 / 4 / 2 (wide)
+            costs, per_step, border = ((1, 3, 3, 3), 3, 1) if wide == "narrow" else ((0, 1, 4, 2), 4, 3)
+            longer = limit // per_step - border - (0 if at_limit else 1)
+            queries = [bytes(rng.choice(b"ACGT") for _ in range(longer))]
+            candidates = [bytes(rng.choice(b"ACGT") for _ in range(longer - 5)), b"", queries[0][:100]]
+            engine = szs.LevenshteinDistances(*costs, capabilities=gpu)
+            expected = oracle.levenshtein(queries, candidates, *costs)
+        with knob("team", shape), knob("tier", "lanes"), knob("swap", 0):
+            got = engine(queries, candidates, device=gpu)
+            profile = engine.last_call_profile()
+        assert np.array_equal(got.view(np.int64), expected.view(np.int64)), (case, at_limit, profile.team, profile.team_wide, profile.cell_bits)
+        if not at_limit:  # below the limit: this order of cells
+            assert profile.team == shape and profile.team_wide == (wide == "wide"), (case, profile.team, profile.team_wide)
+        elif wide == "narrow":  # at the narrow limit: the unsigned order takes over
+            assert profile.team == shape and profile.team_wide == 1, (case, profile.team, profile.team_wide)
+        else:  # at the wide limit: 32-bit cells
+            assert profile.team == 0 and profile.cell_bits == 32, (case, profile.team, profile.cell_bits)
