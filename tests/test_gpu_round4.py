@@ -284,10 +284,10 @@ def test_engines_are_reused_across_sizes_and_tiers(gpu, oracle):
         ("levenshtein", szs.LevenshteinDistances(1, 3, 3, 3, capabilities=gpu), b"ACGT", None),
         ("levenshtein", szs.LevenshteinDistances(capabilities=gpu), b"ACGT", None),
     ]
-    sizes = [128, 256, 512, 1024, 2048, 4096, 8192, 4096, 1024, 256, 128, 8192, 128]
+    sizes = [128, 256, 512, 1024, 2048, 8192, 4096, 1024, 128, 8192, 128]
     seen = set()
     for round_index, size in enumerate(sizes):
-        wide_batch = round_index % 2 == 0  # alternate: a few long pairs / many candidates
+        wide_batch = round_index % 2 == 0 or size > 1024  # alternate: a few long pairs / many candidates (the oracle scores them all)
         for kind, engine, alphabet, extra in engines:
             queries = _rand(rng, 2 if wide_batch else 5, size // 2, size, alphabet) + [b""]
             candidates = _rand(rng, 3 if wide_batch else 70, size // 3, size, alphabet)
@@ -331,8 +331,9 @@ def test_team_tier_limits_are_straddled(gpu, oracle, case):
             candidates = [core, bytes(rng.choice(b"ACGT") for _ in range(shorter + 7))]
             engine = szs.SmithWatermanScores(*nuc, open=-5, extend=-1, capabilities=gpu)
             expected = oracle.smith_waterman(queries, candidates, *nuc, -5, -1)
-        else:  # reach = (longer side + 1) x 3, costs 1 / 3 / 3 (narrow) or (longer + 3) x 4, costs 0 / 1 / 4 / 2 (wide)
-            costs, per_step, border = ((1, 3, 3, 3), 3, 1) if wide == "narrow" else ((0, 1, 4, 2), 4, 3)
+        else:  # reach = (longer side + 1) x 6, costs 2 / 6 / 6 (narrow) or (longer + 3) x 16, costs 0 / 8 / 16 / 4 (wide): strings the
+            # device planner takes (under 6 KB) - the batch's byte alphabet is counted on the device, host-planned calls keep 32-bit cells
+            costs, per_step, border = ((2, 6, 6, 6), 6, 1) if wide == "narrow" else ((0, 8, 16, 4), 16, 3)
             longer = limit // per_step - border - (0 if at_limit else 1)
             queries = [bytes(rng.choice(b"ACGT") for _ in range(longer))]
             candidates = [bytes(rng.choice(b"ACGT") for _ in range(longer - 5)), b"", queries[0][:100]]
