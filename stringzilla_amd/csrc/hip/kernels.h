@@ -167,8 +167,9 @@ typedef struct szs_queue_plan_t {
  */
 int szs_hip_levenshtein_myers_queue(szs_queue_plan_t const *plan, szs_string_ref_t const *queries, szs_string_ref_t const *candidates,
                                     uint64_t *results, uint64_t results_row_stride, int layout, uint32_t *tickets, uint32_t ticket_base,
-                                    uint32_t *tickets_taken, uint64_t *trace /* NULL, or 3 x szs_hip_levenshtein_myers_queue_grid(items)
-                                    qwords of device memory: per workgroup its first and last 100 MHz tick and the items it took */,
+                                    uint32_t *tickets_taken, uint64_t *trace /* NULL, or 7 x szs_hip_levenshtein_myers_queue_grid(items)
+                                    qwords of device memory: per workgroup its first and last 100 MHz tick, the items it took, its last item and when that
+                                    began, its longest item and how long that took */,
                                     uint32_t alphabet /* 0: byte strings; A: UTF-32 arrays of ids 1 ... A (szs_hip_alphabet_rename) */,
                                     uint32_t *unfit_flag /* pinned host memory, or NULL: receives `unfit_sequence` when a query fits no
                                     table of the kernel (the plan's job to prevent; the host then scores the call another way) */,

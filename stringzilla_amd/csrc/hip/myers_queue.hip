@@ -517,7 +517,8 @@ __global__ __launch_bounds__(queue_threads_k, 4 /* wavefronts per SIMD: two work
     u32 const tid = threadIdx.x;
     // measuring aid (`trace` knob): when every workgroup began and ended, in 100 MHz ticks, and how many items it took
     u64 const began = trace ? wall_clock64() : 0;
-    u32 items_taken = 0;
+    u32 items_taken = 0, last_item = 0, longest_item = 0;
+    u64 last_began = 0, longest_took = 0;
     if (tid == 0) next_ticket = atomicAdd(tickets, 1u) - ticket_base;
     __syncthreads();
     u32 tile_index = 0;
@@ -525,6 +526,11 @@ __global__ __launch_bounds__(queue_threads_k, 4 /* wavefronts per SIMD: two work
         u32 const item = __builtin_amdgcn_readfirstlane(next_ticket);
         if (item >= plan.items_total) break;
         ++items_taken;
+        if (trace) {
+            u64 const now = wall_clock64();
+            if (items_taken > 1 && now - last_began > longest_took) longest_took = now - last_began, longest_item = last_item;
+            last_item = item, last_began = now;
+        }
         // ---- ticket -> tile -> (queries [q_first, q_first + q_count), candidates [c_lo, c_hi)): tickets only grow, so the tile
         //      index only moves forward
         while (tile_index + 1 < plan.tiles_count && item >= plan.tiles[tile_index + 1].first_item) ++tile_index;
@@ -693,7 +699,12 @@ __global__ __launch_bounds__(queue_threads_k, 4 /* wavefronts per SIMD: two work
             __syncthreads(); // C: nobody reads the tables any more; after the last pass the next ticket is visible
         }
     }
-    if (trace && tid == 0) trace[3 * blockIdx.x] = began, trace[3 * blockIdx.x + 1] = wall_clock64(), trace[3 * blockIdx.x + 2] = items_taken;
+    if (trace && tid == 0) {
+        u64 *const mine = trace + 7 * (u64)blockIdx.x;
+        u64 const ended = wall_clock64();
+        if (items_taken && ended - last_began > longest_took) longest_took = ended - last_began, longest_item = last_item;
+        mine[0] = began, mine[1] = ended, mine[2] = items_taken, mine[3] = last_item, mine[4] = last_began, mine[5] = longest_item, mine[6] = longest_took;
+    }
 }
 
 /** Workgroups the device keeps resident (two per CU), per device ordinal and flavour. */

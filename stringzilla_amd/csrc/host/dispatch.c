@@ -747,7 +747,7 @@ static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int dev
         uint64_t *trace = NULL; /* `trace` knob: where every workgroup's begin / end ticks go (finish() prints their spread) */
         if (szs_tuning_get(szs_knob_trace_k) > 0 &&
             szs_buffer_reserve(&engine->device_queue_trace, szs_memory_device_k, device,
-                               3 * sizeof(uint64_t) * (size_t)szs_hip_levenshtein_myers_queue_grid(d->queue.items_total, d->runes), NULL) == sz_success_k)
+                               7 * sizeof(uint64_t) * (size_t)szs_hip_levenshtein_myers_queue_grid(d->queue.items_total, d->runes), NULL) == sz_success_k)
             trace = (uint64_t *)engine->device_queue_trace.pointer;
         /* a query that fits no table of the kernel (the plan's job to prevent) raises this flag in pinned memory: szs_engine_cross
          * looks after the call's wait and scores the batch with the per-width launches instead */
@@ -901,20 +901,58 @@ static sz_status_t finish(szs_call_t *call, szs_decision_t const *d, hipError_t 
 #endif
     if (call->trace && profile->queue_items && engine->device_queue_trace.pointer) { /* the persistent launch, workgroup by workgroup */
         unsigned const grid = szs_hip_levenshtein_myers_queue_grid(profile->queue_items, d->runes);
-        uint64_t *const ticks = (uint64_t *)malloc(3 * sizeof(uint64_t) * (size_t)grid);
-        if (ticks && hipMemcpy(ticks, engine->device_queue_trace.pointer, 3 * sizeof(uint64_t) * (size_t)grid, hipMemcpyDeviceToHost) == hipSuccess) {
+        uint64_t *const ticks = (uint64_t *)malloc(7 * sizeof(uint64_t) * (size_t)grid);
+        if (ticks && hipMemcpy(ticks, engine->device_queue_trace.pointer, 7 * sizeof(uint64_t) * (size_t)grid, hipMemcpyDeviceToHost) == hipSuccess) {
             uint64_t first = ~0ull, last = 0, busy = 0, latest_begin = 0;
             for (unsigned w = 0; w < grid; ++w) {
-                first = ticks[3 * w] < first ? ticks[3 * w] : first, last = ticks[3 * w + 1] > last ? ticks[3 * w + 1] : last;
-                latest_begin = ticks[3 * w] > latest_begin ? ticks[3 * w] : latest_begin, busy += ticks[3 * w + 1] - ticks[3 * w];
+                first = ticks[7 * w] < first ? ticks[7 * w] : first, last = ticks[7 * w + 1] > last ? ticks[7 * w + 1] : last;
+                latest_begin = ticks[7 * w] > latest_begin ? ticks[7 * w] : latest_begin, busy += ticks[7 * w + 1] - ticks[7 * w];
             }
             unsigned done_by[10] = {0}; /* workgroups that had ended by k / 10 of the launch */
             for (unsigned w = 0; w < grid; ++w)
-                for (unsigned k = 0; k < 10; ++k) done_by[k] += (ticks[3 * w + 1] - first) * 10 <= (uint64_t)(k + 1) * (last - first);
+                for (unsigned k = 0; k < 10; ++k) done_by[k] += (ticks[7 * w + 1] - first) * 10 <= (uint64_t)(k + 1) * (last - first);
             fprintf(stderr, "queue launch: %u workgroups, %.1f us from the first begin to the last end (last begin at %.1f us), mean busy %.3f | ended by tenth:",
                     grid, (last - first) * 1e-2, (latest_begin - first) * 1e-2, (double)busy / ((double)(last - first) * grid));
             for (unsigned k = 0; k < 10; ++k) fprintf(stderr, " %u", done_by[k]);
             fprintf(stderr, "\n");
+            for (unsigned shown = 0, w = 0; w < grid && shown < 12; ++w) /* the latest few, one by one */
+                if ((last - ticks[7 * w + 1]) * 50 <= (last - first))
+                    fprintf(stderr, "  latest: workgroup %u took %u items; its last was ticket %u, begun at %.1f us, ended at %.1f us; its longest was ticket %u: %.1f us\n", w,
+                            (unsigned)ticks[7 * w + 2], (unsigned)ticks[7 * w + 3], (ticks[7 * w + 4] - first) * 1e-2, (ticks[7 * w + 1] - first) * 1e-2,
+                            (unsigned)ticks[7 * w + 5], ticks[7 * w + 6] * 1e-2), ++shown;
+            { /* the longest items of the launch, by tile */
+                double longest_of_tile[SZS_QUEUE_MOST_TILES] = {0};
+                for (unsigned w = 0; w < grid; ++w) {
+                    if (!ticks[7 * w + 2]) continue;
+                    unsigned tile = 0;
+                    while (tile + 1 < d->queue.tiles_count && ticks[7 * w + 5] >= d->queue.tiles[tile + 1].first_item) ++tile;
+                    if (ticks[7 * w + 6] * 1e-2 > longest_of_tile[tile]) longest_of_tile[tile] = ticks[7 * w + 6] * 1e-2;
+                }
+                for (unsigned tile = 0; tile < d->queue.tiles_count && tile < 24; ++tile)
+                    if (longest_of_tile[tile] > 0) {
+                        szs_queue_tile_t const *t = &d->queue.tiles[tile];
+                        fprintf(stderr, "  tile %2u (items %u.., queries %u+%u, candidates %u..%u, %u per item x %u queries, %u lanes x %u words): longest item seen %.1f us\n", tile,
+                                t->first_item, t->query_first, t->query_count, t->candidate_first, t->candidate_end, t->candidates_per_item, t->queries_per_item, t->lanes,
+                                t->words_per_lane, longest_of_tile[tile]);
+                    }
+            }
+            /* what the LAST workgroups were holding: the tiles of the items that ended in the last twentieth of the launch */
+            unsigned late_of_tile[SZS_QUEUE_MOST_TILES] = {0};
+            double late_ms_of_tile[SZS_QUEUE_MOST_TILES] = {0};
+            for (unsigned w = 0; w < grid; ++w) {
+                if ((last - ticks[7 * w + 1]) * 20 > (last - first) || !ticks[7 * w + 2]) continue;
+                unsigned tile = 0;
+                while (tile + 1 < d->queue.tiles_count && ticks[7 * w + 3] >= d->queue.tiles[tile + 1].first_item) ++tile;
+                late_of_tile[tile]++, late_ms_of_tile[tile] += (ticks[7 * w + 1] - ticks[7 * w + 4]) * 1e-5;
+            }
+            for (unsigned tile = 0; tile < d->queue.tiles_count; ++tile)
+                if (late_of_tile[tile]) {
+                    szs_queue_tile_t const *t = &d->queue.tiles[tile];
+                    fprintf(stderr, "  late: %3u workgroups ended on tile %2u (items %u..; queries %u+%u, candidates %u..%u, %u per item x %u queries, %u lanes x %u words%s): their last item took %.3f ms on average, began at %.0f %% of the queue\n",
+                            late_of_tile[tile], tile, t->first_item, t->query_first, t->query_count, t->candidate_first, t->candidate_end, t->candidates_per_item,
+                            t->queries_per_item, t->lanes, t->words_per_lane, t->flags & SZS_QUEUE_TILE_SPARSE ? ", sparse" : "",
+                            late_ms_of_tile[tile] / late_of_tile[tile], 100.0 * t->first_item / d->queue.items_total);
+                }
         }
         free(ticks);
     }
