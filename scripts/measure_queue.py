@@ -15,6 +15,7 @@ parser.add_argument("--config", type=int, default=5)
 parser.add_argument("--shards", default="1,8")
 parser.add_argument("--words", default="auto,4,8,12,16")
 parser.add_argument("--rounds", default="auto")
+parser.add_argument("--priority", default="auto", help="auto | 0 | 1 (comma list): longest chain first on the SIMD, or one priority")
 parser.add_argument("--seconds", type=float, default=0.6)
 args = parser.parse_args()
 load = workloads.config(args.config)
@@ -30,8 +31,11 @@ for shards in [int(x) for x in args.shards.split(",")]:
     settings = [("per-width launches", {"queue": 0})]
     for words in args.words.split(","):
         for rounds in args.rounds.split(","):
-            settings.append((f"queue words={words} rounds={rounds}", {"queue": None, "queue_words": None if words == "auto" else words,
-                                                                      "queue_rounds": None if rounds == "auto" else rounds}))
+            for priority in args.priority.split(","):
+                settings.append((f"queue words={words} rounds={rounds} priority={priority}",
+                                 {"queue": None, "queue_words": None if words == "auto" else words,
+                                  "queue_rounds": None if rounds == "auto" else rounds,
+                                  "queue_priority": None if priority == "auto" else priority}))
     reference_sum = None
     for name, knobs in settings:
         for knob, value in knobs.items():

@@ -158,6 +158,8 @@ typedef struct szs_queue_tile_t {
 #define SZS_QUEUE_TILE_SPARSE 1u /* codepoints: the tile's tables are pointers + a pool of non-zero chunks (hip/myers_queue.hip) */
 typedef struct szs_queue_plan_t {
     uint32_t tiles_count, items_total;
+    uint32_t chain_most; /* the longest chain of dependent steps a wave block of this queue holds: words one lane holds x the longest
+                            candidate of its column (0: wave blocks all run at one priority) */
     szs_queue_tile_t tiles[SZS_QUEUE_MOST_TILES];
 } szs_queue_plan_t;
 /**
@@ -211,6 +213,7 @@ enum {
                                the ONE persistent launch of hip/myers_queue.hip instead of a launch per width */
     szs_knob_queue_words_k, /* -1 automatic | 4 / 8 / 12 / 16: the most words of a pattern one lane may hold in that launch */
     szs_knob_queue_rounds_k,/* -1 automatic | n: candidates per work item, in rounds of the workgroup's eight wavefronts */
+    szs_knob_queue_priority_k, /* -1 automatic (on) | 0: every wave block of that launch at one hardware priority | 1: longest chain first */
     szs_knob_count_k
 };
 int szs_tuning_get(int knob);
@@ -296,13 +299,14 @@ int szs_hip_utf8_transcode(szs_string_ref_t const *strings, uint32_t count, uint
  */
 int szs_hip_utf8_transcode_tape(void const *data, void const *offsets, uint32_t count, int wide, void const *before_offsets,
                                 uint32_t before_count, int before_wide, uint64_t capacity, uint32_t *runes, uint64_t *rune_starts,
-                                uint32_t *rune_counts, uint32_t *any_multibyte, uint64_t *needed, void *stream);
+                                uint32_t *rune_counts, uint32_t *any_multibyte, uint64_t *needed, void *alphabet_workspace, void *stream);
 /** Both tapes of a call in one launch: the second tape's runes follow the first's (`rune_starts` / `rune_counts`: first_count
- *  entries, then second_count); second_count 0: the first tape alone. */
+ *  entries, then second_count); second_count 0: the first tape alone.  `alphabet_workspace` (or NULL): the table of the
+ *  szs_hip_alphabet_rename that follows, emptied by this launch instead of by two fills of its own (`workspace_is_empty` there). */
 int szs_hip_utf8_transcode_tapes(void const *first_data, void const *first_offsets, uint32_t first_count, int first_wide,
                                  void const *second_data, void const *second_offsets, uint32_t second_count, int second_wide,
                                  uint64_t capacity, uint32_t *runes, uint64_t *rune_starts, uint32_t *rune_counts,
-                                 uint32_t *any_multibyte, uint64_t *needed, void *stream);
+                                 uint32_t *any_multibyte, uint64_t *needed, void *alphabet_workspace, void *stream);
 
 /**
  *  Renumbers the runes of a transcoded batch 1 ... A (equal runes, equal ids) in place, when it holds at most `most` distinct
@@ -314,7 +318,8 @@ int szs_hip_utf8_transcode_tapes(void const *first_data, void const *first_offse
 #define SZS_ALPHABET_MOST 4095u
 #define SZS_ALPHABET_WORTH_BYTES (1u << 16) /* smaller batches keep their runes: three launches cost more than the probes */
 int szs_hip_alphabet_rename(uint32_t count, uint64_t const *rune_starts, uint32_t const *rune_counts, uint32_t *runes,
-                            uint32_t const *any_multibyte, void *workspace, uint32_t most, uint32_t *alphabet_out, void *stream);
+                            uint32_t const *any_multibyte, void *workspace, int workspace_is_empty, uint32_t most, uint32_t *alphabet_out,
+                            void *stream);
 size_t szs_hip_alphabet_workspace_bytes(void);
 
 /** Scoring model handed to the weighted kernels; lives in device memory, one per engine. */

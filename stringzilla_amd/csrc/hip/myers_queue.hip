@@ -656,6 +656,19 @@ __global__ __launch_bounds__(queue_threads_k, 4 /* wavefronts per SIMD: two work
                 u32 const lo = hi - c_lo > pairs_per_wave ? hi - pairs_per_wave : c_lo;
                 szs_string_ref_t const query = queries[q_first + done + g];
                 queue_table_t const table = {g * slot_dwords, rows, pointer_dwords};
+                // ---- a wave block is a chain of dependent steps, one per symbol of its longest candidate, each as many
+                //      instructions as the lane holds words: the SIMD's four wavefronts share its issue slots, and a long chain begun
+                //      late would hold the launch's end back at a quarter of the speed it could run at.  Longest chain first, on the
+                //      SIMD as in the queue: the hardware's own priority, in quarters of the plan's longest chain.
+                if (plan.chain_most) {
+                    u32 const held = lanes > 1u ? words_per_lane : __builtin_amdgcn_readfirstlane(query.length ? (query.length + 31u) / 32u : 1u);
+                    u32 const chain = held * __builtin_amdgcn_readfirstlane(candidates[hi - 1u].length);
+                    u32 const quarter = (u32)(((u64)chain * 4u) / plan.chain_most);
+                    if (quarter >= 3u) __builtin_amdgcn_s_setprio(3);
+                    else if (quarter == 2u) __builtin_amdgcn_s_setprio(2);
+                    else if (quarter == 1u) __builtin_amdgcn_s_setprio(1);
+                    else __builtin_amdgcn_s_setprio(0);
+                }
 #define SZS_QUEUE_LANES(W, D) queue_lanes<W, D, runes_>(table, query, candidates, lo, hi, results, results_row_stride, layout)
 #define SZS_QUEUE_TEAM(W)                                                                                                          \
     do {                                                                                                                           \
@@ -693,6 +706,7 @@ __global__ __launch_bounds__(queue_threads_k, 4 /* wavefronts per SIMD: two work
 #undef SZS_QUEUE_LANES
 #undef SZS_QUEUE_TEAM
             }
+            if (plan.chain_most) __builtin_amdgcn_s_setprio(0);
             } // fit
             done += together;
             if (done >= q_count && tid == 0) next_ticket = ahead - ticket_base;

@@ -34,6 +34,7 @@ namespace szs_hip {
  *  runes of a chunk are written in one coalesced burst.  The next chunk's bytes are in flight while this one is decoded.
  */
 constexpr int transcode_waves_k = 4; // wavefronts (strings in flight) per workgroup
+constexpr u32 alphabet_slots_k = SZS_ALPHABET_SLOTS, alphabet_empty_k = ~0u; // the renumbering pass's table (below): [keys][ids][control]
 
 /** Where string i lies and where its runes go - from refs and host-made starts (the host-planned path) ... */
 struct transcode_refs_t {
@@ -93,7 +94,15 @@ struct transcode_tapes_t {
 template <typename source_t>
 __global__ __launch_bounds__(64 * transcode_waves_k) void utf8_transcode_kernel(source_t source, u32 count, u32 *__restrict__ runes,
                                                                                 u32 *__restrict__ rune_counts,
-                                                                                u32 *__restrict__ any_multibyte) {
+                                                                                u32 *__restrict__ any_multibyte,
+                                                                                u32 *__restrict__ alphabet_workspace) {
+    // ---- the renumbering pass that follows wants an empty table: emptied here, by everybody, instead of by two fills of the
+    //      stream ahead of it (each an operation of its own in front of the planner, ~5 us of a short call)
+    if (alphabet_workspace) {
+        for (u32 slot = blockIdx.x * blockDim.x + threadIdx.x; slot < alphabet_slots_k; slot += gridDim.x * blockDim.x)
+            alphabet_workspace[slot] = alphabet_empty_k;
+        if (blockIdx.x == 0 && threadIdx.x < 2) alphabet_workspace[2 * alphabet_slots_k + threadIdx.x] = 0; // `control`
+    }
     __shared__ u8 reached[transcode_waves_k][64];
     u32 const lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     u8 volatile *const mine = reached[wave];
@@ -117,8 +126,23 @@ __global__ __launch_bounds__(64 * transcode_waves_k) void utf8_transcode_kernel(
             u64 const high_mask = __ballot(valid && byte >= 0x80u);
             multibyte |= high_mask != 0;
 
+            // ---- well-formed text (round 4): when every byte that is not a continuation byte is followed by exactly the
+            //      continuation bytes its own value announces - and the chunk's head by exactly the ones the previous chunk left
+            //      hanging - the chain of jumps below visits the non-continuation bytes and nothing else: two ballots instead
+            //      of six rounds through LDS.  (A 2048-byte line of prose was 32 chunks x 6 rounds, one after another: the
+            //      transcoding of an eighth of config 5u took 73 us, all of it that one chain.)  Anything else - stray
+            //      continuation bytes, tails cut short, a lead at the end of the string - takes the chain, as before.
+            u64 const continuing = __ballot(valid && (byte & 0xC0u) == 0x80u);
+            u64 const continuing_ahead = __ballot(after < length && (ahead & 0xC0u) == 0x80u);
+            u32 const following = (u32)(((continuing >> lane) >> 1) | (continuing_ahead << (63u - lane))) & 0xFu; // bytes lane + 1 ... + 4
+            bool const announced = (following & ((1u << sequence) - 1u)) == (1u << (sequence - 1u)) - 1u;
+            bool const lead = valid && (byte & 0xC0u) != 0x80u;
+            bool const head_as_left = hanging < 4u && (continuing & ((2ull << hanging) - 1ull)) == (1ull << hanging) - 1ull;
+            bool const well_formed = head_as_left && !__ballot(lead && !announced);
+
             u64 leads;
             if (!high_mask && !hanging) leads = valid_mask; // plain ASCII: every byte is a lead
+            else if (well_formed) leads = valid_mask & ~continuing;
             else {
                 u32 jump = valid ? lane + sequence : 64u; // next^(2^k) of this position, 64 = beyond the chunk
                 jump = jump > 64u ? 64u : jump;
@@ -179,7 +203,7 @@ __global__ __launch_bounds__(64 * transcode_waves_k) void utf8_transcode_kernel(
  *  place.  With A <= SZS_ALPHABET_MOST the kernels then look a symbol up in a direct table (`local[id]`, one LDS read, no loop);
  *  a richer batch keeps its runes (the second pass does nothing) and the kernels keep probing.
  */
-constexpr u32 alphabet_slots_k = SZS_ALPHABET_SLOTS, alphabet_empty_k = ~0u, alphabet_seen_lines_k = 4096;
+constexpr u32 alphabet_seen_lines_k = 4096;
 
 __device__ __forceinline__ u32 alphabet_slot(u32 rune) { return (rune * 2654435761u) >> (32 - __builtin_ctz(alphabet_slots_k)); }
 
@@ -260,35 +284,35 @@ extern "C" int szs_hip_utf8_transcode(szs_string_ref_t const *strings, uint32_t 
     u32 const blocks = (count + transcode_waves_k - 1) / transcode_waves_k;
     transcode_refs_t const source = {strings, rune_starts};
     hipLaunchKernelGGL(utf8_transcode_kernel<transcode_refs_t>, dim3(blocks < 65536u ? blocks : 65536u), dim3(64 * transcode_waves_k), 0,
-                       static_cast<hipStream_t>(stream), source, count, runes, rune_counts, any_multibyte);
+                       static_cast<hipStream_t>(stream), source, count, runes, rune_counts, any_multibyte, static_cast<u32 *>(nullptr));
     return (int)hipGetLastError();
 }
 
 extern "C" int szs_hip_utf8_transcode_tape(void const *data, void const *offsets, uint32_t count, int wide, void const *before_offsets,
                                            uint32_t before_count, int before_wide, uint64_t capacity, uint32_t *runes,
                                            uint64_t *rune_starts, uint32_t *rune_counts, uint32_t *any_multibyte, uint64_t *needed,
-                                           void *stream) {
+                                           void *alphabet_workspace, void *stream) {
     using namespace szs_hip;
-    if (!count) return 0;
+    if (!count) return 0; /* (nothing to renumber either) */
     u32 const blocks = (count + transcode_waves_k - 1) / transcode_waves_k;
     transcode_tape_t const source = {static_cast<u8 const *>(data), offsets, before_offsets, count, (u32)(wide != 0), before_count,
                                      (u32)(before_wide != 0), capacity, rune_starts, needed};
     hipLaunchKernelGGL(utf8_transcode_kernel<transcode_tape_t>, dim3(blocks < 65536u ? blocks : 65536u), dim3(64 * transcode_waves_k), 0,
-                       static_cast<hipStream_t>(stream), source, count, runes, rune_counts, any_multibyte);
+                       static_cast<hipStream_t>(stream), source, count, runes, rune_counts, any_multibyte, static_cast<u32 *>(alphabet_workspace));
     return (int)hipGetLastError();
 }
 
 extern "C" int szs_hip_utf8_transcode_tapes(void const *first_data, void const *first_offsets, uint32_t first_count, int first_wide,
                                             void const *second_data, void const *second_offsets, uint32_t second_count, int second_wide,
                                             uint64_t capacity, uint32_t *runes, uint64_t *rune_starts, uint32_t *rune_counts,
-                                            uint32_t *any_multibyte, uint64_t *needed, void *stream) {
+                                            uint32_t *any_multibyte, uint64_t *needed, void *alphabet_workspace, void *stream) {
     using namespace szs_hip;
     if (!second_count)
         return szs_hip_utf8_transcode_tape(first_data, first_offsets, first_count, first_wide, nullptr, 0, 0, capacity, runes, rune_starts,
-                                           rune_counts, any_multibyte, needed, stream);
+                                           rune_counts, any_multibyte, needed, alphabet_workspace, stream);
     if (!first_count)
         return szs_hip_utf8_transcode_tape(second_data, second_offsets, second_count, second_wide, first_offsets, 0, first_wide, capacity, runes,
-                                           rune_starts, rune_counts, any_multibyte, needed, stream);
+                                           rune_starts, rune_counts, any_multibyte, needed, alphabet_workspace, stream);
     u64 const count = (u64)first_count + second_count;
     if (count > 0xFFFFFFFFull) return (int)hipErrorInvalidValue;
     u64 const blocks = (count + transcode_waves_k - 1) / transcode_waves_k;
@@ -297,22 +321,24 @@ extern "C" int szs_hip_utf8_transcode_tapes(void const *first_data, void const *
         {static_cast<u8 const *>(second_data), second_offsets, first_offsets, second_count, (u32)(second_wide != 0), first_count,
          (u32)(first_wide != 0), capacity, rune_starts + first_count, needed}};
     hipLaunchKernelGGL(utf8_transcode_kernel<transcode_tapes_t>, dim3(blocks < 65536u ? (u32)blocks : 65536u), dim3(64 * transcode_waves_k), 0,
-                       static_cast<hipStream_t>(stream), source, (u32)count, runes, rune_counts, any_multibyte);
+                       static_cast<hipStream_t>(stream), source, (u32)count, runes, rune_counts, any_multibyte, static_cast<u32 *>(alphabet_workspace));
     return (int)hipGetLastError();
 }
 
 extern "C" size_t szs_hip_alphabet_workspace_bytes(void) { return (size_t)SZS_ALPHABET_SLOTS * 2 * sizeof(uint32_t) + 2 * sizeof(uint32_t); }
 
 extern "C" int szs_hip_alphabet_rename(uint32_t count, uint64_t const *rune_starts, uint32_t const *rune_counts, uint32_t *runes,
-                                       uint32_t const *any_multibyte, void *workspace, uint32_t most, uint32_t *alphabet_out,
-                                       void *stream) {
+                                       uint32_t const *any_multibyte, void *workspace, int workspace_is_empty, uint32_t most,
+                                       uint32_t *alphabet_out, void *stream) {
     using namespace szs_hip;
     if (!count) return 0;
     hipStream_t const s = static_cast<hipStream_t>(stream);
     u32 *const keys = static_cast<u32 *>(workspace), *const ids = keys + alphabet_slots_k, *const control = ids + alphabet_slots_k;
-    hipError_t error = hipMemsetAsync(keys, 0xFF, (size_t)alphabet_slots_k * sizeof(u32), s);
-    if (error == hipSuccess) error = hipMemsetAsync(control, 0, 2 * sizeof(u32), s);
-    if (error != hipSuccess) return (int)error;
+    if (!workspace_is_empty) { /* (the transcoding launch ahead of this one was not asked to empty it) */
+        hipError_t error = hipMemsetAsync(keys, 0xFF, (size_t)alphabet_slots_k * sizeof(u32), s);
+        if (error == hipSuccess) error = hipMemsetAsync(control, 0, 2 * sizeof(u32), s);
+        if (error != hipSuccess) return (int)error;
+    }
     u32 const blocks = (count + 3) / 4 < 2048u ? (count + 3) / 4 : 2048u;
     u32 const claim_waves = alphabet_claim_threads_k / 64u, claim_blocks = (count + claim_waves - 1) / claim_waves;
     hipLaunchKernelGGL(alphabet_claim_kernel, dim3(claim_blocks < 256u ? claim_blocks : 256u), dim3(alphabet_claim_threads_k), 0, s, count, rune_starts,

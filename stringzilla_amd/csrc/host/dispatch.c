@@ -206,7 +206,7 @@ static sz_status_t transcode_to_runes(szs_engine_s *engine, int device, hipStrea
     if (error == hipSuccess && renumber)
         error = (hipError_t)szs_hip_alphabet_rename((uint32_t)strings, (uint64_t const *)(remote + starts_at), (uint32_t const *)(remote + counts_at),
                                                     (uint32_t *)engine->device_runes.pointer, (uint32_t const *)(remote + flag_at),
-                                                    engine->device_alphabet.pointer, SZS_ALPHABET_MOST,
+                                                    engine->device_alphabet.pointer, 0, SZS_ALPHABET_MOST,
                                                     (uint32_t *)(remote + flag_at + sizeof(uint32_t)), stream);
     if (error == hipSuccess)
         error = hipMemcpyAsync(host + counts_at, remote + counts_at, staging_bytes - counts_at, hipMemcpyDeviceToHost, stream);
@@ -1272,10 +1272,10 @@ static hipError_t enqueue_transcoding(szs_call_t *call, char *remote, size_t fla
                                                          call->symmetric ? NULL : call->candidates->offsets, call->symmetric ? 0u : c_count,
                                                          !call->symmetric && call->candidates->kind == szs_input_u64tape_k, capacity,
                                                          (uint32_t *)engine->device_runes.pointer, starts, counts, device_flags,
-                                                         (uint64_t *)(remote + needed_at), stream);
+                                                         (uint64_t *)(remote + needed_at), renumber ? engine->device_alphabet.pointer : NULL, stream);
     if (error == hipSuccess && renumber)
         error = (hipError_t)szs_hip_alphabet_rename((uint32_t)strings, starts, counts, (uint32_t *)engine->device_runes.pointer, device_flags,
-                                                    engine->device_alphabet.pointer, SZS_ALPHABET_MOST, device_flags + 1, stream);
+                                                    engine->device_alphabet.pointer, 1, SZS_ALPHABET_MOST, device_flags + 1, stream);
     return error;
 }
 

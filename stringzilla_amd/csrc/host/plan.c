@@ -290,6 +290,7 @@ void szs_plan_queue(szs_plan_t const *plan, uint32_t queries_count, uint32_t can
     double const item_ns = call_ns / 16.0; /* what one item may hold a workgroup for: the queue's granularity at its end */
     double keys[SZS_QUEUE_MOST_TILES];
     unsigned tiles = 0;
+    uint64_t chain_most = 0; /* words one lane holds x the longest candidate it meets: the launch's longest chain of dependent steps */
     for (unsigned column = 0; column < columns; ++column) {
         uint32_t const begin = column_begin[column], end = column_end[column], longest = column_longest[column];
         /* the most words one lane may hold against THIS column: the largest of 16 / 12 / 8 / 4 whose wave block fits.  The shape
@@ -337,6 +338,7 @@ void szs_plan_queue(szs_plan_t const *plan, uint32_t queries_count, uint32_t can
             tile->queries_per_item = (uint8_t)side_by_side, tile->flags = sparse ? SZS_QUEUE_TILE_SPARSE : 0;
             uint64_t const blocks_of_item = side_by_side * ((per_item + pairs_per_wave - 1) / pairs_per_wave);
             keys[tiles] = (double)((blocks_of_item + 7u) / 8u) * lane_words * longest;
+            if ((uint64_t)lane_words * longest > chain_most) chain_most = (uint64_t)lane_words * longest;
             ++tiles;
         }
     }
@@ -371,6 +373,7 @@ void szs_plan_queue(szs_plan_t const *plan, uint32_t queries_count, uint32_t can
     }
 #undef SZS_QUEUE_ITEMS_OF
     queue->tiles_count = tiles, queue->items_total = items;
+    queue->chain_most = szs_tuning_get(szs_knob_queue_priority_k) == 0 ? 0u : chain_most < 0xFFFFFFFFull ? (uint32_t)chain_most : 0xFFFFFFFFu;
 }
 
 /* ---- tier and orientation choice ------------------------------------------------------------------------------------ */

@@ -349,3 +349,31 @@ def test_team_tier_limits_are_straddled(gpu, oracle, case):
             assert profile.team == shape and profile.team_wide == 1, (case, profile.team, profile.team_wide)
         else:  # at the wide limit: 32-bit cells
             assert profile.team == 0 and profile.cell_bits == 32, (case, profile.team, profile.cell_bits)
+
+
+def test_transcoding_of_long_lines_well_formed_and_not(gpu, oracle):
+    """The transcoder takes well-formed chunks with two ballots and anything else through its chain of jumps (hip/utf8.hip):
+    long lines whose sequences straddle the 64-byte chunks at every phase, with and without damage - stray continuation
+    bytes, tails cut short, leads at the very end - must decode as `sz_rune_decode_unchecked` does, chunk after chunk."""
+    rng = np.random.default_rng(404)
+    alphabet = ["a", "b", " ", "é", "ß", "中", "文", "𝄞", "😀"]
+    lines = []
+    for k in range(24):
+        text = "".join(rng.choice(alphabet, size=int(rng.integers(60, 400))))
+        raw = bytearray(("x" * (k % 5) + text).encode())
+        if k % 3 == 1:  # damage: bytes flipped into strays / leads, one tail cut
+            for at in rng.integers(0, len(raw), size=6):
+                raw[at] = int(rng.choice([0x80, 0xBF, 0xC3, 0xE4, 0xF0, 0x41]))
+        if k % 3 == 2:
+            raw = raw[:len(raw) - int(rng.integers(1, 3))] + bytes([0xE4])  # a lead as the last byte
+        lines.append(bytes(raw))
+    lines += [b"", "é".encode() * 32, ("a" + "中" * 21).encode(), ("ab" + "𝄞" * 16).encode()]
+    engine = szs.LevenshteinDistancesUTF8(capabilities=gpu)
+    expected = oracle.levenshtein_utf8(lines, lines)
+    assert np.array_equal(engine(lines, lines, device=gpu), expected)
+    with knob("alphabet", 1):
+        assert np.array_equal(engine(lines, lines, device=gpu), expected)
+    with knob("alphabet", 0):
+        assert np.array_equal(engine(lines, lines[:7], device=gpu), oracle.levenshtein_utf8(lines, lines[:7]))
+    with knob("planner", "host"), knob("alphabet", 1):  # the host-planned path transcodes refs, and empties the table with fills
+        assert np.array_equal(engine(lines, lines, device=gpu), expected)
