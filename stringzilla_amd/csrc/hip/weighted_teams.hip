@@ -243,28 +243,33 @@ __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
             };
             // The profile row arrives 16 bytes at a time, one chunk ahead of the rows that consume it, and nothing moves across
             // a chunk: left alone, hipcc hoists every read of all four steps of a batch (4 R registers) above the first row.
-            // `whole` passes take all R registers without a question; the last pass of a pair (fewer rows per lane) asks a
-            // wavefront-uniform question per chunk - measured 14 % slower per step, so it gets its own copy of the loops.
+            // The MAIN LOOP of a pass knows how many chunks the pass holds as a constant (round 4: one copy of the loop per
+            // count - a pass that asks a wavefront-uniform question per chunk instead measured 14 % slower per step, and half of
+            // config 3's pairs have no other pass: a 448-row protein is ONE pass of 28 of the 32 registers); the predicated
+            // steps of a short pass - fill, drain - still ask, they are few.
             // `opening`: in the main loop a lane knows its row of the NEXT step when this one begins (it is its left neighbour's
             // row of this step), so the first chunk of every step is fetched a whole step early (`row_after` -> `opening`); a
             // predicated step fetches its own.
             uint4 opening = make_uint4(0, 0, 0, 0);
-            auto advance = [&](auto whole, auto pipelined, team_edge_t const &in, u32 in_row, u32 row_after) {
-                constexpr bool whole_ = decltype(whole)::value, pipelined_ = decltype(pipelined)::value;
+            auto advance = [&](auto chunks, auto pipelined, team_edge_t const &in, u32 in_row, u32 row_after) {
+                // `chunks`: the chunks of four registers this pass holds, as a constant - or 0: ask `chunks_now`, chunk by chunk
+                constexpr int fixed_ = decltype(chunks)::value;
+                constexpr bool pipelined_ = decltype(pipelined)::value;
+                constexpr int most_ = fixed_ ? fixed_ : R / 4;
                 uint4 const *const row = reinterpret_cast<uint4 const *>(profile + strip_base + in_row);
                 team_step_t<costs_t, R> step;
                 uint4 next = pipelined_ ? opening : row[0];
                 if constexpr (pipelined_) opening = *reinterpret_cast<uint4 const *>(profile + strip_base + row_after);
                 step.begin(in, diagonal, next.x);
 #pragma unroll
-                for (int chunk = 0; chunk < R / 4; ++chunk) {
+                for (int chunk = 0; chunk < most_; ++chunk) {
                     // one way OUT per chunk, not a way AROUND it: the rows of a skipped chunk then need no copies to meet
                     // the rows of a scored one again (a guard around every chunk cost ten v_mov per four rows)
-                    if (!whole_ && (u32)chunk >= chunks_now) break;
+                    if (!fixed_ && (u32)chunk >= chunks_now) break;
                     uint4 const now = next;
                     // one chunk past the last one of a short pass: inside the profile, unused.  (TWO chunks ahead measured the
                     // same within a percent - 14.27 / 525 ms against 14.10 / 529 on configs 3 / 4: it is not the LDS round trip.)
-                    if (chunk + 1 < R / 4) next = row[chunk + 1];
+                    if (chunk + 1 < most_) next = row[chunk + 1];
                     // (a row is handed the cost of the row BELOW it: team_step_t::row)
                     step.row(k, rows, 4 * chunk + 0, now.y, best), step.row(k, rows, 4 * chunk + 1, now.z, best);
                     step.row(k, rows, 4 * chunk + 2, now.w, best), step.row(k, rows, 4 * chunk + 3, next.x, best);
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
                 out_row = in_row;
             };
             // Predicated step `t`: the head's column is t + 1, this lane's is t + 1 - lane_in_team.
-            auto careful_step = [&](auto whole, u32 t) {
+            auto careful_step = [&](auto chunks, u32 t) {
                 u32 const head_column = t + 1;
                 team_edge_t head_edge = {0, 0};
                 u32 head_row = 0;
@@ -288,16 +293,18 @@ __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
                 hand_over(head_edge, head_row, in, in_row);
                 u32 const column = head_column - lane_in_team; // wraps for a lane that has not started
                 if (column - 1 < text_length) {
-                    advance(whole, std::false_type {}, in, in_row, 0u);
+                    advance(chunks, std::false_type {}, in, in_row, 0u);
                     if (is_tail && park_this_pass) parked[(u64)column * teams] = park_of<affine_>(out);
                 }
             };
 
-            auto walk = [&](auto whole) {
+            auto walk = [&](auto chunks) {
+                constexpr int fixed_ = decltype(chunks)::value;
+                std::integral_constant<int, fixed_ == R / 4 ? R / 4 : 0> const careful; // every register, or ask
                 constexpr u32 fill = (u32)((L - 1 + 3) / 4 * 4); // the first step at which every lane of a team has a column
                 u32 t = 0;
 #pragma unroll 1
-                for (; t < fill && t < longest_in_wave + L - 1; ++t) careful_step(whole, t);
+                for (; t < fill && t < longest_in_wave + L - 1; ++t) careful_step(careful, t);
                 // ---- main loop: batches of four steps in which EVERY live lane of the wavefront has a column - no length
                 //      checks, unconditional loads / stores (dead teams run along on their own parked slots).
                 if (t == fill && t + 4 <= shortest_in_wave) {
@@ -326,7 +333,7 @@ __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
                             team_edge_t in;
                             in.h = from_left<L>(head_edge.h, out.h, is_head);
                             in.f = affine_ ? from_left<L>(head_edge.f, out.f, is_head) : 0u;
-                            advance(whole, std::true_type {}, in, my_row, my_row_after);
+                            advance(chunks, std::true_type {}, in, my_row, my_row_after);
                             my_row = my_row_after;
                             // the tail's column of step t + s is t + s + 2 - L >= 1: L - 1 <= fill <= t
                             if (park_this_pass && is_tail) parked[(u64)(t + s + 2 - L) * teams] = park_of<affine_>(out);
@@ -336,11 +343,15 @@ __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
                 }
                 // ---- drain: ragged lengths and the lanes that are still behind their head
 #pragma unroll 1
-                for (; t < longest_in_wave + L - 1; ++t) careful_step(whole, t);
+                for (; t < longest_in_wave + L - 1; ++t) careful_step(careful, t);
             };
             if (longest_in_wave) {
-                if (chunks_now == R / 4) walk(std::true_type {});
-                else walk(std::false_type {});
+#define SZS_TEAM_WALK(C)                                                                                               \
+    if constexpr (R / 4 >= C)                                                                                          \
+        if (chunks_now == C) walk(std::integral_constant<int, C> {});
+                SZS_TEAM_WALK(1) SZS_TEAM_WALK(2) SZS_TEAM_WALK(3) SZS_TEAM_WALK(4) SZS_TEAM_WALK(5) SZS_TEAM_WALK(6) SZS_TEAM_WALK(7) SZS_TEAM_WALK(8)
+#undef SZS_TEAM_WALK
+                static_assert(R / 4 <= 8, "one copy of the main loop per chunk count");
             }
 
             // ---- scores that are complete after this pass
