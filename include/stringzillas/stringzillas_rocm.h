@@ -155,6 +155,8 @@ typedef struct szs_rocm_node_stats_t {
 SZ_API_RUNTIME sz_status_t szs_rocm_node_init(sz_size_t const *gpu_devices, sz_size_t count, szs_rocm_node_t *node,
                                               char const **error_message);
 SZ_API_RUNTIME sz_size_t szs_rocm_node_size(szs_rocm_node_t node);
+/** Engines created from the node keep it alive until they are freed themselves.  The handle must not be used after this call:
+ *  a second free is recognised (and ignored) only while such engines still exist - afterwards the memory is gone. */
 SZ_API_RUNTIME void szs_rocm_node_free(szs_rocm_node_t node);
 
 /** Engines of a node: same arguments and meaning as `szs_*_init` (stringzillas.h), `*engine` must be NULL on entry. */

@@ -607,8 +607,14 @@ static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int dev
         return (hipError_t)launch_error;
     }
     /* Persistent kernels address their work items with 32 bits: cross-products beyond that are cut along the query axis. */
-    uint64_t const candidate_blocks = ((uint64_t)d->kc_count + SZS_CANDIDATES_PER_WORKGROUP - 1) / SZS_CANDIDATES_PER_WORKGROUP;
-    uint32_t const queries_per_launch = (uint32_t)(0xFFFFFFF0ull / (candidate_blocks ? candidate_blocks : 1));
+    uint64_t candidate_blocks = ((uint64_t)d->kc_count + SZS_CANDIDATES_PER_WORKGROUP - 1) / SZS_CANDIDATES_PER_WORKGROUP;
+    uint64_t queries_most = 0xFFFFFFF0ull / (candidate_blocks ? candidate_blocks : 1);
+    if (d->team) { /* the team tier's item is a PAIR of queries x the 256 / lanes candidates of a workgroup (weighted_teams.hip) */
+        uint64_t const per_block = 256u / (d->team / 10000u ? d->team / 10000u : 1u);
+        candidate_blocks = ((uint64_t)d->kc_count + per_block - 1) / per_block;
+        queries_most = 2 * (0xFFFFFFF0ull / (candidate_blocks ? candidate_blocks : 1)); /* even: the pairs of a cut stay pairs */
+    }
+    uint32_t const queries_per_launch = queries_most < 0xFFFFFFF0ull ? (uint32_t)queries_most : 0xFFFFFFF0u;
 
     /* A batch of mixed lengths is several launches (one per bit-vector width), and every launch ends in a tail: its last,
      * longest pairs hold a few wavefronts while the rest of the chip idles - on config 5 the two widest launches kept 0.7
