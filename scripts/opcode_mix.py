@@ -106,6 +106,20 @@ def main():
             out[short] = {"source": source, "main_loop": header, "valu_instructions": total, "full_rate": full, "half_rate": half,
                           "ceiling_Tlane_ops_per_s": round(total / (full / FULL_RATE_T + half / HALF_RATE_T), 2),
                           "opcodes": dict(mix.most_common()), "priced_half_rate_unmeasured": unknown}
+    # The one-launch kernel (hip/myers_queue.hip) spends its time in `noinline` BODIES - functions of their own in the code
+    # object - while the largest loop of the `__global__` function itself is the table build: its mix is the sum of its
+    # bodies' main loops (their ceilings differ by a percent: 59.7 ... 61.6), the kernel's own loop kept beside it.
+    for name in [name for name in out if name.startswith("levenshtein_myers_queue_kernel<")]:
+        runes = name.split("<", 1)[1].rstrip(">").strip()
+        bodies = [body for body in out if (body.startswith("queue_lanes<") and body.rstrip(">").split(",")[-1].strip() == runes) or
+                  (body.startswith("queue_team<") and body.split("<", 1)[1].split(",")[1].strip() == runes)]
+        if not bodies:
+            continue
+        full, half = sum(out[body]["full_rate"] for body in bodies), sum(out[body]["half_rate"] for body in bodies)
+        out[name] = {"source": out[name]["source"], "main_loop": f"the main loops of its {len(bodies)} bodies (queue_lanes / queue_team), summed",
+                     "valu_instructions": full + half, "full_rate": full, "half_rate": half,
+                     "ceiling_Tlane_ops_per_s": round((full + half) / (full / FULL_RATE_T + half / HALF_RATE_T), 2),
+                     "bodies": sorted(bodies), "table_build_loop": out[name], "priced_half_rate_unmeasured": []}
     text = json.dumps(out, indent=1)
     if len(sys.argv) > 1:
         with open(sys.argv[1], "w") as handle:

@@ -83,12 +83,19 @@ for directory in sorted(glob.glob(os.path.join(root, "cfg*"))):
         scoring = {name: entry for name, entry in summary.items()
                    if entry.get("_config") == config and not name.endswith(":__call__") and
                    not any(helper in name for helper in ("plan_kernel", "utf8_transcode", "byte_presence", "alphabet_"))}  # not scoring launches
-        launches_seen = sum(entry.get("_calls", 0) for entry in scoring.values())
         launches_per_call = line["roofline"].get("launches_per_step", 1)
+        # The run may hold more calls than steps + warm-up (bench.py's fresh-batch leg), and its FIRST call may be another kind of
+        # call altogether (codepoints: no alphabet yet, so the per-width launches instead of the one queue launch): the kernels of
+        # the steady call are the ones launched at least half as often as the most frequent one; the launches one steady call
+        # makes (the bench line's `launches_per_step`) are dealt over them in proportion.
+        most = max([entry.get("_calls", 0) for entry in scoring.values()] + [1])
+        steady = {name: entry.get("_calls", 0) / most for name, entry in scoring.items() if entry.get("_calls", 0) * 2 >= most}
+        weight = sum(steady.values()) or 1.0
         for name, entry in scoring.items():
-            # the run may hold more calls than steps + warm-up (bench.py's fresh-batch leg): scale by the launches one call makes
-            per_call = entry.get("_calls", 0) / max(launches_seen, 1) * launches_per_call
+            per_call = steady.get(name, 0.0) / weight * launches_per_call
             call["kernels"][name.split(":", 1)[1]] = {"launches_per_call": round(per_call, 3), "share_of_kernel_time": round(entry.get("_share", 0.0), 4)}
+            if name not in steady:
+                call["kernels"][name.split(":", 1)[1]]["only_in_the_cold_call"] = True
             for counter in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT",
                             "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAVES",
                             "hbm_fetch_bytes_raw", "hbm_write_bytes_raw"):

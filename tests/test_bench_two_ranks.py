@@ -43,7 +43,9 @@ def test_ranks_on_one_device(ranks):
     gpu = szs.DeviceScope(gpu_device=0)
     expected = {}
     for config in (4, 5):
-        load = workloads.config(config, scale=scale)
+        # the batches bench.py scores: std::mt19937_64 for configs 1-4 when the helper library is built, numpy otherwise
+        helper = os.path.join(ROOT, "tests", "native", "bin", "libworkloads_mt19937.so")
+        load = workloads.config(config, scale=scale, generator="mt19937_64" if config <= 4 and os.path.exists(helper) else "numpy")
         if load.kind == "levenshtein":
             engine = szs.LevenshteinDistances(**load.costs, capabilities=gpu)
         else:

@@ -377,3 +377,20 @@ def test_transcoding_of_long_lines_well_formed_and_not(gpu, oracle):
         assert np.array_equal(engine(lines, lines[:7], device=gpu), oracle.levenshtein_utf8(lines, lines[:7]))
     with knob("planner", "host"), knob("alphabet", 1):  # the host-planned path transcodes refs, and empties the table with fills
         assert np.array_equal(engine(lines, lines, device=gpu), expected)
+
+
+def test_a_host_planned_call_never_scores_with_the_previous_batch_alphabet(gpu, oracle):
+    """Non-unit Levenshtein engines key the team tier's profile by the dense alphabet of THE BATCH (counted on the device).  A
+    host-planned call - the `planner` knob, callback sequences, host-only pointers - does not count one: it must not inherit the
+    previous call's (bytes absent from the earlier batch all mapped to class 0 and scored as equal)."""
+    rng = random.Random(77)
+    engine = szs.LevenshteinDistances(0, 2, 3, 3, capabilities=gpu)
+    first_q, first_c = _rand(rng, 12, 90, 300, b"ACGT"), _rand(rng, 140, 60, 300, b"ACGT")
+    other_q, other_c = _rand(rng, 12, 90, 300, b"klmnopqrstuvwxyz"), _rand(rng, 140, 60, 300, b"klmnopqrstuvwxyz")
+    with knob("tier", "lanes"):
+        assert np.array_equal(engine(first_q, first_c, device=gpu), oracle.levenshtein(first_q, first_c, 0, 2, 3, 3))
+        assert engine.last_call_profile().team, "the device-planned call is expected on the team tier"
+        with knob("planner", "host"):
+            assert np.array_equal(engine(other_q, other_c, device=gpu), oracle.levenshtein(other_q, other_c, 0, 2, 3, 3))
+            assert np.array_equal(engine(other_q, first_c, device=gpu), oracle.levenshtein(other_q, first_c, 0, 2, 3, 3))
+        assert np.array_equal(engine(other_q, other_c, device=gpu), oracle.levenshtein(other_q, other_c, 0, 2, 3, 3))
