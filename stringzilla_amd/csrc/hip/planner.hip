@@ -29,6 +29,7 @@ namespace szs_hip {
 
 constexpr int plan_threads_k = 1024;
 constexpr int plan_waves_k = plan_threads_k / 64;
+constexpr u32 plan_cached_k = 4; // strings per thread and side kept in registers from the first fetch on
 constexpr u32 plan_bins_k = SZS_PLAN_DEVICE_LONGEST + 1;         // lengths below this are counting-sorted in LDS
 constexpr u32 plan_chunk_k = plan_bins_k / plan_threads_k;       // histogram bins per thread
 static_assert(plan_bins_k % plan_threads_k == 0, "the histogram is cut into equal chunks");
@@ -82,14 +83,21 @@ __global__ __launch_bounds__(plan_threads_k) void plan_kernel(szs_plan_side_t qu
 
     // ---- phase 0: both histograms cleared; each thread's first string of each side fetched (one round trip for the kernel
     //      when a side has at most 1024 strings: every later phase reads registers)
-    u64 first_from[2] = {0, 0}, first_to[2] = {0, 0}, first_start[2] = {0, 0};
-    u32 first_length[2] = {0, 0};
+    // (round 4: the first FOUR strings of each side - a side of up to 4096 strings, config 5's 3163 - are fetched here, all
+    // loads in flight at once: phases 1 and 4 walked a thread's strings one memory round trip after the other, 31 us for an
+    // eighth of config 5u's 3,559 strings where 1,024 + 1,024 take 13)
+    u64 first_from[2][plan_cached_k] = {}, first_to[2][plan_cached_k] = {}, first_start[2][plan_cached_k] = {};
+    u32 first_length[2][plan_cached_k] = {};
 #pragma unroll
     for (int s = 0; s < 2; ++s)
-        if (s < sides && tid < side_of[s]->count) {
-            first_from[s] = tape_offset(side_of[s]->offsets, side_of[s]->wide, tid),
-            first_to[s] = tape_offset(side_of[s]->offsets, side_of[s]->wide, (u64)tid + 1);
-            if (side_of[s]->lengths) first_length[s] = side_of[s]->lengths[tid], first_start[s] = side_of[s]->starts[tid];
+#pragma unroll
+        for (u32 slot = 0; slot < plan_cached_k; ++slot) {
+            u32 const i = tid + slot * plan_threads_k;
+            if (s < sides && i < side_of[s]->count) {
+                first_from[s][slot] = tape_offset(side_of[s]->offsets, side_of[s]->wide, i),
+                first_to[s][slot] = tape_offset(side_of[s]->offsets, side_of[s]->wide, (u64)i + 1);
+                if (side_of[s]->lengths) first_length[s][slot] = side_of[s]->lengths[i], first_start[s][slot] = side_of[s]->starts[i];
+            }
         }
     for (int s = 0; s < sides; ++s)
 #pragma unroll
@@ -97,29 +105,46 @@ __global__ __launch_bounds__(plan_threads_k) void plan_kernel(szs_plan_side_t qu
     if (tid == 0) shared_cells = 0, shared_held = 0;
     __syncthreads();
     SZS_PLAN_STAMP(1);
-    auto span_of = [&](int s, u32 i, u64 &from, u64 &to) {
-        if (i == tid) from = first_from[s], to = first_to[s];
-        else from = tape_offset(side_of[s]->offsets, side_of[s]->wide, i), to = tape_offset(side_of[s]->offsets, side_of[s]->wide, (u64)i + 1);
+    // a string of this thread: (from, to) of its span in the tape, its length in symbols and where its symbols live - from the
+    // registers above for the first `plan_cached_k`, from memory beyond.  Codepoint engines: a string's length is its RUNE count
+    // and its symbols live in the UTF-32 scratch tape (kernels.h).
+    auto beyond = [&](int s, u32 i, u64 &from, u64 &to, u64 &length, u64 &address) {
+        from = tape_offset(side_of[s]->offsets, side_of[s]->wide, i), to = tape_offset(side_of[s]->offsets, side_of[s]->wide, (u64)i + 1);
+        length = !side_of[s]->lengths ? to - from : (u64)side_of[s]->lengths[i];
+        address = !side_of[s]->lengths ? side_of[s]->base + from : side_of[s]->base + 4 * side_of[s]->starts[i];
     };
-    // codepoint engines: a string's length is its RUNE count and its symbols live in the UTF-32 scratch tape (kernels.h)
-    auto length_of = [&](int s, u32 i, u64 from, u64 to) -> u64 {
-        return !side_of[s]->lengths ? to - from : i == tid ? (u64)first_length[s] : (u64)side_of[s]->lengths[i];
+    auto cached = [&](int s, u32 slot, u64 &from, u64 &to, u64 &length, u64 &address) {
+        from = first_from[s][slot], to = first_to[s][slot];
+        length = !side_of[s]->lengths ? to - from : (u64)first_length[s][slot];
+        address = !side_of[s]->lengths ? side_of[s]->base + from : side_of[s]->base + 4 * first_start[s][slot];
     };
-    auto address_of = [&](int s, u32 i, u64 from) -> u64 {
-        return !side_of[s]->lengths ? side_of[s]->base + from : side_of[s]->base + 4 * (i == tid ? first_start[s] : side_of[s]->starts[i]);
+    // every string of this thread, the cached ones first: `visit(s, i, from, to, length, address)`
+    auto each_string = [&](int s, auto &&visit) {
+#pragma unroll
+        for (u32 slot = 0; slot < plan_cached_k; ++slot) {
+            u32 const i = tid + slot * plan_threads_k;
+            if (i >= side_of[s]->count) break;
+            u64 from, to, length, address;
+            cached(s, slot, from, to, length, address);
+            visit(i, from, to, length, address);
+        }
+        for (u32 i = tid + plan_cached_k * plan_threads_k; i < side_of[s]->count; i += plan_threads_k) {
+            u64 from, to, length, address;
+            beyond(s, i, from, to, length, address);
+            visit(i, from, to, length, address);
+        }
     };
 
     // ---- phase 1: the histogram of the lengths; malformed or over-long strings only raise a flag (the host takes over)
     u32 status = 0;
-    for (int s = 0; s < sides; ++s)
-        for (u32 i = tid; i < side_of[s]->count; i += plan_threads_k) {
-            u64 from, to;
-            span_of(s, i, from, to);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) // (unrolled: the cached strings are registers only under constant indices)
+        if (s < sides) each_string(s, [&](u32, u64 from, u64 to, u64 length, u64) {
             if (to < from) status |= SZS_PLAN_STATUS_DESCENDING;
             else if (to - from > 0xFFFFFFFFull) status |= SZS_PLAN_STATUS_OVERFLOW;
-            else if (length_of(s, i, from, to) >= plan_bins_k) status |= SZS_PLAN_STATUS_UNSORTED;
-            else atomicAdd(&histogram[s][(u32)length_of(s, i, from, to)], 1u); // per-lane addresses: a plain ds_add
-        }
+            else if (length >= plan_bins_k) status |= SZS_PLAN_STATUS_UNSORTED;
+            else atomicAdd(&histogram[s][(u32)length], 1u); // per-lane addresses: a plain ds_add
+        });
 #pragma unroll
     for (int offset = 32; offset >= 1; offset >>= 1) status |= (u32)__shfl_xor((int)status, offset, 64);
     if (lane == 0) wave_status[wave] = status;
@@ -222,12 +247,15 @@ __global__ __launch_bounds__(plan_threads_k) void plan_kernel(szs_plan_side_t qu
 
     // ---- symmetric calls: cells of the lower triangle = sum_i len_i * sum_{j <= i} len_j, in the caller's order
     if (symmetric && !shared_status) {
+        auto symbols_of_query = [&](u32 i) -> u64 { // (consecutive strings per thread here: straight from memory)
+            return queries.lengths ? (u64)queries.lengths[i] : tape_offset(queries.offsets, queries.wide, (u64)i + 1) - tape_offset(queries.offsets, queries.wide, i);
+        };
         u32 const chunk = (queries.count + plan_threads_k - 1) / plan_threads_k;
         u32 const first = tid * chunk < queries.count ? tid * chunk : queries.count;
         u32 const last = first + chunk < queries.count ? first + chunk : queries.count;
         u64 mine = 0;
         for (u32 i = first; i < last; ++i)
-            mine += length_of(0, i, tape_offset(queries.offsets, queries.wide, i), tape_offset(queries.offsets, queries.wide, (u64)i + 1));
+            mine += symbols_of_query(i);
         chunk_sums[tid] = mine; // prefix of the chunk sums: 64-bit; a serial pass by one thread is 1024 additions
         __syncthreads();
         if (tid == 0) {
@@ -240,7 +268,7 @@ __global__ __launch_bounds__(plan_threads_k) void plan_kernel(szs_plan_side_t qu
         __syncthreads();
         u64 running = chunk_sums[tid], cells = 0;
         for (u32 i = first; i < last; ++i) {
-            u64 const length = length_of(0, i, tape_offset(queries.offsets, queries.wide, i), tape_offset(queries.offsets, queries.wide, (u64)i + 1));
+            u64 const length = symbols_of_query(i);
             running += length, cells += length * running;
         }
 #pragma unroll
@@ -287,17 +315,16 @@ __global__ __launch_bounds__(plan_threads_k) void plan_kernel(szs_plan_side_t qu
                 }
     }
     else
-        for (int s = 0; s < sides; ++s)
-            for (u32 i = tid; i < side_of[s]->count; i += plan_threads_k) {
-                u64 from, to;
-                span_of(s, i, from, to);
-                u32 const length = (u32)length_of(s, i, from, to);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            if (s < sides) each_string(s, [&](u32 i, u64, u64, u64 symbols, u64 address) {
+                u32 const length = (u32)symbols;
                 u32 const position = atomicAdd(&histogram[s][length], 1u); // equal lengths: any order scores the same matrix
                 szs_string_ref_t ref;
-                ref.address = address_of(s, i, from), ref.length = blank ? 0u : length, ref.index = i;
+                ref.address = address, ref.length = blank ? 0u : length, ref.index = i;
                 side_of[s]->ascending[position] = ref;
                 side_of[s]->descending[side_of[s]->count - 1 - position] = ref;
-            }
+            });
 
     SZS_PLAN_STAMP(6);
     if (tid == 0) { // one struct, written once: the host reads it after the stream has drained

@@ -33,7 +33,8 @@ namespace szs_hip {
  *  chunk before) skip all of it: every byte is a lead.  A lead's rune index is a popcount of the lead mask below it, so the
  *  runes of a chunk are written in one coalesced burst.  The next chunk's bytes are in flight while this one is decoded.
  */
-constexpr int transcode_waves_k = 4; // wavefronts (strings in flight) per workgroup
+constexpr int transcode_waves_k = 16; // wavefronts (strings in flight) per workgroup
+constexpr u32 transcode_depth_k = 8; // 64-byte chunks of a string in flight
 constexpr u32 alphabet_slots_k = SZS_ALPHABET_SLOTS, alphabet_empty_k = ~0u; // the renumbering pass's table (below): [keys][ids][control]
 
 /** Where string i lies and where its runes go - from refs and host-made starts (the host-planned path) ... */
@@ -115,11 +116,22 @@ __global__ __launch_bounds__(64 * transcode_waves_k) void utf8_transcode_kernel(
         u32 *const out = runes + start;
         u32 produced = 0, hanging = 0; // `hanging`: bytes at the head of the chunk that belong to the previous chunk's last rune
         bool multibyte = false;
-        u32 ahead = lane < length ? bytes[lane] : 0u; // the chunk after the current one, loaded one step early
-        for (u32 base = 0; base < length; base += 64) {
-            u32 const byte = ahead;
+        // A string is a chain of 64-byte chunks, each waiting for its bytes: with the next chunk alone in flight a 2048-byte line
+        // was 32 memory round trips one after the other (59 us for an eighth of config 5u, whatever the other 3,500 strings did).
+        // Eight chunks are in flight now: a chunk's bytes are asked for eight steps before they are decoded.
+        u32 window[transcode_depth_k];
+#pragma unroll
+        for (u32 j = 0; j < transcode_depth_k; ++j) window[j] = 64u * j + lane < length ? bytes[64u * j + lane] : 0u;
+        for (u32 round_base = 0; round_base < length; round_base += 64u * transcode_depth_k)
+#pragma unroll
+        for (u32 j = 0; j < transcode_depth_k; ++j) {
+            u32 const base = round_base + 64u * j;
+            if (base >= length) break; // (wavefront-uniform)
+            u32 const byte = window[j];
+            u32 const refill = base + 64u * transcode_depth_k + lane;
+            window[j] = refill < length ? bytes[refill] : 0u;
             u32 const after = base + 64 + lane;
-            ahead = after < length ? bytes[after] : 0u;
+            u32 const ahead = window[(j + 1) % transcode_depth_k]; // the chunk after this one (j = depth - 1: refilled at j = 0)
             bool const valid = base + lane < length;
             u64 const valid_mask = __ballot(valid);
             u32 const sequence = 1u + (byte >= 0xC0u) + (byte >= 0xE0u) + (byte >= 0xF0u);
@@ -187,7 +199,9 @@ __global__ __launch_bounds__(64 * transcode_waves_k) void utf8_transcode_kernel(
         }
         if (lane == 0) {
             rune_counts[i] = produced;
-            if (multibyte) atomicOr(any_multibyte, 1u);
+            // (the flag is ONE address: an atomic from every wavefront of a 6,000-string batch is 6,000 read-modify-writes in a row at
+            // the memory side, ~13 ns each - the kernel lasted 83 us however short its strings were.  Once it is set, nobody writes.)
+            if (multibyte && !__atomic_load_n(any_multibyte, __ATOMIC_RELAXED)) atomicOr(any_multibyte, 1u);
         }
     }
 }
@@ -203,7 +217,7 @@ __global__ __launch_bounds__(64 * transcode_waves_k) void utf8_transcode_kernel(
  *  place.  With A <= SZS_ALPHABET_MOST the kernels then look a symbol up in a direct table (`local[id]`, one LDS read, no loop);
  *  a richer batch keeps its runes (the second pass does nothing) and the kernels keep probing.
  */
-constexpr u32 alphabet_seen_lines_k = 4096;
+constexpr u32 alphabet_seen_lines_k = 4096, alphabet_batch_k = 8; // ... and the 64-rune chunks of a string a wavefront asks for at once
 
 __device__ __forceinline__ u32 alphabet_slot(u32 rune) { return (rune * 2654435761u) >> (32 - __builtin_ctz(alphabet_slots_k)); }
 
@@ -230,27 +244,39 @@ __global__ __launch_bounds__(alphabet_claim_threads_k) void alphabet_claim_kerne
     for (u32 i = blockIdx.x * (blockDim.x / 64u) + threadIdx.x / 64u; i < count; i += waves) {
         u32 const *const text = runes + rune_starts[i];
         u32 const length = rune_counts[i];
-        for (u32 j = lane; j < length; j += 64) {
-            u32 const rune = text[j]; // (never alphabet_empty_k: a decoded sequence has 21 bits)
-            u32 slot = alphabet_slot(rune);
-            u32 const line = slot & (alphabet_seen_lines_k - 1);
-            if (taken[line] == rune || atomicCAS(&taken[line], alphabet_empty_k, rune) == rune) continue;
-            // Once the alphabet has outgrown `most` (or the table) nothing will be renamed: stop claiming.  A batch of
-            // high-entropy bytes decoded unchecked would otherwise fill all 65536 slots and every later rune would probe the
-            // whole table (seconds on a large batch, for a result that is thrown away).  The counter only grows, and the
-            // renaming pass reads the same words and skips.
-            if (__atomic_load_n(&control[0], __ATOMIC_RELAXED) > most || __atomic_load_n(&control[1], __ATOMIC_RELAXED)) return;
-            for (u32 probes = 0;; ++probes) {
-                u32 key = keys[slot]; // a slot is written once: a stale line can only read as empty, and then the swap decides
-                if (key == alphabet_empty_k) key = atomicCAS(&keys[slot], alphabet_empty_k, rune);
-                if (key == rune) break;
-                if (key == alphabet_empty_k) { // this thread claimed the slot: the rune's id is the next one
-                    u32 const id = atomicAdd(&control[0], 1u) + 1;
-                    ids[slot] = id;
-                    break;
+        // (eight 64-rune chunks asked for at once: one wavefront walks a 1,500-rune line in three memory round trips, not 24)
+        for (u32 first = 0; first < length; first += 64u * alphabet_batch_k) {
+            u32 batch[alphabet_batch_k];
+#pragma unroll
+            for (u32 b = 0; b < alphabet_batch_k; ++b) batch[b] = first + 64u * b + lane < length ? text[first + 64u * b + lane] : alphabet_empty_k;
+            // (asked once per batch, with the batch's runes, not once per new rune behind its own round trip)
+            bool const given_up = __atomic_load_n(&control[0], __ATOMIC_RELAXED) > most || __atomic_load_n(&control[1], __ATOMIC_RELAXED);
+#pragma unroll
+            for (u32 b = 0; b < alphabet_batch_k; ++b) {
+                u32 const rune = batch[b]; // (a decoded sequence has 21 bits: alphabet_empty_k marks the lanes past the end)
+                if (rune == alphabet_empty_k) continue;
+                u32 slot = alphabet_slot(rune);
+                u32 const line = slot & (alphabet_seen_lines_k - 1);
+                if (taken[line] == rune || atomicCAS(&taken[line], alphabet_empty_k, rune) == rune) continue;
+                // Once the alphabet has outgrown `most` (or the table) nothing will be renamed: stop claiming.  A batch of
+                // high-entropy bytes decoded unchecked would otherwise fill all 65536 slots and every later rune would probe the
+                // whole table (seconds on a large batch, for a result that is thrown away).  The counter only grows, and the
+                // renaming pass reads the same words and skips.
+                if (given_up) return;
+                for (u32 probes = 0;; ++probes) {
+                    u32 key = keys[slot]; // a slot is written once: a stale line can only read as empty, and then the swap decides
+                    if (key == alphabet_empty_k) key = atomicCAS(&keys[slot], alphabet_empty_k, rune);
+                    if (key == rune) break;
+                    if (key == alphabet_empty_k) { // this thread claimed the slot: the rune's id is the next one
+                        u32 const id = atomicAdd(&control[0], 1u) + 1;
+                        ids[slot] = id;
+                        break;
+                    }
+                    if (probes >= alphabet_slots_k) { control[1] = 1; break; } // table full: the batch keeps its runes
+                    // (a crowded table: somebody has given up by now, or soon will - asked every sixteen probes)
+                    if ((probes & 15u) == 15u && (__atomic_load_n(&control[0], __ATOMIC_RELAXED) > most || __atomic_load_n(&control[1], __ATOMIC_RELAXED))) return;
+                    slot = (slot + 1) & (alphabet_slots_k - 1);
                 }
-                if (probes >= alphabet_slots_k) { control[1] = 1; break; } // table full: the batch keeps its runes
-                slot = (slot + 1) & (alphabet_slots_k - 1);
             }
         }
     }
@@ -266,11 +292,18 @@ __global__ __launch_bounds__(256) void alphabet_rename_kernel(u32 count, u64 con
     for (u32 i = blockIdx.x * (blockDim.x / 64u) + threadIdx.x / 64u; i < count; i += waves) {
         u32 *const text = runes + rune_starts[i];
         u32 const length = rune_counts[i];
-        for (u32 j = lane; j < length; j += 64) {
-            u32 const rune = text[j];
-            u32 slot = alphabet_slot(rune);
-            while (keys[slot] != rune) slot = (slot + 1) & (alphabet_slots_k - 1); // every rune of the batch was claimed
-            text[j] = ids[slot];
+        for (u32 first = 0; first < length; first += 64u * alphabet_batch_k) {
+            u32 batch[alphabet_batch_k];
+#pragma unroll
+            for (u32 b = 0; b < alphabet_batch_k; ++b) batch[b] = first + 64u * b + lane < length ? text[first + 64u * b + lane] : alphabet_empty_k;
+#pragma unroll
+            for (u32 b = 0; b < alphabet_batch_k; ++b) {
+                u32 const rune = batch[b];
+                if (rune == alphabet_empty_k) continue;
+                u32 slot = alphabet_slot(rune);
+                while (keys[slot] != rune) slot = (slot + 1) & (alphabet_slots_k - 1); // every rune of the batch was claimed
+                text[first + 64u * b + lane] = ids[slot];
+            }
         }
     }
 }
