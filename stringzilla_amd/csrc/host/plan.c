@@ -373,7 +373,12 @@ void szs_plan_queue(szs_plan_t const *plan, uint32_t queries_count, uint32_t can
     }
 #undef SZS_QUEUE_ITEMS_OF
     queue->tiles_count = tiles, queue->items_total = items;
-    queue->chain_most = szs_tuning_get(szs_knob_queue_priority_k) == 0 ? 0u : chain_most < 0xFFFFFFFFull ? (uint32_t)chain_most : 0xFFFFFFFFu;
+    /* Longest chain first on the SIMD (hip/myers_queue.hip): -11 % on an eighth of config 5, -9 % on a half, -0.7 % on the whole; on
+     * codepoints -4 % on an eighth, 0 on a half and +2 % on the whole batch (5.40 -> 5.51 ms, profiles/r04/queue_priority_5u.txt):
+     * automatic for byte calls and for codepoint calls of up to ~3 ms; the `queue_priority` knob pins it. */
+    int const priority_knob = szs_tuning_get(szs_knob_queue_priority_k);
+    int const prioritised = priority_knob >= 0 ? priority_knob != 0 : !(tables.runes && call_ns > 3.0e6);
+    queue->chain_most = !prioritised ? 0u : chain_most < 0xFFFFFFFFull ? (uint32_t)chain_most : 0xFFFFFFFFu;
 }
 
 /* ---- tier and orientation choice ------------------------------------------------------------------------------------ */
