@@ -467,6 +467,16 @@ static int has_group_of_variant_zero(szs_decision_t const *d) {
     return 0;
 }
 
+/** Calls whose scoring is ONE launch are speculated (launched behind the planner on the previous call's shape, §3): one width
+ *  group, or - round 4 - every width in the one persistent launch of hip/myers_queue.hip.  The queue of the previous call
+ *  addresses the sorted refs by position, so it is valid for any batch of the same counts per width; a query longer than its
+ *  slice's bound takes the kernel's pass of its own, and the planner blanks every ref when the counts or the longest strings
+ *  differ.  (Several launches released by one event reach the device in no particular order: those calls are planned and
+ *  waited for.) */
+static int is_one_launch(szs_decision_t const *d) {
+    return d->plan.groups_count == 1 || (d->use_queue && d->queue.items_total && !has_group_of_variant_zero(d));
+}
+
 static sz_status_t upload_model(szs_engine_s *engine, szs_decision_t const *d, int device, hipStream_t stream,
                                 char const **error_message) {
     int const per_call = d->team && d->team_objective == 2; /* the byte classes are the batch's: a new model every call */
@@ -1137,7 +1147,7 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
      * Config 5: 9.68 ms speculated, 9.60 planned-and-waited-for; an eighth of it 1.95 / 1.85; codepoints 8.4 / 7.1.) */
     int const speculate = remembered->valid && !remembered->runes && remembered->tier == SZS_TIER_LANES && remembered->q_count == q_count &&
                           remembered->c_count == c_count && remembered->symmetric == symmetric && knobs_automatic && !uniform_bytes &&
-                          remembered->plan.groups_count == 1;
+                          is_one_launch(remembered);
     szs_plan_summary_t seen;
     int have_summary = 0;
     if (speculate) {
@@ -1369,7 +1379,7 @@ static sz_status_t cross_device_planned_runes(szs_call_t *call) {
                                 szs_tuning_get(szs_knob_team_k) < 0 && szs_tuning_get(szs_knob_rune_ids_k) < 0;
     if (remembered->valid && remembered->runes && remembered->tier == SZS_TIER_LANES && remembered->use_myers && remembered->q_count == q_count &&
         remembered->c_count == c_count && remembered->symmetric == symmetric && knobs_automatic && (!remembered->alphabet || renumber) &&
-        remembered->plan.groups_count == 1 /* one launch: see cross_device_planned */) {
+        is_one_launch(remembered) /* see cross_device_planned */) {
         szs_decision_t const *d = remembered;
         SZS_RUNE_SIDES();
         szs_plan_expectation_t expected;

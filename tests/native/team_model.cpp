@@ -104,10 +104,7 @@ void score_item(text_t q_low, text_t q_high, bool has_high, std::vector<text_t> 
                         int64_t const column = (int64_t)t - lane + 1;
                         bool const active = column >= 1 && column <= (int64_t)text.length;
                         if (!predicated && !active) __builtin_trap(); // the unpredicated loop must only see active lanes
-                        if (!active) {
-                            state.out = in[lane], state.out_class = in_class[lane]; // whatever: nobody active consumes it
-                            continue;
-                        }
+                        if (!active) continue; // as in the kernel's predicated step: a lane without a column keeps what it last produced
                         uint32_t const *costs = &profile[((size_t)lane * 33 + in_class[lane]) * R];
                         state.out = team_advance<costs_t, R>(k, state.rows, costs, in[lane], state.diagonal, state.best, registers);
                         state.out_class = in_class[lane];
