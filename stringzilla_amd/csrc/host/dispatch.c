@@ -467,15 +467,13 @@ static int has_group_of_variant_zero(szs_decision_t const *d) {
     return 0;
 }
 
-/** Calls whose scoring is ONE launch are speculated (launched behind the planner on the previous call's shape, §3): one width
- *  group, or - round 4 - every width in the one persistent launch of hip/myers_queue.hip.  The queue of the previous call
- *  addresses the sorted refs by position, so it is valid for any batch of the same counts per width; a query longer than its
- *  slice's bound takes the kernel's pass of its own, and the planner blanks every ref when the counts or the longest strings
- *  differ.  (Several launches released by one event reach the device in no particular order: those calls are planned and
- *  waited for.) */
-static int is_one_launch(szs_decision_t const *d) {
-    return d->plan.groups_count == 1 || (d->use_queue && d->queue.items_total && !has_group_of_variant_zero(d));
-}
+/** Calls of ONE width group are speculated (launched behind the planner on the previous call's shape, §3).  Calls of the one
+ *  persistent launch of hip/myers_queue.hip are NOT, although its queue addresses the sorted refs by position and would be valid
+ *  for any batch of the same counts per width: measured (round 4), the host's round trip it saves (16 us) came back as a longer
+ *  launch (an eighth of config 5: 1.610 ms planned, 1.612 speculated; codepoints 1.061 / 1.049) - the planner's own 35 - 45 us for
+ *  3,500 strings are what such a call waits for, not the host.  (Several launches released by one event reach the device in no
+ *  particular order: those calls are planned and waited for as well.) */
+static int is_one_launch(szs_decision_t const *d) { return d->plan.groups_count == 1; }
 
 static sz_status_t upload_model(szs_engine_s *engine, szs_decision_t const *d, int device, hipStream_t stream,
                                 char const **error_message) {
