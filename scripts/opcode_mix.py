@@ -65,7 +65,7 @@ def opcode_of(line):
     return token
 
 
-def main_loop(body):
+def main_loop(body, prefer_dpp=False):
     """Blocks -> innermost loop header; returns (header label, Counter of VALU opcodes) of the loop with the most VALU."""
     loops, header_of_block, block = defaultdict(Counter), None, None
     for line in body:
@@ -83,8 +83,13 @@ def main_loop(body):
             loops[header_of_block][opcode] += 1
     if not loops:
         return None, Counter()
-    header = max(loops, key=lambda name: sum(loops[name].values()))
-    return header, loops[header]
+    # The team tier's main loop exists once per chunk count of a pass since round 4 (weighted_teams.hip: `walk`), so the loop
+    # with the most instructions may be the PROFILE BUILD of a rich alphabet instead: among loops that hand values from lane to
+    # lane (`row_shr` DPP moves - only the step loops do) the largest one is the whole-pass main loop.
+    stepping = {name: mix for name, mix in loops.items() if any(opcode.endswith("_dpp") for opcode in mix)} if prefer_dpp else {}
+    pool = stepping or loops
+    header = max(pool, key=lambda name: sum(pool[name].values()))
+    return header, pool[header]
 
 
 def main():
@@ -96,7 +101,7 @@ def main():
         for mangled, body in kernels_of(source):
             pretty = subprocess.run(["c++filt", mangled], capture_output=True, text=True).stdout.strip()
             short = pretty.split("(")[0].replace("void ", "").replace("szs_hip::", "").strip()
-            header, mix = main_loop(body)
+            header, mix = main_loop(body, prefer_dpp="weighted_team_kernel" in pretty)
             total = sum(mix.values())
             if not total:
                 continue
