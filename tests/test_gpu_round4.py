@@ -422,3 +422,31 @@ def test_a_stream_of_mixed_length_batches_on_one_engine(gpu, oracle):
     others = [c[: max(1, len(c) - rng.randint(0, 5))] for c in candidates]
     assert scored(grown, others).launches == 1
     assert scored(queries[::2], candidates[5:]).launches == 1
+
+
+def test_input_formats_and_result_placement_through_the_queue(gpu, oracle):
+    """The one-launch kernel behind every way a caller hands strings over and takes results back: 64-bit tapes, plain host
+    results (staged copy), a padded device matrix (stride > columns, padding never written: cuda.cuh:2201-2203), a Python list
+    (packed into a tape), bytes codepoint engine on the same strings."""
+    import torch
+
+    rng = random.Random(64)
+    queries = _rand(rng, 30, 0, 120, b"ACGT") + _rand(rng, 5, 300, 2048, b"ACGT")
+    candidates = _rand(rng, 333, 0, 140, b"ACGT") + _rand(rng, 7, 500, 900, b"ACGT")
+    expected = oracle.levenshtein(queries, candidates)
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+    with knob("tier", "lanes"), knob("swap", 0):
+        wide_q, wide_c = szs.Strs(queries, wide_offsets=True), szs.Strs(candidates, wide_offsets=True)
+        assert np.array_equal(engine(wide_q, wide_c, device=gpu), expected)                       # *_u64tape
+        assert engine.last_call_profile().queue_items > 0 and engine.last_call_profile().launches == 1
+        out = np.full((len(queries), len(candidates)), 0xDEADBEEF, dtype=np.uint64)              # plain host results
+        assert engine(queries, candidates, device=gpu, out=out) is out and np.array_equal(out, expected)
+        assert engine.last_call_profile().queue_items > 0
+        padded = torch.full((len(queries), len(candidates) + 20), -7, dtype=torch.int64, device="cuda")
+        view = padded[:, :len(candidates)]
+        engine(queries, candidates, device=gpu, out=view)
+        assert np.array_equal(view.cpu().numpy().view(np.uint64), expected) and (padded[:, len(candidates):] == -7).all()
+        assert engine.last_call_profile().queue_items > 0
+        # ASCII through the codepoint engine: scored by the byte kernels (serial.hpp:2809-2813), the same one launch
+        utf8 = szs.LevenshteinDistancesUTF8(capabilities=gpu)
+        assert np.array_equal(utf8(queries, candidates, device=gpu), expected)
