@@ -396,3 +396,30 @@ def test_mt19937_64_workloads_are_reproducible_and_in_shape():
     fill.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
     offsets = np.zeros(2, dtype=np.uint32)
     assert fill(5489, 1, 7, 7 + (1 << 20) - 1, None, 1, offsets.ctypes.data, None) == 7 + 14514284786278117030 % (1 << 20) == int(offsets[1])
+
+
+def test_shard_triangle_cuts_bands_of_equal_weight():
+    """`szs_rocm_shard_triangle`: contiguous bands of the lower triangle, row i weighing (len_i + 1) x sum_{j <= i} (len_j + 1)
+     - every row in exactly one band, weights that add up to the triangle, balance within a row's weight,
+    empty bands when there are fewer rows than shards."""
+    from stringzilla_amd import sharded
+
+    rng = np.random.default_rng(8)
+    for rows, shards in [(1000, 8), (3163, 8), (64, 3), (5, 8), (1, 4), (0, 2), (17, 1)]:
+        lengths = np.minimum(rng.zipf(1.3, size=rows) * 8, 2048).astype(np.uint64)
+        band_first, weights = sharded.shard_triangle(lengths, shards)
+        assert band_first[0] == 0 and band_first[-1] == rows and len(band_first) == shards + 1
+        assert np.all(np.diff(band_first) >= 0)
+        plus_one = lengths.astype(np.float64) + 1
+        row_weights = plus_one * np.cumsum(plus_one)
+        for g in range(shards):
+            inside = row_weights[band_first[g]:band_first[g + 1]].sum()
+            assert abs(float(weights[g]) - inside) <= 1e-9 * max(inside, 1.0) + 1.0, (rows, shards, g)
+        assert abs(float(weights.sum()) - row_weights.sum()) <= 1e-9 * max(row_weights.sum(), 1.0) + shards
+        if rows >= 8 * shards:  # no band further from its share than the heaviest row
+            share = row_weights.sum() / shards
+            assert np.all(np.abs(weights.astype(np.float64) - share) <= row_weights.max() + 1.0), (rows, shards)
+        if rows < shards:
+            assert np.count_nonzero(np.diff(band_first)) <= rows
+    status = _abi.lib.szs_rocm_shard_triangle(None, 0, 0, None, None)
+    assert status != 0
