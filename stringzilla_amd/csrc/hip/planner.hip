@@ -29,6 +29,7 @@ namespace szs_hip {
 
 constexpr int plan_threads_k = 1024;
 constexpr int plan_waves_k = plan_threads_k / 64;
+constexpr u32 plan_staged_k = 4096; // refs of ONE side sorted through LDS before they are written out (64 KB)
 constexpr u32 plan_cached_k = 4; // strings per thread and side kept in registers from the first fetch on
 constexpr u32 plan_bins_k = SZS_PLAN_DEVICE_LONGEST + 1;         // lengths below this are counting-sorted in LDS
 constexpr u32 plan_chunk_k = plan_bins_k / plan_threads_k;       // histogram bins per thread
@@ -62,6 +63,7 @@ __global__ __launch_bounds__(plan_threads_k) void plan_kernel(szs_plan_side_t qu
                                                               int symmetric, u32 myers_words,
                                                               szs_plan_expectation_t expected,
                                                               szs_plan_summary_t *__restrict__ summary) {
+    extern __shared__ __attribute__((aligned(16))) szs_string_ref_t staged[]; // `plan_staged_k` refs: phase 4
     __shared__ u32 histogram[2][plan_bins_k];
     __shared__ u32 wave_counts[2][plan_waves_k], wave_symbols[2][plan_waves_k], wave_bands_systolic[2][plan_waves_k],
         wave_bands_chain[2][plan_waves_k], wave_longest[2][plan_waves_k], wave_status[plan_waves_k];
@@ -317,14 +319,30 @@ __global__ __launch_bounds__(plan_threads_k) void plan_kernel(szs_plan_side_t qu
     else
 #pragma unroll
         for (int s = 0; s < 2; ++s)
-            if (s < sides) each_string(s, [&](u32 i, u64, u64, u64 symbols, u64 address) {
-                u32 const length = (u32)symbols;
-                u32 const position = atomicAdd(&histogram[s][length], 1u); // equal lengths: any order scores the same matrix
-                szs_string_ref_t ref;
-                ref.address = address, ref.length = blank ? 0u : length, ref.index = i;
-                side_of[s]->ascending[position] = ref;
-                side_of[s]->descending[side_of[s]->count - 1 - position] = ref;
-            });
+            if (s < sides) {
+                // (round 4) A ref lands at the position its length sorts it to - sixteen bytes at a random place, twice: 64
+                // write transactions per store instruction, all through ONE compute unit (17.9 of the planner's 44 us on config
+                // 5's 6,326 strings, 4 of 13 on config 2's 2,048).  A side of up to `plan_staged_k` strings is sorted into LDS
+                // instead and leaves it in order: position p and count - 1 - p, whole lines per wavefront.
+                u32 const count = side_of[s]->count;
+                bool const through_lds = count <= plan_staged_k;
+                each_string(s, [&](u32 i, u64, u64, u64 symbols, u64 address) {
+                    u32 const length = (u32)symbols;
+                    u32 const position = atomicAdd(&histogram[s][length], 1u); // equal lengths: any order scores the same matrix
+                    szs_string_ref_t ref;
+                    ref.address = address, ref.length = blank ? 0u : length, ref.index = i;
+                    if (through_lds) staged[position] = ref;
+                    else side_of[s]->ascending[position] = ref, side_of[s]->descending[count - 1 - position] = ref;
+                });
+                if (through_lds) {
+                    __syncthreads();
+                    for (u32 position = tid; position < count; position += plan_threads_k) {
+                        szs_string_ref_t const ref = staged[position];
+                        side_of[s]->ascending[position] = ref, side_of[s]->descending[count - 1 - position] = ref;
+                    }
+                    __syncthreads(); // the other side sorts into the same LDS
+                }
+            }
 
     SZS_PLAN_STAMP(6);
     if (tid == 0) { // one struct, written once: the host reads it after the stream has drained
@@ -355,7 +373,16 @@ extern "C" int szs_hip_plan(szs_plan_side_t const *queries, szs_plan_side_t cons
                             szs_plan_expectation_t const *expected, szs_plan_summary_t *summary, void *stream) {
     using namespace szs_hip;
     szs_plan_expectation_t none = {};
-    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(plan_threads_k), 0, static_cast<hipStream_t>(stream), *queries,
+    // 64 KB of dynamic LDS beside the 58 KB of histograms: asked for once per device
+    static int allowed_on[device_slots_k];
+    int *const slot = &allowed_on[device_slot()];
+    if (!cached(slot)) {
+        if (hipFuncSetAttribute(reinterpret_cast<void const *>(plan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(plan_staged_k * sizeof(szs_string_ref_t))) != hipSuccess)
+            return (int)hipGetLastError();
+        remember(slot, 1);
+    }
+    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(plan_threads_k), plan_staged_k * sizeof(szs_string_ref_t), static_cast<hipStream_t>(stream), *queries,
                        candidates ? *candidates : *queries, candidates ? 0 : 1, (u32)myers_words, expected ? *expected : none,
                        summary);
     return (int)hipGetLastError();
