@@ -203,8 +203,9 @@ SZ_API_RUNTIME sz_status_t szs_rocm_node_scores_u64tape(szs_rocm_node_engine_t e
  *  of a codepoint batch on the device), "merge" (n: candidate blocks per workgroup of the short bit-parallel kernels),
  *  "team" (0: never | lanes * 10000 + registers * 100 + waves: that shape of the team tier of the 16-bit weighted scorers),
  *  "queue" (0: never | 1: every unit-cost byte call - the one persistent launch of hip/myers_queue.hip; automatic: calls of two or
- *  more bit-vector widths), "queue_words" (4 | 8 | 12 | 16: the most words of a pattern one lane holds there), "queue_rounds" (n:
- *  candidates per work item in rounds of eight wavefronts),
+ *  more bit-vector widths whose lengths are skewed), "queue_words" (4 | 8 | 12 | 16: the most words of a pattern one lane holds
+ *  there), "queue_rounds" (n: candidates per work item in rounds of eight wavefronts), "queue_priority" (0 | 1: wave priorities by
+ *  chain length inside that launch; automatic: byte calls and short codepoint calls),
  *  "queues" (see below), "roctx" (1: the host phases of every call - plan, decide, enqueue, wait - as roctx ranges for a
  *  `rocprofv3 --marker-trace` timeline; the marker library is looked up at run time, never linked),
  *  "cpu_requests" (strict | gpu: serve capability
