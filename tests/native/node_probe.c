@@ -40,9 +40,12 @@ static tape_t make_tape(size_t count, size_t lo, size_t hi, char const *alphabet
 }
 
 int main(int argc, char **argv) {
-    if (argc < 7) return fprintf(stderr, "usage: node_probe lev|nw|sw Q C LEN_LO LEN_HI GPU [GPU ...]\n"), 2;
-    char const *family = argv[1];
-    size_t const q = strtoul(argv[2], NULL, 10), c = strtoul(argv[3], NULL, 10), lo = strtoul(argv[4], NULL, 10), hi = strtoul(argv[5], NULL, 10);
+    if (argc < 7) return fprintf(stderr, "usage: node_probe lev|nw|sw[-sym] Q C LEN_LO LEN_HI GPU [GPU ...]   (-sym: the queries against themselves)\n"), 2;
+    char family[8] = {0};
+    strncpy(family, argv[1], 7);
+    int const symmetric = strstr(argv[1], "-sym") != NULL; /* `candidates == NULL`: the lower triangle in bands, mirrored (node.c) */
+    if (strchr(family, '-')) *strchr(family, '-') = 0;
+    size_t const q = strtoul(argv[2], NULL, 10), c = symmetric ? q : strtoul(argv[3], NULL, 10), lo = strtoul(argv[4], NULL, 10), hi = strtoul(argv[5], NULL, 10);
     sz_size_t gpus[SZS_ROCM_NODE_MOST_GPUS];
     size_t gpu_count = 0;
     for (int i = 6; i < argc && gpu_count < SZS_ROCM_NODE_MOST_GPUS; ++i) gpus[gpu_count++] = strtoul(argv[i], NULL, 10);
@@ -68,15 +71,16 @@ int main(int argc, char **argv) {
     sz_sequence_u32tape_t const q_tape = {queries.data, queries.offsets, q}, c_tape = {candidates.data, candidates.offsets, c};
     szs_rocm_node_stats_t stats;
     for (int round = 0; round < 2; ++round) { /* the second call reuses replicas, blocks and speculates its launches */
-        status = szs_rocm_node_scores_u32tape(engine, &q_tape, &c_tape, results, stride, &stats, &error);
+        status = szs_rocm_node_scores_u32tape(engine, &q_tape, symmetric ? NULL : &c_tape, results, stride, &stats, &error);
         if (status != sz_success_k) return fprintf(stderr, "scores: %d %s\n", status, error ? error : ""), 1;
     }
 
     size_t mismatches = 0;
     for (size_t i = 0; i < q; ++i) {
         for (size_t j = 0; j < c; ++j) {
-            char const *a = queries.data + queries.offsets[i], *b = candidates.data + candidates.offsets[j];
-            size_t const la = queries.offsets[i + 1] - queries.offsets[i], lb = candidates.offsets[j + 1] - candidates.offsets[j];
+            tape_t const *other = symmetric ? &queries : &candidates;
+            char const *a = queries.data + queries.offsets[i], *b = other->data + other->offsets[j];
+            size_t const la = queries.offsets[i + 1] - queries.offsets[i], lb = other->offsets[j + 1] - other->offsets[j];
             int64_t const expected = !strcmp(family, "lev")  ? (int64_t)szo_levenshtein(a, la, b, lb, 0, 1, 1, 1)
                                      : !strcmp(family, "nw") ? szo_needleman_wunsch(a, la, b, lb, byte_to_class, class_costs, -4, -1)
                                                              : szo_smith_waterman(a, la, b, lb, byte_to_class, class_costs, -4, -1);
