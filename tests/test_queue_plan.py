@@ -172,3 +172,33 @@ def test_codepoint_batches_get_tables_that_fit(alphabet):
         assert any(tile[9] & 1 for tile in tiles), "long codepoint queries over a rich alphabet take the sparse tables"
     if alphabet <= 255:
         assert not any(tile[9] & 1 for tile in tiles), "a small alphabet's tables are rows, like the byte tables"
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_batches_are_covered_exactly_once(seed):
+    """Two dozen random batches - counts from 1 to a few thousand, lengths uniform, Zipf, two-peaked or constant, bytes and
+    codepoint alphabets small and rich: whatever the plan, every cell once, every table within its share of the arena."""
+    rng = np.random.default_rng(1000 + seed)
+
+    def side(count):
+        kind = rng.integers(0, 5)
+        if kind == 0:
+            return rng.integers(0, int(rng.integers(2, 2049)) + 1, count)
+        if kind == 1:
+            return zipf_lengths(rng, count, low=int(rng.integers(1, 64)), high=int(rng.integers(128, 2049)), exponent=float(rng.uniform(0.8, 1.6)))
+        if kind == 2:
+            return np.where(rng.random(count) < 0.9, rng.integers(0, 60, count), rng.integers(900, 2049, count))
+        if kind == 3:
+            return np.full(count, int(rng.integers(0, 2049)))
+        return np.concatenate([rng.integers(0, 2049, max(count - 4, 1)), [0, 1, 2047, 2048]])[:max(count, 1)]
+
+    queries, candidates = side(int(rng.integers(1, 900))), side(int(rng.integers(1, 2500)))
+    alphabet = int(rng.choice([0, 0, 40, 300, 1500]))
+    if alphabet:  # the tables of a rich alphabet hold fewer words: the host only queues what fits (dispatch.c), as here
+        queries = np.minimum(queries, 2048 if alphabet <= 300 else 1024)
+    tiles, items = plan(queries, candidates, alphabet=alphabet)
+    if not len(tiles):
+        assert alphabet, "a byte call always has a plan"
+        return
+    covered = walk(tiles, items, queries, candidates, alphabet=alphabet)
+    assert covered.min() == 1 and covered.max() == 1, (seed, alphabet, np.argwhere(covered != 1)[:5].tolist())
