@@ -289,7 +289,7 @@ SZ_API_RUNTIME void szs_smith_waterman_scores_free(szs_smith_waterman_scores_t e
  *  its C shim assigns them (c/stringzillas/fingerprints.cuh:31-176).
  *    dimensions        > 0; ideally a multiple of 64 x the number of window widths (one width per wavefront)
  *    alphabet_size     accepted, unused by the reference's f64 hasher (0 = 256)
- *    window_widths     NULL / 0 = {3, 4, 5, 7, 9, 11, 15, 31}; every width within [2, 1024], else sz_unexpected_dimensions_k
+ *    window_widths     NULL / 0 = {3, 4, 5, 7, 9, 11, 15, 31}; every width within [2, 65536], else sz_unexpected_dimensions_k
  *    min_hashes        `count` rows of `dimensions` u32, rows `min_hashes_stride` BYTES apart (>= 4 * dimensions, multiple of 4);
  *    min_counts        likewise.  A text shorter than a dimension's window yields hash 0xFFFFFFFF and count 0.
  *  Outputs may live in device, unified or plain host memory (the latter two are staged); text bytes must be device-accessible. */

@@ -60,6 +60,7 @@ __device__ __forceinline__ void fingerprint_export(fingerprint_state_t const &st
  *                          their fingerprint straight to the outputs (the common case: many short documents)
  *  @param widths, multipliers, modulos, reciprocals, complements   [dimensions] per-dimension parameters (host/fingerprint_engines.c)
  */
+template <bool staged_>
 __global__ __launch_bounds__(fingerprint_threads_k) void fingerprint_segments_kernel(
     szs_string_ref_t const *__restrict__ texts, u32 first_segment, u32 const *__restrict__ segment_text,
     u32 const *__restrict__ segment_prefix, u32 const *__restrict__ partial_prefix, u32 dimensions,
@@ -68,7 +69,10 @@ __global__ __launch_bounds__(fingerprint_threads_k) void fingerprint_segments_ke
     double const *__restrict__ complements, double *__restrict__ partial_minimums, u32 *__restrict__ partial_counts,
     u32 *__restrict__ min_hashes, u64 min_hashes_stride, u32 *__restrict__ min_counts, u64 min_counts_stride) {
 
-    __shared__ u8 staged[fingerprint_segment_k + fingerprint_max_width_k];
+    // `staged_`: the segment's bytes and the widest window's warm-up in LDS (every width up to 1024); windows wider than that
+    // (round 4: up to SZS_FINGERPRINT_WIDEST) read the text where it lies - every lane of a wavefront the same byte, one line
+    // per read, L2-resident.
+    __shared__ u8 staged[staged_ ? fingerprint_segment_k + fingerprint_max_width_k : 16];
 
     // Which text does this segment belong to?  One segment per text (every text shorter than 4096 bytes, the common
     // case) needs no table; otherwise the host lists the owner of every segment.
@@ -92,14 +96,16 @@ __global__ __launch_bounds__(fingerprint_threads_k) void fingerprint_segments_ke
     u32 const last_end = first_end + fingerprint_segment_k < text.length ? first_end + fingerprint_segment_k : text.length;
     u32 const staged_from = first_end >= fingerprint_max_width_k - 1 ? first_end - (fingerprint_max_width_k - 1) : 0u;
     u8 const *const bytes = reinterpret_cast<u8 const *>(text.address);
-    for (u32 i = staged_from + threadIdx.x; i < last_end; i += fingerprint_threads_k) staged[i - staged_from] = bytes[i];
-    __syncthreads();
+    if constexpr (staged_) {
+        for (u32 i = staged_from + threadIdx.x; i < last_end; i += fingerprint_threads_k) staged[i - staged_from] = bytes[i];
+        __syncthreads();
+    }
 
     fingerprint_state_t state = {fingerprint_skipped_k, 0};
     // This dimension's windows end at positions >= width - 1.
     u32 const my_first_end = first_end > width - 1 ? first_end : width - 1;
     if (owns_dimension && my_first_end < last_end) {
-        u8 const *const window_bytes = staged - staged_from; // window_bytes[i] = byte i of the text
+        u8 const *const window_bytes = staged_ ? staged - staged_from : bytes; // window_bytes[i] = byte i of the text
         auto term = [&](u32 i) -> double { return (double)((u32)window_bytes[i] + 1u); };
         // x < 2^52 -> x mod modulo: Barrett with a reciprocal rounded DOWN, so the quotient is floor(x / modulo) or one
         // less and a single conditional subtraction finishes the job
@@ -169,7 +175,7 @@ extern "C" int szs_hip_fingerprints(szs_string_ref_t const *texts, uint32_t text
                                     double const *multipliers, double const *modulos, double const *reciprocals,
                                     double const *complements, double *partial_minimums, uint32_t *partial_counts,
                                     uint32_t *min_hashes, uint64_t min_hashes_stride, uint32_t *min_counts,
-                                    uint64_t min_counts_stride, void *stream) {
+                                    uint64_t min_counts_stride, uint32_t widest, void *stream) {
     using namespace szs_hip;
     if (!texts_count || !dimensions || !total_segments) return 0;
     hipStream_t const s = static_cast<hipStream_t>(stream);
@@ -177,10 +183,16 @@ extern "C" int szs_hip_fingerprints(szs_string_ref_t const *texts, uint32_t text
     hipError_t error = hipSuccess;
     for (u32 first = 0; first < total_segments && error == hipSuccess; first += 1u << 30) { // keep each grid below 2^31 rows
         u32 const batch = total_segments - first < (1u << 30) ? total_segments - first : (1u << 30);
-        hipLaunchKernelGGL(fingerprint_segments_kernel, dim3(batch, dimension_blocks), dim3(fingerprint_threads_k), 0, s, texts,
-                           first, segment_text, segment_prefix, partial_prefix, dimensions, widths, multipliers, modulos,
-                           reciprocals, complements, partial_minimums, partial_counts, min_hashes, min_hashes_stride,
-                           min_counts, min_counts_stride);
+        if (widest <= fingerprint_max_width_k)
+            hipLaunchKernelGGL(fingerprint_segments_kernel<true>, dim3(batch, dimension_blocks), dim3(fingerprint_threads_k), 0, s, texts,
+                               first, segment_text, segment_prefix, partial_prefix, dimensions, widths, multipliers, modulos,
+                               reciprocals, complements, partial_minimums, partial_counts, min_hashes, min_hashes_stride,
+                               min_counts, min_counts_stride);
+        else
+            hipLaunchKernelGGL(fingerprint_segments_kernel<false>, dim3(batch, dimension_blocks), dim3(fingerprint_threads_k), 0, s, texts,
+                               first, segment_text, segment_prefix, partial_prefix, dimensions, widths, multipliers, modulos,
+                               reciprocals, complements, partial_minimums, partial_counts, min_hashes, min_hashes_stride,
+                               min_counts, min_counts_stride);
         error = hipGetLastError();
     }
     if (error != hipSuccess || !merge_count) return (int)error;

@@ -454,14 +454,15 @@ int szs_hip_myers_chain(szs_string_ref_t const *queries, uint32_t queries_count,
  *  `partial_*` with one (double, u32) per (segment of a multi-segment text, dimension).  Output strides in BYTES.
  */
 #define SZS_FINGERPRINT_SEGMENT 4096u
-#define SZS_FINGERPRINT_MAX_WIDTH 1024u
+#define SZS_FINGERPRINT_MAX_WIDTH 1024u   /* windows up to here find their bytes staged in LDS */
+#define SZS_FINGERPRINT_WIDEST 65536u    /* wider ones (round 4) read the text where it lies; the engine takes [2, this] */
 int szs_hip_fingerprints(szs_string_ref_t const *texts, uint32_t texts_count, uint32_t const *segment_text,
                          uint32_t const *segment_prefix, uint32_t const *partial_prefix, uint32_t total_segments,
                          uint32_t const *merge_list, uint32_t merge_count, uint32_t dimensions, uint32_t const *widths,
                          double const *multipliers, double const *modulos, double const *reciprocals,
                          double const *complements, double *partial_minimums, uint32_t *partial_counts,
                          uint32_t *min_hashes, uint64_t min_hashes_stride, uint32_t *min_counts,
-                         uint64_t min_counts_stride, void *stream);
+                         uint64_t min_counts_stride, uint32_t widest /* the engine's widest window */, void *stream);
 
 #ifdef __cplusplus
 }

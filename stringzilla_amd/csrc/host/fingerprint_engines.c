@@ -60,8 +60,8 @@ sz_status_t szs_fingerprints_create(sz_size_t dimensions, sz_size_t alphabet_siz
     static sz_size_t const default_widths[] = {3, 4, 5, 7, 9, 11, 15, 31}; /* fingerprints.cuh:44 */
     if (!window_widths || !window_widths_count) window_widths = default_widths, window_widths_count = 8;
     for (sz_size_t i = 0; i < window_widths_count; ++i)
-        if (window_widths[i] < 2 || window_widths[i] > SZS_FINGERPRINT_MAX_WIDTH) /* the reference asserts width > 1 */
-            return szs_report(sz_unexpected_dimensions_k, error_message, "Window widths must be within [2, 1024]");
+        if (window_widths[i] < 2 || window_widths[i] > SZS_FINGERPRINT_WIDEST) /* the reference asserts width > 1 */
+            return szs_report(sz_unexpected_dimensions_k, error_message, "Window widths must be within [2, 65536]");
 
     szs_fingerprints_s *engine = (szs_fingerprints_s *)calloc(1, sizeof(szs_fingerprints_s));
     if (engine) engine->widths = (uint32_t *)malloc(dimensions * sizeof(uint32_t));
@@ -252,7 +252,7 @@ sz_status_t szs_fingerprints_call(szs_fingerprints_s *engine, szs_scope_s *scope
         (uint32_t const *)(device_tables + merge_list_at), merge_count, dimensions,
         (uint32_t const *)(device_doubles + (size_t)dimensions * 4), device_doubles, device_doubles + dimensions,
         device_doubles + (size_t)dimensions * 2, device_doubles + (size_t)dimensions * 3, partial_minimums, partial_counts,
-        device_hashes, hashes_stride, device_counts, counts_stride, stream);
+        device_hashes, hashes_stride, device_counts, counts_stride, engine->widest, stream);
     if (launch_error) return szs_report_hip((hipError_t)launch_error, error_message);
 
     if (!direct) {

@@ -831,6 +831,16 @@ def test_fingerprints_fuzz(gpu):
         engine(texts, device=gpu, out=out)
         assert np.array_equal(out[0], expected[0]) and np.array_equal(out[1], expected[1]), (dimensions, "out=")
     assert szs.Fingerprints(64, capabilities=gpu)([], device=gpu)[0].shape == (0, 64)
+    # windows wider than the 1024 bytes the kernel stages in LDS read the text in place (round 4): wider than a segment of 4096
+    # window ends, wider than most of the texts, mixed with narrow ones
+    for dimensions, widths, seed in [(128, [1025], 6), (192, [3, 5000, 31], 7), (64, [20000], 8), (70, [4097, 2, 65536], 9)]:
+        texts = [bytes(rng.randrange(256) for _ in range(n)) for n in [0, 5, 1024, 1025, 1026, 4096, 5000, 5001, 9000, 20000, 20001, 30000]]
+        engine = szs.Fingerprints(dimensions, window_widths=widths, seed=seed, capabilities=gpu)
+        expected = binding.oracle_fingerprints(texts, dimensions, widths, seed)
+        got = engine(texts, device=gpu)
+        assert np.array_equal(got[0], expected[0]) and np.array_equal(got[1], expected[1]), (dimensions, widths)
+    with pytest.raises(szs.StringZillasError):
+        szs.Fingerprints(64, window_widths=[65537], capabilities=gpu)
     with pytest.raises(szs.StringZillasError):
         szs.Fingerprints(64, window_widths=[1], capabilities=gpu)  # the reference asserts width > 1
     with pytest.raises(szs.StringZillasError):
