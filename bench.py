@@ -754,7 +754,7 @@ def main():
             line["same_tapes"] = same_tapes
         if not args.no_cpu_baseline:  # rank 0, whatever N: the host cores are this box's
             line["cpu_baseline"] = cpu_baseline(load, gpu_matrix, args.cpu_seconds)
-            attach_cpu_baselines(records, args.cpu_seconds)
+            attach_cpu_baselines(records, args.cpu_seconds / 2)  # half the headline's budget each: the default run stays within ~2.5 minutes
         for record in records:
             record.pop("_cpu_baseline_inputs", None)
         if records:
