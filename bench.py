@@ -2,7 +2,10 @@
 """bench.py - BASELINE.json's metric on BASELINE.json's configs, through the C-ABI.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2] [--extra-configs 3,4,5,6] [--no-cpu-baseline]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+`--gpus N` with N > 1 starts its own N ranks (one process per GPU under torch.distributed.run, 127.0.0.1, a free port); under a
+launcher that already set WORLD_SIZE (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N`) it
+is one of those ranks.  Fewer than N GPUs visible: one JSON line with "error", exit code 2.
 
 Metric : DP cell-updates/s (GCUPS) = sum over scored pairs of len(query) * len(candidate) / seconds / 1e9
          (the reference's accounting, /root/reference/bench/similarities.cuh:344-366).
@@ -12,20 +15,21 @@ Step   : one `szs_levenshtein_distances_u32tape` call - the whole synchronous C-
 N > 1  : one process per GPU.  The HEADLINE shards by QUERY ROW BLOCKS: every rank scores its own
          1024 query rows against the same 1024 candidates (broadcast once over RCCL/xGMI before timing), so per-GPU work
          is fixed: "weak" scaling, and the timed path has no collective (rows are independent; results stay sharded).
-Line   : rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel against HBM with ALGORITHMIC bytes
-         (272 B per pair at len 128: len(q) + len(c) + 2 offsets + one 8-byte result) over the
-         hipEvent-measured kernel time the library records on its own stream.  `cpu_baseline` times the reference's own
-         SIMD engines (oracle/_ref, built from /root/reference) on this box's host cores - a reported baseline only.
-configs: the same line carries a `configs` array - one record per other BASELINE.json config (9: config 2 at a fixed 128 bytes,
-         its "peak" variant; 3: NW BLOSUM62, 4: SW
-         affine NUC.4.4, 5: byte-level Levenshtein on Zipf UTF-8, 5u: the same at the codepoint level, 7 / 8: config 2's batch
-         under non-unit costs, linear 1/3/3 and affine 0/1/4/2), each timed
-         through its own C-ABI entry point with its kernel and wall GCUPS, checksum, HBM roofline, the VALU counters of
-         its dominant kernel (profiles/r02, committed PMC passes) and the reference's Ice Lake engine as `cpu_baseline`
-         on a stated sample whose cells are also compared with the GPU's.  With N > 1 configs 4 and 5 are STRONG-scaled
-         the way BASELINE.json specifies them: ONE batch, rows dealt over the ranks by LPT (`stringzilla_amd/sharded.py`),
-         per-GPU busy time, imbalance = max / mean, aggregate GCUPS - plus the same batch through the single-process C
-         entry `szs_rocm_node_*` (one host thread per GPU) when the library exports it.
+Line   : the LAST stdout line of rank 0 is the headline alone, under 4 KB (tests/test_bench_line.py).  `roofline` prices the
+         dominant kernel against HBM with ALGORITHMIC bytes (272 B per pair at len 128: len(q) + len(c) + 2 offsets + one
+         8-byte result) over the hipEvent-measured kernel time the library records on its own stream.
+         `cpu_baseline` times the reference's own SIMD engines (oracle/_ref, built from /root/reference) on this box's host
+         cores - a reported baseline only.
+configs: BEFORE the headline, one `{"configs_record": {...}}` line per other config (9: config 2 at a fixed 128 bytes, its
+         "peak" variant; 3: NW BLOSUM62; 4: SW affine NUC.4.4; 5: byte-level Levenshtein on Zipf UTF-8; 6 = 5u: the same at the
+         codepoint level; 7 / 8: config 2's batch under non-unit costs, linear 1/3/3 and affine 0/1/4/2; 10: 4096 x 4096 tiny
+         tokens), each timed through its own C-ABI entry point with kernel and wall GCUPS, checksum, HBM roofline, the VALU
+         counters of its dominant kernel (committed PMC passes) and the reference's Ice Lake engine as `cpu_baseline` on a
+         stated sample whose cells are also compared with the GPU's; all of it also in gpurun_out/bench_configs.json.  The
+         headline keeps their wall GCUPS as `configs_gcups`.  With N > 1 configs 4 and 5 are STRONG-scaled the way
+         BASELINE.json specifies them: ONE batch, rows dealt over the ranks by LPT (`stringzilla_amd/sharded.py`), per-GPU busy
+         time, imbalance = max / mean, aggregate GCUPS - plus the same batch through the single-process C entry
+         `szs_rocm_node_*` (one host thread per GPU).
 """
 
 import argparse
@@ -45,7 +49,7 @@ HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 # The binding resource of this path is integer VALU issue, not HBM.  Its ceiling is MEASURED, not quoted: the Myers
 # column update (the kernel's exact instruction mix) on register-resident match masks, no LDS and no memory, sustains
 # this many DP cells per second at full bit-vector width on one MI355X (scripts/valu_peak.hip -> profiles/).
-PROFILE_DIRS = [os.path.join(ROOT, "profiles", name) for name in ("r04", "r03", "r02", "r01")]
+PROFILE_DIRS = [os.path.join(ROOT, "profiles", name) for name in ("r05", "r04", "r03", "r02", "r01")]
 # VALU issue ceiling, class-weighted: gfx950's SIMDs are 32 lanes wide, a full-rate VALU instruction (32-bit add / sub / logic /
 # right shift / move) takes a wavefront 2 cycles, every other one (maxima, packed 16-bit, carries, funnel shifts, VOP3 three-
 # operand forms, DPP) 4 - MI355X_MICROARCH.md "Wave scheduling", measured per opcode by scripts/valu_peak.hip.  A main loop of F
@@ -72,14 +76,21 @@ def parse_args():
     parser.add_argument("--config", type=int, default=2, help="BASELINE.json config index of the headline (2 = the metric's config)")
     parser.add_argument("--generator", default="mt19937_64", choices=["numpy", "mt19937_64"],
                         help="where configs 1-4 come from: std::mt19937_64, the generator SURVEY.md section 8(d) names "
-                             "(tests/native/workloads_mt19937.cpp spells the mapping out; reproducible from C++), or numpy's "
+                             "(csrc/workloads/workloads_mt19937.cpp spells the mapping out; reproducible from C++), or numpy's "
                              "default_rng (the batches rounds 1-3 were profiled on: the same shapes, other strings).  Configs 5 / 5u "
-                             "(Zipf UTF-8) exist in numpy only.  Falls back to numpy, and says so, when the helper library is not built")
+                             "(Zipf UTF-8) exist in numpy only.  A run whose generator is not available FAILS; it never scores another batch "
+                             "under the same config name")
     parser.add_argument("--extra-configs", default=None,
                         help="comma-separated configs reported in the `configs` array (default: 3,4,5,6,7,8 on one GPU, "
                              "4,5 strong-scaled on several; 'none' to skip)")
-    parser.add_argument("--extra-seconds", type=float, default=4.0, help="GPU time budget per extra config")
-    parser.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget per cpu_baseline sample")
+    parser.add_argument("--extra-seconds", type=float, default=2.0, help="GPU time budget per extra config")
+    parser.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU time budget of the headline's cpu_baseline sample")
+    parser.add_argument("--extra-cpu-seconds", type=float, default=2.5,
+                        help="CPU time budget of each `configs` record's cpu_baseline (a config whose smallest fair sample - a row per "
+                             "thread x one SIMD lane group - takes longer gets three runs of that sample)")
+    parser.add_argument("--details", default=os.path.join("gpurun_out", "bench_configs.json"),
+                        help="where the `configs` records and the untrimmed headline are written (also printed, one JSON line each, "
+                             "BEFORE the headline; the LAST stdout line is the headline alone, under 4 KB)")
     parser.add_argument("--extra-scale", type=float, default=1.0,
                         help="testing aid: shrinks the matrix side of the `configs` records (1.0 = BASELINE.json's sizes)")
     parser.add_argument("--no-cpu-baseline", action="store_true")
@@ -94,9 +105,13 @@ def parse_args():
 
 
 def resolve_generator(wanted):
-    """`mt19937_64` needs tests/native/bin/libworkloads_mt19937.so (built by __graft_entry__.build()); without it: numpy."""
-    if wanted == "mt19937_64" and not os.path.exists(os.path.join(ROOT, "tests", "native", "bin", "libworkloads_mt19937.so")):
-        return "numpy"
+    """`mt19937_64` needs stringzilla_amd/lib/libszs_workloads_mt19937.so (csrc/Makefile builds it beside the scoring library).
+    Without it the run FAILS: numpy batches under the same config name would be a different measurement."""
+    from stringzilla_amd import workloads
+
+    if wanted == "mt19937_64" and not os.path.exists(workloads.MT19937_64_LIBRARY):
+        raise SystemExit(json.dumps({"error": f"--generator mt19937_64 needs {os.path.relpath(workloads.MT19937_64_LIBRARY, ROOT)} "
+                                              f"(make -C stringzilla_amd/csrc); pass --generator numpy to score numpy batches"}))
     return wanted
 
 
@@ -185,10 +200,10 @@ def make_step(engine, scope, load, queries, candidates, results, device_index):
 
 # ---- the reference's CPU engines beside it ---------------------------------------------------------------------------------
 
-def cpu_baseline(load, gpu_matrix, seconds):
+def cpu_baseline(load, gpu_matrix, seconds, cell_bits=0, with_serial=True):
     """Times the reference's own CPU engines (best SIMD tier, all host threads) on a BOUNDED sample of the same batch -
-    evenly spaced query rows x evenly spaced candidates, sized by a calibration pass to about `seconds` of CPU work, the
-    whole batch when that fits - and checks that they produce the very cells the GPU produced.  Test-infrastructure
+    evenly spaced query rows x evenly spaced candidates, sized from its first (verified) run to about `seconds` of CPU work,
+    the whole batch when that fits - and checks that they produce the very cells the GPU produced.  Test-infrastructure
     code path: the only place bench.py touches oracle/."""
     from oracle import binding
     from stringzilla_amd import matrices
@@ -205,96 +220,82 @@ def cpu_baseline(load, gpu_matrix, seconds):
     if checker is None:
         checker, kind, label, cores = binding.oracle(), "port", "plain-C oracle", 1
 
-    def run(rows, columns):
+    def run(rows, columns, engine=None):
+        engine = engine or checker
         queries = [load.queries[int(i)] for i in rows]
         candidates = [load.candidates[int(j)] for j in columns]
         if load.kind == "levenshtein":
-            return checker.levenshtein(queries, candidates, **load.costs)
+            return engine.levenshtein(queries, candidates, **load.costs)
         if load.kind == "levenshtein_utf8":
-            return checker.levenshtein_utf8(queries, candidates, **load.costs)
-        scorer = checker.needleman_wunsch if load.kind == "needleman_wunsch" else checker.smith_waterman
+            return engine.levenshtein_utf8(queries, candidates, **load.costs)
+        scorer = engine.needleman_wunsch if load.kind == "needleman_wunsch" else engine.smith_waterman
         return scorer(queries, candidates, *matrices.by_name(load.table), **load.costs)
+
+    def verified(rows, columns, engine=None):
+        started = time.perf_counter()
+        matrix = run(rows, columns, engine)
+        elapsed = time.perf_counter() - started
+        assert np.array_equal(matrix.view(np.int64), gpu_matrix[np.ix_(rows, columns)].view(np.int64)), "CPU baseline and GPU disagree"
+        return elapsed
 
     q_lengths, c_lengths = load.queries.lengths(), load.candidates.lengths()
     spaced = lambda count, take: np.unique(np.linspace(0, count - 1, num=max(1, min(count, take))).round().astype(np.int64))
     cells_of = lambda rows, columns: float(q_lengths[rows].sum()) * float(c_lengths[columns].sum())
 
-    # calibration: one row per thread (the shim deals contiguous row blocks to threads) x 64 candidates - the reference's SIMD
-    # engines score one query against 16 / 32 / 64 candidates at once, one per lane, so a sample's candidates come in whole
-    # multiples of 64 (round 2's config-4 sample of 26 candidates left a third of the lanes empty and read 26 GCUPS for ~32)
-    lanes = 64
-    rows = spaced(len(q_lengths), max(cores, 1))
-    columns = spaced(len(c_lengths), lanes)
-    started = time.perf_counter()
-    run(rows, columns)
-    rate = cells_of(rows, columns) / max(time.perf_counter() - started, 1e-4)
-    budget_cells = rate * seconds / 5  # one run of the sample takes about a fifth of the budget: five or more timed repeats
-    # grow the sample towards the budget: first more candidates (whole lane groups), then more rows
-    per_column = cells_of(rows, np.arange(len(c_lengths))) / len(c_lengths)
-    take_columns = int(min(len(c_lengths), max(lanes, budget_cells / max(per_column, 1.0) // lanes * lanes)))
-    columns = spaced(len(c_lengths), take_columns)
-    if take_columns == len(c_lengths):
-        per_row = cells_of(np.arange(len(q_lengths)), columns) / len(q_lengths)
-        rows = spaced(len(q_lengths), int(min(len(q_lengths), max(len(rows), budget_cells / max(per_row, 1.0)))))
+    # The smallest fair sample: one row per thread (the shim deals contiguous row blocks to threads) x one SIMD lane group of
+    # candidates - the reference's engines score one query against 16 (32-bit cells) / 32 / 64 candidates at once, one per lane,
+    # so a sample's candidates come in whole lane groups (round 2's config-4 sample of 26 candidates left a third of the lanes
+    # empty and read 26 GCUPS for ~32).  Its first run is verified against the GPU's cells and sizes everything after it.
+    lanes = 16 if int(cell_bits) == 32 else 64
+    rows, columns = spaced(len(q_lengths), max(cores, 1)), spaced(len(c_lengths), lanes)
+    first = verified(rows, columns)
+    if first < seconds / 5:  # grow towards a fifth of the budget per run: first more candidates (whole lane groups), then more rows
+        budget_cells = cells_of(rows, columns) / max(first, 1e-4) * seconds / 5
+        per_column = cells_of(rows, np.arange(len(c_lengths))) / len(c_lengths)
+        take_columns = int(min(len(c_lengths), max(lanes, budget_cells / max(per_column, 1.0) // lanes * lanes)))
+        columns = spaced(len(c_lengths), take_columns)
+        if take_columns == len(c_lengths):
+            per_row = cells_of(np.arange(len(q_lengths)), columns) / len(q_lengths)
+            rows = spaced(len(q_lengths), int(min(len(q_lengths), max(len(rows), budget_cells / max(per_row, 1.0)))))
+        first = verified(rows, columns)
     whole = len(rows) == len(q_lengths) and len(columns) == len(c_lengths)
-
-    started = time.perf_counter()
-    matrix = run(rows, columns)
-    first = time.perf_counter() - started
-    expected = gpu_matrix[np.ix_(rows, columns)]
-    assert np.array_equal(matrix.view(np.int64), expected.view(np.int64)), "CPU baseline and GPU disagree"
-    # five or more runs when the budget allows; a batch whose SMALLEST fair sample (a row per thread x one lane group) already
-    # takes seconds per run - config 4 - gets three
-    # ... and a run lasts a quarter of a second or more: a batch the CPU finishes in 30 ms (configs 2, 7, 8) is passed several
-    # times back to back per run - timed one pass at a time, 256 threads starting up made the median wander between 340 and 580
+    # A run lasts a quarter of a second or more: a batch the CPU finishes in 30 ms (configs 2, 7, 8) is passed several times back
+    # to back per run - timed one pass at a time, 256 threads starting up made the median wander between 340 and 580.  Five or
+    # more runs when the budget allows; a batch whose smallest fair sample already takes a third of the budget gets three.
     passes = 1 if first >= 0.25 else int(min(64, np.ceil(0.25 / max(first, 1e-4))))
     repeats = int(max(3 if first * passes > seconds / 5 else 5, min(20, (seconds - first) / max(first * passes, 1e-3))))
-    runs = []
-    for _ in range(repeats):
+    runs = [first] if passes == 1 and first * 3 > seconds else []  # ... the verified run counting as the first of them
+    while len(runs) < repeats:
         started = time.perf_counter()
         for _ in range(passes):
             run(rows, columns)
         runs.append((time.perf_counter() - started) / passes)
     elapsed = float(np.median(runs))  # the median: a 256-thread host shows stragglers, a mean of two runs wandered by 25 %
+    record = {
+        "value": round(cells_of(rows, columns) / elapsed / 1e9, 2), "unit": "GCUPS", "cores": cores, "kind": kind, "tier": label,
+        "spread": [round(cells_of(rows, columns) / max(runs) / 1e9, 2), round(cells_of(rows, columns) / min(runs) / 1e9, 2)],
+        "sample": (f"full {len(q_lengths)}x{len(c_lengths)} batch" if whole else f"{len(rows)} spaced rows x {len(columns)} spaced candidates")
+                  + f"; median of {len(runs)} runs" + (f" x {passes} passes" if passes > 1 else "") + "; cells verified equal to the GPU's",
+        "sample_rows": len(rows), "sample_columns": len(columns), "runs": len(runs), "passes_per_run": passes, "verified": True,
+    }
     # the reference reports its Serial engine beside the SIMD tiers (similarities/README.md:21-24): ONE thread of the serial tier
-    # on a sample of about a second (a row per eight of the SIMD sample's, one lane group of candidates)
-    serial = None
-    if kind == "reference":
+    # on a sample of about a second (four rows, one lane group of candidates)
+    if with_serial and kind == "reference":
         try:
             plain = binding.reference(tier=0, threads=1)
             serial_rows, serial_columns = spaced(len(q_lengths), 4), spaced(len(c_lengths), lanes)
-            def run_serial():
-                queries = [load.queries[int(i)] for i in serial_rows]
-                candidates = [load.candidates[int(j)] for j in serial_columns]
-                if load.kind == "levenshtein":
-                    return plain.levenshtein(queries, candidates, **load.costs)
-                if load.kind == "levenshtein_utf8":
-                    return plain.levenshtein_utf8(queries, candidates, **load.costs)
-                scorer = plain.needleman_wunsch if load.kind == "needleman_wunsch" else plain.smith_waterman
-                return scorer(queries, candidates, *matrices.by_name(load.table), **load.costs)
-            started = time.perf_counter()
-            got = run_serial()
-            once = time.perf_counter() - started
-            assert np.array_equal(got.view(np.int64), gpu_matrix[np.ix_(serial_rows, serial_columns)].view(np.int64)), "serial CPU baseline and GPU disagree"
+            once = verified(serial_rows, serial_columns, plain)
             again = int(max(1, min(50, 1.0 / max(once, 1e-4))))
             started = time.perf_counter()
             for _ in range(again):
-                run_serial()
-            serial = {"value": round(cells_of(serial_rows, serial_columns) * again / (time.perf_counter() - started) / 1e9, 3), "unit": "GCUPS",
-                      "cores": 1, "sample": f"{len(serial_rows)} query rows x {len(serial_columns)} candidates, {again} passes, serial tier, cells verified equal"}
+                run(serial_rows, serial_columns, plain)
+            record["serial_1_thread"] = {"value": round(cells_of(serial_rows, serial_columns) * again / (time.perf_counter() - started) / 1e9, 3),
+                                         "unit": "GCUPS", "cores": 1, "sample": f"{len(serial_rows)} rows x {len(serial_columns)} candidates x {again} passes, serial tier, verified"}
         except AssertionError:
             raise
         except Exception as problem:
-            serial = {"error": repr(problem)}
-    what = (f"the full {len(q_lengths)}x{len(c_lengths)} batch of the timed config" if whole else
-            f"{len(rows)} evenly spaced query rows x {len(columns)} evenly spaced candidates of the timed config")
-    return {
-        "value": round(cells_of(rows, columns) / elapsed / 1e9, 2), "unit": "GCUPS", "cores": cores, "kind": kind,
-        "spread": [round(cells_of(rows, columns) / max(runs) / 1e9, 2), round(cells_of(rows, columns) / min(runs) / 1e9, 2)],
-        "sample": f"{what}, median of {repeats} runs{f' of {passes} passes each' if passes > 1 else ''} (`spread`: slowest and fastest run), {label} tier, {cores} threads, tape packing "
-                  f"included; the sampled cells verified equal to the GPU's",
-        "serial_1_thread": serial,
-    }
+            record["serial_1_thread"] = {"error": repr(problem)}
+    return record
 
 
 # ---- rooflines -------------------------------------------------------------------------------------------------------------
@@ -302,7 +303,9 @@ def cpu_baseline(load, gpu_matrix, seconds):
 def roofline(config, profile, kernel_seconds, traffic_override=None):
     """HBM roofline from the ALGORITHMIC bytes of one call over the kernel time measured live (hipEvent pair on the library's
     stream), beside what the committed rocprofv3 --pmc passes of this same command saw: HBM bytes actually moved per call
-    and - what actually binds this path - VALU issue and LDS occupancy (scripts/profile_configs.sh -> profiles/rNN)."""
+    (`traffic`: (FETCH_SIZE + WRITE_SIZE) x 1024 summed over the kernels of one call, raw) and - what actually binds this path -
+    VALU issue and LDS occupancy (scripts/profile_configs.sh -> profiles/rNN).  Keys only, no prose: the line must stay short
+    (DESIGN.md section 5 says what each key means)."""
     achieved = profile.algorithmic_bytes / kernel_seconds / 1e9
     record = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
               "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic_override, "kernel_ms": round(kernel_seconds * 1e3, 4),
@@ -311,47 +314,41 @@ def roofline(config, profile, kernel_seconds, traffic_override=None):
     summary, where = _profile_json("pmc_configs.json")  # "cfgN:kernel" and "cfgN:__call__" (scripts/pmc_configs.py)
     call = (summary or {}).get(f"cfg{config}:__call__")
     counted_on = (summary or {}).get("_library_sha256")
-    record["pmc_library_sha256"] = counted_on
-    record["pmc_stale"] = None if not counted_on else counted_on != library_digest()  # True: the counters below were taken on other code
+    # pmc_stale True: the counters below were taken on another build of the library than the one this run executes
+    record["pmc_stale"] = None if not counted_on else counted_on != library_digest()
     if not call:
-        record["traffic_source"] = "no committed PMC pass for this config" if traffic_override is None else "from --hbm-traffic-bytes"
+        record["traffic_source"] = "none: no committed PMC pass for this config" if traffic_override is None else "--hbm-traffic-bytes"
         return record
+    record["pmc_source"] = where
     kernels = call.get("kernels", {})
     if kernels:
         dominant = max(kernels, key=lambda name: kernels[name]["share_of_kernel_time"])
-        record["kernel"] = dominant if len(kernels) == 1 else f"{dominant} + {len(kernels) - 1} more (launches of different widths overlap on {int(getattr(profile, 'streams', 0)) or 'several'} streams)"
+        record["kernel"] = dominant
+        if len(kernels) > 1:
+            record["kernels_in_call"] = len(kernels)
     if traffic_override is None and "hbm_fetch_bytes_raw" in call and "hbm_write_bytes_raw" in call:
         record["traffic"] = round(call["hbm_fetch_bytes_raw"] + call["hbm_write_bytes_raw"])
-        record["traffic_source"] = (f"{where}: (FETCH_SIZE + WRITE_SIZE) x 1024 summed over the kernels of one call, committed rocprofv3 "
-                                    f"--pmc passes of this command (raw; wide-stream reads may count double)")
     if "SQ_INSTS_VALU" in call:
         lane_ops = call["SQ_INSTS_VALU"] * 64.0
-        mixes, mix_where = _profile_json("opcode_mix.json")
-        # the ceiling of the call = its kernels' ceilings weighted by their share of the kernel time
+        mixes, _ = _profile_json("opcode_mix.json")
+        # the ceiling of the call = its kernels' ceilings weighted by their share of the kernel time:
+        # (F + H) / (F / 78.6 T + H / 39.3 T), F / H = full- / half-rate instructions of a kernel's main loop (scripts/opcode_mix.py)
         weights = {name: kernels[name]["share_of_kernel_time"] for name in kernels if (mixes or {}).get(name)}
         if weights:
             total = sum(weights.values())
             ceiling = 1e12 * total / sum(share / mixes[name]["ceiling_Tlane_ops_per_s"] for name, share in weights.items())
             main = max(weights, key=weights.get)
-            mix = {"kernel": main, "main_loop": mixes[main]["main_loop"], "full_rate_instructions": mixes[main]["full_rate"],
-                   "half_rate_instructions": mixes[main]["half_rate"], "source": mix_where}
+            full, half = mixes[main]["full_rate"], mixes[main]["half_rate"]
         else:
-            ceiling, mix = VALU_HALF_RATE_PEAK, None
+            ceiling, full, half = VALU_HALF_RATE_PEAK, None, None
+        fraction = lambda key: round(call[key], 4) if key in call else None
         record["valu"] = {
-            "bound": "integer VALU issue (PMC), class-weighted ceiling", "source": where,
-            "wave_instructions_per_call": round(call["SQ_INSTS_VALU"]),
+            "bound": "int VALU issue, class-weighted", "frac": round(lane_ops / kernel_seconds / ceiling, 4),
+            "achieved_Tlane_ops_per_s": round(lane_ops / kernel_seconds / 1e12, 2), "peak_Tlane_ops_per_s": round(ceiling / 1e12, 2),
             "lane_ops_per_cell": round(lane_ops / max(float(profile.cells), 1.0), 4),
-            "achieved_Tlane_ops_per_s": round(lane_ops / kernel_seconds / 1e12, 2),
-            "peak_Tlane_ops_per_s": round(ceiling / 1e12, 2),
-            "frac": round(lane_ops / kernel_seconds / ceiling, 4),
-            "opcode_mix": mix,
-            "lds_busy_fraction": round(call["lds_busy_fraction"], 4) if "lds_busy_fraction" in call else None,
-            "lds_conflict_fraction": round(call["lds_conflict_fraction"], 4) if "lds_conflict_fraction" in call else None,
-            "wave_cycles_waiting_to_issue": round(call["wave_wait_inst_fraction"], 4) if "wave_wait_inst_fraction" in call else None,
-            "wave_cycles_parked": round(call["wave_wait_any_fraction"], 4) if "wave_wait_any_fraction" in call else None,
-            "note": "frac = (VALU wave-instructions of one call x 64 lanes / live kernel seconds) over (F + H) / (F / 78.6 T + H / 39.3 T), "
-                    "F / H = full- / half-rate instructions of the dominant kernels' main loops (time-weighted over the kernels of the "
-                    "call); the instruction count is a committed PMC pass of this command, the kernel time is this run's",
+            "wave_instructions_per_call": round(call["SQ_INSTS_VALU"]), "full_rate": full, "half_rate": half,
+            "lds_busy": fraction("lds_busy_fraction"), "lds_conflict": fraction("lds_conflict_fraction"),
+            "wait_to_issue": fraction("wave_wait_inst_fraction"), "parked": fraction("wave_wait_any_fraction"),
         }
     return record
 
@@ -447,9 +444,8 @@ def measure_fingerprints(scope, device_index, args, fence):
             "passes_ms": [round(w * 1e3, 3) for w in walls],
             "value": round(text_bytes * dimensions / wall / 1e12, 3), "unit": "10^12 byte-dimensions/s",
             "text_gb_s": round(text_bytes / wall / 1e9, 2), "results_checksum": int(hashes.astype(np.uint64).sum() % (1 << 53)),
-            "roofline": {"bound": f"integer / fp64 VALU issue, ESTIMATED: {per_position:.2f} instructions per byte and dimension "
-                                  f"(main loop of the kernel's assembly / 4 positions) against that loop's class-weighted ceiling"
-                                  f"{' (' + mix_where + ')' if mix else ' (no opcode mix committed: 25 assumed, flat half-rate peak)'}; wall time, no PMC pass",
+            "roofline": {"bound": "int / fp64 VALU issue", "instructions_per_byte_and_dimension": round(per_position, 2),
+                         "counted": "assembly of the main loop / 4 positions" if mix else "assumed 25",
                          "achieved_Tlane_ops_per_s": round(lane_ops / wall / 1e12, 2), "peak_Tlane_ops_per_s": round(ceiling / 1e12, 2),
                          "frac": round(lane_ops / wall / ceiling, 4),
                          "hbm": {"algorithmic_bytes": text_bytes + 8 * dimensions * len(texts), "achieved_gb_s": round((text_bytes + 8 * dimensions * len(texts)) / wall / 1e9, 2),
@@ -462,7 +458,7 @@ def attach_cpu_baselines(records, seconds):
         if inputs is None:
             continue
         try:
-            record["cpu_baseline"] = cpu_baseline(inputs[0], inputs[1].cpu().numpy(), seconds)
+            record["cpu_baseline"] = cpu_baseline(inputs[0], inputs[1].cpu().numpy(), seconds, cell_bits=record.get("cell_bits", 0), with_serial=False)
         except AssertionError:
             raise
         except Exception as problem:  # the checker is optional equipment; the GPU numbers stand without it
@@ -545,8 +541,35 @@ def measure_c_node(config, devices, args):
             "results_checksum": int(out.sum().item())}
 
 
+def free_port():
+    import socket
+
+    with socket.socket() as probe:
+        probe.bind(("127.0.0.1", 0))
+        return probe.getsockname()[1]
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves (one process per GPU under
+    `torch.distributed.run`, rendezvous on 127.0.0.1 and a free port, the same argv) and become them.  A box with fewer than N
+    devices gets a parseable line and a non-zero exit, not a traceback ("missing" #2)."""
+    import torch
+
+    visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if visible < (1 if args.same_device else args.gpus):
+        print(json.dumps({"error": f"--gpus {args.gpus} but {visible} GPU(s) visible", "n_gpus": args.gpus, "visible_gpus": visible}), flush=True)
+        raise SystemExit(2)
+    command = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, command)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)  # does not return
+    clock = {"started": time.perf_counter()}
     # The application's choice, made before HIP initialises: twelve hardware queues, so that the per-width launches of a
     # mixed-length batch (configs 5 / 5u: up to eight streams) each get their own.  The library itself never writes the
     # environment; it reads this variable when it is loaded and sizes its fan-out to it (csrc/host/tuning.c).
@@ -560,12 +583,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(json.dumps({"error": f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", "n_gpus": args.gpus}), flush=True)
+        raise SystemExit(2)
     if world > 1:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     where = torch.device("cuda", local_rank)
 
@@ -651,8 +677,8 @@ def main():
         fence()
         same_elapsed = time.perf_counter() - same_started
         profile = engine.last_call_profile()
-        same_tapes = {"what": "the same tapes again and again: the plan of the previous call is re-used behind a guard, no planner kernel",
-                      "ms_per_step": round(same_elapsed / calls * 1e3, 4), "value": round(profile.cells * calls / same_elapsed / 1e9, 1),
+        # the same tapes again and again: the plan of the previous call is re-used behind a guard, no planner kernel
+        same_tapes = {"ms_per_step": round(same_elapsed / calls * 1e3, 4), "value": round(profile.cells * calls / same_elapsed / 1e9, 1),
                       "unit": "GCUPS", "calls": calls, "planner_mode": int(profile.planner)}
 
     for index in range(args.warmup):
@@ -698,32 +724,29 @@ def main():
                     records.append({"config": config, "entry_point": "szs_rocm_node_scores_u32tape", "error": repr(problem)})
         fence()
 
+    clock["gpu_done"] = time.perf_counter()
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total_cells / elapsed / 1e9
         kernel = float(np.mean(kernel_ms)) * 1e-3  # seconds per launch group, hipEvent pair on the library's stream
         gpu_matrix = results.cpu().numpy()
-        valu_table, valu_where = _profile_json("valu_peak.json")
+        valu_table, _ = _profile_json("valu_peak.json")
         pure = (valu_table or {}).get("myers_pure_W4_Tcells")
         lengths = load.queries.lengths().astype(np.int64)
         padded_cells = float((np.maximum(1, -(-lengths // 32)) * 32).sum()) * float(load.candidates.lengths().sum())
         line_roofline = roofline(args.config, profile, kernel, args.hbm_traffic_bytes)
-        try:
+        try:  # device-to-device copy of 1 GiB on this box, read + write bytes over the best of five (torch, HIP events)
             line_roofline["peak_measured"] = measured_hbm_peak(where)
             line_roofline["frac_of_measured_peak"] = round(line_roofline["achieved"] / line_roofline["peak_measured"], 6)
-            line_roofline["peak_measured_how"] = "device-to-device copy of 1 GiB on this box, read + write bytes over the best of five (torch, HIP events)"
         except Exception as problem:
             line_roofline["peak_measured"] = None
-            line_roofline["peak_measured_how"] = repr(problem)
-        line_roofline["note"] = ("integer-VALU bound by construction (HBM traffic is a few % of the algorithmic bytes: tapes are "
-                                 "L2-resident); the HBM fraction is reported because the metric asks for it, the `valu` and "
-                                 "`myers_ceiling` objects are the rooflines that say something about the kernel")
+            line_roofline["peak_measured_error"] = repr(problem)[:80]
         if load.kind == "levenshtein" and pure:
+            # the ceiling of the kernel's own column update on register-resident masks, measured: scripts/valu_peak.hip
+            # `myers_pure_W4_Tcells`; cells counted at full bit-vector width (phantom rows included) on both sides
             line_roofline["myers_ceiling"] = {
-                "bound": "integer VALU issue, measured", "achieved_Tcells_per_s_full_width": round(padded_cells / kernel / 1e12, 2),
+                "bound": "int VALU issue, measured (valu_peak.hip)", "achieved_Tcells_per_s_full_width": round(padded_cells / kernel / 1e12, 2),
                 "peak_Tcells_per_s_full_width": pure, "frac": round(padded_cells / kernel / 1e12 / pure, 4),
-                "peak_source": f"scripts/valu_peak.hip `myers_pure_W4_Tcells`: the kernel's column update on "
-                               f"register-resident masks ({valu_where})",
                 "useful_fraction_of_width": round(float(profile.cells) / padded_cells, 4)}
         line = {
             "metric": "DP cell-updates/s (GCUPS) on 1M-pair Levenshtein batch" if args.config == 2 else f"DP cell-updates/s (GCUPS), {load.name}",
@@ -735,34 +758,83 @@ def main():
             "data": "synthetic",
             "config": {"workload": load.name, "pairs_per_gpu": rows * columns, "cells_per_gpu": int(profile.cells),
                        "sharding": "query row blocks, candidates replicated" if world > 1 else "single GPU",
-                       "entry_point": ENTRY_POINTS[load.kind], "generator": args.generator},
+                       "entry_point": ENTRY_POINTS[load.kind], "generator": args.generator,
+                       # "fresh batches": two different batches of this shape alternate, every timed call plans its tapes afresh
+                       "stream": "fresh batches alternate" if len(steps_of) > 1 else "same batch every step"},
             "roofline": line_roofline,
             "host_overhead_ms_per_step": round(ms_per_step - kernel * 1e3, 4),
-            "planner": " / ".join({0: "host", 1: "device", 2: "device, launches speculated on the previous call's shape",
-                                   3: "plan of the previous call re-used for the same tapes, validated in the kernels"}[mode] for mode in sorted(planners)),
+            "planner": "+".join({0: "host", 1: "device", 2: "device, speculated", 3: "re-used"}[mode] for mode in sorted(planners)),
             "results_checksum": float(checksum),
             # the three figures the reference's own bench prints per engine (bench/similarities.cuh:344-366: bytes passed, operations =
             # cells, inputs processed, and the device-measured "Kernel" line :303-308)
             "reference_style": {"throughput_gb_s": round(float(load.queries.lengths().sum() * columns + load.candidates.lengths().sum() * rows) * world / (elapsed / args.steps) / 1e9, 1),
                                 "efficiency_gops_s": round(value, 1), "pairs_per_second": round(rows * columns * world / (elapsed / args.steps), 0),
-                                "kernel_gcups": round(float(profile.cells) / kernel / 1e9, 1), "kernel_ms": round(kernel * 1e3, 4)},
+                                "kernel_gcups": round(float(profile.cells) / kernel / 1e9, 1)},
         }
-        line["config"]["stream"] = ("two different batches of this shape alternate: every timed call plans its tapes afresh on the device"
-                                    if len(steps_of) > 1 else "the same batch every step")
         if same_tapes is not None:
-            line["config"]["same_tapes_gcups"] = same_tapes["value"]  # kept inside `config` so that a truncated record still has it
+            line["config"]["same_tapes_gcups"] = same_tapes["value"]
             line["same_tapes"] = same_tapes
         if not args.no_cpu_baseline:  # rank 0, whatever N: the host cores are this box's
-            line["cpu_baseline"] = cpu_baseline(load, gpu_matrix, args.cpu_seconds)
-            attach_cpu_baselines(records, args.cpu_seconds / 2)  # half the headline's budget each: the default run stays within ~2.5 minutes
+            line["cpu_baseline"] = cpu_baseline(load, gpu_matrix, args.cpu_seconds, cell_bits=profile.cell_bits)
+            clock["headline_cpu_done"] = time.perf_counter()
+            attach_cpu_baselines(records, args.extra_cpu_seconds)
         for record in records:
             record.pop("_cpu_baseline_inputs", None)
-        if records:
-            line["configs"] = records
-        print(json.dumps(line), flush=True)
+        clock["done"] = time.perf_counter()
+        line["run_seconds"] = {"total": round(clock["done"] - clock["started"], 1), "gpu_legs": round(clock["gpu_done"] - clock["started"], 1),
+                               "cpu_baselines": round(clock["done"] - clock["gpu_done"], 1)}
+        emit(line, records, args.details)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# ---- output -----------------------------------------------------------------------------------------------------------------
+
+HEADLINE_LIMIT = 4096  # bytes: round 4's line carried eight config records, grew to 22 KB and the driver kept only its tail
+
+
+def headline(line, records=()):
+    """The LAST stdout line: the headline alone, under HEADLINE_LIMIT bytes whatever the records hold.  Everything the contract
+    names stays; of the `configs` records only wall GCUPS per config (`configs_gcups`).  Optional objects are dropped, least
+    important first, should the line ever grow past the limit again."""
+    short = dict(line)
+    short.pop("configs", None)
+    summary = {}
+    for record in records:
+        if "value" in record and "config" in record:
+            key = str(record["config"]) + ("@node" if str(record.get("entry_point", "")).startswith("szs_rocm_node") else "")
+            summary[key] = record["value"]
+        elif "error" in record:
+            summary[str(record.get("config"))] = "error"
+    if summary:
+        short["configs_gcups"] = summary
+    for optional in ("reference_style", "same_tapes", "run_seconds", "configs_gcups", "planner", "host_overhead_ms_per_step"):
+        if len(json.dumps(short)) < HEADLINE_LIMIT:
+            break
+        short.pop(optional, None)
+    for inner in ("myers_ceiling", "valu"):
+        if len(json.dumps(short)) < HEADLINE_LIMIT:
+            break
+        short["roofline"] = {k: v for k, v in short.get("roofline", {}).items() if k != inner}
+    text = json.dumps(short)
+    assert len(text) < HEADLINE_LIMIT, f"headline line is {len(text)} bytes"
+    return text
+
+
+def emit(line, records, details_path):
+    """Prints one `{"configs_record": ...}` line per record, then - LAST - the headline alone; writes both, untrimmed, to
+    `details_path` (gpurun_out/bench_configs.json by default; merged back from the GPU box)."""
+    for record in records:
+        print(json.dumps({"configs_record": record}), flush=True)
+    if details_path:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(details_path)), exist_ok=True)
+            with open(details_path, "w") as handle:
+                json.dump({"headline": line, "configs": list(records)}, handle, indent=1)
+        except OSError as problem:
+            print(json.dumps({"note": f"details file not written: {problem!r}"}), flush=True)
+    print(headline(line, records), flush=True)
 
 
 if __name__ == "__main__":

@@ -1,11 +1,12 @@
-// tests/native/workloads_mt19937.cpp - the synthetic batches of SURVEY.md section 8(d) from std::mt19937_64, so that a C++
+// csrc/workloads/workloads_mt19937.cpp - the synthetic batches of SURVEY.md section 8(d) from std::mt19937_64, so that a C++
 // program can reproduce them without this repository's Python: `workloads.config(n, generator="mt19937_64")` calls in here.
 //
 // The mapping from the engine to strings is spelled out (the standard leaves uniform_int_distribution to the implementation):
 //   one engine per tape, seeded with  seed = 1000 x config + side  (side: 0 queries, 1 candidates);
 //   lengths first:  length[i] = low + engine() % (high - low + 1),  i = 0 .. count - 1;
 //   then the bytes: byte[j]  = alphabet[engine() % alphabet_size],  j over the whole tape in order.
-// Test infrastructure: nothing in the product links or loads this.
+// Built into stringzilla_amd/lib/libszs_workloads_mt19937.so beside the scoring library (csrc/Makefile); the scoring library
+// itself neither links nor loads it - only stringzilla_amd/workloads.py does, for bench.py and the tests.
 #include <cstdint>
 #include <random>
 

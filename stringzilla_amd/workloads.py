@@ -6,6 +6,7 @@ baseline leg so that all three see byte-identical batches.
 
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -16,6 +17,7 @@ from . import Strs
 ASCII_PRINTABLE = np.arange(0x20, 0x7F, dtype=np.uint8)
 AMINO_ACIDS = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)
 NUCLEOTIDES = np.frombuffer(b"ACGT", dtype=np.uint8)
+MT19937_64_LIBRARY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libszs_workloads_mt19937.so")
 
 
 def random_tape(rng: np.random.Generator, count: int, low: int, high: int, alphabet: np.ndarray) -> Strs:
@@ -55,13 +57,15 @@ def zipf_utf8_tape(rng: np.random.Generator, count: int, low: int = 8, high: int
 
 
 def mt19937_64_tape(seed: int, count: int, low: int, high: int, alphabet: np.ndarray) -> Strs:
-    """The same kind of tape from `std::mt19937_64` (tests/native/workloads_mt19937.cpp spells the mapping out), for callers
-    that want to reproduce a batch from C++: SURVEY.md section 8(d) names that generator."""
+    """The same kind of tape from `std::mt19937_64` (csrc/workloads/workloads_mt19937.cpp spells the mapping out), for callers
+    that want to reproduce a batch from C++: SURVEY.md section 8(d) names that generator.  Raises when the helper library
+    (built by csrc/Makefile beside the scoring library) is missing: a batch of another generator under the same name is no
+    substitute."""
     import ctypes
-    import os
 
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "native", "bin", "libworkloads_mt19937.so")
-    fill = ctypes.CDLL(path).szs_workload_mt19937_64
+    if not os.path.exists(MT19937_64_LIBRARY):
+        raise FileNotFoundError(f"{MT19937_64_LIBRARY} is not built (make -C stringzilla_amd/csrc)")
+    fill = ctypes.CDLL(MT19937_64_LIBRARY).szs_workload_mt19937_64
     fill.restype = ctypes.c_uint64
     fill.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
     alphabet = np.ascontiguousarray(alphabet, dtype=np.uint8)

@@ -1,0 +1,98 @@
+"""bench.py's output contract, without a GPU: the LAST stdout line is the headline alone - parseable, under 4 KB, carrying
+`roofline` and `cpu_baseline` - whatever the `configs` records hold (round 4's line carried them all, grew to 22 KB, and the
+driver's record of the round kept only its tail).  The records travel on EARLIER lines and in a details file."""
+import io
+import json
+import os
+import subprocess
+import sys
+from contextlib import redirect_stdout
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def canned_line():
+    """A headline of the richest shape bench.py builds (every optional object present, long names)."""
+    return {
+        "metric": "DP cell-updates/s (GCUPS) on 1M-pair Levenshtein batch", "value": 82383.1, "unit": "GCUPS", "n_gpus": 8, "steps": 200,
+        "warmup": 20, "ms_per_step": 0.2084, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u32 bit-vectors (u64 results)", "data": "synthetic",
+        "config": {"workload": "cfg2: 1024x1024 ASCII len U[96,160], Levenshtein unit [std::mt19937_64]", "pairs_per_gpu": 1048576,
+                   "cells_per_gpu": 17151815600, "sharding": "query row blocks, candidates replicated",
+                   "entry_point": "szs_levenshtein_distances_u32tape", "generator": "mt19937_64", "stream": "fresh batches alternate",
+                   "same_tapes_gcups": 85032.2},
+        "roofline": {"bound": "hbm", "achieved": 1614.96, "peak": 8000.0, "unit": "GB/s", "frac": 0.20187, "traffic": 10330183,
+                     "kernel_ms": 0.1765, "algorithmic_bytes": 284993536, "launches_per_step": 1, "kernel_gcups": 97193.2, "pmc_stale": False,
+                     "pmc_source": "profiles/r05/pmc_configs.json", "kernel": "levenshtein_myers_short_kernel<false>",
+                     "valu": {"bound": "int VALU issue, class-weighted", "frac": 0.6727, "achieved_Tlane_ops_per_s": 41.04,
+                              "peak_Tlane_ops_per_s": 61.0, "lane_ops_per_cell": 0.4222, "wave_instructions_per_call": 113149755,
+                              "full_rate": 513, "half_rate": 208, "lds_busy": 0.3516, "lds_conflict": 0.65, "wait_to_issue": 0.5567, "parked": 0.1612},
+                     "peak_measured": 5186.6, "frac_of_measured_peak": 0.311372,
+                     "myers_ceiling": {"bound": "int VALU issue, measured (valu_peak.hip)", "achieved_Tcells_per_s_full_width": 108.62,
+                                       "peak_Tcells_per_s_full_width": 124.2, "frac": 0.8745, "useful_fraction_of_width": 0.8948}},
+        "host_overhead_ms_per_step": 0.0319, "planner": "device, speculated", "results_checksum": 136945828.0,
+        "reference_style": {"throughput_gb_s": 1287.1, "efficiency_gops_s": 82383.1, "pairs_per_second": 5031779249.0, "kernel_gcups": 97193.2},
+        "same_tapes": {"ms_per_step": 0.2017, "value": 85032.2, "unit": "GCUPS", "calls": 60, "planner_mode": 3},
+        "cpu_baseline": {"value": 171.57, "unit": "GCUPS", "cores": 256, "kind": "reference", "tier": "icelake (AVX-512)", "spread": [165.35, 178.43],
+                         "sample": "full 1024x1024 batch; median of 20 runs x 11 passes; cells verified equal to the GPU's", "sample_rows": 1024,
+                         "sample_columns": 1024, "runs": 20, "passes_per_run": 11, "verified": True,
+                         "serial_1_thread": {"value": 19.414, "unit": "GCUPS", "cores": 1, "sample": "4 rows x 64 candidates x 50 passes, serial tier, verified"}},
+        "run_seconds": {"total": 93.1, "gpu_legs": 41.0, "cpu_baselines": 52.1},
+    }
+
+
+def canned_records(count=12, padding=2500):
+    return [{"config": index, "workload": "w" * 80, "entry_point": "szs_needleman_wunsch_scores_u32tape", "value": 1000.0 + index,
+             "unit": "GCUPS", "roofline": {"note": "x" * padding}, "cpu_baseline": {"value": 1.0, "sample": "y" * 200}} for index in range(3, 3 + count)]
+
+
+def test_the_headline_is_short_parseable_and_complete():
+    text = bench.headline(canned_line(), canned_records())
+    assert len(text) < 4096 and "\n" not in text
+    line = json.loads(text)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline", "results_checksum"):
+        assert key in line, key
+    assert "configs" not in line and line["configs_gcups"]["3"] == 1003.0
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "algorithmic_bytes", "peak_measured", "valu"):
+        assert key in line["roofline"], key
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in line["cpu_baseline"], key
+    assert line["config"]["workload"].startswith("cfg2") and line["config"]["entry_point"] and line["config"]["generator"]
+
+
+def test_the_headline_sheds_optional_objects_before_it_breaks_the_limit():
+    fat = canned_line()
+    fat["reference_style"]["padding"] = "z" * 3000
+    line = json.loads(bench.headline(fat, canned_records(40)))
+    assert "reference_style" not in line and "roofline" in line and "cpu_baseline" in line and line["value"] == 82383.1
+
+
+def test_records_go_first_and_to_the_details_file(tmp_path):
+    details = tmp_path / "out" / "bench_configs.json"
+    captured = io.StringIO()
+    with redirect_stdout(captured):
+        bench.emit(canned_line(), canned_records(3), str(details))
+    lines = captured.getvalue().splitlines()
+    assert len(lines) == 4 and all(json.loads(text)["configs_record"]["config"] in (3, 4, 5) for text in lines[:3])
+    last = json.loads(lines[-1])
+    assert last["metric"].startswith("DP cell-updates/s") and len(lines[-1]) < 4096
+    stored = json.loads(details.read_text())
+    assert stored["headline"]["value"] == last["value"] and len(stored["configs"]) == 3
+    # what the driver keeps is the tail of stdout: whatever it cuts, the last line survives whole
+    assert captured.getvalue()[-8081:].splitlines()[-1] == lines[-1]
+
+
+def test_more_gpus_than_the_box_has_is_a_parseable_error_not_a_traceback():
+    """`python bench.py --gpus 2` with no launcher starts its own ranks; here there is no GPU at all, so it must say so in one
+    JSON line and exit 2 (it used to die on `assert world == args.gpus`)."""
+    environment = {key: value for key, value in os.environ.items() if key not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    environment["HIP_VISIBLE_DEVICES"] = ""  # also on a GPU box: none visible
+    done = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=ROOT,
+                          capture_output=True, text=True, timeout=600, env=environment)
+    assert done.returncode == 2, done.stderr[-2000:]
+    line = json.loads(done.stdout.strip().splitlines()[-1])
+    assert "error" in line and line["n_gpus"] == 2 and line["visible_gpus"] == 0
+    assert "Traceback" not in done.stderr

@@ -22,36 +22,45 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("ranks", [2, 8])
-def test_ranks_on_one_device(ranks):
-    """Two ranks, and EIGHT - the world size BASELINE.json's curve ends at, never run anywhere before round 4."""
+@pytest.mark.parametrize("ranks,launcher", [(2, "torchrun"), (8, "torchrun"), (2, "self")])
+def test_ranks_on_one_device(ranks, launcher):
+    """Two ranks, and EIGHT - the world size BASELINE.json's curve ends at, never run anywhere before round 4 - under the driver's
+    launcher; and plain `python bench.py --gpus 2`, which starts its own ranks (round 5: it used to assert on WORLD_SIZE)."""
     import stringzilla_amd as szs
     from stringzilla_amd import matrices, workloads
 
     scale = 1 / 8
-    command = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
-               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "5", "--warmup", "2",
-               "--backend", "gloo", "--same-device", "--extra-scale", str(scale), "--extra-seconds", "0.2", "--cpu-seconds", "1"]
-    done = subprocess.run(command, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    options = ["--gpus", str(ranks), "--steps", "5", "--warmup", "2", "--backend", "gloo", "--same-device", "--extra-scale", str(scale),
+               "--extra-seconds", "0.2", "--cpu-seconds", "1", "--extra-cpu-seconds", "0.5"]
+    if launcher == "torchrun":
+        command = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+                   "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + options
+    else:
+        command = [sys.executable, os.path.join(ROOT, "bench.py")] + options
+    environment = {key: value for key, value in os.environ.items() if key not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    done = subprocess.run(command, cwd=ROOT, capture_output=True, text=True, timeout=900, env=environment)
     assert done.returncode == 0, done.stdout[-3000:] + done.stderr[-3000:]
-    line = json.loads([text for text in done.stdout.splitlines() if text.startswith("{")][-1])
+    printed = [json.loads(text) for text in done.stdout.splitlines() if text.startswith("{")]
+    line = printed[-1]
+    assert len(json.dumps(line)) < 4096 and "configs" not in line  # the last line is the headline alone (tests/test_bench_line.py)
     assert line["n_gpus"] == ranks and line["scaling"] == "weak" and line["value"] > 0
     assert line["config"]["pairs_per_gpu"] == 1024 * 1024
     assert "alternate" in line["config"]["stream"] and line["same_tapes"]["value"] > 0  # the headline is the fresh-batch stream
     assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1     # reported on rank 0 whatever N (VERDICT r2)
+    assert line["roofline"]["frac"] > 0
 
     gpu = szs.DeviceScope(gpu_device=0)
     expected = {}
     for config in (4, 5):
         # the batches bench.py scores: std::mt19937_64 for configs 1-4 when the helper library is built, numpy otherwise
-        helper = os.path.join(ROOT, "tests", "native", "bin", "libworkloads_mt19937.so")
-        load = workloads.config(config, scale=scale, generator="mt19937_64" if config <= 4 and os.path.exists(helper) else "numpy")
+        load = workloads.config(config, scale=scale, generator="mt19937_64" if config <= 4 else "numpy")
         if load.kind == "levenshtein":
             engine = szs.LevenshteinDistances(**load.costs, capabilities=gpu)
         else:
             engine = szs.SmithWatermanScores(*matrices.by_name(load.table), **load.costs, capabilities=gpu)
         expected[config] = (int(engine(load.queries, load.candidates, device=gpu).view(np.int64).sum()), load.cells, len(load.queries))
-    records = line["configs"]
+    records = [entry["configs_record"] for entry in printed if "configs_record" in entry]
+    assert set(line["configs_gcups"]) >= {"4", "5", "4@node", "5@node"}
     strong = {record["config"]: record for record in records if record.get("scaling") == "strong" and "sharding" in record}
     node = {record["config"]: record for record in records if record.get("entry_point", "").startswith("szs_rocm_node")}
     for config in (4, 5):
