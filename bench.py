@@ -261,9 +261,11 @@ def cpu_baseline(load, gpu_matrix, seconds, cell_bits=0, with_serial=True):
     whole = len(rows) == len(q_lengths) and len(columns) == len(c_lengths)
     # A run lasts a quarter of a second or more: a batch the CPU finishes in 30 ms (configs 2, 7, 8) is passed several times back
     # to back per run - timed one pass at a time, 256 threads starting up made the median wander between 340 and 580.  Five or
-    # more runs when the budget allows; a batch whose smallest fair sample already takes a third of the budget gets three.
+    # more runs when the budget allows; a batch whose smallest fair sample already takes a third of the budget gets three, the whole budget: two.
     passes = 1 if first >= 0.25 else int(min(64, np.ceil(0.25 / max(first, 1e-4))))
     repeats = int(max(3 if first * passes > seconds / 5 else 5, min(20, (seconds - first) / max(first * passes, 1e-3))))
+    if first > seconds:  # one run of the smallest fair sample is already the whole budget (config 4: ~10 s): the verified run and one more
+        repeats = 2
     runs = [first] if passes == 1 and first * 3 > seconds else []  # ... the verified run counting as the first of them
     while len(runs) < repeats:
         started = time.perf_counter()

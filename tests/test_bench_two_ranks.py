@@ -23,7 +23,7 @@ def _free_port():
 
 
 @pytest.mark.parametrize("ranks,launcher", [(2, "torchrun"), (8, "torchrun"), (2, "self")])
-def test_ranks_on_one_device(ranks, launcher):
+def test_ranks_on_one_device(ranks, launcher, tmp_path):
     """Two ranks, and EIGHT - the world size BASELINE.json's curve ends at, never run anywhere before round 4 - under the driver's
     launcher; and plain `python bench.py --gpus 2`, which starts its own ranks (round 5: it used to assert on WORLD_SIZE)."""
     import stringzilla_amd as szs
@@ -31,7 +31,8 @@ def test_ranks_on_one_device(ranks, launcher):
 
     scale = 1 / 8
     options = ["--gpus", str(ranks), "--steps", "5", "--warmup", "2", "--backend", "gloo", "--same-device", "--extra-scale", str(scale),
-               "--extra-seconds", "0.2", "--cpu-seconds", "1", "--extra-cpu-seconds", "0.5"]
+               "--extra-seconds", "0.2", "--cpu-seconds", "1", "--extra-cpu-seconds", "0.5",
+               "--details", str(tmp_path / "bench_configs.json")]  # not gpurun_out/bench_configs.json: that is the real run's
     if launcher == "torchrun":
         command = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
                    "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + options
