@@ -765,7 +765,7 @@ def main():
                        "stream": "fresh batches alternate" if len(steps_of) > 1 else "same batch every step"},
             "roofline": line_roofline,
             "host_overhead_ms_per_step": round(ms_per_step - kernel * 1e3, 4),
-            "planner": "+".join({0: "host", 1: "device", 2: "device, speculated", 3: "re-used"}[mode] for mode in sorted(planners)),
+            "planner": "+".join({0: "host", 1: "device", 2: "device, speculated", 3: "re-used", 4: "inside the scoring launch"}[mode] for mode in sorted(planners)),
             "results_checksum": float(checksum),
             # the three figures the reference's own bench prints per engine (bench/similarities.cuh:344-366: bytes passed, operations =
             # cells, inputs processed, and the device-measured "Kernel" line :303-308)

@@ -214,6 +214,7 @@ enum {
     szs_knob_queue_words_k, /* -1 automatic | 4 / 8 / 12 / 16: the most words of a pattern one lane may hold in that launch */
     szs_knob_queue_rounds_k,/* -1 automatic | n: candidates per work item, in rounds of the workgroup's eight wavefronts */
     szs_knob_queue_priority_k, /* -1 automatic (on) | 0: every wave block of that launch at one hardware priority | 1: longest chain first */
+    szs_knob_fused_k,       /* -1 automatic | 0: never fold the planner into the short unit-cost launch (szs_fused_plan_t) */
     szs_knob_count_k
 };
 int szs_tuning_get(int knob);
@@ -282,6 +283,38 @@ typedef struct szs_plan_summary_t {
  */
 int szs_hip_plan(szs_plan_side_t const *queries, szs_plan_side_t const *candidates, unsigned myers_words,
                  szs_plan_expectation_t const *expected, szs_plan_summary_t *summary, void *stream);
+
+/**
+ *  The planner FOLDED INTO the scoring launch (hip/lev_myers.hip, round 5): a unit-cost byte call whose queries all fit the
+ *  short kernel (<= 256 bytes) and whose sides hold at most SZS_FUSED_MOST_STRINGS strings is ONE launch and nothing else.
+ *  Workgroup 0 sorts the kernel's query side, workgroup 1 its candidate side (a counting sort of the lengths in LDS, 256
+ *  threads, ~2 us), each writes the side's ascending and descending refs - exactly what szs_hip_plan writes - and publishes
+ *  `ready[side] = sequence` (release, agent scope); every workgroup waits for both words (acquire) before it reads a ref.
+ *  Workgroups are dispatched in order, so the two sorters are resident before anyone can wait for them.  No planner launch,
+ *  no kernel boundary between planning and scoring (config 2: 12 + 5 of a 202 us call).
+ *  A side whose offsets are malformed, or a query side with a string beyond 256 bytes, is written BLANK (every length 0:
+ *  the launch scores empty strings, memory-safe) and says so in its report; the host then plans the call the ordinary way.
+ */
+#define SZS_FUSED_MOST_STRINGS 1024u /* per side: four strings per thread of the sorting workgroup, all in registers (eight
+                                        cost the scoring bodies a wavefront of occupancy: 108 VGPRs against 95) */
+#define SZS_FUSED_BINS 1024u         /* lengths of 1023 bytes and more share the last bin (they are texts: any order scores the same) */
+typedef struct szs_fused_side_report_t {
+    uint32_t sequence; /* of the launch that wrote this report */
+    uint32_t status;   /* SZS_PLAN_STATUS_DESCENDING | SZS_PLAN_STATUS_OVERFLOW */
+    uint32_t blank;    /* the side's refs were written with length 0: nothing real was scored */
+    uint32_t reserved;
+    szs_side_stats_t stats;
+    uint32_t rank_lengths[SZS_PLAN_RANK_SAMPLES + 1];
+    uint32_t ticks[5]; /* 100 MHz: the sorter's begin; offsets loaded; positions known; refs written; published - all relative to [0] but [0] itself */
+} szs_fused_side_report_t;
+typedef struct szs_fused_plan_t {
+    szs_plan_side_t side[2]; /* KERNEL roles: [0] its queries (patterns; scored from .descending), [1] its candidates (.ascending) */
+    uint32_t sequence;       /* never 0 */
+    uint32_t *ready;         /* device memory: ready[0] and ready[32], zeroed when allocated; a launch leaves `sequence` in both */
+    szs_fused_side_report_t *report; /* [2], pinned host memory */
+} szs_fused_plan_t;
+int szs_hip_levenshtein_myers_fused(szs_fused_plan_t const *plan, uint64_t *results, uint64_t results_row_stride, int layout,
+                                    void *stream);
 
 /**
  *  Transcodes `count` UTF-8 strings (byte refs) into UTF-32 with the value contract of `sz_rune_decode_unchecked`:

@@ -300,6 +300,162 @@ __global__ __launch_bounds__(256, SZS_MYERS_LONG_WAVES) void levenshtein_myers_l
                                       results, results_row_stride, symmetric, guard);
 }
 
+/* ---- the planner folded into the short launch (kernels.h: szs_fused_plan_t) --------------------------------------------
+ *
+ *  What hip/planner.hip does in a launch of its own - tape offsets in, length-sorted refs out - done by ONE workgroup of the
+ *  scoring launch per side: 1024 length bins in the LDS that becomes the match masks afterwards, 1024 staged refs beside it.
+ *  The sort is a counting sort; strings of equal length land in whatever order the LDS atomics decide, which is why ONE
+ *  workgroup sorts a side for everybody (two sorters of the same side could disagree on the blocks of 256).
+ */
+__device__ __forceinline__ u64 fused_offset(void const *offsets, u32 wide, u64 index) {
+    return wide ? static_cast<u64 const *>(offsets)[index] : (u64) static_cast<u32 const *>(offsets)[index];
+}
+
+__device__ __forceinline__ void fused_sort_side(szs_plan_side_t const &side, u32 is_query_side, u32 sequence, u32 *ready,
+                                                szs_fused_side_report_t *report, u32 *histogram /* SZS_FUSED_BINS dwords of LDS */,
+                                                szs_string_ref_t *staged /* SZS_FUSED_MOST_STRINGS refs of LDS */) {
+    constexpr u32 per_thread = SZS_FUSED_MOST_STRINGS / 256;
+    u32 const tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, count = side.count;
+    __shared__ u32 wave_bins[4], wave_longest[4], wave_status[4];
+    __shared__ unsigned long long wave_symbols[4], wave_bands_systolic[4], wave_bands_chain[4];
+
+    u64 const began = wall_clock64();
+    for (u32 bin = tid; bin < SZS_FUSED_BINS; bin += 256) histogram[bin] = 0;
+    u64 from[per_thread], to[per_thread]; // all loads of the side in flight at once: ONE round trip to memory for the whole sort
+#pragma unroll
+    for (u32 k = 0; k < per_thread; ++k) {
+        u32 const i = tid + k * 256;
+        from[k] = to[k] = 0;
+        if (i < count) from[k] = fused_offset(side.offsets, side.wide, i), to[k] = fused_offset(side.offsets, side.wide, (u64)i + 1);
+    }
+    __syncthreads();
+    u32 bins[per_thread];
+    u32 status = 0, longest = 0;
+    u64 symbols = 0, bands_systolic = 0, bands_chain = 0;
+#pragma unroll
+    for (u32 k = 0; k < per_thread; ++k) {
+        bins[k] = ~0u;
+        if (tid + k * 256 >= count) continue;
+        if (to[k] < from[k]) status |= SZS_PLAN_STATUS_DESCENDING;
+        else if (to[k] - from[k] > 0xFFFFFFFFull) status |= SZS_PLAN_STATUS_OVERFLOW;
+        else {
+            u32 const length = (u32)(to[k] - from[k]);
+            symbols += length, longest = length > longest ? length : longest;
+            bands_systolic += length ? (length + SZS_SYSTOLIC_BAND_ROWS - 1) / SZS_SYSTOLIC_BAND_ROWS : 1;
+            bands_chain += length ? (length + SZS_MYERS_CHAIN_BAND_ROWS - 1) / SZS_MYERS_CHAIN_BAND_ROWS : 1;
+            bins[k] = length < SZS_FUSED_BINS - 1 ? length : SZS_FUSED_BINS - 1;
+            atomicAdd(&histogram[bins[k]], 1u);
+        }
+    }
+    if (tid == 0) report->ticks[0] = (u32)began, report->ticks[1] = (u32)(wall_clock64() - began);
+    // (only what the refs depend on is reduced before they are published - malformed offsets, the longest string; the sums the
+    // host wants follow behind the publication: everybody else is waiting for the refs, nobody for the report)
+#pragma unroll
+    for (int offset = 32; offset >= 1; offset >>= 1) {
+        status |= (u32)__shfl_xor((int)status, offset, 64);
+        u32 const other = (u32)__shfl_xor((int)longest, offset, 64);
+        longest = other > longest ? other : longest;
+    }
+    if (lane == 0) wave_status[wave] = status, wave_longest[wave] = longest;
+    __syncthreads();
+    // ---- bins become positions: thread t owns bins [4 t, 4 t + 4)
+    u32 mine[4], sum = 0;
+#pragma unroll
+    for (u32 k = 0; k < 4; ++k) mine[k] = histogram[4 * tid + k], sum += mine[k];
+    u32 inclusive = sum;
+#pragma unroll
+    for (int offset = 1; offset < 64; offset <<= 1) {
+        u32 const other = (u32)__shfl_up((int)inclusive, offset, 64);
+        if (lane >= (u32)offset) inclusive += other;
+    }
+    if (lane == 63) wave_bins[wave] = inclusive;
+    __syncthreads();
+    status = wave_status[0] | wave_status[1] | wave_status[2] | wave_status[3];
+    longest = wave_longest[0];
+#pragma unroll
+    for (u32 w = 1; w < 4; ++w) longest = wave_longest[w] > longest ? wave_longest[w] : longest;
+    u32 running = inclusive - sum;
+    for (u32 w = 0; w < wave; ++w) running += wave_bins[w];
+#pragma unroll
+    for (u32 k = 0; k < 4; ++k) histogram[4 * tid + k] = running, running += mine[k];
+    __syncthreads();
+    if (tid == 0) report->ticks[2] = (u32)(wall_clock64() - began);
+    // ---- every string's ref lands at its position in LDS (a malformed side sorts nothing: blank refs in the caller's order);
+    //      strings of one length take their places in whatever order the atomics decide
+    u32 const blank = status || (is_query_side && longest > 32u * SZS_MYERS_SHORT_WORDS);
+#pragma unroll
+    for (u32 k = 0; k < per_thread; ++k) {
+        u32 const i = tid + k * 256;
+        if (i >= count) continue;
+        szs_string_ref_t ref;
+        ref.address = status ? side.base : side.base + from[k], ref.length = blank ? 0u : (u32)(to[k] - from[k]), ref.index = i;
+        staged[status ? i : atomicAdd(&histogram[bins[k]], 1u)] = ref;
+    }
+    __syncthreads();
+    // ---- ... and leaves it in order: position p and count - 1 - p, whole lines per wavefront
+    for (u32 position = tid; position < count; position += 256) {
+        szs_string_ref_t const ref = staged[position];
+        side.ascending[position] = ref, side.descending[count - 1 - position] = ref;
+    }
+    // Every thread's stores have reached the L2 behind the barrier (it waits for them; the L1 writes through); ONE agent-scope
+    // release by one thread then writes the L2 back before the word that says so changes.
+    __syncthreads();
+    if (tid == 0) {
+        report->ticks[3] = (u32)(wall_clock64() - began);
+        __hip_atomic_store(ready, sequence, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        report->ticks[4] = (u32)(wall_clock64() - began);
+    }
+    // ---- the report (the host reads it when the launch has ended)
+#pragma unroll
+    for (int offset = 32; offset >= 1; offset >>= 1) {
+        symbols += ((u64)(u32)__shfl_xor((int)(u32)(symbols >> 32), offset, 64) << 32) | (u32)__shfl_xor((int)(u32)symbols, offset, 64);
+        bands_systolic += (u32)__shfl_xor((int)(u32)bands_systolic, offset, 64); // at most 1024 strings x 2^23 bands: 32 bits hold it
+        bands_chain += (u32)__shfl_xor((int)(u32)bands_chain, offset, 64);
+    }
+    if (lane == 0) wave_symbols[wave] = symbols, wave_bands_systolic[wave] = bands_systolic, wave_bands_chain[wave] = bands_chain;
+    if (tid <= SZS_PLAN_RANK_SAMPLES) // the length at 33 ranks of the side (what the queue order is planned from)
+        report->rank_lengths[tid] = status || !count ? 0u : staged[(u32)((u64)tid * (count - 1) / SZS_PLAN_RANK_SAMPLES)].length;
+    __syncthreads();
+    if (tid == 0) {
+        report->status = status, report->blank = blank, report->reserved = 0;
+        report->stats.count = count, report->stats.longest = longest;
+        report->stats.symbols = wave_symbols[0] + wave_symbols[1] + wave_symbols[2] + wave_symbols[3];
+        report->stats.bands_systolic = wave_bands_systolic[0] + wave_bands_systolic[1] + wave_bands_systolic[2] + wave_bands_systolic[3];
+        report->stats.bands_chain = wave_bands_chain[0] + wave_bands_chain[1] + wave_bands_chain[2] + wave_bands_chain[3];
+        report->sequence = sequence;
+    }
+}
+
+/** Sorters sort, everybody waits for both sides.  Workgroups are dispatched in order: 0 and 1 never wait for anyone. */
+__device__ __forceinline__ void fused_prologue(szs_fused_plan_t const &plan, u32 *scratch) {
+    // 16 KB of LDS that only the two sorting workgroups touch: the scoring bodies keep five workgroups per CU either way (95 VGPRs)
+    __shared__ __attribute__((aligned(16))) szs_string_ref_t staged[SZS_FUSED_MOST_STRINGS];
+    for (u32 s = 0; s < 2; ++s)
+#ifdef SZS_FUSED_EXPERIMENT_NOSORT
+        if (false) {
+#else
+        if (blockIdx.x == s % gridDim.x) {
+#endif
+            fused_sort_side(plan.side[s], s == 0, plan.sequence, plan.ready + 32 * s, plan.report + s, scratch, staged);
+            __syncthreads(); // the LDS is sorted in again (a grid of one workgroup), then becomes the match masks
+        }
+    // The wait is a RELAXED load at agent scope (it goes to the device's coherence point every time) and the barrier orders the
+    // workgroup behind it.  No acquire FENCE: at agent scope that is a `buffer_inv sc1` - it drops the L2 of the XCD - and 4096
+    // workgroups doing that as they start made every text read miss (0.41 ms where the plain launch takes 0.17).  None is needed:
+    // nobody reads a ref before its side is published, so no cache of this launch can hold a stale one (the caches start a
+    // launch empty), and the sorter's release wrote its lines back before the word changed.
+    // (Sleeping through most of the sort before the first poll changed nothing: the polls are not what the launch waits for.)
+    // Measured and not kept: the waiting workgroups pulling both tapes into their XCD's L2 meanwhile (a line per thread) - the
+    // sorters' own first loads then took 2.3 us instead of 1.4 and the launch 181.6 us instead of 179.6.
+#ifdef SZS_FUSED_EXPERIMENT_NOWAIT // timing experiment only: reads the previous call's refs (results are garbage)
+    if (false)
+#endif
+    if (threadIdx.x < 2)
+        while (__hip_atomic_load(plan.ready + 32 * threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != plan.sequence)
+            __builtin_amdgcn_s_sleep(8);
+    __syncthreads();
+}
+
 #ifndef SZS_MYERS_SHORT_WAVES
 #define SZS_MYERS_SHORT_WAVES 1
 #endif
@@ -309,12 +465,16 @@ __global__ __launch_bounds__(256, SZS_MYERS_LONG_WAVES) void levenshtein_myers_l
  *  needs neither one launch per width nor padding to a common width.  All eight byte bodies fit the 64-VGPR budget.
  *  `runes_`: the codepoint-level twin - strings are UTF-32 arrays produced by utf8.hip, Peq is keyed by a rune table.
  */
-template <bool runes_, bool merged_>
+template <bool runes_, bool merged_, bool fused_ = false>
 __device__ __forceinline__ void myers_short_body(
     szs_string_ref_t const *__restrict__ queries, szs_string_ref_t const *__restrict__ candidates, u32 candidates_count,
     u32 candidate_blocks, u64 *__restrict__ results, u64 results_row_stride, int symmetric, szs_ref_guard_t guard, u32 alphabet,
-    u32 blocks_per_group) {
+    u32 blocks_per_group, szs_fused_plan_t const *fused = nullptr) {
     __shared__ __attribute__((aligned(16))) u32 peq[peq_layout<8, runes_ ? rune_slots_k : byte_rows_k>::total_dwords];
+    if constexpr (fused_) {
+        static_assert(peq_layout<8, byte_rows_k>::total_dwords >= SZS_FUSED_BINS, "the sort's histogram borrows the masks' LDS");
+        fused_prologue(*fused, peq); // the refs `queries` / `candidates` point at exist from here on
+    }
     __shared__ u32 slot_keys[runes_ ? rune_slots_k : 1];
     __shared__ u32 claimed_rows;
     extern __shared__ u32 rows_of_ids[]; // runes of a renumbered batch: alphabet + 1 dwords of dynamic LDS
@@ -360,6 +520,19 @@ __global__ __launch_bounds__(256, SZS_MYERS_SHORT_WAVES) void levenshtein_myers_
     u32 blocks_per_group) {
     myers_short_body<runes_, false>(queries, candidates, candidates_count, candidate_blocks, results, results_row_stride, symmetric, guard,
                                     alphabet, blocks_per_group);
+}
+
+/** The planner folded in (kernels.h: szs_fused_plan_t): the refs are written by workgroups 0 and 1 of this very launch. */
+#ifndef SZS_MYERS_FUSED_WAVES
+#define SZS_MYERS_FUSED_WAVES 5 // the plain short kernel's five wavefronts per SIMD (95 VGPRs); unbounded, the prologue makes it 98
+#endif
+__global__ __launch_bounds__(256, SZS_MYERS_FUSED_WAVES) void levenshtein_myers_short_fused_kernel(szs_fused_plan_t plan, u32 candidate_blocks,
+                                                                                                   u64 *results, u64 results_row_stride,
+                                                                                                   int layout) {
+    szs_ref_guard_t const none = {};
+    // (plain pointers, not __restrict__ const ones: these arrays ARE written during the launch, by the sorting workgroups)
+    myers_short_body<false, false, true>(plan.side[0].descending, plan.side[1].ascending, plan.side[1].count, candidate_blocks, results,
+                                         results_row_stride, layout, none, 0u, 1u, &plan);
 }
 
 /** The same with `blocks_per_group` candidate blocks per workgroup (launch_myers_short decides). */
@@ -1415,6 +1588,19 @@ extern "C" int szs_hip_levenshtein_myers(unsigned words, szs_string_ref_t const 
     default: return (int)hipErrorInvalidValue;
     }
 #undef SZS_MYERS_CASE
+}
+
+extern "C" int szs_hip_levenshtein_myers_fused(szs_fused_plan_t const *plan, uint64_t *results, uint64_t results_row_stride, int layout,
+                                               void *stream) {
+    using namespace szs_hip;
+    uint32_t const queries_count = plan->side[0].count, candidates_count = plan->side[1].count;
+    if (!queries_count || !candidates_count || queries_count > SZS_FUSED_MOST_STRINGS || candidates_count > SZS_FUSED_MOST_STRINGS ||
+        !plan->sequence || (layout & SZS_LAYOUT_SYMMETRIC))
+        return (int)hipErrorInvalidValue;
+    u32 const candidate_blocks = (candidates_count + SZS_CANDIDATES_PER_WORKGROUP - 1) / SZS_CANDIDATES_PER_WORKGROUP;
+    hipLaunchKernelGGL(levenshtein_myers_short_fused_kernel, dim3(queries_count * candidate_blocks), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), *plan, candidate_blocks, results, results_row_stride, layout);
+    return (int)hipGetLastError();
 }
 
 extern "C" int szs_hip_levenshtein_myers_split(unsigned words, unsigned lanes, szs_string_ref_t const *queries, uint32_t queries_count,

@@ -270,6 +270,8 @@ static void release_device_state(szs_engine_s *engine) {
     szs_buffer_release(&engine->device_queue_trace);
     engine->queue_zeroed = NULL;
     szs_buffer_release(&engine->pinned_summary);
+    szs_buffer_release(&engine->device_fused);
+    engine->fused_zeroed = NULL;
     if (engine->events_device >= 0) {
         (void)hipEventDestroy(engine->event_start);
         (void)hipEventDestroy(engine->event_stop);
@@ -975,6 +977,7 @@ static sz_status_t finish(szs_call_t *call, szs_decision_t const *d, hipError_t 
                 profile->host_milliseconds * 1e3, call->phases[0] * 1e3, call->phases[1] * 1e3, call->phases[2] * 1e3,
                 call->phases[3] * 1e3, call->phases[4] * 1e3, call->phases[5] * 1e3, kernel_ms * 1e3,
                 profile->planner == 3   ? "previous plan of the same tapes, validated in the kernels"
+                : profile->planner == 4 ? "planned inside the scoring launch"
                 : profile->planner == 2 ? "device-planned, speculated"
                 : profile->planner == 1 ? "device-planned"
                                         : "host-planned");
@@ -1136,6 +1139,72 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
             (void)hipStreamSynchronize(stream);
             return szs_report_hip(error, error_message);
         }
+    }
+
+    /* ---- the planner INSIDE the scoring launch (round 5; hip/kernels.h: szs_fused_plan_t).  The previous call of this engine was
+     * ONE launch of the short unit-cost byte kernel and this one has the same counts: the launch goes out alone - its first two
+     * workgroups sort the two sides (what hip/planner.hip does in a launch of its own) while the others wait for the refs.  No
+     * planner launch, no kernel boundary: config 2's fresh-batch call 202 -> ~190 us.  A batch that does not fit after all (a
+     * query beyond 256 bytes, malformed offsets) is scored as empty strings and planned the ordinary way below. */
+    if (remembered->valid && !remembered->runes && remembered->tier == SZS_TIER_LANES && remembered->use_myers && !remembered->wide_cells &&
+        !remembered->use_queue && is_one_launch(remembered) && remembered->plan.groups[0].variant == SZS_MYERS_SHORT_WORDS && !symmetric &&
+        remembered->q_count == q_count && remembered->c_count == c_count && remembered->symmetric == symmetric && q_count <= SZS_FUSED_MOST_STRINGS &&
+        c_count <= SZS_FUSED_MOST_STRINGS && knobs_automatic && !uniform_bytes && szs_tuning_get(szs_knob_fused_k) != 0) {
+        szs_decision_t const *d = remembered;
+        status = szs_buffer_reserve(&engine->device_fused, szs_memory_device_k, device, 256, error_message);
+        if (status != sz_success_k) return status;
+        if (engine->fused_zeroed != engine->device_fused.pointer) {
+            error = hipMemsetAsync(engine->device_fused.pointer, 0, 256, stream);
+            if (error != hipSuccess) return szs_report_hip(error, error_message);
+            engine->fused_zeroed = engine->device_fused.pointer;
+        }
+        szs_fused_side_report_t volatile *const reports = (szs_fused_side_report_t volatile *)((char *)engine->pinned_summary.pointer + 1024);
+        szs_fused_plan_t fused;
+        memset(&fused, 0, sizeof(fused));
+        fused.side[0] = d->transposed ? c_side : q_side, fused.side[1] = d->transposed ? q_side : c_side;
+        if (!++engine->plan_sequence) ++engine->plan_sequence; /* never 0: the ready words start there */
+        fused.sequence = engine->plan_sequence;
+        fused.ready = (uint32_t *)engine->device_fused.pointer, fused.report = (szs_fused_side_report_t *)reports;
+        status = prepare(engine, d, device, stream, error_message); /* buffers of the previous call: nothing to allocate */
+        if (status != sz_success_k) return status;
+        phase(call, 2);
+        remembered->refs_current = 0; /* the launch is about to overwrite the refs */
+        error = hipEventRecord(engine->event_start, stream);
+        uint32_t launches = 0;
+        if (error == hipSuccess) {
+            error = (hipError_t)szs_hip_levenshtein_myers_fused(&fused, (uint64_t *)call->device_results, call->device_stride, d->layout, stream);
+            launches = error == hipSuccess;
+        }
+        engine->last_streams = 1;
+        int stalled = 0;
+        szs_decision_t scored = *d;
+        engine->last_profile.planner = 4;
+        status = finish(call, &scored, error, sz_success_k, launches, 0, 0, 0, &stalled);
+        if (status != sz_success_k) return status;
+        szs_fused_side_report_t sides[2];
+        memcpy(sides, (void const *)reports, sizeof(sides));
+        if (sides[0].sequence == fused.sequence && sides[1].sequence == fused.sequence && !sides[0].status && !sides[1].status && !sides[0].blank &&
+            !sides[1].blank) { /* scored; the profile and the remembered plan take this batch's figures (caller roles again) */
+            szs_fused_side_report_t const *const of_queries = &sides[d->transposed ? 1 : 0], *const of_candidates = &sides[d->transposed ? 0 : 1];
+            if (call->trace)
+                for (int s = 0; s < 2; ++s)
+                    fprintf(stderr, "fused sorter %d (10 ns ticks since it began): offsets loaded %u, positions %u, refs written %u, published %u; began %d ticks after sorter 0\n",
+                            s, sides[s].ticks[1], sides[s].ticks[2], sides[s].ticks[3], sides[s].ticks[4], (int)(sides[s].ticks[0] - sides[0].ticks[0]));
+            szs_plan_summary_t seen_here = remembered->summary;
+            seen_here.status = 0, seen_here.speculation_held = 1, seen_here.sequence = fused.sequence;
+            seen_here.side[0] = of_queries->stats, seen_here.side[1] = of_candidates->stats;
+            memcpy(seen_here.rank_lengths[0], of_queries->rank_lengths, sizeof(seen_here.rank_lengths[0]));
+            memcpy(seen_here.rank_lengths[1], of_candidates->rank_lengths, sizeof(seen_here.rank_lengths[1]));
+            szs_rocm_call_profile_t *profile = &engine->last_profile;
+            profile->cells = seen_here.side[0].symbols * seen_here.side[1].symbols;
+            profile->algorithmic_bytes = (uint64_t)c_count * seen_here.side[0].symbols + (uint64_t)q_count * seen_here.side[1].symbols + profile->pairs * 16;
+            profile->unique_bytes += seen_here.side[0].symbols + seen_here.side[1].symbols;
+            profile->longest_query = seen_here.side[0].longest, profile->longest_candidate = seen_here.side[1].longest;
+            remembered->longest[0] = seen_here.side[0].longest, remembered->longest[1] = seen_here.side[1].longest;
+            stamp_refs(remembered, key_data, key_offsets, key_wide, &seen_here);
+            return szs_report(sz_success_k, error_message, NULL);
+        }
+        /* not this shape after all: nothing real was scored; plan it */
     }
 
     /* ---- speculate: launches shaped like the previous call go in right behind the planner */
@@ -1693,7 +1762,7 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
         engine->events_device = device;
     }
     /* pinned: the device planner's summary, and behind it the stall flag of the chained tiers */
-    status = szs_buffer_reserve(&engine->pinned_summary, szs_memory_pinned_k, device, 1024, error_message);
+    status = szs_buffer_reserve(&engine->pinned_summary, szs_memory_pinned_k, device, 2048, error_message); /* [1024, 2048): the reports of a fused launch */
     if (status != sz_success_k) return status;
 
     call.engine = engine, call.device = device, call.stream = stream;

@@ -42,6 +42,7 @@ static struct {
     [szs_knob_queue_words_k] = {"queue_words", "SZS_ROCM_QUEUE_WORDS"},
     [szs_knob_queue_rounds_k] = {"queue_rounds", "SZS_ROCM_QUEUE_ROUNDS"},
     [szs_knob_queue_priority_k] = {"queue_priority", "SZS_ROCM_QUEUE_PRIORITY"},
+    [szs_knob_fused_k] = {"fused", "SZS_ROCM_FUSED"},
 };
 
 /** Text -> value.  -1 always means "automatic".  Tier names: lanes 0, systolic 1, chain 2; planner: host 0, device 1. */

@@ -1,0 +1,143 @@
+"""`-m gpu`, round 5 against the oracle.
+
+1. The planner INSIDE the scoring launch (hip/lev_myers.hip: `levenshtein_myers_short_fused_kernel`; kernels.h:
+   `szs_fused_plan_t`): a unit-cost byte call whose queries fit the short kernel and whose sides hold at most 1024 strings is ONE
+   launch whose first two workgroups sort the two sides while the others wait for the refs.  The reference's own fast path
+   skips its task pass the same way (cuda.cuh:4297-4340).  Pinned here: such calls report `planner == 4` and `launches == 1`,
+   score what the oracle scores over a stream of different batches, ragged shapes, both orientations and both tape flavours;
+   a batch that does not fit after all (a query beyond 256 bytes) is planned the ordinary way, never scored wrongly; the plan
+   the launch leaves behind serves the same-tapes path; the `fused` knob turns it off.
+"""
+import contextlib
+import ctypes
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import stringzilla_amd as szs  # noqa: E402
+from stringzilla_amd import _abi, workloads  # noqa: E402
+
+
+@contextlib.contextmanager
+def knob(name, value):
+    previous = _abi.tuning_set(name, value)
+    try:
+        yield
+    finally:
+        _abi.tuning_set(name, previous)
+
+
+def _rand(rng, count, lo, hi, alphabet=b"ACGTN"):
+    return [bytes(rng.choice(alphabet) for _ in range(rng.randint(lo, hi))) for _ in range(count)]
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+
+    assert torch.cuda.is_available(), "the gpu-marked tests need a GPU"
+    return szs.DeviceScope(gpu_device=0)
+
+
+@pytest.mark.parametrize("rows,columns,q_span,c_span", [
+    (40, 300, (0, 256), (0, 300)),      # ragged both ways, empties, the widest short query
+    (257, 513, (90, 170), (1, 90)),     # counts that straddle the blocks of 256; texts shorter than patterns
+    (1, 1, (5, 5), (7, 7)),             # a grid of ONE workgroup sorts both sides itself
+    (1, 700, (33, 64), (0, 1500)),      # one query; texts beyond the sort's last bin (1023 and more share it)
+    (1024, 1024, (8, 40), (8, 40)),     # the most strings a side may hold
+    (300, 20, (100, 256), (10, 30)),    # more queries than candidates, long against short: the planner swaps the sides
+])
+def test_a_short_call_plans_itself_inside_its_launch(gpu, oracle, rows, columns, q_span, c_span):
+    rng = random.Random(rows * 1000 + columns)
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+    modes = []
+    for batch in range(4):  # the first call is planned by the planner kernel; every later one of these counts by its own launch
+        queries, candidates = _rand(rng, rows, *q_span), _rand(rng, columns, *c_span)
+        got = engine(queries, candidates, device=gpu)
+        profile = engine.last_call_profile()
+        expected = oracle.levenshtein(queries, candidates)
+        assert np.array_equal(got, expected), (batch, np.argwhere(got != expected)[:5].tolist())
+        assert profile.cells == sum(map(len, queries)) * sum(map(len, candidates))
+        assert profile.longest_query == max(map(len, queries)) and profile.longest_candidate == max(map(len, candidates))
+        modes.append((profile.planner, profile.launches))
+    if modes[0] == (1, 1):  # a first call of one short launch on the lanes tier: the shape the fused launch takes over
+        # (3: torch handed the new tapes the previous ones' addresses - tiny batches - and the guarded plan was tried first)
+        assert all(mode in ((4, 1), (3, 1)) for mode in modes[1:]) and ((4, 1) in modes or rows * columns < 64), modes
+    else:  # another tier or several launches took the first call (a single pair, skewed lengths): no later call may be fused
+        assert all(mode[0] != 4 for mode in modes), modes
+
+
+def test_a_batch_that_no_longer_fits_is_planned_the_ordinary_way(gpu, oracle):
+    rng = random.Random(55)
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+    shape = lambda longest: (_rand(rng, 200, 20, longest), _rand(rng, 260, 0, 200))
+    # (no knob is pinned here: a pinned tier or orientation turns speculation, and with it the fused launch, off)
+    queries, candidates = shape(256)
+    assert np.array_equal(engine(queries, candidates, device=gpu), oracle.levenshtein(queries, candidates))
+    queries, candidates = shape(256)
+    assert np.array_equal(engine(queries, candidates, device=gpu), oracle.levenshtein(queries, candidates))
+    fused_before = engine.last_call_profile().planner == 4
+    # same counts, but one query is now 300 bytes: the sorter blanks its side, the call is planned and scored by two launches
+    queries, candidates = shape(256)
+    queries[17] = bytes(rng.choice(b"ACGT") for _ in range(300))
+    got = engine(queries, candidates, device=gpu)
+    expected = oracle.levenshtein(queries, candidates)
+    assert np.array_equal(got, expected), np.argwhere(got != expected)[:5].tolist()
+    assert engine.last_call_profile().planner != 4
+    # ... and the stream goes on: short batches plan themselves again once a short call has been remembered
+    for _ in range(3):
+        queries, candidates = shape(256)
+        assert np.array_equal(engine(queries, candidates, device=gpu), oracle.levenshtein(queries, candidates))
+    assert engine.last_call_profile().planner == 4 or not fused_before
+
+
+def test_the_plan_a_fused_launch_leaves_serves_the_same_tapes_and_the_knob_turns_it_off(gpu, oracle):
+    rng = random.Random(77)
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+    first = (szs.Strs(_rand(rng, 300, 64, 200)).to_device(0), szs.Strs(_rand(rng, 500, 32, 220)).to_device(0))
+    second = (szs.Strs(_rand(rng, 300, 64, 200)).to_device(0), szs.Strs(_rand(rng, 500, 32, 220)).to_device(0))
+    strings = lambda tape: [tape[i] for i in range(len(tape))]
+    expected_second = oracle.levenshtein(strings(second[0]), strings(second[1]))
+    assert np.array_equal(engine(*first, device=gpu), oracle.levenshtein(strings(first[0]), strings(first[1])))
+    assert np.array_equal(engine(*second, device=gpu), expected_second)
+    assert engine.last_call_profile().planner == 4
+    assert np.array_equal(engine(*second, device=gpu), expected_second)  # the same tapes again: the refs the launch wrote, re-used
+    assert engine.last_call_profile().planner == 3
+    with knob("fused", 0):
+        assert np.array_equal(engine(*first, device=gpu), oracle.levenshtein(strings(first[0]), strings(first[1])))
+        assert engine.last_call_profile().planner in (1, 2)
+
+
+def test_fused_launches_on_64_bit_tapes_and_results_with_a_stride(gpu, oracle):
+    import torch
+
+    rng = random.Random(99)
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+    for batch in range(3):
+        queries = szs.Strs(_rand(rng, 130, 0, 256), wide_offsets=True)
+        candidates = szs.Strs(_rand(rng, 333, 0, 180), wide_offsets=True)
+        out = torch.full((130, 400), -1, dtype=torch.int64, device="cuda:0")
+        engine(queries, candidates, device=gpu, out=out[:, :333])
+        expected = oracle.levenshtein([queries[i] for i in range(130)], [candidates[i] for i in range(333)])
+        assert np.array_equal(out[:, :333].cpu().numpy().view(np.uint64), expected)
+        assert (out[:, 333:] == -1).all()  # padding columns are never written (cuda.cuh:2201-2203)
+    assert engine.last_call_profile().planner == 4
+
+
+def test_malformed_offsets_reach_the_caller_from_a_fused_launch_too(gpu):
+    """Descending offsets: the sorting workgroup blanks its side and says why; the ordinary planner then reports the error."""
+    import torch
+
+    rng = random.Random(5)
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+    for _ in range(2):
+        engine(_rand(rng, 64, 10, 60), _rand(rng, 300, 10, 60), device=gpu)
+    queries, candidates = szs.Strs(_rand(rng, 64, 10, 60)).to_device(0), szs.Strs(_rand(rng, 300, 10, 60)).to_device(0)
+    _, _, offsets = candidates._device
+    offsets[100] = offsets[99] - 5  # string 99 now "ends" before it begins
+    with pytest.raises(Exception) as problem:
+        engine(queries, candidates, device=gpu)
+    assert "ascend" in str(problem.value).lower() or "dimension" in str(problem.value).lower(), str(problem.value)
