@@ -395,6 +395,15 @@ def measure_extra(config, scope, device_index, args, fence, with_cpu):
         "results_checksum": int(results.sum().item()),
         "roofline": roofline(config, profile, kernel),
     }
+    if config == 10:
+        # Tiny tokens: the one regime of this path where HBM is the roofline that binds - the RESULT MATRIX (8 bytes a pair against
+        # ~13 bytes of strings per pair-row).  Algorithmic bytes here = results + both tapes + their offsets, once each.
+        bytes_moved = len(queries) * len(candidates) * 8 + int(load.queries.lengths().sum() + load.candidates.lengths().sum()) + 4 * (len(queries) + len(candidates) + 2)
+        record["roofline"] = {"bound": "hbm", "achieved": round(bytes_moved / kernel / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                              "frac": round(bytes_moved / kernel / 1e9 / HBM_PEAK_GBPS, 4), "algorithmic_bytes": bytes_moved,
+                              "algorithmic_bytes_are": "the results matrix + both tapes + offsets, once", "kernel_ms": round(kernel * 1e3, 4),
+                              "launches_per_step": int(profile.launches), "traffic": None,
+                              "kernels": "levenshtein_tiny_kernel + levenshtein_outliers_kernel", "planner_mode": int(profile.planner)}
     if with_cpu:  # timed later, after every GPU measurement of the run (the host cores are busy for ~10 s per baseline); the
         # matrix stays in HBM until then - downloading 80 MB here would idle the shader engines right before the headline
         record["_cpu_baseline_inputs"] = (load, results)
@@ -633,7 +642,7 @@ def main():
     # of NW / SW scoring the clocks are where a busy GPU keeps them.  The headline itself is unchanged: W untimed steps, then
     # exactly K timed ones.  (The single-process C driver of N > 1 runs last, while the other ranks wait.)
     if args.extra_configs is None:
-        extras = [9, 3, 4, 5, 6, 7, 8] if world == 1 else [4, 5]
+        extras = [9, 3, 4, 5, 6, 7, 8, 10] if world == 1 else [4, 5]
     else:
         extras = [] if args.extra_configs.strip().lower() in ("", "none") else [int(x) for x in args.extra_configs.split(",")]
     records = []
@@ -765,7 +774,7 @@ def main():
                        "stream": "fresh batches alternate" if len(steps_of) > 1 else "same batch every step"},
             "roofline": line_roofline,
             "host_overhead_ms_per_step": round(ms_per_step - kernel * 1e3, 4),
-            "planner": "+".join({0: "host", 1: "device", 2: "device, speculated", 3: "re-used", 4: "inside the scoring launch"}[mode] for mode in sorted(planners)),
+            "planner": "+".join({0: "host", 1: "device", 2: "device, speculated", 3: "re-used", 4: "inside the scoring launch", 5: "none (tiny tokens)"}[mode] for mode in sorted(planners)),
             "results_checksum": float(checksum),
             # the three figures the reference's own bench prints per engine (bench/similarities.cuh:344-366: bytes passed, operations =
             # cells, inputs processed, and the device-measured "Kernel" line :303-308)

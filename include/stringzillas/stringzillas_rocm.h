@@ -38,7 +38,8 @@ typedef struct szs_rocm_call_profile_t {
     sz_u32_t cell_bits;           /* width of the DP cells of the last launch: 16 (weighted_packed.hip), 32, 64 (wide.hip), or 0 (bit-parallel) */
     sz_u32_t planner;             /* 0: planned on the host; 1: on the device (hip/planner.hip); 2: on the device, launches speculated;
                                      3: the plan of the previous call of the same tapes, re-used behind a guard;
-                                     4: planned INSIDE the scoring launch (its first two workgroups sort the sides; hip/lev_myers.hip) */
+                                     4: planned INSIDE the scoring launch (its first two workgroups sort the sides; hip/lev_myers.hip);
+                                     5: not planned at all - the tiny-token kernel scores straight from the tapes (hip/myers_tiny.hip) */
     sz_u32_t team;                /* 0, or lanes * 10000 + registers * 100 + wavefronts per SIMD of the team tier (weighted_teams.hip) */
     sz_u32_t team_wide;           /* team tier: 0 cells ordered as half-float patterns (three-input maxima), 1 as unsigned integers */
     sz_u32_t streams;             /* streams the launches of the call were dealt over: 1 ... 8, never more than the `queues` knob */
@@ -207,7 +208,8 @@ SZ_API_RUNTIME sz_status_t szs_rocm_node_scores_u64tape(szs_rocm_node_engine_t e
  *  more bit-vector widths whose lengths are skewed), "queue_words" (4 | 8 | 12 | 16: the most words of a pattern one lane holds
  *  there), "queue_rounds" (n: candidates per work item in rounds of eight wavefronts), "queue_priority" (0 | 1: wave priorities by
  *  chain length inside that launch; automatic: byte calls and short codepoint calls), "fused" (0: never plan a short unit-cost
- *  call inside its own scoring launch),
+ *  call inside its own scoring launch), "tiny" (0: never | 1: every unit-cost byte call whose queries fit 256 bytes - the
+ *  tiny-token kernel of hip/myers_tiny.hip; automatic: batches of tiny tokens on both sides),
  *  "queues" (see below), "roctx" (1: the host phases of every call - plan, decide, enqueue, wait - as roctx ranges for a
  *  `rocprofv3 --marker-trace` timeline; the marker library is looked up at run time, never linked),
  *  "cpu_requests" (strict | gpu: serve capability

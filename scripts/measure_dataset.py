@@ -53,4 +53,7 @@ profile = engine.last_call_profile()
 print(json.dumps({"dataset": os.path.basename(args.dataset), "tokens": args.tokens, "tokens_found": len(tokens),
                   "engine": args.engine, "pairs": profile.pairs, "cells": profile.cells,
                   "kernel_gcups": round(profile.cells / min(kernel) / 1e9, 1), "wall_gcups": round(profile.cells / min(wall) / 1e9, 1),
-                  "tier": profile.tier, "transposed": profile.transposed, "launches": profile.launches}))
+                  "tier": profile.tier, "transposed": profile.transposed, "launches": profile.launches, "planner": profile.planner,
+                  "kernel_us": round(min(kernel) * 1e6, 1), "wall_us": round(min(wall) * 1e6, 1),
+                  "longest": [int(queries.lengths().max()), int(candidates.lengths().max())],
+                  "results_gb_s": round(profile.pairs * 8 / min(kernel) / 1e9, 1)}))

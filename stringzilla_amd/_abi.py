@@ -169,7 +169,7 @@ _KNOBS = {"tier": "SZS_ROCM_TIER", "swap": "SZS_ROCM_SWAP", "packed": "SZS_ROCM_
           "split": "SZS_ROCM_SPLIT", "alphabet": "SZS_ROCM_ALPHABET", "merge": "SZS_ROCM_MERGE",
           "team": "SZS_ROCM_TEAM", "queues": "SZS_ROCM_QUEUES", "roctx": "SZS_ROCM_ROCTX",
           "queue": "SZS_ROCM_QUEUE", "queue_words": "SZS_ROCM_QUEUE_WORDS", "queue_rounds": "SZS_ROCM_QUEUE_ROUNDS",
-          "queue_priority": "SZS_ROCM_QUEUE_PRIORITY", "fused": "SZS_ROCM_FUSED"}
+          "queue_priority": "SZS_ROCM_QUEUE_PRIORITY", "fused": "SZS_ROCM_FUSED", "tiny": "SZS_ROCM_TINY"}
 _knob_values = {name: os.environ.get(variable) for name, variable in _KNOBS.items()}  # what the library read when it was loaded
 
 

@@ -181,6 +181,39 @@ unsigned szs_hip_levenshtein_myers_queue_grid(uint64_t items, int runes);
 size_t szs_hip_levenshtein_myers_queue_table_bytes(int runes);
 
 /**
+ *  Unit-cost byte-level distances over TINY strings (hip/myers_tiny.hip), straight from the tapes - no refs, no planner:
+ *  a workgroup scores 256 consecutive candidates against a span of the queries, THIRTY-TWO queries at a time per lane (16-bit
+ *  bit-vectors, two to a register), and writes whole 2 KB runs of the result rows.  Plain layout only
+ *  (results[query * stride + candidate]).  Strings of more than 16 bytes are skipped - their rows / columns left untouched - and
+ *  listed in `outliers` (device memory; the caller zeroes `counts` before the launch) for szs_hip_levenshtein_outliers, which
+ *  must follow on the same stream.  More than SZS_TINY_MOST_OUTLIERS of them on a side, one beyond 256 bytes, or malformed
+ *  offsets leave `*unfit = unfit_sequence` in pinned host memory: the caller then scores the call the ordinary way.
+ *  `symbols_out` (pinned, or NULL): [0] the bytes of the queries' tape, [1] of the candidates' - their product is the call's cells.
+ */
+#define SZS_TINY_MOST_OUTLIERS 256u
+typedef struct szs_tiny_outliers_t {
+    uint32_t counts[2]; /* [0] queries, [1] candidates; may exceed the capacity (the call is unfit then) */
+    uint32_t reserved[2];
+    szs_string_ref_t refs[2][SZS_TINY_MOST_OUTLIERS];
+} szs_tiny_outliers_t;
+typedef struct szs_tape_t {
+    void const *offsets;
+    uint64_t base; /* address of the tape's bytes */
+    uint32_t count, wide;
+} szs_tape_t;
+int szs_hip_levenshtein_tiny(szs_tape_t const *queries, szs_tape_t const *candidates, uint64_t *results, uint64_t results_row_stride,
+                             uint32_t *unfit, uint32_t unfit_sequence, szs_tiny_outliers_t *outliers, unsigned long long *symbols_out,
+                             void *stream);
+/**
+ *  The strings szs_hip_levenshtein_tiny listed (hip/lev_myers.hip): a workgroup scores ONE listed string - the pattern, up to 256
+ *  bytes - against a block of 256 strings of the other side's tape, whatever their lengths, with the bodies of the short
+ *  bit-parallel kernel.  A listed query fills its row, a listed candidate its column.  The grid covers the list's capacity;
+ *  workgroups beyond the counts the first kernel left return at once.
+ */
+int szs_hip_levenshtein_outliers(szs_tiny_outliers_t const *outliers, szs_tape_t const *queries, szs_tape_t const *candidates, uint64_t *results,
+                                 uint64_t results_row_stride, void *stream);
+
+/**
  *  Fills the cells above the diagonal of a `side` x `side` matrix of 8-byte values from the ones below it (hip/mirror.hip): what a
  *  symmetric call sharded over several GPUs by bands of rows (host/node.c) needs once every band has landed.
  */
@@ -215,6 +248,8 @@ enum {
     szs_knob_queue_rounds_k,/* -1 automatic | n: candidates per work item, in rounds of the workgroup's eight wavefronts */
     szs_knob_queue_priority_k, /* -1 automatic (on) | 0: every wave block of that launch at one hardware priority | 1: longest chain first */
     szs_knob_fused_k,       /* -1 automatic | 0: never fold the planner into the short unit-cost launch (szs_fused_plan_t) */
+    szs_knob_tiny_k,        /* -1 automatic (tiny tokens on both sides) | 0 never | 1 every unit-cost byte call whose queries fit 256 bytes:
+                               the tiny-token kernel of hip/myers_tiny.hip */
     szs_knob_count_k
 };
 int szs_tuning_get(int knob);

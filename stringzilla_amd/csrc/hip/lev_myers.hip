@@ -431,11 +431,7 @@ __device__ __forceinline__ void fused_prologue(szs_fused_plan_t const &plan, u32
     // 16 KB of LDS that only the two sorting workgroups touch: the scoring bodies keep five workgroups per CU either way (95 VGPRs)
     __shared__ __attribute__((aligned(16))) szs_string_ref_t staged[SZS_FUSED_MOST_STRINGS];
     for (u32 s = 0; s < 2; ++s)
-#ifdef SZS_FUSED_EXPERIMENT_NOSORT
-        if (false) {
-#else
         if (blockIdx.x == s % gridDim.x) {
-#endif
             fused_sort_side(plan.side[s], s == 0, plan.sequence, plan.ready + 32 * s, plan.report + s, scratch, staged);
             __syncthreads(); // the LDS is sorted in again (a grid of one workgroup), then becomes the match masks
         }
@@ -447,9 +443,8 @@ __device__ __forceinline__ void fused_prologue(szs_fused_plan_t const &plan, u32
     // (Sleeping through most of the sort before the first poll changed nothing: the polls are not what the launch waits for.)
     // Measured and not kept: the waiting workgroups pulling both tapes into their XCD's L2 meanwhile (a line per thread) - the
     // sorters' own first loads then took 2.3 us instead of 1.4 and the launch 181.6 us instead of 179.6.
-#ifdef SZS_FUSED_EXPERIMENT_NOWAIT // timing experiment only: reads the previous call's refs (results are garbage)
-    if (false)
-#endif
+    // (What the wait costs, measured with build variants that skip it - reading the previous call's refs, results garbage: the
+    // launch 179.6 us; without the wait 173.0; without the sort as well 171.5, the plain launch's time.)
     if (threadIdx.x < 2)
         while (__hip_atomic_load(plan.ready + 32 * threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != plan.sequence)
             __builtin_amdgcn_s_sleep(8);
@@ -533,6 +528,208 @@ __global__ __launch_bounds__(256, SZS_MYERS_FUSED_WAVES) void levenshtein_myers_
     // (plain pointers, not __restrict__ const ones: these arrays ARE written during the launch, by the sorting workgroups)
     myers_short_body<false, false, true>(plan.side[0].descending, plan.side[1].ascending, plan.side[1].count, candidate_blocks, results,
                                          results_row_stride, layout, none, 0u, 1u, &plan);
+}
+
+/**
+ *  The strings the tiny-token kernel (hip/myers_tiny.hip) left out - tokens of more than 16 bytes among words of text, a few per
+ *  cent of them, listed by that kernel.  ONE launch, three kinds of workgroup:
+ *
+ *    A  listed CANDIDATES as texts against the tiny queries as patterns: a workgroup builds the 16-bit masks of 128 consecutive
+ *       queries (`table[byte][64 dwords]`: lane l holds query l in its low half and query 64 + l in its high half) and every
+ *       wavefront walks listed texts ONE AT A TIME - the text's symbol is the same for all 64 lanes, each lane reads its own dword
+ *       of the row (no bank conflict) and advances two patterns with the eleven instructions of `tiny_column`.  A 100-byte URL
+ *       costs its wavefront 100 such steps, not 100 steps of sixteen registers; nobody waits for it but its own wavefront.
+ *    B  the same with the sides swapped: listed QUERIES as texts against the tiny candidates (a lane's results are consecutive
+ *       columns of the text's row).
+ *    C  listed queries against listed candidates: the ordinary bodies of the short kernel, a listed query as the pattern (up to
+ *       256 bytes) and the list of candidates as its block of texts.
+ *
+ *  (Round 5's first version scored a listed string as the PATTERN against the other side's tape, block by block: unsorted
+ *  texts, every column through the predicated tail loop - 56 us for the 410 outliers of 4096 x 4096 words, as long as the
+ *  tiny-token kernel itself.  This one: 49 us - kind C alone 19, kinds A and B ~45 each, side by side; they are chains of
+ *  dependent instructions on one or two wavefronts per SIMD, and what is left of the call's time once the tiny kernel's is
+ *  taken out.  Measured on the way: one text at a time per wavefront 65 us; four at a time with a uniform branch per column 68;
+ *  branch-free with the sixteen mask reads of a step issued together 49.)
+ */
+constexpr u32 outlier_patterns_k = 128;  // tiny patterns per workgroup of kinds A / B: two per lane
+constexpr u32 outlier_text_chunk_k = 32; // listed texts per workgroup: eight per wavefront, four at a time
+typedef unsigned short outlier_pk_u16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void outlier_column(u32 &vp, u32 &vn, u32 eq) { // one DP column of two 16-row patterns (myers_tiny.hip)
+    u32 const xv = eq | vn;
+    outlier_pk_u16 const sum16 = __builtin_bit_cast(outlier_pk_u16, eq & vp) + __builtin_bit_cast(outlier_pk_u16, vp);
+    u32 const sum = __builtin_bit_cast(u32, sum16);
+    u32 const d0 = (sum ^ vp) | eq;
+    u32 const hp = vn | ~(d0 | vp);
+    u32 const hn = vp & d0;
+    outlier_pk_u16 const hp16 = __builtin_bit_cast(outlier_pk_u16, hp) << (outlier_pk_u16)(1), hn16 = __builtin_bit_cast(outlier_pk_u16, hn) << (outlier_pk_u16)(1);
+    u32 const hp_shifted = __builtin_bit_cast(u32, hp16) | 0x00010001u, hn_shifted = __builtin_bit_cast(u32, hn16);
+    vp = hn_shifted | ~(xv | hp_shifted);
+    vn = hp_shifted & xv;
+}
+
+__global__ __launch_bounds__(256) void levenshtein_outliers_kernel(szs_tiny_outliers_t const *__restrict__ outliers, szs_tape_t queries,
+                                                                  szs_tape_t candidates, u32 query_groups, u32 candidate_groups,
+                                                                  u64 *__restrict__ results, u64 results_row_stride) {
+    __shared__ __attribute__((aligned(16))) u32 table[256 * 64]; // kinds A / B: the masks, 64 KB; kind C: the short kernel's masks + refs
+    __shared__ u64 pattern_offsets[outlier_patterns_k + 1];
+    constexpr u32 chunks = SZS_TINY_MOST_OUTLIERS / outlier_text_chunk_k;
+    u32 const tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    u32 const listed_queries = outliers->counts[0] < SZS_TINY_MOST_OUTLIERS ? outliers->counts[0] : SZS_TINY_MOST_OUTLIERS;
+    u32 const listed_candidates = outliers->counts[1] < SZS_TINY_MOST_OUTLIERS ? outliers->counts[1] : SZS_TINY_MOST_OUTLIERS;
+    u32 const workgroups_a = query_groups * chunks, workgroups_b = candidate_groups * chunks;
+
+    if (blockIdx.x >= workgroups_a + workgroups_b) { // ---- kind C: a listed query against the listed candidates
+        u32 const listed = blockIdx.x - workgroups_a - workgroups_b;
+        if (listed >= listed_queries || !listed_candidates) return;
+        szs_string_ref_t const pattern = outliers->refs[0][listed];
+        szs_string_ref_t *const texts = reinterpret_cast<szs_string_ref_t *>(table + peq_layout<8, byte_rows_k>::total_dwords);
+        if (tid < listed_candidates) texts[tid] = outliers->refs[1][tid];
+        __syncthreads();
+        szs_ref_guard_t const none = {};
+        u32 const words = __builtin_amdgcn_readfirstlane(pattern.length ? (pattern.length + 31u) / 32u : 1u);
+#define SZS_OUTLIER_BODY(W)                                                                                            \
+    case W:                                                                                                            \
+        myers_workgroup<W, SZS_MYERS_SHORT_TEXT_DWORDS, false>(table, nullptr, pattern, texts, listed_candidates, 0u, results, \
+                                                               results_row_stride, 0, none);                          \
+        break;
+        switch (words) {
+            SZS_OUTLIER_BODY(1)
+            SZS_OUTLIER_BODY(2)
+            SZS_OUTLIER_BODY(3)
+            SZS_OUTLIER_BODY(4)
+            SZS_OUTLIER_BODY(5)
+            SZS_OUTLIER_BODY(6)
+            SZS_OUTLIER_BODY(7)
+        default: // 8; the tiny kernel lists nothing longer
+            myers_workgroup<8, SZS_MYERS_SHORT_TEXT_DWORDS, false>(table, nullptr, pattern, texts, listed_candidates, 0u, results,
+                                                                   results_row_stride, 0, none);
+            break;
+        }
+#undef SZS_OUTLIER_BODY
+        return;
+    }
+
+    // ---- kinds A and B
+    bool const texts_are_candidates = blockIdx.x < workgroups_a;
+    u32 const local = texts_are_candidates ? blockIdx.x : blockIdx.x - workgroups_a;
+    u32 const group = local / chunks, chunk = local % chunks;
+    int const side_of_texts = texts_are_candidates ? 1 : 0;
+    u32 const texts_count = texts_are_candidates ? listed_candidates : listed_queries;
+    if (chunk * outlier_text_chunk_k >= texts_count) return;
+    szs_tape_t const &patterns = texts_are_candidates ? queries : candidates;
+    u32 const pattern_first = group * outlier_patterns_k;
+    u32 const patterns_here = patterns.count - pattern_first < outlier_patterns_k ? patterns.count - pattern_first : outlier_patterns_k;
+    for (u32 i = tid; i <= patterns_here; i += 256) pattern_offsets[i] = fused_offset(patterns.offsets, patterns.wide, (u64)pattern_first + i);
+    for (u32 i = tid; i < 256 * 64; i += 256) table[i] = 0;
+    __syncthreads();
+    auto rows_of = [&](u32 p) -> u32 { // bytes of pattern p of the group; ~0: absent, or one of the listed (long) strings itself
+        if (p >= patterns_here) return ~0u;
+        u64 const from = pattern_offsets[p], to = pattern_offsets[p + 1];
+        return to >= from && to - from <= 16 ? (u32)(to - from) : ~0u;
+    };
+    { // this thread's eight pattern bytes: all loads first (one round trip), then the atomics
+        constexpr u32 items = outlier_patterns_k * 16 / 256;
+        u32 bytes[items], bits[items];
+#pragma unroll
+        for (u32 k = 0; k < items; ++k) {
+            u32 const item = tid + k * 256, p = item >> 4, at = item & 15u, rows = rows_of(p);
+            bytes[k] = 0x100u, bits[k] = 0;
+            if (rows == ~0u || at >= rows) continue;
+            bytes[k] = reinterpret_cast<u8 const *>(patterns.base + pattern_offsets[p])[at];
+            bits[k] = (p < 64 ? 1u : 0x10000u) << (16 - rows + at);
+        }
+#pragma unroll
+        for (u32 k = 0; k < items; ++k)
+            if (bytes[k] < 0x100u) atomicOr(&table[bytes[k] * 64 + (((tid + k * 256) >> 4) & 63u)], bits[k]);
+    }
+    __syncthreads();
+    u32 const rows_low = rows_of(lane), rows_high = rows_of(lane + 64);
+    u32 const vp_start = ((0xFFFFu << (16 - (rows_low == ~0u ? 0u : rows_low))) & 0xFFFFu) |
+                         ((0xFFFF0000u << (16 - (rows_high == ~0u ? 0u : rows_high))) & 0xFFFF0000u);
+    u32 const texts_end = (chunk + 1) * outlier_text_chunk_k < texts_count ? (chunk + 1) * outlier_text_chunk_k : texts_count;
+    // FOUR texts at a time per wavefront: one text is one chain of dependent instructions (a column needs the column before it),
+    // and a CU holds only two of these workgroups (the table) - four independent chains keep the SIMD issuing.
+    constexpr u32 together = 4;
+    // (the refs and the first two dwords of the NEXT four texts are fetched before the columns of the current four: two dependent
+    // round trips to memory otherwise stand in front of every quartet)
+    auto fetch_refs = [&](u32 first_text, szs_string_ref_t (&refs)[together]) {
+#pragma unroll
+        for (u32 k = 0; k < together; ++k) {
+            refs[k] = outliers->refs[side_of_texts][first_text + k < texts_end ? first_text + k : texts_end - 1]; // the same for all 64 lanes
+            if (first_text + k >= texts_end) refs[k].length = 0;
+        }
+    };
+    szs_string_ref_t refs_ahead[together];
+    u32 raw_ahead[together][2];
+    u32 const first_quartet = chunk * outlier_text_chunk_k + wave * together;
+    fetch_refs(first_quartet, refs_ahead);
+#pragma unroll
+    for (u32 k = 0; k < together; ++k) {
+        text_stream_t const text(refs_ahead[k].address, refs_ahead[k].length);
+        raw_ahead[k][0] = text.raw(0), raw_ahead[k][1] = text.raw(1);
+    }
+#pragma unroll 1
+    for (u32 first_text = first_quartet; first_text < texts_end; first_text += 4 * together) {
+        szs_string_ref_t refs[together];
+        u32 vp[together], vn[together], raw_low[together], next[together], longest = 0;
+#pragma unroll
+        for (u32 k = 0; k < together; ++k) {
+            refs[k] = refs_ahead[k], raw_low[k] = raw_ahead[k][0], next[k] = raw_ahead[k][1];
+            longest = refs[k].length > longest ? refs[k].length : longest;
+            vp[k] = vp_start, vn[k] = 0;
+        }
+        text_stream_t const texts[together] = {text_stream_t(refs[0].address, refs[0].length), text_stream_t(refs[1].address, refs[1].length),
+                                               text_stream_t(refs[2].address, refs[2].length), text_stream_t(refs[3].address, refs[3].length)};
+        if (first_text + 4 * together < texts_end) {
+            fetch_refs(first_text + 4 * together, refs_ahead);
+#pragma unroll
+            for (u32 k = 0; k < together; ++k) {
+                text_stream_t const text(refs_ahead[k].address, refs_ahead[k].length);
+                raw_ahead[k][0] = text.raw(0), raw_ahead[k][1] = text.raw(1);
+            }
+        }
+#pragma unroll 1
+        for (u32 at = 0, dword = 0; at < longest; at += 4, ++dword) {
+            u32 symbols[together];
+#pragma unroll
+            for (u32 k = 0; k < together; ++k) {
+                u32 const after = texts[k].raw(dword + 2);
+                symbols[k] = texts[k].splice(raw_low[k], next[k]);
+                raw_low[k] = next[k], next[k] = after;
+            }
+            // sixteen LDS reads go out together; a column past a text's end is computed and dropped (two selects on a uniform
+            // condition) - as sixteen uniform BRANCHES, each with its read behind it, a quartet took ~15 us
+            u32 masks[4][together];
+#pragma unroll
+            for (u32 step = 0; step < 4; ++step)
+#pragma unroll
+                for (u32 k = 0; k < together; ++k) masks[step][k] = table[((symbols[k] >> (8 * step)) & 0xFFu) * 64 + lane];
+#pragma unroll
+            for (u32 step = 0; step < 4; ++step)
+#pragma unroll
+                for (u32 k = 0; k < together; ++k) {
+                    u32 vp_next = vp[k], vn_next = vn[k];
+                    outlier_column(vp_next, vn_next, masks[step][k]);
+                    bool const within = at + step < refs[k].length;
+                    vp[k] = within ? vp_next : vp[k], vn[k] = within ? vn_next : vn[k];
+                }
+        }
+#pragma unroll
+        for (u32 k = 0; k < together; ++k) {
+            if (first_text + k >= texts_end) break;
+            u32 const low = refs[k].length + (u32)__builtin_popcount(vp[k] & 0xFFFFu) - (u32)__builtin_popcount(vn[k] & 0xFFFFu);
+            u32 const high = refs[k].length + (u32)__builtin_popcount(vp[k] >> 16) - (u32)__builtin_popcount(vn[k] >> 16);
+            u64 const pattern_low = pattern_first + lane, pattern_high = pattern_first + lane + 64;
+            if (texts_are_candidates) { // results[query = pattern][candidate = text]
+                if (rows_low != ~0u) results[pattern_low * results_row_stride + refs[k].index] = low;
+                if (rows_high != ~0u) results[pattern_high * results_row_stride + refs[k].index] = high;
+            }
+            else { // results[query = text][candidate = pattern]: 512 contiguous bytes per wavefront and half
+                if (rows_low != ~0u) results[(u64)refs[k].index * results_row_stride + pattern_low] = low;
+                if (rows_high != ~0u) results[(u64)refs[k].index * results_row_stride + pattern_high] = high;
+            }
+        }
+    }
 }
 
 /** The same with `blocks_per_group` candidate blocks per workgroup (launch_myers_short decides). */
@@ -1600,6 +1797,19 @@ extern "C" int szs_hip_levenshtein_myers_fused(szs_fused_plan_t const *plan, uin
     u32 const candidate_blocks = (candidates_count + SZS_CANDIDATES_PER_WORKGROUP - 1) / SZS_CANDIDATES_PER_WORKGROUP;
     hipLaunchKernelGGL(levenshtein_myers_short_fused_kernel, dim3(queries_count * candidate_blocks), dim3(256), 0,
                        static_cast<hipStream_t>(stream), *plan, candidate_blocks, results, results_row_stride, layout);
+    return (int)hipGetLastError();
+}
+
+extern "C" int szs_hip_levenshtein_outliers(szs_tiny_outliers_t const *outliers, szs_tape_t const *queries, szs_tape_t const *candidates,
+                                            uint64_t *results, uint64_t results_row_stride, void *stream) {
+    using namespace szs_hip;
+    if (!queries->count || !candidates->count) return 0;
+    u64 const query_groups = ((u64)queries->count + outlier_patterns_k - 1) / outlier_patterns_k;
+    u64 const candidate_groups = ((u64)candidates->count + outlier_patterns_k - 1) / outlier_patterns_k;
+    u64 const grid = (query_groups + candidate_groups) * (SZS_TINY_MOST_OUTLIERS / outlier_text_chunk_k) + SZS_TINY_MOST_OUTLIERS;
+    if (grid > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(levenshtein_outliers_kernel, dim3((u32)grid), dim3(256), 0, static_cast<hipStream_t>(stream), outliers, *queries, *candidates,
+                       (u32)query_groups, (u32)candidate_groups, results, results_row_stride);
     return (int)hipGetLastError();
 }
 

@@ -1,0 +1,276 @@
+/*
+ *  myers_tiny.hip - unit-cost Levenshtein distances over TINY byte strings (words of text: ~6 x 6 cells per pair), straight
+ *  from the caller's tapes: no planner, no refs, no sorted sides.
+ *
+ *  Replaces, for the ROCm build, the reference's tiny-token fast path
+ *      unit_myers_singleword_direct_per_cuda_cell_   /root/reference/include/stringzillas/similarities/cuda.cuh:2864
+ *      (launch site :4297-4340: one thread per cell, Peq on the fly, straight to the matrix - "removes the host-orchestration
+ *      overhead that leaves the GPU >60% idle on tiny-token cross-products")
+ *  and returns what levenshtein_distance_myers<char, serial> returns (.../similarities/serial.hpp:2073-2314).
+ *
+ *  What binds this regime is not the DP (36 cells a pair) but everything around it - and the RESULT MATRIX: 4096 x 4096 words
+ *  are 134 MB of 8-byte results against 48 KB of strings, the one place on this path where the HBM roofline is the real one.
+ *  The lanes-tier kernels (lev_myers.hip) give every pair a lane and every query a workgroup: ~390 lane-operations per pair
+ *  here, and results scattered 8 bytes at a time over the length-sorted columns.  This kernel instead:
+ *
+ *  - SIXTEEN-BIT bit-vectors, two to a register.  A token of up to 16 bytes is a 16-row pattern; the recurrence runs on both
+ *    halves of a 32-bit register at once - the boolean algebra does not care, the one addition is `v_pk_add_u16` (no carry
+ *    between the halves) and the two shifts are `v_pk_lshlrev_b16`.  A lane scores its candidate against THIRTY-TWO queries at
+ *    once: sixteen registers of VP, sixteen of VN, sixteen independent dependency chains to interleave.
+ *  - The masks of a group of 32 queries sit side by side in LDS, `peq[byte][16 dwords]`: one 64-byte row per text byte hands a
+ *    lane the masks of all thirty-two (four ds_read_b128).  Built with LDS atomics from bytes the threads fetched one group
+ *    ahead, and un-built (the same dwords cleared) instead of zeroing 16 KB per group.
+ *  - A workgroup owns 256 CONSECUTIVE candidates (a block of result columns) and walks a span of the queries.  Candidates are
+ *    only sorted INSIDE the block (a counting sort of 256 lengths in LDS; wavefront w of workgroup b takes the (w + b) % 4-th
+ *    quarter, so that the longest quarter does not always land on the same SIMD): each wavefront gets texts of near-equal length
+ *    and a query's 256 results still form one contiguous 2 KB run of its row.  The candidate's bytes live in four registers.
+ *  - Results go through LDS, a byte each (a distance of two tiny tokens is at most 16): `out[j][candidate of the block]` packs
+ *    four queries; then every wavefront writes 512 contiguous bytes per row.
+ *
+ *  Tokens LONGER than 16 bytes are not this kernel's business: it skips them (their rows / columns are left untouched) and
+ *  lists them - refs in device memory, at most SZS_TINY_MOST_OUTLIERS per side - for `levenshtein_outliers_kernel`
+ *  (lev_myers.hip), which scores a listed string against the other side's tape, block by block, with the ordinary bit-parallel
+ *  bodies.  One long URL in a wavefront would otherwise hold its sixty-three neighbours - and, through the workgroup's
+ *  barriers, the other three wavefronts - for ten times their own work (measured: 441 us where this design takes a fraction).
+ *  More outliers than the list holds, a listed string beyond 256 bytes, malformed offsets: `*unfit = unfit_sequence` (pinned
+ *  memory) and the host scores the call the ordinary way.
+ */
+#include "myers_core.hpp"
+
+namespace szs_hip {
+
+constexpr u32 tiny_group_k = 32;         // queries scored side by side by one lane: two per register
+constexpr u32 tiny_block_k = 256;        // candidates per workgroup: one per lane
+constexpr u32 tiny_rows_k = 16;          // bytes of a tiny token = rows of its bit-vector
+constexpr u32 tiny_most_queries_k = 256; // queries of one workgroup's span (their offsets live in LDS)
+// (Rows 20 dwords apart - their first banks then spread over sixteen values instead of four - measured the same 67.6 us: bank
+// conflicts of the mask reads are not what the launch waits for.)
+constexpr u32 tiny_row_dwords_k = 16;
+
+typedef unsigned short tiny_pk_u16 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ u64 tiny_offset(void const *offsets, u32 wide, u64 index) {
+    return wide ? static_cast<u64 const *>(offsets)[index] : (u64) static_cast<u32 const *>(offsets)[index];
+}
+__device__ __forceinline__ u32 tiny_pk_add(u32 a, u32 b) { // v_pk_add_u16: the halves do not carry into each other
+    tiny_pk_u16 const sum = __builtin_bit_cast(tiny_pk_u16, a) + __builtin_bit_cast(tiny_pk_u16, b);
+    return __builtin_bit_cast(u32, sum);
+}
+__device__ __forceinline__ u32 tiny_pk_shl1(u32 a) { // v_pk_lshlrev_b16
+    tiny_pk_u16 const shifted = __builtin_bit_cast(tiny_pk_u16, a) << (tiny_pk_u16)(1);
+    return __builtin_bit_cast(u32, shifted);
+}
+
+/** One DP column of TWO 16-row patterns at once (the column update of myers_core.hpp on packed halves). */
+__device__ __forceinline__ void tiny_column(u32 &vp, u32 &vn, u32 eq) {
+    u32 const xv = eq | vn;
+    u32 const sum = tiny_pk_add(eq & vp, vp);
+    u32 const d0 = (sum ^ vp) | eq;
+    u32 const hp = vn | ~(d0 | vp);
+    u32 const hn = vp & d0;
+    u32 const hp_shifted = tiny_pk_shl1(hp) | 0x00010001u; // the constant +1 of DP row zero enters bit 0 of each half
+    u32 const hn_shifted = tiny_pk_shl1(hn);
+    vp = hn_shifted | ~(xv | hp_shifted);
+    vn = hp_shifted & xv;
+}
+
+__global__ __launch_bounds__(256) void levenshtein_tiny_kernel(szs_tape_t queries, szs_tape_t candidates, u32 queries_per_workgroup,
+                                                              u64 *__restrict__ results, u64 results_row_stride, u32 *unfit,
+                                                              u32 unfit_sequence, szs_tiny_outliers_t *outliers,
+                                                              unsigned long long *symbols_out) {
+    __shared__ __attribute__((aligned(16))) u32 peq[256 * tiny_row_dwords_k]; // [byte][dword d: slots d (low half) and d + 16 (high)]: 20 KB
+    __shared__ u32 out[8 * tiny_block_k]; // [j][column of the block]: the distances of slots j, j + 8, j + 16, j + 24, a byte each: 8 KB
+    __shared__ u64 query_offsets[tiny_most_queries_k + 1];
+    __shared__ u64 froms[tiny_block_k];
+    __shared__ u32 lengths[tiny_block_k], bins[32], lane_of_rank[tiny_block_k];
+
+    u32 const tid = threadIdx.x;
+    u32 const blocks = (candidates.count + tiny_block_k - 1) / tiny_block_k;
+    u32 const block = blockIdx.x % blocks, span = blockIdx.x / blocks;
+    u32 const query_first = span * queries_per_workgroup;
+    u32 const queries_here = queries.count - query_first < queries_per_workgroup ? queries.count - query_first : queries_per_workgroup;
+    auto list = [&](int side, u64 address, u64 length, u32 index) { // an outlier: scored by levenshtein_outliers_kernel
+        u32 const place = atomicAdd(&outliers->counts[side], 1u);
+        if (place >= SZS_TINY_MOST_OUTLIERS) { // too many: the host scores the call the ordinary way (the other kernel reads no further)
+            *unfit = unfit_sequence;
+            return;
+        }
+        szs_string_ref_t ref;
+        ref.address = address, ref.length = (u32)length, ref.index = index;
+        if (length > 32u * SZS_MYERS_SHORT_WORDS) // too long for that kernel's bodies: listed as an EMPTY string (every slot the
+            ref.length = 0, *unfit = unfit_sequence; // other kernel reads holds a ref of this call), and the call is scored again
+        outliers->refs[side][place] = ref;
+    };
+
+    // ---- once per workgroup: the block's candidates (offsets, local sort by length), the span's query offsets, clean masks
+    u32 const my_candidate = block * tiny_block_k + tid;
+    u64 my_from = 0;
+    u32 my_length = 0;
+    bool my_tiny = false; // this thread's candidate exists and is scored here (up to 16 bytes)
+    if (my_candidate < candidates.count) {
+        my_from = tiny_offset(candidates.offsets, candidates.wide, my_candidate);
+        u64 const to = tiny_offset(candidates.offsets, candidates.wide, (u64)my_candidate + 1);
+        if (to < my_from) *unfit = unfit_sequence; // malformed offsets: the host's planner reports them
+        else if (to - my_from > tiny_rows_k) {
+            if (span == 0) list(1, candidates.base + my_from, to - my_from, my_candidate);
+        }
+        else my_length = (u32)(to - my_from), my_tiny = true;
+    }
+    for (u32 i = tid; i <= queries_here; i += 256) query_offsets[i] = tiny_offset(queries.offsets, queries.wide, (u64)query_first + i);
+    for (u32 i = tid; i < 256 * tiny_row_dwords_k; i += 256) peq[i] = 0;
+    if (tid < 32) bins[tid] = 0;
+    froms[tid] = my_from, lengths[tid] = my_tiny ? my_length : 0x80000000u; // (a skipped column sorts last and scores as an empty text)
+    if (blockIdx.x == 0 && tid < 2 && symbols_out) { // the call's cell count is the product of these two (the host's profile)
+        szs_tape_t const &tape = tid ? candidates : queries;
+        symbols_out[tid] = tiny_offset(tape.offsets, tape.wide, tape.count) - tiny_offset(tape.offsets, tape.wide, 0);
+    }
+    __syncthreads();
+    if (block == 0) // the span's long queries: listed once, by the workgroup of the first candidate block
+        for (u32 i = tid; i < queries_here; i += 256) {
+            u64 const from = query_offsets[i], to = query_offsets[i + 1];
+            if (to < from) *unfit = unfit_sequence;
+            else if (to - from > tiny_rows_k) list(0, queries.base + from, to - from, query_first + i);
+        }
+    // counting sort of the block's 256 lengths (0 ... 16, skipped columns last): rank -> the thread that holds that candidate
+    u32 const bin = my_tiny ? my_length : tiny_rows_k + 1;
+    u32 const place_in_bin = atomicAdd(&bins[bin], 1u);
+    __syncthreads();
+    if (tid < 32) { // exclusive scan of the bins by half a wavefront
+        u32 const mine = bins[tid];
+        u32 inclusive = mine;
+#pragma unroll
+        for (int offset = 1; offset < 32; offset <<= 1) {
+            u32 const other = (u32)__shfl_up((int)inclusive, offset, 64);
+            if (tid >= (u32)offset) inclusive += other;
+        }
+        bins[tid] = inclusive - mine;
+    }
+    __syncthreads();
+    lane_of_rank[bins[bin] + place_in_bin] = tid;
+    __syncthreads();
+    // this lane SCORES the candidate of rank ((wave + block) % 4) x 64 + lane - column `column` of the block
+    u32 const column = lane_of_rank[(((tid >> 6) + blockIdx.x) & 3u) * 64u + (tid & 63u)];
+    u32 const text_length = lengths[column] & 0x7FFFFFFFu; // 0 for a skipped column: nothing to consume, nothing written
+
+    text_stream_t const text(candidates.base + froms[column], text_length);
+    u32 symbols[4]; // the text's (up to) 16 bytes
+    {
+        u32 raw[5];
+#pragma unroll
+        for (u32 d = 0; d < 5; ++d) raw[d] = text.raw(d);
+#pragma unroll
+        for (u32 d = 0; d < 4; ++d) symbols[d] = text.splice(raw[d], raw[d + 1]);
+    }
+    u32 const longest_in_wave = wave_max_u32(text_length);
+
+    // ---- the span's queries, thirty-two at a time.  Thread t holds byte (t % 16) of slot t / 16 and of slot 16 + t / 16 - both
+    //      live in dword t / 16 of a row: the bytes of the NEXT group are in flight while this one is scored.
+    u32 const dword_of_mine = tid >> 4, position = tid & 15u, lane = tid & 63u;
+    auto length_of = [&](u32 query) -> u32 { // of a query of the span; 0 past the span's end, ~0 for one this kernel skips
+        if (query >= queries_here) return 0;
+        u64 const from = query_offsets[query], to = query_offsets[query + 1];
+        return to >= from && to - from <= tiny_rows_k ? (u32)(to - from) : ~0u;
+    };
+    auto fetch = [&](u32 query) -> u32 { // this thread's byte of that query, 0x100 where it has none
+        u32 const length = length_of(query);
+        if (length == ~0u || position >= length) return 0x100u;
+        return reinterpret_cast<u8 const *>(queries.base + query_offsets[query])[position];
+    };
+    u32 ahead_low = fetch(dword_of_mine), ahead_high = fetch(dword_of_mine + 16);
+#pragma unroll 1
+    for (u32 group_first = 0; group_first < queries_here; group_first += tiny_group_k) {
+        // masks: slot s lives in half s / 16 of dword s % 16 of every row; its query is right-aligned in the half's sixteen bits
+        u32 const length_low = length_of(group_first + dword_of_mine), length_high = length_of(group_first + dword_of_mine + 16);
+        if (ahead_low < 0x100u) atomicOr(&peq[ahead_low * tiny_row_dwords_k + dword_of_mine], 1u << (tiny_rows_k - length_low + position));
+        if (ahead_high < 0x100u) atomicOr(&peq[ahead_high * tiny_row_dwords_k + dword_of_mine], 0x10000u << (tiny_rows_k - length_high + position));
+        u32 const built_low = ahead_low, built_high = ahead_high;
+        // the next group's bytes go out now and come back under the scoring below
+        ahead_low = fetch(group_first + tiny_group_k + dword_of_mine), ahead_high = fetch(group_first + tiny_group_k + dword_of_mine + 16);
+        // the group's 32 lengths: lane l of every wavefront works out slot l's, `readlane` hands them round as scalars
+        u32 const length_of_my_slot = length_of(group_first + (lane & 31u));
+        __syncthreads();
+        // ---- sixteen registers of two patterns each; phantom low rows below a pattern shorter than 16
+        u32 vp[16], vn[16];
+        u32 skipped = 0; // bit s: slot s is a query this kernel leaves to the outliers' kernel (or lies past the span's end)
+#pragma unroll
+        for (u32 d = 0; d < 16; ++d) {
+            u32 const low = __builtin_amdgcn_readlane(length_of_my_slot, d), high = __builtin_amdgcn_readlane(length_of_my_slot, d + 16);
+            u32 const low_rows = low == ~0u ? 0u : low, high_rows = high == ~0u ? 0u : high;
+            skipped |= (low == ~0u || group_first + d >= queries_here ? 1u : 0u) << d;
+            skipped |= (high == ~0u || group_first + d + 16 >= queries_here ? 1u : 0u) << (d + 16);
+            vp[d] = ((0xFFFFu << (tiny_rows_k - low_rows)) & 0xFFFFu) | ((0xFFFF0000u << (tiny_rows_k - high_rows)) & 0xFFFF0000u);
+            vn[d] = 0;
+        }
+        uint4 const *const rows = reinterpret_cast<uint4 const *>(peq);
+        auto take = [&](u32 symbol) {
+            uint4 const *const row = rows + symbol * (tiny_row_dwords_k / 4);
+            uint4 const a = row[0], b = row[1], c = row[2], e = row[3];
+            u32 const masks[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, e.x, e.y, e.z, e.w};
+#pragma unroll
+            for (u32 d = 0; d < 16; ++d) tiny_column(vp[d], vn[d], masks[d]);
+        };
+#pragma unroll
+        for (u32 d = 0; d < 4; ++d) {
+            if (4 * d >= longest_in_wave) break; // wave-uniform
+#pragma unroll
+            for (u32 step = 0; step < 4; ++step)
+                if (4 * d + step < text_length) take((symbols[d] >> (8 * step)) & 0xFFu);
+        }
+        // ---- results: distance = text length + popcount(VP) - popcount(VN) per half (phantom rows hold zeros; at most 16, a byte
+        //      each), through LDS - `out[j][column]` packs the slots j, j + 8, j + 16, j + 24 - so that every wavefront writes 512
+        //      contiguous bytes of a row.  (Written straight from the registers - a lane its column, row by row - the launch took
+        //      70 us instead of 67 with one group per workgroup and 115 instead of 77 with four: partial lines.)
+#pragma unroll
+        for (u32 j = 0; j < 8; ++j) {
+            u32 packed = 0;
+#pragma unroll
+            for (u32 k = 0; k < 2; ++k) {
+                u32 const d = j + 8 * k;
+                u32 const low = text_length + (u32)__builtin_popcount(vp[d] & 0xFFFFu) - (u32)__builtin_popcount(vn[d] & 0xFFFFu);
+                u32 const high = text_length + (u32)__builtin_popcount(vp[d] >> 16) - (u32)__builtin_popcount(vn[d] >> 16);
+                packed |= (low << (8 * k)) | (high << (16 + 8 * k));
+            }
+            out[j * tiny_block_k + column] = packed;
+        }
+        __syncthreads();
+        // un-build the masks (the same dwords back to zero: cheaper than clearing 16 KB) ...
+        if (built_low < 0x100u) peq[built_low * tiny_row_dwords_k + dword_of_mine] = 0;
+        if (built_high < 0x100u) peq[built_high * tiny_row_dwords_k + dword_of_mine] = 0;
+        // ... and write the rows out: rows of skipped queries and columns of skipped candidates belong to the outliers' kernel
+        if (my_tiny) {
+            u64 *const first_row = results + (u64)(query_first + group_first) * results_row_stride + my_candidate;
+            u32 packed[8];
+#pragma unroll
+            for (u32 j = 0; j < 8; ++j) packed[j] = out[j * tiny_block_k + tid];
+#pragma unroll
+            for (u32 s = 0; s < tiny_group_k; ++s)
+                if (!((skipped >> s) & 1u)) first_row[(u64)s * results_row_stride] = (packed[s & 7u] >> (8 * (s >> 3))) & 0xFFu;
+        }
+        __syncthreads(); // the next group's atomics must not meet the un-building stores, nor its distances these reads
+    }
+}
+
+} // namespace szs_hip
+
+extern "C" int szs_hip_levenshtein_tiny(szs_tape_t const *queries_tape, szs_tape_t const *candidates_tape, uint64_t *results,
+                                        uint64_t results_row_stride, uint32_t *unfit, uint32_t unfit_sequence,
+                                        szs_tiny_outliers_t *outliers, unsigned long long *symbols_out, void *stream) {
+    using namespace szs_hip;
+    szs_tape_t const queries = *queries_tape, candidates = *candidates_tape;
+    u32 const queries_count = queries.count, candidates_count = candidates.count;
+    if (!queries_count || !candidates_count) return 0;
+    u64 const blocks = ((u64)candidates_count + tiny_block_k - 1) / tiny_block_k;
+    // Spans of the queries: enough workgroups to fill the device a few times over (a workgroup's set-up - offsets, the local sort -
+    // is paid once per span), whole groups of thirty-two, at most tiny_most_queries_k queries each.
+    // (measured on 4096 x 4096 words: 2048 workgroups of one group each 55.7 us, 1024 of two 57.1, 512 of four 68.6)
+    u64 const wanted_workgroups = 2048;
+    u64 spans = (wanted_workgroups + blocks - 1) / blocks;
+    u64 per_span = ((u64)queries_count + spans - 1) / spans;
+    per_span = (per_span + tiny_group_k - 1) / tiny_group_k * tiny_group_k;
+    if (per_span > tiny_most_queries_k) per_span = tiny_most_queries_k;
+    spans = ((u64)queries_count + per_span - 1) / per_span;
+    if (blocks * spans > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(levenshtein_tiny_kernel, dim3((u32)(blocks * spans)), dim3(256), 0, static_cast<hipStream_t>(stream), queries, candidates,
+                       (u32)per_span, results, results_row_stride, unfit, unfit_sequence, outliers, symbols_out);
+    return (int)hipGetLastError();
+}

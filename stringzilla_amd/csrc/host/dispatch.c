@@ -271,6 +271,8 @@ static void release_device_state(szs_engine_s *engine) {
     engine->queue_zeroed = NULL;
     szs_buffer_release(&engine->pinned_summary);
     szs_buffer_release(&engine->device_fused);
+    szs_buffer_release(&engine->device_outliers);
+    engine->tiny_valid = 0;
     engine->fused_zeroed = NULL;
     if (engine->events_device >= 0) {
         (void)hipEventDestroy(engine->event_start);
@@ -978,6 +980,7 @@ static sz_status_t finish(szs_call_t *call, szs_decision_t const *d, hipError_t 
                 call->phases[3] * 1e3, call->phases[4] * 1e3, call->phases[5] * 1e3, kernel_ms * 1e3,
                 profile->planner == 3   ? "previous plan of the same tapes, validated in the kernels"
                 : profile->planner == 4 ? "planned inside the scoring launch"
+                : profile->planner == 5 ? "not planned: tiny tokens, straight from the tapes"
                 : profile->planner == 2 ? "device-planned, speculated"
                 : profile->planner == 1 ? "device-planned"
                                         : "host-planned");
@@ -1023,6 +1026,84 @@ static int device_plannable(szs_engine_s const *engine, szs_input_t const *input
     return szs_classify_pointer(input->offsets).device_accessible && szs_classify_pointer(input->data).device_accessible;
 }
 
+/* ---- the tiny-token regime (hip/myers_tiny.hip; reference: cuda.cuh:2864, :4297-4340) ------------------------------------- */
+
+#define SZS_TINY_NOT_TAKEN ((sz_status_t)3) /* internal: score the call the ordinary way */
+
+/** Tiny tokens on both sides, enough of them to fill the device - or whatever the `tiny` knob says. */
+static int tiny_shaped(szs_engine_s const *engine, int symmetric, szs_side_stats_t const *queries, szs_side_stats_t const *candidates) {
+    int const knob = szs_tuning_get(szs_knob_tiny_k);
+    if (symmetric || !engine->is_unit_cost || knob == 0) return 0;
+    if (engine->family != szs_family_levenshtein_k && engine->family != szs_family_levenshtein_utf8_k /* an ASCII corpus */) return 0;
+    if (knob > 0) return 1;
+    /* word-like: mean length well under the sixteen rows of that kernel's bit-vectors (what is longer is listed for the outliers'
+     * kernel - a few per cent of a text's tokens; the kernel itself says when its lists overflow) and a matrix worth a launch */
+    return queries->symbols <= 10ull * queries->count && candidates->symbols <= 10ull * candidates->count && queries->count >= 64 &&
+           candidates->count >= 1024 && (uint64_t)queries->count * candidates->count >= (1ull << 20);
+}
+
+/**
+ *  One launch of the tiny-token kernel, straight from the caller's tapes, and the call's wait.  sz_success_k: scored.
+ *  SZS_TINY_NOT_TAKEN: the kernel met a query beyond 256 bytes or malformed offsets - nothing it wrote counts, the caller goes on
+ *  to the ordinary path (which also reports malformed tapes).  `planner_mode`: 1 when a planner's summary chose this kernel, 5 when
+ *  the previous call of the engine did and nothing was planned at all.
+ */
+static sz_status_t cross_tiny(szs_call_t *call, uint32_t planner_mode, szs_plan_summary_t const *seen /* or NULL */) {
+    szs_engine_s *engine = call->engine;
+    hipStream_t const stream = call->stream;
+    uint32_t volatile *const unfit = (uint32_t volatile *)((char *)engine->pinned_summary.pointer + 992);
+    unsigned long long volatile *const symbols = (unsigned long long volatile *)((char *)engine->pinned_summary.pointer + 976);
+    if (!++engine->plan_sequence) ++engine->plan_sequence;
+    uint32_t const sequence = engine->plan_sequence;
+    *unfit = 0, symbols[0] = symbols[1] = 0;
+    phase(call, 2);
+    sz_status_t reserved = szs_buffer_reserve(&engine->device_outliers, szs_memory_device_k, call->device, sizeof(szs_tiny_outliers_t), call->error_message);
+    if (reserved != sz_success_k) return reserved;
+    szs_tiny_outliers_t *const outliers = (szs_tiny_outliers_t *)engine->device_outliers.pointer;
+    szs_tape_t const q_tape = {call->queries->offsets, (uint64_t)(uintptr_t)call->queries->data, call->q_count, call->queries->kind == szs_input_u64tape_k};
+    szs_tape_t const c_tape = {call->candidates->offsets, (uint64_t)(uintptr_t)call->candidates->data, call->c_count,
+                               call->candidates->kind == szs_input_u64tape_k};
+    hipError_t error = hipMemsetAsync(outliers, 0, 16, stream); /* the two counts */
+    if (error == hipSuccess) error = hipEventRecord(engine->event_start, stream);
+    uint32_t launches = 0;
+    if (error == hipSuccess) {
+        error = (hipError_t)szs_hip_levenshtein_tiny(&q_tape, &c_tape, (uint64_t *)call->device_results, call->device_stride, (uint32_t *)unfit, sequence,
+                                                     outliers, (unsigned long long *)symbols, stream);
+        launches += error == hipSuccess;
+    }
+    if (error == hipSuccess) { /* tokens of more than 16 bytes: their rows and columns, by the ordinary bodies */
+        error = (hipError_t)szs_hip_levenshtein_outliers(outliers, &q_tape, &c_tape, (uint64_t *)call->device_results, call->device_stride, stream);
+        launches += error == hipSuccess;
+    }
+    szs_decision_t *const shape = (szs_decision_t *)calloc(1, sizeof(szs_decision_t)); /* what finish() reads: lanes tier, one launch */
+    if (!shape) return szs_report(sz_bad_alloc_k, call->error_message, NULL);
+    shape->tier = SZS_TIER_LANES, shape->q_count = call->q_count, shape->c_count = call->c_count;
+    if (seen) shape->longest[0] = seen->side[0].longest, shape->longest[1] = seen->side[1].longest;
+    engine->last_streams = 1;
+    engine->last_profile.planner = planner_mode;
+    int stalled = 0;
+    sz_status_t status = finish(call, shape, error, sz_success_k, launches, 0, 0, 0, &stalled);
+    free(shape);
+    if (status != sz_success_k) return status;
+    if (*unfit == sequence) {
+        engine->tiny_valid = 0;
+        return SZS_TINY_NOT_TAKEN;
+    }
+    szs_rocm_call_profile_t *profile = &engine->last_profile;
+    uint64_t const q_symbols = symbols[0], c_symbols = symbols[1];
+    profile->cells = q_symbols * c_symbols;
+    profile->algorithmic_bytes = (uint64_t)call->c_count * q_symbols + (uint64_t)call->q_count * c_symbols + profile->pairs * 16;
+    profile->unique_bytes += q_symbols + c_symbols;
+    /* the next call of these counts comes straight here - as long as the batch keeps looking like tiny tokens */
+    szs_side_stats_t now[2];
+    memset(now, 0, sizeof(now));
+    now[0].count = call->q_count, now[0].symbols = q_symbols, now[1].count = call->c_count, now[1].symbols = c_symbols;
+    engine->tiny_valid = tiny_shaped(engine, 0, &now[0], &now[1]);
+    engine->tiny_q_count = call->q_count, engine->tiny_c_count = call->c_count;
+    if (engine->remembered) engine->remembered->refs_current = 0, engine->remembered->valid = 0; /* another kind of call came between */
+    return szs_report(sz_success_k, call->error_message, NULL);
+}
+
 static sz_status_t cross_device_planned(szs_call_t *call) {
     szs_engine_s *engine = call->engine;
     hipStream_t const stream = call->stream;
@@ -1060,6 +1141,15 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
     status = place_results(call);
     if (status != sz_success_k) return status;
     phase(call, 0);
+
+    /* ---- tiny tokens (hip/myers_tiny.hip): the previous call of these counts was scored straight from the tapes - so is this one,
+     * with no planner at all; the kernel says when a query does not fit it */
+    if (engine->tiny_valid && !symmetric && engine->tiny_q_count == q_count && engine->tiny_c_count == c_count && use_myers &&
+        szs_tuning_get(szs_knob_tiny_k) != 0 && szs_tuning_get(szs_knob_speculate_k) != 0 && szs_tuning_get(szs_knob_tier_k) < 0 &&
+        szs_tuning_get(szs_knob_swap_k) < 0 && szs_tuning_get(szs_knob_queue_k) < 0) {
+        status = cross_tiny(call, 5, NULL);
+        if (status != SZS_TINY_NOT_TAKEN) return status;
+    }
 
     hipError_t error = hipSuccess;
     int const knobs_automatic = szs_tuning_get(szs_knob_speculate_k) != 0 && szs_tuning_get(szs_knob_tier_k) < 0 &&
@@ -1202,6 +1292,8 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
             profile->longest_query = seen_here.side[0].longest, profile->longest_candidate = seen_here.side[1].longest;
             remembered->longest[0] = seen_here.side[0].longest, remembered->longest[1] = seen_here.side[1].longest;
             stamp_refs(remembered, key_data, key_offsets, key_wide, &seen_here);
+            if (tiny_shaped(engine, symmetric, &seen_here.side[0], &seen_here.side[1]))
+                engine->tiny_valid = 1, engine->tiny_q_count = q_count, engine->tiny_c_count = c_count;
             return szs_report(sz_success_k, error_message, NULL);
         }
         /* not this shape after all: nothing real was scored; plan it */
@@ -1258,6 +1350,9 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
             profile->unique_bytes += seen.side[0].symbols + (symmetric ? 0 : seen.side[1].symbols);
             profile->longest_query = seen.side[0].longest, profile->longest_candidate = seen.side[1].longest;
             stamp_refs(remembered, key_data, key_offsets, key_wide, &seen);
+            /* scored on the previous call's shape - but if the batch turned out to be tiny tokens, the next one goes to their kernel */
+            if (tiny_shaped(engine, symmetric, &seen.side[0], &seen.side[1]))
+                engine->tiny_valid = 1, engine->tiny_q_count = q_count, engine->tiny_c_count = c_count;
             return szs_report(sz_success_k, error_message, NULL);
         }
         /* the shape changed (or the offsets are malformed): the refs were blanked, nothing real was scored */
@@ -1286,6 +1381,12 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
         engine->uniform_classes = classes ? classes : 1; /* a batch of empty strings: one class nobody belongs to */
     }
     phase(call, 1);
+
+    if (use_myers && szs_tuning_get(szs_knob_tier_k) < 0 && szs_tuning_get(szs_knob_swap_k) < 0 && szs_tuning_get(szs_knob_queue_k) < 0 &&
+        tiny_shaped(engine, symmetric, &seen.side[0], &seen.side[1])) { /* the summary says tiny tokens: no refs needed after all */
+        status = cross_tiny(call, 1, &seen);
+        if (status != SZS_TINY_NOT_TAKEN) return status;
+    }
 
     for (int attempt = 0; attempt < 2; ++attempt) { /* second round: a stalled band chain is re-run on the lanes tier */
         szs_decision_t d;

@@ -115,6 +115,9 @@ typedef struct szs_engine_s {
     int queue_refused;             /* this call is being scored again without the queue */
     szs_buffer_t device_fused;     /* device: the two `ready` words of the short launch that plans itself (kernels.h: szs_fused_plan_t) */
     void *fused_zeroed;            /* the allocation of `device_fused` that was zeroed */
+    szs_buffer_t device_outliers;  /* device: szs_tiny_outliers_t - the strings the tiny-token kernel leaves to the outliers' kernel */
+    int tiny_valid;                /* the previous call of these counts was scored by the tiny-token kernel (hip/myers_tiny.hip): go straight there */
+    uint32_t tiny_q_count, tiny_c_count;
     hipEvent_t event_start, event_stop;
     int events_device;
     /* launches of different bit-vector widths fan out over these and fill each other's tails (dispatch.c: enqueue) */

@@ -43,6 +43,7 @@ static struct {
     [szs_knob_queue_rounds_k] = {"queue_rounds", "SZS_ROCM_QUEUE_ROUNDS"},
     [szs_knob_queue_priority_k] = {"queue_priority", "SZS_ROCM_QUEUE_PRIORITY"},
     [szs_knob_fused_k] = {"fused", "SZS_ROCM_FUSED"},
+    [szs_knob_tiny_k] = {"tiny", "SZS_ROCM_TINY"},
 };
 
 /** Text -> value.  -1 always means "automatic".  Tier names: lanes 0, systolic 1, chain 2; planner: host 0, device 1. */

@@ -139,6 +139,21 @@ def config(index: int, scale: float = 1.0, generator: str = "numpy") -> Workload
         return Workload("cfg2p: 1024x1024 ASCII len 128 exactly, Levenshtein unit", "levenshtein",
                         random_tape(rng, side(1024), 128, 128, ASCII_PRINTABLE), random_tape(rng, side(1024), 128, 128, ASCII_PRINTABLE),
                         dict(match=0, mismatch=1, open=1, extend=1))
+    if index == 10:  # tiny tokens: what the reference's own benchmark tokeniser feeds (words of text, bench/shared.hpp:240-290) - the
+        # regime of its direct kernel (cuda.cuh:2864).  4096 x 4096 word-like tokens: lengths 1 ... 16 with the shape of English
+        # word lengths (mean ~5.6) and one token in 25 between 17 and 48 bytes (identifiers, paths), letters by their frequency
+        rng = np.random.default_rng(10)
+        letters = np.frombuffer(b"etaoinshrdlcumwfgypbvkjxqz", dtype=np.uint8)
+        weights = np.array([12.7, 9.1, 8.2, 7.5, 7.0, 6.7, 6.3, 6.1, 6.0, 4.3, 4.0, 2.8, 2.8, 2.4, 2.4, 2.2, 2.0, 2.0, 1.9, 1.5, 1.0, 0.8, 0.2, 0.2, 0.1, 0.1])
+        def words(count):
+            lengths = np.clip(rng.poisson(4.6, size=count) + 1, 1, 16)
+            long_ones = rng.random(count) < 0.04
+            lengths[long_ones] = rng.integers(17, 49, size=int(long_ones.sum()))
+            offsets = np.zeros(count + 1, dtype=np.uint32)
+            np.cumsum(lengths, out=offsets[1:])
+            return Strs.from_tape(letters[rng.choice(len(letters), size=int(offsets[-1]), p=weights / weights.sum())], offsets)
+        return Workload("words: 4096x4096 word-like tokens (mean 6.6 bytes, 4 % of 17-48), Levenshtein unit", "levenshtein",
+                        words(side(4096)), words(side(4096)), dict(match=0, mismatch=1, open=1, extend=1))
     if index in (7, 8):  # config 2's batch under NON-UNIT costs (a north_star function: szs_levenshtein_distances_init takes all four):
         rng = np.random.default_rng(2)  # 7: linear gaps, match 1 / mismatch 3 / gap 3; 8: affine gaps, mismatch 1 / open 4 / extend 2
         costs = dict(match=1, mismatch=3, open=3, extend=3) if index == 7 else dict(match=0, mismatch=1, open=4, extend=2)

@@ -561,9 +561,11 @@ def test_profile_cells_belong_to_the_batch_that_was_scored(gpu):
     assert cells(first) != cells(second)
     engine = szs.LevenshteinDistances(capabilities=gpu)
     seen = []
-    for pair in (first, second, first, second, second, second, first, first):
-        engine(pair[0], pair[1], device=gpu)
-        profile = engine.last_call_profile()
-        seen.append(int(profile.planner))
-        assert int(profile.cells) == cells(pair), (seen, int(profile.cells), cells(first), cells(second))
-    assert 2 in seen and 3 in seen  # both the speculated and the re-used path were taken
+    for fused in ("0", None):  # round 5: such calls plan themselves inside their launch (mode 4) unless the `fused` knob says no (mode 2)
+        with knob("fused", fused):
+            for pair in (first, second, first, second, second, second, first, first):
+                engine(pair[0], pair[1], device=gpu)
+                profile = engine.last_call_profile()
+                seen.append(int(profile.planner))
+                assert int(profile.cells) == cells(pair), (seen, int(profile.cells), cells(first), cells(second))
+    assert 2 in seen and 3 in seen and 4 in seen, seen  # the speculated, the re-used and the self-planned path were all taken

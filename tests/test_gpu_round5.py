@@ -141,3 +141,106 @@ def test_malformed_offsets_reach_the_caller_from_a_fused_launch_too(gpu):
     with pytest.raises(Exception) as problem:
         engine(queries, candidates, device=gpu)
     assert "ascend" in str(problem.value).lower() or "dimension" in str(problem.value).lower(), str(problem.value)
+
+
+# ---- 2. the tiny-token kernel (hip/myers_tiny.hip; the reference's fast path: cuda.cuh:2864, :4297-4340) -------------------------------
+#
+# Straight from the tapes, thirty-two queries per lane on 16-bit bit-vectors, whole runs of the result rows; strings of more than 16
+# bytes are listed for the outliers' kernel (the short kernel's bodies, a listed string against the other side's tape).  Pinned
+# here: tokens at every length 0 ... 16 beside outliers of up to 256 bytes on either side and on both, ragged counts around the
+# blocks of 256 candidates and the groups of 32 queries, bytes >= 0x80, 64-bit tapes, a padded results matrix; an outlier beyond
+# 256 bytes (or more outliers than the list holds) sends the call to the ordinary path; the automatic choice takes word-like
+# batches and nothing else.
+
+WORDS = b"etaoinshrdlucmfwypvbgkqjxz" + bytes(range(0xC0, 0xC8)) + b"\xff\x80"
+
+
+@pytest.mark.parametrize("rows,columns,longest_query,longest_text", [
+    (1, 1, 8, 8), (31, 255, 16, 16), (32, 256, 16, 16), (33, 257, 16, 16), (100, 700, 32, 40), (70, 300, 17, 16), (40, 520, 64, 9),
+    (65, 260, 128, 70), (20, 270, 256, 300), (300, 1000, 10, 10), (600, 300, 9, 256),
+])
+def test_tiny_tokens_straight_from_the_tapes(gpu, oracle, rows, columns, longest_query, longest_text):
+    rng = random.Random(rows * 7919 + columns)
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+    previous_fit = False
+    with knob("tiny", 1):
+        for batch in range(3):
+            # mostly word-sized, a few at the longest the shape allows (a group's width follows its longest query), some empty
+            length = lambda longest: rng.choice([0, 1, 2, 3, 5, 7, 8, longest, rng.randint(0, longest)])
+            queries = [bytes(rng.choice(WORDS) for _ in range(length(longest_query))) for _ in range(rows)]
+            candidates = [bytes(rng.choice(WORDS) for _ in range(length(longest_text))) for _ in range(columns)]
+            got = engine(queries, candidates, device=gpu)
+            expected = oracle.levenshtein(queries, candidates)
+            assert np.array_equal(got, expected), (batch, np.argwhere(got != expected)[:5].tolist())
+            profile = engine.last_call_profile()
+            assert profile.cells == sum(map(len, queries)) * sum(map(len, candidates))
+            fits = all(sum(len(s) > 16 for s in side) <= 256 and max(map(len, side)) <= 256 for side in (queries, candidates))
+            if fits:  # two launches: the tiny tokens, then the rows and columns of the longer ones
+                assert profile.launches == 2 and profile.planner == (5 if previous_fit else 1), (batch, profile.planner, profile.launches)
+            else:  # refused by the kernel (an outlier beyond 256 bytes): scored by the ordinary path
+                assert profile.planner != 5
+            previous_fit = fits
+
+
+def test_tiny_tokens_are_chosen_for_words_and_for_nothing_else(gpu, oracle):
+    rng = random.Random(2024)
+    word = lambda: bytes(rng.choice(b"etaoinshrdlu") for _ in range(rng.choice([1, 2, 3, 3, 4, 4, 5, 5, 6, 7, 8, 9, 11, 14])))
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+    modes = []
+    for batch in range(3):
+        queries, candidates = [word() for _ in range(600)], [word() for _ in range(2100)]
+        got = engine(queries, candidates, device=gpu)
+        assert np.array_equal(got, oracle.levenshtein(queries, candidates))
+        modes.append(int(engine.last_call_profile().planner))
+    assert modes == [1, 5, 5], modes
+    # the same counts, but the strings are sentences now: tried straight from the tapes (the previous call was), refused by the kernel
+    # - every string is an outlier - and scored by the ordinary kernels; words after that are recognised again by their summary
+    sentence = lambda: b" ".join(word() for _ in range(rng.randint(8, 20)))[:250]
+    queries, candidates = [sentence() for _ in range(600)], [sentence() for _ in range(2100)]
+    assert np.array_equal(engine(queries, candidates, device=gpu), oracle.levenshtein(queries, candidates))
+    assert engine.last_call_profile().planner != 5
+    modes = []
+    for _ in range(2):  # the first may still be scored on the sentences' remembered shape (speculated: 2); its summary says "words"
+        queries, candidates = [word() for _ in range(600)], [word() for _ in range(2100)]
+        assert np.array_equal(engine(queries, candidates, device=gpu), oracle.levenshtein(queries, candidates))
+        modes.append(int(engine.last_call_profile().planner))
+    assert modes[0] in (1, 2) and modes[1] == 5 and engine.last_call_profile().launches == 2, modes
+    # config 2's shape never goes there
+    load = workloads.config(2, scale=1 / 4)
+    engine(load.queries, load.candidates, device=gpu)
+    assert engine.last_call_profile().planner != 5
+    with knob("tiny", 0):  # ... and words do not when the knob says so
+        queries, candidates = [word() for _ in range(600)], [word() for _ in range(2100)]
+        for _ in range(2):
+            assert np.array_equal(engine(queries, candidates, device=gpu), oracle.levenshtein(queries, candidates))
+            assert engine.last_call_profile().planner != 5
+
+
+def test_a_query_the_tiny_kernel_cannot_hold_sends_the_call_to_the_ordinary_path(gpu, oracle):
+    import torch
+
+    rng = random.Random(31)
+    word = lambda: bytes(rng.choice(WORDS) for _ in range(rng.randint(0, 12)))
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+    with knob("tiny", 1):
+        for batch in range(2):
+            queries, candidates = [word() for _ in range(50)], [word() for _ in range(400)]
+            assert np.array_equal(engine(queries, candidates, device=gpu), oracle.levenshtein(queries, candidates))
+        assert engine.last_call_profile().planner == 5
+        queries = [word() for _ in range(50)]
+        queries[33] = bytes(rng.choice(WORDS) for _ in range(257))
+        candidates = [word() for _ in range(400)]
+        got = engine(queries, candidates, device=gpu)  # same counts: tried straight from the tapes, refused by the kernel, planned
+        expected = oracle.levenshtein(queries, candidates)
+        assert np.array_equal(got, expected), np.argwhere(got != expected)[:5].tolist()
+        assert engine.last_call_profile().planner != 5
+        # 64-bit tapes, a results matrix with padding columns that must stay untouched
+        for batch in range(2):
+            queries = szs.Strs([word() for _ in range(37)], wide_offsets=True)
+            candidates = szs.Strs([word() for _ in range(513)], wide_offsets=True)
+            out = torch.full((37, 600), -1, dtype=torch.int64, device="cuda:0")
+            engine(queries, candidates, device=gpu, out=out[:, :513])
+            expected = oracle.levenshtein([queries[i] for i in range(37)], [candidates[i] for i in range(513)])
+            assert np.array_equal(out[:, :513].cpu().numpy().view(np.uint64), expected)
+            assert (out[:, 513:] == -1).all()
+        assert engine.last_call_profile().planner == 5
