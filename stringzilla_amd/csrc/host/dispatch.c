@@ -775,7 +775,7 @@ static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int dev
                                                        (uint32_t *)engine->device_queue.pointer, engine->queue_tickets, &taken, trace,
                                                        d->runes ? d->alphabet : 0u, unfit, engine->queue_unfit_sequence, stream);
         engine->queue_tickets += taken; /* wraps with the counter */
-        if (!launch_error) ++*launches;
+        if (!launch_error) ++*launches, engine->last_queued = 1; /* (a guarded re-use of the plan takes the per-width launches: not this) */
     }
     if (fan_out) /* join, also after a failed launch: whatever was enqueued anywhere is drained by the wait on the scope's stream */
         for (unsigned i = 0; i < aux_used; ++i) {
@@ -878,6 +878,9 @@ static sz_status_t finish(szs_call_t *call, szs_decision_t const *d, hipError_t 
     phase(call, 3); /* launches enqueued */
     hipError_t const drained = hipStreamSynchronize(stream); /* the call is synchronous, like the reference's - also when it fails */
     phase(call, 4); /* waiting for the device */
+    if (status != sz_success_k || error != hipSuccess || drained != hipSuccess)
+        engine->queue_zeroed = NULL; /* the host's mirror of the queue kernel's ticket counter may no longer match the device's (a launch
+                                        counted but never run, or run but reported failed): prepare() zeroes both before the next one */
     if (status != sz_success_k) return status;
     if (error == hipSuccess) error = drained;
     if (error != hipSuccess) return szs_report_hip(error, call->error_message);
@@ -905,7 +908,8 @@ static sz_status_t finish(szs_call_t *call, szs_decision_t const *d, hipError_t 
     profile->team = cell_bits == 16 ? d->team : 0;
     profile->team_wide = profile->team ? (uint32_t)d->team_wide : 0;
     profile->streams = engine->last_streams ? engine->last_streams : 1;
-    profile->queue_items = d->use_queue && launches ? d->queue.items_total : 0, profile->queue_tiles = profile->queue_items ? d->queue.tiles_count : 0;
+    profile->queue_items = engine->last_queued ? d->queue.items_total : 0, profile->queue_tiles = profile->queue_items ? d->queue.tiles_count : 0;
+    engine->last_queued = 0;
     profile->longest_query = d->longest[0], profile->longest_candidate = d->longest[1];
     profile->host_milliseconds = now_milliseconds() - call->started;
     phase(call, 5);
@@ -1544,7 +1548,9 @@ static sz_status_t cross_device_planned_runes(szs_call_t *call) {
      * was as long as the scoring (profiles/r03/real_text.jsonl). */
     int const knobs_automatic = szs_tuning_get(szs_knob_speculate_k) != 0 && szs_tuning_get(szs_knob_tier_k) < 0 &&
                                 szs_tuning_get(szs_knob_swap_k) < 0 && szs_tuning_get(szs_knob_cells_k) < 0 && szs_tuning_get(szs_knob_packed_k) < 0 &&
-                                szs_tuning_get(szs_knob_team_k) < 0 && szs_tuning_get(szs_knob_rune_ids_k) < 0;
+                                szs_tuning_get(szs_knob_team_k) < 0 && szs_tuning_get(szs_knob_rune_ids_k) < 0 &&
+                                szs_tuning_get(szs_knob_queue_k) < 0; /* (a pinned `queue` knob makes one-group calls queue launches: those are
+                                                                         planned and waited for, like the byte path's) */
     if (remembered->valid && remembered->runes && remembered->tier == SZS_TIER_LANES && remembered->use_myers && remembered->q_count == q_count &&
         remembered->c_count == c_count && remembered->symmetric == symmetric && knobs_automatic && (!remembered->alphabet || renumber) &&
         is_one_launch(remembered) /* see cross_device_planned */) {

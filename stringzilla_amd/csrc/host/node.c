@@ -411,28 +411,49 @@ static void *node_worker(void *argument) {
     return NULL;
 }
 
-/** Fills the cells above the diagonal from the ones below: on the device when it can reach the matrix, on the host otherwise. */
+/** Fills the cells above the diagonal from the ones below: in place on the GPU that owns the matrix when that is one of the node's
+ *  (or the matrix is unified / pinned memory any GPU reaches); staged through the node's first GPU when the matrix lives on a GPU
+ *  the node does not drive (peer access is only arranged among the node's own GPUs: a kernel there would fault); on the host, tile
+ *  by tile, when no GPU reaches it. */
 static sz_status_t node_mirror(szs_node_s *node, void *results, size_t side, size_t stride, char const **error_message) {
     szs_pointer_traits_t const traits = szs_classify_pointer(results);
     if (!traits.device_accessible) {
         uint64_t *const matrix = (uint64_t *)results;
-        for (size_t i = 1; i < side; ++i)
-            for (size_t j = 0; j < i; ++j) matrix[j * stride + i] = matrix[i * stride + j];
+        enum { tile = 32 }; /* a strided column walk over the whole triangle missed the cache on every cell */
+        for (size_t i0 = 0; i0 < side; i0 += tile)
+            for (size_t j0 = 0; j0 <= i0; j0 += tile)
+                for (size_t i = i0; i < side && i < i0 + tile; ++i)
+                    for (size_t j = j0; j < i && j < j0 + tile; ++j) matrix[j * stride + i] = matrix[i * stride + j];
         return sz_success_k;
     }
     size_t shard = 0; /* the GPU that owns the matrix, when it is one of the node's; else the first */
+    int foreign = 0;  /* device memory of a GPU that is not one of the node's */
     hipPointerAttribute_t attributes;
     memset(&attributes, 0, sizeof(attributes));
     if (hipPointerGetAttributes(&attributes, results) == hipSuccess && attributes.type == hipMemoryTypeDevice) {
+        foreign = 1;
         for (size_t s = 0; s < node->count; ++s)
-            if (node->devices[s] == attributes.device) { shard = s; break; }
+            if (node->devices[s] == attributes.device) { shard = s, foreign = 0; break; }
     }
     else (void)hipGetLastError();
     int device = 0;
     hipStream_t stream = NULL;
     sz_status_t const status = szs_scope_bind_gpu(node->scopes[shard], &device, &stream, error_message);
     if (status != sz_success_k) return status;
-    hipError_t error = (hipError_t)szs_hip_mirror_lower((uint64_t *)results, (uint32_t)side, stride, stream);
+    hipError_t error = hipSuccess;
+    if (foreign) { /* copy in (the runtime routes device-to-device copies itself), mirror here, copy back */
+        uint64_t *staged = NULL;
+        size_t const row_bytes = side * sizeof(uint64_t);
+        error = hipMalloc((void **)&staged, side * row_bytes);
+        if (error == hipSuccess) error = hipMemcpy2DAsync(staged, row_bytes, results, stride * sizeof(uint64_t), row_bytes, side, hipMemcpyDefault, stream);
+        if (error == hipSuccess) error = (hipError_t)szs_hip_mirror_lower(staged, (uint32_t)side, side, stream);
+        if (error == hipSuccess) error = hipMemcpy2DAsync(results, stride * sizeof(uint64_t), staged, row_bytes, row_bytes, side, hipMemcpyDefault, stream);
+        hipError_t const drained = hipStreamSynchronize(stream);
+        if (error == hipSuccess) error = drained;
+        if (staged) (void)hipFree(staged);
+        return error == hipSuccess ? sz_success_k : szs_report_hip(error, error_message);
+    }
+    error = (hipError_t)szs_hip_mirror_lower((uint64_t *)results, (uint32_t)side, stride, stream);
     hipError_t const drained = hipStreamSynchronize(stream);
     if (error == hipSuccess) error = drained;
     return error == hipSuccess ? sz_success_k : szs_report_hip(error, error_message);

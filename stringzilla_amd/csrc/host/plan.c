@@ -180,7 +180,8 @@ static uint32_t queue_table_dwords(queue_tables_t const *tables, uint32_t length
     *sparse = 0;
     if (!tables->runes) { /* rows of 1, 2 or 4 words: [chunk][256][4] */
         unsigned const body = lanes > 1 ? words_per_lane * lanes : needed <= 8 ? needed : needed <= 10 ? 10u : needed <= 12 ? 12u : needed <= 16 ? 16u : 20u;
-        return body >= 3 ? 256u * ((body + 3u) & ~3u) : 256u * body;
+        uint64_t const dwords = body >= 3 ? 256ull * ((body + 3u) & ~3u) : 256ull * body;
+        return dwords <= tables->arena_dwords ? (uint32_t)dwords : 0u; /* (a 12 x 6 = 72-word team does not fit the 64 KB arena: not a shape) */
     }
     unsigned const body = lanes > 1 ? words_per_lane * lanes : needed <= 8 ? needed : needed <= 12 ? 12u : 16u;
     uint64_t const direct = (uint64_t)tables->rows * ((body + 3u) & ~3u);
@@ -350,11 +351,18 @@ void szs_plan_queue(szs_plan_t const *plan, uint32_t queries_count, uint32_t can
         uint64_t items = 0;
         for (unsigned t = 0; t < tiles; ++t) items += SZS_QUEUE_ITEMS_OF(&queue->tiles[t]);
         if (items < (1ull << 31)) break;
+        unsigned coarsened = 0;
         for (unsigned t = 0; t < tiles; ++t) {
             szs_queue_tile_t *tile = &queue->tiles[t];
             uint32_t const span = tile->candidate_end - tile->candidate_first;
+            if (tile->candidates_per_item >= span) continue; /* an item already spans the column */
             tile->candidates_per_item = tile->candidates_per_item * 2u < span ? tile->candidates_per_item * 2u : span;
-            keys[t] *= 2;
+            keys[t] *= 2, ++coarsened;
+        }
+        if (!coarsened) { /* 2^31 items even with whole columns per item (2^31 groups of queries): no queue - the call takes the
+                             per-width launches, which cut enormous cross-products along the query axis themselves */
+            memset(queue, 0, sizeof(*queue));
+            return;
         }
     }
     /* ---- longest first (stable: equal keys keep widest-slice-first, lightest column first), then the tiles' places in the queue */

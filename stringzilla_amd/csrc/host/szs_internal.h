@@ -113,6 +113,7 @@ typedef struct szs_engine_s {
     uint32_t queue_tickets;        /* the counter's value when the next launch begins (every launch says what it takes) */
     uint32_t queue_unfit_sequence; /* what the current call's queue launch writes to pinned memory if a query fits none of its tables; 0: no such launch */
     int queue_refused;             /* this call is being scored again without the queue */
+    int last_queued;               /* enqueue() issued the persistent launch for the call being finished (the call profile says so) */
     szs_buffer_t device_fused;     /* device: the two `ready` words of the short launch that plans itself (kernels.h: szs_fused_plan_t) */
     void *fused_zeroed;            /* the allocation of `device_fused` that was zeroed */
     szs_buffer_t device_outliers;  /* device: szs_tiny_outliers_t - the strings the tiny-token kernel leaves to the outliers' kernel */

@@ -144,7 +144,15 @@ class ShardedEngine:
             if first:
                 parts.append(self._score(band, strings.select(np.arange(0, first))))  # the rectangle
             parts.append(self._score(band, None))                                        # the band's own triangle, mirrored inside
-        as_tensor = any(isinstance(part, torch.Tensor) for part in parts)
+        # What kind of matrix this is - a device tensor or a NumPy one, signed or unsigned cells - is the SCORER's choice, and a rank
+        # whose band is empty (fewer rows than ranks, very skewed strings) has no part to read it from: the ranks agree on it (one
+        # small all-reduce; -1 = "no part here"), so that every rank returns the same kind and collectives on the results line up.
+        kind = torch.tensor([-1 if not parts else int(any(isinstance(part, torch.Tensor) for part in parts)),
+                             -1 if not parts or isinstance(parts[0], torch.Tensor) else int(np.asarray(parts[0]).dtype == np.uint64)],
+                            dtype=torch.int64, device=self._device())
+        self._dist.all_reduce(kind, op=self._dist.ReduceOp.MAX, group=self.group)
+        as_tensor = int(kind[0]) > 0
+        agreed_dtype = np.uint64 if int(kind[1]) > 0 else np.int64
         device = self._device() if as_tensor or gather else torch.device("cpu")
         local = torch.zeros((end - first, count), dtype=torch.int64, device=device if as_tensor else torch.device("cpu"))
         column = 0
@@ -152,7 +160,7 @@ class ShardedEngine:
             block = part if isinstance(part, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(part).view(np.int64))
             local[:, column:column + block.shape[1]] = block.to(local.device)
             column += block.shape[1]
-        dtype = np.int64 if as_tensor or not parts else np.asarray(parts[0]).dtype
+        dtype = np.int64 if as_tensor else agreed_dtype
         if not gather:
             return rows, (local if as_tensor else local.numpy().view(dtype))
         # equal-sized (padded) bands, all-gathered; then the cells above the diagonal from the ones below

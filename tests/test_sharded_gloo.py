@@ -57,8 +57,10 @@ def _worker(rank, world, port, out_dir):
     few = workloads.config(5, scale=1 / 640) if rank == 0 else None
     few_full = engine(few.queries if few else None, few.candidates if few else None, source=0, gather=True)
     few_mirrored = engine(few.queries if few else None, None, source=0, gather=True)
+    _, few_band = engine(few.queries if few else None, None, source=0)  # ranks without a row still return the scorer's KIND of matrix
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), rows=rows, local=local, full=full, balance=balance, band_rows=band_rows,
-             band=band, band_cells=band_cells, band_balance=band_balance, mirrored=mirrored, few_full=few_full, few_mirrored=few_mirrored)
+             band=band, band_cells=band_cells, band_balance=band_balance, mirrored=mirrored, few_full=few_full, few_mirrored=few_mirrored,
+             few_band_kind=f"{type(few_band).__name__}:{few_band.dtype}:{few_band.shape[0]}")
     dist.barrier()
     dist.destroy_process_group()
 
@@ -98,5 +100,8 @@ def test_sharding_reassembles_the_matrix(tmp_path, oracle, world):
         band_cells += int(shard["band_cells"])
         assert np.array_equal(shard["few_full"], oracle.levenshtein(strings(few.queries), strings(few.candidates)))
         assert np.array_equal(shard["few_mirrored"], oracle.levenshtein(strings(few.queries), None))
+    kinds = [str(np.load(os.path.join(str(tmp_path), f"rank{rank}.npz"))["few_band_kind"]) for rank in range(world)]
+    assert len({kind.rsplit(":", 1)[0] for kind in kinds}) == 1 and kinds[0].startswith("ndarray:uint64"), kinds  # one kind on every rank,
+    assert world == 2 or any(kind.endswith(":0") for kind in kinds)                                              # also on those without a row
     assert seen.all() and band_seen.all()                                 # every row scored exactly once, in both modes
     assert band_cells == triangle_cells                                   # the ranks together scored the TRIANGLE, not the square
