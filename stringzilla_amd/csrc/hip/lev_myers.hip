@@ -534,11 +534,12 @@ __global__ __launch_bounds__(256, SZS_MYERS_FUSED_WAVES) void levenshtein_myers_
  *  The strings the tiny-token kernel (hip/myers_tiny.hip) left out - tokens of more than 16 bytes among words of text, a few per
  *  cent of them, listed by that kernel.  ONE launch, three kinds of workgroup:
  *
- *    A  listed CANDIDATES as texts against the tiny queries as patterns: a workgroup builds the 16-bit masks of 128 consecutive
- *       queries (`table[byte][64 dwords]`: lane l holds query l in its low half and query 64 + l in its high half) and every
- *       wavefront walks listed texts ONE AT A TIME - the text's symbol is the same for all 64 lanes, each lane reads its own dword
- *       of the row (no bank conflict) and advances two patterns with the eleven instructions of `tiny_column`.  A 100-byte URL
- *       costs its wavefront 100 such steps, not 100 steps of sixteen registers; nobody waits for it but its own wavefront.
+ *    A  listed CANDIDATES as texts against the tiny queries as patterns: a wavefront takes 128 consecutive queries - lane l holds
+ *       query l in the low half of a register and query 64 + l in the high half - and FOUR listed texts side by side (one text
+ *       is one chain of dependent instructions).  A text's symbol is the same for all 64 lanes; each lane reads its own dword
+ *       of that symbol's row of the masks table (device memory, built by `levenshtein_tiny_prepare_kernel`; L2-resident, 256
+ *       contiguous bytes per wavefront and read) and advances two patterns with the eleven instructions of the packed column.
+ *       A 100-byte URL costs its wavefront 100 such steps, not 100 steps of sixteen registers; nobody else waits for it.
  *    B  the same with the sides swapped: listed QUERIES as texts against the tiny candidates (a lane's results are consecutive
  *       columns of the text's row).
  *    C  listed queries against listed candidates: the ordinary bodies of the short kernel, a listed query as the pattern (up to
@@ -546,13 +547,12 @@ __global__ __launch_bounds__(256, SZS_MYERS_FUSED_WAVES) void levenshtein_myers_
  *
  *  (Round 5's first version scored a listed string as the PATTERN against the other side's tape, block by block: unsorted
  *  texts, every column through the predicated tail loop - 56 us for the 410 outliers of 4096 x 4096 words, as long as the
- *  tiny-token kernel itself.  This one: 49 us - kind C alone 19, kinds A and B ~45 each, side by side; they are chains of
- *  dependent instructions on one or two wavefronts per SIMD, and what is left of the call's time once the tiny kernel's is
- *  taken out.  Measured on the way: one text at a time per wavefront 65 us; four at a time with a uniform branch per column 68;
- *  branch-free with the sixteen mask reads of a step issued together 49.)
+ *  tiny-token kernel itself.  The second kept the masks of 128 patterns in 64 KB of LDS per workgroup: two workgroups per CU,
+ *  chains of dependent instructions on one or two wavefronts per SIMD - one text at a time per wavefront 65 us, four at a time
+ *  with a uniform branch per column 68, branch-free with the sixteen mask reads of a step issued together 49; kind C alone 19.)
  */
-constexpr u32 outlier_patterns_k = 128;  // tiny patterns per workgroup of kinds A / B: two per lane
-constexpr u32 outlier_text_chunk_k = 32; // listed texts per workgroup: eight per wavefront, four at a time
+constexpr u32 outlier_patterns_k = 128;  // tiny patterns per wavefront of kinds A / B: two per lane
+constexpr u32 outlier_text_chunk_k = 16; // listed texts per workgroup: four per wavefront, side by side
 typedef unsigned short outlier_pk_u16 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void outlier_column(u32 &vp, u32 &vn, u32 eq) { // one DP column of two 16-row patterns (myers_tiny.hip)
     u32 const xv = eq | vn;
@@ -568,10 +568,11 @@ __device__ __forceinline__ void outlier_column(u32 &vp, u32 &vn, u32 eq) { // on
 }
 
 __global__ __launch_bounds__(256) void levenshtein_outliers_kernel(szs_tiny_outliers_t const *__restrict__ outliers, szs_tape_t queries,
-                                                                  szs_tape_t candidates, u32 query_groups, u32 candidate_groups,
-                                                                  u64 *__restrict__ results, u64 results_row_stride) {
-    __shared__ __attribute__((aligned(16))) u32 table[256 * 64]; // kinds A / B: the masks, 64 KB; kind C: the short kernel's masks + refs
-    __shared__ u64 pattern_offsets[outlier_patterns_k + 1];
+                                                                  szs_tape_t candidates, u32 const *__restrict__ query_masks,
+                                                                  u32 const *__restrict__ candidate_masks, u32 query_groups,
+                                                                  u32 candidate_groups, u64 *__restrict__ results, u64 results_row_stride) {
+    __shared__ __attribute__((aligned(16))) u32 peq[peq_layout<8, byte_rows_k>::total_dwords]; // kind C only
+    __shared__ __attribute__((aligned(16))) szs_string_ref_t listed_texts[SZS_TINY_MOST_OUTLIERS];
     constexpr u32 chunks = SZS_TINY_MOST_OUTLIERS / outlier_text_chunk_k;
     u32 const tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     u32 const listed_queries = outliers->counts[0] < SZS_TINY_MOST_OUTLIERS ? outliers->counts[0] : SZS_TINY_MOST_OUTLIERS;
@@ -582,14 +583,13 @@ __global__ __launch_bounds__(256) void levenshtein_outliers_kernel(szs_tiny_outl
         u32 const listed = blockIdx.x - workgroups_a - workgroups_b;
         if (listed >= listed_queries || !listed_candidates) return;
         szs_string_ref_t const pattern = outliers->refs[0][listed];
-        szs_string_ref_t *const texts = reinterpret_cast<szs_string_ref_t *>(table + peq_layout<8, byte_rows_k>::total_dwords);
-        if (tid < listed_candidates) texts[tid] = outliers->refs[1][tid];
+        if (tid < listed_candidates) listed_texts[tid] = outliers->refs[1][tid];
         __syncthreads();
         szs_ref_guard_t const none = {};
         u32 const words = __builtin_amdgcn_readfirstlane(pattern.length ? (pattern.length + 31u) / 32u : 1u);
 #define SZS_OUTLIER_BODY(W)                                                                                            \
     case W:                                                                                                            \
-        myers_workgroup<W, SZS_MYERS_SHORT_TEXT_DWORDS, false>(table, nullptr, pattern, texts, listed_candidates, 0u, results, \
+        myers_workgroup<W, SZS_MYERS_SHORT_TEXT_DWORDS, false>(peq, nullptr, pattern, listed_texts, listed_candidates, 0u, results, \
                                                                results_row_stride, 0, none);                          \
         break;
         switch (words) {
@@ -600,8 +600,8 @@ __global__ __launch_bounds__(256) void levenshtein_outliers_kernel(szs_tiny_outl
             SZS_OUTLIER_BODY(5)
             SZS_OUTLIER_BODY(6)
             SZS_OUTLIER_BODY(7)
-        default: // 8; the tiny kernel lists nothing longer
-            myers_workgroup<8, SZS_MYERS_SHORT_TEXT_DWORDS, false>(table, nullptr, pattern, texts, listed_candidates, 0u, results,
+        default: // 8; nothing longer is listed
+            myers_workgroup<8, SZS_MYERS_SHORT_TEXT_DWORDS, false>(peq, nullptr, pattern, listed_texts, listed_candidates, 0u, results,
                                                                    results_row_stride, 0, none);
             break;
         }
@@ -609,125 +609,89 @@ __global__ __launch_bounds__(256) void levenshtein_outliers_kernel(szs_tiny_outl
         return;
     }
 
-    // ---- kinds A and B
+    // ---- kinds A and B: this wavefront's 128 patterns (their masks come from the table `levenshtein_tiny_prepare_kernel` built in
+    //      device memory - 2 MB for a side of 4096 strings, L2-resident) against four listed texts side by side
     bool const texts_are_candidates = blockIdx.x < workgroups_a;
     u32 const local = texts_are_candidates ? blockIdx.x : blockIdx.x - workgroups_a;
     u32 const group = local / chunks, chunk = local % chunks;
     int const side_of_texts = texts_are_candidates ? 1 : 0;
     u32 const texts_count = texts_are_candidates ? listed_candidates : listed_queries;
-    if (chunk * outlier_text_chunk_k >= texts_count) return;
+    constexpr u32 together = 4;
+    u32 const first_text = chunk * outlier_text_chunk_k + wave * together;
+    if (first_text >= texts_count) return; // (uniform per wavefront; no barrier below)
     szs_tape_t const &patterns = texts_are_candidates ? queries : candidates;
+    u32 const *const masks = texts_are_candidates ? query_masks : candidate_masks;
+    u32 const row_dwords = ((patterns.count + 127u) / 128u) * 64u;
     u32 const pattern_first = group * outlier_patterns_k;
-    u32 const patterns_here = patterns.count - pattern_first < outlier_patterns_k ? patterns.count - pattern_first : outlier_patterns_k;
-    for (u32 i = tid; i <= patterns_here; i += 256) pattern_offsets[i] = fused_offset(patterns.offsets, patterns.wide, (u64)pattern_first + i);
-    for (u32 i = tid; i < 256 * 64; i += 256) table[i] = 0;
-    __syncthreads();
-    auto rows_of = [&](u32 p) -> u32 { // bytes of pattern p of the group; ~0: absent, or one of the listed (long) strings itself
-        if (p >= patterns_here) return ~0u;
-        u64 const from = pattern_offsets[p], to = pattern_offsets[p + 1];
+    auto rows_of = [&](u32 p) -> u32 { // bytes of pattern p; ~0: absent, or one of the listed (long) strings itself
+        if (p >= patterns.count) return ~0u;
+        u64 const from = fused_offset(patterns.offsets, patterns.wide, p), to = fused_offset(patterns.offsets, patterns.wide, (u64)p + 1);
         return to >= from && to - from <= 16 ? (u32)(to - from) : ~0u;
     };
-    { // this thread's eight pattern bytes: all loads first (one round trip), then the atomics
-        constexpr u32 items = outlier_patterns_k * 16 / 256;
-        u32 bytes[items], bits[items];
-#pragma unroll
-        for (u32 k = 0; k < items; ++k) {
-            u32 const item = tid + k * 256, p = item >> 4, at = item & 15u, rows = rows_of(p);
-            bytes[k] = 0x100u, bits[k] = 0;
-            if (rows == ~0u || at >= rows) continue;
-            bytes[k] = reinterpret_cast<u8 const *>(patterns.base + pattern_offsets[p])[at];
-            bits[k] = (p < 64 ? 1u : 0x10000u) << (16 - rows + at);
-        }
-#pragma unroll
-        for (u32 k = 0; k < items; ++k)
-            if (bytes[k] < 0x100u) atomicOr(&table[bytes[k] * 64 + (((tid + k * 256) >> 4) & 63u)], bits[k]);
-    }
-    __syncthreads();
-    u32 const rows_low = rows_of(lane), rows_high = rows_of(lane + 64);
+    u32 const rows_low = rows_of(pattern_first + lane), rows_high = rows_of(pattern_first + lane + 64);
     u32 const vp_start = ((0xFFFFu << (16 - (rows_low == ~0u ? 0u : rows_low))) & 0xFFFFu) |
                          ((0xFFFF0000u << (16 - (rows_high == ~0u ? 0u : rows_high))) & 0xFFFF0000u);
-    u32 const texts_end = (chunk + 1) * outlier_text_chunk_k < texts_count ? (chunk + 1) * outlier_text_chunk_k : texts_count;
-    // FOUR texts at a time per wavefront: one text is one chain of dependent instructions (a column needs the column before it),
-    // and a CU holds only two of these workgroups (the table) - four independent chains keep the SIMD issuing.
-    constexpr u32 together = 4;
-    // (the refs and the first two dwords of the NEXT four texts are fetched before the columns of the current four: two dependent
-    // round trips to memory otherwise stand in front of every quartet)
-    auto fetch_refs = [&](u32 first_text, szs_string_ref_t (&refs)[together]) {
-#pragma unroll
-        for (u32 k = 0; k < together; ++k) {
-            refs[k] = outliers->refs[side_of_texts][first_text + k < texts_end ? first_text + k : texts_end - 1]; // the same for all 64 lanes
-            if (first_text + k >= texts_end) refs[k].length = 0;
-        }
-    };
-    szs_string_ref_t refs_ahead[together];
-    u32 raw_ahead[together][2];
-    u32 const first_quartet = chunk * outlier_text_chunk_k + wave * together;
-    fetch_refs(first_quartet, refs_ahead);
+    u32 const *const my_masks = masks + group * 64u + lane; // + byte x row_dwords
+    szs_string_ref_t refs[together];
+    u32 vp[together], vn[together], raw_low[together], next[together], longest = 0;
 #pragma unroll
     for (u32 k = 0; k < together; ++k) {
-        text_stream_t const text(refs_ahead[k].address, refs_ahead[k].length);
-        raw_ahead[k][0] = text.raw(0), raw_ahead[k][1] = text.raw(1);
+        refs[k] = outliers->refs[side_of_texts][first_text + k < texts_count ? first_text + k : first_text]; // the same for all 64 lanes
+        if (first_text + k >= texts_count) refs[k].length = 0;
+        longest = refs[k].length > longest ? refs[k].length : longest;
+        vp[k] = vp_start, vn[k] = 0;
     }
-#pragma unroll 1
-    for (u32 first_text = first_quartet; first_text < texts_end; first_text += 4 * together) {
-        szs_string_ref_t refs[together];
-        u32 vp[together], vn[together], raw_low[together], next[together], longest = 0;
+    text_stream_t const texts[together] = {text_stream_t(refs[0].address, refs[0].length), text_stream_t(refs[1].address, refs[1].length),
+                                           text_stream_t(refs[2].address, refs[2].length), text_stream_t(refs[3].address, refs[3].length)};
+#pragma unroll
+    for (u32 k = 0; k < together; ++k) raw_low[k] = texts[k].raw(0), next[k] = texts[k].raw(1);
+    // The masks of a step come from the L2 (~1 us away): those of the NEXT four columns are requested before the current four
+    // are computed - sixteen reads of 256 contiguous bytes per wavefront in flight behind sixteen packed columns.  (Requested
+    // and consumed in the same iteration, kinds A and B took 37 and 30 us: a 100-byte text is 25 such round trips in a row.)
+    u32 eq_ahead[4][together];
+    auto request = [&](u32 dword) { // text dwords `dword` (spliced from the stream's state) -> the masks of its four columns
 #pragma unroll
         for (u32 k = 0; k < together; ++k) {
-            refs[k] = refs_ahead[k], raw_low[k] = raw_ahead[k][0], next[k] = raw_ahead[k][1];
-            longest = refs[k].length > longest ? refs[k].length : longest;
-            vp[k] = vp_start, vn[k] = 0;
-        }
-        text_stream_t const texts[together] = {text_stream_t(refs[0].address, refs[0].length), text_stream_t(refs[1].address, refs[1].length),
-                                               text_stream_t(refs[2].address, refs[2].length), text_stream_t(refs[3].address, refs[3].length)};
-        if (first_text + 4 * together < texts_end) {
-            fetch_refs(first_text + 4 * together, refs_ahead);
+            u32 const after = texts[k].raw(dword + 2);
+            u32 const symbols = texts[k].splice(raw_low[k], next[k]);
+            raw_low[k] = next[k], next[k] = after;
 #pragma unroll
-            for (u32 k = 0; k < together; ++k) {
-                text_stream_t const text(refs_ahead[k].address, refs_ahead[k].length);
-                raw_ahead[k][0] = text.raw(0), raw_ahead[k][1] = text.raw(1);
-            }
+            for (u32 step = 0; step < 4; ++step) eq_ahead[step][k] = my_masks[(u64)((symbols >> (8 * step)) & 0xFFu) * row_dwords];
         }
+    };
+    if (longest) request(0);
 #pragma unroll 1
-        for (u32 at = 0, dword = 0; at < longest; at += 4, ++dword) {
-            u32 symbols[together];
+    for (u32 at = 0, dword = 0; at < longest; at += 4, ++dword) {
+        u32 eq[4][together];
+#pragma unroll
+        for (u32 step = 0; step < 4; ++step)
+#pragma unroll
+            for (u32 k = 0; k < together; ++k) eq[step][k] = eq_ahead[step][k];
+        if (at + 4 < longest) request(dword + 1);
+        // a column past a text's end is computed and dropped - two selects on a uniform condition, no branch
+#pragma unroll
+        for (u32 step = 0; step < 4; ++step)
 #pragma unroll
             for (u32 k = 0; k < together; ++k) {
-                u32 const after = texts[k].raw(dword + 2);
-                symbols[k] = texts[k].splice(raw_low[k], next[k]);
-                raw_low[k] = next[k], next[k] = after;
+                u32 vp_next = vp[k], vn_next = vn[k];
+                outlier_column(vp_next, vn_next, eq[step][k]);
+                bool const within = at + step < refs[k].length;
+                vp[k] = within ? vp_next : vp[k], vn[k] = within ? vn_next : vn[k];
             }
-            // sixteen LDS reads go out together; a column past a text's end is computed and dropped (two selects on a uniform
-            // condition) - as sixteen uniform BRANCHES, each with its read behind it, a quartet took ~15 us
-            u32 masks[4][together];
+    }
 #pragma unroll
-            for (u32 step = 0; step < 4; ++step)
-#pragma unroll
-                for (u32 k = 0; k < together; ++k) masks[step][k] = table[((symbols[k] >> (8 * step)) & 0xFFu) * 64 + lane];
-#pragma unroll
-            for (u32 step = 0; step < 4; ++step)
-#pragma unroll
-                for (u32 k = 0; k < together; ++k) {
-                    u32 vp_next = vp[k], vn_next = vn[k];
-                    outlier_column(vp_next, vn_next, masks[step][k]);
-                    bool const within = at + step < refs[k].length;
-                    vp[k] = within ? vp_next : vp[k], vn[k] = within ? vn_next : vn[k];
-                }
+    for (u32 k = 0; k < together; ++k) {
+        if (first_text + k >= texts_count) break;
+        u32 const low = refs[k].length + (u32)__builtin_popcount(vp[k] & 0xFFFFu) - (u32)__builtin_popcount(vn[k] & 0xFFFFu);
+        u32 const high = refs[k].length + (u32)__builtin_popcount(vp[k] >> 16) - (u32)__builtin_popcount(vn[k] >> 16);
+        u64 const pattern_low = pattern_first + lane, pattern_high = pattern_first + lane + 64;
+        if (texts_are_candidates) { // results[query = pattern][candidate = text]
+            if (rows_low != ~0u) results[pattern_low * results_row_stride + refs[k].index] = low;
+            if (rows_high != ~0u) results[pattern_high * results_row_stride + refs[k].index] = high;
         }
-#pragma unroll
-        for (u32 k = 0; k < together; ++k) {
-            if (first_text + k >= texts_end) break;
-            u32 const low = refs[k].length + (u32)__builtin_popcount(vp[k] & 0xFFFFu) - (u32)__builtin_popcount(vn[k] & 0xFFFFu);
-            u32 const high = refs[k].length + (u32)__builtin_popcount(vp[k] >> 16) - (u32)__builtin_popcount(vn[k] >> 16);
-            u64 const pattern_low = pattern_first + lane, pattern_high = pattern_first + lane + 64;
-            if (texts_are_candidates) { // results[query = pattern][candidate = text]
-                if (rows_low != ~0u) results[pattern_low * results_row_stride + refs[k].index] = low;
-                if (rows_high != ~0u) results[pattern_high * results_row_stride + refs[k].index] = high;
-            }
-            else { // results[query = text][candidate = pattern]: 512 contiguous bytes per wavefront and half
-                if (rows_low != ~0u) results[(u64)refs[k].index * results_row_stride + pattern_low] = low;
-                if (rows_high != ~0u) results[(u64)refs[k].index * results_row_stride + pattern_high] = high;
-            }
+        else { // results[query = text][candidate = pattern]: 512 contiguous bytes per wavefront and half
+            if (rows_low != ~0u) results[(u64)refs[k].index * results_row_stride + pattern_low] = low;
+            if (rows_high != ~0u) results[(u64)refs[k].index * results_row_stride + pattern_high] = high;
         }
     }
 }
@@ -1801,7 +1765,8 @@ extern "C" int szs_hip_levenshtein_myers_fused(szs_fused_plan_t const *plan, uin
 }
 
 extern "C" int szs_hip_levenshtein_outliers(szs_tiny_outliers_t const *outliers, szs_tape_t const *queries, szs_tape_t const *candidates,
-                                            uint64_t *results, uint64_t results_row_stride, void *stream) {
+                                            uint32_t const *query_masks, uint32_t const *candidate_masks, uint64_t *results,
+                                            uint64_t results_row_stride, void *stream) {
     using namespace szs_hip;
     if (!queries->count || !candidates->count) return 0;
     u64 const query_groups = ((u64)queries->count + outlier_patterns_k - 1) / outlier_patterns_k;
@@ -1809,7 +1774,7 @@ extern "C" int szs_hip_levenshtein_outliers(szs_tiny_outliers_t const *outliers,
     u64 const grid = (query_groups + candidate_groups) * (SZS_TINY_MOST_OUTLIERS / outlier_text_chunk_k) + SZS_TINY_MOST_OUTLIERS;
     if (grid > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(levenshtein_outliers_kernel, dim3((u32)grid), dim3(256), 0, static_cast<hipStream_t>(stream), outliers, *queries, *candidates,
-                       (u32)query_groups, (u32)candidate_groups, results, results_row_stride);
+                       query_masks, candidate_masks, (u32)query_groups, (u32)candidate_groups, results, results_row_stride);
     return (int)hipGetLastError();
 }
 

@@ -27,11 +27,11 @@
  *  - Results go through LDS, a byte each (a distance of two tiny tokens is at most 16): `out[j][candidate of the block]` packs
  *    four queries; then every wavefront writes 512 contiguous bytes per row.
  *
- *  Tokens LONGER than 16 bytes are not this kernel's business: it skips them (their rows / columns are left untouched) and
- *  lists them - refs in device memory, at most SZS_TINY_MOST_OUTLIERS per side - for `levenshtein_outliers_kernel`
- *  (lev_myers.hip), which scores a listed string against the other side's tape, block by block, with the ordinary bit-parallel
- *  bodies.  One long URL in a wavefront would otherwise hold its sixty-three neighbours - and, through the workgroup's
- *  barriers, the other three wavefronts - for ten times their own work (measured: 441 us where this design takes a fraction).
+ *  Tokens LONGER than 16 bytes are not this kernel's business: it skips them (their rows / columns are left untouched).
+ *  `levenshtein_tiny_prepare_kernel` lists them up front - refs in device memory, at most SZS_TINY_MOST_OUTLIERS per side - for
+ *  `levenshtein_outliers_kernel` (lev_myers.hip), which runs BESIDE this one on a second stream.  One long URL in a wavefront
+ *  would otherwise hold its sixty-three neighbours - and, through the workgroup's barriers, the other three wavefronts - for ten
+ *  times their own work (measured: 441 us for 4096 x 4096 words of text with every token scored here, whatever its length).
  *  More outliers than the list holds, a listed string beyond 256 bytes, malformed offsets: `*unfit = unfit_sequence` (pinned
  *  memory) and the host scores the call the ordinary way.
  */
@@ -74,10 +74,66 @@ __device__ __forceinline__ void tiny_column(u32 &vp, u32 &vn, u32 eq) {
     vn = hp_shifted & xv;
 }
 
+/**
+ *  Ahead of the two scoring kernels: one thread per string of either tape.  Strings of more than 16 bytes are listed for the
+ *  outliers' kernel; malformed offsets, a listed string beyond 256 bytes or more of them than the list holds raise `*unfit`.
+ *  (The tiny kernel's own workgroups listed them at first; but then the outliers' kernel could only start when the tiny kernel
+ *  had ended, and the two - both bound by latency, not by work - took 55 + 49 us one after the other.  Listed up front, they run
+ *  side by side on two streams.)
+ */
+__global__ __launch_bounds__(256) void levenshtein_tiny_prepare_kernel(szs_tape_t queries, szs_tape_t candidates, u32 query_workgroups,
+                                                                      u32 *unfit, u32 unfit_sequence, szs_tiny_outliers_t *outliers,
+                                                                      u32 *query_masks, u32 *candidate_masks,
+                                                                      unsigned long long *symbols_out, int unbuild) {
+    int const side = blockIdx.x < query_workgroups ? 0 : 1;
+    szs_tape_t const &tape = side ? candidates : queries;
+    u32 const index = (side ? blockIdx.x - query_workgroups : blockIdx.x) * 256 + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x < 2 && symbols_out && !unbuild) { // the call's cell count is the product of these two (the host's profile)
+        szs_tape_t const &whole = threadIdx.x ? candidates : queries;
+        symbols_out[threadIdx.x] = tiny_offset(whole.offsets, whole.wide, whole.count) - tiny_offset(whole.offsets, whole.wide, 0);
+    }
+    if (index >= tape.count) return;
+    u64 const from = tiny_offset(tape.offsets, tape.wide, index), to = tiny_offset(tape.offsets, tape.wide, (u64)index + 1);
+    if (to < from) { // malformed offsets: the host's planner reports them
+        if (!unbuild) *unfit = unfit_sequence;
+        return;
+    }
+    if (to - from <= tiny_rows_k) { // a tiny string: its match masks, for the outliers' kernel (kernels.h: SZS_TINY_TABLE_BYTES)
+        u32 *const masks = side ? candidate_masks : query_masks;
+        u32 const rows = (u32)(to - from), row_dwords = ((tape.count + 127u) / 128u) * 64u;
+        u32 const dword = (index / 128u) * 64u + (index % 64u), half = (index % 128u) / 64u;
+        text_stream_t const text(tape.base + from, rows);
+        u32 raw[5], symbols[4]; // all of the string in one round trip; then the atomics
+#pragma unroll
+        for (u32 d = 0; d < 5; ++d) raw[d] = text.raw(d);
+#pragma unroll
+        for (u32 d = 0; d < 4; ++d) symbols[d] = text.splice(raw[d], raw[d + 1]);
+#pragma unroll
+        for (u32 at = 0; at < tiny_rows_k; ++at) {
+            if (at >= rows) break;
+            u32 *const where = &masks[(u64)((symbols[at / 4] >> (8 * (at % 4))) & 0xFFu) * row_dwords + dword];
+            // `unbuild`: the same dwords back to zero when the call's kernels have read them - the tables are all zeros between calls,
+            // which spares every call a fill of 512 bytes per string (4 MB and 7.5 us for 4096 x 4096 words)
+            if (unbuild) *where = 0;
+            else atomicOr(where, (half ? 0x10000u : 1u) << (tiny_rows_k - rows + at));
+        }
+        return;
+    }
+    if (unbuild) return;
+    u32 const place = atomicAdd(&outliers->counts[side], 1u);
+    if (place >= SZS_TINY_MOST_OUTLIERS) { // too many: the host scores the call the ordinary way (the other kernel reads no further)
+        *unfit = unfit_sequence;
+        return;
+    }
+    szs_string_ref_t ref;
+    ref.address = tape.base + from, ref.length = (u32)(to - from), ref.index = index;
+    if (to - from > 32u * SZS_MYERS_SHORT_WORDS) // too long for the outliers' kernel's bodies: listed as an EMPTY string (every slot that
+        ref.length = 0, *unfit = unfit_sequence; // kernel reads holds a ref of this call), and the call is scored again
+    outliers->refs[side][place] = ref;
+}
+
 __global__ __launch_bounds__(256) void levenshtein_tiny_kernel(szs_tape_t queries, szs_tape_t candidates, u32 queries_per_workgroup,
-                                                              u64 *__restrict__ results, u64 results_row_stride, u32 *unfit,
-                                                              u32 unfit_sequence, szs_tiny_outliers_t *outliers,
-                                                              unsigned long long *symbols_out) {
+                                                              u64 *__restrict__ results, u64 results_row_stride) {
     __shared__ __attribute__((aligned(16))) u32 peq[256 * tiny_row_dwords_k]; // [byte][dword d: slots d (low half) and d + 16 (high)]: 20 KB
     __shared__ u32 out[8 * tiny_block_k]; // [j][column of the block]: the distances of slots j, j + 8, j + 16, j + 24, a byte each: 8 KB
     __shared__ u64 query_offsets[tiny_most_queries_k + 1];
@@ -89,19 +145,6 @@ __global__ __launch_bounds__(256) void levenshtein_tiny_kernel(szs_tape_t querie
     u32 const block = blockIdx.x % blocks, span = blockIdx.x / blocks;
     u32 const query_first = span * queries_per_workgroup;
     u32 const queries_here = queries.count - query_first < queries_per_workgroup ? queries.count - query_first : queries_per_workgroup;
-    auto list = [&](int side, u64 address, u64 length, u32 index) { // an outlier: scored by levenshtein_outliers_kernel
-        u32 const place = atomicAdd(&outliers->counts[side], 1u);
-        if (place >= SZS_TINY_MOST_OUTLIERS) { // too many: the host scores the call the ordinary way (the other kernel reads no further)
-            *unfit = unfit_sequence;
-            return;
-        }
-        szs_string_ref_t ref;
-        ref.address = address, ref.length = (u32)length, ref.index = index;
-        if (length > 32u * SZS_MYERS_SHORT_WORDS) // too long for that kernel's bodies: listed as an EMPTY string (every slot the
-            ref.length = 0, *unfit = unfit_sequence; // other kernel reads holds a ref of this call), and the call is scored again
-        outliers->refs[side][place] = ref;
-    };
-
     // ---- once per workgroup: the block's candidates (offsets, local sort by length), the span's query offsets, clean masks
     u32 const my_candidate = block * tiny_block_k + tid;
     u64 my_from = 0;
@@ -110,27 +153,13 @@ __global__ __launch_bounds__(256) void levenshtein_tiny_kernel(szs_tape_t querie
     if (my_candidate < candidates.count) {
         my_from = tiny_offset(candidates.offsets, candidates.wide, my_candidate);
         u64 const to = tiny_offset(candidates.offsets, candidates.wide, (u64)my_candidate + 1);
-        if (to < my_from) *unfit = unfit_sequence; // malformed offsets: the host's planner reports them
-        else if (to - my_from > tiny_rows_k) {
-            if (span == 0) list(1, candidates.base + my_from, to - my_from, my_candidate);
-        }
-        else my_length = (u32)(to - my_from), my_tiny = true;
+        if (to >= my_from && to - my_from <= tiny_rows_k) my_length = (u32)(to - my_from), my_tiny = true; // (longer: the outliers' kernel's)
     }
     for (u32 i = tid; i <= queries_here; i += 256) query_offsets[i] = tiny_offset(queries.offsets, queries.wide, (u64)query_first + i);
     for (u32 i = tid; i < 256 * tiny_row_dwords_k; i += 256) peq[i] = 0;
     if (tid < 32) bins[tid] = 0;
     froms[tid] = my_from, lengths[tid] = my_tiny ? my_length : 0x80000000u; // (a skipped column sorts last and scores as an empty text)
-    if (blockIdx.x == 0 && tid < 2 && symbols_out) { // the call's cell count is the product of these two (the host's profile)
-        szs_tape_t const &tape = tid ? candidates : queries;
-        symbols_out[tid] = tiny_offset(tape.offsets, tape.wide, tape.count) - tiny_offset(tape.offsets, tape.wide, 0);
-    }
     __syncthreads();
-    if (block == 0) // the span's long queries: listed once, by the workgroup of the first candidate block
-        for (u32 i = tid; i < queries_here; i += 256) {
-            u64 const from = query_offsets[i], to = query_offsets[i + 1];
-            if (to < from) *unfit = unfit_sequence;
-            else if (to - from > tiny_rows_k) list(0, queries.base + from, to - from, query_first + i);
-        }
     // counting sort of the block's 256 lengths (0 ... 16, skipped columns last): rank -> the thread that holds that candidate
     u32 const bin = my_tiny ? my_length : tiny_rows_k + 1;
     u32 const place_in_bin = atomicAdd(&bins[bin], 1u);
@@ -252,9 +281,20 @@ __global__ __launch_bounds__(256) void levenshtein_tiny_kernel(szs_tape_t querie
 
 } // namespace szs_hip
 
+extern "C" int szs_hip_levenshtein_tiny_prepare(szs_tape_t const *queries, szs_tape_t const *candidates, uint32_t *unfit, uint32_t unfit_sequence,
+                                                szs_tiny_outliers_t *outliers, uint32_t *query_masks, uint32_t *candidate_masks,
+                                                unsigned long long *symbols_out, int unbuild, void *stream) {
+    using namespace szs_hip;
+    if (!queries->count || !candidates->count) return 0;
+    u64 const query_workgroups = ((u64)queries->count + 255) / 256, candidate_workgroups = ((u64)candidates->count + 255) / 256;
+    hipLaunchKernelGGL(levenshtein_tiny_prepare_kernel, dim3((u32)(query_workgroups + candidate_workgroups)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), *queries, *candidates, (u32)query_workgroups, unfit, unfit_sequence, outliers, query_masks,
+                       candidate_masks, symbols_out, unbuild);
+    return (int)hipGetLastError();
+}
+
 extern "C" int szs_hip_levenshtein_tiny(szs_tape_t const *queries_tape, szs_tape_t const *candidates_tape, uint64_t *results,
-                                        uint64_t results_row_stride, uint32_t *unfit, uint32_t unfit_sequence,
-                                        szs_tiny_outliers_t *outliers, unsigned long long *symbols_out, void *stream) {
+                                        uint64_t results_row_stride, void *stream) {
     using namespace szs_hip;
     szs_tape_t const queries = *queries_tape, candidates = *candidates_tape;
     u32 const queries_count = queries.count, candidates_count = candidates.count;
@@ -271,6 +311,6 @@ extern "C" int szs_hip_levenshtein_tiny(szs_tape_t const *queries_tape, szs_tape
     spans = ((u64)queries_count + per_span - 1) / per_span;
     if (blocks * spans > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(levenshtein_tiny_kernel, dim3((u32)(blocks * spans)), dim3(256), 0, static_cast<hipStream_t>(stream), queries, candidates,
-                       (u32)per_span, results, results_row_stride, unfit, unfit_sequence, outliers, symbols_out);
+                       (u32)per_span, results, results_row_stride);
     return (int)hipGetLastError();
 }

@@ -272,7 +272,7 @@ static void release_device_state(szs_engine_s *engine) {
     szs_buffer_release(&engine->pinned_summary);
     szs_buffer_release(&engine->device_fused);
     szs_buffer_release(&engine->device_outliers);
-    engine->tiny_valid = 0;
+    engine->tiny_valid = 0, engine->outliers_zeroed = NULL;
     engine->fused_zeroed = NULL;
     if (engine->events_device >= 0) {
         (void)hipEventDestroy(engine->event_start);
@@ -1061,29 +1061,53 @@ static sz_status_t cross_tiny(szs_call_t *call, uint32_t planner_mode, szs_plan_
     uint32_t const sequence = engine->plan_sequence;
     *unfit = 0, symbols[0] = symbols[1] = 0;
     phase(call, 2);
-    sz_status_t reserved = szs_buffer_reserve(&engine->device_outliers, szs_memory_device_k, call->device, sizeof(szs_tiny_outliers_t), call->error_message);
+    /* [the two counts | both tapes' mask tables] are cleared by ONE fill; the lists' refs lie behind them */
+    size_t const q_table = (size_t)SZS_TINY_TABLE_BYTES(call->q_count), c_table = (size_t)SZS_TINY_TABLE_BYTES(call->c_count);
+    sz_status_t reserved = szs_buffer_reserve(&engine->device_outliers, szs_memory_device_k, call->device, 256 + q_table + c_table + sizeof(szs_tiny_outliers_t),
+                                              call->error_message);
     if (reserved != sz_success_k) return reserved;
-    szs_tiny_outliers_t *const outliers = (szs_tiny_outliers_t *)engine->device_outliers.pointer;
+    char *const cleared = (char *)engine->device_outliers.pointer;
+    uint32_t *const q_masks = (uint32_t *)(cleared + 256), *const c_masks = (uint32_t *)(cleared + 256 + q_table);
+    szs_tiny_outliers_t *const outliers = (szs_tiny_outliers_t *)(cleared + 256 + q_table + c_table);
+    /* (the counts are the first 16 bytes of the struct, right behind the tables: the one fill covers them) */
     szs_tape_t const q_tape = {call->queries->offsets, (uint64_t)(uintptr_t)call->queries->data, call->q_count, call->queries->kind == szs_input_u64tape_k};
     szs_tape_t const c_tape = {call->candidates->offsets, (uint64_t)(uintptr_t)call->candidates->data, call->c_count,
                                call->candidates->kind == szs_input_u64tape_k};
-    hipError_t error = hipMemsetAsync(outliers, 0, 16, stream); /* the two counts */
-    if (error == hipSuccess) error = hipEventRecord(engine->event_start, stream);
+    /* One stream, five small steps: the two counts cleared; strings of more than 16 bytes listed and the tiny ones' masks tabled (a
+     * pass over the tapes); the outliers' rows and columns; the tables set back to zeros; the tiny tokens.  (Measured and not kept:
+     * the outliers' kernel on a second stream beside the tiny-token kernel - 119 us against 111 one after the other on 4096 x 4096
+     * words of text: the two do not overlap, each fills the device's wavefront slots on its own.) */
+    hipError_t error = hipEventRecord(engine->event_start, stream);
+    /* The tables hold zeros between calls (every call sets back what it set: the `unbuild` pass below); they are filled once, when
+     * the buffer is new - and the counts live in the first 16 bytes behind them. */
+    if (error == hipSuccess && engine->outliers_zeroed != engine->device_outliers.pointer) {
+        error = hipMemsetAsync(cleared, 0, engine->device_outliers.capacity, stream);
+        engine->outliers_zeroed = error == hipSuccess ? engine->device_outliers.pointer : NULL;
+    }
+    if (error == hipSuccess) error = hipMemsetAsync(outliers, 0, 16, stream); /* the two counts */
     uint32_t launches = 0;
     if (error == hipSuccess) {
-        error = (hipError_t)szs_hip_levenshtein_tiny(&q_tape, &c_tape, (uint64_t *)call->device_results, call->device_stride, (uint32_t *)unfit, sequence,
-                                                     outliers, (unsigned long long *)symbols, stream);
+        error = (hipError_t)szs_hip_levenshtein_tiny_prepare(&q_tape, &c_tape, (uint32_t *)unfit, sequence, outliers, q_masks, c_masks, (unsigned long long *)symbols, 0, stream);
+        launches += error == hipSuccess;
+        if (error == hipSuccess) { /* tokens of more than 16 bytes: their rows and columns (hip/lev_myers.hip) */
+            error = (hipError_t)szs_hip_levenshtein_outliers(outliers, &q_tape, &c_tape, q_masks, c_masks, (uint64_t *)call->device_results, call->device_stride, stream);
+            launches += error == hipSuccess;
+        }
+        /* ... and the tables set back to zeros behind it (the same pass over the tapes, stores instead of atomics) - also when the
+         * launch before it failed: whatever the first pass set must go */
+        hipError_t const unbuilt = (hipError_t)szs_hip_levenshtein_tiny_prepare(&q_tape, &c_tape, (uint32_t *)unfit, sequence, outliers, q_masks, c_masks, NULL, 1, stream);
+        if (unbuilt != hipSuccess) engine->outliers_zeroed = NULL; /* fill them before the next call */
+        launches += unbuilt == hipSuccess;
+    }
+    if (error == hipSuccess) {
+        error = (hipError_t)szs_hip_levenshtein_tiny(&q_tape, &c_tape, (uint64_t *)call->device_results, call->device_stride, stream);
         launches += error == hipSuccess;
     }
-    if (error == hipSuccess) { /* tokens of more than 16 bytes: their rows and columns, by the ordinary bodies */
-        error = (hipError_t)szs_hip_levenshtein_outliers(outliers, &q_tape, &c_tape, (uint64_t *)call->device_results, call->device_stride, stream);
-        launches += error == hipSuccess;
-    }
+    engine->last_streams = 1;
     szs_decision_t *const shape = (szs_decision_t *)calloc(1, sizeof(szs_decision_t)); /* what finish() reads: lanes tier, one launch */
     if (!shape) return szs_report(sz_bad_alloc_k, call->error_message, NULL);
     shape->tier = SZS_TIER_LANES, shape->q_count = call->q_count, shape->c_count = call->c_count;
     if (seen) shape->longest[0] = seen->side[0].longest, shape->longest[1] = seen->side[1].longest;
-    engine->last_streams = 1;
     engine->last_profile.planner = planner_mode;
     int stalled = 0;
     sz_status_t status = finish(call, shape, error, sz_success_k, launches, 0, 0, 0, &stalled);
