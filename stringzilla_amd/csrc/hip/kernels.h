@@ -191,9 +191,10 @@ size_t szs_hip_levenshtein_myers_queue_table_bytes(int runes);
  *  `symbols_out` (pinned, or NULL): [0] the bytes of the queries' tape, [1] of the candidates' - their product is the call's cells.
  */
 #define SZS_TINY_MOST_OUTLIERS 256u
+#define SZS_TINY_LONG_OUTLIER 40u
 typedef struct szs_tiny_outliers_t {
     uint32_t counts[2]; /* [0] queries, [1] candidates; may exceed the capacity (the call is unfit then) */
-    uint32_t reserved[2];
+    uint32_t long_counts[2]; /* of those, the strings of more than SZS_TINY_LONG_OUTLIER bytes (a wavefront each in the outliers' kernel) */
     szs_string_ref_t refs[2][SZS_TINY_MOST_OUTLIERS];
 } szs_tiny_outliers_t;
 /** The 16-bit match masks of a tape's tiny strings, for the outliers' kernel: row `byte` holds, for every group of 128 strings, 64
@@ -212,7 +213,8 @@ int szs_hip_levenshtein_tiny_prepare(szs_tape_t const *queries, szs_tape_t const
                                      szs_tiny_outliers_t *outliers, uint32_t *query_masks /* SZS_TINY_TABLE_BYTES(queries) */,
                                      uint32_t *candidate_masks, unsigned long long *symbols_out, int unbuild, void *stream);
 /** Step 2a: every pair of two tiny strings.  Needs nothing of step 1: may run beside step 2b on another stream. */
-int szs_hip_levenshtein_tiny(szs_tape_t const *queries, szs_tape_t const *candidates, uint64_t *results, uint64_t results_row_stride, void *stream);
+int szs_hip_levenshtein_tiny(szs_tape_t const *queries, szs_tape_t const *candidates, uint64_t *results, uint64_t results_row_stride,
+                             uint64_t *trace /* NULL, or 8 qwords per workgroup of device memory: 100 MHz ticks at its phases (`trace` knob) */, void *stream);
 /**
  *  The strings szs_hip_levenshtein_tiny listed (hip/lev_myers.hip): a workgroup scores ONE listed string - the pattern, up to 256
  *  bytes - against a block of 256 strings of the other side's tape, whatever their lengths, with the bodies of the short
@@ -221,7 +223,7 @@ int szs_hip_levenshtein_tiny(szs_tape_t const *queries, szs_tape_t const *candid
  */
 int szs_hip_levenshtein_outliers(szs_tiny_outliers_t const *outliers, szs_tape_t const *queries, szs_tape_t const *candidates,
                                  uint32_t const *query_masks, uint32_t const *candidate_masks, uint64_t *results, uint64_t results_row_stride,
-                                 void *stream);
+                                 uint64_t *trace /* NULL, or 4 qwords per wavefront of device memory (`trace` knob) */, void *stream);
 
 /**
  *  Fills the cells above the diagonal of a `side` x `side` matrix of 8-byte values from the ones below it (hip/mirror.hip): what a

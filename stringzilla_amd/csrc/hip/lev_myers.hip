@@ -552,7 +552,9 @@ __global__ __launch_bounds__(256, SZS_MYERS_FUSED_WAVES) void levenshtein_myers_
  *  with a uniform branch per column 68, branch-free with the sixteen mask reads of a step issued together 49; kind C alone 19.)
  */
 constexpr u32 outlier_patterns_k = 128;  // tiny patterns per wavefront of kinds A / B: two per lane
-constexpr u32 outlier_text_chunk_k = 16; // listed texts per workgroup: four per wavefront, side by side
+constexpr u32 outlier_text_chunk_k = 16; // listed texts per workgroup where a wavefront takes four side by side
+// (a listed text of more than SZS_TINY_LONG_OUTLIER bytes gets a wavefront to itself: the first pass counts them)
+constexpr u32 outlier_chunks_k = SZS_TINY_MOST_OUTLIERS / 4 + 1; // workgroups per group of patterns: enough when every text runs alone
 typedef unsigned short outlier_pk_u16 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void outlier_column(u32 &vp, u32 &vn, u32 eq) { // one DP column of two 16-row patterns (myers_tiny.hip)
     u32 const xv = eq | vn;
@@ -567,13 +569,102 @@ __device__ __forceinline__ void outlier_column(u32 &vp, u32 &vn, u32 eq) { // on
     vn = hp_shifted & xv;
 }
 
+/**
+ *  Kinds A / B of the outliers' kernel: `together_` listed texts (refs, the same for all 64 lanes) side by side against the 128
+ *  patterns this wavefront holds two to a lane; `my_masks` = the masks table + this lane's dword; see the kernel below.
+ */
+template <u32 together_>
+__device__ __forceinline__ void outlier_wave(szs_string_ref_t const (&refs)[together_], u32 live, u32 vp_start, u32 const *__restrict__ my_masks,
+                                             u32 row_dwords, u32 rows_low, u32 rows_high, u64 pattern_low, bool texts_are_candidates,
+                                             u64 *__restrict__ results, u64 results_row_stride, u64 *trace_of_wave, u64 began) {
+    // Everything about a text is the same for all 64 lanes - and the compiler must KNOW it (`readfirstlane`): with the lengths in
+    // vector registers every "is this column still inside the text" became an EXEC-masked branch or a per-lane `v_cndmask` on
+    // VCC (a ninth of the rate of the other VALU instructions here, scripts/valu_peak.hip), and behind the masked branch around the
+    // next step's loads the compiler waited for every outstanding load at the join: a step cost a whole round trip to the L2
+    // however far ahead its masks had been requested (0.8 us per step; A and B 37 / 30 us).
+    u32 lengths[together_], index_of[together_], longest = 0;
+    u32 const *bases[together_]; // the text's first dword (its address rounded down to 4 bytes) ...
+    u32 shifts[together_], dwords[together_]; // ... the bytes its first symbol lies into it, and the dwords that hold its bytes
+#pragma unroll
+    for (u32 k = 0; k < together_; ++k) {
+        lengths[k] = (u32)__builtin_amdgcn_readfirstlane(k < live ? refs[k].length : 0u); // (of the FINAL value: `live` is a vector register too)
+        index_of[k] = (u32)__builtin_amdgcn_readfirstlane(refs[k].index);
+        u64 const address = ((u64)(u32)__builtin_amdgcn_readfirstlane((u32)(refs[k].address >> 32)) << 32) |
+                            (u64)(u32)__builtin_amdgcn_readfirstlane((u32)refs[k].address); // (the builtin returns a SIGNED int)
+        bases[k] = reinterpret_cast<u32 const *>(address & ~(u64)3), shifts[k] = (u32)(address & 3);
+        dwords[k] = lengths[k] ? (shifts[k] + lengths[k] + 3) / 4 : 1u; // (an absent text reads - and never consumes - a listed one's first dword)
+        longest = lengths[k] > longest ? lengths[k] : longest;
+    }
+    u32 const steps = (u32)__builtin_amdgcn_readfirstlane((longest + 3) / 4); // of four columns
+    auto raw = [&](u32 k, u32 dword) -> u32 { return bases[k][dword < dwords[k] ? dword : dwords[k] - 1]; }; // (clamped: never past the text's last dword)
+    u32 vp[together_], vn[together_];
+#pragma unroll
+    for (u32 k = 0; k < together_; ++k) vp[k] = vp_start, vn[k] = 0;
+    // Two steps' masks in flight: buffer A holds the even steps', B the odd ones'; a buffer is refilled - straight into the
+    // registers it will be consumed from, two steps later - as soon as its columns are through.
+    u32 masks_a[4][together_], masks_b[4][together_], text_a[together_][2], text_b[together_][2];
+    auto request = [&](u32 step, u32 (&into)[4][together_], u32 (&text)[together_][2]) { // the masks of step `step`, whose two raw dwords `text` holds
+#pragma unroll
+        for (u32 k = 0; k < together_; ++k) {
+            u32 const symbols = __builtin_amdgcn_alignbyte(text[k][1], text[k][0], shifts[k]);
+#pragma unroll
+            for (u32 column = 0; column < 4; ++column) into[column][k] = my_masks[(u64)((symbols >> (8 * column)) & 0xFFu) * row_dwords];
+        }
+        (void)step;
+    };
+    auto fetch_text = [&](u32 step, u32 (&text)[together_][2]) {
+#pragma unroll
+        for (u32 k = 0; k < together_; ++k) text[k][0] = raw(k, step), text[k][1] = raw(k, step + 1);
+    };
+    auto columns = [&](u32 step, u32 const (&from)[4][together_]) {
+#pragma unroll
+        for (u32 column = 0; column < 4; ++column)
+#pragma unroll
+            for (u32 k = 0; k < together_; ++k)
+                if (4 * step + column < lengths[k]) outlier_column(vp[k], vn[k], from[column][k]); // (a scalar branch)
+    };
+    u64 const set_up = trace_of_wave ? wall_clock64() : 0;
+    if (steps) {
+        fetch_text(0, text_a), fetch_text(1, text_b);
+        request(0, masks_a, text_a);
+        request(1, masks_b, text_b);
+        fetch_text(2, text_a), fetch_text(3, text_b);
+#pragma unroll 1
+        for (u32 step = 0;;) {
+            columns(step, masks_a);
+            if (step + 2 < steps) request(step + 2, masks_a, text_a), fetch_text(step + 4, text_a);
+            if (++step >= steps) break;
+            columns(step, masks_b);
+            if (step + 2 < steps) request(step + 2, masks_b, text_b), fetch_text(step + 4, text_b);
+            if (++step >= steps) break;
+        }
+    }
+    if (trace_of_wave) trace_of_wave[0] = began, trace_of_wave[1] = set_up, trace_of_wave[2] = wall_clock64(), trace_of_wave[3] = longest;
+#pragma unroll
+    for (u32 k = 0; k < together_; ++k) {
+        if (k >= live) break;
+        u32 const low = lengths[k] + (u32)__builtin_popcount(vp[k] & 0xFFFFu) - (u32)__builtin_popcount(vn[k] & 0xFFFFu);
+        u32 const high = lengths[k] + (u32)__builtin_popcount(vp[k] >> 16) - (u32)__builtin_popcount(vn[k] >> 16);
+        u64 const pattern_high = pattern_low + 64;
+        if (texts_are_candidates) { // results[query = pattern][candidate = text]
+            if (rows_low != ~0u) results[pattern_low * results_row_stride + index_of[k]] = low;
+            if (rows_high != ~0u) results[pattern_high * results_row_stride + index_of[k]] = high;
+        }
+        else { // results[query = text][candidate = pattern]: 512 contiguous bytes per wavefront and half
+            if (rows_low != ~0u) results[(u64)index_of[k] * results_row_stride + pattern_low] = low;
+            if (rows_high != ~0u) results[(u64)index_of[k] * results_row_stride + pattern_high] = high;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void levenshtein_outliers_kernel(szs_tiny_outliers_t const *__restrict__ outliers, szs_tape_t queries,
                                                                   szs_tape_t candidates, u32 const *__restrict__ query_masks,
                                                                   u32 const *__restrict__ candidate_masks, u32 query_groups,
-                                                                  u32 candidate_groups, u64 *__restrict__ results, u64 results_row_stride) {
+                                                                  u32 candidate_groups, u64 *__restrict__ results, u64 results_row_stride, u64 *trace) {
     __shared__ __attribute__((aligned(16))) u32 peq[peq_layout<8, byte_rows_k>::total_dwords]; // kind C only
+    u64 const began = trace ? wall_clock64() : 0;
     __shared__ __attribute__((aligned(16))) szs_string_ref_t listed_texts[SZS_TINY_MOST_OUTLIERS];
-    constexpr u32 chunks = SZS_TINY_MOST_OUTLIERS / outlier_text_chunk_k;
+    constexpr u32 chunks = outlier_chunks_k;
     u32 const tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     u32 const listed_queries = outliers->counts[0] < SZS_TINY_MOST_OUTLIERS ? outliers->counts[0] : SZS_TINY_MOST_OUTLIERS;
     u32 const listed_candidates = outliers->counts[1] < SZS_TINY_MOST_OUTLIERS ? outliers->counts[1] : SZS_TINY_MOST_OUTLIERS;
@@ -610,15 +701,43 @@ __global__ __launch_bounds__(256) void levenshtein_outliers_kernel(szs_tiny_outl
     }
 
     // ---- kinds A and B: this wavefront's 128 patterns (their masks come from the table `levenshtein_tiny_prepare_kernel` built in
-    //      device memory - 2 MB for a side of 4096 strings, L2-resident) against four listed texts side by side
+    //      device memory - 2 MB for a side of 4096 strings, L2-resident) against listed texts
     bool const texts_are_candidates = blockIdx.x < workgroups_a;
     u32 const local = texts_are_candidates ? blockIdx.x : blockIdx.x - workgroups_a;
     u32 const group = local / chunks, chunk = local % chunks;
     int const side_of_texts = texts_are_candidates ? 1 : 0;
     u32 const texts_count = texts_are_candidates ? listed_candidates : listed_queries;
-    constexpr u32 together = 4;
-    u32 const first_text = chunk * outlier_text_chunk_k + wave * together;
-    if (first_text >= texts_count) return; // (uniform per wavefront; no barrier below)
+    if (!texts_count) return;
+    // A wavefront runs its texts side by side for as many steps as the LONGEST of them has, and the kernel is bound by VALU issue
+    // (`trace` knob: in the order the first pass listed them, a quartet's longest was ~50 bytes where the mean is 27 - twice the
+    // instructions).  So every workgroup ranks the (at most 256) listed texts by length - a count of the shorter ones per thread -
+    // and the work is dealt in that order: FOUR texts per wavefront up to `outlier_alone_k` bytes, ONE beyond (the wavefront of
+    // the four longest was the whole kernel's duration: 23 steps of four texts at the pace of a shared SIMD).
+    // (how many run alone the first pass has counted: a workgroup without work leaves before it ranks anything)
+    u32 const alone_listed = outliers->long_counts[side_of_texts];
+    u32 const alone = alone_listed < texts_count ? alone_listed : texts_count, together_count = texts_count - alone;
+    u32 const chunks_together = (together_count + outlier_text_chunk_k - 1) / outlier_text_chunk_k;
+    bool const by_fours = chunk < chunks_together;
+    u32 const end_text = by_fours ? together_count : texts_count;
+    if ((by_fours ? chunk * outlier_text_chunk_k : together_count + (chunk - chunks_together) * 4) >= end_text) return; // (uniform per workgroup)
+    __shared__ __attribute__((aligned(16))) u32 listed_lengths[SZS_TINY_MOST_OUTLIERS];
+    __shared__ unsigned short listed_order[SZS_TINY_MOST_OUTLIERS];
+    listed_lengths[tid] = tid < texts_count ? outliers->refs[side_of_texts][tid].length : ~0u;
+    __syncthreads();
+    if (tid < texts_count) { // ranks [0, together_count) are dealt by fours, the rest one by one
+        u32 const mine = listed_lengths[tid];
+        u32 rank = 0;
+        uint4 const *const four = reinterpret_cast<uint4 const *>(listed_lengths);
+        for (u32 j = 0; j < (texts_count + 3) / 4; ++j) { // (slots past the count hold ~0: never shorter)
+            uint4 const them = four[j];
+            rank += (them.x < mine || (them.x == mine && 4 * j + 0 < tid)) + (them.y < mine || (them.y == mine && 4 * j + 1 < tid)) +
+                    (them.z < mine || (them.z == mine && 4 * j + 2 < tid)) + (them.w < mine || (them.w == mine && 4 * j + 3 < tid));
+        }
+        listed_order[rank] = (unsigned short)tid;
+    }
+    __syncthreads();
+    u32 const first_text = by_fours ? chunk * outlier_text_chunk_k + wave * 4 : together_count + (chunk - chunks_together) * 4 + wave;
+    if (first_text >= end_text) return; // (uniform per wavefront; no barrier below)
     szs_tape_t const &patterns = texts_are_candidates ? queries : candidates;
     u32 const *const masks = texts_are_candidates ? query_masks : candidate_masks;
     u32 const row_dwords = ((patterns.count + 127u) / 128u) * 64u;
@@ -632,67 +751,19 @@ __global__ __launch_bounds__(256) void levenshtein_outliers_kernel(szs_tiny_outl
     u32 const vp_start = ((0xFFFFu << (16 - (rows_low == ~0u ? 0u : rows_low))) & 0xFFFFu) |
                          ((0xFFFF0000u << (16 - (rows_high == ~0u ? 0u : rows_high))) & 0xFFFF0000u);
     u32 const *const my_masks = masks + group * 64u + lane; // + byte x row_dwords
-    szs_string_ref_t refs[together];
-    u32 vp[together], vn[together], raw_low[together], next[together], longest = 0;
+    u64 *const trace_of_wave = trace && lane == 0 ? trace + ((u64)blockIdx.x * 4 + wave) * 4 : nullptr;
+    if (by_fours) {
+        szs_string_ref_t refs[4];
+        u32 const live = end_text - first_text < 4 ? end_text - first_text : 4;
 #pragma unroll
-    for (u32 k = 0; k < together; ++k) {
-        refs[k] = outliers->refs[side_of_texts][first_text + k < texts_count ? first_text + k : first_text]; // the same for all 64 lanes
-        if (first_text + k >= texts_count) refs[k].length = 0;
-        longest = refs[k].length > longest ? refs[k].length : longest;
-        vp[k] = vp_start, vn[k] = 0;
+        for (u32 k = 0; k < 4; ++k) refs[k] = outliers->refs[side_of_texts][listed_order[first_text + (k < live ? k : 0)]]; // the same for all 64 lanes
+        outlier_wave<4>(refs, live, vp_start, my_masks, row_dwords, rows_low, rows_high, pattern_first + lane, texts_are_candidates, results,
+                        results_row_stride, trace_of_wave, began);
     }
-    text_stream_t const texts[together] = {text_stream_t(refs[0].address, refs[0].length), text_stream_t(refs[1].address, refs[1].length),
-                                           text_stream_t(refs[2].address, refs[2].length), text_stream_t(refs[3].address, refs[3].length)};
-#pragma unroll
-    for (u32 k = 0; k < together; ++k) raw_low[k] = texts[k].raw(0), next[k] = texts[k].raw(1);
-    // The masks of a step come from the L2 (~1 us away): those of the NEXT four columns are requested before the current four
-    // are computed - sixteen reads of 256 contiguous bytes per wavefront in flight behind sixteen packed columns.  (Requested
-    // and consumed in the same iteration, kinds A and B took 37 and 30 us: a 100-byte text is 25 such round trips in a row.)
-    u32 eq_ahead[4][together];
-    auto request = [&](u32 dword) { // text dwords `dword` (spliced from the stream's state) -> the masks of its four columns
-#pragma unroll
-        for (u32 k = 0; k < together; ++k) {
-            u32 const after = texts[k].raw(dword + 2);
-            u32 const symbols = texts[k].splice(raw_low[k], next[k]);
-            raw_low[k] = next[k], next[k] = after;
-#pragma unroll
-            for (u32 step = 0; step < 4; ++step) eq_ahead[step][k] = my_masks[(u64)((symbols >> (8 * step)) & 0xFFu) * row_dwords];
-        }
-    };
-    if (longest) request(0);
-#pragma unroll 1
-    for (u32 at = 0, dword = 0; at < longest; at += 4, ++dword) {
-        u32 eq[4][together];
-#pragma unroll
-        for (u32 step = 0; step < 4; ++step)
-#pragma unroll
-            for (u32 k = 0; k < together; ++k) eq[step][k] = eq_ahead[step][k];
-        if (at + 4 < longest) request(dword + 1);
-        // a column past a text's end is computed and dropped - two selects on a uniform condition, no branch
-#pragma unroll
-        for (u32 step = 0; step < 4; ++step)
-#pragma unroll
-            for (u32 k = 0; k < together; ++k) {
-                u32 vp_next = vp[k], vn_next = vn[k];
-                outlier_column(vp_next, vn_next, eq[step][k]);
-                bool const within = at + step < refs[k].length;
-                vp[k] = within ? vp_next : vp[k], vn[k] = within ? vn_next : vn[k];
-            }
-    }
-#pragma unroll
-    for (u32 k = 0; k < together; ++k) {
-        if (first_text + k >= texts_count) break;
-        u32 const low = refs[k].length + (u32)__builtin_popcount(vp[k] & 0xFFFFu) - (u32)__builtin_popcount(vn[k] & 0xFFFFu);
-        u32 const high = refs[k].length + (u32)__builtin_popcount(vp[k] >> 16) - (u32)__builtin_popcount(vn[k] >> 16);
-        u64 const pattern_low = pattern_first + lane, pattern_high = pattern_first + lane + 64;
-        if (texts_are_candidates) { // results[query = pattern][candidate = text]
-            if (rows_low != ~0u) results[pattern_low * results_row_stride + refs[k].index] = low;
-            if (rows_high != ~0u) results[pattern_high * results_row_stride + refs[k].index] = high;
-        }
-        else { // results[query = text][candidate = pattern]: 512 contiguous bytes per wavefront and half
-            if (rows_low != ~0u) results[(u64)refs[k].index * results_row_stride + pattern_low] = low;
-            if (rows_high != ~0u) results[(u64)refs[k].index * results_row_stride + pattern_high] = high;
-        }
+    else {
+        szs_string_ref_t const refs[1] = {outliers->refs[side_of_texts][listed_order[first_text]]};
+        outlier_wave<1>(refs, 1u, vp_start, my_masks, row_dwords, rows_low, rows_high, pattern_first + lane, texts_are_candidates, results,
+                        results_row_stride, trace_of_wave, began);
     }
 }
 
@@ -1766,15 +1837,15 @@ extern "C" int szs_hip_levenshtein_myers_fused(szs_fused_plan_t const *plan, uin
 
 extern "C" int szs_hip_levenshtein_outliers(szs_tiny_outliers_t const *outliers, szs_tape_t const *queries, szs_tape_t const *candidates,
                                             uint32_t const *query_masks, uint32_t const *candidate_masks, uint64_t *results,
-                                            uint64_t results_row_stride, void *stream) {
+                                            uint64_t results_row_stride, uint64_t *trace, void *stream) {
     using namespace szs_hip;
     if (!queries->count || !candidates->count) return 0;
     u64 const query_groups = ((u64)queries->count + outlier_patterns_k - 1) / outlier_patterns_k;
     u64 const candidate_groups = ((u64)candidates->count + outlier_patterns_k - 1) / outlier_patterns_k;
-    u64 const grid = (query_groups + candidate_groups) * (SZS_TINY_MOST_OUTLIERS / outlier_text_chunk_k) + SZS_TINY_MOST_OUTLIERS;
+    u64 const grid = (query_groups + candidate_groups) * outlier_chunks_k + SZS_TINY_MOST_OUTLIERS;
     if (grid > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(levenshtein_outliers_kernel, dim3((u32)grid), dim3(256), 0, static_cast<hipStream_t>(stream), outliers, *queries, *candidates,
-                       query_masks, candidate_masks, (u32)query_groups, (u32)candidate_groups, results, results_row_stride);
+                       query_masks, candidate_masks, (u32)query_groups, (u32)candidate_groups, results, results_row_stride, trace);
     return (int)hipGetLastError();
 }
 

@@ -125,6 +125,7 @@ __global__ __launch_bounds__(256) void levenshtein_tiny_prepare_kernel(szs_tape_
         *unfit = unfit_sequence;
         return;
     }
+    if (to - from > SZS_TINY_LONG_OUTLIER) atomicAdd(&outliers->long_counts[side], 1u);
     szs_string_ref_t ref;
     ref.address = tape.base + from, ref.length = (u32)(to - from), ref.index = index;
     if (to - from > 32u * SZS_MYERS_SHORT_WORDS) // too long for the outliers' kernel's bodies: listed as an EMPTY string (every slot that
@@ -133,7 +134,9 @@ __global__ __launch_bounds__(256) void levenshtein_tiny_prepare_kernel(szs_tape_
 }
 
 __global__ __launch_bounds__(256) void levenshtein_tiny_kernel(szs_tape_t queries, szs_tape_t candidates, u32 queries_per_workgroup,
-                                                              u64 *__restrict__ results, u64 results_row_stride) {
+                                                              u64 *__restrict__ results, u64 results_row_stride, u64 *trace) {
+#define SZS_TINY_STAMP(K) do { if (trace && threadIdx.x == 0) trace[(u64)blockIdx.x * 8 + (K)] = wall_clock64(); } while (0)
+    SZS_TINY_STAMP(0);
     __shared__ __attribute__((aligned(16))) u32 peq[256 * tiny_row_dwords_k]; // [byte][dword d: slots d (low half) and d + 16 (high)]: 20 KB
     __shared__ u32 out[8 * tiny_block_k]; // [j][column of the block]: the distances of slots j, j + 8, j + 16, j + 24, a byte each: 8 KB
     __shared__ u64 query_offsets[tiny_most_queries_k + 1];
@@ -145,6 +148,21 @@ __global__ __launch_bounds__(256) void levenshtein_tiny_kernel(szs_tape_t querie
     u32 const block = blockIdx.x % blocks, span = blockIdx.x / blocks;
     u32 const query_first = span * queries_per_workgroup;
     u32 const queries_here = queries.count - query_first < queries_per_workgroup ? queries.count - query_first : queries_per_workgroup;
+    // ---- the FIRST group's query bytes: requested before anything else, straight from the tape's offsets (not through the LDS copy
+    //      of them, a barrier away): two dependent round trips that used to stand between the local sort and the first masks
+    //      (4.6 of a workgroup's 20 us) now run beside the candidates' own two
+    u32 first_low = 0x100u, first_high = 0x100u;
+    {
+        u32 const at = tid & 15u;
+        u32 const slots[2] = {tid >> 4, (tid >> 4) + 16};
+        u64 from[2] = {0, 0}, to[2] = {0, 0};
+#pragma unroll
+        for (u32 k = 0; k < 2; ++k)
+            if (slots[k] < queries_here)
+                from[k] = tiny_offset(queries.offsets, queries.wide, (u64)query_first + slots[k]), to[k] = tiny_offset(queries.offsets, queries.wide, (u64)query_first + slots[k] + 1);
+        if (to[0] >= from[0] && to[0] - from[0] <= tiny_rows_k && at < to[0] - from[0]) first_low = reinterpret_cast<u8 const *>(queries.base + from[0])[at];
+        if (to[1] >= from[1] && to[1] - from[1] <= tiny_rows_k && at < to[1] - from[1]) first_high = reinterpret_cast<u8 const *>(queries.base + from[1])[at];
+    }
     // ---- once per workgroup: the block's candidates (offsets, local sort by length), the span's query offsets, clean masks
     u32 const my_candidate = block * tiny_block_k + tid;
     u64 my_from = 0;
@@ -177,6 +195,7 @@ __global__ __launch_bounds__(256) void levenshtein_tiny_kernel(szs_tape_t querie
     __syncthreads();
     lane_of_rank[bins[bin] + place_in_bin] = tid;
     __syncthreads();
+    SZS_TINY_STAMP(1);
     // this lane SCORES the candidate of rank ((wave + block) % 4) x 64 + lane - column `column` of the block
     u32 const column = lane_of_rank[(((tid >> 6) + blockIdx.x) & 3u) * 64u + (tid & 63u)];
     u32 const text_length = lengths[column] & 0x7FFFFFFFu; // 0 for a skipped column: nothing to consume, nothing written
@@ -191,6 +210,7 @@ __global__ __launch_bounds__(256) void levenshtein_tiny_kernel(szs_tape_t querie
         for (u32 d = 0; d < 4; ++d) symbols[d] = text.splice(raw[d], raw[d + 1]);
     }
     u32 const longest_in_wave = wave_max_u32(text_length);
+    SZS_TINY_STAMP(2);
 
     // ---- the span's queries, thirty-two at a time.  Thread t holds byte (t % 16) of slot t / 16 and of slot 16 + t / 16 - both
     //      live in dword t / 16 of a row: the bytes of the NEXT group are in flight while this one is scored.
@@ -205,7 +225,7 @@ __global__ __launch_bounds__(256) void levenshtein_tiny_kernel(szs_tape_t querie
         if (length == ~0u || position >= length) return 0x100u;
         return reinterpret_cast<u8 const *>(queries.base + query_offsets[query])[position];
     };
-    u32 ahead_low = fetch(dword_of_mine), ahead_high = fetch(dword_of_mine + 16);
+    u32 ahead_low = first_low, ahead_high = first_high;
 #pragma unroll 1
     for (u32 group_first = 0; group_first < queries_here; group_first += tiny_group_k) {
         // masks: slot s lives in half s / 16 of dword s % 16 of every row; its query is right-aligned in the half's sixteen bits
@@ -218,6 +238,7 @@ __global__ __launch_bounds__(256) void levenshtein_tiny_kernel(szs_tape_t querie
         // the group's 32 lengths: lane l of every wavefront works out slot l's, `readlane` hands them round as scalars
         u32 const length_of_my_slot = length_of(group_first + (lane & 31u));
         __syncthreads();
+        if (group_first == 0) SZS_TINY_STAMP(3);
         // ---- sixteen registers of two patterns each; phantom low rows below a pattern shorter than 16
         u32 vp[16], vn[16];
         u32 skipped = 0; // bit s: slot s is a query this kernel leaves to the outliers' kernel (or lies past the span's end)
@@ -261,7 +282,9 @@ __global__ __launch_bounds__(256) void levenshtein_tiny_kernel(szs_tape_t querie
             }
             out[j * tiny_block_k + column] = packed;
         }
+        if (group_first == 0) SZS_TINY_STAMP(4);
         __syncthreads();
+        if (group_first == 0) SZS_TINY_STAMP(5);
         // un-build the masks (the same dwords back to zero: cheaper than clearing 16 KB) ...
         if (built_low < 0x100u) peq[built_low * tiny_row_dwords_k + dword_of_mine] = 0;
         if (built_high < 0x100u) peq[built_high * tiny_row_dwords_k + dword_of_mine] = 0;
@@ -275,8 +298,11 @@ __global__ __launch_bounds__(256) void levenshtein_tiny_kernel(szs_tape_t querie
             for (u32 s = 0; s < tiny_group_k; ++s)
                 if (!((skipped >> s) & 1u)) first_row[(u64)s * results_row_stride] = (packed[s & 7u] >> (8 * (s >> 3))) & 0xFFu;
         }
+        if (group_first == 0) SZS_TINY_STAMP(6);
         __syncthreads(); // the next group's atomics must not meet the un-building stores, nor its distances these reads
     }
+    SZS_TINY_STAMP(7);
+#undef SZS_TINY_STAMP
 }
 
 } // namespace szs_hip
@@ -294,7 +320,7 @@ extern "C" int szs_hip_levenshtein_tiny_prepare(szs_tape_t const *queries, szs_t
 }
 
 extern "C" int szs_hip_levenshtein_tiny(szs_tape_t const *queries_tape, szs_tape_t const *candidates_tape, uint64_t *results,
-                                        uint64_t results_row_stride, void *stream) {
+                                        uint64_t results_row_stride, uint64_t *trace, void *stream) {
     using namespace szs_hip;
     szs_tape_t const queries = *queries_tape, candidates = *candidates_tape;
     u32 const queries_count = queries.count, candidates_count = candidates.count;
@@ -302,8 +328,9 @@ extern "C" int szs_hip_levenshtein_tiny(szs_tape_t const *queries_tape, szs_tape
     u64 const blocks = ((u64)candidates_count + tiny_block_k - 1) / tiny_block_k;
     // Spans of the queries: enough workgroups to fill the device a few times over (a workgroup's set-up - offsets, the local sort -
     // is paid once per span), whole groups of thirty-two, at most tiny_most_queries_k queries each.
-    // (measured on 4096 x 4096 words: 2048 workgroups of one group each 55.7 us, 1024 of two 57.1, 512 of four 68.6)
-    u64 const wanted_workgroups = 2048;
+    // (measured on 4096 x 4096 words: 2048 workgroups of one group each 55.6 us, 1024 of two 50.5, 688 of three 63.0 - a workgroup's
+    // set-up is 7 of its 20 us, but fewer workgroups than 4 per CU leave nobody to run while the others wait)
+    u64 const wanted_workgroups = 1024;
     u64 spans = (wanted_workgroups + blocks - 1) / blocks;
     u64 per_span = ((u64)queries_count + spans - 1) / spans;
     per_span = (per_span + tiny_group_k - 1) / tiny_group_k * tiny_group_k;
@@ -311,6 +338,6 @@ extern "C" int szs_hip_levenshtein_tiny(szs_tape_t const *queries_tape, szs_tape
     spans = ((u64)queries_count + per_span - 1) / per_span;
     if (blocks * spans > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(levenshtein_tiny_kernel, dim3((u32)(blocks * spans)), dim3(256), 0, static_cast<hipStream_t>(stream), queries, candidates,
-                       (u32)per_span, results, results_row_stride);
+                       (u32)per_span, results, results_row_stride, trace);
     return (int)hipGetLastError();
 }

@@ -1086,11 +1086,18 @@ static sz_status_t cross_tiny(szs_call_t *call, uint32_t planner_mode, szs_plan_
     }
     if (error == hipSuccess) error = hipMemsetAsync(outliers, 0, 16, stream); /* the two counts */
     uint32_t launches = 0;
+    uint64_t *trace = NULL; /* `trace` knob: the phases of every workgroup of the tiny-token kernel, then of every wavefront of the outliers' (printed after the wait) */
+    size_t const trace_workgroups = 8192, trace_waves = 65536;
+    if (call->trace && szs_buffer_reserve(&engine->device_queue_trace, szs_memory_device_k, call->device, trace_workgroups * 64 + trace_waves * 32, NULL) == sz_success_k) {
+        trace = (uint64_t *)engine->device_queue_trace.pointer;
+        if (hipMemsetAsync(trace, 0, trace_workgroups * 64 + trace_waves * 32, stream) != hipSuccess) trace = NULL;
+    }
     if (error == hipSuccess) {
         error = (hipError_t)szs_hip_levenshtein_tiny_prepare(&q_tape, &c_tape, (uint32_t *)unfit, sequence, outliers, q_masks, c_masks, (unsigned long long *)symbols, 0, stream);
         launches += error == hipSuccess;
         if (error == hipSuccess) { /* tokens of more than 16 bytes: their rows and columns (hip/lev_myers.hip) */
-            error = (hipError_t)szs_hip_levenshtein_outliers(outliers, &q_tape, &c_tape, q_masks, c_masks, (uint64_t *)call->device_results, call->device_stride, stream);
+            error = (hipError_t)szs_hip_levenshtein_outliers(outliers, &q_tape, &c_tape, q_masks, c_masks, (uint64_t *)call->device_results, call->device_stride,
+                                                             trace ? trace + trace_workgroups * 8 : NULL, stream);
             launches += error == hipSuccess;
         }
         /* ... and the tables set back to zeros behind it (the same pass over the tapes, stores instead of atomics) - also when the
@@ -1100,7 +1107,7 @@ static sz_status_t cross_tiny(szs_call_t *call, uint32_t planner_mode, szs_plan_
         launches += unbuilt == hipSuccess;
     }
     if (error == hipSuccess) {
-        error = (hipError_t)szs_hip_levenshtein_tiny(&q_tape, &c_tape, (uint64_t *)call->device_results, call->device_stride, stream);
+        error = (hipError_t)szs_hip_levenshtein_tiny(&q_tape, &c_tape, (uint64_t *)call->device_results, call->device_stride, trace, stream);
         launches += error == hipSuccess;
     }
     engine->last_streams = 1;
@@ -1113,6 +1120,41 @@ static sz_status_t cross_tiny(szs_call_t *call, uint32_t planner_mode, szs_plan_
     sz_status_t status = finish(call, shape, error, sz_success_k, launches, 0, 0, 0, &stalled);
     free(shape);
     if (status != sz_success_k) return status;
+    if (trace) { /* where a workgroup of the tiny-token kernel spends its time: mean ticks (10 ns) between its stamps */
+        uint64_t *const ticks = (uint64_t *)malloc(trace_workgroups * 64);
+        if (ticks && hipMemcpy(ticks, trace, trace_workgroups * 64, hipMemcpyDeviceToHost) == hipSuccess) {
+            double sums[8] = {0};
+            uint64_t first = ~0ull, last = 0;
+            size_t seen = 0;
+            for (size_t w = 0; w < trace_workgroups; ++w) {
+                if (!ticks[8 * w] || !ticks[8 * w + 7]) continue;
+                ++seen;
+                first = ticks[8 * w] < first ? ticks[8 * w] : first, last = ticks[8 * w + 7] > last ? ticks[8 * w + 7] : last;
+                for (int k = 1; k < 8; ++k) sums[k] += (double)(ticks[8 * w + k] - ticks[8 * w + k - 1]);
+            }
+            if (seen)
+                fprintf(stderr, "tiny kernel: %zu workgroups over %.1f us; mean us per workgroup: offsets + local sort %.2f, texts %.2f, first masks %.2f, columns %.2f, "
+                                "barrier %.2f, un-build + stores %.2f, rest (further groups) %.2f\n", seen, (last - first) * 1e-2, sums[1] / seen * 1e-2,
+                        sums[2] / seen * 1e-2, sums[3] / seen * 1e-2, sums[4] / seen * 1e-2, sums[5] / seen * 1e-2, sums[6] / seen * 1e-2, sums[7] / seen * 1e-2);
+        }
+        free(ticks);
+        uint64_t *const waves = (uint64_t *)malloc(trace_waves * 32);
+        if (waves && hipMemcpy(waves, trace + trace_workgroups * 8, trace_waves * 32, hipMemcpyDeviceToHost) == hipSuccess) {
+            uint64_t first = ~0ull, last = 0, longest_life = 0, longest_text = 0;
+            double set_up = 0, columns = 0;
+            size_t seen = 0;
+            for (size_t w = 0; w < trace_waves; ++w) {
+                if (!waves[4 * w] || !waves[4 * w + 2]) continue;
+                ++seen, set_up += (double)(waves[4 * w + 1] - waves[4 * w]), columns += (double)(waves[4 * w + 2] - waves[4 * w + 1]);
+                first = waves[4 * w] < first ? waves[4 * w] : first, last = waves[4 * w + 2] > last ? waves[4 * w + 2] : last;
+                if (waves[4 * w + 2] - waves[4 * w] > longest_life) longest_life = waves[4 * w + 2] - waves[4 * w], longest_text = waves[4 * w + 3];
+            }
+            if (seen)
+                fprintf(stderr, "outliers' kernel, kinds A / B: %zu wavefronts over %.1f us; mean us per wavefront: set-up %.2f, columns %.2f; the longest-lived %.2f us (its longest text: %u bytes)\n",
+                        seen, (last - first) * 1e-2, set_up / seen * 1e-2, columns / seen * 1e-2, longest_life * 1e-2, (unsigned)longest_text);
+        }
+        free(waves);
+    }
     if (*unfit == sequence) {
         engine->tiny_valid = 0;
         return SZS_TINY_NOT_TAKEN;
