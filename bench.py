@@ -413,7 +413,7 @@ def measure_extra(config, scope, device_index, args, fence, with_cpu):
 def measure_fingerprints(scope, device_index, args, fence):
     """`szs_fingerprints_u32tape`: rolling MinHash over 1024 documents of ~10 KB, 1024 dimensions of the
     reference's default window widths - bytes of text per second and byte-dimensions per second of the whole C-ABI call.  The
-    kernel's work is 25 instructions per byte and dimension (DESIGN.md section 4.6): VALU-bound, the text is read once per 256
+    kernel's work is 25 instructions per byte and dimension (DESIGN.md section 4.5): VALU-bound, the text is read once per 256
     dimensions from LDS."""
     import torch
 

@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void levenshtein_tiny_kernel(szs_tape_t querie
 #pragma unroll
         for (u32 d = 0; d < 4; ++d) symbols[d] = text.splice(raw[d], raw[d + 1]);
     }
-    u32 const longest_in_wave = wave_max_u32(text_length);
+    u32 const longest_in_wave = (u32)__builtin_amdgcn_readfirstlane(wave_max_u32(text_length)); // (the compiler must know it is uniform)
     SZS_TINY_STAMP(2);
 
     // ---- the span's queries, thirty-two at a time.  Thread t holds byte (t % 16) of slot t / 16 and of slot 16 + t / 16 - both

@@ -425,7 +425,7 @@ def test_real_text_tokens_match_the_oracle(gpu, oracle, tokens):
     import os
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    corpus = b"".join(open(os.path.join(root, name), "rb").read() for name in ("SURVEY.md", "DESIGN.md"))
+    corpus = b"".join(open(os.path.join(root, name), "rb").read() for name in ("SURVEY.md", "DESIGN.md", os.path.join("docs", "history", "DESIGN_rounds_1_to_4.md")))
     found = workloads.tokenize_dataset(corpus, tokens)
     assert len(found) > 300
     rng = np.random.default_rng(7)
