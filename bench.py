@@ -94,6 +94,8 @@ def parse_args():
     parser.add_argument("--extra-scale", type=float, default=1.0,
                         help="testing aid: shrinks the matrix side of the `configs` records (1.0 = BASELINE.json's sizes)")
     parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--fingerprints-only", action="store_true",
+                        help="time `szs_fingerprints_u32tape` alone and print its record (what scripts/profile_configs.sh runs as config 11)")
     parser.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI)")
     parser.add_argument("--same-device", action="store_true",
                         help="testing aid: every rank uses cuda:0 (with --backend gloo), to exercise the N > 1 code "
@@ -420,43 +422,61 @@ def measure_fingerprints(scope, device_index, args, fence):
     import stringzilla_amd as szs
     from stringzilla_amd import workloads
 
+    from stringzilla_amd import _abi
+
     dimensions = 1024
     texts = workloads.random_tape(np.random.default_rng(11), 1024, 8192, 12288, workloads.ASCII_PRINTABLE).to_device(device_index)
     engine = szs.Fingerprints(dimensions, capabilities=scope)
-    engine(texts, device=scope)
+    # the raw C-ABI call into matrices that live in HBM, like every other record (round 4 timed the Python wrapper, which also
+    # downloads 8 MB into fresh pageable NumPy arrays per call: its "first pass" ran at twice the time of every later one -
+    # host pages being faulted in, not the kernel, whose dispatches take 5.8 ms from the sixth on and 6.5 the very first:
+    # profiles/r05/fingerprints_first_pass.txt)
+    outputs = torch.empty((2, len(texts), dimensions), dtype=torch.int32, device=torch.device("cuda", device_index))
+    tape, error = texts._tape(device_index), ctypes.c_char_p()
+
+    def step():
+        status = _abi.lib.szs_fingerprints_u32tape(engine.handle, scope.handle, ctypes.byref(tape), outputs[0].data_ptr(), dimensions * 4,
+                                                   outputs[1].data_ptr(), dimensions * 4, ctypes.byref(error))
+        if status:
+            raise RuntimeError(f"szs_fingerprints_u32tape failed: {status} {error.value}")
+
+    step()
     fence()
     started = time.perf_counter()
-    engine(texts, device=scope)
+    step()
     once = time.perf_counter() - started
     repeats = int(max(3, min(50, args.extra_seconds / max(once, 1e-4))))
-    # two passes, the faster one counts: the first pass after an engine is created has been seen at twice the time of every later
-    # one (12.7 ms, then 6.2 ms and staying there: profiles/r04/fingerprints_first_pass.txt) - grow-only buffers and clocks settling
     walls = []
-    for _ in range(2):
+    for _ in range(2):  # two passes; both are reported, the faster one counts
         fence()
         started = time.perf_counter()
         for _ in range(repeats):
-            hashes, counts = engine(texts, device=scope)
+            step()
         fence()
         walls.append((time.perf_counter() - started) / repeats)
     wall = min(walls)
     text_bytes = int(texts.lengths().sum())
-    # Instructions per byte and dimension from the kernel's own assembly: its main loop is unrolled over FOUR positions
-    # (`#pragma unroll 4`, hip/fingerprints.hip), so VALU instructions of that loop / 4; the ceiling is that loop's class-weighted
-    # one (scripts/opcode_mix.py).  An estimate - no PMC pass counts this call - and said so; round 3 assumed 25 per position
-    # against the flat half-rate peak and could read above 1.
+    # VALU work: counted by a committed PMC pass of this very call when there is one (`cfg11:fingerprint_segments_kernel`,
+    # scripts/profile_configs.sh 11), else estimated from the kernel's assembly (its main loop is unrolled over four positions)
+    summary, where = _profile_json("pmc_configs.json")
+    counted = (summary or {}).get("cfg11:fingerprint_segments_kernel", {}).get("SQ_INSTS_VALU")
     mixes, mix_where = _profile_json("opcode_mix.json")
     mix = (mixes or {}).get("fingerprint_segments_kernel")
-    per_position = mix["valu_instructions"] / 4.0 if mix else 25.0
     ceiling = mix["ceiling_Tlane_ops_per_s"] * 1e12 if mix else VALU_HALF_RATE_PEAK
-    lane_ops = per_position * text_bytes * dimensions  # one lane per dimension: instructions per position x positions x lanes
+    if counted:
+        lane_ops, how = counted * 64.0, f"PMC: SQ_INSTS_VALU of the segments kernel, {where}"
+    else:
+        per_position = mix["valu_instructions"] / 4.0 if mix else 25.0
+        lane_ops, how = per_position * text_bytes * dimensions, "ESTIMATE: main loop of the assembly / 4 positions" if mix else "ESTIMATE: 25 assumed"
+    counted_on = (summary or {}).get("_library_sha256")
     return {"config": "fingerprints", "workload": "1024 ASCII documents of 8-12 KB, 1024 dimensions, default window widths",
             "entry_point": "szs_fingerprints_u32tape", "n_gpus": 1, "steps": repeats, "ms_per_step": round(wall * 1e3, 3),
             "passes_ms": [round(w * 1e3, 3) for w in walls],
             "value": round(text_bytes * dimensions / wall / 1e12, 3), "unit": "10^12 byte-dimensions/s",
-            "text_gb_s": round(text_bytes / wall / 1e9, 2), "results_checksum": int(hashes.astype(np.uint64).sum() % (1 << 53)),
-            "roofline": {"bound": "int / fp64 VALU issue", "instructions_per_byte_and_dimension": round(per_position, 2),
-                         "counted": "assembly of the main loop / 4 positions" if mix else "assumed 25",
+            "text_gb_s": round(text_bytes / wall / 1e9, 2), "results_checksum": int(outputs[0].to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item() % (1 << 53)),
+            "roofline": {"bound": "int / fp64 VALU issue", "counted": how,
+                         "lane_ops_per_byte_and_dimension": round(lane_ops / (text_bytes * dimensions), 2),
+                         "pmc_stale": None if not (counted and counted_on) else counted_on != library_digest(),
                          "achieved_Tlane_ops_per_s": round(lane_ops / wall / 1e12, 2), "peak_Tlane_ops_per_s": round(ceiling / 1e12, 2),
                          "frac": round(lane_ops / wall / ceiling, 4),
                          "hbm": {"algorithmic_bytes": text_bytes + 8 * dimensions * len(texts), "achieved_gb_s": round((text_bytes + 8 * dimensions * len(texts)) / wall / 1e9, 2),
@@ -637,6 +657,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.fingerprints_only:
+        print(json.dumps(measure_fingerprints(scope, local_rank, args, fence)), flush=True)
+        return
     # ---- the other configs run BEFORE the headline's warm-up: a run of W = 5 short warm-up steps on a GPU that has idled
     # through the set-up is timed on its clock ramp (round 1: 64.4 TCUPS with 20 steps against 67.9 with 200); after seconds
     # of NW / SW scoring the clocks are where a busy GPU keeps them.  The headline itself is unchanged: W untimed steps, then

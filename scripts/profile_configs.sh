@@ -15,6 +15,7 @@ cd /tmp && export TMPDIR=/tmp
 for N in "${CONFIGS[@]}"; do
     case $N in 2) STEPS=(--steps 50 --warmup 5);; 4) STEPS=(--steps 2 --warmup 1);; *) STEPS=(--steps 5 --warmup 1);; esac
     ARGS=(--config "$N" --extra-configs none --no-cpu-baseline "${STEPS[@]}")
+    [ "$N" = 11 ] && ARGS=(--fingerprints-only --extra-seconds 0.05) # `szs_fingerprints_u32tape` alone: cfg11:fingerprint_segments_kernel
     D=$OUT/cfg$N; mkdir -p "$D"
     timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$D/stats" -o stats -- python "$ROOT/bench.py" "${ARGS[@]}" > "$D/bench.json" 2> "$D/stats.log" \
         || echo "cfg$N stats run failed"
