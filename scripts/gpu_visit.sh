@@ -19,6 +19,10 @@ for step in "$@"; do
                 export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:use_sigaltstack=0 UBSAN_OPTIONS=print_stacktrace=1 PROBE_ALARM=120
                 { for args in "lev 40 300 50 700 1" "levw 40 300 50 700 1" "nw 40 300 50 700 1" "sw 40 300 50 700 1" "nw 9 300 900 1100 1 -4 -1" "lev 3 4 2040 2100 1" "lev 1 1 30000 40000 1" "nw 1 1 30000 40000 1"; do
                     echo "--- systolic_probe $args"; timeout 300 tests/native/bin/systolic_probe_asan $args 2>&1 | grep -v "^    #" | tail -6; done
+                  for args in "lev 300 700 40 200 6" "lev 1024 1024 96 160 4"; do # round 5: streams of fresh batches - the launch that plans itself
+                    echo "--- systolic_probe $args (PROBE_ALTERNATE=1)"; PROBE_ALTERNATE=1 timeout 300 tests/native/bin/systolic_probe_asan $args 2>&1 | grep -v "^    #" | tail -7; done
+                  for args in "lev 600 2100 1 12 4" "lev 300 700 0 20 4"; do # ... and tiny tokens straight from the tapes (the second with a fifth of its strings beyond 16 bytes: the outliers' kernel)
+                    echo "--- systolic_probe $args (PROBE_ALTERNATE=1 SZS_ROCM_TINY=1)"; PROBE_ALTERNATE=1 SZS_ROCM_TINY=1 timeout 300 tests/native/bin/systolic_probe_asan $args 2>&1 | grep -v "^    #" | tail -5; done
                   for args in "lev 70 300 10 400 0 0" "nw 33 200 100 600 0 0 0" "sw 20 100 500 900 0" "lev-sym 150 0 10 400 0 0 0" "nw-sym 90 0 100 600 0 0 0 0 0 0 0 0" "lev 5 40 10 90 0 0 0 0 0 0 0 0"; do
                     echo "--- node_probe $args"; timeout 300 tests/native/bin/node_probe_asan $args 2>&1 | grep -v "^    #" | tail -6; done
                   for args in "lev 120 900 8 2040 0" "lev-sym 200 0 8 2040 0 0"; do # the one-launch kernel: its queue is planned by the sanitized host

@@ -5,6 +5,8 @@
  *
  *      systolic_probe FAMILY Q C LEN_LO LEN_HI [REPEATS] [OPEN EXTEND]      FAMILY = lev | levw | nw | sw
  *  The tier / orientation are chosen by the library; pin them with SZS_ROCM_TIER / SZS_ROCM_SWAP as usual.
+ *  PROBE_ALTERNATE=1: two batches of the same shape take turns (a stream of FRESH batches: the calls that plan themselves inside
+ *  their launch, or that score tiny tokens straight from the tapes - the same tapes again would take the re-use path).
  */
 #define _POSIX_C_SOURCE 200809L
 #define __HIP_PLATFORM_AMD__ 1
@@ -82,7 +84,10 @@ int main(int argc, char **argv) {
     if (family[0] == 'n') szo_blosum62(byte_to_class, class_costs);
     else szo_nuc44(byte_to_class, class_costs);
     char const *alphabet = family[0] == 'n' ? "ARNDCQEGHILKMFPSTWYV" : "ACGT";
-    tape_t const queries = make_tape(q_count, lo, hi, alphabet), candidates = make_tape(c_count, lo, hi, alphabet);
+    int const alternate = getenv("PROBE_ALTERNATE") != NULL;
+    tape_t const batches[2][2] = {{make_tape(q_count, lo, hi, alphabet), make_tape(c_count, lo, hi, alphabet)},
+                                  {make_tape(alternate ? q_count : 1, lo, hi, alphabet), make_tape(alternate ? c_count : 1, lo, hi, alphabet)}};
+    tape_t const queries = batches[0][0], candidates = batches[0][1];
 
     char const *error = NULL;
     szs_device_scope_t scope = NULL;
@@ -97,7 +102,7 @@ int main(int argc, char **argv) {
     if (status) return fprintf(stderr, "init: %d %s\n", status, error ? error : ""), 1;
 
     size_t const cells_count = q_count * c_count;
-    int64_t *expected = malloc(cells_count * 8), *got = malloc(cells_count * 8), *device_results = NULL;
+    int64_t *expected = malloc(cells_count * 8), *expected_other = malloc(cells_count * 8), *got = malloc(cells_count * 8), *device_results = NULL;
     hipMalloc((void **)&device_results, cells_count * 8);
     stage = "oracle";
     int const no_oracle = getenv("PROBE_NO_ORACLE") != NULL; /* timing runs on batches the CPU checker would take minutes for */
@@ -106,10 +111,19 @@ int main(int argc, char **argv) {
     else if (family[0] == 'n') szo_needleman_wunsch_cross(queries.data, queries.offsets64, q_count, candidates.data, candidates.offsets64, c_count, byte_to_class, class_costs, open, extend, expected, c_count);
     else szo_smith_waterman_cross(queries.data, queries.offsets64, q_count, candidates.data, candidates.offsets64, c_count, byte_to_class, class_costs, open, extend, expected, c_count);
 
-    sz_sequence_u32tape_t q_tape = {queries.device_data, queries.device_offsets, q_count};
-    sz_sequence_u32tape_t c_tape = {candidates.device_data, candidates.device_offsets, c_count};
+    if (alternate && !no_oracle) { /* the second batch's matrix */
+        tape_t const *q = &batches[1][0], *c = &batches[1][1];
+        if (is_lev) szo_levenshtein_cross(q->data, q->offsets64, q_count, c->data, c->offsets64, c_count, match, mismatch, open, extend, (uint64_t *)expected_other, c_count);
+        else if (family[0] == 'n') szo_needleman_wunsch_cross(q->data, q->offsets64, q_count, c->data, c->offsets64, c_count, byte_to_class, class_costs, open, extend, expected_other, c_count);
+        else szo_smith_waterman_cross(q->data, q->offsets64, q_count, c->data, c->offsets64, c_count, byte_to_class, class_costs, open, extend, expected_other, c_count);
+    }
+    int64_t *const expected_first = expected;
     int failures = 0;
     for (int run = 0; run < repeats; ++run) {
+        int const which = alternate ? run & 1 : 0;
+        sz_sequence_u32tape_t q_tape = {batches[which][0].device_data, batches[which][0].device_offsets, q_count};
+        sz_sequence_u32tape_t c_tape = {batches[which][1].device_data, batches[which][1].device_offsets, c_count};
+        expected = which ? expected_other : expected_first;
         stage = "engine call";
         alarm(patience);
         hipMemset(device_results, 0xEE, cells_count * 8);
@@ -124,13 +138,13 @@ int main(int argc, char **argv) {
         szs_rocm_last_call_profile(engine, &profile);
         size_t bad = 0;
         for (size_t i = 0; i < cells_count && !no_oracle; ++i) bad += got[i] != expected[i];
-        printf("%s %zux%zu len[%zu,%zu] gaps %d/%d run %d: tier %u swapped %u %.3f ms wall %.3f ms kernel, %zu bad cells", family, q_count, c_count, lo, hi,
-               open, extend, run, profile.tier, profile.transposed, elapsed, profile.kernel_milliseconds, bad);
+        printf("%s %zux%zu len[%zu,%zu] gaps %d/%d run %d: tier %u swapped %u planner %u launches %u %.3f ms wall %.3f ms kernel, %zu bad cells", family, q_count,
+               c_count, lo, hi, open, extend, run, profile.tier, profile.transposed, profile.planner, profile.launches, elapsed, profile.kernel_milliseconds, bad);
         for (size_t i = 0, shown = 0; i < cells_count && shown < 4 && !no_oracle; ++i)
             if (got[i] != expected[i])
                 printf(" [q%zu(len %llu) c%zu(len %llu): got %lld want %lld]", i / c_count,
-                       (unsigned long long)(queries.offsets64[i / c_count + 1] - queries.offsets64[i / c_count]), i % c_count,
-                       (unsigned long long)(candidates.offsets64[i % c_count + 1] - candidates.offsets64[i % c_count]),
+                       (unsigned long long)(batches[which][0].offsets64[i / c_count + 1] - batches[which][0].offsets64[i / c_count]), i % c_count,
+                       (unsigned long long)(batches[which][1].offsets64[i % c_count + 1] - batches[which][1].offsets64[i % c_count]),
                        (long long)got[i], (long long)expected[i]), ++shown;
         printf("\n");
         fflush(stdout);
