@@ -245,3 +245,29 @@ def test_a_query_the_tiny_kernel_cannot_hold_sends_the_call_to_the_ordinary_path
             assert np.array_equal(out[:, :513].cpu().numpy().view(np.uint64), expected)
             assert (out[:, 513:] == -1).all()
         assert engine.last_call_profile().planner == 5
+
+
+def test_round5_paths_fill_a_host_matrix_too(gpu, oracle):
+    """Results in plain host memory (a NumPy `out=`): the library stages a dense matrix in HBM and copies it out with one 2-D copy -
+    behind the launch that plans itself and behind the four launches of the tiny-token path alike (cuda.cuh:2205-2215)."""
+    rng = random.Random(8)
+    # (one token in 25 beyond 16 bytes: 160 of the 4000 candidates - the outliers' lists hold 256 a side)
+    word = lambda: bytes(rng.choice(b"etaoinshrdlu") for _ in range(rng.choice([0, 1, 2, 3, 3, 4, 4, 5, 5, 5, 6, 6, 6, 7, 7, 8, 9, 10, 11, 12, 13, 14, 16, 16, 23])))
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+    modes = []
+    for batch in range(3):  # words: summary-chosen, then straight from the tapes
+        queries, candidates = [word() for _ in range(300)], [word() for _ in range(4000)]
+        out = np.full((300, 4100), 0xEEEE, dtype=np.uint64)
+        engine(queries, candidates, device=gpu, out=out[:, :4000])
+        assert np.array_equal(out[:, :4000], oracle.levenshtein(queries, candidates)) and (out[:, 4000:] == 0xEEEE).all()
+        modes.append(int(engine.last_call_profile().planner))
+    assert modes[1:] == [5, 5], modes
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+    modes = []
+    for batch in range(3):  # config 2's shape, an eighth of it: planned, then planning itself
+        queries, candidates = _rand(rng, 128, 96, 160), _rand(rng, 1024, 96, 160)
+        out = np.full((128, 1024), 0xEEEE, dtype=np.uint64)
+        engine(queries, candidates, device=gpu, out=out)
+        assert np.array_equal(out, oracle.levenshtein(queries, candidates))
+        modes.append(int(engine.last_call_profile().planner))
+    assert modes[1:] == [4, 4], modes
