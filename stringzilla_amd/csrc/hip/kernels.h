@@ -326,10 +326,14 @@ typedef struct szs_plan_summary_t {
 /**
  *  Plans one call on the device: reads the offsets of both tapes (`candidates` NULL: symmetric), writes for each side the
  *  refs sorted by ascending and by descending length, and the summary (pinned host memory is fine).  With `expected`
- *  enabled and violated, every ref is written with length 0.  One workgroup; see hip/planner.hip.
+ *  enabled and violated, the refs of the side that violates it are written with length 0.  One workgroup per side; see
+ *  hip/planner.hip.
  */
 int szs_hip_plan(szs_plan_side_t const *queries, szs_plan_side_t const *candidates, unsigned myers_words,
-                 szs_plan_expectation_t const *expected, szs_plan_summary_t *summary, void *stream);
+                 szs_plan_expectation_t const *expected, szs_plan_summary_t *summary,
+                 uint32_t *verdicts /* 8 dwords of device memory, zeroed when allocated and never again: where the two workgroups of a
+                                       two-sided plan leave their verdicts and count themselves (NULL allowed when `candidates` is) */,
+                 void *stream);
 
 /**
  *  The planner FOLDED INTO the scoring launch (hip/lev_myers.hip, round 5): a unit-cost byte call whose queries all fit the

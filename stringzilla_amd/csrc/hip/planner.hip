@@ -5,10 +5,10 @@
  *  and scattered afterwards (/root/reference/include/stringzillas/similarities/cuda.cuh:1652-1711,1887-1957) - or, on its
  *  fast path, skips task materialisation altogether (cuda.cuh:4297-4340).  This build plans per ROW and COLUMN
  *  (host/plan.c); round 1 did that on the host, which cost a download of the offsets and a stream synchronisation before
- *  the first scoring launch could even be enqueued (18 % of config 2's wall time).  Here the same plan is produced by ONE
- *  workgroup of 1024 threads straight from the caller's offsets:
+ *  the first scoring launch could even be enqueued (18 % of config 2's wall time).  Here the same plan is produced by one
+ *  workgroup of 1024 threads PER SIDE straight from the caller's offsets:
  *
- *    histogram   both sides at once: every string's length goes into its side's LDS histogram; offsets that descend,
+ *    histogram   every string's length goes into its side's LDS histogram; offsets that descend,
  *                strings of 4 GiB and strings beyond the histogram are flagged, not scored (the host planner takes over);
  *    statistics  everything the host decides from - strings per bit-parallel launch variant, longest string, sums, the
  *                band counts of the tier model - is read off the histogram: 6 bins per thread, one scan, four reductions;
@@ -52,127 +52,120 @@ __device__ __forceinline__ u64 shuffle_xor_u64(u64 value, int offset) {
 
 /**
  *  What bounds this kernel is LATENCY - dependent memory round trips, workgroup barriers, LDS crossbar shuffles - not work:
- *  a side of 1024 strings is one string per thread.  So both sides advance through every phase TOGETHER (two histograms,
- *  half the barriers), each thread keeps its strings' offsets in registers from the first load on, and every statistic the
- *  host wants - counts per launch variant, longest string, sums, band counts - is read off the HISTOGRAM of the lengths
- *  (6 bins per thread, then one scan and four reductions per side) instead of being reduced string by string (round 2's
- *  first version reduced fifteen 64-bit values per side through LDS atomics, which hipcc expands into scalar loops over
- *  the 64 lanes: 40 us; then through shuffles: 25 us).
+ *  a side of 1024 strings is one string per thread.  Each thread keeps its strings' offsets in registers from the first load
+ *  on, and every statistic the host wants - counts per launch variant, longest string, sums, band counts - is read off the
+ *  HISTOGRAM of the lengths (6 bins per thread, then one scan and four reductions) instead of being reduced string by string.
+ *
+ *  Round 5: ONE WORKGROUP PER SIDE.  Rounds 2-4 planned both sides in one workgroup, phase by phase together; the two sides
+ *  share nothing but the verdict on the host's expectation, so each now has a workgroup (and a CU) of its own - half the
+ *  strings per thread, half the LDS traffic per phase - and the SECOND one to finish (a counter in device memory says which)
+ *  folds the two verdicts into the summary: config-5-sized sides (2 x 3163 strings) 33-37 us -> see profiles/r05.  A side that
+ *  does not fit the expectation blanks ITS OWN refs; a speculated launch then scores against empty strings whichever side it was.
  */
 __global__ __launch_bounds__(plan_threads_k) void plan_kernel(szs_plan_side_t queries, szs_plan_side_t candidates,
                                                               int symmetric, u32 myers_words,
                                                               szs_plan_expectation_t expected,
-                                                              szs_plan_summary_t *__restrict__ summary) {
+                                                              szs_plan_summary_t *__restrict__ summary, u32 *__restrict__ verdicts) {
     extern __shared__ __attribute__((aligned(16))) szs_string_ref_t staged[]; // `plan_staged_k` refs: phase 4
-    __shared__ u32 histogram[2][plan_bins_k];
-    __shared__ u32 wave_counts[2][plan_waves_k], wave_symbols[2][plan_waves_k], wave_bands_systolic[2][plan_waves_k],
-        wave_bands_chain[2][plan_waves_k], wave_longest[2][plan_waves_k], wave_status[plan_waves_k];
-    __shared__ u32 side_count_before_wave[2][plan_waves_k], side_symbols[2], side_bands_systolic[2], side_bands_chain[2],
-        side_longest[2], side_strings[2], variants[2][SZS_PLAN_VARIANTS], shared_status, shared_held,
-        rank_lengths[2][SZS_PLAN_RANK_SAMPLES + 1];
+    __shared__ u32 histogram[plan_bins_k];
+    __shared__ u32 wave_counts[plan_waves_k], wave_symbols[plan_waves_k], wave_bands_systolic[plan_waves_k],
+        wave_bands_chain[plan_waves_k], wave_longest[plan_waves_k], wave_status[plan_waves_k];
+    __shared__ u32 count_before_wave[plan_waves_k], side_symbols, side_bands_systolic, side_bands_chain, side_longest, side_strings,
+        variants[SZS_PLAN_VARIANTS], shared_status, shared_held, rank_lengths[SZS_PLAN_RANK_SAMPLES + 1];
     __shared__ unsigned long long chunk_sums[plan_threads_k], shared_cells;
 
     u32 const tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    int const sides = symmetric ? 1 : 2;
-    szs_plan_side_t const *const side_of[2] = {&queries, &candidates};
+    int const mine = symmetric ? 0 : (int)blockIdx.x; // the side this workgroup plans: 0 the caller's queries, 1 its candidates
+    szs_plan_side_t const &side = mine ? candidates : queries;
 #ifdef SZS_PLAN_TIMESTAMPS // measuring aid (build variant): 100 MHz timestamps of the phases, behind the summary, for the trace
     unsigned long long *const stamps = reinterpret_cast<unsigned long long *>(summary) + 56;
-#define SZS_PLAN_STAMP(K) do { if (tid == 0) stamps[K] = wall_clock64(); } while (0)
+#define SZS_PLAN_STAMP(K) do { if (tid == 0 && mine == 0) stamps[K] = wall_clock64(); } while (0)
 #else
 #define SZS_PLAN_STAMP(K) do {} while (0)
 #endif
     SZS_PLAN_STAMP(0);
 
-    // ---- phase 0: both histograms cleared; each thread's first string of each side fetched (one round trip for the kernel
-    //      when a side has at most 1024 strings: every later phase reads registers)
-    // (round 4: the first FOUR strings of each side - a side of up to 4096 strings, config 5's 3163 - are fetched here, all
-    // loads in flight at once: phases 1 and 4 walked a thread's strings one memory round trip after the other, 31 us for an
-    // eighth of config 5u's 3,559 strings where 1,024 + 1,024 take 13)
-    u64 first_from[2][plan_cached_k] = {}, first_to[2][plan_cached_k] = {}, first_start[2][plan_cached_k] = {};
-    u32 first_length[2][plan_cached_k] = {};
+    // ---- phase 0: the histogram cleared; each thread's first FOUR strings fetched, all loads in flight at once (a side of up to
+    //      4096 strings - config 5's 3163 - is then one round trip; every later phase reads registers)
+    u64 first_from[plan_cached_k] = {}, first_to[plan_cached_k] = {}, first_start[plan_cached_k] = {};
+    u32 first_length[plan_cached_k] = {};
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (u32 slot = 0; slot < plan_cached_k; ++slot) {
-            u32 const i = tid + slot * plan_threads_k;
-            if (s < sides && i < side_of[s]->count) {
-                first_from[s][slot] = tape_offset(side_of[s]->offsets, side_of[s]->wide, i),
-                first_to[s][slot] = tape_offset(side_of[s]->offsets, side_of[s]->wide, (u64)i + 1);
-                if (side_of[s]->lengths) first_length[s][slot] = side_of[s]->lengths[i], first_start[s][slot] = side_of[s]->starts[i];
-            }
+    for (u32 slot = 0; slot < plan_cached_k; ++slot) {
+        u32 const i = tid + slot * plan_threads_k;
+        if (i < side.count) {
+            first_from[slot] = tape_offset(side.offsets, side.wide, i), first_to[slot] = tape_offset(side.offsets, side.wide, (u64)i + 1);
+            if (side.lengths) first_length[slot] = side.lengths[i], first_start[slot] = side.starts[i];
         }
-    for (int s = 0; s < sides; ++s)
+    }
 #pragma unroll
-        for (u32 k = 0; k < plan_chunk_k; ++k) histogram[s][k * plan_threads_k + tid] = 0;
+    for (u32 k = 0; k < plan_chunk_k; ++k) histogram[k * plan_threads_k + tid] = 0;
     if (tid == 0) shared_cells = 0, shared_held = 0;
     __syncthreads();
     SZS_PLAN_STAMP(1);
     // a string of this thread: (from, to) of its span in the tape, its length in symbols and where its symbols live - from the
     // registers above for the first `plan_cached_k`, from memory beyond.  Codepoint engines: a string's length is its RUNE count
     // and its symbols live in the UTF-32 scratch tape (kernels.h).
-    auto beyond = [&](int s, u32 i, u64 &from, u64 &to, u64 &length, u64 &address) {
-        from = tape_offset(side_of[s]->offsets, side_of[s]->wide, i), to = tape_offset(side_of[s]->offsets, side_of[s]->wide, (u64)i + 1);
-        length = !side_of[s]->lengths ? to - from : (u64)side_of[s]->lengths[i];
-        address = !side_of[s]->lengths ? side_of[s]->base + from : side_of[s]->base + 4 * side_of[s]->starts[i];
+    auto beyond = [&](u32 i, u64 &from, u64 &to, u64 &length, u64 &address) {
+        from = tape_offset(side.offsets, side.wide, i), to = tape_offset(side.offsets, side.wide, (u64)i + 1);
+        length = !side.lengths ? to - from : (u64)side.lengths[i];
+        address = !side.lengths ? side.base + from : side.base + 4 * side.starts[i];
     };
-    auto cached = [&](int s, u32 slot, u64 &from, u64 &to, u64 &length, u64 &address) {
-        from = first_from[s][slot], to = first_to[s][slot];
-        length = !side_of[s]->lengths ? to - from : (u64)first_length[s][slot];
-        address = !side_of[s]->lengths ? side_of[s]->base + from : side_of[s]->base + 4 * first_start[s][slot];
+    auto cached = [&](u32 slot, u64 &from, u64 &to, u64 &length, u64 &address) {
+        from = first_from[slot], to = first_to[slot];
+        length = !side.lengths ? to - from : (u64)first_length[slot];
+        address = !side.lengths ? side.base + from : side.base + 4 * first_start[slot];
     };
-    // every string of this thread, the cached ones first: `visit(s, i, from, to, length, address)`
-    auto each_string = [&](int s, auto &&visit) {
+    // every string of this thread, the cached ones first: `visit(i, from, to, length, address)`
+    auto each_string = [&](auto &&visit) {
 #pragma unroll
         for (u32 slot = 0; slot < plan_cached_k; ++slot) {
             u32 const i = tid + slot * plan_threads_k;
-            if (i >= side_of[s]->count) break;
+            if (i >= side.count) break;
             u64 from, to, length, address;
-            cached(s, slot, from, to, length, address);
+            cached(slot, from, to, length, address);
             visit(i, from, to, length, address);
         }
-        for (u32 i = tid + plan_cached_k * plan_threads_k; i < side_of[s]->count; i += plan_threads_k) {
+        for (u32 i = tid + plan_cached_k * plan_threads_k; i < side.count; i += plan_threads_k) {
             u64 from, to, length, address;
-            beyond(s, i, from, to, length, address);
+            beyond(i, from, to, length, address);
             visit(i, from, to, length, address);
         }
     };
 
     // ---- phase 1: the histogram of the lengths; malformed or over-long strings only raise a flag (the host takes over)
     u32 status = 0;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) // (unrolled: the cached strings are registers only under constant indices)
-        if (s < sides) each_string(s, [&](u32, u64 from, u64 to, u64 length, u64) {
-            if (to < from) status |= SZS_PLAN_STATUS_DESCENDING;
-            else if (to - from > 0xFFFFFFFFull) status |= SZS_PLAN_STATUS_OVERFLOW;
-            else if (length >= plan_bins_k) status |= SZS_PLAN_STATUS_UNSORTED;
-            else atomicAdd(&histogram[s][(u32)length], 1u); // per-lane addresses: a plain ds_add
-        });
+    each_string([&](u32, u64 from, u64 to, u64 length, u64) {
+        if (to < from) status |= SZS_PLAN_STATUS_DESCENDING;
+        else if (to - from > 0xFFFFFFFFull) status |= SZS_PLAN_STATUS_OVERFLOW;
+        else if (length >= plan_bins_k) status |= SZS_PLAN_STATUS_UNSORTED;
+        else atomicAdd(&histogram[(u32)length], 1u); // per-lane addresses: a plain ds_add
+    });
 #pragma unroll
     for (int offset = 32; offset >= 1; offset >>= 1) status |= (u32)__shfl_xor((int)status, offset, 64);
     if (lane == 0) wave_status[wave] = status;
     __syncthreads();
     SZS_PLAN_STAMP(2);
 
-    // ---- phase 2: every statistic from the histogram.  Thread t owns bins [6 t, 6 t + 6) of both sides.
-    u32 chunk_counts[2] = {0, 0}, chunk_inclusive[2] = {0, 0};
-    for (int s = 0; s < sides; ++s) {
+    // ---- phase 2: every statistic from the histogram.  Thread t owns bins [6 t, 6 t + 6).
+    u32 chunk_counts = 0, chunk_inclusive = 0;
+    {
         u32 symbols = 0, bands_systolic = 0, bands_chain = 0, longest = 0;
 #pragma unroll
         for (u32 k = 0; k < plan_chunk_k; ++k) {
-            u32 const length = tid * plan_chunk_k + k, strings = histogram[s][length];
-            chunk_counts[s] += strings;
+            u32 const length = tid * plan_chunk_k + k, strings = histogram[length];
+            chunk_counts += strings;
             symbols += strings * length;
             bands_systolic += strings * (length ? (length + SZS_SYSTOLIC_BAND_ROWS - 1) / SZS_SYSTOLIC_BAND_ROWS : 1);
             bands_chain += strings * (length ? (length + SZS_MYERS_CHAIN_BAND_ROWS - 1) / SZS_MYERS_CHAIN_BAND_ROWS : 1);
             longest = strings ? length : longest;
         }
-        u32 inclusive = chunk_counts[s];
+        u32 inclusive = chunk_counts;
 #pragma unroll
         for (int offset = 1; offset < 64; offset <<= 1) {
             u32 const other = (u32)__shfl_up((int)inclusive, offset, 64);
             if (lane >= (u32)offset) inclusive += other;
         }
-        chunk_inclusive[s] = inclusive;
+        chunk_inclusive = inclusive;
 #pragma unroll
         for (int offset = 32; offset >= 1; offset >>= 1) {
             symbols += (u32)__shfl_xor((int)symbols, offset, 64);
@@ -181,24 +174,23 @@ __global__ __launch_bounds__(plan_threads_k) void plan_kernel(szs_plan_side_t qu
             u32 const other = (u32)__shfl_xor((int)longest, offset, 64);
             longest = other > longest ? other : longest;
         }
-        if (lane == 63) wave_counts[s][wave] = inclusive;
+        if (lane == 63) wave_counts[wave] = inclusive;
         if (lane == 0)
-            wave_symbols[s][wave] = symbols, wave_bands_systolic[s][wave] = bands_systolic, wave_bands_chain[s][wave] = bands_chain,
-            wave_longest[s][wave] = longest;
+            wave_symbols[wave] = symbols, wave_bands_systolic[wave] = bands_systolic, wave_bands_chain[wave] = bands_chain,
+            wave_longest[wave] = longest;
     }
     __syncthreads();
-    if (tid < (u32)sides) { // one thread per side folds the sixteen wavefronts
-        int const s = (int)tid;
+    if (tid == 0) { // one thread folds the sixteen wavefronts
         u32 running = 0, symbols = 0, bands_systolic = 0, bands_chain = 0, longest = 0;
         for (int w = 0; w < plan_waves_k; ++w) {
-            side_count_before_wave[s][w] = running, running += wave_counts[s][w];
-            symbols += wave_symbols[s][w], bands_systolic += wave_bands_systolic[s][w], bands_chain += wave_bands_chain[s][w];
-            longest = wave_longest[s][w] > longest ? wave_longest[s][w] : longest;
+            count_before_wave[w] = running, running += wave_counts[w];
+            symbols += wave_symbols[w], bands_systolic += wave_bands_systolic[w], bands_chain += wave_bands_chain[w];
+            longest = wave_longest[w] > longest ? wave_longest[w] : longest;
         }
-        side_strings[s] = running, side_symbols[s] = symbols, side_bands_systolic[s] = bands_systolic, side_bands_chain[s] = bands_chain;
-        side_longest[s] = longest;
+        side_strings = running, side_symbols = symbols, side_bands_systolic = bands_systolic, side_bands_chain = bands_chain;
+        side_longest = longest;
     }
-    if (tid == 2) {
+    if (tid == 64) {
         u32 all = 0;
         for (int w = 0; w < plan_waves_k; ++w) all |= wave_status[w];
         shared_status = all;
@@ -207,43 +199,41 @@ __global__ __launch_bounds__(plan_threads_k) void plan_kernel(szs_plan_side_t qu
 
     SZS_PLAN_STAMP(3);
     // ---- phase 3: bins become positions (exclusive prefix); strings per launch variant are differences of positions
-    for (int s = 0; s < sides; ++s) {
-        u32 running = side_count_before_wave[s][wave] + chunk_inclusive[s] - chunk_counts[s];
+    {
+        u32 running = count_before_wave[wave] + chunk_inclusive - chunk_counts;
 #pragma unroll
         for (u32 k = 0; k < plan_chunk_k; ++k) {
-            u32 const length = tid * plan_chunk_k + k, strings = histogram[s][length];
-            histogram[s][length] = running, running += strings;
+            u32 const length = tid * plan_chunk_k + k, strings = histogram[length];
+            histogram[length] = running, running += strings;
         }
     }
     __syncthreads();
-    if (tid < (u32)(sides * SZS_PLAN_VARIANTS)) {
-        int const s = tid / SZS_PLAN_VARIANTS;
-        u32 const slot = tid % SZS_PLAN_VARIANTS, total = side_strings[s];
-        auto strings_shorter_than = [&](u32 length) -> u32 { return length < plan_bins_k ? histogram[s][length] : total; };
+    if (tid < SZS_PLAN_VARIANTS) {
+        u32 const slot = tid, total = side_strings;
+        auto strings_shorter_than = [&](u32 length) -> u32 { return length < plan_bins_k ? histogram[length] : total; };
         u32 strings;
         if (!myers_words) strings = slot == 0 ? total : 0; // weighted engines: one launch group
         else if (slot == 0) strings = total - strings_shorter_than(variant_longest(SZS_PLAN_VARIANTS - 1) + 1);
         else strings = strings_shorter_than(variant_longest(slot) + 1) - (slot == 1 ? 0 : strings_shorter_than(variant_longest(slot - 1) + 1));
-        variants[s][slot] = strings;
+        variants[slot] = strings;
     }
-    // ---- the length at 33 ranks of each side (the queue order of hip/myers_queue.hip is planned from them, host/plan.c): strings
+    // ---- the length at 33 ranks of the side (the queue order of hip/myers_queue.hip is planned from them, host/plan.c): strings
     //      of length l hold the ascending ranks [positions[l], positions[l + 1]), so the string at rank r is as long as the LARGEST
     //      l whose position is <= r - a binary search of the positions by one thread per sample, beside the threads above
-    if (tid >= 64 && tid < 64 + (u32)sides * (SZS_PLAN_RANK_SAMPLES + 1)) {
-        int const s = (int)((tid - 64) / (SZS_PLAN_RANK_SAMPLES + 1));
-        u32 const k = (tid - 64) % (SZS_PLAN_RANK_SAMPLES + 1), total = side_strings[s];
+    if (tid >= 64 && tid < 64 + (SZS_PLAN_RANK_SAMPLES + 1)) {
+        u32 const k = tid - 64, total = side_strings;
         u32 length = 0;
         if (total) {
             u32 const rank = (u32)((u64)k * (total - 1) / SZS_PLAN_RANK_SAMPLES);
             u32 low = 0, high = plan_bins_k - 1;
             while (low < high) {
                 u32 const middle = (low + high + 1) / 2;
-                if (histogram[s][middle] <= rank) low = middle;
+                if (histogram[middle] <= rank) low = middle;
                 else high = middle - 1;
             }
             length = low;
         }
-        rank_lengths[s][k] = length;
+        rank_lengths[k] = length;
     }
     __syncthreads();
 
@@ -255,10 +245,10 @@ __global__ __launch_bounds__(plan_threads_k) void plan_kernel(szs_plan_side_t qu
         u32 const chunk = (queries.count + plan_threads_k - 1) / plan_threads_k;
         u32 const first = tid * chunk < queries.count ? tid * chunk : queries.count;
         u32 const last = first + chunk < queries.count ? first + chunk : queries.count;
-        u64 mine = 0;
+        u64 own = 0;
         for (u32 i = first; i < last; ++i)
-            mine += symbols_of_query(i);
-        chunk_sums[tid] = mine; // prefix of the chunk sums: 64-bit; a serial pass by one thread is 1024 additions
+            own += symbols_of_query(i);
+        chunk_sums[tid] = own; // prefix of the chunk sums: 64-bit; a serial pass by one thread is 1024 additions
         __syncthreads();
         if (tid == 0) {
             unsigned long long running = 0;
@@ -287,18 +277,20 @@ __global__ __launch_bounds__(plan_threads_k) void plan_kernel(szs_plan_side_t qu
     }
 
     SZS_PLAN_STAMP(4);
-    // ---- does this batch have the shape the host already enqueued launches for?
+    // ---- does this SIDE of the batch have the shape the host already enqueued launches for?  (the whole batch does when both do)
     if (tid == 0) {
         u32 held = expected.enabled && !shared_status;
         if (held) {
             int const query_side = symmetric ? 0 : (int)expected.query_side;
-            for (u32 v = 0; v < SZS_PLAN_VARIANTS; ++v) held &= variants[query_side][v] == expected.variant_counts[v];
-            held &= side_longest[0] <= expected.longest[0];
-            held &= side_longest[symmetric ? 0 : 1] <= expected.longest[1];
+            if (mine == query_side)
+                for (u32 v = 0; v < SZS_PLAN_VARIANTS; ++v) held &= variants[v] == expected.variant_counts[v];
+            held &= side_longest <= expected.longest[mine];
+            if (symmetric) held &= side_longest <= expected.longest[1];
         }
         // codepoints: every string was transcoded (none skipped for want of room) and the arrays hold what the launches index with
-        if (held && expected.runes_needed) held &= *expected.runes_needed <= expected.runes_capacity;
-        if (held && expected.alphabet)
+        // (facts about the whole batch: the queries' workgroup checks them)
+        if (held && mine == 0 && expected.runes_needed) held &= *expected.runes_needed <= expected.runes_capacity;
+        if (held && mine == 0 && expected.alphabet)
             held &= expected.alphabet_flags[0] != 0 && expected.alphabet_flags[2] == 0 && expected.alphabet_flags[1] <= expected.alphabet;
         shared_held = held;
     }
@@ -309,59 +301,71 @@ __global__ __launch_bounds__(plan_threads_k) void plan_kernel(szs_plan_side_t qu
     // ---- phase 4: scatter into the ascending and the descending ref arrays
     if (shared_status) { // nothing was sorted; launches that are already in flight must still find only empty strings
         if (expected.enabled)
-            for (int s = 0; s < sides; ++s)
-                for (u32 i = tid; i < side_of[s]->count; i += plan_threads_k) {
-                    szs_string_ref_t ref;
-                    ref.address = side_of[s]->base, ref.length = 0, ref.index = i;
-                    side_of[s]->ascending[i] = ref, side_of[s]->descending[i] = ref;
-                }
-    }
-    else
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-            if (s < sides) {
-                // (round 4) A ref lands at the position its length sorts it to - sixteen bytes at a random place, twice: 64
-                // write transactions per store instruction, all through ONE compute unit (17.9 of the planner's 44 us on config
-                // 5's 6,326 strings, 4 of 13 on config 2's 2,048).  A side of up to `plan_staged_k` strings is sorted into LDS
-                // instead and leaves it in order: position p and count - 1 - p, whole lines per wavefront.
-                u32 const count = side_of[s]->count;
-                bool const through_lds = count <= plan_staged_k;
-                each_string(s, [&](u32 i, u64, u64, u64 symbols, u64 address) {
-                    u32 const length = (u32)symbols;
-                    u32 const position = atomicAdd(&histogram[s][length], 1u); // equal lengths: any order scores the same matrix
-                    szs_string_ref_t ref;
-                    ref.address = address, ref.length = blank ? 0u : length, ref.index = i;
-                    if (through_lds) staged[position] = ref;
-                    else side_of[s]->ascending[position] = ref, side_of[s]->descending[count - 1 - position] = ref;
-                });
-                if (through_lds) {
-                    __syncthreads();
-                    for (u32 position = tid; position < count; position += plan_threads_k) {
-                        szs_string_ref_t const ref = staged[position];
-                        side_of[s]->ascending[position] = ref, side_of[s]->descending[count - 1 - position] = ref;
-                    }
-                    __syncthreads(); // the other side sorts into the same LDS
-                }
+            for (u32 i = tid; i < side.count; i += plan_threads_k) {
+                szs_string_ref_t ref;
+                ref.address = side.base, ref.length = 0, ref.index = i;
+                side.ascending[i] = ref, side.descending[i] = ref;
             }
+    }
+    else {
+        // A ref lands at the position its length sorts it to - sixteen bytes at a random place, twice: 64 write transactions
+        // per store instruction, all through ONE compute unit.  A side of up to `plan_staged_k` strings is sorted into LDS
+        // instead and leaves it in order: position p and count - 1 - p, whole lines per wavefront.
+        u32 const count = side.count;
+        bool const through_lds = count <= plan_staged_k;
+        each_string([&](u32 i, u64, u64, u64 symbols, u64 address) {
+            u32 const length = (u32)symbols;
+            u32 const position = atomicAdd(&histogram[length], 1u); // equal lengths: any order scores the same matrix
+            szs_string_ref_t ref;
+            ref.address = address, ref.length = blank ? 0u : length, ref.index = i;
+            if (through_lds) staged[position] = ref;
+            else side.ascending[position] = ref, side.descending[count - 1 - position] = ref;
+        });
+        if (through_lds) {
+            __syncthreads();
+            for (u32 position = tid; position < count; position += plan_threads_k) {
+                szs_string_ref_t const ref = staged[position];
+                side.ascending[position] = ref, side.descending[count - 1 - position] = ref;
+            }
+        }
+    }
 
     SZS_PLAN_STAMP(6);
-    if (tid == 0) { // one struct, written once: the host reads it after the stream has drained
-        szs_plan_summary_t report;
-        report.status = shared_status;
-        report.speculation_held = shared_held;
-        for (int s = 0; s < 2; ++s) {
-            int const from = symmetric ? 0 : s;
-            report.side[s].count = from ? candidates.count : queries.count;
-            report.side[s].longest = side_longest[from];
-            report.side[s].symbols = side_symbols[from];
-            report.side[s].bands_systolic = side_bands_systolic[from];
-            report.side[s].bands_chain = side_bands_chain[from];
-            for (u32 v = 0; v < SZS_PLAN_VARIANTS; ++v) report.variant_counts[s][v] = variants[from][v];
-            for (u32 k = 0; k <= SZS_PLAN_RANK_SAMPLES; ++k) report.rank_lengths[s][k] = rank_lengths[from][k];
+    // ---- the summary (pinned host memory; the host reads it after the stream has drained): this side's part by this workgroup,
+    //      the verdict on the whole batch by whichever workgroup finishes second
+    if (tid <= SZS_PLAN_RANK_SAMPLES) {
+        summary->rank_lengths[mine][tid] = rank_lengths[tid];
+        if (symmetric) summary->rank_lengths[1][tid] = rank_lengths[tid];
+    }
+    if (tid < SZS_PLAN_VARIANTS) {
+        summary->variant_counts[mine][tid] = variants[tid];
+        if (symmetric) summary->variant_counts[1][tid] = variants[tid];
+    }
+    if (tid == 0) {
+        szs_side_stats_t stats;
+        stats.count = side.count, stats.longest = side_longest, stats.symbols = side_symbols;
+        stats.bands_systolic = side_bands_systolic, stats.bands_chain = side_bands_chain;
+        summary->side[mine] = stats;
+        if (symmetric) summary->side[1] = stats;
+        u32 all_status = shared_status, all_held = shared_held;
+        bool last = true;
+        if (!symmetric) { // two workgroups: leave this one's verdict in device memory; the second to arrive folds both
+            verdicts[2 + 2 * mine] = shared_status, verdicts[3 + 2 * mine] = shared_held;
+            __threadfence();
+            last = (atomicAdd(&verdicts[0], 1u) & 1u) != 0; // (counted up for ever: the parity tells the second from the first)
+            if (last) {
+                __threadfence();
+                u32 const other_status = __hip_atomic_load(&verdicts[2 + 2 * (1 - mine)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                u32 const other_held = __hip_atomic_load(&verdicts[3 + 2 * (1 - mine)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                all_status |= other_status, all_held &= other_held;
+            }
         }
-        report.symmetric_cells = shared_cells;
-        report.sequence = expected.sequence; // the host can tell a fresh summary from a stale one
-        *summary = report;
+        if (last) {
+            summary->status = all_status, summary->speculation_held = all_held;
+            summary->symmetric_cells = shared_cells;
+            __threadfence_system();
+            summary->sequence = expected.sequence; // the host can tell a fresh summary from a stale one
+        }
     }
     SZS_PLAN_STAMP(7);
 #undef SZS_PLAN_STAMP
@@ -370,10 +374,11 @@ __global__ __launch_bounds__(plan_threads_k) void plan_kernel(szs_plan_side_t qu
 } // namespace szs_hip
 
 extern "C" int szs_hip_plan(szs_plan_side_t const *queries, szs_plan_side_t const *candidates, unsigned myers_words,
-                            szs_plan_expectation_t const *expected, szs_plan_summary_t *summary, void *stream) {
+                            szs_plan_expectation_t const *expected, szs_plan_summary_t *summary, uint32_t *verdicts, void *stream) {
     using namespace szs_hip;
     szs_plan_expectation_t none = {};
-    // 64 KB of dynamic LDS beside the 58 KB of histograms: asked for once per device
+    if (candidates && !verdicts) return (int)hipErrorInvalidValue;
+    // 64 KB of dynamic LDS beside the 29 KB of histogram: asked for once per device
     static int allowed_on[device_slots_k];
     int *const slot = &allowed_on[device_slot()];
     if (!cached(slot)) {
@@ -382,8 +387,7 @@ extern "C" int szs_hip_plan(szs_plan_side_t const *queries, szs_plan_side_t cons
             return (int)hipGetLastError();
         remember(slot, 1);
     }
-    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(plan_threads_k), plan_staged_k * sizeof(szs_string_ref_t), static_cast<hipStream_t>(stream), *queries,
-                       candidates ? *candidates : *queries, candidates ? 0 : 1, (u32)myers_words, expected ? *expected : none,
-                       summary);
+    hipLaunchKernelGGL(plan_kernel, dim3(candidates ? 2 : 1), dim3(plan_threads_k), plan_staged_k * sizeof(szs_string_ref_t), static_cast<hipStream_t>(stream),
+                       *queries, candidates ? *candidates : *queries, candidates ? 0 : 1, (u32)myers_words, expected ? *expected : none, summary, verdicts);
     return (int)hipGetLastError();
 }

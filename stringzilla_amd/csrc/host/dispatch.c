@@ -1030,6 +1030,20 @@ static int device_plannable(szs_engine_s const *engine, szs_input_t const *input
     return szs_classify_pointer(input->offsets).device_accessible && szs_classify_pointer(input->data).device_accessible;
 }
 
+/** 256 bytes of device memory per engine, zeroed when allocated and never again: the two `ready` words of the launch that plans
+ *  itself (dwords 0 and 32; kernels.h: szs_fused_plan_t) and the verdict words of the two-workgroup planner (dwords 48 ... 55). */
+static sz_status_t reserve_device_words(szs_engine_s *engine, int device, hipStream_t stream, char const **error_message) {
+    sz_status_t const status = szs_buffer_reserve(&engine->device_fused, szs_memory_device_k, device, 256, error_message);
+    if (status != sz_success_k) return status;
+    if (engine->fused_zeroed != engine->device_fused.pointer) {
+        hipError_t const error = hipMemsetAsync(engine->device_fused.pointer, 0, 256, stream);
+        if (error != hipSuccess) return szs_report_hip(error, error_message);
+        engine->fused_zeroed = engine->device_fused.pointer;
+    }
+    return sz_success_k;
+}
+#define SZS_PLAN_VERDICTS(ENGINE) ((uint32_t *)(ENGINE)->device_fused.pointer + 48)
+
 /* ---- the tiny-token regime (hip/myers_tiny.hip; reference: cuda.cuh:2864, :4297-4340) ------------------------------------- */
 
 #define SZS_TINY_NOT_TAKEN ((sz_status_t)3) /* internal: score the call the ordinary way */
@@ -1210,6 +1224,8 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
     szs_decision_t *const remembered = engine->remembered;
     status = place_results(call);
     if (status != sz_success_k) return status;
+    status = reserve_device_words(engine, device, stream, error_message);
+    if (status != sz_success_k) return status;
     phase(call, 0);
 
     /* ---- tiny tokens (hip/myers_tiny.hip): the previous call of these counts was scored straight from the tapes - so is this one,
@@ -1311,13 +1327,6 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
         remembered->q_count == q_count && remembered->c_count == c_count && remembered->symmetric == symmetric && q_count <= SZS_FUSED_MOST_STRINGS &&
         c_count <= SZS_FUSED_MOST_STRINGS && knobs_automatic && !uniform_bytes && szs_tuning_get(szs_knob_fused_k) != 0) {
         szs_decision_t const *d = remembered;
-        status = szs_buffer_reserve(&engine->device_fused, szs_memory_device_k, device, 256, error_message);
-        if (status != sz_success_k) return status;
-        if (engine->fused_zeroed != engine->device_fused.pointer) {
-            error = hipMemsetAsync(engine->device_fused.pointer, 0, 256, stream);
-            if (error != hipSuccess) return szs_report_hip(error, error_message);
-            engine->fused_zeroed = engine->device_fused.pointer;
-        }
         szs_fused_side_report_t volatile *const reports = (szs_fused_side_report_t volatile *)((char *)engine->pinned_summary.pointer + 1024);
         szs_fused_plan_t fused;
         memset(&fused, 0, sizeof(fused));
@@ -1394,7 +1403,7 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
         phase(call, 2);
         uint32_t launches = 0, cell_bits = 0;
         remembered->refs_current = 0; /* the planner is about to overwrite the refs */
-        error = (hipError_t)szs_hip_plan(&q_side, symmetric ? NULL : &c_side, myers_words, &expected, (szs_plan_summary_t *)summary, stream);
+        error = (hipError_t)szs_hip_plan(&q_side, symmetric ? NULL : &c_side, myers_words, &expected, (szs_plan_summary_t *)summary, SZS_PLAN_VERDICTS(engine), stream);
         if (error != hipSuccess) return szs_report_hip(error, error_message); /* nothing enqueued yet */
         error = hipEventRecord(engine->event_start, stream);
         szs_string_ref_t const *const query_refs = d->transposed ? c_side.descending : q_side.descending;
@@ -1436,7 +1445,7 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
         szs_plan_expectation_t none;
         memset(&none, 0, sizeof(none));
         none.sequence = ++engine->plan_sequence;
-        error = (hipError_t)szs_hip_plan(&q_side, symmetric ? NULL : &c_side, myers_words, &none, (szs_plan_summary_t *)summary, stream);
+        error = (hipError_t)szs_hip_plan(&q_side, symmetric ? NULL : &c_side, myers_words, &none, (szs_plan_summary_t *)summary, SZS_PLAN_VERDICTS(engine), stream);
         hipError_t const drained = hipStreamSynchronize(stream);
         if (error == hipSuccess) error = drained;
         if (error != hipSuccess) return szs_report_hip(error, error_message);
@@ -1474,7 +1483,7 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
             szs_plan_expectation_t none;
             memset(&none, 0, sizeof(none));
             none.sequence = ++engine->plan_sequence;
-            error = (hipError_t)szs_hip_plan(&q_side, symmetric ? NULL : &c_side, myers_words, &none, (szs_plan_summary_t *)summary, stream);
+            error = (hipError_t)szs_hip_plan(&q_side, symmetric ? NULL : &c_side, myers_words, &none, (szs_plan_summary_t *)summary, SZS_PLAN_VERDICTS(engine), stream);
             if (error != hipSuccess) return szs_report_hip(error, error_message);
             have_summary = 0;
         }
@@ -1576,6 +1585,7 @@ static sz_status_t cross_device_planned_runes(szs_call_t *call) {
     if (status == sz_success_k && renumber)
         status = szs_buffer_reserve(&engine->device_alphabet, szs_memory_device_k, device, szs_hip_alphabet_workspace_bytes(), error_message);
     if (status == sz_success_k) status = place_results(call);
+    if (status == sz_success_k) status = reserve_device_words(engine, device, stream, error_message);
     if (status == sz_success_k && !engine->remembered) {
         engine->remembered = (szs_decision_t *)calloc(1, sizeof(szs_decision_t));
         if (!engine->remembered) status = szs_report(sz_bad_alloc_k, error_message, NULL);
@@ -1637,7 +1647,7 @@ static sz_status_t cross_device_planned_runes(szs_call_t *call) {
         phase(call, 2);
         hipError_t error = enqueue_transcoding(call, remote, flags_at, needed_at, staging_bytes, starts, counts, renumber);
         if (error == hipSuccess)
-            error = (hipError_t)szs_hip_plan(&q_side, symmetric ? NULL : &c_side, myers_words, &expected, (szs_plan_summary_t *)summary, stream);
+            error = (hipError_t)szs_hip_plan(&q_side, symmetric ? NULL : &c_side, myers_words, &expected, (szs_plan_summary_t *)summary, SZS_PLAN_VERDICTS(engine), stream);
         if (error == hipSuccess) error = hipMemcpyAsync((void *)flags, remote + flags_at, staging_bytes - flags_at, hipMemcpyDeviceToHost, stream);
         if (error != hipSuccess) {
             (void)hipStreamSynchronize(stream);
@@ -1681,7 +1691,7 @@ static sz_status_t cross_device_planned_runes(szs_call_t *call) {
         memset(&none, 0, sizeof(none));
         none.sequence = ++engine->plan_sequence;
         if (error == hipSuccess)
-            error = (hipError_t)szs_hip_plan(&q_side, symmetric ? NULL : &c_side, myers_words, &none, (szs_plan_summary_t *)summary, stream);
+            error = (hipError_t)szs_hip_plan(&q_side, symmetric ? NULL : &c_side, myers_words, &none, (szs_plan_summary_t *)summary, SZS_PLAN_VERDICTS(engine), stream);
         if (error == hipSuccess) error = hipMemcpyAsync((void *)flags, remote + flags_at, staging_bytes - flags_at, hipMemcpyDeviceToHost, stream);
         hipError_t const drained = hipStreamSynchronize(stream); /* THE wait of the planning half; also on failure */
         if (error == hipSuccess) error = drained;
