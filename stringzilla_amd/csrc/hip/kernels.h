@@ -216,6 +216,15 @@ int szs_hip_levenshtein_tiny_prepare(szs_tape_t const *queries, szs_tape_t const
 int szs_hip_levenshtein_tiny(szs_tape_t const *queries, szs_tape_t const *candidates, uint64_t *results, uint64_t results_row_stride,
                              uint64_t *trace /* NULL, or 8 qwords per workgroup of device memory: 100 MHz ticks at its phases (`trace` knob) */, void *stream);
 /**
+ *  ONE launch for the whole call (round 5's second design): the kernel of szs_hip_levenshtein_tiny with the strings of 17 ... 255
+ *  bytes scored by the same workgroups - a block's long candidates under the groups' own masks, a span's long queries as W-word
+ *  patterns over the block - so that no list, no table in device memory and no second kernel is needed.  Malformed offsets or a
+ *  string beyond 255 bytes leave `*unfit = unfit_sequence` (pinned host memory): the caller then scores the call the ordinary way.
+ */
+int szs_hip_levenshtein_tiny_whole(szs_tape_t const *queries, szs_tape_t const *candidates, uint64_t *results, uint64_t results_row_stride,
+                                   uint32_t *unfit, uint32_t unfit_sequence, unsigned long long *symbols_out,
+                                   uint64_t *trace /* NULL, or 10 qwords per workgroup of device memory (`trace` knob) */, void *stream);
+/**
  *  The strings szs_hip_levenshtein_tiny listed (hip/lev_myers.hip): a workgroup scores ONE listed string - the pattern, up to 256
  *  bytes - against a block of 256 strings of the other side's tape, whatever their lengths, with the bodies of the short
  *  bit-parallel kernel.  A listed query fills its row, a listed candidate its column.  The grid covers the list's capacity;

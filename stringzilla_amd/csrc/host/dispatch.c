@@ -1075,6 +1075,27 @@ static sz_status_t cross_tiny(szs_call_t *call, uint32_t planner_mode, szs_plan_
     uint32_t const sequence = engine->plan_sequence;
     *unfit = 0, symbols[0] = symbols[1] = 0;
     phase(call, 2);
+    szs_tape_t const q_tape = {call->queries->offsets, (uint64_t)(uintptr_t)call->queries->data, call->q_count, call->queries->kind == szs_input_u64tape_k};
+    szs_tape_t const c_tape = {call->candidates->offsets, (uint64_t)(uintptr_t)call->candidates->data, call->c_count,
+                               call->candidates->kind == szs_input_u64tape_k};
+    int const four_launches = szs_tuning_get(szs_knob_tiny_k) == 2; /* round 5's first design, kept to be measured against */
+    uint32_t launches = 0;
+    uint64_t *trace = NULL; /* `trace` knob: the phases of every workgroup of the tiny-token kernel, then of every wavefront of the outliers' (printed after the wait) */
+    size_t const trace_workgroups = 8192, trace_waves = 65536, trace_slots = 10;
+    hipError_t error = hipEventRecord(engine->event_start, stream);
+    if (call->trace && szs_buffer_reserve(&engine->device_queue_trace, szs_memory_device_k, call->device, trace_workgroups * trace_slots * 8 + trace_waves * 32, NULL) == sz_success_k) {
+        trace = (uint64_t *)engine->device_queue_trace.pointer;
+        if (hipMemsetAsync(trace, 0, trace_workgroups * trace_slots * 8 + trace_waves * 32, stream) != hipSuccess) trace = NULL;
+    }
+    if (!four_launches) {
+        /* ONE launch: the tiny tokens and, in their shadow, the few longer ones (hip/myers_tiny.hip: levenshtein_tiny_whole_kernel) */
+        if (error == hipSuccess) {
+            error = (hipError_t)szs_hip_levenshtein_tiny_whole(&q_tape, &c_tape, (uint64_t *)call->device_results, call->device_stride, (uint32_t *)unfit, sequence,
+                                                               (unsigned long long *)symbols, trace, stream);
+            launches += error == hipSuccess;
+        }
+    }
+    else {
     /* [the two counts | both tapes' mask tables] are cleared by ONE fill; the lists' refs lie behind them */
     size_t const q_table = (size_t)SZS_TINY_TABLE_BYTES(call->q_count), c_table = (size_t)SZS_TINY_TABLE_BYTES(call->c_count);
     sz_status_t reserved = szs_buffer_reserve(&engine->device_outliers, szs_memory_device_k, call->device, 256 + q_table + c_table + sizeof(szs_tiny_outliers_t),
@@ -1083,39 +1104,19 @@ static sz_status_t cross_tiny(szs_call_t *call, uint32_t planner_mode, szs_plan_
     char *const cleared = (char *)engine->device_outliers.pointer;
     uint32_t *const q_masks = (uint32_t *)(cleared + 256), *const c_masks = (uint32_t *)(cleared + 256 + q_table);
     szs_tiny_outliers_t *const outliers = (szs_tiny_outliers_t *)(cleared + 256 + q_table + c_table);
-    /* (the counts are the first 16 bytes of the struct, right behind the tables: the one fill covers them) */
-    szs_tape_t const q_tape = {call->queries->offsets, (uint64_t)(uintptr_t)call->queries->data, call->q_count, call->queries->kind == szs_input_u64tape_k};
-    szs_tape_t const c_tape = {call->candidates->offsets, (uint64_t)(uintptr_t)call->candidates->data, call->c_count,
-                               call->candidates->kind == szs_input_u64tape_k};
-    /* One stream, five small steps: the two counts cleared; strings of more than 16 bytes listed and the tiny ones' masks tabled (a
-     * pass over the tapes); the outliers' rows and columns; the tables set back to zeros; the tiny tokens.  (Measured and not kept:
-     * the outliers' kernel on a second stream beside the tiny-token kernel - 119 us against 111 one after the other on 4096 x 4096
-     * words of text: the two do not overlap, each fills the device's wavefront slots on its own.) */
-    hipError_t error = hipEventRecord(engine->event_start, stream);
-    /* The tables hold zeros between calls (every call sets back what it set: the `unbuild` pass below); they are filled once, when
-     * the buffer is new - and the counts live in the first 16 bytes behind them. */
     if (error == hipSuccess && engine->outliers_zeroed != engine->device_outliers.pointer) {
         error = hipMemsetAsync(cleared, 0, engine->device_outliers.capacity, stream);
         engine->outliers_zeroed = error == hipSuccess ? engine->device_outliers.pointer : NULL;
     }
     if (error == hipSuccess) error = hipMemsetAsync(outliers, 0, 16, stream); /* the two counts */
-    uint32_t launches = 0;
-    uint64_t *trace = NULL; /* `trace` knob: the phases of every workgroup of the tiny-token kernel, then of every wavefront of the outliers' (printed after the wait) */
-    size_t const trace_workgroups = 8192, trace_waves = 65536;
-    if (call->trace && szs_buffer_reserve(&engine->device_queue_trace, szs_memory_device_k, call->device, trace_workgroups * 64 + trace_waves * 32, NULL) == sz_success_k) {
-        trace = (uint64_t *)engine->device_queue_trace.pointer;
-        if (hipMemsetAsync(trace, 0, trace_workgroups * 64 + trace_waves * 32, stream) != hipSuccess) trace = NULL;
-    }
     if (error == hipSuccess) {
         error = (hipError_t)szs_hip_levenshtein_tiny_prepare(&q_tape, &c_tape, (uint32_t *)unfit, sequence, outliers, q_masks, c_masks, (unsigned long long *)symbols, 0, stream);
         launches += error == hipSuccess;
         if (error == hipSuccess) { /* tokens of more than 16 bytes: their rows and columns (hip/lev_myers.hip) */
             error = (hipError_t)szs_hip_levenshtein_outliers(outliers, &q_tape, &c_tape, q_masks, c_masks, (uint64_t *)call->device_results, call->device_stride,
-                                                             trace ? trace + trace_workgroups * 8 : NULL, stream);
+                                                             trace ? trace + trace_workgroups * trace_slots : NULL, stream);
             launches += error == hipSuccess;
         }
-        /* ... and the tables set back to zeros behind it (the same pass over the tapes, stores instead of atomics) - also when the
-         * launch before it failed: whatever the first pass set must go */
         hipError_t const unbuilt = (hipError_t)szs_hip_levenshtein_tiny_prepare(&q_tape, &c_tape, (uint32_t *)unfit, sequence, outliers, q_masks, c_masks, NULL, 1, stream);
         if (unbuilt != hipSuccess) engine->outliers_zeroed = NULL; /* fill them before the next call */
         launches += unbuilt == hipSuccess;
@@ -1123,6 +1124,7 @@ static sz_status_t cross_tiny(szs_call_t *call, uint32_t planner_mode, szs_plan_
     if (error == hipSuccess) {
         error = (hipError_t)szs_hip_levenshtein_tiny(&q_tape, &c_tape, (uint64_t *)call->device_results, call->device_stride, trace, stream);
         launches += error == hipSuccess;
+    }
     }
     engine->last_streams = 1;
     szs_decision_t *const shape = (szs_decision_t *)calloc(1, sizeof(szs_decision_t)); /* what finish() reads: lanes tier, one launch */
@@ -1135,25 +1137,49 @@ static sz_status_t cross_tiny(szs_call_t *call, uint32_t planner_mode, szs_plan_
     free(shape);
     if (status != sz_success_k) return status;
     if (trace) { /* where a workgroup of the tiny-token kernel spends its time: mean ticks (10 ns) between its stamps */
-        uint64_t *const ticks = (uint64_t *)malloc(trace_workgroups * 64);
-        if (ticks && hipMemcpy(ticks, trace, trace_workgroups * 64, hipMemcpyDeviceToHost) == hipSuccess) {
-            double sums[8] = {0};
+        size_t const slots = four_launches ? 8 : trace_slots, last_slot = four_launches ? 7 : 8;
+        uint64_t *const ticks = (uint64_t *)malloc(trace_workgroups * slots * 8);
+        if (ticks && hipMemcpy(ticks, trace, trace_workgroups * slots * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            double sums[10] = {0};
             uint64_t first = ~0ull, last = 0;
             size_t seen = 0;
             for (size_t w = 0; w < trace_workgroups; ++w) {
-                if (!ticks[8 * w] || !ticks[8 * w + 7]) continue;
+                if (!ticks[slots * w] || !ticks[slots * w + last_slot]) continue;
                 ++seen;
-                first = ticks[8 * w] < first ? ticks[8 * w] : first, last = ticks[8 * w + 7] > last ? ticks[8 * w + 7] : last;
-                for (int k = 1; k < 8; ++k) sums[k] += (double)(ticks[8 * w + k] - ticks[8 * w + k - 1]);
+                first = ticks[slots * w] < first ? ticks[slots * w] : first, last = ticks[slots * w + last_slot] > last ? ticks[slots * w + last_slot] : last;
+                for (size_t k = 1; k < slots; ++k)
+                    if (ticks[slots * w + k] && ticks[slots * w + k - 1]) sums[k] += (double)(ticks[slots * w + k] - ticks[slots * w + k - 1]);
+            }
+            if (getenv("SZS_TRACE_DUMP")) { /* every workgroup's stamps, relative to the first begin, in 10 ns ticks */
+                FILE *const dump = fopen(getenv("SZS_TRACE_DUMP"), "w");
+                for (size_t w = 0; dump && w < trace_workgroups; ++w) {
+                    if (!ticks[slots * w] || !ticks[slots * w + last_slot]) continue;
+                    fprintf(dump, "%zu", w);
+                    for (size_t k = 0; k <= last_slot; ++k) fprintf(dump, " %lld", ticks[slots * w + k] ? (long long)(ticks[slots * w + k] - first) : -1ll);
+                    fprintf(dump, "\n");
+                }
+                if (dump) fclose(dump);
+            }
+            uint64_t last_begin = 0, longest_life = 0, first_end = ~0ull;
+            double lives = 0;
+            for (size_t w = 0; w < trace_workgroups; ++w) {
+                if (!ticks[slots * w] || !ticks[slots * w + last_slot]) continue;
+                uint64_t const life = ticks[slots * w + last_slot] - ticks[slots * w];
+                last_begin = ticks[slots * w] > last_begin ? ticks[slots * w] : last_begin, longest_life = life > longest_life ? life : longest_life, lives += (double)life;
+                first_end = ticks[slots * w + last_slot] < first_end ? ticks[slots * w + last_slot] : first_end;
             }
             if (seen)
+                fprintf(stderr, "tiny kernel: last begin at %.1f us, first end at %.1f us; a workgroup lives %.1f us on average, %.1f at most\n", (last_begin - first) * 1e-2,
+                        (first_end - first) * 1e-2, lives / seen * 1e-2, longest_life * 1e-2);
+            if (seen)
                 fprintf(stderr, "tiny kernel: %zu workgroups over %.1f us; mean us per workgroup: offsets + local sort %.2f, texts %.2f, first masks %.2f, columns %.2f, "
-                                "barrier %.2f, un-build + stores %.2f, rest (further groups) %.2f\n", seen, (last - first) * 1e-2, sums[1] / seen * 1e-2,
-                        sums[2] / seen * 1e-2, sums[3] / seen * 1e-2, sums[4] / seen * 1e-2, sums[5] / seen * 1e-2, sums[6] / seen * 1e-2, sums[7] / seen * 1e-2);
+                                "%s %.2f, un-build + stores %.2f, rest (further groups) %.2f, long queries %.2f\n", seen, (last - first) * 1e-2, sums[1] / seen * 1e-2,
+                        sums[2] / seen * 1e-2, sums[3] / seen * 1e-2, sums[4] / seen * 1e-2, four_launches ? "barrier" : "long candidates + barrier", sums[5] / seen * 1e-2,
+                        sums[6] / seen * 1e-2, sums[7] / seen * 1e-2, sums[8] / seen * 1e-2);
         }
         free(ticks);
         uint64_t *const waves = (uint64_t *)malloc(trace_waves * 32);
-        if (waves && hipMemcpy(waves, trace + trace_workgroups * 8, trace_waves * 32, hipMemcpyDeviceToHost) == hipSuccess) {
+        if (waves && hipMemcpy(waves, trace + trace_workgroups * trace_slots, trace_waves * 32, hipMemcpyDeviceToHost) == hipSuccess) {
             uint64_t first = ~0ull, last = 0, longest_life = 0, longest_text = 0;
             double set_up = 0, columns = 0;
             size_t seen = 0;

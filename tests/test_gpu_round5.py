@@ -174,11 +174,10 @@ def test_tiny_tokens_straight_from_the_tapes(gpu, oracle, rows, columns, longest
             assert np.array_equal(got, expected), (batch, np.argwhere(got != expected)[:5].tolist())
             profile = engine.last_call_profile()
             assert profile.cells == sum(map(len, queries)) * sum(map(len, candidates))
-            fits = all(sum(len(s) > 16 for s in side) <= 256 and max(map(len, side)) <= 256 for side in (queries, candidates))
-            if fits:  # four launches: the longer strings listed (and the tiny ones' masks tabled); then, side by side, the tiny tokens and the rows and
-                # columns of the longer ones with the tables' clean-up behind them
-                assert profile.launches == 4 and profile.planner == (5 if previous_fit else 1), (batch, profile.planner, profile.launches)
-            else:  # refused by the kernel (an outlier beyond 256 bytes): scored by the ordinary path
+            fits = all(max(map(len, side)) <= 255 for side in (queries, candidates))
+            if fits:  # ONE launch: the tiny tokens and, in their shadow, the longer ones (a distance of up to 255 fits a byte of the staging rows)
+                assert profile.launches == 1 and profile.planner == (5 if previous_fit else 1), (batch, profile.planner, profile.launches)
+            else:  # refused by the kernel (a string beyond 255 bytes): scored by the ordinary path
                 assert profile.planner != 5
             previous_fit = fits
 
@@ -205,7 +204,7 @@ def test_tiny_tokens_are_chosen_for_words_and_for_nothing_else(gpu, oracle):
         queries, candidates = [word() for _ in range(600)], [word() for _ in range(2100)]
         assert np.array_equal(engine(queries, candidates, device=gpu), oracle.levenshtein(queries, candidates))
         modes.append(int(engine.last_call_profile().planner))
-    assert modes[0] in (1, 2) and modes[1] == 5 and engine.last_call_profile().launches == 4, modes
+    assert modes[0] in (1, 2) and modes[1] == 5 and engine.last_call_profile().launches == 1, modes
     # config 2's shape never goes there
     load = workloads.config(2, scale=1 / 4)
     engine(load.queries, load.candidates, device=gpu)
@@ -249,9 +248,9 @@ def test_a_query_the_tiny_kernel_cannot_hold_sends_the_call_to_the_ordinary_path
 
 def test_round5_paths_fill_a_host_matrix_too(gpu, oracle):
     """Results in plain host memory (a NumPy `out=`): the library stages a dense matrix in HBM and copies it out with one 2-D copy -
-    behind the launch that plans itself and behind the four launches of the tiny-token path alike (cuda.cuh:2205-2215)."""
+    behind the launch that plans itself and behind the one launch of the tiny-token path alike (cuda.cuh:2205-2215)."""
     rng = random.Random(8)
-    # (one token in 25 beyond 16 bytes: 160 of the 4000 candidates - the outliers' lists hold 256 a side)
+    # (one token in 25 beyond 16 bytes: 160 of the 4000 candidates, scored by the same launch)
     word = lambda: bytes(rng.choice(b"etaoinshrdlu") for _ in range(rng.choice([0, 1, 2, 3, 3, 4, 4, 5, 5, 5, 6, 6, 6, 7, 7, 8, 9, 10, 11, 12, 13, 14, 16, 16, 23])))
     engine = szs.LevenshteinDistances(capabilities=gpu)
     modes = []
