@@ -405,7 +405,7 @@ def measure_extra(config, scope, device_index, args, fence, with_cpu):
                               "frac": round(bytes_moved / kernel / 1e9 / HBM_PEAK_GBPS, 4), "algorithmic_bytes": bytes_moved,
                               "algorithmic_bytes_are": "the results matrix + both tapes + offsets, once", "kernel_ms": round(kernel * 1e3, 4),
                               "launches_per_step": int(profile.launches), "traffic": None,
-                              "kernels": "levenshtein_tiny_kernel + levenshtein_outliers_kernel", "planner_mode": int(profile.planner)}
+                              "kernels": "levenshtein_tiny_kernel", "planner_mode": int(profile.planner)}
     if with_cpu:  # timed later, after every GPU measurement of the run (the host cores are busy for ~10 s per baseline); the
         # matrix stays in HBM until then - downloading 80 MB here would idle the shader engines right before the headline
         record["_cpu_baseline_inputs"] = (load, results)

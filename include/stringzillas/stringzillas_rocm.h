@@ -208,8 +208,9 @@ SZ_API_RUNTIME sz_status_t szs_rocm_node_scores_u64tape(szs_rocm_node_engine_t e
  *  more bit-vector widths whose lengths are skewed), "queue_words" (4 | 8 | 12 | 16: the most words of a pattern one lane holds
  *  there), "queue_rounds" (n: candidates per work item in rounds of eight wavefronts), "queue_priority" (0 | 1: wave priorities by
  *  chain length inside that launch; automatic: byte calls and short codepoint calls), "fused" (0: never plan a short unit-cost
- *  call inside its own scoring launch), "tiny" (0: never | 1: every unit-cost byte call whose queries fit 256 bytes - the
- *  tiny-token kernel of hip/myers_tiny.hip; automatic: batches of tiny tokens on both sides),
+ *  call inside its own scoring launch), "tiny" (0: never | 1: every unit-cost byte call of strings up to 255 bytes of which
+ *  few are beyond 16 - the tiny-token launch of hip/myers_tiny.hip | 2: the same, and blocks full of longer strings are scored there
+ *  too, slowly, instead of refused (testing); automatic: batches of tiny tokens on both sides),
  *  "queues" (see below), "roctx" (1: the host phases of every call - plan, decide, enqueue, wait - as roctx ranges for a
  *  `rocprofv3 --marker-trace` timeline; the marker library is looked up at run time, never linked),
  *  "cpu_requests" (strict | gpu: serve capability

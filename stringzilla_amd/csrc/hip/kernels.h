@@ -181,58 +181,24 @@ unsigned szs_hip_levenshtein_myers_queue_grid(uint64_t items, int runes);
 size_t szs_hip_levenshtein_myers_queue_table_bytes(int runes);
 
 /**
- *  Unit-cost byte-level distances over TINY strings (hip/myers_tiny.hip), straight from the tapes - no refs, no planner:
+ *  Unit-cost byte-level distances over TINY strings (hip/myers_tiny.hip), straight from the tapes - no refs, no planner, ONE launch:
  *  a workgroup scores 256 consecutive candidates against a span of the queries, THIRTY-TWO queries at a time per lane (16-bit
  *  bit-vectors, two to a register), and writes whole 2 KB runs of the result rows.  Plain layout only
- *  (results[query * stride + candidate]).  Strings of more than 16 bytes are skipped - their rows / columns left untouched - and
- *  listed by szs_hip_levenshtein_tiny_prepare in `outliers` (device memory) for szs_hip_levenshtein_outliers (step 2b: after step 1,
- *  beside step 2a).  More than SZS_TINY_MOST_OUTLIERS of them on a side, one beyond 256 bytes, or malformed
- *  offsets leave `*unfit = unfit_sequence` in pinned host memory: the caller then scores the call the ordinary way.
- *  `symbols_out` (pinned, or NULL): [0] the bytes of the queries' tape, [1] of the candidates' - their product is the call's cells.
+ *  (results[query * stride + candidate]).  The few strings of 17 ... 255 bytes are scored by the same workgroups in the shadow of
+ *  that work: a block's long candidates under the groups' own masks, a span's long queries as W-word patterns over the block.
+ *  Malformed offsets, a string beyond 255 bytes, or a block of candidates / span of queries of which more than a quarter is long
+ *  leave `*unfit = unfit_sequence` in pinned host memory: the caller then scores the call the ordinary way.  `symbols_out` (pinned, or NULL): [0] the bytes of the queries' tape, [1] of the candidates' - their
+ *  product is the call's cells.
  */
-#define SZS_TINY_MOST_OUTLIERS 256u
-#define SZS_TINY_LONG_OUTLIER 40u
-typedef struct szs_tiny_outliers_t {
-    uint32_t counts[2]; /* [0] queries, [1] candidates; may exceed the capacity (the call is unfit then) */
-    uint32_t long_counts[2]; /* of those, the strings of more than SZS_TINY_LONG_OUTLIER bytes (a wavefront each in the outliers' kernel) */
-    szs_string_ref_t refs[2][SZS_TINY_MOST_OUTLIERS];
-} szs_tiny_outliers_t;
-/** The 16-bit match masks of a tape's tiny strings, for the outliers' kernel: row `byte` holds, for every group of 128 strings, 64
- *  dwords - string 128 g + l in the low half of dword 64 g + l, string 128 g + 64 + l in its high half (right-aligned patterns,
- *  as in hip/myers_tiny.hip).  szs_hip_levenshtein_tiny_prepare fills both tapes' tables; the caller zeroes them first. */
-#define SZS_TINY_TABLE_BYTES(COUNT) (256ull * ((((uint64_t)(COUNT)) + 127u) / 128u) * 64u * 4u)
 typedef struct szs_tape_t {
     void const *offsets;
     uint64_t base; /* address of the tape's bytes */
     uint32_t count, wide;
 } szs_tape_t;
-/** Step 1: lists both tapes' strings of more than 16 bytes in `outliers` (the caller zeroes `counts` first), raises `*unfit`, and ORs
- *  the tiny strings' match masks into the two tables, which must hold ZEROS.  `unbuild` != 0 (step 3, behind step 2b): nothing but
- *  those same dwords set back to zero - the tables are zeroed when allocated and stay all zeros between calls. */
-int szs_hip_levenshtein_tiny_prepare(szs_tape_t const *queries, szs_tape_t const *candidates, uint32_t *unfit, uint32_t unfit_sequence,
-                                     szs_tiny_outliers_t *outliers, uint32_t *query_masks /* SZS_TINY_TABLE_BYTES(queries) */,
-                                     uint32_t *candidate_masks, unsigned long long *symbols_out, int unbuild, void *stream);
-/** Step 2a: every pair of two tiny strings.  Needs nothing of step 1: may run beside step 2b on another stream. */
 int szs_hip_levenshtein_tiny(szs_tape_t const *queries, szs_tape_t const *candidates, uint64_t *results, uint64_t results_row_stride,
-                             uint64_t *trace /* NULL, or 8 qwords per workgroup of device memory: 100 MHz ticks at its phases (`trace` knob) */, void *stream);
-/**
- *  ONE launch for the whole call (round 5's second design): the kernel of szs_hip_levenshtein_tiny with the strings of 17 ... 255
- *  bytes scored by the same workgroups - a block's long candidates under the groups' own masks, a span's long queries as W-word
- *  patterns over the block - so that no list, no table in device memory and no second kernel is needed.  Malformed offsets or a
- *  string beyond 255 bytes leave `*unfit = unfit_sequence` (pinned host memory): the caller then scores the call the ordinary way.
- */
-int szs_hip_levenshtein_tiny_whole(szs_tape_t const *queries, szs_tape_t const *candidates, uint64_t *results, uint64_t results_row_stride,
                                    uint32_t *unfit, uint32_t unfit_sequence, unsigned long long *symbols_out,
-                                   uint64_t *trace /* NULL, or 10 qwords per workgroup of device memory (`trace` knob) */, void *stream);
-/**
- *  The strings szs_hip_levenshtein_tiny listed (hip/lev_myers.hip): a workgroup scores ONE listed string - the pattern, up to 256
- *  bytes - against a block of 256 strings of the other side's tape, whatever their lengths, with the bodies of the short
- *  bit-parallel kernel.  A listed query fills its row, a listed candidate its column.  The grid covers the list's capacity;
- *  workgroups beyond the counts the first kernel left return at once.
- */
-int szs_hip_levenshtein_outliers(szs_tiny_outliers_t const *outliers, szs_tape_t const *queries, szs_tape_t const *candidates,
-                                 uint32_t const *query_masks, uint32_t const *candidate_masks, uint64_t *results, uint64_t results_row_stride,
-                                 uint64_t *trace /* NULL, or 4 qwords per wavefront of device memory (`trace` knob) */, void *stream);
+                                   uint64_t *trace /* NULL, or 10 qwords per workgroup of device memory (`trace` knob) */,
+                                   int dense /* testing: score blocks and spans full of long strings too (slowly) instead of refusing them */, void *stream);
 
 /**
  *  Fills the cells above the diagonal of a `side` x `side` matrix of 8-byte values from the ones below it (hip/mirror.hip): what a
@@ -269,8 +235,8 @@ enum {
     szs_knob_queue_rounds_k,/* -1 automatic | n: candidates per work item, in rounds of the workgroup's eight wavefronts */
     szs_knob_queue_priority_k, /* -1 automatic (on) | 0: every wave block of that launch at one hardware priority | 1: longest chain first */
     szs_knob_fused_k,       /* -1 automatic | 0: never fold the planner into the short unit-cost launch (szs_fused_plan_t) */
-    szs_knob_tiny_k,        /* -1 automatic (tiny tokens on both sides) | 0 never | 1 every unit-cost byte call whose queries fit 256 bytes:
-                               the tiny-token kernel of hip/myers_tiny.hip */
+    szs_knob_tiny_k,        /* -1 automatic (tiny tokens on both sides) | 0 never | 1 every unit-cost byte call of strings up to 255 bytes, few
+                               of them beyond 16: the tiny-token launch of hip/myers_tiny.hip | 2 (testing): dense batches are scored there too */
     szs_knob_count_k
 };
 int szs_tuning_get(int knob);

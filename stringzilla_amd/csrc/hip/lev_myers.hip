@@ -530,243 +530,6 @@ __global__ __launch_bounds__(256, SZS_MYERS_FUSED_WAVES) void levenshtein_myers_
                                          results_row_stride, layout, none, 0u, 1u, &plan);
 }
 
-/**
- *  The strings the tiny-token kernel (hip/myers_tiny.hip) left out - tokens of more than 16 bytes among words of text, a few per
- *  cent of them, listed by that kernel.  ONE launch, three kinds of workgroup:
- *
- *    A  listed CANDIDATES as texts against the tiny queries as patterns: a wavefront takes 128 consecutive queries - lane l holds
- *       query l in the low half of a register and query 64 + l in the high half - and FOUR listed texts side by side (one text
- *       is one chain of dependent instructions).  A text's symbol is the same for all 64 lanes; each lane reads its own dword
- *       of that symbol's row of the masks table (device memory, built by `levenshtein_tiny_prepare_kernel`; L2-resident, 256
- *       contiguous bytes per wavefront and read) and advances two patterns with the eleven instructions of the packed column.
- *       A 100-byte URL costs its wavefront 100 such steps, not 100 steps of sixteen registers; nobody else waits for it.
- *    B  the same with the sides swapped: listed QUERIES as texts against the tiny candidates (a lane's results are consecutive
- *       columns of the text's row).
- *    C  listed queries against listed candidates: the ordinary bodies of the short kernel, a listed query as the pattern (up to
- *       256 bytes) and the list of candidates as its block of texts.
- *
- *  (Round 5's first version scored a listed string as the PATTERN against the other side's tape, block by block: unsorted
- *  texts, every column through the predicated tail loop - 56 us for the 410 outliers of 4096 x 4096 words, as long as the
- *  tiny-token kernel itself.  The second kept the masks of 128 patterns in 64 KB of LDS per workgroup: two workgroups per CU,
- *  chains of dependent instructions on one or two wavefronts per SIMD - one text at a time per wavefront 65 us, four at a time
- *  with a uniform branch per column 68, branch-free with the sixteen mask reads of a step issued together 49; kind C alone 19.)
- */
-constexpr u32 outlier_patterns_k = 128;  // tiny patterns per wavefront of kinds A / B: two per lane
-constexpr u32 outlier_text_chunk_k = 16; // listed texts per workgroup where a wavefront takes four side by side
-// (a listed text of more than SZS_TINY_LONG_OUTLIER bytes gets a wavefront to itself: the first pass counts them)
-constexpr u32 outlier_chunks_k = SZS_TINY_MOST_OUTLIERS / 4 + 1; // workgroups per group of patterns: enough when every text runs alone
-typedef unsigned short outlier_pk_u16 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void outlier_column(u32 &vp, u32 &vn, u32 eq) { // one DP column of two 16-row patterns (myers_tiny.hip)
-    u32 const xv = eq | vn;
-    outlier_pk_u16 const sum16 = __builtin_bit_cast(outlier_pk_u16, eq & vp) + __builtin_bit_cast(outlier_pk_u16, vp);
-    u32 const sum = __builtin_bit_cast(u32, sum16);
-    u32 const d0 = (sum ^ vp) | eq;
-    u32 const hp = vn | ~(d0 | vp);
-    u32 const hn = vp & d0;
-    outlier_pk_u16 const hp16 = __builtin_bit_cast(outlier_pk_u16, hp) << (outlier_pk_u16)(1), hn16 = __builtin_bit_cast(outlier_pk_u16, hn) << (outlier_pk_u16)(1);
-    u32 const hp_shifted = __builtin_bit_cast(u32, hp16) | 0x00010001u, hn_shifted = __builtin_bit_cast(u32, hn16);
-    vp = hn_shifted | ~(xv | hp_shifted);
-    vn = hp_shifted & xv;
-}
-
-/**
- *  Kinds A / B of the outliers' kernel: `together_` listed texts (refs, the same for all 64 lanes) side by side against the 128
- *  patterns this wavefront holds two to a lane; `my_masks` = the masks table + this lane's dword; see the kernel below.
- */
-template <u32 together_>
-__device__ __forceinline__ void outlier_wave(szs_string_ref_t const (&refs)[together_], u32 live, u32 vp_start, u32 const *__restrict__ my_masks,
-                                             u32 row_dwords, u32 rows_low, u32 rows_high, u64 pattern_low, bool texts_are_candidates,
-                                             u64 *__restrict__ results, u64 results_row_stride, u64 *trace_of_wave, u64 began) {
-    // Everything about a text is the same for all 64 lanes - and the compiler must KNOW it (`readfirstlane`): with the lengths in
-    // vector registers every "is this column still inside the text" became an EXEC-masked branch or a per-lane `v_cndmask` on
-    // VCC (a ninth of the rate of the other VALU instructions here, scripts/valu_peak.hip), and behind the masked branch around the
-    // next step's loads the compiler waited for every outstanding load at the join: a step cost a whole round trip to the L2
-    // however far ahead its masks had been requested (0.8 us per step; A and B 37 / 30 us).
-    u32 lengths[together_], index_of[together_], longest = 0;
-    u32 const *bases[together_]; // the text's first dword (its address rounded down to 4 bytes) ...
-    u32 shifts[together_], dwords[together_]; // ... the bytes its first symbol lies into it, and the dwords that hold its bytes
-#pragma unroll
-    for (u32 k = 0; k < together_; ++k) {
-        lengths[k] = (u32)__builtin_amdgcn_readfirstlane(k < live ? refs[k].length : 0u); // (of the FINAL value: `live` is a vector register too)
-        index_of[k] = (u32)__builtin_amdgcn_readfirstlane(refs[k].index);
-        u64 const address = ((u64)(u32)__builtin_amdgcn_readfirstlane((u32)(refs[k].address >> 32)) << 32) |
-                            (u64)(u32)__builtin_amdgcn_readfirstlane((u32)refs[k].address); // (the builtin returns a SIGNED int)
-        bases[k] = reinterpret_cast<u32 const *>(address & ~(u64)3), shifts[k] = (u32)(address & 3);
-        dwords[k] = lengths[k] ? (shifts[k] + lengths[k] + 3) / 4 : 1u; // (an absent text reads - and never consumes - a listed one's first dword)
-        longest = lengths[k] > longest ? lengths[k] : longest;
-    }
-    u32 const steps = (u32)__builtin_amdgcn_readfirstlane((longest + 3) / 4); // of four columns
-    auto raw = [&](u32 k, u32 dword) -> u32 { return bases[k][dword < dwords[k] ? dword : dwords[k] - 1]; }; // (clamped: never past the text's last dword)
-    u32 vp[together_], vn[together_];
-#pragma unroll
-    for (u32 k = 0; k < together_; ++k) vp[k] = vp_start, vn[k] = 0;
-    // Two steps' masks in flight: buffer A holds the even steps', B the odd ones'; a buffer is refilled - straight into the
-    // registers it will be consumed from, two steps later - as soon as its columns are through.
-    u32 masks_a[4][together_], masks_b[4][together_], text_a[together_][2], text_b[together_][2];
-    auto request = [&](u32 step, u32 (&into)[4][together_], u32 (&text)[together_][2]) { // the masks of step `step`, whose two raw dwords `text` holds
-#pragma unroll
-        for (u32 k = 0; k < together_; ++k) {
-            u32 const symbols = __builtin_amdgcn_alignbyte(text[k][1], text[k][0], shifts[k]);
-#pragma unroll
-            for (u32 column = 0; column < 4; ++column) into[column][k] = my_masks[(u64)((symbols >> (8 * column)) & 0xFFu) * row_dwords];
-        }
-        (void)step;
-    };
-    auto fetch_text = [&](u32 step, u32 (&text)[together_][2]) {
-#pragma unroll
-        for (u32 k = 0; k < together_; ++k) text[k][0] = raw(k, step), text[k][1] = raw(k, step + 1);
-    };
-    auto columns = [&](u32 step, u32 const (&from)[4][together_]) {
-#pragma unroll
-        for (u32 column = 0; column < 4; ++column)
-#pragma unroll
-            for (u32 k = 0; k < together_; ++k)
-                if (4 * step + column < lengths[k]) outlier_column(vp[k], vn[k], from[column][k]); // (a scalar branch)
-    };
-    u64 const set_up = trace_of_wave ? wall_clock64() : 0;
-    if (steps) {
-        fetch_text(0, text_a), fetch_text(1, text_b);
-        request(0, masks_a, text_a);
-        request(1, masks_b, text_b);
-        fetch_text(2, text_a), fetch_text(3, text_b);
-#pragma unroll 1
-        for (u32 step = 0;;) {
-            columns(step, masks_a);
-            if (step + 2 < steps) request(step + 2, masks_a, text_a), fetch_text(step + 4, text_a);
-            if (++step >= steps) break;
-            columns(step, masks_b);
-            if (step + 2 < steps) request(step + 2, masks_b, text_b), fetch_text(step + 4, text_b);
-            if (++step >= steps) break;
-        }
-    }
-    if (trace_of_wave) trace_of_wave[0] = began, trace_of_wave[1] = set_up, trace_of_wave[2] = wall_clock64(), trace_of_wave[3] = longest;
-#pragma unroll
-    for (u32 k = 0; k < together_; ++k) {
-        if (k >= live) break;
-        u32 const low = lengths[k] + (u32)__builtin_popcount(vp[k] & 0xFFFFu) - (u32)__builtin_popcount(vn[k] & 0xFFFFu);
-        u32 const high = lengths[k] + (u32)__builtin_popcount(vp[k] >> 16) - (u32)__builtin_popcount(vn[k] >> 16);
-        u64 const pattern_high = pattern_low + 64;
-        if (texts_are_candidates) { // results[query = pattern][candidate = text]
-            if (rows_low != ~0u) results[pattern_low * results_row_stride + index_of[k]] = low;
-            if (rows_high != ~0u) results[pattern_high * results_row_stride + index_of[k]] = high;
-        }
-        else { // results[query = text][candidate = pattern]: 512 contiguous bytes per wavefront and half
-            if (rows_low != ~0u) results[(u64)index_of[k] * results_row_stride + pattern_low] = low;
-            if (rows_high != ~0u) results[(u64)index_of[k] * results_row_stride + pattern_high] = high;
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void levenshtein_outliers_kernel(szs_tiny_outliers_t const *__restrict__ outliers, szs_tape_t queries,
-                                                                  szs_tape_t candidates, u32 const *__restrict__ query_masks,
-                                                                  u32 const *__restrict__ candidate_masks, u32 query_groups,
-                                                                  u32 candidate_groups, u64 *__restrict__ results, u64 results_row_stride, u64 *trace) {
-    __shared__ __attribute__((aligned(16))) u32 peq[peq_layout<8, byte_rows_k>::total_dwords]; // kind C only
-    u64 const began = trace ? wall_clock64() : 0;
-    __shared__ __attribute__((aligned(16))) szs_string_ref_t listed_texts[SZS_TINY_MOST_OUTLIERS];
-    constexpr u32 chunks = outlier_chunks_k;
-    u32 const tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    u32 const listed_queries = outliers->counts[0] < SZS_TINY_MOST_OUTLIERS ? outliers->counts[0] : SZS_TINY_MOST_OUTLIERS;
-    u32 const listed_candidates = outliers->counts[1] < SZS_TINY_MOST_OUTLIERS ? outliers->counts[1] : SZS_TINY_MOST_OUTLIERS;
-    u32 const workgroups_a = query_groups * chunks, workgroups_b = candidate_groups * chunks;
-
-    if (blockIdx.x >= workgroups_a + workgroups_b) { // ---- kind C: a listed query against the listed candidates
-        u32 const listed = blockIdx.x - workgroups_a - workgroups_b;
-        if (listed >= listed_queries || !listed_candidates) return;
-        szs_string_ref_t const pattern = outliers->refs[0][listed];
-        if (tid < listed_candidates) listed_texts[tid] = outliers->refs[1][tid];
-        __syncthreads();
-        szs_ref_guard_t const none = {};
-        u32 const words = __builtin_amdgcn_readfirstlane(pattern.length ? (pattern.length + 31u) / 32u : 1u);
-#define SZS_OUTLIER_BODY(W)                                                                                            \
-    case W:                                                                                                            \
-        myers_workgroup<W, SZS_MYERS_SHORT_TEXT_DWORDS, false>(peq, nullptr, pattern, listed_texts, listed_candidates, 0u, results, \
-                                                               results_row_stride, 0, none);                          \
-        break;
-        switch (words) {
-            SZS_OUTLIER_BODY(1)
-            SZS_OUTLIER_BODY(2)
-            SZS_OUTLIER_BODY(3)
-            SZS_OUTLIER_BODY(4)
-            SZS_OUTLIER_BODY(5)
-            SZS_OUTLIER_BODY(6)
-            SZS_OUTLIER_BODY(7)
-        default: // 8; nothing longer is listed
-            myers_workgroup<8, SZS_MYERS_SHORT_TEXT_DWORDS, false>(peq, nullptr, pattern, listed_texts, listed_candidates, 0u, results,
-                                                                   results_row_stride, 0, none);
-            break;
-        }
-#undef SZS_OUTLIER_BODY
-        return;
-    }
-
-    // ---- kinds A and B: this wavefront's 128 patterns (their masks come from the table `levenshtein_tiny_prepare_kernel` built in
-    //      device memory - 2 MB for a side of 4096 strings, L2-resident) against listed texts
-    bool const texts_are_candidates = blockIdx.x < workgroups_a;
-    u32 const local = texts_are_candidates ? blockIdx.x : blockIdx.x - workgroups_a;
-    u32 const group = local / chunks, chunk = local % chunks;
-    int const side_of_texts = texts_are_candidates ? 1 : 0;
-    u32 const texts_count = texts_are_candidates ? listed_candidates : listed_queries;
-    if (!texts_count) return;
-    // A wavefront runs its texts side by side for as many steps as the LONGEST of them has, and the kernel is bound by VALU issue
-    // (`trace` knob: in the order the first pass listed them, a quartet's longest was ~50 bytes where the mean is 27 - twice the
-    // instructions).  So every workgroup ranks the (at most 256) listed texts by length - a count of the shorter ones per thread -
-    // and the work is dealt in that order: FOUR texts per wavefront up to `outlier_alone_k` bytes, ONE beyond (the wavefront of
-    // the four longest was the whole kernel's duration: 23 steps of four texts at the pace of a shared SIMD).
-    // (how many run alone the first pass has counted: a workgroup without work leaves before it ranks anything)
-    u32 const alone_listed = outliers->long_counts[side_of_texts];
-    u32 const alone = alone_listed < texts_count ? alone_listed : texts_count, together_count = texts_count - alone;
-    u32 const chunks_together = (together_count + outlier_text_chunk_k - 1) / outlier_text_chunk_k;
-    bool const by_fours = chunk < chunks_together;
-    u32 const end_text = by_fours ? together_count : texts_count;
-    if ((by_fours ? chunk * outlier_text_chunk_k : together_count + (chunk - chunks_together) * 4) >= end_text) return; // (uniform per workgroup)
-    __shared__ __attribute__((aligned(16))) u32 listed_lengths[SZS_TINY_MOST_OUTLIERS];
-    __shared__ unsigned short listed_order[SZS_TINY_MOST_OUTLIERS];
-    listed_lengths[tid] = tid < texts_count ? outliers->refs[side_of_texts][tid].length : ~0u;
-    __syncthreads();
-    if (tid < texts_count) { // ranks [0, together_count) are dealt by fours, the rest one by one
-        u32 const mine = listed_lengths[tid];
-        u32 rank = 0;
-        uint4 const *const four = reinterpret_cast<uint4 const *>(listed_lengths);
-        for (u32 j = 0; j < (texts_count + 3) / 4; ++j) { // (slots past the count hold ~0: never shorter)
-            uint4 const them = four[j];
-            rank += (them.x < mine || (them.x == mine && 4 * j + 0 < tid)) + (them.y < mine || (them.y == mine && 4 * j + 1 < tid)) +
-                    (them.z < mine || (them.z == mine && 4 * j + 2 < tid)) + (them.w < mine || (them.w == mine && 4 * j + 3 < tid));
-        }
-        listed_order[rank] = (unsigned short)tid;
-    }
-    __syncthreads();
-    u32 const first_text = by_fours ? chunk * outlier_text_chunk_k + wave * 4 : together_count + (chunk - chunks_together) * 4 + wave;
-    if (first_text >= end_text) return; // (uniform per wavefront; no barrier below)
-    szs_tape_t const &patterns = texts_are_candidates ? queries : candidates;
-    u32 const *const masks = texts_are_candidates ? query_masks : candidate_masks;
-    u32 const row_dwords = ((patterns.count + 127u) / 128u) * 64u;
-    u32 const pattern_first = group * outlier_patterns_k;
-    auto rows_of = [&](u32 p) -> u32 { // bytes of pattern p; ~0: absent, or one of the listed (long) strings itself
-        if (p >= patterns.count) return ~0u;
-        u64 const from = fused_offset(patterns.offsets, patterns.wide, p), to = fused_offset(patterns.offsets, patterns.wide, (u64)p + 1);
-        return to >= from && to - from <= 16 ? (u32)(to - from) : ~0u;
-    };
-    u32 const rows_low = rows_of(pattern_first + lane), rows_high = rows_of(pattern_first + lane + 64);
-    u32 const vp_start = ((0xFFFFu << (16 - (rows_low == ~0u ? 0u : rows_low))) & 0xFFFFu) |
-                         ((0xFFFF0000u << (16 - (rows_high == ~0u ? 0u : rows_high))) & 0xFFFF0000u);
-    u32 const *const my_masks = masks + group * 64u + lane; // + byte x row_dwords
-    u64 *const trace_of_wave = trace && lane == 0 ? trace + ((u64)blockIdx.x * 4 + wave) * 4 : nullptr;
-    if (by_fours) {
-        szs_string_ref_t refs[4];
-        u32 const live = end_text - first_text < 4 ? end_text - first_text : 4;
-#pragma unroll
-        for (u32 k = 0; k < 4; ++k) refs[k] = outliers->refs[side_of_texts][listed_order[first_text + (k < live ? k : 0)]]; // the same for all 64 lanes
-        outlier_wave<4>(refs, live, vp_start, my_masks, row_dwords, rows_low, rows_high, pattern_first + lane, texts_are_candidates, results,
-                        results_row_stride, trace_of_wave, began);
-    }
-    else {
-        szs_string_ref_t const refs[1] = {outliers->refs[side_of_texts][listed_order[first_text]]};
-        outlier_wave<1>(refs, 1u, vp_start, my_masks, row_dwords, rows_low, rows_high, pattern_first + lane, texts_are_candidates, results,
-                        results_row_stride, trace_of_wave, began);
-    }
-}
-
 /** The same with `blocks_per_group` candidate blocks per workgroup (launch_myers_short decides). */
 template <bool runes_>
 __global__ __launch_bounds__(256, SZS_MYERS_SHORT_WAVES) void levenshtein_myers_short_merged_kernel(
@@ -1832,20 +1595,6 @@ extern "C" int szs_hip_levenshtein_myers_fused(szs_fused_plan_t const *plan, uin
     u32 const candidate_blocks = (candidates_count + SZS_CANDIDATES_PER_WORKGROUP - 1) / SZS_CANDIDATES_PER_WORKGROUP;
     hipLaunchKernelGGL(levenshtein_myers_short_fused_kernel, dim3(queries_count * candidate_blocks), dim3(256), 0,
                        static_cast<hipStream_t>(stream), *plan, candidate_blocks, results, results_row_stride, layout);
-    return (int)hipGetLastError();
-}
-
-extern "C" int szs_hip_levenshtein_outliers(szs_tiny_outliers_t const *outliers, szs_tape_t const *queries, szs_tape_t const *candidates,
-                                            uint32_t const *query_masks, uint32_t const *candidate_masks, uint64_t *results,
-                                            uint64_t results_row_stride, uint64_t *trace, void *stream) {
-    using namespace szs_hip;
-    if (!queries->count || !candidates->count) return 0;
-    u64 const query_groups = ((u64)queries->count + outlier_patterns_k - 1) / outlier_patterns_k;
-    u64 const candidate_groups = ((u64)candidates->count + outlier_patterns_k - 1) / outlier_patterns_k;
-    u64 const grid = (query_groups + candidate_groups) * outlier_chunks_k + SZS_TINY_MOST_OUTLIERS;
-    if (grid > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(levenshtein_outliers_kernel, dim3((u32)grid), dim3(256), 0, static_cast<hipStream_t>(stream), outliers, *queries, *candidates,
-                       query_masks, candidate_masks, (u32)query_groups, (u32)candidate_groups, results, results_row_stride, trace);
     return (int)hipGetLastError();
 }
 

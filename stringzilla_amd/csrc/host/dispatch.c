@@ -271,8 +271,7 @@ static void release_device_state(szs_engine_s *engine) {
     engine->queue_zeroed = NULL;
     szs_buffer_release(&engine->pinned_summary);
     szs_buffer_release(&engine->device_fused);
-    szs_buffer_release(&engine->device_outliers);
-    engine->tiny_valid = 0, engine->outliers_zeroed = NULL;
+    engine->tiny_valid = 0;
     engine->fused_zeroed = NULL;
     if (engine->events_device >= 0) {
         (void)hipEventDestroy(engine->event_start);
@@ -1054,15 +1053,15 @@ static int tiny_shaped(szs_engine_s const *engine, int symmetric, szs_side_stats
     if (symmetric || !engine->is_unit_cost || knob == 0) return 0;
     if (engine->family != szs_family_levenshtein_k && engine->family != szs_family_levenshtein_utf8_k /* an ASCII corpus */) return 0;
     if (knob > 0) return 1;
-    /* word-like: mean length well under the sixteen rows of that kernel's bit-vectors (what is longer is listed for the outliers'
-     * kernel - a few per cent of a text's tokens; the kernel itself says when its lists overflow) and a matrix worth a launch */
+    /* word-like: mean length well under the sixteen rows of that kernel's bit-vectors (what is longer - a few per cent of a text's
+     * tokens - rides along in the same launch; the kernel itself says when a string is beyond it) and a matrix worth a launch */
     return queries->symbols <= 10ull * queries->count && candidates->symbols <= 10ull * candidates->count && queries->count >= 64 &&
            candidates->count >= 1024 && (uint64_t)queries->count * candidates->count >= (1ull << 20);
 }
 
 /**
  *  One launch of the tiny-token kernel, straight from the caller's tapes, and the call's wait.  sz_success_k: scored.
- *  SZS_TINY_NOT_TAKEN: the kernel met a query beyond 256 bytes or malformed offsets - nothing it wrote counts, the caller goes on
+ *  SZS_TINY_NOT_TAKEN: the kernel met a string beyond 255 bytes or malformed offsets - nothing it wrote counts, the caller goes on
  *  to the ordinary path (which also reports malformed tapes).  `planner_mode`: 1 when a planner's summary chose this kernel, 5 when
  *  the previous call of the engine did and nothing was planned at all.
  */
@@ -1078,53 +1077,21 @@ static sz_status_t cross_tiny(szs_call_t *call, uint32_t planner_mode, szs_plan_
     szs_tape_t const q_tape = {call->queries->offsets, (uint64_t)(uintptr_t)call->queries->data, call->q_count, call->queries->kind == szs_input_u64tape_k};
     szs_tape_t const c_tape = {call->candidates->offsets, (uint64_t)(uintptr_t)call->candidates->data, call->c_count,
                                call->candidates->kind == szs_input_u64tape_k};
-    int const four_launches = szs_tuning_get(szs_knob_tiny_k) == 2; /* round 5's first design, kept to be measured against */
     uint32_t launches = 0;
-    uint64_t *trace = NULL; /* `trace` knob: the phases of every workgroup of the tiny-token kernel, then of every wavefront of the outliers' (printed after the wait) */
-    size_t const trace_workgroups = 8192, trace_waves = 65536, trace_slots = 10;
+    uint64_t *trace = NULL; /* `trace` knob: the phases of every workgroup of the launch (printed after the wait) */
+    size_t const trace_workgroups = 8192, trace_slots = 10;
     hipError_t error = hipEventRecord(engine->event_start, stream);
-    if (call->trace && szs_buffer_reserve(&engine->device_queue_trace, szs_memory_device_k, call->device, trace_workgroups * trace_slots * 8 + trace_waves * 32, NULL) == sz_success_k) {
+    if (call->trace && szs_buffer_reserve(&engine->device_queue_trace, szs_memory_device_k, call->device, trace_workgroups * trace_slots * 8, NULL) == sz_success_k) {
         trace = (uint64_t *)engine->device_queue_trace.pointer;
-        if (hipMemsetAsync(trace, 0, trace_workgroups * trace_slots * 8 + trace_waves * 32, stream) != hipSuccess) trace = NULL;
+        if (hipMemsetAsync(trace, 0, trace_workgroups * trace_slots * 8, stream) != hipSuccess) trace = NULL;
     }
-    if (!four_launches) {
-        /* ONE launch: the tiny tokens and, in their shadow, the few longer ones (hip/myers_tiny.hip: levenshtein_tiny_whole_kernel) */
-        if (error == hipSuccess) {
-            error = (hipError_t)szs_hip_levenshtein_tiny_whole(&q_tape, &c_tape, (uint64_t *)call->device_results, call->device_stride, (uint32_t *)unfit, sequence,
-                                                               (unsigned long long *)symbols, trace, stream);
-            launches += error == hipSuccess;
-        }
-    }
-    else {
-    /* [the two counts | both tapes' mask tables] are cleared by ONE fill; the lists' refs lie behind them */
-    size_t const q_table = (size_t)SZS_TINY_TABLE_BYTES(call->q_count), c_table = (size_t)SZS_TINY_TABLE_BYTES(call->c_count);
-    sz_status_t reserved = szs_buffer_reserve(&engine->device_outliers, szs_memory_device_k, call->device, 256 + q_table + c_table + sizeof(szs_tiny_outliers_t),
-                                              call->error_message);
-    if (reserved != sz_success_k) return reserved;
-    char *const cleared = (char *)engine->device_outliers.pointer;
-    uint32_t *const q_masks = (uint32_t *)(cleared + 256), *const c_masks = (uint32_t *)(cleared + 256 + q_table);
-    szs_tiny_outliers_t *const outliers = (szs_tiny_outliers_t *)(cleared + 256 + q_table + c_table);
-    if (error == hipSuccess && engine->outliers_zeroed != engine->device_outliers.pointer) {
-        error = hipMemsetAsync(cleared, 0, engine->device_outliers.capacity, stream);
-        engine->outliers_zeroed = error == hipSuccess ? engine->device_outliers.pointer : NULL;
-    }
-    if (error == hipSuccess) error = hipMemsetAsync(outliers, 0, 16, stream); /* the two counts */
+    /* ONE launch: the tiny tokens and, in their shadow, the few longer ones (hip/myers_tiny.hip).  (Round 5's first design was four:
+     * a pass that listed the longer strings and tabled the tiny ones' masks in device memory, the outliers' kernel, a pass that set
+     * the tables back, the tiny-token kernel - 100 us of kernels on 4096 x 4096 words of text where the one launch takes 92.) */
     if (error == hipSuccess) {
-        error = (hipError_t)szs_hip_levenshtein_tiny_prepare(&q_tape, &c_tape, (uint32_t *)unfit, sequence, outliers, q_masks, c_masks, (unsigned long long *)symbols, 0, stream);
+        error = (hipError_t)szs_hip_levenshtein_tiny(&q_tape, &c_tape, (uint64_t *)call->device_results, call->device_stride, (uint32_t *)unfit, sequence,
+                                                           (unsigned long long *)symbols, trace, szs_tuning_get(szs_knob_tiny_k) == 2, stream);
         launches += error == hipSuccess;
-        if (error == hipSuccess) { /* tokens of more than 16 bytes: their rows and columns (hip/lev_myers.hip) */
-            error = (hipError_t)szs_hip_levenshtein_outliers(outliers, &q_tape, &c_tape, q_masks, c_masks, (uint64_t *)call->device_results, call->device_stride,
-                                                             trace ? trace + trace_workgroups * trace_slots : NULL, stream);
-            launches += error == hipSuccess;
-        }
-        hipError_t const unbuilt = (hipError_t)szs_hip_levenshtein_tiny_prepare(&q_tape, &c_tape, (uint32_t *)unfit, sequence, outliers, q_masks, c_masks, NULL, 1, stream);
-        if (unbuilt != hipSuccess) engine->outliers_zeroed = NULL; /* fill them before the next call */
-        launches += unbuilt == hipSuccess;
-    }
-    if (error == hipSuccess) {
-        error = (hipError_t)szs_hip_levenshtein_tiny(&q_tape, &c_tape, (uint64_t *)call->device_results, call->device_stride, trace, stream);
-        launches += error == hipSuccess;
-    }
     }
     engine->last_streams = 1;
     szs_decision_t *const shape = (szs_decision_t *)calloc(1, sizeof(szs_decision_t)); /* what finish() reads: lanes tier, one launch */
@@ -1137,7 +1104,7 @@ static sz_status_t cross_tiny(szs_call_t *call, uint32_t planner_mode, szs_plan_
     free(shape);
     if (status != sz_success_k) return status;
     if (trace) { /* where a workgroup of the tiny-token kernel spends its time: mean ticks (10 ns) between its stamps */
-        size_t const slots = four_launches ? 8 : trace_slots, last_slot = four_launches ? 7 : 8;
+        size_t const slots = trace_slots, last_slot = 8;
         uint64_t *const ticks = (uint64_t *)malloc(trace_workgroups * slots * 8);
         if (ticks && hipMemcpy(ticks, trace, trace_workgroups * slots * 8, hipMemcpyDeviceToHost) == hipSuccess) {
             double sums[10] = {0};
@@ -1174,26 +1141,10 @@ static sz_status_t cross_tiny(szs_call_t *call, uint32_t planner_mode, szs_plan_
             if (seen)
                 fprintf(stderr, "tiny kernel: %zu workgroups over %.1f us; mean us per workgroup: offsets + local sort %.2f, texts %.2f, first masks %.2f, columns %.2f, "
                                 "%s %.2f, un-build + stores %.2f, rest (further groups) %.2f, long queries %.2f\n", seen, (last - first) * 1e-2, sums[1] / seen * 1e-2,
-                        sums[2] / seen * 1e-2, sums[3] / seen * 1e-2, sums[4] / seen * 1e-2, four_launches ? "barrier" : "long candidates + barrier", sums[5] / seen * 1e-2,
+                        sums[2] / seen * 1e-2, sums[3] / seen * 1e-2, sums[4] / seen * 1e-2, "long candidates + barrier", sums[5] / seen * 1e-2,
                         sums[6] / seen * 1e-2, sums[7] / seen * 1e-2, sums[8] / seen * 1e-2);
         }
         free(ticks);
-        uint64_t *const waves = (uint64_t *)malloc(trace_waves * 32);
-        if (waves && hipMemcpy(waves, trace + trace_workgroups * trace_slots, trace_waves * 32, hipMemcpyDeviceToHost) == hipSuccess) {
-            uint64_t first = ~0ull, last = 0, longest_life = 0, longest_text = 0;
-            double set_up = 0, columns = 0;
-            size_t seen = 0;
-            for (size_t w = 0; w < trace_waves; ++w) {
-                if (!waves[4 * w] || !waves[4 * w + 2]) continue;
-                ++seen, set_up += (double)(waves[4 * w + 1] - waves[4 * w]), columns += (double)(waves[4 * w + 2] - waves[4 * w + 1]);
-                first = waves[4 * w] < first ? waves[4 * w] : first, last = waves[4 * w + 2] > last ? waves[4 * w + 2] : last;
-                if (waves[4 * w + 2] - waves[4 * w] > longest_life) longest_life = waves[4 * w + 2] - waves[4 * w], longest_text = waves[4 * w + 3];
-            }
-            if (seen)
-                fprintf(stderr, "outliers' kernel, kinds A / B: %zu wavefronts over %.1f us; mean us per wavefront: set-up %.2f, columns %.2f; the longest-lived %.2f us (its longest text: %u bytes)\n",
-                        seen, (last - first) * 1e-2, set_up / seen * 1e-2, columns / seen * 1e-2, longest_life * 1e-2, (unsigned)longest_text);
-        }
-        free(waves);
     }
     if (*unfit == sequence) {
         engine->tiny_valid = 0;

@@ -116,9 +116,6 @@ typedef struct szs_engine_s {
     int last_queued;               /* enqueue() issued the persistent launch for the call being finished (the call profile says so) */
     szs_buffer_t device_fused;     /* device: the two `ready` words of the short launch that plans itself (kernels.h: szs_fused_plan_t) */
     void *fused_zeroed;            /* the allocation of `device_fused` that was zeroed */
-    szs_buffer_t device_outliers;  /* device: szs_tiny_outliers_t - the strings the tiny-token kernel leaves to the outliers' kernel -
-                                      and behind it the two tapes' tables of 16-bit match masks (kernels.h: SZS_TINY_TABLE_BYTES) */
-    void *outliers_zeroed;         /* the allocation of `device_outliers` whose mask tables hold zeros (zeroed once; every call un-builds what it built) */
     int tiny_valid;                /* the previous call of these counts was scored by the tiny-token kernel (hip/myers_tiny.hip): go straight there */
     uint32_t tiny_q_count, tiny_c_count;
     hipEvent_t event_start, event_stop;

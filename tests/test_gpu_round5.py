@@ -9,6 +9,8 @@
    the launch leaves behind serves the same-tapes path; the `fused` knob turns it off.
 """
 import contextlib
+import json
+import os
 import ctypes
 import random
 
@@ -145,12 +147,12 @@ def test_malformed_offsets_reach_the_caller_from_a_fused_launch_too(gpu):
 
 # ---- 2. the tiny-token kernel (hip/myers_tiny.hip; the reference's fast path: cuda.cuh:2864, :4297-4340) -------------------------------
 #
-# Straight from the tapes, thirty-two queries per lane on 16-bit bit-vectors, whole runs of the result rows; strings of more than 16
-# bytes are listed for the outliers' kernel (the short kernel's bodies, a listed string against the other side's tape).  Pinned
-# here: tokens at every length 0 ... 16 beside outliers of up to 256 bytes on either side and on both, ragged counts around the
-# blocks of 256 candidates and the groups of 32 queries, bytes >= 0x80, 64-bit tapes, a padded results matrix; an outlier beyond
-# 256 bytes (or more outliers than the list holds) sends the call to the ordinary path; the automatic choice takes word-like
-# batches and nothing else.
+# Straight from the tapes, thirty-two queries per lane on 16-bit bit-vectors, whole runs of the result rows; strings of 17 ... 255
+# bytes ride along in the same launch (a block's long candidates under the groups' masks, a span's long queries as W-word patterns).
+# Pinned here: tokens at every length 0 ... 16 beside longer ones of up to 255 bytes on either side and on both, ragged counts
+# around the blocks of 256 candidates and the groups of 32 queries, bytes >= 0x80, 64-bit tapes, a padded results matrix; a string
+# beyond 255 bytes sends the call to the ordinary path; the automatic choice takes word-like batches and nothing else.  The same
+# path from plain C on denser mixes (every string long, hundreds of long ones a block): tests/native/words_probe.c, run below.
 
 WORDS = b"etaoinshrdlucmfwypvbgkqjxz" + bytes(range(0xC0, 0xC8)) + b"\xff\x80"
 
@@ -180,6 +182,33 @@ def test_tiny_tokens_straight_from_the_tapes(gpu, oracle, rows, columns, longest
             else:  # refused by the kernel (a string beyond 255 bytes): scored by the ordinary path
                 assert profile.planner != 5
             previous_fit = fits
+
+
+@pytest.mark.parametrize("source,rows,columns,padding,wide,knob_value,taken", [
+    ("mix:60:40", 100, 700, 0, False, 1, True), ("mix:50:64", 37, 513, 87, True, 1, True), ("mix:20:64", 1, 1, 0, False, 1, True),
+    ("mix:300:128", 65, 260, 0, False, 1, False), ("mix:1000:200", 40, 300, 0, False, 1, False), ("mix:500:33", 257, 31, 1, False, 1, False),
+    ("mix:100:255", 300, 1000, 7, False, 2, True), ("mix:300:128", 65, 260, 0, False, 2, True), ("mix:1000:200", 40, 300, 0, False, 2, True),
+    ("mix:500:33", 257, 31, 1, False, 2, True),
+])
+def test_dense_mixes_of_tiny_and_long_tokens_from_plain_c(gpu, source, rows, columns, padding, wide, knob_value, taken):
+    """tests/native/words_probe.c: device tapes, a padded matrix, every cell against the oracle.  `tiny` = 1: mixes of which more than
+    a quarter of a block or span is long are REFUSED by the launch (the ordinary kernels score them - ten times faster there - and
+    `planner` says so).  `tiny` = 2 (testing) scores them in the launch all the same: dozens and hundreds of long candidates in a
+    block (rounds of sixteen), more long queries in a span than one round of tables holds, W = 1, 2, 4 and 8, strings of exactly
+    255 bytes, every string long (the groups' columns idle, kinds A / B / C carry the call)."""
+    import subprocess
+
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "native", "bin", "words_probe")
+    if not os.path.exists(probe):
+        pytest.skip("tests/native/bin/words_probe is not built (make -C tests/native)")
+    env = dict(os.environ, SZS_ROCM_TINY=str(knob_value))
+    if wide:
+        env["PROBE_WIDE"] = "1"
+    done = subprocess.run([probe, source, str(rows), str(columns), "3", str(padding)], env=env, capture_output=True, text=True, timeout=300)
+    assert done.returncode == 0, done.stdout[-2000:] + done.stderr[-2000:]
+    summary = json.loads(done.stdout.strip().splitlines()[-1])
+    assert summary["failures"] == 0 and summary["checked"], summary
+    assert (summary["planner"] == 5 and summary["launches"] == 1) == taken, summary
 
 
 def test_tiny_tokens_are_chosen_for_words_and_for_nothing_else(gpu, oracle):
