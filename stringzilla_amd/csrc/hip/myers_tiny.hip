@@ -58,6 +58,13 @@ __device__ __forceinline__ u32 tiny_pk_shl1(u32 a) { // v_pk_lshlrev_b16
     return __builtin_bit_cast(u32, shifted);
 }
 
+__device__ __forceinline__ void tiny_set_priority(u32 priority) { // (`s_setprio` takes an immediate; `priority` is wave-uniform)
+    if (priority == 0) __builtin_amdgcn_s_setprio(0);
+    else if (priority == 1) __builtin_amdgcn_s_setprio(1);
+    else if (priority == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+}
+
 /** One DP column of TWO 16-row patterns at once (the column update of myers_core.hpp on packed halves). */
 __device__ __forceinline__ void tiny_column(u32 &vp, u32 &vn, u32 eq) {
     u32 const xv = eq | vn;
@@ -199,6 +206,7 @@ __device__ __forceinline__ void tiny_long_queries(u32 *peq, u32 *out, u64 const 
             if (column_is_tiny) out16[r * 256u + column] = (unsigned short)distance(text_length, vp, vn);
         }
         // ---- C: the block's long candidates, a cluster of R lanes each; lane r of a cluster takes pattern r of the round
+        __builtin_amdgcn_s_setprio(3);
 #pragma unroll 1
         for (u32 k_first = 0; k_first < long_count; k_first += 4 * texts_per_wave) {
             tiny_held_text_t<registers_> const held =
@@ -249,6 +257,7 @@ __device__ __forceinline__ void tiny_long_queries(u32 *peq, u32 *out, u64 const 
             }
             if (live) out16[r * 256u + held.column] = (unsigned short)distance(held.length, vp, vn);
         }
+        __builtin_amdgcn_s_setprio(1);
         __syncthreads();
         // ---- the rows leave as whole runs (thread t: candidate t of the block); the tables go back to zeros
         if (my_exists) {
@@ -405,6 +414,12 @@ __device__ __forceinline__ void tiny_body(szs_tape_t const &queries, szs_tape_t 
 #pragma unroll 1
     for (u32 group_first = 0; group_first < queries_here; group_first += group_k) {
         u32 *const out = out_both + parity * H * tiny_block_k;
+        // Wave priority by PROGRESS: a workgroup on its first group runs above one on its second, and so on.  The four workgroups
+        // of a CU start together, and the hardware serves the oldest wavefront first: left alone, the first of them finished in 27 us,
+        // the fourth in 50 (tiny tokens alone), and the CU ran on three, two, one workgroup for the second half of the launch -
+        // bound by latency, with less and less to hide it behind.  Levelled by progress they end together: 67 -> 63 us.
+        u32 const priority = group_first / group_k < 3u ? 3u - group_first / group_k : 0u;
+        tiny_set_priority(priority);
         // masks: slot s lives in half s / R of dword s % R of every row; its query is right-aligned in the half's sixteen bits
         u32 built[slots_per_thread];
 #pragma unroll
@@ -473,7 +488,10 @@ __device__ __forceinline__ void tiny_body(szs_tape_t const &queries, szs_tape_t 
             }
         }
         if (group_first == 0) SZS_TINY_STAMP(4);
-        // ---- A: the block's long candidates under the group's masks - R lanes a text, lane d of them the patterns of dword d
+        // ---- A: the block's long candidates under the group's masks - R lanes a text, lane d of them the patterns of dword d.
+        //      A chain of dependent columns as long as the text: the wavefront runs it at a raised priority (`s_setprio`) - few
+        //      instructions, but the launch ends when the workgroup with the longest chains does.
+        if (long_count) __builtin_amdgcn_s_setprio(3);
 #pragma unroll 1
         for (u32 k_first = 0; k_first < long_count; k_first += 4 * texts_per_wave) {
             tiny_held_text_t<R> const held =
@@ -503,6 +521,7 @@ __device__ __forceinline__ void tiny_body(szs_tape_t const &queries, szs_tape_t 
                 bytes[2] = (u8)(held.length + (u32)__builtin_popcount(vp >> 16) - (u32)__builtin_popcount(vn >> 16));
             }
         }
+        tiny_set_priority(priority);
         __syncthreads();
         if (group_first == 0) SZS_TINY_STAMP(5);
         // un-build the masks (the same dwords back to zero: cheaper than clearing the table) ...
@@ -516,6 +535,7 @@ __device__ __forceinline__ void tiny_body(szs_tape_t const &queries, szs_tape_t 
     }
 #pragma unroll
     for (u32 step = 0; step < R; ++step) flush(step); // the last group's rows
+    __builtin_amdgcn_s_setprio(1); // (what is left - the span's long queries - yields to workgroups still on their groups)
     SZS_TINY_STAMP(7);
     // ---- B and C: the span's long queries, as W-word patterns by the longest of them
     u32 *const out = out_both;
