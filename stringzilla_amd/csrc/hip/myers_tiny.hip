@@ -414,6 +414,9 @@ __device__ __forceinline__ void tiny_body(szs_tape_t const &queries, szs_tape_t 
 #pragma unroll 1
     for (u32 group_first = 0; group_first < queries_here; group_first += group_k) {
         u32 *const out = out_both + parity * H * tiny_block_k;
+        // (the text's bytes are the same for every group; left alone, the compiler keeps the sixteen LDS row addresses they select in
+        // sixteen registers across the whole loop - two instructions a column step recompute one)
+        asm volatile("" : "+v"(symbols[0]), "+v"(symbols[1]), "+v"(symbols[2]), "+v"(symbols[3]));
         // Wave priority by PROGRESS: a workgroup on its first group runs above one on its second, and so on.  The four workgroups
         // of a CU start together, and the hardware serves the oldest wavefront first: left alone, the first of them finished in 27 us,
         // the fourth in 50 (tiny tokens alone), and the CU ran on three, two, one workgroup for the second half of the launch -
@@ -557,6 +560,17 @@ __device__ __forceinline__ void tiny_body(szs_tape_t const &queries, szs_tape_t 
 #undef SZS_TINY_STAMP
 }
 
+/*  Measured and not kept (4096 x 4096 words of text, 81 us as it stands):
+ *  - the groups DRAWN from a ticket counter per block of candidates (a workgroup its own place first, then whatever comes; the next
+ *    group's bytes and lengths requested straight from the tape one group ahead, the ticket two ahead): 82 us.  A workgroup lives
+ *    54 us on average and the launch ends at 76 - but what the last workgroups are busy with is not groups somebody else could take:
+ *    it is the long queries of their own groups (kinds B and C, 9 us on average and up to 28 behind the last group) and the long
+ *    candidates of their own block.  (With all blocks' counters in one 128-byte line the thousand first draws queued up at one
+ *    place in the L2: 12.8 us to the first barrier instead of 3.5.)
+ *  - kinds B and C at the top wave priority instead of below the groups: the same.
+ *  - half of the workgroups starting 4 ... 12 us late, so that some compute while others drain: the late half runs 6 us faster, and
+ *    the launch ends 4 ... 5 us later.
+ */
 /** R = 16: thirty-two queries a group, four wavefronts a SIMD (128 registers), 39 KB of LDS - four workgroups a CU.  (R = 8 - groups
  *  of sixteen, 64 or 80 registers for eight or six wavefronts a SIMD - measured 66 ... 75 us on tiny tokens alone where this takes
  *  56: twice the mask builds, barriers and staging per pair, and what the launch waits for is not hidden by more wavefronts.) */
