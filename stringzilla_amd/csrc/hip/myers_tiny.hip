@@ -293,7 +293,7 @@ __device__ __forceinline__ void tiny_body(szs_tape_t const &queries, szs_tape_t 
     __shared__ u32 listed_count, listed_longest;
 
     u32 const tid = threadIdx.x;
-    u32 const blocks = (candidates.count + tiny_block_k - 1) / tiny_block_k;
+    u32 const blocks = (u32)(((u64)candidates.count + tiny_block_k - 1) / tiny_block_k);
     u32 const block = blockIdx.x % blocks, span = blockIdx.x / blocks;
     u32 const query_first = span * queries_per_workgroup;
     u32 const queries_here = queries.count - query_first < queries_per_workgroup ? queries.count - query_first : queries_per_workgroup;

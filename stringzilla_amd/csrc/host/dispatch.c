@@ -1087,7 +1087,7 @@ static sz_status_t cross_tiny(szs_call_t *call, uint32_t planner_mode, szs_plan_
     }
     /* ONE launch: the tiny tokens and, in their shadow, the few longer ones (hip/myers_tiny.hip).  (Round 5's first design was four:
      * a pass that listed the longer strings and tabled the tiny ones' masks in device memory, the outliers' kernel, a pass that set
-     * the tables back, the tiny-token kernel - 100 us of kernels on 4096 x 4096 words of text where the one launch takes 92.) */
+     * the tables back, the tiny-token kernel - 100 us of kernels on 4096 x 4096 words of text where the one launch takes 81.) */
     if (error == hipSuccess) {
         error = (hipError_t)szs_hip_levenshtein_tiny(&q_tape, &c_tape, (uint64_t *)call->device_results, call->device_stride, (uint32_t *)unfit, sequence,
                                                            (unsigned long long *)symbols, trace, szs_tuning_get(szs_knob_tiny_k) == 2, stream);
@@ -1116,16 +1116,6 @@ static sz_status_t cross_tiny(szs_call_t *call, uint32_t planner_mode, szs_plan_
                 first = ticks[slots * w] < first ? ticks[slots * w] : first, last = ticks[slots * w + last_slot] > last ? ticks[slots * w + last_slot] : last;
                 for (size_t k = 1; k < slots; ++k)
                     if (ticks[slots * w + k] && ticks[slots * w + k - 1]) sums[k] += (double)(ticks[slots * w + k] - ticks[slots * w + k - 1]);
-            }
-            if (getenv("SZS_TRACE_DUMP")) { /* every workgroup's stamps, relative to the first begin, in 10 ns ticks */
-                FILE *const dump = fopen(getenv("SZS_TRACE_DUMP"), "w");
-                for (size_t w = 0; dump && w < trace_workgroups; ++w) {
-                    if (!ticks[slots * w] || !ticks[slots * w + last_slot]) continue;
-                    fprintf(dump, "%zu", w);
-                    for (size_t k = 0; k <= last_slot; ++k) fprintf(dump, " %lld", ticks[slots * w + k] ? (long long)(ticks[slots * w + k] - first) : -1ll);
-                    fprintf(dump, "\n");
-                }
-                if (dump) fclose(dump);
             }
             uint64_t last_begin = 0, longest_life = 0, first_end = ~0ull;
             double lives = 0;
