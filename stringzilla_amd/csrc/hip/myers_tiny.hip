@@ -21,9 +21,9 @@
  *    whole group (R / 4 ds_read_b128).  Built with LDS atomics from bytes the threads fetched one group ahead, and un-built (the
  *    same dwords cleared) instead of zeroing the table per group.
  *  - A workgroup owns 256 CONSECUTIVE candidates (a block of result columns) and walks a span of the queries.  Candidates are
- *    only sorted INSIDE the block (a counting sort of 256 lengths in LDS; wavefront w of workgroup b takes the (w + b) % 4-th
- *    quarter, so that the longest quarter does not always land on the same SIMD): each wavefront gets texts of near-equal length
- *    and a query's 256 results still form one contiguous 2 KB run of its row.  The candidate's bytes live in four registers.
+ *    only sorted INSIDE the block (a counting sort of 256 lengths in LDS; wavefront w takes the w-th quarter): each wavefront
+ *    gets texts of near-equal length and a query's 256 results still form one contiguous 2 KB run of its row.  The candidate's
+ *    bytes live in four registers.
  *  - Results go through LDS, a byte each (a distance of two tiny tokens is at most 16): `out[j][candidate of the block]` packs
  *    four queries; then every wavefront writes 512 contiguous bytes per row.
  *
@@ -32,7 +32,7 @@
  *  of the group's columns - one long URL in a wavefront holds its sixty-three neighbours and, through the workgroup's barriers,
  *  the other three wavefronts for ten times their own work: 441 us for 4096 x 4096 words of text.  Round 5's first design
  *  listed them in a pass over the tapes and scored them in a kernel of their own from masks tabled in device memory: four
- *  launches, 100 us; the one launch: 92.)
+ *  launches, 100 us; the one launch: 81.)
  */
 #include "myers_core.hpp"
 
