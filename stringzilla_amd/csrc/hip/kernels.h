@@ -190,6 +190,7 @@ size_t szs_hip_levenshtein_myers_queue_table_bytes(int runes);
  *  leave `*unfit = unfit_sequence` in pinned host memory: the caller then scores the call the ordinary way.  `symbols_out` (pinned, or NULL): [0] the bytes of the queries' tape, [1] of the candidates' - their
  *  product is the call's cells.
  */
+#define SZS_TINY_LONGEST 255u /* bytes of the longest string that launch scores (a distance fits a byte of its staging rows) */
 typedef struct szs_tape_t {
     void const *offsets;
     uint64_t base; /* address of the tape's bytes */

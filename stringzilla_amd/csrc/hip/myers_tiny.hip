@@ -97,7 +97,7 @@ __device__ __forceinline__ void tiny_column(u32 &vp, u32 &vn, u32 eq) {
  *  No list, no table in device memory, nothing to set back.  Malformed offsets, a string beyond 255 bytes, or a block / span of
  *  which more than a quarter is long leave `*unfit = unfit_sequence` (pinned memory) and the host scores the call the ordinary way.
  */
-constexpr u32 tiny_longest_k = 255; // bytes of the longest string this kernel scores: a distance fits a byte of `out`
+constexpr u32 tiny_longest_k = SZS_TINY_LONGEST; // bytes of the longest string this kernel scores: a distance fits a byte of `out`
 
 /**
  *  A long candidate's bytes, HELD by the R lanes of a cluster: lane e of the cluster keeps the text's dwords e, R + e, 2 R + e ...
@@ -173,17 +173,25 @@ __device__ __forceinline__ void tiny_long_queries(u32 *peq, u32 *out, u64 const 
 #pragma unroll 1
     for (u32 first = 0; first < listed_count; first += per_round) {
         u32 const here = listed_count - first < per_round ? listed_count - first : per_round;
-        // ---- the round's tables: thread p ORs bit `pad + p` of pattern r into the row of the pattern's p-th byte
-#pragma unroll 1
-        for (u32 r = 0; r < here; ++r) {
-            u32 const q = listed[first + r];
-            u64 const from = query_offsets[q];
-            u32 const length = (u32)(query_offsets[q + 1] - from);
-            if (tid < length) {
-                u32 const byte = reinterpret_cast<u8 const *>(queries.base + from)[tid], bit = rows_k - length + tid;
-                atomicOr(&peq[(r * 256u + byte) * words_ + (bit >> 5)], 1u << (bit & 31u));
+        // ---- the round's tables: thread p ORs bit `pad + p` of pattern r into the row of the pattern's p-th byte (all of the round's
+        //      bytes are requested before the first of them is used: one round trip to the L2, not one per pattern)
+        u32 bytes_of[per_round];
+#pragma unroll
+        for (u32 r = 0; r < per_round; ++r) {
+            bytes_of[r] = 0x100u;
+            if (r < here) {
+                u32 const q = listed[first + r];
+                u64 const from = query_offsets[q];
+                if (tid < (u32)(query_offsets[q + 1] - from)) bytes_of[r] = reinterpret_cast<u8 const *>(queries.base + from)[tid];
             }
         }
+#pragma unroll
+        for (u32 r = 0; r < per_round; ++r)
+            if (bytes_of[r] < 0x100u) {
+                u32 const q = listed[first + r];
+                u32 const bit = rows_k - (u32)(query_offsets[q + 1] - query_offsets[q]) + tid;
+                atomicOr(&peq[(r * 256u + bytes_of[r]) * words_ + (bit >> 5)], 1u << (bit & 31u));
+            }
         __syncthreads();
         // ---- B: this lane's tiny candidate under every pattern of the round
 #pragma unroll 1

@@ -1052,6 +1052,9 @@ static int tiny_shaped(szs_engine_s const *engine, int symmetric, szs_side_stats
     int const knob = szs_tuning_get(szs_knob_tiny_k);
     if (symmetric || !engine->is_unit_cost || knob == 0) return 0;
     if (engine->family != szs_family_levenshtein_k && engine->family != szs_family_levenshtein_utf8_k /* an ASCII corpus */) return 0;
+    /* a string beyond that launch's 255 bytes (an occasional long line among the words: the planner's summary knows the longest) - the
+     * launch would refuse the call after scoring most of it, every call again */
+    if (queries->longest > SZS_TINY_LONGEST || candidates->longest > SZS_TINY_LONGEST) return 0;
     if (knob > 0) return 1;
     /* word-like: mean length well under the sixteen rows of that kernel's bit-vectors (what is longer - a few per cent of a text's
      * tokens - rides along in the same launch; the kernel itself says when a string is beyond it) and a matrix worth a launch */
