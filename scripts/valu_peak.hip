@@ -176,6 +176,39 @@ __global__ __launch_bounds__(256) void k_myers_pure(uint32_t *out, uint32_t seed
     if (sum == 0x12345678u) out[0] = sum;
 }
 
+/* The tiny-token launch's column (hip/myers_tiny.hip: `tiny_column`): two 16-row patterns to a register, R registers a lane, one
+ * column of a text per step - on register-resident masks, no LDS, no barriers: the issue ceiling of that launch's columns. */
+typedef unsigned short probe_pk_u16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void tiny_column_probe(uint32_t &vp, uint32_t &vn, uint32_t eq) {
+    uint32_t const xv = eq | vn;
+    probe_pk_u16 const sum16 = __builtin_bit_cast(probe_pk_u16, eq & vp) + __builtin_bit_cast(probe_pk_u16, vp);
+    uint32_t const sum = __builtin_bit_cast(uint32_t, sum16);
+    uint32_t const d0 = (sum ^ vp) | eq;
+    uint32_t const hp = vn | ~(d0 | vp);
+    uint32_t const hn = vp & d0;
+    probe_pk_u16 const hp16 = __builtin_bit_cast(probe_pk_u16, hp) << (probe_pk_u16)(1), hn16 = __builtin_bit_cast(probe_pk_u16, hn) << (probe_pk_u16)(1);
+    uint32_t const hp_shifted = __builtin_bit_cast(uint32_t, hp16) | 0x00010001u, hn_shifted = __builtin_bit_cast(uint32_t, hn16);
+    vp = hn_shifted | ~(xv | hp_shifted);
+    vn = hp_shifted & xv;
+}
+template <int registers_>
+__global__ __launch_bounds__(256, 4) void k_tiny_pure(uint32_t *out, uint32_t seed, int iterations) {
+    uint32_t vp[registers_], vn[registers_], eq[4][registers_];
+    for (int d = 0; d < registers_; ++d) {
+        vp[d] = ~0u, vn[d] = 0;
+        for (int k = 0; k < 4; ++k) eq[k][d] = (seed * (d + 3) + threadIdx.x * 2654435761u) >> (k * 3 + (blockIdx.x & 3));
+    }
+    for (int i = 0; i < iterations; ++i) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int d = 0; d < registers_; ++d) tiny_column_probe(vp[d], vn[d], eq[k][d]);
+    }
+    uint32_t sum = 0;
+    for (int d = 0; d < registers_; ++d) sum ^= vp[d] ^ vn[d];
+    if (sum == 0x12345678u) out[0] = sum;
+}
+
 template <typename kernel_t>
 static double time_kernel(kernel_t kernel, uint32_t *out, int iterations, int blocks) {
     hipEvent_t start, stop;
@@ -256,6 +289,12 @@ int main() {
         printf(", \"myers_block_addshift_W4_Tcells\": %.2f", base * 128 / time_kernel((k_myers_block<4, true>), out, columns / 16, blocks) / 1e12);
         printf(", \"myers_block_W8_Tcells\": %.2f", base * 256 / time_kernel((k_myers_block<8, false>), out, columns / 16, blocks) / 1e12);
         printf(", \"myers_block_addshift_W8_Tcells\": %.2f", base * 256 / time_kernel((k_myers_block<8, true>), out, columns / 16, blocks) / 1e12);
+    }
+    {   /* pair-columns per second: one step of a lane = one text column under 2 R patterns (hip/myers_tiny.hip) */
+        int const columns = 1600, tiny_blocks = cus * 4; /* four workgroups a CU, as that launch runs */
+        double const base = (double)tiny_blocks * 256 * columns;
+        printf(", \"tiny_pure_R16_Tpair_columns\": %.3f", base * 32 / time_kernel(k_tiny_pure<16>, out, columns / 4, tiny_blocks) / 1e12);
+        printf(", \"tiny_pure_R8_Tpair_columns\": %.3f", base * 16 / time_kernel(k_tiny_pure<8>, out, columns / 4, tiny_blocks) / 1e12);
     }
     double const lds_reads = (double)blocks * 256 * iterations * INNER;
     printf(", \"ds_read_b128_random95_Tlane_reads\": %.3f", lds_reads / time_kernel(k_lds_b128<1>, out, iterations, blocks) / 1e12);
