@@ -357,6 +357,28 @@ def roofline(config, profile, kernel_seconds, traffic_override=None):
     return record
 
 
+def words_roofline(counted, bytes_moved, kernel_seconds, launches, planner_mode, peaks):
+    """Config 10's record: the HBM-shaped figures (`bytes_moved` = the results matrix + both tapes + offsets, once) over the kernel
+    time, beside what the committed PMC passes of this config saw (`counted` = roofline()'s record: HBM bytes per call, VALU issue,
+    staleness) and - `issue_floor` - the launch's own wavefront-instructions at the pace its column update issues at when nothing
+    else is in the way (`peaks` = profiles/rNN/valu_peak.json, scripts/valu_peak.hip: 192 instructions a wavefront-column of 2048
+    pair-columns, 1024 SIMDs)."""
+    record = {"bound": "hbm", "achieved": round(bytes_moved / kernel_seconds / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+              "frac": round(bytes_moved / kernel_seconds / 1e9 / HBM_PEAK_GBPS, 4), "algorithmic_bytes": int(bytes_moved),
+              "algorithmic_bytes_are": "the results matrix + both tapes + offsets, once", "kernel_ms": round(kernel_seconds * 1e3, 4),
+              "launches_per_step": launches, "traffic": counted.get("traffic"), "pmc_stale": counted.get("pmc_stale"),
+              "pmc_source": counted.get("pmc_source"), "kernel": counted.get("kernel", "levenshtein_tiny_kernel"), "planner_mode": planner_mode}
+    valu = counted.get("valu")
+    if valu:
+        record["valu"] = valu
+    pace = (peaks or {}).get("tiny_pure_R16_Tpair_columns")
+    if valu and pace and valu.get("wave_instructions_per_call"):
+        floor_seconds = valu["wave_instructions_per_call"] * 2048.0 / (pace * 1e12) / 192.0
+        record["issue_floor"] = {"bound": "its own instructions at the measured pace of its column (valu_peak.hip)",
+                                 "floor_ms": round(floor_seconds * 1e3, 4), "frac": round(floor_seconds / kernel_seconds, 4)}
+    return record
+
+
 def time_config(step, engine, budget_seconds, fence, floor=2, ceiling=50):
     """Warm-up call, then as many timed calls as `budget_seconds` allows; returns (wall s per call, kernel s per call)."""
     step()
@@ -401,23 +423,7 @@ def measure_extra(config, scope, device_index, args, fence, with_cpu):
         # Tiny tokens: the one regime of this path where HBM is the roofline that binds - the RESULT MATRIX (8 bytes a pair against
         # ~13 bytes of strings per pair-row).  Algorithmic bytes here = results + both tapes + their offsets, once each.
         bytes_moved = len(queries) * len(candidates) * 8 + int(load.queries.lengths().sum() + load.candidates.lengths().sum()) + 4 * (len(queries) + len(candidates) + 2)
-        counted = record["roofline"]  # what the committed PMC passes of this config saw: HBM bytes per call, VALU issue, staleness
-        record["roofline"] = {"bound": "hbm", "achieved": round(bytes_moved / kernel / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                              "frac": round(bytes_moved / kernel / 1e9 / HBM_PEAK_GBPS, 4), "algorithmic_bytes": bytes_moved,
-                              "algorithmic_bytes_are": "the results matrix + both tapes + offsets, once", "kernel_ms": round(kernel * 1e3, 4),
-                              "launches_per_step": int(profile.launches), "traffic": counted.get("traffic"),
-                              "pmc_stale": counted.get("pmc_stale"), "pmc_source": counted.get("pmc_source"),
-                              "kernel": counted.get("kernel", "levenshtein_tiny_kernel"), "planner_mode": int(profile.planner)}
-        if "valu" in counted:
-            record["roofline"]["valu"] = counted["valu"]
-        peaks, _ = _profile_json("valu_peak.json")  # scripts/valu_peak.hip: that launch's packed column on register-resident masks
-        if peaks and "tiny_pure_R16_Tpair_columns" in peaks and "valu" in counted:
-            # the launch's own instruction floor: its wavefront-instructions at the pace its column update issues at when nothing else
-            # is in the way (192 instructions a wavefront-column of 2048 pair-columns)
-            seconds_per_instruction = 2048.0 / (peaks["tiny_pure_R16_Tpair_columns"] * 1e12) / 192.0 * 1024.0  # per SIMD; 1024 SIMDs
-            floor_seconds = counted["valu"]["wave_instructions_per_call"] * seconds_per_instruction / 1024.0
-            record["roofline"]["issue_floor"] = {"bound": "its own instructions at the measured pace of its column (valu_peak.hip)",
-                                                 "floor_ms": round(floor_seconds * 1e3, 4), "frac": round(floor_seconds / kernel, 4)}
+        record["roofline"] = words_roofline(record["roofline"], bytes_moved, kernel, int(profile.launches), int(profile.planner), _profile_json("valu_peak.json")[0])
     if with_cpu:  # timed later, after every GPU measurement of the run (the host cores are busy for ~10 s per baseline); the
         # matrix stays in HBM until then - downloading 80 MB here would idle the shader engines right before the headline
         record["_cpu_baseline_inputs"] = (load, results)

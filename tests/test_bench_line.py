@@ -96,3 +96,20 @@ def test_more_gpus_than_the_box_has_is_a_parseable_error_not_a_traceback():
     line = json.loads(done.stdout.strip().splitlines()[-1])
     assert "error" in line and line["n_gpus"] == 2 and line["visible_gpus"] == 0
     assert "Traceback" not in done.stderr
+
+
+def test_the_words_record_prices_the_launch_against_its_traffic_and_its_own_instructions():
+    """Config 10's `roofline` (bench.words_roofline): HBM-shaped - the results matrix is the algorithmic traffic - beside the counter
+    traffic, the staleness flag and the VALU figures of the committed PMC passes, and `issue_floor` from the measured pace of the
+    launch's own column; with nothing committed (no counters, no microbenchmark) it still builds."""
+    counted = {"traffic": 135023224, "pmc_stale": False, "pmc_source": "profiles/r05/pmc_configs.json", "kernel": "levenshtein_tiny_kernel",
+               "valu": {"frac": 0.43, "wave_instructions_per_call": 31206548, "lane_ops_per_cell": 2.65}}
+    record = bench.words_roofline(counted, 134305451, 78.1e-6, 1, 5, {"tiny_pure_R16_Tpair_columns": 6.301})
+    assert record["bound"] == "hbm" and record["unit"] == "GB/s" and record["algorithmic_bytes"] == 134305451
+    assert abs(record["achieved"] - 134305451 / 78.1e-6 / 1e9) < 0.1 and abs(record["frac"] - record["achieved"] / 8000.0) < 1e-3
+    assert record["traffic"] == 135023224 and record["pmc_stale"] is False and record["launches_per_step"] == 1 and record["planner_mode"] == 5
+    # 31.2 M wavefront-instructions x 2048 pair-columns / 192 instructions / 6.301e12 pair-columns a second = 52.8 us of issue
+    assert abs(record["issue_floor"]["floor_ms"] - 0.0528) < 0.0005 and 0.6 < record["issue_floor"]["frac"] < 0.75
+    bare = bench.words_roofline({"pmc_stale": None}, 134305451, 78.1e-6, 1, 5, None)
+    assert bare["traffic"] is None and "valu" not in bare and "issue_floor" not in bare and bare["kernel"] == "levenshtein_tiny_kernel"
+    json.dumps(record), json.dumps(bare)
