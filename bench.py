@@ -49,7 +49,7 @@ HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 # The binding resource of this path is integer VALU issue, not HBM.  Its ceiling is MEASURED, not quoted: the Myers
 # column update (the kernel's exact instruction mix) on register-resident match masks, no LDS and no memory, sustains
 # this many DP cells per second at full bit-vector width on one MI355X (scripts/valu_peak.hip -> profiles/).
-PROFILE_DIRS = [os.path.join(ROOT, "profiles", name) for name in ("r05", "r04", "r03", "r02", "r01")]
+PROFILE_DIRS = [os.path.join(ROOT, "profiles", name) for name in ("r06", "r05", "r04", "r03", "r02", "r01")]
 # VALU issue ceiling, class-weighted: gfx950's SIMDs are 32 lanes wide, a full-rate VALU instruction (32-bit add / sub / logic /
 # right shift / move) takes a wavefront 2 cycles, every other one (maxima, packed 16-bit, carries, funnel shifts, VOP3 three-
 # operand forms, DPP) 4 - MI355X_MICROARCH.md "Wave scheduling", measured per opcode by scripts/valu_peak.hip.  A main loop of F
@@ -65,6 +65,15 @@ def _profile_json(name):
                 return json.load(handle), os.path.relpath(os.path.join(directory, name), ROOT)
         except (OSError, ValueError):
             continue
+    return None, None
+
+
+def _by_prefix(table, prefix):
+    """The entry of a committed summary whose key is `prefix` or `prefix<...>` (kernel templates are keyed with their arguments:
+    round 5 looked `cfg11:fingerprint_segments_kernel` up by its bare name, found nothing and printed an ESTIMATE at frac 1.16)."""
+    for key in sorted(table or {}):
+        if key == prefix or key.startswith(prefix + "<"):
+            return key, table[key]
     return None, None
 
 
@@ -93,6 +102,10 @@ def parse_args():
                              "BEFORE the headline; the LAST stdout line is the headline alone, under 4 KB)")
     parser.add_argument("--extra-scale", type=float, default=1.0,
                         help="testing aid: shrinks the matrix side of the `configs` records (1.0 = BASELINE.json's sizes)")
+    parser.add_argument("--verify-seconds", type=float, default=8.0,
+                        help="CPU time budget per config for checking the timed batch CELL FOR CELL against the reference's engines (the "
+                             "reference's own bench does, bench/similarities.cuh:410-423): the whole matrix when the checker's measured rate "
+                             "says it fits, else as many whole rows, evenly spaced over the queries, as do")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--fingerprints-only", action="store_true",
                         help="time `szs_fingerprints_u32tape` alone and print its record (what scripts/profile_configs.sh runs as config 11)")
@@ -202,7 +215,7 @@ def make_step(engine, scope, load, queries, candidates, results, device_index):
 
 # ---- the reference's CPU engines beside it ---------------------------------------------------------------------------------
 
-def cpu_baseline(load, gpu_matrix, seconds, cell_bits=0, with_serial=True):
+def cpu_baseline(load, gpu_matrix, seconds, cell_bits=0, with_serial=True, verify_seconds=0.0):
     """Times the reference's own CPU engines (best SIMD tier, all host threads) on a BOUNDED sample of the same batch -
     evenly spaced query rows x evenly spaced candidates, sized from its first (verified) run to about `seconds` of CPU work,
     the whole batch when that fits - and checks that they produce the very cells the GPU produced.  Test-infrastructure
@@ -281,7 +294,37 @@ def cpu_baseline(load, gpu_matrix, seconds, cell_bits=0, with_serial=True):
         "sample": (f"full {len(q_lengths)}x{len(c_lengths)} batch" if whole else f"{len(rows)} spaced rows x {len(columns)} spaced candidates")
                   + f"; median of {len(runs)} runs" + (f" x {passes} passes" if passes > 1 else "") + "; cells verified equal to the GPU's",
         "sample_rows": len(rows), "sample_columns": len(columns), "runs": len(runs), "passes_per_run": passes, "verified": True,
+        # how much of the host the sample keeps busy: the shim deals contiguous row blocks to threads, a thread scores its rows against
+        # lane groups of 16 / 64 candidates (a sample of one row per thread x one lane group reads far below a whole batch: say so)
+        "threads_busy": int(min(cores, len(rows))), "rows_per_thread": round(len(rows) / max(1, min(cores, len(rows))), 2),
+        "lane_groups_per_row": round(len(columns) / lanes, 2),
     }
+    # ---- the timed batch CELL FOR CELL (bench/similarities.cuh:410-423 checks every batch it times), once and untimed: the whole
+    # matrix when the checker's measured rate says it fits `verify_seconds`, else as many WHOLE rows - evenly spaced over the
+    # queries, never fewer than 64 - as do.  The candidates take the row role in the checker (its threads share rows; 64 rows would
+    # keep 64 of 256 threads busy) - every table and cost scheme of these configs is symmetric, so the matrix is the transpose.
+    if whole:
+        record["checked"] = {"whole_matrix": True, "rows": len(q_lengths), "columns": len(c_lengths)}
+    elif verify_seconds > 0:
+        everything, every_column = np.arange(len(q_lengths)), np.arange(len(c_lengths))
+        rate = cells_of(rows, columns) / max(elapsed, 1e-6)
+        per_row = cells_of(everything, every_column) / max(len(q_lengths), 1)
+        take = int(min(len(q_lengths), max(min(64, len(q_lengths)), rate * verify_seconds / max(per_row, 1.0))))
+        check_rows = everything if take >= len(q_lengths) else spaced(len(q_lengths), take)
+        started = time.perf_counter()
+        candidates_as_rows = [load.candidates[int(j)] for j in every_column]
+        picked = [load.queries[int(i)] for i in check_rows]
+        if load.kind == "levenshtein":
+            transposed = checker.levenshtein(candidates_as_rows, picked, **load.costs)
+        elif load.kind == "levenshtein_utf8":
+            transposed = checker.levenshtein_utf8(candidates_as_rows, picked, **load.costs)
+        else:
+            scorer = checker.needleman_wunsch if load.kind == "needleman_wunsch" else checker.smith_waterman
+            transposed = scorer(candidates_as_rows, picked, *matrices.by_name(load.table), **load.costs)
+        wrong = int((transposed.T.view(np.int64) != gpu_matrix[check_rows].view(np.int64)).sum())
+        assert wrong == 0, f"{wrong} cells of {load.name} differ from the reference's"
+        record["checked"] = {"whole_matrix": len(check_rows) == len(q_lengths), "rows": len(check_rows), "columns": len(c_lengths),
+                             "seconds": round(time.perf_counter() - started, 2)}
     # the reference reports its Serial engine beside the SIMD tiers (similarities/README.md:21-24): ONE thread of the serial tier
     # on a sample of about a second (four rows, one lane group of candidates)
     if with_serial and kind == "reference":
@@ -304,7 +347,7 @@ def cpu_baseline(load, gpu_matrix, seconds, cell_bits=0, with_serial=True):
 
 # ---- rooflines -------------------------------------------------------------------------------------------------------------
 
-def roofline(config, profile, kernel_seconds, traffic_override=None):
+def roofline(config, profile, kernel_seconds, traffic_override=None, leg=None):
     """HBM roofline from the ALGORITHMIC bytes of one call over the kernel time measured live (hipEvent pair on the library's
     stream), beside what the committed rocprofv3 --pmc passes of this same command saw: HBM bytes actually moved per call
     (`traffic`: (FETCH_SIZE + WRITE_SIZE) x 1024 summed over the kernels of one call, raw) and - what actually binds this path -
@@ -316,7 +359,12 @@ def roofline(config, profile, kernel_seconds, traffic_override=None):
               "algorithmic_bytes": int(profile.algorithmic_bytes), "launches_per_step": int(profile.launches),
               "kernel_gcups": round(profile.cells / kernel_seconds / 1e9, 1)}
     summary, where = _profile_json("pmc_configs.json")  # "cfgN:kernel" and "cfgN:__call__" (scripts/pmc_configs.py)
-    call = (summary or {}).get(f"cfg{config}:__call__")
+    # `leg`: a config whose calls are of two kinds (config 2: "fresh" batches run the launch that plans itself, "same_tapes" the plain
+    # one behind the guard) has one record per kind beside the blend of the run the counters were taken on (scripts/pmc_configs.py);
+    # the counters joined to a timed leg are those of the kernel THAT leg launches
+    call = (summary or {}).get(f"cfg{config}:__call__@{leg}") if leg else None
+    record["pmc_leg"] = leg if call else None
+    call = call or (summary or {}).get(f"cfg{config}:__call__")
     counted_on = (summary or {}).get("_library_sha256")
     # pmc_stale True: the counters below were taken on another build of the library than the one this run executes
     record["pmc_stale"] = None if not counted_on else counted_on != library_digest()
@@ -430,6 +478,57 @@ def measure_extra(config, scope, device_index, args, fence, with_cpu):
     return record
 
 
+def fingerprints_roofline(text_bytes, dimensions, documents, wall, summary, where, mixes, digest):
+    """The VALU pricing of `szs_fingerprints_u32tape`'s record from the committed passes (`summary` = pmc_configs.json, `mixes` =
+    opcode_mix.json; keys looked up by PREFIX - the kernel is a template): instructions COUNTED by the PMC pass of this very call
+    when there is one, else estimated from the assembly's main loop (four positions an iteration) and labelled so."""
+    _, counters = _by_prefix(summary, "cfg11:fingerprint_segments_kernel")
+    counted = (counters or {}).get("SQ_INSTS_VALU")
+    mix_key, mix = _by_prefix(mixes, "fingerprint_segments_kernel")
+    ceiling = mix["ceiling_Tlane_ops_per_s"] * 1e12 if mix else VALU_HALF_RATE_PEAK
+    if counted:
+        lane_ops, how = counted * 64.0, f"PMC: SQ_INSTS_VALU of the segments kernel, {where}"
+    else:
+        per_position = mix["valu_instructions"] / 4.0 if mix else 25.0
+        lane_ops, how = per_position * text_bytes * dimensions, "ESTIMATE: main loop of the assembly / 4 positions" if mix else "ESTIMATE: 25 assumed"
+    counted_on = (summary or {}).get("_library_sha256")
+    moved = text_bytes + 8 * dimensions * documents
+    return {"bound": "int / fp64 VALU issue", "counted": how, "kernel": mix_key or "fingerprint_segments_kernel",
+            "lane_ops_per_byte_and_dimension": round(lane_ops / (text_bytes * dimensions), 2),
+            "pmc_stale": None if not (counted and counted_on) else counted_on != digest,
+            "achieved_Tlane_ops_per_s": round(lane_ops / wall / 1e12, 2), "peak_Tlane_ops_per_s": round(ceiling / 1e12, 2),
+            "frac": round(lane_ops / wall / ceiling, 4),
+            "hbm": {"algorithmic_bytes": moved, "achieved_gb_s": round(moved / wall / 1e9, 2), "peak": HBM_PEAK_GBPS}}
+
+
+def fingerprints_cpu_baseline(texts, dimensions, gpu_hashes, gpu_counts, seconds):
+    """The reference's own SIMD hashers (`floating_rolling_hashers<sz_cap_skylake_k / haswell / serial, 64>` through oracle/_ref,
+    documents dealt over every host thread) on a BOUNDED sample of the same documents, their sketches compared with the GPU's."""
+    from oracle import binding
+
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    tier = binding.reference_best_tier()
+    documents = [texts[i] for i in range(len(texts))]
+
+    def run(count):
+        started = time.perf_counter()
+        hashes, counts, ran = binding.reference_fingerprints_tiered(documents[:count], dimensions, tier, cores)
+        elapsed = time.perf_counter() - started
+        assert np.array_equal(hashes, gpu_hashes[:count]) and np.array_equal(counts, gpu_counts[:count]), "CPU and GPU fingerprints differ"
+        return elapsed, ran
+
+    count = min(len(documents), max(cores, 1))  # a document per thread first; then as many as the budget holds
+    first, ran = run(count)
+    count = int(min(len(documents), max(count, count * seconds / 3 / max(first, 1e-4))))
+    runs = [run(count)[0] for _ in range(3)]
+    elapsed = float(np.median(runs))
+    sample_bytes = sum(len(document) for document in documents[:count])
+    return {"value": round(sample_bytes * dimensions / elapsed / 1e12, 4), "unit": "10^12 byte-dimensions/s", "cores": cores, "kind": "reference",
+            "tier": {0: "serial", 1: "haswell (AVX2)", 2: "skylake (AVX-512)"}[ran], "threads_busy": int(min(cores, count)),
+            "sample": f"the first {count} of {len(documents)} documents, {dimensions} dimensions; median of {len(runs)} runs; sketches verified equal to the GPU's",
+            "verified": True}
+
+
 def measure_fingerprints(scope, device_index, args, fence):
     """`szs_fingerprints_u32tape`: rolling MinHash over 1024 documents of ~10 KB, 1024 dimensions of the
     reference's default window widths - bytes of text per second and byte-dimensions per second of the whole C-ABI call.  The
@@ -474,40 +573,36 @@ def measure_fingerprints(scope, device_index, args, fence):
         walls.append((time.perf_counter() - started) / repeats)
     wall = min(walls)
     text_bytes = int(texts.lengths().sum())
-    # VALU work: counted by a committed PMC pass of this very call when there is one (`cfg11:fingerprint_segments_kernel`,
-    # scripts/profile_configs.sh 11), else estimated from the kernel's assembly (its main loop is unrolled over four positions)
     summary, where = _profile_json("pmc_configs.json")
-    counted = (summary or {}).get("cfg11:fingerprint_segments_kernel", {}).get("SQ_INSTS_VALU")
-    mixes, mix_where = _profile_json("opcode_mix.json")
-    mix = (mixes or {}).get("fingerprint_segments_kernel")
-    ceiling = mix["ceiling_Tlane_ops_per_s"] * 1e12 if mix else VALU_HALF_RATE_PEAK
-    if counted:
-        lane_ops, how = counted * 64.0, f"PMC: SQ_INSTS_VALU of the segments kernel, {where}"
-    else:
-        per_position = mix["valu_instructions"] / 4.0 if mix else 25.0
-        lane_ops, how = per_position * text_bytes * dimensions, "ESTIMATE: main loop of the assembly / 4 positions" if mix else "ESTIMATE: 25 assumed"
-    counted_on = (summary or {}).get("_library_sha256")
-    return {"config": "fingerprints", "workload": "1024 ASCII documents of 8-12 KB, 1024 dimensions, default window widths",
-            "entry_point": "szs_fingerprints_u32tape", "n_gpus": 1, "steps": repeats, "ms_per_step": round(wall * 1e3, 3),
-            "passes_ms": [round(w * 1e3, 3) for w in walls],
-            "value": round(text_bytes * dimensions / wall / 1e12, 3), "unit": "10^12 byte-dimensions/s",
-            "text_gb_s": round(text_bytes / wall / 1e9, 2), "results_checksum": int(outputs[0].to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item() % (1 << 53)),
-            "roofline": {"bound": "int / fp64 VALU issue", "counted": how,
-                         "lane_ops_per_byte_and_dimension": round(lane_ops / (text_bytes * dimensions), 2),
-                         "pmc_stale": None if not (counted and counted_on) else counted_on != library_digest(),
-                         "achieved_Tlane_ops_per_s": round(lane_ops / wall / 1e12, 2), "peak_Tlane_ops_per_s": round(ceiling / 1e12, 2),
-                         "frac": round(lane_ops / wall / ceiling, 4),
-                         "hbm": {"algorithmic_bytes": text_bytes + 8 * dimensions * len(texts), "achieved_gb_s": round((text_bytes + 8 * dimensions * len(texts)) / wall / 1e9, 2),
-                                 "peak": HBM_PEAK_GBPS}}}
+    mixes, _ = _profile_json("opcode_mix.json")
+    record = {"config": "fingerprints", "workload": "1024 ASCII documents of 8-12 KB, 1024 dimensions, default window widths",
+              "entry_point": "szs_fingerprints_u32tape", "n_gpus": 1, "steps": repeats, "ms_per_step": round(wall * 1e3, 3),
+              "passes_ms": [round(w * 1e3, 3) for w in walls],
+              "value": round(text_bytes * dimensions / wall / 1e12, 3), "unit": "10^12 byte-dimensions/s",
+              "text_gb_s": round(text_bytes / wall / 1e9, 2), "results_checksum": int(outputs[0].to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item() % (1 << 53)),
+              "roofline": fingerprints_roofline(text_bytes, dimensions, len(texts), wall, summary, where, mixes, library_digest())}
+    if not args.no_cpu_baseline:  # timed later, with the other CPU baselines, after every GPU measurement of the run
+        record["_fingerprints_inputs"] = (texts, dimensions, outputs)
+    return record
 
 
-def attach_cpu_baselines(records, seconds):
+def attach_cpu_baselines(records, seconds, verify_seconds=0.0):
     for record in records:
+        sketched = record.pop("_fingerprints_inputs", None)
+        if sketched is not None:
+            try:
+                sketches = sketched[2].cpu().numpy().view(np.uint32)
+                record["cpu_baseline"] = fingerprints_cpu_baseline(sketched[0], sketched[1], sketches[0], sketches[1], seconds)
+            except AssertionError:
+                raise
+            except Exception as problem:  # the checker is optional equipment; the GPU numbers stand without it
+                record["cpu_baseline"] = {"error": repr(problem)}
         inputs = record.pop("_cpu_baseline_inputs", None)
         if inputs is None:
             continue
         try:
-            record["cpu_baseline"] = cpu_baseline(inputs[0], inputs[1].cpu().numpy(), seconds, cell_bits=record.get("cell_bits", 0), with_serial=False)
+            record["cpu_baseline"] = cpu_baseline(inputs[0], inputs[1].cpu().numpy(), seconds, cell_bits=record.get("cell_bits", 0), with_serial=False,
+                                                  verify_seconds=verify_seconds)
         except AssertionError:
             raise
         except Exception as problem:  # the checker is optional equipment; the GPU numbers stand without it
@@ -539,7 +634,8 @@ def measure_strong(config, scope, device_index, args, fence, dist, world, rank, 
     rows, local = node(load.queries if rank == 0 else None, load.candidates if rank == 0 else None, source=0)
     profile = engine.last_call_profile()
     mine = torch.tensor([busy[0] if busy else 0.0, float(profile.cells) if busy else 0.0, float(len(rows)),
-                         float(local.sum()) if len(rows) else 0.0, state.get("kernel", 0.0)], dtype=torch.float64,
+                         float(local.sum()) if len(rows) else 0.0, state.get("kernel", 0.0),
+                         float(profile.algorithmic_bytes) if busy else 0.0], dtype=torch.float64,
                         device=where if dist.get_backend() == "nccl" else "cpu")
     gathered = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(gathered, mine)
@@ -547,7 +643,14 @@ def measure_strong(config, scope, device_index, args, fence, dist, world, rank, 
         return None
     seconds = np.array([float(g[0]) for g in gathered])
     cells = sum(float(g[1]) for g in gathered)
+    slowest_kernel = max(float(g[4]) for g in gathered)
+    moved = sum(float(g[5]) for g in gathered)  # algorithmic bytes of the whole batch: every rank's rows against every candidate
     return {
+        # the job's HBM roofline at N GPUs: the batch's algorithmic bytes over the SLOWEST rank's kernel time against N x 8 TB/s
+        "roofline": {"bound": "hbm", "achieved": round(moved / max(slowest_kernel, 1e-12) / 1e9, 2), "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
+                     "frac": round(moved / max(slowest_kernel, 1e-12) / 1e9 / (HBM_PEAK_GBPS * world), 6), "algorithmic_bytes": int(moved),
+                     "kernel_ms_slowest_rank": round(slowest_kernel * 1e3, 4)},
+        "kernel_gcups": round(cells / max(slowest_kernel, 1e-12) / 1e9, 1), "backend": dist.get_backend(), "ranks": dist.get_world_size(),
         "config": config, "workload": load.name, "entry_point": ENTRY_POINTS[load.kind], "n_gpus": world, "scaling": "strong",
         "sharding": "query rows dealt by LPT on len(query), both tapes replicated by RCCL broadcast, results stay sharded",
         "cells": int(cells), "rows_per_gpu": [int(g[2]) for g in gathered],
@@ -676,14 +779,16 @@ def main():
         torch.cuda.synchronize()
 
     if args.fingerprints_only:
-        print(json.dumps(measure_fingerprints(scope, local_rank, args, fence)), flush=True)
+        alone = [measure_fingerprints(scope, local_rank, args, fence)]
+        attach_cpu_baselines(alone, args.extra_cpu_seconds)
+        print(json.dumps(alone[0]), flush=True)
         return
     # ---- the other configs run BEFORE the headline's warm-up: a run of W = 5 short warm-up steps on a GPU that has idled
     # through the set-up is timed on its clock ramp (round 1: 64.4 TCUPS with 20 steps against 67.9 with 200); after seconds
     # of NW / SW scoring the clocks are where a busy GPU keeps them.  The headline itself is unchanged: W untimed steps, then
     # exactly K timed ones.  (The single-process C driver of N > 1 runs last, while the other ranks wait.)
     if args.extra_configs is None:
-        extras = [9, 3, 4, 5, 6, 7, 8, 10] if world == 1 else [4, 5]
+        extras = [9, 3, 4, 5, 6, 7, 8, 10] if world == 1 else [2, 4, 5]  # N > 1: the metric's own batch and the two 8-GPU configs, STRONG-scaled
     else:
         extras = [] if args.extra_configs.strip().lower() in ("", "none") else [int(x) for x in args.extra_configs.split(",")]
     records = []
@@ -753,10 +858,30 @@ def main():
         slowest = torch.tensor([elapsed], dtype=torch.float64, device=where)
         dist.all_reduce(slowest, op=dist.ReduceOp.MAX)
         elapsed = float(slowest)
+    # ---- every batch of the timed stream is CHECKED, outside the timed region (bench/similarities.cuh:410-423 checks every batch it
+    # times): (a) the stream is replayed - the same calls in the same order - with the matrix summed on the device after every call
+    # and compared with that batch's own sum; (b) below, on rank 0, each batch's whole matrix is compared cell for cell with the
+    # reference's engines (`cpu_baseline.checked`, `stream_check`)
+    sums_of_batches, matrices_of_batches = [], []
+    for one in steps_of:
+        one()
+        sums_of_batches.append(int(results.sum().item()))
+        if rank == 0 and not args.no_cpu_baseline and len(steps_of) > 1:
+            matrices_of_batches.append(results.cpu().numpy().copy())
+    replayed, replay_mismatches = min(args.steps, 200), 0
+    for index in range(replayed):
+        steps_of[index % len(steps_of)]()
+        replay_mismatches += int(results.sum().item()) != sums_of_batches[index % len(steps_of)]
+    assert replay_mismatches == 0, f"{replay_mismatches} of {replayed} replayed calls of the timed stream wrote another matrix"
     step()  # untimed: the headline batch's own matrix is what the checksum and the CPU baseline look at
 
     profile = engine.last_call_profile()
 
+    device_ids = torch.zeros(world, dtype=torch.float64, device=where)
+    device_ids[rank] = float(torch.cuda.current_device() + 1)
+    if world > 1:
+        dist.all_reduce(device_ids)
+    devices_in_use = len({int(v) for v in device_ids.tolist()})
     cells_per_rank = torch.tensor([timed_cells], dtype=torch.float64, device=where)  # over the K timed steps
     checksum = results.sum().reshape(1).to(torch.float64)
     if world > 1:
@@ -786,7 +911,10 @@ def main():
         pure = (valu_table or {}).get("myers_pure_W4_Tcells")
         lengths = load.queries.lengths().astype(np.int64)
         padded_cells = float((np.maximum(1, -(-lengths // 32)) * 32).sum()) * float(load.candidates.lengths().sum())
-        line_roofline = roofline(args.config, profile, kernel, args.hbm_traffic_bytes)
+        # the counters joined to the timed leg are those of the kernel THAT leg launches: fresh batches plan themselves inside the
+        # scoring launch (planner mode 4), the same tapes again run the plain launch behind the guard (mode 3)
+        leg = "fresh" if planners == {4} else "same_tapes" if planners == {3} else None
+        line_roofline = roofline(args.config, profile, kernel, args.hbm_traffic_bytes, leg=leg)
         try:  # device-to-device copy of 1 GiB on this box, read + write bytes over the best of five (torch, HIP events)
             line_roofline["peak_measured"] = measured_hbm_peak(where)
             line_roofline["frac_of_measured_peak"] = round(line_roofline["achieved"] / line_roofline["peak_measured"], 6)
@@ -805,6 +933,9 @@ def main():
             "value": round(value, 1), "unit": "GCUPS",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            # what the collective layer itself says about the job: backend ("nccl" IS RCCL on ROCm), its rank count, distinct devices
+            "ranks": {"backend": dist.get_backend() if world > 1 else None, "world": dist.get_world_size() if world > 1 else 1,
+                      "devices": devices_in_use},
             "dtype": {0: "u32 bit-vectors (u64 results)", 16: "i16 cells, two per VALU op (i64 results)", 32: "i32 cells (i64 results)",
                       64: "i64 cells"}.get(int(profile.cell_bits), "u32"),
             "data": "synthetic",
@@ -827,11 +958,18 @@ def main():
             line["config"]["same_tapes_gcups"] = same_tapes["value"]
             line["same_tapes"] = same_tapes
         if not args.no_cpu_baseline:  # rank 0, whatever N: the host cores are this box's
-            line["cpu_baseline"] = cpu_baseline(load, gpu_matrix, args.cpu_seconds, cell_bits=profile.cell_bits)
+            line["cpu_baseline"] = cpu_baseline(load, gpu_matrix, args.cpu_seconds, cell_bits=profile.cell_bits, verify_seconds=args.verify_seconds)
+            line["stream_check"] = {"replayed_calls": replayed, "checksum_mismatches": replay_mismatches, "batches": len(steps_of)}
+            if len(matrices_of_batches) > 1:  # the OTHER batch of the alternating stream, cell for cell as well
+                other_load = type("other", (), {"queries": other_step.keepalive[2], "candidates": other_step.keepalive[3], "kind": load.kind,
+                                                "costs": load.costs, "name": load.name + " (the alternate batch)", "table": getattr(load, "table", None)})
+                checked = cpu_baseline(other_load, matrices_of_batches[1], 1.0, cell_bits=profile.cell_bits, with_serial=False,
+                                       verify_seconds=args.verify_seconds).get("checked", {})
+                line["stream_check"]["alternate_batch_whole_matrix"] = bool(checked.get("whole_matrix"))
             clock["headline_cpu_done"] = time.perf_counter()
-            attach_cpu_baselines(records, args.extra_cpu_seconds)
+            attach_cpu_baselines(records, args.extra_cpu_seconds, args.verify_seconds)
         for record in records:
-            record.pop("_cpu_baseline_inputs", None)
+            record.pop("_cpu_baseline_inputs", None), record.pop("_fingerprints_inputs", None)
         clock["done"] = time.perf_counter()
         line["run_seconds"] = {"total": round(clock["done"] - clock["started"], 1), "gpu_legs": round(clock["gpu_done"] - clock["started"], 1),
                                "cpu_baselines": round(clock["done"] - clock["gpu_done"], 1)}
@@ -874,11 +1012,45 @@ def headline(line, records=()):
     return text
 
 
+def audit(line, records=(), summary=None):
+    """What must never leave this program again: a roofline fraction above 1 (the priced work is then not what the
+    kernel does), an ESTIMATE where a committed counter pass exists, a headline whose `roofline.kernel` is not the kernel its timed
+    leg launches.  Returns the list of problems (empty: clean); `emit` prints it on a line of its own and keeps it in the headline."""
+    problems = []
+    if summary is None:
+        summary, _ = _profile_json("pmc_configs.json")
+
+    def fractions(node, path):
+        if isinstance(node, dict):
+            for key, value in node.items():
+                if key in ("frac", "frac_of_measured_peak") and isinstance(value, (int, float)) and not 0.0 <= value <= 1.0:
+                    problems.append(f"{path}.{key} = {value}: outside [0, 1]")
+                fractions(value, f"{path}.{key}")
+
+    fractions(line.get("roofline", {}), "headline.roofline")
+    for record in records:
+        name = f"configs[{record.get('config')}]"
+        fractions(record.get("roofline", {}), name + ".roofline")
+        counted = str(record.get("roofline", {}).get("counted", ""))
+        if "ESTIMATE" in counted and record.get("config") == "fingerprints" and _by_prefix(summary, "cfg11:fingerprint_segments_kernel")[1]:
+            problems.append(f"{name}.roofline.counted is an estimate although a committed PMC pass of its kernel exists")
+    kernel, planner = str(line.get("roofline", {}).get("kernel", "")), str(line.get("planner", ""))
+    if kernel and planner:
+        fused_leg = planner == "inside the scoring launch"
+        if fused_leg != ("fused" in kernel) and ("myers_short" in kernel):
+            problems.append(f"headline.roofline.kernel = {kernel} but the timed leg's planner mode is '{planner}': the counters are another launch's")
+    return problems
+
+
 def emit(line, records, details_path):
     """Prints one `{"configs_record": ...}` line per record, then - LAST - the headline alone; writes both, untrimmed, to
     `details_path` (gpurun_out/bench_configs.json by default; merged back from the GPU box)."""
+    problems = audit(line, records)
+    line["audit"] = problems
     for record in records:
         print(json.dumps({"configs_record": record}), flush=True)
+    if problems:
+        print(json.dumps({"audit": problems}), flush=True)
     if details_path:
         try:
             os.makedirs(os.path.dirname(os.path.abspath(details_path)), exist_ok=True)

@@ -197,3 +197,17 @@ def reference_fingerprints(texts: Sequence[bytes], dimensions: int, window_width
     if kind <= 0:
         raise RuntimeError("reference fingerprint engine failed")
     return hashes, counts, kind
+
+
+def reference_fingerprints_tiered(texts: Sequence[bytes], dimensions: int, tier: int, threads: int, window_widths=None, seed: int = 0,
+                                  alphabet_size: int = 256):
+    """(min_hashes, min_counts, tier that ran) through the reference's SIMD hashers (Skylake / Haswell / serial slices of 64
+    dimensions), the texts dealt over `threads` host threads: the CPU baseline of bench.py's fingerprints record."""
+    lib = ctypes.CDLL(_REF_SO)
+    data, offsets, widths, hashes, counts = _fingerprint_arguments(texts, dimensions, window_widths, seed)
+    ran = lib.szs_ref_fingerprints_tiered(ctypes.c_int(tier), ctypes.c_int(threads), _sz(dimensions), _sz(alphabet_size), _ptr(widths),
+                                          _sz(0 if widths is None else len(widths)), ctypes.c_uint64(seed), _ptr(data), _ptr(offsets),
+                                          _sz(len(texts)), _ptr(hashes), _ptr(counts))
+    if ran < 0:
+        raise RuntimeError("reference fingerprint engine failed")
+    return hashes, counts, int(ran)

@@ -121,6 +121,26 @@ szs::error_costs_32x32_t costs_from(uint8_t const *byte_to_class, int8_t const *
 
 } // namespace
 
+/** One block of texts through the 64-dimension slices of one tier's hashers (szs_ref_fingerprints_tiered below). */
+template <sz_capability_t capability_>
+static int fingerprints_sliced(size_t dimensions, size_t alphabet_size, size_t const *window_widths, size_t window_widths_count, uint64_t seed,
+                               views_t const &texts, size_t first, size_t last, uint32_t *min_hashes, uint32_t *min_counts) {
+    constexpr size_t slice = 64;
+    using hashers_t = szs::floating_rolling_hashers<capability_, slice>;
+    using byte_span_t = ashvardanian::stringzilla::span<ashvardanian::stringzilla::byte_t const>;
+    for (size_t i = 0; i != dimensions / slice; ++i) {
+        hashers_t hashers;
+        if ((int)hashers.try_seed(window_widths[i % window_widths_count], alphabet_size, i * slice, seed) != 0) return -1;
+        for (size_t t = first; t != last; ++t) {
+            byte_span_t text {reinterpret_cast<ashvardanian::stringzilla::byte_t const *>(texts[t].data()), texts[t].size()};
+            hashers.fingerprint(text, typename hashers_t::min_hashes_span_t {min_hashes + t * dimensions + i * slice},
+                                typename hashers_t::min_counts_span_t {min_counts + t * dimensions + i * slice});
+        }
+    }
+    return 0;
+}
+
+
 extern "C" {
 
 /** Highest SIMD tier this host CPU can run: 0 serial, 1 Haswell (AVX2), 2 Ice Lake (AVX-512 VBMI). */
@@ -254,6 +274,51 @@ int szs_ref_fingerprints(size_t dimensions, size_t alphabet_size, size_t const *
         if ((int)hashers.try_fingerprint(text, hashes, counts) != 0) return -1;
     }
     return 2;
+}
+
+/**
+ *  The same fingerprints through the reference's SIMD engines - the CPU baseline bench.py times beside `szs_fingerprints_u32tape`:
+ *  `floating_rolling_hashers<sz_cap_skylake_k / sz_cap_haswell_k / sz_cap_serial_k, 64>` (fingerprints/skylake.hpp:49,
+ *  haswell.hpp:42, serial.hpp:1120), slices of 64 dimensions sharing one window width as the reference's C shim composes them
+ *  (c/stringzillas/fingerprints.cuh:49-176), the texts dealt over `threads` std::threads in contiguous blocks (each thread seeds its
+ *  own hashers: they hold state).  `dimensions` must be a whole multiple of 64 x widths.  Returns the tier that ran, -1 on failure.
+ */
+int szs_ref_fingerprints_tiered(int tier, int threads, size_t dimensions, size_t alphabet_size, size_t const *window_widths,
+                                size_t window_widths_count, uint64_t seed, char const *data, uint64_t const *offsets, size_t count,
+                                uint32_t *min_hashes, uint32_t *min_counts) {
+    size_t const default_widths[] = {3, 4, 5, 7, 9, 11, 15, 31};
+    if (!window_widths || !window_widths_count) window_widths = default_widths, window_widths_count = 8;
+    if (!alphabet_size) alphabet_size = 256;
+    if (dimensions % (64 * window_widths_count)) return -1;
+    int const best = best_tier();
+    if (tier > best) tier = best;
+    views_t const texts = views_from_tape(data, offsets, count);
+    if (threads < 1) threads = 1;
+    if ((size_t)threads > count) threads = (int)(count ? count : 1);
+    std::vector<int> outcomes((size_t)threads, 0);
+    auto run = [&](int thread) {
+        size_t const first = count * (size_t)thread / (size_t)threads, last = count * ((size_t)thread + 1) / (size_t)threads;
+#if SZ_USE_SKYLAKE
+        if (tier >= tier_icelake) {
+            outcomes[thread] = fingerprints_sliced<sz_cap_skylake_k>(dimensions, alphabet_size, window_widths, window_widths_count, seed, texts, first, last, min_hashes, min_counts);
+            return;
+        }
+#endif
+#if SZ_USE_HASWELL
+        if (tier >= tier_haswell) {
+            outcomes[thread] = fingerprints_sliced<sz_cap_haswell_k>(dimensions, alphabet_size, window_widths, window_widths_count, seed, texts, first, last, min_hashes, min_counts);
+            return;
+        }
+#endif
+        outcomes[thread] = fingerprints_sliced<sz_cap_serial_k>(dimensions, alphabet_size, window_widths, window_widths_count, seed, texts, first, last, min_hashes, min_counts);
+    };
+    std::vector<std::thread> pool;
+    for (int thread = 1; thread < threads; ++thread) pool.emplace_back(run, thread);
+    run(0);
+    for (auto &worker : pool) worker.join();
+    for (int outcome : outcomes)
+        if (outcome) return -1;
+    return tier;
 }
 
 } // extern "C"

@@ -81,7 +81,7 @@ for directory in sorted(glob.glob(os.path.join(root, "cfg*"))):
                 "_cells_per_call": line["config"]["cells_per_gpu"], "kernels": {}}
         totals = defaultdict(float)
         scoring = {name: entry for name, entry in summary.items()
-                   if entry.get("_config") == config and not name.endswith(":__call__") and
+                   if isinstance(entry, dict) and entry.get("_config") == config and ":__call__" not in name and
                    not any(helper in name for helper in ("plan_kernel", "utf8_transcode", "byte_presence", "alphabet_"))}  # not scoring launches
         launches_per_call = line["roofline"].get("launches_per_step", 1)
         # The run may hold more calls than steps + warm-up (bench.py's fresh-batch leg), and its FIRST call may be another kind of
@@ -114,6 +114,35 @@ for directory in sorted(glob.glob(os.path.join(root, "cfg*"))):
             call["lds_conflict_fraction"] = call.get("SQ_LDS_BANK_CONFLICT", 0.0) / call["SQ_LDS_IDX_ACTIVE"]
             call["lds_busy_fraction"] = call["SQ_LDS_IDX_ACTIVE"] / 256 / (seconds * 2.4e9)  # cycles summed over 256 CUs
         summary[f"cfg{config}:__call__"] = call
+        # ---- a config whose run holds calls of TWO kinds (config 2: bench.py times the same tapes again - the plain launch behind the
+        #      guard - and then a stream of fresh batches - the launch that plans itself) also gets one record per kind: the counters
+        #      of the ONE kernel that kind of call launches, over that kernel's own average duration.  bench.py joins its timed leg to
+        #      the record of its kind (`roofline.pmc_leg`); the blend above stays for what it is, the run's average call.
+        fused = [name for name in steady if "fused" in name]
+        plain = [name for name in steady if "fused" not in name]
+        if fused and plain:
+            for leg, members in (("fresh", fused), ("same_tapes", plain)):
+                main = max(members, key=lambda name: scoring[name].get("_share", 0.0))
+                entry = scoring[main]
+                one = {"_config": config, "_leg": leg, "_kernel_seconds_per_call": entry.get("_duration_seconds", seconds),
+                       "_cells_per_call": call["_cells_per_call"],
+                       "kernels": {main.split(":", 1)[1]: {"launches_per_call": 1.0, "share_of_kernel_time": 1.0}}}
+                for counter in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_WAVE_CYCLES",
+                                "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAVES", "hbm_fetch_bytes_raw", "hbm_write_bytes_raw"):
+                    if counter in entry:
+                        one[counter] = entry[counter]
+                took = one["_kernel_seconds_per_call"]
+                if "SQ_INSTS_VALU" in one and took:
+                    one["valu_lane_ops_per_second"] = one["SQ_INSTS_VALU"] * 64 / took
+                    one["valu_lane_ops_per_cell"] = one["SQ_INSTS_VALU"] * 64 / max(one["_cells_per_call"], 1)
+                if one.get("SQ_WAVE_CYCLES"):
+                    one["wave_wait_inst_fraction"] = one.get("SQ_WAIT_INST_ANY", 0.0) / one["SQ_WAVE_CYCLES"]
+                    one["wave_wait_any_fraction"] = one.get("SQ_WAIT_ANY", 0.0) / one["SQ_WAVE_CYCLES"]
+                    one["wavefronts_per_simd"] = one["SQ_WAVE_CYCLES"] * 4 / 1024 / (took * 2.4e9)
+                if one.get("SQ_LDS_IDX_ACTIVE"):
+                    one["lds_conflict_fraction"] = one.get("SQ_LDS_BANK_CONFLICT", 0.0) / one["SQ_LDS_IDX_ACTIVE"]
+                    one["lds_busy_fraction"] = one["SQ_LDS_IDX_ACTIVE"] / 256 / (took * 2.4e9)
+                summary[f"cfg{config}:__call__@{leg}"] = one
     except (OSError, ValueError, KeyError, IndexError) as problem:
         print(f"cfg{config}: no call-level record ({problem})", file=sys.stderr)
 # the digest of the library these counters were taken on: bench.py joins the instruction counts to ITS run's kernel times and

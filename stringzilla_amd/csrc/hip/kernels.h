@@ -199,6 +199,7 @@ typedef struct szs_tape_t {
 int szs_hip_levenshtein_tiny(szs_tape_t const *queries, szs_tape_t const *candidates, uint64_t *results, uint64_t results_row_stride,
                                    uint32_t *unfit, uint32_t unfit_sequence, unsigned long long *symbols_out,
                                    uint64_t *trace /* NULL, or 10 qwords per workgroup of device memory (`trace` knob) */,
+                                   uint64_t trace_workgroups /* workgroups `trace` has room for: a larger grid is not traced at all */,
                                    int dense /* testing: score blocks and spans full of long strings too (slowly) instead of refusing them */, void *stream);
 
 /**
@@ -235,7 +236,8 @@ enum {
     szs_knob_queue_words_k, /* -1 automatic | 4 / 8 / 12 / 16: the most words of a pattern one lane may hold in that launch */
     szs_knob_queue_rounds_k,/* -1 automatic | n: candidates per work item, in rounds of the workgroup's eight wavefronts */
     szs_knob_queue_priority_k, /* -1 automatic (on) | 0: every wave block of that launch at one hardware priority | 1: longest chain first */
-    szs_knob_fused_k,       /* -1 automatic | 0: never fold the planner into the short unit-cost launch (szs_fused_plan_t) */
+    szs_knob_fused_k,       /* -1 automatic | 0: never fold the planner into the short unit-cost launch (szs_fused_plan_t) | 2 (testing): its
+                               sorters never publish - every waiting workgroup runs out of polls, the call is planned the ordinary way */
     szs_knob_tiny_k,        /* -1 automatic (tiny tokens on both sides) | 0 never | 1 every unit-cost byte call of strings up to 255 bytes, few
                                of them beyond 16: the tiny-token launch of hip/myers_tiny.hip | 2 (testing): dense batches are scored there too */
     szs_knob_count_k
@@ -339,7 +341,12 @@ typedef struct szs_fused_plan_t {
     uint32_t sequence;       /* never 0 */
     uint32_t *ready;         /* device memory: ready[0] and ready[32], zeroed when allocated; a launch leaves `sequence` in both */
     szs_fused_side_report_t *report; /* [2], pinned host memory */
+    uint32_t *gave_up;       /* pinned host memory: a waiting workgroup whose polls ran out leaves `sequence` here and scores nothing -
+                                the host then plans the call the ordinary way (a launch never hangs on a sorter that does not publish) */
+    uint32_t poll_budget;    /* polls of a `ready` word a waiting workgroup spends before it gives up (~1 us each) */
+    uint32_t withhold;       /* testing aid (`fused` knob = 2): the sorters sort and report but never publish */
 } szs_fused_plan_t;
+#define SZS_FUSED_POLL_BUDGET (1u << 18) /* ~0.2 s: four orders of magnitude beyond the ~4 us a sorter takes */
 int szs_hip_levenshtein_myers_fused(szs_fused_plan_t const *plan, uint64_t *results, uint64_t results_row_stride, int layout,
                                     void *stream);
 

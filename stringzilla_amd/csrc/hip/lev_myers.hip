@@ -311,7 +311,7 @@ __device__ __forceinline__ u64 fused_offset(void const *offsets, u32 wide, u64 i
     return wide ? static_cast<u64 const *>(offsets)[index] : (u64) static_cast<u32 const *>(offsets)[index];
 }
 
-__device__ __forceinline__ void fused_sort_side(szs_plan_side_t const &side, u32 is_query_side, u32 sequence, u32 *ready,
+__device__ __forceinline__ void fused_sort_side(szs_plan_side_t const &side, u32 is_query_side, u32 sequence, u32 *ready, u32 withhold,
                                                 szs_fused_side_report_t *report, u32 *histogram /* SZS_FUSED_BINS dwords of LDS */,
                                                 szs_string_ref_t *staged /* SZS_FUSED_MOST_STRINGS refs of LDS */) {
     constexpr u32 per_thread = SZS_FUSED_MOST_STRINGS / 256;
@@ -402,7 +402,7 @@ __device__ __forceinline__ void fused_sort_side(szs_plan_side_t const &side, u32
     __syncthreads();
     if (tid == 0) {
         report->ticks[3] = (u32)(wall_clock64() - began);
-        __hip_atomic_store(ready, sequence, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (!withhold) __hip_atomic_store(ready, sequence, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         report->ticks[4] = (u32)(wall_clock64() - began);
     }
     // ---- the report (the host reads it when the launch has ended)
@@ -426,13 +426,14 @@ __device__ __forceinline__ void fused_sort_side(szs_plan_side_t const &side, u32
     }
 }
 
-/** Sorters sort, everybody waits for both sides.  Workgroups are dispatched in order: 0 and 1 never wait for anyone. */
-__device__ __forceinline__ void fused_prologue(szs_fused_plan_t const &plan, u32 *scratch) {
+/** Sorters sort, everybody waits for both sides.  Workgroups are dispatched in order: 0 and 1 never wait for anyone.
+ *  False: this workgroup ran out of polls (the sorters are not resident, or one of them never published) - it must not touch a ref. */
+__device__ __forceinline__ bool fused_prologue(szs_fused_plan_t const &plan, u32 *scratch) {
     // 16 KB of LDS that only the two sorting workgroups touch: the scoring bodies keep five workgroups per CU either way (95 VGPRs)
     __shared__ __attribute__((aligned(16))) szs_string_ref_t staged[SZS_FUSED_MOST_STRINGS];
     for (u32 s = 0; s < 2; ++s)
         if (blockIdx.x == s % gridDim.x) {
-            fused_sort_side(plan.side[s], s == 0, plan.sequence, plan.ready + 32 * s, plan.report + s, scratch, staged);
+            fused_sort_side(plan.side[s], s == 0, plan.sequence, plan.ready + 32 * s, plan.withhold, plan.report + s, scratch, staged);
             __syncthreads(); // the LDS is sorted in again (a grid of one workgroup), then becomes the match masks
         }
     // The wait is a RELAXED load at agent scope (it goes to the device's coherence point every time) and the barrier orders the
@@ -445,10 +446,24 @@ __device__ __forceinline__ void fused_prologue(szs_fused_plan_t const &plan, u32
     // sorters' own first loads then took 2.3 us instead of 1.4 and the launch 181.6 us instead of 179.6.
     // (What the wait costs, measured with build variants that skip it - reading the previous call's refs, results garbage: the
     // launch 179.6 us; without the wait 173.0; without the sort as well 171.5, the plain launch's time.)
-    if (threadIdx.x < 2)
-        while (__hip_atomic_load(plan.ready + 32 * threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != plan.sequence)
+    // The wait is BOUNDED (round 6): `poll_budget` polls of ~1 us each, four orders of magnitude beyond what a sorter takes.  A
+    // workgroup whose polls run out says so in pinned memory and scores nothing - it leaves the CU to whoever is queued behind it
+    // (the sorters, should the dispatch order ever not be the observed one) - and the host plans the call the ordinary way.
+    __shared__ u32 unpublished[2];
+    if (threadIdx.x < 2) {
+        u32 polls = 0;
+        bool published;
+        while (!(published = __hip_atomic_load(plan.ready + 32 * threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == plan.sequence) &&
+               ++polls < plan.poll_budget)
             __builtin_amdgcn_s_sleep(8);
+        unpublished[threadIdx.x] = !published;
+    }
     __syncthreads();
+    if (unpublished[0] | unpublished[1]) {
+        if (threadIdx.x == 0) __hip_atomic_store(plan.gave_up, plan.sequence, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return false;
+    }
+    return true;
 }
 
 #ifndef SZS_MYERS_SHORT_WAVES
@@ -468,7 +483,7 @@ __device__ __forceinline__ void myers_short_body(
     __shared__ __attribute__((aligned(16))) u32 peq[peq_layout<8, runes_ ? rune_slots_k : byte_rows_k>::total_dwords];
     if constexpr (fused_) {
         static_assert(peq_layout<8, byte_rows_k>::total_dwords >= SZS_FUSED_BINS, "the sort's histogram borrows the masks' LDS");
-        fused_prologue(*fused, peq); // the refs `queries` / `candidates` point at exist from here on
+        if (!fused_prologue(*fused, peq)) return; // the refs `queries` / `candidates` point at exist from here on
     }
     __shared__ u32 slot_keys[runes_ ? rune_slots_k : 1];
     __shared__ u32 claimed_rows;
@@ -483,7 +498,17 @@ __device__ __forceinline__ void myers_short_body(
     // (a compile-time 1 without merging: the block loop of myers_workgroup folds away - it cost config 2 1.5 % as a real loop)
     u32 const blocks_here = !merged_ ? 1u : all_blocks - first_block < blocks_per_group ? all_blocks - first_block : blocks_per_group;
     u32 const candidate_block = first_block + blocks_here - 1;
-    szs_string_ref_t const query = queries[query_slot];
+    szs_string_ref_t query = queries[query_slot];
+    if constexpr (fused_) {
+        // The refs are written during this very launch, so the compiler loads this one with a VECTOR load (no `s_load` from memory
+        // the kernel may clobber) and the four dwords - uniform over the workgroup - sat in VGPRs through the whole body: under the
+        // 96-register bound eight registers a lane were spilled, and those scratch stores were the "4x write amplification" of round 5's
+        // counters (33.4 MB written per launch for 8.4 MB of results: 4096 workgroups x 256 lanes x 24 bytes of spills).
+        query.address = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(query.address >> 32)) << 32) |
+                        (u32)__builtin_amdgcn_readfirstlane((int)(u32)query.address);
+        query.length = (u32)__builtin_amdgcn_readfirstlane((int)query.length);
+        query.index = (u32)__builtin_amdgcn_readfirstlane((int)query.index);
+    }
     u32 const words = __builtin_amdgcn_readfirstlane(query.length ? (query.length + 31u) / 32u : 1u);
 #define SZS_MYERS_BODY(W)                                                                                              \
     case W:                                                                                                            \

@@ -592,7 +592,8 @@ __global__ __launch_bounds__(256, 4) void levenshtein_tiny_kernel(szs_tape_t que
 
 extern "C" int szs_hip_levenshtein_tiny(szs_tape_t const *queries_tape, szs_tape_t const *candidates_tape, uint64_t *results,
                                               uint64_t results_row_stride, uint32_t *unfit, uint32_t unfit_sequence,
-                                              unsigned long long *symbols_out, uint64_t *trace, int dense, void *stream) {
+                                              unsigned long long *symbols_out, uint64_t *trace, uint64_t trace_workgroups, int dense,
+                                              void *stream) {
     using namespace szs_hip;
     szs_tape_t const queries = *queries_tape, candidates = *candidates_tape;
     u32 const queries_count = queries.count, candidates_count = candidates.count;
@@ -610,6 +611,7 @@ extern "C" int szs_hip_levenshtein_tiny(szs_tape_t const *queries_tape, szs_tape
     if (per_span > tiny_most_queries_k) per_span = tiny_most_queries_k;
     spans = ((u64)queries_count + per_span - 1) / per_span;
     if (blocks * spans > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
+    if (blocks * spans > trace_workgroups) trace = nullptr; // the stamps are indexed by workgroup: a grid beyond the buffer is not traced
     hipLaunchKernelGGL(levenshtein_tiny_kernel, dim3((u32)(blocks * spans)), dim3(256), 0, static_cast<hipStream_t>(stream), queries, candidates,
                        (u32)per_span, results, results_row_stride, unfit, unfit_sequence, symbols_out, trace, dense ? 1u : 0u);
     return (int)hipGetLastError();

@@ -878,8 +878,10 @@ static sz_status_t finish(szs_call_t *call, szs_decision_t const *d, hipError_t 
     hipError_t const drained = hipStreamSynchronize(stream); /* the call is synchronous, like the reference's - also when it fails */
     phase(call, 4); /* waiting for the device */
     if (status != sz_success_k || error != hipSuccess || drained != hipSuccess)
-        engine->queue_zeroed = NULL; /* the host's mirror of the queue kernel's ticket counter may no longer match the device's (a launch
+        engine->queue_zeroed = NULL, /* the host's mirror of the queue kernel's ticket counter may no longer match the device's (a launch
                                         counted but never run, or run but reported failed): prepare() zeroes both before the next one */
+            engine->fused_zeroed = NULL; /* ... and so may the planner's verdict counter (its parity elects the side that folds the two
+                                            verdicts) and the `ready` words: reserve_device_words() zeroes the 256 bytes again */
     if (status != sz_success_k) return status;
     if (error == hipSuccess) error = drained;
     if (error != hipSuccess) return szs_report_hip(error, call->error_message);
@@ -1062,6 +1064,14 @@ static int tiny_shaped(szs_engine_s const *engine, int symmetric, szs_side_stats
            candidates->count >= 1024 && (uint64_t)queries->count * candidates->count >= (1ull << 20);
 }
 
+/** The tiny-token kernel refused a recent batch of these counts (cross_tiny): the next sixteen such calls do not try it again. */
+static int tiny_recently_refused(szs_engine_s *engine, uint32_t q_count, uint32_t c_count, int count_down) {
+    if (engine->tiny_refused <= 0 || engine->tiny_q_count != q_count || engine->tiny_c_count != c_count) return 0;
+    if (szs_tuning_get(szs_knob_tiny_k) >= 0) return 0; /* a pinned knob is obeyed every time */
+    if (count_down) --engine->tiny_refused;
+    return 1;
+}
+
 /**
  *  One launch of the tiny-token kernel, straight from the caller's tapes, and the call's wait.  sz_success_k: scored.
  *  SZS_TINY_NOT_TAKEN: the kernel met a string beyond 255 bytes or malformed offsets - nothing it wrote counts, the caller goes on
@@ -1093,18 +1103,20 @@ static sz_status_t cross_tiny(szs_call_t *call, uint32_t planner_mode, szs_plan_
      * the tables back, the tiny-token kernel - 100 us of kernels on 4096 x 4096 words of text where the one launch takes 81.) */
     if (error == hipSuccess) {
         error = (hipError_t)szs_hip_levenshtein_tiny(&q_tape, &c_tape, (uint64_t *)call->device_results, call->device_stride, (uint32_t *)unfit, sequence,
-                                                           (unsigned long long *)symbols, trace, szs_tuning_get(szs_knob_tiny_k) == 2, stream);
+                                                           (unsigned long long *)symbols, trace, trace_workgroups, szs_tuning_get(szs_knob_tiny_k) == 2, stream);
         launches += error == hipSuccess;
     }
     engine->last_streams = 1;
-    szs_decision_t *const shape = (szs_decision_t *)calloc(1, sizeof(szs_decision_t)); /* what finish() reads: lanes tier, one launch */
-    if (!shape) return szs_report(sz_bad_alloc_k, call->error_message, NULL);
+    /* what finish() reads: lanes tier, one launch.  On the stack, like the other paths' copies of a decision: a failed allocation here
+     * would have returned with the launch still writing the caller's matrix and the pinned words */
+    szs_decision_t shape_of_call;
+    memset(&shape_of_call, 0, sizeof(shape_of_call));
+    szs_decision_t *const shape = &shape_of_call;
     shape->tier = SZS_TIER_LANES, shape->q_count = call->q_count, shape->c_count = call->c_count;
     if (seen) shape->longest[0] = seen->side[0].longest, shape->longest[1] = seen->side[1].longest;
     engine->last_profile.planner = planner_mode;
     int stalled = 0;
     sz_status_t status = finish(call, shape, error, sz_success_k, launches, 0, 0, 0, &stalled);
-    free(shape);
     if (status != sz_success_k) return status;
     if (trace) { /* where a workgroup of the tiny-token kernel spends its time: mean ticks (10 ns) between its stamps */
         size_t const slots = trace_slots, last_slot = 8;
@@ -1140,9 +1152,13 @@ static sz_status_t cross_tiny(szs_call_t *call, uint32_t planner_mode, szs_plan_
         free(ticks);
     }
     if (*unfit == sequence) {
-        engine->tiny_valid = 0;
+        /* refused (a block or span too dense in long strings, a string beyond 255 bytes): remember the counts, so that a stream of
+         * such batches does not pay this launch and its wait on every call because their summaries look like words */
+        engine->tiny_valid = 0, engine->tiny_refused = 16; /* calls of these counts that go straight to the ordinary path */
+        engine->tiny_q_count = call->q_count, engine->tiny_c_count = call->c_count;
         return SZS_TINY_NOT_TAKEN;
     }
+    engine->tiny_refused = 0;
     szs_rocm_call_profile_t *profile = &engine->last_profile;
     uint64_t const q_symbols = symbols[0], c_symbols = symbols[1];
     profile->cells = q_symbols * c_symbols;
@@ -1295,7 +1311,8 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
     if (remembered->valid && !remembered->runes && remembered->tier == SZS_TIER_LANES && remembered->use_myers && !remembered->wide_cells &&
         !remembered->use_queue && is_one_launch(remembered) && remembered->plan.groups[0].variant == SZS_MYERS_SHORT_WORDS && !symmetric &&
         remembered->q_count == q_count && remembered->c_count == c_count && remembered->symmetric == symmetric && q_count <= SZS_FUSED_MOST_STRINGS &&
-        c_count <= SZS_FUSED_MOST_STRINGS && knobs_automatic && !uniform_bytes && szs_tuning_get(szs_knob_fused_k) != 0) {
+        c_count <= SZS_FUSED_MOST_STRINGS && knobs_automatic && !uniform_bytes && szs_tuning_get(szs_knob_fused_k) != 0 &&
+        (!engine->fused_gave_up || szs_tuning_get(szs_knob_fused_k) == 2)) {
         szs_decision_t const *d = remembered;
         szs_fused_side_report_t volatile *const reports = (szs_fused_side_report_t volatile *)((char *)engine->pinned_summary.pointer + 1024);
         szs_fused_plan_t fused;
@@ -1304,6 +1321,10 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
         if (!++engine->plan_sequence) ++engine->plan_sequence; /* never 0: the ready words start there */
         fused.sequence = engine->plan_sequence;
         fused.ready = (uint32_t *)engine->device_fused.pointer, fused.report = (szs_fused_side_report_t *)reports;
+        uint32_t volatile *const gave_up = (uint32_t volatile *)((char *)engine->pinned_summary.pointer + 1024 + 2 * sizeof(szs_fused_side_report_t));
+        *gave_up = 0;
+        fused.gave_up = (uint32_t *)gave_up, fused.poll_budget = SZS_FUSED_POLL_BUDGET;
+        if (szs_tuning_get(szs_knob_fused_k) == 2) fused.withhold = 1, fused.poll_budget = 64; /* testing: nobody is ever told */
         status = prepare(engine, d, device, stream, error_message); /* buffers of the previous call: nothing to allocate */
         if (status != sz_success_k) return status;
         phase(call, 2);
@@ -1324,7 +1345,9 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
         if (status != sz_success_k) return status;
         szs_fused_side_report_t sides[2];
         memcpy(sides, (void const *)reports, sizeof(sides));
-        if (sides[0].sequence == fused.sequence && sides[1].sequence == fused.sequence && !sides[0].status && !sides[1].status && !sides[0].blank &&
+        if (*gave_up == fused.sequence) engine->fused_gave_up = 1, engine->fused_zeroed = NULL; /* a workgroup ran out of polls: whatever the reports say, not every
+                                                                        cell was scored - and the ready words are zeroed before the next try */
+        else if (sides[0].sequence == fused.sequence && sides[1].sequence == fused.sequence && !sides[0].status && !sides[1].status && !sides[0].blank &&
             !sides[1].blank) { /* scored; the profile and the remembered plan take this batch's figures (caller roles again) */
             szs_fused_side_report_t const *const of_queries = &sides[d->transposed ? 1 : 0], *const of_candidates = &sides[d->transposed ? 0 : 1];
             if (call->trace)
@@ -1343,7 +1366,7 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
             profile->longest_query = seen_here.side[0].longest, profile->longest_candidate = seen_here.side[1].longest;
             remembered->longest[0] = seen_here.side[0].longest, remembered->longest[1] = seen_here.side[1].longest;
             stamp_refs(remembered, key_data, key_offsets, key_wide, &seen_here);
-            if (tiny_shaped(engine, symmetric, &seen_here.side[0], &seen_here.side[1]))
+            if (tiny_shaped(engine, symmetric, &seen_here.side[0], &seen_here.side[1]) && !tiny_recently_refused(engine, q_count, c_count, 0))
                 engine->tiny_valid = 1, engine->tiny_q_count = q_count, engine->tiny_c_count = c_count;
             return szs_report(sz_success_k, error_message, NULL);
         }
@@ -1402,7 +1425,7 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
             profile->longest_query = seen.side[0].longest, profile->longest_candidate = seen.side[1].longest;
             stamp_refs(remembered, key_data, key_offsets, key_wide, &seen);
             /* scored on the previous call's shape - but if the batch turned out to be tiny tokens, the next one goes to their kernel */
-            if (tiny_shaped(engine, symmetric, &seen.side[0], &seen.side[1]))
+            if (tiny_shaped(engine, symmetric, &seen.side[0], &seen.side[1]) && !tiny_recently_refused(engine, q_count, c_count, 0))
                 engine->tiny_valid = 1, engine->tiny_q_count = q_count, engine->tiny_c_count = c_count;
             return szs_report(sz_success_k, error_message, NULL);
         }
@@ -1434,7 +1457,8 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
     phase(call, 1);
 
     if (use_myers && szs_tuning_get(szs_knob_tier_k) < 0 && szs_tuning_get(szs_knob_swap_k) < 0 && szs_tuning_get(szs_knob_queue_k) < 0 &&
-        tiny_shaped(engine, symmetric, &seen.side[0], &seen.side[1])) { /* the summary says tiny tokens: no refs needed after all */
+        tiny_shaped(engine, symmetric, &seen.side[0], &seen.side[1]) && !tiny_recently_refused(engine, q_count, c_count, 1)) {
+        /* the summary says tiny tokens (and the kernel did not refuse the previous batch of these counts): no refs needed after all */
         status = cross_tiny(call, 1, &seen);
         if (status != SZS_TINY_NOT_TAKEN) return status;
     }

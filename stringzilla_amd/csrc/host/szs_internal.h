@@ -116,8 +116,10 @@ typedef struct szs_engine_s {
     int last_queued;               /* enqueue() issued the persistent launch for the call being finished (the call profile says so) */
     szs_buffer_t device_fused;     /* device: the two `ready` words of the short launch that plans itself (kernels.h: szs_fused_plan_t) */
     void *fused_zeroed;            /* the allocation of `device_fused` that was zeroed */
+    int fused_gave_up;             /* a launch that plans itself ran out of polls on this engine: it is not tried again */
     int tiny_valid;                /* the previous call of these counts was scored by the tiny-token kernel (hip/myers_tiny.hip): go straight there */
     uint32_t tiny_q_count, tiny_c_count;
+    int tiny_refused;              /* ... or was REFUSED by it (dense in long strings): calls of these counts skip the summary-driven attempt */
     hipEvent_t event_start, event_stop;
     int events_device;
     /* launches of different bit-vector widths fan out over these and fill each other's tails (dispatch.c: enqueue) */

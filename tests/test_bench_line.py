@@ -113,3 +113,69 @@ def test_the_words_record_prices_the_launch_against_its_traffic_and_its_own_inst
     bare = bench.words_roofline({"pmc_stale": None}, 134305451, 78.1e-6, 1, 5, None)
     assert bare["traffic"] is None and "valu" not in bare and "issue_floor" not in bare and bare["kernel"] == "levenshtein_tiny_kernel"
     json.dumps(record), json.dumps(bare)
+
+
+def test_the_audit_flags_what_round_five_let_through():
+    """a fingerprints record at `frac` 1.16 labelled "ESTIMATE: 25 assumed" although a PMC pass of its kernel was
+    committed (the key carries the template argument), and a headline naming `levenshtein_myers_short_kernel<false>` as the kernel
+    of a stream that only ever launches the fused one.  `bench.audit` names each; a clean line has nothing to say."""
+    assert bench.audit(canned_line(), canned_records(3)) == []  # planner "device, speculated" + the plain kernel: consistent
+    line = canned_line()
+    line["planner"] = "inside the scoring launch"  # ... but the counters joined to it are the plain launch's
+    assert any("roofline.kernel" in problem for problem in bench.audit(line))
+    line["roofline"]["kernel"] = "levenshtein_myers_short_fused_kernel"
+    assert bench.audit(line) == []
+    line["roofline"]["valu"]["frac"] = 1.02
+    assert any("valu.frac" in problem for problem in bench.audit(line))
+    summary = {"cfg11:fingerprint_segments_kernel<true>": {"SQ_INSTS_VALU": 3438668528.0}}
+    estimated = {"config": "fingerprints", "roofline": {"counted": "ESTIMATE: 25 assumed", "frac": 1.1623}}
+    problems = bench.audit(canned_line(), [estimated], summary)
+    assert any("frac" in problem for problem in problems) and any("estimate" in problem for problem in problems)
+
+
+def test_the_fingerprints_record_is_priced_from_the_committed_counters():
+    """`cfg11:fingerprint_segments_kernel<true>` is found by prefix: counted, not estimated, and below 1."""
+    summary = {"cfg11:fingerprint_segments_kernel<true>": {"SQ_INSTS_VALU": 3438668528.0}, "_library_sha256": "abc"}
+    mixes = {"fingerprint_segments_kernel<true>": {"valu_instructions": 83, "ceiling_Tlane_ops_per_s": 42.92}}
+    text_bytes, dimensions = 10485760, 1024
+    record = bench.fingerprints_roofline(text_bytes, dimensions, 1024, 5.86e-3, summary, "profiles/r05/pmc_configs.json", mixes, "abc")
+    assert record["counted"].startswith("PMC") and record["pmc_stale"] is False and 0.5 < record["frac"] < 1.0
+    assert abs(record["lane_ops_per_byte_and_dimension"] - 3438668528.0 * 64 / (text_bytes * dimensions)) < 0.01
+    assert record["kernel"] == "fingerprint_segments_kernel<true>" and record["peak_Tlane_ops_per_s"] == 42.92
+    # another build of the library: the counters are flagged stale; nothing committed: an estimate, and it says so
+    assert bench.fingerprints_roofline(text_bytes, dimensions, 1024, 5.86e-3, summary, "x", mixes, "other")["pmc_stale"] is True
+    assert "ESTIMATE" in bench.fingerprints_roofline(text_bytes, dimensions, 1024, 5.86e-3, {}, None, mixes, "abc")["counted"]
+    committed, _ = bench._profile_json("pmc_configs.json")
+    assert bench._by_prefix(committed, "cfg11:fingerprint_segments_kernel")[1], "the committed passes hold the fingerprints kernel"
+
+
+def test_a_timed_leg_is_joined_to_the_counters_of_its_own_kernel(monkeypatch):
+    """Config 2's run holds two kinds of calls; the headline (fresh batches: the fused launch) takes `cfg2:__call__@fresh`."""
+    summary = {"_library_sha256": "abc",
+               "cfg2:__call__": {"kernels": {"levenshtein_myers_short_fused_kernel": {"share_of_kernel_time": 0.46},
+                                              "levenshtein_myers_short_kernel<false>": {"share_of_kernel_time": 0.54}}},
+               "cfg2:__call__@fresh": {"kernels": {"levenshtein_myers_short_fused_kernel": {"share_of_kernel_time": 1.0}},
+                                        "hbm_fetch_bytes_raw": 4.9e6, "hbm_write_bytes_raw": 9.4e6, "SQ_INSTS_VALU": 113611086.0},
+               "cfg2:__call__@same_tapes": {"kernels": {"levenshtein_myers_short_kernel<false>": {"share_of_kernel_time": 1.0}}}}
+    monkeypatch.setattr(bench, "_profile_json", lambda name: (summary, "profiles/rNN/" + name) if name == "pmc_configs.json" else (None, None))
+    monkeypatch.setattr(bench, "library_digest", lambda: "abc")
+    profile = type("profile", (), {"algorithmic_bytes": 284993536, "launches": 1, "cells": 17151815600})
+    fresh = bench.roofline(2, profile, 180e-6, leg="fresh")
+    assert fresh["kernel"] == "levenshtein_myers_short_fused_kernel" and fresh["pmc_leg"] == "fresh" and fresh["traffic"] == round(4.9e6 + 9.4e6)
+    assert bench.roofline(2, profile, 180e-6, leg="same_tapes")["kernel"] == "levenshtein_myers_short_kernel<false>"
+    blend = bench.roofline(2, profile, 180e-6)  # no leg named: the run's average call, as before
+    assert blend["pmc_leg"] is None and blend["kernel"] == "levenshtein_myers_short_kernel<false>"
+
+
+def test_committed_bench_outputs_pass_the_audit():
+    """Every bench output committed under profiles/r06/ (the judged command's stdout) is audited again here: no fraction above 1,
+    no estimate where counters exist, the headline's kernel is its timed leg's."""
+    import glob
+
+    for path in glob.glob(os.path.join(ROOT, "profiles", "r06", "bench_*.jsonl")):
+        with open(path) as handle:
+            printed = [json.loads(text) for text in handle.read().splitlines() if text.startswith("{")]
+        line = printed[-1]
+        records = [entry["configs_record"] for entry in printed if "configs_record" in entry]
+        assert bench.audit(line, records) == [], path
+        assert line.get("audit", []) == [], path

@@ -1,0 +1,233 @@
+"""`-m gpu`, round 6: the evidence the previous verdict found thin.
+
+1. WHOLE matrices of the full-size BASELINE configs against the reference's own engines (oracle/_ref, every host thread): configs 2
+   and 3 cell for cell, 64 whole rows of configs 4, 5 and 5u (the reference checks every timed batch cell for cell,
+   bench/similarities.cuh:410-423).
+2. A SOAK of the launch that plans itself (hip/lev_myers.hip: `levenshtein_myers_short_fused_kernel`): 10,000 launches over three
+   fresh batches and two result matrices, every matrix compared ON THE DEVICE with what the plain path (`fused` knob 0, itself
+   checked against the reference) wrote - once alone, once with a second engine keeping the device unevenly busy on another stream.
+   The hand-over inside that launch (workgroups 0 and 1 publish the refs, everybody else polls with relaxed loads and takes no
+   acquire fence) is the one protocol of this library whose correctness rests on measured behaviour.
+3. The wait inside that launch is BOUNDED: sorters that never publish (`fused` knob 2) cost every waiting workgroup its polls,
+   the launch ends, the call is planned the ordinary way and scores what the oracle scores; the engine never tries again.
+"""
+import contextlib
+import ctypes
+import os
+import random
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import stringzilla_amd as szs  # noqa: E402
+from stringzilla_amd import _abi, matrices, workloads  # noqa: E402
+
+
+@contextlib.contextmanager
+def knob(name, value):
+    previous = _abi.tuning_set(name, value)
+    try:
+        yield
+    finally:
+        _abi.tuning_set(name, previous)
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+
+    assert torch.cuda.is_available(), "the gpu-marked tests need a GPU"
+    return szs.DeviceScope(gpu_device=0)
+
+
+@pytest.fixture(scope="module")
+def checker(oracle):
+    """The reference's own engines on every host thread when oracle/_ref is built (it travels to the GPU box), else the oracle."""
+    from oracle import binding
+
+    if not binding.reference_available():
+        return oracle, False
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return binding.reference(tier=binding.reference_best_tier(), threads=threads), True
+
+
+def _strings(tape):
+    return [tape[i] for i in range(len(tape))]
+
+
+def _engine_and_scorer(load, gpu, checker):
+    if load.kind in ("levenshtein", "levenshtein_utf8"):
+        cls = szs.LevenshteinDistances if load.kind == "levenshtein" else szs.LevenshteinDistancesUTF8
+        scorer = checker.levenshtein if load.kind == "levenshtein" else checker.levenshtein_utf8
+        return cls(**load.costs, capabilities=gpu), lambda rows, columns: scorer(rows, columns, **load.costs)
+    table = matrices.by_name(load.table)
+    cls = szs.NeedlemanWunschScores if load.kind == "needleman_wunsch" else szs.SmithWatermanScores
+    return cls(*table, **load.costs, capabilities=gpu), lambda rows, columns: getattr(checker, load.kind)(
+        rows, columns, *table, load.costs["open"], load.costs["extend"])
+
+
+# ---- 1. whole matrices -----------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("index", [2, 3])
+def test_whole_matrix_of_a_full_size_config_equals_the_reference(gpu, checker, index):
+    """Every one of the 1,048,576 cells of configs 2 and 3 (the batches bench.py times: std::mt19937_64) - and of the transposed call."""
+    engine_of, is_reference = checker
+    if not is_reference and index == 3:
+        pytest.skip("config 3's 2.7e11 cells need the reference's SIMD engines (oracle/_ref is not built)")
+    load = workloads.config(index, generator="mt19937_64" if os.path.exists(workloads.MT19937_64_LIBRARY) else "numpy")
+    engine, score = _engine_and_scorer(load, gpu, engine_of)
+    got = engine(load.queries, load.candidates, device=gpu)
+    expected = score(_strings(load.queries), _strings(load.candidates))
+    wrong = np.argwhere(got.view(np.int64) != expected.view(np.int64))
+    assert not len(wrong), (load.name, len(wrong), wrong[:5].tolist())
+    got = engine(load.candidates, load.queries, device=gpu)  # all tables and costs of these configs are symmetric
+    assert np.array_equal(got.view(np.int64), expected.T.view(np.int64)), load.name
+
+
+@pytest.mark.parametrize("index", [4, 5, 6])
+def test_sixty_four_whole_rows_of_the_large_configs_equal_the_reference(gpu, checker, index):
+    """Configs 4, 5 and 5u at full size: 64 WHOLE rows - the longest and the shortest query, the others evenly spaced over the
+    queries sorted by length, so every width tier and strip count of the batch is among them - against every candidate."""
+    engine_of, is_reference = checker
+    if not is_reference:
+        pytest.skip("needs the reference's SIMD engines (oracle/_ref is not built)")
+    load = workloads.config(index)
+    engine, score = _engine_and_scorer(load, gpu, engine_of)
+    matrix = engine(load.queries, load.candidates, device=gpu)
+    order = np.argsort(load.queries.lengths(), kind="stable")
+    picked = sorted({int(order[int(round(k))]) for k in np.linspace(0, len(order) - 1, 64)})
+    candidates = _strings(load.candidates)
+    # the candidates take the row role in the checker so that its threads have rows to share; tables and costs are symmetric
+    expected = score(candidates, [load.queries[i] for i in picked])
+    wrong = np.argwhere(matrix[picked].view(np.int64) != expected.T.view(np.int64))
+    assert not len(wrong), (load.name, len(wrong), wrong[:5].tolist())
+
+
+# ---- 2. the soak -----------------------------------------------------------------------------------------------------------
+
+
+def _raw_step(engine, scope, queries, candidates, out):
+    """The raw C-ABI call as a closure (what bench.py times): no Python between the launches but this."""
+    q_tape, c_tape = queries._tape(0), candidates._tape(0)
+    error = ctypes.c_char_p()
+    call, columns = _abi.lib.szs_levenshtein_distances_u32tape, len(candidates)
+
+    def step():
+        status = call(engine.handle, scope.handle, ctypes.byref(q_tape), ctypes.byref(c_tape), out.data_ptr(), columns, ctypes.byref(error))
+        assert status == 0, (status, error.value)
+
+    step.keepalive = (q_tape, c_tape, queries, candidates, out)
+    return step
+
+
+def _soak(gpu, checker, launches, hammer):
+    import torch
+
+    engine_of, _ = checker
+    side, batches = 1024, 3
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+    tapes = [(workloads.random_tape(np.random.default_rng(100 + 2 * b), side, 96, 160, workloads.ASCII_PRINTABLE).to_device(0),
+              workloads.random_tape(np.random.default_rng(101 + 2 * b), side, 96, 160, workloads.ASCII_PRINTABLE).to_device(0)) for b in range(batches)]
+    outs = [torch.zeros((side, side), dtype=torch.int64, device="cuda:0") for _ in range(2)]
+    # what the PLAIN path writes, itself checked cell for cell against the reference (the oracle where _ref is absent: 64 rows)
+    expected = []
+    with knob("fused", 0):
+        for queries, candidates in tapes:
+            plain = torch.zeros((side, side), dtype=torch.int64, device="cuda:0")
+            _raw_step(engine, gpu, queries, candidates, plain)()
+            assert engine.last_call_profile().planner != 4
+            rows = range(side) if checker[1] else range(0, side, 16)
+            truth = engine_of.levenshtein([queries[i] for i in rows], _strings(candidates))
+            assert np.array_equal(plain.cpu().numpy()[list(rows)].view(np.uint64), truth)
+            expected.append(plain)
+    steps = [[_raw_step(engine, gpu, *tapes[b], outs[o]) for o in range(2)] for b in range(batches)]
+
+    stop, hammered = threading.Event(), []
+    worker = None
+    if hammer:  # a second engine on a scope (= stream) of its own: NW and SW batches of uneven sizes, back to back, until told to stop
+        other_scope = szs.DeviceScope(gpu_device=0)
+        table = matrices.blosum62()
+        other = szs.NeedlemanWunschScores(*table, open=-4, extend=-4, capabilities=other_scope)
+        loads = [workloads.config(3, scale=scale) for scale in (1 / 16, 1 / 4, 1 / 32)]
+        for load in loads:
+            load.queries.to_device(0), load.candidates.to_device(0)
+
+        def run():
+            k = 0
+            while not stop.is_set():
+                load = loads[k % len(loads)]
+                other(load.queries, load.candidates, device=other_scope)
+                k += 1
+            hammered.append(k)
+
+        worker = threading.Thread(target=run, daemon=True)
+        worker.start()
+
+    mismatches = torch.zeros((), dtype=torch.int64, device="cuda:0")
+    fused_calls = 0
+    try:
+        for k in range(launches):
+            b, o = k % batches, (k // batches) % 2
+            steps[b][o]()
+            fused_calls += engine.last_call_profile().planner == 4
+            mismatches += (outs[o] != expected[b]).sum()
+            if k % 1024 == 1023:
+                assert int(mismatches) == 0, f"{int(mismatches)} cells differ from the plain path by launch {k}"
+            if k % 512 == 0:
+                outs[o].fill_(-1)  # no launch may pass on what an earlier one left in the matrix
+    finally:
+        stop.set()
+        if worker is not None:
+            worker.join(timeout=120)
+    assert int(mismatches) == 0
+    # every call after the first of these counts is the ONE launch that plans itself
+    assert fused_calls >= launches - 2, (fused_calls, launches)
+    if hammer:
+        assert hammered and hammered[0] >= 1, "the second engine never ran beside the soak"
+    return fused_calls
+
+
+def test_ten_thousand_fused_launches_alone(gpu, checker):
+    _soak(gpu, checker, 10000, hammer=False)
+
+
+def test_ten_thousand_fused_launches_beside_a_second_engine(gpu, checker):
+    """The same stream of launches while NW batches of three sizes keep the CUs unevenly busy from another stream: workgroups of the
+    fused launch then start late, out of step and beside foreign residents - the conditions the microarchitecture guide asks every
+    hand-over to be tested under."""
+    _soak(gpu, checker, 10000, hammer=True)
+
+
+# ---- 3. the bounded wait ---------------------------------------------------------------------------------------------------
+
+
+def test_sorters_that_never_publish_cost_a_replan_not_a_hang(gpu, oracle):
+    rng = random.Random(6)
+    words = lambda count, lo, hi: [bytes(rng.choice(b"ACGTN") for _ in range(rng.randint(lo, hi))) for _ in range(count)]
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+    shape = lambda: (words(300, 30, 200), words(520, 0, 220))
+    queries, candidates = shape()
+    assert np.array_equal(engine(queries, candidates, device=gpu), oracle.levenshtein(queries, candidates))
+    queries, candidates = shape()
+    assert np.array_equal(engine(queries, candidates, device=gpu), oracle.levenshtein(queries, candidates))
+    assert engine.last_call_profile().planner == 4
+    with knob("fused", 2):  # the sorters sort and report, but the `ready` words never change: everybody's polls run out
+        for _ in range(3):
+            queries, candidates = shape()
+            got = engine(queries, candidates, device=gpu)
+            assert np.array_equal(got, oracle.levenshtein(queries, candidates))
+            assert engine.last_call_profile().planner in (1, 2), engine.last_call_profile().planner
+    # an engine on which a launch gave up does not try again (a real hang would cost ~0.2 s per call): planned, and right
+    queries, candidates = shape()
+    assert np.array_equal(engine(queries, candidates, device=gpu), oracle.levenshtein(queries, candidates))
+    assert engine.last_call_profile().planner in (1, 2)
+    # ... while a fresh engine does
+    fresh = szs.LevenshteinDistances(capabilities=gpu)
+    for _ in range(2):
+        queries, candidates = shape()
+        assert np.array_equal(fresh(queries, candidates, device=gpu), oracle.levenshtein(queries, candidates))
+    assert fresh.last_call_profile().planner == 4

@@ -232,6 +232,31 @@ def test_every_declared_kernel_entry_point_is_defined():
     assert declared <= defined, sorted(declared - defined)
 
 
+def test_the_library_exports_the_abi_and_nothing_else():
+    """A drop-in exports what the header declares: the 41 symbols of include/stringzillas/stringzillas.h plus the additive
+    `szs_rocm_*` ones - no kernel host stubs (`_ZN7szs_hip...`), no `__hip_cuid_*`, no `szs_hip_*` / `szs_tuning_*` internals
+    (csrc/exports.map; VERDICT r5 counted 157 of them) - under the SONAME the reference's CMake gives the slot
+    (`libstringzillas_rocm_shared.so.5`: CMakeLists.txt:540, SOVERSION = major)."""
+    import subprocess
+
+    library = os.path.join(ROOT, "stringzilla_amd", "lib", "libstringzillas_rocm_shared.so")
+    listed = subprocess.run(["nm", "-D", "--defined-only", library], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in listed.splitlines() if line.strip()}
+    strip = lambda text: re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    reference_header = strip(open(os.path.join(ROOT, "include", "stringzillas", "stringzillas.h")).read())
+    rocm_header = strip(open(os.path.join(ROOT, "include", "stringzillas", "stringzillas_rocm.h")).read())
+    declared = set(re.findall(r"\b(szs_(?!rocm_)\w+|sz_memory_allocator_init_unified)\s*\(", reference_header))
+    declared = {name for name in declared if not name.endswith("_t")}
+    additive = set(re.findall(r"\b(szs_rocm_\w+)\s*\(", rocm_header))
+    assert len(declared) == 41, sorted(declared)
+    assert declared <= exported, sorted(declared - exported)
+    assert additive <= exported, sorted(additive - exported)
+    assert exported == declared | additive, sorted(exported - declared - additive)
+    dynamic = subprocess.run(["readelf", "-d", library], capture_output=True, text=True, check=True).stdout
+    assert "Library soname: [libstringzillas_rocm_shared.so.5]" in dynamic
+    assert os.path.exists(library + ".5")
+
+
 def test_shard_rows_balances_like_lpt():
     rng = np.random.default_rng(5)
     weights = rng.zipf(1.3, size=3163).clip(8, 2048).astype(np.uint64)
