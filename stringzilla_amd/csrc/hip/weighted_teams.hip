@@ -133,8 +133,18 @@ __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
     u32 const lane_in_team = threadIdx.x % L, team = threadIdx.x / L;
     bool const is_head = lane_in_team == 0, is_tail = lane_in_team == L - 1;
     u32 const strip_base = layout::strip_base(lane_in_team, classes);
-    // this workgroup's parked rows: [column][team]
-    parked_t *const parked = reinterpret_cast<parked_t *>(parked_rows) + (u64)blockIdx.x * parked_columns * teams + team;
+    // this workgroup's parked rows: [column][team], and behind them its copy of what DP row 0 hands down: [column]
+    parked_t *const region = reinterpret_cast<parked_t *>(parked_rows) + (u64)blockIdx.x * parked_columns * (teams + 1);
+    parked_t *const parked = region + team;
+    parked_t *const border_row = region + (u64)parked_columns * teams;
+    // What DP row 0 hands down is a function of the column alone: written ONCE per workgroup of the persistent grid, read by the first
+    // pass of every work item with the very loads the later passes read their parked rows with (another base, stride 1 instead of
+    // `teams`: both wavefront-uniform).  (Rounds 3 - 5 prefilled the parked rows with it for every work item - (longest + 9) x teams
+    // stores per item: config 3, where most pairs have no other pass, wrote 1.3 GB per call for 1.1 GB of algorithmic traffic.
+    // Computing it in the first pass instead - scalar arithmetic, the column is uniform - put a branch into every step of the main
+    // loop and cost config 3 6.5 % (21.0 -> 19.7 TCUPS): the loop must stay one basic block.)
+    for (u32 column = threadIdx.x; column < parked_columns; column += team_block_threads_k)
+        border_row[column] = park_of<affine_>(team_border_edge(k, column));
 
     bool const transposed = (layout_flags & SZS_LAYOUT_TRANSPOSED) != 0, symmetric = (layout_flags & SZS_LAYOUT_SYMMETRIC) != 0;
     auto write_result = [&](szs_string_ref_t const &query, szs_string_ref_t const &candidate, i64 score) {
@@ -183,9 +193,7 @@ __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
         }
         if (!longer) continue;
 
-        // ---- what DP row 0 hands down, parked like any other group boundary (the passes below then are all alike)
-        for (u32 slot = threadIdx.x; slot < (longest_in_block + 1 + team_slack_columns_k) * teams; slot += team_block_threads_k)
-            (parked - team)[slot] = park_of<affine_>(team_border_edge(k, slot / teams));
+        (void)longest_in_block;
 
         u32 const passes = team_passes<L, R>(longer);
         team_rows_t<affine_, R> rows;
@@ -196,6 +204,9 @@ __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
         for (u32 pass = 0; pass < passes; ++pass) {
             u32 const first_row = pass * group_rows;
             bool const park_this_pass = pass + 1 < passes;
+            // where the head lanes read what the rows above hand down: the border row (first pass) or this team's parked row
+            parked_t const *const above = pass ? parked : border_row;
+            u32 const above_stride = pass ? teams : 1u;
 
             // Rows per lane in this pass: R, or - last pass - what is left over L lanes in whole chunks of four (team_core.hpp).
             u32 const registers_now = (u32)__builtin_amdgcn_readfirstlane((int)team_pass_registers<L, R>(longer, pass));
@@ -278,15 +289,21 @@ __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
                 out = step.end();
                 out_row = in_row;
             };
-            // Predicated step `t`: the head's column is t + 1, this lane's is t + 1 - lane_in_team.
-            auto careful_step = [&](auto chunks, u32 t) {
+            // Predicated step `t`: the head's column is t + 1, this lane's is t + 1 - lane_in_team.  `fetched`: the head's text byte
+            // and (later passes) parked entry of this column are at hand - the fill phase fetches them a batch of four steps at a time;
+            // the drain phase, where few heads still have a column, fetches its own.
+            auto careful_step = [&](auto chunks, u32 t, auto fetched, u32 fetched_byte, parked_t const &fetched_slot) {
+                constexpr bool fetched_ = decltype(fetched)::value;
                 u32 const head_column = t + 1;
                 team_edge_t head_edge = {0, 0};
                 u32 head_row = 0;
                 if (head_column <= text_length) {
-                    head_edge = unpark<affine_>(parked[(u64)head_column * teams]);
-                    u32 const at = text.byte_shift + head_column - 1;
-                    head_row = class_offset_of_byte[(text.aligned_base[at / 4] >> (8 * (at % 4))) & 0xFFu];
+                    head_edge = unpark<affine_>(fetched_ ? fetched_slot : above[(u64)head_column * above_stride]);
+                    if constexpr (fetched_) head_row = class_offset_of_byte[fetched_byte];
+                    else {
+                        u32 const at = text.byte_shift + head_column - 1;
+                        head_row = class_offset_of_byte[(text.aligned_base[at / 4] >> (8 * (at % 4))) & 0xFFu];
+                    }
                 }
                 team_edge_t in;
                 u32 in_row;
@@ -303,8 +320,32 @@ __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
                 std::integral_constant<int, fixed_ == R / 4 ? R / 4 : 0> const careful; // every register, or ask
                 constexpr u32 fill = (u32)((L - 1 + 3) / 4 * 4); // the first step at which every lane of a team has a column
                 u32 t = 0;
+                // ---- fill: the first lanes of every team start one after the other.  Batches of four steps: the head's four text bytes
+                //      are one spliced dword, fetched - like the parked entries of a later pass - a batch ahead of the steps that use them
+                //      (rounds 3 - 5: a dependent global load, an LDS lookup and - later passes - another global load INSIDE every one of
+                //      these steps; config 3's candidates are ~512 columns, 16 of them walked that way per pass).  Steps past the end of
+                //      a short wavefront's texts find no lane with a column and do nothing.
+#ifndef SZS_TEAM_FILL_BATCHED
+#define SZS_TEAM_FILL_BATCHED 1
+#endif
+                if (SZS_TEAM_FILL_BATCHED && fill && longest_in_wave) {
+                    u32 raw_low = text.raw(0), raw_high = text.raw(1);
 #pragma unroll 1
-                for (; t < fill && t < longest_in_wave + L - 1; ++t) careful_step(careful, t);
+                    for (; t < fill && t < longest_in_wave + L - 1; t += 4) {
+                        u32 const bytes = text.splice(raw_low, raw_high);
+                        raw_low = raw_high, raw_high = text.raw(t / 4 + 2);
+                        parked_t now[4] = {}; // the batch's four entries from above in flight together (one latency, not four)
+#pragma unroll
+                        for (u32 s = 0; s < 4; ++s)
+                            if (t + 1 + s <= text_length) now[s] = above[(u64)(t + 1 + s) * above_stride];
+#pragma unroll
+                        for (u32 s = 0; s < 4; ++s) careful_step(careful, t + s, std::true_type {}, (bytes >> (8 * s)) & 0xFFu, now[s]);
+                    }
+                }
+#if !SZS_TEAM_FILL_BATCHED
+#pragma unroll 1
+                for (; t < fill && t < longest_in_wave + L - 1; ++t) careful_step(careful, t, std::false_type {}, 0u, parked_t {});
+#endif
                 // ---- main loop: batches of four steps in which EVERY live lane of the wavefront has a column - no length
                 //      checks, unconditional loads / stores (dead teams run along on their own parked slots).
                 if (t == fill && t + 4 <= shortest_in_wave) {
@@ -312,7 +353,7 @@ __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
                     u32 raw_low = text.raw_clamped(dword), raw_high = text.raw_clamped(dword + 1);
                     parked_t ahead[4]; // what the head takes at the steps t ... t + 3; refilled for the next batch as it goes
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) ahead[s] = parked[(u64)(t + 1 + s) * teams];
+                    for (int s = 0; s < 4; ++s) ahead[s] = above[(u64)(t + 1 + s) * above_stride];
                     u32 bytes_now = text.splice(raw_low, raw_high);
                     raw_low = raw_high, raw_high = text.raw_clamped(dword + 2);
                     // rows travel one step AHEAD of the cells: this lane's row of the first step of the loop ...
@@ -327,7 +368,7 @@ __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
 #pragma unroll
                         for (int s = 0; s < 4; ++s) {
                             team_edge_t const head_edge = unpark<affine_>(ahead[s]);
-                            ahead[s] = parked[(u64)(t + 5 + s) * teams]; // the slack columns make the overrun harmless
+                            ahead[s] = above[(u64)(t + 5 + s) * above_stride]; // the slack columns make the overrun harmless
                             u32 const my_row_after = from_left<L>(head_row_after, my_row, is_head);
                             head_row_after = class_offset_of_byte[(s < 2 ? bytes_now >> (8 * (s + 2)) : bytes_ahead >> (8 * (s - 2))) & 0xFFu];
                             team_edge_t in;
@@ -343,7 +384,7 @@ __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
                 }
                 // ---- drain: ragged lengths and the lanes that are still behind their head
 #pragma unroll 1
-                for (; t < longest_in_wave + L - 1; ++t) careful_step(careful, t);
+                for (; t < longest_in_wave + L - 1; ++t) careful_step(careful, t, std::false_type {}, 0u, parked_t {});
             };
             if (longest_in_wave) {
 #define SZS_TEAM_WALK(C)                                                                                               \
@@ -502,7 +543,7 @@ extern "C" size_t szs_hip_weighted_team_workspace_bytes(int objective, int affin
     if (classes > (objective == 2 ? 256u : 32u) || !szs_hip_weighted_team_fits(shape, classes)) return 0;
 #define SZS_TEAM_BYTES(LOCAL, AFFINE, WIDE, DISTANCE, L, R, W)                                                         \
     return team_header_bytes_k + (size_t)team_grid<LOCAL, AFFINE, WIDE, DISTANCE, L, R, W>(team_work_items<L>(queries_count, candidates_count), classes) * \
-                                     (longest_candidate + 1 + team_slack_columns_k) * (team_block_threads_k / L) *     \
+                                     (longest_candidate + 1 + team_slack_columns_k) * (team_block_threads_k / L + 1) * \
                                      sizeof(parked_edge_t<AFFINE>)
 #define SZS_TEAM_SHAPE_BYTES(L, R, W) SZS_TEAM_DISPATCH(L, R, W, SZS_TEAM_BYTES)
     SZS_TEAM_SHAPES(SZS_TEAM_SHAPE_BYTES)

@@ -1154,8 +1154,13 @@ static sz_status_t cross_tiny(szs_call_t *call, uint32_t planner_mode, szs_plan_
     if (*unfit == sequence) {
         /* refused (a block or span too dense in long strings, a string beyond 255 bytes): remember the counts, so that a stream of
          * such batches does not pay this launch and its wait on every call because their summaries look like words */
-        engine->tiny_valid = 0, engine->tiny_refused = 16; /* calls of these counts that go straight to the ordinary path */
-        engine->tiny_q_count = call->q_count, engine->tiny_c_count = call->c_count;
+        engine->tiny_valid = 0;
+        if (planner_mode == 1) { /* ... a batch whose SUMMARY looked like words (clustered long lines among short ones).  A batch that
+                                    came straight here on the previous call's word (mode 5: sentences after words) is judged by its
+                                    own summary next time - nothing to remember */
+            engine->tiny_refused = 16; /* calls of these counts that go straight to the ordinary path */
+            engine->tiny_q_count = call->q_count, engine->tiny_c_count = call->c_count;
+        }
         return SZS_TINY_NOT_TAKEN;
     }
     engine->tiny_refused = 0;

@@ -41,10 +41,8 @@ void score_item(text_t q_low, text_t q_high, bool has_high, std::vector<text_t> 
 
     uint32_t longest_text = 0;
     for (auto const &text : block) longest_text = std::max(longest_text, text.length);
-    // parked rows [column][team]: prefilled with what DP row 0 hands down
-    std::vector<team_edge_t> parked((size_t)(longest_text + 1) * teams);
-    for (uint32_t j = 0; j <= longest_text; ++j)
-        for (uint32_t team = 0; team < teams; ++team) parked[(size_t)j * teams + team] = team_border_edge(k, j);
+    // parked rows [column][team]: poisoned - nothing may read an entry before a tail lane has written it
+    std::vector<team_edge_t> parked((size_t)(longest_text + 1) * teams, team_edge_t {0xDEADBEEFu, 0xDEADBEEFu});
 
     uint32_t const passes = team_passes<L, R>(longer);
     struct lane_t {
@@ -95,7 +93,9 @@ void score_item(text_t q_low, text_t q_high, bool has_high, std::vector<text_t> 
                         in[lane] = lanes[(size_t)team * L + lane - 1].out, in_class[lane] = lanes[(size_t)team * L + lane - 1].out_class;
                     uint32_t const head_column = t + 1;
                     if (head_column <= text.length) {
-                        in[0] = parked[(size_t)head_column * teams + team];
+                        // the first pass COMPUTES what DP row 0 hands down (as the kernel does since round 6); later passes read what the
+                        // tail lanes of the previous pass parked
+                        in[0] = pass == 0 ? team_border_edge(k, head_column) : parked[(size_t)head_column * teams + team];
                         in_class[0] = byte_to_class[text.bytes[head_column - 1]];
                     }
                     else in[0] = team_edge_t {0xDEADBEEFu, 0xDEADBEEFu}, in_class[0] = 0;

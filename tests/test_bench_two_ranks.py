@@ -52,7 +52,7 @@ def test_ranks_on_one_device(ranks, launcher, tmp_path):
 
     gpu = szs.DeviceScope(gpu_device=0)
     expected = {}
-    for config in (4, 5):
+    for config in (2, 4, 5):
         # the batches bench.py scores: std::mt19937_64 for configs 1-4 when the helper library is built, numpy otherwise
         load = workloads.config(config, scale=scale, generator="mt19937_64" if config <= 4 else "numpy")
         if load.kind == "levenshtein":
@@ -61,14 +61,50 @@ def test_ranks_on_one_device(ranks, launcher, tmp_path):
             engine = szs.SmithWatermanScores(*matrices.by_name(load.table), **load.costs, capabilities=gpu)
         expected[config] = (int(engine(load.queries, load.candidates, device=gpu).view(np.int64).sum()), load.cells, len(load.queries))
     records = [entry["configs_record"] for entry in printed if "configs_record" in entry]
-    assert set(line["configs_gcups"]) >= {"4", "5", "4@node", "5@node"}
+    assert set(line["configs_gcups"]) >= {"2", "4", "5", "2@node", "4@node", "5@node"}
+    assert line["ranks"] == {"backend": "gloo", "world": ranks, "devices": 1}  # what the collective layer says about the job
     strong = {record["config"]: record for record in records if record.get("scaling") == "strong" and "sharding" in record}
     node = {record["config"]: record for record in records if record.get("entry_point", "").startswith("szs_rocm_node")}
-    for config in (4, 5):
+    for config in (2, 4, 5):  # 2: the metric's own batch, strong-scaled beside the weak-scaled headline (round 6)
         checksum, cells, rows = expected[config]
         assert "error" not in strong[config] and "error" not in node[config], (strong[config], node[config])
         assert strong[config]["results_checksum"] == checksum and strong[config]["cells"] == cells
         assert sum(strong[config]["rows_per_gpu"]) == rows and len(strong[config]["busy_ms_per_gpu"]) == ranks
         assert strong[config]["imbalance_max_over_mean"] >= 1.0
+        assert 0 < strong[config]["roofline"]["frac"] <= 1 and strong[config]["roofline"]["peak"] == 8000.0 * ranks
+        assert strong[config]["ranks"] == ranks and strong[config]["backend"] == "gloo" and strong[config]["kernel_gcups"] > 0
         assert node[config]["results_checksum"] == checksum and sum(node[config]["rows_per_gpu"]) == rows
         assert len(node[config]["busy_ms_per_gpu"]) == ranks and all(ms > 0 for ms in node[config]["busy_ms_per_gpu"])
+
+
+def test_two_ranks_on_two_devices_over_rccl(tmp_path):
+    """The path the driver's 8-GPU run takes - `--backend nccl` (RCCL), one rank per DEVICE - on the smallest box that has it: two
+    GPUs.  Skipped on a one-GPU box (every `gpurun` box of this pool): there the same code runs over `gloo` on one device, above.
+    Checks what only distinct devices can show: the broadcast tapes arrive on the other device, every rank scores on its own GPU,
+    the strong-scaled checksums equal a single-GPU computation."""
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip(f"needs two GPUs, {torch.cuda.device_count()} visible")
+    import stringzilla_amd as szs
+    from stringzilla_amd import workloads
+
+    scale = 1 / 8
+    command = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--backend", "nccl",
+               "--extra-scale", str(scale), "--extra-seconds", "0.2", "--cpu-seconds", "1", "--extra-cpu-seconds", "0.5", "--extra-configs", "2,5",
+               "--details", str(tmp_path / "bench_configs.json")]
+    environment = {key: value for key, value in os.environ.items() if key not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    environment["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"  # the host driver only supports dmabuf IPC
+    done = subprocess.run(command, cwd=ROOT, capture_output=True, text=True, timeout=900, env=environment)
+    assert done.returncode == 0, done.stdout[-3000:] + done.stderr[-3000:]
+    printed = [json.loads(text) for text in done.stdout.splitlines() if text.startswith("{")]
+    line = printed[-1]
+    assert line["n_gpus"] == 2 and line["ranks"] == {"backend": "nccl", "world": 2, "devices": 2}
+    gpu = szs.DeviceScope(gpu_device=0)
+    records = {record["config"]: record for record in (entry["configs_record"] for entry in printed if "configs_record" in entry)
+               if record.get("scaling") == "strong" and "sharding" in record}
+    for config in (2, 5):
+        load = workloads.config(config, scale=scale, generator="mt19937_64" if config <= 4 else "numpy")
+        engine = szs.LevenshteinDistances(**load.costs, capabilities=gpu)
+        checksum = int(engine(load.queries, load.candidates, device=gpu).view(np.int64).sum())
+        assert records[config]["results_checksum"] == checksum and records[config]["backend"] == "nccl" and not records[config]["same_device"]
