@@ -452,6 +452,8 @@ unsigned szs_hip_weighted_team_shape(unsigned index);
 int szs_hip_weighted_team_has_shape(unsigned shape);
 uint32_t szs_hip_weighted_team_reach_limit(int objective, int wide);
 int szs_hip_weighted_team_fits(unsigned shape, uint32_t classes);
+/** Candidates per work item of a compiled shape (= teams per workgroup: 256 / lanes, or 512 / lanes for teams of more than sixteen lanes); 0: no such shape. */
+unsigned szs_hip_weighted_team_candidates_per_item(unsigned shape);
 /** OR-s into `presence[8]` (device memory, zeroed by the caller) one bit per byte value that occurs in the tape's strings. */
 int szs_hip_byte_presence(void const *data, void const *offsets, uint32_t count, int wide, uint32_t *presence, void *stream);
 int szs_hip_weighted_team_scores(int objective, int affine, int wide, unsigned shape, uint32_t classes, szs_cost_model_t const *model,

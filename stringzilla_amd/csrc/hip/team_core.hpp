@@ -318,6 +318,9 @@ SZS_HD void team_last_row(u32 length, u32 longer_query, u32 &pass, u32 &lane, u3
  *    L = 16  a lane group holds each strip exactly once, so (address / 16) mod 16 is made a function of the strip alone: the
  *            strips are dealt over `blocks` regions whose sizes are 16 modulo 256, and inside a region the rows of `slots`
  *            strips of one class share a block of 256 bytes.  No conflicts whatever the classes (PMC, config 4: 0.0 %).
+ *    L > 16  (round 6: teams of 32 or 64 lanes, handed over by `wave_shr:1`) every lane group still holds sixteen DIFFERENT strips
+ *            whose numbers are distinct modulo 16 (the groups are {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32): strip k
+ *            lies where strip k mod 16 of the sixteen-lane layout lies, in quarter k / 16 - the quarters a multiple of 256 bytes apart.
  *    L < 16  a lane group holds 16 / L teams with a class each.  Rows of R x 4 + 16 bytes, classes L rows + 16 bytes apart:
  *            the lanes of one team never collide, two teams collide on a lane or two for some class differences - the first
  *            layout (classes 256 bytes apart) had every team of a group on the SAME banks: 72 % of the LDS cycles of a
@@ -325,15 +328,19 @@ SZS_HD void team_last_row(u32 length, u32 longer_query, u32 &pass, u32 &lane, u3
 template <int L, int R>
 struct team_profile_layout {
     static constexpr u32 row_bytes = (u32)R * 4;
-    static constexpr bool whole_row = L == 16; // every strip once per lane group
-    static constexpr u32 slots = !whole_row ? 1 : row_bytes >= 256 ? 1 : (256 / row_bytes < (u32)L ? 256 / row_bytes : (u32)L); // strips per class block
-    static constexpr u32 blocks = whole_row ? (u32)L / slots : 1;
+    static constexpr bool whole_row = L >= 16; // every strip (modulo 16) once per lane group
+    static constexpr u32 inner = L >= 16 ? 16u : (u32)L; // strips that share one sixteen-lane layout
+    static constexpr u32 slots = !whole_row ? 1 : row_bytes >= 256 ? 1 : (256 / row_bytes < inner ? 256 / row_bytes : inner); // strips per class block
+    static constexpr u32 blocks = whole_row ? inner / slots : 1;
     static constexpr u32 strip_bytes = row_bytes + 16; // L < 16
     static constexpr u32 class_bytes = !whole_row ? (u32)L * strip_bytes + 16 : slots > 1 ? 256 : row_bytes;
     SZS_HD static u32 region_bytes(u32 classes) { return classes * class_bytes + 16; }
-    SZS_HD static u32 total_bytes(u32 classes) { return blocks * region_bytes(classes); }
+    /** L > 16: the bytes of sixteen strips, rounded up to the 256 bytes the banks repeat after. */
+    SZS_HD static u32 quarter_bytes(u32 classes) { return (blocks * region_bytes(classes) + 255u) / 256u * 256u; }
+    SZS_HD static u32 total_bytes(u32 classes) { return L > 16 ? (u32)(L / 16) * quarter_bytes(classes) : blocks * region_bytes(classes); }
     /** Byte offset of the row of strip `k`, class 0; the row of class c lies c x class_bytes further. */
     SZS_HD static u32 strip_base(u32 k, u32 classes) {
+        if (L > 16) return (k / 16) * quarter_bytes(classes) + ((k % 16) % blocks) * region_bytes(classes) + ((k % 16) / blocks) * row_bytes;
         return whole_row ? (k % blocks) * region_bytes(classes) + (k / blocks) * row_bytes : k * strip_bytes;
     }
 };

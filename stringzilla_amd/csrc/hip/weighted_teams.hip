@@ -43,7 +43,10 @@ namespace szs_hip {
 
 using namespace szs_team;
 
-constexpr u32 team_block_threads_k = 256;
+/** Threads of a workgroup: 256, or - teams of more than sixteen lanes - 512: their sixty-four strips of profile fill most of a CU's LDS
+ *  (NUC.4.4: 132 KB), one workgroup per CU, and two wavefronts per SIMD - what the affine bodies' 256 registers allow anyway - are 512 threads. */
+template <int L>
+constexpr u32 team_threads() { return L > 16 ? 512u : 256u; }
 constexpr u32 team_slack_columns_k = 8;      // columns the parked-row prefetch may run past the longest candidate
 constexpr size_t team_header_bytes_k = 256;  // the work counter lives at the head of the workspace
 constexpr size_t team_most_profile_bytes_k = 160 * 1024 - 4096; // a CU's LDS less the static arrays of the kernel
@@ -52,6 +55,13 @@ constexpr size_t team_most_profile_bytes_k = 160 * 1024 - 4096; // a CU's LDS le
 template <int L>
 __device__ __forceinline__ u32 from_left(u32 head_value, u32 value, bool is_head) {
     if constexpr (L == 1) return head_value;
+    else if constexpr (L > 16) {
+        // wave_shr:1 - the whole wavefront shifts by one lane, across its four rows of sixteen (a GFX9 control; exact on gfx950 and at the
+        // rate of row_shr:1: scripts/dpp_wave_probe.hip, profiles/r06/dpp_wave_probe.txt).  Lane 0 has no source and keeps `old`.
+        u32 const moved = (u32)__builtin_amdgcn_update_dpp((int)head_value, (int)value, 0x138, 0xF, 0xF, false);
+        if constexpr (L == 64) return moved;
+        else return is_head ? head_value : moved; // lane 32 heads the second team; its source lane belongs to the first
+    }
     else {
         // row_shr:1 - lane 0 of a 16-lane row has no source and keeps `old` = the head's own input
         u32 const moved = (u32)__builtin_amdgcn_update_dpp((int)head_value, (int)value, 0x111, 0xF, 0xF, false);
@@ -102,7 +112,7 @@ __device__ __forceinline__ parked_edge_t<affine_> park_of(team_edge_t const &edg
  *                   its narrow register kernels cuda.cuh:2939-3128.
  */
 template <bool local_, bool affine_, bool wide_, bool distance_, int L, int R, int W>
-__global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
+__global__ __launch_bounds__(team_threads<L>(), W) void weighted_team_kernel(
     szs_cost_model_t const *__restrict__ model, szs_string_ref_t const *__restrict__ queries, u32 queries_count,
     szs_string_ref_t const *__restrict__ candidates, u32 candidates_count, u32 candidate_blocks, i64 *__restrict__ results,
     u64 results_row_stride, int layout_flags, char *__restrict__ parked_rows, u32 parked_columns, u32 *__restrict__ work_counter,
@@ -110,9 +120,10 @@ __global__ __launch_bounds__(team_block_threads_k, W) void weighted_team_kernel(
 
     using layout = team_profile_layout<L, R>;
     using parked_t = parked_edge_t<affine_>;
+    constexpr u32 team_block_threads_k = team_threads<L>();
     constexpr u32 teams = team_block_threads_k / L; // candidates per workgroup
     constexpr u32 group_rows = (u32)L * R;          // query rows per pass
-    static_assert(R % 4 == 0 && 16 % L == 0, "whole 16-byte profile chunks; teams inside a DPP row");
+    static_assert(R % 4 == 0 && (L <= 16 ? 16 % L == 0 : 64 % L == 0), "whole 16-byte profile chunks; teams inside a DPP row, or rows inside a team");
 
     extern __shared__ __attribute__((aligned(16))) char profile[];
     // Static LDS is kept small on purpose: BLOSUM62's sixteen strips are 51,328 bytes of profile, and THREE workgroups fit a CU
@@ -464,6 +475,7 @@ static u32 team_grid(u64 work_items, u32 classes) {
         // the attribute is per function, not per launch: the most this instance may ever ask for, set once
         size_t const most = team_profile_bytes<L, R>(distance_ ? 256 : 32) < team_most_profile_bytes_k ? team_profile_bytes<L, R>(distance_ ? 256 : 32)
                                                                                                       : team_most_profile_bytes_k;
+        constexpr u32 team_block_threads_k = team_threads<L>();
         if (hipFuncSetAttribute(reinterpret_cast<void const *>(weighted_team_kernel<local_, affine_, wide_, distance_, L, R, W>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)most) != hipSuccess ||
             hipGetDevice(&device) != hipSuccess ||
@@ -482,7 +494,7 @@ static u32 team_grid(u64 work_items, u32 classes) {
 
 template <int L>
 static u64 team_work_items(u32 queries_count, u32 candidates_count) {
-    u32 const teams = team_block_threads_k / L;
+    u32 const teams = team_threads<L>() / L;
     return (u64)((queries_count + 1) / 2) * ((candidates_count + teams - 1) / teams);
 }
 
@@ -490,7 +502,7 @@ static u64 team_work_items(u32 queries_count, u32 candidates_count) {
 
 /* The instances that are compiled: (lanes per team, registers per track, wavefronts per SIMD), each in both orders. */
 #ifndef SZS_TEAM_SHAPES
-#define SZS_TEAM_SHAPES(CALL) CALL(16, 32, 2) CALL(16, 16, 4) CALL(4, 32, 2) CALL(4, 16, 4)
+#define SZS_TEAM_SHAPES(CALL) CALL(16, 32, 2) CALL(16, 16, 4) CALL(4, 32, 2) CALL(4, 16, 4) CALL(64, 32, 2)
 #endif
 
 /* `objective`: 0 global (Needleman-Wunsch), 1 local (Smith-Waterman, gaps <= 0), 2 distance (Levenshtein, uniform costs). */
@@ -525,6 +537,16 @@ extern "C" int szs_hip_weighted_team_has_shape(unsigned shape) {
     return 0;
 }
 
+/** Candidates per work item (= teams per workgroup) of a shape; 0: not compiled. */
+extern "C" unsigned szs_hip_weighted_team_candidates_per_item(unsigned shape) {
+    using namespace szs_hip;
+#define SZS_TEAM_SHAPE_TEAMS(L, R, W)                                                                                  \
+    if (shape == L * 10000u + R * 100u + W) return team_threads<L>() / L;
+    SZS_TEAM_SHAPES(SZS_TEAM_SHAPE_TEAMS)
+#undef SZS_TEAM_SHAPE_TEAMS
+    return 0;
+}
+
 extern "C" uint32_t szs_hip_weighted_team_reach_limit(int objective, int wide) { return szs_team::team_reach_limit(objective, wide != 0); }
 
 /** Does the profile of `classes` classes fit a CU's LDS for this shape?  (Sixteen lanes x 32 registers: up to 77 classes.) */
@@ -543,7 +565,7 @@ extern "C" size_t szs_hip_weighted_team_workspace_bytes(int objective, int affin
     if (classes > (objective == 2 ? 256u : 32u) || !szs_hip_weighted_team_fits(shape, classes)) return 0;
 #define SZS_TEAM_BYTES(LOCAL, AFFINE, WIDE, DISTANCE, L, R, W)                                                         \
     return team_header_bytes_k + (size_t)team_grid<LOCAL, AFFINE, WIDE, DISTANCE, L, R, W>(team_work_items<L>(queries_count, candidates_count), classes) * \
-                                     (longest_candidate + 1 + team_slack_columns_k) * (team_block_threads_k / L + 1) * \
+                                     (longest_candidate + 1 + team_slack_columns_k) * (team_threads<L>() / L + 1) * \
                                      sizeof(parked_edge_t<AFFINE>)
 #define SZS_TEAM_SHAPE_BYTES(L, R, W) SZS_TEAM_DISPATCH(L, R, W, SZS_TEAM_BYTES)
     SZS_TEAM_SHAPES(SZS_TEAM_SHAPE_BYTES)
@@ -569,9 +591,9 @@ extern "C" int szs_hip_weighted_team_scores(int objective, int affine, int wide,
         hipError_t const error = hipMemsetAsync(counter, 0, sizeof(u32), s);                                           \
         if (error != hipSuccess) return (int)error;                                                                    \
         u32 const grid = team_grid<LOCAL, AFFINE, WIDE, DISTANCE, L, R, W>(work_items, classes);                                 \
-        u32 const teams = team_block_threads_k / L;                                                                    \
+        u32 const teams = team_threads<L>() / L;                                                                       \
         size_t const profile_bytes = team_profile_bytes<L, R>(classes);                                                \
-        hipLaunchKernelGGL((weighted_team_kernel<LOCAL, AFFINE, WIDE, DISTANCE, L, R, W>), dim3(grid), dim3(team_block_threads_k), \
+        hipLaunchKernelGGL((weighted_team_kernel<LOCAL, AFFINE, WIDE, DISTANCE, L, R, W>), dim3(grid), dim3(team_threads<L>()), \
                            profile_bytes, s, model, queries, queries_count, candidates,                                \
                            candidates_count, (candidates_count + teams - 1) / teams, results, results_row_stride,      \
                            layout_flags, parked, longest_candidate + 1 + team_slack_columns_k, counter, classes);      \

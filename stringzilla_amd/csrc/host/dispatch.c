@@ -312,7 +312,8 @@ static unsigned team_shape_for(int affine, uint32_t classes, szs_side_stats_t co
     if (knob == 0) return 0;
     if (knob > 0) return szs_hip_weighted_team_has_shape((unsigned)knob) && szs_hip_weighted_team_fits((unsigned)knob, classes) ? (unsigned)knob : 0;
     unsigned lanes = szs_plan_team_lanes(affine, queries, candidates);
-    for (; lanes; lanes = lanes > 4 ? 4 : 0) { /* sixteen strips of a rich alphabet (text: ~95 classes) do not fit a CU's LDS: four do */
+    for (; lanes; lanes = lanes > 16 ? 16 : lanes > 4 ? 4 : 0) { /* sixty-four strips fit a CU's LDS up to ~19 classes (DNA), sixteen strips
+                                                                     of a rich alphabet (text: ~95 classes) do not either: four do */
         /* Rows per lane: 16 (four wavefronts per SIMD, half the profile) when the longest query fits ONE pass of that shape
          * anyway - 4 x 16 rows: +17 ... 20 % at 24 ... 48 rows; 16 x 16: +4 ... 21 % at 192 ... 256 - or when the alphabet is
          * rich: four strips of 95 classes are 55 KB at 32 rows, two workgroups per CU (non-unit Levenshtein costs over text:
@@ -621,7 +622,8 @@ static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int dev
     uint64_t candidate_blocks = ((uint64_t)d->kc_count + SZS_CANDIDATES_PER_WORKGROUP - 1) / SZS_CANDIDATES_PER_WORKGROUP;
     uint64_t queries_most = 0xFFFFFFF0ull / (candidate_blocks ? candidate_blocks : 1);
     if (d->team) { /* the team tier's item is a PAIR of queries x the 256 / lanes candidates of a workgroup (weighted_teams.hip) */
-        uint64_t const per_block = 256u / (d->team / 10000u ? d->team / 10000u : 1u);
+        uint64_t per_block = szs_hip_weighted_team_candidates_per_item(d->team); /* 256 / lanes; 512 / lanes for the wave-wide teams */
+        if (!per_block) per_block = 256u / (d->team / 10000u ? d->team / 10000u : 1u);
         candidate_blocks = ((uint64_t)d->kc_count + per_block - 1) / per_block;
         queries_most = 2 * (0xFFFFFFF0ull / (candidate_blocks ? candidate_blocks : 1)); /* even: the pairs of a cut stay pairs */
     }

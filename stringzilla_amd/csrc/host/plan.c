@@ -413,6 +413,11 @@ unsigned szs_plan_team_lanes(int affine, szs_side_stats_t const *queries, szs_si
      * four lanes beat one pair per lane from 24 rows (linear: +8 % there, +50 % at 48) / 40 rows (affine) up; sixteen lanes pay
      * their fifteen fill and drain steps back only over candidates of a few hundred columns, from ~190 query rows. */
     if (mean_query < (affine ? 40 : 24)) return 0; /* a few rows per lane: the step's fixed cost takes over */
+    /* Round 6: the WHOLE wavefront as one team (64 lanes x 32 rows = 2048 query rows per pass; hip/weighted_teams.hip, `wave_shr:1`) is
+     * compiled and selectable (`team` knob = 643202) but never chosen here: config 4's 4 KB queries are then two or three passes instead
+     * of eight or nine and the call moves 12.6 GB instead of 55.5 (5.9 x its algorithmic bytes instead of 26 x) - and takes 595 ms
+     * instead of 517 (7.4 TCUPS against 8.5; a share of an eighth of the rows: 78.7 against 78.4 ms).  The parked rows are 107 GB/s
+     * of an 8 TB/s memory: traffic this path can afford, time it cannot (profiles/r06/team_wave_wide_cfg4.txt). */
     if (mean_query >= 192 && mean_candidate >= 256) return 16;
     if (items * 4 / 64 < 4096 && mean_query >= 128) return 16; /* four lanes per item would leave SIMDs short of wavefronts */
     return 4;
@@ -468,7 +473,7 @@ double szs_plan_estimate(unsigned bit_parallel_limit, int bit_parallel_chain, in
     lanes_cycles *= 1.0 + 0.5 * (1.0 - live_waves / 4.0);
     /* A team workgroup is one pair of queries x 256 / team candidates: with fewer candidates than that its other teams idle
      * (32768 x 8 scored 1.3 TCUPS in the caller's orientation, 7.0 on its side: profiles/r03/shapes.jsonl). */
-    if (team && candidates_count < 256u / team) lanes_cycles *= (256.0 / team) / candidates_count;
+    if (team && candidates_count < (team > 16 ? 512u : 256u) / team) lanes_cycles *= ((team > 16 ? 512.0 : 256.0) / team) / candidates_count;
     double const largest_pair = (double)longest_query * longest_candidate / lane_rate / split;
     if (largest_pair > lanes_cycles) lanes_cycles = largest_pair;
 

@@ -152,7 +152,7 @@ void cross(text_t const *queries, uint32_t queries_count, text_t const *candidat
     for (uint32_t i = 0; i < candidates_count; ++i) c_order[i] = i;
     std::stable_sort(q_order.begin(), q_order.end(), [&](uint32_t a, uint32_t b) { return queries[a].length > queries[b].length; });
     std::stable_sort(c_order.begin(), c_order.end(), [&](uint32_t a, uint32_t b) { return candidates[a].length < candidates[b].length; });
-    uint32_t const per_block = 256 / L;
+    uint32_t const per_block = (L > 16 ? 512 : 256) / L; // teams of more than sixteen lanes: workgroups of 512 threads
     for (uint32_t pair = 0; pair * 2 < queries_count; ++pair) {
         uint32_t const low = q_order[2 * pair];
         bool const has_high = 2 * pair + 1 < queries_count;
@@ -174,7 +174,7 @@ void cross(text_t const *queries, uint32_t queries_count, text_t const *candidat
 
 } // namespace
 
-#define TEAM_SHAPES(CALL) CALL(16, 32) CALL(16, 16) CALL(16, 24) CALL(8, 32) CALL(4, 32) CALL(4, 16) CALL(4, 8) CALL(2, 16) CALL(1, 32) CALL(1, 4)
+#define TEAM_SHAPES(CALL) CALL(16, 32) CALL(16, 16) CALL(16, 24) CALL(8, 32) CALL(4, 32) CALL(4, 16) CALL(4, 8) CALL(2, 16) CALL(1, 32) CALL(1, 4) CALL(64, 32) CALL(32, 16) CALL(64, 4)
 
 /** Tapes with count + 1 64-bit offsets; results[q * stride + c].  `wide`: cells ordered as unsigned integers (two-input maxima)
  *  instead of as half-float patterns.  `local` = 2: a DISTANCE engine - the caller passes negated costs (a 256-class identity map

@@ -231,3 +231,109 @@ def test_sorters_that_never_publish_cost_a_replan_not_a_hang(gpu, oracle):
         queries, candidates = shape()
         assert np.array_equal(fresh(queries, candidates, device=gpu), oracle.levenshtein(queries, candidates))
     assert fresh.last_call_profile().planner == 4
+
+
+# ---- 4. every plan mode x engine family x layout ------------------------------------------------------------------------------
+
+
+PLAN_MODES = {0: "host", 1: "device", 2: "device, speculated", 3: "re-used", 4: "inside the scoring launch", 5: "none (tiny tokens)"}
+
+
+def _family(name, gpu):
+    """(engine, oracle scorer, alphabet, (query lengths), (candidate lengths)) of one engine family."""
+    from oracle import binding
+
+    oracle = binding.oracle()
+    if name == "levenshtein":
+        return szs.LevenshteinDistances(capabilities=gpu), lambda q, c: oracle.levenshtein(q, c), b"ACGTN", (10, 90), (0, 120)
+    if name == "levenshtein_weighted":
+        costs = dict(match=0, mismatch=3, open=2, extend=2)
+        return szs.LevenshteinDistances(**costs, capabilities=gpu), lambda q, c: oracle.levenshtein(q, c, **costs), b"ACGTN", (10, 90), (0, 120)
+    if name == "levenshtein_utf8":
+        return (szs.LevenshteinDistancesUTF8(capabilities=gpu), lambda q, c: oracle.levenshtein_utf8(q, c),
+                ["a", "b", "é", "ж", "語", "😀"], (5, 40), (0, 60))
+    table = matrices.blosum62() if name == "needleman_wunsch" else matrices.nuc44()
+    alphabet = b"ARNDCQEGHILKMFPSTWYV" if name == "needleman_wunsch" else b"ACGT"
+    if name == "needleman_wunsch":
+        return (szs.NeedlemanWunschScores(*table, open=-4, extend=-4, capabilities=gpu),
+                lambda q, c: oracle.needleman_wunsch(q, c, *table, -4, -4), alphabet, (20, 120), (0, 150))
+    return (szs.SmithWatermanScores(*table, open=-4, extend=-1, capabilities=gpu),
+            lambda q, c: oracle.smith_waterman(q, c, *table, -4, -1), alphabet, (20, 120), (0, 150))
+
+
+def _batch(rng, alphabet, count, span):
+    if isinstance(alphabet, list):  # codepoints
+        return ["".join(rng.choice(alphabet) for _ in range(rng.randint(*span))).encode() for _ in range(count)]
+    return [bytes(rng.choice(alphabet) for _ in range(rng.randint(*span))) for _ in range(count)]
+
+
+@pytest.mark.parametrize("family", ["levenshtein", "levenshtein_weighted", "levenshtein_utf8", "needleman_wunsch", "smith_waterman"])
+@pytest.mark.parametrize("layout", ["cross_u32", "cross_u64_strided", "symmetric", "tall"])
+def test_every_plan_mode_of_every_family_and_layout_scores_what_the_oracle_scores(gpu, family, layout):
+    """host/dispatch.c reaches a call's plan five ways (planned on the host, on the device, on the device with the
+    launches speculated behind the planner, re-used for the same tapes, inside the scoring launch) - six with the tiny-token launch
+    that needs none - and each round added one.  This walks EVERY way a (family, layout) can take - streams of fresh batches, the same
+    tapes again, the planner pinned to the host, speculation off, tiny tokens forced - checks every matrix against the oracle, and pins
+    WHICH ways each combination may take: the launch that plans itself only for unit-cost byte calls that are not symmetric, the guarded
+    re-use only there too, tiny tokens only for unit costs over bytes."""
+    import torch
+
+    rng = random.Random(hash((family, layout)) % 100000)
+    engine, score, alphabet, q_span, c_span = _family(family, gpu)
+    rows, columns = (70, 300) if layout != "tall" else (300, 20)  # tall: more and longer queries than candidates - the planner swaps
+    if layout == "tall":
+        q_span, c_span = (q_span[1] // 2, q_span[1]), (1, max(2, c_span[1] // 6))
+    symmetric = layout == "symmetric"
+    wide = layout == "cross_u64_strided"
+    seen, alive = set(), []  # (every tape stays alive: a freed one's address handed to the next batch would look like "the same tapes")
+
+    def call(queries, candidates):
+        q_tape = szs.Strs(queries, wide_offsets=wide).to_device(0)
+        c_tape = None if symmetric else szs.Strs(candidates, wide_offsets=wide).to_device(0)
+        width = len(queries) if symmetric else len(candidates)
+        out = torch.full((len(queries), width + (13 if wide else 0)), -7, dtype=torch.int64, device="cuda:0")
+        engine(q_tape, c_tape, device=gpu, out=out[:, :width])
+        expected = score(queries, queries if symmetric else candidates)
+        got = out[:, :width].cpu().numpy()
+        assert np.array_equal(got.view(np.int64), expected.view(np.int64)), (family, layout, np.argwhere(got.view(np.int64) != expected.view(np.int64))[:4].tolist())
+        assert (out[:, width:] == -7).all()  # padding columns are never written (cuda.cuh:2201-2203)
+        mode = int(engine.last_call_profile().planner)
+        seen.add(mode)
+        alive.append((q_tape, c_tape, out))
+        return q_tape, c_tape, out, mode
+
+    fresh = lambda: (_batch(rng, alphabet, rows, q_span), _batch(rng, alphabet, columns, c_span))
+    # a stream of fresh batches: planned on the device, then speculated or planned inside the launch
+    stream = [call(*fresh())[3] for _ in range(3)]
+    # the same tapes again
+    queries, candidates = fresh()
+    q_tape, c_tape, out, _ = call(queries, candidates)
+    engine(q_tape, c_tape, device=gpu, out=out[:, :out.shape[1] - (13 if wide else 0)])
+    again = int(engine.last_call_profile().planner)
+    seen.add(again)
+    assert np.array_equal(out[:, :out.shape[1] - (13 if wide else 0)].cpu().numpy().view(np.int64), score(queries, queries if symmetric else candidates).view(np.int64))
+    with knob("planner", "host"):
+        assert call(*fresh())[3] == 0
+    with knob("speculate", 0):
+        assert call(*fresh())[3] == 1
+    with knob("fused", 0), knob("reuse", 0):
+        assert call(*fresh())[3] in (1, 2)
+    unit_bytes = family == "levenshtein" or (family == "levenshtein_utf8")  # (codepoint engines take the byte path only for ASCII corpora)
+    if family == "levenshtein" and not symmetric:
+        with knob("tiny", 1):  # tiny tokens, forced (the automatic rule wants 2^20 pairs): scored straight from the tapes
+            words = lambda count: _batch(rng, b"etaoinshr", count, (1, 9))
+            modes = [call(words(rows), words(columns))[3] for _ in range(2)]
+            assert 5 in modes, modes
+    # ---- which ways this combination may take
+    allowed = {0, 1, 2}
+    if family == "levenshtein":
+        allowed |= {3}
+        if not symmetric:
+            allowed |= {4, 5}
+    assert seen <= allowed, (family, layout, sorted(seen), sorted(allowed))
+    assert stream[0] == 1 and {0, 1} <= seen, (stream, seen)
+    if family == "levenshtein" and layout in ("cross_u32", "cross_u64_strided"):
+        assert stream[1:] == [4, 4] and again == 3, (stream, again)  # short unit-cost byte calls: the launch plans itself; same tapes: re-used
+    elif family in ("needleman_wunsch", "smith_waterman", "levenshtein_weighted") or symmetric:
+        assert 4 not in seen and 5 not in seen
+    del unit_bytes

@@ -59,7 +59,7 @@ def random_table(rng, classes=9):
     return byte_to_class, table
 
 
-SHAPES = [(16, 32), (16, 16), (16, 24), (8, 32), (4, 32), (4, 16), (4, 8), (2, 16), (1, 32), (1, 4)]
+SHAPES = [(16, 32), (16, 16), (16, 24), (8, 32), (4, 32), (4, 16), (4, 8), (2, 16), (1, 32), (1, 4), (64, 32), (64, 4), (32, 16)]  # the last three: teams across DPP rows (round 6)
 
 
 @pytest.mark.parametrize("lanes,registers", SHAPES)
@@ -81,7 +81,7 @@ def test_model_agrees_with_the_oracle(model, lanes, registers, local, affine, wi
             alphabet = b"ABCDEFGHIJKLMNOPQRSTUVWXYZab"
         # queries around one, two and a half passes, plus tiny, empty and badly matched partners
         longest = min(2 * rows + rows // 2, 700)
-        queries = random_strings(rng, 5, max(1, rows - 3), longest, alphabet) + [b"", alphabet[:1], alphabet[:3]]
+        queries = random_strings(rng, 5, min(max(1, rows - 3), longest // 2), longest, alphabet) + [b"", alphabet[:1], alphabet[:3]]
         queries += random_strings(rng, 2, 1, 12, alphabet)
         if trial == 3:
             queries = queries[:-1]  # an odd count: the last query has no partner
