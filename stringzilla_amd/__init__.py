@@ -282,6 +282,9 @@ class _Engine:
         else:  # a torch tensor, host or device
             if tuple(out.shape) != (rows, columns) or out.element_size() != 8 or (columns and out.stride(1) != 1):
                 raise ValueError("`out` must be a (rows, columns) matrix of 8-byte cells with contiguous rows")
+            if out.is_cuda:  # whatever torch still has in flight for this matrix (a fill, say) runs on TORCH's stream; the scoring
+                # launches run on the scope's own: drain the former, or a late fill overwrites cells the call has already scored
+                torch.cuda.current_stream(out.device).synchronize()
             results, pointer, stride = out, out.data_ptr(), out.stride(0) if rows > 1 else max(columns, 1)
 
         q_tape = queries._tape(gpu_device)

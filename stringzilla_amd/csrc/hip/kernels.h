@@ -324,8 +324,10 @@ int szs_hip_plan(szs_plan_side_t const *queries, szs_plan_side_t const *candidat
  *  A side whose offsets are malformed, or a query side with a string beyond 256 bytes, is written BLANK (every length 0:
  *  the launch scores empty strings, memory-safe) and says so in its report; the host then plans the call the ordinary way.
  */
-#define SZS_FUSED_MOST_STRINGS 1024u /* per side: four strings per thread of the sorting workgroup, all in registers (eight
-                                        cost the scoring bodies a wavefront of occupancy: 108 VGPRs against 95) */
+#define SZS_FUSED_MOST_STRINGS 1024u /* per side, sorted in ONE pass: four strings per thread of the sorting workgroup, all in registers
+                                        (eight cost the scoring bodies a wavefront of occupancy: 108 VGPRs against 95) */
+#define SZS_FUSED_MOST_STRINGS_TWO_PASSES 16384u /* per side, round 6: larger sides are counted in one walk over their offsets and
+                                        placed in a second (the offsets come from the L2 the second time; the refs go straight to memory) */
 #define SZS_FUSED_BINS 1024u         /* lengths of 1023 bytes and more share the last bin (they are texts: any order scores the same) */
 typedef struct szs_fused_side_report_t {
     uint32_t sequence; /* of the launch that wrote this report */
@@ -335,6 +337,8 @@ typedef struct szs_fused_side_report_t {
     szs_side_stats_t stats;
     uint32_t rank_lengths[SZS_PLAN_RANK_SAMPLES + 1];
     uint32_t ticks[5]; /* 100 MHz: the sorter's begin; offsets loaded; positions known; refs written; published - all relative to [0] but [0] itself */
+    uint32_t padding;
+    uint64_t squares;  /* sum of the squared lengths: a symmetric call's cells are ((sum of lengths)^2 + squares) / 2 */
 } szs_fused_side_report_t;
 typedef struct szs_fused_plan_t {
     szs_plan_side_t side[2]; /* KERNEL roles: [0] its queries (patterns; scored from .descending), [1] its candidates (.ascending) */
@@ -345,6 +349,8 @@ typedef struct szs_fused_plan_t {
                                 the host then plans the call the ordinary way (a launch never hangs on a sorter that does not publish) */
     uint32_t poll_budget;    /* polls of a `ready` word a waiting workgroup spends before it gives up (~1 us each) */
     uint32_t withhold;       /* testing aid (`fused` knob = 2): the sorters sort and report but never publish */
+    uint32_t symmetric;      /* one side only: side[0] is sorted by workgroup 0 and serves both roles; report[1] is not written */
+    uint32_t blocks_per_group; /* candidate blocks a workgroup walks (1: the plain grid; the launcher merges blocks of tiny strings) */
 } szs_fused_plan_t;
 #define SZS_FUSED_POLL_BUDGET (1u << 18) /* ~0.2 s: four orders of magnitude beyond the ~4 us a sorter takes */
 int szs_hip_levenshtein_myers_fused(szs_fused_plan_t const *plan, uint64_t *results, uint64_t results_row_stride, int layout,

@@ -311,40 +311,60 @@ __device__ __forceinline__ u64 fused_offset(void const *offsets, u32 wide, u64 i
     return wide ? static_cast<u64 const *>(offsets)[index] : (u64) static_cast<u32 const *>(offsets)[index];
 }
 
-__device__ __forceinline__ void fused_sort_side(szs_plan_side_t const &side, u32 is_query_side, u32 sequence, u32 *ready, u32 withhold,
-                                                szs_fused_side_report_t *report, u32 *histogram /* SZS_FUSED_BINS dwords of LDS */,
+__device__ __forceinline__ void fused_sort_side(szs_plan_side_t const &side, u32 is_query_side, u32 sequence, u32 *ready, u32 second_ready,
+                                                u32 withhold, szs_fused_side_report_t *report, u32 *histogram /* SZS_FUSED_BINS dwords of LDS */,
                                                 szs_string_ref_t *staged /* SZS_FUSED_MOST_STRINGS refs of LDS */) {
     constexpr u32 per_thread = SZS_FUSED_MOST_STRINGS / 256;
     u32 const tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, count = side.count;
+    bool const one_pass = count <= SZS_FUSED_MOST_STRINGS; // every string of the side in this workgroup's registers at once
     __shared__ u32 wave_bins[4], wave_longest[4], wave_status[4];
-    __shared__ unsigned long long wave_symbols[4], wave_bands_systolic[4], wave_bands_chain[4];
+    __shared__ unsigned long long wave_symbols[4], wave_bands_systolic[4], wave_bands_chain[4], wave_squares[4];
 
     u64 const began = wall_clock64();
     for (u32 bin = tid; bin < SZS_FUSED_BINS; bin += 256) histogram[bin] = 0;
-    u64 from[per_thread], to[per_thread]; // all loads of the side in flight at once: ONE round trip to memory for the whole sort
+    u64 from[per_thread], to[per_thread]; // one pass: all loads of the side in flight at once - ONE round trip to memory for the whole sort
 #pragma unroll
     for (u32 k = 0; k < per_thread; ++k) {
         u32 const i = tid + k * 256;
         from[k] = to[k] = 0;
-        if (i < count) from[k] = fused_offset(side.offsets, side.wide, i), to[k] = fused_offset(side.offsets, side.wide, (u64)i + 1);
+        if (one_pass && i < count) from[k] = fused_offset(side.offsets, side.wide, i), to[k] = fused_offset(side.offsets, side.wide, (u64)i + 1);
     }
     __syncthreads();
     u32 bins[per_thread];
     u32 status = 0, longest = 0;
-    u64 symbols = 0, bands_systolic = 0, bands_chain = 0;
+    u64 symbols = 0, bands_systolic = 0, bands_chain = 0, squares = 0;
+    // what one string adds to the side's figures; its bin, or ~0 when its offsets are malformed
+    auto count_in = [&](u64 first, u64 last) -> u32 {
+        if (last < first) return status |= SZS_PLAN_STATUS_DESCENDING, ~0u;
+        if (last - first > 0xFFFFFFFFull) return status |= SZS_PLAN_STATUS_OVERFLOW, ~0u;
+        u32 const length = (u32)(last - first);
+        symbols += length, squares += (u64)length * length, longest = length > longest ? length : longest;
+        bands_systolic += length ? (length + SZS_SYSTOLIC_BAND_ROWS - 1) / SZS_SYSTOLIC_BAND_ROWS : 1;
+        bands_chain += length ? (length + SZS_MYERS_CHAIN_BAND_ROWS - 1) / SZS_MYERS_CHAIN_BAND_ROWS : 1;
+        u32 const bin = length < SZS_FUSED_BINS - 1 ? length : SZS_FUSED_BINS - 1;
+        atomicAdd(&histogram[bin], 1u);
+        return bin;
+    };
+    if (one_pass) {
 #pragma unroll
-    for (u32 k = 0; k < per_thread; ++k) {
-        bins[k] = ~0u;
-        if (tid + k * 256 >= count) continue;
-        if (to[k] < from[k]) status |= SZS_PLAN_STATUS_DESCENDING;
-        else if (to[k] - from[k] > 0xFFFFFFFFull) status |= SZS_PLAN_STATUS_OVERFLOW;
-        else {
-            u32 const length = (u32)(to[k] - from[k]);
-            symbols += length, longest = length > longest ? length : longest;
-            bands_systolic += length ? (length + SZS_SYSTOLIC_BAND_ROWS - 1) / SZS_SYSTOLIC_BAND_ROWS : 1;
-            bands_chain += length ? (length + SZS_MYERS_CHAIN_BAND_ROWS - 1) / SZS_MYERS_CHAIN_BAND_ROWS : 1;
-            bins[k] = length < SZS_FUSED_BINS - 1 ? length : SZS_FUSED_BINS - 1;
-            atomicAdd(&histogram[bins[k]], 1u);
+        for (u32 k = 0; k < per_thread; ++k) {
+            bins[k] = ~0u;
+            if (tid + k * 256 < count) bins[k] = count_in(from[k], to[k]);
+        }
+    }
+    else { // a larger side (round 6): counted in one walk over its offsets, 256 strings at a time, placed in a second one below
+#pragma unroll 1
+        for (u32 first = 0; first < count; first += 1024) {
+            u64 some_from[4], some_to[4];
+#pragma unroll
+            for (u32 k = 0; k < 4; ++k) {
+                u32 const i = first + tid + k * 256;
+                some_from[k] = some_to[k] = 0;
+                if (i < count) some_from[k] = fused_offset(side.offsets, side.wide, i), some_to[k] = fused_offset(side.offsets, side.wide, (u64)i + 1);
+            }
+#pragma unroll
+            for (u32 k = 0; k < 4; ++k)
+                if (first + tid + k * 256 < count) (void)count_in(some_from[k], some_to[k]);
         }
     }
     if (tid == 0) report->ticks[0] = (u32)began, report->ticks[1] = (u32)(wall_clock64() - began);
@@ -380,41 +400,71 @@ __device__ __forceinline__ void fused_sort_side(szs_plan_side_t const &side, u32
     for (u32 k = 0; k < 4; ++k) histogram[4 * tid + k] = running, running += mine[k];
     __syncthreads();
     if (tid == 0) report->ticks[2] = (u32)(wall_clock64() - began);
-    // ---- every string's ref lands at its position in LDS (a malformed side sorts nothing: blank refs in the caller's order);
+    // ---- every string's ref lands at its position (a malformed side sorts nothing: blank refs in the caller's order);
     //      strings of one length take their places in whatever order the atomics decide
     u32 const blank = status || (is_query_side && longest > 32u * SZS_MYERS_SHORT_WORDS);
+    if (one_pass) { // ... in LDS first, and leaves it in order: position p and count - 1 - p, whole lines per wavefront
 #pragma unroll
-    for (u32 k = 0; k < per_thread; ++k) {
-        u32 const i = tid + k * 256;
-        if (i >= count) continue;
-        szs_string_ref_t ref;
-        ref.address = status ? side.base : side.base + from[k], ref.length = blank ? 0u : (u32)(to[k] - from[k]), ref.index = i;
-        staged[status ? i : atomicAdd(&histogram[bins[k]], 1u)] = ref;
+        for (u32 k = 0; k < per_thread; ++k) {
+            u32 const i = tid + k * 256;
+            if (i >= count) continue;
+            szs_string_ref_t ref;
+            ref.address = status ? side.base : side.base + from[k], ref.length = blank ? 0u : (u32)(to[k] - from[k]), ref.index = i;
+            staged[status ? i : atomicAdd(&histogram[bins[k]], 1u)] = ref;
+        }
+        __syncthreads();
+        for (u32 position = tid; position < count; position += 256) {
+            szs_string_ref_t const ref = staged[position];
+            side.ascending[position] = ref, side.descending[count - 1 - position] = ref;
+        }
     }
-    __syncthreads();
-    // ---- ... and leaves it in order: position p and count - 1 - p, whole lines per wavefront
-    for (u32 position = tid; position < count; position += 256) {
-        szs_string_ref_t const ref = staged[position];
-        side.ascending[position] = ref, side.descending[count - 1 - position] = ref;
+    else { // ... straight in memory: the second walk over the offsets (they come from the L2 now), sixteen bytes a ref, scattered
+#pragma unroll 1
+        for (u32 first = 0; first < count; first += 1024) {
+            u64 some_from[4], some_to[4];
+#pragma unroll
+            for (u32 k = 0; k < 4; ++k) {
+                u32 const i = first + tid + k * 256;
+                some_from[k] = some_to[k] = 0;
+                if (i < count) some_from[k] = fused_offset(side.offsets, side.wide, i), some_to[k] = fused_offset(side.offsets, side.wide, (u64)i + 1);
+            }
+#pragma unroll
+            for (u32 k = 0; k < 4; ++k) {
+                u32 const i = first + tid + k * 256;
+                if (i >= count) continue;
+                u32 const length = status ? 0u : (u32)(some_to[k] - some_from[k]);
+                szs_string_ref_t ref;
+                ref.address = status ? side.base : side.base + some_from[k], ref.length = blank ? 0u : length, ref.index = i;
+                u32 const position = status ? i : atomicAdd(&histogram[length < SZS_FUSED_BINS - 1 ? length : SZS_FUSED_BINS - 1], 1u);
+                side.ascending[position] = ref, side.descending[count - 1 - position] = ref;
+            }
+        }
     }
     // Every thread's stores have reached the L2 behind the barrier (it waits for them; the L1 writes through); ONE agent-scope
     // release by one thread then writes the L2 back before the word that says so changes.
     __syncthreads();
     if (tid == 0) {
         report->ticks[3] = (u32)(wall_clock64() - began);
-        if (!withhold) __hip_atomic_store(ready, sequence, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (!withhold) {
+            __hip_atomic_store(ready, sequence, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (second_ready) __hip_atomic_store(ready + 32, sequence, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // a symmetric call: both roles
+        }
         report->ticks[4] = (u32)(wall_clock64() - began);
     }
     // ---- the report (the host reads it when the launch has ended)
 #pragma unroll
     for (int offset = 32; offset >= 1; offset >>= 1) {
         symbols += ((u64)(u32)__shfl_xor((int)(u32)(symbols >> 32), offset, 64) << 32) | (u32)__shfl_xor((int)(u32)symbols, offset, 64);
-        bands_systolic += (u32)__shfl_xor((int)(u32)bands_systolic, offset, 64); // at most 1024 strings x 2^23 bands: 32 bits hold it
-        bands_chain += (u32)__shfl_xor((int)(u32)bands_chain, offset, 64);
+        squares += ((u64)(u32)__shfl_xor((int)(u32)(squares >> 32), offset, 64) << 32) | (u32)__shfl_xor((int)(u32)squares, offset, 64);
+        bands_systolic += ((u64)(u32)__shfl_xor((int)(u32)(bands_systolic >> 32), offset, 64) << 32) | (u32)__shfl_xor((int)(u32)bands_systolic, offset, 64);
+        bands_chain += ((u64)(u32)__shfl_xor((int)(u32)(bands_chain >> 32), offset, 64) << 32) | (u32)__shfl_xor((int)(u32)bands_chain, offset, 64);
     }
-    if (lane == 0) wave_symbols[wave] = symbols, wave_bands_systolic[wave] = bands_systolic, wave_bands_chain[wave] = bands_chain;
-    if (tid <= SZS_PLAN_RANK_SAMPLES) // the length at 33 ranks of the side (what the queue order is planned from)
-        report->rank_lengths[tid] = status || !count ? 0u : staged[(u32)((u64)tid * (count - 1) / SZS_PLAN_RANK_SAMPLES)].length;
+    if (lane == 0) wave_symbols[wave] = symbols, wave_bands_systolic[wave] = bands_systolic, wave_bands_chain[wave] = bands_chain, wave_squares[wave] = squares;
+    if (tid <= SZS_PLAN_RANK_SAMPLES) { // the length at 33 ranks of the side (what the queue order is planned from)
+        u32 const rank = (u32)((u64)tid * (count ? count - 1 : 0) / SZS_PLAN_RANK_SAMPLES);
+        // (the larger sides read their own stores back: the same CU wrote them, behind the barrier above)
+        report->rank_lengths[tid] = status || !count ? 0u : one_pass ? staged[rank].length : side.ascending[rank].length;
+    }
     __syncthreads();
     if (tid == 0) {
         report->status = status, report->blank = blank, report->reserved = 0;
@@ -422,6 +472,7 @@ __device__ __forceinline__ void fused_sort_side(szs_plan_side_t const &side, u32
         report->stats.symbols = wave_symbols[0] + wave_symbols[1] + wave_symbols[2] + wave_symbols[3];
         report->stats.bands_systolic = wave_bands_systolic[0] + wave_bands_systolic[1] + wave_bands_systolic[2] + wave_bands_systolic[3];
         report->stats.bands_chain = wave_bands_chain[0] + wave_bands_chain[1] + wave_bands_chain[2] + wave_bands_chain[3];
+        report->squares = wave_squares[0] + wave_squares[1] + wave_squares[2] + wave_squares[3];
         report->sequence = sequence;
     }
 }
@@ -431,9 +482,10 @@ __device__ __forceinline__ void fused_sort_side(szs_plan_side_t const &side, u32
 __device__ __forceinline__ bool fused_prologue(szs_fused_plan_t const &plan, u32 *scratch) {
     // 16 KB of LDS that only the two sorting workgroups touch: the scoring bodies keep five workgroups per CU either way (95 VGPRs)
     __shared__ __attribute__((aligned(16))) szs_string_ref_t staged[SZS_FUSED_MOST_STRINGS];
-    for (u32 s = 0; s < 2; ++s)
+    for (u32 s = 0; s < (plan.symmetric ? 1u : 2u); ++s) // a symmetric call: one side, sorted once, serves both roles
         if (blockIdx.x == s % gridDim.x) {
-            fused_sort_side(plan.side[s], s == 0, plan.sequence, plan.ready + 32 * s, plan.withhold, plan.report + s, scratch, staged);
+            fused_sort_side(plan.side[s], s == 0 || plan.symmetric, plan.sequence, plan.ready + 32 * s, plan.symmetric, plan.withhold, plan.report + s,
+                            scratch, staged);
             __syncthreads(); // the LDS is sorted in again (a grid of one workgroup), then becomes the match masks
         }
     // The wait is a RELAXED load at agent scope (it goes to the device's coherence point every time) and the barrier orders the
@@ -546,13 +598,16 @@ __global__ __launch_bounds__(256, SZS_MYERS_SHORT_WAVES) void levenshtein_myers_
 #ifndef SZS_MYERS_FUSED_WAVES
 #define SZS_MYERS_FUSED_WAVES 5 // the plain short kernel's five wavefronts per SIMD (95 VGPRs); unbounded, the prologue makes it 98
 #endif
+template <bool merged_>
 __global__ __launch_bounds__(256, SZS_MYERS_FUSED_WAVES) void levenshtein_myers_short_fused_kernel(szs_fused_plan_t plan, u32 candidate_blocks,
                                                                                                    u64 *results, u64 results_row_stride,
                                                                                                    int layout) {
     szs_ref_guard_t const none = {};
     // (plain pointers, not __restrict__ const ones: these arrays ARE written during the launch, by the sorting workgroups)
-    myers_short_body<false, false, true>(plan.side[0].descending, plan.side[1].ascending, plan.side[1].count, candidate_blocks, results,
-                                         results_row_stride, layout, none, 0u, 1u, &plan);
+    // a symmetric call (round 6): the one side in both roles - its descending refs the patterns, its ascending refs the texts
+    szs_plan_side_t const &texts = plan.symmetric ? plan.side[0] : plan.side[1];
+    myers_short_body<false, merged_, true>(plan.side[0].descending, texts.ascending, texts.count, candidate_blocks, results, results_row_stride,
+                                           layout, none, 0u, plan.blocks_per_group, &plan);
 }
 
 /** The same with `blocks_per_group` candidate blocks per workgroup (launch_myers_short decides). */
@@ -1610,16 +1665,32 @@ extern "C" int szs_hip_levenshtein_myers(unsigned words, szs_string_ref_t const 
 #undef SZS_MYERS_CASE
 }
 
-extern "C" int szs_hip_levenshtein_myers_fused(szs_fused_plan_t const *plan, uint64_t *results, uint64_t results_row_stride, int layout,
+extern "C" int szs_hip_levenshtein_myers_fused(szs_fused_plan_t const *plan_of_call, uint64_t *results, uint64_t results_row_stride, int layout,
                                                void *stream) {
     using namespace szs_hip;
-    uint32_t const queries_count = plan->side[0].count, candidates_count = plan->side[1].count;
-    if (!queries_count || !candidates_count || queries_count > SZS_FUSED_MOST_STRINGS || candidates_count > SZS_FUSED_MOST_STRINGS ||
-        !plan->sequence || (layout & SZS_LAYOUT_SYMMETRIC))
+    szs_fused_plan_t plan = *plan_of_call;
+    plan.symmetric = (layout & SZS_LAYOUT_SYMMETRIC) != 0;
+    uint32_t const queries_count = plan.side[0].count, candidates_count = plan.symmetric ? queries_count : plan.side[1].count;
+    if (!queries_count || !candidates_count || queries_count > SZS_FUSED_MOST_STRINGS_TWO_PASSES || candidates_count > SZS_FUSED_MOST_STRINGS_TWO_PASSES ||
+        !plan.sequence)
         return (int)hipErrorInvalidValue;
     u32 const candidate_blocks = (candidates_count + SZS_CANDIDATES_PER_WORKGROUP - 1) / SZS_CANDIDATES_PER_WORKGROUP;
-    hipLaunchKernelGGL(levenshtein_myers_short_fused_kernel, dim3(queries_count * candidate_blocks), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), *plan, candidate_blocks, results, results_row_stride, layout);
+    // candidate blocks per workgroup: the rule of launch_myers_short (tens of thousands of short-lived workgroups share a query's table)
+    u32 blocks_per_group = 1;
+    int const pinned = szs_tuning_get(szs_knob_merge_k);
+    if (pinned > 0) blocks_per_group = (u32)pinned < candidate_blocks ? (u32)pinned : candidate_blocks;
+    else
+        while (blocks_per_group < 8 && (u64)queries_count * ((candidate_blocks + 2 * blocks_per_group - 1) / (2 * blocks_per_group)) >= 16384)
+            blocks_per_group *= 2;
+    u32 const groups = (candidate_blocks + blocks_per_group - 1) / blocks_per_group;
+    if ((u64)queries_count * groups > (1ull << 30)) return (int)hipErrorInvalidValue;
+    plan.blocks_per_group = blocks_per_group;
+    if (blocks_per_group > 1)
+        hipLaunchKernelGGL(levenshtein_myers_short_fused_kernel<true>, dim3(queries_count * groups), dim3(256), 0, static_cast<hipStream_t>(stream), plan,
+                           groups, results, results_row_stride, layout);
+    else
+        hipLaunchKernelGGL(levenshtein_myers_short_fused_kernel<false>, dim3(queries_count * groups), dim3(256), 0, static_cast<hipStream_t>(stream), plan,
+                           groups, results, results_row_stride, layout);
     return (int)hipGetLastError();
 }
 

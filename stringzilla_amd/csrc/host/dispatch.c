@@ -1316,9 +1316,12 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
      * planner launch, no kernel boundary: config 2's fresh-batch call 202 -> ~190 us.  A batch that does not fit after all (a
      * query beyond 256 bytes, malformed offsets) is scored as empty strings and planned the ordinary way below. */
     if (remembered->valid && !remembered->runes && remembered->tier == SZS_TIER_LANES && remembered->use_myers && !remembered->wide_cells &&
-        !remembered->use_queue && is_one_launch(remembered) && remembered->plan.groups[0].variant == SZS_MYERS_SHORT_WORDS && !symmetric &&
-        remembered->q_count == q_count && remembered->c_count == c_count && remembered->symmetric == symmetric && q_count <= SZS_FUSED_MOST_STRINGS &&
-        c_count <= SZS_FUSED_MOST_STRINGS && knobs_automatic && !uniform_bytes && szs_tuning_get(szs_knob_fused_k) != 0 &&
+        !remembered->use_queue && is_one_launch(remembered) && remembered->plan.groups[0].variant == SZS_MYERS_SHORT_WORDS &&
+        /* (round 6: symmetric calls too - one side sorted once serves both roles - and sides of up to 16,384 strings, counted and placed
+         * in two walks over their offsets where up to 1024 are sorted in the sorter's registers) */
+        remembered->q_count == q_count && remembered->c_count == c_count && remembered->symmetric == symmetric &&
+        q_count <= SZS_FUSED_MOST_STRINGS_TWO_PASSES && c_count <= SZS_FUSED_MOST_STRINGS_TWO_PASSES && knobs_automatic && !uniform_bytes &&
+        szs_tuning_get(szs_knob_fused_k) != 0 &&
         (!engine->fused_gave_up || szs_tuning_get(szs_knob_fused_k) == 2)) {
         szs_decision_t const *d = remembered;
         szs_fused_side_report_t volatile *const reports = (szs_fused_side_report_t volatile *)((char *)engine->pinned_summary.pointer + 1024);
@@ -1354,11 +1357,13 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
         memcpy(sides, (void const *)reports, sizeof(sides));
         if (*gave_up == fused.sequence) engine->fused_gave_up = 1, engine->fused_zeroed = NULL; /* a workgroup ran out of polls: whatever the reports say, not every
                                                                         cell was scored - and the ready words are zeroed before the next try */
-        else if (sides[0].sequence == fused.sequence && sides[1].sequence == fused.sequence && !sides[0].status && !sides[1].status && !sides[0].blank &&
-            !sides[1].blank) { /* scored; the profile and the remembered plan take this batch's figures (caller roles again) */
-            szs_fused_side_report_t const *const of_queries = &sides[d->transposed ? 1 : 0], *const of_candidates = &sides[d->transposed ? 0 : 1];
+        else if (sides[0].sequence == fused.sequence && !sides[0].status && !sides[0].blank &&
+                 (symmetric || (sides[1].sequence == fused.sequence && !sides[1].status && !sides[1].blank))) {
+            /* scored; the profile and the remembered plan take this batch's figures (caller roles again; a symmetric call has one side) */
+            szs_fused_side_report_t const *const of_queries = &sides[!symmetric && d->transposed ? 1 : 0];
+            szs_fused_side_report_t const *const of_candidates = symmetric ? of_queries : &sides[d->transposed ? 0 : 1];
             if (call->trace)
-                for (int s = 0; s < 2; ++s)
+                for (int s = 0; s < (symmetric ? 1 : 2); ++s)
                     fprintf(stderr, "fused sorter %d (10 ns ticks since it began): offsets loaded %u, positions %u, refs written %u, published %u; began %d ticks after sorter 0\n",
                             s, sides[s].ticks[1], sides[s].ticks[2], sides[s].ticks[3], sides[s].ticks[4], (int)(sides[s].ticks[0] - sides[0].ticks[0]));
             szs_plan_summary_t seen_here = remembered->summary;
@@ -1367,9 +1372,13 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
             memcpy(seen_here.rank_lengths[0], of_queries->rank_lengths, sizeof(seen_here.rank_lengths[0]));
             memcpy(seen_here.rank_lengths[1], of_candidates->rank_lengths, sizeof(seen_here.rank_lengths[1]));
             szs_rocm_call_profile_t *profile = &engine->last_profile;
-            profile->cells = seen_here.side[0].symbols * seen_here.side[1].symbols;
-            profile->algorithmic_bytes = (uint64_t)c_count * seen_here.side[0].symbols + (uint64_t)q_count * seen_here.side[1].symbols + profile->pairs * 16;
-            profile->unique_bytes += seen_here.side[0].symbols + seen_here.side[1].symbols;
+            /* the lower triangle of a symmetric call: sum over i of len_i x (sum over j <= i of len_j) = ((sum len)^2 + sum len^2) / 2 */
+            seen_here.symmetric_cells = symmetric ? (seen_here.side[0].symbols * seen_here.side[0].symbols + of_queries->squares) / 2 : 0;
+            profile->cells = symmetric ? seen_here.symmetric_cells : seen_here.side[0].symbols * seen_here.side[1].symbols;
+            profile->algorithmic_bytes = (symmetric ? ((uint64_t)q_count + 1) * seen_here.side[0].symbols
+                                                    : (uint64_t)c_count * seen_here.side[0].symbols + (uint64_t)q_count * seen_here.side[1].symbols) +
+                                         profile->pairs * 16;
+            profile->unique_bytes += seen_here.side[0].symbols + (symmetric ? 0 : seen_here.side[1].symbols);
             profile->longest_query = seen_here.side[0].longest, profile->longest_candidate = seen_here.side[1].longest;
             remembered->longest[0] = seen_here.side[0].longest, remembered->longest[1] = seen_here.side[1].longest;
             stamp_refs(remembered, key_data, key_offsets, key_wide, &seen_here);

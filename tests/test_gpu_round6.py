@@ -138,11 +138,18 @@ def _soak(gpu, checker, launches, hammer):
     with knob("fused", 0):
         for queries, candidates in tapes:
             plain = torch.zeros((side, side), dtype=torch.int64, device="cuda:0")
+            torch.cuda.synchronize()  # the fill runs on torch's stream, the raw C-ABI call launches on the scope's: nothing else orders them
             _raw_step(engine, gpu, queries, candidates, plain)()
             assert engine.last_call_profile().planner != 4
             rows = range(side) if checker[1] else range(0, side, 16)
             truth = engine_of.levenshtein([queries[i] for i in rows], _strings(candidates))
-            assert np.array_equal(plain.cpu().numpy()[list(rows)].view(np.uint64), truth)
+            got = plain.cpu().numpy()[list(rows)].view(np.uint64)
+            wrong = np.argwhere(got != truth)
+            profile = engine.last_call_profile()
+            assert not len(wrong), (f"plain path, batch {len(expected)}: {len(wrong)} cells differ (planner {profile.planner}, launches {profile.launches}, "
+                                    f"tier {profile.tier}); first {wrong[:6].tolist()}: got {[int(got[tuple(w)]) for w in wrong[:6]]}, "
+                                    f"expected {[int(truth[tuple(w)]) for w in wrong[:6]]}; rows hit {len(set(wrong[:, 0].tolist()))}, "
+                                    f"columns hit {sorted(set(wrong[:, 1].tolist()))[:8]}")
             expected.append(plain)
     steps = [[_raw_step(engine, gpu, *tapes[b], outs[o]) for o in range(2)] for b in range(batches)]
 
@@ -175,10 +182,13 @@ def _soak(gpu, checker, launches, hammer):
             steps[b][o]()
             fused_calls += engine.last_call_profile().planner == 4
             mismatches += (outs[o] != expected[b]).sum()
+            torch.cuda.current_stream().synchronize()  # the comparison runs on torch's stream: it must have read the matrix before the next
+            # call's launch - on the scope's stream - writes into it
             if k % 1024 == 1023:
                 assert int(mismatches) == 0, f"{int(mismatches)} cells differ from the plain path by launch {k}"
             if k % 512 == 0:
                 outs[o].fill_(-1)  # no launch may pass on what an earlier one left in the matrix
+                torch.cuda.synchronize()  # (torch's stream against the scope's: see above)
     finally:
         stop.set()
         if worker is not None:
@@ -327,13 +337,79 @@ def test_every_plan_mode_of_every_family_and_layout_scores_what_the_oracle_score
     # ---- which ways this combination may take
     allowed = {0, 1, 2}
     if family == "levenshtein":
-        allowed |= {3}
+        allowed |= {3, 4}  # (round 6: symmetric calls plan themselves inside their launch too)
         if not symmetric:
-            allowed |= {4, 5}
+            allowed |= {5}
     assert seen <= allowed, (family, layout, sorted(seen), sorted(allowed))
     assert stream[0] == 1 and {0, 1} <= seen, (stream, seen)
     if family == "levenshtein" and layout in ("cross_u32", "cross_u64_strided"):
         assert stream[1:] == [4, 4] and again == 3, (stream, again)  # short unit-cost byte calls: the launch plans itself; same tapes: re-used
-    elif family in ("needleman_wunsch", "smith_waterman", "levenshtein_weighted") or symmetric:
+    elif family == "levenshtein" and symmetric:
+        assert stream[1:] == [4, 4] and again == 3 and 5 not in seen, (stream, again, seen)
+    elif family in ("needleman_wunsch", "smith_waterman", "levenshtein_weighted", "levenshtein_utf8"):
         assert 4 not in seen and 5 not in seen
     del unit_bytes
+
+
+# ---- 5. the wave-wide team shape over several passes ----------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("kind,gaps", [("smith_waterman", (-4, -1)), ("needleman_wunsch", (-4, -4)), ("needleman_wunsch", (-5, -1))])
+def test_the_wave_wide_team_shape_over_several_passes(gpu, oracle, kind, gaps):
+    """64 lanes x 32 rows (`team` knob 643202; hip/weighted_teams.hip: strips handed over by `wave_shr:1` across the rows of a
+    wavefront): reads of 2 ... 5 thousand symbols are two or three passes of 2048 query rows - one strip boundary parked per pass -
+    against candidates longer and shorter than the 63 fill steps, ragged inside a workgroup.  NUC.4.4, both objectives."""
+    shape = 643202
+    if shape not in _abi.team_shapes():
+        pytest.skip("the wave-wide shape is not compiled")
+    rng = random.Random(64 + len(kind))
+    dna = lambda length: bytes(rng.choice(b"ACGT") for _ in range(length))
+    limit = 2500 if kind == "needleman_wunsch" else 5200  # the 16-bit reach of a global objective: (rows + columns + 3) x 5 < 32000
+    queries = [dna(n) for n in (limit, 2049, 2048, 2047, limit - 700, 4097 if limit > 4097 else 300, 33, 1)]
+    candidates = [dna(rng.randint(40, 900)) for _ in range(13)] + [dna(n) for n in (0, 1, 62, 63, 64, 65, 1500)]
+    table = matrices.nuc44()
+    cls = szs.SmithWatermanScores if kind == "smith_waterman" else szs.NeedlemanWunschScores
+    engine = cls(*table, open=gaps[0], extend=gaps[1], capabilities=gpu)
+    expected = getattr(oracle, kind)(queries, candidates, *table, *gaps)
+    with knob("team", shape), knob("tier", "lanes"):
+        got = engine(queries, candidates, device=gpu)
+        profile = engine.last_call_profile()
+        assert profile.team == shape and profile.cell_bits == 16, (profile.team, profile.cell_bits)
+    wrong = np.argwhere(got != expected)
+    assert wrong.size == 0, (kind, gaps, wrong[:5].tolist(), got[tuple(wrong[0])], expected[tuple(wrong[0])])
+
+
+# ---- 6. the launch that plans itself, generalised ---------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("rows,columns,q_span,c_span,symmetric", [
+    (3163, 3163, (20, 200), (0, 300), False),   # config 5's counts, queries the short kernel takes: sides sorted in two walks over their offsets
+    (1500, 5000, (1, 256), (5, 60), False),     # counts that straddle the one-pass limit on one side only; the widest short query
+    (700, 0, (0, 256), None, True),             # symmetric: one side, sorted once, in both roles
+    (2500, 0, (30, 120), None, True),           # symmetric beyond the one-pass limit
+    (6000, 3000, (12, 40), (12, 40), False),    # tens of thousands of workgroups of short strings: the launcher merges candidate blocks
+])
+def test_larger_sides_and_symmetric_calls_plan_themselves_too(gpu, checker, rows, columns, q_span, c_span, symmetric):
+    """Round 5's launch that plans itself took sides of up to 1024 strings and no symmetric calls; the reference's
+    fast path has neither limit (cuda.cuh:4297-4340).  Here: every call after the first of its counts is ONE launch (`planner` 4) and
+    scores what the reference's engines score; the plan it leaves serves the same tapes again."""
+    engine_of, _ = checker
+    rng = random.Random(rows + columns)
+    words = lambda count, span: [bytes(rng.choice(b"ACGTN") for _ in range(rng.randint(*span))) for _ in range(count)]
+    engine = szs.LevenshteinDistances(capabilities=gpu)
+    modes = []
+    for batch in range(3):
+        queries = szs.Strs(words(rows, q_span)).to_device(0)
+        candidates = None if symmetric else szs.Strs(words(columns, c_span)).to_device(0)
+        got = engine(queries, candidates, device=gpu)
+        profile = engine.last_call_profile()
+        modes.append((int(profile.planner), int(profile.launches)))
+        expected = engine_of.levenshtein(_strings(queries), None if symmetric else _strings(candidates))
+        wrong = np.argwhere(got != expected)
+        assert not len(wrong), (batch, modes, len(wrong), wrong[:5].tolist())
+        lengths = queries.lengths().astype(np.int64)
+        cells = int((lengths.sum() ** 2 + (lengths ** 2).sum()) // 2) if symmetric else int(lengths.sum()) * int(candidates.lengths().sum())
+        assert profile.cells == cells, (profile.cells, cells)
+    assert modes[0][0] == 1 and modes[1:] == [(4, 1), (4, 1)], modes
+    got = engine(queries, candidates, device=gpu)  # the same tapes again: the refs the launch wrote, re-used behind the guard
+    assert engine.last_call_profile().planner == 3 and np.array_equal(got, expected)
