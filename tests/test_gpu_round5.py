@@ -233,7 +233,7 @@ def test_tiny_tokens_are_chosen_for_words_and_for_nothing_else(gpu, oracle):
         queries, candidates = [word() for _ in range(600)], [word() for _ in range(2100)]
         assert np.array_equal(engine(queries, candidates, device=gpu), oracle.levenshtein(queries, candidates))
         modes.append(int(engine.last_call_profile().planner))
-    assert modes[0] in (1, 2) and modes[1] == 5 and engine.last_call_profile().launches == 1, modes
+    assert modes[0] in (1, 2, 4) and modes[1] == 5 and engine.last_call_profile().launches == 1, modes  # (4: round 6, sides beyond 1024 strings plan themselves too)
     # config 2's shape never goes there
     load = workloads.config(2, scale=1 / 4)
     engine(load.queries, load.candidates, device=gpu)
