@@ -21,6 +21,8 @@ for step in "$@"; do
                     echo "--- systolic_probe $args"; timeout 300 tests/native/bin/systolic_probe_asan $args 2>&1 | grep -v "^    #" | tail -6; done
                   for args in "lev 300 700 40 200 6" "lev 1024 1024 96 160 4"; do # round 5: streams of fresh batches - the launch that plans itself
                     echo "--- systolic_probe $args (PROBE_ALTERNATE=1)"; PROBE_ALTERNATE=1 timeout 300 tests/native/bin/systolic_probe_asan $args 2>&1 | grep -v "^    #" | tail -7; done
+                  for args in "lev 3000 2500 10 120 4" "lev 1500 5000 1 60 3" "lev 6000 3000 12 40 3"; do # round 6: sides beyond 1024 strings plan themselves too (two walks over the offsets; merged candidate blocks)
+                    echo "--- systolic_probe $args (PROBE_ALTERNATE=1)"; PROBE_ALTERNATE=1 timeout 300 tests/native/bin/systolic_probe_asan $args 2>&1 | grep -v "^    #" | tail -7; done
                   for args in "lev 600 2100 1 12 4" "lev 300 700 0 20 4"; do # ... and tiny tokens straight from the tapes (the second with a fifth of its strings beyond 16 bytes: the longer tokens of the same launch)
                     echo "--- systolic_probe $args (PROBE_ALTERNATE=1 SZS_ROCM_TINY=1)"; PROBE_ALTERNATE=1 SZS_ROCM_TINY=1 timeout 300 tests/native/bin/systolic_probe_asan $args 2>&1 | grep -v "^    #" | tail -5; done
                   for args in "mix:60:40 100 700 3" "mix:100:255 300 1000 3 7" "mix:1000:200 40 300 2"; do # ... the one launch of tiny and longer tokens (refusals included: tiny = 1)

@@ -86,7 +86,10 @@ def main_loop(body, prefer_dpp=False):
     # The team tier's main loop exists once per chunk count of a pass since round 4 (weighted_teams.hip: `walk`), so the loop
     # with the most instructions may be the PROFILE BUILD of a rich alphabet instead: among loops that hand values from lane to
     # lane (`row_shr` DPP moves - only the step loops do) the largest one is the whole-pass main loop.
-    stepping = {name: mix for name, mix in loops.items() if any(opcode.endswith("_dpp") for opcode in mix)} if prefer_dpp else {}
+    # (round 6: the fill phase walks its predicated steps four at a time, a loop larger than the main loop - and full of length
+    # checks: the main loop is the largest one that hands values over by DPP and compares next to nothing)
+    stepping = {name: mix for name, mix in loops.items() if any(opcode.endswith("_dpp") for opcode in mix) and
+                sum(count for opcode, count in mix.items() if opcode.startswith("v_cmp")) <= 4} if prefer_dpp else {}
     pool = stepping or loops
     header = max(pool, key=lambda name: sum(pool[name].values()))
     return header, pool[header]

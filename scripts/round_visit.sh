@@ -18,3 +18,7 @@ timeout 600 python scripts/measure_queue.py --config 5 --shards 1,2,4,8 --words 
 timeout 600 python scripts/measure_queue.py --config 6 --shards 1,2,4,8 --words auto --seconds 0.4 2>/dev/null > "$OUT/queue_cfg5u.jsonl"; cut -c1-200 "$OUT/queue_cfg5u.jsonl"
 bash scripts/measure_words.sh "$TAG/words" > /dev/null 2>&1; grep -c '"failures": 0' "$OUT/words/words.txt"; grep "tiny kernel" "$OUT/words/words.txt" | tail -2
 bash scripts/run_real_text.sh > "$OUT/real_text.log" 2>&1; cp gpurun_out/real_text/real_text.jsonl "$OUT/real_text.jsonl"; cut -c1-220 "$OUT/real_text.jsonl"
+# round 6: the C host under ASan + UBSan driven by the torch-free probes (scripts/gpu_visit.sh asan), and the harness race of
+# scripts/repro_plain_path.py (a matrix filled on torch's stream, scored on the scope's) with and without the fill drained
+bash scripts/gpu_visit.sh "$TAG" asan > "$OUT/asan_visit.log" 2>&1; tail -3 "$OUT/asan_visit.log"
+for mode in sync nosync; do timeout 600 python scripts/repro_plain_path.py 40 $mode 2>&1 | tail -3 | cut -c1-300; done > "$OUT/harness_stream_race.txt"; tail -2 "$OUT/harness_stream_race.txt"
