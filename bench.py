@@ -826,7 +826,10 @@ def main():
         steps_of.append(other_step)
         for _ in range(max(2, args.warmup // 2)):
             step()
-        calls = max(60, args.steps)
+        # (at least 400 calls, ~76 ms: the same-tapes figure is an average over them, and the power management has then settled on this
+        # kernel's instruction mix before the headline's W + K steps begin - with 60 calls a run of K = 20 steps was timed on the
+        # ramp: 87.2 TCUPS where K = 200 reads 89.9, the kernel itself 94.4 against 96.3; profiles/r06/bench_20_steps.jsonl)
+        calls = max(400, args.steps)
         fence()
         same_started = time.perf_counter()
         for _ in range(calls):
