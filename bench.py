@@ -472,6 +472,24 @@ def measure_extra(config, scope, device_index, args, fence, with_cpu):
         # ~13 bytes of strings per pair-row).  Algorithmic bytes here = results + both tapes + their offsets, once each.
         bytes_moved = len(queries) * len(candidates) * 8 + int(load.queries.lengths().sum() + load.candidates.lengths().sum()) + 4 * (len(queries) + len(candidates) + 2)
         record["roofline"] = words_roofline(record["roofline"], bytes_moved, kernel, int(profile.launches), int(profile.planner), _profile_json("valu_peak.json")[0])
+    if config == 4:
+        # Config 4's whole matrix is ~150 s of the reference's engines on this host (64 whole rows are checked against them below, in
+        # `cpu_baseline.checked`).  ALL 262,144 cells are checked here against an independent implementation on the device: the
+        # one-pair-per-lane kernel (`team` knob 0: 32-bit cells, another recurrence layout, hip/weighted.hip), untimed.
+        from stringzilla_amd import _abi
+
+        other = torch.empty_like(results)
+        previous = _abi.tuning_set("team", 0)
+        try:
+            make_step(engine, scope, load, queries, candidates, other, device_index)()
+            other_tier = engine.last_call_profile()
+            record["cross_tier_check"] = {"against": "one pair per lane, 32-bit cells (team knob 0)", "cell_bits": int(other_tier.cell_bits),
+                                          "team": int(other_tier.team), "whole_matrix": True, "cells_equal": bool(torch.equal(other, results))}
+        finally:
+            _abi.tuning_set("team", previous)
+        assert record["cross_tier_check"]["cells_equal"], "config 4: the team tier and the one-pair-per-lane kernel disagree"
+        make_step(engine, scope, load, queries, candidates, results, device_index)()  # (the engine's remembered plan is the team tier's again)
+        del other
     if with_cpu:  # timed later, after every GPU measurement of the run (the host cores are busy for ~10 s per baseline); the
         # matrix stays in HBM until then - downloading 80 MB here would idle the shader engines right before the headline
         record["_cpu_baseline_inputs"] = (load, results)
