@@ -413,3 +413,61 @@ def test_larger_sides_and_symmetric_calls_plan_themselves_too(gpu, checker, rows
     assert modes[0][0] == 1 and modes[1:] == [(4, 1), (4, 1)], modes
     got = engine(queries, candidates, device=gpu)  # the same tapes again: the refs the launch wrote, re-used behind the guard
     assert engine.last_call_profile().planner == 3 and np.array_equal(got, expected)
+
+
+# ---- 7. RCCL on the one device this pool has -------------------------------------------------------------------------------------
+
+
+def _rccl_worker(rank, world, port, out_dir):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    import stringzilla_amd as szs_
+    from stringzilla_amd import sharded, workloads as workloads_
+
+    scope = szs_.DeviceScope(gpu_device=0)
+    engine = szs_.LevenshteinDistances(capabilities=scope)
+    node = sharded.ShardedEngine(engine=engine, scope=scope)
+    load = workloads_.config(5, scale=1 / 32)
+    rows, local = node(load.queries, load.candidates, source=0)
+    full = node(load.queries, load.candidates, source=0, gather=True)
+    mirrored = node(load.queries, None, source=0, gather=True)
+    total = torch.tensor([float(local.sum())], dtype=torch.float64, device="cuda:0")
+    dist.all_reduce(total)
+    as_numpy = lambda matrix: matrix.cpu().numpy() if hasattr(matrix, "cpu") else np.asarray(matrix)
+    np.savez(os.path.join(out_dir, f"rccl{rank}.npz"), rows=np.asarray(rows), local=as_numpy(local), full=as_numpy(full), mirrored=as_numpy(mirrored),
+             total=float(total.item()), backend=dist.get_backend(), where=str(local.device) if hasattr(local, "device") else "host")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_the_sharded_driver_over_rccl_with_a_world_of_one(tmp_path, oracle):
+    """No box of this pool has two GPUs, so the `nccl` backend (RCCL on ROCm) never ran before the driver's 8-GPU job.  What ONE
+    device can exercise of it does run here: the process group over RCCL, the tape broadcasts, the symmetry flag, the all-gather of the
+    result rows and an all-reduce, all on device buffers, around the real engine - the code path of `bench.py --gpus N --backend nccl`
+    and of `stringzilla_amd.sharded` with N = 1.  (Two and eight ranks: `gloo`, tests/test_sharded_gloo.py and test_bench_two_ranks.py;
+    two DEVICES: test_two_ranks_on_two_devices_over_rccl, which skips here.)"""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as probe:
+        probe.bind(("127.0.0.1", 0))
+        port = probe.getsockname()[1]
+    mp.spawn(_rccl_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    shard = np.load(os.path.join(str(tmp_path), "rccl0.npz"))
+    load = workloads.config(5, scale=1 / 32)
+    expected = oracle.levenshtein(_strings(load.queries), _strings(load.candidates))
+    assert str(shard["backend"]) == "nccl" and str(shard["where"]).startswith("cuda")  # the rows stayed in HBM
+    assert np.array_equal(np.sort(shard["rows"]), np.arange(len(load.queries)))
+    assert np.array_equal(shard["local"].view(np.uint64), expected[shard["rows"]])
+    assert np.array_equal(shard["full"].view(np.uint64), expected)
+    assert np.array_equal(shard["mirrored"].view(np.uint64), oracle.levenshtein(_strings(load.queries), None))
+    assert float(shard["total"]) == float(expected.sum())
