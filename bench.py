@@ -113,6 +113,9 @@ def parse_args():
     parser.add_argument("--same-device", action="store_true",
                         help="testing aid: every rank uses cuda:0 (with --backend gloo), to exercise the N > 1 code "
                              "path on a one-GPU box; the numbers of such a run mean nothing")
+    parser.add_argument("--force-distributed", action="store_true",
+                        help="testing aid: run the N > 1 code path (torch.distributed over --backend, strong-scaled records, the C node driver) "
+                             "also with --gpus 1: RCCL's first contact on a one-GPU box")
     parser.add_argument("--hbm-traffic-bytes", type=float, default=None,
                         help="HBM bytes per launch from a separate rocprofv3 --pmc pass; default: the committed summary "
                              "profiles/rNN/pmc_summary.json of this same command (scripts/profile_gpu.sh)")
@@ -750,14 +753,19 @@ def main():
     import stringzilla_amd as szs
     from stringzilla_amd import workloads
 
+    if args.force_distributed and args.gpus == 1 and "WORLD_SIZE" not in os.environ:  # a world of one rank, no launcher around it
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # `--force-distributed`: the N > 1 code path - process group, broadcast tapes, strong-scaled records through the sharded driver, the C
+    # node driver, the barriers and all-reduces of the headline - with a world of ONE rank: what a one-GPU box can run of `--backend nccl`
+    distributed = world > 1 or args.force_distributed
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
             print(json.dumps({"error": f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", "n_gpus": args.gpus}), flush=True)
         raise SystemExit(2)
-    if world > 1:
+    if distributed:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -773,7 +781,7 @@ def main():
         load.queries = fresh_tape(args.generator, args.config + 1000 * rank, len(load.queries), 96 if args.config == 2 else low,
                                   160 if args.config == 2 else high)
     queries = load.queries.to_device(local_rank)
-    if world > 1:  # the one exchange step of the path: replicate the candidates tape over RCCL / xGMI, before timing;
+    if distributed:  # the one exchange step of the path: replicate the candidates tape over RCCL / xGMI, before timing;
         # the received tape stays in HBM (only its offsets are mirrored on the host)
         size = torch.tensor([load.candidates.data.size], device=where)
         dist.broadcast(size, 0)
@@ -792,7 +800,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -806,13 +814,13 @@ def main():
     # of NW / SW scoring the clocks are where a busy GPU keeps them.  The headline itself is unchanged: W untimed steps, then
     # exactly K timed ones.  (The single-process C driver of N > 1 runs last, while the other ranks wait.)
     if args.extra_configs is None:
-        extras = [9, 3, 4, 5, 6, 7, 8, 10] if world == 1 else [2, 4, 5]  # N > 1: the metric's own batch and the two 8-GPU configs, STRONG-scaled
+        extras = [9, 3, 4, 5, 6, 7, 8, 10] if not distributed else [2, 4, 5]  # N > 1: the metric's own batch and the two 8-GPU configs, STRONG-scaled
     else:
         extras = [] if args.extra_configs.strip().lower() in ("", "none") else [int(x) for x in args.extra_configs.split(",")]
     records = []
     for config in extras:
         try:
-            if world == 1:
+            if not distributed:
                 records.append(measure_extra(config, scope, local_rank, args, fence, not args.no_cpu_baseline))
             else:  # configs 4 and 5 strong-scaled over the ranks; every rank takes part
                 record = measure_strong(config, scope, local_rank, args, fence, dist, world, rank, where)
@@ -823,7 +831,7 @@ def main():
         except Exception as problem:  # an extra record must never cost the headline line
             records.append({"config": config, "error": repr(problem)})
 
-    if world == 1 and args.extra_configs is None:
+    if not distributed and args.extra_configs is None:
         try:
             records.append(measure_fingerprints(scope, local_rank, args, fence))
         except Exception as problem:
@@ -875,7 +883,7 @@ def main():
         timed_cells += cells_of_step[index % len(steps_of)]
     fence()
     elapsed = time.perf_counter() - started
-    if world > 1:
+    if distributed:
         slowest = torch.tensor([elapsed], dtype=torch.float64, device=where)
         dist.all_reduce(slowest, op=dist.ReduceOp.MAX)
         elapsed = float(slowest)
@@ -900,17 +908,17 @@ def main():
 
     device_ids = torch.zeros(world, dtype=torch.float64, device=where)
     device_ids[rank] = float(torch.cuda.current_device() + 1)
-    if world > 1:
+    if distributed:
         dist.all_reduce(device_ids)
     devices_in_use = len({int(v) for v in device_ids.tolist()})
     cells_per_rank = torch.tensor([timed_cells], dtype=torch.float64, device=where)  # over the K timed steps
     checksum = results.sum().reshape(1).to(torch.float64)
-    if world > 1:
+    if distributed:
         dist.all_reduce(cells_per_rank)
         dist.all_reduce(checksum)
     total_cells = float(cells_per_rank)
 
-    if world > 1 and extras:
+    if distributed and extras:
         fence()
         if rank == 0:  # single-process C driver over the same GPUs, while the other ranks wait
             for config in extras:
@@ -955,7 +963,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             # what the collective layer itself says about the job: backend ("nccl" IS RCCL on ROCm), its rank count, distinct devices
-            "ranks": {"backend": dist.get_backend() if world > 1 else None, "world": dist.get_world_size() if world > 1 else 1,
+            "ranks": {"backend": dist.get_backend() if distributed else None, "world": dist.get_world_size() if distributed else 1,
                       "devices": devices_in_use},
             "dtype": {0: "u32 bit-vectors (u64 results)", 16: "i16 cells, two per VALU op (i64 results)", 32: "i32 cells (i64 results)",
                       64: "i64 cells"}.get(int(profile.cell_bits), "u32"),
@@ -995,7 +1003,7 @@ def main():
         line["run_seconds"] = {"total": round(clock["done"] - clock["started"], 1), "gpu_legs": round(clock["gpu_done"] - clock["started"], 1),
                                "cpu_baselines": round(clock["done"] - clock["gpu_done"], 1)}
         emit(line, records, args.details)
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -108,3 +108,38 @@ def test_two_ranks_on_two_devices_over_rccl(tmp_path):
         engine = szs.LevenshteinDistances(**load.costs, capabilities=gpu)
         checksum = int(engine(load.queries, load.candidates, device=gpu).view(np.int64).sum())
         assert records[config]["results_checksum"] == checksum and records[config]["backend"] == "nccl" and not records[config]["same_device"]
+
+
+def test_the_distributed_path_over_rccl_with_a_world_of_one(tmp_path):
+    """`bench.py --gpus 1 --force-distributed --backend nccl`: the N > 1 code path of the judged command - process group over RCCL, the
+    candidates' broadcast, configs 2 / 4 / 5 strong-scaled through `stringzilla_amd.sharded`, the C node driver, the all-reduces and
+    barriers of the headline - with a world of ONE rank: RCCL's first contact on the one-GPU boxes of this pool (the gloo tests above
+    cover two and eight ranks on one device; the two-DEVICE test skips here)."""
+    import stringzilla_amd as szs
+    from stringzilla_amd import matrices, workloads
+
+    scale = 1 / 8
+    command = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-distributed", "--backend", "nccl", "--steps", "5", "--warmup", "2",
+               "--extra-scale", str(scale), "--extra-seconds", "0.2", "--cpu-seconds", "1", "--extra-cpu-seconds", "0.5",
+               "--details", str(tmp_path / "bench_configs.json")]
+    environment = {key: value for key, value in os.environ.items() if key not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    environment["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    done = subprocess.run(command, cwd=ROOT, capture_output=True, text=True, timeout=900, env=environment)
+    assert done.returncode == 0, done.stdout[-3000:] + done.stderr[-3000:]
+    printed = [json.loads(text) for text in done.stdout.splitlines() if text.startswith("{")]
+    line = printed[-1]
+    assert line["ranks"] == {"backend": "nccl", "world": 1, "devices": 1} and line["n_gpus"] == 1 and line["value"] > 0 and line["audit"] == []
+    gpu = szs.DeviceScope(gpu_device=0)
+    records = [entry["configs_record"] for entry in printed if "configs_record" in entry]
+    strong = {record["config"]: record for record in records if record.get("scaling") == "strong" and "sharding" in record}
+    node = {record["config"]: record for record in records if record.get("entry_point", "").startswith("szs_rocm_node")}
+    for config in (2, 4, 5):
+        load = workloads.config(config, scale=scale, generator="mt19937_64" if config <= 4 else "numpy")
+        if load.kind == "levenshtein":
+            engine = szs.LevenshteinDistances(**load.costs, capabilities=gpu)
+        else:
+            engine = szs.SmithWatermanScores(*matrices.by_name(load.table), **load.costs, capabilities=gpu)
+        checksum = int(engine(load.queries, load.candidates, device=gpu).view(np.int64).sum())
+        assert "error" not in strong[config] and "error" not in node[config], (strong[config], node[config])
+        assert strong[config]["results_checksum"] == checksum and strong[config]["backend"] == "nccl" and strong[config]["ranks"] == 1
+        assert node[config]["results_checksum"] == checksum
