@@ -124,3 +124,39 @@ def test_reference_binding_scores_on_the_gpu(modules, oracle):
     sw = szs.SmithWatermanScores(*nuc, open=-4, extend=-1, capabilities=gpu)
     expected = oracle.smith_waterman([r.encode() for r in reads], [g.encode() for g in genome], *nuc, -4, -1)
     assert np.array_equal(sw(sz.Strs(reads), sz.Strs(genome), device=gpu), expected)
+
+
+WHEELS = os.path.join(ROOT, "oracle", "_ref", "wheel")
+
+
+@needs_binding
+@pytest.mark.gpu
+def test_the_installed_wheel_scores_on_the_gpu(tmp_path, oracle):
+    """The `stringzillas-rocm` WHEEL (bindings/python/setup.py; prebuilt by `__graft_entry__.build()` into oracle/_ref/wheel, which
+    travels): `pip install` into a scratch target, then a FRESH interpreter that knows nothing of this repository's build tree but
+    that target (and the base `stringzilla` module the wheel requires) imports `stringzillas` - the library comes out of the wheel
+    through the module's RUNPATH - and scores on the GPU."""
+    wheels = glob.glob(os.path.join(WHEELS, "stringzillas_rocm-*.whl"))
+    if not wheels:
+        pytest.skip("the wheel is not prebuilt (no /root/reference where build() ran)")
+    target = tmp_path / "site"
+    done = subprocess.run([sys.executable, "-m", "pip", "install", "--no-deps", "--no-index", "--target", str(target), wheels[0]], capture_output=True, text=True)
+    assert done.returncode == 0, done.stdout[-1500:] + done.stderr[-1500:]
+    script = """
+import os, sys
+import numpy as np
+import torch  # (one HIP runtime per process: torch's comes first, as in stringzilla_amd/_abi.py)
+import stringzilla as sz, stringzillas as szs
+assert os.path.dirname(szs.__file__) == sys.argv[1], szs.__file__
+loaded = [line.split()[-1] for line in open("/proc/self/maps") if "libstringzillas_rocm_shared" in line]
+assert loaded and all(path.startswith(sys.argv[1]) for path in loaded), loaded  # the wheel's own copy, not the build tree's
+gpu = szs.DeviceScope(gpu_device=0)
+engine = szs.LevenshteinDistances(capabilities=gpu)
+got = engine(sz.Strs(["kitten", "LISTEN", "ATCA", ""]), sz.Strs(["sitting", "SILENT", "CTACTCACCC", "ABC"]), device=gpu)
+print("DIAGONAL", [int(got[i, i]) for i in range(4)], szs.__version__)
+"""
+    environment = {key: value for key, value in os.environ.items() if key != "PYTHONPATH"}
+    environment["PYTHONPATH"] = os.pathsep.join([str(target), BINDING])  # BINDING: the base `stringzilla` module (Str / Strs)
+    run = subprocess.run([sys.executable, "-c", script, str(target)], capture_output=True, text=True, env=environment, cwd=str(tmp_path), timeout=600)
+    assert run.returncode == 0, run.stdout[-1500:] + run.stderr[-1500:]
+    assert "DIAGONAL [3, 4, 6, 3] 5.1.2" in run.stdout  # the reference's own known answers (test/similarities.cuh:613-624)
