@@ -568,7 +568,14 @@ __device__ __forceinline__ void tiny_body(szs_tape_t const &queries, szs_tape_t 
 #undef SZS_TINY_STAMP
 }
 
-/*  Measured and not kept (4096 x 4096 words of text, 81 us as it stands):
+/*  Measured and not kept, round 6 (profiles/r06/tiny_split_long_queries.txt): the long queries of every (block, span) in a workgroup
+ *  of their own - the grid doubled, even workgroups the groups, odd ones kinds B and C (they share nothing but their set-up, and the
+ *  long queries would no longer trail a workgroup's last group).  Words of text 96 -> 124 us, tokens of exactly 16 bytes - no long query
+ *  anywhere, the odd workgroups leave after their set-up - 67 -> 124 us: the launch lasts about as long as ONE workgroup lives (57 us on
+ *  average) because all 1024 are resident at once; 2048 workgroups are two rounds of residents, and a workgroup does not live shorter
+ *  for having fewer neighbours.  What binds this launch is the latency of a workgroup's own chain of phases, not the device's throughput.
+ *
+ *  Measured and not kept (4096 x 4096 words of text, 81 us as it stands):
  *  - the groups DRAWN from a ticket counter per block of candidates (a workgroup its own place first, then whatever comes; the next
  *    group's bytes and lengths requested straight from the tape one group ahead, the ticket two ahead): 82 us.  A workgroup lives
  *    54 us on average and the launch ends at 76 - but what the last workgroups are busy with is not groups somebody else could take:
