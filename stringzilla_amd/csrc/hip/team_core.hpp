@@ -286,27 +286,36 @@ SZS_HD team_edge_t team_advance(costs_t const &k, team_rows_t<costs_t::affine, R
 
 /* ---- passes ------------------------------------------------------------------------------------------------------------
  *  A team walks the longer query of its pair in passes of L x R rows, lane k on the rows [first + k R, first + (k + 1) R).
- *  The LAST pass rarely has L x R rows left: it deals what is left in chunks of four registers, the same number to every
- *  lane, so that a pair wastes fewer than 4 L padded rows instead of half a pass on average (config 3's 512-row proteins
- *  on sixteen lanes x sixteen registers: a quarter of all rows). */
+ *  The LAST pass rarely has L x R rows left: it deals what is left in chunks of four registers or (global scores under linear
+ *  gaps, round 6) in pairs of them, the same number to every lane, so that a pair wastes fewer than 4 L or 2 L padded rows instead of half
+ *  a pass on average (config 3's 512-row proteins on sixteen lanes x sixteen registers: a quarter of all rows). */
 
 /** Passes over the candidate that a pair of queries needs: the LONGER one decides. */
 template <int L, int R>
 SZS_HD u32 team_passes(u32 longer_query) { return (longer_query + (u32)L * R - 1) / ((u32)L * R); }
 
-/** Registers (rows per lane) of pass `pass`: R, or in the last pass the rows left over L lanes, rounded up to a chunk. */
-template <int L, int R>
+/** The registers that a short last pass is rounded up to: a pair for global scores under linear gaps, a chunk of four otherwise. */
+template <bool local_, bool affine_>
+SZS_HD constexpr int team_granule() { return local_ || affine_ ? 4 : 2; }
+
+/** Registers (rows per lane) of pass `pass`: R, or in the last pass the rows left over L lanes, rounded up to `G` of them. */
+template <int L, int R, int G>
 SZS_HD u32 team_pass_registers(u32 longer_query, u32 pass) {
+    static_assert(G == 2 || G == 4, "a profile row is read four registers at a time: whole chunks, or whole chunks and half a one");
     u32 const left = longer_query - pass * (u32)L * R;
-    return left >= (u32)L * R ? (u32)R : (left + 4 * (u32)L - 1) / (4 * (u32)L) * 4;
+    // (round 6: whole PAIRS of registers under linear gaps - a pair of queries wastes fewer than 2 L padded rows in its last pass;
+    // config 3's 385 ... 640-row proteins on sixteen lanes padded 32 rows on average, 7 % of a 450-row pass, now 16.  The affine
+    // and the local kernels keep whole chunks: one copy of the main loop per count of pairs took the affine four-lane shape from
+    // 4 spilled registers to 39 and the local linear ones from 17 to 32, and config 4 gained 0.7 % where config 3 gained 2.2 %)
+    return left >= (u32)L * R ? (u32)R : (left + (u32)G * L - 1) / ((u32)G * L) * (u32)G;
 }
 
 /** Where the last DP row of a query of `length` > 0 lives when its pair's longer query has `longer_query` rows. */
-template <int L, int R>
+template <int L, int R, int G>
 SZS_HD void team_last_row(u32 length, u32 longer_query, u32 &pass, u32 &lane, u32 &reg) {
     u32 const row = length - 1;
     pass = row / ((u32)L * R);
-    u32 const registers = team_pass_registers<L, R>(longer_query, pass), within = row - pass * (u32)L * R;
+    u32 const registers = team_pass_registers<L, R, G>(longer_query, pass), within = row - pass * (u32)L * R;
     lane = within / registers, reg = within % registers;
 }
 

@@ -123,6 +123,7 @@ __global__ __launch_bounds__(team_threads<L>(), W) void weighted_team_kernel(
     constexpr u32 team_block_threads_k = team_threads<L>();
     constexpr u32 teams = team_block_threads_k / L; // candidates per workgroup
     constexpr u32 group_rows = (u32)L * R;          // query rows per pass
+    constexpr int granule_ = team_granule<local_, affine_>(); // registers a short last pass is rounded up to
     static_assert(R % 4 == 0 && (L <= 16 ? 16 % L == 0 : 64 % L == 0), "whole 16-byte profile chunks; teams inside a DPP row, or rows inside a team");
 
     extern __shared__ __attribute__((aligned(16))) char profile[];
@@ -220,8 +221,9 @@ __global__ __launch_bounds__(team_threads<L>(), W) void weighted_team_kernel(
             u32 const above_stride = pass ? teams : 1u;
 
             // Rows per lane in this pass: R, or - last pass - what is left over L lanes in whole chunks of four (team_core.hpp).
-            u32 const registers_now = (u32)__builtin_amdgcn_readfirstlane((int)team_pass_registers<L, R>(longer, pass));
-            u32 const chunks_now = registers_now / 4;
+            u32 const registers_now = (u32)__builtin_amdgcn_readfirstlane((int)team_pass_registers<L, R, granule_>(longer, pass));
+            // whole chunks of four registers (one 16-byte read of the profile each) and, round 6, half a chunk behind them
+            u32 const chunks_now = registers_now / 4, half_now = registers_now & 2u, chunks_built = (registers_now + 3u) / 4u;
 
             // ---- the profile of the group's L strips: thread -> (strip, class, chunk of 4 registers)
             __syncthreads(); // everyone is done with the previous pass's profile; the prefilled rows are written
@@ -233,12 +235,14 @@ __global__ __launch_bounds__(team_threads<L>(), W) void weighted_team_kernel(
                     row < query.length ? (row_class_t)model->byte_to_class[reinterpret_cast<u8 const *>(query.address)[row]] : (row_class_t)padded_row_k;
             }
             __syncthreads();
-            for (u32 slot = threadIdx.x; slot < (u32)L * classes * chunks_now; slot += team_block_threads_k) {
-                u32 const chunk = slot % chunks_now, symbol_class = slot / chunks_now % classes, strip = slot / chunks_now / classes;
+            for (u32 slot = threadIdx.x; slot < (u32)L * classes * chunks_built; slot += team_block_threads_k) {
+                u32 const chunk = slot % chunks_built, symbol_class = slot / chunks_built % classes, strip = slot / chunks_built / classes;
                 u32 entries[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    u32 const low_class = group_classes[0][strip * R + 4 * chunk + r], high_class = group_classes[1][strip * R + 4 * chunk + r];
+                    bool const held = 4 * chunk + r < registers_now; // (the second half of a half chunk: rows nobody scores, never written above)
+                    u32 const low_class = held ? (u32)group_classes[0][strip * R + 4 * chunk + r] : padded_row_k;
+                    u32 const high_class = held ? (u32)group_classes[1][strip * R + 4 * chunk + r] : padded_row_k;
                     i32 low, high;
                     if constexpr (distance_) { // uniform costs: equal bytes have equal classes (serial.hpp:106-115)
                         low = low_class == padded_row_k ? 0 : low_class == symbol_class ? model->uniform_match : model->uniform_mismatch;
@@ -274,27 +278,37 @@ __global__ __launch_bounds__(team_threads<L>(), W) void weighted_team_kernel(
             // predicated step fetches its own.
             uint4 opening = make_uint4(0, 0, 0, 0);
             auto advance = [&](auto chunks, auto pipelined, team_edge_t const &in, u32 in_row, u32 row_after) {
-                // `chunks`: the chunks of four registers this pass holds, as a constant - or 0: ask `chunks_now`, chunk by chunk
-                constexpr int fixed_ = decltype(chunks)::value;
+                // `chunks`: HALF the registers this pass holds, as a constant (2 c: c chunks of four; 2 c + 1: and half a chunk behind them) -
+                // or 0: ask `chunks_now` / `half_now`, chunk by chunk
+                constexpr int code_ = decltype(chunks)::value;
+                constexpr int fixed_ = code_ / 2;
+                constexpr bool half_ = (code_ & 1) != 0;
                 constexpr bool pipelined_ = decltype(pipelined)::value;
-                constexpr int most_ = fixed_ ? fixed_ : R / 4;
+                constexpr int most_ = code_ ? fixed_ : R / 4;
                 uint4 const *const row = reinterpret_cast<uint4 const *>(profile + strip_base + in_row);
                 team_step_t<costs_t, R> step;
                 uint4 next = pipelined_ ? opening : row[0];
                 if constexpr (pipelined_) opening = *reinterpret_cast<uint4 const *>(profile + strip_base + row_after);
                 step.begin(in, diagonal, next.x);
 #pragma unroll
-                for (int chunk = 0; chunk < most_; ++chunk) {
+                for (int chunk = 0; chunk < most_ + (half_ ? 1 : 0); ++chunk) {
                     // one way OUT per chunk, not a way AROUND it: the rows of a skipped chunk then need no copies to meet
                     // the rows of a scored one again (a guard around every chunk cost ten v_mov per four rows)
-                    if (!fixed_ && (u32)chunk >= chunks_now) break;
+                    if (!code_ && (u32)chunk >= chunks_now) {
+                        if (half_now) // (uniform) the pass ends on half a chunk: its two rows, and out
+                            step.row(k, rows, 4 * chunk + 0, next.y, best), step.row(k, rows, 4 * chunk + 1, next.z, best);
+                        break;
+                    }
                     uint4 const now = next;
                     // one chunk past the last one of a short pass: inside the profile, unused.  (TWO chunks ahead measured the
                     // same within a percent - 14.27 / 525 ms against 14.10 / 529 on configs 3 / 4: it is not the LDS round trip.)
-                    if (chunk + 1 < most_) next = row[chunk + 1];
+                    if (chunk + 1 < most_ + (half_ ? 1 : 0)) next = row[chunk + 1];
                     // (a row is handed the cost of the row BELOW it: team_step_t::row)
                     step.row(k, rows, 4 * chunk + 0, now.y, best), step.row(k, rows, 4 * chunk + 1, now.z, best);
-                    step.row(k, rows, 4 * chunk + 2, now.w, best), step.row(k, rows, 4 * chunk + 3, next.x, best);
+                    // the half chunk behind the whole ones is a chunk like them with two rows (one body per chunk, one scheduling
+                    // fence behind each: as a tail outside the loop it cost every instance 40 registers)
+                    if (!(half_ && chunk == fixed_))
+                        step.row(k, rows, 4 * chunk + 2, now.w, best), step.row(k, rows, 4 * chunk + 3, next.x, best);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 out = step.end();
@@ -327,8 +341,11 @@ __global__ __launch_bounds__(team_threads<L>(), W) void weighted_team_kernel(
             };
 
             auto walk = [&](auto chunks) {
-                constexpr int fixed_ = decltype(chunks)::value;
-                std::integral_constant<int, fixed_ == R / 4 ? R / 4 : 0> const careful; // every register, or ask
+                constexpr int code_ = decltype(chunks)::value;
+                // (rounds 4 - 5: the predicated steps of a short pass asked `chunks_now` chunk by chunk.  They are instantiated per walk
+                // anyway, and with half chunks the asking version grew every instance's registers: the linear 16 x 32 body 123 -> 164,
+                // the affine 4 x 16 distance body to 39 spilled - so they take the walk's own constant)
+                std::integral_constant<int, code_> const careful;
                 constexpr u32 fill = (u32)((L - 1 + 3) / 4 * 4); // the first step at which every lane of a team has a column
                 u32 t = 0;
                 // ---- fill: the first lanes of every team start one after the other.  Batches of four steps: the head's four text bytes
@@ -398,12 +415,13 @@ __global__ __launch_bounds__(team_threads<L>(), W) void weighted_team_kernel(
                 for (; t < longest_in_wave + L - 1; ++t) careful_step(careful, t, std::false_type {}, 0u, parked_t {});
             };
             if (longest_in_wave) {
-#define SZS_TEAM_WALK(C)                                                                                               \
-    if constexpr (R / 4 >= C)                                                                                          \
-        if (chunks_now == C) walk(std::integral_constant<int, C> {});
+#define SZS_TEAM_WALK(CODE) /* CODE = registers of the pass / 2 */                                                    \
+    if constexpr (R / 2 >= CODE && (CODE % 2 == 0 || granule_ == 2))                                                   \
+        if (registers_now == 2u * CODE) walk(std::integral_constant<int, CODE> {});
                 SZS_TEAM_WALK(1) SZS_TEAM_WALK(2) SZS_TEAM_WALK(3) SZS_TEAM_WALK(4) SZS_TEAM_WALK(5) SZS_TEAM_WALK(6) SZS_TEAM_WALK(7) SZS_TEAM_WALK(8)
+                SZS_TEAM_WALK(9) SZS_TEAM_WALK(10) SZS_TEAM_WALK(11) SZS_TEAM_WALK(12) SZS_TEAM_WALK(13) SZS_TEAM_WALK(14) SZS_TEAM_WALK(15) SZS_TEAM_WALK(16)
 #undef SZS_TEAM_WALK
-                static_assert(R / 4 <= 8, "one copy of the main loop per chunk count");
+                static_assert(R / 2 <= 16, "one copy of the main loop per count of register pairs");
             }
 
             // ---- scores that are complete after this pass
@@ -413,7 +431,7 @@ __global__ __launch_bounds__(team_threads<L>(), W) void weighted_team_kernel(
                     szs_string_ref_t const &query = half ? query_high : query_low;
                     if (!query.length) continue;
                     u32 last_pass, last_lane, last_reg;
-                    team_last_row<L, R>(query.length, longer, last_pass, last_lane, last_reg);
+                    team_last_row<L, R, granule_>(query.length, longer, last_pass, last_lane, last_reg);
                     if (pass != last_pass || lane_in_team != last_lane || !(half ? live_high : live_low)) continue;
                     u32 cell = 0;
 #pragma unroll

@@ -58,7 +58,7 @@ void score_item(text_t q_low, text_t q_high, bool has_high, std::vector<text_t> 
 
     for (uint32_t pass = 0; pass < passes; ++pass) {
         uint32_t const first_row = pass * L * R;
-        uint32_t const registers = team_pass_registers<L, R>(longer, pass); // rows per lane in this pass
+        uint32_t const registers = team_pass_registers<L, R, team_granule<local_, affine_>()>(longer, pass); // rows per lane in this pass
         // ---- the profile of the L strips: [strip][class][register]
         std::vector<uint32_t> profile((size_t)L * 33 * R);
         for (uint32_t strip = 0; strip < (uint32_t)L; ++strip)
@@ -125,7 +125,7 @@ void score_item(text_t q_low, text_t q_high, bool has_high, std::vector<text_t> 
             int64_t *const out = half ? out_high : out_low;
             if (!query.length) continue;
             uint32_t last_pass, last_lane, last_reg;
-            team_last_row<L, R>(query.length, longer, last_pass, last_lane, last_reg);
+            team_last_row<L, R, team_granule<local_, affine_>()>(query.length, longer, last_pass, last_lane, last_reg);
             if (local_ ? pass + 1 != passes : pass != last_pass) continue;
             for (uint32_t team = 0; team < teams; ++team) {
                 if (local_) {
