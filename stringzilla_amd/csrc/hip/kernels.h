@@ -194,13 +194,31 @@ size_t szs_hip_levenshtein_myers_queue_table_bytes(int runes);
 typedef struct szs_tape_t {
     void const *offsets;
     uint64_t base; /* address of the tape's bytes */
-    uint32_t count, wide;
+    uint32_t count, wide; /* wide: 0 - 32-bit offsets, 1 - 64-bit offsets, 2 - the words szs_hip_utf8_narrow writes (below) */
 } szs_tape_t;
 int szs_hip_levenshtein_tiny(szs_tape_t const *queries, szs_tape_t const *candidates, uint64_t *results, uint64_t results_row_stride,
                                    uint32_t *unfit, uint32_t unfit_sequence, unsigned long long *symbols_out,
+                                   uint64_t *rune_totals /* NULL, or (tapes of kind 2) the two totals szs_hip_utf8_narrow counted: read, and zeroed for the next call */,
                                    uint64_t *trace /* NULL, or 10 qwords per workgroup of device memory (`trace` knob) */,
                                    uint64_t trace_workgroups /* workgroups `trace` has room for: a larger grid is not traced at all */,
                                    int dense /* testing: score blocks and spans full of long strings too (slowly) instead of refusing them */, void *stream);
+
+/**
+ *  The CODEPOINT twin of that launch (round 6; reference: unit_utf8_per_cuda_thread_, cuda.cuh:3294 - short runes scored without the
+ *  general codepoint machinery): one pass (hip/utf8.hip: utf8_narrow_kernel) decodes both UTF-8 tapes - `sz_rune_decode_unchecked`'s
+ *  contract, as the transcoder - and writes every string as BYTES, one per rune: an ASCII rune is its own id, any other rune gets
+ *  128 + its slot in a table of SZS_NARROW_SLOTS claimed runes.  Only equality of symbols matters to the distance, so the byte
+ *  kernel then scores the narrow strings as they are.  `entries[i]` (queries first, then candidates): string i's place in `narrow`
+ *  below bit 56, its count of runes above - a szs_tape_t of kind 2.  `workspace`: SZS_NARROW_SLOTS dwords (the table: zeroed by the
+ *  caller ONCE - it lives on from call to call, a stream of batches claims its runes in the first - and again after a batch that
+ *  overflowed it) + two qwords (the totals of runes per side: zero before the pass; the scoring launch reads them and zeroes them).  Leaves `*unfit = unfit_sequence` (and the strings unscored) when the tapes'
+ *  offsets descend, a string has more than 4 x 255 bytes or more than 255 runes, the batch more than SZS_NARROW_SLOTS distinct
+ *  runes beyond ASCII, or the tapes more bytes than `capacity`.
+ */
+#define SZS_NARROW_SLOTS 128u
+#define SZS_NARROW_WORKSPACE 1024u /* bytes a caller sets aside for `workspace` */
+int szs_hip_utf8_narrow(szs_tape_t const *queries, szs_tape_t const *candidates, void *narrow, uint64_t capacity, uint64_t *entries,
+                        void *workspace, uint32_t *unfit, uint32_t unfit_sequence, void *stream);
 
 /**
  *  Fills the cells above the diagonal of a `side` x `side` matrix of 8-byte values from the ones below it (hip/mirror.hip): what a

@@ -49,6 +49,38 @@ typedef unsigned short tiny_pk_u16 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u64 tiny_offset(void const *offsets, u32 wide, u64 index) {
     return wide ? static_cast<u64 const *>(offsets)[index] : (u64) static_cast<u32 const *>(offsets)[index];
 }
+/**
+ *  Where a string lies and how long it is.  A caller's tape says it with offsets i and i + 1; the CODEPOINT twin (round 6) is
+ *  launched on the byte strings of rune ids that `utf8_narrow_kernel` (hip/utf8.hip) made of a UTF-8 tape - there entry i is one
+ *  word, the length above bit 56 and the place in the narrow buffer below (`szs_tape_t::wide` = 2): strings that do not touch, no
+ *  entry past the last string.  `bytes` beyond tiny_longest_k: malformed, not scored.
+ */
+constexpr u64 tiny_packed_place_k = (1ull << 56) - 1;
+struct tiny_extent_t {
+    u64 from, bytes;
+};
+template <bool packed_>
+__device__ __forceinline__ tiny_extent_t tiny_extent(void const *offsets, u32 wide, u64 index) {
+    if constexpr (packed_) {
+        u64 const entry = static_cast<u64 const *>(offsets)[index];
+        return {entry & tiny_packed_place_k, entry >> 56};
+    }
+    else {
+        u64 const from = tiny_offset(offsets, wide, index), to = tiny_offset(offsets, wide, index + 1);
+        return {from, to >= from ? to - from : ~0ull};
+    }
+}
+/** The same of a query of the span, from the words the workgroup keeps in LDS (offsets i and i + 1, or the packed entry). */
+template <bool packed_>
+__device__ __forceinline__ u64 tiny_query_from(u64 const *query_offsets, u32 q) {
+    return packed_ ? query_offsets[q] & tiny_packed_place_k : query_offsets[q];
+}
+template <bool packed_>
+__device__ __forceinline__ u64 tiny_query_bytes(u64 const *query_offsets, u32 q) {
+    if constexpr (packed_) return query_offsets[q] >> 56;
+    else return query_offsets[q + 1] >= query_offsets[q] ? query_offsets[q + 1] - query_offsets[q] : ~0ull;
+}
+
 __device__ __forceinline__ u32 tiny_pk_add(u32 a, u32 b) { // v_pk_add_u16: the halves do not carry into each other
     tiny_pk_u16 const sum = __builtin_bit_cast(tiny_pk_u16, a) + __builtin_bit_cast(tiny_pk_u16, b);
     return __builtin_bit_cast(u32, sum);
@@ -139,7 +171,7 @@ __device__ __forceinline__ u32 tiny_held_four(tiny_held_text_t<registers_> const
 }
 
 /** Kinds B and C: the span's long queries `listed[0 ... listed_count)` as W-word patterns, R / W of them a round. */
-template <int words_, u32 registers_>
+template <int words_, u32 registers_, bool packed_>
 __device__ __forceinline__ void tiny_long_queries(u32 *peq, u32 *out, u64 const *query_offsets, unsigned short const *listed, u32 listed_count,
                                                   szs_tape_t const &queries, szs_tape_t const &candidates, u32 query_first,
                                                   u64 const *froms, u32 const *lengths, u32 const *lane_of_rank, u32 tiny_count,
@@ -181,15 +213,15 @@ __device__ __forceinline__ void tiny_long_queries(u32 *peq, u32 *out, u64 const 
             bytes_of[r] = 0x100u;
             if (r < here) {
                 u32 const q = listed[first + r];
-                u64 const from = query_offsets[q];
-                if (tid < (u32)(query_offsets[q + 1] - from)) bytes_of[r] = reinterpret_cast<u8 const *>(queries.base + from)[tid];
+                u64 const from = tiny_query_from<packed_>(query_offsets, q);
+                if (tid < (u32)tiny_query_bytes<packed_>(query_offsets, q)) bytes_of[r] = reinterpret_cast<u8 const *>(queries.base + from)[tid];
             }
         }
 #pragma unroll
         for (u32 r = 0; r < per_round; ++r)
             if (bytes_of[r] < 0x100u) {
                 u32 const q = listed[first + r];
-                u32 const bit = rows_k - (u32)(query_offsets[q + 1] - query_offsets[q]) + tid;
+                u32 const bit = rows_k - (u32)tiny_query_bytes<packed_>(query_offsets, q) + tid;
                 atomicOr(&peq[(r * 256u + bytes_of[r]) * words_ + (bit >> 5)], 1u << (bit & 31u));
             }
         __syncthreads();
@@ -197,7 +229,7 @@ __device__ __forceinline__ void tiny_long_queries(u32 *peq, u32 *out, u64 const 
 #pragma unroll 1
         for (u32 r = 0; r < here; ++r) {
             u32 const q = listed[first + r];
-            u32 const length = (u32)(query_offsets[q + 1] - query_offsets[q]);
+            u32 const length = (u32)tiny_query_bytes<packed_>(query_offsets, q);
             u32 vp[words_], vn[words_];
             start(rows_k - length, vp, vn);
 #pragma unroll
@@ -225,7 +257,7 @@ __device__ __forceinline__ void tiny_long_queries(u32 *peq, u32 *out, u64 const 
             bool const live = r < here && held.length;
             u32 const table = r < here ? r : 0u;
             u32 const q = listed[first + table];
-            u32 const length = (u32)(query_offsets[q + 1] - query_offsets[q]);
+            u32 const length = (u32)tiny_query_bytes<packed_>(query_offsets, q);
             u32 vp[words_], vn[words_];
             start(rows_k - length, vp, vn);
             if constexpr (words_ <= 2) { // the next step's masks in flight under this step's columns
@@ -278,10 +310,10 @@ __device__ __forceinline__ void tiny_long_queries(u32 *peq, u32 *out, u64 const 
     }
 }
 
-template <u32 registers_>
+template <u32 registers_, bool packed_>
 __device__ __forceinline__ void tiny_body(szs_tape_t const &queries, szs_tape_t const &candidates, u32 queries_per_workgroup,
                                                 u64 *__restrict__ results, u64 results_row_stride, u32 *unfit, u32 unfit_sequence,
-                                                unsigned long long *symbols_out, u64 *trace, u32 dense) {
+                                                unsigned long long *symbols_out, u64 *rune_totals, u64 *trace, u32 dense) {
     constexpr u32 R = registers_, H = R / 2, group_k = 2 * R; // registers of VP (of VN) a lane, rows of `out`, queries a group
     constexpr u32 texts_per_wave = 64u / R;                   // clusters of R lanes: kinds A and C
     constexpr u32 slots_per_thread = group_k / 16u;           // thread t builds byte t % 16 of slots t / 16 (+ 16)
@@ -307,7 +339,8 @@ __device__ __forceinline__ void tiny_body(szs_tape_t const &queries, szs_tape_t 
     u32 const queries_here = queries.count - query_first < queries_per_workgroup ? queries.count - query_first : queries_per_workgroup;
     if (blockIdx.x == 0 && tid < 2 && symbols_out) { // the call's cell count is the product of these two (the host's profile)
         szs_tape_t const &whole = tid ? candidates : queries;
-        symbols_out[tid] = tiny_offset(whole.offsets, whole.wide, whole.count) - tiny_offset(whole.offsets, whole.wide, 0);
+        if constexpr (packed_) symbols_out[tid] = rune_totals[tid], rune_totals[tid] = 0; // (counted by the pass that made the strings; zero for the next call's)
+        else symbols_out[tid] = tiny_offset(whole.offsets, whole.wide, whole.count) - tiny_offset(whole.offsets, whole.wide, 0);
     }
     // ---- the FIRST group's query bytes: requested before anything else, straight from the tape's offsets (two dependent round
     //      trips that would otherwise stand between the local sort and the first masks run beside the candidates' own two)
@@ -318,8 +351,8 @@ __device__ __forceinline__ void tiny_body(szs_tape_t const &queries, szs_tape_t 
         u32 const slot = (tid >> 4) + 16 * k;
         ahead[k] = 0x100u;
         if (slot < queries_here) {
-            u64 const from = tiny_offset(queries.offsets, queries.wide, (u64)query_first + slot), to = tiny_offset(queries.offsets, queries.wide, (u64)query_first + slot + 1);
-            if (to >= from && to - from <= tiny_rows_k && position < to - from) ahead[k] = reinterpret_cast<u8 const *>(queries.base + from)[position];
+            tiny_extent_t const query = tiny_extent<packed_>(queries.offsets, queries.wide, (u64)query_first + slot);
+            if (query.bytes <= tiny_rows_k && position < query.bytes) ahead[k] = reinterpret_cast<u8 const *>(queries.base + query.from)[position];
         }
     }
     // ---- once per workgroup: the block's candidates (offsets, local sort by length: tiny ones, then the long ones, then the absent)
@@ -328,12 +361,13 @@ __device__ __forceinline__ void tiny_body(szs_tape_t const &queries, szs_tape_t 
     u32 my_length = 0;
     bool my_exists = false; // this thread's candidate exists and this kernel scores it (up to 255 bytes)
     if (my_candidate < candidates.count) {
-        my_from = tiny_offset(candidates.offsets, candidates.wide, my_candidate);
-        u64 const to = tiny_offset(candidates.offsets, candidates.wide, (u64)my_candidate + 1);
-        if (to >= my_from && to - my_from <= tiny_longest_k) my_length = (u32)(to - my_from), my_exists = true;
+        tiny_extent_t const mine = tiny_extent<packed_>(candidates.offsets, candidates.wide, my_candidate);
+        my_from = mine.from;
+        if (mine.bytes <= tiny_longest_k) my_length = (u32)mine.bytes, my_exists = true;
         else *unfit = unfit_sequence; // malformed, or too long for this kernel: the host scores the call the ordinary way
     }
-    for (u32 i = tid; i <= queries_here; i += 256) query_offsets[i] = tiny_offset(queries.offsets, queries.wide, (u64)query_first + i);
+    for (u32 i = tid; i < queries_here + (packed_ ? 0u : 1u); i += 256)
+        query_offsets[i] = packed_ ? static_cast<u64 const *>(queries.offsets)[(u64)query_first + i] : tiny_offset(queries.offsets, queries.wide, (u64)query_first + i);
     for (u32 i = tid; i < 256 * R; i += 256) peq[i] = 0;
     if (tid < 32) bins[tid] = 0;
     if (tid == 0) listed_count = 0, listed_longest = 0;
@@ -342,9 +376,9 @@ __device__ __forceinline__ void tiny_body(szs_tape_t const &queries, szs_tape_t 
     u32 const bin = !my_exists ? tiny_rows_k + 2 : my_length <= tiny_rows_k ? my_length : tiny_rows_k + 1;
     u32 const place_in_bin = atomicAdd(&bins[bin], 1u);
     for (u32 i = tid; i < queries_here; i += 256) { // the span's long queries, in whatever order the atomics hand out
-        u64 const from = query_offsets[i], to = query_offsets[i + 1];
-        if (to < from || to - from > tiny_longest_k) *unfit = unfit_sequence;
-        else if (to - from > tiny_rows_k) listed[atomicAdd(&listed_count, 1u)] = (unsigned short)i, atomicMax(&listed_longest, (u32)(to - from));
+        u64 const bytes = tiny_query_bytes<packed_>(query_offsets, i);
+        if (bytes > tiny_longest_k) *unfit = unfit_sequence;
+        else if (bytes > tiny_rows_k) listed[atomicAdd(&listed_count, 1u)] = (unsigned short)i, atomicMax(&listed_longest, (u32)bytes);
     }
     __syncthreads();
     if (tid < 32) { // exclusive scan of the bins by half a wavefront
@@ -395,13 +429,13 @@ __device__ __forceinline__ void tiny_body(szs_tape_t const &queries, szs_tape_t 
 
     auto length_of = [&](u32 query) -> u32 { // of a query of the span; 0 past the span's end, ~0 for one the groups skip
         if (query >= queries_here) return 0;
-        u64 const from = query_offsets[query], to = query_offsets[query + 1];
-        return to >= from && to - from <= tiny_rows_k ? (u32)(to - from) : ~0u;
+        u64 const bytes = tiny_query_bytes<packed_>(query_offsets, query);
+        return bytes <= tiny_rows_k ? (u32)bytes : ~0u;
     };
     auto fetch = [&](u32 query) -> u32 { // this thread's byte of that query, 0x100 where it has none
         u32 const length = length_of(query);
         if (length == ~0u || position >= length) return 0x100u;
-        return reinterpret_cast<u8 const *>(queries.base + query_offsets[query])[position];
+        return reinterpret_cast<u8 const *>(queries.base + tiny_query_from<packed_>(query_offsets, query))[position];
     };
     auto start_of = [&](u32 low, u32 high) -> u32 { // VP of a register whose halves hold patterns of `low` and `high` rows (~0: none)
         u32 const low_rows = low == ~0u ? 0u : low, high_rows = high == ~0u ? 0u : high;
@@ -555,7 +589,7 @@ __device__ __forceinline__ void tiny_body(szs_tape_t const &queries, szs_tape_t 
     if (long_queries) {
         u32 const longest_query = listed_longest;
 #define SZS_TINY_LONG(W)                                                                                                                   \
-    tiny_long_queries<W, R>(peq, out, query_offsets, listed, long_queries, queries, candidates, query_first, froms, lengths, lane_of_rank, \
+    tiny_long_queries<W, R, packed_>(peq, out, query_offsets, listed, long_queries, queries, candidates, query_first, froms, lengths, lane_of_rank, \
                             tiny_count, long_count, held_first, column, column_is_tiny, text_length, longest_in_wave, symbols, my_exists,  \
                             my_candidate, results, results_row_stride)
         if (longest_query <= 32) SZS_TINY_LONG(1);
@@ -589,18 +623,21 @@ __device__ __forceinline__ void tiny_body(szs_tape_t const &queries, szs_tape_t 
 /** R = 16: thirty-two queries a group, four wavefronts a SIMD (128 registers), 39 KB of LDS - four workgroups a CU.  (R = 8 - groups
  *  of sixteen, 64 or 80 registers for eight or six wavefronts a SIMD - measured 66 ... 75 us on tiny tokens alone where this takes
  *  56: twice the mask builds, barriers and staging per pair, and what the launch waits for is not hidden by more wavefronts.) */
+template <bool packed_>
 __global__ __launch_bounds__(256, 4) void levenshtein_tiny_kernel(szs_tape_t queries, szs_tape_t candidates, u32 queries_per_workgroup,
                                                                        u64 *__restrict__ results, u64 results_row_stride, u32 *unfit,
-                                                                       u32 unfit_sequence, unsigned long long *symbols_out, u64 *trace, u32 dense) {
-    tiny_body<16>(queries, candidates, queries_per_workgroup, results, results_row_stride, unfit, unfit_sequence, symbols_out, trace, dense);
+                                                                       u32 unfit_sequence, unsigned long long *symbols_out, u64 *rune_totals,
+                                                                       u64 *trace, u32 dense) {
+    tiny_body<16, packed_>(queries, candidates, queries_per_workgroup, results, results_row_stride, unfit, unfit_sequence, symbols_out, rune_totals,
+                           trace, dense);
 }
 
 } // namespace szs_hip
 
 extern "C" int szs_hip_levenshtein_tiny(szs_tape_t const *queries_tape, szs_tape_t const *candidates_tape, uint64_t *results,
                                               uint64_t results_row_stride, uint32_t *unfit, uint32_t unfit_sequence,
-                                              unsigned long long *symbols_out, uint64_t *trace, uint64_t trace_workgroups, int dense,
-                                              void *stream) {
+                                              unsigned long long *symbols_out, uint64_t *rune_totals, uint64_t *trace,
+                                              uint64_t trace_workgroups, int dense, void *stream) {
     using namespace szs_hip;
     szs_tape_t const queries = *queries_tape, candidates = *candidates_tape;
     u32 const queries_count = queries.count, candidates_count = candidates.count;
@@ -619,7 +656,13 @@ extern "C" int szs_hip_levenshtein_tiny(szs_tape_t const *queries_tape, szs_tape
     spans = ((u64)queries_count + per_span - 1) / per_span;
     if (blocks * spans > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
     if (blocks * spans > trace_workgroups) trace = nullptr; // the stamps are indexed by workgroup: a grid beyond the buffer is not traced
-    hipLaunchKernelGGL(levenshtein_tiny_kernel, dim3((u32)(blocks * spans)), dim3(256), 0, static_cast<hipStream_t>(stream), queries, candidates,
-                       (u32)per_span, results, results_row_stride, unfit, unfit_sequence, symbols_out, trace, dense ? 1u : 0u);
+    bool const packed = queries.wide == 2; // the codepoint twin: both sides are strings of rune ids made by utf8_narrow_kernel
+    if (packed != (candidates.wide == 2) || (packed && !rune_totals)) return (int)hipErrorInvalidValue;
+    if (packed)
+        hipLaunchKernelGGL(levenshtein_tiny_kernel<true>, dim3((u32)(blocks * spans)), dim3(256), 0, static_cast<hipStream_t>(stream), queries, candidates,
+                           (u32)per_span, results, results_row_stride, unfit, unfit_sequence, symbols_out, rune_totals, trace, dense ? 1u : 0u);
+    else
+        hipLaunchKernelGGL(levenshtein_tiny_kernel<false>, dim3((u32)(blocks * spans)), dim3(256), 0, static_cast<hipStream_t>(stream), queries, candidates,
+                           (u32)per_span, results, results_row_stride, unfit, unfit_sequence, symbols_out, rune_totals, trace, dense ? 1u : 0u);
     return (int)hipGetLastError();
 }

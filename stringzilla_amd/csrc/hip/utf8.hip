@@ -308,6 +308,199 @@ __global__ __launch_bounds__(256) void alphabet_rename_kernel(u32 count, u64 con
     }
 }
 
+
+/* ---- tiny tokens of a codepoint call as strings of BYTES (round 6) ----------------------------------------------------------------
+ *
+ *  Words of text are ~6 runes: the general front end above (transcode, claim, rename, plan: five dependent launches and a wait,
+ *  ~120 us) costs more than scoring 4096 x 4096 of them (85 us in hip/myers_tiny.hip).  That kernel keys its masks by BYTE; only
+ *  equality of symbols matters; and a batch of words holds a hundred distinct runes, not a million.  So: one pass, one thread per
+ *  string (a word is a handful of sequential steps - the chain of lead bytes is walked as it stands), every rune becomes a byte:
+ *  ASCII itself, anything else 128 + the slot it claims in a table of 128 runes in device memory (open addressing, compare-and-
+ *  swap; the table outlives the call and every workgroup works from a copy in LDS, so a stream of batches claims its runes once).  The strings land where their bytes lay - string i at `side base + offset[i] - offset[0]`, runes <= bytes - so no
+ *  scan is needed; what says where and how long is one word per string (kernels.h: szs_hip_utf8_narrow).
+ */
+constexpr u32 narrow_slots_k = SZS_NARROW_SLOTS, narrow_most_runes_k = SZS_TINY_LONGEST, narrow_most_bytes_k = 4u * SZS_TINY_LONGEST;
+
+__global__ __launch_bounds__(64) void utf8_narrow_kernel(szs_tape_t queries, szs_tape_t candidates, u8 *__restrict__ narrow, u64 capacity,
+                                                          u64 *__restrict__ entries, u32 *__restrict__ table, u64 *__restrict__ totals,
+                                                          u32 *unfit, u32 unfit_sequence) {
+    // The table of claimed runes LIVES ON from call to call (the host zeroes it once, and again after a batch that overflowed it): a
+    // stream of batches in one language claims its hundred runes in the first call and none after.  Every workgroup starts from a copy
+    // of it in LDS; only a rune that copy does not hold goes to device memory (one compare-and-swap a probe).
+    __shared__ u32 keys[narrow_slots_k];
+    u32 const lane = threadIdx.x & 63u;
+    u64 const strings = (u64)queries.count + candidates.count, i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    auto at = [](szs_tape_t const &tape, u64 index) { return transcode_tape_t::at(tape.offsets, tape.wide, index); };
+    // where the sides lie in the narrow buffer: the candidates behind the queries' span (every thread works it out: two cached loads)
+    u64 const q_first = at(queries, 0), q_last = at(queries, queries.count), c_first = at(candidates, 0), c_last = at(candidates, candidates.count);
+    for (u32 slot = threadIdx.x; slot < narrow_slots_k; slot += blockDim.x) keys[slot] = __hip_atomic_load(&table[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads(); // (the copy's loads travel beside the offsets')
+    u64 const c_base = q_last >= q_first ? ((q_last - q_first + 15) & ~(u64)15) + 16 : 0;
+    if (q_last < q_first || c_last < c_first || c_base + (c_last - c_first) + 16 > capacity) { // (+ 16: the byte kernel reads whole dwords)
+        if (threadIdx.x == 0) *unfit = unfit_sequence;
+        return;
+    }
+    bool const mine = i < strings, of_candidates = mine && i >= queries.count;
+    szs_tape_t const &tape = of_candidates ? candidates : queries;
+    u64 const index = of_candidates ? i - queries.count : i;
+    u64 address = 0, place = 0;
+    u32 length = 0, produced = 0;
+    bool fits = true;
+    if (mine) {
+        u64 const first = of_candidates ? c_first : q_first, last = of_candidates ? c_last : q_last;
+        u64 const from = at(tape, index), to = at(tape, index + 1);
+        bool const sound = from >= first && to >= from && to <= last && to - from <= narrow_most_bytes_k;
+        place = (of_candidates ? c_base : 0) + (from - first), address = tape.base + from;
+        length = sound ? (u32)(to - from) : 0u, fits = sound;
+    }
+    u8 *const out = narrow + place;
+
+    /** A rune's byte: itself below 0x80, else 128 + its slot in the table (claimed now if nobody has); `fits` falls when the table is full. */
+    auto id_of = [&](u32 rune, bool &fits) -> u32 {
+        if (rune < 0x80u) return rune;
+        u32 slot = ((rune * 2654435761u) >> 16) & (narrow_slots_k - 1), probes = 0;
+#pragma unroll 1
+        for (; probes < narrow_slots_k; ++probes) {
+            u32 key = keys[slot];
+            if (!key) { // a slot is written once, from zero: the copy can only be behind by saying "empty", and then the swap decides
+                key = atomicCAS(&table[slot], 0u, rune);
+                keys[slot] = key ? key : rune;
+            }
+            if (!key || key == rune) break;
+            slot = (slot + 1) & (narrow_slots_k - 1);
+        }
+        if (probes == narrow_slots_k) fits = false; // more distinct runes than the table holds: not a batch for this way
+        return 128u + slot;
+    };
+    auto rune_of = [](u32 byte, u32 sequence, u32 const (&tail)[3]) -> u32 {
+        u32 rune = byte;
+        if (sequence == 2) rune = (byte & 0x1Fu) << 6 | tail[0];
+        if (sequence == 3) rune = (byte & 0x0Fu) << 12 | tail[0] << 6 | tail[1];
+        if (sequence == 4) rune = (byte & 0x07u) << 18 | tail[0] << 12 | tail[1] << 6 | tail[2];
+        return rune;
+    };
+
+    /**
+     *  This thread's string, by itself: the chain of lead bytes walked as it stands - a WORD's way (one round per rune, four ASCII
+     *  bytes a round; a round is ~50 dependent instructions of one wavefront, a quarter of a microsecond), and the way of the rare
+     *  string that is not well-formed UTF-8.  Sixteen bytes at a time in a window of five registers: the sequence at the window's head is
+     *  decoded, the window shifted down by its length (`v_alignbyte_b32` takes the count from a register).
+     */
+    auto walk = [&]() {
+        text_stream_t const text(address, length);
+        u32 raw[6];
+#pragma unroll
+        for (u32 d = 0; d < 6; ++d) raw[d] = text.raw(d);
+        u32 position = 0; // of the window's head in the string
+        produced = 0;
+#pragma unroll 1
+        for (u32 base = 0; base < length && fits; base += 16) {
+            u32 w[5]; // bytes [base, base + 20): a lead at the chunk's end finds its tail here
+#pragma unroll
+            for (u32 d = 0; d < 5; ++d) w[d] = text.splice(raw[d], raw[d + 1]);
+            raw[0] = raw[4], raw[1] = raw[5];
+#pragma unroll
+            for (u32 d = 2; d < 6; ++d) raw[d] = text.raw(base / 4 + 4 + d);
+            auto shift = [&](u32 bytes) { // the window down by 0 ... 4 bytes
+                if (bytes == 4) w[0] = w[1], w[1] = w[2], w[2] = w[3], w[3] = w[4], w[4] = 0;
+                else {
+#pragma unroll
+                    for (u32 d = 0; d < 4; ++d) w[d] = __builtin_amdgcn_alignbyte(w[d + 1], w[d], bytes);
+                    w[4] >>= 8 * bytes;
+                }
+            };
+            shift(position - base); // what the last sequence of the chunk before took of this one
+            u32 const end = base + 16 < length ? base + 16 : length;
+#pragma unroll 1
+            while (position < end && fits) {
+                if (!(w[0] & 0x80808080u) && position + 4 <= end) { // four ASCII bytes at the head: four runes that are their own ids
+#pragma unroll
+                    for (u32 k = 0; k < 4; ++k) out[produced + k] = (u8)(w[0] >> (8 * k));
+                    produced += 4, position += 4;
+                    shift(4);
+                    continue;
+                }
+                u32 const byte = w[0] & 0xFFu;
+                u32 const sequence = 1u + (byte >= 0xC0u) + (byte >= 0xE0u) + (byte >= 0xF0u);
+                u32 tail[3]; // (bytes missing from a sequence cut short by the end of the string read as zero: the transcoder's contract)
+#pragma unroll
+                for (u32 k = 1; k < 4; ++k) tail[k - 1] = k < sequence && position + k < length ? (w[0] >> (8 * k)) & 0x3Fu : 0u;
+                out[produced] = (u8)id_of(rune_of(byte, sequence, tail), fits); // (produced <= position: inside the string's own bytes)
+                ++produced, position += sequence;
+                shift(sequence);
+            }
+        }
+    };
+
+    constexpr u32 alone_k = 16; // bytes of the longest string a thread walks by itself
+    bool const is_long = length > alone_k;
+    if (length && !is_long) walk();
+    // ---- the longer strings (a few per cent of a text's tokens, and every wavefront holds one): by the WHOLE wavefront, one string
+    //      after the other, sixty-four bytes a step - walked by their own threads they held the wavefront for a round per rune (a
+    //      60-byte line of box-drawing characters: 40 rounds, 19 us of a pass whose other strings took 2).  In well-formed text the
+    //      leads are the bytes that are not continuation bytes (hip/utf8.hip: utf8_transcode_kernel makes the same observation):
+    //      every such byte followed by exactly the continuation bytes its value announces, the string's first byte among them.
+    //      A string that is anything else goes back to its own thread.
+    bool alone_after_all = false;
+    u64 const below = (1ull << lane) - 1;
+    for (u64 pending = __ballot(is_long); pending; pending &= pending - 1) {
+        int const owner = (int)__builtin_ctzll(pending);
+        u64 const its_address = (u64)(u32)__shfl((int)(u32)address, owner, 64) | (u64)(u32)__shfl((int)(u32)(address >> 32), owner, 64) << 32;
+        u64 const its_place = (u64)(u32)__shfl((int)(u32)place, owner, 64) | (u64)(u32)__shfl((int)(u32)(place >> 32), owner, 64) << 32;
+        u32 const its_length = (u32)__builtin_amdgcn_readfirstlane(__shfl((int)length, owner, 64));
+        u8 const *const bytes = reinterpret_cast<u8 const *>(its_address);
+        u8 *const its_out = narrow + its_place;
+        u32 done = 0;
+        bool well_formed = true, all_fit = true;
+        u32 byte = lane < its_length ? bytes[lane] : 0u;
+#pragma unroll 1
+        for (u32 base = 0; base < its_length; base += 64) {
+            u32 const ahead = base + 64 + lane < its_length ? bytes[base + 64 + lane] : 0u; // (a byte past the end reads as no continuation)
+            bool const valid = base + lane < its_length;
+            u64 const continuing = __ballot(valid && (byte & 0xC0u) == 0x80u), continuing_ahead = __ballot((ahead & 0xC0u) == 0x80u);
+            u32 const sequence = 1u + (byte >= 0xC0u) + (byte >= 0xE0u) + (byte >= 0xF0u);
+            u32 const following = (u32)(((continuing >> lane) >> 1) | (continuing_ahead << (63u - lane))) & 0xFu; // bytes lane + 1 ... + 4
+            bool const lead = valid && (byte & 0xC0u) != 0x80u;
+            bool const announced = (following & ((1u << sequence) - 1u)) == (1u << (sequence - 1u)) - 1u;
+            if (__ballot(lead && !announced) || (base == 0 && (continuing & 1ull))) {
+                well_formed = false;
+                break;
+            }
+            u32 tail[3];
+#pragma unroll
+            for (u32 k = 1; k < 4; ++k) {
+                u32 const here = (u32)__shfl((int)byte, (int)((lane + k) & 63u), 64), there = (u32)__shfl((int)ahead, (int)((lane + k) & 63u), 64);
+                tail[k - 1] = k < sequence ? (lane + k < 64u ? here : there) & 0x3Fu : 0u;
+            }
+            u64 const leads = __ballot(lead);
+            if (lead) {
+                bool lane_fits = true;
+                its_out[done + (u32)__popcll(leads & below)] = (u8)id_of(rune_of(byte, sequence, tail), lane_fits);
+                if (!lane_fits) all_fit = false;
+            }
+            done += (u32)__popcll(leads);
+            byte = ahead;
+        }
+        bool const somebody_did_not_fit = __ballot(!all_fit) != 0;
+        if ((int)lane == owner) {
+            if (!well_formed) alone_after_all = true;
+            else produced = done, fits = fits && !somebody_did_not_fit;
+        }
+    }
+    if (alone_after_all) walk();
+    if (mine) {
+        if (!fits || produced > narrow_most_runes_k) *unfit = unfit_sequence, produced = 0;
+        entries[i] = place | (u64)produced << 56;
+    }
+    // the sides' totals of runes (the call's cells are their product): one atomic per wavefront and side
+    for (u32 side = 0; side < 2; ++side) {
+        u32 sum = mine && (side != 0) == of_candidates ? produced : 0u;
+#pragma unroll
+        for (int offset = 32; offset; offset >>= 1) sum += (u32)__shfl_xor((int)sum, offset, 64);
+        if ((threadIdx.x & 63u) == 0 && sum) atomicAdd(reinterpret_cast<unsigned long long *>(&totals[side]), (unsigned long long)sum);
+    }
+}
+
 } // namespace szs_hip
 
 extern "C" int szs_hip_utf8_transcode(szs_string_ref_t const *strings, uint32_t count, uint64_t const *rune_starts,
@@ -380,3 +573,17 @@ extern "C" int szs_hip_alphabet_rename(uint32_t count, uint64_t const *rune_star
                        control, most, alphabet_out);
     return (int)hipGetLastError();
 }
+
+extern "C" int szs_hip_utf8_narrow(szs_tape_t const *queries, szs_tape_t const *candidates, void *narrow, uint64_t capacity, uint64_t *entries,
+                                   void *workspace, uint32_t *unfit, uint32_t unfit_sequence, void *stream) {
+    using namespace szs_hip;
+    u64 const strings = (u64)queries->count + candidates->count;
+    if (!strings) return 0;
+    u64 const blocks = (strings + 63) / 64; // (small workgroups: 8192 words are 128 of them - the pass is latency, spread it out)
+    if (blocks > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
+    u32 *const table = static_cast<u32 *>(workspace);
+    hipLaunchKernelGGL(utf8_narrow_kernel, dim3((u32)blocks), dim3(64), 0, static_cast<hipStream_t>(stream), *queries, *candidates,
+                       static_cast<u8 *>(narrow), capacity, entries, table, reinterpret_cast<u64 *>(table + narrow_slots_k), unfit, unfit_sequence);
+    return (int)hipGetLastError();
+}
+

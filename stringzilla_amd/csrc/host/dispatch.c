@@ -264,6 +264,7 @@ static void release_device_state(szs_engine_s *engine) {
     szs_buffer_release(&engine->device_transcode);
     szs_buffer_release(&engine->pinned_transcode);
     szs_buffer_release(&engine->device_alphabet);
+    szs_buffer_release(&engine->device_narrow);
     szs_buffer_release(&engine->device_plan_refs);
     szs_buffer_release(&engine->device_presence);
     szs_buffer_release(&engine->device_queue);
@@ -271,7 +272,7 @@ static void release_device_state(szs_engine_s *engine) {
     engine->queue_zeroed = NULL;
     szs_buffer_release(&engine->pinned_summary);
     szs_buffer_release(&engine->device_fused);
-    engine->tiny_valid = 0;
+    engine->tiny_valid = 0, engine->tiny_runes_valid = 0, engine->narrow_zeroed = NULL;
     engine->fused_zeroed = NULL;
     if (engine->events_device >= 0) {
         (void)hipEventDestroy(engine->event_start);
@@ -1082,7 +1083,7 @@ static int tiny_recently_refused(szs_engine_s *engine, uint32_t q_count, uint32_
  *  to the ordinary path (which also reports malformed tapes).  `planner_mode`: 1 when a planner's summary chose this kernel, 5 when
  *  the previous call of the engine did and nothing was planned at all.
  */
-static sz_status_t cross_tiny(szs_call_t *call, uint32_t planner_mode, szs_plan_summary_t const *seen /* or NULL */) {
+static sz_status_t cross_tiny(szs_call_t *call, uint32_t planner_mode, szs_plan_summary_t const *seen /* or NULL */, int runes) {
     szs_engine_s *engine = call->engine;
     hipStream_t const stream = call->stream;
     uint32_t volatile *const unfit = (uint32_t volatile *)((char *)engine->pinned_summary.pointer + 992);
@@ -1091,10 +1092,18 @@ static sz_status_t cross_tiny(szs_call_t *call, uint32_t planner_mode, szs_plan_
     uint32_t const sequence = engine->plan_sequence;
     *unfit = 0, symbols[0] = symbols[1] = 0;
     phase(call, 2);
-    szs_tape_t const q_tape = {call->queries->offsets, (uint64_t)(uintptr_t)call->queries->data, call->q_count, call->queries->kind == szs_input_u64tape_k};
-    szs_tape_t const c_tape = {call->candidates->offsets, (uint64_t)(uintptr_t)call->candidates->data, call->c_count,
-                               call->candidates->kind == szs_input_u64tape_k};
+    szs_tape_t q_tape = {call->queries->offsets, (uint64_t)(uintptr_t)call->queries->data, call->q_count, call->queries->kind == szs_input_u64tape_k};
+    szs_tape_t c_tape = {call->candidates->offsets, (uint64_t)(uintptr_t)call->candidates->data, call->c_count,
+                         call->candidates->kind == szs_input_u64tape_k};
     uint32_t launches = 0;
+    /* The codepoint engine (round 6; reference: cuda.cuh:3294): one pass ahead of the launch turns both UTF-8 tapes into byte strings of
+     * rune ids (hip/utf8.hip: utf8_narrow_kernel) in a buffer of the engine's, and the launch scores THOSE - no transcoding to UTF-32,
+     * no renumbering passes, no planner.  Device staging (cross_device_planned_runes reserved it): a word per string. */
+    uint64_t *const entries = runes ? (uint64_t *)engine->device_transcode.pointer : NULL;
+    /* the head of the narrow buffer: the pass's table of claimed runes - it LIVES ON from call to call, zeroed when the buffer is new
+     * and after a batch that the pass refused (a full table, perhaps) - and the sides' totals of runes */
+    char *const narrow_workspace = runes ? (char *)engine->device_narrow.pointer : NULL;
+    char *const narrow_strings = runes ? narrow_workspace + SZS_NARROW_WORKSPACE : NULL;
     uint64_t *trace = NULL; /* `trace` knob: the phases of every workgroup of the launch (printed after the wait) */
     size_t const trace_workgroups = 8192, trace_slots = 10;
     hipError_t error = hipEventRecord(engine->event_start, stream);
@@ -1105,9 +1114,24 @@ static sz_status_t cross_tiny(szs_call_t *call, uint32_t planner_mode, szs_plan_
     /* ONE launch: the tiny tokens and, in their shadow, the few longer ones (hip/myers_tiny.hip).  (Round 5's first design was four:
      * a pass that listed the longer strings and tabled the tiny ones' masks in device memory, the outliers' kernel, a pass that set
      * the tables back, the tiny-token kernel - 100 us of kernels on 4096 x 4096 words of text where the one launch takes 81.) */
+    if (error == hipSuccess && runes) {
+        if (engine->narrow_zeroed != (void *)narrow_workspace) {
+            error = hipMemsetAsync(narrow_workspace, 0, SZS_NARROW_WORKSPACE, stream);
+            engine->narrow_zeroed = error == hipSuccess ? (void *)narrow_workspace : NULL;
+        }
+        if (error == hipSuccess)
+            error = (hipError_t)szs_hip_utf8_narrow(&q_tape, &c_tape, narrow_strings, engine->device_narrow.capacity - SZS_NARROW_WORKSPACE, entries,
+                                                    narrow_workspace, (uint32_t *)unfit, sequence, stream);
+        launches += error == hipSuccess;
+        szs_tape_t const q_narrow = {entries, (uint64_t)(uintptr_t)narrow_strings, call->q_count, 2};
+        szs_tape_t const c_narrow = {entries + call->q_count, (uint64_t)(uintptr_t)narrow_strings, call->c_count, 2};
+        q_tape = q_narrow, c_tape = c_narrow;
+    }
     if (error == hipSuccess) {
         error = (hipError_t)szs_hip_levenshtein_tiny(&q_tape, &c_tape, (uint64_t *)call->device_results, call->device_stride, (uint32_t *)unfit, sequence,
-                                                           (unsigned long long *)symbols, trace, trace_workgroups, szs_tuning_get(szs_knob_tiny_k) == 2, stream);
+                                                           (unsigned long long *)symbols,
+                                                           runes ? (uint64_t *)(narrow_workspace + SZS_NARROW_SLOTS * sizeof(uint32_t)) : NULL, trace,
+                                                           trace_workgroups, szs_tuning_get(szs_knob_tiny_k) == 2, stream);
         launches += error == hipSuccess;
     }
     engine->last_streams = 1;
@@ -1116,11 +1140,12 @@ static sz_status_t cross_tiny(szs_call_t *call, uint32_t planner_mode, szs_plan_
     szs_decision_t shape_of_call;
     memset(&shape_of_call, 0, sizeof(shape_of_call));
     szs_decision_t *const shape = &shape_of_call;
-    shape->tier = SZS_TIER_LANES, shape->q_count = call->q_count, shape->c_count = call->c_count;
+    shape->tier = SZS_TIER_LANES, shape->q_count = call->q_count, shape->c_count = call->c_count, shape->runes = runes;
     if (seen) shape->longest[0] = seen->side[0].longest, shape->longest[1] = seen->side[1].longest;
     engine->last_profile.planner = planner_mode;
     int stalled = 0;
     sz_status_t status = finish(call, shape, error, sz_success_k, launches, 0, 0, 0, &stalled);
+    if (runes && (status != sz_success_k || *unfit == sequence)) engine->narrow_zeroed = NULL; /* a full table, totals nobody read: start over */
     if (status != sz_success_k) return status;
     if (trace) { /* where a workgroup of the tiny-token kernel spends its time: mean ticks (10 ns) between its stamps */
         size_t const slots = trace_slots, last_slot = 8;
@@ -1158,7 +1183,8 @@ static sz_status_t cross_tiny(szs_call_t *call, uint32_t planner_mode, szs_plan_
     if (*unfit == sequence) {
         /* refused (a block or span too dense in long strings, a string beyond 255 bytes): remember the counts, so that a stream of
          * such batches does not pay this launch and its wait on every call because their summaries look like words */
-        engine->tiny_valid = 0;
+        if (runes) engine->tiny_runes_valid = 0;
+        else engine->tiny_valid = 0;
         if (planner_mode == 1) { /* ... a batch whose SUMMARY looked like words (clustered long lines among short ones).  A batch that
                                     came straight here on the previous call's word (mode 5: sentences after words) is judged by its
                                     own summary next time - nothing to remember */
@@ -1177,8 +1203,8 @@ static sz_status_t cross_tiny(szs_call_t *call, uint32_t planner_mode, szs_plan_
     szs_side_stats_t now[2];
     memset(now, 0, sizeof(now));
     now[0].count = call->q_count, now[0].symbols = q_symbols, now[1].count = call->c_count, now[1].symbols = c_symbols;
-    engine->tiny_valid = tiny_shaped(engine, 0, &now[0], &now[1]);
-    engine->tiny_q_count = call->q_count, engine->tiny_c_count = call->c_count;
+    if (runes) engine->tiny_runes_valid = tiny_shaped(engine, 0, &now[0], &now[1]), engine->tiny_runes_q_count = call->q_count, engine->tiny_runes_c_count = call->c_count;
+    else engine->tiny_valid = tiny_shaped(engine, 0, &now[0], &now[1]), engine->tiny_q_count = call->q_count, engine->tiny_c_count = call->c_count;
     if (engine->remembered) engine->remembered->refs_current = 0, engine->remembered->valid = 0; /* another kind of call came between */
     return szs_report(sz_success_k, call->error_message, NULL);
 }
@@ -1453,7 +1479,7 @@ static sz_status_t planned_and_waited_for(planned_call_t *way) {
     if (way->use_myers && szs_tuning_get(szs_knob_tier_k) < 0 && szs_tuning_get(szs_knob_swap_k) < 0 && szs_tuning_get(szs_knob_queue_k) < 0 &&
         tiny_shaped(engine, symmetric, &seen->side[0], &seen->side[1]) && !tiny_recently_refused(engine, call->q_count, call->c_count, 1)) {
         /* the summary says tiny tokens (and the kernel did not refuse the previous batch of these counts): no refs needed after all */
-        status = cross_tiny(call, 1, seen);
+        status = cross_tiny(call, 1, seen, 0);
         if (status != SZS_TINY_NOT_TAKEN) return status;
     }
 
@@ -1544,7 +1570,7 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
     if (engine->tiny_valid && !symmetric && engine->tiny_q_count == q_count && engine->tiny_c_count == c_count && way.use_myers &&
         szs_tuning_get(szs_knob_tiny_k) != 0 && szs_tuning_get(szs_knob_speculate_k) != 0 && szs_tuning_get(szs_knob_tier_k) < 0 &&
         szs_tuning_get(szs_knob_swap_k) < 0 && szs_tuning_get(szs_knob_queue_k) < 0) {
-        status = cross_tiny(call, 5, NULL);
+        status = cross_tiny(call, 5, NULL, 0);
         if (status != SZS_TINY_NOT_TAKEN) return status;
     }
 
@@ -1646,7 +1672,10 @@ static sz_status_t cross_device_planned_runes(szs_call_t *call) {
     size_t const starts_at = 0, counts_at = strings * sizeof(uint64_t);
     size_t const flags_at = (counts_at + strings * sizeof(uint32_t) + 7) & ~(size_t)7, needed_at = flags_at + 4 * sizeof(uint32_t);
     size_t const staging_bytes = needed_at + sizeof(uint64_t);
-    sz_status_t status = szs_buffer_reserve(&engine->device_transcode, szs_memory_device_k, device, staging_bytes, error_message);
+    /* (... or, for a batch of tiny tokens - cross_tiny: a word per string) */
+    size_t const narrow_staging_bytes = strings * sizeof(uint64_t);
+    sz_status_t status = szs_buffer_reserve(&engine->device_transcode, szs_memory_device_k, device,
+                                            staging_bytes > narrow_staging_bytes ? staging_bytes : narrow_staging_bytes, error_message);
     if (status == sz_success_k) status = szs_buffer_reserve(&engine->pinned_transcode, szs_memory_pinned_k, device, 64, error_message);
     void *const refs_before = engine->device_plan_refs.pointer;
     if (status == sz_success_k)
@@ -1676,6 +1705,15 @@ static sz_status_t cross_device_planned_runes(szs_call_t *call) {
     szs_decision_t *const remembered = engine->remembered;
     remembered->refs_current = 0; /* the planner is about to overwrite the refs */
     phase(call, 0);
+
+    /* ---- tiny tokens (round 6): the previous call of these counts was words of a few runes - this one is narrowed to byte strings and
+     * scored by the tiny-token launch without being transcoded, renumbered or planned (cross_tiny; the byte path's way 5).  A batch that
+     * is something else says so itself (a string beyond 255 runes, too many long ones, an alphabet beyond the table) and is scored below. */
+    if (engine->tiny_runes_valid && engine->device_narrow.capacity && !symmetric && engine->tiny_runes_q_count == q_count && engine->tiny_runes_c_count == c_count &&
+        engine->is_unit_cost && szs_tuning_get(szs_knob_tiny_k) != 0 && szs_tuning_get(szs_knob_speculate_k) != 0 && szs_tuning_get(szs_knob_tier_k) < 0) {
+        status = cross_tiny(call, 5, NULL, 1);
+        if (status != SZS_TINY_NOT_TAKEN) return status;
+    }
 
     char *const remote = (char *)engine->device_transcode.pointer;
     uint32_t volatile *const flags = (uint32_t volatile *)engine->pinned_transcode.pointer; /* 4 flags, then `needed` */
@@ -1760,6 +1798,14 @@ static sz_status_t cross_device_planned_runes(szs_call_t *call) {
             engine->runes_needed = *(uint64_t const volatile *)(flags + 4);
             remembered->summary = seen;
             remembered->plan.cells = profile->cells;
+            /* words scored on the shape of an earlier batch (sentences before them, or words the tiny-token launch was not tried on): the
+             * next call of these counts goes to that launch (cross_tiny) */
+            if (flags[0] && tiny_shaped(engine, symmetric, &seen.side[0], &seen.side[1]) && !tiny_recently_refused(engine, q_count, c_count, 1)) {
+                size_t const narrow_before = engine->device_narrow.capacity;
+                if (szs_buffer_reserve(&engine->device_narrow, szs_memory_device_k, device, (size_t)engine->runes_needed + 64 + SZS_NARROW_WORKSPACE, NULL) == sz_success_k)
+                    engine->tiny_runes_valid = 1, engine->tiny_runes_q_count = q_count, engine->tiny_runes_c_count = c_count;
+                if (engine->device_narrow.capacity != narrow_before) engine->narrow_zeroed = NULL;
+            }
             return szs_report(sz_success_k, error_message, NULL);
         }
         /* the batch has another shape, more runes or a richer alphabet: every ref was blanked, nothing real was scored */
@@ -1793,6 +1839,17 @@ static sz_status_t cross_device_planned_runes(szs_call_t *call) {
     if (remembered->runes) remembered->valid = 0; /* whatever happens below, the next call is not launched on an older codepoint shape */
     if (!flags[0]) return SZS_RUNES_ARE_BYTES;
     if (seen.status & SZS_PLAN_STATUS_UNSORTED) return SZS_NOT_DEVICE_PLANNABLE; /* strings beyond the planner's histogram */
+    if (tiny_shaped(engine, symmetric, &seen.side[0], &seen.side[1]) && !tiny_recently_refused(engine, q_count, c_count, 1)) {
+        /* the summary (in RUNES) says words: their launch instead, and the next call of these counts goes there unplanned.  The narrow
+         * strings get a buffer of their own - should that launch refuse the batch, the UTF-32 arrays are scored below.  `needed`
+         * counts every string's BYTE span rounded up (hip/utf8.hip: transcode_tape_t::span): it bounds the bytes of both tapes. */
+        size_t const narrow_before = engine->device_narrow.capacity;
+        status = szs_buffer_reserve(&engine->device_narrow, szs_memory_device_k, device, (size_t)engine->runes_needed + 64 + SZS_NARROW_WORKSPACE, error_message);
+        if (engine->device_narrow.capacity != narrow_before) engine->narrow_zeroed = NULL; /* (a new buffer, wherever it lies) */
+        if (status != sz_success_k) return status;
+        status = cross_tiny(call, 1, &seen, 1);
+        if (status != SZS_TINY_NOT_TAKEN) return status;
+    }
     uint32_t const distinct = flags[1], overflowed = flags[2];
     /* the arrays hold ids 1 ... distinct: the kernels index direct tables with them */
     uint32_t const alphabet = renumber && distinct && distinct <= SZS_ALPHABET_MOST && !overflowed ? alphabet_with_room(distinct) : 0;

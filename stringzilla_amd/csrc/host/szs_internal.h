@@ -94,6 +94,7 @@ typedef struct szs_engine_s {
     szs_buffer_t device_tape;    /* device: packed copy of strings living in plain host memory (`cpu_requests = gpu` only) */
     szs_buffer_t pinned_tape;    /* pinned: the host side of that copy */
     szs_buffer_t device_runes;   /* device: UTF-32 transcription of both sides (codepoint-level engine) */
+    szs_buffer_t device_narrow;  /* device: tiny tokens of a codepoint call as byte strings of rune ids (hip/utf8.hip: utf8_narrow_kernel) */
     uint64_t runes_needed;       /* runes the last device-planned codepoint call needed in that buffer (~ the bytes of its batch) */
     uint64_t cells_before;       /* cells of the previous call of this engine (the call profile is cleared when a call begins) */
     szs_buffer_t device_transcode; /* device: raw refs, rune starts, rune counts and the multibyte flag of that pass */
@@ -119,6 +120,9 @@ typedef struct szs_engine_s {
     int fused_gave_up;             /* a launch that plans itself ran out of polls on this engine: it is not tried again */
     int tiny_valid;                /* the previous call of these counts was scored by the tiny-token kernel (hip/myers_tiny.hip): go straight there */
     uint32_t tiny_q_count, tiny_c_count;
+    int tiny_runes_valid;          /* the same for the codepoint engine: narrowed to byte strings of rune ids, then that kernel (round 6) */
+    uint32_t tiny_runes_q_count, tiny_runes_c_count;
+    void *narrow_zeroed;           /* the narrow buffer whose head - the table of claimed runes, the totals - holds what the last call left */
     int tiny_refused;              /* ... or was REFUSED by it (dense in long strings): calls of these counts skip the summary-driven attempt */
     hipEvent_t event_start, event_stop;
     int events_device;

@@ -471,3 +471,145 @@ def test_the_sharded_driver_over_rccl_with_a_world_of_one(tmp_path, oracle):
     assert np.array_equal(shard["full"].view(np.uint64), expected)
     assert np.array_equal(shard["mirrored"].view(np.uint64), oracle.levenshtein(_strings(load.queries), None))
     assert float(shard["total"]) == float(expected.sum())
+
+
+# ---- the CODEPOINT twin of the tiny-token launch (hip/utf8.hip: utf8_narrow_kernel; the reference's per-thread kernel for short
+#      runes: cuda.cuh:3294) ---------------------------------------------------------------------------------------------------------
+#
+# Words of a few runes through `LevenshteinDistancesUTF8`: one pass writes every string as bytes, a byte per rune (ASCII itself, any
+# other rune 128 + its slot among 128 claimed ones), and the byte kernel of hip/myers_tiny.hip scores those.  Pinned here: every
+# sequence length 1 ... 4, ragged counts around the blocks and groups, strings of up to 255 RUNES (1020 bytes) riding along, bytes the
+# transcoder's unchecked contract decodes in its own way (stray continuation bytes, sequences cut short by the end of a string, 0xFF),
+# an alphabet beyond the table (refused, scored the ordinary way), ASCII batches of a codepoint engine, the automatic choice.
+
+RUNE_LETTERS = list("etaoinshrdlu") + list("éèüößñçåøæ") + list("дежзийклмноп") + list("αβγδε") + ["中", "文", "😀", "🎉", "—", " "]
+ODD_BYTES = [b"\xc3", b"\x80\xbf", b"ab\xe2\x82", b"\xf0", b"\xff", b"\xf0\x9f\x98", b"a\x80b", b"\xe2\x82\xac\xc3", b"\xc3\xa9\xa9"]
+
+
+def _rune_count(string):
+    """Runes of a byte string under `sz_rune_decode_unchecked`: the length of a sequence comes from its lead byte alone."""
+    count = position = 0
+    while position < len(string):
+        byte = string[position]
+        position += 1 + (byte >= 0xC0) + (byte >= 0xE0) + (byte >= 0xF0)
+        count += 1
+    return count
+
+
+@pytest.mark.parametrize("rows,columns,longest_query,longest_text", [
+    (1, 1, 8, 8), (31, 255, 16, 16), (33, 257, 16, 16), (100, 700, 32, 40), (70, 300, 17, 16), (65, 260, 128, 70), (20, 270, 256, 300),
+    (300, 1000, 10, 10), (600, 300, 9, 255),
+])
+def test_tiny_tokens_of_the_codepoint_engine(gpu, oracle, rows, columns, longest_query, longest_text):
+    rng = random.Random(rows * 104729 + columns)
+    engine = szs.LevenshteinDistancesUTF8(capabilities=gpu)
+    previous_fit = False
+    with knob("tiny", 2):  # (2: spans and blocks of which more than a quarter is long are scored too - the draws below come close to that)
+        for batch in range(3):
+            length = lambda longest: rng.choice([0, 1, 2, 3, 5, 7, 8, longest, rng.randint(0, longest)])
+            word = lambda longest: rng.choice(ODD_BYTES) if rng.random() < 0.03 else "".join(rng.choice(RUNE_LETTERS) for _ in range(length(longest))).encode()
+            queries = [word(longest_query) for _ in range(rows)]
+            candidates = [word(longest_text) for _ in range(columns)]
+            candidates[rng.randrange(columns)] = "ü".encode()  # (an ASCII batch is the byte engines': tested below)
+            got = engine(queries, candidates, device=gpu)
+            expected = oracle.levenshtein_utf8(queries, candidates)
+            assert np.array_equal(got, expected), (batch, np.argwhere(got != expected)[:5].tolist())
+            profile = engine.last_call_profile()
+            fits = all(max(map(_rune_count, side)) <= 255 for side in (queries, candidates))
+            if fits:  # the narrowing pass and the one launch
+                assert profile.cells == sum(map(_rune_count, queries)) * sum(map(_rune_count, candidates))
+                assert profile.launches == 2 and profile.planner == (5 if previous_fit else 1), (batch, profile.planner, profile.launches)
+            else:  # refused (a string beyond 255 runes): the UTF-32 arrays are scored by the ordinary kernels
+                assert profile.planner != 5
+            previous_fit = fits
+
+
+def test_codepoint_words_are_recognised_and_richer_alphabets_are_not(gpu, oracle):
+    rng = random.Random(77)
+    letters = list("etaoinshrdlu") + list("éüßñдежз")
+    word = lambda alphabet: "".join(rng.choice(alphabet) for _ in range(rng.choice([1, 2, 3, 3, 4, 4, 5, 5, 6, 7, 8, 9, 11, 14]))).encode()
+    engine = szs.LevenshteinDistancesUTF8(capabilities=gpu)
+    modes = []
+    for batch in range(3):
+        queries, candidates = [word(letters) for _ in range(600)], [word(letters) for _ in range(2100)]
+        assert np.array_equal(engine(queries, candidates, device=gpu), oracle.levenshtein_utf8(queries, candidates))
+        modes.append(int(engine.last_call_profile().planner))
+    assert modes == [1, 5, 5] and engine.last_call_profile().launches == 2, modes
+    # the same counts over an alphabet of 400 runes beyond ASCII: the pass cannot number them in 128 slots, says so, and the call is
+    # transcoded, planned and scored the ordinary way - as is the next one, judged by its own summary again
+    rich = [chr(0x4E00 + i) for i in range(400)]
+    for batch in range(2):
+        queries, candidates = [word(rich) for _ in range(600)], [word(rich) for _ in range(2100)]
+        assert np.array_equal(engine(queries, candidates, device=gpu), oracle.levenshtein_utf8(queries, candidates))
+        assert engine.last_call_profile().planner != 5
+    # words again: a batch whose SUMMARY said words was refused, so the next sixteen calls of these counts do not try (dispatch.c:
+    # tiny_recently_refused - a stream of such batches must not pay the refused launch every time); after that words are words again.
+    # Then a batch without a single byte >= 0x80: a codepoint engine scores that one as bytes
+    modes = []
+    for batch in range(19):
+        queries, candidates = [word(letters) for _ in range(600)], [word(letters) for _ in range(2100)]
+        assert np.array_equal(engine(queries, candidates, device=gpu), oracle.levenshtein_utf8(queries, candidates))
+        modes.append(int(engine.last_call_profile().planner))
+    assert 5 not in modes[:14] and modes[-1] == 5, modes
+    plain = list("etaoinshrdlu")
+    queries, candidates = [word(plain) for _ in range(600)], [word(plain) for _ in range(2100)]
+    assert np.array_equal(engine(queries, candidates, device=gpu), oracle.levenshtein_utf8(queries, candidates))
+    with knob("tiny", 0):  # ... and nothing goes there when the knob says so
+        queries, candidates = [word(letters) for _ in range(600)], [word(letters) for _ in range(2100)]
+        for _ in range(2):
+            assert np.array_equal(engine(queries, candidates, device=gpu), oracle.levenshtein_utf8(queries, candidates))
+            assert engine.last_call_profile().planner != 5
+
+
+def test_codepoint_words_on_wide_tapes_and_padded_matrices(gpu, oracle):
+    import torch
+
+    rng = random.Random(5)
+    word = lambda: "".join(rng.choice(RUNE_LETTERS) for _ in range(rng.randint(0, 12))).encode()
+    engine = szs.LevenshteinDistancesUTF8(capabilities=gpu)
+    with knob("tiny", 1):
+        for batch in range(3):
+            queries = szs.Strs([word() for _ in range(37)], wide_offsets=True)
+            candidates = szs.Strs([word() for _ in range(513)] , wide_offsets=True)
+            out = torch.full((37, 600), -1, dtype=torch.int64, device="cuda:0")
+            torch.cuda.synchronize()
+            engine(queries, candidates, device=gpu, out=out[:, :513])
+            expected = oracle.levenshtein_utf8([queries[i] for i in range(37)], [candidates[i] for i in range(513)])
+            assert np.array_equal(out[:, :513].cpu().numpy().view(np.uint64), expected)
+            assert (out[:, 513:] == -1).all()
+        assert engine.last_call_profile().planner == 5
+
+
+def test_codepoint_strings_the_wavefront_decodes(gpu, oracle):
+    """Strings beyond sixteen bytes are decoded by their whole wavefront, sixty-four bytes a step, ON THE ASSUMPTION that they are
+    well-formed (every byte that is not a continuation byte followed by exactly the continuation bytes it announces) - and by their
+    own thread, the chain of lead bytes walked as it stands, when they are not.  Pinned: sequences of every length straddling the
+    steps' boundaries (bytes 64, 128, 192), strings of exactly 16 / 17 / 64 / 65 / 128 bytes, and every way of not being well-formed
+    (a stray continuation byte at the start, in the middle, behind a complete sequence; a sequence cut short by the end of the string
+    or by the next lead; 0xFF; a lead at the very end) at every such place."""
+    rng = random.Random(99)
+    letters = list("etaoin") + list("éüд") + ["中", "😀"]
+    strings = []
+    for filler in (13, 14, 15, 16, 17, 60, 61, 62, 63, 64, 65, 124, 125, 126, 127, 128, 129, 190, 191, 192, 193, 250):
+        body = "".join(rng.choice("etaoin") for _ in range(filler)).encode()
+        for tail in ("é", "中", "😀", "é中😀", ""):
+            strings.append(body + tail.encode() + b"xy")
+            strings.append(body + tail.encode())
+        for odd in (b"\x80", b"\xc3", b"\xe2\x82", b"\xf0\x9f\x98", b"\xff", b"\xc3\xa9\xa9", b"\xe2\xc3\xa9", b"\xf0\x9f"):
+            strings.append(body + odd + b"tail")
+            strings.append(body + odd)
+            strings.append(odd + body)
+    strings += ["".join(rng.choice(letters) for _ in range(rng.randint(17, 120))).encode() for _ in range(200)]
+    strings = [s for s in strings if _rune_count(s) <= 255]
+    words = lambda count: ["".join(rng.choice(letters) for _ in range(rng.randint(0, 9))).encode() for _ in range(count)]
+    engine = szs.LevenshteinDistancesUTF8(capabilities=gpu)
+    with knob("tiny", 2):
+        for batch in range(2):
+            rng.shuffle(strings)
+            queries = strings[:48] + words(80)
+            candidates = strings[48:] + words(900)
+            rng.shuffle(queries), rng.shuffle(candidates)
+            got = engine(queries, candidates, device=gpu)
+            expected = oracle.levenshtein_utf8(queries, candidates)
+            assert np.array_equal(got, expected), (batch, np.argwhere(got != expected)[:5].tolist())
+            assert engine.last_call_profile().planner == (5 if batch else 1) and engine.last_call_profile().launches == 2
