@@ -1709,8 +1709,16 @@ static sz_status_t cross_device_planned_runes(szs_call_t *call) {
     /* ---- tiny tokens (round 6): the previous call of these counts was words of a few runes - this one is narrowed to byte strings and
      * scored by the tiny-token launch without being transcoded, renumbered or planned (cross_tiny; the byte path's way 5).  A batch that
      * is something else says so itself (a string beyond 255 runes, too many long ones, an alphabet beyond the table) and is scored below. */
-    if (engine->tiny_runes_valid && engine->device_narrow.capacity && !symmetric && engine->tiny_runes_q_count == q_count && engine->tiny_runes_c_count == c_count &&
-        engine->is_unit_cost && szs_tuning_get(szs_knob_tiny_k) != 0 && szs_tuning_get(szs_knob_speculate_k) != 0 && szs_tuning_get(szs_knob_tier_k) < 0) {
+    /* (... or was ASCII words, which this engine hands to the byte kernels - after transcoding and planning them to find that out:
+     * narrowed, an ASCII batch is its own bytes, 13 us instead of that front end) */
+    int const words_before = (engine->tiny_runes_valid && engine->tiny_runes_q_count == q_count && engine->tiny_runes_c_count == c_count) ||
+                             (engine->tiny_valid && engine->tiny_q_count == q_count && engine->tiny_c_count == c_count);
+    if (words_before && engine->runes_needed && !symmetric && engine->is_unit_cost && szs_tuning_get(szs_knob_tiny_k) != 0 &&
+        szs_tuning_get(szs_knob_speculate_k) != 0 && szs_tuning_get(szs_knob_tier_k) < 0) {
+        size_t const narrow_before = engine->device_narrow.capacity;
+        status = szs_buffer_reserve(&engine->device_narrow, szs_memory_device_k, device, (size_t)(engine->runes_needed + engine->runes_needed / 4) + 64 + SZS_NARROW_WORKSPACE, error_message);
+        if (engine->device_narrow.capacity != narrow_before) engine->narrow_zeroed = NULL; /* (a new buffer, wherever it lies) */
+        if (status != sz_success_k) return status;
         status = cross_tiny(call, 5, NULL, 1);
         if (status != SZS_TINY_NOT_TAKEN) return status;
     }
@@ -1802,7 +1810,7 @@ static sz_status_t cross_device_planned_runes(szs_call_t *call) {
              * next call of these counts goes to that launch (cross_tiny) */
             if (flags[0] && tiny_shaped(engine, symmetric, &seen.side[0], &seen.side[1]) && !tiny_recently_refused(engine, q_count, c_count, 1)) {
                 size_t const narrow_before = engine->device_narrow.capacity;
-                if (szs_buffer_reserve(&engine->device_narrow, szs_memory_device_k, device, (size_t)engine->runes_needed + 64 + SZS_NARROW_WORKSPACE, NULL) == sz_success_k)
+                if (szs_buffer_reserve(&engine->device_narrow, szs_memory_device_k, device, (size_t)(engine->runes_needed + engine->runes_needed / 4) + 64 + SZS_NARROW_WORKSPACE, NULL) == sz_success_k)
                     engine->tiny_runes_valid = 1, engine->tiny_runes_q_count = q_count, engine->tiny_runes_c_count = c_count;
                 if (engine->device_narrow.capacity != narrow_before) engine->narrow_zeroed = NULL;
             }
@@ -1844,7 +1852,7 @@ static sz_status_t cross_device_planned_runes(szs_call_t *call) {
          * strings get a buffer of their own - should that launch refuse the batch, the UTF-32 arrays are scored below.  `needed`
          * counts every string's BYTE span rounded up (hip/utf8.hip: transcode_tape_t::span): it bounds the bytes of both tapes. */
         size_t const narrow_before = engine->device_narrow.capacity;
-        status = szs_buffer_reserve(&engine->device_narrow, szs_memory_device_k, device, (size_t)engine->runes_needed + 64 + SZS_NARROW_WORKSPACE, error_message);
+        status = szs_buffer_reserve(&engine->device_narrow, szs_memory_device_k, device, (size_t)(engine->runes_needed + engine->runes_needed / 4) + 64 + SZS_NARROW_WORKSPACE, error_message);
         if (engine->device_narrow.capacity != narrow_before) engine->narrow_zeroed = NULL; /* (a new buffer, wherever it lies) */
         if (status != sz_success_k) return status;
         status = cross_tiny(call, 1, &seen, 1);

@@ -552,8 +552,17 @@ def test_codepoint_words_are_recognised_and_richer_alphabets_are_not(gpu, oracle
         modes.append(int(engine.last_call_profile().planner))
     assert 5 not in modes[:14] and modes[-1] == 5, modes
     plain = list("etaoinshrdlu")
-    queries, candidates = [word(plain) for _ in range(600)], [word(plain) for _ in range(2100)]
-    assert np.array_equal(engine(queries, candidates, device=gpu), oracle.levenshtein_utf8(queries, candidates))
+    for batch in range(3):  # (narrowed like the others - an ASCII string is its own ids; a stream of ASCII batches too, once it is known for words)
+        queries, candidates = [word(plain) for _ in range(600)], [word(plain) for _ in range(2100)]
+        assert np.array_equal(engine(queries, candidates, device=gpu), oracle.levenshtein_utf8(queries, candidates))
+        assert engine.last_call_profile().planner == 5
+    ascii_only = szs.LevenshteinDistancesUTF8(capabilities=gpu)
+    modes = []
+    for batch in range(3):
+        queries, candidates = [word(plain) for _ in range(600)], [word(plain) for _ in range(2100)]
+        assert np.array_equal(ascii_only(queries, candidates, device=gpu), oracle.levenshtein_utf8(queries, candidates))
+        modes.append((int(ascii_only.last_call_profile().planner), int(ascii_only.last_call_profile().launches)))
+    assert modes[1:] == [(5, 2), (5, 2)], modes
     with knob("tiny", 0):  # ... and nothing goes there when the knob says so
         queries, candidates = [word(letters) for _ in range(600)], [word(letters) for _ in range(2100)]
         for _ in range(2):
