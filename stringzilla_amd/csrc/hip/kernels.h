@@ -199,6 +199,8 @@ typedef struct szs_tape_t {
 int szs_hip_levenshtein_tiny(szs_tape_t const *queries, szs_tape_t const *candidates, uint64_t *results, uint64_t results_row_stride,
                                    uint32_t *unfit, uint32_t unfit_sequence, unsigned long long *symbols_out,
                                    uint64_t *rune_totals /* NULL, or (tapes of kind 2) the two totals szs_hip_utf8_narrow counted: read, and zeroed for the next call */,
+                                   uint64_t *squares_out /* NULL, or (a symmetric call: both tapes the same) a qword per block of 256 strings in PINNED memory:
+                                                            the sums of their squared lengths */,
                                    uint64_t *trace /* NULL, or 10 qwords per workgroup of device memory (`trace` knob) */,
                                    uint64_t trace_workgroups /* workgroups `trace` has room for: a larger grid is not traced at all */,
                                    int dense /* testing: score blocks and spans full of long strings too (slowly) instead of refusing them */, void *stream);

@@ -313,7 +313,7 @@ __device__ __forceinline__ void tiny_long_queries(u32 *peq, u32 *out, u64 const 
 template <u32 registers_, bool packed_>
 __device__ __forceinline__ void tiny_body(szs_tape_t const &queries, szs_tape_t const &candidates, u32 queries_per_workgroup,
                                                 u64 *__restrict__ results, u64 results_row_stride, u32 *unfit, u32 unfit_sequence,
-                                                unsigned long long *symbols_out, u64 *rune_totals, u64 *trace, u32 dense) {
+                                                unsigned long long *symbols_out, u64 *rune_totals, u64 *squares_out, u64 *trace, u32 dense) {
     constexpr u32 R = registers_, H = R / 2, group_k = 2 * R; // registers of VP (of VN) a lane, rows of `out`, queries a group
     constexpr u32 texts_per_wave = 64u / R;                   // clusters of R lanes: kinds A and C
     constexpr u32 slots_per_thread = group_k / 16u;           // thread t builds byte t % 16 of slots t / 16 (+ 16)
@@ -330,7 +330,7 @@ __device__ __forceinline__ void tiny_body(szs_tape_t const &queries, szs_tape_t 
     __shared__ u64 froms[tiny_block_k];
     __shared__ u32 lengths[tiny_block_k], bins[32], lane_of_rank[tiny_block_k];
     __shared__ unsigned short listed[tiny_most_queries_k]; // the span's long queries (17 ... 255 bytes), by their place in the span
-    __shared__ u32 listed_count, listed_longest;
+    __shared__ u32 listed_count, listed_longest, squares_sum;
 
     u32 const tid = threadIdx.x;
     u32 const blocks = (u32)(((u64)candidates.count + tiny_block_k - 1) / tiny_block_k);
@@ -370,11 +370,14 @@ __device__ __forceinline__ void tiny_body(szs_tape_t const &queries, szs_tape_t 
         query_offsets[i] = packed_ ? static_cast<u64 const *>(queries.offsets)[(u64)query_first + i] : tiny_offset(queries.offsets, queries.wide, (u64)query_first + i);
     for (u32 i = tid; i < 256 * R; i += 256) peq[i] = 0;
     if (tid < 32) bins[tid] = 0;
-    if (tid == 0) listed_count = 0, listed_longest = 0;
+    if (tid == 0) listed_count = 0, listed_longest = 0, squares_sum = 0;
     froms[tid] = my_from, lengths[tid] = my_exists ? my_length : 0x80000000u;
     __syncthreads();
     u32 const bin = !my_exists ? tiny_rows_k + 2 : my_length <= tiny_rows_k ? my_length : tiny_rows_k + 1;
     u32 const place_in_bin = atomicAdd(&bins[bin], 1u);
+    // a SYMMETRIC call (both tapes are the one tape) counts the cells of its lower triangle, ((sum len)^2 + sum len^2) / 2: the blocks of
+    // the first span leave the sums of their candidates' squared lengths where the host adds them up (plain stores to pinned memory)
+    if (squares_out && span == 0 && my_exists) atomicAdd(&squares_sum, my_length * my_length);
     for (u32 i = tid; i < queries_here; i += 256) { // the span's long queries, in whatever order the atomics hand out
         u64 const bytes = tiny_query_bytes<packed_>(query_offsets, i);
         if (bytes > tiny_longest_k) *unfit = unfit_sequence;
@@ -393,6 +396,7 @@ __device__ __forceinline__ void tiny_body(szs_tape_t const &queries, szs_tape_t 
     }
     __syncthreads();
     lane_of_rank[bins[bin] + place_in_bin] = tid;
+    if (squares_out && span == 0 && tid == 0) squares_out[block] = squares_sum;
     __syncthreads();
     SZS_TINY_STAMP(1);
     u32 const tiny_count = bins[tiny_rows_k + 1], long_count = bins[tiny_rows_k + 2] - tiny_count; // of the block's candidates
@@ -627,17 +631,17 @@ template <bool packed_>
 __global__ __launch_bounds__(256, 4) void levenshtein_tiny_kernel(szs_tape_t queries, szs_tape_t candidates, u32 queries_per_workgroup,
                                                                        u64 *__restrict__ results, u64 results_row_stride, u32 *unfit,
                                                                        u32 unfit_sequence, unsigned long long *symbols_out, u64 *rune_totals,
-                                                                       u64 *trace, u32 dense) {
+                                                                       u64 *squares_out, u64 *trace, u32 dense) {
     tiny_body<16, packed_>(queries, candidates, queries_per_workgroup, results, results_row_stride, unfit, unfit_sequence, symbols_out, rune_totals,
-                           trace, dense);
+                           squares_out, trace, dense);
 }
 
 } // namespace szs_hip
 
 extern "C" int szs_hip_levenshtein_tiny(szs_tape_t const *queries_tape, szs_tape_t const *candidates_tape, uint64_t *results,
                                               uint64_t results_row_stride, uint32_t *unfit, uint32_t unfit_sequence,
-                                              unsigned long long *symbols_out, uint64_t *rune_totals, uint64_t *trace,
-                                              uint64_t trace_workgroups, int dense, void *stream) {
+                                              unsigned long long *symbols_out, uint64_t *rune_totals, uint64_t *squares_out,
+                                              uint64_t *trace, uint64_t trace_workgroups, int dense, void *stream) {
     using namespace szs_hip;
     szs_tape_t const queries = *queries_tape, candidates = *candidates_tape;
     u32 const queries_count = queries.count, candidates_count = candidates.count;
@@ -660,9 +664,9 @@ extern "C" int szs_hip_levenshtein_tiny(szs_tape_t const *queries_tape, szs_tape
     if (packed != (candidates.wide == 2) || (packed && !rune_totals)) return (int)hipErrorInvalidValue;
     if (packed)
         hipLaunchKernelGGL(levenshtein_tiny_kernel<true>, dim3((u32)(blocks * spans)), dim3(256), 0, static_cast<hipStream_t>(stream), queries, candidates,
-                           (u32)per_span, results, results_row_stride, unfit, unfit_sequence, symbols_out, rune_totals, trace, dense ? 1u : 0u);
+                           (u32)per_span, results, results_row_stride, unfit, unfit_sequence, symbols_out, rune_totals, squares_out, trace, dense ? 1u : 0u);
     else
         hipLaunchKernelGGL(levenshtein_tiny_kernel<false>, dim3((u32)(blocks * spans)), dim3(256), 0, static_cast<hipStream_t>(stream), queries, candidates,
-                           (u32)per_span, results, results_row_stride, unfit, unfit_sequence, symbols_out, rune_totals, trace, dense ? 1u : 0u);
+                           (u32)per_span, results, results_row_stride, unfit, unfit_sequence, symbols_out, rune_totals, squares_out, trace, dense ? 1u : 0u);
     return (int)hipGetLastError();
 }

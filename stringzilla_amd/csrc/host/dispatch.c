@@ -271,6 +271,7 @@ static void release_device_state(szs_engine_s *engine) {
     szs_buffer_release(&engine->device_queue_trace);
     engine->queue_zeroed = NULL;
     szs_buffer_release(&engine->pinned_summary);
+    szs_buffer_release(&engine->pinned_squares);
     szs_buffer_release(&engine->device_fused);
     engine->tiny_valid = 0, engine->tiny_runes_valid = 0, engine->narrow_zeroed = NULL;
     engine->fused_zeroed = NULL;
@@ -1057,7 +1058,8 @@ static sz_status_t reserve_device_words(szs_engine_s *engine, int device, hipStr
 /** Tiny tokens on both sides, enough of them to fill the device - or whatever the `tiny` knob says. */
 static int tiny_shaped(szs_engine_s const *engine, int symmetric, szs_side_stats_t const *queries, szs_side_stats_t const *candidates) {
     int const knob = szs_tuning_get(szs_knob_tiny_k);
-    if (symmetric || !engine->is_unit_cost || knob == 0) return 0;
+    if (!engine->is_unit_cost || knob == 0) return 0;
+    if (symmetric) candidates = queries; /* (round 6: one tape against itself - the launch scores the whole square, both triangles) */
     if (engine->family != szs_family_levenshtein_k && engine->family != szs_family_levenshtein_utf8_k /* an ASCII corpus */) return 0;
     /* a string beyond that launch's 255 bytes (an occasional long line among the words: the planner's summary knows the longest) - the
      * launch would refuse the call after scoring most of it, every call again */
@@ -1093,9 +1095,23 @@ static sz_status_t cross_tiny(szs_call_t *call, uint32_t planner_mode, szs_plan_
     *unfit = 0, symbols[0] = symbols[1] = 0;
     phase(call, 2);
     szs_tape_t q_tape = {call->queries->offsets, (uint64_t)(uintptr_t)call->queries->data, call->q_count, call->queries->kind == szs_input_u64tape_k};
-    szs_tape_t c_tape = {call->candidates->offsets, (uint64_t)(uintptr_t)call->candidates->data, call->c_count,
-                         call->candidates->kind == szs_input_u64tape_k};
+    szs_tape_t c_tape = q_tape; /* a symmetric call: the one tape against itself, the whole square (what the ordinary path leaves too) */
+    if (!call->symmetric) {
+        szs_tape_t const other = {call->candidates->offsets, (uint64_t)(uintptr_t)call->candidates->data, call->c_count,
+                                  call->candidates->kind == szs_input_u64tape_k};
+        c_tape = other;
+    }
     uint32_t launches = 0;
+    /* ... and the cells of its lower triangle are ((sum len)^2 + sum len^2) / 2: the launch leaves a partial sum of squares per block of
+     * 256 strings in pinned memory */
+    size_t const square_blocks = call->symmetric ? ((size_t)call->c_count + 255) / 256 : 0;
+    uint64_t volatile *squares = NULL;
+    if (square_blocks) {
+        sz_status_t const reserved = szs_buffer_reserve(&engine->pinned_squares, szs_memory_pinned_k, call->device, square_blocks * sizeof(uint64_t), call->error_message);
+        if (reserved != sz_success_k) return reserved;
+        squares = (uint64_t volatile *)engine->pinned_squares.pointer;
+        for (size_t b = 0; b < square_blocks; ++b) squares[b] = 0;
+    }
     /* The codepoint engine (round 6; reference: cuda.cuh:3294): one pass ahead of the launch turns both UTF-8 tapes into byte strings of
      * rune ids (hip/utf8.hip: utf8_narrow_kernel) in a buffer of the engine's, and the launch scores THOSE - no transcoding to UTF-32,
      * no renumbering passes, no planner.  Device staging (cross_device_planned_runes reserved it): a word per string. */
@@ -1119,18 +1135,20 @@ static sz_status_t cross_tiny(szs_call_t *call, uint32_t planner_mode, szs_plan_
             error = hipMemsetAsync(narrow_workspace, 0, SZS_NARROW_WORKSPACE, stream);
             engine->narrow_zeroed = error == hipSuccess ? (void *)narrow_workspace : NULL;
         }
+        szs_tape_t narrowed_too = c_tape;
+        if (call->symmetric) narrowed_too.count = 0; /* (the one tape is narrowed once) */
         if (error == hipSuccess)
-            error = (hipError_t)szs_hip_utf8_narrow(&q_tape, &c_tape, narrow_strings, engine->device_narrow.capacity - SZS_NARROW_WORKSPACE, entries,
+            error = (hipError_t)szs_hip_utf8_narrow(&q_tape, &narrowed_too, narrow_strings, engine->device_narrow.capacity - SZS_NARROW_WORKSPACE, entries,
                                                     narrow_workspace, (uint32_t *)unfit, sequence, stream);
         launches += error == hipSuccess;
         szs_tape_t const q_narrow = {entries, (uint64_t)(uintptr_t)narrow_strings, call->q_count, 2};
         szs_tape_t const c_narrow = {entries + call->q_count, (uint64_t)(uintptr_t)narrow_strings, call->c_count, 2};
-        q_tape = q_narrow, c_tape = c_narrow;
+        q_tape = q_narrow, c_tape = call->symmetric ? q_narrow : c_narrow;
     }
     if (error == hipSuccess) {
         error = (hipError_t)szs_hip_levenshtein_tiny(&q_tape, &c_tape, (uint64_t *)call->device_results, call->device_stride, (uint32_t *)unfit, sequence,
                                                            (unsigned long long *)symbols,
-                                                           runes ? (uint64_t *)(narrow_workspace + SZS_NARROW_SLOTS * sizeof(uint32_t)) : NULL, trace,
+                                                           runes ? (uint64_t *)(narrow_workspace + SZS_NARROW_SLOTS * sizeof(uint32_t)) : NULL, (uint64_t *)squares, trace,
                                                            trace_workgroups, szs_tuning_get(szs_knob_tiny_k) == 2, stream);
         launches += error == hipSuccess;
     }
@@ -1199,12 +1217,19 @@ static sz_status_t cross_tiny(szs_call_t *call, uint32_t planner_mode, szs_plan_
     profile->cells = q_symbols * c_symbols;
     profile->algorithmic_bytes = (uint64_t)call->c_count * q_symbols + (uint64_t)call->q_count * c_symbols + profile->pairs * 16;
     profile->unique_bytes += q_symbols + c_symbols;
+    if (call->symmetric) { /* (the conventions of complete_from_summary) */
+        uint64_t sum_of_squares = 0;
+        for (size_t b = 0; b < square_blocks; ++b) sum_of_squares += squares[b];
+        profile->cells = (q_symbols * q_symbols + sum_of_squares) / 2;
+        profile->algorithmic_bytes = ((uint64_t)call->q_count + 1) * q_symbols + profile->pairs * 16;
+        profile->unique_bytes -= c_symbols;
+    }
     /* the next call of these counts comes straight here - as long as the batch keeps looking like tiny tokens */
     szs_side_stats_t now[2];
     memset(now, 0, sizeof(now));
     now[0].count = call->q_count, now[0].symbols = q_symbols, now[1].count = call->c_count, now[1].symbols = c_symbols;
-    if (runes) engine->tiny_runes_valid = tiny_shaped(engine, 0, &now[0], &now[1]), engine->tiny_runes_q_count = call->q_count, engine->tiny_runes_c_count = call->c_count;
-    else engine->tiny_valid = tiny_shaped(engine, 0, &now[0], &now[1]), engine->tiny_q_count = call->q_count, engine->tiny_c_count = call->c_count;
+    if (runes) engine->tiny_runes_valid = tiny_shaped(engine, call->symmetric, &now[0], &now[1]), engine->tiny_runes_q_count = call->q_count, engine->tiny_runes_c_count = call->c_count;
+    else engine->tiny_valid = tiny_shaped(engine, call->symmetric, &now[0], &now[1]), engine->tiny_q_count = call->q_count, engine->tiny_c_count = call->c_count;
     if (engine->remembered) engine->remembered->refs_current = 0, engine->remembered->valid = 0; /* another kind of call came between */
     return szs_report(sz_success_k, call->error_message, NULL);
 }
@@ -1567,7 +1592,7 @@ static sz_status_t cross_device_planned(szs_call_t *call) {
 
     /* ---- way 5, tiny tokens (hip/myers_tiny.hip): the previous call of these counts was scored straight from the tapes - so is this
      * one, with no planner at all; the kernel says when a query does not fit it */
-    if (engine->tiny_valid && !symmetric && engine->tiny_q_count == q_count && engine->tiny_c_count == c_count && way.use_myers &&
+    if (engine->tiny_valid && engine->tiny_q_count == q_count && engine->tiny_c_count == c_count && way.use_myers &&
         szs_tuning_get(szs_knob_tiny_k) != 0 && szs_tuning_get(szs_knob_speculate_k) != 0 && szs_tuning_get(szs_knob_tier_k) < 0 &&
         szs_tuning_get(szs_knob_swap_k) < 0 && szs_tuning_get(szs_knob_queue_k) < 0) {
         status = cross_tiny(call, 5, NULL, 0);
@@ -1713,7 +1738,7 @@ static sz_status_t cross_device_planned_runes(szs_call_t *call) {
      * narrowed, an ASCII batch is its own bytes, 13 us instead of that front end) */
     int const words_before = (engine->tiny_runes_valid && engine->tiny_runes_q_count == q_count && engine->tiny_runes_c_count == c_count) ||
                              (engine->tiny_valid && engine->tiny_q_count == q_count && engine->tiny_c_count == c_count);
-    if (words_before && engine->runes_needed && !symmetric && engine->is_unit_cost && szs_tuning_get(szs_knob_tiny_k) != 0 &&
+    if (words_before && engine->runes_needed && engine->is_unit_cost && szs_tuning_get(szs_knob_tiny_k) != 0 &&
         szs_tuning_get(szs_knob_speculate_k) != 0 && szs_tuning_get(szs_knob_tier_k) < 0) {
         size_t const narrow_before = engine->device_narrow.capacity;
         status = szs_buffer_reserve(&engine->device_narrow, szs_memory_device_k, device, (size_t)(engine->runes_needed + engine->runes_needed / 4) + 64 + SZS_NARROW_WORKSPACE, error_message);

@@ -140,6 +140,7 @@ typedef struct szs_engine_s {
     /* device-side planning (hip/planner.hip) */
     szs_buffer_t device_plan_refs; /* device: ascending + descending refs of both sides */
     szs_buffer_t pinned_summary;   /* pinned: the planner's szs_plan_summary_t */
+    szs_buffer_t pinned_squares;   /* pinned: a symmetric tiny-token call's sums of squared lengths, one per block of 256 strings */
     uint32_t plan_sequence;        /* echoed by the planner: tells this call's summary from a stale one */
     struct szs_decision_t *remembered; /* the launch shape of the previous device-planned call (speculation), or NULL */
 

@@ -622,3 +622,38 @@ def test_codepoint_strings_the_wavefront_decodes(gpu, oracle):
             expected = oracle.levenshtein_utf8(queries, candidates)
             assert np.array_equal(got, expected), (batch, np.argwhere(got != expected)[:5].tolist())
             assert engine.last_call_profile().planner == (5 if batch else 1) and engine.last_call_profile().launches == 2
+
+
+@pytest.mark.parametrize("family", ["bytes", "codepoints"])
+def test_symmetric_calls_of_words(gpu, oracle, family):
+    """One tape against itself through the tiny-token launch: the whole square (both triangles, a zero diagonal - what the ordinary
+    path leaves, test/similarities.cuh:1259-1264), the profile's cells those of the lower triangle."""
+    rng = random.Random(17)
+    letters = list("etaoinshrdlu") + (list("éüßдж中") if family == "codepoints" else [])
+    word = lambda: "".join(rng.choice(letters) for _ in range(rng.choice([0, 1, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 9, 10, 11, 12, 14, 16, 16, 40]))).encode()
+    engine = (szs.LevenshteinDistancesUTF8 if family == "codepoints" else szs.LevenshteinDistances)(capabilities=gpu)
+    check = oracle.levenshtein_utf8 if family == "codepoints" else oracle.levenshtein
+    modes = []
+    for batch in range(3):
+        strings = [word() for _ in range(1100)]
+        got = engine(strings, device=gpu)
+        assert np.array_equal(got, check(strings, strings)), batch
+        assert np.array_equal(got, got.T) and not np.diagonal(got).any()
+        profile = engine.last_call_profile()
+        lengths = np.array([_rune_count(s) if family == "codepoints" else len(s) for s in strings], dtype=np.int64)
+        assert profile.cells == (int(lengths.sum()) ** 2 + int((lengths ** 2).sum())) // 2, batch
+        modes.append(int(profile.planner))
+    assert modes == [1, 5, 5], modes
+    # a cross call of the same counts right behind it, and a padded matrix
+    import torch
+
+    queries, candidates = [word() for _ in range(1100)], [word() for _ in range(1100)]
+    assert np.array_equal(engine(queries, candidates, device=gpu), check(queries, candidates))
+    strings = szs.Strs([word() for _ in range(300)], wide_offsets=True)
+    out = torch.full((300, 320), -1, dtype=torch.int64, device="cuda:0")
+    torch.cuda.synchronize()
+    with knob("tiny", 1):
+        engine(strings, device=gpu, out=out[:, :300])
+    listed = [strings[i] for i in range(300)]
+    assert np.array_equal(out[:, :300].cpu().numpy().view(np.uint64), check(listed, listed)) and (out[:, 300:] == -1).all()
+    assert engine.last_call_profile().planner in (1, 5)
