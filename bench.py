@@ -470,8 +470,8 @@ def measure_extra(config, scope, device_index, args, fence, with_cpu):
         "results_checksum": int(results.sum().item()),
         "roofline": roofline(config, profile, kernel),
     }
-    if config == 10:
-        # Tiny tokens: the one regime of this path where HBM is the roofline that binds - the RESULT MATRIX (8 bytes a pair against
+    if config in (10, 12):
+        # Tiny tokens (12: at the codepoint level, one pass ahead of the launch writes the strings as bytes of rune ids): the one regime of this path where HBM is the roofline that binds - the RESULT MATRIX (8 bytes a pair against
         # ~13 bytes of strings per pair-row).  Algorithmic bytes here = results + both tapes + their offsets, once each.
         bytes_moved = len(queries) * len(candidates) * 8 + int(load.queries.lengths().sum() + load.candidates.lengths().sum()) + 4 * (len(queries) + len(candidates) + 2)
         record["roofline"] = words_roofline(record["roofline"], bytes_moved, kernel, int(profile.launches), int(profile.planner), _profile_json("valu_peak.json")[0])
@@ -814,7 +814,7 @@ def main():
     # of NW / SW scoring the clocks are where a busy GPU keeps them.  The headline itself is unchanged: W untimed steps, then
     # exactly K timed ones.  (The single-process C driver of N > 1 runs last, while the other ranks wait.)
     if args.extra_configs is None:
-        extras = [9, 3, 4, 5, 6, 7, 8, 10] if not distributed else [2, 4, 5]  # N > 1: the metric's own batch and the two 8-GPU configs, STRONG-scaled
+        extras = [9, 3, 4, 5, 6, 7, 8, 10, 12] if not distributed else [2, 4, 5]  # N > 1: the metric's own batch and the two 8-GPU configs, STRONG-scaled
     else:
         extras = [] if args.extra_configs.strip().lower() in ("", "none") else [int(x) for x in args.extra_configs.split(",")]
     records = []

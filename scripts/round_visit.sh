@@ -9,7 +9,7 @@ ROUND=${1:-04}; TAG=${2:-r${ROUND}_final}
 OUT=gpurun_out/$TAG; mkdir -p "$OUT" "profiles/r$ROUND"
 timeout 1500 python -m pytest tests -m gpu -q --durations=5 > "$OUT/gpu_tests.txt" 2>&1; tail -4 "$OUT/gpu_tests.txt"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > "$OUT/smoke.txt" 2>&1; tail -2 "$OUT/smoke.txt"
-bash scripts/profile_configs.sh "${TAG}_pmc" 2 9 3 4 5 6 7 8 10 11 > "$OUT/pmc.log" 2>&1; tail -2 "$OUT/pmc.log"
+bash scripts/profile_configs.sh "${TAG}_pmc" 2 9 3 4 5 6 7 8 10 12 11 > "$OUT/pmc.log" 2>&1; tail -2 "$OUT/pmc.log"
 cp "gpurun_out/${TAG}_pmc/pmc_configs.json" "profiles/r$ROUND/pmc_configs.json"
 timeout 900 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"; tail -c 300 "$OUT/bench_default.json"
 timeout 600 python bench.py --steps 20 --warmup 5 > "$OUT/bench_20.json" 2> "$OUT/bench_20.err"

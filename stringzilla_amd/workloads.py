@@ -154,6 +154,22 @@ def config(index: int, scale: float = 1.0, generator: str = "numpy") -> Workload
             return Strs.from_tape(letters[rng.choice(len(letters), size=int(offsets[-1]), p=weights / weights.sum())], offsets)
         return Workload("words: 4096x4096 word-like tokens (mean 6.6 bytes, 4 % of 17-48), Levenshtein unit", "levenshtein",
                         words(side(4096)), words(side(4096)), dict(match=0, mismatch=1, open=1, extend=1))
+    if index == 12:  # config 10's words at the CODEPOINT level: the same lengths in runes, one letter in twelve an accented or Cyrillic one
+        # (two bytes of UTF-8) - through `szs_levenshtein_distances_utf8_*`, the regime of the reference's per-thread kernel for short
+        # runes (cuda.cuh:3294)
+        rng = np.random.default_rng(12)
+        plain, accented = "etaoinshrdlcumwfgypbvkjxqz", "éèüöäßñçåøæîôдежзиклмноп"
+        def words(count):
+            lengths = np.clip(rng.poisson(4.6, size=count) + 1, 1, 16)
+            long_ones = rng.random(count) < 0.04
+            lengths[long_ones] = rng.integers(17, 49, size=int(long_ones.sum()))
+            total = int(lengths.sum())
+            runes = np.where(rng.random(total) < 1 / 12, np.array(list(accented))[rng.integers(0, len(accented), size=total)],
+                             np.array(list(plain))[rng.integers(0, len(plain), size=total)])
+            ends = np.cumsum(lengths)
+            return Strs(["".join(runes[end - length:end]).encode() for end, length in zip(ends, lengths)])
+        return Workload("wordsu: 4096x4096 word-like tokens (mean 6.6 runes, 1 in 12 of two bytes), codepoint-level Levenshtein unit",
+                        "levenshtein_utf8", words(side(4096)), words(side(4096)), dict(match=0, mismatch=1, open=1, extend=1))
     if index in (7, 8):  # config 2's batch under NON-UNIT costs (a north_star function: szs_levenshtein_distances_init takes all four):
         rng = np.random.default_rng(2)  # 7: linear gaps, match 1 / mismatch 3 / gap 3; 8: affine gaps, mismatch 1 / open 4 / extend 2
         costs = dict(match=1, mismatch=3, open=3, extend=3) if index == 7 else dict(match=0, mismatch=1, open=4, extend=2)
