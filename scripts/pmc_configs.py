@@ -89,7 +89,9 @@ for directory in sorted(glob.glob(os.path.join(root, "cfg*"))):
         # the steady call are the ones launched at least half as often as the most frequent one; the launches one steady call
         # makes (the bench line's `launches_per_step`) are dealt over them in proportion.
         most = max([entry.get("_calls", 0) for entry in scoring.values()] + [1])
-        steady = {name: entry.get("_calls", 0) / most for name, entry in scoring.items() if entry.get("_calls", 0) * 2 >= most}
+        # (... or at least once per timed call: config 2's run times 400 calls on the same tapes beside its 55 fresh batches)
+        steady = {name: entry.get("_calls", 0) / most for name, entry in scoring.items()
+                  if entry.get("_calls", 0) * 2 >= most or entry.get("_calls", 0) >= calls}
         weight = sum(steady.values()) or 1.0
         for name, entry in scoring.items():
             per_call = steady.get(name, 0.0) / weight * launches_per_call
