@@ -338,6 +338,7 @@ __global__ __launch_bounds__(64) void utf8_narrow_kernel(szs_tape_t queries, szs
     u64 const c_base = q_last >= q_first ? ((q_last - q_first + 15) & ~(u64)15) + 16 : 0;
     if (q_last < q_first || c_last < c_first || c_base + (c_last - c_first) + 16 > capacity) { // (+ 16: the byte kernel reads whole dwords)
         if (threadIdx.x == 0) *unfit = unfit_sequence;
+        if (i < strings) entries[i] = 0; // (the scoring launch is already behind this one: it finds empty strings, not what the memory held)
         return;
     }
     bool const mine = i < strings, of_candidates = mine && i >= queries.count;

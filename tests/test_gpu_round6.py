@@ -657,3 +657,23 @@ def test_symmetric_calls_of_words(gpu, oracle, family):
     listed = [strings[i] for i in range(300)]
     assert np.array_equal(out[:, :300].cpu().numpy().view(np.uint64), check(listed, listed)) and (out[:, 300:] == -1).all()
     assert engine.last_call_profile().planner in (1, 5)
+
+
+def test_a_batch_beyond_the_narrow_buffer_is_scored_the_ordinary_way(gpu, oracle):
+    """Words, then the same counts of strings forty times their size: the pass that writes them as bytes has a buffer sized by the
+    words, says so before it touches a string, and the call is transcoded, planned and scored as codepoint calls were before;
+    descending offsets under those counts are reported, not scored."""
+    rng = random.Random(123)
+    letters = list("etaoin") + list("éд😀")
+    word = lambda low, high: "".join(rng.choice(letters) for _ in range(rng.randint(low, high))).encode()
+    engine = szs.LevenshteinDistancesUTF8(capabilities=gpu)
+    with knob("tiny", 1):
+        for batch in range(2):
+            queries, candidates = [word(0, 9) for _ in range(70)], [word(0, 9) for _ in range(520)]
+            assert np.array_equal(engine(queries, candidates, device=gpu), oracle.levenshtein_utf8(queries, candidates))
+        assert engine.last_call_profile().planner == 5
+        queries, candidates = [word(150, 250) for _ in range(70)], [word(150, 250) for _ in range(520)]
+        assert np.array_equal(engine(queries, candidates, device=gpu), oracle.levenshtein_utf8(queries, candidates))
+        assert engine.last_call_profile().planner != 5
+        queries, candidates = [word(0, 9) for _ in range(70)], [word(0, 9) for _ in range(520)]
+        assert np.array_equal(engine(queries, candidates, device=gpu), oracle.levenshtein_utf8(queries, candidates))
