@@ -19,7 +19,7 @@
  *  Every failure after the first enqueue leaves through one exit that drains the stream first: the call is synchronous
  *  also when it fails, so the caller may free its buffers the moment it returns.
  */
-#include "szs_internal.h"
+#include "dispatch_internal.h"
 
 #include <dlfcn.h>
 #include <pthread.h>
@@ -334,7 +334,7 @@ static unsigned team_shape_for(int affine, uint32_t classes, szs_side_stats_t co
     return 0;
 }
 
-static sz_status_t decide(szs_engine_s const *engine, int symmetric, int runes, int force_lanes, szs_side_stats_t const *q_stats,
+sz_status_t szs_call_decide(szs_engine_s const *engine, int symmetric, int runes, int force_lanes, szs_side_stats_t const *q_stats,
                           szs_side_stats_t const *c_stats, uint32_t const *q_variants, uint32_t const *c_variants,
                           uint32_t const (*ranks)[SZS_PLAN_RANK_SAMPLES + 1] /* the caller's sides, or NULL: not known yet */,
                           uint64_t cells, szs_decision_t *d, char const **error_message) {
@@ -451,7 +451,7 @@ static sz_status_t decide(szs_engine_s const *engine, int symmetric, int runes, 
  *  length class that merely straddles two or three widths keeps its launches: its work items would all be alike, a handful
  *  per workgroup, and the last round of them runs the device half empty (1024 x 1024 x 500 bytes: 112 against 90 TCUPS).
  */
-static void decide_queue(szs_engine_s const *engine, szs_decision_t *d, uint32_t const (*ranks)[SZS_PLAN_RANK_SAMPLES + 1]) {
+void szs_call_decide_queue(szs_engine_s const *engine, szs_decision_t *d, uint32_t const (*ranks)[SZS_PLAN_RANK_SAMPLES + 1]) {
     int const queue_knob = szs_tuning_get(szs_knob_queue_k);
     unsigned bit_parallel_groups = 0;
     for (unsigned g = 0; g < d->plan.groups_count; ++g) bit_parallel_groups += d->plan.groups[g].variant != 0;
@@ -467,7 +467,7 @@ static void decide_queue(szs_engine_s const *engine, szs_decision_t *d, uint32_t
 }
 
 /** Does the lanes tier of this decision run a kernel that reads the cost model / the weighted strip workspace? */
-static int has_group_of_variant_zero(szs_decision_t const *d) {
+int szs_decision_has_variant_zero(szs_decision_t const *d) {
     for (unsigned g = 0; g < d->plan.groups_count; ++g)
         if (d->plan.groups[g].variant == 0) return 1;
     return 0;
@@ -479,7 +479,7 @@ static int has_group_of_variant_zero(szs_decision_t const *d) {
  *  launch (an eighth of config 5: 1.610 ms planned, 1.612 speculated; codepoints 1.061 / 1.049) - the planner's own 35 - 45 us for
  *  3,500 strings are what such a call waits for, not the host.  (Several launches released by one event reach the device in no
  *  particular order: those calls are planned and waited for as well.) */
-static int is_one_launch(szs_decision_t const *d) { return d->plan.groups_count == 1; }
+int szs_decision_is_one_launch(szs_decision_t const *d) { return d->plan.groups_count == 1; }
 
 static sz_status_t upload_model(szs_engine_s *engine, szs_decision_t const *d, int device, hipStream_t stream,
                                 char const **error_message) {
@@ -510,7 +510,7 @@ static size_t weighted_boundary_bytes(szs_engine_s const *engine, szs_decision_t
  *  queries parks 0.25 B per column and lane where the weighted kernels park 4, so a unit-cost call over 100 KB strings
  *  reserves ~5 GB, not ~77.
  */
-static sz_status_t prepare(szs_engine_s *engine, szs_decision_t const *d, int device, hipStream_t stream, char const **error_message) {
+sz_status_t szs_call_prepare(szs_engine_s *engine, szs_decision_t const *d, int device, hipStream_t stream, char const **error_message) {
     sz_status_t status = sz_success_k;
     hipError_t error = hipSuccess;
     int const chained = d->tier == SZS_TIER_SYSTOLIC || d->tier == SZS_TIER_MYERS_CHAIN;
@@ -548,7 +548,7 @@ static sz_status_t prepare(szs_engine_s *engine, szs_decision_t const *d, int de
             engine->queue_zeroed = engine->device_queue.pointer, engine->queue_tickets = 0;
         }
     }
-    int const variant_zero = has_group_of_variant_zero(d);
+    int const variant_zero = szs_decision_has_variant_zero(d);
     size_t boundary_bytes = 0;
     if (d->use_myers && d->runes && variant_zero) /* codepoint queries beyond 2048 runes: the strip kernel's parked deltas */
         boundary_bytes = szs_hip_levenshtein_myers_banded_runes_bytes(d->kq_count, d->kc_count, d->plan.longest_candidate);
@@ -591,7 +591,7 @@ static hipError_t szs_aux_streams(int device, unsigned wanted, hipStream_t *stre
 }
 
 /** Launches of one decision over device refs in kernel roles.  Returns the first launch error; counts launches. */
-static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int device, szs_string_ref_t const *query_refs,
+hipError_t szs_call_enqueue(szs_engine_s *engine, szs_decision_t const *d, int device, szs_string_ref_t const *query_refs,
                           szs_string_ref_t const *candidate_refs, void *device_results, size_t device_stride, hipStream_t stream,
                           szs_ref_guard_t const *guard /* refs of an earlier call: validate in the kernels; else NULL */,
                           uint32_t *launches, uint32_t *cell_bits, sz_status_t *status, char const **error_message) {
@@ -765,7 +765,7 @@ static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int dev
     }
     if (queued && !launch_error && *status == sz_success_k) {
         uint32_t taken = 0;
-        uint64_t *trace = NULL; /* `trace` knob: where every workgroup's begin / end ticks go (finish() prints their spread) */
+        uint64_t *trace = NULL; /* `trace` knob: where every workgroup's begin / end ticks go (szs_call_finish() prints their spread) */
         if (szs_tuning_get(szs_knob_trace_k) > 0 &&
             szs_buffer_reserve(&engine->device_queue_trace, szs_memory_device_k, device,
                                7 * sizeof(uint64_t) * (size_t)szs_hip_levenshtein_myers_queue_grid(d->queue.items_total, d->runes), NULL) == sz_success_k)
@@ -794,23 +794,7 @@ static hipError_t enqueue(szs_engine_s *engine, szs_decision_t const *d, int dev
 
 /* ---- one call ---------------------------------------------------------------------------------------------------------- */
 
-typedef struct szs_call_t {
-    szs_engine_s *engine;
-    int device;
-    hipStream_t stream;
-    szs_input_t const *queries, *candidates;
-    int symmetric;
-    uint32_t q_count, c_count;
-    void *results;
-    size_t results_row_stride;
-    int direct; /* kernels write the caller's matrix in place */
-    void *device_results;
-    size_t device_stride;
-    double started, phase_started, phases[6];
-    int trace;
-    int ranges; /* roctx ranges currently open for this call: 0, 1 (the call) or 2 (the call and a phase) */
-    char const **error_message;
-} szs_call_t;
+/* (szs_call_t: dispatch_internal.h) */
 
 /* ---- roctx ranges (`roctx` knob): the host phases of a call as nested ranges a `rocprofv3 --marker-trace` timeline shows
  *      next to the kernels - the counterpart of the reference's NVTX-free but timer-instrumented executors.
@@ -850,7 +834,7 @@ static void ranges_end(szs_call_t *call) {
 }
 
 /** The END of phase `index`: accounts its time (`trace` knob) and opens the next phase's range (`roctx` knob). */
-static void phase(szs_call_t *call, int index) {
+void szs_call_phase(szs_call_t *call, int index) {
     if (call->ranges == 2) {
         (void)roctx.pop();
         if (index + 1 < 6) (void)roctx.push(phase_names[index + 1]);
@@ -863,7 +847,7 @@ static void phase(szs_call_t *call, int index) {
 
 /** Everything after the last launch: stop event, stall flag, copy-out, THE wait, profile.  `enqueued` failures and every
  *  failure in here drain the stream before the status leaves the library. */
-static sz_status_t finish(szs_call_t *call, szs_decision_t const *d, hipError_t error, sz_status_t status, uint32_t launches,
+sz_status_t szs_call_finish(szs_call_t *call, szs_decision_t const *d, hipError_t error, sz_status_t status, uint32_t launches,
                           uint32_t cell_bits, uint64_t query_symbols, uint64_t candidate_symbols, int *stalled) {
     szs_engine_s *engine = call->engine;
     hipStream_t const stream = call->stream;
@@ -878,16 +862,16 @@ static sz_status_t finish(szs_call_t *call, szs_decision_t const *d, hipError_t 
         error = hipMemcpy2DAsync(call->results, call->results_row_stride * sizeof(uint64_t), call->device_results,
                                  call->device_stride * sizeof(uint64_t), (size_t)call->c_count * sizeof(uint64_t), call->q_count,
                                  hipMemcpyDefault, stream);
-    phase(call, 3); /* launches enqueued */
+    szs_call_phase(call, 3); /* launches enqueued */
     hipError_t const drained = hipStreamSynchronize(stream); /* the call is synchronous, like the reference's - also when it fails */
     /* (Round 6, measured and not kept: polling the stop event from the calling thread before blocking - config 2's call 193.9 us
      * either way, host overhead 14.0 against 13.6: the runtime's own wait already spins.  profiles/r06/wait_polling.txt) */
-    phase(call, 4); /* waiting for the device */
+    szs_call_phase(call, 4); /* waiting for the device */
     if (status != sz_success_k || error != hipSuccess || drained != hipSuccess)
         engine->queue_zeroed = NULL, /* the host's mirror of the queue kernel's ticket counter may no longer match the device's (a launch
-                                        counted but never run, or run but reported failed): prepare() zeroes both before the next one */
+                                        counted but never run, or run but reported failed): szs_call_prepare() zeroes both before the next one */
             engine->fused_zeroed = NULL; /* ... and so may the planner's verdict counter (its parity elects the side that folds the two
-                                            verdicts) and the `ready` words: reserve_device_words() zeroes the 256 bytes again */
+                                            verdicts) and the `ready` words: szs_call_reserve_device_words() zeroes the 256 bytes again */
     if (status != sz_success_k) return status;
     if (error == hipSuccess) error = drained;
     if (error != hipSuccess) return szs_report_hip(error, call->error_message);
@@ -919,7 +903,7 @@ static sz_status_t finish(szs_call_t *call, szs_decision_t const *d, hipError_t 
     engine->last_queued = 0;
     profile->longest_query = d->longest[0], profile->longest_candidate = d->longest[1];
     profile->host_milliseconds = now_milliseconds() - call->started;
-    phase(call, 5);
+    szs_call_phase(call, 5);
 #ifdef SZS_PLAN_TIMESTAMPS
     if (call->trace) {
         unsigned long long const *stamps = (unsigned long long const *)engine->pinned_summary.pointer + 56;
@@ -1002,7 +986,7 @@ static sz_status_t finish(szs_call_t *call, szs_decision_t const *d, hipError_t 
  *  kernel at all, and unified / pinned memory only across the host link, 8 scattered bytes at a time (measured on
  *  config 2: 0.90 ms instead of 0.22 ms of kernel time) - those are staged densely in HBM and copied out in one
  *  piece, unless the matrix is so small that the extra copy costs more than it saves. */
-static sz_status_t place_results(szs_call_t *call) {
+sz_status_t szs_call_place_results(szs_call_t *call) {
     szs_engine_s *engine = call->engine;
     szs_pointer_traits_t const traits = szs_classify_pointer(call->results);
     size_t const matrix_bytes = (size_t)call->q_count * call->c_count * sizeof(uint64_t);
@@ -1018,7 +1002,7 @@ static sz_status_t place_results(szs_call_t *call) {
 /* ---- device-planned calls ---------------------------------------------------------------------------------------------- */
 
 /** The refs on the device are the complete plan of exactly these tapes: remember what they were planned from. */
-static void stamp_refs(szs_decision_t *remembered, void const *const data[2], void const *const offsets[2], int const wide[2],
+void szs_call_stamp_refs(szs_decision_t *remembered, void const *const data[2], void const *const offsets[2], int const wide[2],
                        szs_plan_summary_t const *summary) {
     for (int s = 0; s < 2; ++s) remembered->key_data[s] = data[s], remembered->key_offsets[s] = offsets[s], remembered->key_wide[s] = wide[s];
     remembered->summary = *summary;
@@ -1028,7 +1012,6 @@ static void stamp_refs(szs_decision_t *remembered, void const *const data[2], vo
 }
 
 #define SZS_PLAN_DEVICE_MOST_STRINGS (1u << 18) /* per side; one workgroup plans, so larger batches go to the host planner */
-#define SZS_NOT_DEVICE_PLANNABLE ((sz_status_t)1) /* internal: take the host-planned path instead */
 
 static int device_plannable(szs_engine_s const *engine, szs_input_t const *input) {
     if (input->kind == szs_input_sequence_k || !input->offsets || !input->data) return 0;
@@ -1039,7 +1022,7 @@ static int device_plannable(szs_engine_s const *engine, szs_input_t const *input
 
 /** 256 bytes of device memory per engine, zeroed when allocated and never again: the two `ready` words of the launch that plans
  *  itself (dwords 0 and 32; kernels.h: szs_fused_plan_t) and the verdict words of the two-workgroup planner (dwords 48 ... 55). */
-static sz_status_t reserve_device_words(szs_engine_s *engine, int device, hipStream_t stream, char const **error_message) {
+sz_status_t szs_call_reserve_device_words(szs_engine_s *engine, int device, hipStream_t stream, char const **error_message) {
     sz_status_t const status = szs_buffer_reserve(&engine->device_fused, szs_memory_device_k, device, 256, error_message);
     if (status != sz_success_k) return status;
     if (engine->fused_zeroed != engine->device_fused.pointer) {
@@ -1048,876 +1031,6 @@ static sz_status_t reserve_device_words(szs_engine_s *engine, int device, hipStr
         engine->fused_zeroed = engine->device_fused.pointer;
     }
     return sz_success_k;
-}
-#define SZS_PLAN_VERDICTS(ENGINE) ((uint32_t *)(ENGINE)->device_fused.pointer + 48)
-
-/* ---- the tiny-token regime (hip/myers_tiny.hip; reference: cuda.cuh:2864, :4297-4340) ------------------------------------- */
-
-#define SZS_TINY_NOT_TAKEN ((sz_status_t)3) /* internal: score the call the ordinary way */
-
-/** Tiny tokens on both sides, enough of them to fill the device - or whatever the `tiny` knob says. */
-static int tiny_shaped(szs_engine_s const *engine, int symmetric, szs_side_stats_t const *queries, szs_side_stats_t const *candidates) {
-    int const knob = szs_tuning_get(szs_knob_tiny_k);
-    if (!engine->is_unit_cost || knob == 0) return 0;
-    if (symmetric) candidates = queries; /* (round 6: one tape against itself - the launch scores the whole square, both triangles) */
-    if (engine->family != szs_family_levenshtein_k && engine->family != szs_family_levenshtein_utf8_k /* an ASCII corpus */) return 0;
-    /* a string beyond that launch's 255 bytes (an occasional long line among the words: the planner's summary knows the longest) - the
-     * launch would refuse the call after scoring most of it, every call again */
-    if (queries->longest > SZS_TINY_LONGEST || candidates->longest > SZS_TINY_LONGEST) return 0;
-    if (knob > 0) return 1;
-    /* word-like: mean length well under the sixteen rows of that kernel's bit-vectors (what is longer - a few per cent of a text's
-     * tokens - rides along in the same launch; the kernel itself says when a string is beyond it) and a matrix worth a launch */
-    return queries->symbols <= 10ull * queries->count && candidates->symbols <= 10ull * candidates->count && queries->count >= 64 &&
-           candidates->count >= 1024 && (uint64_t)queries->count * candidates->count >= (1ull << 20);
-}
-
-/** The tiny-token kernel refused a recent batch of these counts (cross_tiny): the next sixteen such calls do not try it again. */
-static int tiny_recently_refused(szs_engine_s *engine, uint32_t q_count, uint32_t c_count, int count_down) {
-    if (engine->tiny_refused <= 0 || engine->tiny_q_count != q_count || engine->tiny_c_count != c_count) return 0;
-    if (szs_tuning_get(szs_knob_tiny_k) >= 0) return 0; /* a pinned knob is obeyed every time */
-    if (count_down) --engine->tiny_refused;
-    return 1;
-}
-
-/**
- *  One launch of the tiny-token kernel, straight from the caller's tapes, and the call's wait.  sz_success_k: scored.
- *  SZS_TINY_NOT_TAKEN: the kernel met a string beyond 255 bytes or malformed offsets - nothing it wrote counts, the caller goes on
- *  to the ordinary path (which also reports malformed tapes).  `planner_mode`: 1 when a planner's summary chose this kernel, 5 when
- *  the previous call of the engine did and nothing was planned at all.
- */
-static sz_status_t cross_tiny(szs_call_t *call, uint32_t planner_mode, szs_plan_summary_t const *seen /* or NULL */, int runes) {
-    szs_engine_s *engine = call->engine;
-    hipStream_t const stream = call->stream;
-    uint32_t volatile *const unfit = (uint32_t volatile *)((char *)engine->pinned_summary.pointer + 992);
-    unsigned long long volatile *const symbols = (unsigned long long volatile *)((char *)engine->pinned_summary.pointer + 976);
-    if (!++engine->plan_sequence) ++engine->plan_sequence;
-    uint32_t const sequence = engine->plan_sequence;
-    *unfit = 0, symbols[0] = symbols[1] = 0;
-    phase(call, 2);
-    szs_tape_t q_tape = {call->queries->offsets, (uint64_t)(uintptr_t)call->queries->data, call->q_count, call->queries->kind == szs_input_u64tape_k};
-    szs_tape_t c_tape = q_tape; /* a symmetric call: the one tape against itself, the whole square (what the ordinary path leaves too) */
-    if (!call->symmetric) {
-        szs_tape_t const other = {call->candidates->offsets, (uint64_t)(uintptr_t)call->candidates->data, call->c_count,
-                                  call->candidates->kind == szs_input_u64tape_k};
-        c_tape = other;
-    }
-    uint32_t launches = 0;
-    /* ... and the cells of its lower triangle are ((sum len)^2 + sum len^2) / 2: the launch leaves a partial sum of squares per block of
-     * 256 strings in pinned memory */
-    size_t const square_blocks = call->symmetric ? ((size_t)call->c_count + 255) / 256 : 0;
-    uint64_t volatile *squares = NULL;
-    if (square_blocks) {
-        sz_status_t const reserved = szs_buffer_reserve(&engine->pinned_squares, szs_memory_pinned_k, call->device, square_blocks * sizeof(uint64_t), call->error_message);
-        if (reserved != sz_success_k) return reserved;
-        squares = (uint64_t volatile *)engine->pinned_squares.pointer;
-        for (size_t b = 0; b < square_blocks; ++b) squares[b] = 0;
-    }
-    /* The codepoint engine (round 6; reference: cuda.cuh:3294): one pass ahead of the launch turns both UTF-8 tapes into byte strings of
-     * rune ids (hip/utf8.hip: utf8_narrow_kernel) in a buffer of the engine's, and the launch scores THOSE - no transcoding to UTF-32,
-     * no renumbering passes, no planner.  Device staging (cross_device_planned_runes reserved it): a word per string. */
-    uint64_t *const entries = runes ? (uint64_t *)engine->device_transcode.pointer : NULL;
-    /* the head of the narrow buffer: the pass's table of claimed runes - it LIVES ON from call to call, zeroed when the buffer is new
-     * and after a batch that the pass refused (a full table, perhaps) - and the sides' totals of runes */
-    char *const narrow_workspace = runes ? (char *)engine->device_narrow.pointer : NULL;
-    char *const narrow_strings = runes ? narrow_workspace + SZS_NARROW_WORKSPACE : NULL;
-    uint64_t *trace = NULL; /* `trace` knob: the phases of every workgroup of the launch (printed after the wait) */
-    size_t const trace_workgroups = 8192, trace_slots = 10;
-    hipError_t error = hipEventRecord(engine->event_start, stream);
-    if (call->trace && szs_buffer_reserve(&engine->device_queue_trace, szs_memory_device_k, call->device, trace_workgroups * trace_slots * 8, NULL) == sz_success_k) {
-        trace = (uint64_t *)engine->device_queue_trace.pointer;
-        if (hipMemsetAsync(trace, 0, trace_workgroups * trace_slots * 8, stream) != hipSuccess) trace = NULL;
-    }
-    /* ONE launch: the tiny tokens and, in their shadow, the few longer ones (hip/myers_tiny.hip).  (Round 5's first design was four:
-     * a pass that listed the longer strings and tabled the tiny ones' masks in device memory, the outliers' kernel, a pass that set
-     * the tables back, the tiny-token kernel - 100 us of kernels on 4096 x 4096 words of text where the one launch takes 81.) */
-    if (error == hipSuccess && runes) {
-        if (engine->narrow_zeroed != (void *)narrow_workspace) {
-            error = hipMemsetAsync(narrow_workspace, 0, SZS_NARROW_WORKSPACE, stream);
-            engine->narrow_zeroed = error == hipSuccess ? (void *)narrow_workspace : NULL;
-        }
-        szs_tape_t narrowed_too = c_tape;
-        if (call->symmetric) narrowed_too.count = 0; /* (the one tape is narrowed once) */
-        if (error == hipSuccess)
-            error = (hipError_t)szs_hip_utf8_narrow(&q_tape, &narrowed_too, narrow_strings, engine->device_narrow.capacity - SZS_NARROW_WORKSPACE, entries,
-                                                    narrow_workspace, (uint32_t *)unfit, sequence, stream);
-        launches += error == hipSuccess;
-        szs_tape_t const q_narrow = {entries, (uint64_t)(uintptr_t)narrow_strings, call->q_count, 2};
-        szs_tape_t const c_narrow = {entries + call->q_count, (uint64_t)(uintptr_t)narrow_strings, call->c_count, 2};
-        q_tape = q_narrow, c_tape = call->symmetric ? q_narrow : c_narrow;
-    }
-    if (error == hipSuccess) {
-        error = (hipError_t)szs_hip_levenshtein_tiny(&q_tape, &c_tape, (uint64_t *)call->device_results, call->device_stride, (uint32_t *)unfit, sequence,
-                                                           (unsigned long long *)symbols,
-                                                           runes ? (uint64_t *)(narrow_workspace + SZS_NARROW_SLOTS * sizeof(uint32_t)) : NULL, (uint64_t *)squares, trace,
-                                                           trace_workgroups, szs_tuning_get(szs_knob_tiny_k) == 2, stream);
-        launches += error == hipSuccess;
-    }
-    engine->last_streams = 1;
-    /* what finish() reads: lanes tier, one launch.  On the stack, like the other paths' copies of a decision: a failed allocation here
-     * would have returned with the launch still writing the caller's matrix and the pinned words */
-    szs_decision_t shape_of_call;
-    memset(&shape_of_call, 0, sizeof(shape_of_call));
-    szs_decision_t *const shape = &shape_of_call;
-    shape->tier = SZS_TIER_LANES, shape->q_count = call->q_count, shape->c_count = call->c_count, shape->runes = runes;
-    if (seen) shape->longest[0] = seen->side[0].longest, shape->longest[1] = seen->side[1].longest;
-    engine->last_profile.planner = planner_mode;
-    int stalled = 0;
-    sz_status_t status = finish(call, shape, error, sz_success_k, launches, 0, 0, 0, &stalled);
-    if (runes && (status != sz_success_k || *unfit == sequence)) engine->narrow_zeroed = NULL; /* a full table, totals nobody read: start over */
-    if (status != sz_success_k) return status;
-    if (trace) { /* where a workgroup of the tiny-token kernel spends its time: mean ticks (10 ns) between its stamps */
-        size_t const slots = trace_slots, last_slot = 8;
-        uint64_t *const ticks = (uint64_t *)malloc(trace_workgroups * slots * 8);
-        if (ticks && hipMemcpy(ticks, trace, trace_workgroups * slots * 8, hipMemcpyDeviceToHost) == hipSuccess) {
-            double sums[10] = {0};
-            uint64_t first = ~0ull, last = 0;
-            size_t seen = 0;
-            for (size_t w = 0; w < trace_workgroups; ++w) {
-                if (!ticks[slots * w] || !ticks[slots * w + last_slot]) continue;
-                ++seen;
-                first = ticks[slots * w] < first ? ticks[slots * w] : first, last = ticks[slots * w + last_slot] > last ? ticks[slots * w + last_slot] : last;
-                for (size_t k = 1; k < slots; ++k)
-                    if (ticks[slots * w + k] && ticks[slots * w + k - 1]) sums[k] += (double)(ticks[slots * w + k] - ticks[slots * w + k - 1]);
-            }
-            uint64_t last_begin = 0, longest_life = 0, first_end = ~0ull;
-            double lives = 0;
-            for (size_t w = 0; w < trace_workgroups; ++w) {
-                if (!ticks[slots * w] || !ticks[slots * w + last_slot]) continue;
-                uint64_t const life = ticks[slots * w + last_slot] - ticks[slots * w];
-                last_begin = ticks[slots * w] > last_begin ? ticks[slots * w] : last_begin, longest_life = life > longest_life ? life : longest_life, lives += (double)life;
-                first_end = ticks[slots * w + last_slot] < first_end ? ticks[slots * w + last_slot] : first_end;
-            }
-            if (seen)
-                fprintf(stderr, "tiny kernel: last begin at %.1f us, first end at %.1f us; a workgroup lives %.1f us on average, %.1f at most\n", (last_begin - first) * 1e-2,
-                        (first_end - first) * 1e-2, lives / seen * 1e-2, longest_life * 1e-2);
-            if (seen)
-                fprintf(stderr, "tiny kernel: %zu workgroups over %.1f us; mean us per workgroup: offsets + local sort %.2f, texts %.2f, first masks %.2f, columns %.2f, "
-                                "%s %.2f, un-build + stores %.2f, rest (further groups) %.2f, long queries %.2f\n", seen, (last - first) * 1e-2, sums[1] / seen * 1e-2,
-                        sums[2] / seen * 1e-2, sums[3] / seen * 1e-2, sums[4] / seen * 1e-2, "long candidates + barrier", sums[5] / seen * 1e-2,
-                        sums[6] / seen * 1e-2, sums[7] / seen * 1e-2, sums[8] / seen * 1e-2);
-        }
-        free(ticks);
-    }
-    if (*unfit == sequence) {
-        /* refused (a block or span too dense in long strings, a string beyond 255 bytes): remember the counts, so that a stream of
-         * such batches does not pay this launch and its wait on every call because their summaries look like words */
-        if (runes) engine->tiny_runes_valid = 0;
-        else engine->tiny_valid = 0;
-        if (planner_mode == 1) { /* ... a batch whose SUMMARY looked like words (clustered long lines among short ones).  A batch that
-                                    came straight here on the previous call's word (mode 5: sentences after words) is judged by its
-                                    own summary next time - nothing to remember */
-            engine->tiny_refused = 16; /* calls of these counts that go straight to the ordinary path */
-            engine->tiny_q_count = call->q_count, engine->tiny_c_count = call->c_count;
-        }
-        return SZS_TINY_NOT_TAKEN;
-    }
-    engine->tiny_refused = 0;
-    szs_rocm_call_profile_t *profile = &engine->last_profile;
-    uint64_t const q_symbols = symbols[0], c_symbols = symbols[1];
-    profile->cells = q_symbols * c_symbols;
-    profile->algorithmic_bytes = (uint64_t)call->c_count * q_symbols + (uint64_t)call->q_count * c_symbols + profile->pairs * 16;
-    profile->unique_bytes += q_symbols + c_symbols;
-    if (call->symmetric) { /* (the conventions of complete_from_summary) */
-        uint64_t sum_of_squares = 0;
-        for (size_t b = 0; b < square_blocks; ++b) sum_of_squares += squares[b];
-        profile->cells = (q_symbols * q_symbols + sum_of_squares) / 2;
-        profile->algorithmic_bytes = ((uint64_t)call->q_count + 1) * q_symbols + profile->pairs * 16;
-        profile->unique_bytes -= c_symbols;
-    }
-    /* the next call of these counts comes straight here - as long as the batch keeps looking like tiny tokens */
-    szs_side_stats_t now[2];
-    memset(now, 0, sizeof(now));
-    now[0].count = call->q_count, now[0].symbols = q_symbols, now[1].count = call->c_count, now[1].symbols = c_symbols;
-    if (runes) engine->tiny_runes_valid = tiny_shaped(engine, call->symmetric, &now[0], &now[1]), engine->tiny_runes_q_count = call->q_count, engine->tiny_runes_c_count = call->c_count;
-    else engine->tiny_valid = tiny_shaped(engine, call->symmetric, &now[0], &now[1]), engine->tiny_q_count = call->q_count, engine->tiny_c_count = call->c_count;
-    if (engine->remembered) engine->remembered->refs_current = 0, engine->remembered->valid = 0; /* another kind of call came between */
-    return szs_report(sz_success_k, call->error_message, NULL);
-}
-
-/* ---- device-planned byte calls: five ways to a call's plan, tried cheapest first ------------------------------------------------
- *
- *  (round 6: one function per way - rounds 2 to 5 grew them inside one function of 380 lines.)  Each returns the call's status,
- *  or SZS_WAY_NOT_TAKEN: this call is not one for this way (or turned out not to be: nothing real was scored) - try the next.
- */
-#define SZS_WAY_NOT_TAKEN ((sz_status_t)4)
-
-typedef struct planned_call_t {
-    szs_call_t *call;
-    szs_engine_s *engine;
-    szs_decision_t *remembered;  /* the engine's previous device-planned call */
-    szs_plan_side_t q_side, c_side; /* the caller's sides (the same one twice for a symmetric call) */
-    szs_plan_summary_t volatile *summary; /* pinned: where the device planner reports */
-    int use_myers, knobs_automatic, uniform_bytes;
-    unsigned myers_words;
-    void const *key_data[2], *key_offsets[2]; /* what "the same tapes" means */
-    int key_wide[2];
-    szs_plan_summary_t seen; /* the summary of THIS call's tapes, once a planner has reported */
-    int have_summary;        /* ... by a speculated plan whose launches did not hold: the refs on the device are blank */
-} planned_call_t;
-
-/** The profile of a call that was scored before its statistics were known (speculated, or planned inside its launch), and what the
- *  next call may count on: the refs on the device describe these tapes; a batch of tiny tokens goes to their kernel next time. */
-static void complete_from_summary(planned_call_t *way, szs_plan_summary_t const *seen) {
-    szs_engine_s *engine = way->engine;
-    int const symmetric = way->call->symmetric;
-    uint32_t const q_count = way->call->q_count, c_count = way->call->c_count;
-    szs_rocm_call_profile_t *profile = &engine->last_profile;
-    profile->cells = symmetric ? seen->symmetric_cells : seen->side[0].symbols * seen->side[1].symbols;
-    profile->algorithmic_bytes = (symmetric ? ((uint64_t)q_count + 1) * seen->side[0].symbols
-                                            : (uint64_t)c_count * seen->side[0].symbols + (uint64_t)q_count * seen->side[1].symbols) + profile->pairs * 16;
-    profile->unique_bytes += seen->side[0].symbols + (symmetric ? 0 : seen->side[1].symbols);
-    profile->longest_query = seen->side[0].longest, profile->longest_candidate = seen->side[1].longest;
-    stamp_refs(way->remembered, way->key_data, way->key_offsets, way->key_wide, seen);
-    if (tiny_shaped(engine, symmetric, &seen->side[0], &seen->side[1]) && !tiny_recently_refused(engine, q_count, c_count, 0))
-        engine->tiny_valid = 1, engine->tiny_q_count = q_count, engine->tiny_c_count = c_count;
-}
-
-/** The kernel's refs for a decision's orientation: its queries longest first, its candidates shortest first. */
-static void refs_of(planned_call_t const *way, szs_decision_t const *d, szs_string_ref_t const **query_refs, szs_string_ref_t const **candidate_refs) {
-    *query_refs = d->transposed ? way->c_side.descending : way->q_side.descending;
-    *candidate_refs = d->transposed ? way->q_side.ascending : way->c_side.ascending;
-}
-
-/**
- *  Way 3 - the same tapes again: the refs planned for them are still on the device, no planner at all.  Every workgroup and lane
- *  of the byte kernels checks its ref against the offsets as they are NOW before it touches a string (hip/kernels.h:
- *  szs_ref_guard_t), so a tape that was rewritten in place, freed or reallocated costs one re-plan, never a wrong score or a stray
- *  read.  Only launches whose kernels carry the guard take this way: unit-cost byte queries of up to 256 bytes - ONE launch of
- *  ~0.2 ms, where 25 us of planning matter (with longer queries the guarded launches were slower than planning: 128 x 128 x 1 KB
- *  over eight lanes per pair 0.67 ms behind the guard, 0.50 ms planned - profiles/r03).
- */
-static sz_status_t planned_on_the_same_tapes(planned_call_t *way) {
-    szs_call_t *call = way->call;
-    szs_engine_s *engine = way->engine;
-    szs_decision_t *const remembered = way->remembered;
-    int const symmetric = call->symmetric;
-    if (!(remembered->valid && remembered->refs_current && way->knobs_automatic && szs_tuning_get(szs_knob_reuse_k) != 0 &&
-          remembered->tier == SZS_TIER_LANES && remembered->use_myers && !remembered->runes && !remembered->wide_cells &&
-          !has_group_of_variant_zero(remembered) && remembered->plan.groups_count == 1 &&
-          remembered->plan.groups[0].variant == SZS_MYERS_SHORT_WORDS && remembered->q_count == call->q_count && remembered->c_count == call->c_count &&
-          remembered->symmetric == symmetric && remembered->key_data[0] == way->key_data[0] && remembered->key_data[1] == way->key_data[1] &&
-          remembered->key_offsets[0] == way->key_offsets[0] && remembered->key_offsets[1] == way->key_offsets[1] &&
-          remembered->key_wide[0] == way->key_wide[0] && remembered->key_wide[1] == way->key_wide[1]))
-        return SZS_WAY_NOT_TAKEN;
-    szs_decision_t const *d = remembered;
-    uint32_t volatile *const stale = (uint32_t volatile *)((char *)engine->pinned_summary.pointer + 768);
-    szs_ref_guard_t guard;
-    memset(&guard, 0, sizeof(guard));
-    guard.enabled = 1, guard.sequence = ++engine->plan_sequence, guard.stale = (uint32_t *)stale;
-    for (int role = 0; role < 2; ++role) { /* kernel roles: 0 = its queries, 1 = its candidates */
-        szs_plan_side_t const *side = (role == 0) == (d->transposed == 0) ? &way->q_side : &way->c_side;
-        if (symmetric) side = &way->q_side;
-        guard.side[role].offsets = side->offsets, guard.side[role].base = side->base;
-        guard.side[role].wide = side->wide, guard.side[role].count = side->count;
-    }
-    *stale = 0;
-    sz_status_t status = prepare(engine, d, call->device, call->stream, call->error_message);
-    if (status != sz_success_k) return status;
-    phase(call, 2);
-    uint32_t launches = 0, cell_bits = 0;
-    sz_status_t enqueue_status = sz_success_k;
-    hipError_t error = hipEventRecord(engine->event_start, call->stream);
-    szs_string_ref_t const *query_refs, *candidate_refs;
-    refs_of(way, d, &query_refs, &candidate_refs);
-    if (error == hipSuccess)
-        error = enqueue(engine, d, call->device, query_refs, candidate_refs, call->device_results, call->device_stride, call->stream, &guard, &launches,
-                        &cell_bits, &enqueue_status, call->error_message);
-    int stalled = 0;
-    engine->last_profile.planner = 3;
-    status = finish(call, d, error, enqueue_status, launches, cell_bits, d->summary.side[0].symbols, d->summary.side[1].symbols, &stalled);
-    if (status != sz_success_k) return status;
-    if (*stale != guard.sequence) return sz_success_k; /* every ref still described its string: scored */
-    remembered->refs_current = 0;                      /* the tapes changed under the same pointers: plan them afresh */
-    return SZS_WAY_NOT_TAKEN;
-}
-
-/**
- *  Way 4 - the planner INSIDE the scoring launch (round 5; hip/kernels.h: szs_fused_plan_t).  The previous call of this engine was
- *  ONE launch of the short unit-cost byte kernel and this one has the same counts: the launch goes out alone - its first two
- *  workgroups sort the two sides (what hip/planner.hip does in a launch of its own) while the others wait for the refs.  No planner
- *  launch, no kernel boundary: config 2's fresh-batch call 202 -> ~190 us.  Round 6: symmetric calls too (one side, sorted once,
- *  serves both roles) and sides of up to 16,384 strings (counted and placed in two walks over their offsets).  A batch that does not
- *  fit after all (a query beyond 256 bytes, malformed offsets) is scored as empty strings; a launch whose waiting workgroups ran out
- *  of polls scored only part of the matrix: either way the call goes on to the next way.
- */
-static sz_status_t planned_inside_the_launch(planned_call_t *way) {
-    szs_call_t *call = way->call;
-    szs_engine_s *engine = way->engine;
-    szs_decision_t *const remembered = way->remembered;
-    int const symmetric = call->symmetric;
-    int const knob = szs_tuning_get(szs_knob_fused_k);
-    if (!(remembered->valid && !remembered->runes && remembered->tier == SZS_TIER_LANES && remembered->use_myers && !remembered->wide_cells &&
-          !remembered->use_queue && is_one_launch(remembered) && remembered->plan.groups[0].variant == SZS_MYERS_SHORT_WORDS &&
-          remembered->q_count == call->q_count && remembered->c_count == call->c_count && remembered->symmetric == symmetric &&
-          call->q_count <= SZS_FUSED_MOST_STRINGS_TWO_PASSES && call->c_count <= SZS_FUSED_MOST_STRINGS_TWO_PASSES && way->knobs_automatic &&
-          !way->uniform_bytes && knob != 0 && (!engine->fused_gave_up || knob == 2)))
-        return SZS_WAY_NOT_TAKEN;
-    szs_decision_t const *d = remembered;
-    szs_fused_side_report_t volatile *const reports = (szs_fused_side_report_t volatile *)((char *)engine->pinned_summary.pointer + 1024);
-    uint32_t volatile *const gave_up = (uint32_t volatile *)((char *)engine->pinned_summary.pointer + 1024 + 2 * sizeof(szs_fused_side_report_t));
-    szs_fused_plan_t fused;
-    memset(&fused, 0, sizeof(fused));
-    fused.side[0] = d->transposed ? way->c_side : way->q_side, fused.side[1] = d->transposed ? way->q_side : way->c_side;
-    if (!++engine->plan_sequence) ++engine->plan_sequence; /* never 0: the ready words start there */
-    fused.sequence = engine->plan_sequence;
-    fused.ready = (uint32_t *)engine->device_fused.pointer, fused.report = (szs_fused_side_report_t *)reports;
-    *gave_up = 0;
-    fused.gave_up = (uint32_t *)gave_up, fused.poll_budget = SZS_FUSED_POLL_BUDGET;
-    if (knob == 2) fused.withhold = 1, fused.poll_budget = 64; /* testing: nobody is ever told */
-    sz_status_t status = prepare(engine, d, call->device, call->stream, call->error_message); /* buffers of the previous call: nothing to allocate */
-    if (status != sz_success_k) return status;
-    phase(call, 2);
-    remembered->refs_current = 0; /* the launch is about to overwrite the refs */
-    /* (Measured and not kept: the launch stamping the event pair itself - hipExtLaunchKernel with a start and a stop event, no
-     * records around it.  The kernel's own time reads 177.0 us instead of 180.9, but the call takes 200.7 us instead of 193.7.) */
-    hipError_t error = hipEventRecord(engine->event_start, call->stream);
-    uint32_t launches = 0;
-    if (error == hipSuccess) {
-        error = (hipError_t)szs_hip_levenshtein_myers_fused(&fused, (uint64_t *)call->device_results, call->device_stride, d->layout, call->stream);
-        launches = error == hipSuccess;
-    }
-    engine->last_streams = 1;
-    int stalled = 0;
-    szs_decision_t scored = *d;
-    engine->last_profile.planner = 4;
-    status = finish(call, &scored, error, sz_success_k, launches, 0, 0, 0, &stalled);
-    if (status != sz_success_k) return status;
-    szs_fused_side_report_t sides[2];
-    memcpy(sides, (void const *)reports, sizeof(sides));
-    if (*gave_up == fused.sequence) { /* a workgroup ran out of polls: whatever the reports say, not every cell was scored - the ready
-                                         words are zeroed before anything waits on them again, and this engine does not try again */
-        engine->fused_gave_up = 1, engine->fused_zeroed = NULL;
-        return SZS_WAY_NOT_TAKEN;
-    }
-    if (!(sides[0].sequence == fused.sequence && !sides[0].status && !sides[0].blank &&
-          (symmetric || (sides[1].sequence == fused.sequence && !sides[1].status && !sides[1].blank))))
-        return SZS_WAY_NOT_TAKEN; /* not this shape after all: nothing real was scored */
-    /* scored; the profile and the remembered plan take this batch's figures (caller roles again; a symmetric call has one side) */
-    szs_fused_side_report_t const *const of_queries = &sides[!symmetric && d->transposed ? 1 : 0];
-    szs_fused_side_report_t const *const of_candidates = symmetric ? of_queries : &sides[d->transposed ? 0 : 1];
-    if (call->trace)
-        for (int s = 0; s < (symmetric ? 1 : 2); ++s)
-            fprintf(stderr, "fused sorter %d (10 ns ticks since it began): offsets loaded %u, positions %u, refs written %u, published %u; began %d ticks after sorter 0\n",
-                    s, sides[s].ticks[1], sides[s].ticks[2], sides[s].ticks[3], sides[s].ticks[4], (int)(sides[s].ticks[0] - sides[0].ticks[0]));
-    szs_plan_summary_t seen_here = remembered->summary;
-    seen_here.status = 0, seen_here.speculation_held = 1, seen_here.sequence = fused.sequence;
-    seen_here.side[0] = of_queries->stats, seen_here.side[1] = of_candidates->stats;
-    memcpy(seen_here.rank_lengths[0], of_queries->rank_lengths, sizeof(seen_here.rank_lengths[0]));
-    memcpy(seen_here.rank_lengths[1], of_candidates->rank_lengths, sizeof(seen_here.rank_lengths[1]));
-    /* the lower triangle of a symmetric call: sum over i of len_i x (sum over j <= i of len_j) = ((sum len)^2 + sum len^2) / 2 */
-    seen_here.symmetric_cells = symmetric ? (seen_here.side[0].symbols * seen_here.side[0].symbols + of_queries->squares) / 2 : 0;
-    remembered->longest[0] = seen_here.side[0].longest, remembered->longest[1] = seen_here.side[1].longest;
-    complete_from_summary(way, &seen_here);
-    return szs_report(sz_success_k, call->error_message, NULL);
-}
-
-/**
- *  Way 2 - speculate: launches shaped like the previous call go in right behind the planner, which validates the shape and blanks
- *  the refs of a side that does not have it.  (Round 3: only calls of ONE launch.  The launches of a mixed-length batch leave the
- *  host one after the other, longest pairs first, and reach the device in that order; enqueued behind the planner they are all
- *  released by the same event and the device takes them as it likes - the short launch's thousands of workgroups first, the long
- *  pairs late.  Config 5: 9.68 ms speculated, 9.60 planned-and-waited-for; an eighth of it 1.95 / 1.85; codepoints 8.4 / 7.1.)
- *  Leaves `way->seen` / `way->have_summary` when the planner reported but the shape did not hold.
- */
-static sz_status_t planned_and_speculated(planned_call_t *way) {
-    szs_call_t *call = way->call;
-    szs_engine_s *engine = way->engine;
-    szs_decision_t *const remembered = way->remembered;
-    int const symmetric = call->symmetric;
-    if (!(remembered->valid && !remembered->runes && remembered->tier == SZS_TIER_LANES && remembered->q_count == call->q_count &&
-          remembered->c_count == call->c_count && remembered->symmetric == symmetric && way->knobs_automatic && !way->uniform_bytes &&
-          is_one_launch(remembered)))
-        return SZS_WAY_NOT_TAKEN;
-    szs_decision_t const *d = remembered;
-    szs_plan_expectation_t expected;
-    memset(&expected, 0, sizeof(expected));
-    expected.enabled = 1, expected.query_side = (uint32_t)d->transposed;
-    expected.longest[0] = d->longest[0], expected.longest[1] = d->longest[1];
-    memcpy(expected.variant_counts, d->variant_counts, sizeof(expected.variant_counts));
-    expected.sequence = ++engine->plan_sequence;
-    sz_status_t status = prepare(engine, d, call->device, call->stream, call->error_message); /* buffers of the previous call: nothing to allocate */
-    if (status != sz_success_k) return status;
-    phase(call, 2);
-    uint32_t launches = 0, cell_bits = 0;
-    remembered->refs_current = 0; /* the planner is about to overwrite the refs */
-    hipError_t error = (hipError_t)szs_hip_plan(&way->q_side, symmetric ? NULL : &way->c_side, way->myers_words, &expected, (szs_plan_summary_t *)way->summary,
-                                                SZS_PLAN_VERDICTS(engine), call->stream);
-    if (error != hipSuccess) return szs_report_hip(error, call->error_message); /* nothing enqueued yet */
-    error = hipEventRecord(engine->event_start, call->stream);
-    szs_string_ref_t const *query_refs, *candidate_refs;
-    refs_of(way, d, &query_refs, &candidate_refs);
-    sz_status_t enqueue_status = sz_success_k;
-    if (error == hipSuccess)
-        error = enqueue(engine, d, call->device, query_refs, candidate_refs, call->device_results, call->device_stride, call->stream, NULL, &launches,
-                        &cell_bits, &enqueue_status, call->error_message);
-    /* the summary is read after the wait inside finish(); profile numbers come from it, so finish() runs on a copy of the decision
-     * whose statistics are filled in afterwards */
-    int stalled = 0;
-    szs_decision_t scored = *d;
-    engine->last_profile.planner = 2;
-    status = finish(call, &scored, error, enqueue_status, launches, cell_bits, 0, 0, &stalled);
-    if (status != sz_success_k) return status;
-    memcpy(&way->seen, (void const *)way->summary, sizeof(way->seen));
-    way->have_summary = way->seen.sequence == expected.sequence;
-    if (!(way->have_summary && !way->seen.status && way->seen.speculation_held))
-        return SZS_WAY_NOT_TAKEN; /* the shape changed (or the offsets are malformed): the refs were blanked, nothing real was scored */
-    complete_from_summary(way, &way->seen); /* the batch had the remembered shape and has been scored */
-    return szs_report(sz_success_k, call->error_message, NULL);
-}
-
-/** Way 1 - plan on the device, wait for the summary, decide, launch (and, for a batch of tiny tokens, their launch instead). */
-static sz_status_t planned_and_waited_for(planned_call_t *way) {
-    szs_call_t *call = way->call;
-    szs_engine_s *engine = way->engine;
-    szs_decision_t *const remembered = way->remembered;
-    hipStream_t const stream = call->stream;
-    int const symmetric = call->symmetric;
-    char const **error_message = call->error_message;
-    szs_plan_summary_t *const seen = &way->seen;
-    sz_status_t status;
-    hipError_t error;
-    remembered->refs_current = 0;
-    if (!way->have_summary) {
-        szs_plan_expectation_t none;
-        memset(&none, 0, sizeof(none));
-        none.sequence = ++engine->plan_sequence;
-        error = (hipError_t)szs_hip_plan(&way->q_side, symmetric ? NULL : &way->c_side, way->myers_words, &none, (szs_plan_summary_t *)way->summary,
-                                         SZS_PLAN_VERDICTS(engine), stream);
-        hipError_t const drained = hipStreamSynchronize(stream);
-        if (error == hipSuccess) error = drained;
-        if (error != hipSuccess) return szs_report_hip(error, error_message);
-        memcpy(seen, (void const *)way->summary, sizeof(*seen));
-        if (seen->sequence != none.sequence) return szs_report(sz_status_unknown_k, error_message, "The device planner did not report");
-    }
-    if (seen->status & SZS_PLAN_STATUS_DESCENDING) return szs_report(sz_unexpected_dimensions_k, error_message, "Tape offsets must ascend");
-    if (seen->status & SZS_PLAN_STATUS_OVERFLOW) return szs_report(sz_overflow_risk_k, error_message, NULL);
-    if (seen->status & SZS_PLAN_STATUS_UNSORTED) return SZS_NOT_DEVICE_PLANNABLE; /* strings beyond the planner's histogram */
-    if (way->uniform_bytes) { /* the scan has landed (the planner's wait covered it): number the bytes that occur 0 ... A - 1 */
-        uint32_t volatile const *const presence = (uint32_t volatile const *)((char *)engine->pinned_summary.pointer + 896);
-        uint32_t classes = 0;
-        for (unsigned byte = 0; byte < 256; ++byte)
-            engine->uniform_byte_to_class[byte] = (presence[byte / 32] >> (byte % 32)) & 1u ? (uint8_t)classes++ : 0;
-        engine->uniform_classes = classes ? classes : 1; /* a batch of empty strings: one class nobody belongs to */
-    }
-    phase(call, 1);
-
-    if (way->use_myers && szs_tuning_get(szs_knob_tier_k) < 0 && szs_tuning_get(szs_knob_swap_k) < 0 && szs_tuning_get(szs_knob_queue_k) < 0 &&
-        tiny_shaped(engine, symmetric, &seen->side[0], &seen->side[1]) && !tiny_recently_refused(engine, call->q_count, call->c_count, 1)) {
-        /* the summary says tiny tokens (and the kernel did not refuse the previous batch of these counts): no refs needed after all */
-        status = cross_tiny(call, 1, seen, 0);
-        if (status != SZS_TINY_NOT_TAKEN) return status;
-    }
-
-    for (int attempt = 0; attempt < 2; ++attempt) { /* second round: a stalled band chain is re-run on the lanes tier */
-        szs_decision_t d;
-        uint64_t const cells = symmetric ? seen->symmetric_cells : seen->side[0].symbols * seen->side[1].symbols;
-        status = decide(engine, symmetric, 0, attempt > 0, &seen->side[0], &seen->side[1], seen->variant_counts[0], seen->variant_counts[1],
-                        seen->rank_lengths, cells, &d, error_message);
-        if (status != sz_success_k) return status;
-        decide_queue(engine, &d, seen->rank_lengths);
-        status = prepare(engine, &d, call->device, stream, error_message);
-        if (status != sz_success_k) return status;
-        phase(call, 2);
-        if (way->have_summary) { /* the refs on the device are blank (failed speculation): write the real ones */
-            szs_plan_expectation_t none;
-            memset(&none, 0, sizeof(none));
-            none.sequence = ++engine->plan_sequence;
-            error = (hipError_t)szs_hip_plan(&way->q_side, symmetric ? NULL : &way->c_side, way->myers_words, &none, (szs_plan_summary_t *)way->summary,
-                                             SZS_PLAN_VERDICTS(engine), stream);
-            if (error != hipSuccess) return szs_report_hip(error, error_message);
-            way->have_summary = 0;
-        }
-        uint32_t launches = 0, cell_bits = 0;
-        error = hipEventRecord(engine->event_start, stream);
-        szs_string_ref_t const *query_refs, *candidate_refs;
-        refs_of(way, &d, &query_refs, &candidate_refs);
-        sz_status_t enqueue_status = sz_success_k;
-        if (error == hipSuccess)
-            error = enqueue(engine, &d, call->device, query_refs, candidate_refs, call->device_results, call->device_stride, stream, NULL, &launches,
-                            &cell_bits, &enqueue_status, error_message);
-        int stalled = 0;
-        engine->last_profile.planner = 1;
-        status = finish(call, &d, error, enqueue_status, launches, cell_bits, seen->side[0].symbols, seen->side[1].symbols, &stalled);
-        if (status != sz_success_k) return status;
-        if (!stalled) {
-            *remembered = d; /* the next call of this shape goes in speculatively - or, on the same tapes, without a planner */
-            stamp_refs(remembered, way->key_data, way->key_offsets, way->key_wide, seen);
-            return sz_success_k;
-        }
-    }
-    return szs_report(sz_status_unknown_k, error_message, "Systolic pipeline stalled");
-}
-
-static sz_status_t cross_device_planned(szs_call_t *call) {
-    szs_engine_s *engine = call->engine;
-    hipStream_t const stream = call->stream;
-    int const device = call->device, symmetric = call->symmetric;
-    uint32_t const q_count = call->q_count, c_count = call->c_count;
-    char const **error_message = call->error_message;
-
-    size_t const refs_bytes = 2 * ((size_t)q_count + (symmetric ? 0 : c_count)) * sizeof(szs_string_ref_t);
-    void *const refs_before = engine->device_plan_refs.pointer;
-    sz_status_t status = szs_buffer_reserve(&engine->device_plan_refs, szs_memory_device_k, device, refs_bytes, error_message);
-    /* The refs of the previous call live in that buffer.  If the reserve moved it (or failed), the remembered plan describes
-     * memory that is gone: forget it HERE, before any way below could re-use it behind nothing but the in-kernel guard. */
-    if (engine->remembered && (status != sz_success_k || engine->device_plan_refs.pointer != refs_before))
-        engine->remembered->refs_current = 0, engine->remembered->valid = 0;
-    if (status != sz_success_k) return status;
-    if (!engine->remembered) {
-        engine->remembered = (szs_decision_t *)calloc(1, sizeof(szs_decision_t));
-        if (!engine->remembered) return szs_report(sz_bad_alloc_k, error_message, NULL);
-    }
-    planned_call_t way;
-    memset(&way, 0, sizeof(way));
-    way.call = call, way.engine = engine, way.remembered = engine->remembered;
-    szs_string_ref_t *const base = (szs_string_ref_t *)engine->device_plan_refs.pointer;
-    szs_plan_side_t const q_side = {call->queries->offsets, (uint64_t)(uintptr_t)call->queries->data, q_count,
-                                    call->queries->kind == szs_input_u64tape_k, base, base + q_count, NULL, NULL};
-    way.q_side = way.c_side = q_side;
-    if (!symmetric) {
-        szs_plan_side_t const other = {call->candidates->offsets, (uint64_t)(uintptr_t)call->candidates->data, c_count,
-                                       call->candidates->kind == szs_input_u64tape_k, base + 2 * (size_t)q_count,
-                                       base + 2 * (size_t)q_count + c_count, NULL, NULL};
-        way.c_side = other;
-    }
-    way.summary = (szs_plan_summary_t volatile *)engine->pinned_summary.pointer;
-    /* (the codepoint family gets here with an ASCII corpus: its runes are its bytes) */
-    way.use_myers = engine->is_unit_cost && (engine->family == szs_family_levenshtein_k || engine->family == szs_family_levenshtein_utf8_k);
-    way.myers_words = way.use_myers ? SZS_MYERS_MAX_WORDS : 0;
-    status = place_results(call);
-    if (status != sz_success_k) return status;
-    status = reserve_device_words(engine, device, stream, error_message);
-    if (status != sz_success_k) return status;
-    phase(call, 0);
-
-    /* ---- way 5, tiny tokens (hip/myers_tiny.hip): the previous call of these counts was scored straight from the tapes - so is this
-     * one, with no planner at all; the kernel says when a query does not fit it */
-    if (engine->tiny_valid && engine->tiny_q_count == q_count && engine->tiny_c_count == c_count && way.use_myers &&
-        szs_tuning_get(szs_knob_tiny_k) != 0 && szs_tuning_get(szs_knob_speculate_k) != 0 && szs_tuning_get(szs_knob_tier_k) < 0 &&
-        szs_tuning_get(szs_knob_swap_k) < 0 && szs_tuning_get(szs_knob_queue_k) < 0) {
-        status = cross_tiny(call, 5, NULL, 0);
-        if (status != SZS_TINY_NOT_TAKEN) return status;
-    }
-
-    way.knobs_automatic = szs_tuning_get(szs_knob_speculate_k) != 0 && szs_tuning_get(szs_knob_tier_k) < 0 && szs_tuning_get(szs_knob_swap_k) < 0 &&
-                          szs_tuning_get(szs_knob_cells_k) < 0 && szs_tuning_get(szs_knob_packed_k) < 0 && szs_tuning_get(szs_knob_team_k) < 0 &&
-                          szs_tuning_get(szs_knob_queue_k) < 0;
-    way.key_data[0] = call->queries->data, way.key_data[1] = symmetric ? call->queries->data : call->candidates->data;
-    way.key_offsets[0] = call->queries->offsets, way.key_offsets[1] = symmetric ? call->queries->offsets : call->candidates->offsets;
-    way.key_wide[0] = (int)way.q_side.wide, way.key_wide[1] = (int)way.c_side.wide;
-
-    status = planned_on_the_same_tapes(&way); /* way 3 */
-    if (status != SZS_WAY_NOT_TAKEN) return status;
-
-    /* ---- a Levenshtein engine with non-unit costs: which bytes occur in this batch?  One pass over both tapes, enqueued ahead
-     * of the planner and read after the planner's own wait; the team tier keys its profile by the classes the host numbers
-     * from it (decide()).  Such a call is not speculated: its launch depends on what the scan finds. */
-    way.uniform_bytes = (engine->family == szs_family_levenshtein_k || engine->family == szs_family_levenshtein_utf8_k) && !engine->is_unit_cost &&
-                        szs_tuning_get(szs_knob_packed_k) != 0 && szs_tuning_get(szs_knob_team_k) != 0;
-    engine->uniform_classes = 0;
-    if (way.uniform_bytes) {
-        uint32_t volatile *const presence = (uint32_t volatile *)((char *)engine->pinned_summary.pointer + 896);
-        status = szs_buffer_reserve(&engine->device_presence, szs_memory_device_k, device, 8 * sizeof(uint32_t), error_message);
-        if (status != sz_success_k) return status;
-        hipError_t error = hipMemsetAsync(engine->device_presence.pointer, 0, 8 * sizeof(uint32_t), stream);
-        if (error == hipSuccess)
-            error = (hipError_t)szs_hip_byte_presence(call->queries->data, call->queries->offsets, q_count, (int)way.q_side.wide,
-                                                      (uint32_t *)engine->device_presence.pointer, stream);
-        if (error == hipSuccess && !symmetric)
-            error = (hipError_t)szs_hip_byte_presence(call->candidates->data, call->candidates->offsets, c_count, (int)way.c_side.wide,
-                                                      (uint32_t *)engine->device_presence.pointer, stream);
-        if (error == hipSuccess)
-            error = hipMemcpyAsync((void *)presence, engine->device_presence.pointer, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
-        if (error != hipSuccess) {
-            (void)hipStreamSynchronize(stream);
-            return szs_report_hip(error, error_message);
-        }
-    }
-
-    status = planned_inside_the_launch(&way); /* way 4 */
-    if (status != SZS_WAY_NOT_TAKEN) return status;
-    status = planned_and_speculated(&way); /* way 2 */
-    if (status != SZS_WAY_NOT_TAKEN) return status;
-    return planned_and_waited_for(&way); /* way 1 */
-}
-
-/* ---- device-planned codepoint calls --------------------------------------------------------------------------------------- */
-
-#define SZS_RUNES_ARE_BYTES ((sz_status_t)2) /* internal: the corpus is ASCII - the byte engines compute the same distances */
-
-/**
- *  The codepoint engine over tapes the device can read, without the host reading a single offset (round 2 planned these calls
- *  on the host: offsets downloaded, strings gathered and re-addressed in O(Q + C) host loops, a wait between transcoding and
- *  planning - a third of the wall time of a batch of short words).  One stream, one wait:
- *      transcode both tapes (hip/utf8.hip: rune starts follow from the byte offsets alone, no scan) -> renumber the runes
- *      -> plan on RUNE counts (hip/planner.hip) -> wait -> decide -> launch.
- *  The UTF-32 buffer is sized by the previous calls; a batch that needs more says so (`needed`) and is transcoded again.
- *  An ASCII corpus goes to the byte engines (serial.hpp:2809-2813, applied per call).
- */
-/** Both tapes into the engine's UTF-32 buffer and, with `renumber`, their runes into ids: launches only, no wait. */
-static hipError_t enqueue_transcoding(szs_call_t *call, char *remote, size_t flags_at, size_t needed_at, size_t staging_bytes, uint64_t *starts,
-                                      uint32_t *counts, int renumber) {
-    szs_engine_s *engine = call->engine;
-    hipStream_t const stream = call->stream;
-    uint32_t const q_count = call->q_count, c_count = call->c_count;
-    uint64_t const capacity = engine->device_runes.capacity / sizeof(uint32_t);
-    uint32_t *const device_flags = (uint32_t *)(remote + flags_at);
-    size_t const strings = (size_t)q_count + (call->symmetric ? 0 : c_count);
-    hipError_t error = hipMemsetAsync(remote + flags_at, 0, staging_bytes - flags_at, stream);
-    if (error == hipSuccess)
-        error = (hipError_t)szs_hip_utf8_transcode_tapes(call->queries->data, call->queries->offsets, q_count, call->queries->kind == szs_input_u64tape_k,
-                                                         call->symmetric ? NULL : call->candidates->data,
-                                                         call->symmetric ? NULL : call->candidates->offsets, call->symmetric ? 0u : c_count,
-                                                         !call->symmetric && call->candidates->kind == szs_input_u64tape_k, capacity,
-                                                         (uint32_t *)engine->device_runes.pointer, starts, counts, device_flags,
-                                                         (uint64_t *)(remote + needed_at), renumber ? engine->device_alphabet.pointer : NULL, stream);
-    if (error == hipSuccess && renumber)
-        error = (hipError_t)szs_hip_alphabet_rename((uint32_t)strings, starts, counts, (uint32_t *)engine->device_runes.pointer, device_flags,
-                                                    engine->device_alphabet.pointer, 1, SZS_ALPHABET_MOST, device_flags + 1, stream);
-    return error;
-}
-
-/** The size of the direct tables the codepoint kernels are launched with for a batch of `distinct` renumbered runes: some
- *  room above it, so that the NEXT batch of the stream - launched on this one's shape before anyone has counted its runes -
- *  still fits when it holds a few more (a table row is 4 bytes of LDS). */
-static uint32_t alphabet_with_room(uint32_t distinct) {
-    uint32_t const roomy = distinct + distinct / 8 + 8;
-    return roomy < SZS_ALPHABET_MOST ? roomy : SZS_ALPHABET_MOST;
-}
-
-static sz_status_t cross_device_planned_runes(szs_call_t *call) {
-    szs_engine_s *engine = call->engine;
-    hipStream_t const stream = call->stream;
-    int const device = call->device, symmetric = call->symmetric;
-    uint32_t const q_count = call->q_count, c_count = call->c_count;
-    char const **error_message = call->error_message;
-    size_t const strings = (size_t)q_count + (symmetric ? 0 : c_count);
-
-    /* device staging: [rune starts, u64][rune counts, u32][any_multibyte, distinct runes, alphabet overflow, pad][needed, u64] */
-    size_t const starts_at = 0, counts_at = strings * sizeof(uint64_t);
-    size_t const flags_at = (counts_at + strings * sizeof(uint32_t) + 7) & ~(size_t)7, needed_at = flags_at + 4 * sizeof(uint32_t);
-    size_t const staging_bytes = needed_at + sizeof(uint64_t);
-    /* (... or, for a batch of tiny tokens - cross_tiny: a word per string) */
-    size_t const narrow_staging_bytes = strings * sizeof(uint64_t);
-    sz_status_t status = szs_buffer_reserve(&engine->device_transcode, szs_memory_device_k, device,
-                                            staging_bytes > narrow_staging_bytes ? staging_bytes : narrow_staging_bytes, error_message);
-    if (status == sz_success_k) status = szs_buffer_reserve(&engine->pinned_transcode, szs_memory_pinned_k, device, 64, error_message);
-    void *const refs_before = engine->device_plan_refs.pointer;
-    if (status == sz_success_k)
-        status = szs_buffer_reserve(&engine->device_plan_refs, szs_memory_device_k, device, 2 * strings * sizeof(szs_string_ref_t), error_message);
-    if (engine->remembered && (status != sz_success_k || engine->device_plan_refs.pointer != refs_before))
-        engine->remembered->refs_current = 0, engine->remembered->valid = 0;
-    if (status == sz_success_k && engine->device_runes.capacity < ((size_t)1 << 20))
-        status = szs_buffer_reserve(&engine->device_runes, szs_memory_device_k, device, (size_t)1 << 20, error_message);
-    /* Renumbering the runes (hip/utf8.hip) is four more operations ahead of the planner - ~60 us and a pass over every rune,
-     * ~15 ps each - and makes the scoring kernels ~15 % faster (one LDS read per column instead of a hash probe, ~3 fs per
-     * cell): worth it when the CELLS of the call outweigh its runes.  4096 x 4096 words of prose (6e8 cells): 0.39 ms
-     * renumbered, 0.31 not; config 5u (4.4e11 cells): 7.1 against 8.4 ms, an eighth of it 1.82 / 2.16.  The host has not read
-     * an offset, so it goes by the PREVIOUS call of this engine - a stream of batches settles at once. */
-    int const alphabet_knob = szs_tuning_get(szs_knob_alphabet_k);
-    int const renumber = alphabet_knob == 0  ? 0
-                         : alphabet_knob > 0 ? 1
-                                             : engine->cells_before >= 20000000000ull + 5000ull * engine->runes_needed && engine->runes_needed > 0;
-    if (status == sz_success_k && renumber)
-        status = szs_buffer_reserve(&engine->device_alphabet, szs_memory_device_k, device, szs_hip_alphabet_workspace_bytes(), error_message);
-    if (status == sz_success_k) status = place_results(call);
-    if (status == sz_success_k) status = reserve_device_words(engine, device, stream, error_message);
-    if (status == sz_success_k && !engine->remembered) {
-        engine->remembered = (szs_decision_t *)calloc(1, sizeof(szs_decision_t));
-        if (!engine->remembered) status = szs_report(sz_bad_alloc_k, error_message, NULL);
-    }
-    if (status != sz_success_k) return status;
-    szs_decision_t *const remembered = engine->remembered;
-    remembered->refs_current = 0; /* the planner is about to overwrite the refs */
-    phase(call, 0);
-
-    /* ---- tiny tokens (round 6): the previous call of these counts was words of a few runes - this one is narrowed to byte strings and
-     * scored by the tiny-token launch without being transcoded, renumbered or planned (cross_tiny; the byte path's way 5).  A batch that
-     * is something else says so itself (a string beyond 255 runes, too many long ones, an alphabet beyond the table) and is scored below. */
-    /* (... or was ASCII words, which this engine hands to the byte kernels - after transcoding and planning them to find that out:
-     * narrowed, an ASCII batch is its own bytes, 13 us instead of that front end) */
-    int const words_before = (engine->tiny_runes_valid && engine->tiny_runes_q_count == q_count && engine->tiny_runes_c_count == c_count) ||
-                             (engine->tiny_valid && engine->tiny_q_count == q_count && engine->tiny_c_count == c_count);
-    if (words_before && engine->runes_needed && engine->is_unit_cost && szs_tuning_get(szs_knob_tiny_k) != 0 &&
-        szs_tuning_get(szs_knob_speculate_k) != 0 && szs_tuning_get(szs_knob_tier_k) < 0) {
-        size_t const narrow_before = engine->device_narrow.capacity;
-        status = szs_buffer_reserve(&engine->device_narrow, szs_memory_device_k, device, (size_t)(engine->runes_needed + engine->runes_needed / 4) + 64 + SZS_NARROW_WORKSPACE, error_message);
-        if (engine->device_narrow.capacity != narrow_before) engine->narrow_zeroed = NULL; /* (a new buffer, wherever it lies) */
-        if (status != sz_success_k) return status;
-        status = cross_tiny(call, 5, NULL, 1);
-        if (status != SZS_TINY_NOT_TAKEN) return status;
-    }
-
-    char *const remote = (char *)engine->device_transcode.pointer;
-    uint32_t volatile *const flags = (uint32_t volatile *)engine->pinned_transcode.pointer; /* 4 flags, then `needed` */
-    szs_string_ref_t *const base = (szs_string_ref_t *)engine->device_plan_refs.pointer;
-    szs_plan_summary_t volatile *const summary = (szs_plan_summary_t volatile *)engine->pinned_summary.pointer;
-    uint64_t *const starts = (uint64_t *)(remote + starts_at);
-    uint32_t *const counts = (uint32_t *)(remote + counts_at);
-    unsigned const myers_words = SZS_MYERS_MAX_WORDS * (unsigned)(engine->is_unit_cost != 0);
-    szs_plan_summary_t seen;
-    szs_plan_side_t q_side, c_side;
-    /* (the UTF-32 buffer may move when it grows: the sides are rebuilt from it for every round) */
-#define SZS_RUNE_SIDES()                                                                                                                  \
-    do {                                                                                                                                  \
-        szs_plan_side_t const queries_side = {call->queries->offsets, (uint64_t)(uintptr_t)engine->device_runes.pointer, q_count,        \
-                                              call->queries->kind == szs_input_u64tape_k, base, base + q_count, counts, starts};         \
-        q_side = queries_side, c_side = queries_side;                                                                                    \
-        if (!symmetric) {                                                                                                                 \
-            szs_plan_side_t const other = {call->candidates->offsets, (uint64_t)(uintptr_t)engine->device_runes.pointer, c_count,        \
-                                           call->candidates->kind == szs_input_u64tape_k, base + 2 * (size_t)q_count,                    \
-                                           base + 2 * (size_t)q_count + c_count, counts + q_count, starts + q_count};                    \
-            c_side = other;                                                                                                               \
-        }                                                                                                                                 \
-    } while (0)
-
-    /* ---- speculate (round 3): a stream of batches of one shape - the same counts, the same strings per launch width, no longer
-     * longest strings, no more runes than the buffer holds, no more distinct ones than the tables have rows - is transcoded,
-     * renumbered, planned AND scored without the host waiting in between: the launches of the previous call go in right behind
-     * the planner, which blanks every ref if this batch does not fit them (hip/planner.hip; the byte engines' speculation, with
-     * the two conditions only the device can check added to the expectation).  4096 x 4096 words of prose: the planning half
-     * was as long as the scoring (profiles/r03/real_text.jsonl). */
-    int const knobs_automatic = szs_tuning_get(szs_knob_speculate_k) != 0 && szs_tuning_get(szs_knob_tier_k) < 0 &&
-                                szs_tuning_get(szs_knob_swap_k) < 0 && szs_tuning_get(szs_knob_cells_k) < 0 && szs_tuning_get(szs_knob_packed_k) < 0 &&
-                                szs_tuning_get(szs_knob_team_k) < 0 && szs_tuning_get(szs_knob_rune_ids_k) < 0 &&
-                                szs_tuning_get(szs_knob_queue_k) < 0; /* (a pinned `queue` knob makes one-group calls queue launches: those are
-                                                                         planned and waited for, like the byte path's) */
-    if (remembered->valid && remembered->runes && remembered->tier == SZS_TIER_LANES && remembered->use_myers && remembered->q_count == q_count &&
-        remembered->c_count == c_count && remembered->symmetric == symmetric && knobs_automatic && (!remembered->alphabet || renumber) &&
-        is_one_launch(remembered) /* see cross_device_planned */) {
-        szs_decision_t const *d = remembered;
-        SZS_RUNE_SIDES();
-        szs_plan_expectation_t expected;
-        memset(&expected, 0, sizeof(expected));
-        expected.enabled = 1, expected.query_side = (uint32_t)d->transposed;
-        expected.longest[0] = d->longest[0], expected.longest[1] = d->longest[1];
-        memcpy(expected.variant_counts, d->variant_counts, sizeof(expected.variant_counts));
-        expected.sequence = ++engine->plan_sequence;
-        expected.runes_needed = (uint64_t const *)(remote + needed_at), expected.runes_capacity = engine->device_runes.capacity / sizeof(uint32_t);
-        expected.alphabet_flags = (uint32_t const *)(remote + flags_at), expected.alphabet = d->alphabet;
-        status = prepare(engine, d, device, stream, error_message); /* buffers of the previous call: nothing to allocate */
-        if (status != sz_success_k) return status;
-        phase(call, 2);
-        hipError_t error = enqueue_transcoding(call, remote, flags_at, needed_at, staging_bytes, starts, counts, renumber);
-        if (error == hipSuccess)
-            error = (hipError_t)szs_hip_plan(&q_side, symmetric ? NULL : &c_side, myers_words, &expected, (szs_plan_summary_t *)summary, SZS_PLAN_VERDICTS(engine), stream);
-        if (error == hipSuccess) error = hipMemcpyAsync((void *)flags, remote + flags_at, staging_bytes - flags_at, hipMemcpyDeviceToHost, stream);
-        if (error != hipSuccess) {
-            (void)hipStreamSynchronize(stream);
-            return szs_report_hip(error, error_message); /* no scoring launch has been enqueued */
-        }
-        uint32_t launches = 0, cell_bits = 0;
-        error = hipEventRecord(engine->event_start, stream);
-        szs_string_ref_t const *const query_refs = d->transposed ? c_side.descending : q_side.descending;
-        szs_string_ref_t const *const candidate_refs = d->transposed ? q_side.ascending : c_side.ascending;
-        sz_status_t enqueue_status = sz_success_k;
-        if (error == hipSuccess)
-            error = enqueue(engine, d, device, query_refs, candidate_refs, call->device_results, call->device_stride, stream, NULL, &launches,
-                            &cell_bits, &enqueue_status, error_message);
-        int stalled = 0;
-        szs_decision_t scored = *d;
-        engine->last_profile.planner = 2;
-        status = finish(call, &scored, error, enqueue_status, launches, cell_bits, 0, 0, &stalled);
-        if (status != sz_success_k) return status;
-        memcpy(&seen, (void const *)summary, sizeof(seen));
-        if (seen.sequence == expected.sequence && !seen.status && seen.speculation_held) {
-            szs_rocm_call_profile_t *profile = &engine->last_profile;
-            uint64_t const pairs = profile->pairs;
-            profile->cells = symmetric ? seen.symmetric_cells : seen.side[0].symbols * seen.side[1].symbols;
-            profile->algorithmic_bytes = (symmetric ? ((uint64_t)q_count + 1) * seen.side[0].symbols
-                                                    : (uint64_t)c_count * seen.side[0].symbols + (uint64_t)q_count * seen.side[1].symbols) + pairs * 16;
-            profile->unique_bytes += seen.side[0].symbols + (symmetric ? 0 : seen.side[1].symbols);
-            profile->longest_query = seen.side[0].longest, profile->longest_candidate = seen.side[1].longest;
-            engine->runes_needed = *(uint64_t const volatile *)(flags + 4);
-            remembered->summary = seen;
-            remembered->plan.cells = profile->cells;
-            /* words scored on the shape of an earlier batch (sentences before them, or words the tiny-token launch was not tried on): the
-             * next call of these counts goes to that launch (cross_tiny) */
-            if (flags[0] && tiny_shaped(engine, symmetric, &seen.side[0], &seen.side[1]) && !tiny_recently_refused(engine, q_count, c_count, 1)) {
-                size_t const narrow_before = engine->device_narrow.capacity;
-                if (szs_buffer_reserve(&engine->device_narrow, szs_memory_device_k, device, (size_t)(engine->runes_needed + engine->runes_needed / 4) + 64 + SZS_NARROW_WORKSPACE, NULL) == sz_success_k)
-                    engine->tiny_runes_valid = 1, engine->tiny_runes_q_count = q_count, engine->tiny_runes_c_count = c_count;
-                if (engine->device_narrow.capacity != narrow_before) engine->narrow_zeroed = NULL;
-            }
-            return szs_report(sz_success_k, error_message, NULL);
-        }
-        /* the batch has another shape, more runes or a richer alphabet: every ref was blanked, nothing real was scored */
-    }
-
-    for (int round = 0;; ++round) {
-        uint64_t const capacity = engine->device_runes.capacity / sizeof(uint32_t);
-        hipError_t error = enqueue_transcoding(call, remote, flags_at, needed_at, staging_bytes, starts, counts, renumber);
-        SZS_RUNE_SIDES();
-        szs_plan_expectation_t none;
-        memset(&none, 0, sizeof(none));
-        none.sequence = ++engine->plan_sequence;
-        if (error == hipSuccess)
-            error = (hipError_t)szs_hip_plan(&q_side, symmetric ? NULL : &c_side, myers_words, &none, (szs_plan_summary_t *)summary, SZS_PLAN_VERDICTS(engine), stream);
-        if (error == hipSuccess) error = hipMemcpyAsync((void *)flags, remote + flags_at, staging_bytes - flags_at, hipMemcpyDeviceToHost, stream);
-        hipError_t const drained = hipStreamSynchronize(stream); /* THE wait of the planning half; also on failure */
-        if (error == hipSuccess) error = drained;
-        if (error != hipSuccess) return szs_report_hip(error, error_message);
-        memcpy(&seen, (void const *)summary, sizeof(seen));
-        if (seen.sequence != none.sequence) return szs_report(sz_status_unknown_k, error_message, "The device planner did not report");
-        if (seen.status & SZS_PLAN_STATUS_DESCENDING) return szs_report(sz_unexpected_dimensions_k, error_message, "Tape offsets must ascend");
-        if (seen.status & SZS_PLAN_STATUS_OVERFLOW) return szs_report(sz_overflow_risk_k, error_message, NULL);
-        uint64_t const needed = *(uint64_t const volatile *)(flags + 4);
-        engine->runes_needed = needed;
-        if (needed <= capacity) break;
-        if (round) return szs_report(sz_status_unknown_k, error_message, "The UTF-32 buffer did not settle");
-        status = szs_buffer_reserve(&engine->device_runes, szs_memory_device_k, device, (size_t)(needed + needed / 4 + 4) * sizeof(uint32_t), error_message);
-        if (status != sz_success_k) return status; /* grown: transcode again, every string fits now */
-    }
-#undef SZS_RUNE_SIDES
-    if (remembered->runes) remembered->valid = 0; /* whatever happens below, the next call is not launched on an older codepoint shape */
-    if (!flags[0]) return SZS_RUNES_ARE_BYTES;
-    if (seen.status & SZS_PLAN_STATUS_UNSORTED) return SZS_NOT_DEVICE_PLANNABLE; /* strings beyond the planner's histogram */
-    if (tiny_shaped(engine, symmetric, &seen.side[0], &seen.side[1]) && !tiny_recently_refused(engine, q_count, c_count, 1)) {
-        /* the summary (in RUNES) says words: their launch instead, and the next call of these counts goes there unplanned.  The narrow
-         * strings get a buffer of their own - should that launch refuse the batch, the UTF-32 arrays are scored below.  `needed`
-         * counts every string's BYTE span rounded up (hip/utf8.hip: transcode_tape_t::span): it bounds the bytes of both tapes. */
-        size_t const narrow_before = engine->device_narrow.capacity;
-        status = szs_buffer_reserve(&engine->device_narrow, szs_memory_device_k, device, (size_t)(engine->runes_needed + engine->runes_needed / 4) + 64 + SZS_NARROW_WORKSPACE, error_message);
-        if (engine->device_narrow.capacity != narrow_before) engine->narrow_zeroed = NULL; /* (a new buffer, wherever it lies) */
-        if (status != sz_success_k) return status;
-        status = cross_tiny(call, 1, &seen, 1);
-        if (status != SZS_TINY_NOT_TAKEN) return status;
-    }
-    uint32_t const distinct = flags[1], overflowed = flags[2];
-    /* the arrays hold ids 1 ... distinct: the kernels index direct tables with them */
-    uint32_t const alphabet = renumber && distinct && distinct <= SZS_ALPHABET_MOST && !overflowed ? alphabet_with_room(distinct) : 0;
-    phase(call, 1);
-
-    for (int attempt = 0; attempt < 2; ++attempt) { /* second round: a stalled band chain is re-run on the lanes tier */
-        szs_decision_t d;
-        uint64_t const cells = symmetric ? seen.symmetric_cells : seen.side[0].symbols * seen.side[1].symbols;
-        status = decide(engine, symmetric, 1, attempt > 0, &seen.side[0], &seen.side[1], seen.variant_counts[0], seen.variant_counts[1],
-                        seen.rank_lengths, cells, &d, error_message);
-        if (status != sz_success_k) return status;
-        d.alphabet = alphabet;
-        decide_queue(engine, &d, seen.rank_lengths);
-        status = prepare(engine, &d, device, stream, error_message);
-        if (status != sz_success_k) return status;
-        phase(call, 2);
-        uint32_t launches = 0, cell_bits = 0;
-        hipError_t error = hipEventRecord(engine->event_start, stream);
-        szs_string_ref_t const *const query_refs = d.transposed ? c_side.descending : q_side.descending;
-        szs_string_ref_t const *const candidate_refs = d.transposed ? q_side.ascending : c_side.ascending;
-        sz_status_t enqueue_status = sz_success_k;
-        if (error == hipSuccess)
-            error = enqueue(engine, &d, device, query_refs, candidate_refs, call->device_results, call->device_stride, stream, NULL, &launches,
-                            &cell_bits, &enqueue_status, error_message);
-        int stalled = 0;
-        engine->last_profile.planner = 1;
-        status = finish(call, &d, error, enqueue_status, launches, cell_bits, seen.side[0].symbols, seen.side[1].symbols, &stalled);
-        if (status != sz_success_k) return status;
-        if (!stalled) {
-            *remembered = d; /* the next batch of this shape goes in behind its own planner, unseen by the host */
-            remembered->summary = seen, remembered->refs_current = 0;
-            return sz_success_k;
-        }
-    }
-    return szs_report(sz_status_unknown_k, error_message, "Systolic pipeline stalled");
 }
 
 /* ---- host-planned calls ------------------------------------------------------------------------------------------------ */
@@ -1951,7 +1064,7 @@ static sz_status_t cross_host_planned(szs_call_t *call) {
         if (status == sz_success_k && error != hipSuccess) return szs_report_hip(error, error_message);
     }
     if (status != sz_success_k) return status;
-    phase(call, 0); /* checks, buffers, offsets download + its synchronisation */
+    szs_call_phase(call, 0); /* checks, buffers, offsets download + its synchronisation */
 
     /* Host scratch: [q addresses][c addresses][q lengths][c lengths] */
     size_t const fixed_bytes = ((size_t)q_count + c_count) * (sizeof(uint64_t) + sizeof(uint32_t));
@@ -2023,16 +1136,16 @@ static sz_status_t cross_host_planned(szs_call_t *call) {
     uint32_t *const keys = (uint32_t *)engine->host_scratch.pointer;
     void *const scratch = (char *)engine->host_scratch.pointer + keys_bytes;
 
-    status = place_results(call);
+    status = szs_call_place_results(call);
     if (status != sz_success_k) return status;
 
     for (int attempt = 0; attempt < 2; ++attempt) { /* second round: a stalled band chain is re-run on the lanes tier */
         szs_decision_t d;
-        status = decide(engine, symmetric, runes, attempt > 0, &q_stats, &c_stats, q_variants, c_variants, NULL /* ranks: after the sort below */,
+        status = szs_call_decide(engine, symmetric, runes, attempt > 0, &q_stats, &c_stats, q_variants, c_variants, NULL /* ranks: after the sort below */,
                         cells, &d, error_message);
         if (status != sz_success_k) return status;
         d.alphabet = alphabet;
-        decide_queue(engine, &d, NULL); /* planned below, once the lengths are sorted */
+        szs_call_decide_queue(engine, &d, NULL); /* planned below, once the lengths are sorted */
         /* kernel roles */
         uint64_t *const kq_addresses = d.transposed ? c_addresses : q_addresses, *const kc_addresses = d.transposed ? q_addresses : c_addresses;
         uint32_t *const kq_lengths = d.transposed ? c_lengths : q_lengths, *const kc_lengths = d.transposed ? q_lengths : c_lengths;
@@ -2049,25 +1162,25 @@ static sz_status_t cross_host_planned(szs_call_t *call) {
             szs_plan_queue(&d.plan, d.kq_count, d.kc_count, d.runes ? d.alphabet : 0u, szs_hip_levenshtein_myers_queue_table_bytes(d.runes), &d.queue);
             if (!d.queue.items_total) d.use_queue = 0;
         }
-        phase(call, 1); /* gathering strings, transcoding, orientation, planning */
+        szs_call_phase(call, 1); /* gathering strings, transcoding, orientation, planning */
 
-        status = prepare(engine, &d, device, stream, error_message);
+        status = szs_call_prepare(engine, &d, device, stream, error_message);
         if (status != sz_success_k) return status;
         szs_string_ref_t *device_query_refs = (szs_string_ref_t *)engine->device_refs.pointer;
         szs_string_ref_t *device_candidate_refs = device_query_refs + d.kq_count;
         hipError_t error = hipMemcpyAsync(device_query_refs, host_query_refs, refs_bytes, hipMemcpyHostToDevice, stream);
-        phase(call, 2); /* ref upload enqueued, result placement, workspaces */
+        szs_call_phase(call, 2); /* ref upload enqueued, result placement, workspaces */
 
         /* ---- launches, bracketed by the engine's event pair on the scope's stream ---- */
         uint32_t launches = 0, cell_bits = 0;
         sz_status_t enqueue_status = sz_success_k;
         if (error == hipSuccess) error = hipEventRecord(engine->event_start, stream);
         if (error == hipSuccess)
-            error = enqueue(engine, &d, device, device_query_refs, device_candidate_refs, call->device_results, call->device_stride, stream,
+            error = szs_call_enqueue(engine, &d, device, device_query_refs, device_candidate_refs, call->device_results, call->device_stride, stream,
                             NULL, &launches, &cell_bits, &enqueue_status, error_message);
         int stalled = 0;
         engine->last_profile.planner = 0;
-        status = finish(call, &d, error, enqueue_status, launches, cell_bits, query_bytes, candidate_bytes, &stalled);
+        status = szs_call_finish(call, &d, error, enqueue_status, launches, cell_bits, query_bytes, candidate_bytes, &stalled);
         if (status != sz_success_k || !stalled) return status;
     }
     return szs_report(sz_status_unknown_k, error_message, "Systolic pipeline stalled");
@@ -2095,7 +1208,7 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
     engine->cells_before = engine->last_profile.cells;
     memset(&engine->last_profile, 0, sizeof(engine->last_profile));
     /* The dense byte alphabet of a non-unit Levenshtein engine belongs to ONE call: only the device-planned path scans the
-     * tapes and fills it, and decide() / fill_cost_model() read it on every path - a host-planned call after a device-planned
+     * tapes and fills it, and szs_call_decide() / fill_cost_model() read it on every path - a host-planned call after a device-planned
      * one must not score with the previous batch's byte-to-class map (bytes that batch lacked would all share class 0). */
     engine->uniform_classes = 0;
     if (!queries_count || !candidates_count) return szs_report(sz_success_k, error_message, NULL); /* cuda.cuh:4257 */
@@ -2134,10 +1247,10 @@ sz_status_t szs_engine_cross(szs_engine_s *engine, szs_scope_s *scope, szs_input
         engine->queue_unfit_sequence = 0;
         status = SZS_NOT_DEVICE_PLANNABLE;
         if (planner != 0 && device_plannable(engine, queries) && (symmetric || device_plannable(engine, candidates))) {
-            status = engine->family == szs_family_levenshtein_utf8_k ? cross_device_planned_runes(&call) : SZS_RUNES_ARE_BYTES;
+            status = engine->family == szs_family_levenshtein_utf8_k ? szs_cross_device_planned_runes(&call) : SZS_RUNES_ARE_BYTES;
             if (status == SZS_RUNES_ARE_BYTES) {
                 if (call.ranges) ranges_end(&call), ranges_begin(&call);
-                status = cross_device_planned(&call);
+                status = szs_cross_device_planned(&call);
             }
         }
         if (status == SZS_NOT_DEVICE_PLANNABLE) {

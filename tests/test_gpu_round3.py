@@ -191,7 +191,7 @@ def test_weighted_levenshtein_on_the_team_tier(gpu, oracle, costs):
 @pytest.mark.parametrize("costs", [(0, 1, 1, 1), (1, 3, 3, 3), (0, 1, 4, 2)])
 def test_codepoint_engine_planned_on_the_device(gpu, oracle, costs):
     """Round 3 plans codepoint calls over tapes on the device too: both tapes are transcoded without the host reading an
-    offset, the planner sorts by RUNE count, one wait (csrc/host/dispatch.c: cross_device_planned_runes).  Against the oracle
+    offset, the planner sorts by RUNE count, one wait (csrc/host/ways_runes.c: szs_cross_device_planned_runes).  Against the oracle
     and against the host-planned path (`planner` knob), for: mixed scripts, an ASCII corpus (byte engines), symmetric calls, a
     batch that outgrows the UTF-32 buffer of the call before, strings longer than the planner's histogram, 64-bit tapes."""
     rng = random.Random(hash(costs) & 0xFFF)

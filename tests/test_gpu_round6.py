@@ -280,7 +280,7 @@ def _batch(rng, alphabet, count, span):
 @pytest.mark.parametrize("family", ["levenshtein", "levenshtein_weighted", "levenshtein_utf8", "needleman_wunsch", "smith_waterman"])
 @pytest.mark.parametrize("layout", ["cross_u32", "cross_u64_strided", "symmetric", "tall"])
 def test_every_plan_mode_of_every_family_and_layout_scores_what_the_oracle_scores(gpu, family, layout):
-    """host/dispatch.c reaches a call's plan five ways (planned on the host, on the device, on the device with the
+    """host/dispatch.c + ways_*.c reach a call's plan five ways (planned on the host, on the device, on the device with the
     launches speculated behind the planner, re-used for the same tapes, inside the scoring launch) - six with the tiny-token launch
     that needs none - and each round added one.  This walks EVERY way a (family, layout) can take - streams of fresh batches, the same
     tapes again, the planner pinned to the host, speculation off, tiny tokens forced - checks every matrix against the oracle, and pins
@@ -542,7 +542,7 @@ def test_codepoint_words_are_recognised_and_richer_alphabets_are_not(gpu, oracle
         queries, candidates = [word(rich) for _ in range(600)], [word(rich) for _ in range(2100)]
         assert np.array_equal(engine(queries, candidates, device=gpu), oracle.levenshtein_utf8(queries, candidates))
         assert engine.last_call_profile().planner != 5
-    # words again: a batch whose SUMMARY said words was refused, so the next sixteen calls of these counts do not try (dispatch.c:
+    # words again: a batch whose SUMMARY said words was refused, so the next sixteen calls of these counts do not try (ways_tiny.c:
     # tiny_recently_refused - a stream of such batches must not pay the refused launch every time); after that words are words again.
     # Then a batch without a single byte >= 0x80: a codepoint engine scores that one as bytes
     modes = []
