@@ -677,3 +677,26 @@ def test_a_batch_beyond_the_narrow_buffer_is_scored_the_ordinary_way(gpu, oracle
         assert engine.last_call_profile().planner != 5
         queries, candidates = [word(0, 9) for _ in range(70)], [word(0, 9) for _ in range(520)]
         assert np.array_equal(engine(queries, candidates, device=gpu), oracle.levenshtein_utf8(queries, candidates))
+
+
+def test_codepoint_words_of_arbitrary_bytes(gpu, oracle):
+    """Strings of RANDOM bytes from a handful of values - ASCII, a continuation byte, a two-byte lead, a three-byte lead: most of
+    them are not UTF-8 at all.  `sz_rune_decode_unchecked` decodes them anyway (the sequence length from the lead byte alone,
+    whatever follows taken for its low six bits, the end of the string cutting a sequence short), and so must the pass that narrows
+    them - by a thread alone up to sixteen bytes, by the wavefront (and, malformed as they are, by the thread after all) beyond."""
+    rng = random.Random(4242)
+    values = [0x61, 0x62, 0x80, 0xC3, 0xA9, 0xE2]
+    weights = [5, 3, 2, 2, 2, 1]
+    draw = lambda low, high: bytes(rng.choices(values, weights)[0] for _ in range(rng.randint(low, high)))
+    engine = szs.LevenshteinDistancesUTF8(capabilities=gpu)
+    with knob("tiny", 2):
+        for batch in range(3):
+            queries = [draw(0, 16) for _ in range(150)] + [draw(17, 70) for _ in range(40)]
+            candidates = [draw(0, 16) for _ in range(900)] + [draw(17, 130) for _ in range(150)]
+            rng.shuffle(queries), rng.shuffle(candidates)
+            got = engine(queries, candidates, device=gpu)
+            expected = oracle.levenshtein_utf8(queries, candidates)
+            assert np.array_equal(got, expected), (batch, np.argwhere(got != expected)[:5].tolist())
+            profile = engine.last_call_profile()
+            assert profile.launches == 2 and profile.planner == (5 if batch else 1), (batch, profile.planner, profile.launches)
+            assert profile.cells == sum(map(_rune_count, queries)) * sum(map(_rune_count, candidates))
