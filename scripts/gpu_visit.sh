@@ -27,6 +27,8 @@ for step in "$@"; do
                     echo "--- systolic_probe $args (PROBE_ALTERNATE=1 SZS_ROCM_TINY=1)"; PROBE_ALTERNATE=1 SZS_ROCM_TINY=1 timeout 300 tests/native/bin/systolic_probe_asan $args 2>&1 | grep -v "^    #" | tail -5; done
                   for args in "mix:60:40 100 700 3" "mix:100:255 300 1000 3 7" "mix:1000:200 40 300 2"; do # ... the one launch of tiny and longer tokens (refusals included: tiny = 1)
                     for knob in 1 2; do echo "--- words_probe $args (SZS_ROCM_TINY=$knob)"; SZS_ROCM_TINY=$knob timeout 300 tests/native/bin/words_probe_asan $args 2>&1 | grep -v "^    #" | tail -4; done; done
+                  for mode in "PROBE_UTF8=1" "PROBE_UTF8=1 PROBE_WIDE=1" "PROBE_SYMMETRIC=1" "PROBE_UTF8=1 PROBE_SYMMETRIC=1"; do # round 6: the codepoint twin (one pass writes the runes as bytes), symmetric calls of words
+                    for args in "mix:40:60 300 1100 4 5" "mix:150:255 1100 1100 3"; do echo "--- words_probe $args ($mode SZS_ROCM_TINY=1)"; env $mode SZS_ROCM_TINY=1 timeout 300 tests/native/bin/words_probe_asan $args 2>&1 | grep -v "^    #" | tail -5; done; done
                   for args in "lev 70 300 10 400 0 0" "nw 33 200 100 600 0 0 0" "sw 20 100 500 900 0" "lev-sym 150 0 10 400 0 0 0" "nw-sym 90 0 100 600 0 0 0 0 0 0 0 0" "lev 5 40 10 90 0 0 0 0 0 0 0 0"; do
                     echo "--- node_probe $args"; timeout 300 tests/native/bin/node_probe_asan $args 2>&1 | grep -v "^    #" | tail -6; done
                   for args in "lev 120 900 8 2040 0" "lev-sym 200 0 8 2040 0 0"; do # the one-launch kernel: its queue is planned by the sanitized host

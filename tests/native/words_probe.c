@@ -8,7 +8,9 @@
  *  SOURCE = file:PATH            words of that file (split at white space), drawn at random
  *         | mix:PERMILLE:LONGEST tokens of 0 ... 16 bytes, PERMILLE in a thousand of 17 ... LONGEST bytes instead
  *  Two batches of the same counts take turns (a fresh batch every call); SZS_ROCM_TINY picks the path as usual.
- *  PROBE_WIDE=1: 64-bit offsets.  PROBE_NO_ORACLE=1: times only.
+ *  PROBE_WIDE=1: 64-bit offsets.  PROBE_NO_ORACLE=1: times only.  PROBE_UTF8=1: the codepoint engine (`mix` tokens then hold
+ *  two- and three-byte runes and a few bytes that are not UTF-8; lengths are in BYTES).  PROBE_SYMMETRIC=1: the queries against
+ *  themselves (C is ignored).
  */
 #define _POSIX_C_SOURCE 200809L
 #define __HIP_PLATFORM_AMD__ 1
@@ -73,6 +75,9 @@ static void load_corpus(char const *path) {
 }
 
 static char const letters[] = "etaoinshrdlucmfwypvbgkqjxz\xC0\xC1\xC2\xC3\xFF\x80";
+static int utf8_tokens = 0;
+/* (PROBE_UTF8: whole sequences - e-acute, the euro sign, a Cyrillic letter - among ASCII, and now and then a lone byte of one) */
+static char const *const runes[] = {"e", "t", "a", "o", "i", "n", "s", "h", "r", "\xC3\xA9", "\xE2\x82\xAC", "\xD0\xB6", "\xC3\xBC", "\x80", "\xE2"};
 
 static tape_t make_tape(char const *source, size_t count, int wide) {
     tape_t tape;
@@ -96,6 +101,12 @@ static tape_t make_tape(char const *source, size_t count, int wide) {
     for (size_t i = 0; i < count; ++i)
         for (size_t j = 0; j < lengths[i]; ++j)
             tape.data[tape.offsets64[i] + j] = from_file ? corpus[word_starts[picks[i]] + j] : letters[rng() % (sizeof(letters) - 1)];
+    if (utf8_tokens && !from_file)
+        for (size_t i = 0; i < count; ++i) /* whole sequences as far as the token's bytes go (what is cut short at its end is part of the test) */
+            for (size_t j = 0; j < lengths[i];) {
+                char const *const rune = runes[rng() % (rng() % 4 ? 9 : sizeof(runes) / sizeof(runes[0]))];
+                for (size_t k = 0; rune[k] && j < lengths[i]; ++k, ++j) tape.data[tape.offsets64[i] + j] = rune[k];
+            }
     hipMalloc((void **)&tape.device_data, total + 1), hipMalloc(&tape.device_offsets, (count + 1) * 8);
     hipMemcpy(tape.device_data, tape.data, total, hipMemcpyHostToDevice);
     if (wide) hipMemcpy(tape.device_offsets, tape.offsets64, (count + 1) * 8, hipMemcpyHostToDevice);
@@ -107,10 +118,11 @@ static tape_t make_tape(char const *source, size_t count, int wide) {
 int main(int argc, char **argv) {
     if (argc < 4) return fprintf(stderr, "usage: %s file:PATH|mix:PERMILLE:LONGEST Q C [REPEATS] [PADDING]\n", argv[0]), 2;
     char const *source = argv[1];
-    size_t const q_count = strtoul(argv[2], 0, 10), c_count = strtoul(argv[3], 0, 10);
+    size_t const q_count = strtoul(argv[2], 0, 10), c_count = getenv("PROBE_SYMMETRIC") ? q_count : strtoul(argv[3], 0, 10);
     int const repeats = argc > 4 ? atoi(argv[4]) : 4;
     size_t const padding = argc > 5 ? strtoul(argv[5], 0, 10) : 0, stride = c_count + padding;
-    int const wide = getenv("PROBE_WIDE") != NULL, no_oracle = getenv("PROBE_NO_ORACLE") != NULL;
+    int const wide = getenv("PROBE_WIDE") != NULL, no_oracle = getenv("PROBE_NO_ORACLE") != NULL, symmetric = getenv("PROBE_SYMMETRIC") != NULL;
+    utf8_tokens = getenv("PROBE_UTF8") != NULL;
     if (getenv("PROBE_SEED")) rng_state ^= strtoull(getenv("PROBE_SEED"), 0, 10) * 0x2545F4914F6CDD1Dull;
     signal(SIGALRM, on_alarm);
     unsigned const patience = getenv("PROBE_ALARM") ? (unsigned)atoi(getenv("PROBE_ALARM")) : 60;
@@ -118,7 +130,7 @@ int main(int argc, char **argv) {
     if (!strncmp(source, "file:", 5)) load_corpus(source + 5);
 
     tape_t batches[2][2];
-    for (int b = 0; b < 2; ++b) batches[b][0] = make_tape(source, q_count, wide), batches[b][1] = make_tape(source, c_count, wide);
+    for (int b = 0; b < 2; ++b) batches[b][0] = make_tape(source, q_count, wide), batches[b][1] = symmetric ? batches[b][0] : make_tape(source, c_count, wide);
 
     char const *error = NULL;
     szs_device_scope_t scope = NULL;
@@ -127,7 +139,8 @@ int main(int argc, char **argv) {
     sz_capability_t caps;
     szs_device_scope_get_capabilities(scope, &caps, &error);
     void *engine = NULL;
-    status = szs_levenshtein_distances_init(0, 1, 1, 1, NULL, caps, &engine, &error);
+    status = utf8_tokens ? szs_levenshtein_distances_utf8_init(0, 1, 1, 1, NULL, caps, &engine, &error)
+                         : szs_levenshtein_distances_init(0, 1, 1, 1, NULL, caps, &engine, &error);
     if (status) return fprintf(stderr, "init: %d %s\n", status, error ? error : ""), 1;
 
     size_t const cells_count = q_count * stride;
@@ -136,7 +149,8 @@ int main(int argc, char **argv) {
     stage = "oracle";
     alarm(600);
     for (int b = 0; b < 2 && !no_oracle; ++b)
-        szo_levenshtein_cross(batches[b][0].data, batches[b][0].offsets64, q_count, batches[b][1].data, batches[b][1].offsets64, c_count, 0, 1, 1, 1, expected[b], c_count);
+        (utf8_tokens ? szo_levenshtein_utf8_cross : szo_levenshtein_cross)(batches[b][0].data, batches[b][0].offsets64, q_count, batches[b][1].data,
+                                                                             batches[b][1].offsets64, c_count, 0, 1, 1, 1, expected[b], c_count);
 
     int failures = 0;
     double best_kernel = 1e30, best_wall = 1e30;
@@ -152,11 +166,13 @@ int main(int argc, char **argv) {
         double const started = now_ms();
         if (wide) {
             sz_sequence_u64tape_t q_tape = {q->device_data, (sz_u64_t const *)q->device_offsets, q_count}, c_tape = {c->device_data, (sz_u64_t const *)c->device_offsets, c_count};
-            status = szs_levenshtein_distances_u64tape(engine, scope, &q_tape, &c_tape, (sz_size_t *)device_results, stride, &error);
+            status = (utf8_tokens ? szs_levenshtein_distances_utf8_u64tape : szs_levenshtein_distances_u64tape)(engine, scope, &q_tape, symmetric ? NULL : &c_tape,
+                                                                                                               (sz_size_t *)device_results, stride, &error);
         }
         else {
             sz_sequence_u32tape_t q_tape = {q->device_data, (sz_u32_t const *)q->device_offsets, q_count}, c_tape = {c->device_data, (sz_u32_t const *)c->device_offsets, c_count};
-            status = szs_levenshtein_distances_u32tape(engine, scope, &q_tape, &c_tape, (sz_size_t *)device_results, stride, &error);
+            status = (utf8_tokens ? szs_levenshtein_distances_utf8_u32tape : szs_levenshtein_distances_u32tape)(engine, scope, &q_tape, symmetric ? NULL : &c_tape,
+                                                                                                               (sz_size_t *)device_results, stride, &error);
         }
         double const elapsed = now_ms() - started;
         if (status) { printf("run %d: status %d %s\n", run, status, error ? error : ""); ++failures; continue; }
