@@ -17,6 +17,8 @@ for step in "$@"; do
     asan)       # the C host under ASan + UBSan, driven by the torch-free probes: every family, the chained tiers, the node driver
                 # (use_sigaltstack=0: the HIP runtime pins pages the sanitizer wants to unmap when a worker thread exits)
                 export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:use_sigaltstack=0 UBSAN_OPTIONS=print_stacktrace=1 PROBE_ALARM=120
+                # (the sanitized library is built HERE, not by build(): `make -C stringzilla_amd/csrc asan && make -C tests/native asan` - say so when it is older than the sources)
+                [ -n "$(find stringzilla_amd/csrc/host stringzilla_amd/csrc/hip -newer stringzilla_amd/lib_asan/libstringzillas_rocm_shared.so -type f 2>/dev/null | head -1)" ] && echo "WARNING: stringzilla_amd/lib_asan is older than the sources it was built from"
                 { for args in "lev 40 300 50 700 1" "levw 40 300 50 700 1" "nw 40 300 50 700 1" "sw 40 300 50 700 1" "nw 9 300 900 1100 1 -4 -1" "lev 3 4 2040 2100 1" "lev 1 1 30000 40000 1" "nw 1 1 30000 40000 1"; do
                     echo "--- systolic_probe $args"; timeout 300 tests/native/bin/systolic_probe_asan $args 2>&1 | grep -v "^    #" | tail -6; done
                   for args in "lev 300 700 40 200 6" "lev 1024 1024 96 160 4"; do # round 5: streams of fresh batches - the launch that plans itself
