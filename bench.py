@@ -119,6 +119,9 @@ def parse_args():
     parser.add_argument("--hbm-traffic-bytes", type=float, default=None,
                         help="HBM bytes per launch from a separate rocprofv3 --pmc pass; default: the committed summary "
                              "profiles/rNN/pmc_summary.json of this same command (scripts/profile_gpu.sh)")
+    parser.add_argument("--c-node-leg", default=None, metavar="CONFIG:DEVICE,DEVICE,...",
+                        help="internal: ONE strong-scaled record through the single-process C node driver, printed as a JSON line (the N > 1 "
+                             "run calls itself with this in a child process: first contact with real peers must not cost the headline line)")
     return parser.parse_args()
 
 
@@ -738,8 +741,35 @@ def launch_ranks(args):
     os.execv(sys.executable, command)
 
 
+def c_node_leg_in_a_child(config, devices, args):
+    """measure_c_node() in a process of its own: one process driving every GPU of the node through peer copies is the part of the
+    N > 1 run that no one-GPU box has exercised on distinct devices - whatever happens to it there (a fault, a hang), rank 0 still
+    prints the headline, and the record says what happened."""
+    import subprocess
+
+    command = [sys.executable, os.path.abspath(__file__), "--c-node-leg", f"{config}:{','.join(str(d) for d in devices)}",
+               "--extra-seconds", str(args.extra_seconds), "--extra-scale", str(args.extra_scale), "--generator", args.generator]
+    environment = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE")}
+    try:
+        done = subprocess.run(command, env=environment, capture_output=True, text=True, timeout=300)
+    except subprocess.TimeoutExpired:
+        return {"config": config, "entry_point": "szs_rocm_node_scores_u32tape", "error": "the child process did not finish in 300 s"}
+    lines = [line for line in done.stdout.splitlines() if line.startswith("{")]
+    if done.returncode != 0 or not lines:
+        return {"config": config, "entry_point": "szs_rocm_node_scores_u32tape",
+                "error": f"the child process ended with {done.returncode}: {done.stderr.strip()[-300:]}"}
+    return json.loads(lines[-1])
+
+
 def main():
     args = parse_args()
+    if args.c_node_leg:  # (the child of c_node_leg_in_a_child)
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
+        config, devices = args.c_node_leg.split(":")
+        args.generator = resolve_generator(args.generator)
+        record = measure_c_node(int(config), [int(d) for d in devices.split(",")], args)
+        print(json.dumps(record if record is not None else {"config": int(config), "entry_point": "szs_rocm_node_scores_u32tape", "error": "this build has no node driver"}), flush=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args)  # does not return
     clock = {"started": time.perf_counter()}
@@ -923,7 +953,7 @@ def main():
         if rank == 0:  # single-process C driver over the same GPUs, while the other ranks wait
             for config in extras:
                 try:
-                    record = measure_c_node(config, [0] * world if args.same_device else list(range(world)), args)
+                    record = c_node_leg_in_a_child(config, [0] * world if args.same_device else list(range(world)), args)
                     if record is not None:
                         records.append(record)
                 except Exception as problem:
