@@ -316,8 +316,10 @@ __global__ __launch_bounds__(256) void alphabet_rename_kernel(u32 count, u64 con
  *  equality of symbols matters; and a batch of words holds a hundred distinct runes, not a million.  So: one pass, one thread per
  *  string (a word is a handful of sequential steps - the chain of lead bytes is walked as it stands), every rune becomes a byte:
  *  ASCII itself, anything else 128 + the slot it claims in a table of 128 runes in device memory (open addressing, compare-and-
- *  swap; the table outlives the call and every workgroup works from a copy in LDS, so a stream of batches claims its runes once).  The strings land where their bytes lay - string i at `side base + offset[i] - offset[0]`, runes <= bytes - so no
- *  scan is needed; what says where and how long is one word per string (kernels.h: szs_hip_utf8_narrow).
+ *  swap; the table outlives the call and every workgroup works from a copy in LDS, so a stream of batches claims its runes
+ *  once).  A word is walked by its own thread, a longer string by its whole wavefront (below).  The strings land where their
+ *  bytes lay - string i at `side base + offset[i] - offset[0]`, runes <= bytes - so no scan is needed; what says where and how
+ *  long is one word per string (kernels.h: szs_hip_utf8_narrow).
  */
 constexpr u32 narrow_slots_k = SZS_NARROW_SLOTS, narrow_most_runes_k = SZS_TINY_LONGEST, narrow_most_bytes_k = 4u * SZS_TINY_LONGEST;
 
